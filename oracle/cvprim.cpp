@@ -1,0 +1,223 @@
+// oracle/cvprim.cpp — TEST INFRASTRUCTURE (CPU oracle), not product code.
+// Restatements of OpenCV 3.4.x primitives; see cvprim.h and SURVEY.md Appendix A.
+// Build with -ffp-contract=off (no FMA contraction: OpenCV's scalar paths are
+// plain mul/add on the x86-64 baseline).
+#include "cvprim.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace orc {
+
+int cv_round(double v) { return (int)std::nearbyint(v); }   // default FE_TONEAREST = half-to-even
+int cv_round(float v) { return (int)std::nearbyintf(v); }
+
+// --- A5: cv::fastAtan2 (modules/core/src/mathfuncs_core.simd.hpp, atan_f32) -------------
+float fast_atan2(float y, float x) {
+    static const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    static const float p1 = 0.9997878412794807f * scale;
+    static const float p3 = -0.3258083974640975f * scale;
+    static const float p5 = 0.1555786518463281f * scale;
+    static const float p7 = -0.04432655554792128f * scale;
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// --- A2: cv::resize INTER_LINEAR, 8UC1 (modules/imgproc/src/resize.cpp) -------------------
+// resizeGeneric_ with HResizeLinear<uchar,int,short,2048> and the 8-bit VResizeLinear.
+static inline short sat_short(float v) {
+    int i = cv_round(v);
+    return (short)std::min(32767, std::max(-32768, i));
+}
+
+void resize_linear_u8(const uint8_t* src, int sw, int sh, int sstep,
+                      uint8_t* dst, int dw, int dh, int dstep) {
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<short> ialpha(2 * dw), ibeta(2 * dh);
+    int xmax = dw;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw) {
+            xmax = std::min(xmax, dx);
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat_short((1.f - fx) * 2048);
+        ialpha[2 * dx + 1] = sat_short(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ibeta[2 * dy] = sat_short((1.f - fy) * 2048);
+        ibeta[2 * dy + 1] = sat_short(fy * 2048);
+    }
+    std::vector<int> row0(dw), row1(dw);
+    auto hresize = [&](int sy, std::vector<int>& D) {
+        const uint8_t* S = src + (size_t)sy * sstep;
+        int dx = 0;
+        for (; dx < xmax; dx++) {
+            int sx = xofs[dx];
+            D[dx] = S[sx] * ialpha[2 * dx] + S[sx + 1] * ialpha[2 * dx + 1];
+        }
+        for (; dx < dw; dx++) D[dx] = S[xofs[dx]] * 2048;
+    };
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = std::min(std::max(yofs[dy], 0), sh - 1);
+        int sy1 = std::min(std::max(yofs[dy] + 1, 0), sh - 1);
+        hresize(sy0, row0);
+        hresize(sy1, row1);
+        const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+        uint8_t* D = dst + (size_t)dy * dstep;
+        for (int x = 0; x < dw; x++)
+            D[x] = (uint8_t)((((b0 * (row0[x] >> 4)) >> 16) + ((b1 * (row1[x] >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+// --- A4: GaussianBlur 7x7 sigma 2, 8U ---------------------------------------------------
+// getGaussianKernel(7, 2): exp(-x^2/8)/sum -> Q8 taps cvRound(k*256) = {18,34,49,55,49,34,18}
+// (sum 257); separable; dst = saturate_u8((sum + 2^15) >> 16).  The <=3.4.0 integer
+// SymmRowSmallFilter/SymmColumnSmallFilter path and the 3.4.1 ufixedpoint16 path reduce to
+// the same arithmetic (u8*Q8.8 is exact in 16 bits: 257*255 = 65535).
+static void gaussian_taps(int taps[7]) {
+    double k[7], sum = 0;
+    for (int i = 0; i < 7; i++) { double x = i - 3; k[i] = std::exp(-0.5 / (2.0 * 2.0) * x * x); sum += k[i]; }
+    for (int i = 0; i < 7; i++) taps[i] = cv_round(k[i] / sum * 256.0);
+}
+
+void gaussian7_s2_u8(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep) {
+    int taps[7];
+    gaussian_taps(taps);
+    std::vector<uint16_t> hbuf((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src + (size_t)y * sstep;
+        for (int x = 0; x < w; x++) {
+            uint32_t s = 0;
+            for (int k = 0; k < 7; k++) s += (uint32_t)taps[k] * S[reflect101(x + k - 3, w)];
+            hbuf[(size_t)y * w + x] = (uint16_t)std::min<uint32_t>(s, 65535u);
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        uint8_t* D = dst + (size_t)y * dstep;
+        for (int x = 0; x < w; x++) {
+            uint32_t s = 0;
+            for (int k = 0; k < 7; k++) s += (uint32_t)taps[k] * hbuf[(size_t)reflect101(y + k - 3, h) * w + x];
+            uint32_t v = (s + (1u << 15)) >> 16;
+            D[x] = (uint8_t)std::min<uint32_t>(v, 255u);
+        }
+    }
+}
+
+// --- A1: cv::FAST TYPE_9_16 (modules/features2d/src/fast.cpp, fast_score.cpp) ------------
+static void make_offsets(int pixel[25], int step) {
+    static const int off[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                                   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+    for (int k = 0; k < 16; k++) pixel[k] = off[k][0] + off[k][1] * step;
+    for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+}
+
+int fast_corner_score(const uint8_t* ptr, const int pixel[25], int threshold) {
+    const int K = 8, N = K * 3 + 1;
+    int d[N];
+    const int v = ptr[0];
+    for (int k = 0; k < N; k++) d[k] = v - ptr[pixel[k]];
+    int a0 = threshold;
+    for (int k = 0; k < 16; k += 2) {
+        int a = std::min(d[k + 1], d[k + 2]);
+        a = std::min(a, d[k + 3]);
+        if (a <= a0) continue;
+        a = std::min(a, d[k + 4]); a = std::min(a, d[k + 5]); a = std::min(a, d[k + 6]);
+        a = std::min(a, d[k + 7]); a = std::min(a, d[k + 8]);
+        a0 = std::max(a0, std::min(a, d[k]));
+        a0 = std::max(a0, std::min(a, d[k + 9]));
+    }
+    int b0 = -a0;
+    for (int k = 0; k < 16; k += 2) {
+        int b = std::max(d[k + 1], d[k + 2]);
+        b = std::max(b, d[k + 3]); b = std::max(b, d[k + 4]); b = std::max(b, d[k + 5]);
+        if (b >= b0) continue;
+        b = std::max(b, d[k + 6]); b = std::max(b, d[k + 7]); b = std::max(b, d[k + 8]);
+        b0 = std::min(b0, std::max(b, d[k]));
+        b0 = std::min(b0, std::max(b, d[k + 9]));
+    }
+    return -b0 - 1;
+}
+
+void fast9_16(const uint8_t* img, int w, int h, int step, int threshold, bool nms, std::vector<FastKp>& out) {
+    out.clear();
+    const int K = 8, N = 25;
+    int pixel[25];
+    make_offsets(pixel, step);
+    threshold = std::min(std::max(threshold, 0), 255);
+    if (w < 7 || h < 7) return;
+    // three rolling score rows + corner position lists, as in FAST_t<16>
+    std::vector<uint8_t> buf[3];
+    std::vector<int> cpos[3];
+    for (int i = 0; i < 3; i++) { buf[i].assign(w, 0); cpos[i].clear(); }
+    for (int i = 3; i < h - 2; i++) {
+        std::vector<uint8_t>& curr = buf[(i - 3) % 3];
+        std::vector<int>& cornerpos = cpos[(i - 3) % 3];
+        std::fill(curr.begin(), curr.end(), 0);
+        cornerpos.clear();
+        if (i < h - 3) {
+            const uint8_t* row = img + (size_t)i * step;
+            for (int j = 3; j < w - 3; j++) {
+                const uint8_t* ptr = row + j;
+                const int v = ptr[0];
+                bool corner = false;
+                {   // darker arc: x < v - t
+                    const int vt = v - threshold;
+                    int count = 0;
+                    for (int k = 0; k < N; k++) {
+                        if (ptr[pixel[k]] < vt) { if (++count > K) { corner = true; break; } }
+                        else count = 0;
+                    }
+                }
+                if (!corner) {  // brighter arc: x > v + t
+                    const int vt = v + threshold;
+                    int count = 0;
+                    for (int k = 0; k < N; k++) {
+                        if (ptr[pixel[k]] > vt) { if (++count > K) { corner = true; break; } }
+                        else count = 0;
+                    }
+                }
+                if (corner) {
+                    cornerpos.push_back(j);
+                    if (nms) curr[j] = (uint8_t)fast_corner_score(ptr, pixel, threshold);
+                }
+            }
+        }
+        if (i == 3) continue;
+        const std::vector<uint8_t>& prev = buf[(i - 4 + 3) % 3];
+        const std::vector<uint8_t>& pprev = buf[(i - 5 + 3) % 3];
+        const std::vector<int>& cp = cpos[(i - 4 + 3) % 3];
+        for (int j : cp) {
+            int score = prev[j];
+            if (!nms || (score > prev[j + 1] && score > prev[j - 1] && score > pprev[j - 1] && score > pprev[j] &&
+                         score > pprev[j + 1] && score > curr[j - 1] && score > curr[j] && score > curr[j + 1]))
+                out.push_back({j, i - 1, score});
+        }
+    }
+}
+
+}  // namespace orc

@@ -1,0 +1,50 @@
+// oracle/cvprim.h — TEST INFRASTRUCTURE (CPU oracle), not product code.
+//
+// Plain-C++ restatements of the un-vendored OpenCV 3.4.x primitives the
+// PlanarSLAM hot path calls.  The real OpenCV is not
+// available in the authoring container, so these are written from the
+// published algorithms of the pinned version (3.4.1, reference README.md:62)
+// and parity against the real library is UNPINNED.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// link or call anything in oracle/.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace orc {
+
+// cvRound(): SSE cvtss2si / cvtsd2si => round-half-to-even (A6).
+int cv_round(double v);
+int cv_round(float v);
+inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
+
+// cv::fastAtan2(y, x) in degrees, [0,360) (A5).
+float fast_atan2(float y, float x);
+
+// reflect-101 border index map (A3).
+inline int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { p = p < 0 ? -p : 2 * n - 2 - p; }
+    return p;
+}
+
+// cv::resize(src, dst, dsize, 0, 0, INTER_LINEAR) for CV_8UC1 (A2).
+void resize_linear_u8(const uint8_t* src, int sw, int sh, int sstep,
+                      uint8_t* dst, int dw, int dh, int dstep);
+
+// cv::GaussianBlur(src, dst, Size(7,7), 2, 2, BORDER_REFLECT_101) for CV_8UC1 (A4).
+// dst may alias src (the reference blurs a clone in place).
+void gaussian7_s2_u8(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep);
+
+struct FastKp { int x, y, score; };
+// cv::FAST(img, kps, threshold, nonmaxSuppression) TYPE_9_16 on the ROI it is given (A1).
+void fast9_16(const uint8_t* img, int w, int h, int step, int threshold, bool nms,
+              std::vector<FastKp>& out);
+// cornerScore<16>: largest threshold for which the pixel stays a 9/16 corner
+// (>= threshold-1 by construction).
+int fast_corner_score(const uint8_t* ptr, const int pixel[25], int threshold);
+
+}  // namespace orc

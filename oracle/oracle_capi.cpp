@@ -1,0 +1,74 @@
+// oracle/oracle_capi.cpp — TEST INFRASTRUCTURE (CPU oracle), not product code.
+// extern "C" surface of liboracle.so for ctypes (tests/, smoke(), bench.py cpu_baseline only).
+#include <cstring>
+
+#include "cvprim.h"
+#include "orb_oracle.h"
+
+using namespace orc;
+
+extern "C" {
+
+void* orc_orb_create(int nfeatures, float scale, int nlevels, int ini, int mn) {
+    return new OrbOracle(nfeatures, scale, nlevels, ini, mn);
+}
+void orc_orb_destroy(void* h) { delete (OrbOracle*)h; }
+
+int orc_orb_extract(void* h, const uint8_t* gray, int W, int H, int pitch, KeyPoint* kps, uint8_t* desc, int cap) {
+    OrbOracle* o = (OrbOracle*)h;
+    std::vector<KeyPoint> k; std::vector<uint8_t> d;
+    int n = o->extract(gray, W, H, pitch, k, d);
+    if (n > cap) return -n;
+    if (n) { std::memcpy(kps, k.data(), sizeof(KeyPoint) * n); std::memcpy(desc, d.data(), 32 * (size_t)n); }
+    return n;
+}
+int orc_orb_features_per_level(void* h, int l) { return ((OrbOracle*)h)->features_per_level[l]; }
+float orc_orb_scale(void* h, int l) { return ((OrbOracle*)h)->scale[l]; }
+int orc_orb_umax(void* h, int v) { return ((OrbOracle*)h)->umax[v]; }
+int orc_orb_level_size(void* h, int l, int* w, int* hh) {
+    OrbOracle* o = (OrbOracle*)h;
+    if (l < 0 || l >= (int)o->pyramid.size()) return -1;
+    *w = o->pyramid[l].w; *hh = o->pyramid[l].h; return 0;
+}
+int orc_orb_get_level(void* h, int l, uint8_t* out) {
+    OrbOracle* o = (OrbOracle*)h;
+    std::memcpy(out, o->pyramid[l].px.data(), o->pyramid[l].px.size()); return 0;
+}
+int orc_orb_get_blurred(void* h, int l, uint8_t* out) {
+    OrbOracle* o = (OrbOracle*)h;
+    if (o->blurred[l].px.empty()) return -1;
+    std::memcpy(out, o->blurred[l].px.data(), o->blurred[l].px.size()); return 0;
+}
+int orc_orb_num_candidates(void* h, int l) { return (int)((OrbOracle*)h)->candidates[l].size(); }
+int orc_orb_get_candidates(void* h, int l, int32_t* xys) {   // n x 3 (x, y, score)
+    OrbOracle* o = (OrbOracle*)h;
+    for (size_t i = 0; i < o->candidates[l].size(); i++) {
+        xys[3 * i] = o->candidates[l][i].x; xys[3 * i + 1] = o->candidates[l][i].y; xys[3 * i + 2] = o->candidates[l][i].score;
+    }
+    return (int)o->candidates[l].size();
+}
+int orc_orb_get_level_kps(void* h, int l, KeyPoint* out, int cap) {   // level coordinates, with angle
+    OrbOracle* o = (OrbOracle*)h;
+    int n = (int)o->level_kps[l].size();
+    if (n > cap) return -n;
+    if (n) std::memcpy(out, o->level_kps[l].data(), sizeof(KeyPoint) * n);
+    return n;
+}
+
+// primitives
+void orc_resize_linear_u8(const uint8_t* s, int sw, int sh, int sstep, uint8_t* d, int dw, int dh, int dstep) {
+    resize_linear_u8(s, sw, sh, sstep, d, dw, dh, dstep);
+}
+void orc_gaussian7_s2_u8(const uint8_t* s, int w, int h, int sstep, uint8_t* d, int dstep) { gaussian7_s2_u8(s, w, h, sstep, d, dstep); }
+int orc_fast9_16(const uint8_t* img, int w, int h, int step, int th, int nms, int32_t* xys, int cap) {
+    std::vector<FastKp> out;
+    fast9_16(img, w, h, step, th, nms != 0, out);
+    if ((int)out.size() > cap) return -(int)out.size();
+    for (size_t i = 0; i < out.size(); i++) { xys[3 * i] = out[i].x; xys[3 * i + 1] = out[i].y; xys[3 * i + 2] = out[i].score; }
+    return (int)out.size();
+}
+float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+int orc_cv_round_f(float v) { return cv_round(v); }
+int orc_cv_round_d(double v) { return cv_round(v); }
+
+}  // extern "C"

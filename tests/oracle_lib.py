@@ -1,0 +1,134 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE (the CPU oracle).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_orb_create.restype = C.c_void_p
+        L.orc_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_orb_destroy.argtypes = [C.c_void_p]
+        L.orc_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        for name in ("orc_orb_features_per_level", "orc_orb_umax", "orc_orb_num_candidates"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+        L.orc_orb_scale.argtypes = [C.c_void_p, C.c_int]
+        L.orc_orb_scale.restype = C.c_float
+        L.orc_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_orb_get_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_orb_get_blurred.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_orb_get_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_orb_get_level_kps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_gaussian7_s2_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_cv_round_f.argtypes = [C.c_float]
+        L.orc_cv_round_d.argtypes = [C.c_double]
+        _LIB = L
+    return _LIB
+
+
+class OrbOracle:
+    """CPU oracle of ORBextractor (reference src/ORBextractor.cc)."""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.h = self.L.orc_orb_create(nfeatures, scale, nlevels, ini, mn)
+        self.cap = max(4 * nfeatures, 64)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_orb_destroy(self.h)
+            self.h = None
+
+    def extract(self, gray: np.ndarray):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        H, W = gray.shape
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = self.L.orc_orb_extract(self.h, gray.ctypes.data, W, H, W, kps.ctypes.data, desc.ctypes.data, self.cap)
+        assert n >= 0
+        return kps[:n].copy(), desc[:n].copy()
+
+    def features_per_level(self):
+        return [self.L.orc_orb_features_per_level(self.h, l) for l in range(self.nlevels)]
+
+    def level(self, l):
+        w, h = C.c_int(), C.c_int()
+        assert self.L.orc_orb_level_size(self.h, l, C.byref(w), C.byref(h)) == 0
+        out = np.zeros((h.value, w.value), np.uint8)
+        self.L.orc_orb_get_level(self.h, l, out.ctypes.data)
+        return out
+
+    def blurred(self, l):
+        w, h = C.c_int(), C.c_int()
+        self.L.orc_orb_level_size(self.h, l, C.byref(w), C.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        if self.L.orc_orb_get_blurred(self.h, l, out.ctypes.data) != 0:
+            return None
+        return out
+
+    def candidates(self, l):
+        n = self.L.orc_orb_num_candidates(self.h, l)
+        out = np.zeros((n, 3), np.int32)
+        self.L.orc_orb_get_candidates(self.h, l, out.ctypes.data)
+        return out
+
+    def level_kps(self, l):
+        out = np.zeros(self.cap, KP_DTYPE)
+        n = self.L.orc_orb_get_level_kps(self.h, l, out.ctypes.data, self.cap)
+        return out[:n].copy()
+
+
+def ref_orb_path():
+    return os.path.join(ORACLE_DIR, "_ref", "ref_orb")
+
+
+def run_ref_orb(gray: np.ndarray, nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7):
+    """Run the REAL reference ORBextractor (oracle/_ref/ref_orb). Returns (kps, desc, pyramid)."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    H, W = gray.shape
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.raw"), os.path.join(d, "out.bin")
+        gray.tofile(fin)
+        subprocess.check_call([ref_orb_path(), fin, str(W), str(H), str(nfeatures), repr(float(scale)), str(nlevels),
+                               str(ini), str(mn), fout])
+        buf = open(fout, "rb").read()
+    n = int(np.frombuffer(buf, "<i4", 1, 0)[0])
+    off = 4
+    kps = np.frombuffer(buf, KP_DTYPE, n, off).copy(); off += 28 * n
+    desc = np.frombuffer(buf, np.uint8, 32 * n, off).reshape(n, 32).copy(); off += 32 * n
+    nl = int(np.frombuffer(buf, "<i4", 1, off)[0]); off += 4
+    pyr = []
+    for _ in range(nl):
+        w, h = np.frombuffer(buf, "<i4", 2, off); off += 8
+        pyr.append(np.frombuffer(buf, np.uint8, int(w) * int(h), off).reshape(int(h), int(w)).copy()); off += int(w) * int(h)
+    return kps, desc, pyr
