@@ -1,0 +1,108 @@
+/* planar_abi.h — C ABI of libplanar_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for PlanarSLAM's per-frame extract -> match -> pose-optimise
+ * hot path.  POD only: plain pointers and sizes, no OpenCV /
+ * Eigen / torch types.  Every entry point cites the reference interface it
+ * replaces (paths relative to the PlanarSLAM tree).
+ *
+ * Conventions
+ *  - return 0 (PLANAR_OK) on success, a negative PLANAR_E* code otherwise;
+ *    never throws, never exits.  planar_last_error() gives a message (per thread).
+ *  - "_dev" entry points take DEVICE pointers and only enqueue work on the
+ *    context's stream (results valid after planar_ctx_sync / a stream sync);
+ *    entry points without the suffix take HOST pointers, are synchronous, and
+ *    are what the reference-signature adapters call.
+ *  - the caller owns every buffer; a context is not re-entrant (one per host
+ *    thread, as the reference's ORBextractor instance is, include/ORBextractor.h:85).
+ *  - a batch is B independent frames; frame b of a per-frame array starts at
+ *    b * <documented stride>.
+ */
+#ifndef PLANAR_ABI_H
+#define PLANAR_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLANAR_OK 0
+#define PLANAR_EINVAL (-1)   /* bad argument (null pointer, size out of range) */
+#define PLANAR_ENOMEM (-2)   /* device/host allocation failed */
+#define PLANAR_EDEVICE (-3)  /* HIP runtime error (no device, launch failure) */
+#define PLANAR_ECAPACITY (-4) /* output capacity too small */
+#define PLANAR_ESTATE (-5)   /* call out of order */
+
+typedef struct planar_ctx planar_ctx;
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id),
+ * so an adapter can memcpy into std::vector<cv::KeyPoint>. */
+typedef struct planar_keypoint {
+    float x, y;       /* level-0 pixel coordinates (level coords * scale[octave]), ORBextractor.cc:1094-1100 */
+    float size;       /* (int)(31 * scale[octave]),                                  ORBextractor.cc:835,845 */
+    float angle;      /* IC_Angle, degrees [0,360),                                  ORBextractor.cc:77-104 */
+    float response;   /* FAST-9/16 corner score                                                              */
+    int32_t octave;   /* pyramid level                                                                       */
+    int32_t class_id; /* -1                                                                                  */
+} planar_keypoint;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* Creates a context on HIP device `device` with its own stream. */
+int planar_ctx_create(planar_ctx** out, int device);
+void planar_ctx_destroy(planar_ctx* ctx);
+/* Use an external hipStream_t (e.g. torch's current stream) for all subsequent work; NULL
+ * restores the context's own stream. */
+int planar_ctx_set_stream(planar_ctx* ctx, void* hip_stream);
+void* planar_ctx_get_stream(planar_ctx* ctx);
+int planar_ctx_sync(planar_ctx* ctx);
+const char* planar_last_error(void);
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int planar_abi_version(void);
+
+/* ---- ORB extractor (replaces Planar_SLAM::ORBextractor, include/ORBextractor.h:45-112) -- */
+typedef struct planar_orb planar_orb;
+
+typedef struct planar_orb_params {
+    int32_t nfeatures;    /* ORBextractor.nFeatures   (1000) */
+    float scale_factor;   /* ORBextractor.scaleFactor (1.2)  */
+    int32_t nlevels;      /* ORBextractor.nLevels     (8)    */
+    int32_t ini_th_fast;  /* ORBextractor.iniThFAST   (20)   */
+    int32_t min_th_fast;  /* ORBextractor.minThFAST   (7)    */
+} planar_orb_params;
+
+/* ORBextractor::ORBextractor (src/ORBextractor.cc:410-470) + all device workspace for
+ * batches of up to max_batch frames of width x height 8-bit gray. */
+int planar_orb_create(planar_ctx* ctx, const planar_orb_params* params, int width, int height, int max_batch,
+                      planar_orb** out);
+void planar_orb_destroy(planar_orb* orb);
+/* Upper bound on keypoints per frame (nfeatures + small octree overshoot); the per-frame
+ * stride of `kps`/`desc` below. */
+int planar_orb_max_keypoints(const planar_orb* orb);
+/* Getters of the reference class (include/ORBextractor.h:63-83): out[nlevels]. */
+int planar_orb_get_scale_factors(const planar_orb* orb, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2);
+int planar_orb_level_size(const planar_orb* orb, int level, int* w, int* h);
+int planar_orb_features_per_level(const planar_orb* orb, int32_t* out);
+
+/* ORBextractor::operator() (src/ORBextractor.cc:1043-1105) on B frames.
+ *   gray   : B frames, row pitch `pitch` bytes, frame stride `frame_stride` bytes
+ *   kps    : [B][planar_orb_max_keypoints]           desc : [B][max_keypoints][32]
+ *   n_out  : [B] keypoints found per frame
+ * Host-pointer version: copies in, runs, copies out, synchronous. */
+int planar_orb_extract(planar_orb* orb, const uint8_t* gray, int B, int pitch, int64_t frame_stride,
+                       planar_keypoint* kps, uint8_t* desc, int32_t* n_out);
+/* Device-pointer version: enqueues on the context stream and returns. */
+int planar_orb_extract_dev(planar_orb* orb, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride,
+                           planar_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n_out);
+
+/* Stage read-back for parity tests and for the adapter's public mvImagePyramid member
+ * (include/ORBextractor.h:85).  Valid after an extract call; host output buffers. */
+int planar_orb_read_level(planar_orb* orb, int frame, int level, uint8_t* out /* w*h */);
+int planar_orb_read_blurred(planar_orb* orb, int frame, int level, uint8_t* out /* w*h */);
+/* FAST survivors of one level in the reference's emission order (ORBextractor.cc:789-826):
+ * out = n x {x, y, score} relative to (minBorderX, minBorderY); returns n or a negative code. */
+int planar_orb_read_candidates(planar_orb* orb, int frame, int level, int32_t* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLANAR_ABI_H */

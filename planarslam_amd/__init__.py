@@ -1,0 +1,5 @@
+"""planarslam_amd — MI355X-native (gfx950) hot path of PlanarSLAM behind a C ABI.
+
+Python here is thin plumbing (ctypes) over libplanar_hip.so; see include/planar_abi.h."""
+from ._lib import KP_DTYPE, Context, PlanarError, lib  # noqa: F401
+from .orb import ORBextractor  # noqa: F401

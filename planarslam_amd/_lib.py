@@ -1,0 +1,108 @@
+"""ctypes binding of libplanar_hip.so (the C ABI in include/planar_abi.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible the calls fail
+loudly (PlanarError / OSError)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplanar_hip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+
+class PlanarError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libplanar_hip error {code}: {msg}")
+        self.code = code
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "planar_last_error": (C.c_char_p, []),
+    "planar_abi_version": (C.c_int, []),
+    "planar_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "planar_ctx_destroy": (None, [C.c_void_p]),
+    "planar_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "planar_ctx_get_stream": (C.c_void_p, [C.c_void_p]),
+    "planar_ctx_sync": (C.c_int, [C.c_void_p]),
+    "planar_orb_create": (C.c_int, [C.c_void_p, C.POINTER(OrbParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "planar_orb_destroy": (None, [C.c_void_p]),
+    "planar_orb_max_keypoints": (C.c_int, [C.c_void_p]),
+    "planar_orb_get_scale_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_orb_level_size": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "planar_orb_features_per_level": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "planar_orb_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_orb_extract_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_orb_read_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "planar_orb_read_blurred": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "planar_orb_read_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+}
+
+_LIB = None
+
+
+def exported_symbols():
+    """Every symbol include/planar_abi.h declares (kept in sync by tests/test_abi.py)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int):
+    if rc < 0:
+        raise PlanarError(rc, lib().planar_last_error().decode(errors="replace"))
+    return rc
+
+
+class Context:
+    """planar_ctx: one HIP device + stream.  Not re-entrant (one per host thread)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.L = lib()
+        h = C.c_void_p()
+        check(self.L.planar_ctx_create(C.byref(h), device))
+        self.h = h
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, hip_stream: int | None):
+        check(self.L.planar_ctx_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def sync(self):
+        check(self.L.planar_ctx_sync(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.planar_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

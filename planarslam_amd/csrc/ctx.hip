@@ -1,0 +1,56 @@
+// planarslam_amd/csrc/ctx.hip — context / error plumbing of libplanar_hip.so.
+#include "common.h"
+
+namespace planar {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace planar
+
+extern "C" {
+
+const char* planar_last_error(void) { return planar::g_err; }
+int planar_abi_version(void) { return 100; }
+
+int planar_ctx_create(planar_ctx** out, int device) {
+    PLANAR_REQUIRE(out != nullptr, PLANAR_EINVAL, "out is null");
+    *out = nullptr;
+    int n = 0;
+    PLANAR_HIP_CHECK(hipGetDeviceCount(&n));
+    PLANAR_REQUIRE(device >= 0 && device < n, PLANAR_EDEVICE, "no such HIP device");
+    PLANAR_HIP_CHECK(hipSetDevice(device));
+    planar_ctx* c = new (std::nothrow) planar_ctx();
+    PLANAR_REQUIRE(c != nullptr, PLANAR_ENOMEM, "host allocation failed");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; planar::set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
+    c->stream = c->own_stream;
+    *out = c;
+    return PLANAR_OK;
+}
+
+void planar_ctx_destroy(planar_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int planar_ctx_set_stream(planar_ctx* ctx, void* s) {
+    PLANAR_REQUIRE(ctx != nullptr, PLANAR_EINVAL, "ctx is null");
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return PLANAR_OK;
+}
+
+void* planar_ctx_get_stream(planar_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int planar_ctx_sync(planar_ctx* ctx) {
+    PLANAR_REQUIRE(ctx != nullptr, PLANAR_EINVAL, "ctx is null");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PLANAR_OK;
+}
+
+}  // extern "C"
