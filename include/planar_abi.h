@@ -102,6 +102,15 @@ int planar_orb_read_blurred(planar_orb* orb, int frame, int level, uint8_t* out 
  * out = n x {x, y, score} relative to (minBorderX, minBorderY); returns n or a negative code. */
 int planar_orb_read_candidates(planar_orb* orb, int frame, int level, int32_t* out, int cap);
 
+/* Per-launch timing with HIP events on the context stream (bench.py's roofline leg).
+ * set_profiling(1) starts recording an event before/after every kernel launch of each
+ * extract call; get_profile synchronises, returns the summed milliseconds per launch slot
+ * (total_ms[planar_orb_profile_num_launches]) and the number of recorded calls, and resets. */
+int planar_orb_set_profiling(planar_orb* orb, int enable);
+int planar_orb_profile_num_launches(const planar_orb* orb);
+const char* planar_orb_profile_launch_name(const planar_orb* orb, int i);
+int planar_orb_get_profile(planar_orb* orb, double* total_ms, int64_t* calls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,10 @@ _SIGS = {
     "planar_orb_read_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "planar_orb_read_blurred": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "planar_orb_read_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "planar_orb_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "planar_orb_profile_num_launches": (C.c_int, [C.c_void_p]),
+    "planar_orb_profile_launch_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "planar_orb_get_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _LIB = None

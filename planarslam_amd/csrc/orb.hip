@@ -753,6 +753,14 @@ struct planar_orb {
         d_kept, d_kept_count;
     // staging for the host-pointer entry point
     DevBuf d_in, d_kps, d_desc, d_nout;
+    // optional per-launch HIP-event timing (planar_orb_set_profiling)
+    bool profiling = false;
+    std::vector<std::vector<hipEvent_t>> ev_sets;   // one set of (launches+1) events per recorded call
+    size_t ev_used = 0;
+    std::vector<const char*> launch_names;          // kernel name per launch of one extract call
+    ~planar_orb() {
+        for (auto& v : ev_sets) for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    }
 };
 
 static inline int cv_round_f(float v) { return (int)nearbyintf(v); }
@@ -936,11 +944,44 @@ int planar_orb_create(planar_ctx* ctx, const planar_orb_params* p, int W, int H,
     if (e == hipSuccess && o->oct_smem > 64 * 1024)
         e = hipFuncSetAttribute((const void*)orb_octree, hipFuncAttributeMaxDynamicSharedMemorySize, o->oct_smem);
     if (e != hipSuccess) { delete o; set_error("planar_orb_create: upload failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
+    o->launch_names.push_back("orb_copy_level0");
+    for (int l = 1; l < nl; l++) o->launch_names.push_back("orb_resize");
+    for (const char* n : {"orb_fast_cells", "orb_sort", "orb_octree", "orb_blur", "orb_describe"}) o->launch_names.push_back(n);
     *out = o;
     return PLANAR_OK;
 }
 
 void planar_orb_destroy(planar_orb* o) { delete o; }
+
+int planar_orb_set_profiling(planar_orb* o, int enable) {
+    PLANAR_REQUIRE(o != nullptr, PLANAR_EINVAL, "orb is null");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
+    o->profiling = enable != 0;
+    o->ev_used = 0;
+    return PLANAR_OK;
+}
+
+int planar_orb_profile_num_launches(const planar_orb* o) { return o ? (int)o->launch_names.size() : PLANAR_EINVAL; }
+
+const char* planar_orb_profile_launch_name(const planar_orb* o, int i) {
+    return (o && i >= 0 && i < (int)o->launch_names.size()) ? o->launch_names[i] : nullptr;
+}
+
+int planar_orb_get_profile(planar_orb* o, double* total_ms, int64_t* calls) {
+    PLANAR_REQUIRE(o && total_ms && calls, PLANAR_EINVAL, "null argument");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
+    const size_t nl = o->launch_names.size();
+    for (size_t i = 0; i < nl; i++) total_ms[i] = 0;
+    for (size_t c = 0; c < o->ev_used; c++)
+        for (size_t i = 0; i < nl; i++) {
+            float ms = 0;
+            PLANAR_HIP_CHECK(hipEventElapsedTime(&ms, o->ev_sets[c][i], o->ev_sets[c][i + 1]));
+            total_ms[i] += ms;
+        }
+    *calls = (int64_t)o->ev_used;
+    o->ev_used = 0;
+    return PLANAR_OK;
+}
 
 int planar_orb_max_keypoints(const planar_orb* o) { return o ? o->plan.kp_cap : PLANAR_EINVAL; }
 
@@ -976,23 +1017,43 @@ int planar_orb_extract_dev(planar_orb* o, const uint8_t* d_gray, int B, int pitc
     const PlanDev& P = o->plan;
     const PlanDev* dp = o->d_plan.as<PlanDev>();
     uint8_t* pyr = o->d_pyr.as<uint8_t>();
+    std::vector<hipEvent_t>* evs = nullptr;
+    if (o->profiling) {
+        const size_t need = (size_t)P.nlevels + 5 + 1;
+        if (o->ev_used == o->ev_sets.size()) {
+            std::vector<hipEvent_t> v(need);
+            for (size_t i = 0; i < need; i++) PLANAR_HIP_CHECK(hipEventCreate(&v[i]));
+            o->ev_sets.push_back(v);
+        }
+        evs = &o->ev_sets[o->ev_used++];
+    }
+    int li = 0;
+    auto mark = [&]() { if (evs) (void)hipEventRecord((*evs)[li], st); li++; };
+    mark();
     {
         const int n = (P.lv[0].pitch / 4) * P.lv[0].h;
         hipLaunchKernelGGL(orb_copy_level0, dim3((n + 255) / 256, B), dim3(256), 0, st, dp, d_gray, pitch, frame_stride, pyr);
+        mark();
     }
     for (int l = 1; l < P.nlevels; l++) {
         const int n = (P.lv[l].pitch / 4) * P.lv[l].h;
         hipLaunchKernelGGL(orb_resize, dim3((n + 255) / 256, B), dim3(256), 0, st, dp, o->d_tabs.as<short4>(), pyr, l);
+        mark();
     }
     hipLaunchKernelGGL(orb_fast_cells, dim3(P.ncells_total, B), dim3(256), o->fast_smem, st, dp, o->d_cells.as<CellDev>(), pyr,
                        o->d_cand.as<uint32_t>(), o->d_cell_count.as<int>());
+    mark();
     hipLaunchKernelGGL(orb_sort, dim3(P.nlevels, B), dim3(256), 0, st, dp, o->d_cells.as<CellDev>(), o->d_cand.as<uint32_t>(),
                        o->d_cell_count.as<int>(), o->d_sortA.as<uint64_t>(), o->d_sortB.as<uint64_t>(), o->d_level_count.as<int>());
+    mark();
     hipLaunchKernelGGL(orb_octree, dim3(P.nlevels, B), dim3(64), o->oct_smem, st, dp, o->d_sortA.as<uint64_t>(), o->d_sortB.as<uint64_t>(),
                        o->d_level_count.as<int>(), o->d_kept.as<uint32_t>(), o->d_kept_count.as<int>(), o->node_cap);
+    mark();
     hipLaunchKernelGGL(orb_blur, dim3((unsigned)o->tiles.size(), B), dim3(256), 0, st, dp, o->d_tiles.as<TileDev>(), pyr, o->d_blur.as<uint8_t>());
+    mark();
     hipLaunchKernelGGL(orb_describe, dim3((P.kp_cap + 15) / 16, B), dim3(256), 0, st, dp, pyr, o->d_blur.as<uint8_t>(), o->d_kept.as<uint32_t>(),
                        o->d_kept_count.as<int>(), d_kps, d_desc, d_n_out);
+    mark();
     PLANAR_HIP_CHECK(hipGetLastError());
     o->last_B = B;
     return PLANAR_OK;

@@ -110,3 +110,20 @@ class ORBextractor:
         out = np.zeros((cap, 3), np.int32)
         n = check(self.L.planar_orb_read_candidates(self.h, frame, level, out.ctypes.data, cap))
         return out[:n].copy()
+
+    # --- per-launch HIP-event timing (bench.py roofline leg) ---
+    def set_profiling(self, enable: bool):
+        check(self.L.planar_orb_set_profiling(self.h, int(enable)))
+
+    def get_profile(self):
+        """Returns ({kernel name: (total_ms, launches)}, calls) since profiling was enabled; resets."""
+        n = check(self.L.planar_orb_profile_num_launches(self.h))
+        ms = np.zeros(n, np.float64)
+        calls = C.c_int64()
+        check(self.L.planar_orb_get_profile(self.h, ms.ctypes.data, C.byref(calls)))
+        out = {}
+        for i in range(n):
+            name = self.L.planar_orb_profile_launch_name(self.h, i).decode()
+            t, k = out.get(name, (0.0, 0))
+            out[name] = (t + float(ms[i]), k + calls.value)
+        return out, calls.value
