@@ -111,6 +111,52 @@ int planar_orb_profile_num_launches(const planar_orb* orb);
 const char* planar_orb_profile_launch_name(const planar_orb* orb, int i);
 int planar_orb_get_profile(planar_orb* orb, double* total_ms, int64_t* calls);
 
+/* ---- pose optimisation (replaces Optimizer::PoseOptimization, src/Optimizer.cc:550-1275, and
+ *      Optimizer::TranslationOptimization, :2995-3738; include/Optimizer.h:37,43) ------------ */
+#define PLANAR_POSE_FULL 0         /* PoseOptimization: point/line/plane/parallel/vertical edges, 6-DoF */
+#define PLANAR_POSE_TRANSLATION 1  /* TranslationOptimization: ...OnlyTranslation edges, rotation kept  */
+
+typedef struct planar_pose_params {
+    float fx, fy, cx, cy, bf;      /* Frame::fx, fy, cx, cy, mbf                                         */
+    /* raw Config values (src/Optimizer.cc:771-783): Plane.AngleInfo, Plane.DistanceInfo,
+     * Plane.ParallelInfo, Plane.VerticalInfo, Plane.Chi, Plane.VPChi                                    */
+    double angle_info, distance_info, parallel_info, vertical_info, plane_chi, vp_chi;
+} planar_pose_params;
+
+/* B frames, structure-of-arrays with per-frame strides max_points / max_lines / max_planes.
+ * Inputs mirror the Frame fields the reference reads:                            */
+typedef struct planar_pose_batch {
+    int32_t B, max_points, max_lines, max_planes;
+    const int32_t* n_points;       /* [B]  Frame::N                                                      */
+    const int32_t* n_lines;        /* [B]  Frame::NL                                                     */
+    const int32_t* n_planes;       /* [B]  Frame::mnPlaneNum                                             */
+    const uint8_t* pt_valid;       /* [B][max_points]      mvpMapPoints[i] != NULL                       */
+    const float* pt_xw;            /* [B][max_points][3]   MapPoint::GetWorldPos() (float32)             */
+    const float* pt_obs;           /* [B][max_points][3]   mvKeysUn[i].pt.x, .pt.y, mvuRight[i] (<0: mono) */
+    const float* pt_inv_sigma2;    /* [B][max_points]      mvInvLevelSigma2[mvKeysUn[i].octave]          */
+    const uint8_t* ln_valid;       /* [B][max_lines]       mvpMapLines[i] != NULL                        */
+    const double* ln_obs;          /* [B][max_lines][3]    mvKeyLineFunctions[i]                         */
+    const double* ln_xw;           /* [B][max_lines][6]    MapLine::mWorldPos (start xyz, end xyz)       */
+    const float* pl_meas;          /* [B][max_planes][4]   mvPlaneCoefficients[i]                        */
+    const uint8_t* pl_valid;       /* [B][max_planes][3]   mvpMapPlanes / mvpParallelPlanes / mvpVerticalPlanes[i] != NULL */
+    const float* pl_world;         /* [B][max_planes][3][4] GetWorldPos() of those three map planes      */
+    const float* Tcw_in;           /* [B][16]              Frame::mTcw, row-major 4x4 float32            */
+    /* outputs */
+    float* Tcw_out;                /* [B][16]              pose passed to Frame::SetPose                 */
+    uint8_t* pt_outlier;           /* [B][max_points]      mvbOutlier      (written only where pt_valid) */
+    uint8_t* ln_outlier;           /* [B][max_lines]       mvbLineOutlier  (written only where ln_valid) */
+    uint8_t* pl_outlier;           /* [B][max_planes][3]   mvbPlaneOutlier / mvbParPlaneOutlier / mvbVerPlaneOutlier */
+    int32_t* n_inliers;            /* [B]                  the reference function's return value         */
+    int32_t* lm_iters;             /* [B] or NULL          LM iterations run (diagnostic)                */
+} planar_pose_batch;
+
+/* rounds = 4, its = 10 reproduce the reference protocol (4 x optimize(10) with outlier
+ * re-classification, src/Optimizer.cc:990-1000).  All pointers in `batch` are HOST pointers for
+ * planar_pose_opt (synchronous) and DEVICE pointers for planar_pose_opt_dev (enqueue only; the
+ * struct itself is always host memory, passed by value to the kernel). */
+int planar_pose_opt(planar_ctx* ctx, const planar_pose_batch* batch, const planar_pose_params* params, int mode, int rounds, int its);
+int planar_pose_opt_dev(planar_ctx* ctx, const planar_pose_batch* d_batch, const planar_pose_params* params, int mode, int rounds, int its);
+
 #ifdef __cplusplus
 }
 #endif

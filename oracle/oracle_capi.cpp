@@ -72,3 +72,38 @@ int orc_cv_round_f(float v) { return cv_round(v); }
 int orc_cv_round_d(double v) { return cv_round(v); }
 
 }  // extern "C"
+
+// ---- pose optimisation oracle (pose_oracle.cpp) ----
+#include "pose_oracle.h"
+extern "C" {
+// Flat batch layout == include/planar_abi.h planar_pose_batch (per-frame strides max_*).
+int orc_pose_optimize_batch(int B, int max_points, int max_lines, int max_planes, const int32_t* n_points,
+                            const int32_t* n_lines, const int32_t* n_planes, const uint8_t* pt_valid, const float* pt_xw,
+                            const float* pt_obs, const float* pt_inv_sigma2, const uint8_t* ln_valid, const double* ln_obs,
+                            const double* ln_xw, const float* pl_meas, const uint8_t* pl_valid, const float* pl_world,
+                            const float* Tcw_in, const orc::PoseParams* prm, int mode, int rounds, int its, float* Tcw_out,
+                            uint8_t* pt_outlier, uint8_t* ln_outlier, uint8_t* pl_outlier, int32_t* n_inliers, int32_t* lm_iters,
+                            double* final_chi2) {
+    for (int b = 0; b < B; b++) {
+        orc::PoseProblem p;
+        p.n_points = n_points[b]; p.n_lines = n_lines[b]; p.n_planes = n_planes[b];
+        p.pt_valid = pt_valid + (size_t)b * max_points; p.pt_xw = pt_xw + (size_t)b * max_points * 3;
+        p.pt_obs = pt_obs + (size_t)b * max_points * 3; p.pt_inv_sigma2 = pt_inv_sigma2 + (size_t)b * max_points;
+        p.ln_valid = ln_valid + (size_t)b * max_lines; p.ln_obs = ln_obs + (size_t)b * max_lines * 3;
+        p.ln_xw = ln_xw + (size_t)b * max_lines * 6;
+        p.pl_meas = pl_meas + (size_t)b * max_planes * 4; p.pl_valid = pl_valid + (size_t)b * max_planes * 3;
+        p.pl_world = pl_world + (size_t)b * max_planes * 12;
+        p.Tcw = Tcw_in + (size_t)b * 16;
+        orc::PoseResult r;
+        r.pt_outlier = pt_outlier + (size_t)b * max_points; r.ln_outlier = ln_outlier + (size_t)b * max_lines;
+        r.pl_outlier = pl_outlier + (size_t)b * max_planes * 3;
+        r.n_inliers = 0; r.lm_iterations = 0; r.final_chi2 = 0;
+        orc::pose_optimize(p, *prm, mode, rounds, its, r);
+        std::memcpy(Tcw_out + (size_t)b * 16, r.Tcw, sizeof(r.Tcw));
+        n_inliers[b] = r.n_inliers;
+        if (lm_iters) lm_iters[b] = r.lm_iterations;
+        if (final_chi2) final_chi2[b] = r.final_chi2;
+    }
+    return 0;
+}
+}

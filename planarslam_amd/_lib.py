@@ -27,6 +27,19 @@ class OrbParams(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class PoseParams(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+                ("angle_info", C.c_double), ("distance_info", C.c_double), ("parallel_info", C.c_double),
+                ("vertical_info", C.c_double), ("plane_chi", C.c_double), ("vp_chi", C.c_double)]
+
+
+class PoseBatch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("max_points", C.c_int32), ("max_lines", C.c_int32), ("max_planes", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid",
+                                  "ln_obs", "ln_xw", "pl_meas", "pl_valid", "pl_world", "Tcw_in", "Tcw_out", "pt_outlier",
+                                  "ln_outlier", "pl_outlier", "n_inliers", "lm_iters")]
+
+
 _SIGS = {
     # name: (restype, argtypes)
     "planar_last_error": (C.c_char_p, []),
@@ -51,6 +64,8 @@ _SIGS = {
     "planar_orb_profile_num_launches": (C.c_int, [C.c_void_p]),
     "planar_orb_profile_launch_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "planar_orb_get_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "planar_pose_opt": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
+    "planar_pose_opt_dev": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
 }
 
 _LIB = None

@@ -43,3 +43,101 @@ def gray_image(seed: int = 1234, w: int = 640, h: int = 480) -> np.ndarray:
 
 def gray_batch(n: int, seed: int = 1234, w: int = 640, h: int = 480) -> np.ndarray:
     return np.stack([gray_image(seed + i, w, h) for i in range(n)])
+
+
+# ----------------------------------------------------------------------------------------------
+# Pose-optimisation problems: SoA batch in the layout of
+# include/planar_abi.h `planar_pose_batch`.
+TUM3 = dict(fx=535.4, fy=539.2, cx=320.1, cy=247.6, bf=40.0, angle_info=0.5, distance_info=50.0, parallel_info=0.1,
+            vertical_info=0.1, plane_chi=100.0, vp_chi=50.0)
+LEVEL_COUNTS = np.array([217, 181, 151, 126, 105, 87, 73, 60])
+
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def pose_batch(B=4, n_points=1000, n_lines=75, n_planes=4, seed=7, outlier_frac=0.10, stereo_frac=0.85,
+               max_points=None, max_lines=None, max_planes=None, rot_pert=0.02, trans_pert=0.05):
+    """B synthetic frames.  Returns a dict of contiguous numpy arrays (+ 'T_gt' [B,4,4] float64)."""
+    P = TUM3
+    MP, ML, MM = max_points or n_points, max_lines or n_lines, max_planes or n_planes
+    scale = 1.2 ** np.arange(8)
+    out = dict(
+        n_points=np.full(B, n_points, np.int32), n_lines=np.full(B, n_lines, np.int32), n_planes=np.full(B, n_planes, np.int32),
+        pt_valid=np.zeros((B, MP), np.uint8), pt_xw=np.zeros((B, MP, 3), np.float32), pt_obs=np.zeros((B, MP, 3), np.float32),
+        pt_inv_sigma2=np.ones((B, MP), np.float32), ln_valid=np.zeros((B, ML), np.uint8), ln_obs=np.zeros((B, ML, 3), np.float64),
+        ln_xw=np.zeros((B, ML, 6), np.float64), pl_meas=np.zeros((B, MM, 4), np.float32), pl_valid=np.zeros((B, MM, 3), np.uint8),
+        pl_world=np.zeros((B, MM, 3, 4), np.float32), Tcw=np.zeros((B, 16), np.float32), T_gt=np.zeros((B, 4, 4)))
+    for b in range(B):
+        rng = np.random.default_rng(seed + b)
+        w = rng.normal(size=3); w *= rng.uniform(0, 0.05) / np.linalg.norm(w)
+        t = rng.normal(size=3); t *= rng.uniform(0, 0.1) / np.linalg.norm(t)
+        R = _rodrigues(w)
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+        out["T_gt"][b] = T
+        Rinv, tinv = R.T, -R.T @ t
+
+        def backproject(u, v, z):
+            return np.stack([(u - P["cx"]) * z / P["fx"], (v - P["cy"]) * z / P["fy"], z], -1)
+
+        def project(Xw):
+            Xc = Xw @ R.T + t
+            return np.stack([Xc[..., 0] / Xc[..., 2] * P["fx"] + P["cx"], Xc[..., 1] / Xc[..., 2] * P["fy"] + P["cy"]], -1), Xc[..., 2]
+
+        # points
+        u, v, z = rng.uniform(20, 620, n_points), rng.uniform(20, 460, n_points), rng.uniform(0.5, 6, n_points)
+        Xw = (backproject(u, v, z) @ Rinv.T + tinv).astype(np.float32)
+        octave = rng.choice(8, n_points, p=LEVEL_COUNTS / LEVEL_COUNTS.sum())
+        uv, zc = project(Xw.astype(np.float64))
+        sig = scale[octave]
+        obs = np.zeros((n_points, 3))
+        obs[:, :2] = uv + rng.normal(size=(n_points, 2)) * sig[:, None]
+        obs[:, 2] = obs[:, 0] - P["bf"] / zc + rng.normal(size=n_points) * sig * 0.5
+        mono = rng.random(n_points) > stereo_frac
+        obs[mono, 2] = -1
+        bad = rng.random(n_points) < outlier_frac
+        obs[bad, 0] = rng.uniform(0, 640, bad.sum()); obs[bad, 1] = rng.uniform(0, 480, bad.sum())
+        out["pt_valid"][b, :n_points] = (rng.random(n_points) < 0.97).astype(np.uint8)    # a few NULL map points
+        out["pt_xw"][b, :n_points] = Xw
+        out["pt_obs"][b, :n_points] = obs.astype(np.float32)
+        out["pt_inv_sigma2"][b, :n_points] = (1.0 / (scale[octave].astype(np.float32) ** 2)).astype(np.float32)
+        # lines: two 3-D endpoints; observation = normalised cross product of noisy projected endpoints
+        for i in range(n_lines):
+            uu, vv, zz = rng.uniform(30, 610, 2), rng.uniform(30, 450, 2), rng.uniform(0.8, 5, 2)
+            Xl = backproject(uu, vv, zz) @ Rinv.T + tinv
+            pe, _ = project(Xl)
+            pe = pe + rng.normal(size=(2, 2)) * 0.7
+            if rng.random() < outlier_frac:
+                pe = pe + rng.uniform(-60, 60, (2, 2))
+            l = np.cross(np.append(pe[0], 1.0), np.append(pe[1], 1.0))
+            out["ln_obs"][b, i] = l / np.linalg.norm(l)
+            out["ln_xw"][b, i] = Xl.reshape(6)
+            out["ln_valid"][b, i] = 1 if rng.random() < 0.95 else 0
+        # planes: observed camera-frame plane i with a matched, a parallel and a vertical map plane
+        for i in range(n_planes):
+            nc = rng.normal(size=3); nc /= np.linalg.norm(nc)
+            dc = rng.uniform(0.8, 3.0)
+            nw = Rinv @ nc
+            dw = dc + t @ nc            # d_c = d_w - t.n_c  (Plane3D operator*)
+            def noisy(n, d, ang=np.radians(0.5), dd=0.005):
+                a = rng.normal(size=3); a -= a.dot(n) * n; a /= np.linalg.norm(a)
+                n2 = n * np.cos(ang) + a * np.sin(ang) * rng.normal()
+                n2 /= np.linalg.norm(n2)
+                return np.append(n2, d + rng.normal() * dd)
+            out["pl_meas"][b, i] = noisy(nc, dc).astype(np.float32)
+            out["pl_world"][b, i, 0] = np.append(nw, dw).astype(np.float32)
+            out["pl_world"][b, i, 1] = np.append(nw, dw + rng.uniform(0.3, 1.0)).astype(np.float32)     # parallel, other offset
+            a = rng.normal(size=3); a -= a.dot(nw) * nw; a /= np.linalg.norm(a)
+            out["pl_world"][b, i, 2] = np.append(a, rng.uniform(0.5, 2.0)).astype(np.float32)          # perpendicular
+            out["pl_valid"][b, i] = [1, 1, 1]
+        # initial pose = ground truth perturbed
+        dw_ = rng.normal(size=3); dw_ *= rot_pert / np.linalg.norm(dw_)
+        dt_ = rng.normal(size=3); dt_ *= trans_pert / np.linalg.norm(dt_)
+        T0 = np.eye(4); T0[:3, :3] = _rodrigues(dw_) @ R; T0[:3, 3] = t + dt_
+        out["Tcw"][b] = T0.astype(np.float32).reshape(16)
+    return out

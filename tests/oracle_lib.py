@@ -132,3 +132,35 @@ def run_ref_orb(gray: np.ndarray, nfeatures=1000, scale=1.2, nlevels=8, ini=20, 
         w, h = np.frombuffer(buf, "<i4", 2, off); off += 8
         pyr.append(np.frombuffer(buf, np.uint8, int(w) * int(h), off).reshape(int(h), int(w)).copy()); off += int(w) * int(h)
     return kps, desc, pyr
+
+
+# ---- pose optimisation oracle ----
+class PoseParamsC(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+                ("angle_info", C.c_double), ("distance_info", C.c_double), ("parallel_info", C.c_double),
+                ("vertical_info", C.c_double), ("plane_chi", C.c_double), ("vp_chi", C.c_double)]
+
+
+def pose_params(d):
+    return PoseParamsC(d["fx"], d["fy"], d["cx"], d["cy"], d["bf"], d["angle_info"], d["distance_info"], d["parallel_info"],
+                       d["vertical_info"], d["plane_chi"], d["vp_chi"])
+
+
+def pose_optimize(batch, params, mode=0, rounds=4, its=10):
+    """CPU oracle of Optimizer::PoseOptimization (mode 0) / TranslationOptimization (mode 1) on a synth.pose_batch()."""
+    L = lib()
+    B = len(batch["n_points"])
+    MP, ML, MM = batch["pt_valid"].shape[1], batch["ln_valid"].shape[1], batch["pl_valid"].shape[1]
+    res = dict(Tcw=np.zeros((B, 16), np.float32), pt_outlier=np.zeros((B, MP), np.uint8), ln_outlier=np.zeros((B, ML), np.uint8),
+               pl_outlier=np.zeros((B, MM, 3), np.uint8), n_inliers=np.zeros(B, np.int32), lm_iters=np.zeros(B, np.int32),
+               final_chi2=np.zeros(B, np.float64))
+    prm = pose_params(params)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.orc_pose_optimize_batch.restype = C.c_int
+    L.orc_pose_optimize_batch(
+        C.c_int(B), C.c_int(MP), C.c_int(ML), C.c_int(MM), p(batch["n_points"]), p(batch["n_lines"]), p(batch["n_planes"]),
+        p(batch["pt_valid"]), p(batch["pt_xw"]), p(batch["pt_obs"]), p(batch["pt_inv_sigma2"]), p(batch["ln_valid"]),
+        p(batch["ln_obs"]), p(batch["ln_xw"]), p(batch["pl_meas"]), p(batch["pl_valid"]), p(batch["pl_world"]), p(batch["Tcw"]),
+        C.byref(prm), C.c_int(mode), C.c_int(rounds), C.c_int(its), p(res["Tcw"]), p(res["pt_outlier"]), p(res["ln_outlier"]),
+        p(res["pl_outlier"]), p(res["n_inliers"]), p(res["lm_iters"]), p(res["final_chi2"]))
+    return res
