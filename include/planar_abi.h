@@ -157,6 +157,41 @@ typedef struct planar_pose_batch {
 int planar_pose_opt(planar_ctx* ctx, const planar_pose_batch* batch, const planar_pose_params* params, int mode, int rounds, int its);
 int planar_pose_opt_dev(planar_ctx* ctx, const planar_pose_batch* d_batch, const planar_pose_params* params, int mode, int rounds, int its);
 
+/* ---- descriptor matchers ------------------------------------------------------------------
+ * Descriptors are 32-byte rows (cv::Mat N x 32 CV_8U: Frame::mDescriptors, Frame::mLdesc).
+ * Batched over B frame pairs: pair b uses rows [b*stride, b*stride + n[b]).                      */
+
+/* cv::BFMatcher(cv::NORM_HAMMING).match (k = 1) / .knnMatch(..., 2) (k = 2), as called at
+ * src/ORBmatcher.cc:1346-1347 and src/LSDmatcher.cpp:249-254.  idx/dist: [B][q_stride][k], ascending
+ * distance, lowest train index on ties; a missing neighbour is idx -1 / dist INT32_MAX. */
+int planar_hamming_knn(planar_ctx* ctx, const uint8_t* q, const int32_t* nq, int q_stride, const uint8_t* t, const int32_t* nt,
+                       int t_stride, int B, int k, int32_t* idx, int32_t* dist);
+int planar_hamming_knn_dev(planar_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, int q_stride, const uint8_t* d_t,
+                           const int32_t* d_nt, int t_stride, int B, int k, int32_t* d_idx, int32_t* d_dist);
+
+/* ORBmatcher::MatchORBPoints(Frame& Current, const Frame& Last) (src/ORBmatcher.cc:1332-1394).
+ *   last_has_mp[j]   LastFrame.mvpMapPoints[j] != NULL        last_outlier[j]  LastFrame.mvbOutlier[j]
+ *   cur_match[q]     (in/out) index j of the last-frame keypoint whose MapPoint the reference copies into
+ *                    CurrentFrame.mvpMapPoints[q]; entries the reference does not assign keep their value
+ *   npair[b]         the function's return value (number of good matches)                           */
+int planar_match_orb_points(planar_ctx* ctx, const uint8_t* cur, const int32_t* n_cur, int cur_stride, const uint8_t* last,
+                            const int32_t* n_last, int last_stride, const uint8_t* last_has_mp, const uint8_t* last_outlier, int B,
+                            int32_t* cur_match, int32_t* npair);
+int planar_match_orb_points_dev(planar_ctx* ctx, const uint8_t* d_cur, const int32_t* d_n_cur, int cur_stride, const uint8_t* d_last,
+                                const int32_t* d_n_last, int last_stride, const uint8_t* d_last_has_mp, const uint8_t* d_last_outlier,
+                                int B, int32_t* d_cur_match, int32_t* d_npair);
+
+/* LSDmatcher::SearchByDescriptor(KeyFrame*, Frame&, vector<MapLine*>&) (src/LSDmatcher.cpp:242-279).
+ *   kf_has_ml[i]     pKF->GetMapLineMatches()[i] != NULL
+ *   cur_match[t]     (out) keyframe line index whose MapLine lands in vpMapLineMatches[t], or -1
+ *   nmatches[b]      the function's return value                                                    */
+int planar_lsd_search_by_descriptor(planar_ctx* ctx, const uint8_t* kf, const int32_t* n_kf, int kf_stride, const uint8_t* cur,
+                                    const int32_t* n_cur, int cur_stride, const uint8_t* kf_has_ml, int B, int32_t* cur_match,
+                                    int32_t* nmatches);
+int planar_lsd_search_by_descriptor_dev(planar_ctx* ctx, const uint8_t* d_kf, const int32_t* d_n_kf, int kf_stride, const uint8_t* d_cur,
+                                        const int32_t* d_n_cur, int cur_stride, const uint8_t* d_kf_has_ml, int B, int32_t* d_cur_match,
+                                        int32_t* d_nmatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,3 +4,4 @@ Python here is thin plumbing (ctypes) over libplanar_hip.so; see include/planar_
 from ._lib import KP_DTYPE, Context, PlanarError, lib  # noqa: F401
 from .orb import ORBextractor  # noqa: F401
 from .optimizer import Optimizer  # noqa: F401
+from .matcher import LSDmatcher, ORBmatcher, hamming_knn  # noqa: F401

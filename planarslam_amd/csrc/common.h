@@ -51,10 +51,56 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
+// Host<->device staging for the synchronous host-pointer entry points: one device block, inputs
+// copied in on the stream, outputs copied back after the launch.
+struct Stager {
+    struct Item { const void* h_in; void* h_out; size_t bytes; size_t off; };
+    std::vector<Item> items;
+    size_t total = 0;
+    DevBuf buf;
+    // returns the index of the item; call dev<T>(idx) after upload()
+    int in(const void* h, size_t bytes) { return add(h, nullptr, bytes); }
+    int out(void* h, size_t bytes) { return add(nullptr, h, bytes); }
+    int inout(void* h, size_t bytes) { return add(h, h, bytes); }
+    int add(const void* hin, void* hout, size_t bytes) {
+        items.push_back({hin, hout, bytes, total});
+        total += align_up(bytes ? bytes : (size_t)1, (size_t)256);
+        return (int)items.size() - 1;
+    }
+    int upload(hipStream_t st) {
+        int rc = buf.alloc(total);
+        if (rc) return rc;
+        for (const Item& it : items)
+            if (it.h_in && it.bytes) {
+                hipError_t e = hipMemcpyAsync(buf.as<uint8_t>() + it.off, it.h_in, it.bytes, hipMemcpyHostToDevice, st);
+                if (e != hipSuccess) { set_error("staging upload failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
+            }
+        return PLANAR_OK;
+    }
+    template <typename T> T* dev(int idx) const { return (T*)(buf.as<uint8_t>() + items[idx].off); }
+    int download(hipStream_t st) {
+        for (const Item& it : items)
+            if (it.h_out && it.bytes) {
+                hipError_t e = hipMemcpyAsync(it.h_out, buf.as<uint8_t>() + it.off, it.bytes, hipMemcpyDeviceToHost, st);
+                if (e != hipSuccess) { set_error("staging download failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
+            }
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("stream sync failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
+        return PLANAR_OK;
+    }
+};
+
 }  // namespace planar
 
 struct planar_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;   // the stream work is enqueued on (own_stream unless overridden)
+    planar::DevBuf scratch;         // grow-only device scratch for entry points that need temporaries
+    int ensure_scratch(size_t bytes) {
+        if (scratch.bytes >= bytes) return PLANAR_OK;
+        // a previous kernel may still be reading the old block
+        if (scratch.p) (void)hipStreamSynchronize(stream);
+        return scratch.alloc(bytes);
+    }
 };

@@ -164,3 +164,31 @@ def pose_optimize(batch, params, mode=0, rounds=4, its=10):
         C.byref(prm), C.c_int(mode), C.c_int(rounds), C.c_int(its), p(res["Tcw"]), p(res["pt_outlier"]), p(res["ln_outlier"]),
         p(res["pl_outlier"]), p(res["n_inliers"]), p(res["lm_iters"]), p(res["final_chi2"]))
     return res
+
+
+# ---- matcher oracle ----
+def bf_knn(q, t, k):
+    L = lib()
+    q, t = np.ascontiguousarray(q, np.uint8), np.ascontiguousarray(t, np.uint8)
+    idx = np.zeros((len(q), k), np.int32); dist = np.zeros((len(q), k), np.int32)
+    L.orc_bf_knn(C.c_void_p(q.ctypes.data), len(q), C.c_void_p(t.ctypes.data), len(t), k, C.c_void_p(idx.ctypes.data), C.c_void_p(dist.ctypes.data))
+    return idx, dist
+
+
+def match_orb_points(cur, last, has_mp, outl, cur_match):
+    L = lib()
+    cur, last = np.ascontiguousarray(cur, np.uint8), np.ascontiguousarray(last, np.uint8)
+    has_mp, outl = np.ascontiguousarray(has_mp, np.uint8), np.ascontiguousarray(outl, np.uint8)
+    m = np.ascontiguousarray(cur_match, np.int32).copy()
+    n = L.orc_match_orb_points(C.c_void_p(cur.ctypes.data), len(cur), C.c_void_p(last.ctypes.data), len(last), C.c_void_p(has_mp.ctypes.data),
+                               C.c_void_p(outl.ctypes.data), C.c_void_p(m.ctypes.data))
+    return m, n
+
+
+def lsd_search_by_descriptor(kf, cur, has_ml):
+    L = lib()
+    kf, cur, has_ml = np.ascontiguousarray(kf, np.uint8), np.ascontiguousarray(cur, np.uint8), np.ascontiguousarray(has_ml, np.uint8)
+    m = np.zeros(len(cur), np.int32)
+    n = L.orc_lsd_search_by_descriptor(C.c_void_p(kf.ctypes.data), len(kf), C.c_void_p(cur.ctypes.data), len(cur), C.c_void_p(has_ml.ctypes.data),
+                                       C.c_void_p(m.ctypes.data))
+    return m, n
