@@ -55,6 +55,21 @@ template <typename T> static inline Point_<T>& operator*=(Point_<T>& a, float b)
 }
 template <typename T> static inline bool operator==(const Point_<T>& a, const Point_<T>& b) { return a.x == b.x && a.y == b.y; }
 
+template <typename T> struct Point3_ { T x, y, z; Point3_() : x(0), y(0), z(0) {} Point3_(T a, T b, T c) : x(a), y(b), z(c) {} };
+typedef Point3_<float> Point3f;
+typedef Point3_<double> Point3d;
+template <typename T, int N> struct Vec {
+    T val[N];
+    Vec() { for (int i = 0; i < N; i++) val[i] = T(0); }
+    Vec(T a, T b, T c) { static_assert(N == 3, "Vec3 ctor"); val[0] = a; val[1] = b; val[2] = c; }
+    explicit Vec(const T* p) { for (int i = 0; i < N; i++) val[i] = p[i]; }
+    T& operator[](int i) { return val[i]; }
+    const T& operator[](int i) const { return val[i]; }
+};
+typedef Vec<uchar, 3> Vec3b;
+typedef Vec<double, 2> Vec2d;
+struct Range { int start, end; Range(int s, int e) : start(s), end(e) {} };
+
 struct Size { int width, height; Size() : width(0), height(0) {} Size(int w, int h) : width(w), height(h) {}
               int area() const { return width * height; } };
 struct Rect { int x, y, width, height; Rect() : x(0), y(0), width(0), height(0) {}
@@ -76,6 +91,7 @@ static inline int cvElemSize(int type) {
 }
 
 struct MatZerosExpr { int rows, cols, type; };
+struct MatOnesExpr { int rows, cols, type; };
 
 struct MatStep {
     size_t v = 0;
@@ -119,6 +135,7 @@ public:
         m.off_x_ = off_x_ + r.x; m.off_y_ = off_y_ + r.y;
         return m;
     }
+    Mat operator()(const Range& rr, const Range& cr) const { return (*this)(Rect(cr.start, rr.start, cr.end - cr.start, rr.end - rr.start)); }
     Mat rowRange(int a, int b) const { return (*this)(Rect(0, a, cols, b - a)); }
     Mat colRange(int a, int b) const { return (*this)(Rect(a, 0, b - a, rows)); }
     Mat row(int y) const { return rowRange(y, y + 1); }
@@ -133,8 +150,8 @@ public:
     }
     template <typename T> T& at(int y, int x) { return *(T*)(data + (size_t)y * step.v + (size_t)x * sizeof(T)); }
     template <typename T> const T& at(int y, int x) const { return *(const T*)(data + (size_t)y * step.v + (size_t)x * sizeof(T)); }
-    template <typename T> T& at(int i) { return ((T*)data)[i]; }
-    template <typename T> const T& at(int i) const { return ((const T*)data)[i]; }
+    template <typename T> T& at(int i) { assert(isContinuous()); return ((T*)data)[i]; }
+    template <typename T> const T& at(int i) const { assert(isContinuous()); return ((const T*)data)[i]; }
     uchar* ptr(int y = 0) { return data + (size_t)y * step.v; }
     const uchar* ptr(int y = 0) const { return data + (size_t)y * step.v; }
     template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step.v); }
@@ -148,11 +165,24 @@ public:
         return *this;
     }
     Mat(const MatZerosExpr& e) { *this = e; }
-    Mat& setTo(const Scalar& s) {
-        assert(s.v[0] == 0);
-        for (int y = 0; y < rows; y++) std::memset(data + (size_t)y * step.v, 0, (size_t)cols * cvElemSize(type_));
+    // setTo for the element types the reference uses: CV_8U, CV_32S scalars and CV_8UC3 colours
+    Mat& setTo(int v) {
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < cols; x++) {
+                if (type_ == CV_32SC1) at<int>(y, x) = v;
+                else if (type_ == CV_8UC1) at<uchar>(y, x) = (uchar)v;
+                else { assert(type_ == CV_8UC3); uchar* p = data + (size_t)y * step.v + 3 * (size_t)x; p[0] = (uchar)v; p[1] = p[2] = 0; }
+            }
         return *this;
     }
+    Mat& setTo(const Vec3b& c) {
+        assert(type_ == CV_8UC3);
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < cols; x++) { uchar* p = data + (size_t)y * step.v + 3 * (size_t)x; p[0] = c[0]; p[1] = c[1]; p[2] = c[2]; }
+        return *this;
+    }
+    static MatOnesExpr ones(int r, int c, int t) { return MatOnesExpr{r, c, t}; }
+    Mat& operator=(const MatOnesExpr& e) { create(e.rows, e.cols, e.type); return setTo(1); }
     // geometry of the view inside its allocation (for copyMakeBorder without BORDER_ISOLATED)
     int parent_w_ = 0, parent_h_ = 0, off_x_ = 0, off_y_ = 0;
 private:
@@ -186,6 +216,9 @@ typedef const _OutputArray& InputOutputArray;
 enum { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT = 2, BORDER_WRAP = 3, BORDER_REFLECT_101 = 4,
        BORDER_REFLECT101 = 4, BORDER_DEFAULT = 4, BORDER_ISOLATED = 16 };
 enum { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2, INTER_AREA = 3 };
+
+static inline int64_t getTickCount() { return 0; }
+static inline double getTickFrequency() { return 1.0; }
 
 // Only referenced from dead code (ORBextractor::ComputeKeyPointsOld, never called).
 struct KeyPointsFilter {

@@ -1,2 +1,2 @@
-// oracle/shim: forwards to the minimal OpenCV stand-in (TEST INFRASTRUCTURE; see ../cvshim.hpp)
+// oracle/shim: forwards to the minimal OpenCV stand-in (TEST INFRASTRUCTURE)
 #include "../cvshim.hpp"

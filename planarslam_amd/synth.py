@@ -141,3 +141,48 @@ def pose_batch(B=4, n_points=1000, n_lines=75, n_planes=4, seed=7, outlier_frac=
         T0 = np.eye(4); T0[:3, :3] = _rodrigues(dw_) @ R; T0[:3, 3] = t + dt_
         out["Tcw"][b] = T0.astype(np.float32).reshape(16)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Depth images: a box room of planes rendered by ray-plane intersection, TUM units.
+def depth_image(seed: int = 4321, w: int = 640, h: int = 480, factor: float = 5000.0, noise: bool = True, holes: bool = True):
+    """u16 depth (TUM scale: value / 5000 = metres): floor, ceiling, two or three walls and a table-top box seen
+    from a random camera; depth-dependent noise; ~3 % of the pixels zeroed in blobs."""
+    rng = np.random.default_rng(seed)
+    P = TUM3
+    yy, xx = np.mgrid[0:h, 0:w]
+    rays = np.stack([(xx - P["cx"]) / P["fx"], (yy - P["cy"]) / P["fy"], np.ones_like(xx, dtype=np.float64)], -1)
+    R = _rodrigues(rng.normal(size=3) * 0.15)
+    rays = rays @ R.T
+    planes = [  # n.X + d = 0 in the camera frame before the random rotation
+        (np.array([0.0, -1.0, 0.0]), rng.uniform(0.9, 1.4)),      # floor (y down)
+        (np.array([0.0, 1.0, 0.0]), rng.uniform(1.0, 1.5)),       # ceiling
+        (np.array([0.0, 0.0, -1.0]), rng.uniform(2.5, 4.0)),      # back wall
+        (np.array([1.0, 0.0, 0.0]), rng.uniform(1.2, 2.5)),       # left wall
+        (np.array([-1.0, 0.0, 0.0]), rng.uniform(1.2, 2.5)),      # right wall
+    ]
+    z = np.full((h, w), np.inf)
+    for n, d in planes:
+        denom = rays @ n
+        t = np.where(np.abs(denom) > 1e-9, -d / denom, np.inf)
+        t = np.where(t > 0.05, t, np.inf)
+        z = np.minimum(z, t * rays[..., 2])
+    # a box (table) in front of the back wall: top face + front face
+    bx0, bx1 = sorted(rng.uniform(-0.8, 0.8, 2)); by = rng.uniform(0.2, 0.6); bz0 = rng.uniform(1.2, 2.0); bz1 = bz0 + rng.uniform(0.4, 0.9)
+    t = by / np.where(np.abs(rays[..., 1]) > 1e-9, rays[..., 1], np.inf)           # plane y = by (top)
+    X = rays * t[..., None]
+    ok = (t > 0) & (X[..., 0] > bx0) & (X[..., 0] < bx1) & (X[..., 2] > bz0) & (X[..., 2] < bz1)
+    z = np.where(ok & (X[..., 2] < z), X[..., 2], z)
+    t = bz0 / rays[..., 2]                                                         # plane z = bz0 (front)
+    X = rays * t[..., None]
+    ok = (X[..., 0] > bx0) & (X[..., 0] < bx1) & (X[..., 1] > by) & (X[..., 1] < planes[0][1])
+    z = np.where(ok & (X[..., 2] < z), X[..., 2], z)
+    z = np.where(np.isfinite(z), z, 0.0)
+    if noise:
+        z = z + rng.normal(size=z.shape) * 0.0012 * z * z
+    d = np.clip(np.rint(z * factor), 0, 65535).astype(np.uint16)
+    if holes:
+        for _ in range(12):
+            cx, cy, r = rng.integers(0, w), rng.integers(0, h), rng.integers(8, 40)
+            d[(xx - cx) ** 2 + (yy - cy) ** 2 < r * r] = 0
+    return d

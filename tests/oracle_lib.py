@@ -192,3 +192,45 @@ def lsd_search_by_descriptor(kf, cur, has_ml):
     n = L.orc_lsd_search_by_descriptor(C.c_void_p(kf.ctypes.data), len(kf), C.c_void_p(cur.ctypes.data), len(cur), C.c_void_p(has_ml.ctypes.data),
                                        C.c_void_p(m.ctypes.data))
     return m, n
+
+
+# ---- PEAC reference runner ----
+def ref_peac_path():
+    return os.path.join(ORACLE_DIR, "_ref", "ref_peac")
+
+
+def run_ref_peac(depth: np.ndarray, fx=535.4, fy=539.2, cx=320.1, cy=247.6, factor=1.0 / 5000.0):
+    """Run the REAL reference PlaneDetection (oracle/_ref/ref_peac). Returns (planes, labels[H,W])."""
+    depth = np.ascontiguousarray(depth, np.uint16)
+    H, W = depth.shape
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.raw"), os.path.join(d, "out.bin")
+        depth.tofile(fin)
+        subprocess.check_call([ref_peac_path(), fin, str(W), str(H), repr(fx), repr(fy), repr(cx), repr(cy), repr(float(np.float32(factor))), fout],
+                              stdout=subprocess.DEVNULL)
+        buf = open(fout, "rb").read()
+    n = int(np.frombuffer(buf, "<i4", 1, 0)[0]); off = 4
+    planes = []
+    for _ in range(n):
+        N = int(np.frombuffer(buf, "<i4", 1, off)[0]); off += 4
+        v = np.frombuffer(buf, "<f8", 7, off); off += 56
+        nv = int(np.frombuffer(buf, "<i4", 1, off)[0]); off += 4
+        planes.append(dict(N=N, normal=v[:3].copy(), center=v[3:6].copy(), mse=float(v[6]), nverts=nv))
+    labels = np.frombuffer(buf, "<i4", H * W, off).reshape(H, W).copy()
+    return planes, labels
+
+
+def peac_run(depth: np.ndarray, fx=535.4, fy=539.2, cx=320.1, cy=247.6, factor=1.0 / 5000.0, max_planes=64, want_blocks=False):
+    """CPU oracle of PlaneDetection::readDepthImage + runPlaneDetection.  Returns (planes [n,8], labels[H,W]) (+ blocks)."""
+    L = lib()
+    depth = np.ascontiguousarray(depth, np.uint16)
+    H, W = depth.shape
+    labels = np.zeros((H, W), np.int32)
+    planes = np.zeros((max_planes, 8), np.float64)
+    blocks = np.zeros(((H // 10) * (W // 10), 6), np.float64)
+    L.orc_peac_run.restype = C.c_int
+    n = L.orc_peac_run(C.c_void_p(depth.ctypes.data), W, H, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_float(factor),
+                       C.c_void_p(labels.ctypes.data), C.c_void_p(planes.ctypes.data), max_planes, C.c_void_p(blocks.ctypes.data))
+    if want_blocks:
+        return planes[:min(n, max_planes)].copy(), labels, blocks
+    return planes[:min(n, max_planes)].copy(), labels
