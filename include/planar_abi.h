@@ -192,6 +192,27 @@ int planar_lsd_search_by_descriptor_dev(planar_ctx* ctx, const uint8_t* d_kf, co
                                         const int32_t* d_n_cur, int cur_stride, const uint8_t* d_kf_has_ml, int B, int32_t* d_cur_match,
                                         int32_t* d_nmatches);
 
+/* ---- plane extractor (replaces PlaneDetection::readDepthImage + runPlaneDetection,
+ *      src/PlaneExtractor.cpp:26-65 / include/PlaneExtractor.h:36-56, i.e. ahc::PlaneFitter::run with
+ *      PlanarSLAM's defaults, include/peac/AHCPlaneFitter.hpp:154-158,211) ------------------------- */
+typedef struct planar_peac planar_peac;
+int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, planar_peac** out);
+void planar_peac_destroy(planar_peac* peac);
+int planar_peac_max_planes(void);   /* per-frame stride of `planes` (128) */
+/* depth  : B frames of 16-bit depth (cv::Mat CV_16U as passed to readDepthImage), pitch / frame stride in PIXELS
+ * fx..cy : K.at<float>(0,0), (1,1), (0,2), (1,2);   depth_factor : kScaleFactor (mDepthMapFactor, 1/5000)
+ * labels : [B][H*W] int32, plane id of every pixel in the order of plane_vertices_ (= extractedPlanes), -1 = none;
+ *          plane_vertices_[i] is the raster-ordered list of pixels with label i (src/Frame.cc:652-656)
+ * planes : [B][max_planes][8] doubles: N, normal[3], center[3], mse of extractedPlanes[i] (src/Frame.cc:663-669)
+ * n_planes : [B] plane_num_                                                                             */
+int planar_peac_segment(planar_peac* peac, const uint16_t* depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy,
+                        float cx, float cy, float depth_factor, int32_t* labels, double* planes, int32_t* n_planes);
+int planar_peac_segment_dev(planar_peac* peac, const uint16_t* d_depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy,
+                            float cx, float cy, float depth_factor, int32_t* d_labels, double* d_planes, int32_t* d_n_planes);
+/* Synchronises and returns PLANAR_ECAPACITY if any of the last B frames overflowed an internal capacity
+ * (more than max_planes planes, flood-fill queue, neighbour pool); the host-pointer entry point calls it itself. */
+int planar_peac_check(planar_peac* peac, int B);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,12 @@ _SIGS = {
     "planar_match_orb_points_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "planar_lsd_search_by_descriptor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "planar_lsd_search_by_descriptor_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "planar_peac_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "planar_peac_destroy": (None, [C.c_void_p]),
+    "planar_peac_max_planes": (C.c_int, []),
+    "planar_peac_segment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_peac_segment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_peac_check": (C.c_int, [C.c_void_p, C.c_int]),
     "planar_pose_opt": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
     "planar_pose_opt_dev": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
 }

@@ -1,0 +1,790 @@
+// planarslam_amd/csrc/peac.hip — batched PEAC / AHC plane segmentation on depth for MI355X (gfx950).
+//
+// Replaces PlaneDetection::readDepthImage + runPlaneDetection (reference src/PlaneExtractor.cpp:26-65), i.e.
+// ahc::PlaneFitter::run (reference include/peac/AHCPlaneFitter.hpp:211) with PlanarSLAM's defaults, for a batch of
+// B independent depth frames.  Plane labels, plane normals/centres/MSE are bit-exact against the CPU oracle, which
+// is pinned label-for-label against the real reference sources.
+//
+//   K1 peac_blocks   one THREAD per 10x10 block: depth -> XYZ in FP64, validity / depth-discontinuity tests,
+//                    the nine moment sums accumulated in the reference's raster order (bit-exact FP64 sums),
+//                    PCA by the iterative 3x3 symmetric eigen-solver (Eigen's algorithm, restated)        (a13-a15)
+//   K2 peac_segment  one WAVE per frame, the order-dependent part:
+//                      initGraph edges -> ahCluster (libstdc++-exact binary min-MSE heap in LDS, the candidate
+//                      merges of one node evaluated one-per-lane) -> block erosion + seed queue (prefix sums) ->
+//                      floodFill (16 queue entries x 4 neighbours per wave step, same-pixel conflicts replayed in
+//                      order) -> final ahCluster over the surviving planes -> relabel                     (a16-a17)
+// Frame-level batch parallelism supplies the occupancy; inside a frame only the
+// order-independent work is spread over the 64 lanes.
+#include "common.h"
+
+namespace planar {
+namespace peac {
+
+constexpr int WIN = 10;             // windowWidth == windowHeight (AHCPlaneFitter.hpp:156)
+constexpr int MIN_SUPPORT = 3000;   // minSupport (:155)
+constexpr int MAX_PLANES = 128;
+constexpr int MAX_STEP = 100000;
+
+// ---- thresholds (AHCParamSet.hpp) ----
+__device__ __forceinline__ double T_mse_init(double z) { const double t = 1.6e-6 * z * z + 5; return t * t; }
+__device__ __forceinline__ double T_mse_merge(double z) { const double t = 1.6e-6 * z * z + 8; return t * t; }
+__device__ __forceinline__ double T_dz(double z) { return 0.04 * fabs(z) + 0.02; }
+
+struct Consts {   // values the reference computes with libm at run time; passed in from the host so both sides agree
+    double ang_near, ang_factor, cos_init_near, cos_merge, cos_refine;
+};
+__device__ __forceinline__ double T_ang_init(const Consts& c, double z) {   // AHCParamSet.hpp:112-122
+    double cz = fmax(z, 500.0);
+    cz = fmin(cz, 4000.0);
+    if (cz == 500.0) return c.cos_init_near;   // every depth in metres lands here (the thresholds are in mm)
+    return cos(c.ang_factor * cz + c.ang_near - c.ang_factor * 500.0);
+}
+
+// ---- Eigen 3.3 SelfAdjointEigenSolver<Matrix3d>::compute, restated (see oracle/eigprim.cpp for the citations) ----
+__device__ __forceinline__ double eig_hypot(double x, double y) {
+    const double ax = fabs(x), ay = fabs(y);
+    double p, qp;
+    if (ax > ay) { p = ax; qp = ay / p; } else { p = ay; qp = ax / p; }
+    if (p == 0) return 0;
+    return p * sqrt(1.0 + qp * qp);
+}
+__device__ __forceinline__ void make_givens(double p, double q, double& c, double& s) {
+    if (q == 0) { c = p < 0 ? -1.0 : 1.0; s = 0; }
+    else if (p == 0) { c = 0; s = q < 0 ? 1.0 : -1.0; }
+    else if (fabs(p) > fabs(q)) { const double t = q / p; double u = sqrt(1.0 + t * t); if (p < 0) u = -u; c = 1.0 / u; s = -t * c; }
+    else { const double t = p / q; double u = sqrt(1.0 + t * t); if (q < 0) u = -u; s = -1.0 / u; c = -t * s; }
+}
+// lower triangle a00,a10,a11,a20,a21,a22 -> smallest eigenvalue ev0 (+ev1, ev2) and its eigenvector v0
+__device__ void eig33(double a00, double a10, double a11, double a20, double a21, double a22, double ev[3], double v0[3]) {
+    double scale = fmax(fmax(fmax(fabs(a00), fabs(a10)), fmax(fabs(a11), fabs(a20))), fmax(fabs(a21), fabs(a22)));
+    if (scale == 0) scale = 1;
+    a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
+    double d0, d1, d2, s0, s1;
+    double q00 = 1, q01 = 0, q02 = 0, q10 = 0, q11 = 1, q12 = 0, q20 = 0, q21 = 0, q22 = 1;
+    d0 = a00;
+    const double v1norm2 = a20 * a20;
+    if (v1norm2 <= 2.2250738585072014e-308) { d1 = a11; d2 = a22; s0 = a10; s1 = a21; }
+    else {
+        const double beta = sqrt(a10 * a10 + v1norm2);
+        const double invBeta = 1.0 / beta;
+        const double m01 = a10 * invBeta, m02 = a20 * invBeta;
+        const double q = 2.0 * m01 * a21 + m02 * (a22 - a11);
+        d1 = a11 + m02 * q; d2 = a22 - m02 * q; s0 = beta; s1 = a21 - m01 * q;
+        q11 = m01; q12 = m02; q21 = m02; q22 = -m01;
+    }
+    double diag[3] = {d0, d1, d2}, sub[2] = {s0, s1};
+    double Q[3][3] = {{q00, q01, q02}, {q10, q11, q12}, {q20, q21, q22}};
+    int end = 2, start = 0, iter = 0;
+    const double considerAsZero = 2.2250738585072014e-308, precision = 2.0 * 2.220446049250313e-16;
+    while (end > 0) {
+        for (int i = start; i < end; ++i)
+            if (fabs(sub[i]) <= (fabs(diag[i]) + fabs(diag[i + 1])) * precision || fabs(sub[i]) <= considerAsZero) sub[i] = 0;
+        while (end > 0 && sub[end - 1] == 0) end--;
+        if (end <= 0) break;
+        iter++;
+        if (iter > 90) break;
+        start = end - 1;
+        while (start > 0 && sub[start - 1] != 0) start--;
+        const double td = (diag[end - 1] - diag[end]) * 0.5, e = sub[end - 1];
+        double mu = diag[end];
+        if (td == 0) mu -= fabs(e);
+        else {
+            const double e2 = e * e, h = eig_hypot(td, e);
+            if (e2 == 0) mu -= (e / (td + (td > 0 ? 1.0 : -1.0))) * (e / h);
+            else mu -= e2 / (td + (td > 0 ? h : -h));
+        }
+        double x = diag[start] - mu, z = sub[start];
+        for (int k = start; k < end; ++k) {
+            double c, s;
+            make_givens(x, z, c, s);
+            const double sdk = s * diag[k] + c * sub[k];
+            const double dkp1 = s * sub[k] + c * diag[k + 1];
+            diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+            diag[k + 1] = s * sdk + c * dkp1;
+            sub[k] = c * sdk - s * dkp1;
+            if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+            x = sub[k];
+            if (k < end - 1) { z = -s * sub[k + 1]; sub[k + 1] = c * sub[k + 1]; }
+            for (int r = 0; r < 3; r++) { const double xi = Q[r][k], yi = Q[r][k + 1]; Q[r][k] = c * xi - s * yi; Q[r][k + 1] = s * xi + c * yi; }
+        }
+    }
+    if (iter <= 90) {
+        for (int i = 0; i < 2; ++i) {
+            int k = 0;
+            for (int j = 1; j < 3 - i; j++) if (diag[i + j] < diag[i + k]) k = j;
+            if (k > 0) {
+                const double t = diag[i]; diag[i] = diag[k + i]; diag[k + i] = t;
+                for (int r = 0; r < 3; r++) { const double u = Q[r][i]; Q[r][i] = Q[r][k + i]; Q[r][k + i] = u; }
+            }
+        }
+    }
+    for (int i = 0; i < 3; i++) ev[i] = diag[i] * scale;
+    v0[0] = Q[0][0]; v0[1] = Q[1][0]; v0[2] = Q[2][0];
+}
+
+// Stats: sx sy sz sxx syy szz sxy syz sxz (9 doubles) + N.  PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:125-156)
+struct Geo { double center[3], normal[3], mse; };
+__device__ void stats_compute(const double s[9], int N, Geo& g) {
+    const double sc = 1.0 / N;
+    g.center[0] = s[0] * sc; g.center[1] = s[1] * sc; g.center[2] = s[2] * sc;
+    const double k00 = s[3] - s[0] * s[0] * sc, k01 = s[6] - s[0] * s[1] * sc, k02 = s[8] - s[0] * s[2] * sc;
+    const double k11 = s[4] - s[1] * s[1] * sc, k12 = s[7] - s[1] * s[2] * sc, k22 = s[5] - s[2] * s[2] * sc;
+    double ev[3], v[3];
+    eig33(k00, k01, k11, k02, k12, k22, ev, v);   // lower triangle of the symmetric K
+    if (v[0] * g.center[0] + v[1] * g.center[1] + v[2] * g.center[2] <= 0) { g.normal[0] = v[0]; g.normal[1] = v[1]; g.normal[2] = v[2]; }
+    else { g.normal[0] = -v[0]; g.normal[1] = -v[1]; g.normal[2] = -v[2]; }
+    g.mse = ev[0] * sc;
+}
+
+struct Layout {   // per-frame workspace (element offsets), identical for every frame
+    int W, H, Nw, Nh, NB, NB2;   // NB2 = 2*NB: initial blocks + merged nodes
+    int pool_cap, q_cap;
+    size_t off_stats, off_geo, off_N, off_rid, off_flags, off_nb_off, off_nb_cnt, off_nb_cap, off_pool, off_parent, off_size,
+        off_member, off_dist, off_blkmap, off_queue, off_seedcnt, frame_bytes;
+};
+
+struct Intr { float fx, fy, cx, cy, factor; };
+
+// ------------------------------------------------------------------------------------------------------------
+// K1: one thread per block.
+__global__ __launch_bounds__(64) void peac_blocks(Layout L, Intr K, const uint16_t* __restrict__ depth, int pitch_px, int64_t frame_stride_px,
+                                                  uint8_t* __restrict__ ws) {
+    const int blk = blockIdx.x * blockDim.x + threadIdx.x, frame = blockIdx.y;
+    if (blk >= L.NB) return;
+    uint8_t* F = ws + (size_t)frame * L.frame_bytes;
+    double* stats = (double*)(F + L.off_stats) + (size_t)blk * 9;
+    double* geo = (double*)(F + L.off_geo) + (size_t)blk * 7;
+    int* Narr = (int*)(F + L.off_N);
+    int* rid = (int*)(F + L.off_rid);
+    uint8_t* flags = F + L.off_flags;   // bit0: in graph (pushed to minQ), bit1: nouse
+    const uint16_t* D = depth + (size_t)frame * frame_stride_px;
+    const int bi = blk / L.Nw, bj = blk - bi * L.Nw;
+    const int r0 = bi * WIN, c0 = bj * WIN;
+    const double factor = (double)K.factor;
+    bool valid = true;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = r0; i < r0 + WIN; i++) {
+        for (int j = c0; j < c0 + WIN; j++) {
+            const double z = (double)D[(size_t)i * pitch_px + j] * factor;      // src/PlaneExtractor.cpp:45
+            if (z == 0) { valid = false; continue; }                              // ImagePointCloud::get (PlaneExtractor.h:29)
+            if (j + 1 < L.W) { const double zn = (double)D[(size_t)i * pitch_px + j + 1] * factor; if (zn != 0 && fabs(z - zn) > T_dz(z)) valid = false; }
+            if (i + 1 < L.H) { const double zn = (double)D[(size_t)(i + 1) * pitch_px + j] * factor; if (zn != 0 && fabs(z - zn) > T_dz(z)) valid = false; }
+            const double x = ((double)j - (double)K.cx) * z / (double)K.fx;     // :51-52
+            const double y = ((double)i - (double)K.cy) * z / (double)K.fy;
+            s[0] += x; s[1] += y; s[2] += z; s[3] += x * x; s[4] += y * y; s[5] += z * z; s[6] += x * y; s[7] += y * z; s[8] += x * z;
+        }
+    }
+    Geo g;
+    for (int k = 0; k < 3; k++) { g.center[k] = 0; g.normal[k] = 0; }
+    g.mse = 0;
+    bool in_graph = false;
+    if (valid) {
+        stats_compute(s, WIN * WIN, g);
+        in_graph = g.mse < T_mse_init(g.center[2]);                              // AHCPlaneFitter.hpp:807
+    } else {
+        for (int k = 0; k < 9; k++) s[k] = 0;
+    }
+    for (int k = 0; k < 9; k++) stats[k] = s[k];
+    for (int k = 0; k < 3; k++) { geo[k] = g.center[k]; geo[3 + k] = g.normal[k]; }
+    geo[6] = g.mse;
+    Narr[blk] = valid ? WIN * WIN : 0;
+    rid[blk] = blk;
+    flags[blk] = (in_graph ? 1 : 0) | (valid ? 0 : 2);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2: one wave per frame.
+struct Seg {   // views into the frame workspace
+    double* stats; double* geo; int* N; int* rid; uint8_t* flags; int* nb_off; int* nb_cnt; int* nb_cap; int* pool;
+    int* parent; int* size;
+};
+__device__ __forceinline__ double seg_mse(const Seg& S, int id) { return S.geo[(size_t)id * 7 + 6]; }
+__device__ __forceinline__ double normal_sim(const Seg& S, int a, int b) {
+    const double* ga = S.geo + (size_t)a * 7 + 3; const double* gb = S.geo + (size_t)b * 7 + 3;
+    return fabs(ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]);
+}
+__device__ int ds_find(int* parent, int x) {   // DisjointSet::Find with path compression (recursion unrolled)
+    int r = x;
+    while (parent[r] != r) r = parent[r];
+    while (parent[x] != r) { const int nx = parent[x]; parent[x] = r; x = nx; }
+    return r;
+}
+
+// sorted-list helpers executed by lane 0 only
+__device__ void list_erase(int* lst, int& cnt, int v) {
+    int i = 0;
+    while (i < cnt && lst[i] < v) i++;
+    if (i < cnt && lst[i] == v) { for (; i + 1 < cnt; i++) lst[i] = lst[i + 1]; cnt--; }
+}
+__device__ void list_insert(int* lst, int& cnt, int v) {
+    int i = 0;
+    while (i < cnt && lst[i] < v) i++;
+    if (i < cnt && lst[i] == v) return;
+    for (int j = cnt; j > i; j--) lst[j] = lst[j - 1];
+    lst[i] = v; cnt++;
+}
+
+__global__ __launch_bounds__(64) void peac_segment(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
+                                                   int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
+                                                   int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
+                                                   int32_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    uint8_t* F = ws + (size_t)frame * L.frame_bytes;
+    Seg S;
+    S.stats = (double*)(F + L.off_stats); S.geo = (double*)(F + L.off_geo); S.N = (int*)(F + L.off_N); S.rid = (int*)(F + L.off_rid);
+    S.flags = F + L.off_flags; S.nb_off = (int*)(F + L.off_nb_off); S.nb_cnt = (int*)(F + L.off_nb_cnt); S.nb_cap = (int*)(F + L.off_nb_cap);
+    S.pool = (int*)(F + L.off_pool); S.parent = (int*)(F + L.off_parent); S.size = (int*)(F + L.off_size);
+    int* member = (int*)(F + L.off_member);
+    float* distMap = (float*)(F + L.off_dist);
+    int* blkMap = (int*)(F + L.off_blkmap);
+    int2* queue = (int2*)(F + L.off_queue);
+    int* seedcnt = (int*)(F + L.off_seedcnt);
+    const uint16_t* D = depth + (size_t)frame * frame_stride_px;
+    int32_t* lab = labels + (size_t)frame * label_stride;
+    const int NB = L.NB, Nw = L.Nw, Nh = L.Nh, W = L.W, H = L.H;
+
+    // LDS: mse of every node (heap comparisons) + the heap itself
+    double* s_mse = (double*)smem;                 // [NB2]
+    int* heap = (int*)(s_mse + L.NB2);             // [NB]
+    __shared__ int s_ext[MAX_PLANES];              // extractedPlanes (node ids)
+    __shared__ int s_old[MAX_PLANES];
+    __shared__ int s_plidmap[MAX_PLANES];
+    __shared__ uint8_t s_valid[MAX_PLANES];
+    __shared__ int s_tmp[256];
+    int err = 0;
+
+    auto sync = [&]() { __threadfence_block(); __syncthreads(); };
+
+    // ---- init: disjoint set, neighbour lists (capacity 4 per block), mse copy ----
+    for (int b = lane; b < NB; b += 64) {
+        S.parent[b] = b; S.size[b] = 1;
+        S.nb_off[b] = 4 * b; S.nb_cnt[b] = 0; S.nb_cap[b] = 4;
+        s_mse[b] = seg_mse(S, b);
+    }
+    int pool_top = 4 * NB;
+    sync();
+
+    // ---- initGraph edges (AHCPlaneFitter.hpp:896-954): rows are independent in the horizontal pass and columns in
+    //      the vertical pass, each row/column is a sequential scan with the reference's --j/++j skip logic.
+    //      connect() is symmetric set insertion; edges of one pass touch disjoint (row|column) node sets, so
+    //      lanes own whole rows/columns and insert with lane-0-style list code.
+    auto connect = [&](int a, int b) {
+        int ca = S.nb_cnt[a]; list_insert(S.pool + S.nb_off[a], ca, b); S.nb_cnt[a] = ca;
+        int cb = S.nb_cnt[b]; list_insert(S.pool + S.nb_off[b], cb, a); S.nb_cnt[b] = cb;
+    };
+    auto inG = [&](int idx) { return (S.flags[idx] & 1) != 0; };
+    for (int i = lane; i < Nh; i += 64) {
+        for (int j = 1; j < Nw; j += 2) {
+            const int c = i * Nw + j;
+            if (!inG(c - 1)) { --j; continue; }
+            if (!inG(c)) continue;
+            if (j < Nw - 1 && !inG(c + 1)) { ++j; continue; }
+            const double th = T_ang_init(C, S.geo[(size_t)c * 7 + 2]);
+            if ((j < Nw - 1 && normal_sim(S, c - 1, c + 1) >= th) || (j == Nw - 1 && normal_sim(S, c, c - 1) >= th)) {
+                connect(c, c - 1);
+                if (j < Nw - 1) connect(c, c + 1);
+            } else --j;
+        }
+    }
+    sync();
+    for (int j = lane; j < Nw; j += 64) {
+        for (int i = 1; i < Nh; i += 2) {
+            const int c = i * Nw + j;
+            if (!inG(c - Nw)) { --i; continue; }
+            if (!inG(c)) continue;
+            if (i < Nh - 1 && !inG(c + Nw)) { ++i; continue; }
+            const double th = T_ang_init(C, S.geo[(size_t)c * 7 + 2]);
+            if ((i < Nh - 1 && normal_sim(S, c - Nw, c + Nw) >= th) || (i == Nh - 1 && normal_sim(S, c, c - Nw) >= th)) {
+                connect(c, c - Nw);
+                if (i < Nh - 1) connect(c, c + Nw);
+            } else --i;
+        }
+    }
+    sync();
+
+    // ---- libstdc++ binary heap with comp(a,b) = mse[b] < mse[a]  (std::priority_queue, PlaneSegMinMSECmp) ----
+    int heap_n = 0;
+    auto hcmp = [&](int a, int b) { return s_mse[b] < s_mse[a]; };
+    auto heap_push = [&](int v) {      // all lanes execute identically on LDS
+        int hole = heap_n, parent = (hole - 1) / 2;
+        heap_n++;
+        while (hole > 0 && hcmp(heap[parent], v)) { if (lane == 0) heap[hole] = heap[parent]; __threadfence_block(); hole = parent; parent = (hole - 1) / 2; }
+        if (lane == 0) heap[hole] = v;
+        __threadfence_block();
+    };
+    auto heap_pop = [&]() -> int {
+        const int top = heap[0];
+        const int value = heap[heap_n - 1];
+        heap_n--;
+        const int len = heap_n;
+        if (len == 0) return top;
+        int hole = 0, second = 0;
+        while (second < (len - 1) / 2) {
+            second = 2 * (second + 1);
+            if (hcmp(heap[second], heap[second - 1])) second--;
+            if (lane == 0) heap[hole] = heap[second];
+            __threadfence_block();
+            hole = second;
+        }
+        if ((len & 1) == 0 && second == (len - 2) / 2) { second = 2 * (second + 1); if (lane == 0) heap[hole] = heap[second - 1]; __threadfence_block(); hole = second - 1; }
+        int parent = (hole - 1) / 2;
+        while (hole > 0 && hcmp(heap[parent], value)) { if (lane == 0) heap[hole] = heap[parent]; __threadfence_block(); hole = parent; parent = (hole - 1) / 2; }
+        if (lane == 0) heap[hole] = value;
+        __threadfence_block();
+        return top;
+    };
+    for (int b = 0; b < NB; b++) if (S.flags[b] & 1) heap_push(b);   // minQ.push in block order (:809)
+    int n_nodes = NB;        // next node id
+    int n_ext = 0;
+
+    auto disconnect_all = [&](int a) {     // PlaneSeg::disconnectAllNbs
+        const int cnt = S.nb_cnt[a];
+        const int* lst = S.pool + S.nb_off[a];
+        for (int k = lane; k < cnt; k += 64) {     // every neighbour owns its own list: lanes are independent
+            const int nb = lst[k];
+            int c = S.nb_cnt[nb];
+            list_erase(S.pool + S.nb_off[nb], c, a);
+            S.nb_cnt[nb] = c;
+        }
+        sync();
+        if (lane == 0) S.nb_cnt[a] = 0;
+        sync();
+    };
+
+    // ---- ahCluster (:983-1189) ----
+    auto ah_cluster = [&]() {
+        int step = 0;
+        while (heap_n > 0 && step <= MAX_STEP) {
+            const int p = heap_pop();
+            if (S.flags[p] & 2) continue;                       // nouse
+            const int cnt = S.nb_cnt[p];
+            const int* lst = S.pool + S.nb_off[p];
+            // candidate merges: lane k evaluates neighbour k (+64, ...), then an in-order fold reproduces the
+            // reference's "first minimum wins (with the N<mse quirk)" rule
+            double best_mse = 0; int best_nb = -1, best_N = 0; bool have = false;
+            double best_stats[9]; Geo best_geo;
+            for (int k0 = 0; k0 < cnt; k0 += 64) {
+                const int k = k0 + lane;
+                bool ok = false;
+                double ms[9]; Geo mg; int mN = 0, nb = -1;
+                if (k < cnt) {
+                    nb = lst[k];
+                    if (!(normal_sim(S, p, nb) < C.cos_merge)) {
+                        const double* sa = S.stats + (size_t)p * 9; const double* sb = S.stats + (size_t)nb * 9;
+                        for (int t = 0; t < 9; t++) ms[t] = sa[t] + sb[t];
+                        mN = S.N[p] + S.N[nb];
+                        stats_compute(ms, mN, mg);
+                        ok = true;
+                    }
+                }
+                // in-order fold across lanes (k ascending == ascending node id == std::set iteration order)
+                unsigned long long m = __ballot(ok);
+                while (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const double c_mse = __shfl(mg.mse, src);
+                    if (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse)) {   // quirk :1045
+                        have = true; best_mse = c_mse; best_nb = __shfl(nb, src); best_N = __shfl(mN, src);
+                        for (int t = 0; t < 9; t++) best_stats[t] = __shfl(ms[t], src);
+                        for (int t = 0; t < 3; t++) { best_geo.center[t] = __shfl(mg.center[t], src); best_geo.normal[t] = __shfl(mg.normal[t], src); }
+                        best_geo.mse = c_mse;
+                    }
+                }
+            }
+            if (have && best_mse < T_mse_merge(best_geo.center[2])) {
+                const int m = n_nodes++;
+                const int nb = best_nb;
+                if (m >= L.NB2) { err = 1; break; }
+                // new node
+                if (lane == 0) {
+                    for (int t = 0; t < 9; t++) S.stats[(size_t)m * 9 + t] = best_stats[t];
+                    for (int t = 0; t < 3; t++) { S.geo[(size_t)m * 7 + t] = best_geo.center[t]; S.geo[(size_t)m * 7 + 3 + t] = best_geo.normal[t]; }
+                    S.geo[(size_t)m * 7 + 6] = best_geo.mse;
+                    S.N[m] = best_N;
+                    S.rid[m] = S.N[p] >= S.N[nb] ? S.rid[p] : S.rid[nb];
+                    S.flags[m] = 0;
+                    s_mse[m] = best_geo.mse;
+                    // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:64-84)
+                    const int xr = ds_find(S.parent, S.rid[p]), yr = ds_find(S.parent, S.rid[nb]);
+                    if (xr != yr) {
+                        if (S.size[xr] < S.size[yr]) { S.parent[xr] = yr; S.size[yr] += S.size[xr]; }
+                        else { S.parent[yr] = xr; S.size[xr] += S.size[yr]; }
+                    }
+                }
+                sync();
+                heap_push(m);
+                // mergeNbsFrom (AHCPlaneSeg.hpp:379-404): union of the two sorted lists minus {p, nb}
+                const int ca = S.nb_cnt[p], cb = S.nb_cnt[nb];
+                if (pool_top + ca + cb > L.pool_cap) {
+                    // compact the pool: live lists only (lane 0; rare)
+                    if (lane == 0) {
+                        int top = 4 * NB;
+                        for (int id = NB; id < n_nodes - 1; id++) {
+                            if (S.flags[id] & 2) { S.nb_cnt[id] = 0; continue; }
+                            const int c = S.nb_cnt[id]; const int o = S.nb_off[id];
+                            for (int t = 0; t < c; t++) S.pool[top + t] = S.pool[o + t];
+                            S.nb_off[id] = top; S.nb_cap[id] = c; top += c;
+                        }
+                        s_tmp[0] = top;
+                    }
+                    sync();
+                    pool_top = s_tmp[0];
+                    sync();
+                    if (pool_top + ca + cb > L.pool_cap) { err = 2; break; }
+                }
+                const int off = pool_top;
+                pool_top += ca + cb;
+                if (lane == 0) {
+                    const int* A = S.pool + S.nb_off[p]; const int* Bl = S.pool + S.nb_off[nb];
+                    int i = 0, j = 0, n = 0;
+                    while (i < ca || j < cb) {
+                        int v;
+                        if (j >= cb || (i < ca && A[i] < Bl[j])) v = A[i++];
+                        else if (i >= ca || Bl[j] < A[i]) v = Bl[j++];
+                        else { v = A[i]; i++; j++; }
+                        if (v != p && v != nb) S.pool[off + n++] = v;
+                    }
+                    S.nb_off[m] = off; S.nb_cnt[m] = n; S.nb_cap[m] = ca + cb;
+                }
+                sync();
+                disconnect_all(p);
+                disconnect_all(nb);
+                {   // nb->nbs.insert(this): m is the largest id so far -> append
+                    const int n = S.nb_cnt[m];
+                    const int* lstm = S.pool + off;
+                    for (int k = lane; k < n; k += 64) {
+                        const int q = lstm[k];
+                        const int c = S.nb_cnt[q];
+                        if (c >= S.nb_cap[q]) err = 3;
+                        else { S.pool[S.nb_off[q] + c] = m; S.nb_cnt[q] = c + 1; }
+                    }
+                }
+                if (lane == 0) { S.flags[p] |= 2; S.flags[nb] |= 2; }
+                sync();
+                if (__any(err)) { err = 3; break; }
+            } else {
+                if (S.N[p] >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
+                disconnect_all(p);
+            }
+            ++step;
+        }
+        while (heap_n > 0) {
+            const int p = heap_pop();
+            if (S.N[p] >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
+            disconnect_all(p);
+        }
+        sync();
+        // std::sort(extractedPlanes, b->N < a->N): insertion sort (stable), lane 0
+        if (lane == 0) {
+            for (int i = 1; i < n_ext; i++) {
+                const int v = s_ext[i];
+                int j = i;
+                while (j > 0 && S.N[s_ext[j - 1]] < S.N[v]) { s_ext[j] = s_ext[j - 1]; j--; }
+                s_ext[j] = v;
+            }
+        }
+        sync();
+    };
+    ah_cluster();
+
+    // ---- refineDetails (:299-379) ----
+    // findBlockMembership (:485-587): blkMap, membership image, seed queue.
+    for (int i = lane; i < W * H; i += 64) { member[i] = -1; distMap[i] = 3.4028234663852886e38f; }
+    for (int i = lane; i < MAX_PLANES; i += 64) { s_valid[i] = 0; s_plidmap[i] = -1; }
+    sync();
+    // pass 1 (parallel over blocks): blkMap
+    for (int b = lane; b < NB; b += 64) {
+        const int i = b / Nw, j = b - i * Nw;
+        const int setid = ds_find(S.parent, b);   // path compression races are benign: every write stores a valid ancestor
+        int plid = -1;
+        if (S.size[setid] * (WIN * WIN) >= MIN_SUPPORT) {
+            bool same = true;
+            if (j > 0 && ds_find(S.parent, b - 1) != setid) same = false;
+            if (j < Nw - 1 && ds_find(S.parent, b + 1) != setid) same = false;
+            if (i > 0 && ds_find(S.parent, b - Nw) != setid) same = false;
+            if (i < Nh - 1 && ds_find(S.parent, b + Nw) != setid) same = false;
+            if (same) {
+                plid = 0;                                    // std::map::operator[] default when absent
+                for (int q = 0; q < n_ext; q++) if (S.rid[s_ext[q]] == setid) { plid = q; break; }
+                s_valid[plid] = 1;
+            }
+        }
+        blkMap[b] = plid;
+    }
+    sync();
+    // pass 2: per-block seed counts (depends only on blkMap of self / up / left), exclusive scan, fill
+    for (int b = lane; b < NB; b += 64) {
+        const int i = b / Nw, j = b - i * Nw, me = blkMap[b];
+        int c = 0;
+        if (me < 0) {
+            if (i > 0 && blkMap[b - Nw] >= 0) c += WIN - 1;
+            if (j > 0 && blkMap[b - 1] >= 0) c += WIN - 1;
+        } else {
+            if (i > 0 && blkMap[b - Nw] != me) c += WIN - 1;
+            if (j > 0 && blkMap[b - 1] != me) c += WIN - 1;
+        }
+        seedcnt[b] = c;
+    }
+    sync();
+    int q_tail = 0;
+    for (int b0 = 0; b0 < NB; b0 += 64) {      // wave scan in block order
+        const int b = b0 + lane;
+        const int c = b < NB ? seedcnt[b] : 0;
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int start = q_tail + incl - c;
+        if (b < NB) seedcnt[b] = start;
+        q_tail += __shfl(incl, 63);
+    }
+    sync();
+    if (q_tail > L.q_cap) err = 5;
+    for (int b = lane; b < NB && !err; b += 64) {
+        const int i = b / Nw, j = b - i * Nw, me = blkMap[b];
+        int o = seedcnt[b];
+        if (me >= 0)   // membershipImg(block) = plid
+            for (int y = i * WIN; y < (i + 1) * WIN; y++) for (int x = j * WIN; x < (j + 1) * WIN; x++) member[y * W + x] = me;
+        if (me < 0) {
+            if (i > 0 && blkMap[b - Nw] >= 0) { const int up = blkMap[b - Nw]; const int sp = (i * WIN - 1) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = make_int2(sp + k, up); }
+            if (j > 0 && blkMap[b - 1] >= 0) { const int lp = blkMap[b - 1]; const int sp = (i * WIN) * W + j * WIN - 1; for (int k = 0; k < WIN - 1; ++k) queue[o++] = make_int2(sp + k * W, lp); }
+        } else {
+            if (i > 0 && blkMap[b - Nw] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 0; k < WIN - 1; ++k) queue[o++] = make_int2(sp + k, me); }
+            if (j > 0 && blkMap[b - 1] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = make_int2(sp + k * W, me); }
+        }
+    }
+    sync();
+
+    // floodFill (:428-476).  Per wave step: 16 queue entries x 4 neighbours, one (entry, neighbour) pair per lane.
+    // Pairs that hit the same pixel are replayed in lane (== reference) order; plane-plane connect() is a
+    // commutative set insertion and goes to an LDS bit matrix; queue pushes are appended in lane order.
+    __shared__ unsigned s_adj[MAX_PLANES][MAX_PLANES / 32];
+    for (int t = lane; t < MAX_PLANES * (MAX_PLANES / 32); t += 64) (&s_adj[0][0])[t] = 0;
+    sync();
+    {
+        const double factor = (double)K.factor;
+        int* s_slot = s_tmp;                 // 256-entry direct-mapped table for same-pixel detection
+        int q_head = 0;
+        while (q_head < q_tail && !err) {
+            const int nent = min(16, q_tail - q_head);
+            const int e = lane >> 2, dir = lane & 3;
+            bool act = e < nent;
+            int cIdx = -1, plid = -1, cx = 0, cy = 0;
+            if (act) {
+                const int2 ent = queue[q_head + e];
+                plid = ent.y;
+                const int sy = ent.x / W, sx = ent.x - sy * W;
+                // getValid4Neighbor order (:398-410): left, right, up, down, invalid ones skipped
+                if (dir == 0) { act = sx > 0; cIdx = ent.x - 1; }
+                else if (dir == 1) { act = sx < W - 1; cIdx = ent.x + 1; }
+                else if (dir == 2) { act = sy > 0; cIdx = ent.x - W; }
+                else { act = sy < H - 1; cIdx = ent.x + W; }
+                if (act) { cy = cIdx / W; cx = cIdx - cy * W; }
+            }
+            bool geo_ok = false; float cdist = -1.f;
+            if (act) {
+                const int by = cy / WIN, bx = cx / WIN;
+                const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
+                if (blkid >= 0 && blkMap[blkid] >= 0) act = false;          // only "black" blocks are refined
+            }
+            if (act) {
+                const double z = (double)D[(size_t)cy * pitch_px + cx] * factor;
+                if (z != 0) {
+                    const double x = ((double)cx - (double)K.cx) * z / (double)K.fx;
+                    const double y = ((double)cy - (double)K.cy) * z / (double)K.fy;
+                    const double* g = S.geo + (size_t)s_ext[plid] * 7;
+                    const double sd = g[3] * (x - g[0]) + g[4] * (y - g[1]) + g[5] * (z - g[2]);
+                    cdist = (float)fabs(sd);
+                    geo_ok = (double)cdist * (double)cdist < 9 * g[6] + 1e-5;
+                }
+            }
+            bool done = !act, push = false;
+            while (__any(!done)) {
+                for (int t = lane; t < 256; t += 64) s_slot[t] = 64;
+                sync();
+                if (!done) atomicMin(&s_slot[cIdx & 255], lane);
+                sync();
+                if (!done && s_slot[cIdx & 255] == lane) {
+                    const int trail = member[cIdx];
+                    if (!(trail <= -6) && !(trail >= 0 && trail == plid)) {
+                        if (geo_ok) {
+                            if (trail >= 0 && normal_sim(S, s_ext[plid], s_ext[trail]) >= C.cos_refine) {   // n_pl.connect(pl)
+                                atomicOr(&s_adj[trail][plid >> 5], 1u << (plid & 31));
+                                atomicOr(&s_adj[plid][trail >> 5], 1u << (trail & 31));
+                            }
+                            if (cdist < distMap[cIdx]) { member[cIdx] = plid; distMap[cIdx] = cdist; push = true; }
+                            else if (trail < 0) member[cIdx] = trail - 1;
+                        } else if (trail < 0) member[cIdx] = trail - 1;
+                    }
+                    done = true;
+                }
+                sync();
+            }
+            const unsigned long long pm = __ballot(push);
+            const int npush = __popcll(pm);
+            if (q_tail + npush > L.q_cap) { err = 5; break; }
+            if (push) queue[q_tail + __popcll(pm & ((1ull << lane) - 1ull))] = make_int2(cIdx, plid);
+            q_tail += npush;
+            q_head += nent;
+            sync();
+        }
+    }
+
+    // ---- final ahCluster over the surviving planes (:319-326), relabel (:327-372) ----
+    const int n_old = n_ext;
+    for (int q = lane; q < n_old; q += 64) s_old[q] = s_ext[q];
+    sync();
+    // neighbour lists (ascending NODE id == std::set<PlaneSeg*> order) from the bit matrix; fresh pool region
+    pool_top = 0;   // every list is empty after ahCluster (all nodes were disconnected), the pool can be reused
+    for (int q = lane; q < n_old; q += 64) {
+        const int id = s_old[q];
+        const int off = q * MAX_PLANES;
+        int c = 0;
+        for (int r = 0; r < n_old; r++)
+            if (s_adj[q][r >> 5] & (1u << (r & 31))) list_insert(S.pool + off, c, s_old[r]);
+        S.nb_off[id] = off; S.nb_cnt[id] = c; S.nb_cap[id] = MAX_PLANES;
+    }
+    pool_top = n_old * MAX_PLANES;
+    sync();
+    n_ext = 0;
+    heap_n = 0;
+    for (int q = 0; q < n_old; q++) if (s_valid[q]) heap_push(s_old[q]);
+    if (!err) ah_cluster();
+    for (int q = lane; q < n_old; q += 64) {
+        int m = -1;
+        if (s_valid[q]) {
+            const int np_rid = ds_find(S.parent, S.rid[s_old[q]]);
+            for (int j = 0; j < n_ext; j++) if (S.rid[s_ext[j]] == np_rid) { m = j; break; }
+        }
+        s_plidmap[q] = m;
+    }
+    sync();
+    for (int i = lane; i < W * H; i += 64) {
+        const int plid = member[i];
+        lab[i] = (plid >= 0 && s_plidmap[plid] >= 0) ? s_plidmap[plid] : -1;
+    }
+    for (int j = lane; j < n_ext; j += 64) {
+        const int id = s_ext[j];
+        double* o = planes + ((size_t)frame * MAX_PLANES + j) * 8;
+        o[0] = (double)S.N[id];
+        for (int t = 0; t < 3; t++) { o[1 + t] = S.geo[(size_t)id * 7 + 3 + t]; o[4 + t] = S.geo[(size_t)id * 7 + t]; }
+        o[7] = S.geo[(size_t)id * 7 + 6];
+    }
+    if (lane == 0) { n_planes[frame] = n_ext; status[frame] = err; }
+}
+
+}  // namespace peac
+}  // namespace planar
+
+// ==========================================================================================================
+// host side
+// ==========================================================================================================
+using namespace planar;
+
+struct planar_peac {
+    planar_ctx* ctx = nullptr;
+    int W = 0, H = 0, max_batch = 0;
+    peac::Layout L{};
+    peac::Consts C{};
+    int smem = 0;
+    DevBuf d_ws, d_status;
+    DevBuf d_depth, d_labels, d_planes, d_nplanes;   // staging for the host-pointer entry point
+};
+
+extern "C" {
+
+int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, planar_peac** out) {
+    PLANAR_REQUIRE(ctx && out, PLANAR_EINVAL, "null argument");
+    *out = nullptr;
+    PLANAR_REQUIRE(width >= 2 * peac::WIN && height >= 2 * peac::WIN && width <= 4096 && height <= 4096, PLANAR_EINVAL, "image size out of range");
+    PLANAR_REQUIRE(max_batch >= 1, PLANAR_EINVAL, "max_batch must be >= 1");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    planar_peac* o = new (std::nothrow) planar_peac();
+    PLANAR_REQUIRE(o != nullptr, PLANAR_ENOMEM, "host allocation failed");
+    o->ctx = ctx; o->W = width; o->H = height; o->max_batch = max_batch;
+    peac::Layout& L = o->L;
+    L.W = width; L.H = height; L.Nw = width / peac::WIN; L.Nh = height / peac::WIN; L.NB = L.Nw * L.Nh; L.NB2 = 2 * L.NB;
+    L.pool_cap = std::max(32 * L.NB, 4 * L.NB + peac::MAX_PLANES * peac::MAX_PLANES);
+    L.q_cap = 2 * width * height;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o2 = off; off = align_up(off + bytes, (size_t)256); return o2; };
+    L.off_stats = carve((size_t)L.NB2 * 9 * 8); L.off_geo = carve((size_t)L.NB2 * 7 * 8); L.off_N = carve((size_t)L.NB2 * 4);
+    L.off_rid = carve((size_t)L.NB2 * 4); L.off_flags = carve((size_t)L.NB2); L.off_nb_off = carve((size_t)L.NB2 * 4);
+    L.off_nb_cnt = carve((size_t)L.NB2 * 4); L.off_nb_cap = carve((size_t)L.NB2 * 4); L.off_pool = carve((size_t)L.pool_cap * 4);
+    L.off_parent = carve((size_t)L.NB * 4); L.off_size = carve((size_t)L.NB * 4); L.off_member = carve((size_t)width * height * 4);
+    L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 8);
+    L.off_seedcnt = carve((size_t)L.NB * 4);
+    L.frame_bytes = off;
+    o->smem = L.NB2 * 8 + L.NB * 4;
+    if (o->smem > 150 * 1024) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
+    // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
+    const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
+    o->C.ang_near = 15.0 * deg;
+    o->C.ang_factor = (90.0 * deg - 15.0 * deg) / (4000.0 - 500.0);
+    o->C.cos_init_near = std::cos(o->C.ang_factor * 500.0 + o->C.ang_near - o->C.ang_factor * 500.0);
+    o->C.cos_merge = std::cos(60.0 * deg);
+    o->C.cos_refine = std::cos(30.0 * deg);
+    int rc;
+    if ((rc = o->d_ws.alloc((size_t)max_batch * L.frame_bytes)) || (rc = o->d_status.alloc((size_t)max_batch * 4))) { delete o; return rc; }
+    if (o->smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)peac::peac_segment, hipFuncAttributeMaxDynamicSharedMemorySize, o->smem);
+        if (e != hipSuccess) { delete o; set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
+    }
+    *out = o;
+    return PLANAR_OK;
+}
+
+void planar_peac_destroy(planar_peac* p) { delete p; }
+int planar_peac_max_planes(void) { return peac::MAX_PLANES; }
+
+int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy,
+                            float cx, float cy, float depth_factor, int32_t* d_labels, double* d_planes, int32_t* d_n_planes) {
+    PLANAR_REQUIRE(p && d_depth && d_labels && d_planes && d_n_planes, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "B must be in [1, max_batch]");
+    PLANAR_REQUIRE(pitch_px >= p->W && frame_stride_px >= (int64_t)pitch_px * p->H, PLANAR_EINVAL, "pitch/frame_stride too small");
+    hipStream_t st = p->ctx->stream;
+    const peac::Intr K{fx, fy, cx, cy, depth_factor};
+    hipLaunchKernelGGL(peac::peac_blocks, dim3((p->L.NB + 63) / 64, B), dim3(64), 0, st, p->L, K, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>());
+    hipLaunchKernelGGL(peac::peac_segment, dim3(B), dim3(64), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>(),
+                       d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>());
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+// Returns PLANAR_ECAPACITY if a frame overflowed an internal capacity (node pool, flood-fill queue, > MAX_PLANES planes).
+int planar_peac_check(planar_peac* p, int B) {
+    PLANAR_REQUIRE(p && B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "bad argument");
+    std::vector<int32_t> st(B);
+    PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    PLANAR_HIP_CHECK(hipMemcpy(st.data(), p->d_status.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++)
+        if (st[b] != 0) { set_error("planar_peac: frame %d overflowed an internal capacity (code %d)", b, st[b]); return PLANAR_ECAPACITY; }
+    return PLANAR_OK;
+}
+
+int planar_peac_segment(planar_peac* p, const uint16_t* depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy, float cx,
+                        float cy, float depth_factor, int32_t* labels, double* planes, int32_t* n_planes) {
+    PLANAR_REQUIRE(p && depth && labels && planes && n_planes, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "B must be in [1, max_batch]");
+    PLANAR_REQUIRE(pitch_px >= p->W && frame_stride_px >= (int64_t)pitch_px * p->H, PLANAR_EINVAL, "pitch/frame_stride too small");
+    PLANAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    const size_t in_bytes = ((size_t)frame_stride_px * (B - 1) + (size_t)pitch_px * p->H) * 2;
+    const size_t npx = (size_t)p->W * p->H;
+    int rc;
+    if (p->d_depth.bytes < in_bytes && (rc = p->d_depth.alloc(in_bytes))) return rc;
+    if (!p->d_labels.p) {
+        if ((rc = p->d_labels.alloc((size_t)p->max_batch * npx * 4)) || (rc = p->d_planes.alloc((size_t)p->max_batch * peac::MAX_PLANES * 64)) ||
+            (rc = p->d_nplanes.alloc((size_t)p->max_batch * 4)))
+            return rc;
+    }
+    hipStream_t st = p->ctx->stream;
+    PLANAR_HIP_CHECK(hipMemcpyAsync(p->d_depth.p, depth, in_bytes, hipMemcpyHostToDevice, st));
+    if ((rc = planar_peac_segment_dev(p, p->d_depth.as<uint16_t>(), B, pitch_px, frame_stride_px, fx, fy, cx, cy, depth_factor,
+                                      p->d_labels.as<int32_t>(), p->d_planes.as<double>(), p->d_nplanes.as<int32_t>())))
+        return rc;
+    PLANAR_HIP_CHECK(hipMemcpyAsync(labels, p->d_labels.p, (size_t)B * npx * 4, hipMemcpyDeviceToHost, st));
+    PLANAR_HIP_CHECK(hipMemcpyAsync(planes, p->d_planes.p, (size_t)B * peac::MAX_PLANES * 64, hipMemcpyDeviceToHost, st));
+    PLANAR_HIP_CHECK(hipMemcpyAsync(n_planes, p->d_nplanes.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    return planar_peac_check(p, B);
+}
+
+}  // extern "C"
