@@ -76,6 +76,7 @@ _SIGS = {
     "planar_peac_segment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_peac_segment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_peac_check": (C.c_int, [C.c_void_p, C.c_int]),
+    "planar_peac_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "planar_pose_opt": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
     "planar_pose_opt_dev": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
 }

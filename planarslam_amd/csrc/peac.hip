@@ -193,194 +193,229 @@ __global__ __launch_bounds__(64) void peac_blocks(Layout L, Intr K, const uint16
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K2: one wave per frame.
-struct Seg {   // views into the frame workspace
-    double* stats; double* geo; int* N; int* rid; uint8_t* flags; int* nb_off; int* nb_cnt; int* nb_cap; int* pool;
-    int* parent; int* size;
+// K2: one 256-thread workgroup per frame.  Everything the sequential part chases pointers through lives in LDS
+// (merge heap with its MSE keys, the neighbour lists as u16, the disjoint set, the block map); the per-node
+// moments / plane parameters stay in the frame's global workspace and are read once per merge step.
+constexpr int NT = 256;
+typedef unsigned short u16;
+
+struct Lds {
+    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; u16* dsp; u16* dss; u16* rid; unsigned* nouse; signed char* blk;
 };
-__device__ __forceinline__ double seg_mse(const Seg& S, int id) { return S.geo[(size_t)id * 7 + 6]; }
-__device__ __forceinline__ double normal_sim(const Seg& S, int a, int b) {
-    const double* ga = S.geo + (size_t)a * 7 + 3; const double* gb = S.geo + (size_t)b * 7 + 3;
-    return fabs(ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]);
-}
-__device__ int ds_find(int* parent, int x) {   // DisjointSet::Find with path compression (recursion unrolled)
+
+__device__ __forceinline__ int lds_find(u16* parent, int x) {   // DisjointSet::Find with path compression
     int r = x;
     while (parent[r] != r) r = parent[r];
-    while (parent[x] != r) { const int nx = parent[x]; parent[x] = r; x = nx; }
+    while (parent[x] != r) { const int nx = parent[x]; parent[x] = (u16)r; x = nx; }
     return r;
 }
-
-// sorted-list helpers executed by lane 0 only
-__device__ void list_erase(int* lst, int& cnt, int v) {
+__device__ __forceinline__ void lst_erase(u16* lst, int& cnt, int v) {
     int i = 0;
     while (i < cnt && lst[i] < v) i++;
     if (i < cnt && lst[i] == v) { for (; i + 1 < cnt; i++) lst[i] = lst[i + 1]; cnt--; }
 }
-__device__ void list_insert(int* lst, int& cnt, int v) {
+__device__ __forceinline__ void lst_insert(u16* lst, int& cnt, int v) {
     int i = 0;
     while (i < cnt && lst[i] < v) i++;
     if (i < cnt && lst[i] == v) return;
     for (int j = cnt; j > i; j--) lst[j] = lst[j - 1];
-    lst[i] = v; cnt++;
+    lst[i] = (u16)v; cnt++;
 }
 
-__global__ __launch_bounds__(64) void peac_segment(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
+__global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
                                                    int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
                                                    int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
-                                                   int32_t* __restrict__ status) {
+                                                   int32_t* __restrict__ status, long long* __restrict__ timing) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* F = ws + (size_t)frame * L.frame_bytes;
-    Seg S;
-    S.stats = (double*)(F + L.off_stats); S.geo = (double*)(F + L.off_geo); S.N = (int*)(F + L.off_N); S.rid = (int*)(F + L.off_rid);
-    S.flags = F + L.off_flags; S.nb_off = (int*)(F + L.off_nb_off); S.nb_cnt = (int*)(F + L.off_nb_cnt); S.nb_cap = (int*)(F + L.off_nb_cap);
-    S.pool = (int*)(F + L.off_pool); S.parent = (int*)(F + L.off_parent); S.size = (int*)(F + L.off_size);
+    double* g_stats = (double*)(F + L.off_stats);
+    double* g_geo = (double*)(F + L.off_geo);
+    int* g_N = (int*)(F + L.off_N);
+    uint8_t* g_flags = F + L.off_flags;
     int* member = (int*)(F + L.off_member);
     float* distMap = (float*)(F + L.off_dist);
-    int* blkMap = (int*)(F + L.off_blkmap);
     int2* queue = (int2*)(F + L.off_queue);
     int* seedcnt = (int*)(F + L.off_seedcnt);
     const uint16_t* D = depth + (size_t)frame * frame_stride_px;
     int32_t* lab = labels + (size_t)frame * label_stride;
     const int NB = L.NB, Nw = L.Nw, Nh = L.Nh, W = L.W, H = L.H;
 
-    // LDS: mse of every node (heap comparisons) + the heap itself
-    double* s_mse = (double*)smem;                 // [NB2]
-    int* heap = (int*)(s_mse + L.NB2);             // [NB]
-    __shared__ int s_ext[MAX_PLANES];              // extractedPlanes (node ids)
-    __shared__ int s_old[MAX_PLANES];
-    __shared__ int s_plidmap[MAX_PLANES];
+    Lds S;
+    S.h_mse = (double*)smem;
+    S.h_id = (u16*)(S.h_mse + NB);
+    S.pool = S.h_id + NB;
+    S.nb_off = S.pool + L.pool_cap;
+    S.nb_cnt = S.nb_off + L.NB2;
+    S.dsp = S.nb_cnt + L.NB2;
+    S.dss = S.dsp + NB;
+    S.rid = S.dss + NB;                       // rid of every node (root block id)
+    S.nouse = (unsigned*)(S.rid + L.NB2);     // bit per node: merged away (PlaneSeg::nouse)
+    S.blk = (signed char*)(S.nouse + (L.NB2 + 31) / 32);
+
+    __shared__ int s_ext[MAX_PLANES], s_old[MAX_PLANES], s_plidmap[MAX_PLANES];
     __shared__ uint8_t s_valid[MAX_PLANES];
-    __shared__ int s_tmp[256];
-    int err = 0;
+    __shared__ unsigned s_adj[MAX_PLANES][MAX_PLANES / 32];
+    __shared__ int s_slot[1024];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_scalar[4];   // [0] n_ext, [1] err, [2] q_tail, [3] scratch
+    long long tphase[8];
+    int nph = 0;
+    auto mark = [&]() { if (nph < 8) tphase[nph++] = (long long)wall_clock64(); };
+    mark();
+    auto wfence = [&]() { __threadfence_block(); };   // single-wave sections: LDS ops of one wave are in order
 
-    auto sync = [&]() { __threadfence_block(); __syncthreads(); };
-
-    // ---- init: disjoint set, neighbour lists (capacity 4 per block), mse copy ----
-    for (int b = lane; b < NB; b += 64) {
-        S.parent[b] = b; S.size[b] = 1;
-        S.nb_off[b] = 4 * b; S.nb_cnt[b] = 0; S.nb_cap[b] = 4;
-        s_mse[b] = seg_mse(S, b);
-    }
-    int pool_top = 4 * NB;
-    sync();
-
-    // ---- initGraph edges (AHCPlaneFitter.hpp:896-954): rows are independent in the horizontal pass and columns in
-    //      the vertical pass, each row/column is a sequential scan with the reference's --j/++j skip logic.
-    //      connect() is symmetric set insertion; edges of one pass touch disjoint (row|column) node sets, so
-    //      lanes own whole rows/columns and insert with lane-0-style list code.
-    auto connect = [&](int a, int b) {
-        int ca = S.nb_cnt[a]; list_insert(S.pool + S.nb_off[a], ca, b); S.nb_cnt[a] = ca;
-        int cb = S.nb_cnt[b]; list_insert(S.pool + S.nb_off[b], cb, a); S.nb_cnt[b] = cb;
+    auto geo_of = [&](int id) { return g_geo + (size_t)id * 7; };
+    auto nsim = [&](int a, int b) {
+        const double* ga = geo_of(a) + 3; const double* gb = geo_of(b) + 3;
+        return fabs(ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]);
     };
-    auto inG = [&](int idx) { return (S.flags[idx] & 1) != 0; };
-    for (int i = lane; i < Nh; i += 64) {
+
+    // ---- init (all threads) ----
+    for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.rid[b] = (u16)b; }
+    for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) S.nouse[t] = 0;
+    for (int t = tid; t < MAX_PLANES; t += NT) { s_valid[t] = 0; s_plidmap[t] = -1; }
+    for (int t = tid; t < MAX_PLANES * (MAX_PLANES / 32); t += NT) (&s_adj[0][0])[t] = 0;
+    if (tid < 4) s_scalar[tid] = 0;
+    __syncthreads();
+
+    // ---- initGraph edges (AHCPlaneFitter.hpp:896-954).  The horizontal pass only links nodes of one row and the
+    //      vertical pass nodes of one column, each a sequential scan with the reference's --j/++j skip logic, so a
+    //      thread owns a whole row / column.  Every block has its own 4-slot list.
+    auto connect = [&](int a, int b) {
+        int ca = S.nb_cnt[a]; lst_insert(S.pool + S.nb_off[a], ca, b); S.nb_cnt[a] = (u16)ca;
+        int cb = S.nb_cnt[b]; lst_insert(S.pool + S.nb_off[b], cb, a); S.nb_cnt[b] = (u16)cb;
+    };
+    auto inG = [&](int idx) { return (g_flags[idx] & 1) != 0; };
+    for (int i = tid; i < Nh; i += NT) {
         for (int j = 1; j < Nw; j += 2) {
             const int c = i * Nw + j;
             if (!inG(c - 1)) { --j; continue; }
             if (!inG(c)) continue;
             if (j < Nw - 1 && !inG(c + 1)) { ++j; continue; }
-            const double th = T_ang_init(C, S.geo[(size_t)c * 7 + 2]);
-            if ((j < Nw - 1 && normal_sim(S, c - 1, c + 1) >= th) || (j == Nw - 1 && normal_sim(S, c, c - 1) >= th)) {
+            const double th = T_ang_init(C, geo_of(c)[2]);
+            if ((j < Nw - 1 && nsim(c - 1, c + 1) >= th) || (j == Nw - 1 && nsim(c, c - 1) >= th)) {
                 connect(c, c - 1);
                 if (j < Nw - 1) connect(c, c + 1);
             } else --j;
         }
     }
-    sync();
-    for (int j = lane; j < Nw; j += 64) {
+    __syncthreads();
+    for (int j = tid; j < Nw; j += NT) {
         for (int i = 1; i < Nh; i += 2) {
             const int c = i * Nw + j;
             if (!inG(c - Nw)) { --i; continue; }
             if (!inG(c)) continue;
             if (i < Nh - 1 && !inG(c + Nw)) { ++i; continue; }
-            const double th = T_ang_init(C, S.geo[(size_t)c * 7 + 2]);
-            if ((i < Nh - 1 && normal_sim(S, c - Nw, c + Nw) >= th) || (i == Nh - 1 && normal_sim(S, c, c - Nw) >= th)) {
+            const double th = T_ang_init(C, geo_of(c)[2]);
+            if ((i < Nh - 1 && nsim(c - Nw, c + Nw) >= th) || (i == Nh - 1 && nsim(c, c - Nw) >= th)) {
                 connect(c, c - Nw);
                 if (i < Nh - 1) connect(c, c + Nw);
             } else --i;
         }
     }
-    sync();
+    __syncthreads();
+    mark();
 
-    // ---- libstdc++ binary heap with comp(a,b) = mse[b] < mse[a]  (std::priority_queue, PlaneSegMinMSECmp) ----
-    int heap_n = 0;
-    auto hcmp = [&](int a, int b) { return s_mse[b] < s_mse[a]; };
-    auto heap_push = [&](int v) {      // all lanes execute identically on LDS
+    // =========================== sequential section: wave 0 only ===========================
+    int heap_n = 0, n_nodes = NB, n_ext = 0, pool_top = 4 * NB, err = 0;
+    // libstdc++ binary heap (std::priority_queue with PlaneSegMinMSECmp: comp(a,b) = b.mse < a.mse); entries carry
+    // their key so a comparison is one LDS read.
+    auto heap_push = [&](int id, double mse) {
         int hole = heap_n, parent = (hole - 1) / 2;
         heap_n++;
-        while (hole > 0 && hcmp(heap[parent], v)) { if (lane == 0) heap[hole] = heap[parent]; __threadfence_block(); hole = parent; parent = (hole - 1) / 2; }
-        if (lane == 0) heap[hole] = v;
-        __threadfence_block();
+        while (hole > 0 && mse < S.h_mse[parent]) {
+            if (lane == 0) { S.h_mse[hole] = S.h_mse[parent]; S.h_id[hole] = S.h_id[parent]; }
+            wfence(); hole = parent; parent = (hole - 1) / 2;
+        }
+        if (lane == 0) { S.h_mse[hole] = mse; S.h_id[hole] = (u16)id; }
+        wfence();
     };
     auto heap_pop = [&]() -> int {
-        const int top = heap[0];
-        const int value = heap[heap_n - 1];
+        const int top = S.h_id[0];
+        const double vm = S.h_mse[heap_n - 1]; const int vi = S.h_id[heap_n - 1];
         heap_n--;
         const int len = heap_n;
         if (len == 0) return top;
         int hole = 0, second = 0;
         while (second < (len - 1) / 2) {
             second = 2 * (second + 1);
-            if (hcmp(heap[second], heap[second - 1])) second--;
-            if (lane == 0) heap[hole] = heap[second];
-            __threadfence_block();
-            hole = second;
+            if (S.h_mse[second - 1] < S.h_mse[second]) second--;          // comp(first[second], first[second-1])
+            if (lane == 0) { S.h_mse[hole] = S.h_mse[second]; S.h_id[hole] = S.h_id[second]; }
+            wfence(); hole = second;
         }
-        if ((len & 1) == 0 && second == (len - 2) / 2) { second = 2 * (second + 1); if (lane == 0) heap[hole] = heap[second - 1]; __threadfence_block(); hole = second - 1; }
+        if ((len & 1) == 0 && second == (len - 2) / 2) {
+            second = 2 * (second + 1);
+            if (lane == 0) { S.h_mse[hole] = S.h_mse[second - 1]; S.h_id[hole] = S.h_id[second - 1]; }
+            wfence(); hole = second - 1;
+        }
         int parent = (hole - 1) / 2;
-        while (hole > 0 && hcmp(heap[parent], value)) { if (lane == 0) heap[hole] = heap[parent]; __threadfence_block(); hole = parent; parent = (hole - 1) / 2; }
-        if (lane == 0) heap[hole] = value;
-        __threadfence_block();
+        while (hole > 0 && vm < S.h_mse[parent]) {
+            if (lane == 0) { S.h_mse[hole] = S.h_mse[parent]; S.h_id[hole] = S.h_id[parent]; }
+            wfence(); hole = parent; parent = (hole - 1) / 2;
+        }
+        if (lane == 0) { S.h_mse[hole] = vm; S.h_id[hole] = (u16)vi; }
+        wfence();
         return top;
     };
-    for (int b = 0; b < NB; b++) if (S.flags[b] & 1) heap_push(b);   // minQ.push in block order (:809)
-    int n_nodes = NB;        // next node id
-    int n_ext = 0;
-
-    auto disconnect_all = [&](int a) {     // PlaneSeg::disconnectAllNbs
+    auto disconnect_all = [&](int a) {     // PlaneSeg::disconnectAllNbs; every neighbour owns its own list
         const int cnt = S.nb_cnt[a];
-        const int* lst = S.pool + S.nb_off[a];
-        for (int k = lane; k < cnt; k += 64) {     // every neighbour owns its own list: lanes are independent
-            const int nb = lst[k];
-            int c = S.nb_cnt[nb];
-            list_erase(S.pool + S.nb_off[nb], c, a);
-            S.nb_cnt[nb] = c;
+        const u16* lst = S.pool + S.nb_off[a];
+        for (int k = lane; k < cnt; k += 64) {
+            const int q = lst[k];
+            int c = S.nb_cnt[q];
+            lst_erase(S.pool + S.nb_off[q], c, a);
+            S.nb_cnt[q] = (u16)c;
         }
-        sync();
+        wfence();
         if (lane == 0) S.nb_cnt[a] = 0;
-        sync();
+        wfence();
     };
-
-    // ---- ahCluster (:983-1189) ----
+    auto node_N = [&](int id) { return (int)S.dss[S.rid[id]] * (WIN * WIN); };   // live node: rid is its set's root
+    auto extract = [&](int p) {
+        if (node_N(p) >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
+    };
+    // ahCluster (:983-1189)
+    long long cyc[6] = {0, 0, 0, 0, 0, 0};
     auto ah_cluster = [&]() {
         int step = 0;
-        while (heap_n > 0 && step <= MAX_STEP) {
+        while (heap_n > 0 && step <= MAX_STEP && !err) {
+            long long c0 = clock64();
             const int p = heap_pop();
-            if (S.flags[p] & 2) continue;                       // nouse
+            cyc[0] += clock64() - c0; c0 = clock64();
+            if (S.nouse[p >> 5] & (1u << (p & 31))) continue;   // nouse
             const int cnt = S.nb_cnt[p];
-            const int* lst = S.pool + S.nb_off[p];
-            // candidate merges: lane k evaluates neighbour k (+64, ...), then an in-order fold reproduces the
-            // reference's "first minimum wins (with the N<mse quirk)" rule
+            const u16* lst = S.pool + S.nb_off[p];
+            const double* sp = g_stats + (size_t)p * 9;
+            const int Np = node_N(p);
+            const double* gp = geo_of(p) + 3;
+            const double pn0 = gp[0], pn1 = gp[1], pn2 = gp[2];
+            double ps[9];
+            for (int t = 0; t < 9; t++) ps[t] = sp[t];
+            // candidate merges, one per lane; the in-order fold reproduces "first minimum wins (+ the N<mse quirk)"
             double best_mse = 0; int best_nb = -1, best_N = 0; bool have = false;
             double best_stats[9]; Geo best_geo;
             for (int k0 = 0; k0 < cnt; k0 += 64) {
                 const int k = k0 + lane;
                 bool ok = false;
                 double ms[9]; Geo mg; int mN = 0, nb = -1;
+                mg.mse = 0;
                 if (k < cnt) {
                     nb = lst[k];
-                    if (!(normal_sim(S, p, nb) < C.cos_merge)) {
-                        const double* sa = S.stats + (size_t)p * 9; const double* sb = S.stats + (size_t)nb * 9;
-                        for (int t = 0; t < 9; t++) ms[t] = sa[t] + sb[t];
-                        mN = S.N[p] + S.N[nb];
+                    // one memory round trip: the neighbour's normal and moments are fetched together
+                    const double* gn = geo_of(nb) + 3;
+                    const double* sb = g_stats + (size_t)nb * 9;
+                    const double n0 = gn[0], n1 = gn[1], n2 = gn[2];
+                    for (int t = 0; t < 9; t++) ms[t] = sb[t];
+                    if (!(fabs(pn0 * n0 + pn1 * n1 + pn2 * n2) < C.cos_merge)) {
+                        for (int t = 0; t < 9; t++) ms[t] = ps[t] + ms[t];
+                        mN = Np + node_N(nb);
                         stats_compute(ms, mN, mg);
                         ok = true;
                     }
                 }
-                // in-order fold across lanes (k ascending == ascending node id == std::set iteration order)
                 unsigned long long m = __ballot(ok);
-                while (m) {
+                while (m) {                                      // ascending k == ascending node id == std::set order
                     const int src = __ffsll((long long)m) - 1;
                     m &= m - 1;
                     const double c_mse = __shfl(mg.mse, src);
@@ -392,181 +427,186 @@ __global__ __launch_bounds__(64) void peac_segment(Layout L, Intr K, Consts C, c
                     }
                 }
             }
+            cyc[1] += clock64() - c0; c0 = clock64();
             if (have && best_mse < T_mse_merge(best_geo.center[2])) {
                 const int m = n_nodes++;
                 const int nb = best_nb;
                 if (m >= L.NB2) { err = 1; break; }
-                // new node
+                const int rp = S.rid[p], rn = S.rid[nb];
+                const int Nn = node_N(nb);
                 if (lane == 0) {
-                    for (int t = 0; t < 9; t++) S.stats[(size_t)m * 9 + t] = best_stats[t];
-                    for (int t = 0; t < 3; t++) { S.geo[(size_t)m * 7 + t] = best_geo.center[t]; S.geo[(size_t)m * 7 + 3 + t] = best_geo.normal[t]; }
-                    S.geo[(size_t)m * 7 + 6] = best_geo.mse;
-                    S.N[m] = best_N;
-                    S.rid[m] = S.N[p] >= S.N[nb] ? S.rid[p] : S.rid[nb];
-                    S.flags[m] = 0;
-                    s_mse[m] = best_geo.mse;
+                    for (int t = 0; t < 9; t++) g_stats[(size_t)m * 9 + t] = best_stats[t];
+                    for (int t = 0; t < 3; t++) { g_geo[(size_t)m * 7 + t] = best_geo.center[t]; g_geo[(size_t)m * 7 + 3 + t] = best_geo.normal[t]; }
+                    g_geo[(size_t)m * 7 + 6] = best_geo.mse;
+                    g_N[m] = best_N;
+                    S.rid[m] = (u16)(Np >= Nn ? rp : rn);
+                    S.nouse[p >> 5] |= 1u << (p & 31);
+                    S.nouse[nb >> 5] |= 1u << (nb & 31);
                     // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:64-84)
-                    const int xr = ds_find(S.parent, S.rid[p]), yr = ds_find(S.parent, S.rid[nb]);
+                    const int xr = lds_find(S.dsp, rp), yr = lds_find(S.dsp, rn);
                     if (xr != yr) {
-                        if (S.size[xr] < S.size[yr]) { S.parent[xr] = yr; S.size[yr] += S.size[xr]; }
-                        else { S.parent[yr] = xr; S.size[xr] += S.size[yr]; }
+                        if (S.dss[xr] < S.dss[yr]) { S.dsp[xr] = (u16)yr; S.dss[yr] += S.dss[xr]; }
+                        else { S.dsp[yr] = (u16)xr; S.dss[xr] += S.dss[yr]; }
                     }
                 }
-                sync();
-                heap_push(m);
+                wfence();
+                heap_push(m, best_geo.mse);
+                cyc[2] += clock64() - c0; c0 = clock64();
                 // mergeNbsFrom (AHCPlaneSeg.hpp:379-404): union of the two sorted lists minus {p, nb}
                 const int ca = S.nb_cnt[p], cb = S.nb_cnt[nb];
-                if (pool_top + ca + cb > L.pool_cap) {
-                    // compact the pool: live lists only (lane 0; rare)
+                if (pool_top + ca + cb > L.pool_cap) {          // compact: live merged lists only (rare)
                     if (lane == 0) {
                         int top = 4 * NB;
-                        for (int id = NB; id < n_nodes - 1; id++) {
-                            if (S.flags[id] & 2) { S.nb_cnt[id] = 0; continue; }
-                            const int c = S.nb_cnt[id]; const int o = S.nb_off[id];
+                        for (int id = NB; id < m; id++) {
+                            const int c = S.nb_cnt[id];
+                            if (c == 0) continue;
+                            const int o = S.nb_off[id];
                             for (int t = 0; t < c; t++) S.pool[top + t] = S.pool[o + t];
-                            S.nb_off[id] = top; S.nb_cap[id] = c; top += c;
+                            S.nb_off[id] = (u16)top; top += c;
                         }
-                        s_tmp[0] = top;
+                        s_scalar[3] = top;
                     }
-                    sync();
-                    pool_top = s_tmp[0];
-                    sync();
+                    wfence();
+                    pool_top = s_scalar[3];
                     if (pool_top + ca + cb > L.pool_cap) { err = 2; break; }
                 }
                 const int off = pool_top;
                 pool_top += ca + cb;
                 if (lane == 0) {
-                    const int* A = S.pool + S.nb_off[p]; const int* Bl = S.pool + S.nb_off[nb];
+                    const u16* A = S.pool + S.nb_off[p]; const u16* Bl = S.pool + S.nb_off[nb];
                     int i = 0, j = 0, n = 0;
                     while (i < ca || j < cb) {
                         int v;
                         if (j >= cb || (i < ca && A[i] < Bl[j])) v = A[i++];
                         else if (i >= ca || Bl[j] < A[i]) v = Bl[j++];
                         else { v = A[i]; i++; j++; }
-                        if (v != p && v != nb) S.pool[off + n++] = v;
+                        if (v != p && v != nb) S.pool[off + n++] = (u16)v;
                     }
-                    S.nb_off[m] = off; S.nb_cnt[m] = n; S.nb_cap[m] = ca + cb;
+                    S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n;
                 }
-                sync();
+                wfence();
+                cyc[3] += clock64() - c0; c0 = clock64();
                 disconnect_all(p);
                 disconnect_all(nb);
-                {   // nb->nbs.insert(this): m is the largest id so far -> append
+                cyc[4] += clock64() - c0; c0 = clock64();
+                {   // nb->nbs.insert(this): m is the largest id so far -> append (a slot was freed by the erase above)
                     const int n = S.nb_cnt[m];
-                    const int* lstm = S.pool + off;
+                    const u16* lstm = S.pool + off;
                     for (int k = lane; k < n; k += 64) {
                         const int q = lstm[k];
                         const int c = S.nb_cnt[q];
-                        if (c >= S.nb_cap[q]) err = 3;
-                        else { S.pool[S.nb_off[q] + c] = m; S.nb_cnt[q] = c + 1; }
+                        S.pool[S.nb_off[q] + c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
                     }
                 }
-                if (lane == 0) { S.flags[p] |= 2; S.flags[nb] |= 2; }
-                sync();
-                if (__any(err)) { err = 3; break; }
+                wfence();
+                cyc[5] += clock64() - c0;
             } else {
-                if (S.N[p] >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
+                extract(p);
                 disconnect_all(p);
             }
             ++step;
         }
-        while (heap_n > 0) {
-            const int p = heap_pop();
-            if (S.N[p] >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
-            disconnect_all(p);
-        }
-        sync();
-        // std::sort(extractedPlanes, b->N < a->N): insertion sort (stable), lane 0
-        if (lane == 0) {
+        while (heap_n > 0 && !err) { const int p = heap_pop(); extract(p); disconnect_all(p); }
+        wfence();
+        if (lane == 0) {   // std::sort(extractedPlanes, b->N < a->N): insertion sort (stable)
             for (int i = 1; i < n_ext; i++) {
                 const int v = s_ext[i];
                 int j = i;
-                while (j > 0 && S.N[s_ext[j - 1]] < S.N[v]) { s_ext[j] = s_ext[j - 1]; j--; }
+                while (j > 0 && node_N(s_ext[j - 1]) < node_N(v)) { s_ext[j] = s_ext[j - 1]; j--; }
                 s_ext[j] = v;
             }
         }
-        sync();
+        wfence();
     };
-    ah_cluster();
+    if (wave == 0) {
+        for (int b0 = 0; b0 < NB; b0 += 64) {   // minQ.push in block order (:809); 64 blocks fetched per round
+            const int b = b0 + lane;
+            const bool in = b < NB && (g_flags[b] & 1);
+            const double m = in ? geo_of(b)[6] : 0.0;
+            unsigned long long mask = __ballot(in);
+            while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                heap_push(b0 + src, __shfl(m, src));
+            }
+        }
+        mark();
+        ah_cluster();
+        if (lane == 0) { s_scalar[0] = n_ext; s_scalar[1] = err; }
+    } else mark();
+    __syncthreads();
+    n_ext = s_scalar[0]; err = s_scalar[1];
+    mark();
 
-    // ---- refineDetails (:299-379) ----
-    // findBlockMembership (:485-587): blkMap, membership image, seed queue.
-    for (int i = lane; i < W * H; i += 64) { member[i] = -1; distMap[i] = 3.4028234663852886e38f; }
-    for (int i = lane; i < MAX_PLANES; i += 64) { s_valid[i] = 0; s_plidmap[i] = -1; }
-    sync();
-    // pass 1 (parallel over blocks): blkMap
-    for (int b = lane; b < NB; b += 64) {
+    // ---- refineDetails (:299-379): findBlockMembership (:485-587), all threads ----
+    for (int i = tid; i < W * H; i += NT) { member[i] = -1; distMap[i] = 3.4028234663852886e38f; }
+    for (int b = tid; b < NB; b += NT) {
         const int i = b / Nw, j = b - i * Nw;
-        const int setid = ds_find(S.parent, b);   // path compression races are benign: every write stores a valid ancestor
+        const int setid = lds_find(S.dsp, b);   // concurrent path compression only ever stores true roots: benign
         int plid = -1;
-        if (S.size[setid] * (WIN * WIN) >= MIN_SUPPORT) {
+        if (S.dss[setid] * (WIN * WIN) >= MIN_SUPPORT) {
             bool same = true;
-            if (j > 0 && ds_find(S.parent, b - 1) != setid) same = false;
-            if (j < Nw - 1 && ds_find(S.parent, b + 1) != setid) same = false;
-            if (i > 0 && ds_find(S.parent, b - Nw) != setid) same = false;
-            if (i < Nh - 1 && ds_find(S.parent, b + Nw) != setid) same = false;
+            if (j > 0 && lds_find(S.dsp, b - 1) != setid) same = false;
+            if (j < Nw - 1 && lds_find(S.dsp, b + 1) != setid) same = false;
+            if (i > 0 && lds_find(S.dsp, b - Nw) != setid) same = false;
+            if (i < Nh - 1 && lds_find(S.dsp, b + Nw) != setid) same = false;
             if (same) {
                 plid = 0;                                    // std::map::operator[] default when absent
                 for (int q = 0; q < n_ext; q++) if (S.rid[s_ext[q]] == setid) { plid = q; break; }
                 s_valid[plid] = 1;
             }
         }
-        blkMap[b] = plid;
+        S.blk[b] = (signed char)plid;
     }
-    sync();
-    // pass 2: per-block seed counts (depends only on blkMap of self / up / left), exclusive scan, fill
-    for (int b = lane; b < NB; b += 64) {
-        const int i = b / Nw, j = b - i * Nw, me = blkMap[b];
+    __syncthreads();
+    for (int b = tid; b < NB; b += NT) {       // seeds per block (depend on blkMap of self / up / left only)
+        const int i = b / Nw, j = b - i * Nw, me = S.blk[b];
         int c = 0;
-        if (me < 0) {
-            if (i > 0 && blkMap[b - Nw] >= 0) c += WIN - 1;
-            if (j > 0 && blkMap[b - 1] >= 0) c += WIN - 1;
-        } else {
-            if (i > 0 && blkMap[b - Nw] != me) c += WIN - 1;
-            if (j > 0 && blkMap[b - 1] != me) c += WIN - 1;
-        }
+        if (me < 0) { if (i > 0 && S.blk[b - Nw] >= 0) c += WIN - 1; if (j > 0 && S.blk[b - 1] >= 0) c += WIN - 1; }
+        else { if (i > 0 && S.blk[b - Nw] != me) c += WIN - 1; if (j > 0 && S.blk[b - 1] != me) c += WIN - 1; }
         seedcnt[b] = c;
     }
-    sync();
-    int q_tail = 0;
-    for (int b0 = 0; b0 < NB; b0 += 64) {      // wave scan in block order
-        const int b = b0 + lane;
-        const int c = b < NB ? seedcnt[b] : 0;
-        int incl = c;
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        const int start = q_tail + incl - c;
-        if (b < NB) seedcnt[b] = start;
-        q_tail += __shfl(incl, 63);
+    __syncthreads();
+    if (wave == 0) {                           // exclusive scan in block order
+        int run = 0;
+        for (int b0 = 0; b0 < NB; b0 += 64) {
+            const int b = b0 + lane;
+            const int c = b < NB ? seedcnt[b] : 0;
+            int incl = c;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            if (b < NB) seedcnt[b] = run + incl - c;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) { s_scalar[2] = run; if (run > L.q_cap) s_scalar[1] = 5; }
     }
-    sync();
-    if (q_tail > L.q_cap) err = 5;
-    for (int b = lane; b < NB && !err; b += 64) {
-        const int i = b / Nw, j = b - i * Nw, me = blkMap[b];
+    __syncthreads();
+    err = s_scalar[1];
+    for (int b = tid; b < NB && !err; b += NT) {
+        const int i = b / Nw, j = b - i * Nw, me = S.blk[b];
         int o = seedcnt[b];
         if (me >= 0)   // membershipImg(block) = plid
             for (int y = i * WIN; y < (i + 1) * WIN; y++) for (int x = j * WIN; x < (j + 1) * WIN; x++) member[y * W + x] = me;
         if (me < 0) {
-            if (i > 0 && blkMap[b - Nw] >= 0) { const int up = blkMap[b - Nw]; const int sp = (i * WIN - 1) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = make_int2(sp + k, up); }
-            if (j > 0 && blkMap[b - 1] >= 0) { const int lp = blkMap[b - 1]; const int sp = (i * WIN) * W + j * WIN - 1; for (int k = 0; k < WIN - 1; ++k) queue[o++] = make_int2(sp + k * W, lp); }
+            if (i > 0 && S.blk[b - Nw] >= 0) { const int up = S.blk[b - Nw]; const int sp = (i * WIN - 1) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = make_int2(sp + k, up); }
+            if (j > 0 && S.blk[b - 1] >= 0) { const int lp = S.blk[b - 1]; const int sp = (i * WIN) * W + j * WIN - 1; for (int k = 0; k < WIN - 1; ++k) queue[o++] = make_int2(sp + k * W, lp); }
         } else {
-            if (i > 0 && blkMap[b - Nw] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 0; k < WIN - 1; ++k) queue[o++] = make_int2(sp + k, me); }
-            if (j > 0 && blkMap[b - 1] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = make_int2(sp + k * W, me); }
+            if (i > 0 && S.blk[b - Nw] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 0; k < WIN - 1; ++k) queue[o++] = make_int2(sp + k, me); }
+            if (j > 0 && S.blk[b - 1] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = make_int2(sp + k * W, me); }
         }
     }
-    sync();
+    __threadfence_block();
+    __syncthreads();
+    mark();
 
-    // floodFill (:428-476).  Per wave step: 16 queue entries x 4 neighbours, one (entry, neighbour) pair per lane.
-    // Pairs that hit the same pixel are replayed in lane (== reference) order; plane-plane connect() is a
-    // commutative set insertion and goes to an LDS bit matrix; queue pushes are appended in lane order.
-    __shared__ unsigned s_adj[MAX_PLANES][MAX_PLANES / 32];
-    for (int t = lane; t < MAX_PLANES * (MAX_PLANES / 32); t += 64) (&s_adj[0][0])[t] = 0;
-    sync();
+    // ---- floodFill (:428-476), all threads.  Per step: 64 queue entries x 4 neighbours, one (entry, neighbour) pair per
+    //      thread.  Pairs that hit the same pixel are replayed in thread (== reference) order; plane-plane connect() is a
+    //      commutative set insertion and goes to an LDS bit matrix; queue pushes are appended in thread order.
     {
         const double factor = (double)K.factor;
-        int* s_slot = s_tmp;                 // 256-entry direct-mapped table for same-pixel detection
-        int q_head = 0;
+        int q_head = 0, q_tail = s_scalar[2];
         while (q_head < q_tail && !err) {
-            const int nent = min(16, q_tail - q_head);
-            const int e = lane >> 2, dir = lane & 3;
+            const int nent = min(NT / 4, q_tail - q_head);
+            const int e = tid >> 2, dir = tid & 3;
             bool act = e < nent;
             int cIdx = -1, plid = -1, cx = 0, cy = 0;
             if (act) {
@@ -584,30 +624,30 @@ __global__ __launch_bounds__(64) void peac_segment(Layout L, Intr K, Consts C, c
             if (act) {
                 const int by = cy / WIN, bx = cx / WIN;
                 const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
-                if (blkid >= 0 && blkMap[blkid] >= 0) act = false;          // only "black" blocks are refined
+                if (blkid >= 0 && S.blk[blkid] >= 0) act = false;          // only "black" blocks are refined
             }
             if (act) {
                 const double z = (double)D[(size_t)cy * pitch_px + cx] * factor;
                 if (z != 0) {
                     const double x = ((double)cx - (double)K.cx) * z / (double)K.fx;
                     const double y = ((double)cy - (double)K.cy) * z / (double)K.fy;
-                    const double* g = S.geo + (size_t)s_ext[plid] * 7;
+                    const double* g = geo_of(s_ext[plid]);
                     const double sd = g[3] * (x - g[0]) + g[4] * (y - g[1]) + g[5] * (z - g[2]);
                     cdist = (float)fabs(sd);
                     geo_ok = (double)cdist * (double)cdist < 9 * g[6] + 1e-5;
                 }
             }
             bool done = !act, push = false;
-            while (__any(!done)) {
-                for (int t = lane; t < 256; t += 64) s_slot[t] = 64;
-                sync();
-                if (!done) atomicMin(&s_slot[cIdx & 255], lane);
-                sync();
-                if (!done && s_slot[cIdx & 255] == lane) {
+            while (__syncthreads_or(!done)) {
+                for (int t = tid; t < 1024; t += NT) s_slot[t] = NT;
+                __syncthreads();
+                if (!done) atomicMin(&s_slot[cIdx & 1023], tid);
+                __syncthreads();
+                if (!done && s_slot[cIdx & 1023] == tid) {
                     const int trail = member[cIdx];
                     if (!(trail <= -6) && !(trail >= 0 && trail == plid)) {
                         if (geo_ok) {
-                            if (trail >= 0 && normal_sim(S, s_ext[plid], s_ext[trail]) >= C.cos_refine) {   // n_pl.connect(pl)
+                            if (trail >= 0 && nsim(s_ext[plid], s_ext[trail]) >= C.cos_refine) {   // n_pl.connect(pl)
                                 atomicOr(&s_adj[trail][plid >> 5], 1u << (plid & 31));
                                 atomicOr(&s_adj[plid][trail >> 5], 1u << (trail & 31));
                             }
@@ -617,59 +657,82 @@ __global__ __launch_bounds__(64) void peac_segment(Layout L, Intr K, Consts C, c
                     }
                     done = true;
                 }
-                sync();
+                __threadfence_block();
             }
             const unsigned long long pm = __ballot(push);
-            const int npush = __popcll(pm);
-            if (q_tail + npush > L.q_cap) { err = 5; break; }
-            if (push) queue[q_tail + __popcll(pm & ((1ull << lane) - 1ull))] = make_int2(cIdx, plid);
-            q_tail += npush;
+            if (lane == 0) s_wcnt[wave] = __popcll(pm);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 4; w++) { const int c = s_wcnt[w]; if (w < wave) before += c; total += c; }
+            if (q_tail + total > L.q_cap) { err = 5; }
+            else if (push) queue[q_tail + before + __popcll(pm & ((1ull << lane) - 1ull))] = make_int2(cIdx, plid);
+            q_tail += total;
             q_head += nent;
-            sync();
+            __threadfence_block();
+            __syncthreads();
         }
+        if (tid == 0) { s_scalar[2] = q_tail; if (err) s_scalar[1] = err; }
     }
+    __syncthreads();
+    err = s_scalar[1];
+    mark();
 
-    // ---- final ahCluster over the surviving planes (:319-326), relabel (:327-372) ----
+    // ---- final ahCluster over the surviving planes (:319-326): wave 0 ----
     const int n_old = n_ext;
-    for (int q = lane; q < n_old; q += 64) s_old[q] = s_ext[q];
-    sync();
-    // neighbour lists (ascending NODE id == std::set<PlaneSeg*> order) from the bit matrix; fresh pool region
-    pool_top = 0;   // every list is empty after ahCluster (all nodes were disconnected), the pool can be reused
-    for (int q = lane; q < n_old; q += 64) {
-        const int id = s_old[q];
-        const int off = q * MAX_PLANES;
-        int c = 0;
-        for (int r = 0; r < n_old; r++)
-            if (s_adj[q][r >> 5] & (1u << (r & 31))) list_insert(S.pool + off, c, s_old[r]);
-        S.nb_off[id] = off; S.nb_cnt[id] = c; S.nb_cap[id] = MAX_PLANES;
-    }
-    pool_top = n_old * MAX_PLANES;
-    sync();
-    n_ext = 0;
-    heap_n = 0;
-    for (int q = 0; q < n_old; q++) if (s_valid[q]) heap_push(s_old[q]);
-    if (!err) ah_cluster();
-    for (int q = lane; q < n_old; q += 64) {
-        int m = -1;
-        if (s_valid[q]) {
-            const int np_rid = ds_find(S.parent, S.rid[s_old[q]]);
-            for (int j = 0; j < n_ext; j++) if (S.rid[s_ext[j]] == np_rid) { m = j; break; }
+    if (wave == 0) {
+        for (int q = lane; q < n_old; q += 64) s_old[q] = s_ext[q];
+        wfence();
+        // neighbour lists in ascending NODE id (== std::set<PlaneSeg*> order) from the bit matrix.  Every list is empty
+        // after the first ahCluster (all nodes were disconnected), so the pool is reused from the start.
+        for (int q = lane; q < n_old; q += 64) {
+            const int id = s_old[q];
+            const int off = q * n_old;
+            int c = 0;
+            for (int r = 0; r < n_old; r++)
+                if (s_adj[q][r >> 5] & (1u << (r & 31))) lst_insert(S.pool + off, c, s_old[r]);
+            S.nb_off[id] = (u16)off; S.nb_cnt[id] = (u16)c;
         }
-        s_plidmap[q] = m;
+        pool_top = n_old * n_old;
+        wfence();
+        n_ext = 0;
+        heap_n = 0;
+        for (int q = 0; q < n_old; q++) if (s_valid[q]) heap_push(s_old[q], geo_of(s_old[q])[6]);
+        if (!err) ah_cluster();
+        for (int q = lane; q < n_old; q += 64) {
+            int m = -1;
+            if (s_valid[q]) {
+                const int np_rid = lds_find(S.dsp, S.rid[s_old[q]]);
+                for (int j = 0; j < n_ext; j++) if (S.rid[s_ext[j]] == np_rid) { m = j; break; }
+            }
+            s_plidmap[q] = m;
+        }
+        if (lane == 0) { s_scalar[0] = n_ext; if (err) s_scalar[1] = err; }
     }
-    sync();
-    for (int i = lane; i < W * H; i += 64) {
+    __threadfence_block();
+    __syncthreads();
+    n_ext = s_scalar[0]; err = s_scalar[1];
+
+    // ---- relabel (:327-372) and plane parameters, all threads ----
+    for (int i = tid; i < W * H; i += NT) {
         const int plid = member[i];
         lab[i] = (plid >= 0 && s_plidmap[plid] >= 0) ? s_plidmap[plid] : -1;
     }
-    for (int j = lane; j < n_ext; j += 64) {
+    for (int j = tid; j < n_ext; j += NT) {
         const int id = s_ext[j];
         double* o = planes + ((size_t)frame * MAX_PLANES + j) * 8;
-        o[0] = (double)S.N[id];
-        for (int t = 0; t < 3; t++) { o[1 + t] = S.geo[(size_t)id * 7 + 3 + t]; o[4 + t] = S.geo[(size_t)id * 7 + t]; }
-        o[7] = S.geo[(size_t)id * 7 + 6];
+        o[0] = (double)g_N[id];
+        for (int t = 0; t < 3; t++) { o[1 + t] = geo_of(id)[3 + t]; o[4 + t] = geo_of(id)[t]; }
+        o[7] = geo_of(id)[6];
     }
-    if (lane == 0) { n_planes[frame] = n_ext; status[frame] = err; }
+    mark();
+    if (tid == 0) {
+        n_planes[frame] = n_ext; status[frame] = err;
+        if (timing) {
+            for (int t = 0; t < 8; t++) timing[(size_t)frame * 16 + t] = t < nph ? tphase[t] - tphase[0] : 0;
+            timing[(size_t)frame * 16 + 8] = s_scalar[2]; timing[(size_t)frame * 16 + 9] = n_nodes;
+            for (int t = 0; t < 6; t++) timing[(size_t)frame * 16 + 10 + t] = cyc[t];
+        }
+    }
 }
 
 }  // namespace peac
@@ -686,7 +749,7 @@ struct planar_peac {
     peac::Layout L{};
     peac::Consts C{};
     int smem = 0;
-    DevBuf d_ws, d_status;
+    DevBuf d_ws, d_status, d_timing;
     DevBuf d_depth, d_labels, d_planes, d_nplanes;   // staging for the host-pointer entry point
 };
 
@@ -703,7 +766,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     o->ctx = ctx; o->W = width; o->H = height; o->max_batch = max_batch;
     peac::Layout& L = o->L;
     L.W = width; L.H = height; L.Nw = width / peac::WIN; L.Nh = height / peac::WIN; L.NB = L.Nw * L.Nh; L.NB2 = 2 * L.NB;
-    L.pool_cap = std::max(32 * L.NB, 4 * L.NB + peac::MAX_PLANES * peac::MAX_PLANES);
+    L.pool_cap = 4 * L.NB + std::max(4 * L.NB, peac::MAX_PLANES * peac::MAX_PLANES);   // u16 entries, in LDS
     L.q_cap = 2 * width * height;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o2 = off; off = align_up(off + bytes, (size_t)256); return o2; };
@@ -714,8 +777,8 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 8);
     L.off_seedcnt = carve((size_t)L.NB * 4);
     L.frame_bytes = off;
-    o->smem = L.NB2 * 8 + L.NB * 4;
-    if (o->smem > 150 * 1024) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
+    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 4 + L.NB * 4 + L.NB2 * 2 + ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
+    if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
     const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
     o->C.ang_near = 15.0 * deg;
@@ -724,7 +787,8 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     o->C.cos_merge = std::cos(60.0 * deg);
     o->C.cos_refine = std::cos(30.0 * deg);
     int rc;
-    if ((rc = o->d_ws.alloc((size_t)max_batch * L.frame_bytes)) || (rc = o->d_status.alloc((size_t)max_batch * 4))) { delete o; return rc; }
+    if ((rc = o->d_ws.alloc((size_t)max_batch * L.frame_bytes)) || (rc = o->d_status.alloc((size_t)max_batch * 4)) ||
+        (rc = o->d_timing.alloc((size_t)max_batch * 128))) { delete o; return rc; }
     if (o->smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)peac::peac_segment, hipFuncAttributeMaxDynamicSharedMemorySize, o->smem);
         if (e != hipSuccess) { delete o; set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
@@ -744,13 +808,22 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     hipStream_t st = p->ctx->stream;
     const peac::Intr K{fx, fy, cx, cy, depth_factor};
     hipLaunchKernelGGL(peac::peac_blocks, dim3((p->L.NB + 63) / 64, B), dim3(64), 0, st, p->L, K, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>());
-    hipLaunchKernelGGL(peac::peac_segment, dim3(B), dim3(64), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>(),
-                       d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>());
+    hipLaunchKernelGGL(peac::peac_segment, dim3(B), dim3(peac::NT), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>(),
+                       d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
 }
 
 // Returns PLANAR_ECAPACITY if a frame overflowed an internal capacity (node pool, flood-fill queue, > MAX_PLANES planes).
+// Debug/profiling: per-frame phase timestamps of the last call (100 MHz wall clock ticks since kernel entry):
+// [1] graph edges, [2] heap built, [3]/[4] ahCluster done, [5] seeds done, [6] floodFill done, [7] end, [8] queue entries, [9] nodes
+int planar_peac_read_timing(planar_peac* p, int B, int64_t* out) {
+    PLANAR_REQUIRE(p && out && B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "bad argument");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    PLANAR_HIP_CHECK(hipMemcpy(out, p->d_timing.p, (size_t)B * 128, hipMemcpyDeviceToHost));
+    return PLANAR_OK;
+}
+
 int planar_peac_check(planar_peac* p, int B) {
     PLANAR_REQUIRE(p && B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "bad argument");
     std::vector<int32_t> st(B);
