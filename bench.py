@@ -3,17 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-A "step" = one pass of the hot path over one batch of `--batch` synthetic 640x480 frames that are
-already resident in HBM.  Frames are independent, so ranks shard them with no data-path collective
-("scaling": "weak": every rank processes its own `--batch` frames per step).  Rank 0 prints ONE JSON
-line carrying the whole-job frames/s, the roofline of the dominant kernel (HIP events recorded on the
-stream the kernels run on, inside the timed region) and a CPU baseline (the oracle restatement of
-the reference path, timed on this box's host cores on a bounded sample).
+A "step" = one pass of the hot path over one batch of `--batch` synthetic 640x480 RGB-D frames that are already
+resident in HBM: ORB extraction + PEAC plane segmentation (extract), MatchORBPoints against the previous batch's
+descriptors (match) and the 4x10 PoseOptimization protocol on a config-4-shaped problem per frame (pose-opt).
+Frames are independent, so ranks shard them with no data-path collective ("scaling": "weak": every rank processes
+its own `--batch` frames per step).  Rank 0 prints ONE JSON line: whole-job frames/s, per-stage times, the roofline
+of the dominant kernel (HIP events on the stream the kernels run on, inside the timed region) and a CPU baseline
+(the oracle restatement of the same stages, timed on this box's host cores on a bounded sample).
 
-What the workload covers is named in config.workload; stages not yet built are listed in
-config.not_yet_in_workload — the number is NOT the full extract+match+pose-opt rate yet.
+--workload orb restricts the step to BASELINE config[1] (ORB only).  Stages of the metric that are not built yet are
+listed in config.not_yet_in_workload; the number is NOT the complete extract+match+pose-opt rate until that is empty.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -24,34 +26,30 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 W, H = 640, 480
+NPTS, NLINES, NPLANES = 1000, 75, 4          # BASELINE config 4: 1000 point + 150 line-endpoint + 12 plane edges
 
 
-def orb_algorithmic_bytes(ex):
-    """Algorithmic HBM bytes per frame per kernel launch: each input read once,
-    each output written once, nothing for data that could stay on chip."""
-    sizes = [ex.level_size(l) for l in range(ex.nlevels)]
-    px = [w * h for w, h in sizes]
-    kp = 1000
-    per = {
+def orb_algorithmic_bytes(ex, avg_kp):
+    """Algorithmic HBM bytes per frame per kernel launch."""
+    px = [w * h for w, h in (ex.level_size(l) for l in range(ex.nlevels))]
+    return {
         "orb_copy_level0": 2 * px[0],
-        # average over the nlevels-1 launches: read level l-1, write level l
         "orb_resize": sum(px[l - 1] + px[l] for l in range(1, ex.nlevels)) / max(1, ex.nlevels - 1),
-        "orb_fast_cells": sum(px),                 # every level read once; survivors are a few KB
-        "orb_sort": 0,                             # filled from the measured candidate count below
-        "orb_octree": 0,
+        "orb_fast_cells": sum(px),
+        "orb_sort": 0, "orb_octree": 0,
         "orb_blur": 2 * sum(px),
-        "orb_describe": kp * (709 + 512 + 60),     # IC_Angle disc + 512 BRIEF taps + keypoint/descriptor out
+        "orb_describe": avg_kp * (709 + 512 + 60),
     }
-    return per, sum(px)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--workload", choices=["full", "orb"], default="full")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -65,29 +63,79 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=dev)
 
-    from planarslam_amd import Context, ORBextractor
-    from planarslam_amd.synth import gray_image
+    from planarslam_amd import Context, ORBextractor, Optimizer, PlaneDetection
+    from planarslam_amd._lib import PoseBatch, check, lib
+    from planarslam_amd.synth import TUM3, depth_image, gray_image, pose_batch
 
     B = args.batch
+    full = args.workload == "full"
     stream = torch.cuda.Stream(device=local_rank)
     ctx = Context(local_rank, stream=stream.cuda_stream)
+    L = lib()
+
+    # ---- inputs resident in HBM (synthetic; distinct per rank, 16 distinct frames tiled over the batch) ----
+    nsrc = min(B, 16)
+    rep = lambda a: np.concatenate([a] * ((B + len(a) - 1) // len(a)))[:B]
+    gray_src = np.stack([gray_image(1234 + 16 * rank + i) for i in range(nsrc)])
+    frames = torch.from_numpy(rep(gray_src)).to(dev)
     ex = ORBextractor(1000, 1.2, 8, 20, 7, width=W, height=H, max_batch=B, ctx=ctx)
+    d_kps = torch.zeros((B, ex.kp_cap, 7), dtype=torch.float32, device=dev)
+    d_desc = [torch.zeros((B, ex.kp_cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]   # current / previous batch
+    d_n = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    if full:
+        depth_src = np.stack([depth_image(4321 + 16 * rank + i) for i in range(nsrc)])
+        depth = torch.from_numpy(rep(depth_src).view(np.int16)).to(dev)
+        pd = PlaneDetection(W, H, max_batch=B, ctx=ctx)
+        d_lab = torch.zeros((B, H * W), dtype=torch.int32, device=dev)
+        d_pl = torch.zeros((B, pd.max_planes, 8), dtype=torch.float64, device=dev)
+        d_npl = torch.zeros(B, dtype=torch.int32, device=dev)
+        # matcher state
+        has_mp = torch.ones((B, ex.kp_cap), dtype=torch.uint8, device=dev)
+        outl = torch.zeros((B, ex.kp_cap), dtype=torch.uint8, device=dev)
+        cur_match = torch.full((B, ex.kp_cap), -1, dtype=torch.int32, device=dev)
+        npair = torch.zeros(B, dtype=torch.int32, device=dev)
+        # pose problems (config 4 shape)
+        pbn = pose_batch(B=nsrc, n_points=NPTS, n_lines=NLINES, n_planes=NPLANES, seed=7 + 100 * rank)
+        keep = {}
+        pb = PoseBatch()
+        pb.B, pb.max_points, pb.max_lines, pb.max_planes = B, NPTS, NLINES, NPLANES
+        for k in ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid", "ln_obs", "ln_xw",
+                  "pl_meas", "pl_valid", "pl_world"):
+            keep[k] = torch.from_numpy(rep(pbn[k])).to(dev)
+            setattr(pb, k, keep[k].data_ptr())
+        keep["Tcw"] = torch.from_numpy(rep(pbn["Tcw"])).to(dev)
+        pb.Tcw_in = keep["Tcw"].data_ptr()
+        outs = dict(Tcw_out=torch.zeros((B, 16), dtype=torch.float32, device=dev), pt_outlier=torch.zeros((B, NPTS), dtype=torch.uint8, device=dev),
+                    ln_outlier=torch.zeros((B, NLINES), dtype=torch.uint8, device=dev), pl_outlier=torch.zeros((B, NPLANES, 3), dtype=torch.uint8, device=dev),
+                    n_inliers=torch.zeros(B, dtype=torch.int32, device=dev), lm_iters=torch.zeros(B, dtype=torch.int32, device=dev))
+        for k, v in outs.items():
+            setattr(pb, k, v.data_ptr())
+        opt = Optimizer(TUM3, ctx=ctx)
 
-    # synthetic frames, distinct per rank; 16 distinct images tiled over the batch
-    base = np.stack([gray_image(1234 + 16 * rank + i) for i in range(min(B, 16))])
-    frames = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]).cuda(local_rank)
-    d_kps = torch.zeros((B, ex.kp_cap, 7), dtype=torch.float32, device=frames.device)
-    d_desc = torch.zeros((B, ex.kp_cap, 32), dtype=torch.uint8, device=frames.device)
-    d_n = torch.zeros(B, dtype=torch.int32, device=frames.device)
+    stage_names = ["orb_extract"] + (["peac_extract", "match_orb_points", "pose_opt_4x10"] if full else [])
+    nst = len(stage_names)
 
-    def step():
-        ex.extract_dev(frames.data_ptr(), d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), B)
+    def step(i, evs=None):
+        cur, prev = i & 1, (i & 1) ^ 1
+        if evs: evs[0].record(stream)
+        ex.extract_dev(frames.data_ptr(), d_kps.data_ptr(), d_desc[cur].data_ptr(), d_n[cur].data_ptr(), B)
+        if evs: evs[1].record(stream)
+        if full:
+            pd.segment_dev(depth.data_ptr(), d_lab.data_ptr(), d_pl.data_ptr(), d_npl.data_ptr(), B)
+            if evs: evs[2].record(stream)
+            check(L.planar_match_orb_points_dev(ctx.h, d_desc[cur].data_ptr(), d_n[cur].data_ptr(), ex.kp_cap, d_desc[prev].data_ptr(),
+                                                d_n[prev].data_ptr(), ex.kp_cap, has_mp.data_ptr(), outl.data_ptr(), B, cur_match.data_ptr(),
+                                                npair.data_ptr()))
+            if evs: evs[3].record(stream)
+            opt.enqueue_dev(pb, 0, 4, 10)
+            if evs: evs[4].record(stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -96,71 +144,102 @@ def main():
         torch.cuda.synchronize()
 
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
+        for i in range(args.warmup):
+            step(i)
         ex.set_profiling(True)
+        evsets = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(args.steps)]
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for i in range(args.steps):
+            step(args.warmup + i, evsets[i])
         barrier()
         elapsed = time.perf_counter() - t0
         prof, calls = ex.get_profile()
         ex.set_profiling(False)
+    if full:
+        pd.L.planar_peac_check(pd.h, B)
 
+    stage_ms = {n: sum(e[k].elapsed_time(e[k + 1]) for e in evsets) / args.steps for k, n in enumerate(stage_names)}
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=frames.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_kp = int(d_n.sum().item())
+    n_kp = int(d_n[(args.warmup + args.steps - 1) & 1].sum().item())
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
     fps = world * B * args.steps / elapsed
-    # ---- roofline of the dominant kernel (largest summed HIP-event time in the timed region) ----
-    per, px_total = orb_algorithmic_bytes(ex)
     avg_kp = n_kp / B
-    per["orb_describe"] = avg_kp * (709 + 512 + 60)
-    dom = max(prof, key=lambda k: prof[k][0])
-    dom_ms_total, dom_launches = prof[dom]
-    avg_launch_ms = dom_ms_total / max(1, dom_launches)
-    alg_bytes_launch = per.get(dom, 0) * B
-    achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    # ---- kernels: per-launch HIP-event times (ORB kernels individually; the other stages are one or two launches each) ----
     kernels = {k: {"ms_per_step": round(v[0] / max(1, calls), 4), "launches_per_step": v[1] // max(1, calls)} for k, v in prof.items()}
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_launch_ms": round(avg_launch_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-                "pipeline_algorithmic_GBps": round(1961064 * fps / 1e9, 2), "kernels": kernels}
+    alg = orb_algorithmic_bytes(ex, avg_kp)
+    cand = {k: (v[0] / max(1, v[1]), alg.get(k, 0) * B) for k, v in prof.items()}          # (avg launch ms, algorithmic bytes per launch)
+    if full:
+        avg_planes = float(d_npl.float().mean().item())
+        # PEAC: read u16 depth + write int32 labels (1 843 200 B/frame); peac_blocks + peac_segment timed together
+        cand["peac_blocks+peac_segment"] = (stage_ms["peac_extract"], 1843200 * B)
+        kernels["peac_blocks+peac_segment"] = {"ms_per_step": round(stage_ms["peac_extract"], 4), "launches_per_step": 2}
+        cand["hamming_knn+match_orb_points"] = (stage_ms["match_orb_points"], (64000 + 8000) * B)
+        kernels["hamming_knn+match_orb_points"] = {"ms_per_step": round(stage_ms["match_orb_points"], 4), "launches_per_step": 2}
+        # pose LM: 65 130 B per frame per LM evaluation; evaluations = LM iterations + trial steps (>= 2 per iteration)
+        lm = float(outs["lm_iters"].float().mean().item())
+        cand["pose_opt_kernel"] = (stage_ms["pose_opt_4x10"], 65130 * B * 2 * lm)
+        kernels["pose_opt_kernel"] = {"ms_per_step": round(stage_ms["pose_opt_4x10"], 4), "launches_per_step": 1, "avg_lm_iterations": round(lm, 2)}
+    dom = max(cand, key=lambda k: cand[k][0] * (kernels[k]["launches_per_step"] if k in prof else 1))
+    dom_ms, dom_bytes = cand[dom]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    per_frame = 1961064 + (1843200 if full else 0) + (72000 + 65130 * 2 * 20 if full else 0)
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(dom_ms, 4),
+                "algorithmic_bytes_per_launch": int(dom_bytes), "pipeline_algorithmic_GBps": round(per_frame * fps / 1e9, 2),
+                "note": "latency/occupancy-bound sequential stage (one workgroup per frame); see DESIGN.md" if dom.startswith("peac") else None,
+                "kernels": kernels}
 
-    # ---- CPU baseline: the oracle restatement of the same workload on this box's host cores ----
+    # ---- CPU baseline: the oracle restatement of the same stages on this box's host cores (1 thread) ----
     cpu = None
     if args.cpu_seconds > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
         o = ol.OrbOracle()
-        o.extract(base[0])
+        o.extract(gray_src[0])
         n, t0 = 0, time.perf_counter()
+        per = {"orb": 0.0, "peac": 0.0, "match": 0.0, "pose": 0.0}
+        prev_desc = o.extract(gray_src[-1])[1]
         while time.perf_counter() - t0 < args.cpu_seconds:
-            o.extract(base[n % len(base)])
+            i = n % nsrc
+            t1 = time.perf_counter(); kp, de = o.extract(gray_src[i]); per["orb"] += time.perf_counter() - t1
+            if full:
+                t1 = time.perf_counter(); ol.peac_run(depth_src[i]); per["peac"] += time.perf_counter() - t1
+                t1 = time.perf_counter()
+                ol.match_orb_points(de, prev_desc, np.ones(len(prev_desc), np.uint8), np.zeros(len(prev_desc), np.uint8), np.full(len(de), -1, np.int32))
+                per["match"] += time.perf_counter() - t1
+                one = {k: (v[i:i + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (nsrc,) else v) for k, v in pbn.items()}
+                t1 = time.perf_counter(); ol.pose_optimize(one, TUM3, 0, 4, 10); per["pose"] += time.perf_counter() - t1
+                prev_desc = de
             n += 1
         dt = time.perf_counter() - t0
         cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{n} frames of the same synthetic set through oracle/orb_oracle.cpp (1 thread, {dt:.1f} s)",
-               "host_cores": os.cpu_count()}
+               "sample": f"{n} frames of the same synthetic set through the oracle/ restatements of the same stages (1 thread, {dt:.1f} s)",
+               "ms_per_frame": {k: round(v / n * 1e3, 2) for k, v in per.items() if v > 0}, "host_cores": os.cpu_count()}
 
+    workload = ("ORB (BASELINE config[1]) + PEAC planes + MatchORBPoints + PoseOptimization 4x10 (config[3] shape: 1000 pt + 150 line-endpoint + 12 plane edges)"
+                if full else "configs[1]: ORB only, 640x480 gray, 8-level pyramid, 1000 keypoints + 256-bit rBRIEF")
     out = {
         "metric": "RGB-D frames/sec (extract+match+pose-opt) @640x480; 1->8-GPU batch scaling",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "configs[1]: ORB only, 640x480 gray, 8-level pyramid, 1000 keypoints + 256-bit rBRIEF",
-                   "frames_per_gpu_per_step": B, "avg_keypoints_per_frame": round(avg_kp, 1),
-                   "not_yet_in_workload": ["LSD/LBD lines", "PEAC planes", "matching", "pose optimisation"],
+        "vs_baseline": None, "dtype": "u8/f64" if full else "u8", "data": "synthetic",
+        "config": {"workload": workload, "frames_per_gpu_per_step": B, "avg_keypoints_per_frame": round(avg_kp, 1),
+                   "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+                   "not_yet_in_workload": (["LSD/LBD line extraction", "SearchByProjection matchers"] if full else
+                                           ["LSD/LBD lines", "PEAC planes", "matching", "pose optimisation"]),
                    "parallelism": f"frame-sharded x{world}, no collective"},
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    if full:
+        out["config"]["avg_planes_per_frame"] = round(avg_planes, 2)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

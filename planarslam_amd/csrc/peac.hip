@@ -200,7 +200,7 @@ constexpr int NT = 256;
 typedef unsigned short u16;
 
 struct Lds {
-    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; u16* dsp; u16* dss; u16* rid; unsigned* nouse; signed char* blk;
+    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; u16* nb_cap; u16* dsp; u16* dss; u16* rid; unsigned* nouse; signed char* blk;
 };
 
 __device__ __forceinline__ int lds_find(u16* parent, int x) {   // DisjointSet::Find with path compression
@@ -247,10 +247,11 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     S.pool = S.h_id + NB;
     S.nb_off = S.pool + L.pool_cap;
     S.nb_cnt = S.nb_off + L.NB2;
-    S.dsp = S.nb_cnt + L.NB2;
+    S.nb_cap = S.nb_cnt + L.NB2;
+    S.dsp = S.nb_cap + L.NB2;
     S.dss = S.dsp + NB;
     S.rid = S.dss + NB;                       // rid of every node (root block id)
-    S.nouse = (unsigned*)(S.rid + L.NB2);     // bit per node: merged away (PlaneSeg::nouse)
+    S.nouse = (unsigned*)(S.rid + L.NB2);     // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
     S.blk = (signed char*)(S.nouse + (L.NB2 + 31) / 32);
 
     __shared__ int s_ext[MAX_PLANES], s_old[MAX_PLANES], s_plidmap[MAX_PLANES];
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     };
 
     // ---- init (all threads) ----
-    for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.rid[b] = (u16)b; }
+    for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.nb_cap[b] = 4; S.rid[b] = (u16)b; }
     for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) S.nouse[t] = 0;
     for (int t = tid; t < MAX_PLANES; t += NT) { s_valid[t] = 0; s_plidmap[t] = -1; }
     for (int t = tid; t < MAX_PLANES * (MAX_PLANES / 32); t += NT) (&s_adj[0][0])[t] = 0;
@@ -358,19 +359,11 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
         wfence();
         return top;
     };
-    auto disconnect_all = [&](int a) {     // PlaneSeg::disconnectAllNbs; every neighbour owns its own list
-        const int cnt = S.nb_cnt[a];
-        const u16* lst = S.pool + S.nb_off[a];
-        for (int k = lane; k < cnt; k += 64) {
-            const int q = lst[k];
-            int c = S.nb_cnt[q];
-            lst_erase(S.pool + S.nb_off[q], c, a);
-            S.nb_cnt[q] = (u16)c;
-        }
-        wfence();
-        if (lane == 0) S.nb_cnt[a] = 0;
-        wfence();
-    };
+    // Neighbour lists use LAZY deletion: a node that leaves the graph (merged away or disconnected) only gets its
+    // `dead` bit set; readers skip dead entries and a list is compacted when it is full.  Lists stay sorted by node
+    // id because new ids are always the largest.
+    auto is_dead = [&](int id) { return (S.nouse[id >> 5] >> (id & 31)) & 1u; };
+    auto mark_dead = [&](int id) { if (lane == 0) S.nouse[id >> 5] |= 1u << (id & 31); wfence(); };   // PlaneSeg::disconnectAllNbs
     auto node_N = [&](int id) { return (int)S.dss[S.rid[id]] * (WIN * WIN); };   // live node: rid is its set's root
     auto extract = [&](int p) {
         if (node_N(p) >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
@@ -383,7 +376,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
             long long c0 = clock64();
             const int p = heap_pop();
             cyc[0] += clock64() - c0; c0 = clock64();
-            if (S.nouse[p >> 5] & (1u << (p & 31))) continue;   // nouse
+            if (is_dead(p)) continue;                           // nouse
             const int cnt = S.nb_cnt[p];
             const u16* lst = S.pool + S.nb_off[p];
             const double* sp = g_stats + (size_t)p * 9;
@@ -400,7 +393,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                 bool ok = false;
                 double ms[9]; Geo mg; int mN = 0, nb = -1;
                 mg.mse = 0;
-                if (k < cnt) {
+                if (k < cnt && !is_dead(lst[k])) {
                     nb = lst[k];
                     // one memory round trip: the neighbour's normal and moments are fetched together
                     const double* gn = geo_of(nb) + 3;
@@ -414,16 +407,30 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                         ok = true;
                     }
                 }
-                unsigned long long m = __ballot(ok);
-                while (m) {                                      // ascending k == ascending node id == std::set order
-                    const int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const double c_mse = __shfl(mg.mse, src);
-                    if (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse)) {   // quirk :1045
-                        have = true; best_mse = c_mse; best_nb = __shfl(nb, src); best_N = __shfl(mN, src);
-                        for (int t = 0; t < 9; t++) best_stats[t] = __shfl(ms[t], src);
-                        for (int t = 0; t < 3; t++) { best_geo.center[t] = __shfl(mg.center[t], src); best_geo.normal[t] = __shfl(mg.normal[t], src); }
-                        best_geo.mse = c_mse;
+                // Reference rule (:1043-1049), candidates in ascending node id: take a candidate if none yet, or its mse is
+                // smaller, or (equal mse and best.N < mse — quirk).  Without exact ties that is "first minimum": a butterfly
+                // arg-min on (mse, lane); exact ties among this round's candidates fall back to the in-order scan.
+                unsigned long long okm = __ballot(ok);
+                if (okm) {
+                    double rm = ok ? mg.mse : 1.7976931348623157e308;
+                    int rl = ok ? lane : 64;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const double om = __shfl_xor(rm, o); const int ol = __shfl_xor(rl, o);
+                        if (om < rm || (om == rm && ol < rl)) { rm = om; rl = ol; }
+                    }
+                    const bool tie = __popcll(__ballot(ok && mg.mse == rm)) > 1;
+                    unsigned long long scan = tie ? okm : (1ull << rl);
+                    while (scan) {
+                        const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)scan) - 1);
+                        scan &= scan - 1;
+                        const double c_mse = __shfl(mg.mse, src);
+                        if (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse)) {   // quirk :1045
+                            have = true; best_mse = c_mse; best_nb = __shfl(nb, src); best_N = __shfl(mN, src);
+                            for (int t = 0; t < 9; t++) best_stats[t] = __shfl(ms[t], src);
+                            for (int t = 0; t < 3; t++) { best_geo.center[t] = __shfl(mg.center[t], src); best_geo.normal[t] = __shfl(mg.normal[t], src); }
+                            best_geo.mse = c_mse;
+                        }
                     }
                 }
             }
@@ -452,61 +459,111 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                 wfence();
                 heap_push(m, best_geo.mse);
                 cyc[2] += clock64() - c0; c0 = clock64();
-                // mergeNbsFrom (AHCPlaneSeg.hpp:379-404): union of the two sorted lists minus {p, nb}
+                // mergeNbsFrom (AHCPlaneSeg.hpp:379-404): union of the two sorted lists minus {p, nb} (both dead by now),
+                // built cooperatively: prefix counts of the surviving entries, then every entry writes itself to its rank.
                 const int ca = S.nb_cnt[p], cb = S.nb_cnt[nb];
-                if (pool_top + ca + cb > L.pool_cap) {          // compact: live merged lists only (rare)
+                const int need = 2 * (ca + cb) + 2 + (ca + cb) / 4 + 8;
+                if (pool_top + need > L.pool_cap) {             // compact the pool: live merged nodes only (rare)
                     if (lane == 0) {
                         int top = 4 * NB;
                         for (int id = NB; id < m; id++) {
-                            const int c = S.nb_cnt[id];
-                            if (c == 0) continue;
-                            const int o = S.nb_off[id];
-                            for (int t = 0; t < c; t++) S.pool[top + t] = S.pool[o + t];
-                            S.nb_off[id] = (u16)top; top += c;
+                            if (is_dead(id) && id != p && id != nb) { S.nb_cnt[id] = 0; continue; }
+                            const int c = S.nb_cnt[id], o = S.nb_off[id];
+                            int n2 = 0;
+                            for (int t = 0; t < c; t++) { const int v = S.pool[o + t]; if (!is_dead(v) || id == p || id == nb) S.pool[top + n2++] = (u16)v; }
+                            S.nb_off[id] = (u16)top; S.nb_cnt[id] = (u16)n2;
+                            if (id != p && id != nb) { const int cap = n2 + max(8, n2 / 4); S.nb_cap[id] = (u16)cap; top += cap; } else top += n2;
                         }
                         s_scalar[3] = top;
                     }
                     wfence();
                     pool_top = s_scalar[3];
-                    if (pool_top + ca + cb > L.pool_cap) { err = 2; break; }
                 }
-                const int off = pool_top;
-                pool_top += ca + cb;
-                if (lane == 0) {
-                    const u16* A = S.pool + S.nb_off[p]; const u16* Bl = S.pool + S.nb_off[nb];
-                    int i = 0, j = 0, n = 0;
-                    while (i < ca || j < cb) {
-                        int v;
-                        if (j >= cb || (i < ca && A[i] < Bl[j])) v = A[i++];
-                        else if (i >= ca || Bl[j] < A[i]) v = Bl[j++];
-                        else { v = A[i]; i++; j++; }
-                        if (v != p && v != nb) S.pool[off + n++] = (u16)v;
+                const int ca2 = S.nb_cnt[p], cb2 = S.nb_cnt[nb];
+                if (pool_top + 2 * (ca2 + cb2) + 2 + (ca2 + cb2) / 4 + 8 > L.pool_cap) { err = 2; break; }
+                const u16* A = S.pool + S.nb_off[p];
+                const u16* Bl = S.pool + S.nb_off[nb];
+                u16* PA = S.pool + pool_top;                    // [ca2+1] exclusive counts of surviving A entries
+                u16* PB = PA + ca2 + 1;                         // [cb2+1] ... of surviving, non-duplicate B entries
+                u16* out = PB + cb2 + 1;
+                int na = 0, nbk = 0;
+                for (int i0 = 0; i0 < ca2; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool keep = i < ca2 && !is_dead(A[i]);
+                    const unsigned long long mk = __ballot(keep);
+                    if (i < ca2) PA[i] = (u16)(na + __popcll(mk & ((1ull << lane) - 1ull)));
+                    na += __popcll(mk);
+                }
+                for (int j0 = 0; j0 < cb2; j0 += 64) {
+                    const int j = j0 + lane;
+                    bool keep = false;
+                    if (j < cb2) {
+                        const int x = Bl[j];
+                        if (!is_dead(x)) {
+                            int lo = 0, hi = ca2;               // duplicate test: x in A (then it is alive there too)
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
+                            keep = !(lo < ca2 && A[lo] == x);
+                        }
                     }
-                    S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n;
+                    const unsigned long long mk = __ballot(keep);
+                    if (j < cb2) PB[j] = (u16)(nbk + __popcll(mk & ((1ull << lane) - 1ull)));
+                    nbk += __popcll(mk);
+                }
+                if (lane == 0) { PA[ca2] = (u16)na; PB[cb2] = (u16)nbk; }
+                wfence();
+                for (int i0 = 0; i0 < ca2; i0 += 64) {
+                    const int i = i0 + lane;
+                    if (i < ca2 && PA[i + 1] != PA[i]) {
+                        const int x = A[i];
+                        int lo = 0, hi = cb2;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (Bl[mid] < x) lo = mid + 1; else hi = mid; }
+                        out[PA[i] + PB[lo]] = (u16)x;
+                    }
+                }
+                for (int j0 = 0; j0 < cb2; j0 += 64) {
+                    const int j = j0 + lane;
+                    if (j < cb2 && PB[j + 1] != PB[j]) {
+                        const int x = Bl[j];
+                        int lo = 0, hi = ca2;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
+                        out[PB[j] + PA[lo]] = (u16)x;
+                    }
                 }
                 wfence();
+                const int n = na + nbk;
+                // move the list down over the scratch counters and reserve some slack for later appends
+                const int off = pool_top;
+                for (int k0 = 0; k0 < n; k0 += 64) {            // forward copy, destination below source: chunk-safe
+                    const int k = k0 + lane;
+                    const int v = k < n ? out[k] : 0;
+                    wfence();
+                    if (k < n) S.pool[off + k] = (u16)v;
+                    wfence();
+                }
+                const int cap = n + max(8, n / 4);
+                pool_top = off + cap;
+                if (lane == 0) { S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n; S.nb_cap[m] = (u16)cap; S.nb_cnt[p] = 0; S.nb_cnt[nb] = 0; }
+                wfence();
                 cyc[3] += clock64() - c0; c0 = clock64();
-                disconnect_all(p);
-                disconnect_all(nb);
-                cyc[4] += clock64() - c0; c0 = clock64();
-                {   // nb->nbs.insert(this): m is the largest id so far -> append (a slot was freed by the erase above)
-                    const int n = S.nb_cnt[m];
+                {   // nb->nbs.insert(this): m is the largest id so far -> append; a full list is compacted first
                     const u16* lstm = S.pool + off;
                     for (int k = lane; k < n; k += 64) {
                         const int q = lstm[k];
-                        const int c = S.nb_cnt[q];
-                        S.pool[S.nb_off[q] + c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
+                        u16* ql = S.pool + S.nb_off[q];
+                        int c = S.nb_cnt[q];
+                        if (c >= S.nb_cap[q]) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
+                        ql[c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
                     }
                 }
                 wfence();
                 cyc[5] += clock64() - c0;
             } else {
                 extract(p);
-                disconnect_all(p);
+                mark_dead(p);
             }
             ++step;
         }
-        while (heap_n > 0 && !err) { const int p = heap_pop(); extract(p); disconnect_all(p); }
+        while (heap_n > 0 && !err) { const int p = heap_pop(); extract(p); mark_dead(p); }
         wfence();
         if (lane == 0) {   // std::sort(extractedPlanes, b->N < a->N): insertion sort (stable)
             for (int i = 1; i < n_ext; i++) {
@@ -690,7 +747,8 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
             int c = 0;
             for (int r = 0; r < n_old; r++)
                 if (s_adj[q][r >> 5] & (1u << (r & 31))) lst_insert(S.pool + off, c, s_old[r]);
-            S.nb_off[id] = (u16)off; S.nb_cnt[id] = (u16)c;
+            S.nb_off[id] = (u16)off; S.nb_cnt[id] = (u16)c; S.nb_cap[id] = (u16)n_old;
+            atomicAnd(&S.nouse[id >> 5], ~(1u << (id & 31)));   // back in the graph
         }
         pool_top = n_old * n_old;
         wfence();
@@ -777,7 +835,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 8);
     L.off_seedcnt = carve((size_t)L.NB * 4);
     L.frame_bytes = off;
-    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 4 + L.NB * 4 + L.NB2 * 2 + ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
+    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 6 + L.NB * 4 + L.NB2 * 2 + ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
     const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
