@@ -55,20 +55,16 @@ def main():
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
+    from planarslam_amd.dist import Ranks, whole_job_fps
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    ranks = Ranks(backend="nccl", device=dev)          # RCCL: barrier + max-over-ranks only (frames shard, no data collective)
+    rank, world = ranks.rank, ranks.world
 
     from planarslam_amd import Context, ORBextractor, Optimizer, PlaneDetection
     from planarslam_amd._lib import PoseBatch, check, lib
@@ -139,8 +135,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
         torch.cuda.synchronize()
 
     with torch.cuda.stream(stream):
@@ -160,17 +155,13 @@ def main():
         pd.L.planar_peac_check(pd.h, B)
 
     stage_ms = {n: sum(e[k].elapsed_time(e[k + 1]) for e in evsets) / args.steps for k, n in enumerate(stage_names)}
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ranks.max_over_ranks(elapsed)
     n_kp = int(d_n[(args.warmup + args.steps - 1) & 1].sum().item())
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        ranks.close()
         return
 
-    fps = world * B * args.steps / elapsed
+    fps = whole_job_fps(world, B, args.steps, elapsed)
     avg_kp = n_kp / B
     # ---- kernels: per-launch HIP-event times (ORB kernels individually; the other stages are one or two launches each) ----
     kernels = {k: {"ms_per_step": round(v[0] / max(1, calls), 4), "launches_per_step": v[1] // max(1, calls)} for k, v in prof.items()}
@@ -241,8 +232,7 @@ def main():
     if full:
         out["config"]["avg_planes_per_frame"] = round(avg_planes, 2)
     print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
