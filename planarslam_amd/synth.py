@@ -186,3 +186,93 @@ def depth_image(seed: int = 4321, w: int = 640, h: int = 480, factor: float = 50
             cx, cy, r = rng.integers(0, w), rng.integers(0, h), rng.integers(8, 40)
             d[(xx - cx) ** 2 + (yy - cy) ** 2 < r * r] = 0
     return d
+
+
+# ----------------------------------------------------------------------------------------------
+# Local bundle adjustment problems, layout of include/planar_abi.h `planar_ba_problem`.
+BE_MONO, BE_STEREO, BE_LINE, BE_PLANE, BE_VER, BE_PAR = range(6)
+
+
+def ba_problem(seed=99, n_kf=10, n_points=2400, n_lines=500, n_planes=100, n_fixed_extra=2, outlier_frac=0.03, pose_noise=(0.01, 0.03),
+               point_noise=0.02):
+    """Keyframes on a 2 m arc looking at a cloud of points / line segments / planes 2-6 m away.  KF 0 is fixed, plus
+    `n_fixed_extra` fixed observers at the end.  Every landmark is seen by 4-10 keyframes.  Returns a dict of numpy arrays
+    (+ 'T_gt' [n_kf,4,4], 'lm_gt' [n_lm,4])."""
+    rng = np.random.default_rng(seed)
+    P = TUM3
+    K = n_kf + n_fixed_extra
+    T_gt = np.zeros((K, 4, 4))
+    for k in range(K):
+        ang = (k / max(1, K - 1) - 0.5) * 0.6
+        Rwc = _rodrigues(np.array([0.0, ang, 0.0])) @ _rodrigues(rng.normal(size=3) * 0.03)
+        c = np.array([2.0 * np.sin(ang), 0.05 * rng.normal(), -2.0 * (1 - np.cos(ang))])
+        T = np.eye(4); T[:3, :3] = Rwc.T; T[:3, 3] = -Rwc.T @ c
+        T_gt[k] = T
+    fixed = np.zeros(K, np.uint8); fixed[0] = 1; fixed[n_kf:] = 1
+    scale = 1.2 ** np.arange(8)
+
+    def proj(T, X):
+        Xc = T[:3, :3] @ X + T[:3, 3]
+        return np.array([Xc[0] / Xc[2] * P["fx"] + P["cx"], Xc[1] / Xc[2] * P["fy"] + P["cy"]]), Xc[2]
+
+    lm_type, lm_gt, e_kf, e_lm, e_type, e_meas, e_is2 = [], [], [], [], [], [], []
+
+    def observers():
+        n = rng.integers(4, min(10, K) + 1)
+        return np.sort(rng.choice(K, n, replace=False))
+
+    def sample_point():
+        return np.array([rng.uniform(-2.5, 2.5), rng.uniform(-1.2, 1.2), rng.uniform(2.0, 6.0)])
+
+    for _ in range(n_points):
+        X = sample_point(); l = len(lm_gt); lm_type.append(0); lm_gt.append(np.append(X, 0))
+        for k in observers():
+            uv, z = proj(T_gt[k], X)
+            if z < 0.3 or not (0 < uv[0] < 640 and 0 < uv[1] < 480):
+                continue
+            o = rng.integers(0, 8); s = scale[o]
+            uv = uv + rng.normal(size=2) * s
+            if rng.random() < outlier_frac:
+                uv = uv + rng.uniform(-40, 40, 2)
+            stereo = rng.random() < 0.85
+            e_kf.append(k); e_lm.append(l); e_type.append(BE_STEREO if stereo else BE_MONO)
+            e_meas.append([uv[0], uv[1], (uv[0] - P["bf"] / z + rng.normal() * 0.5 * s) if stereo else -1, 0]); e_is2.append(1.0 / np.float32(s) ** 2)
+    for _ in range(n_lines):
+        A = sample_point(); Bp = A + rng.normal(size=3) * 0.4
+        la = len(lm_gt); lm_type += [0, 0]; lm_gt += [np.append(A, 0), np.append(Bp, 0)]
+        for k in observers():
+            (pa, za), (pb, zb) = proj(T_gt[k], A), proj(T_gt[k], Bp)
+            if min(za, zb) < 0.3:
+                continue
+            pa = pa + rng.normal(size=2) * 0.7; pb = pb + rng.normal(size=2) * 0.7
+            ln = np.cross(np.append(pa, 1), np.append(pb, 1)); ln /= np.linalg.norm(ln)
+            for lmi in (la, la + 1):          # start edge then end edge, consecutive (the reference pairs them)
+                e_kf.append(k); e_lm.append(lmi); e_type.append(BE_LINE); e_meas.append([ln[0], ln[1], ln[2], 0]); e_is2.append(1.0)
+    for _ in range(n_planes):
+        n = rng.normal(size=3); n /= np.linalg.norm(n); d = rng.uniform(1.0, 4.0)
+        l = len(lm_gt); lm_type.append(1); lm_gt.append(np.append(n, d))
+        for k in observers():
+            R, t = T_gt[k][:3, :3], T_gt[k][:3, 3]
+            nc = R @ n; dc = d - t @ nc
+            a = rng.normal(size=3); a -= a.dot(nc) * nc; a /= np.linalg.norm(a)
+            nm = nc * np.cos(0.004) + a * np.sin(0.004) * rng.normal(); nm /= np.linalg.norm(nm)
+            e_kf.append(k); e_lm.append(l); e_type.append(BE_PLANE); e_meas.append([*nm, dc + rng.normal() * 0.004]); e_is2.append(1.0)
+            if rng.random() < 0.3:      # an extra parallel / vertical association of the same map plane from this keyframe
+                if rng.random() < 0.5:
+                    e_kf.append(k); e_lm.append(l); e_type.append(BE_PAR); e_meas.append([*nm, dc + rng.uniform(0.3, 1.0)]); e_is2.append(1.0)
+                else:
+                    v = np.cross(nm, a); v /= np.linalg.norm(v)
+                    e_kf.append(k); e_lm.append(l); e_type.append(BE_VER); e_meas.append([*v, rng.uniform(0.5, 2.0)]); e_is2.append(1.0)
+    lm_gt = np.array(lm_gt)
+    lm_init = lm_gt.copy()
+    pts = np.array(lm_type) == 0
+    lm_init[pts, :3] += rng.normal(size=(pts.sum(), 3)) * point_noise
+    lm_init[~pts, :3] += rng.normal(size=((~pts).sum(), 3)) * 0.01
+    kf_T = T_gt.copy()
+    for k in range(K):
+        if not fixed[k]:
+            kf_T[k, :3, :3] = _rodrigues(rng.normal(size=3) * pose_noise[0]) @ T_gt[k, :3, :3]
+            kf_T[k, :3, 3] += rng.normal(size=3) * pose_noise[1]
+    return dict(kf_Tcw=kf_T.astype(np.float32).reshape(K, 16), kf_fixed=fixed, lm_type=np.array(lm_type, np.uint8), lm_init=np.ascontiguousarray(lm_init),
+                e_kf=np.array(e_kf, np.int32), e_lm=np.array(e_lm, np.int32), e_type=np.array(e_type, np.uint8),
+                e_meas=np.array(e_meas, np.float64), e_inv_sigma2=np.array(e_is2, np.float32), T_gt=T_gt, lm_gt=lm_gt)

@@ -234,3 +234,19 @@ def peac_run(depth: np.ndarray, fx=535.4, fy=539.2, cx=320.1, cy=247.6, factor=1
     if want_blocks:
         return planes[:min(n, max_planes)].copy(), labels, blocks
     return planes[:min(n, max_planes)].copy(), labels
+
+
+def local_ba(prob, params, its1=5, its2=10):
+    """CPU oracle of the numerical core of Optimizer::LocalBundleAdjustment on a synth.ba_problem()."""
+    L = lib()
+    K, NL, NE = len(prob["kf_fixed"]), len(prob["lm_type"]), len(prob["e_kf"])
+    res = dict(kf_Tcw=np.zeros((K, 16), np.float32), lm=np.zeros((NL, 4), np.float64), e_outlier=np.zeros(NE, np.uint8))
+    chi = C.c_double()
+    prm = pose_params(params)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.orc_local_ba.restype = C.c_int
+    res["lm_iters"] = L.orc_local_ba(C.c_int(K), p(prob["kf_Tcw"]), p(prob["kf_fixed"]), C.c_int(NL), p(prob["lm_type"]), p(prob["lm_init"]), C.c_int(NE),
+                                     p(prob["e_kf"]), p(prob["e_lm"]), p(prob["e_type"]), p(prob["e_meas"]), p(prob["e_inv_sigma2"]), C.byref(prm),
+                                     C.c_int(its1), C.c_int(its2), p(res["kf_Tcw"]), p(res["lm"]), p(res["e_outlier"]), C.byref(chi))
+    res["chi2"] = chi.value
+    return res
