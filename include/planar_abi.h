@@ -216,6 +216,56 @@ int planar_peac_check(planar_peac* peac, int B);
  * [1] graph edges, [2] heap built, [3] ahCluster, [4] seeds, [5] floodFill, [6] end; [8] flood-fill queue entries, [9] nodes). */
 int planar_peac_read_timing(planar_peac* peac, int B, int64_t* out);
 
+/* ---- local bundle adjustment (replaces the numerical core of Optimizer::LocalBundleAdjustment,
+ *      src/Optimizer.cc:1853-2680 / include/Optimizer.h:35: optimize(5) -> outlier levels -> optimize(10) -> erase lists) ---- */
+/* RCCL communicator for the one exchange step on the path: the all-reduce of the reduced camera system when landmarks
+ * are partitioned over GPUs.  Rank 0 creates an id, every rank gets it out of band (e.g. a
+ * torch.distributed broadcast), then all ranks call planar_comm_create. */
+typedef struct planar_comm planar_comm;
+typedef struct planar_comm_id { char internal[128]; } planar_comm_id;   /* == ncclUniqueId */
+int planar_comm_unique_id(planar_comm_id* out);
+int planar_comm_create(planar_ctx* ctx, const planar_comm_id* id, int nranks, int rank, planar_comm** out);
+void planar_comm_destroy(planar_comm* comm);
+
+#define PLANAR_BA_MONO 0      /* g2o::EdgeSE3ProjectXYZ        (types_six_dof_expmap.cpp:103-139)  meas = u, v            */
+#define PLANAR_BA_STEREO 1    /* g2o::EdgeStereoSE3ProjectXYZ  (:188-235)                          meas = u, v, ur        */
+#define PLANAR_BA_LINE 2      /* EdgeLineProjectXYZ            (include/EdgeLine.h:53-153)         meas = line a, b, c    */
+#define PLANAR_BA_PLANE 3     /* g2o::EdgePlane                (g2oAddition/EdgePlane.h:25-126)    meas = plane coeffs    */
+#define PLANAR_BA_VERTICAL 4  /* g2o::EdgeVerticalPlane        (g2oAddition/EdgeVerticalPlane.h:21) meas = plane coeffs   */
+#define PLANAR_BA_PARALLEL 5  /* g2o::EdgeParallelPlane        (g2oAddition/EdgeParallelPlane.h:21) meas = plane coeffs   */
+
+/* The graph the reference assembles at src/Optimizer.cc:1985-2350, as arrays (all HOST pointers).  Keyframes in
+ * ascending mnId; landmarks are 3-dof vertices: MapPoints and the two endpoints of every MapLine (type 0,
+ * VertexSBAPointXYZ) and MapPlanes (type 1, VertexPlane).  The two edges of a line observation (start, end) must be
+ * consecutive.  With a communicator every rank passes ITS landmarks and their edges (keyframes replicated). */
+typedef struct planar_ba_problem {
+    int32_t n_kf;
+    const float* kf_Tcw;          /* [n_kf][16]  KeyFrame::GetPose(), row-major float32                              */
+    const uint8_t* kf_fixed;      /* [n_kf]      setFixed(): mnId == 0 or a fixed camera (:1994, :2007)               */
+    int32_t n_lm;
+    const uint8_t* lm_type;       /* [n_lm]      0 = XYZ vertex, 1 = plane vertex                                    */
+    const double* lm_init;        /* [n_lm][4]   x, y, z, 0  |  plane coefficients (GetWorldPos())                    */
+    int32_t n_edges;
+    const int32_t* e_kf;          /* [n_edges]   keyframe index (vertex 1)                                           */
+    const int32_t* e_lm;          /* [n_edges]   landmark index (vertex 0)                                           */
+    const uint8_t* e_type;        /* [n_edges]   PLANAR_BA_*                                                         */
+    const double* e_meas;         /* [n_edges][4]                                                                    */
+    const float* e_inv_sigma2;    /* [n_edges]   mvInvLevelSigma2[octave] for point edges (ignored otherwise)        */
+} planar_ba_problem;
+
+typedef struct planar_ba_result {
+    float* kf_Tcw;                /* [n_kf][16]  optimised poses (what the reference passes to KeyFrame::SetPose)    */
+    double* lm;                   /* [n_lm][4]   optimised landmarks                                                 */
+    uint8_t* e_outlier;           /* [n_edges]   1 = the observation lands in the reference's erase lists (:2471-2575) */
+    int32_t lm_iterations;        /* LM iterations run                                                               */
+    int32_t stopped;              /* 1 if *stop_flag was seen (pbStopFlag, :1982-1983)                               */
+} planar_ba_result;
+
+/* its1 = 5, its2 = 10 reproduce the reference.  `params` supplies fx, fy, cx, cy, bf and the Plane.* configuration.
+ * comm may be NULL (single GPU).  Synchronous. */
+int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* problem, const planar_pose_params* params, int its1, int its2,
+                    planar_ba_result* result, volatile int* stop_flag, planar_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,53 +167,91 @@ struct BA {
         return true;
     }
 
+    // ---- linear system pieces (block_solver.hpp) ----
+    struct Cpl { int lm, p; double W[6][3]; };
+    std::vector<std::vector<int>> lm_edges, lm_cpl;
+    std::vector<Cpl> cpl;
+    std::vector<double> Hpp, bp, Hll, bl, Dinv;
+
+    void build_system() {   // buildSystem :502-560 (errors must be current)
+        const int L = (int)st.lm.size(), NP = 6 * np;
+        lm_edges.assign(L, {});
+        for (int k : active) lm_edges[edges[k].lm].push_back(k);
+        Hpp.assign((size_t)np * 36, 0.0); bp.assign(NP, 0.0); Hll.assign((size_t)L * 9, 0.0); bl.assign((size_t)L * 3, 0.0);
+        cpl.clear(); lm_cpl.assign(L, {});
+        for (int l = 0; l < L; l++) {
+            for (int k : lm_edges[l]) {
+                Edge& e = edges[k];
+                double A[3][3], B[3][6];
+                linearize(e, A, B);
+                double w = 1;
+                if (e.robust) { double r0; robustify(e, chi2(e), r0, w); }
+                const int p = pidx[e.kf];
+                int ci = -1;
+                if (p >= 0) {
+                    for (int c : lm_cpl[l]) if (cpl[c].p == p) { ci = c; break; }
+                    if (ci < 0) { Cpl c; c.lm = l; c.p = p; std::memset(c.W, 0, sizeof(c.W)); cpl.push_back(c); ci = (int)cpl.size() - 1; lm_cpl[l].push_back(ci); }
+                }
+                for (int i = 0; i < e.dim; i++) {
+                    const double wo = w * e.info[i], r = -e.info[i] * e.err[i] * w;      // omega_r (scaled by rho')
+                    for (int a = 0; a < 3; a++) {
+                        bl[(size_t)l * 3 + a] += A[i][a] * r;
+                        for (int c = 0; c < 3; c++) Hll[(size_t)l * 9 + a * 3 + c] += A[i][a] * wo * A[i][c];
+                    }
+                    if (p >= 0) {
+                        for (int a = 0; a < 6; a++) {
+                            bp[p * 6 + a] += B[i][a] * r;
+                            for (int c = 0; c < 6; c++) Hpp[(size_t)p * 36 + a * 6 + c] += B[i][a] * wo * B[i][c];
+                            for (int c = 0; c < 3; c++) cpl[ci].W[a][c] += B[i][a] * wo * A[i][c];     // Hpl block (pose x landmark)
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // Schur complement (block_solver.hpp:368-430): S = Hpp + lambda I - sum_l W Dinv W^T, bs = bp - sum_l W Dinv bl
+    void schur(double lambda, std::vector<double>& S, std::vector<double>& bs) {
+        const int L = (int)st.lm.size(), NP = 6 * np;
+        S.assign((size_t)NP * NP, 0.0); bs = bp; Dinv.assign((size_t)L * 9, 0.0);
+        for (int p = 0; p < np; p++)
+            for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) S[(size_t)(p * 6 + a) * NP + p * 6 + c] = Hpp[(size_t)p * 36 + a * 6 + c] + (a == c ? lambda : 0.0);
+        for (int l = 0; l < L; l++) {
+            if (lm_edges[l].empty()) continue;
+            double D[3][3], Di[3][3];
+            for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) D[a][c] = Hll[(size_t)l * 9 + a * 3 + c] + (a == c ? lambda : 0.0);
+            const double det = D[0][0] * (D[1][1] * D[2][2] - D[1][2] * D[2][1]) - D[0][1] * (D[1][0] * D[2][2] - D[1][2] * D[2][0]) + D[0][2] * (D[1][0] * D[2][1] - D[1][1] * D[2][0]);
+            const double id = 1.0 / det;
+            Di[0][0] = (D[1][1] * D[2][2] - D[1][2] * D[2][1]) * id; Di[0][1] = (D[0][2] * D[2][1] - D[0][1] * D[2][2]) * id; Di[0][2] = (D[0][1] * D[1][2] - D[0][2] * D[1][1]) * id;
+            Di[1][0] = (D[1][2] * D[2][0] - D[1][0] * D[2][2]) * id; Di[1][1] = (D[0][0] * D[2][2] - D[0][2] * D[2][0]) * id; Di[1][2] = (D[0][2] * D[1][0] - D[0][0] * D[1][2]) * id;
+            Di[2][0] = (D[1][0] * D[2][1] - D[1][1] * D[2][0]) * id; Di[2][1] = (D[0][1] * D[2][0] - D[0][0] * D[2][1]) * id; Di[2][2] = (D[0][0] * D[1][1] - D[0][1] * D[1][0]) * id;
+            for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) Dinv[(size_t)l * 9 + a * 3 + c] = Di[a][c];
+            double db[3];
+            for (int a = 0; a < 3; a++) db[a] = Di[a][0] * bl[(size_t)l * 3] + Di[a][1] * bl[(size_t)l * 3 + 1] + Di[a][2] * bl[(size_t)l * 3 + 2];
+            for (int ci : lm_cpl[l]) {
+                const Cpl& Ci = cpl[ci];
+                double BD[6][3];
+                for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) BD[a][c] = Ci.W[a][0] * Di[0][c] + Ci.W[a][1] * Di[1][c] + Ci.W[a][2] * Di[2][c];
+                for (int a = 0; a < 6; a++) bs[Ci.p * 6 + a] -= Ci.W[a][0] * db[0] + Ci.W[a][1] * db[1] + Ci.W[a][2] * db[2];
+                for (int cj : lm_cpl[l]) {
+                    const Cpl& Cj = cpl[cj];
+                    for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                        S[(size_t)(Ci.p * 6 + a) * NP + Cj.p * 6 + c] -= BD[a][0] * Cj.W[c][0] + BD[a][1] * Cj.W[c][1] + BD[a][2] * Cj.W[c][2];
+                }
+            }
+        }
+    }
+
     void optimize(int iterations) {
         const int L = (int)st.lm.size(), NP = 6 * np;
         if (active.empty()) return;
         double lambda = -1, ni = 2;
         int nBad = 0;
-        // per (landmark, pose) coupling blocks: edges of a landmark grouped by pose
-        std::vector<std::vector<int>> lm_edges(L);
-        for (int k : active) lm_edges[edges[k].lm].push_back(k);
         for (int it = 0; it < iterations; it++) {
             lm_iters++;
             compute_active_errors();
             double currentChi = active_robust_chi2(), tempChi = currentChi;
             const double iniChi = currentChi;
-            // ---- buildSystem ----
-            std::vector<double> Hpp((size_t)np * 36, 0.0), bp(NP, 0.0), Hll((size_t)L * 9, 0.0), bl((size_t)L * 3, 0.0);
-            struct Cpl { int lm, p; double W[6][3]; };
-            std::vector<Cpl> cpl;
-            std::vector<std::vector<int>> lm_cpl(L);
-            for (int l = 0; l < L; l++) {
-                for (int k : lm_edges[l]) {
-                    Edge& e = edges[k];
-                    double A[3][3], B[3][6];
-                    linearize(e, A, B);
-                    double w = 1;
-                    if (e.robust) { double r0; robustify(e, chi2(e), r0, w); }
-                    const int p = pidx[e.kf];
-                    int ci = -1;
-                    if (p >= 0) {
-                        for (int c : lm_cpl[l]) if (cpl[c].p == p) { ci = c; break; }
-                        if (ci < 0) { Cpl c; c.lm = l; c.p = p; std::memset(c.W, 0, sizeof(c.W)); cpl.push_back(c); ci = (int)cpl.size() - 1; lm_cpl[l].push_back(ci); }
-                    }
-                    for (int i = 0; i < e.dim; i++) {
-                        const double wo = w * e.info[i], r = -e.info[i] * e.err[i] * w;      // omega_r (scaled by rho')
-                        for (int a = 0; a < 3; a++) {
-                            bl[(size_t)l * 3 + a] += A[i][a] * r;
-                            for (int c = 0; c < 3; c++) Hll[(size_t)l * 9 + a * 3 + c] += A[i][a] * wo * A[i][c];
-                        }
-                        if (p >= 0) {
-                            for (int a = 0; a < 6; a++) {
-                                bp[p * 6 + a] += B[i][a] * r;
-                                for (int c = 0; c < 6; c++) Hpp[(size_t)p * 36 + a * 6 + c] += B[i][a] * wo * B[i][c];
-                                for (int c = 0; c < 3; c++) cpl[ci].W[a][c] += B[i][a] * wo * A[i][c];     // Hpl block (pose x landmark)
-                            }
-                        }
-                    }
-                }
-            }
+            build_system();
             if (it == 0) {
                 double mx = 0;
                 for (int p = 0; p < np; p++) for (int a = 0; a < 6; a++) mx = std::max(mx, std::fabs(Hpp[(size_t)p * 36 + a * 7]));
@@ -222,37 +260,10 @@ struct BA {
             }
             double rho = 0;
             int qmax = 0;
-            std::vector<double> xp(NP, 0.0), xl((size_t)L * 3, 0.0);
+            std::vector<double> xp(NP, 0.0), xl((size_t)L * 3, 0.0), S, bs;
             do {
                 const State backup = st;
-                // ---- Schur complement (block_solver.hpp:368-430) ----
-                std::vector<double> S((size_t)NP * NP, 0.0), bs(bp), Dinv((size_t)L * 9, 0.0);
-                for (int p = 0; p < np; p++)
-                    for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) S[(size_t)(p * 6 + a) * NP + p * 6 + c] = Hpp[(size_t)p * 36 + a * 6 + c] + (a == c ? lambda : 0.0);
-                for (int l = 0; l < L; l++) {
-                    if (lm_edges[l].empty()) continue;
-                    double D[3][3], Di[3][3];
-                    for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) D[a][c] = Hll[(size_t)l * 9 + a * 3 + c] + (a == c ? lambda : 0.0);
-                    const double det = D[0][0] * (D[1][1] * D[2][2] - D[1][2] * D[2][1]) - D[0][1] * (D[1][0] * D[2][2] - D[1][2] * D[2][0]) + D[0][2] * (D[1][0] * D[2][1] - D[1][1] * D[2][0]);
-                    const double id = 1.0 / det;
-                    Di[0][0] = (D[1][1] * D[2][2] - D[1][2] * D[2][1]) * id; Di[0][1] = (D[0][2] * D[2][1] - D[0][1] * D[2][2]) * id; Di[0][2] = (D[0][1] * D[1][2] - D[0][2] * D[1][1]) * id;
-                    Di[1][0] = (D[1][2] * D[2][0] - D[1][0] * D[2][2]) * id; Di[1][1] = (D[0][0] * D[2][2] - D[0][2] * D[2][0]) * id; Di[1][2] = (D[0][2] * D[1][0] - D[0][0] * D[1][2]) * id;
-                    Di[2][0] = (D[1][0] * D[2][1] - D[1][1] * D[2][0]) * id; Di[2][1] = (D[0][1] * D[2][0] - D[0][0] * D[2][1]) * id; Di[2][2] = (D[0][0] * D[1][1] - D[0][1] * D[1][0]) * id;
-                    for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) Dinv[(size_t)l * 9 + a * 3 + c] = Di[a][c];
-                    double db[3];
-                    for (int a = 0; a < 3; a++) db[a] = Di[a][0] * bl[(size_t)l * 3] + Di[a][1] * bl[(size_t)l * 3 + 1] + Di[a][2] * bl[(size_t)l * 3 + 2];
-                    for (int ci : lm_cpl[l]) {
-                        const Cpl& Ci = cpl[ci];
-                        double BD[6][3];
-                        for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) BD[a][c] = Ci.W[a][0] * Di[0][c] + Ci.W[a][1] * Di[1][c] + Ci.W[a][2] * Di[2][c];
-                        for (int a = 0; a < 6; a++) bs[Ci.p * 6 + a] -= Ci.W[a][0] * db[0] + Ci.W[a][1] * db[1] + Ci.W[a][2] * db[2];
-                        for (int cj : lm_cpl[l]) {
-                            const Cpl& Cj = cpl[cj];
-                            for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
-                                S[(size_t)(Ci.p * 6 + a) * NP + Cj.p * 6 + c] -= BD[a][0] * Cj.W[c][0] + BD[a][1] * Cj.W[c][1] + BD[a][2] * Cj.W[c][2];
-                        }
-                    }
-                }
+                schur(lambda, S, bs);
                 bool ok2 = NP == 0 ? true : chol_solve(S, NP, bs, xp);
                 if (ok2) {
                     for (int l = 0; l < L; l++) {   // xl = Dinv (bl - Hpl^T xp)
@@ -261,17 +272,19 @@ struct BA {
                         for (int ci : lm_cpl[l]) for (int c = 0; c < 3; c++) for (int a = 0; a < 6; a++) cl[c] -= cpl[ci].W[a][c] * xp[cpl[ci].p * 6 + a];
                         for (int a = 0; a < 3; a++) xl[(size_t)l * 3 + a] = Dinv[(size_t)l * 9 + a * 3] * cl[0] + Dinv[(size_t)l * 9 + a * 3 + 1] * cl[1] + Dinv[(size_t)l * 9 + a * 3 + 2] * cl[2];
                     }
+                    // update (SparseOptimizer::update): poses exp(x)*T, points +=, planes oplus
+                    for (size_t k = 0; k < st.T.size(); k++) if (pidx[k] >= 0) st.T[k] = se3_mul(se3_exp(&xp[pidx[k] * 6]), st.T[k]);
+                    for (int l = 0; l < L; l++) if (!lm_edges[l].empty()) oplus_lm(st.lm[l], &xl[(size_t)l * 3]);
                 }
-                // update (SparseOptimizer::update): poses exp(x)*T, points +=, planes oplus
-                for (size_t k = 0; k < st.T.size(); k++) if (pidx[k] >= 0) st.T[k] = se3_mul(se3_exp(&xp[pidx[k] * 6]), st.T[k]);
-                for (int l = 0; l < L; l++) if (!lm_edges[l].empty()) oplus_lm(st.lm[l], &xl[(size_t)l * 3]);
                 compute_active_errors();
                 tempChi = active_robust_chi2();
                 if (!ok2) tempChi = std::numeric_limits<double>::max();
                 rho = currentChi - tempChi;
                 double scale = 0;
-                for (int j = 0; j < NP; j++) scale += xp[j] * (lambda * xp[j] + bp[j]);
-                for (int l = 0; l < L; l++) if (!lm_edges[l].empty()) for (int a = 0; a < 3; a++) scale += xl[(size_t)l * 3 + a] * (lambda * xl[(size_t)l * 3 + a] + bl[(size_t)l * 3 + a]);
+                if (ok2) {
+                    for (int j = 0; j < NP; j++) scale += xp[j] * (lambda * xp[j] + bp[j]);
+                    for (int l = 0; l < L; l++) if (!lm_edges[l].empty()) for (int a = 0; a < 3; a++) scale += xl[(size_t)l * 3 + a] * (lambda * xl[(size_t)l * 3 + a] + bl[(size_t)l * 3 + a]);
+                }
                 scale += 1e-3;
                 rho /= scale;
                 if (rho > 0 && std::isfinite(tempChi)) {
@@ -297,17 +310,11 @@ SE3 to_se3f(const float* T) {
 }  // namespace
 }  // namespace orc
 
-extern "C" {
-// Flat layout == include/planar_abi.h planar_ba_problem.  e_meas: [n_edges][4] = (u, v, ur, -) | line (a, b, c, -) | plane coefficients.
-// Outputs: kf_out [n_kf][16] float32, lm_out [n_lm][4] double (xyz,0 | plane coefficients), e_outlier [n_edges] = the reference's
-// "to erase" lists (:2471-2575); returns total LM iterations.
-int orc_local_ba(int n_kf, const float* kf_Tcw, const uint8_t* kf_fixed, int n_lm, const uint8_t* lm_type, const double* lm_init,
-                 int n_edges, const int32_t* e_kf, const int32_t* e_lm, const uint8_t* e_type, const double* e_meas,
-                 const float* e_inv_sigma2, const orc::PoseParams* prm, int its1, int its2, float* kf_out, double* lm_out,
-                 uint8_t* e_outlier, double* chi2_out) {
-    using namespace orc;
-    using namespace orc::geom;
-    BA ba;
+namespace orc { namespace {
+void ba_setup(BA& ba, int n_kf, const float* kf_Tcw, const uint8_t* kf_fixed, int n_lm, const uint8_t* lm_type, const double* lm_init,
+              int n_edges, const int32_t* e_kf, const int32_t* e_lm, const uint8_t* e_type, const double* e_meas, const float* e_inv_sigma2,
+              const PoseParams* prm) {
+    using namespace geom;
     ba.fx = prm->fx; ba.fy = prm->fy; ba.cx = prm->cx; ba.cy = prm->cy; ba.bf = prm->bf;
     ba.fixed.assign(kf_fixed, kf_fixed + n_kf);
     ba.pidx.assign(n_kf, -1);
@@ -338,10 +345,48 @@ int orc_local_ba(int n_kf, const float* kf_Tcw, const uint8_t* kf_fixed, int n_l
         }
         ba.edges.push_back(e);
     }
+    for (int k = 0; k < n_edges; k++) ba.active.push_back(k);   // initializeOptimization(): all edges are level 0
+}
+} }
+
+extern "C" {
+// Reduced camera system of the first LM iteration WITHOUT the lambda on the pose diagonal and without Hpp's own lambda:
+// S = Hpp - sum_l W (Hll + lambda I)^-1 W^T, b = bp - sum_l W (Hll + lambda I)^-1 bl, robust chi2 — every term is a sum over
+// landmarks/edges, so per-shard results add up (what the RCCL all-reduce exchanges).  S: [6np x 6np], b: [6np].
+int orc_ba_reduced_system(int n_kf, const float* kf_Tcw, const uint8_t* kf_fixed, int n_lm, const uint8_t* lm_type, const double* lm_init,
+                          int n_edges, const int32_t* e_kf, const int32_t* e_lm, const uint8_t* e_type, const double* e_meas,
+                          const float* e_inv_sigma2, const orc::PoseParams* prm, double lambda, double* S_out, double* b_out, double* chi_out) {
+    using namespace orc;
+    BA ba;
+    ba_setup(ba, n_kf, kf_Tcw, kf_fixed, n_lm, lm_type, lm_init, n_edges, e_kf, e_lm, e_type, e_meas, e_inv_sigma2, prm);
+    ba.compute_active_errors();
+    *chi_out = ba.active_robust_chi2();
+    ba.build_system();
+    std::vector<double> S, bs;
+    ba.schur(0.0, S, bs);            // pose diagonal without lambda ...
+    std::vector<double> S2, bs2;
+    // ... but the landmark blocks need it: redo with lambda and remove it from the pose diagonal
+    ba.schur(lambda, S2, bs2);
+    const int NP = 6 * ba.np;
+    for (int i = 0; i < NP; i++) S2[(size_t)i * NP + i] -= lambda;
+    std::memcpy(S_out, S2.data(), S2.size() * sizeof(double));
+    std::memcpy(b_out, bs2.data(), bs2.size() * sizeof(double));
+    return ba.np;
+}
+
+// Flat layout == include/planar_abi.h planar_ba_problem.  e_meas: [n_edges][4] = (u, v, ur, -) | line (a, b, c, -) | plane coefficients.
+// Outputs: kf_out [n_kf][16] float32, lm_out [n_lm][4] double (xyz,0 | plane coefficients), e_outlier [n_edges] = the reference's
+// "to erase" lists (:2471-2575); returns total LM iterations.
+int orc_local_ba(int n_kf, const float* kf_Tcw, const uint8_t* kf_fixed, int n_lm, const uint8_t* lm_type, const double* lm_init,
+                 int n_edges, const int32_t* e_kf, const int32_t* e_lm, const uint8_t* e_type, const double* e_meas,
+                 const float* e_inv_sigma2, const orc::PoseParams* prm, int its1, int its2, float* kf_out, double* lm_out,
+                 uint8_t* e_outlier, double* chi2_out) {
+    using namespace orc;
+    using namespace orc::geom;
+    BA ba;
+    ba_setup(ba, n_kf, kf_Tcw, kf_fixed, n_lm, lm_type, lm_init, n_edges, e_kf, e_lm, e_type, e_meas, e_inv_sigma2, prm);
     auto thr = [&](const Edge& e) { return e.type == BE_MONO ? 5.991 : (e.type <= BE_LINE ? 7.815 : (e.type == BE_PLANE ? prm->plane_chi : prm->vp_chi)); };
     auto depth_ok = [&](const Edge& e) { return e.type > BE_STEREO || se3_map(ba.st.T[e.kf], ba.st.lm[e.lm].X).z > 0.0; };
-    // initializeOptimization(): all edges (level 0)
-    for (int k = 0; k < n_edges; k++) ba.active.push_back(k);
     ba.optimize(its1);                                            // :2355
     for (size_t k = 0; k < ba.edges.size(); k++) {                // :2363-2462
         Edge& e = ba.edges[k];

@@ -40,6 +40,16 @@ class PoseBatch(C.Structure):
                                   "ln_outlier", "pl_outlier", "n_inliers", "lm_iters")]
 
 
+class BAProblem(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("kf_Tcw", C.c_void_p), ("kf_fixed", C.c_void_p), ("n_lm", C.c_int32), ("lm_type", C.c_void_p),
+                ("lm_init", C.c_void_p), ("n_edges", C.c_int32), ("e_kf", C.c_void_p), ("e_lm", C.c_void_p), ("e_type", C.c_void_p),
+                ("e_meas", C.c_void_p), ("e_inv_sigma2", C.c_void_p)]
+
+
+class BAResult(C.Structure):
+    _fields_ = [("kf_Tcw", C.c_void_p), ("lm", C.c_void_p), ("e_outlier", C.c_void_p), ("lm_iterations", C.c_int32), ("stopped", C.c_int32)]
+
+
 _SIGS = {
     # name: (restype, argtypes)
     "planar_last_error": (C.c_char_p, []),
@@ -77,6 +87,10 @@ _SIGS = {
     "planar_peac_segment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_peac_check": (C.c_int, [C.c_void_p, C.c_int]),
     "planar_peac_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "planar_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "planar_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "planar_comm_destroy": (None, [C.c_void_p]),
+    "planar_local_ba": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(PoseParams), C.c_int, C.c_int, C.POINTER(BAResult), C.c_void_p, C.c_void_p]),
     "planar_pose_opt": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
     "planar_pose_opt_dev": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
 }

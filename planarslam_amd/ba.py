@@ -1,0 +1,73 @@
+"""Host-side mirror of Optimizer::LocalBundleAdjustment's numerical core (reference src/Optimizer.cc:1853-2680) over the
+C ABI, plus the landmark sharding used when the reduced camera system is all-reduced over GPUs."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import BAProblem, BAResult, Context, check, lib
+from .optimizer import make_params
+
+_KEYS = ("kf_Tcw", "kf_fixed", "lm_type", "lm_init", "e_kf", "e_lm", "e_type", "e_meas", "e_inv_sigma2")
+
+
+def shard_problem(prob: dict, rank: int, world: int) -> dict:
+    """Partition LANDMARKS (and every edge of a landmark) round-robin over ranks; keyframes are replicated.  The two endpoint
+    vertices of a line stay together (their edges are classified as a pair).  Returns the rank's sub-problem plus
+    'lm_ids' / 'e_ids' (indices into the full problem) to scatter results back."""
+    L = len(prob["lm_type"])
+    owner = np.zeros(L, np.int64)
+    # line endpoints: consecutive LINE edges (start, end) name the two landmarks of one line -> same group
+    group = np.arange(L)
+    et, el = prob["e_type"], prob["e_lm"]
+    idx = np.nonzero(et == 2)[0]
+    for a, b in zip(idx[0::2], idx[1::2]):
+        group[el[b]] = group[el[a]]
+    uniq, inv = np.unique(group, return_inverse=True)
+    owner = inv % world
+    lm_ids = np.nonzero(owner == rank)[0]
+    remap = -np.ones(L, np.int64); remap[lm_ids] = np.arange(len(lm_ids))
+    e_ids = np.nonzero(owner[el] == rank)[0]
+    out = dict(kf_Tcw=prob["kf_Tcw"], kf_fixed=prob["kf_fixed"], lm_type=prob["lm_type"][lm_ids], lm_init=np.ascontiguousarray(prob["lm_init"][lm_ids]),
+               e_kf=prob["e_kf"][e_ids], e_lm=remap[el[e_ids]].astype(np.int32), e_type=et[e_ids], e_meas=np.ascontiguousarray(prob["e_meas"][e_ids]),
+               e_inv_sigma2=prob["e_inv_sigma2"][e_ids], lm_ids=lm_ids, e_ids=e_ids)
+    return out
+
+
+class Communicator:
+    """planar_comm: RCCL communicator created from an id made on rank 0 (`Communicator.unique_id()`)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(lib().planar_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx: Context, uid: bytes, nranks: int, rank: int):
+        self.L = lib()
+        h = C.c_void_p()
+        self._uid = C.create_string_buffer(uid, 128)
+        check(self.L.planar_comm_create(ctx.h, self._uid, nranks, rank, C.byref(h)))
+        self.h, self.nranks, self.rank = h, nranks, rank
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.planar_comm_destroy(self.h)
+            self.h = None
+
+
+def local_bundle_adjustment(prob: dict, params: dict, its1: int = 5, its2: int = 10, ctx: Context | None = None, comm: Communicator | None = None):
+    """Runs planar_local_ba on a synth.ba_problem()-style dict (or a shard of it).  Returns kf_Tcw, lm, e_outlier, lm_iters."""
+    L = lib()
+    ctx = ctx or Context(0)
+    a = {k: np.ascontiguousarray(prob[k]) for k in _KEYS}
+    K, NL, NE = len(a["kf_fixed"]), len(a["lm_type"]), len(a["e_kf"])
+    out = dict(kf_Tcw=np.zeros((K, 16), np.float32), lm=np.zeros((NL, 4), np.float64), e_outlier=np.zeros(NE, np.uint8))
+    P = BAProblem(K, a["kf_Tcw"].ctypes.data, a["kf_fixed"].ctypes.data, NL, a["lm_type"].ctypes.data, a["lm_init"].ctypes.data, NE,
+                  a["e_kf"].ctypes.data, a["e_lm"].ctypes.data, a["e_type"].ctypes.data, a["e_meas"].ctypes.data, a["e_inv_sigma2"].ctypes.data)
+    R = BAResult(out["kf_Tcw"].ctypes.data, out["lm"].ctypes.data, out["e_outlier"].ctypes.data, 0, 0)
+    prm = make_params(params)
+    check(L.planar_local_ba(ctx.h, C.byref(P), C.byref(prm), its1, its2, C.byref(R), None, comm.h if comm else None))
+    out["lm_iters"], out["stopped"] = R.lm_iterations, R.stopped
+    return out

@@ -1,0 +1,694 @@
+// planarslam_amd/csrc/ba.hip — local bundle adjustment (Schur-complement LM) for MI355X (gfx950) with an RCCL exchange.
+//
+// Replaces the numerical core of Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:1853-2680): from
+// optimizer.initializeOptimization() (:2354) to the outlier lists (:2471-2575).  The graph the reference assembles from
+// KeyFrame / MapPoint / MapLine / MapPlane objects arrives as plain arrays (planar_ba_problem).
+//
+//   ba_errors    thread = edge        FP64 residuals of the active edges (stored, like g2o's _error) + robust chi2
+//   ba_build     thread = landmark    linearise its edges (analytic point/line, numeric plane Jacobians), Hll (3x3), bl,
+//                                     per-edge coupling block W = B^T (w Omega) A (6x3); pose blocks Hpp / bp are summed
+//                                     in LDS per workgroup, then flushed with FP64 atomics
+//   ba_schur     thread = landmark    Dinv = (Hll + lambda I)^-1; S -= W_e Dinv W_f^T, b -= W_e Dinv bl, accumulated in an
+//                                     LDS copy of the reduced system (<= 120 x 120 doubles) per workgroup, then flushed
+//   [exchange]   RCCL all-reduce (sum) of the reduced camera system: landmarks (and all their edges) are partitioned
+//                across GPUs, every GPU then solves the same 6K x 6K system redundantly (29 KB payload)
+//   ba_solve     one workgroup        dense Cholesky of the reduced system in LDS, pose increments
+//   ba_update    thread = landmark    back-substitution x_l = Dinv (bl - W^T x_p), oplus on poses / points / planes
+// LM control (lambda schedule, rho test, retries, stop rules of optimization_algorithm_levenberg.cpp:61-164) runs on the
+// host: one small read-back per trial (BA is ONE problem, not a batch; the exchange is latency-bound anyway).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+#include "common.h"
+#include "geom_dev.h"
+
+namespace planar {
+namespace ba {
+using namespace geomd;
+
+enum { BE_MONO = 0, BE_STEREO = 1, BE_LINE = 2, BE_PLANE = 3, BE_VER = 4, BE_PAR = 5 };
+constexpr int NT = 256;
+constexpr int MAX_NP = 20;          // non-fixed keyframes (reduced system <= 120 x 120 in LDS)
+
+struct Cam { double fx, fy, cx, cy, bf; };
+
+struct Dev {
+    int K, np, L, E;
+    double* T; double* Tbak;                 // [K][8]: quaternion xyzw, translation xyz, pad
+    const int* pidx;                         // [K] hessian block of the keyframe, -1 if fixed
+    double* lm; double* lmbak;               // [L][4]: xyz0 | plane coefficients
+    const uint8_t* lm_type;                  // 0 point, 1 plane
+    const int* lm_start;                     // [L+1] CSR into the (landmark-sorted) edges
+    const int* e_kf; const uint8_t* e_type; const int* e_partner;
+    const double* e_meas;                    // [E][4]
+    const double* e_info;                    // [E][4]: info diag (3) + Huber delta
+    double* e_err;                           // [E][3]
+    uint8_t* e_level;                        // 0 active, 1 outlier
+    uint8_t* e_out;                          // final "to erase" flag
+    double* Hll; double* bl; double* Dinv; double* W; double* xl;   // [L][9] [L][3] [L][9] [E][18] [L][3]
+    double* red;                             // [np*36 Hpp | 6np bp | chi | pad] : summed over ranks at build time
+    double* red2;                            // [NP*NP Schur terms | NP rhs terms | trial chi | landmark scale | pad]
+    double* xp;                              // [NP] + [NP] ok flag / pose scale at the end
+    double* scal;                            // [0] max |diag Hll|
+    Cam cam;
+};
+
+__device__ __forceinline__ SE3 load_T(const double* T, int k) {
+    const double* p = T + (size_t)k * 8;
+    SE3 s; s.r = {p[0], p[1], p[2], p[3]}; s.t = {p[4], p[5], p[6]};
+    return s;
+}
+__device__ __forceinline__ void store_T(double* T, int k, const SE3& s) {
+    double* p = T + (size_t)k * 8;
+    p[0] = s.r.x; p[1] = s.r.y; p[2] = s.r.z; p[3] = s.r.w; p[4] = s.t.x; p[5] = s.t.y; p[6] = s.t.z;
+}
+struct LmV { int type; V3 X; Plane P; };
+__device__ __forceinline__ LmV load_lm(const Dev& D, const double* lm, int l) {
+    const double* p = lm + (size_t)l * 4;
+    LmV v; v.type = D.lm_type[l]; v.X = {p[0], p[1], p[2]}; v.P = Plane{{p[0], p[1], p[2], p[3]}};
+    return v;
+}
+__device__ __forceinline__ void lm_oplus(LmV& v, const double u[3]) {   // types_sba.h:52-56 / VertexPlane::oplusImpl
+    if (v.type == 0) { v.X.x += u[0]; v.X.y += u[1]; v.X.z += u[2]; } else plane_oplus(v.P, u);
+}
+
+__device__ void edge_error(const Dev& D, int type, const SE3& T, const LmV& L, const double* meas, double err[3]) {
+    const Cam& c = D.cam;
+    if (type <= BE_LINE) {
+        const V3 p = qrot(T.r, L.X) + T.t;
+        if (type == BE_MONO) { err[0] = meas[0] - (p.x / p.z * c.fx + c.cx); err[1] = meas[1] - (p.y / p.z * c.fy + c.cy); err[2] = 0; }
+        else if (type == BE_STEREO) {
+            const float invz = (float)(1.0 / p.z);   // float invz quirk (types_six_dof_expmap.cpp:150-157)
+            const double u = p.x * (double)invz * c.fx + c.cx, v = p.y * (double)invz * c.fy + c.cy;
+            err[0] = meas[0] - u; err[1] = meas[1] - v; err[2] = meas[2] - (u - c.bf * (double)invz);
+        } else {
+            const double u = p.x / p.z * c.fx + c.cx, v = p.y / p.z * c.fy + c.cy;
+            err[0] = meas[0] * u + meas[1] * v + meas[2]; err[1] = 0; err[2] = 0;
+        }
+    } else {
+        const Plane local = plane_local(T, L.P, false);
+        const Plane pm = plane_from_double(meas);
+        plane_error(type == BE_PLANE ? 0 : (type == BE_PAR ? 1 : 2), local, pm, err);
+    }
+}
+__device__ __forceinline__ int edge_dim(int type) { return (type == BE_MONO || type >= BE_VER) ? 2 : 3; }
+__device__ __forceinline__ double edge_chi2(int dim, const double* err, const double* info) {
+    double s = 0;
+    for (int i = 0; i < dim; i++) s += err[i] * (info[i] * err[i]);
+    return s;
+}
+__device__ __forceinline__ void huber(double c2, double delta, double& r0, double& r1) {
+    const double dsqr = delta * delta;
+    if (c2 <= dsqr) { r0 = c2; r1 = 1; } else { const double sq = sqrt(c2); r0 = 2 * sq * delta - dsqr; r1 = delta / sq; }
+}
+__device__ __forceinline__ double block_sum(double v, double* lds4) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// landmark of edge e: binary search in the CSR
+__device__ __forceinline__ int edge_landmark(const Dev& D, int e) {
+    int lo = 0, hi = D.L;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (D.lm_start[mid] <= e) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_out) {
+    __shared__ double s4[4];
+    const int e = blockIdx.x * NT + threadIdx.x;
+    double chi = 0;
+    if (e < D.E && D.e_level[e] == 0) {
+        const int l = edge_landmark(D, e);
+        const int type = D.e_type[e];
+        double err[3];
+        edge_error(D, type, load_T(D.T, D.e_kf[e]), load_lm(D, D.lm, l), D.e_meas + (size_t)e * 4, err);
+        for (int i = 0; i < 3; i++) D.e_err[(size_t)e * 3 + i] = err[i];
+        const double c2 = edge_chi2(edge_dim(type), err, D.e_info + (size_t)e * 4);
+        if (robust) { double r0, r1; huber(c2, D.e_info[(size_t)e * 4 + 3], r0, r1); chi = r0; } else chi = c2;
+    }
+    const double tot = block_sum(chi, s4);
+    if (threadIdx.x == 0 && tot != 0) atomicAdd(chi_out, tot);
+}
+
+__global__ __launch_bounds__(NT) void ba_build(Dev D, int robust) {
+    extern __shared__ __attribute__((aligned(16))) double s_pp[];   // [np][42]: Hpp (36) + bp (6)
+    __shared__ double s4[4];
+    const int l = blockIdx.x * NT + threadIdx.x;
+    for (int i = threadIdx.x; i < D.np * 42; i += NT) s_pp[i] = 0;
+    __syncthreads();
+    double maxd = 0;
+    if (l < D.L) {
+        double Hll[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+        const LmV Lm = load_lm(D, D.lm, l);
+        bool any = false;
+        for (int e = D.lm_start[l]; e < D.lm_start[l + 1]; e++) {
+            if (D.e_level[e] != 0) { for (int i = 0; i < 18; i++) D.W[(size_t)e * 18 + i] = 0; continue; }
+            any = true;
+            const int type = D.e_type[e], dim = edge_dim(type), kf = D.e_kf[e], p = D.pidx[kf];
+            const SE3 T = load_T(D.T, kf);
+            const double* meas = D.e_meas + (size_t)e * 4;
+            const double* info = D.e_info + (size_t)e * 4;
+            double err[3] = {D.e_err[(size_t)e * 3], D.e_err[(size_t)e * 3 + 1], D.e_err[(size_t)e * 3 + 2]};
+            double A[3][3], B[3][6];
+            for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) A[i][j] = 0; for (int j = 0; j < 6; j++) B[i][j] = 0; }
+            const Cam& c = D.cam;
+            if (type <= BE_LINE) {
+                const V3 pc = qrot(T.r, Lm.X) + T.t;
+                const M3 R = qmat(T.r);
+                const double x = pc.x, y = pc.y, z = pc.z, z_2 = z * z;
+                if (type == BE_LINE) {          // include/EdgeLine.h:71-114
+                    const double invz = 1.0 / z, invz_2 = invz * invz, lx = meas[0], ly = meas[1], fx = c.fx, fy = c.fy;
+                    B[0][0] = -fy * ly - fx * lx * x * y * invz_2 - fy * ly * y * y * invz_2;
+                    B[0][1] = fx * lx + fx * lx * x * x * invz_2 + fy * ly * x * y * invz_2;
+                    B[0][2] = -fx * lx * y * invz + fy * ly * x * invz;
+                    B[0][3] = fx * lx * invz; B[0][4] = fy * ly * invz; B[0][5] = -(fx * lx * x + fy * ly * y) * invz_2;
+                    const double t0 = fx * lx, t1 = fy * ly, t2 = -(fx * lx * x + fy * ly * y) * invz;
+                    for (int j = 0; j < 3; j++) A[0][j] = invz * (t0 * R.m[0][j] + t1 * R.m[1][j] + t2 * R.m[2][j]);
+                } else {                         // types_six_dof_expmap.cpp:103-139 / :188-235
+                    const double fx = c.fx, fy = c.fy;
+                    B[0][0] = x * y / z_2 * fx; B[0][1] = -(1 + (x * x / z_2)) * fx; B[0][2] = y / z * fx; B[0][3] = -1. / z * fx; B[0][5] = x / z_2 * fx;
+                    B[1][0] = (1 + y * y / z_2) * fy; B[1][1] = -x * y / z_2 * fy; B[1][2] = -x / z * fy; B[1][4] = -1. / z * fy; B[1][5] = y / z_2 * fy;
+                    if (type == BE_MONO) {
+                        const double a02 = -x / z * fx, a12 = -y / z * fy;
+                        for (int j = 0; j < 3; j++) {
+                            A[0][j] = -1. / z * (fx * R.m[0][j] + a02 * R.m[2][j]);
+                            A[1][j] = -1. / z * (fy * R.m[1][j] + a12 * R.m[2][j]);
+                        }
+                    } else {
+                        for (int j = 0; j < 3; j++) {
+                            A[0][j] = -fx * R.m[0][j] / z + fx * x * R.m[2][j] / z_2;
+                            A[1][j] = -fy * R.m[1][j] / z + fy * y * R.m[2][j] / z_2;
+                            A[2][j] = A[0][j] - c.bf * R.m[2][j] / z_2;
+                        }
+                        B[2][0] = B[0][0] - c.bf * y / z_2; B[2][1] = B[0][1] + c.bf * x / z_2; B[2][2] = B[0][2]; B[2][3] = B[0][3]; B[2][5] = B[0][5] - c.bf / z_2;
+                    }
+                }
+            } else {                             // numeric, both vertices (base_binary_edge.hpp:131-198)
+                const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+                for (int d = 0; d < 3; d++) {
+                    double add[3] = {0, 0, 0}, e1[3], e2[3];
+                    add[d] = delta; LmV Lp = Lm; lm_oplus(Lp, add); edge_error(D, type, T, Lp, meas, e1);
+                    add[d] = -delta; LmV Lq = Lm; lm_oplus(Lq, add); edge_error(D, type, T, Lq, meas, e2);
+                    for (int i = 0; i < dim; i++) A[i][d] = scalar * (e1[i] - e2[i]);
+                }
+                if (p >= 0) {
+                    for (int d = 0; d < 6; d++) {
+                        double add[6] = {0, 0, 0, 0, 0, 0}, e1[3], e2[3];
+                        add[d] = delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e1);
+                        add[d] = -delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e2);
+                        for (int i = 0; i < dim; i++) B[i][d] = scalar * (e1[i] - e2[i]);
+                    }
+                }
+            }
+            double w = 1;
+            if (robust) { double r0; huber(edge_chi2(dim, err, info), info[3], r0, w); }
+            double Wb[18];
+            for (int i = 0; i < 18; i++) Wb[i] = 0;
+            for (int i = 0; i < dim; i++) {
+                const double wo = w * info[i], r = -info[i] * err[i] * w;
+                for (int a = 0; a < 3; a++) {
+                    bl[a] += A[i][a] * r;
+                    for (int cc = 0; cc < 3; cc++) Hll[a * 3 + cc] += A[i][a] * wo * A[i][cc];
+                }
+                if (p >= 0) {
+                    for (int a = 0; a < 6; a++) {
+                        atomicAdd(&s_pp[p * 42 + 36 + a], B[i][a] * r);
+                        for (int cc = 0; cc < 6; cc++) atomicAdd(&s_pp[p * 42 + a * 6 + cc], B[i][a] * wo * B[i][cc]);
+                        for (int cc = 0; cc < 3; cc++) Wb[a * 3 + cc] += B[i][a] * wo * A[i][cc];
+                    }
+                }
+            }
+            for (int i = 0; i < 18; i++) D.W[(size_t)e * 18 + i] = Wb[i];
+        }
+        for (int i = 0; i < 9; i++) D.Hll[(size_t)l * 9 + i] = Hll[i];
+        for (int i = 0; i < 3; i++) D.bl[(size_t)l * 3 + i] = bl[i];
+        if (any) maxd = fmax(fabs(Hll[0]), fmax(fabs(Hll[4]), fabs(Hll[8])));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D.np * 42; i += NT) {
+        const int p = i / 42, k = i - p * 42;
+        const double v = s_pp[i];
+        if (v != 0) atomicAdd(k < 36 ? &D.red[(size_t)p * 36 + k] : &D.red[(size_t)D.np * 36 + p * 6 + (k - 36)], v);
+    }
+    for (int o = 32; o > 0; o >>= 1) maxd = fmax(maxd, __shfl_xor(maxd, o));
+    if ((threadIdx.x & 63) == 0 && maxd > 0) atomicMax((unsigned long long*)&D.scal[0], (unsigned long long)__double_as_longlong(maxd));
+    (void)s4;
+}
+
+__device__ __forceinline__ void inv3(const double* H, double lambda, double Di[9]) {   // Matrix3d::inverse (cofactors)
+    const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3], e = H[4] + lambda, f = H[5], g = H[6], h = H[7], i = H[8] + lambda;
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    const double id = 1.0 / det;
+    Di[0] = (e * i - f * h) * id; Di[1] = (c * h - b * i) * id; Di[2] = (b * f - c * e) * id;
+    Di[3] = (f * g - d * i) * id; Di[4] = (a * i - c * g) * id; Di[5] = (c * d - a * f) * id;
+    Di[6] = (d * h - e * g) * id; Di[7] = (b * g - a * h) * id; Di[8] = (a * e - b * d) * id;
+}
+
+__global__ __launch_bounds__(NT) void ba_schur(Dev D, double lambda) {
+    extern __shared__ __attribute__((aligned(16))) double s_S[];    // [NP*NP + NP]
+    const int NP = 6 * D.np, tot = NP * NP + NP;
+    for (int i = threadIdx.x; i < tot; i += NT) s_S[i] = 0;
+    __syncthreads();
+    const int l = blockIdx.x * NT + threadIdx.x;
+    if (l < D.L) {
+        const int e0 = D.lm_start[l], e1 = D.lm_start[l + 1];
+        bool any = false;
+        for (int e = e0; e < e1; e++) any |= D.e_level[e] == 0;
+        if (any) {
+            double Di[9];
+            inv3(D.Hll + (size_t)l * 9, lambda, Di);
+            for (int i = 0; i < 9; i++) D.Dinv[(size_t)l * 9 + i] = Di[i];
+            const double* bl = D.bl + (size_t)l * 3;
+            const double db[3] = {Di[0] * bl[0] + Di[1] * bl[1] + Di[2] * bl[2], Di[3] * bl[0] + Di[4] * bl[1] + Di[5] * bl[2],
+                                  Di[6] * bl[0] + Di[7] * bl[1] + Di[8] * bl[2]};
+            for (int e = e0; e < e1; e++) {
+                const int p = D.pidx[D.e_kf[e]];
+                if (p < 0 || D.e_level[e] != 0) continue;
+                const double* We = D.W + (size_t)e * 18;
+                double BD[18];
+                for (int a = 0; a < 6; a++)
+                    for (int c = 0; c < 3; c++) BD[a * 3 + c] = We[a * 3] * Di[c] + We[a * 3 + 1] * Di[3 + c] + We[a * 3 + 2] * Di[6 + c];
+                for (int a = 0; a < 6; a++) atomicAdd(&s_S[NP * NP + p * 6 + a], -(We[a * 3] * db[0] + We[a * 3 + 1] * db[1] + We[a * 3 + 2] * db[2]));
+                for (int f = e0; f < e1; f++) {
+                    const int q = D.pidx[D.e_kf[f]];
+                    if (q < 0 || D.e_level[f] != 0) continue;
+                    const double* Wf = D.W + (size_t)f * 18;
+                    for (int a = 0; a < 6; a++)
+                        for (int c = 0; c < 6; c++)
+                            atomicAdd(&s_S[(p * 6 + a) * NP + q * 6 + c], -(BD[a * 3] * Wf[c * 3] + BD[a * 3 + 1] * Wf[c * 3 + 1] + BD[a * 3 + 2] * Wf[c * 3 + 2]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tot; i += NT) { const double v = s_S[i]; if (v != 0) atomicAdd(&D.red2[i], v); }
+}
+
+// One workgroup: A = blockdiag(Hpp) + lambda I + Schur terms, rhs = bp + Schur rhs; dense Cholesky in LDS.
+__global__ __launch_bounds__(NT) void ba_solve(Dev D, double lambda) {
+    extern __shared__ __attribute__((aligned(16))) double s_A[];    // [NP*NP] + x[NP]
+    __shared__ int s_ok;
+    const int NP = 6 * D.np, tid = threadIdx.x;
+    double* x = s_A + NP * NP;
+    for (int i = tid; i < NP * NP; i += NT) {
+        const int r = i / NP, c = i - r * NP;
+        double v = D.red2[i];
+        if (r / 6 == c / 6) v += D.red[(size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
+        if (r == c) v += lambda;
+        s_A[i] = v;
+    }
+    for (int i = tid; i < NP; i += NT) x[i] = D.red[(size_t)D.np * 36 + i] + D.red2[NP * NP + i];
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    for (int j = 0; j < NP; j++) {              // right-looking Cholesky, lower triangle
+        if (tid == 0) { const double d = s_A[j * NP + j]; if (!(d > 0)) s_ok = 0; else s_A[j * NP + j] = sqrt(d); }
+        __syncthreads();
+        if (!s_ok) break;
+        const double djj = s_A[j * NP + j];
+        for (int i = j + 1 + tid; i < NP; i += NT) s_A[i * NP + j] /= djj;
+        __syncthreads();
+        for (int t = tid; t < (NP - j - 1) * (NP - j - 1); t += NT) {
+            const int i = j + 1 + t / (NP - j - 1), k = j + 1 + t % (NP - j - 1);
+            if (k <= i) s_A[i * NP + k] -= s_A[i * NP + j] * s_A[k * NP + j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double scale = 0;
+        if (s_ok) {
+            for (int i = 0; i < NP; i++) { double v = x[i]; for (int k = 0; k < i; k++) v -= s_A[i * NP + k] * x[k]; x[i] = v / s_A[i * NP + i]; }
+            for (int i = NP - 1; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < NP; k++) v -= s_A[k * NP + i] * x[k]; x[i] = v / s_A[i * NP + i]; }
+            for (int i = 0; i < NP; i++) { D.xp[i] = x[i]; scale += x[i] * (lambda * x[i] + D.red[(size_t)D.np * 36 + i]); }
+        }
+        D.xp[NP] = s_ok ? 1.0 : 0.0;
+        D.xp[NP + 1] = scale;        // pose part of computeScale()
+    }
+}
+
+__global__ __launch_bounds__(NT) void ba_update(Dev D, double lambda, double* lmscale_out) {
+    __shared__ double s4[4];
+    const int i = blockIdx.x * NT + threadIdx.x;
+    const int NP = 6 * D.np;
+    const bool ok = D.xp[NP] != 0.0;
+    if (i < D.K) {
+        const SE3 T = load_T(D.T, i);
+        store_T(D.Tbak, i, T);
+        if (ok && D.pidx[i] >= 0) { double u[6]; for (int a = 0; a < 6; a++) u[a] = D.xp[D.pidx[i] * 6 + a]; store_T(D.T, i, se3_mul(se3_exp(u), T)); }
+    }
+    double sc = 0;
+    if (i < D.L) {
+        for (int a = 0; a < 4; a++) D.lmbak[(size_t)i * 4 + a] = D.lm[(size_t)i * 4 + a];
+        const int e0 = D.lm_start[i], e1 = D.lm_start[i + 1];
+        bool any = false;
+        for (int e = e0; e < e1; e++) any |= D.e_level[e] == 0;
+        if (any && ok) {
+            const double* bl = D.bl + (size_t)i * 3;
+            double cl[3] = {bl[0], bl[1], bl[2]};
+            for (int e = e0; e < e1; e++) {
+                const int p = D.pidx[D.e_kf[e]];
+                if (p < 0 || D.e_level[e] != 0) continue;
+                const double* We = D.W + (size_t)e * 18;
+                for (int c = 0; c < 3; c++) for (int a = 0; a < 6; a++) cl[c] -= We[a * 3 + c] * D.xp[p * 6 + a];
+            }
+            const double* Di = D.Dinv + (size_t)i * 9;
+            double xl[3];
+            for (int a = 0; a < 3; a++) { xl[a] = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2]; sc += xl[a] * (lambda * xl[a] + bl[a]); }
+            LmV v = load_lm(D, D.lm, i);
+            lm_oplus(v, xl);
+            double* o = D.lm + (size_t)i * 4;
+            if (v.type == 0) { o[0] = v.X.x; o[1] = v.X.y; o[2] = v.X.z; } else for (int a = 0; a < 4; a++) o[a] = v.P.c[a];
+        }
+    }
+    const double tot = block_sum(sc, s4);
+    if (threadIdx.x == 0 && tot != 0) atomicAdd(lmscale_out, tot);
+}
+
+__global__ __launch_bounds__(NT) void ba_restore(Dev D) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i < D.K) for (int a = 0; a < 8; a++) D.T[(size_t)i * 8 + a] = D.Tbak[(size_t)i * 8 + a];
+    if (i < D.L) for (int a = 0; a < 4; a++) D.lm[(size_t)i * 4 + a] = D.lmbak[(size_t)i * 4 + a];
+}
+
+// phase 0: after optimize(5): level = outlier (src/Optimizer.cc:2363-2462); phase 1: final "to erase" flags (:2471-2575)
+__global__ __launch_bounds__(NT) void ba_classify(Dev D, int phase, double planeChi, double vpChi) {
+    const int e = blockIdx.x * NT + threadIdx.x;
+    if (e >= D.E) return;
+    const int type = D.e_type[e];
+    const double c2 = edge_chi2(edge_dim(type), D.e_err + (size_t)e * 3, D.e_info + (size_t)e * 4);
+    bool bad;
+    if (type == BE_LINE) {
+        const int f = D.e_partner[e];
+        const double c2b = f >= 0 ? edge_chi2(3, D.e_err + (size_t)f * 3, D.e_info + (size_t)f * 4) : 0.0;
+        bad = c2 > 7.815 || c2b > 7.815;
+    } else if (type <= BE_STEREO) {
+        const int l = edge_landmark(D, e);
+        const SE3 T = load_T(D.T, D.e_kf[e]);
+        const double* X = D.lm + (size_t)l * 4;
+        const V3 p = qrot(T.r, V3{X[0], X[1], X[2]}) + T.t;
+        bad = c2 > (type == BE_MONO ? 5.991 : 7.815) || !(p.z > 0.0);
+    } else bad = c2 > (type == BE_PLANE ? planeChi : vpChi);
+    if (phase == 0) { if (bad) D.e_level[e] = 1; } else D.e_out[e] = bad ? 1 : 0;
+}
+
+}  // namespace ba
+}  // namespace planar
+
+// ==========================================================================================================
+// RCCL, loaded lazily (torch ships its own librccl; a hard link would put two copies in one process)
+// ==========================================================================================================
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, planar_comm_id, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (h) return true;
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) return false;
+        GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (int (*)(void**, int, planar_comm_id, int))dlsym(h, "ncclCommInitRank");
+        AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+        CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+        GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+        return GetUniqueId && CommInitRank && AllReduce && CommDestroy;
+    }
+} g_rccl;
+constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;   // ncclDataType_t / ncclRedOp_t values (rccl.h)
+}  // namespace
+
+struct planar_comm { planar_ctx* ctx; void* comm; int nranks, rank; };
+
+using namespace planar;
+
+extern "C" {
+
+int planar_comm_unique_id(planar_comm_id* out) {
+    PLANAR_REQUIRE(out != nullptr, PLANAR_EINVAL, "out is null");
+    PLANAR_REQUIRE(g_rccl.load(), PLANAR_EDEVICE, "librccl.so could not be loaded");
+    const int rc = g_rccl.GetUniqueId(out);
+    PLANAR_REQUIRE(rc == 0, PLANAR_EDEVICE, "ncclGetUniqueId failed");
+    return PLANAR_OK;
+}
+
+int planar_comm_create(planar_ctx* ctx, const planar_comm_id* id, int nranks, int rank, planar_comm** out) {
+    PLANAR_REQUIRE(ctx && id && out, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, PLANAR_EINVAL, "bad rank / nranks");
+    PLANAR_REQUIRE(g_rccl.load(), PLANAR_EDEVICE, "librccl.so could not be loaded");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    void* c = nullptr;
+    const int rc = g_rccl.CommInitRank(&c, nranks, *id, rank);
+    if (rc != 0) { set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return PLANAR_EDEVICE; }
+    *out = new planar_comm{ctx, c, nranks, rank};
+    return PLANAR_OK;
+}
+
+void planar_comm_destroy(planar_comm* c) {
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_pose_params* prm, int its1, int its2, planar_ba_result* R,
+                    volatile int* stop_flag, planar_comm* comm) {
+    using namespace planar::ba;
+    PLANAR_REQUIRE(ctx && P && prm && R, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(P->n_kf >= 1 && P->n_lm >= 0 && P->n_edges >= 0, PLANAR_EINVAL, "bad sizes");
+    PLANAR_REQUIRE(P->kf_Tcw && P->kf_fixed && R->kf_Tcw && (P->n_lm == 0 || (P->lm_type && P->lm_init && R->lm)), PLANAR_EINVAL, "null array");
+    PLANAR_REQUIRE(P->n_edges == 0 || (P->e_kf && P->e_lm && P->e_type && P->e_meas && P->e_inv_sigma2 && R->e_outlier), PLANAR_EINVAL, "null edge array");
+    PLANAR_REQUIRE(!comm || comm->ctx == ctx, PLANAR_EINVAL, "communicator belongs to another context");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int K = P->n_kf, L = P->n_lm, E = P->n_edges;
+    std::vector<int> pidx(K, -1);
+    int np = 0;
+    for (int k = 0; k < K; k++) if (!P->kf_fixed[k]) pidx[k] = np++;
+    PLANAR_REQUIRE(np <= MAX_NP, PLANAR_EINVAL, "more than 20 non-fixed keyframes");
+    const int NP = 6 * np;
+    for (int e = 0; e < E; e++) PLANAR_REQUIRE(P->e_kf[e] >= 0 && P->e_kf[e] < K && P->e_lm[e] >= 0 && P->e_lm[e] < L && P->e_type[e] <= BE_PAR, PLANAR_EINVAL, "edge index out of range");
+
+    // ---- host prep: sort edges by landmark (stable), CSR, line partners, information / Huber deltas ----
+    std::vector<int> perm(E), inv(E), lm_start(L + 1, 0);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return P->e_lm[a] < P->e_lm[b]; });
+    for (int i = 0; i < E; i++) { inv[perm[i]] = i; lm_start[P->e_lm[perm[i]] + 1]++; }
+    for (int l = 0; l < L; l++) lm_start[l + 1] += lm_start[l];
+    const double angleInfo = 3282.8 / (prm->angle_info * prm->angle_info), disInfo = prm->distance_info * prm->distance_info;
+    const double dMono = (double)(float)std::sqrt(5.991), dStereo = (double)(float)std::sqrt(7.815);
+    const double dPlane = (double)(float)std::sqrt(prm->plane_chi), dVP = (double)(float)std::sqrt(prm->vp_chi);
+    std::vector<int> e_kf(E), e_partner(E, -1);
+    std::vector<uint8_t> e_type(E);
+    std::vector<double> e_meas((size_t)E * 4), e_info((size_t)E * 4);
+    for (int i = 0; i < E; i++) {
+        const int o = perm[i];
+        e_kf[i] = P->e_kf[o]; e_type[i] = P->e_type[o];
+        for (int a = 0; a < 4; a++) e_meas[(size_t)i * 4 + a] = P->e_meas[(size_t)o * 4 + a];
+        const double is2 = (double)P->e_inv_sigma2[o];
+        double* f = &e_info[(size_t)i * 4];
+        switch (e_type[i]) {
+            case BE_MONO: f[0] = f[1] = is2; f[2] = 0; f[3] = dMono; break;
+            case BE_STEREO: f[0] = f[1] = f[2] = is2; f[3] = dStereo; break;
+            case BE_LINE: f[0] = f[1] = f[2] = 1; f[3] = dStereo; break;
+            case BE_PLANE: f[0] = f[1] = angleInfo; f[2] = disInfo; f[3] = dPlane; break;
+            default: f[0] = f[1] = angleInfo; f[2] = 0; f[3] = dVP; break;      // both VP edges use angleInfo (src/Optimizer.cc:2274-2276)
+        }
+    }
+    // line edges come in consecutive (start, end) pairs in the caller's order (src/Optimizer.cc:2171-2201)
+    for (int o = 0; o < E; o++)
+        if (P->e_type[o] == BE_LINE) {
+            PLANAR_REQUIRE(o + 1 < E && P->e_type[o + 1] == BE_LINE, PLANAR_EINVAL, "line edges must come in (start, end) pairs");
+            e_partner[inv[o]] = inv[o + 1]; e_partner[inv[o + 1]] = inv[o];
+            o++;
+        }
+    std::vector<double> T0((size_t)K * 8, 0.0), lm0((size_t)L * 4);
+    for (int k = 0; k < K; k++) {     // Converter::toSE3Quat (host: same restated kernels as the device, in plain C++)
+        const float* Tm = P->kf_Tcw + 16 * k;
+        double m[3][3];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = (double)Tm[4 * i + j];
+        double q[4];
+        double t = m[0][0] + m[1][1] + m[2][2];
+        if (t > 0) { t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (m[2][1] - m[1][2]) * t; q[1] = (m[0][2] - m[2][0]) * t; q[2] = (m[1][0] - m[0][1]) * t; }
+        else {
+            int i = 0; if (m[1][1] > m[0][0]) i = 1; if (m[2][2] > m[i][i]) i = 2;
+            const int j = (i + 1) % 3, kk = (j + 1) % 3;
+            t = std::sqrt(m[i][i] - m[j][j] - m[kk][kk] + 1.0); q[i] = 0.5 * t; t = 0.5 / t;
+            q[3] = (m[kk][j] - m[j][kk]) * t; q[j] = (m[j][i] + m[i][j]) * t; q[kk] = (m[kk][i] + m[i][kk]) * t;
+        }
+        if (q[3] < 0) for (double& v : q) v = -v;
+        const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        double* o = &T0[(size_t)k * 8];
+        for (int a = 0; a < 4; a++) o[a] = q[a] / n;
+        o[4] = Tm[3]; o[5] = Tm[7]; o[6] = Tm[11];
+    }
+    for (int l = 0; l < L; l++) {
+        double* o = &lm0[(size_t)l * 4];
+        for (int a = 0; a < 4; a++) o[a] = P->lm_init[(size_t)l * 4 + a];
+        if (P->lm_type[l] == 1) {   // Converter::toPlane3D + Plane3D::normalize
+            if (o[3] < 0) for (int a = 0; a < 4; a++) o[a] = -o[a];
+            const double s = 1. / std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+            for (int a = 0; a < 4; a++) o[a] = o[a] * s;
+            if (o[3] < 0.0) for (int a = 0; a < 4; a++) o[a] = -o[a];
+        } else o[3] = 0;
+    }
+
+    // ---- device block ----
+    const size_t nred = (size_t)np * 36 + NP + 2, nred2 = (size_t)NP * NP + NP + 2;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 8), (size_t)256); return o; };
+    const size_t oT = carve((size_t)K * 64), oTb = carve((size_t)K * 64), oP = carve((size_t)K * 4), oLm = carve((size_t)L * 32), oLb = carve((size_t)L * 32),
+                 oLt = carve(L), oLs = carve((size_t)(L + 1) * 4), oEk = carve((size_t)E * 4), oEt = carve(E), oEp = carve((size_t)E * 4),
+                 oEm = carve((size_t)E * 32), oEi = carve((size_t)E * 32), oEe = carve((size_t)E * 24), oEl = carve(E), oEo = carve(E),
+                 oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oDi = carve((size_t)L * 72), oW = carve((size_t)E * 144), oXl = carve((size_t)L * 24),
+                 oR = carve(nred * 8), oR2 = carve(nred2 * 8), oXp = carve((size_t)(NP + 2) * 8), oSc = carve(64);
+    DevBuf buf;
+    int rc = buf.alloc(off);
+    if (rc) return rc;
+    uint8_t* base = buf.as<uint8_t>();
+    PLANAR_HIP_CHECK(hipMemsetAsync(base, 0, off, st));
+    auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
+    PLANAR_HIP_CHECK(up(oT, T0.data(), T0.size() * 8)); PLANAR_HIP_CHECK(up(oP, pidx.data(), (size_t)K * 4));
+    PLANAR_HIP_CHECK(up(oLm, lm0.data(), lm0.size() * 8)); PLANAR_HIP_CHECK(up(oLt, P->lm_type, L)); PLANAR_HIP_CHECK(up(oLs, lm_start.data(), (size_t)(L + 1) * 4));
+    PLANAR_HIP_CHECK(up(oEk, e_kf.data(), (size_t)E * 4)); PLANAR_HIP_CHECK(up(oEt, e_type.data(), E)); PLANAR_HIP_CHECK(up(oEp, e_partner.data(), (size_t)E * 4));
+    PLANAR_HIP_CHECK(up(oEm, e_meas.data(), e_meas.size() * 8)); PLANAR_HIP_CHECK(up(oEi, e_info.data(), e_info.size() * 8));
+    Dev D;
+    D.K = K; D.np = np; D.L = L; D.E = E;
+    D.T = (double*)(base + oT); D.Tbak = (double*)(base + oTb); D.pidx = (const int*)(base + oP); D.lm = (double*)(base + oLm); D.lmbak = (double*)(base + oLb);
+    D.lm_type = base + oLt; D.lm_start = (const int*)(base + oLs); D.e_kf = (const int*)(base + oEk); D.e_type = base + oEt; D.e_partner = (const int*)(base + oEp);
+    D.e_meas = (const double*)(base + oEm); D.e_info = (const double*)(base + oEi); D.e_err = (double*)(base + oEe); D.e_level = base + oEl; D.e_out = base + oEo;
+    D.Hll = (double*)(base + oH); D.bl = (double*)(base + oB); D.Dinv = (double*)(base + oDi); D.W = (double*)(base + oW); D.xl = (double*)(base + oXl);
+    D.red = (double*)(base + oR); D.red2 = (double*)(base + oR2); D.xp = (double*)(base + oXp); D.scal = (double*)(base + oSc);
+    D.cam = Cam{(double)prm->fx, (double)prm->fy, (double)prm->cx, (double)prm->cy, (double)prm->bf};
+
+    const size_t smem_schur = ((size_t)NP * NP + NP) * 8, smem_solve = ((size_t)NP * NP + NP) * 8, smem_build = (size_t)np * 42 * 8;
+    if (smem_schur > 48 * 1024) {
+        PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_schur));
+        PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_solve));
+    }
+    const dim3 gE((E + NT - 1) / NT ? (E + NT - 1) / NT : 1), gL((L + NT - 1) / NT ? (L + NT - 1) / NT : 1), gU((std::max(L, K) + NT - 1) / NT);
+    auto allreduce = [&](double* p, size_t n, int op) -> int {
+        if (!comm || comm->nranks == 1) return PLANAR_OK;
+        const int r = g_rccl.AllReduce(p, p, n, NCCL_FLOAT64, op, comm->comm, st);
+        if (r != 0) { set_error("ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PLANAR_EDEVICE; }
+        return PLANAR_OK;
+    };
+    auto d2h = [&](void* dst, const void* src, size_t bytes) -> int {
+        PLANAR_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+        PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+        return PLANAR_OK;
+    };
+    int lm_iters = 0;
+    bool stopped = false;
+
+    // errors at the current state -> robust chi2 summed over ranks (slot `slot` of red / red2)
+    auto eval_chi = [&](int robust, double* slot, double& chi) -> int {
+        PLANAR_HIP_CHECK(hipMemsetAsync(slot, 0, 8, st));
+        if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, slot);
+        int r = allreduce(slot, 1, NCCL_SUM);
+        if (r) return r;
+        return d2h(&chi, slot, 8);
+    };
+    // SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg
+    auto optimize = [&](int iterations, int robust) -> int {
+        double lambda = -1, ni = 2;
+        int nBad = 0;
+        for (int it = 0; it < iterations; it++) {
+            if (stop_flag && *stop_flag) { stopped = true; break; }          // SparseOptimizer::terminate()
+            lm_iters++;
+            double currentChi = 0;
+            int r;
+            PLANAR_HIP_CHECK(hipMemsetAsync(D.red, 0, nred * 8, st));
+            PLANAR_HIP_CHECK(hipMemsetAsync(D.scal, 0, 8, st));
+            if ((r = eval_chi(robust, D.red + (size_t)np * 36 + NP, currentChi))) return r;
+            PLANAR_HIP_CHECK(hipMemsetAsync(D.red + (size_t)np * 36 + NP, 0, 8, st));
+            if (L) hipLaunchKernelGGL(ba_build, gL, dim3(NT), smem_build, st, D, robust);
+            if ((r = allreduce(D.red, (size_t)np * 36 + NP, NCCL_SUM))) return r;
+            double tempChi = currentChi;
+            const double iniChi = currentChi;
+            std::vector<double> hred((size_t)np * 36 + NP);
+            if (it == 0) {                                                   // computeLambdaInit
+                if ((r = allreduce(D.scal, 1, NCCL_MAX))) return r;
+                double mx = 0;
+                if ((r = d2h(&mx, D.scal, 8))) return r;
+                if (!hred.empty() && (r = d2h(hred.data(), D.red, hred.size() * 8))) return r;
+                for (int p = 0; p < np; p++) for (int a = 0; a < 6; a++) mx = std::max(mx, std::fabs(hred[(size_t)p * 36 + a * 7]));
+                lambda = 1e-5 * mx; ni = 2; nBad = 0;
+            }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                PLANAR_HIP_CHECK(hipMemsetAsync(D.red2, 0, nred2 * 8, st));
+                if (L && NP) hipLaunchKernelGGL(ba_schur, gL, dim3(NT), smem_schur, st, D, lambda);
+                if ((r = allreduce(D.red2, (size_t)NP * NP + NP, NCCL_SUM))) return r;
+                hipLaunchKernelGGL(ba_solve, dim3(1), dim3(NT), smem_solve, st, D, lambda);
+                if (NP == 0 && L) hipLaunchKernelGGL(ba_schur, gL, dim3(NT), 8, st, D, lambda);   // Dinv only
+                hipLaunchKernelGGL(ba_update, gU, dim3(NT), 0, st, D, lambda, D.red2 + (size_t)NP * NP + NP + 1);
+                if ((r = allreduce(D.red2 + (size_t)NP * NP + NP + 1, 1, NCCL_SUM))) return r;
+                if ((r = eval_chi(robust, D.red2 + (size_t)NP * NP + NP, tempChi))) return r;
+                double tail[2], lmscale;
+                if ((r = d2h(tail, D.xp + NP, 16))) return r;
+                if ((r = d2h(&lmscale, D.red2 + (size_t)NP * NP + NP + 1, 8))) return r;
+                const bool ok2 = tail[0] != 0.0;
+                if (!ok2) tempChi = std::numeric_limits<double>::max();
+                rho = currentChi - tempChi;
+                double scale = tail[1] + lmscale + 1e-3;
+                rho /= scale;
+                if (rho > 0 && std::isfinite(tempChi)) {
+                    double alpha = 1. - std::pow((2 * rho - 1), 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                } else {
+                    lambda *= ni; ni *= 2;
+                    hipLaunchKernelGGL(ba_restore, gU, dim3(NT), 0, st, D);
+                }
+                qmax++;
+            } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+            if (nBad >= 3) break;
+        }
+        PLANAR_HIP_CHECK(hipGetLastError());
+        return PLANAR_OK;
+    };
+
+    if ((rc = optimize(its1, 1))) return rc;                                                           // :2354-2355
+    if (!stopped) {
+        if (E) hipLaunchKernelGGL(ba_classify, gE, dim3(NT), 0, st, D, 0, prm->plane_chi, prm->vp_chi);     // :2363-2462
+        if ((rc = optimize(its2, 0))) return rc;                                                       // :2466-2467
+    }
+    if (E) hipLaunchKernelGGL(ba_classify, gE, dim3(NT), 0, st, D, 1, prm->plane_chi, prm->vp_chi);         // :2471-2575
+    PLANAR_HIP_CHECK(hipGetLastError());
+
+    // ---- results ----
+    std::vector<double> Tf((size_t)K * 8), lmf((size_t)L * 4);
+    std::vector<uint8_t> eo(E);
+    PLANAR_HIP_CHECK(hipMemcpyAsync(Tf.data(), D.T, Tf.size() * 8, hipMemcpyDeviceToHost, st));
+    if (L) PLANAR_HIP_CHECK(hipMemcpyAsync(lmf.data(), D.lm, lmf.size() * 8, hipMemcpyDeviceToHost, st));
+    if (E) PLANAR_HIP_CHECK(hipMemcpyAsync(eo.data(), D.e_out, E, hipMemcpyDeviceToHost, st));
+    PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+    for (int k = 0; k < K; k++) {      // SE3Quat -> 4x4 -> float32 (Converter::toCvMat)
+        const double* q = &Tf[(size_t)k * 8];
+        const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2], twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+        const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0], tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+        float* o = R->kf_Tcw + 16 * k;
+        o[0] = (float)(1 - (tyy + tzz)); o[1] = (float)(txy - twz); o[2] = (float)(txz + twy); o[3] = (float)q[4];
+        o[4] = (float)(txy + twz); o[5] = (float)(1 - (txx + tzz)); o[6] = (float)(tyz - twx); o[7] = (float)q[5];
+        o[8] = (float)(txz - twy); o[9] = (float)(tyz + twx); o[10] = (float)(1 - (txx + tyy)); o[11] = (float)q[6];
+        o[12] = o[13] = o[14] = 0; o[15] = 1;
+    }
+    for (int l = 0; l < L; l++) for (int a = 0; a < 4; a++) R->lm[(size_t)l * 4 + a] = (P->lm_type[l] == 0 && a == 3) ? 0.0 : lmf[(size_t)l * 4 + a];
+    for (int i = 0; i < E; i++) R->e_outlier[perm[i]] = eo[i];
+    R->lm_iterations = lm_iters;
+    R->stopped = stopped ? 1 : 0;
+    return PLANAR_OK;
+}
+
+}  // extern "C"

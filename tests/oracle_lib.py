@@ -250,3 +250,18 @@ def local_ba(prob, params, its1=5, its2=10):
                                      C.c_int(its1), C.c_int(its2), p(res["kf_Tcw"]), p(res["lm"]), p(res["e_outlier"]), C.byref(chi))
     res["chi2"] = chi.value
     return res
+
+
+def ba_reduced_system(prob, params, lam=1e-3):
+    """Oracle: reduced camera system (S, b, robust chi2) of the first LM linearisation of a (shard of a) BA problem."""
+    L = lib()
+    K, NL, NE = len(prob["kf_fixed"]), len(prob["lm_type"]), len(prob["e_kf"])
+    npose = int((np.asarray(prob["kf_fixed"]) == 0).sum())
+    S = np.zeros((6 * npose, 6 * npose)); b = np.zeros(6 * npose); chi = C.c_double()
+    prm = pose_params(params)
+    a = {k: np.ascontiguousarray(prob[k]) for k in ("kf_Tcw", "kf_fixed", "lm_type", "lm_init", "e_kf", "e_lm", "e_type", "e_meas", "e_inv_sigma2")}
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    L.orc_ba_reduced_system.restype = C.c_int
+    L.orc_ba_reduced_system(C.c_int(K), p(a["kf_Tcw"]), p(a["kf_fixed"]), C.c_int(NL), p(a["lm_type"]), p(a["lm_init"]), C.c_int(NE), p(a["e_kf"]), p(a["e_lm"]),
+                            p(a["e_type"]), p(a["e_meas"]), p(a["e_inv_sigma2"]), C.byref(prm), C.c_double(lam), p(S), p(b), C.byref(chi))
+    return S, b, chi.value
