@@ -192,6 +192,137 @@ int planar_lsd_search_by_descriptor_dev(planar_ctx* ctx, const uint8_t* d_kf, co
                                         const int32_t* d_n_cur, int cur_stride, const uint8_t* d_kf_has_ml, int B, int32_t* d_cur_match,
                                         int32_t* d_nmatches);
 
+/* ---- guided (projection / vocabulary-node / coefficient) matchers ---------------------------
+ * These reproduce the reference's SEQUENTIAL assignment semantics exactly: probes (map points, last-frame
+ * points, key-frame features) are resolved in the reference's loop order and every assignment updates the
+ * "already matched" state later probes see.  All arrays are batched over B independent frames with fixed
+ * per-frame strides; pointers are HOST pointers for the plain entry points and DEVICE pointers for *_dev
+ * (the view structs themselves are always host memory). */
+#define PLANAR_MAX_LEVELS 16
+#define PLANAR_GRID_COLS 64 /* FRAME_GRID_COLS include/Frame.h:38 */
+#define PLANAR_GRID_ROWS 48 /* FRAME_GRID_ROWS include/Frame.h:37 */
+#define PLANAR_MAX_FRAME_KEYS 4096 /* limit on Frame::N / probes per frame for the guided matchers */
+
+/* The fields of the Frame being matched INTO that the guided matchers read (include/Frame.h). */
+typedef struct planar_frame_view {
+    int32_t B, stride;               /* frames, per-frame capacity of the arrays below                     */
+    const int32_t* n;                /* [B]             Frame::N                                            */
+    const planar_keypoint* keys_un;  /* [B][stride]     mvKeysUn (pt, angle, octave are read)               */
+    const float* u_right;            /* [B][stride]     mvuRight                                            */
+    const uint8_t* desc;             /* [B][stride][32] mDescriptors                                        */
+    const uint8_t* blocked;          /* [B][stride]     mvpMapPoints[i] != NULL && ->Observations() > 0 on entry (NULL = none) */
+    const float* Tcw;                /* [B][16]         mTcw (frame-to-frame variant only)                  */
+    float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY (src/Frame.cc:117-123)              */
+    float grid_w_inv, grid_h_inv;    /* mfGridElementWidthInv / mfGridElementHeightInv                      */
+    float fx, fy, cx, cy, bf, b;     /* Frame::fx.. , mbf, mb                                               */
+    float scale_factors[PLANAR_MAX_LEVELS]; /* mvScaleFactors                                              */
+} planar_frame_view;
+
+/* LastFrame side of ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono). */
+typedef struct planar_last_frame_view {
+    int32_t stride;
+    const int32_t* n;            /* [B]             LastFrame.N                                              */
+    const float* Tcw;            /* [B][16]         LastFrame.mTcw                                           */
+    const uint8_t* usable;       /* [B][stride]     mvpMapPoints[i] != NULL && !mvbOutlier[i]                */
+    const float* xw;             /* [B][stride][3]  mvpMapPoints[i]->GetWorldPos()                           */
+    const int32_t* octave;       /* [B][stride]     mvKeys[i].octave                                         */
+    const float* angle;          /* [B][stride]     mvKeysUn[i].angle                                        */
+    const uint8_t* mp_desc;      /* [B][stride][32] mvpMapPoints[i]->GetDescriptor()                         */
+    const uint8_t* mp_observed;  /* [B][stride]     mvpMapPoints[i]->Observations() > 0                      */
+} planar_last_frame_view;
+
+/* ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) (src/ORBmatcher.cc:1396-1535).
+ *   cur_match[b][i2] (in/out): index i of the LAST-frame keypoint whose MapPoint the reference stores in
+ *       CurrentFrame.mvpMapPoints[i2]; -1 where the rotation check resets it to NULL; untouched otherwise.
+ *   nmatches[b]: the function's return value. */
+int planar_search_by_projection_frame(planar_ctx* ctx, const planar_frame_view* cur, const planar_last_frame_view* last, float th,
+                                      int mono, int check_orientation, int32_t* cur_match, int32_t* nmatches);
+int planar_search_by_projection_frame_dev(planar_ctx* ctx, const planar_frame_view* d_cur, const planar_last_frame_view* d_last, float th,
+                                          int mono, int check_orientation, int32_t* d_cur_match, int32_t* d_nmatches);
+
+/* The MapPoint tracking fields written by Frame::isInFrustum (src/Frame.cc:312-367) and read by
+ * ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:46-130). */
+typedef struct planar_map_probes {
+    int32_t stride;
+    const int32_t* n;            /* [B]             vpMapPoints.size()                                       */
+    const uint8_t* in_view;      /* [B][stride]     mbTrackInView && !isBad()                                */
+    const float* proj_x;         /* [B][stride]     mTrackProjX                                              */
+    const float* proj_y;         /* [B][stride]     mTrackProjY                                              */
+    const float* proj_xr;        /* [B][stride]     mTrackProjXR                                             */
+    const int32_t* level;        /* [B][stride]     mnTrackScaleLevel                                        */
+    const float* view_cos;       /* [B][stride]     mTrackViewCos                                            */
+    const uint8_t* desc;         /* [B][stride][32] GetDescriptor()                                          */
+    const uint8_t* observed;     /* [B][stride]     Observations() > 0                                       */
+} planar_map_probes;
+
+/* match[b][idx] (in/out): index iMP of the map point stored in F.mvpMapPoints[idx]. nn_ratio = mfNNratio. */
+int planar_search_by_projection_map(planar_ctx* ctx, const planar_frame_view* frame, const planar_map_probes* probes, float th,
+                                    float nn_ratio, int32_t* match, int32_t* nmatches);
+int planar_search_by_projection_map_dev(planar_ctx* ctx, const planar_frame_view* d_frame, const planar_map_probes* d_probes, float th,
+                                        float nn_ratio, int32_t* d_match, int32_t* d_nmatches);
+
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:160-292).
+ * The DBoW2 FeatureVectors (node id -> feature indices) are passed as one node id per feature (-1: feature
+ * is in no node), which is what DBoW2's transform(..., levelsup) produces (each feature falls in one node).
+ *   kf_usable[i]  vpMapPointsKF[i] != NULL && !isBad()         kf_angle[i]  pKF->mvKeysUn[i].angle
+ *   f_angle[i]    F.mvKeys[i].angle
+ *   match[b][iF]  (out) index of the key-frame feature whose MapPoint lands in vpMapPointMatches[iF], else -1 */
+int planar_search_by_bow(planar_ctx* ctx, int B, const int32_t* n_kf, int kf_stride, const int32_t* kf_node, const uint8_t* kf_usable,
+                         const float* kf_angle, const uint8_t* kf_desc, const int32_t* n_f, int f_stride, const int32_t* f_node,
+                         const float* f_angle, const uint8_t* f_desc, float nn_ratio, int check_orientation, int32_t* match,
+                         int32_t* nmatches);
+int planar_search_by_bow_dev(planar_ctx* ctx, int B, const int32_t* d_n_kf, int kf_stride, const int32_t* d_kf_node,
+                             const uint8_t* d_kf_usable, const float* d_kf_angle, const uint8_t* d_kf_desc, const int32_t* d_n_f,
+                             int f_stride, const int32_t* d_f_node, const float* d_f_angle, const uint8_t* d_f_desc, float nn_ratio,
+                             int check_orientation, int32_t* d_match, int32_t* d_nmatches);
+
+/* cv::line_descriptor::KeyLine (opencv_contrib line_descriptor/descriptor.hpp), same field order, 68 bytes. */
+typedef struct planar_keyline {
+    float angle;
+    int32_t class_id, octave;
+    float pt_x, pt_y, response, size;
+    float start_x, start_y, end_x, end_y;
+    float s_oct_x, s_oct_y, e_oct_x, e_oct_y;
+    float line_length;
+    int32_t num_pixels;
+} planar_keyline;
+
+/* LSDmatcher::SearchByProjection(Frame& F, const vector<MapLine*>&, th) (src/LSDmatcher.cpp:141-211) with
+ * Frame::GetLinesInArea (src/Frame.cc:491-524).
+ *   keylines[b][i] mvKeylinesUn, ldesc mLdesc, blocked[i] = mvpMapLines[i] && ->Observations() > 0 on entry
+ *   ml_in_view[j] = pML && !isBad() && mbTrackInView;  ml_proj[j] = {mTrackProjX1, Y1, X2, Y2};
+ *   ml_level mnTrackScaleLevel, ml_view_cos mTrackViewCos, ml_desc GetDescriptor(), ml_observed Observations() > 0
+ *   match[b][i] (in/out) index j of the map line stored in F.mvpMapLines[i] */
+int planar_lsd_search_by_projection(planar_ctx* ctx, int B, const int32_t* n_lines, int line_stride, const planar_keyline* keylines,
+                                    const uint8_t* ldesc, const uint8_t* blocked, const int32_t* n_ml, int ml_stride,
+                                    const uint8_t* ml_in_view, const float* ml_proj, const int32_t* ml_level, const float* ml_view_cos,
+                                    const uint8_t* ml_desc, const uint8_t* ml_observed, const float* scale_factors, int n_levels, float th,
+                                    float nn_ratio, int32_t* match, int32_t* nmatches);
+int planar_lsd_search_by_projection_dev(planar_ctx* ctx, int B, const int32_t* d_n_lines, int line_stride, const planar_keyline* d_keylines,
+                                        const uint8_t* d_ldesc, const uint8_t* d_blocked, const int32_t* d_n_ml, int ml_stride,
+                                        const uint8_t* d_ml_in_view, const float* d_ml_proj, const int32_t* d_ml_level,
+                                        const float* d_ml_view_cos, const uint8_t* d_ml_desc, const uint8_t* d_ml_observed,
+                                        const float* scale_factors /* host */, int n_levels, float th, float nn_ratio, int32_t* d_match,
+                                        int32_t* d_nmatches);
+
+/* PlaneMatcher::SearchMapByCoefficients(Frame&, const vector<MapPlane*>&) (src/PlaneMatcher.cpp:10-66) with
+ * Frame::ComputePlaneWorldCoeff (src/Frame.cc:815-820) and PointDistanceFromPlane (:67-79).
+ *   pl_coef [B][pl_stride][4]  mvPlaneCoefficients[i] (camera frame)      Tcw [B][16]
+ *   mp_*: the map planes seen by frame b (b = 0 for every frame when map_shared != 0):
+ *     mp_valid !isBad(); mp_coef GetWorldPos() [4]; mp_pts mvPlanePoints xyz float, [.][mp_stride][pts_stride][3]
+ *   th[4] = {dTh, aTh, verTh, parTh} (PlaneMatcher ctor, include/PlaneMatcher.h:19)
+ *   match / ver / par [B][pl_stride] (in/out): index of the map plane stored in mvpMapPlanes[i] /
+ *   mvpVerticalPlanes[i] / mvpParallelPlanes[i]; untouched where the reference does not assign. */
+int planar_plane_search_by_coefficients(planar_ctx* ctx, int B, const int32_t* n_planes, int pl_stride, const float* pl_coef,
+                                        const float* Tcw, int map_shared, const int32_t* n_mp, int mp_stride, const uint8_t* mp_valid,
+                                        const float* mp_coef, const int32_t* mp_npts, int pts_stride, const float* mp_pts,
+                                        const float* th, int32_t* match, int32_t* ver, int32_t* par, int32_t* nmatches);
+int planar_plane_search_by_coefficients_dev(planar_ctx* ctx, int B, const int32_t* d_n_planes, int pl_stride, const float* d_pl_coef,
+                                            const float* d_Tcw, int map_shared, const int32_t* d_n_mp, int mp_stride,
+                                            const uint8_t* d_mp_valid, const float* d_mp_coef, const int32_t* d_mp_npts, int pts_stride,
+                                            const float* d_mp_pts, const float* th /* host */, int32_t* d_match, int32_t* d_ver,
+                                            int32_t* d_par, int32_t* d_nmatches);
+
 /* ---- plane extractor (replaces PlaneDetection::readDepthImage + runPlaneDetection,
  *      src/PlaneExtractor.cpp:26-65 / include/PlaneExtractor.h:36-56, i.e. ahc::PlaneFitter::run with
  *      PlanarSLAM's defaults, include/peac/AHCPlaneFitter.hpp:154-158,211) ------------------------- */

@@ -46,6 +46,29 @@ class BAProblem(C.Structure):
                 ("e_meas", C.c_void_p), ("e_inv_sigma2", C.c_void_p)]
 
 
+KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"), ("response", "<f4"),
+                          ("size", "<f4"), ("start_x", "<f4"), ("start_y", "<f4"), ("end_x", "<f4"), ("end_y", "<f4"), ("s_oct_x", "<f4"),
+                          ("s_oct_y", "<f4"), ("e_oct_x", "<f4"), ("e_oct_y", "<f4"), ("line_length", "<f4"), ("num_pixels", "<i4")])
+MAX_LEVELS = 16
+
+
+class FrameView(C.Structure):
+    _fields_ = [("B", C.c_int32), ("stride", C.c_int32), ("n", C.c_void_p), ("keys_un", C.c_void_p), ("u_right", C.c_void_p),
+                ("desc", C.c_void_p), ("blocked", C.c_void_p), ("Tcw", C.c_void_p), ("min_x", C.c_float), ("max_x", C.c_float),
+                ("min_y", C.c_float), ("max_y", C.c_float), ("grid_w_inv", C.c_float), ("grid_h_inv", C.c_float), ("fx", C.c_float),
+                ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("b", C.c_float),
+                ("scale_factors", C.c_float * MAX_LEVELS)]
+
+
+class LastFrameView(C.Structure):
+    _fields_ = [("stride", C.c_int32)] + [(n, C.c_void_p) for n in ("n", "Tcw", "usable", "xw", "octave", "angle", "mp_desc", "mp_observed")]
+
+
+class MapProbes(C.Structure):
+    _fields_ = [("stride", C.c_int32)] + [(n, C.c_void_p) for n in ("n", "in_view", "proj_x", "proj_y", "proj_xr", "level", "view_cos", "desc",
+                                                                   "observed")]
+
+
 class BAResult(C.Structure):
     _fields_ = [("kf_Tcw", C.c_void_p), ("lm", C.c_void_p), ("e_outlier", C.c_void_p), ("lm_iterations", C.c_int32), ("stopped", C.c_int32)]
 
@@ -80,6 +103,22 @@ _SIGS = {
     "planar_match_orb_points_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "planar_lsd_search_by_descriptor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "planar_lsd_search_by_descriptor_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "planar_search_by_projection_frame": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.POINTER(LastFrameView), C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "planar_search_by_projection_frame_dev": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.POINTER(LastFrameView), C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "planar_search_by_projection_map": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.POINTER(MapProbes), C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "planar_search_by_projection_map_dev": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.POINTER(MapProbes), C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "planar_search_by_bow": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] +
+                             [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "planar_search_by_bow_dev": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] +
+                                 [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "planar_lsd_search_by_projection": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] +
+                                        [C.c_void_p] * 6 + [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "planar_lsd_search_by_projection_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] +
+                                            [C.c_void_p] * 6 + [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "planar_plane_search_by_coefficients": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_void_p] * 4),
+    "planar_plane_search_by_coefficients_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_void_p] * 4),
     "planar_peac_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_peac_destroy": (None, [C.c_void_p]),
     "planar_peac_max_planes": (C.c_int, []),

@@ -276,3 +276,223 @@ def ba_problem(seed=99, n_kf=10, n_points=2400, n_lines=500, n_planes=100, n_fix
     return dict(kf_Tcw=kf_T.astype(np.float32).reshape(K, 16), kf_fixed=fixed, lm_type=np.array(lm_type, np.uint8), lm_init=np.ascontiguousarray(lm_init),
                 e_kf=np.array(e_kf, np.int32), e_lm=np.array(e_lm, np.int32), e_type=np.array(e_type, np.uint8),
                 e_meas=np.array(e_meas, np.float64), e_inv_sigma2=np.array(e_is2, np.float32), T_gt=T_gt, lm_gt=lm_gt)
+
+
+# ---- guided matcher problems (SearchByProjection x2, SearchByBoW, line projection, plane association) ----------
+def scale_factors(levels=8, s=1.2):
+    """ORBextractor::mvScaleFactor (src/ORBextractor.cc:417-424): float32 running product."""
+    out = np.ones(levels, np.float32)
+    for i in range(1, levels):
+        out[i] = np.float32(out[i - 1] * np.float32(s))
+    return out
+
+
+def _flip_bits(rng, desc, max_bits):
+    """copy of desc [..., 32] uint8 with up to max_bits random bits flipped per row"""
+    out = desc.copy().reshape(-1, 32)
+    for r in range(out.shape[0]):
+        k = int(rng.integers(0, max_bits + 1))
+        for bit in rng.integers(0, 256, k):
+            out[r, bit >> 3] ^= np.uint8(1 << (bit & 7))
+    return out.reshape(desc.shape)
+
+
+def guided_frame(B=2, N=1000, stride=None, seed=5, crowd=0.3):
+    """The current-frame side: keypoints with depth, stereo coordinate, descriptors, TUM3 intrinsics.
+    `crowd` = fraction of keypoints placed in tight clusters (many candidates per search window)."""
+    from ._lib import KP_DTYPE
+    rng = np.random.default_rng(seed)
+    S = stride or N
+    K = TUM3
+    keys = np.zeros((B, S), KP_DTYPE)
+    uR = np.full((B, S), -1, np.float32)
+    depth = np.zeros((B, S), np.float32)
+    desc = rng.integers(0, 256, (B, S, 32), dtype=np.uint8)
+    n = np.zeros(B, np.int32)
+    for b in range(B):
+        nb = N if b == 0 else int(rng.integers(N // 2, N + 1))
+        n[b] = nb
+        x = rng.uniform(2, 637, nb); y = rng.uniform(2, 477, nb)
+        nc = int(crowd * nb)
+        if nc:
+            centers = rng.uniform([60, 60], [580, 420], (8, 2))
+            which = rng.integers(0, 8, nc)
+            x[:nc] = np.clip(centers[which, 0] + rng.normal(0, 12, nc), 0, 639.5)
+            y[:nc] = np.clip(centers[which, 1] + rng.normal(0, 12, nc), 0, 479.5)
+        keys["x"][b, :nb] = x; keys["y"][b, :nb] = y
+        keys["octave"][b, :nb] = np.minimum(rng.geometric(0.35, nb) - 1, 7)
+        keys["angle"][b, :nb] = rng.uniform(0, 360, nb)
+        keys["size"][b, :nb] = 31
+        z = rng.uniform(0.6, 6.0, nb).astype(np.float32)
+        depth[b, :nb] = z
+        has = rng.random(nb) < 0.85
+        uR[b, :nb] = np.where(has, keys["x"][b, :nb] - np.float32(K["bf"]) / z, -1).astype(np.float32)
+    return dict(n=n, keys_un=keys, u_right=uR, desc=desc, depth=depth, min_x=0.0, max_x=640.0, min_y=0.0, max_y=480.0, fx=K["fx"], fy=K["fy"],
+                cx=K["cx"], cy=K["cy"], bf=K["bf"], b=K["bf"] / K["fx"], scale_factors=scale_factors())
+
+
+def _se3(rng, rot, trans):
+    R = _rodrigues(rng.normal(0, rot, 3))
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = trans
+    return T
+
+
+def guided_last_frame(cur, seed=6, motion=(0.0, 0.0, 0.0), dup=0.15, pix_noise=2.0, bits=30):
+    """LastFrame + poses for SearchByProjection(Cur, Last): every last-frame map point is the back-projection of a
+    current keypoint (plus `dup` duplicates competing for the same keypoint), seen from a camera displaced by `motion`."""
+    rng = np.random.default_rng(seed)
+    B, S = cur["keys_un"].shape
+    Tc = np.zeros((B, 16), np.float32); Tl = np.zeros((B, 16), np.float32)
+    L = S
+    out = dict(n=np.zeros(B, np.int32), usable=np.zeros((B, L), np.uint8), xw=np.zeros((B, L, 3), np.float32), octave=np.zeros((B, L), np.int32),
+               angle=np.zeros((B, L), np.float32), mp_desc=rng.integers(0, 256, (B, L, 32), dtype=np.uint8), mp_observed=np.zeros((B, L), np.uint8))
+    for b in range(B):
+        nb = int(cur["n"][b])
+        Tcw = _se3(rng, 0.2, rng.normal(0, 0.5, 3))
+        Tlw = _se3(rng, 0.01, np.asarray(motion, float) + rng.normal(0, 0.005, 3)) @ Tcw
+        Tc[b] = Tcw.astype(np.float32).ravel(); Tl[b] = Tlw.astype(np.float32).ravel()
+        src = rng.permutation(nb)
+        nd = int(dup * nb)
+        src = np.concatenate([src[: nb - nd], rng.choice(src[: max(1, nb - nd)], nd)]) if nd else src
+        src = src[rng.permutation(len(src))]
+        k = cur["keys_un"][b, src]
+        z = cur["depth"][b, src].astype(np.float64)
+        u = k["x"] + rng.normal(0, pix_noise, len(src)); v = k["y"] + rng.normal(0, pix_noise, len(src))
+        Xc = np.stack([(u - cur["cx"]) * z / cur["fx"], (v - cur["cy"]) * z / cur["fy"], z], 1)
+        Xw = (np.linalg.inv(Tcw) @ np.concatenate([Xc, np.ones((len(src), 1))], 1).T).T[:, :3]
+        m = len(src)
+        out["n"][b] = m
+        out["xw"][b, :m] = Xw
+        out["usable"][b, :m] = rng.random(m) < 0.9
+        out["octave"][b, :m] = np.clip(k["octave"] + rng.integers(-1, 2, m), 0, 7)
+        out["angle"][b, :m] = (k["angle"] + rng.normal(0, 6, m) + (rng.random(m) < 0.08) * rng.uniform(0, 360, m)) % 360
+        out["mp_desc"][b, :m] = _flip_bits(rng, cur["desc"][b, src], bits)
+        out["mp_observed"][b, :m] = rng.random(m) < 0.8
+    cur = dict(cur); cur["Tcw"] = Tc
+    cur["blocked"] = (rng.random((B, S)) < 0.05).astype(np.uint8)
+    out["Tcw"] = Tl
+    return cur, out
+
+
+def guided_map_probes(frame, seed=8, n_probes=2000, pix_noise=1.5, bits=30):
+    """Local-map probes for SearchByProjection(F, vpMapPoints, th): the fields Frame::isInFrustum leaves on a MapPoint."""
+    rng = np.random.default_rng(seed)
+    B, S = frame["keys_un"].shape
+    P = n_probes
+    out = dict(n=np.zeros(B, np.int32), in_view=np.zeros((B, P), np.uint8), proj_x=np.zeros((B, P), np.float32), proj_y=np.zeros((B, P), np.float32),
+               proj_xr=np.zeros((B, P), np.float32), level=np.zeros((B, P), np.int32), view_cos=np.zeros((B, P), np.float32),
+               desc=rng.integers(0, 256, (B, P, 32), dtype=np.uint8), observed=np.zeros((B, P), np.uint8))
+    for b in range(B):
+        nb = int(frame["n"][b])
+        m = P if b == 0 else int(rng.integers(P // 2, P + 1))
+        src = rng.integers(0, nb, m)
+        k = frame["keys_un"][b, src]
+        z = frame["depth"][b, src]
+        out["n"][b] = m
+        out["in_view"][b, :m] = rng.random(m) < 0.9
+        out["proj_x"][b, :m] = k["x"] + rng.normal(0, pix_noise, m)
+        out["proj_y"][b, :m] = k["y"] + rng.normal(0, pix_noise, m)
+        out["proj_xr"][b, :m] = out["proj_x"][b, :m] - np.float32(frame["bf"]) / z
+        out["level"][b, :m] = np.clip(k["octave"] + rng.integers(0, 2, m), 0, 7)
+        out["view_cos"][b, :m] = rng.uniform(0.99, 1.0, m)
+        out["desc"][b, :m] = _flip_bits(rng, frame["desc"][b, src], bits)
+        out["observed"][b, :m] = rng.random(m) < 0.8
+    frame = dict(frame)
+    frame["blocked"] = (rng.random((B, S)) < 0.05).astype(np.uint8)
+    return frame, out
+
+
+def guided_bow(B=2, N=1000, seed=9, n_nodes=90, bits=18):
+    """Key frame / frame pair for SearchByBoW: one vocabulary node id per feature (DBoW2 level-4 nodes: ~100 ids)."""
+    rng = np.random.default_rng(seed)
+    kf = dict(n=np.zeros(B, np.int32), node=np.full((B, N), -1, np.int32), usable=np.zeros((B, N), np.uint8), angle=np.zeros((B, N), np.float32),
+              desc=rng.integers(0, 256, (B, N, 32), dtype=np.uint8))
+    f = dict(n=np.zeros(B, np.int32), node=np.full((B, N), -1, np.int32), angle=np.zeros((B, N), np.float32),
+             desc=rng.integers(0, 256, (B, N, 32), dtype=np.uint8))
+    for b in range(B):
+        nk = N if b == 0 else int(rng.integers(N // 2, N + 1))
+        nf = N if b == 0 else int(rng.integers(N // 2, N + 1))
+        kf["n"][b], f["n"][b] = nk, nf
+        kf["node"][b, :nk] = rng.integers(-1, n_nodes, nk) * 7 + 11
+        kf["node"][b, :nk][kf["node"][b, :nk] < 11] = -1
+        kf["usable"][b, :nk] = rng.random(nk) < 0.8
+        kf["angle"][b, :nk] = rng.uniform(0, 360, nk)
+        # most frame features are noisy copies of key-frame features (same node), some twice
+        src = rng.integers(0, nk, nf)
+        f["node"][b, :nf] = kf["node"][b, src]
+        f["desc"][b, :nf] = _flip_bits(rng, kf["desc"][b, src], bits)
+        f["angle"][b, :nf] = (kf["angle"][b, src] + rng.normal(0, 5, nf) + (rng.random(nf) < 0.1) * rng.uniform(0, 360, nf)) % 360
+        stray = rng.random(nf) < 0.15
+        f["node"][b, :nf][stray] = rng.integers(0, n_nodes, int(stray.sum())) * 7 + 11
+    return kf, f
+
+
+def guided_lines(B=3, n_lines=40, n_ml=120, seed=10, bits=30):
+    """Frame lines + projected map lines for LSDmatcher::SearchByProjection."""
+    from ._lib import KEYLINE_DTYPE
+    rng = np.random.default_rng(seed)
+    kl = np.zeros((B, n_lines), KEYLINE_DTYPE)
+    lines = dict(n=np.zeros(B, np.int32), keylines=kl, ldesc=rng.integers(0, 256, (B, n_lines, 32), dtype=np.uint8),
+                 blocked=(rng.random((B, n_lines)) < 0.05).astype(np.uint8))
+    ml = dict(n=np.zeros(B, np.int32), in_view=np.zeros((B, n_ml), np.uint8), proj=np.zeros((B, n_ml, 4), np.float32), level=np.zeros((B, n_ml), np.int32),
+              view_cos=np.zeros((B, n_ml), np.float32), desc=rng.integers(0, 256, (B, n_ml, 32), dtype=np.uint8), observed=np.zeros((B, n_ml), np.uint8))
+    for b in range(B):
+        nl = n_lines if b == 0 else int(rng.integers(n_lines // 2, n_lines + 1))
+        lines["n"][b] = nl
+        kl["pt_x"][b, :nl] = rng.uniform(20, 620, nl); kl["pt_y"][b, :nl] = rng.uniform(20, 460, nl)
+        kl["angle"][b, :nl] = rng.uniform(-np.pi, np.pi, nl)
+        kl["octave"][b, :nl] = rng.integers(0, 3, nl) * (b % 2)   # frame 0: all octave 0 like the reference's 1-octave LSD
+        kl["line_length"][b, :nl] = rng.uniform(30, 200, nl)
+        m = n_ml if b == 0 else int(rng.integers(n_ml // 2, n_ml + 1))
+        ml["n"][b] = m
+        src = rng.integers(0, nl, m)
+        ang = kl["angle"][b, src] + rng.normal(0, 0.3, m)
+        half = rng.uniform(15, 100, m)
+        cx = kl["pt_x"][b, src] + rng.normal(0, 2.0, m); cy = kl["pt_y"][b, src] + rng.normal(0, 2.0, m)
+        ml["proj"][b, :m] = np.stack([cx - half * np.cos(ang), cy - half * np.sin(ang), cx + half * np.cos(ang), cy + half * np.sin(ang)], 1)
+        ml["in_view"][b, :m] = rng.random(m) < 0.9
+        ml["level"][b, :m] = np.clip(kl["octave"][b, src] + rng.integers(0, 2, m), 0, 7)
+        ml["view_cos"][b, :m] = rng.uniform(0.99, 1.0, m)
+        ml["desc"][b, :m] = _flip_bits(rng, lines["ldesc"][b, src], bits)
+        ml["observed"][b, :m] = rng.random(m) < 0.7
+    return lines, ml
+
+
+def guided_planes(B=4, n_planes=8, n_map=40, n_pts=600, seed=12, shared=False):
+    """Frame planes (camera frame) + map planes (world frame, with boundary clouds) for PlaneMatcher::SearchMapByCoefficients."""
+    rng = np.random.default_rng(seed)
+    MB = 1 if shared else B
+    mp = dict(n=np.zeros(MB, np.int32), valid=np.zeros((MB, n_map), np.uint8), coef=np.zeros((MB, n_map, 4), np.float32),
+              npts=np.zeros((MB, n_map), np.int32), pts=np.zeros((MB, n_map, n_pts, 3), np.float32), shared=shared)
+    for m in range(MB):
+        nm = n_map if m == 0 else int(rng.integers(n_map // 2, n_map + 1))
+        mp["n"][m] = nm
+        axes = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        for j in range(nm):
+            nrm = axes[j % 3] * rng.choice([-1, 1]) + rng.normal(0, 0.02 if j % 4 else 0.3, 3)
+            nrm /= np.linalg.norm(nrm)
+            d = rng.uniform(-3, 3)
+            mp["coef"][m, j] = [*nrm, d]
+            k = int(rng.integers(0, n_pts + 1)) if j % 7 == 0 else n_pts
+            mp["npts"][m, j] = k
+            # points on the plane (n.x + d = 0) with a little noise
+            t1 = np.cross(nrm, [1, 0, 0.3]); t1 /= np.linalg.norm(t1); t2 = np.cross(nrm, t1)
+            ab = rng.uniform(-2, 2, (k, 2))
+            mp["pts"][m, j, :k] = (-d * nrm)[None] + ab[:, :1] * t1 + ab[:, 1:] * t2 + rng.normal(0, 0.01, (k, 3))
+            mp["valid"][m, j] = rng.random() < 0.9
+    fr = dict(n=np.zeros(B, np.int32), coef=np.zeros((B, n_planes, 4), np.float32), Tcw=np.zeros((B, 16), np.float32))
+    for b in range(B):
+        m = 0 if shared else b
+        T = _se3(rng, 0.3, rng.normal(0, 0.5, 3))
+        fr["Tcw"][b] = T.astype(np.float32).ravel()
+        np_ = n_planes if b == 0 else int(rng.integers(1, n_planes + 1))
+        fr["n"][b] = np_
+        for i in range(np_):
+            j = int(rng.integers(0, mp["n"][m]))
+            pw = mp["coef"][m, j].astype(np.float64) + np.r_[rng.normal(0, 0.02, 3), rng.normal(0, 0.03)]
+            pw[:3] /= np.linalg.norm(pw[:3])
+            # camera-frame coefficients: pi_c = Tcw^-T pi_w  (so that Tcw^T pi_c = pi_w)
+            fr["coef"][b, i] = np.linalg.inv(T).T @ pw
+    return fr, mp

@@ -265,3 +265,75 @@ def ba_reduced_system(prob, params, lam=1e-3):
     L.orc_ba_reduced_system(C.c_int(K), p(a["kf_Tcw"]), p(a["kf_fixed"]), C.c_int(NL), p(a["lm_type"]), p(a["lm_init"]), C.c_int(NE), p(a["e_kf"]), p(a["e_lm"]),
                             p(a["e_type"]), p(a["e_meas"]), p(a["e_inv_sigma2"]), C.byref(prm), C.c_double(lam), p(S), p(b), C.byref(chi))
     return S, b, chi.value
+
+
+# ---- guided matchers (oracle/guided_oracle.cpp); inputs are the dicts planarslam_amd.guided takes ----
+def _g():
+    from planarslam_amd import guided
+    return guided
+
+
+def search_by_projection_frame(cur, last, th, mono=False, check_orientation=True, cur_match=None):
+    G = _g(); L = lib()
+    fv, k1 = G.frame_view(cur); lv, k2 = G.last_frame_view(last)
+    m = np.full((fv.B, fv.stride), -1, np.int32) if cur_match is None else np.ascontiguousarray(cur_match, np.int32).copy()
+    nm = np.zeros(fv.B, np.int32)
+    L.orc_search_by_projection_frame(C.byref(fv), C.byref(lv), C.c_float(th), int(mono), int(check_orientation), C.c_void_p(m.ctypes.data),
+                                     C.c_void_p(nm.ctypes.data))
+    return m, nm
+
+
+def search_by_projection_map(frame, probes, th=1.0, nn_ratio=0.6, match=None):
+    G = _g(); L = lib()
+    fv, k1 = G.frame_view(frame); pv, k2 = G.map_probes(probes)
+    m = np.full((fv.B, fv.stride), -1, np.int32) if match is None else np.ascontiguousarray(match, np.int32).copy()
+    nm = np.zeros(fv.B, np.int32)
+    L.orc_search_by_projection_map(C.byref(fv), C.byref(pv), C.c_float(th), C.c_float(nn_ratio), C.c_void_p(m.ctypes.data), C.c_void_p(nm.ctypes.data))
+    return m, nm
+
+
+def search_by_bow(kf, f, nn_ratio=0.7, check_orientation=True):
+    L = lib()
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    a = [c(kf["n"], np.int32), c(kf["node"], np.int32), c(kf["usable"], np.uint8), c(kf["angle"], np.float32), c(kf["desc"], np.uint8)]
+    b = [c(f["n"], np.int32), c(f["node"], np.int32), c(f["angle"], np.float32), c(f["desc"], np.uint8)]
+    B, ks = a[1].shape; fs = b[1].shape[1]
+    m = np.full((B, fs), -1, np.int32); nm = np.zeros(B, np.int32)
+    L.orc_search_by_bow(B, p(a[0]), ks, p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(b[0]), fs, p(b[1]), p(b[2]), p(b[3]), C.c_float(nn_ratio),
+                        int(check_orientation), p(m), p(nm))
+    return m, nm
+
+
+def lsd_search_by_projection(lines, maplines, scale_factors, th=1.0, nn_ratio=0.6, match=None):
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    L = lib()
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    p = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None
+    n, kl, ld = c(lines["n"], np.int32), c(lines["keylines"], KEYLINE_DTYPE), c(lines["ldesc"], np.uint8)
+    bl = c(lines["blocked"], np.uint8) if lines.get("blocked") is not None else None
+    mn, iv, pr = c(maplines["n"], np.int32), c(maplines["in_view"], np.uint8), c(maplines["proj"], np.float32)
+    lv, vc, md, ob = c(maplines["level"], np.int32), c(maplines["view_cos"], np.float32), c(maplines["desc"], np.uint8), c(maplines["observed"], np.uint8)
+    sf = c(scale_factors, np.float32)
+    B, S = kl.shape; M = iv.shape[1]
+    m = np.full((B, S), -1, np.int32) if match is None else c(match, np.int32).copy()
+    nm = np.zeros(B, np.int32)
+    L.orc_lsd_search_by_projection(B, p(n), S, p(kl), p(ld), p(bl), p(mn), M, p(iv), p(pr), p(lv), p(vc), p(md), p(ob), p(sf), len(sf), C.c_float(th),
+                                   C.c_float(nn_ratio), p(m), p(nm))
+    return m, nm
+
+
+def plane_search_by_coefficients(frame, mapplanes, th=(0.1, 0.86, 0.08716, 0.9962), init=None):
+    L = lib()
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    n, coef, T = c(frame["n"], np.int32), c(frame["coef"], np.float32), c(frame["Tcw"], np.float32)
+    mn, mv, mc = c(mapplanes["n"], np.int32), c(mapplanes["valid"], np.uint8), c(mapplanes["coef"], np.float32)
+    mnp, mp = c(mapplanes["npts"], np.int32), c(mapplanes["pts"], np.float32)
+    B, S = coef.shape[:2]; M, P = mp.shape[-3], mp.shape[-2]
+    out = [np.full((B, S), -1, np.int32) if init is None else c(init[i], np.int32).copy() for i in range(3)]
+    nm = np.zeros(B, np.int32)
+    tha = np.asarray(th, np.float32)
+    L.orc_plane_search_by_coefficients(B, p(n), S, p(coef), p(T), int(bool(mapplanes.get("shared"))), p(mn), M, p(mv), p(mc), p(mnp), P, p(mp), p(tha),
+                                       p(out[0]), p(out[1]), p(out[2]), p(nm))
+    return out[0], out[1], out[2], nm

@@ -1,0 +1,110 @@
+"""GPU parity (bit-exact): the HIP guided matchers through the C ABI against oracle/guided_oracle.cpp.
+Rows a20, a21, a22, a24, a25 of SURVEY.md §8."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from planarslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from planarslam_amd._lib import Context
+    return Context(0)
+
+
+@pytest.mark.parametrize("motion", [(0, 0, 0), (0, 0, 0.3), (0, 0, -0.3)])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_projection_frame(ctx, motion, check_ori):
+    from planarslam_amd.guided import ORBmatcher
+    fr = synth.guided_frame(B=4, N=1000, seed=61)
+    cur, last = synth.guided_last_frame(fr, seed=62, motion=motion)
+    for th, mono in ((15.0, False), (7.0, False), (30.0, True)):
+        ref_m, ref_n = O.search_by_projection_frame(cur, last, th, mono=mono, check_orientation=check_ori)
+        m, n = ORBmatcher(0.9, check_ori, ctx).SearchByProjectionFrame(cur, last, th, bMono=mono)
+        np.testing.assert_array_equal(n, ref_n)
+        np.testing.assert_array_equal(m, ref_m)
+        assert n.min() > 100
+
+
+def test_search_by_projection_frame_inout_and_ragged(ctx):
+    from planarslam_amd.guided import ORBmatcher
+    fr = synth.guided_frame(B=3, N=700, stride=1024, seed=63, crowd=0.6)
+    cur, last = synth.guided_last_frame(fr, seed=64, dup=0.4)
+    init = np.full((3, 1024), 777, np.int32)
+    ref_m, ref_n = O.search_by_projection_frame(cur, last, 15.0, cur_match=init)
+    m, n = ORBmatcher(0.9, True, ctx).SearchByProjectionFrame(cur, last, 15.0, cur_match=init)
+    np.testing.assert_array_equal(m, ref_m); np.testing.assert_array_equal(n, ref_n)
+    assert (m == 777).any() and (m == -1).any()
+    # empty last frame / empty current frame
+    last0 = dict(last); last0["n"] = np.zeros(3, np.int32)
+    m0, n0 = ORBmatcher(0.9, True, ctx).SearchByProjectionFrame(cur, last0, 15.0)
+    assert (n0 == 0).all() and (m0 == -1).all()
+    cur0 = dict(cur); cur0["n"] = np.zeros(3, np.int32)
+    m0, n0 = ORBmatcher(0.9, True, ctx).SearchByProjectionFrame(cur0, last, 15.0)
+    assert (n0 == 0).all()
+
+
+@pytest.mark.parametrize("th", [1.0, 3.0, 5.0])
+def test_search_by_projection_map(ctx, th):
+    from planarslam_amd.guided import ORBmatcher
+    fr = synth.guided_frame(B=4, N=1000, seed=71, crowd=0.5)
+    fr, pr = synth.guided_map_probes(fr, seed=72, n_probes=3000)
+    for ratio in (0.8, 0.6):
+        ref_m, ref_n = O.search_by_projection_map(fr, pr, th=th, nn_ratio=ratio)
+        m, n = ORBmatcher(ratio, True, ctx).SearchByProjectionMap(fr, pr, th=th)
+        np.testing.assert_array_equal(n, ref_n)
+        np.testing.assert_array_equal(m, ref_m)
+    assert n.min() > 100
+
+
+def test_search_by_projection_map_dense_windows(ctx):
+    """Windows holding more candidates than one chunk of the LDS list (adaptive chunking path)."""
+    from planarslam_amd.guided import ORBmatcher
+    fr = synth.guided_frame(B=2, N=4000, seed=73, crowd=0.9)
+    fr, pr = synth.guided_map_probes(fr, seed=74, n_probes=2500)
+    ref_m, ref_n = O.search_by_projection_map(fr, pr, th=12.0, nn_ratio=0.8)
+    m, n = ORBmatcher(0.8, True, ctx).SearchByProjectionMap(fr, pr, th=12.0)
+    np.testing.assert_array_equal(n, ref_n)
+    np.testing.assert_array_equal(m, ref_m)
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow(ctx, check_ori):
+    from planarslam_amd.guided import ORBmatcher
+    for N, nodes, seed in ((1000, 90, 81), (1500, 12, 82), (300, 400, 83)):
+        kf, f = synth.guided_bow(B=3, N=N, seed=seed, n_nodes=nodes)
+        ref_m, ref_n = O.search_by_bow(kf, f, nn_ratio=0.7, check_orientation=check_ori)
+        m, n = ORBmatcher(0.7, check_ori, ctx).SearchByBoW(kf, f)
+        np.testing.assert_array_equal(n, ref_n)
+        np.testing.assert_array_equal(m, ref_m)
+    assert n.min() > 20
+
+
+def test_lsd_search_by_projection(ctx):
+    from planarslam_amd.guided import LSDmatcher
+    for n_lines, n_ml, seed in ((40, 120, 91), (200, 500, 92), (3, 10, 93)):
+        lines, ml = synth.guided_lines(B=4, n_lines=n_lines, n_ml=n_ml, seed=seed)
+        for th in (1.0, 3.0):
+            ref_m, ref_n = O.lsd_search_by_projection(lines, ml, synth.scale_factors(), th=th, nn_ratio=0.6)
+            m, n = LSDmatcher(0.6, ctx).SearchByProjection(lines, ml, synth.scale_factors(), th=th)
+            np.testing.assert_array_equal(n, ref_n)
+            np.testing.assert_array_equal(m, ref_m)
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_plane_search_by_coefficients(ctx, shared):
+    from planarslam_amd.guided import PlaneMatcher
+    fr, mp = synth.guided_planes(B=6, n_planes=10, n_map=50, n_pts=700, seed=95, shared=shared)
+    ref = O.plane_search_by_coefficients(fr, mp)
+    got = PlaneMatcher(ctx=ctx).SearchMapByCoefficients(fr, mp)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    assert ref[3].sum() > 10
+    init = [np.full((6, 10), 5, np.int32)] * 3
+    ref = O.plane_search_by_coefficients(fr, mp, init=init)
+    got = PlaneMatcher(ctx=ctx).SearchMapByCoefficients(fr, mp, init=init)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
