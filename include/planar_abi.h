@@ -323,6 +323,31 @@ int planar_plane_search_by_coefficients_dev(planar_ctx* ctx, int B, const int32_
                                             const float* d_mp_pts, const float* th /* host */, int32_t* d_match, int32_t* d_ver,
                                             int32_t* d_par, int32_t* d_nmatches);
 
+/* ---- line extractor (replaces LineSegment::ExtractLineSegment, src/LSDextractor.cpp:12-39 /
+ *      include/LSDextractor.h:344-352: cv::line_descriptor::LSDDetector::detect (1 octave, LSD_REFINE_ADV) +
+ *      sort by response, keep max_lines + cv::line_descriptor::BinaryDescriptor::compute + line equations) --- */
+typedef struct planar_lsd planar_lsd;
+int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, planar_lsd** out);
+void planar_lsd_destroy(planar_lsd* lsd);
+int planar_lsd_max_segments(void);   /* raw LSD segments kept per frame before the top-`max_lines` cut (2048) */
+int planar_lsd_scaled_size(planar_lsd* lsd, int* w, int* h);   /* the 0.8x working resolution */
+/* gray     : B frames of 8-bit gray (the `img` argument), pitch / frame_stride in bytes
+ * max_lines: lsdNFeatures (40 in the reference); per-frame stride of the outputs
+ * keylines : [B][max_lines] cv::line_descriptor::KeyLine records   ldesc: [B][max_lines][32] LBD bytes
+ * line_eq  : [B][max_lines][3] keylineFunctions (sp x ep, normalised)   n_lines: [B] keylines.size()
+ * Pixels of equal gradient bin are visited in raster order (the reference library's std::sort leaves that order
+ * to libstdc++). */
+int planar_lsd_extract(planar_lsd* lsd, const uint8_t* gray, int B, int pitch, int64_t frame_stride, int max_lines, planar_keyline* keylines,
+                       uint8_t* ldesc, double* line_eq, int32_t* n_lines);
+int planar_lsd_extract_dev(planar_lsd* lsd, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride, int max_lines,
+                           planar_keyline* d_keylines, uint8_t* d_ldesc, double* d_line_eq, int32_t* d_n_lines);
+/* diagnostics (tests / profiling): stage 0 level-line angle float deg [w*h] (-1024 undefined), 1 squared gradient u32 [w*h],
+ * 2 visiting order int32 (returns n), 3 raw segments 40 B each {x1,y1,x2,y2 float; width,p,nfa double} (returns count),
+ * 4 number of grown regions int32[1] */
+int planar_lsd_read_stage(planar_lsd* lsd, int frame, int stage, void* out, int64_t out_bytes);
+/* test hook: device emulation of libstdc++ std::sort with the sort_lines_by_response comparator (include/auxiliar.h:43-48) */
+int planar_debug_std_sort_desc(planar_ctx* ctx, float* keys, int32_t* perm, int n);
+
 /* ---- plane extractor (replaces PlaneDetection::readDepthImage + runPlaneDetection,
  *      src/PlaneExtractor.cpp:26-65 / include/PlaneExtractor.h:36-56, i.e. ahc::PlaneFitter::run with
  *      PlanarSLAM's defaults, include/peac/AHCPlaneFitter.hpp:154-158,211) ------------------------- */

@@ -221,3 +221,105 @@ void fast9_16(const uint8_t* img, int w, int h, int step, int threshold, bool nm
 }
 
 }  // namespace orc
+
+// --- general 8U Gaussian (LSD: 7x7 sigma 0.75; LBD: 5x5 sigma 1) ------------------------------
+namespace orc {
+void gaussian_taps_q8(int ksize, double sigma, int* taps) {
+    // getGaussianKernel: t = exp(scale2X * x * x), normalised by multiplying with 1/sum
+    const double scale2X = -0.5 / (sigma * sigma);
+    std::vector<double> v(ksize);
+    double sum = 0;
+    for (int i = 0; i < ksize; i++) { const double x = i - (ksize - 1) * 0.5; v[i] = std::exp(scale2X * x * x); sum += v[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < ksize; i++) taps[i] = cv_round(v[i] * sum * 256.0);
+}
+
+void gaussian_u8(const uint8_t* src, int w, int h, int sstep, int ksize, double sigma, uint8_t* dst, int dstep) {
+    int taps[32];
+    gaussian_taps_q8(ksize, sigma, taps);
+    const int r = ksize / 2;
+    std::vector<uint16_t> hbuf((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src + (size_t)y * sstep;
+        for (int x = 0; x < w; x++) {
+            uint32_t s = 0;
+            for (int k = 0; k < ksize; k++) s += (uint32_t)taps[k] * S[reflect101(x + k - r, w)];
+            hbuf[(size_t)y * w + x] = (uint16_t)std::min<uint32_t>(s, 65535u);
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        uint8_t* D = dst + (size_t)y * dstep;
+        for (int x = 0; x < w; x++) {
+            uint32_t s = 0;
+            for (int k = 0; k < ksize; k++) s += (uint32_t)taps[k] * hbuf[(size_t)reflect101(y + k - r, h) * w + x];
+            const uint32_t v = (s + (1u << 15)) >> 16;
+            D[x] = (uint8_t)std::min<uint32_t>(v, 255u);
+        }
+    }
+}
+
+// interpolationLinear<uint8_t>::getCoeffs: fval = scale*(val+0.5)-0.5 (softdouble == IEEE double here),
+// coefficient = cvRound(frac * 256) in ufixedpoint16
+static void exact_coeffs(double inv_scale, int srcsize, int dstsize, std::vector<int>& ofs, std::vector<int>& c0, std::vector<int>& c1,
+                         int& minofst, int& maxofst) {
+    const double scale = 1.0 / inv_scale;
+    ofs.assign(dstsize, 0); c0.assign(dstsize, 0); c1.assign(dstsize, 0);
+    minofst = 0; maxofst = dstsize;
+    for (int val = 0; val < dstsize; val++) {
+        const double fval = scale * ((double)val + 0.5) - 0.5;
+        const int ival = cv_floor(fval);
+        if (ival >= 0 && srcsize > 1) {
+            if (ival < srcsize - 1) {
+                ofs[val] = ival;
+                c1[val] = cv_round((fval - (double)ival) * 256.0);
+                c0[val] = 256 - c1[val];
+            } else { ofs[val] = srcsize - 1; maxofst = std::min(maxofst, val); }
+        } else minofst = std::max(minofst, val + 1);
+    }
+}
+
+void resize_linear_exact_u8(const uint8_t* src, int sw, int sh, int sstep, double inv_scale_x, double inv_scale_y, uint8_t* dst, int dw,
+                            int dh, int dstep) {
+    std::vector<int> xo, xa, xb, yo, ya, yb;
+    int xmin, xmax, ymin, ymax;
+    exact_coeffs(inv_scale_x, sw, dw, xo, xa, xb, xmin, xmax);
+    exact_coeffs(inv_scale_y, sh, dh, yo, ya, yb, ymin, ymax);
+    auto hline = [&](int sy, std::vector<uint32_t>& D) {   // ufixedpoint16 row (Q8.8)
+        const uint8_t* S = src + (size_t)sy * sstep;
+        for (int x = 0; x < dw; x++) {
+            if (x < xmin) D[x] = (uint32_t)S[0] << 8;
+            else if (x >= xmax) D[x] = (uint32_t)S[sw - 1] << 8;
+            else D[x] = std::min<uint32_t>((uint32_t)xa[x] * S[xo[x]] + (uint32_t)xb[x] * S[xo[x] + 1], 65535u);
+        }
+    };
+    std::vector<uint32_t> r0(dw), r1(dw);
+    for (int y = 0; y < dh; y++) {
+        uint8_t* D = dst + (size_t)y * dstep;
+        if (y < ymin || y >= ymax) {
+            hline(y < ymin ? 0 : sh - 1, r0);
+            for (int x = 0; x < dw; x++) D[x] = (uint8_t)std::min<uint32_t>((r0[x] + 128) >> 8, 255u);
+            continue;
+        }
+        hline(yo[y], r0); hline(yo[y] + 1, r1);
+        for (int x = 0; x < dw; x++) {
+            const uint64_t v = (uint64_t)r0[x] * ya[y] + (uint64_t)r1[x] * yb[y];   // ufixedpoint32 (Q16.16)
+            D[x] = (uint8_t)std::min<uint64_t>((v + 32768) >> 16, 255u);
+        }
+    }
+}
+
+void sobel3_s16(const uint8_t* src, int w, int h, int sstep, int dx, int dy, int16_t* dst) {
+    for (int y = 0; y < h; y++) {
+        const uint8_t* r0 = src + (size_t)reflect101(y - 1, h) * sstep;
+        const uint8_t* r1 = src + (size_t)y * sstep;
+        const uint8_t* r2 = src + (size_t)reflect101(y + 1, h) * sstep;
+        for (int x = 0; x < w; x++) {
+            const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+            int v;
+            if (dx == 1 && dy == 0) v = (r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]);
+            else v = (r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]);
+            dst[(size_t)y * w + x] = (int16_t)v;
+        }
+    }
+}
+}  // namespace orc

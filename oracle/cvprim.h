@@ -48,3 +48,17 @@ void fast9_16(const uint8_t* img, int w, int h, int step, int threshold, bool nm
 int fast_corner_score(const uint8_t* ptr, const int pixel[25], int threshold);
 
 }  // namespace orc
+
+namespace orc {
+// Q8 taps of cv::getGaussianKernel(ksize, sigma) as the 8U fixed-point GaussianBlur uses them
+// (modules/imgproc/src/smooth.cpp, 3.4.1 ufixedpoint16 path): cvRound(k[i] * 256).
+void gaussian_taps_q8(int ksize, double sigma, int* taps);
+// cv::GaussianBlur(src, dst, Size(ksize,ksize), sigma, sigma, BORDER_REFLECT_101) for CV_8UC1, ksize odd <= 31.
+void gaussian_u8(const uint8_t* src, int w, int h, int sstep, int ksize, double sigma, uint8_t* dst, int dstep);
+// cv::resize(src, dst, Size(), fx, fy, INTER_LINEAR_EXACT) for CV_8UC1 (resize.cpp resize_bitExact:
+// interpolationLinear<uint8_t> with ufixedpoint16 coefficients, vertical pass in ufixedpoint32, round half up).
+void resize_linear_exact_u8(const uint8_t* src, int sw, int sh, int sstep, double inv_scale_x, double inv_scale_y, uint8_t* dst, int dw,
+                            int dh, int dstep);
+// cv::Sobel(src, dst, CV_16S, dx, dy, 3) with BORDER_REFLECT_101 (dx,dy) in {(1,0),(0,1)}
+void sobel3_s16(const uint8_t* src, int w, int h, int sstep, int dx, int dy, int16_t* dst);
+}  // namespace orc

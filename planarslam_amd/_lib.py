@@ -119,6 +119,14 @@ _SIGS = {
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_void_p] * 4),
     "planar_plane_search_by_coefficients_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_void_p] * 4),
+    "planar_lsd_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "planar_lsd_destroy": (None, [C.c_void_p]),
+    "planar_lsd_max_segments": (C.c_int, []),
+    "planar_lsd_scaled_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "planar_lsd_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_lsd_extract_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_lsd_read_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "planar_debug_std_sort_desc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "planar_peac_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_peac_destroy": (None, [C.c_void_p]),
     "planar_peac_max_planes": (C.c_int, []),

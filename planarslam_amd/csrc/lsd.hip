@@ -1,0 +1,1183 @@
+// planarslam_amd/csrc/lsd.hip — line extraction for MI355X (gfx950): SURVEY.md §8 rows a10, a11, a12.
+//
+//   planar_lsd_extract   LineSegment::ExtractLineSegment                       reference src/LSDextractor.cpp:12-39
+//                        = cv::line_descriptor::LSDDetector::detect (1 octave) -> cv::LineSegmentDetector(LSD_REFINE_ADV)
+//                        + sort by response / keep 40 + cv::line_descriptor::BinaryDescriptor::compute (LBD)
+//                        + homogeneous line equations
+// The arithmetic follows oracle/lsd_oracle.cpp statement by statement (that file lists what is [assumed] about the
+// un-vendored OpenCV sources).  Structure on the GPU:
+//   K1 lsd_gauss        8U fixed-point Gaussian (7x7 sigma 0.75 for LSD, 5x5 sigma 1 for LBD), LDS tile, pixel-parallel
+//   K2 lsd_grad         0.8x INTER_LINEAR_EXACT resample fused with the 2x2 gradient: level-line angle (float degrees,
+//                       exactly what fastAtan2 returned), squared gradient (u32), per-frame max, pixel-parallel
+//   K3 lsd_sort         per frame: drop undefined pixels, 1024-bin descending stable order (two 5-bit LSD radix passes
+//                       with per-thread contiguous segments so that raster order survives inside a bin)
+//   K4 lsd_detect       ONE WAVEFRONT PER FRAME, the sequential part: region growing in the reference's visiting order
+//                       (the level-line angle of a region is updated after every accepted pixel, so acceptance is a
+//                       chain), rectangle fit, density refinement, NFA validation.  The wave hides memory latency by
+//                       expanding 7 queued pixels x 9 neighbours per round trip and resolving acceptances in lane
+//                       order; FP64 moment sums run as three independent chains on three lanes (same order as the
+//                       reference => bit-identical), min/max and NFA pixel counts are order-free wave reductions.
+//   K5 lbd_sobel        Sobel dx, dy (16S) of the 5x5-blurred image
+//   K6 lsd_keylines     per frame: KeyLine fields, libstdc++ std::sort emulation on `response`, keep max_lines, equations
+//   K7 lbd_describe     one wavefront per kept line: 63 support rows on 63 lanes, band sums in reference order
+// HBM traffic is small (a 640x480 frame: 0.3 MB in, 3 KB out, ~5 MB of L2-resident intermediates); K4 is latency bound.
+#include "common.h"
+
+namespace planar {
+namespace lsd {
+
+constexpr double LSD_PI = 3.14159265358979323846;
+constexpr double M_3_2_PI = 3 * LSD_PI / 2, M_2__PI = 2 * LSD_PI;
+constexpr float NOTDEF_F = -1024.0f;
+constexpr double DEG_TO_RADS = LSD_PI / 180;
+constexpr double RELATIVE_ERROR_FACTOR = 100.0;
+constexpr int N_BINS = 1024;
+constexpr int MAX_SEGS = 2048;     // raw LSD segments kept per frame
+constexpr int RING = 4096;         // recent region points kept in LDS
+constexpr int MAX_ROWS = 1024;     // scaled image height limit (rect_nfa row table)
+
+struct Plan {
+    int W, H, w, h;                // input and 0.8x sizes
+    int taps7[7], taps5[5];        // Q8 Gaussian taps
+    double rho, prec, p, log_nt, density_th, log_eps;
+    int min_reg_size;
+    // per-frame workspace offsets (bytes)
+    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_ord, off_tmp, off_reg, off_segs, off_kl, frame_bytes;
+    double gaussCoefL[21], gaussCoefG[63];
+};
+
+struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int pad[2]; };
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    // cv::fastAtan2: 7th-order odd polynomial, degrees; plain mul/add (no FMA), see oracle/cvprim.cpp
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+// ---- K1: 8U fixed-point Gaussian, ksize 5 or 7 (cv::GaussianBlur, BORDER_REFLECT_101) ---------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void lsd_gauss(const uint8_t* __restrict__ src, int pitch, int64_t src_stride, int W, int H,
+                                                 const int* __restrict__ taps_g, uint8_t* __restrict__ ws, size_t frame_bytes, size_t off_dst) {
+    constexpr int R = KS / 2, TW = 64, TH = 16;
+    __shared__ uint8_t s_in[TH + 2 * R][TW + 2 * R];
+    __shared__ uint16_t s_h[TH + 2 * R][TW];
+    int taps[KS];
+    for (int i = 0; i < KS; i++) taps[i] = taps_g[i];
+    const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    const uint8_t* S = src + (int64_t)b * src_stride;
+    for (int i = tid; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
+        const int r = i / (TW + 2 * R), c = i % (TW + 2 * R);
+        s_in[r][c] = S[(int64_t)reflect101(y0 + r - R, H) * pitch + reflect101(x0 + c - R, W)];
+    }
+    __syncthreads();
+    for (int i = tid; i < (TH + 2 * R) * TW; i += 256) {
+        const int r = i / TW, c = i % TW;
+        uint32_t s = 0;
+        for (int k = 0; k < KS; k++) s += (uint32_t)taps[k] * s_in[r][c + k];
+        s_h[r][c] = (uint16_t)min(s, 65535u);
+    }
+    __syncthreads();
+    uint8_t* D = ws + (size_t)b * frame_bytes + off_dst;
+    for (int i = tid; i < TH * TW; i += 256) {
+        const int r = i / TW, c = i % TW;
+        const int x = x0 + c, y = y0 + r;
+        if (x >= W || y >= H) continue;
+        uint32_t s = 0;
+        for (int k = 0; k < KS; k++) s += (uint32_t)taps[k] * s_h[r + k][c];
+        D[(size_t)y * W + x] = (uint8_t)min((s + 32768u) >> 16, 255u);
+    }
+}
+
+// ---- K2: INTER_LINEAR_EXACT 0.8x resample + ll_angle gradient ------------------------------------------------------
+struct Coef { int ofs, c0, c1; };
+
+__device__ __forceinline__ int scaled_px(const uint8_t* __restrict__ B7, int W, const Coef& cx, const Coef& cy) {
+    const uint8_t* r0 = B7 + (size_t)cy.ofs * W + cx.ofs;
+    const uint8_t* r1 = r0 + W;
+    const uint32_t h0 = min((uint32_t)cx.c0 * r0[0] + (uint32_t)cx.c1 * r0[1], 65535u);
+    const uint32_t h1 = min((uint32_t)cx.c0 * r1[0] + (uint32_t)cx.c1 * r1[1], 65535u);
+    const uint32_t v = h0 * (uint32_t)cy.c0 + h1 * (uint32_t)cy.c1;
+    return (int)min((v + 32768u) >> 16, 255u);
+}
+
+__global__ __launch_bounds__(256) void lsd_grad(const Plan* __restrict__ plan, const Coef* __restrict__ cxs, const Coef* __restrict__ cys,
+                                                uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    const Plan& P = *plan;
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.w || y >= P.h) return;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    float* ang = (float*)(F + P.off_ang);
+    uint32_t* g2a = (uint32_t*)(F + P.off_g2);
+    Misc* misc = miscs + b;
+    const size_t o = (size_t)y * P.w + x;
+    if (x >= P.w - 1 || y >= P.h - 1) { ang[o] = NOTDEF_F; g2a[o] = 0; return; }
+    const uint8_t* B7 = F + P.off_blur7;
+    const Coef cx0 = cxs[x], cx1 = cxs[x + 1], cy0 = cys[y], cy1 = cys[y + 1];
+    const int s00 = scaled_px(B7, P.W, cx0, cy0), s10 = scaled_px(B7, P.W, cx1, cy0);
+    const int s01 = scaled_px(B7, P.W, cx0, cy1), s11 = scaled_px(B7, P.W, cx1, cy1);
+    const int DA = s11 - s00, BC = s10 - s01;
+    const int gx = DA + BC, gy = DA - BC;
+    const int g2 = gx * gx + gy * gy;
+    const double norm = sqrt(g2 / 4.0);
+    g2a[o] = (uint32_t)g2;
+    if (norm <= P.rho) ang[o] = NOTDEF_F;
+    else {
+        ang[o] = fast_atan2_deg((float)gx, (float)(-gy));
+        atomicMax(&misc->g2max, (uint32_t)g2);
+    }
+}
+
+// ---- K3: descending 1024-bin order, raster order inside a bin -------------------------------------------------------
+__device__ inline int block_exscan256(int v, int* wsum, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < 4; i++) { if (i < w) base += wsum[i]; tot += wsum[i]; }
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    __shared__ int cnt[32 * 256];
+    __shared__ int wsum[4];
+    const Plan& P = *plan;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    const float* ang = (const float*)(F + P.off_ang);
+    const uint32_t* g2a = (const uint32_t*)(F + P.off_g2);
+    uint32_t* tmp = (uint32_t*)(F + P.off_tmp);
+    uint32_t* ord = (uint32_t*)(F + P.off_ord);
+    Misc* misc = miscs + b;
+    const int NP = P.w * P.h;
+    const double max_grad = misc->g2max ? sqrt(misc->g2max / 4.0) : -1.0;
+    const double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
+    // pass A: pixels (raster) -> tmp, by the low 5 bits of key = 1023 - bin
+    const int segA = (NP + 255) / 256, a0 = min(NP, tid * segA), a1 = min(NP, a0 + segA);
+    for (int d = 0; d < 32; d++) cnt[d * 256 + tid] = 0;
+    for (int i = a0; i < a1; i++)
+        if (ang[i] != NOTDEF_F) { const int key = (N_BINS - 1) - int(sqrt(g2a[i] / 4.0) * bin_coef); cnt[(key & 31) * 256 + tid]++; }
+    __syncthreads();
+    int total;
+    {
+        int local = 0;
+        for (int k = 0; k < 32; k++) local += cnt[tid * 32 + k];
+        int run = block_exscan256(local, wsum, &total);
+        for (int k = 0; k < 32; k++) { const int c = cnt[tid * 32 + k]; cnt[tid * 32 + k] = run; run += c; }
+    }
+    __syncthreads();
+    for (int i = a0; i < a1; i++)
+        if (ang[i] != NOTDEF_F) {
+            const int key = (N_BINS - 1) - int(sqrt(g2a[i] / 4.0) * bin_coef);
+            tmp[cnt[(key & 31) * 256 + tid]++] = ((uint32_t)key << 20) | (uint32_t)i;
+        }
+    const int N = total;
+    __threadfence_block();
+    __syncthreads();
+    // pass B: tmp -> ord, by the high 5 bits
+    const int segB = (N + 255) / 256, b0 = min(N, tid * segB), b1 = min(N, b0 + segB);
+    for (int d = 0; d < 32; d++) cnt[d * 256 + tid] = 0;
+    __syncthreads();
+    for (int i = b0; i < b1; i++) cnt[((tmp[i] >> 25) & 31) * 256 + tid]++;
+    __syncthreads();
+    {
+        int local = 0;
+        for (int k = 0; k < 32; k++) local += cnt[tid * 32 + k];
+        int run = block_exscan256(local, wsum, &total);
+        for (int k = 0; k < 32; k++) { const int c = cnt[tid * 32 + k]; cnt[tid * 32 + k] = run; run += c; }
+    }
+    __syncthreads();
+    for (int i = b0; i < b1; i++) { const uint32_t e = tmp[i]; ord[cnt[((e >> 25) & 31) * 256 + tid]++] = e & 0xfffffu; }
+    if (tid == 0) misc->n_ord = N;
+}
+
+// ---- K4: the sequential detector, one wavefront per frame -----------------------------------------------------------
+struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+
+struct Det {
+    const float* ang;
+    const uint32_t* g2;
+    uint32_t* reg;      // region points, x | y << 16, in growth order
+    uint32_t* tmp;      // scratch (reduce_region_radius)
+    int w, h;
+    double log_nt;
+    // LDS
+    uint32_t* used;     // bitmap
+    uint32_t* ring;
+    double* stage;      // [64][3]
+    int* rowL; int* rowR; int* pre;
+    int lane;
+};
+
+__device__ __forceinline__ bool used_get(const Det& D, int pix) { return (((volatile uint32_t*)D.used)[pix >> 5] >> (pix & 31)) & 1u; }
+__device__ __forceinline__ double dist2(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
+__device__ __forceinline__ double angle_diff_signed(double a, double b) {
+    double diff = a - b;
+    while (diff <= -LSD_PI) diff += M_2__PI;
+    while (diff > LSD_PI) diff -= M_2__PI;
+    return diff;
+}
+__device__ __forceinline__ bool aligned_rad(double a, double theta, double prec) {
+    double n_theta = theta - a;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI) {
+        n_theta -= M_2__PI;
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta <= prec;
+}
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+// region_grow: returns the region size; reg_angle in/out per the reference (out: final level-line angle)
+__device__ int region_grow(const Det& D, int seed_pix, double prec, double& reg_angle) {
+    const int lane = D.lane, w = D.w, h = D.h;
+    reg_angle = (double)D.ang[seed_pix] * DEG_TO_RADS;
+    float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
+    const uint32_t seed_xy = (uint32_t)(seed_pix % w) | ((uint32_t)(seed_pix / w) << 16);
+    if (lane == 0) { D.reg[0] = seed_xy; D.ring[0] = seed_xy; atomicOr(&D.used[seed_pix >> 5], 1u << (seed_pix & 31)); }
+    wave_sync();
+    int reg_n = 1, head = 0;
+    while (head < reg_n) {
+        const int nb = min(7, reg_n - head);
+        const int e = lane / 9, k = lane - e * 9;
+        bool ok = false;
+        int pix = 0;
+        uint32_t nxy = 0;
+        if (lane < 63 && e < nb && k != 4) {
+            const int i = head + e;
+            uint32_t pxy;
+            if (reg_n - i <= RING) pxy = ((volatile uint32_t*)D.ring)[i & (RING - 1)];
+            else pxy = __builtin_nontemporal_load(D.reg + i);
+            const int xx = (int)(pxy & 0xffff) + (k % 3) - 1, yy = (int)(pxy >> 16) + (k / 3) - 1;
+            if (xx >= 0 && xx < w && yy >= 0 && yy < h) { ok = true; pix = yy * w + xx; nxy = (uint32_t)xx | ((uint32_t)yy << 16); }
+        }
+        const float deg = ok ? D.ang[pix] : NOTDEF_F;
+        ok = ok && deg != NOTDEF_F;
+        const double a = (double)deg * DEG_TO_RADS;
+        float c = 0.f, s = 0.f;
+        if (ok) { const float af = (float)a; c = (float)cos((double)af); s = (float)sin((double)af); }
+        int cursor = 0;
+        while (true) {
+            const bool cand = ok && lane >= cursor && !used_get(D, pix) && aligned_rad(a, reg_angle, prec);
+            const unsigned long long m = __ballot(cand);
+            if (!m) break;
+            const int f = __ffsll((long long)m) - 1;
+            const uint32_t axy = (uint32_t)__shfl((int)nxy, f, 64);
+            if (lane == f) atomicOr(&D.used[pix >> 5], 1u << (pix & 31));
+            if (lane == 0) { D.reg[reg_n] = axy; D.ring[reg_n & (RING - 1)] = axy; }
+            reg_n++;
+            sumdx += __shfl(c, f, 64);
+            sumdy += __shfl(s, f, 64);
+            reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * DEG_TO_RADS;
+            cursor = f + 1;
+            wave_sync();
+        }
+        head += nb;
+    }
+    wave_sync();
+    return reg_n;
+}
+
+// three sequential FP64 chains (one per lane 0..2) over per-point triples, in region order: `acc[c] (+|-)= v[c]`
+// vals() fills the triple of point i; sign[c] = -1 makes chain c a subtraction chain.
+template <typename F>
+__device__ inline void chains3(const Det& D, int n, double out[3], bool sub2, F vals) {
+    const int lane = D.lane;
+    double acc = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        if (i < n) { double v[3]; vals(i, v); D.stage[lane * 3] = v[0]; D.stage[lane * 3 + 1] = v[1]; D.stage[lane * 3 + 2] = v[2]; }
+        wave_sync();
+        const int cnt = min(64, n - base);
+        if (lane < 3) {
+            const volatile double* st = D.stage;
+            if (lane == 2 && sub2) for (int j = 0; j < cnt; j++) acc -= st[j * 3 + 2];
+            else for (int j = 0; j < cnt; j++) acc += st[j * 3 + lane];
+        }
+        wave_sync();
+    }
+    out[0] = __shfl(acc, 0, 64); out[1] = __shfl(acc, 1, 64); out[2] = __shfl(acc, 2, 64);
+}
+
+__device__ inline double wave_max_d(double v) { for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; }
+__device__ inline double wave_min_d(double v) { for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64)); return v; }
+__device__ inline int wave_sum_i(int v) { for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+
+__device__ __forceinline__ double modgrad_of(const Det& D, uint32_t pxy) { return sqrt(D.g2[(pxy >> 16) * D.w + (pxy & 0xffff)] / 4.0); }
+
+__device__ void region2rect(const Det& D, int n, double reg_angle, double prec, double p, Rect& rec) {
+    double s3[3];
+    chains3(D, n, s3, false, [&](int i, double* v) {
+        const uint32_t e = D.reg[i];
+        const double wgt = modgrad_of(D, e);
+        v[0] = double(e & 0xffff) * wgt; v[1] = double(e >> 16) * wgt; v[2] = wgt;
+    });
+    const double x = s3[0] / s3[2], y = s3[1] / s3[2];
+    // get_theta
+    chains3(D, n, s3, true, [&](int i, double* v) {
+        const uint32_t e = D.reg[i];
+        const double wgt = modgrad_of(D, e);
+        const double dx = double(e & 0xffff) - x, dy = double(e >> 16) - y;
+        v[0] = dy * dy * wgt; v[1] = dx * dx * wgt; v[2] = dx * dy * wgt;
+    });
+    const double Ixx = s3[0], Iyy = s3[1], Ixy = s3[2];
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? double(fast_atan2_deg(float(lambda - Ixx), float(Ixy))) : double(fast_atan2_deg(float(Ixy), float(lambda - Iyy)));
+    theta *= DEG_TO_RADS;
+    if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += LSD_PI;
+    const double dx = cos(theta), dy = sin(theta);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int i = D.lane; i < n; i += 64) {
+        const uint32_t e = D.reg[i];
+        const double regdx = double(e & 0xffff) - x, regdy = double(e >> 16) - y;
+        const double l = regdx * dx + regdy * dy;
+        const double w = -regdx * dy + regdy * dx;
+        l_max = fmax(l_max, l); l_min = fmin(l_min, l); w_max = fmax(w_max, w); w_min = fmin(w_min, w);
+    }
+    l_max = wave_max_d(l_max); l_min = wave_min_d(l_min); w_max = wave_max_d(w_max); w_min = wave_min_d(w_min);
+    rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy;
+    rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+    rec.width = w_max - w_min;
+    rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy; rec.prec = prec; rec.p = p;
+    if (rec.width < 1.0) rec.width = 1.0;
+}
+
+__device__ bool reduce_region_radius(const Det& D, int& n, double reg_angle, double prec, double p, Rect& rec, double density, double density_th) {
+    const int lane = D.lane;
+    const uint32_t e0 = D.reg[0];
+    const double xc = double(e0 & 0xffff), yc = double(e0 >> 16);
+    const double radSq1 = dist2(xc, yc, rec.x1, rec.y1), radSq2 = dist2(xc, yc, rec.x2, rec.y2);
+    double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
+    while (density < density_th) {
+        radSq *= 0.75 * 0.75;
+        // the reference's swap-with-last removal == keep near points in place, fill each far slot below the new size with
+        // the near points found scanning from the back (LSD)
+        int n_near = 0;
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t e = D.reg[i];
+            const bool far = dist2(xc, yc, double(e & 0xffff), double(e >> 16)) > radSq;
+            if (far) { const int pix = (e >> 16) * D.w + (e & 0xffff); atomicAnd(&D.used[pix >> 5], ~(1u << (pix & 31))); }
+            else n_near++;
+        }
+        n_near = wave_sum_i(n_near);
+        int k = 0;
+        for (int base = n - 1; base >= n_near; base -= 64) {          // back part, descending positions
+            const int pos = base - lane;
+            bool near = false;
+            uint32_t e = 0;
+            if (pos >= n_near) { e = D.reg[pos]; near = !(dist2(xc, yc, double(e & 0xffff), double(e >> 16)) > radSq); }
+            const unsigned long long m = __ballot(near);
+            if (near) D.tmp[k + __popcll(m & ((1ull << lane) - 1))] = e;
+            k += __popcll(m);
+        }
+        wave_sync();
+        k = 0;
+        for (int base = 0; base < n_near; base += 64) {               // front part, ascending positions
+            const int pos = base + lane;
+            bool far = false;
+            if (pos < n_near) { const uint32_t e = D.reg[pos]; far = dist2(xc, yc, double(e & 0xffff), double(e >> 16)) > radSq; }
+            const unsigned long long m = __ballot(far);
+            if (far) D.reg[pos] = D.tmp[k + __popcll(m & ((1ull << lane) - 1))];
+            k += __popcll(m);
+        }
+        wave_sync();
+        n = n_near;
+        if (n < 2) return false;
+        region2rect(D, n, reg_angle, prec, p, rec);
+        density = double(n) / (sqrt(dist2(rec.x1, rec.y1, rec.x2, rec.y2)) * rec.width);
+    }
+    return true;
+}
+
+__device__ bool refine(const Det& D, int& n, double& reg_angle, double prec, double p, Rect& rec, double density_th) {
+    double density = double(n) / (sqrt(dist2(rec.x1, rec.y1, rec.x2, rec.y2)) * rec.width);
+    if (density >= density_th) return true;
+    const uint32_t e0 = D.reg[0];
+    const double xc = double(e0 & 0xffff), yc = double(e0 >> 16);
+    const int seed_pix = (e0 >> 16) * D.w + (e0 & 0xffff);
+    const double ang_c = (double)D.ang[seed_pix] * DEG_TO_RADS;
+    const double width = rec.width;
+    double s3[3];
+    int cnt = 0;
+    chains3(D, n, s3, false, [&](int i, double* v) {
+        const uint32_t e = D.reg[i];
+        const int pix = (e >> 16) * D.w + (e & 0xffff);
+        atomicAnd(&D.used[pix >> 5], ~(1u << (pix & 31)));
+        v[0] = 0; v[1] = 0; v[2] = 0;
+        if (sqrt(dist2(xc, yc, double(e & 0xffff), double(e >> 16))) < width) {
+            const double ang_d = angle_diff_signed((double)D.ang[pix] * DEG_TO_RADS, ang_c);
+            v[0] = ang_d; v[1] = ang_d * ang_d; cnt++;
+        }
+    });
+    // adding +0.0 for skipped points leaves the partial sums unchanged bit for bit (x + 0.0 == x, and sums never are -0.0 + ... issue:
+    // the first addend 0.0 + v is exact), so the conditional chain equals the reference's
+    cnt = wave_sum_i(cnt);
+    const double sum = s3[0], s_sum = s3[1];
+    const double mean_angle = sum / double(cnt);
+    const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / double(cnt) + mean_angle * mean_angle);
+    wave_sync();
+    n = region_grow(D, seed_pix, tau, reg_angle);
+    if (n < 2) return false;
+    region2rect(D, n, reg_angle, prec, p, rec);
+    density = double(n) / (sqrt(dist2(rec.x1, rec.y1, rec.x2, rec.y2)) * rec.width);
+    if (density < density_th) return reduce_region_radius(D, n, reg_angle, prec, p, rec, density, density_th);
+    return true;
+}
+
+__device__ inline bool double_equal(double a, double b) {
+    if (a == b) return true;
+    const double abs_diff = fabs(a - b), aa = fabs(a), bb = fabs(b);
+    double abs_max = (aa > bb) ? aa : bb;
+    if (abs_max < 2.2250738585072014e-308) abs_max = 2.2250738585072014e-308;
+    return (abs_diff / abs_max) <= (RELATIVE_ERROR_FACTOR * 2.220446049250313e-16);
+}
+__device__ inline double log_gamma(double x) {
+    if (x > 15.0) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+    const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * log(x + 5.5) - (x + 5.5);
+    double b = 0;
+    for (int n = 0; n < 7; ++n) { a -= log(x + double(n)); b += q[n] * pow(x, double(n)); }
+    return a + log(b);
+}
+__device__ double nfa(double LOG_NT, int n, int k, double p) {
+    if (n == 0 || k == 0) return -LOG_NT;
+    if (n == k) return -LOG_NT - double(n) * log10(p);
+    const double p_term = p / (1 - p);
+    const double log1term = log_gamma(double(n) + 1) - log_gamma(double(k) + 1) - log_gamma(double(n - k) + 1) + double(k) * log(p) + double(n - k) * log(1.0 - p);
+    double term = exp(log1term);
+    if (double_equal(term, 0)) {
+        if (k > n * p) return -log1term / 2.30258509299404568402 - LOG_NT;
+        else return -LOG_NT;
+    }
+    double bin_tail = term;
+    const double tolerance = 0.1;
+    for (int i = k + 1; i <= n; ++i) {
+        const double bin_term = double(n - i + 1) / double(i);
+        const double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1) {
+            const double err = term * ((1 - pow(mult_term, double(n - i + 1))) / (1 - mult_term) - 1);
+            if (err < tolerance * fabs(-log10(bin_tail) - LOG_NT) * bin_tail) break;
+        }
+    }
+    return -log10(bin_tail) - LOG_NT;
+}
+
+__device__ double rect_nfa(const Det& D, const Rect& rec) {
+    const int lane = D.lane;
+    const double half_width = rec.width / 2.0;
+    const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
+    int ox[4], oy[4];
+    ox[0] = int(rec.x1 - dyhw); oy[0] = int(rec.y1 + dxhw);
+    ox[1] = int(rec.x2 - dyhw); oy[1] = int(rec.y2 + dxhw);
+    ox[2] = int(rec.x2 + dyhw); oy[2] = int(rec.y2 - dxhw);
+    ox[3] = int(rec.x1 + dyhw); oy[3] = int(rec.y1 - dxhw);
+    // std::sort of 4 elements == insertion sort by (x, then y)
+    for (int i = 1; i < 4; i++) {
+        const int vx = ox[i], vy = oy[i];
+        int j = i - 1;
+        while (j >= 0 && (vx == ox[j] ? vy < oy[j] : vx < ox[j])) { ox[j + 1] = ox[j]; oy[j + 1] = oy[j]; j--; }
+        ox[j + 1] = vx; oy[j + 1] = vy;
+    }
+    int min_y = 0, max_y = 0;
+    for (int i = 1; i < 4; ++i) {
+        if (oy[min_y] > oy[i]) min_y = i;
+        if (oy[max_y] < oy[i]) max_y = i;
+    }
+    bool taken[4] = {false, false, false, false};
+    taken[min_y] = true;
+    int leftmost = -1;
+    for (int i = 0; i < 4; ++i) if (!taken[i]) { if (leftmost < 0) leftmost = i; else if (ox[leftmost] > ox[i]) leftmost = i; }
+    taken[leftmost] = true;
+    int rightmost = -1;
+    for (int i = 0; i < 4; ++i) if (!taken[i]) { if (rightmost < 0) rightmost = i; else if (ox[rightmost] < ox[i]) rightmost = i; }
+    taken[rightmost] = true;
+    int tailp = -1;
+    for (int i = 0; i < 4; ++i) if (!taken[i]) { if (tailp < 0) tailp = i; else if (ox[tailp] > ox[i]) tailp = i; }
+    const double flstep = (oy[min_y] != oy[leftmost]) ? (ox[min_y] - ox[leftmost]) / (oy[min_y] - oy[leftmost]) : 0;
+    const double slstep = (oy[leftmost] != ox[tailp]) ? (ox[leftmost] - ox[tailp]) / (oy[leftmost] - ox[tailp]) : 0;
+    const double frstep = (oy[min_y] != oy[rightmost]) ? (ox[min_y] - ox[rightmost]) / (oy[min_y] - oy[rightmost]) : 0;
+    const double srstep = (oy[rightmost] != ox[tailp]) ? (ox[rightmost] - ox[tailp]) / (oy[rightmost] - ox[tailp]) : 0;
+    double lstep = flstep, rstep = frstep;
+    double left_x = ox[min_y], right_x = ox[min_y];
+    const int min_iter = oy[min_y], max_iter = oy[max_y];
+    // row table (in-image rows only), built in row order by every lane redundantly; lane 0 stores it
+    int nrows = 0, total = 0;
+    for (int y = min_iter; y <= max_iter; ++y) {
+        if (y < 0 || y >= D.h) continue;
+        int xa = int(left_x), xb = int(right_x);
+        // count of x in [xa, xb] with 0 <= x < w
+        const int ca = max(xa, 0), cb = min(xb, D.w - 1);
+        const int c = cb >= ca ? cb - ca + 1 : 0;
+        if (lane == 0) { D.rowL[nrows] = ca; D.rowR[nrows] = y; D.pre[nrows] = total; }
+        nrows++;
+        total += c;
+        if (y >= oy[leftmost]) lstep = slstep;
+        if (y >= oy[rightmost]) rstep = srstep;
+        left_x += lstep;
+        right_x += rstep;
+    }
+    if (lane == 0) D.pre[nrows] = total;
+    wave_sync();
+    int alg = 0;
+    const volatile int* pre = D.pre;
+    for (int t = lane; t < total; t += 64) {
+        int lo = 0, hi = nrows - 1;           // last row with pre[row] <= t
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid - 1; }
+        const int x = ((volatile int*)D.rowL)[lo] + (t - pre[lo]), y = ((volatile int*)D.rowR)[lo];
+        const float deg = D.ang[y * D.w + x];
+        if (deg != NOTDEF_F && aligned_rad((double)deg * DEG_TO_RADS, rec.theta, rec.prec)) alg++;
+    }
+    alg = wave_sum_i(alg);
+    wave_sync();
+    return nfa(D.log_nt, total, alg, rec.p);
+}
+
+__device__ double rect_improve(const Det& D, Rect& rec, double LOG_EPS) {
+    const double delta = 0.5, delta_2 = delta / 2.0;
+    double log_nfa = rect_nfa(D, rec);
+    if (log_nfa > LOG_EPS) return log_nfa;
+    Rect r = rec;
+    for (int n = 0; n < 5; ++n) {
+        r.p /= 2;
+        r.prec = r.p * LSD_PI;
+        const double v = rect_nfa(D, r);
+        if (v > log_nfa) { log_nfa = v; rec = r; }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.width -= delta;
+            const double v = rect_nfa(D, r);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
+            r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+            r.width -= delta;
+            const double v = rect_nfa(D, r);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
+            r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+            r.width -= delta;
+            const double v = rect_nfa(D, r);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.p /= 2;
+            r.prec = r.p * LSD_PI;
+            const double v = rect_nfa(D, r);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    return log_nfa;
+}
+
+struct Seg { float x1, y1, x2, y2; double width, p, nfa; };
+
+__global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const Plan& P = *plan;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    Misc* misc = miscs + b;
+    Det D;
+    D.ang = (const float*)(F + P.off_ang); D.g2 = (const uint32_t*)(F + P.off_g2);
+    D.reg = (uint32_t*)(F + P.off_reg); D.tmp = (uint32_t*)(F + P.off_tmp);
+    D.w = P.w; D.h = P.h; D.log_nt = P.log_nt; D.lane = lane;
+    const int used_words = (P.w * P.h + 31) / 32;
+    uint8_t* q = lds_raw;
+    D.stage = (double*)q; q += 64 * 3 * 8;
+    D.used = (uint32_t*)q; q += (size_t)used_words * 4;
+    D.ring = (uint32_t*)q; q += RING * 4;
+    D.rowL = (int*)q; q += MAX_ROWS * 4;
+    D.rowR = (int*)q; q += MAX_ROWS * 4;
+    D.pre = (int*)q;
+    for (int i = lane; i < used_words; i += 64) D.used[i] = 0;
+    wave_sync();
+    const uint32_t* ord = (const uint32_t*)(F + P.off_ord);
+    Seg* segs = (Seg*)(F + P.off_segs);
+    const int n_ord = misc->n_ord;
+    int n_seg = 0, n_regions = 0;
+    for (int base = 0; base < n_ord; base += 64) {
+        const int pix = base + lane < n_ord ? (int)ord[base + lane] : -1;
+        int cursor = 0;
+        while (true) {
+            const bool cand = pix >= 0 && lane >= cursor && !used_get(D, pix);
+            const unsigned long long m = __ballot(cand);
+            if (!m) break;
+            const int f = __ffsll((long long)m) - 1;
+            cursor = f + 1;
+            const int seed = __shfl(pix, f, 64);
+            double reg_angle;
+            int n = region_grow(D, seed, P.prec, reg_angle);
+            n_regions++;
+            if (n < P.min_reg_size) continue;
+            Rect rec;
+            region2rect(D, n, reg_angle, P.prec, P.p, rec);
+            if (!refine(D, n, reg_angle, P.prec, P.p, rec, P.density_th)) continue;
+            const double log_nfa = rect_improve(D, rec, P.log_eps);
+            if (log_nfa <= P.log_eps) continue;
+            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+            rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8; rec.width /= 0.8;
+            if (lane == 0 && n_seg < MAX_SEGS) segs[n_seg] = Seg{float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2), rec.width, rec.p, log_nfa};
+            n_seg++;
+        }
+    }
+    if (lane == 0) { misc->n_seg = n_seg; misc->n_regions = n_regions; if (n_seg > MAX_SEGS) misc->status = 1; }
+}
+
+// ---- K5: Sobel 3x3 (cv::Sobel CV_16S, BORDER_REFLECT_101) of the 5x5-blurred image ------------------------------------
+__global__ __launch_bounds__(256) void lbd_sobel(const Plan* __restrict__ plan, uint8_t* __restrict__ ws) {
+    const Plan& P = *plan;
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.H) return;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    const uint8_t* S = F + P.off_blur5;
+    const int W = P.W, H = P.H;
+    const uint8_t* r0 = S + (size_t)reflect101(y - 1, H) * W;
+    const uint8_t* r1 = S + (size_t)y * W;
+    const uint8_t* r2 = S + (size_t)reflect101(y + 1, H) * W;
+    const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
+    ((int16_t*)(F + P.off_dx))[(size_t)y * W + x] = (int16_t)((r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]));
+    ((int16_t*)(F + P.off_dy))[(size_t)y * W + x] = (int16_t)((r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]));
+}
+
+// ---- K6: KeyLines + std::sort by response + keep max_lines + line equations --------------------------------------------
+// libstdc++ std::sort (bits/stl_algo.h: __introsort_loop, __unguarded_partition_pivot, __final_insertion_sort,
+// heap fallback) on keys[] (descending `response`), carrying idx[]; executed by one lane, data in LDS.
+struct SortBuf { float* key; int* idx; };
+__device__ inline bool sort_comp(float a, float b) { return a > b; }   // sort_lines_by_response (include/auxiliar.h:43-48)
+__device__ inline void sort_swap(const SortBuf& s, int a, int b) {
+    const float k = s.key[a]; s.key[a] = s.key[b]; s.key[b] = k;
+    const int i = s.idx[a]; s.idx[a] = s.idx[b]; s.idx[b] = i;
+}
+__device__ void adjust_heap(const SortBuf& s, int first, int hole, int len, float vk, int vi) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (sort_comp(s.key[first + child], s.key[first + child - 1])) child--;
+        s.key[first + hole] = s.key[first + child]; s.idx[first + hole] = s.idx[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        s.key[first + hole] = s.key[first + child - 1]; s.idx[first + hole] = s.idx[first + child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;   // __push_heap
+    while (hole > top && sort_comp(s.key[first + parent], vk)) {
+        s.key[first + hole] = s.key[first + parent]; s.idx[first + hole] = s.idx[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    s.key[first + hole] = vk; s.idx[first + hole] = vi;
+}
+__device__ void heap_sort_range(const SortBuf& s, int first, int last) {   // __partial_sort(first, last, last)
+    const int len = last - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            adjust_heap(s, first, parent, len, s.key[first + parent], s.idx[first + parent]);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    int l = last;
+    while (l - first > 1) {   // __sort_heap -> __pop_heap(first, last-1, last-1)
+        --l;
+        const float vk = s.key[l]; const int vi = s.idx[l];
+        s.key[l] = s.key[first]; s.idx[l] = s.idx[first];
+        adjust_heap(s, first, 0, l - first, vk, vi);
+    }
+}
+__device__ void std_sort_desc(const SortBuf& s, int n) {
+    if (n <= 0) return;
+    // explicit stack replaces the recursion on the right part
+    int stack_first[64], stack_last[64], stack_depth[64], sp = 0;
+    int lg = 0; { int t = n; while (t > 1) { t >>= 1; lg++; } }
+    stack_first[sp] = 0; stack_last[sp] = n; stack_depth[sp] = 2 * lg; sp++;
+    while (sp > 0) {
+        sp--;
+        int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
+        while (last - first > 16) {
+            if (depth == 0) { heap_sort_range(s, first, last); break; }
+            --depth;
+            // __move_median_to_first(first, first+1, mid, last-1)
+            const int mid = first + (last - first) / 2;
+            const int a = first + 1, bb = mid, c = last - 1;
+            if (sort_comp(s.key[a], s.key[bb])) {
+                if (sort_comp(s.key[bb], s.key[c])) sort_swap(s, first, bb);
+                else if (sort_comp(s.key[a], s.key[c])) sort_swap(s, first, c);
+                else sort_swap(s, first, a);
+            } else if (sort_comp(s.key[a], s.key[c])) sort_swap(s, first, a);
+            else if (sort_comp(s.key[bb], s.key[c])) sort_swap(s, first, c);
+            else sort_swap(s, first, bb);
+            // __unguarded_partition(first+1, last, first)
+            int lo = first + 1, hi = last;
+            const float pv = s.key[first];
+            while (true) {
+                while (sort_comp(s.key[lo], pv)) ++lo;
+                --hi;
+                while (sort_comp(pv, s.key[hi])) --hi;
+                if (!(lo < hi)) break;
+                sort_swap(s, lo, hi);
+                ++lo;
+            }
+            const int cut = lo;
+            stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; sp++;   // __introsort_loop(cut, last, depth)
+            last = cut;
+        }
+    }
+    // __final_insertion_sort
+    auto linear_insert = [&](int last) {
+        const float vk = s.key[last]; const int vi = s.idx[last];
+        int next = last - 1;
+        while (sort_comp(vk, s.key[next])) { s.key[last] = s.key[next]; s.idx[last] = s.idx[next]; last = next; --next; }
+        s.key[last] = vk; s.idx[last] = vi;
+    };
+    auto insertion = [&](int first, int last) {
+        for (int i = first + 1; i < last; ++i) {
+            if (sort_comp(s.key[i], s.key[first])) {
+                const float vk = s.key[i]; const int vi = s.idx[i];
+                for (int j = i; j > first; --j) { s.key[j] = s.key[j - 1]; s.idx[j] = s.idx[j - 1]; }
+                s.key[first] = vk; s.idx[first] = vi;
+            } else linear_insert(i);
+        }
+    };
+    if (n > 16) { insertion(0, 16); for (int i = 16; i < n; ++i) linear_insert(i); }
+    else insertion(0, n);
+}
+
+__device__ inline planar_keyline make_keyline(const Seg& sg, int cols, int rows, int class_id) {
+    float e[4] = {sg.x1, sg.y1, sg.x2, sg.y2};
+    // LSDDetector::checkLineExtremes
+    if (e[0] < 0) e[0] = 0;
+    if (e[0] >= cols) e[0] = (float)cols - 1.0f;
+    if (e[2] < 0) e[2] = 0;
+    if (e[2] >= cols) e[2] = (float)cols - 1.0f;
+    if (e[1] < 0) e[1] = 0;
+    if (e[1] >= rows) e[1] = (float)rows - 1.0f;
+    if (e[3] < 0) e[3] = 0;
+    if (e[3] >= rows) e[3] = (float)rows - 1.0f;
+    planar_keyline kl;
+    const float octaveScale = 1.0f;
+    kl.start_x = e[0] * octaveScale; kl.start_y = e[1] * octaveScale; kl.end_x = e[2] * octaveScale; kl.end_y = e[3] * octaveScale;
+    kl.s_oct_x = e[0]; kl.s_oct_y = e[1]; kl.e_oct_x = e[2]; kl.e_oct_y = e[3];
+    const double d0 = (double)(e[0] - e[2]), d1 = (double)(e[1] - e[3]);
+    kl.line_length = (float)sqrt(d0 * d0 + d1 * d1);
+    const int ax = (int)rintf(e[0]), ay = (int)rintf(e[1]), bx = (int)rintf(e[2]), by = (int)rintf(e[3]);
+    kl.num_pixels = max(abs(bx - ax), abs(by - ay)) + 1;
+    kl.angle = (float)atan2((double)(kl.end_y - kl.start_y), (double)(kl.end_x - kl.start_x));
+    kl.class_id = class_id;
+    kl.octave = 0;
+    kl.size = (kl.end_x - kl.start_x) * (kl.end_y - kl.start_y);
+    kl.response = kl.line_length / (float)max(cols, rows);
+    kl.pt_x = (kl.end_x + kl.start_x) / 2;
+    kl.pt_y = (kl.end_y + kl.start_y) / 2;
+    return kl;
+}
+
+__global__ __launch_bounds__(64) void lsd_keylines(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int max_lines,
+                                                   planar_keyline* __restrict__ out_kl, double* __restrict__ out_eq, int32_t* __restrict__ n_out) {
+    __shared__ float key[MAX_SEGS];
+    __shared__ int idx[MAX_SEGS];
+    const Plan& P = *plan;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    Misc* misc = miscs + b;
+    const Seg* segs = (const Seg*)(F + P.off_segs);
+    const int n = min(misc->n_seg, MAX_SEGS);
+    for (int i = lane; i < n; i += 64) { key[i] = make_keyline(segs[i], P.W, P.H, i).response; idx[i] = i; }
+    __syncthreads();
+    int nk = n;
+    if (n > max_lines) {
+        if (lane == 0) { SortBuf s{key, idx}; std_sort_desc(s, n); }
+        __syncthreads();
+        nk = max_lines;
+    }
+    planar_keyline* K = out_kl + (size_t)b * max_lines;
+    planar_keyline* Kws = (planar_keyline*)(F + P.off_kl);
+    for (int i = lane; i < nk; i += 64) {
+        const planar_keyline kl = make_keyline(segs[idx[i]], P.W, P.H, n > max_lines ? i : idx[i]);
+        K[i] = kl; Kws[i] = kl;
+        const double sp0 = kl.start_x, sp1 = kl.start_y, ep0 = kl.end_x, ep1 = kl.end_y;
+        const double l0 = sp1 * 1.0 - 1.0 * ep1, l1 = 1.0 * ep0 - sp0 * 1.0, l2 = sp0 * ep1 - sp1 * ep0;
+        const double nrm = sqrt(l0 * l0 + l1 * l1 + l2 * l2);
+        double* E = out_eq + ((size_t)b * max_lines + i) * 3;
+        E[0] = l0 / nrm; E[1] = l1 / nrm; E[2] = l2 / nrm;
+    }
+    if (lane == 0) { n_out[b] = nk; misc->n_kl = nk; }
+}
+
+// ---- K7: LBD (BinaryDescriptor::computeLBD + binaryConversion), one wavefront per kept line ----------------------------
+constexpr int NUM_OF_BANDS = 9, WIDTH_OF_BAND = 7, LSP_H = 63;
+__constant__ int LBD_COMB[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6}, {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7},
+                                    {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8}, {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
+
+__global__ __launch_bounds__(64) void lbd_describe(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, const Misc* __restrict__ miscs, int max_lines,
+                                                   uint8_t* __restrict__ out_desc) {
+    __shared__ float row[LSP_H][8];    // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 row sums (after the global weight)
+    __shared__ float des[NUM_OF_BANDS * 8];
+    const Plan& P = *plan;
+    const int b = blockIdx.y, li = blockIdx.x, lane = threadIdx.x;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    const Misc* misc = miscs + b;
+    if (li >= misc->n_kl) return;
+    const planar_keyline L = ((const planar_keyline*)(F + P.off_kl))[li];
+    const int16_t* dxImg = (const int16_t*)(F + P.off_dx);
+    const int16_t* dyImg = (const int16_t*)(F + P.off_dy);
+    const short realWidth = (short)P.W, imageWidth = (short)(P.W - 1), imageHeight = (short)(P.H - 1);
+    const short lengthOfLSP = (short)L.num_pixels;
+    const short halfWidth = (lengthOfLSP - 1) / 2, halfHeight = (LSP_H - 1) / 2;
+    const float lineMiddlePointX = (float)(0.5 * (L.s_oct_x + L.e_oct_x));
+    const float lineMiddlePointY = (float)(0.5 * (L.s_oct_y + L.e_oct_y));
+    float dL[2], dO[2];
+    dL[0] = (float)cos((double)L.angle); dL[1] = (float)sin((double)L.angle);
+    dO[0] = -dL[1]; dO[1] = dL[0];
+    if (lane < LSP_H) {
+        float sCorX0 = -dL[0] * halfWidth + dL[1] * halfHeight + lineMiddlePointX;
+        float sCorY0 = -dL[1] * halfWidth - dL[0] * halfHeight + lineMiddlePointY;
+        for (int h = 0; h < lane; h++) { sCorX0 -= dL[1]; sCorY0 += dL[0]; }
+        float sCorX = sCorX0, sCorY = sCorY0;
+        float pgdLRowSum = 0, ngdLRowSum = 0, pgdORowSum = 0, ngdORowSum = 0;
+        for (short wID = 0; wID < lengthOfLSP; wID++) {
+            short tempCor = (short)roundf(sCorX);
+            const short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
+            tempCor = (short)roundf(sCorY);
+            const short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
+            const short dx = dxImg[(size_t)yCor * realWidth + xCor], dy = dyImg[(size_t)yCor * realWidth + xCor];
+            const float gDL = dx * dL[0] + dy * dL[1];
+            const float gDO = dx * dO[0] + dy * dO[1];
+            if (gDL > 0) pgdLRowSum += gDL; else ngdLRowSum -= gDL;
+            if (gDO > 0) pgdORowSum += gDO; else ngdORowSum -= gDO;
+            sCorX += dL[0];
+            sCorY += dL[1];
+        }
+        const float coef = (float)P.gaussCoefG[lane];
+        pgdLRowSum = coef * pgdLRowSum; ngdLRowSum = coef * ngdLRowSum;
+        pgdORowSum = coef * pgdORowSum; ngdORowSum = coef * ngdORowSum;
+        row[lane][0] = pgdLRowSum; row[lane][1] = ngdLRowSum; row[lane][2] = pgdLRowSum * pgdLRowSum; row[lane][3] = ngdLRowSum * ngdLRowSum;
+        row[lane][4] = pgdORowSum; row[lane][5] = ngdORowSum; row[lane][6] = pgdORowSum * pgdORowSum; row[lane][7] = ngdORowSum * ngdORowSum;
+    }
+    __syncthreads();
+    if (lane < NUM_OF_BANDS) {
+        // rows reach band `lane` in hID order: band-1 rows (as their "below" band), own rows, band+1 rows (as their "above" band)
+        float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int h0 = max(0, (lane - 1) * WIDTH_OF_BAND), h1 = min(LSP_H, (lane + 2) * WIDTH_OF_BAND);
+        for (int hID = h0; hID < h1; hID++) {
+            const int own = hID / WIDTH_OF_BAND;
+            float c;
+            if (own == lane) c = (float)P.gaussCoefL[hID % WIDTH_OF_BAND + WIDTH_OF_BAND];
+            else if (own == lane + 1) c = (float)P.gaussCoefL[hID % WIDTH_OF_BAND + 2 * WIDTH_OF_BAND];
+            else c = (float)P.gaussCoefL[hID % WIDTH_OF_BAND];
+            sum[0] += c * row[hID][0]; sum[1] += c * row[hID][1]; sum[2] += c * c * row[hID][2]; sum[3] += c * c * row[hID][3];
+            sum[4] += c * row[hID][4]; sum[5] += c * row[hID][5]; sum[6] += c * c * row[hID][6]; sum[7] += c * c * row[hID][7];
+        }
+        const float invN2 = (float)(1.0 / (WIDTH_OF_BAND * 2.0)), invN3 = (float)(1.0 / (WIDTH_OF_BAND * 3.0));
+        const float invN = (lane == 0 || lane == NUM_OF_BANDS - 1) ? invN2 : invN3;
+        float* d = des + lane * 8;
+        float temp = sum[0] * invN;
+        d[0] = temp; d[4] = sqrtf(sum[2] * invN - temp * temp);
+        temp = sum[1] * invN;
+        d[1] = temp; d[5] = sqrtf(sum[3] * invN - temp * temp);
+        temp = sum[4] * invN;
+        d[2] = temp; d[6] = sqrtf(sum[6] * invN - temp * temp);
+        temp = sum[5] * invN;
+        d[3] = temp; d[7] = sqrtf(sum[7] * invN - temp * temp);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float tempM = 0, tempS = 0;
+        for (int i = 0; i < NUM_OF_BANDS; i++) {
+            const float* d = des + 8 * i;
+            tempM += d[0] * d[0]; tempM += d[1] * d[1]; tempM += d[2] * d[2]; tempM += d[3] * d[3];
+            tempS += d[4] * d[4]; tempS += d[5] * d[5]; tempS += d[6] * d[6]; tempS += d[7] * d[7];
+        }
+        tempM = 1 / sqrtf(tempM);
+        tempS = 1 / sqrtf(tempS);
+        for (int i = 0; i < NUM_OF_BANDS; i++) {
+            float* d = des + 8 * i;
+            d[0] *= tempM; d[1] *= tempM; d[2] *= tempM; d[3] *= tempM;
+            d[4] *= tempS; d[5] *= tempS; d[6] *= tempS; d[7] *= tempS;
+        }
+        for (int i = 0; i < NUM_OF_BANDS * 8; i++) if ((double)des[i] > 0.4) des[i] = (float)0.4;
+        float temp = 0;
+        for (int i = 0; i < NUM_OF_BANDS * 8; i++) temp += des[i] * des[i];
+        temp = 1 / sqrtf(temp);
+        for (int i = 0; i < NUM_OF_BANDS * 8; i++) des[i] = des[i] * temp;
+    }
+    __syncthreads();
+    if (lane < 32) {
+        const float *f1 = &des[8 * LBD_COMB[lane][0]], *f2 = &des[8 * LBD_COMB[lane][1]];
+        uint8_t result = 0;
+        for (int i = 0; i < 8; i++) if (f1[i] > f2[i]) result += (uint8_t)(128 >> i);
+        out_desc[((size_t)b * max_lines + li) * 32 + lane] = result;
+    }
+}
+
+// debug: device std::sort emulation on raw keys (tests/test_lsd_gpu.py checks it against libstdc++)
+__global__ __launch_bounds__(64) void debug_sort_kernel(float* key, int* idx, int n) {
+    if (threadIdx.x == 0) { SortBuf s{key, idx}; std_sort_desc(s, n); }
+}
+
+}  // namespace lsd
+}  // namespace planar
+
+using namespace planar;
+
+struct planar_lsd {
+    planar_ctx* ctx = nullptr;
+    int W = 0, H = 0, max_batch = 0;
+    lsd::Plan plan{};
+    int detect_smem = 0;
+    DevBuf d_plan, d_cx, d_cy, d_taps, d_ws, d_misc;
+    DevBuf d_in, d_kl, d_desc, d_eq, d_n;   // staging for the host-pointer entry point
+    int stage_lines = 0;
+};
+
+// host mirrors of the oracle's coefficient tables (same expressions, same libm)
+static void host_taps_q8(int ksize, double sigma, int* taps) {
+    const double scale2X = -0.5 / (sigma * sigma);
+    std::vector<double> v(ksize);
+    double sum = 0;
+    for (int i = 0; i < ksize; i++) { const double x = i - (ksize - 1) * 0.5; v[i] = std::exp(scale2X * x * x); sum += v[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < ksize; i++) taps[i] = (int)std::nearbyint(v[i] * sum * 256.0);
+}
+static bool host_exact_coefs(double inv_scale, int srcsize, int dstsize, std::vector<lsd::Coef>& out) {
+    const double scale = 1.0 / inv_scale;
+    out.assign(dstsize, lsd::Coef{0, 0, 0});
+    for (int val = 0; val < dstsize; val++) {
+        const double fval = scale * ((double)val + 0.5) - 0.5;
+        const int ival = (int)std::floor(fval);
+        if (!(ival >= 0 && ival < srcsize - 1)) return false;   // border replication never triggers for a 0.8x downscale
+        out[val].ofs = ival;
+        out[val].c1 = (int)std::nearbyint((fval - (double)ival) * 256.0);
+        out[val].c0 = 256 - out[val].c1;
+    }
+    return true;
+}
+
+extern "C" {
+
+int planar_lsd_max_segments(void) { return lsd::MAX_SEGS; }
+
+int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, planar_lsd** out) {
+    PLANAR_REQUIRE(ctx && out, PLANAR_EINVAL, "null argument");
+    *out = nullptr;
+    PLANAR_REQUIRE(width >= 32 && height >= 32 && width <= 4096 && height <= 1280, PLANAR_EINVAL, "image size out of range (32..4096 x 32..1280)");
+    PLANAR_REQUIRE(max_batch >= 1, PLANAR_EINVAL, "max_batch must be >= 1");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    planar_lsd* o = new (std::nothrow) planar_lsd();
+    PLANAR_REQUIRE(o != nullptr, PLANAR_ENOMEM, "host allocation failed");
+    o->ctx = ctx; o->W = width; o->H = height; o->max_batch = max_batch;
+    lsd::Plan& P = o->plan;
+    // createLineSegmentDetector(LSD_REFINE_ADV) defaults, evaluated as LineSegmentDetectorImpl::flsd does
+    const double SCALE = 0.8, SIGMA_SCALE = 0.6, QUANT = 2.0, ANG_TH = 22.5;
+    P.W = width; P.H = height;
+    P.w = (int)std::nearbyint(width * SCALE); P.h = (int)std::nearbyint(height * SCALE);
+    P.prec = lsd::LSD_PI * ANG_TH / 180; P.p = ANG_TH / 180; P.rho = QUANT / std::sin(P.prec);
+    P.density_th = 0.7; P.log_eps = 0;
+    const double sigma = SIGMA_SCALE / SCALE;
+    const unsigned hk = (unsigned)(std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0))));
+    if (1 + 2 * (int)hk != 7) { delete o; set_error("planar_lsd_create: unexpected LSD Gaussian size"); return PLANAR_EINVAL; }
+    host_taps_q8(7, sigma, P.taps7);
+    host_taps_q8(5, 1.0, P.taps5);
+    P.log_nt = 5 * (std::log10(double(P.w)) + std::log10(double(P.h))) / 2 + std::log10(11.0);
+    P.min_reg_size = (int)(size_t)(-P.log_nt / std::log10(P.p));
+    {   // BinaryDescriptor::BinaryDescriptor weights (integer divisions are the library's)
+        double u = (7 * 3 - 1) / 2, sg = (7 * 2 + 1) / 2, inv = -1 / (2 * sg * sg);
+        for (int i = 0; i < 21; i++) { const double dis = i - u; P.gaussCoefL[i] = std::exp(dis * dis * inv); }
+        u = (9 * 7 - 1) / 2; sg = (9 * 7) / 2; inv = -1 / (2 * sg * sg);
+        for (int i = 0; i < 63; i++) { const double dis = i - u; P.gaussCoefG[i] = std::exp(dis * dis * inv); }
+    }
+    std::vector<lsd::Coef> cx, cy;
+    if (!host_exact_coefs(SCALE, width, P.w, cx) || !host_exact_coefs(SCALE, height, P.h, cy)) {
+        delete o; set_error("planar_lsd_create: resample table hit the border path"); return PLANAR_EINVAL;
+    }
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o2 = off; off = align_up(off + bytes, (size_t)256); return o2; };
+    const size_t NPf = (size_t)width * height, NPs = (size_t)P.w * P.h;
+    P.off_blur7 = carve(NPf); P.off_blur5 = carve(NPf); P.off_dx = carve(NPf * 2); P.off_dy = carve(NPf * 2);
+    P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
+    P.off_segs = carve((size_t)lsd::MAX_SEGS * sizeof(lsd::Seg)); P.off_kl = carve((size_t)lsd::MAX_SEGS * sizeof(planar_keyline));
+    P.frame_bytes = off;
+    o->detect_smem = 64 * 3 * 8 + (int)((NPs + 31) / 32) * 4 + lsd::RING * 4 + 3 * lsd::MAX_ROWS * 4 + 16;
+    if (o->detect_smem > 150 * 1024 || P.h + 2 > lsd::MAX_ROWS || NPs > (1u << 20)) { delete o; set_error("planar_lsd_create: image too large for the LDS-resident used map"); return PLANAR_EINVAL; }
+    int rc = o->d_plan.alloc(sizeof(lsd::Plan));
+    if (!rc) rc = o->d_cx.alloc(cx.size() * sizeof(lsd::Coef));
+    if (!rc) rc = o->d_cy.alloc(cy.size() * sizeof(lsd::Coef));
+    if (!rc) rc = o->d_taps.alloc(16 * 4);
+    if (!rc) rc = o->d_ws.alloc(P.frame_bytes * (size_t)max_batch);
+    if (!rc) rc = o->d_misc.alloc(sizeof(lsd::Misc) * (size_t)max_batch);
+    if (rc) { delete o; return rc; }
+    int taps[16] = {0};
+    for (int i = 0; i < 7; i++) taps[i] = P.taps7[i];
+    for (int i = 0; i < 5; i++) taps[8 + i] = P.taps5[i];
+    hipError_t e = hipMemcpy(o->d_plan.p, &P, sizeof(P), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(o->d_cx.p, cx.data(), cx.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(o->d_cy.p, cy.data(), cy.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(o->d_taps.p, taps, sizeof(taps), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_detect, hipFuncAttributeMaxDynamicSharedMemorySize, o->detect_smem);
+    if (e != hipSuccess) { delete o; set_error("planar_lsd_create: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
+    *out = o;
+    return PLANAR_OK;
+}
+
+void planar_lsd_destroy(planar_lsd* o) { delete o; }
+
+int planar_lsd_extract_dev(planar_lsd* o, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride, int max_lines, planar_keyline* d_keylines,
+                           uint8_t* d_ldesc, double* d_line_eq, int32_t* d_n_lines) {
+    PLANAR_REQUIRE(o && d_gray && d_keylines && d_ldesc && d_line_eq && d_n_lines, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && B <= o->max_batch, PLANAR_EINVAL, "B out of range");
+    PLANAR_REQUIRE(pitch >= o->W && max_lines >= 1 && max_lines <= lsd::MAX_SEGS, PLANAR_EINVAL, "bad pitch / max_lines");
+    hipStream_t st = o->ctx->stream;
+    const lsd::Plan& P = o->plan;
+    const lsd::Plan* dP = o->d_plan.as<lsd::Plan>();
+    uint8_t* ws = o->d_ws.as<uint8_t>();
+    lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
+    PLANAR_HIP_CHECK(hipMemsetAsync(dm, 0, sizeof(lsd::Misc) * (size_t)B, st));
+    const dim3 gfull((P.W + 63) / 64, (P.H + 15) / 16, B);
+    hipLaunchKernelGGL(lsd::lsd_gauss<7>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>(), ws, P.frame_bytes, P.off_blur7);
+    hipLaunchKernelGGL(lsd::lsd_gauss<5>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>() + 8, ws, P.frame_bytes, P.off_blur5);
+    hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
+    hipLaunchKernelGGL(lsd::lbd_sobel, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, dP, ws);
+    hipLaunchKernelGGL(lsd::lsd_sort, dim3(B), dim3(256), 0, st, dP, ws, dm);
+    hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, st, dP, ws, dm);
+    hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines);
+    hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_lsd_extract(planar_lsd* o, const uint8_t* gray, int B, int pitch, int64_t frame_stride, int max_lines, planar_keyline* keylines,
+                       uint8_t* ldesc, double* line_eq, int32_t* n_lines) {
+    PLANAR_REQUIRE(o && gray && keylines && ldesc && line_eq && n_lines, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && B <= o->max_batch, PLANAR_EINVAL, "B out of range");
+    PLANAR_REQUIRE(pitch >= o->W && frame_stride >= (int64_t)pitch * o->H, PLANAR_EINVAL, "bad pitch / frame stride");
+    PLANAR_REQUIRE(max_lines >= 1 && max_lines <= lsd::MAX_SEGS, PLANAR_EINVAL, "bad max_lines");
+    PLANAR_HIP_CHECK(hipSetDevice(o->ctx->device));
+    hipStream_t st = o->ctx->stream;
+    const size_t in_bytes = (size_t)frame_stride * B, nl = (size_t)o->max_batch * max_lines;
+    if (o->d_in.bytes < in_bytes) { int rc = o->d_in.alloc(in_bytes); if (rc) return rc; }
+    if (o->stage_lines < max_lines) {
+        int rc = o->d_kl.alloc(nl * sizeof(planar_keyline));
+        if (!rc) rc = o->d_desc.alloc(nl * 32);
+        if (!rc) rc = o->d_eq.alloc(nl * 24);
+        if (!rc) rc = o->d_n.alloc((size_t)o->max_batch * 4);
+        if (rc) return rc;
+        o->stage_lines = max_lines;
+    }
+    PLANAR_HIP_CHECK(hipMemcpyAsync(o->d_in.p, gray, in_bytes, hipMemcpyHostToDevice, st));
+    int rc = planar_lsd_extract_dev(o, o->d_in.as<uint8_t>(), B, pitch, frame_stride, max_lines, o->d_kl.as<planar_keyline>(), o->d_desc.as<uint8_t>(),
+                                    o->d_eq.as<double>(), o->d_n.as<int32_t>());
+    if (rc) return rc;
+    const size_t n = (size_t)B * max_lines;
+    PLANAR_HIP_CHECK(hipMemcpyAsync(keylines, o->d_kl.p, n * sizeof(planar_keyline), hipMemcpyDeviceToHost, st));
+    PLANAR_HIP_CHECK(hipMemcpyAsync(ldesc, o->d_desc.p, n * 32, hipMemcpyDeviceToHost, st));
+    PLANAR_HIP_CHECK(hipMemcpyAsync(line_eq, o->d_eq.p, n * 24, hipMemcpyDeviceToHost, st));
+    PLANAR_HIP_CHECK(hipMemcpyAsync(n_lines, o->d_n.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+    return PLANAR_OK;
+}
+
+/* diagnostics: stage 0 = level-line angle (float degrees, -1024 = undefined) [w*h]; 1 = squared gradient u32 [w*h];
+ * 2 = pixel visiting order int32 [n] (returns n); 3 = raw segments, 40 bytes each {x1,y1,x2,y2 float; width,p,nfa double}
+ * (returns the count; at most planar_lsd_max_segments() are stored); 4 = {n_regions} int32[1] */
+int planar_lsd_read_stage(planar_lsd* o, int frame, int stage, void* out, int64_t out_bytes) {
+    PLANAR_REQUIRE(o && out, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(frame >= 0 && frame < o->max_batch, PLANAR_EINVAL, "frame out of range");
+    PLANAR_HIP_CHECK(hipSetDevice(o->ctx->device));
+    PLANAR_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
+    const lsd::Plan& P = o->plan;
+    const uint8_t* F = o->d_ws.as<uint8_t>() + (size_t)frame * P.frame_bytes;
+    lsd::Misc m;
+    PLANAR_HIP_CHECK(hipMemcpy(&m, o->d_misc.as<lsd::Misc>() + frame, sizeof(m), hipMemcpyDeviceToHost));
+    const size_t NPs = (size_t)P.w * P.h;
+    size_t bytes = 0, off = 0;
+    int ret = 0;
+    switch (stage) {
+        case 0: bytes = NPs * 4; off = P.off_ang; break;
+        case 1: bytes = NPs * 4; off = P.off_g2; break;
+        case 2: bytes = (size_t)m.n_ord * 4; off = P.off_ord; ret = m.n_ord; break;
+        case 3: bytes = (size_t)std::min(m.n_seg, lsd::MAX_SEGS) * sizeof(lsd::Seg); off = P.off_segs; ret = m.n_seg; break;
+        case 4: { PLANAR_REQUIRE(out_bytes >= 4, PLANAR_EINVAL, "buffer too small"); *(int32_t*)out = m.n_regions; return PLANAR_OK; }
+        default: set_error("planar_lsd_read_stage: unknown stage"); return PLANAR_EINVAL;
+    }
+    PLANAR_REQUIRE((int64_t)bytes <= out_bytes, PLANAR_EINVAL, "buffer too small");
+    if (bytes) PLANAR_HIP_CHECK(hipMemcpy(out, F + off, bytes, hipMemcpyDeviceToHost));
+    return ret;
+}
+
+int planar_lsd_scaled_size(planar_lsd* o, int* w, int* h) {
+    PLANAR_REQUIRE(o && w && h, PLANAR_EINVAL, "null argument");
+    *w = o->plan.w; *h = o->plan.h;
+    return PLANAR_OK;
+}
+
+/* test hook: the device emulation of libstdc++ std::sort(first, last, greater-by-key) used for sort_lines_by_response;
+ * keys [n] float (in/out), perm [n] int32 (out: original index of each sorted element) */
+int planar_debug_std_sort_desc(planar_ctx* ctx, float* keys, int32_t* perm, int n) {
+    PLANAR_REQUIRE(ctx && keys && perm && n >= 0 && n <= (1 << 20), PLANAR_EINVAL, "bad argument");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<int32_t> idx(n);
+    for (int i = 0; i < n; i++) idx[i] = i;
+    DevBuf dk, di;
+    int rc = dk.alloc((size_t)n * 4);
+    if (!rc) rc = di.alloc((size_t)n * 4);
+    if (rc) return rc;
+    PLANAR_HIP_CHECK(hipMemcpyAsync(dk.p, keys, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PLANAR_HIP_CHECK(hipMemcpyAsync(di.p, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(lsd::debug_sort_kernel, dim3(1), dim3(64), 0, ctx->stream, dk.as<float>(), di.as<int>(), n);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    PLANAR_HIP_CHECK(hipMemcpyAsync(keys, dk.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PLANAR_HIP_CHECK(hipMemcpyAsync(perm, di.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PLANAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PLANAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""Host-side mirror of the reference line extractor over the C ABI.
+
+    LineSegment.ExtractLineSegment   reference src/LSDextractor.cpp:12-39 (include/LSDextractor.h:344-352)
+Batched: a [B, H, W] uint8 array stands for B calls.  No CPU fallback: everything runs in libplanar_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import KEYLINE_DTYPE, Context, check, lib
+
+SEG_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("width", "<f8"), ("p", "<f8"), ("nfa", "<f8")])
+
+
+class LineSegment:
+    def __init__(self, width: int = 640, height: int = 480, max_batch: int = 1, ctx: Context | None = None):
+        self.ctx = ctx or Context(0)
+        self.W, self.H, self.max_batch = width, height, max_batch
+        h = C.c_void_p()
+        check(lib().planar_lsd_create(self.ctx.h, width, height, max_batch, C.byref(h)))
+        self.h = h
+        w_, h_ = C.c_int(), C.c_int()
+        check(lib().planar_lsd_scaled_size(self.h, C.byref(w_), C.byref(h_)))
+        self.scaled = (w_.value, h_.value)
+
+    def ExtractLineSegment(self, img, lsdNFeatures: int = 40):
+        """img [B,H,W] or [H,W] uint8.  Returns (keylines [B,40] KEYLINE_DTYPE, ldesc [B,40,32] uint8,
+        keylineFunctions [B,40,3] float64, n [B]); rows >= n[b] are unspecified."""
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.ndim == 2:
+            img = img[None]
+        B, H, W = img.shape
+        assert (H, W) == (self.H, self.W) and B <= self.max_batch
+        kl = np.zeros((B, lsdNFeatures), KEYLINE_DTYPE)
+        desc = np.zeros((B, lsdNFeatures, 32), np.uint8)
+        eq = np.zeros((B, lsdNFeatures, 3), np.float64)
+        n = np.zeros(B, np.int32)
+        check(lib().planar_lsd_extract(self.h, img.ctypes.data, B, W, W * H, lsdNFeatures, kl.ctypes.data, desc.ctypes.data, eq.ctypes.data,
+                                       n.ctypes.data))
+        return kl, desc, eq, n
+
+    def read_stage(self, frame: int, stage: int):
+        """Diagnostics of the last call (see planar_lsd_read_stage)."""
+        w, h = self.scaled
+        if stage in (0, 1):
+            out = np.zeros((h, w), np.float32 if stage == 0 else np.uint32)
+        elif stage == 2:
+            out = np.zeros(w * h, np.int32)
+        elif stage == 3:
+            out = np.zeros(lib().planar_lsd_max_segments(), SEG_DTYPE)
+        else:
+            out = np.zeros(1, np.int32)
+        r = check(lib().planar_lsd_read_stage(self.h, frame, stage, out.ctypes.data, out.nbytes))
+        return out[:min(r, len(out))] if stage in (2, 3) else out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().planar_lsd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

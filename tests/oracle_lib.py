@@ -337,3 +337,44 @@ def plane_search_by_coefficients(frame, mapplanes, th=(0.1, 0.86, 0.08716, 0.996
     L.orc_plane_search_by_coefficients(B, p(n), S, p(coef), p(T), int(bool(mapplanes.get("shared"))), p(mn), M, p(mv), p(mc), p(mnp), P, p(mp), p(tha),
                                        p(out[0]), p(out[1]), p(out[2]), p(nm))
     return out[0], out[1], out[2], nm
+
+
+# ---- line extraction (oracle/lsd_oracle.cpp) ----
+def lsd_detect(img, tie_order=1, want_stages=False):
+    """Raw LSD segments of cv::LineSegmentDetector(LSD_REFINE_ADV).  Returns dict(xy [n,4] f32, wpn [n,3] f64, + stages)."""
+    L = lib()
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    w, h = int(np.rint(W * 0.8)), int(np.rint(H * 0.8))
+    cap = 8192
+    xy = np.zeros((cap, 4), np.float32); wpn = np.zeros((cap, 3), np.float64)
+    scaled = np.zeros((h, w), np.uint8); ang = np.zeros((h, w), np.float64); order = np.full(w * h, -1, np.int32)
+    L.orc_lsd_detect.restype = C.c_int
+    n = L.orc_lsd_detect(C.c_void_p(img.ctypes.data), W, H, W, int(tie_order), C.c_void_p(xy.ctypes.data), C.c_void_p(wpn.ctypes.data), cap,
+                         C.c_void_p(scaled.ctypes.data) if want_stages else None, C.c_void_p(ang.ctypes.data) if want_stages else None,
+                         C.c_void_p(order.ctypes.data) if want_stages else None)
+    out = dict(xy=xy[:n].copy(), wpn=wpn[:n].copy())
+    if want_stages:
+        out.update(scaled=scaled, angles=ang, order=order)
+    return out
+
+
+def extract_line_segment(img, tie_order=1, max_lines=40):
+    """LineSegment::ExtractLineSegment.  Returns (keylines [n], desc [n,32], eq [n,3], desc_float [n,72], n_detected)."""
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    L = lib()
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    kl = np.zeros(max_lines, KEYLINE_DTYPE); desc = np.zeros((max_lines, 32), np.uint8); eq = np.zeros((max_lines, 3)); df = np.zeros((max_lines, 72), np.float32)
+    nd = C.c_int()
+    L.orc_extract_line_segment.restype = C.c_int
+    n = L.orc_extract_line_segment(C.c_void_p(img.ctypes.data), W, H, W, int(tie_order), max_lines, C.c_void_p(kl.ctypes.data), C.c_void_p(desc.ctypes.data),
+                                   C.c_void_p(eq.ctypes.data), C.c_void_p(df.ctypes.data), C.byref(nd))
+    return kl[:n].copy(), desc[:n].copy(), eq[:n].copy(), df[:n].copy(), nd.value
+
+
+def std_sort_desc(keys):
+    L = lib()
+    k = np.ascontiguousarray(keys, np.float32).copy(); perm = np.zeros(len(k), np.int32)
+    L.orc_std_sort_desc(C.c_void_p(k.ctypes.data), C.c_void_p(perm.ctypes.data), len(k))
+    return k, perm

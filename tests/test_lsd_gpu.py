@@ -1,0 +1,86 @@
+"""GPU parity: the HIP line extractor through the C ABI against oracle/lsd_oracle.cpp (tie_order = 1).
+Rows a10, a11, a12 of SURVEY.md §8.  Integer stages, the visiting order, keyline fields and LBD bytes must be
+identical; segment endpoints are float32 roundings of FP64 results whose only cross-platform difference is the
+last-bit behaviour of libm (cos/sin/log/exp/pow), so they are compared exactly as well and any mismatch is reported."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from planarslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEG = np.pi / 180
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from planarslam_amd._lib import Context
+    return Context(0)
+
+
+def test_device_std_sort_matches_libstdcxx(ctx):
+    import ctypes as C
+    from planarslam_amd._lib import check, lib
+    rng = np.random.default_rng(5)
+    cases = [rng.random(n).astype(np.float32) for n in (0, 1, 2, 16, 17, 41, 172, 600, 2048)]
+    cases += [rng.integers(0, 4, 500).astype(np.float32), rng.integers(0, 30, 2048).astype(np.float32), np.zeros(300, np.float32),
+              np.arange(700, dtype=np.float32), np.arange(700, dtype=np.float32)[::-1].copy(),
+              np.concatenate([np.arange(350), np.arange(350)[::-1]]).astype(np.float32)]
+    for keys in cases:
+        rk, rp = O.std_sort_desc(keys)
+        k = keys.copy(); perm = np.zeros(len(k), np.int32)
+        check(lib().planar_debug_std_sort_desc(ctx.h, k.ctypes.data, perm.ctypes.data, len(k)))
+        np.testing.assert_array_equal(k, rk)
+        np.testing.assert_array_equal(perm, rp)
+
+
+@pytest.mark.parametrize("seed", [1234, 77])
+def test_lsd_stages_and_segments(ctx, seed):
+    from planarslam_amd.lines import LineSegment
+    img = synth.gray_image(seed)
+    ref = O.lsd_detect(img, tie_order=1, want_stages=True)
+    ls = LineSegment(640, 480, 1, ctx)
+    ls.ExtractLineSegment(img)
+    ang = ls.read_stage(0, 0)
+    ref_deg_defined = ref["angles"] != -1024.0
+    np.testing.assert_array_equal(ang != -1024.0, ref_deg_defined)
+    np.testing.assert_array_equal((ang.astype(np.float64) * DEG)[ref_deg_defined], ref["angles"][ref_deg_defined])
+    order = ls.read_stage(0, 2)
+    ref_order = ref["order"][ref["order"] >= 0]
+    ref_order = ref_order[ref_deg_defined.ravel()[ref_order]]          # the device list drops undefined pixels up front
+    np.testing.assert_array_equal(order, ref_order)
+    segs = ls.read_stage(0, 3)
+    assert len(segs) == len(ref["xy"]) > 100
+    got = np.stack([segs["x1"], segs["y1"], segs["x2"], segs["y2"]], 1)
+    np.testing.assert_array_equal(got, ref["xy"])
+    np.testing.assert_allclose(segs["nfa"], ref["wpn"][:, 2], rtol=1e-9)
+    np.testing.assert_array_equal(segs["p"], ref["wpn"][:, 1])
+    np.testing.assert_allclose(segs["width"], ref["wpn"][:, 0], rtol=1e-12)
+
+
+def test_extract_line_segment_batch(ctx):
+    from planarslam_amd.lines import LineSegment
+    imgs = np.stack([synth.gray_image(1234), synth.gray_image(5), np.full((480, 640), 90, np.uint8), synth.gray_image(9)])
+    imgs[1, 100:300, 150:450] = 220
+    ls = LineSegment(640, 480, 4, ctx)
+    kl, desc, eq, n = ls.ExtractLineSegment(imgs)
+    for b in range(4):
+        rk, rd, re, _, nd = O.extract_line_segment(imgs[b], tie_order=1)
+        assert n[b] == len(rk)
+        for f in rk.dtype.names:
+            np.testing.assert_array_equal(kl[b, :n[b]][f], rk[f], err_msg=f"frame {b} field {f}")
+        np.testing.assert_array_equal(desc[b, :n[b]], rd)
+        np.testing.assert_array_equal(eq[b, :n[b]], re)
+    assert n[2] == 0 and n[0] == 40
+
+
+def test_few_lines_keep_detection_order(ctx):
+    from planarslam_amd.lines import LineSegment
+    img = np.full((480, 640), 40, np.uint8)
+    img[100:300, 150:450] = 200
+    ls = LineSegment(640, 480, 1, ctx)
+    kl, desc, eq, n = ls.ExtractLineSegment(img)
+    rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=1)
+    assert n[0] == len(rk) == nd and 1 <= nd <= 40
+    np.testing.assert_array_equal(kl[0, :nd]["class_id"], np.arange(nd))
+    np.testing.assert_array_equal(desc[0, :nd], rd)
