@@ -4,8 +4,10 @@
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
 A "step" = one pass of the hot path over one batch of `--batch` synthetic 640x480 RGB-D frames that are already
-resident in HBM: ORB extraction + PEAC plane segmentation (extract), MatchORBPoints against the previous batch's
-descriptors (match) and the 4x10 PoseOptimization protocol on a config-4-shaped problem per frame (pose-opt).
+resident in HBM: ORB extraction, LSD+LBD line extraction and PEAC plane segmentation (extract; three HIP streams,
+mirroring the reference's three extraction threads, src/Frame.cc:90-95), SearchByProjection(Cur, Last) and
+MatchORBPoints against the previous batch (match) and the 4x10 PoseOptimization protocol on a config-4-shaped
+problem per frame (pose-opt), which waits for all three extractors.
 Frames are independent, so ranks shard them with no data-path collective ("scaling": "weak": every rank processes
 its own `--batch` frames per step).  Rank 0 prints ONE JSON line: whole-job frames/s, per-stage times, the roofline
 of the dominant kernel (HIP events on the stream the kernels run on, inside the timed region) and a CPU baseline
@@ -74,6 +76,9 @@ def main():
     full = args.workload == "full"
     stream = torch.cuda.Stream(device=local_rank)
     ctx = Context(local_rank, stream=stream.cuda_stream)
+    # the reference extracts ORB / lines / planes on three threads (src/Frame.cc:90-95): three HIP streams here
+    s_peac, s_lsd = torch.cuda.Stream(device=local_rank), torch.cuda.Stream(device=local_rank)
+    ctx_peac, ctx_lsd = Context(local_rank, stream=s_peac.cuda_stream), Context(local_rank, stream=s_lsd.cuda_stream)
     L = lib()
 
     # ---- inputs resident in HBM (synthetic; distinct per rank, 16 distinct frames tiled over the batch) ----
@@ -88,7 +93,7 @@ def main():
     if full:
         depth_src = np.stack([depth_image(4321 + 16 * rank + i) for i in range(nsrc)])
         depth = torch.from_numpy(rep(depth_src).view(np.int16)).to(dev)
-        pd = PlaneDetection(W, H, max_batch=B, ctx=ctx)
+        pd = PlaneDetection(W, H, max_batch=B, ctx=ctx_peac)
         d_lab = torch.zeros((B, H * W), dtype=torch.int32, device=dev)
         d_pl = torch.zeros((B, pd.max_planes, 8), dtype=torch.float64, device=dev)
         d_npl = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -114,24 +119,80 @@ def main():
         for k, v in outs.items():
             setattr(pb, k, v.data_ptr())
         opt = Optimizer(TUM3, ctx=ctx)
+        # line extractor (LSD + LBD), lsdNFeatures = 40
+        from planarslam_amd._lib import KEYLINE_DTYPE, FrameView, LastFrameView
+        from planarslam_amd.lines import LineSegment
+        from planarslam_amd.synth import scale_factors
+        ls = LineSegment(W, H, B, ctx_lsd)
+        d_kl = torch.zeros(B * 40 * KEYLINE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        d_ldesc = torch.zeros((B, 40, 32), dtype=torch.uint8, device=dev)
+        d_leq = torch.zeros((B, 40, 3), dtype=torch.float64, device=dev)
+        d_nl = torch.zeros(B, dtype=torch.int32, device=dev)
+        # SearchByProjection(Cur, Last): the last frame's map points are the back-projections of the keypoints ORB finds on
+        # the same images (identity motion), so every probe has a realistic window of candidates and a true match.
+        with torch.cuda.stream(stream):
+            ex.extract_dev(frames.data_ptr(), d_kps.data_ptr(), d_desc[0].data_ptr(), d_n[0].data_ptr(), B)
+            ex.extract_dev(frames.data_ptr(), d_kps.data_ptr(), d_desc[1].data_ptr(), d_n[1].data_ptr(), B)
+        torch.cuda.synchronize()
+        h_kps = d_kps.cpu().numpy(); h_n = d_n[0].cpu().numpy()
+        rng = np.random.default_rng(11 + rank)
+        z = rng.uniform(0.8, 5.0, (B, ex.kp_cap)).astype(np.float32)
+        xw = np.stack([(h_kps[..., 0] - TUM3["cx"]) * z / TUM3["fx"], (h_kps[..., 1] - TUM3["cy"]) * z / TUM3["fy"], z], -1).astype(np.float32)
+        eye = np.tile(np.eye(4, dtype=np.float32).ravel(), (B, 1))
+        pj = dict(u_right=torch.from_numpy((h_kps[..., 0] - np.float32(TUM3["bf"]) / z).astype(np.float32)).to(dev),
+                  Tcw=torch.from_numpy(eye).to(dev), usable=torch.ones((B, ex.kp_cap), dtype=torch.uint8, device=dev),
+                  xw=torch.from_numpy(xw).to(dev), octave=torch.from_numpy(np.ascontiguousarray(h_kps[..., 5]).view(np.int32).copy()).to(dev),
+                  angle=torch.from_numpy(np.ascontiguousarray(h_kps[..., 3])).to(dev),
+                  observed=torch.ones((B, ex.kp_cap), dtype=torch.uint8, device=dev),
+                  match=torch.full((B, ex.kp_cap), -1, dtype=torch.int32, device=dev), nm=torch.zeros(B, dtype=torch.int32, device=dev))
+        fv = FrameView()
+        fv.B, fv.stride = B, ex.kp_cap
+        fv.keys_un, fv.u_right, fv.Tcw = d_kps.data_ptr(), pj["u_right"].data_ptr(), pj["Tcw"].data_ptr()
+        fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(W), 0.0, float(H)
+        fv.grid_w_inv, fv.grid_h_inv = 64.0 / W, 48.0 / H
+        fv.fx, fv.fy, fv.cx, fv.cy, fv.bf, fv.b = TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"], TUM3["bf"], TUM3["bf"] / TUM3["fx"]
+        for li, sfv in enumerate(scale_factors()):
+            fv.scale_factors[li] = float(sfv)
+        lv = LastFrameView()
+        lv.stride = ex.kp_cap
+        lv.Tcw, lv.usable, lv.xw, lv.octave, lv.angle, lv.mp_observed = (pj["Tcw"].data_ptr(), pj["usable"].data_ptr(), pj["xw"].data_ptr(),
+                                                                        pj["octave"].data_ptr(), pj["angle"].data_ptr(), pj["observed"].data_ptr())
 
-    stage_names = ["orb_extract"] + (["peac_extract", "match_orb_points", "pose_opt_4x10"] if full else [])
+    stage_names = ["orb_extract"] + (["search_by_projection", "match_orb_points", "wait_lines_planes", "pose_opt_4x10"] if full else [])
     nst = len(stage_names)
+    fork, fork2, join_p, join_l = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 
-    def step(i, evs=None):
+    def step(i, evs=None, side=None):
+        # ORB and the point matchers first (they need most of a CU's LDS and would otherwise queue behind the plane kernel),
+        # then the two sequential extractors side by side: one PEAC workgroup (150 KB LDS) and one LSD wavefront (8 KB) share a CU.
         cur, prev = i & 1, (i & 1) ^ 1
         if evs: evs[0].record(stream)
         ex.extract_dev(frames.data_ptr(), d_kps.data_ptr(), d_desc[cur].data_ptr(), d_n[cur].data_ptr(), B)
         if evs: evs[1].record(stream)
         if full:
-            pd.segment_dev(depth.data_ptr(), d_lab.data_ptr(), d_pl.data_ptr(), d_npl.data_ptr(), B)
+            fv.n, fv.desc = d_n[cur].data_ptr(), d_desc[cur].data_ptr()
+            lv.n, lv.mp_desc = d_n[prev].data_ptr(), d_desc[prev].data_ptr()
+            check(L.planar_search_by_projection_frame_dev(ctx.h, C.byref(fv), C.byref(lv), 15.0, 0, 1, pj["match"].data_ptr(), pj["nm"].data_ptr()))
             if evs: evs[2].record(stream)
             check(L.planar_match_orb_points_dev(ctx.h, d_desc[cur].data_ptr(), d_n[cur].data_ptr(), ex.kp_cap, d_desc[prev].data_ptr(),
                                                 d_n[prev].data_ptr(), ex.kp_cap, has_mp.data_ptr(), outl.data_ptr(), B, cur_match.data_ptr(),
                                                 npair.data_ptr()))
             if evs: evs[3].record(stream)
-            opt.enqueue_dev(pb, 0, 4, 10)
+            fork.record(stream)
+            s_lsd.wait_event(fork)
+            if side: side[2].record(s_lsd)
+            check(L.planar_lsd_preprocess_dev(ls.h, frames.data_ptr(), B, W, W * H))                                     # stream s_lsd (throughput kernels)
+            fork2.record(s_lsd)
+            s_peac.wait_event(fork2)
+            if side: side[0].record(s_peac)
+            pd.segment_dev(depth.data_ptr(), d_lab.data_ptr(), d_pl.data_ptr(), d_npl.data_ptr(), B)                       # stream s_peac
+            check(L.planar_lsd_detect_dev(ls.h, B, 40, d_kl.data_ptr(), d_ldesc.data_ptr(), d_leq.data_ptr(), d_nl.data_ptr()))  # stream s_lsd
+            if side: side[1].record(s_peac); side[3].record(s_lsd)
+            join_p.record(s_peac); join_l.record(s_lsd)
+            stream.wait_event(join_p); stream.wait_event(join_l)      # PoseOptimization consumes points, lines and planes
             if evs: evs[4].record(stream)
+            opt.enqueue_dev(pb, 0, 4, 10)
+            if evs: evs[5].record(stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -143,10 +204,11 @@ def main():
             step(i)
         ex.set_profiling(True)
         evsets = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(args.steps)]
+        sides = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(args.warmup + i, evsets[i])
+            step(args.warmup + i, evsets[i], sides[i])
         barrier()
         elapsed = time.perf_counter() - t0
         prof, calls = ex.get_profile()
@@ -155,6 +217,9 @@ def main():
         pd.L.planar_peac_check(pd.h, B)
 
     stage_ms = {n: sum(e[k].elapsed_time(e[k + 1]) for e in evsets) / args.steps for k, n in enumerate(stage_names)}
+    if full:   # the two side streams run concurrently with the ORB stream
+        stage_ms["peac_extract(stream 2)"] = sum(e[0].elapsed_time(e[1]) for e in sides) / args.steps
+        stage_ms["lsd_lbd_extract(stream 3)"] = sum(e[2].elapsed_time(e[3]) for e in sides) / args.steps
     elapsed = ranks.max_over_ranks(elapsed)
     n_kp = int(d_n[(args.warmup + args.steps - 1) & 1].sum().item())
     if rank != 0:
@@ -170,8 +235,15 @@ def main():
     if full:
         avg_planes = float(d_npl.float().mean().item())
         # PEAC: read u16 depth + write int32 labels (1 843 200 B/frame); peac_blocks + peac_segment timed together
-        cand["peac_blocks+peac_segment"] = (stage_ms["peac_extract"], 1843200 * B)
-        kernels["peac_blocks+peac_segment"] = {"ms_per_step": round(stage_ms["peac_extract"], 4), "launches_per_step": 2}
+        cand["peac_blocks+peac_segment"] = (stage_ms["peac_extract(stream 2)"], 1843200 * B)
+        kernels["peac_blocks+peac_segment"] = {"ms_per_step": round(stage_ms["peac_extract(stream 2)"], 4), "launches_per_step": 2,
+                                               "note": "concurrent with the LSD stream"}
+        # LSD+LBD: read gray + 40 x (32 B descriptor + 68 B KeyLine + 24 B equation) (~311 680 B/frame)
+        cand["lsd_detect(+7 small kernels)"] = (stage_ms["lsd_lbd_extract(stream 3)"], (307200 + 40 * 124) * B)
+        kernels["lsd_detect(+7 small kernels)"] = {"ms_per_step": round(stage_ms["lsd_lbd_extract(stream 3)"], 4), "launches_per_step": 8,
+                                                   "note": "concurrent with the PEAC stream"}
+        cand["projection_kernel"] = (stage_ms["search_by_projection"], (1000 * (28 + 4 + 32) + 1000 * (12 + 4 + 4 + 32 + 2)) * B)
+        kernels["projection_kernel"] = {"ms_per_step": round(stage_ms["search_by_projection"], 4), "launches_per_step": 1}
         cand["hamming_knn+match_orb_points"] = (stage_ms["match_orb_points"], (64000 + 8000) * B)
         kernels["hamming_knn+match_orb_points"] = {"ms_per_step": round(stage_ms["match_orb_points"], 4), "launches_per_step": 2}
         # pose LM: 65 130 B per frame per LM evaluation; evaluations = LM iterations + trial steps (>= 2 per iteration)
@@ -181,11 +253,11 @@ def main():
     dom = max(cand, key=lambda k: cand[k][0] * (kernels[k]["launches_per_step"] if k in prof else 1))
     dom_ms, dom_bytes = cand[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    per_frame = 1961064 + (1843200 if full else 0) + (72000 + 65130 * 2 * 20 if full else 0)
+    per_frame = 1961064 + (1843200 + 312160 if full else 0) + (72000 + 118000 + 65130 * 2 * 20 if full else 0)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(dom_ms, 4),
                 "algorithmic_bytes_per_launch": int(dom_bytes), "pipeline_algorithmic_GBps": round(per_frame * fps / 1e9, 2),
-                "note": "latency/occupancy-bound sequential stage (one workgroup per frame); see DESIGN.md" if dom.startswith("peac") else None,
+                "note": "latency/occupancy-bound sequential stage (one workgroup per frame); see DESIGN.md" if dom.startswith(("peac", "lsd")) else None,
                 "kernels": kernels}
 
     # ---- CPU baseline: the oracle restatement of the same stages on this box's host cores (1 thread) ----
@@ -196,12 +268,13 @@ def main():
         o = ol.OrbOracle()
         o.extract(gray_src[0])
         n, t0 = 0, time.perf_counter()
-        per = {"orb": 0.0, "peac": 0.0, "match": 0.0, "pose": 0.0}
+        per = {"orb": 0.0, "lsd": 0.0, "peac": 0.0, "match": 0.0, "pose": 0.0}
         prev_desc = o.extract(gray_src[-1])[1]
         while time.perf_counter() - t0 < args.cpu_seconds:
             i = n % nsrc
             t1 = time.perf_counter(); kp, de = o.extract(gray_src[i]); per["orb"] += time.perf_counter() - t1
             if full:
+                t1 = time.perf_counter(); ol.extract_line_segment(gray_src[i], tie_order=1); per["lsd"] += time.perf_counter() - t1
                 t1 = time.perf_counter(); ol.peac_run(depth_src[i]); per["peac"] += time.perf_counter() - t1
                 t1 = time.perf_counter()
                 ol.match_orb_points(de, prev_desc, np.ones(len(prev_desc), np.uint8), np.zeros(len(prev_desc), np.uint8), np.full(len(de), -1, np.int32))
@@ -212,10 +285,11 @@ def main():
             n += 1
         dt = time.perf_counter() - t0
         cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{n} frames of the same synthetic set through the oracle/ restatements of the same stages (1 thread, {dt:.1f} s)",
+               "sample": f"{n} frames of the same synthetic set through the oracle/ restatements of the same stages except SearchByProjection (1 thread, {dt:.1f} s)",
                "ms_per_frame": {k: round(v / n * 1e3, 2) for k, v in per.items() if v > 0}, "host_cores": os.cpu_count()}
 
-    workload = ("ORB (BASELINE config[1]) + PEAC planes + MatchORBPoints + PoseOptimization 4x10 (config[3] shape: 1000 pt + 150 line-endpoint + 12 plane edges)"
+    workload = ("configs[2]+[3]: full extract (ORB + LSD/LBD lines + PEAC planes, 3 streams) + SearchByProjection + MatchORBPoints + PoseOptimization 4x10 "
+                "(1000 pt + 150 line-endpoint + 12 plane edges)"
                 if full else "configs[1]: ORB only, 640x480 gray, 8-level pyramid, 1000 keypoints + 256-bit rBRIEF")
     out = {
         "metric": "RGB-D frames/sec (extract+match+pose-opt) @640x480; 1->8-GPU batch scaling",
@@ -224,13 +298,15 @@ def main():
         "vs_baseline": None, "dtype": "u8/f64" if full else "u8", "data": "synthetic",
         "config": {"workload": workload, "frames_per_gpu_per_step": B, "avg_keypoints_per_frame": round(avg_kp, 1),
                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-                   "not_yet_in_workload": (["LSD/LBD line extraction", "SearchByProjection matchers"] if full else
+                   "not_yet_in_workload": ([] if full else
                                            ["LSD/LBD lines", "PEAC planes", "matching", "pose optimisation"]),
                    "parallelism": f"frame-sharded x{world}, no collective"},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     if full:
         out["config"]["avg_planes_per_frame"] = round(avg_planes, 2)
+        out["config"]["avg_lines_per_frame"] = round(float(d_nl.float().mean().item()), 2)
+        out["config"]["avg_projection_matches_per_frame"] = round(float(pj["nm"].float().mean().item()), 1)
     print(json.dumps(out))
     ranks.close()
 

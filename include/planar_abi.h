@@ -341,7 +341,12 @@ int planar_lsd_extract(planar_lsd* lsd, const uint8_t* gray, int B, int pitch, i
                        uint8_t* ldesc, double* line_eq, int32_t* n_lines);
 int planar_lsd_extract_dev(planar_lsd* lsd, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride, int max_lines,
                            planar_keyline* d_keylines, uint8_t* d_ldesc, double* d_line_eq, int32_t* d_n_lines);
-/* diagnostics (tests / profiling): stage 0 level-line angle float deg [w*h] (-1024 undefined), 1 squared gradient u32 [w*h],
+/* The same work as planar_lsd_extract_dev in two enqueues on the context's stream, for callers that overlap the sequential
+ * detector with other stages: preprocess = Gaussians, 0.8x resample + gradients, Sobel, pixel ordering (throughput kernels);
+ * detect = region growing / NFA, KeyLines, LBD.  planar_lsd_detect_dev returns PLANAR_ESTATE without a matching preprocess. */
+int planar_lsd_preprocess_dev(planar_lsd* lsd, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride);
+int planar_lsd_detect_dev(planar_lsd* lsd, int B, int max_lines, planar_keyline* d_keylines, uint8_t* d_ldesc, double* d_line_eq, int32_t* d_n_lines);
+/* diagnostics (tests / profiling; stage 5 = cycle counters, see lsd.hip): stage 0 level-line angle float deg [w*h] (-1024 undefined), 1 squared gradient u32 [w*h],
  * 2 visiting order int32 (returns n), 3 raw segments 40 B each {x1,y1,x2,y2 float; width,p,nfa double} (returns count),
  * 4 number of grown regions int32[1] */
 int planar_lsd_read_stage(planar_lsd* lsd, int frame, int stage, void* out, int64_t out_bytes);

@@ -33,7 +33,8 @@ constexpr double DEG_TO_RADS = LSD_PI / 180;
 constexpr double RELATIVE_ERROR_FACTOR = 100.0;
 constexpr int N_BINS = 1024;
 constexpr int MAX_SEGS = 2048;     // raw LSD segments kept per frame
-constexpr int RING = 4096;         // recent region points kept in LDS
+constexpr int RING = 512;          // recent region points kept in LDS
+constexpr int USED_LDS_BITS = 32768;   // `used` flags of the first 32768 defined pixels live in LDS, the rest in global memory
 constexpr int MAX_ROWS = 1024;     // scaled image height limit (rect_nfa row table)
 
 struct Plan {
@@ -42,11 +43,14 @@ struct Plan {
     double rho, prec, p, log_nt, density_th, log_eps;
     int min_reg_size;
     // per-frame workspace offsets (bytes)
-    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_ord, off_tmp, off_reg, off_segs, off_kl, frame_bytes;
+    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_pix, off_seed, off_ord, off_ordr, off_gused, off_tmp, off_reg, off_segs, off_kl, frame_bytes;
+    // host-evaluated tables (glibc, as the reference library would): log_gamma(x) for integer x, and per halving j of p
+    const double* lgamma_tab;   // [w*h + 3]
+    double p_log[12], p1_log[12], p_log10[12];
     double gaussCoefL[21], gaussCoefG[63];
 };
 
-struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int pad[2]; };
+struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int pad; long long t[8]; };
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2: 7th-order odd polynomial, degrees; plain mul/add (no FMA), see oracle/cvprim.cpp
@@ -130,9 +134,11 @@ __global__ __launch_bounds__(256) void lsd_grad(const Plan* __restrict__ plan, c
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
     float* ang = (float*)(F + P.off_ang);
     uint32_t* g2a = (uint32_t*)(F + P.off_g2);
+    float4* pix4 = (float4*)(F + P.off_pix);      // {angle deg, cosf(angle), sinf(angle), compact index}: one 16-byte gather per neighbour
+    float2* seedcs = (float2*)(F + P.off_seed);   // (float)cos / sin of the FP64 angle, used when the pixel seeds a region
     Misc* misc = miscs + b;
     const size_t o = (size_t)y * P.w + x;
-    if (x >= P.w - 1 || y >= P.h - 1) { ang[o] = NOTDEF_F; g2a[o] = 0; return; }
+    if (x >= P.w - 1 || y >= P.h - 1) { ang[o] = NOTDEF_F; g2a[o] = 0; pix4[o] = make_float4(NOTDEF_F, 0.f, 0.f, 0.f); return; }
     const uint8_t* B7 = F + P.off_blur7;
     const Coef cx0 = cxs[x], cx1 = cxs[x + 1], cy0 = cys[y], cy1 = cys[y + 1];
     const int s00 = scaled_px(B7, P.W, cx0, cy0), s10 = scaled_px(B7, P.W, cx1, cy0);
@@ -142,9 +148,14 @@ __global__ __launch_bounds__(256) void lsd_grad(const Plan* __restrict__ plan, c
     const int g2 = gx * gx + gy * gy;
     const double norm = sqrt(g2 / 4.0);
     g2a[o] = (uint32_t)g2;
-    if (norm <= P.rho) ang[o] = NOTDEF_F;
+    if (norm <= P.rho) { ang[o] = NOTDEF_F; pix4[o] = make_float4(NOTDEF_F, 0.f, 0.f, 0.f); }
     else {
-        ang[o] = fast_atan2_deg((float)gx, (float)(-gy));
+        const float deg = fast_atan2_deg((float)gx, (float)(-gy));
+        ang[o] = deg;
+        const double a = (double)deg * DEG_TO_RADS;
+        const float af = (float)a;
+        pix4[o] = make_float4(deg, (float)cos((double)af), (float)sin((double)af), 0.f);   // .w: compact index, filled by lsd_sort
+        seedcs[o] = make_float2((float)cos(a), (float)sin(a));
         atomicMax(&misc->g2max, (uint32_t)g2);
     }
 }
@@ -194,7 +205,10 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
     for (int i = a0; i < a1; i++)
         if (ang[i] != NOTDEF_F) {
             const int key = (N_BINS - 1) - int(sqrt(g2a[i] / 4.0) * bin_coef);
-            tmp[cnt[(key & 31) * 256 + tid]++] = ((uint32_t)key << 20) | (uint32_t)i;
+            // the slot in tmp doubles as the pixel's compact index among the defined pixels (its `used` flag lives there)
+            const int slot = cnt[(key & 31) * 256 + tid]++;
+            tmp[slot] = ((uint32_t)key << 20) | (uint32_t)i;
+            ((float*)(F + P.off_pix))[(size_t)i * 4 + 3] = __uint_as_float((uint32_t)slot);
         }
     const int N = total;
     __threadfence_block();
@@ -212,29 +226,52 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
         for (int k = 0; k < 32; k++) { const int c = cnt[tid * 32 + k]; cnt[tid * 32 + k] = run; run += c; }
     }
     __syncthreads();
-    for (int i = b0; i < b1; i++) { const uint32_t e = tmp[i]; ord[cnt[((e >> 25) & 31) * 256 + tid]++] = e & 0xfffffu; }
+    uint32_t* ordr = (uint32_t*)(F + P.off_ordr);
+    for (int i = b0; i < b1; i++) {
+        const uint32_t e = tmp[i];
+        const int pos = cnt[((e >> 25) & 31) * 256 + tid]++;
+        ord[pos] = e & 0xfffffu;
+        ordr[pos] = (uint32_t)i;
+    }
     if (tid == 0) misc->n_ord = N;
 }
 
 // ---- K4: the sequential detector, one wavefront per frame -----------------------------------------------------------
-struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; int pj; };   // pj: p == P.p / 2^pj
 
 struct Det {
     const float* ang;
     const uint32_t* g2;
+    const float4* pix4;
+    const float2* seedcs;
+    const Plan* plan;
     uint32_t* reg;      // region points, x | y << 16, in growth order
     uint32_t* tmp;      // scratch (reduce_region_radius)
     int w, h;
     double log_nt;
     // LDS
-    uint32_t* used;     // bitmap
+    uint32_t* used;     // bitmap over compact indices < USED_LDS_BITS (LDS)
+    uint32_t* gused;    // bitmap over all compact indices (global; only indices >= USED_LDS_BITS are kept here)
     uint32_t* ring;
     double* stage;      // [64][3]
-    int* rowL; int* rowR; int* pre;
     int lane;
 };
 
-__device__ __forceinline__ bool used_get(const Det& D, int pix) { return (((volatile uint32_t*)D.used)[pix >> 5] >> (pix & 31)) & 1u; }
+// `used` flags, addressed by the compact index r of a defined pixel.  The global tail is only touched by images with more than
+// USED_LDS_BITS defined pixels; there every update is followed by an agent-scope fence and reads are agent-scope atomic loads.
+__device__ __forceinline__ bool used_get(const Det& D, uint32_t r) {
+    if (r < (uint32_t)USED_LDS_BITS) return (((volatile uint32_t*)D.used)[r >> 5] >> (r & 31)) & 1u;
+    return (__hip_atomic_load(D.gused + (r >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (r & 31)) & 1u;
+}
+__device__ __forceinline__ void used_set(const Det& D, uint32_t r) {
+    if (r < (uint32_t)USED_LDS_BITS) atomicOr(&D.used[r >> 5], 1u << (r & 31));
+    else { atomicOr(D.gused + (r >> 5), 1u << (r & 31)); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
+}
+__device__ __forceinline__ void used_clear(const Det& D, uint32_t r) {
+    if (r < (uint32_t)USED_LDS_BITS) atomicAnd(&D.used[r >> 5], ~(1u << (r & 31)));
+    else { atomicAnd(D.gused + (r >> 5), ~(1u << (r & 31))); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
+}
+__device__ __forceinline__ uint32_t rank_of(const Det& D, int pix) { return __float_as_uint(D.pix4[pix].w); }
 __device__ __forceinline__ double dist2(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
 __device__ __forceinline__ double angle_diff_signed(double a, double b) {
     double diff = a - b;
@@ -252,18 +289,22 @@ __device__ __forceinline__ bool aligned_rad(double a, double theta, double prec)
     return n_theta <= prec;
 }
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// LDS traffic of one wavefront is processed in program order, so lanes only need the compiler to keep that order
+__device__ __forceinline__ void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // region_grow: returns the region size; reg_angle in/out per the reference (out: final level-line angle)
-__device__ int region_grow(const Det& D, int seed_pix, double prec, double& reg_angle) {
+__device__ int region_grow(const Det& D, int seed_pix, uint32_t seed_rank, double prec, double& reg_angle) {
     const int lane = D.lane, w = D.w, h = D.h;
     reg_angle = (double)D.ang[seed_pix] * DEG_TO_RADS;
-    float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
+    const float2 scs = D.seedcs[seed_pix];
+    float sumdx = scs.x, sumdy = scs.y;
     const uint32_t seed_xy = (uint32_t)(seed_pix % w) | ((uint32_t)(seed_pix / w) << 16);
-    if (lane == 0) { D.reg[0] = seed_xy; D.ring[0] = seed_xy; atomicOr(&D.used[seed_pix >> 5], 1u << (seed_pix & 31)); }
+    if (lane == 0) { D.reg[0] = seed_xy; D.ring[0] = seed_xy; used_set(D, seed_rank); }
     wave_sync();
     int reg_n = 1, head = 0;
     while (head < reg_n) {
         const int nb = min(7, reg_n - head);
+        if (reg_n - head > RING) wave_sync();      // (rare) the batch reads entries that left the LDS ring: make the global copies visible
         const int e = lane / 9, k = lane - e * 9;
         bool ok = false;
         int pix = 0;
@@ -276,26 +317,27 @@ __device__ int region_grow(const Det& D, int seed_pix, double prec, double& reg_
             const int xx = (int)(pxy & 0xffff) + (k % 3) - 1, yy = (int)(pxy >> 16) + (k / 3) - 1;
             if (xx >= 0 && xx < w && yy >= 0 && yy < h) { ok = true; pix = yy * w + xx; nxy = (uint32_t)xx | ((uint32_t)yy << 16); }
         }
-        const float deg = ok ? D.ang[pix] : NOTDEF_F;
+        float4 rec4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
+        if (ok) rec4 = D.pix4[pix];
+        const float deg = rec4.x, c = rec4.y, s = rec4.z;
+        const uint32_t rk = __float_as_uint(rec4.w);
         ok = ok && deg != NOTDEF_F;
         const double a = (double)deg * DEG_TO_RADS;
-        float c = 0.f, s = 0.f;
-        if (ok) { const float af = (float)a; c = (float)cos((double)af); s = (float)sin((double)af); }
         int cursor = 0;
         while (true) {
-            const bool cand = ok && lane >= cursor && !used_get(D, pix) && aligned_rad(a, reg_angle, prec);
+            const bool cand = ok && lane >= cursor && !used_get(D, rk) && aligned_rad(a, reg_angle, prec);
             const unsigned long long m = __ballot(cand);
             if (!m) break;
             const int f = __ffsll((long long)m) - 1;
             const uint32_t axy = (uint32_t)__shfl((int)nxy, f, 64);
-            if (lane == f) atomicOr(&D.used[pix >> 5], 1u << (pix & 31));
+            if (lane == f) used_set(D, rk);
             if (lane == 0) { D.reg[reg_n] = axy; D.ring[reg_n & (RING - 1)] = axy; }
             reg_n++;
             sumdx += __shfl(c, f, 64);
             sumdy += __shfl(s, f, 64);
             reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * DEG_TO_RADS;
             cursor = f + 1;
-            wave_sync();
+            lds_sync();
         }
         head += nb;
     }
@@ -312,14 +354,14 @@ __device__ inline void chains3(const Det& D, int n, double out[3], bool sub2, F 
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         if (i < n) { double v[3]; vals(i, v); D.stage[lane * 3] = v[0]; D.stage[lane * 3 + 1] = v[1]; D.stage[lane * 3 + 2] = v[2]; }
-        wave_sync();
+        lds_sync();
         const int cnt = min(64, n - base);
         if (lane < 3) {
             const volatile double* st = D.stage;
             if (lane == 2 && sub2) for (int j = 0; j < cnt; j++) acc -= st[j * 3 + 2];
             else for (int j = 0; j < cnt; j++) acc += st[j * 3 + lane];
         }
-        wave_sync();
+        lds_sync();
     }
     out[0] = __shfl(acc, 0, 64); out[1] = __shfl(acc, 1, 64); out[2] = __shfl(acc, 2, 64);
 }
@@ -363,7 +405,7 @@ __device__ void region2rect(const Det& D, int n, double reg_angle, double prec, 
     rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy;
     rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
     rec.width = w_max - w_min;
-    rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy; rec.prec = prec; rec.p = p;
+    rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy; rec.prec = prec; rec.p = p; rec.pj = 0;
     if (rec.width < 1.0) rec.width = 1.0;
 }
 
@@ -381,7 +423,7 @@ __device__ bool reduce_region_radius(const Det& D, int& n, double reg_angle, dou
         for (int i = lane; i < n; i += 64) {
             const uint32_t e = D.reg[i];
             const bool far = dist2(xc, yc, double(e & 0xffff), double(e >> 16)) > radSq;
-            if (far) { const int pix = (e >> 16) * D.w + (e & 0xffff); atomicAnd(&D.used[pix >> 5], ~(1u << (pix & 31))); }
+            if (far) used_clear(D, rank_of(D, (e >> 16) * D.w + (e & 0xffff)));
             else n_near++;
         }
         n_near = wave_sum_i(n_near);
@@ -427,7 +469,7 @@ __device__ bool refine(const Det& D, int& n, double& reg_angle, double prec, dou
     chains3(D, n, s3, false, [&](int i, double* v) {
         const uint32_t e = D.reg[i];
         const int pix = (e >> 16) * D.w + (e & 0xffff);
-        atomicAnd(&D.used[pix >> 5], ~(1u << (pix & 31)));
+        used_clear(D, rank_of(D, pix));
         v[0] = 0; v[1] = 0; v[2] = 0;
         if (sqrt(dist2(xc, yc, double(e & 0xffff), double(e >> 16))) < width) {
             const double ang_d = angle_diff_signed((double)D.ang[pix] * DEG_TO_RADS, ang_c);
@@ -441,7 +483,7 @@ __device__ bool refine(const Det& D, int& n, double& reg_angle, double prec, dou
     const double mean_angle = sum / double(cnt);
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / double(cnt) + mean_angle * mean_angle);
     wave_sync();
-    n = region_grow(D, seed_pix, tau, reg_angle);
+    n = region_grow(D, seed_pix, rank_of(D, seed_pix), tau, reg_angle);
     if (n < 2) return false;
     region2rect(D, n, reg_angle, prec, p, rec);
     density = double(n) / (sqrt(dist2(rec.x1, rec.y1, rec.x2, rec.y2)) * rec.width);
@@ -456,19 +498,14 @@ __device__ inline bool double_equal(double a, double b) {
     if (abs_max < 2.2250738585072014e-308) abs_max = 2.2250738585072014e-308;
     return (abs_diff / abs_max) <= (RELATIVE_ERROR_FACTOR * 2.220446049250313e-16);
 }
-__device__ inline double log_gamma(double x) {
-    if (x > 15.0) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
-    const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
-    double a = (x + 0.5) * log(x + 5.5) - (x + 5.5);
-    double b = 0;
-    for (int n = 0; n < 7; ++n) { a -= log(x + double(n)); b += q[n] * pow(x, double(n)); }
-    return a + log(b);
-}
-__device__ double nfa(double LOG_NT, int n, int k, double p) {
+__device__ double nfa(const Plan& P, int n, int k, double p, int pj, int lane) {
+    const double LOG_NT = P.log_nt;
     if (n == 0 || k == 0) return -LOG_NT;
-    if (n == k) return -LOG_NT - double(n) * log10(p);
+    if (n == k) return -LOG_NT - double(n) * P.p_log10[pj];
     const double p_term = p / (1 - p);
-    const double log1term = log_gamma(double(n) + 1) - log_gamma(double(k) + 1) - log_gamma(double(n - k) + 1) + double(k) * log(p) + double(n - k) * log(1.0 - p);
+    // log_gamma(n+1) - log_gamma(k+1) - log_gamma(n-k+1) + k log(p) + (n-k) log(1-p), the transcendental terms from the host tables
+    const double* lg = P.lgamma_tab;
+    const double log1term = lg[n + 1] - lg[k + 1] - lg[n - k + 1] + double(k) * P.p_log[pj] + double(n - k) * P.p1_log[pj];
     double term = exp(log1term);
     if (double_equal(term, 0)) {
         if (k > n * p) return -log1term / 2.30258509299404568402 - LOG_NT;
@@ -476,20 +513,34 @@ __device__ double nfa(double LOG_NT, int n, int k, double p) {
     }
     double bin_tail = term;
     const double tolerance = 0.1;
-    for (int i = k + 1; i <= n; ++i) {
-        const double bin_term = double(n - i + 1) / double(i);
-        const double mult_term = bin_term * p_term;
-        term *= mult_term;
-        bin_tail += term;
-        if (bin_term < 1) {
-            const double err = term * ((1 - pow(mult_term, double(n - i + 1))) / (1 - mult_term) - 1);
-            if (err < tolerance * fabs(-log10(bin_tail) - LOG_NT) * bin_tail) break;
+    // The tail is a sequential recurrence (term *= mult; bin_tail += term), but the stopping rule of iteration i only reads
+    // iteration i's values: every lane runs the cheap recurrence for a block of 64 iterations, keeps the values of "its" i and
+    // evaluates the expensive rule (pow, log10) for it; the first lane whose rule fires is where the reference breaks.
+    for (int i = k + 1; i <= n;) {
+        const int cnt = min(64, n - i + 1);
+        double t = term, bt = bin_tail, my_term = 0, my_tail = 0, my_bin = 2, my_mult = 0;
+        for (int j = 0; j < cnt; j++) {
+            const double bin_term = double(n - (i + j) + 1) / double(i + j);
+            const double mult_term = bin_term * p_term;
+            t *= mult_term;
+            bt += t;
+            if (j == lane) { my_term = t; my_tail = bt; my_bin = bin_term; my_mult = mult_term; }
         }
+        bool brk = false;
+        if (lane < cnt && my_bin < 1) {
+            const double err = my_term * ((1 - pow(my_mult, double(n - (i + lane) + 1))) / (1 - my_mult) - 1);
+            brk = err < tolerance * fabs(-log10(my_tail) - LOG_NT) * my_tail;
+        }
+        const unsigned long long m = __ballot(brk);
+        if (m) { bin_tail = __shfl(my_tail, __ffsll((long long)m) - 1, 64); return -log10(bin_tail) - LOG_NT; }
+        term = t; bin_tail = bt; i += cnt;
     }
     return -log10(bin_tail) - LOG_NT;
 }
 
-__device__ double rect_nfa(const Det& D, const Rect& rec) {
+// Counts the pixels of the rectangle (total) and, for each of the np tolerances precs[], those aligned with rec.theta.
+template <int NP>
+__device__ int rect_counts(const Det& D, const Rect& rec, const double* precs, int* alg_out) {
     const int lane = D.lane;
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
@@ -520,54 +571,84 @@ __device__ double rect_nfa(const Det& D, const Rect& rec) {
     taken[rightmost] = true;
     int tailp = -1;
     for (int i = 0; i < 4; ++i) if (!taken[i]) { if (tailp < 0) tailp = i; else if (ox[tailp] > ox[i]) tailp = i; }
-    const double flstep = (oy[min_y] != oy[leftmost]) ? (ox[min_y] - ox[leftmost]) / (oy[min_y] - oy[leftmost]) : 0;
-    const double slstep = (oy[leftmost] != ox[tailp]) ? (ox[leftmost] - ox[tailp]) / (oy[leftmost] - ox[tailp]) : 0;
-    const double frstep = (oy[min_y] != oy[rightmost]) ? (ox[min_y] - ox[rightmost]) / (oy[min_y] - oy[rightmost]) : 0;
-    const double srstep = (oy[rightmost] != ox[tailp]) ? (ox[rightmost] - ox[tailp]) / (oy[rightmost] - ox[tailp]) : 0;
-    double lstep = flstep, rstep = frstep;
-    double left_x = ox[min_y], right_x = ox[min_y];
-    const int min_iter = oy[min_y], max_iter = oy[max_y];
-    // row table (in-image rows only), built in row order by every lane redundantly; lane 0 stores it
-    int nrows = 0, total = 0;
-    for (int y = min_iter; y <= max_iter; ++y) {
-        if (y < 0 || y >= D.h) continue;
-        int xa = int(left_x), xb = int(right_x);
-        // count of x in [xa, xb] with 0 <= x < w
-        const int ca = max(xa, 0), cb = min(xb, D.w - 1);
-        const int c = cb >= ca ? cb - ca + 1 : 0;
-        if (lane == 0) { D.rowL[nrows] = ca; D.rowR[nrows] = y; D.pre[nrows] = total; }
-        nrows++;
-        total += c;
-        if (y >= oy[leftmost]) lstep = slstep;
-        if (y >= oy[rightmost]) rstep = srstep;
-        left_x += lstep;
-        right_x += rstep;
+    // integer divisions and the ox[tailp] (not oy) operands are the library's own
+    const long long flstep = (oy[min_y] != oy[leftmost]) ? (ox[min_y] - ox[leftmost]) / (oy[min_y] - oy[leftmost]) : 0;
+    const long long slstep = (oy[leftmost] != ox[tailp]) ? (ox[leftmost] - ox[tailp]) / (oy[leftmost] - ox[tailp]) : 0;
+    const long long frstep = (oy[min_y] != oy[rightmost]) ? (ox[min_y] - ox[rightmost]) / (oy[min_y] - oy[rightmost]) : 0;
+    const long long srstep = (oy[rightmost] != ox[tailp]) ? (ox[rightmost] - ox[tailp]) / (oy[rightmost] - ox[tailp]) : 0;
+    // The reference walks the rows with left_x += lstep / right_x += rstep (doubles).  All operands are integers, so the sums are
+    // exact and row k of the in-image rows has the closed form below (rows outside the image skip the update in the library).
+    const long long x0 = ox[min_y];
+    const int ylo = max(oy[min_y], 0), yhi = min(oy[max_y], D.h - 1);
+    const int nrows = yhi >= ylo ? yhi - ylo + 1 : 0;
+    const int ly = oy[leftmost], ry = oy[rightmost];
+    auto row_span = [&](int k, int& xa) -> int {      // clipped [xa, xa + c) of in-image row k; returns c
+        const long long nl = min(max((long long)ly - ylo, 0ll), (long long)k), nr = min(max((long long)ry - ylo, 0ll), (long long)k);
+        const long long left = x0 + nl * flstep + (k - nl) * slstep, right = x0 + nr * frstep + (k - nr) * srstep;
+        const long long a = max(left, 0ll), b = min(right, (long long)D.w - 1);
+        xa = (int)a;
+        return b >= a ? (int)(b - a + 1) : 0;
+    };
+    int total = 0, wmax = 0;
+    for (int k = lane; k < nrows; k += 64) { int xa; const int c = row_span(k, xa); total += c; wmax = max(wmax, c); }
+    total = wave_sum_i(total);
+    for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    int alg[NP];
+    for (int q = 0; q < NP; q++) alg[q] = 0;
+    auto test = [&](int pix) {
+        const float deg = D.ang[pix];
+        if (deg == NOTDEF_F) return;
+        double n_theta = rec.theta - (double)deg * DEG_TO_RADS;
+        if (n_theta < 0) n_theta = -n_theta;
+        if (n_theta > M_3_2_PI) {
+            n_theta -= M_2__PI;
+            if (n_theta < 0) n_theta = -n_theta;
+        }
+        for (int q = 0; q < NP; q++) if (n_theta <= precs[q]) alg[q]++;
+    };
+    if (wmax > 0 && wmax <= 64) {
+        int wp = 1; while (wp < wmax) wp <<= 1;
+        const int rps = 64 / wp, sub = lane / wp, xo = lane & (wp - 1);
+        for (int kb = 0; kb < nrows; kb += rps) {
+            const int k = kb + sub;
+            if (k < nrows) {
+                int xa; const int c = row_span(k, xa);
+                if (xo < c) test((ylo + k) * D.w + xa + xo);
+            }
+        }
+    } else if (wmax > 64) {
+        for (int k = 0; k < nrows; k++) {
+            int xa; const int c = row_span(k, xa);
+            for (int xo = lane; xo < c; xo += 64) test((ylo + k) * D.w + xa + xo);
+        }
     }
-    if (lane == 0) D.pre[nrows] = total;
-    wave_sync();
-    int alg = 0;
-    const volatile int* pre = D.pre;
-    for (int t = lane; t < total; t += 64) {
-        int lo = 0, hi = nrows - 1;           // last row with pre[row] <= t
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid - 1; }
-        const int x = ((volatile int*)D.rowL)[lo] + (t - pre[lo]), y = ((volatile int*)D.rowR)[lo];
-        const float deg = D.ang[y * D.w + x];
-        if (deg != NOTDEF_F && aligned_rad((double)deg * DEG_TO_RADS, rec.theta, rec.prec)) alg++;
-    }
-    alg = wave_sum_i(alg);
-    wave_sync();
-    return nfa(D.log_nt, total, alg, rec.p);
+    for (int q = 0; q < NP; q++) alg_out[q] = wave_sum_i(alg[q]);
+    return total;
+}
+
+__device__ double rect_nfa(const Det& D, const Rect& rec) {
+    int alg;
+    const int total = rect_counts<1>(D, rec, &rec.prec, &alg);
+    return nfa(*D.plan, total, alg, rec.p, rec.pj, D.lane);
 }
 
 __device__ double rect_improve(const Det& D, Rect& rec, double LOG_EPS) {
     const double delta = 0.5, delta_2 = delta / 2.0;
-    double log_nfa = rect_nfa(D, rec);
-    if (log_nfa > LOG_EPS) return log_nfa;
+    const Plan& P = *D.plan;
+    // first evaluation + the five "finer precision" trials share the geometry: one pass over the pixels counts all six tolerances
     Rect r = rec;
+    double precs[6], ps[6];
+    precs[0] = rec.prec; ps[0] = rec.p;
+    for (int n = 1; n < 6; ++n) { ps[n] = ps[n - 1] / 2; precs[n] = ps[n] * LSD_PI; }
+    int algs[6];
+    const int total0 = rect_counts<6>(D, rec, precs, algs);
+    double log_nfa = nfa(P, total0, algs[0], ps[0], rec.pj, D.lane);
+    if (log_nfa > LOG_EPS) return log_nfa;
     for (int n = 0; n < 5; ++n) {
         r.p /= 2;
         r.prec = r.p * LSD_PI;
-        const double v = rect_nfa(D, r);
+        r.pj++;
+        const double v = nfa(P, total0, algs[n + 1], r.p, r.pj, D.lane);
         if (v > log_nfa) { log_nfa = v; rec = r; }
     }
     if (log_nfa > LOG_EPS) return log_nfa;
@@ -603,11 +684,14 @@ __device__ double rect_improve(const Det& D, Rect& rec, double LOG_EPS) {
     }
     if (log_nfa > LOG_EPS) return log_nfa;
     r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
+    if ((r.width - delta) >= 0.5) {      // the width test is the same for all five trials (the width does not change here)
+        for (int n = 0; n < 5; ++n) { ps[n] = (n ? ps[n - 1] : r.p) / 2; precs[n] = ps[n] * LSD_PI; }
+        const int total = rect_counts<5>(D, r, precs, algs);
+        for (int n = 0; n < 5; ++n) {
             r.p /= 2;
             r.prec = r.p * LSD_PI;
-            const double v = rect_nfa(D, r);
+            r.pj++;
+            const double v = nfa(P, total, algs[n], r.p, r.pj, D.lane);
             if (v > log_nfa) { rec = r; log_nfa = v; }
         }
     }
@@ -624,40 +708,52 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
     Misc* misc = miscs + b;
     Det D;
     D.ang = (const float*)(F + P.off_ang); D.g2 = (const uint32_t*)(F + P.off_g2);
+    D.pix4 = (const float4*)(F + P.off_pix); D.seedcs = (const float2*)(F + P.off_seed); D.plan = plan;
     D.reg = (uint32_t*)(F + P.off_reg); D.tmp = (uint32_t*)(F + P.off_tmp);
     D.w = P.w; D.h = P.h; D.log_nt = P.log_nt; D.lane = lane;
-    const int used_words = (P.w * P.h + 31) / 32;
+    const int used_words = USED_LDS_BITS / 32, gused_words = (P.w * P.h + 31) / 32;
+    D.gused = (uint32_t*)(F + P.off_gused);
     uint8_t* q = lds_raw;
     D.stage = (double*)q; q += 64 * 3 * 8;
     D.used = (uint32_t*)q; q += (size_t)used_words * 4;
-    D.ring = (uint32_t*)q; q += RING * 4;
-    D.rowL = (int*)q; q += MAX_ROWS * 4;
-    D.rowR = (int*)q; q += MAX_ROWS * 4;
-    D.pre = (int*)q;
+    D.ring = (uint32_t*)q;
     for (int i = lane; i < used_words; i += 64) D.used[i] = 0;
+    if (miscs[b].n_ord > USED_LDS_BITS) for (int i = lane; i < gused_words; i += 64) D.gused[i] = 0;
     wave_sync();
     const uint32_t* ord = (const uint32_t*)(F + P.off_ord);
+    const uint32_t* ordr = (const uint32_t*)(F + P.off_ordr);
     Seg* segs = (Seg*)(F + P.off_segs);
     const int n_ord = misc->n_ord;
-    int n_seg = 0, n_regions = 0;
+    int n_seg = 0, n_regions = 0, n_px = 0;
+    long long t_grow = 0, t_rect = 0, t_refine = 0, t_nfa = 0;
+    const long long t_begin = __builtin_readcyclecounter();
     for (int base = 0; base < n_ord; base += 64) {
         const int pix = base + lane < n_ord ? (int)ord[base + lane] : -1;
+        const uint32_t prk = base + lane < n_ord ? ordr[base + lane] : 0u;
         int cursor = 0;
         while (true) {
-            const bool cand = pix >= 0 && lane >= cursor && !used_get(D, pix);
+            const bool cand = pix >= 0 && lane >= cursor && !used_get(D, prk);
             const unsigned long long m = __ballot(cand);
             if (!m) break;
             const int f = __ffsll((long long)m) - 1;
             cursor = f + 1;
             const int seed = __shfl(pix, f, 64);
+            const uint32_t seed_rank = (uint32_t)__shfl((int)prk, f, 64);
             double reg_angle;
-            int n = region_grow(D, seed, P.prec, reg_angle);
-            n_regions++;
+            long long c0 = __builtin_readcyclecounter();
+            int n = region_grow(D, seed, seed_rank, P.prec, reg_angle);
+            long long c1 = __builtin_readcyclecounter();
+            t_grow += c1 - c0;
+            n_regions++; n_px += n;
             if (n < P.min_reg_size) continue;
             Rect rec;
             region2rect(D, n, reg_angle, P.prec, P.p, rec);
-            if (!refine(D, n, reg_angle, P.prec, P.p, rec, P.density_th)) continue;
+            c0 = __builtin_readcyclecounter(); t_rect += c0 - c1;
+            const bool keep = refine(D, n, reg_angle, P.prec, P.p, rec, P.density_th);
+            c1 = __builtin_readcyclecounter(); t_refine += c1 - c0;
+            if (!keep) continue;
             const double log_nfa = rect_improve(D, rec, P.log_eps);
+            c0 = __builtin_readcyclecounter(); t_nfa += c0 - c1;
             if (log_nfa <= P.log_eps) continue;
             rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
             rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8; rec.width /= 0.8;
@@ -665,7 +761,11 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
             n_seg++;
         }
     }
-    if (lane == 0) { misc->n_seg = n_seg; misc->n_regions = n_regions; if (n_seg > MAX_SEGS) misc->status = 1; }
+    if (lane == 0) {
+        misc->n_seg = n_seg; misc->n_regions = n_regions; misc->n_grown_px = n_px;
+        if (n_seg > MAX_SEGS) misc->status = 1;
+        misc->t[0] = __builtin_readcyclecounter() - t_begin; misc->t[1] = t_grow; misc->t[2] = t_rect; misc->t[3] = t_refine; misc->t[4] = t_nfa;
+    }
 }
 
 // ---- K5: Sobel 3x3 (cv::Sobel CV_16S, BORDER_REFLECT_101) of the 5x5-blurred image ------------------------------------
@@ -974,9 +1074,10 @@ struct planar_lsd {
     int W = 0, H = 0, max_batch = 0;
     lsd::Plan plan{};
     int detect_smem = 0;
-    DevBuf d_plan, d_cx, d_cy, d_taps, d_ws, d_misc;
+    DevBuf d_plan, d_cx, d_cy, d_taps, d_ws, d_misc, d_lgamma;
     DevBuf d_in, d_kl, d_desc, d_eq, d_n;   // staging for the host-pointer entry point
     int stage_lines = 0;
+    int pre_B = 0;
 };
 
 // host mirrors of the oracle's coefficient tables (same expressions, same libm)
@@ -1043,12 +1144,30 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     auto carve = [&](size_t bytes) { size_t o2 = off; off = align_up(off + bytes, (size_t)256); return o2; };
     const size_t NPf = (size_t)width * height, NPs = (size_t)P.w * P.h;
     P.off_blur7 = carve(NPf); P.off_blur5 = carve(NPf); P.off_dx = carve(NPf * 2); P.off_dy = carve(NPf * 2);
-    P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
+    P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_pix = carve(NPs * 16); P.off_seed = carve(NPs * 8); P.off_ordr = carve(NPs * 4); P.off_gused = carve((NPs + 31) / 32 * 4 + 256); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
     P.off_segs = carve((size_t)lsd::MAX_SEGS * sizeof(lsd::Seg)); P.off_kl = carve((size_t)lsd::MAX_SEGS * sizeof(planar_keyline));
     P.frame_bytes = off;
-    o->detect_smem = 64 * 3 * 8 + (int)((NPs + 31) / 32) * 4 + lsd::RING * 4 + 3 * lsd::MAX_ROWS * 4 + 16;
+    o->detect_smem = 64 * 3 * 8 + lsd::USED_LDS_BITS / 8 + lsd::RING * 4 + 16;
     if (o->detect_smem > 150 * 1024 || P.h + 2 > lsd::MAX_ROWS || NPs > (1u << 20)) { delete o; set_error("planar_lsd_create: image too large for the LDS-resident used map"); return PLANAR_EINVAL; }
-    int rc = o->d_plan.alloc(sizeof(lsd::Plan));
+    // log_gamma(x) (lsd.cpp: Windschitl for x > 15, Lanczos otherwise) at every integer argument nfa() can see, and log(p), log(1-p),
+    // log10(p) for p = P.p / 2^j: evaluated here with the host libm, exactly as the reference library evaluates them
+    std::vector<double> lgam(NPs + 3, 0.0);
+    for (size_t i = 1; i < lgam.size(); i++) {
+        const double x = (double)i;
+        if (x > 15.0) lgam[i] = 0.918938533204673 + (x - 0.5) * std::log(x) - x + 0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
+        else {
+            static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+            double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5), bsum = 0;
+            for (int n = 0; n < 7; ++n) { a -= std::log(x + double(n)); bsum += q[n] * std::pow(x, double(n)); }
+            lgam[i] = a + std::log(bsum);
+        }
+    }
+    { double pp = P.p; for (int j = 0; j < 12; j++) { P.p_log[j] = std::log(pp); P.p1_log[j] = std::log(1.0 - pp); P.p_log10[j] = std::log10(pp); pp /= 2; } }
+    int rc = o->d_lgamma.alloc(lgam.size() * 8);
+    if (rc) { delete o; return rc; }
+    P.lgamma_tab = o->d_lgamma.as<double>();
+    if (hipMemcpy(o->d_lgamma.p, lgam.data(), lgam.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { delete o; set_error("planar_lsd_create: table upload failed"); return PLANAR_EDEVICE; }
+    rc = o->d_plan.alloc(sizeof(lsd::Plan));
     if (!rc) rc = o->d_cx.alloc(cx.size() * sizeof(lsd::Coef));
     if (!rc) rc = o->d_cy.alloc(cy.size() * sizeof(lsd::Coef));
     if (!rc) rc = o->d_taps.alloc(16 * 4);
@@ -1070,11 +1189,10 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
 
 void planar_lsd_destroy(planar_lsd* o) { delete o; }
 
-int planar_lsd_extract_dev(planar_lsd* o, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride, int max_lines, planar_keyline* d_keylines,
-                           uint8_t* d_ldesc, double* d_line_eq, int32_t* d_n_lines) {
-    PLANAR_REQUIRE(o && d_gray && d_keylines && d_ldesc && d_line_eq && d_n_lines, PLANAR_EINVAL, "null argument");
+int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride) {
+    PLANAR_REQUIRE(o && d_gray, PLANAR_EINVAL, "null argument");
     PLANAR_REQUIRE(B >= 1 && B <= o->max_batch, PLANAR_EINVAL, "B out of range");
-    PLANAR_REQUIRE(pitch >= o->W && max_lines >= 1 && max_lines <= lsd::MAX_SEGS, PLANAR_EINVAL, "bad pitch / max_lines");
+    PLANAR_REQUIRE(pitch >= o->W, PLANAR_EINVAL, "bad pitch");
     hipStream_t st = o->ctx->stream;
     const lsd::Plan& P = o->plan;
     const lsd::Plan* dP = o->d_plan.as<lsd::Plan>();
@@ -1087,11 +1205,32 @@ int planar_lsd_extract_dev(planar_lsd* o, const uint8_t* d_gray, int B, int pitc
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
     hipLaunchKernelGGL(lsd::lbd_sobel, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, dP, ws);
     hipLaunchKernelGGL(lsd::lsd_sort, dim3(B), dim3(256), 0, st, dP, ws, dm);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    o->pre_B = B;
+    return PLANAR_OK;
+}
+
+int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d_keylines, uint8_t* d_ldesc, double* d_line_eq, int32_t* d_n_lines) {
+    PLANAR_REQUIRE(o && d_keylines && d_ldesc && d_line_eq && d_n_lines, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && B == o->pre_B, PLANAR_ESTATE, "planar_lsd_preprocess_dev must have been enqueued for the same B");
+    PLANAR_REQUIRE(max_lines >= 1 && max_lines <= lsd::MAX_SEGS, PLANAR_EINVAL, "bad max_lines");
+    hipStream_t st = o->ctx->stream;
+    const lsd::Plan* dP = o->d_plan.as<lsd::Plan>();
+    uint8_t* ws = o->d_ws.as<uint8_t>();
+    lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
     hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, st, dP, ws, dm);
     hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines);
     hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
+}
+
+int planar_lsd_extract_dev(planar_lsd* o, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride, int max_lines, planar_keyline* d_keylines,
+                           uint8_t* d_ldesc, double* d_line_eq, int32_t* d_n_lines) {
+    PLANAR_REQUIRE(o && d_gray && d_keylines && d_ldesc && d_line_eq && d_n_lines, PLANAR_EINVAL, "null argument");
+    int rc = planar_lsd_preprocess_dev(o, d_gray, B, pitch, frame_stride);
+    if (rc) return rc;
+    return planar_lsd_detect_dev(o, B, max_lines, d_keylines, d_ldesc, d_line_eq, d_n_lines);
 }
 
 int planar_lsd_extract(planar_lsd* o, const uint8_t* gray, int B, int pitch, int64_t frame_stride, int max_lines, planar_keyline* keylines,
@@ -1146,6 +1285,13 @@ int planar_lsd_read_stage(planar_lsd* o, int frame, int stage, void* out, int64_
         case 2: bytes = (size_t)m.n_ord * 4; off = P.off_ord; ret = m.n_ord; break;
         case 3: bytes = (size_t)std::min(m.n_seg, lsd::MAX_SEGS) * sizeof(lsd::Seg); off = P.off_segs; ret = m.n_seg; break;
         case 4: { PLANAR_REQUIRE(out_bytes >= 4, PLANAR_EINVAL, "buffer too small"); *(int32_t*)out = m.n_regions; return PLANAR_OK; }
+        case 5: {   // shader-clock cycles: total detect, region_grow, region2rect, refine, rect_improve ; then n_ord, grown pixels
+            PLANAR_REQUIRE(out_bytes >= 56, PLANAR_EINVAL, "buffer too small");
+            long long* o64 = (long long*)out;
+            for (int i = 0; i < 5; i++) o64[i] = m.t[i];
+            o64[5] = m.n_ord; o64[6] = m.n_grown_px;
+            return PLANAR_OK;
+        }
         default: set_error("planar_lsd_read_stage: unknown stage"); return PLANAR_EINVAL;
     }
     PLANAR_REQUIRE((int64_t)bytes <= out_bytes, PLANAR_EINVAL, "buffer too small");

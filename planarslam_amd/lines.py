@@ -49,6 +49,8 @@ class LineSegment:
             out = np.zeros(w * h, np.int32)
         elif stage == 3:
             out = np.zeros(lib().planar_lsd_max_segments(), SEG_DTYPE)
+        elif stage == 5:
+            out = np.zeros(7, np.int64)
         else:
             out = np.zeros(1, np.int32)
         r = check(lib().planar_lsd_read_stage(self.h, frame, stage, out.ctypes.data, out.nbytes))

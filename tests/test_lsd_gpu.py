@@ -84,3 +84,21 @@ def test_few_lines_keep_detection_order(ctx):
     assert n[0] == len(rk) == nd and 1 <= nd <= 40
     np.testing.assert_array_equal(kl[0, :nd]["class_id"], np.arange(nd))
     np.testing.assert_array_equal(desc[0, :nd], rd)
+
+
+def test_noisy_image_uses_global_used_tail(ctx):
+    """More than 32768 defined pixels: the `used` flags beyond the LDS-resident head live in global memory."""
+    from planarslam_amd.lines import LineSegment
+    rng = np.random.default_rng(17)
+    img = synth.gray_image(3).astype(np.int32) + rng.integers(-40, 41, (480, 640))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    ref = O.lsd_detect(img, tie_order=1, want_stages=True)
+    assert (ref["angles"] != -1024.0).sum() > 40000
+    ls = LineSegment(640, 480, 1, ctx)
+    kl, desc, eq, n = ls.ExtractLineSegment(img)
+    segs = ls.read_stage(0, 3)
+    got = np.stack([segs["x1"], segs["y1"], segs["x2"], segs["y2"]], 1)
+    np.testing.assert_array_equal(got, ref["xy"])
+    rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=1)
+    assert n[0] == len(rk)
+    np.testing.assert_array_equal(desc[0, :n[0]], rd)
