@@ -923,33 +923,41 @@ __device__ inline planar_keyline make_keyline(const Seg& sg, int cols, int rows,
 
 __global__ __launch_bounds__(64) void lsd_keylines(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int max_lines,
                                                    planar_keyline* __restrict__ out_kl, double* __restrict__ out_eq, int32_t* __restrict__ n_out) {
-    __shared__ float key[MAX_SEGS];
-    __shared__ int idx[MAX_SEGS];
+    // 8 KB of LDS so that this kernel can start while peac_segment still holds most of every CU's LDS; frames with more raw
+    // segments than that sort in global scratch
+    constexpr int LDS_SORT = 1024;
+    __shared__ float key_l[LDS_SORT];
+    __shared__ int idx_l[LDS_SORT];
     const Plan& P = *plan;
     const int b = blockIdx.x, lane = threadIdx.x;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
     Misc* misc = miscs + b;
     const Seg* segs = (const Seg*)(F + P.off_segs);
     const int n = min(misc->n_seg, MAX_SEGS);
-    for (int i = lane; i < n; i += 64) { key[i] = make_keyline(segs[i], P.W, P.H, i).response; idx[i] = i; }
-    __syncthreads();
-    int nk = n;
-    if (n > max_lines) {
-        if (lane == 0) { SortBuf s{key, idx}; std_sort_desc(s, n); }
-        __syncthreads();
-        nk = max_lines;
-    }
+    const int nk = min(n, max_lines);
     planar_keyline* K = out_kl + (size_t)b * max_lines;
     planar_keyline* Kws = (planar_keyline*)(F + P.off_kl);
-    for (int i = lane; i < nk; i += 64) {
-        const planar_keyline kl = make_keyline(segs[idx[i]], P.W, P.H, n > max_lines ? i : idx[i]);
-        K[i] = kl; Kws[i] = kl;
-        const double sp0 = kl.start_x, sp1 = kl.start_y, ep0 = kl.end_x, ep1 = kl.end_y;
-        const double l0 = sp1 * 1.0 - 1.0 * ep1, l1 = 1.0 * ep0 - sp0 * 1.0, l2 = sp0 * ep1 - sp1 * ep0;
-        const double nrm = sqrt(l0 * l0 + l1 * l1 + l2 * l2);
-        double* E = out_eq + ((size_t)b * max_lines + i) * 3;
-        E[0] = l0 / nrm; E[1] = l1 / nrm; E[2] = l2 / nrm;
-    }
+    auto body = [&](float* key, int* idx) {
+        for (int i = lane; i < n; i += 64) { key[i] = make_keyline(segs[i], P.W, P.H, i).response; idx[i] = i; }
+        __threadfence_block();
+        __syncthreads();
+        if (n > max_lines) {
+            if (lane == 0) { SortBuf s{key, idx}; std_sort_desc(s, n); }
+            __threadfence_block();
+            __syncthreads();
+        }
+        for (int i = lane; i < nk; i += 64) {
+            const planar_keyline kl = make_keyline(segs[idx[i]], P.W, P.H, n > max_lines ? i : idx[i]);
+            K[i] = kl; Kws[i] = kl;
+            const double sp0 = kl.start_x, sp1 = kl.start_y, ep0 = kl.end_x, ep1 = kl.end_y;
+            const double l0 = sp1 * 1.0 - 1.0 * ep1, l1 = 1.0 * ep0 - sp0 * 1.0, l2 = sp0 * ep1 - sp1 * ep0;
+            const double nrm = sqrt(l0 * l0 + l1 * l1 + l2 * l2);
+            double* E = out_eq + ((size_t)b * max_lines + i) * 3;
+            E[0] = l0 / nrm; E[1] = l1 / nrm; E[2] = l2 / nrm;
+        }
+    };
+    if (n <= LDS_SORT) body(key_l, idx_l);
+    else body((float*)(F + P.off_tmp), (int*)(F + P.off_tmp) + MAX_SEGS);
     if (lane == 0) { n_out[b] = nk; misc->n_kl = nk; }
 }
 

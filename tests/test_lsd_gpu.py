@@ -102,3 +102,24 @@ def test_noisy_image_uses_global_used_tail(ctx):
     rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=1)
     assert n[0] == len(rk)
     np.testing.assert_array_equal(desc[0, :n[0]], rd)
+
+
+def test_many_segments_sort_in_global_scratch(ctx):
+    """> 1024 raw segments: the response sort leaves LDS; many equal-length edges exercise std::sort's tie order."""
+    from planarslam_amd.lines import LineSegment
+    rng = np.random.default_rng(23)
+    img = np.full((480, 640), 60, np.uint8)
+    for gy in range(0, 480, 24):
+        for gx in range(0, 640, 24):
+            if rng.random() < 0.9:
+                w, h = rng.integers(12, 20, 2)
+                img[gy + 2:gy + 2 + h, gx + 2:gx + 2 + w] = rng.integers(120, 255)
+    ls = LineSegment(640, 480, 1, ctx)
+    kl, desc, eq, n = ls.ExtractLineSegment(img)
+    segs = ls.read_stage(0, 3)
+    assert len(segs) > 1024
+    rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=1)
+    assert nd == len(segs) and n[0] == 40
+    for f in rk.dtype.names:
+        np.testing.assert_array_equal(kl[0][f], rk[f], err_msg=f)
+    np.testing.assert_array_equal(desc[0], rd)
