@@ -286,7 +286,7 @@ int lsd_search_by_projection(int n_lines, const planar_keyline* kl, const uint8_
     for (int j = 0; j < n_ml; j++) {
         if (!ml_in_view[j]) continue;
         const int nPredictLevel = ml_level[j];
-        float r = ml_view_cos[j] > 0.998 ? 2.5f : 4.0f;   // LSDmatcher::RadiusByViewingCos
+        float r = ml_view_cos[j] > 0.998 ? 5.0f : 8.0f;   // LSDmatcher::RadiusByViewingCos (src/LSDmatcher.cpp:369-375: 5 / 8, not ORBmatcher's 2.5 / 4)
         if (bFactor) r *= th;
         // Frame::GetLinesInArea(x1,y1,x2,y2, r*scale, level-1, level)   src/Frame.cc:491-524
         const float x1 = ml_proj[4 * j], y1 = ml_proj[4 * j + 1], x2 = ml_proj[4 * j + 2], y2 = ml_proj[4 * j + 3];

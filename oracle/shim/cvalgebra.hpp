@@ -1,0 +1,156 @@
+// oracle/shim/cvalgebra.hpp — TEST INFRASTRUCTURE.  The slice of cv::Mat matrix algebra the reference's matchers use
+// (src/ORBmatcher.cc, src/PlaneMatcher.cpp), so that those translation units compile and run unmodified in oracle/_ref.
+// Restated from OpenCV 3.4 (core/src/matmul.cpp, matop.cpp) by reading — UNPINNED against the library:
+//   * A*B [+ C] is one lazy cv::gemm.  For CV_32F with no transpose flag and inner length 2..4 equal to the output's width or
+//     height it takes the small-matrix path: products summed in float, left to right, then (float)(t*alpha + c*beta) in
+//     double.  Otherwise (e.g. -A.t()*B) GEMMSingleMul<float,double>: products accumulated in double, (float)(s*alpha + c*beta).
+//   * alpha*A, A/s, -A, A.t(): elementwise (float)(a*alpha) with alpha in double.
+//   * A+B, A-B: float.   norm(), dot(): double accumulation.
+//   * BFMatcher(NORM_HAMMING).match: smallest distance, lowest train index on ties.
+#pragma once
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <vector>
+
+namespace cv {
+
+struct MatExpr {
+    Mat a, b, c;
+    bool tr = false, has_b = false, has_c = false;
+    double alpha = 1, beta = 1;
+    Mat eval() const {
+        const int ar = tr ? a.cols : a.rows, ac = tr ? a.rows : a.cols;
+        auto A = [&](int i, int k) -> float { return tr ? a.at<float>(k, i) : a.at<float>(i, k); };
+        if (!has_b) {
+            Mat d(ar, ac, CV_32F);
+            for (int i = 0; i < ar; i++)
+                for (int j = 0; j < ac; j++) d.at<float>(i, j) = (float)((double)A(i, j) * alpha + (has_c ? (double)c.at<float>(i, j) * beta : 0.0));
+            return d;
+        }
+        assert(ac == b.rows);
+        const int len = ac, dw = b.cols, dh = ar;
+        Mat d(dh, dw, CV_32F);
+        const bool small = !tr && len >= 2 && len <= 4 && (len == dw || len == dh);
+        for (int i = 0; i < dh; i++)
+            for (int j = 0; j < dw; j++) {
+                const double cv_ = has_c ? (double)c.at<float>(i, j) * beta : 0.0;
+                if (small) {
+                    float t = A(i, 0) * b.at<float>(0, j);
+                    for (int k = 1; k < len; k++) t = t + A(i, k) * b.at<float>(k, j);
+                    d.at<float>(i, j) = (float)((double)t * alpha + cv_);
+                } else {
+                    double s = 0;
+                    for (int k = 0; k < len; k++) s += (double)A(i, k) * (double)b.at<float>(k, j);
+                    d.at<float>(i, j) = (float)(s * alpha + cv_);
+                }
+            }
+        return d;
+    }
+    operator Mat() const { return eval(); }
+    template <typename T> T at(int i) const { return eval().at<T>(i); }
+    template <typename T> T at(int y, int x) const { return eval().at<T>(y, x); }
+    MatExpr t() const { assert(!has_b && !has_c); MatExpr e = *this; e.tr = !e.tr; return e; }
+    double dot(const Mat& m) const { return eval().dot(m); }
+};
+
+inline MatExpr Mat::t() const { MatExpr e; e.a = *this; e.tr = true; return e; }
+inline Mat::Mat(const MatExpr& e) { *this = e.eval(); }
+inline Mat& Mat::operator=(const MatExpr& e) { return *this = e.eval(); }
+inline double Mat::dot(const Mat& m) const {
+    double s = 0;
+    for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) s += (double)at<float>(y, x) * (double)m.at<float>(y, x);
+    return s;
+}
+
+static inline MatExpr operator*(const Mat& a, const Mat& b) { MatExpr e; e.a = a; e.b = b; e.has_b = true; return e; }
+static inline MatExpr operator*(const MatExpr& x, const Mat& b) {
+    if (x.has_b || x.has_c) return x.eval() * b;
+    MatExpr e = x; e.b = b; e.has_b = true; return e;
+}
+static inline MatExpr operator*(const Mat& a, const MatExpr& y) { return a * y.eval(); }
+static inline MatExpr operator*(double s, const Mat& a) { MatExpr e; e.a = a; e.alpha = s; return e; }
+static inline MatExpr operator*(const Mat& a, double s) { return s * a; }
+static inline MatExpr operator*(double s, const MatExpr& x) { if (x.has_c) return s * x.eval(); MatExpr e = x; e.alpha *= s; return e; }
+static inline MatExpr operator/(const Mat& a, double s) { return (1.0 / s) * a; }
+static inline MatExpr operator-(const Mat& a) { return -1.0 * a; }
+static inline MatExpr operator-(const MatExpr& x) { return -1.0 * x; }
+static inline MatExpr operator+(const MatExpr& x, const Mat& c) {
+    if (x.has_c) { MatExpr e; e.a = x.eval(); e.c = c; e.has_c = true; return e; }
+    MatExpr e = x; e.c = c; e.has_c = true; e.beta = 1; return e;
+}
+static inline MatExpr operator-(const MatExpr& x, const Mat& c) {
+    if (x.has_c) { MatExpr e; e.a = x.eval(); e.c = c; e.has_c = true; e.beta = -1; return e; }
+    MatExpr e = x; e.c = c; e.has_c = true; e.beta = -1; return e;
+}
+static inline Mat operator+(const Mat& a, const Mat& b) {
+    Mat d(a.rows, a.cols, CV_32F);
+    for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) d.at<float>(y, x) = a.at<float>(y, x) + b.at<float>(y, x);
+    return d;
+}
+static inline Mat operator-(const Mat& a, const Mat& b) {
+    Mat d(a.rows, a.cols, CV_32F);
+    for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) d.at<float>(y, x) = a.at<float>(y, x) - b.at<float>(y, x);
+    return d;
+}
+static inline double norm(const Mat& m) {
+    double s = 0;
+    for (int y = 0; y < m.rows; y++) for (int x = 0; x < m.cols; x++) s += (double)m.at<float>(y, x) * (double)m.at<float>(y, x);
+    return std::sqrt(s);
+}
+static inline double norm(const MatExpr& e) { return norm(e.eval()); }
+static inline void transpose(const Mat& src, Mat& dst) {
+    Mat d(src.cols, src.rows, CV_32F);
+    for (int y = 0; y < src.rows; y++) for (int x = 0; x < src.cols; x++) d.at<float>(x, y) = src.at<float>(y, x);
+    dst = d;
+}
+
+// (Mat_<float>(r, c) << a, b, ...) as used by the reference
+template <typename T> struct MatCommaInit {
+    Mat m; int i = 0;
+    template <typename U> MatCommaInit& operator,(U v) { ((T*)m.data)[i++] = (T)v; return *this; }
+    operator Mat() const { return m; }
+};
+template <typename T> struct Mat_ : public Mat {
+    Mat_(int r, int c) : Mat(r, c, sizeof(T) == 4 ? CV_32F : CV_64F) {}
+    template <typename U> MatCommaInit<T> operator<<(U v) { MatCommaInit<T> ci; ci.m = *this; ((T*)ci.m.data)[ci.i++] = (T)v; return ci; }
+};
+
+struct DMatch { int queryIdx = -1, trainIdx = -1, imgIdx = -1; float distance = 0; };
+enum { NORM_HAMMING = 6 };
+class BFMatcher {
+public:
+    explicit BFMatcher(int normType = NORM_HAMMING, bool crossCheck = false) { assert(normType == NORM_HAMMING && !crossCheck); }
+    void match(const Mat& q, const Mat& t, std::vector<DMatch>& out) const {
+        out.clear();
+        if (t.rows == 0) return;
+        for (int i = 0; i < q.rows; i++) {
+            int best = -1, bd = 1 << 30;
+            for (int j = 0; j < t.rows; j++) {
+                int d = 0;
+                for (int k = 0; k < 32; k++) d += __builtin_popcount(q.ptr(i)[k] ^ t.ptr(j)[k]);
+                if (d < bd) { bd = d; best = j; }
+            }
+            DMatch m; m.queryIdx = i; m.trainIdx = best; m.imgIdx = 0; m.distance = (float)bd;
+            out.push_back(m);
+        }
+    }
+    // knnMatch: per query the k smallest distances, ascending, lowest train index first on ties
+    void knnMatch(const Mat& q, const Mat& t, std::vector<std::vector<DMatch>>& out, int k) const {
+        out.clear();
+        for (int i = 0; i < q.rows; i++) {
+            std::vector<DMatch> all;
+            for (int j = 0; j < t.rows; j++) {
+                int d = 0;
+                for (int kk = 0; kk < 32; kk++) d += __builtin_popcount(q.ptr(i)[kk] ^ t.ptr(j)[kk]);
+                DMatch m; m.queryIdx = i; m.trainIdx = j; m.imgIdx = 0; m.distance = (float)d;
+                all.push_back(m);
+            }
+            std::stable_sort(all.begin(), all.end(), [](const DMatch& a, const DMatch& b) { return a.distance < b.distance; });
+            if ((int)all.size() > k) all.resize(k);
+            out.push_back(all);
+        }
+    }
+};
+
+}  // namespace cv

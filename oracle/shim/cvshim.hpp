@@ -98,6 +98,7 @@ struct MatStep {
     operator size_t() const { return v; }
 };
 
+struct MatExpr;   // cvalgebra.hpp (only the matcher harness uses matrix algebra)
 class Mat {
 public:
     int rows = 0, cols = 0;
@@ -139,6 +140,11 @@ public:
     Mat rowRange(int a, int b) const { return (*this)(Rect(0, a, cols, b - a)); }
     Mat colRange(int a, int b) const { return (*this)(Rect(a, 0, b - a, rows)); }
     Mat row(int y) const { return rowRange(y, y + 1); }
+    Mat col(int x) const { return colRange(x, x + 1); }
+    inline MatExpr t() const;                 // cvalgebra.hpp
+    inline double dot(const Mat& m) const;    // cvalgebra.hpp
+    inline Mat(const MatExpr& e);             // cvalgebra.hpp
+    inline Mat& operator=(const MatExpr& e);  // cvalgebra.hpp
     Mat clone() const {
         Mat m(rows, cols, type_);
         for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step.v, data + (size_t)y * step.v, (size_t)cols * cvElemSize(type_));
@@ -269,3 +275,6 @@ static inline void GaussianBlur(InputArray src, OutputArray dst, Size ksize, dou
 }
 
 }  // namespace cv
+#ifdef CVSHIM_ALGEBRA
+#include "cvalgebra.hpp"
+#endif

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(64) void lsd_projection_kernel(LineArgs a) {
     for (int j = 0; j < NM; j++) {
         if (!a.ml_in_view[mo + j]) continue;
         const int lvl = a.ml_level[mo + j];
-        float r = (double)a.ml_view_cos[mo + j] > 0.998 ? 2.5f : 4.0f;
+        float r = (double)a.ml_view_cos[mo + j] > 0.998 ? 5.0f : 8.0f;   // LSDmatcher::RadiusByViewingCos, src/LSDmatcher.cpp:369-375
         if (bFactor) r *= a.th;
         const float* pr = a.ml_proj + (mo + j) * 4;
         const float x1 = pr[0], y1 = pr[1], x2 = pr[2], y2 = pr[3];

@@ -378,3 +378,97 @@ def std_sort_desc(keys):
     k = np.ascontiguousarray(keys, np.float32).copy(); perm = np.zeros(len(k), np.int32)
     L.orc_std_sort_desc(C.c_void_p(k.ctypes.data), C.c_void_p(perm.ctypes.data), len(k))
     return k, perm
+
+
+# ---- the REAL reference matchers (oracle/_ref/ref_match: src/ORBmatcher.cc, src/PlaneMatcher.cpp) ----
+def ref_match_path():
+    return os.path.join(ORACLE_DIR, "_ref", "ref_match")
+
+
+def _run_ref_match(mode, blocks, n_out):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            for a in blocks:
+                a = np.ascontiguousarray(a)
+                f.write(np.int64(a.nbytes).tobytes()); f.write(a.tobytes())
+        subprocess.check_call([ref_match_path(), mode, fin, fout])
+        buf = open(fout, "rb").read()
+    outs, off = [], 0
+    for _ in range(n_out):
+        n = int(np.frombuffer(buf, "<i8", 1, off)[0]); off += 8
+        outs.append(np.frombuffer(buf, "<i4", n // 4, off).copy()); off += n
+    return outs
+
+
+def _frame_blocks(fr, b):
+    n = int(fr["n"][b])
+    f32 = np.float32
+    gw = f32(64) / f32(f32(fr["max_x"]) - f32(fr["min_x"])); gh = f32(48) / f32(f32(fr["max_y"]) - f32(fr["min_y"]))
+    intr = np.array([fr["min_x"], fr["max_x"], fr["min_y"], fr["max_y"], gw, gh, fr["fx"], fr["fy"], fr["cx"], fr["cy"], fr["bf"], fr["b"]], np.float32)
+    blocked = fr["blocked"][b, :n] if fr.get("blocked") is not None else np.zeros(n, np.uint8)
+    return [fr["keys_un"][b, :n], fr["u_right"][b, :n].astype(np.float32), fr["desc"][b, :n], blocked.astype(np.uint8), intr,
+            np.asarray(fr["scale_factors"], np.float32)]
+
+
+def ref_search_by_projection_frame(cur, last, b, th, mono=False, check_orientation=True):
+    """One frame pair through the real ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono). Returns (match[n], nmatches)."""
+    nl = int(last["n"][b])
+    blocks = [np.array([th, float(mono), float(check_orientation)], np.float32)] + _frame_blocks(cur, b) + [
+        np.asarray(cur["Tcw"][b], np.float32), np.asarray(last["Tcw"][b], np.float32), last["usable"][b, :nl].astype(np.uint8), last["xw"][b, :nl].astype(np.float32),
+        last["octave"][b, :nl].astype(np.int32), last["angle"][b, :nl].astype(np.float32), last["mp_desc"][b, :nl], last["mp_observed"][b, :nl].astype(np.uint8)]
+    m, nm = _run_ref_match("proj_frame", blocks, 2)
+    return m, int(nm[0])
+
+
+def ref_search_by_projection_map(frame, probes, b, th, nn_ratio):
+    npb = int(probes["n"][b])
+    blocks = [np.array([th, nn_ratio], np.float32)] + _frame_blocks(frame, b) + [
+        probes["in_view"][b, :npb].astype(np.uint8), probes["proj_x"][b, :npb].astype(np.float32), probes["proj_y"][b, :npb].astype(np.float32),
+        probes["proj_xr"][b, :npb].astype(np.float32), probes["level"][b, :npb].astype(np.int32), probes["view_cos"][b, :npb].astype(np.float32),
+        probes["desc"][b, :npb], probes["observed"][b, :npb].astype(np.uint8)]
+    m, nm = _run_ref_match("proj_map", blocks, 2)
+    return m, int(nm[0])
+
+
+def ref_search_by_bow(kf, f, b, nn_ratio, check_orientation=True):
+    nk, nf = int(kf["n"][b]), int(f["n"][b])
+    blocks = [np.array([nn_ratio, float(check_orientation)], np.float32), kf["node"][b, :nk].astype(np.int32), kf["usable"][b, :nk].astype(np.uint8),
+              kf["angle"][b, :nk].astype(np.float32), kf["desc"][b, :nk], f["node"][b, :nf].astype(np.int32), f["angle"][b, :nf].astype(np.float32), f["desc"][b, :nf]]
+    m, nm = _run_ref_match("bow", blocks, 2)
+    return m, int(nm[0])
+
+
+def ref_match_orb_points(cur_desc, last_desc, last_has_mp, last_outlier):
+    blocks = [np.zeros(1, np.float32), np.ascontiguousarray(cur_desc, np.uint8), np.ascontiguousarray(last_desc, np.uint8),
+              np.asarray(last_has_mp, np.uint8), np.asarray(last_outlier, np.uint8)]
+    m, nm = _run_ref_match("match_orb", blocks, 2)
+    return m, int(nm[0])
+
+
+def ref_plane_search(frame, mapplanes, b, th=(0.1, 0.86, 0.08716, 0.9962)):
+    m = 0 if mapplanes.get("shared") else b
+    npl, nmp = int(frame["n"][b]), int(mapplanes["n"][m])
+    blocks = [np.asarray(th, np.float32), frame["coef"][b, :npl].astype(np.float32), np.asarray(frame["Tcw"][b], np.float32),
+              mapplanes["valid"][m, :nmp].astype(np.uint8), mapplanes["coef"][m, :nmp].astype(np.float32), mapplanes["npts"][m, :nmp].astype(np.int32),
+              mapplanes["pts"][m, :nmp].astype(np.float32)]
+    a, v, p, nm = _run_ref_match("plane", blocks, 4)
+    return a, v, p, int(nm[0])
+
+
+def ref_lsd_search_by_projection(lines, maplines, b, scale_factors, th, nn_ratio):
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    nl, nm = int(lines["n"][b]), int(maplines["n"][b])
+    blocked = lines["blocked"][b, :nl] if lines.get("blocked") is not None else np.zeros(nl, np.uint8)
+    blocks = [np.array([th, nn_ratio], np.float32), np.ascontiguousarray(lines["keylines"][b, :nl], KEYLINE_DTYPE), lines["ldesc"][b, :nl],
+              blocked.astype(np.uint8), maplines["in_view"][b, :nm].astype(np.uint8), maplines["proj"][b, :nm].astype(np.float32),
+              maplines["level"][b, :nm].astype(np.int32), maplines["view_cos"][b, :nm].astype(np.float32), maplines["desc"][b, :nm],
+              maplines["observed"][b, :nm].astype(np.uint8), np.asarray(scale_factors, np.float32)]
+    m, n = _run_ref_match("lsd_proj", blocks, 2)
+    return m, int(n[0])
+
+
+def ref_lsd_search_by_descriptor(kf_desc, cur_desc, kf_has_ml):
+    blocks = [np.zeros(1, np.float32), np.ascontiguousarray(kf_desc, np.uint8), np.ascontiguousarray(cur_desc, np.uint8), np.asarray(kf_has_ml, np.uint8)]
+    m, n = _run_ref_match("lsd_desc", blocks, 2)
+    return m, int(n[0])

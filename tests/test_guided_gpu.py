@@ -108,3 +108,28 @@ def test_plane_search_by_coefficients(ctx, shared):
     got = PlaneMatcher(ctx=ctx).SearchMapByCoefficients(fr, mp, init=init)
     for a, b in zip(got, ref):
         np.testing.assert_array_equal(a, b)
+
+
+def test_against_real_reference_fixtures(ctx):
+    """tests/golden/guided_ref.npz holds outputs of the REAL reference matchers (oracle/_ref/ref_match, tools/gen_golden_guided.py)."""
+    import os
+    from planarslam_amd.guided import ORBmatcher, PlaneMatcher
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_ref.npz"))
+    seed = int(g["seed"])
+    fr = synth.guided_frame(B=2, N=800, seed=seed)
+    cur, last = synth.guided_last_frame(fr, seed=seed + 1, dup=0.3)
+    m, n = ORBmatcher(0.9, True, ctx).SearchByProjectionFrame(cur, last, 15.0)
+    np.testing.assert_array_equal(m, g["proj_frame_match"]); np.testing.assert_array_equal(n, g["proj_frame_n"])
+    fr2, pr = synth.guided_map_probes(fr, seed=seed + 2, n_probes=2000)
+    m, n = ORBmatcher(0.8, True, ctx).SearchByProjectionMap(fr2, pr, th=3.0)
+    np.testing.assert_array_equal(m, g["proj_map_match"]); np.testing.assert_array_equal(n, g["proj_map_n"])
+    kf, f = synth.guided_bow(B=2, N=800, seed=seed + 3)
+    m, n = ORBmatcher(0.7, True, ctx).SearchByBoW(kf, f)
+    np.testing.assert_array_equal(m, g["bow_match"]); np.testing.assert_array_equal(n, g["bow_n"])
+    frp, mp = synth.guided_planes(B=4, seed=seed + 4)
+    a, v, p, n = PlaneMatcher(ctx=ctx).SearchMapByCoefficients(frp, mp)
+    np.testing.assert_array_equal(np.stack([a, v, p]), g["plane_avp"]); np.testing.assert_array_equal(n, g["plane_n"])
+    from planarslam_amd.guided import LSDmatcher
+    lines, ml = synth.guided_lines(B=3, n_lines=150, n_ml=400, seed=seed + 5)
+    m, n = LSDmatcher(0.6, ctx).SearchByProjection(lines, ml, synth.scale_factors(), th=3.0)
+    np.testing.assert_array_equal(m, g["lsd_proj_match"]); np.testing.assert_array_equal(n, g["lsd_proj_n"])
