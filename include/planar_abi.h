@@ -276,6 +276,31 @@ int planar_search_by_bow_dev(planar_ctx* ctx, int B, const int32_t* d_n_kf, int 
                              int f_stride, const int32_t* d_f_node, const float* d_f_angle, const uint8_t* d_f_desc, float nn_ratio,
                              int check_orientation, int32_t* d_match, int32_t* d_nmatches);
 
+/* Frame::isInFrustum(MapPoint*, viewingCosLimit) (src/Frame.cc:312-367) for every local map point of B frames: fills the tracking
+ * fields SearchByProjection(F, vpMapPoints, th) reads (the non-const twins of planar_map_probes' arrays).
+ *   frame: Tcw, fx fy cx cy bf, min/max bounds are read (mRcw, mtcw, mOw are derived as Frame::UpdatePoseMatrices does, :301-306)
+ *   log_scale_factor = Frame::mfLogScaleFactor, n_levels = mnScaleLevels (MapPoint::PredictScale, src/MapPoint.cc:419-434)
+ *   valid[j] = vpMapPoints[j] usable; xw = GetWorldPos(), normal = GetNormal(), min_dist / max_dist = mfMinDistance / mfMaxDistance
+ *   (GetMin/MaxDistanceInvariance apply the 0.8 / 1.2 factors, src/MapPoint.cc:390-400) */
+int planar_is_in_frustum_points(planar_ctx* ctx, const planar_frame_view* frame, float log_scale_factor, int n_levels, const int32_t* n, int stride,
+                                const uint8_t* valid, const float* xw, const float* normal, const float* min_dist, const float* max_dist,
+                                float viewing_cos_limit, uint8_t* in_view, float* proj_x, float* proj_y, float* proj_xr, int32_t* level,
+                                float* view_cos);
+int planar_is_in_frustum_points_dev(planar_ctx* ctx, const planar_frame_view* d_frame, float log_scale_factor, int n_levels, const int32_t* d_n,
+                                    int stride, const uint8_t* d_valid, const float* d_xw, const float* d_normal, const float* d_min_dist,
+                                    const float* d_max_dist, float viewing_cos_limit, uint8_t* d_in_view, float* d_proj_x, float* d_proj_y,
+                                    float* d_proj_xr, int32_t* d_level, float* d_view_cos);
+/* Frame::isInFrustum(MapLine*, viewingCosLimit) (src/Frame.cc:369-438): xw6 = MapLine::GetWorldPos() (Vector6d: start xyz, end xyz),
+ * normal = GetNormal() (Vector3d), level = MapLine::PredictScale (src/MapLine.cpp:381-390, NOT clamped to the pyramid, as in the reference);
+ * proj[j] = {mTrackProjX1, Y1, X2, Y2}. */
+int planar_is_in_frustum_lines(planar_ctx* ctx, const planar_frame_view* frame, float log_scale_factor, const int32_t* n, int stride,
+                               const uint8_t* valid, const double* xw6, const double* normal, const float* min_dist, const float* max_dist,
+                               float viewing_cos_limit, uint8_t* in_view, float* proj, int32_t* level, float* view_cos);
+int planar_is_in_frustum_lines_dev(planar_ctx* ctx, const planar_frame_view* d_frame, float log_scale_factor, const int32_t* d_n, int stride,
+                                   const uint8_t* d_valid, const double* d_xw6, const double* d_normal, const float* d_min_dist,
+                                   const float* d_max_dist, float viewing_cos_limit, uint8_t* d_in_view, float* d_proj, int32_t* d_level,
+                                   float* d_view_cos);
+
 /* cv::line_descriptor::KeyLine (opencv_contrib line_descriptor/descriptor.hpp), same field order, 68 bytes. */
 typedef struct planar_keyline {
     float angle;

@@ -286,6 +286,7 @@ int lsd_search_by_projection(int n_lines, const planar_keyline* kl, const uint8_
     for (int j = 0; j < n_ml; j++) {
         if (!ml_in_view[j]) continue;
         const int nPredictLevel = ml_level[j];
+        if (nPredictLevel < 0 || nPredictLevel >= PLANAR_MAX_LEVELS) continue;   // mvScaleFactors[level] out of bounds = UB in the reference; defined as "skip"
         float r = ml_view_cos[j] > 0.998 ? 5.0f : 8.0f;   // LSDmatcher::RadiusByViewingCos (src/LSDmatcher.cpp:369-375: 5 / 8, not ORBmatcher's 2.5 / 4)
         if (bFactor) r *= th;
         // Frame::GetLinesInArea(x1,y1,x2,y2, r*scale, level-1, level)   src/Frame.cc:491-524
@@ -360,9 +361,107 @@ int plane_search_by_coefficients(int n_planes, const float* pl_coef, const float
     return nmatches;
 }
 
+// ---- Frame::isInFrustum (src/Frame.cc:312-367 points, :369-438 lines); UNPINNED (Frame.cc cannot be built here) ----
+struct FrustumPose { float Rcw[9], tcw[3], Ow[3]; };
+static FrustumPose frustum_pose(const float* T) {
+    FrustumPose p;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) p.Rcw[3 * r + c] = T[4 * r + c]; p.tcw[r] = T[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) {   // mOw = -mRcw.t()*mtcw : general gemm path, double accumulation
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)p.Rcw[3 * k + i] * (double)p.tcw[k];
+        p.Ow[i] = (float)(s * -1.0);
+    }
+    return p;
+}
+static inline float norm3(const float* v) { return (float)std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); }   // cv::norm: double accumulation
+static inline double dot3(const float* a, const float* b) { return (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]; }
+static inline float logf_cr(float x) { return (float)std::log((double)x); }
+
+void is_in_frustum_points(const planar_frame_view& F, int b, float log_scale_factor, int n_levels, int n, const uint8_t* valid, const float* xw,
+                          const float* normal, const float* min_dist, const float* max_dist, float limit, uint8_t* in_view, float* proj_x,
+                          float* proj_y, float* proj_xr, int32_t* level, float* view_cos) {
+    const FrustumPose P = frustum_pose(F.Tcw + (size_t)b * 16);
+    for (int j = 0; j < n; j++) {
+        in_view[j] = 0;
+        if (!valid[j]) continue;
+        const float* X = xw + 3 * j;
+        const float PcX = gemm3_row(P.Rcw, X, P.tcw[0]), PcY = gemm3_row(P.Rcw + 3, X, P.tcw[1]), PcZ = gemm3_row(P.Rcw + 6, X, P.tcw[2]);
+        if (PcZ < 0.0f) continue;
+        const float invz = 1.0f / PcZ;
+        const float u = F.fx * PcX * invz + F.cx, v = F.fy * PcY * invz + F.cy;
+        if (u < F.min_x || u > F.max_x) continue;
+        if (v < F.min_y || v > F.max_y) continue;
+        const float maxDistance = 1.2f * max_dist[j], minDistance = 0.8f * min_dist[j];
+        const float PO[3] = {X[0] - P.Ow[0], X[1] - P.Ow[1], X[2] - P.Ow[2]};
+        const float dist = norm3(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float viewCos = (float)(dot3(PO, normal + 3 * j) / dist);
+        if (viewCos < limit) continue;
+        const float ratio = max_dist[j] / dist;                      // MapPoint::PredictScale
+        int nScale = (int)std::ceil(logf_cr(ratio) / log_scale_factor);
+        if (nScale < 0) nScale = 0; else if (nScale >= n_levels) nScale = n_levels - 1;
+        in_view[j] = 1; proj_x[j] = u; proj_xr[j] = u - F.bf * invz; proj_y[j] = v; level[j] = nScale; view_cos[j] = viewCos;
+    }
+}
+
+void is_in_frustum_lines(const planar_frame_view& F, int b, float log_scale_factor, int n, const uint8_t* valid, const double* xw6, const double* normal,
+                         const float* min_dist, const float* max_dist, float limit, uint8_t* in_view, float* proj, int32_t* level, float* view_cos) {
+    const FrustumPose P = frustum_pose(F.Tcw + (size_t)b * 16);
+    for (int j = 0; j < n; j++) {
+        in_view[j] = 0;
+        if (!valid[j]) continue;
+        float SP[3], EP[3];
+        for (int k = 0; k < 3; k++) { SP[k] = (float)xw6[6 * j + k]; EP[k] = (float)xw6[6 * j + 3 + k]; }
+        const float SPcX = gemm3_row(P.Rcw, SP, P.tcw[0]), SPcY = gemm3_row(P.Rcw + 3, SP, P.tcw[1]), SPcZ = gemm3_row(P.Rcw + 6, SP, P.tcw[2]);
+        const float EPcX = gemm3_row(P.Rcw, EP, P.tcw[0]), EPcY = gemm3_row(P.Rcw + 3, EP, P.tcw[1]), EPcZ = gemm3_row(P.Rcw + 6, EP, P.tcw[2]);
+        if (SPcZ < 0.0f || EPcZ < 0.0f) continue;
+        const float invz1 = 1.0f / SPcZ;
+        const float u1 = F.fx * SPcX * invz1 + F.cx, v1 = F.fy * SPcY * invz1 + F.cy;
+        if (u1 < F.min_x || u1 > F.max_x) continue;
+        if (v1 < F.min_y || v1 > F.max_y) continue;
+        const float invz2 = 1.0f / EPcZ;
+        const float u2 = F.fx * EPcX * invz2 + F.cx, v2 = F.fy * EPcY * invz2 + F.cy;
+        if (u2 < F.min_x || u2 > F.max_x) continue;
+        if (v2 < F.min_y || v2 > F.max_y) continue;
+        const float maxDistance = 1.2f * max_dist[j], minDistance = 0.8f * min_dist[j];
+        float OM[3];   // 0.5 * (SP + EP) - mOw : float sum, (float)(x * 0.5) in double, float difference
+        for (int k = 0; k < 3; k++) OM[k] = (float)((double)(SP[k] + EP[k]) * 0.5) - P.Ow[k];
+        const float dist = norm3(OM);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float pn[3] = {(float)normal[3 * j], (float)normal[3 * j + 1], (float)normal[3 * j + 2]};
+        const float viewCos = (float)(dot3(OM, pn) / dist);
+        if (viewCos < limit) continue;
+        const float ratio = max_dist[j] / dist;                      // MapLine::PredictScale: no clamping
+        in_view[j] = 1;
+        proj[4 * j] = u1; proj[4 * j + 1] = v1; proj[4 * j + 2] = u2; proj[4 * j + 3] = v2;
+        level[j] = (int)std::ceil(logf_cr(ratio) / log_scale_factor);
+        view_cos[j] = viewCos;
+    }
+}
+
 }  // namespace orc
 
 extern "C" {
+int orc_is_in_frustum_points(const planar_frame_view* F, float lsf, int n_levels, const int32_t* n, int stride, const uint8_t* valid, const float* xw,
+                             const float* normal, const float* min_dist, const float* max_dist, float limit, uint8_t* in_view, float* px, float* py,
+                             float* pxr, int32_t* level, float* vc) {
+    for (int b = 0; b < F->B; b++) {
+        const size_t o = (size_t)b * stride;
+        orc::is_in_frustum_points(*F, b, lsf, n_levels, n[b], valid + o, xw + o * 3, normal + o * 3, min_dist + o, max_dist + o, limit, in_view + o, px + o,
+                                  py + o, pxr + o, level + o, vc + o);
+    }
+    return 0;
+}
+int orc_is_in_frustum_lines(const planar_frame_view* F, float lsf, const int32_t* n, int stride, const uint8_t* valid, const double* xw6,
+                            const double* normal, const float* min_dist, const float* max_dist, float limit, uint8_t* in_view, float* proj,
+                            int32_t* level, float* vc) {
+    for (int b = 0; b < F->B; b++) {
+        const size_t o = (size_t)b * stride;
+        orc::is_in_frustum_lines(*F, b, lsf, n[b], valid + o, xw6 + o * 6, normal + o * 3, min_dist + o, max_dist + o, limit, in_view + o, proj + o * 4,
+                                 level + o, vc + o);
+    }
+    return 0;
+}
 int orc_search_by_projection_frame(const planar_frame_view* cur, const planar_last_frame_view* last, float th, int mono,
                                    int check_orientation, int32_t* cur_match, int32_t* nmatches) {
     for (int b = 0; b < cur->B; b++)

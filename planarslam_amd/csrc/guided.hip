@@ -560,6 +560,7 @@ __global__ __launch_bounds__(64) void lsd_projection_kernel(LineArgs a) {
     for (int j = 0; j < NM; j++) {
         if (!a.ml_in_view[mo + j]) continue;
         const int lvl = a.ml_level[mo + j];
+        if (lvl < 0 || lvl >= PLANAR_MAX_LEVELS) continue;   // F.mvScaleFactors[lvl] would be out of bounds in the reference (UB): skipped here
         float r = (double)a.ml_view_cos[mo + j] > 0.998 ? 5.0f : 8.0f;   // LSDmatcher::RadiusByViewingCos, src/LSDmatcher.cpp:369-375
         if (bFactor) r *= a.th;
         const float* pr = a.ml_proj + (mo + j) * 4;
@@ -659,6 +660,95 @@ __global__ __launch_bounds__(64) void plane_match_kernel(const int32_t* n_planes
         if (ip >= 0) par[po] = ip;
         if (found) atomicAdd(&nmatches[b], 1);
     }
+}
+
+// ---- Frame::isInFrustum for points (src/Frame.cc:312-367) and lines (:369-438): one thread per map point / map line ------------
+struct FrustumPose { float Rcw[9], tcw[3], Ow[3]; };
+__device__ inline FrustumPose frustum_pose(const float* T) {
+    FrustumPose p;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) p.Rcw[3 * r + c] = T[4 * r + c]; p.tcw[r] = T[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) {   // Frame::UpdatePoseMatrices: mOw = -mRcw.t()*mtcw (general gemm path, double accumulation)
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)p.Rcw[3 * k + i] * (double)p.tcw[k];
+        p.Ow[i] = (float)(s * -1.0);
+    }
+    return p;
+}
+__device__ inline float norm3(const float* v) { return (float)sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); }
+__device__ inline double dot3(const float* a, const float* b) { return (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]; }
+
+__global__ __launch_bounds__(256) void frustum_points_kernel(planar_frame_view F, float lsf, int n_levels, const int32_t* __restrict__ n, int stride,
+                                                             const uint8_t* __restrict__ valid, const float* __restrict__ xw,
+                                                             const float* __restrict__ normal, const float* __restrict__ min_dist,
+                                                             const float* __restrict__ max_dist, float limit, uint8_t* __restrict__ in_view,
+                                                             float* __restrict__ proj_x, float* __restrict__ proj_y, float* __restrict__ proj_xr,
+                                                             int32_t* __restrict__ level, float* __restrict__ view_cos) {
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n[b]) return;
+    const size_t o = (size_t)b * stride + j;
+    in_view[o] = 0;
+    if (!valid[o]) return;
+    const FrustumPose P = frustum_pose(F.Tcw + (size_t)b * 16);
+    const float X[3] = {xw[3 * o], xw[3 * o + 1], xw[3 * o + 2]};
+    const float PcX = gemm3_row(P.Rcw[0], P.Rcw[1], P.Rcw[2], X, P.tcw[0]), PcY = gemm3_row(P.Rcw[3], P.Rcw[4], P.Rcw[5], X, P.tcw[1]);
+    const float PcZ = gemm3_row(P.Rcw[6], P.Rcw[7], P.Rcw[8], X, P.tcw[2]);
+    if (PcZ < 0.0f) return;
+    const float invz = 1.0f / PcZ;
+    const float u = F.fx * PcX * invz + F.cx, v = F.fy * PcY * invz + F.cy;
+    if (u < F.min_x || u > F.max_x) return;
+    if (v < F.min_y || v > F.max_y) return;
+    const float maxDistance = 1.2f * max_dist[o], minDistance = 0.8f * min_dist[o];
+    const float PO[3] = {X[0] - P.Ow[0], X[1] - P.Ow[1], X[2] - P.Ow[2]};
+    const float dist = norm3(PO);
+    if (dist < minDistance || dist > maxDistance) return;
+    const float Pn[3] = {normal[3 * o], normal[3 * o + 1], normal[3 * o + 2]};
+    const float viewCos = (float)(dot3(PO, Pn) / (double)dist);
+    if (viewCos < limit) return;
+    const float ratio = max_dist[o] / dist;   // MapPoint::PredictScale (src/MapPoint.cc:419-434)
+    int nScale = (int)ceilf((float)log((double)ratio) / lsf);
+    if (nScale < 0) nScale = 0; else if (nScale >= n_levels) nScale = n_levels - 1;
+    in_view[o] = 1; proj_x[o] = u; proj_xr[o] = u - F.bf * invz; proj_y[o] = v; level[o] = nScale; view_cos[o] = viewCos;
+}
+
+__global__ __launch_bounds__(256) void frustum_lines_kernel(planar_frame_view F, float lsf, const int32_t* __restrict__ n, int stride,
+                                                            const uint8_t* __restrict__ valid, const double* __restrict__ xw6,
+                                                            const double* __restrict__ normal, const float* __restrict__ min_dist,
+                                                            const float* __restrict__ max_dist, float limit, uint8_t* __restrict__ in_view,
+                                                            float* __restrict__ proj, int32_t* __restrict__ level, float* __restrict__ view_cos) {
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n[b]) return;
+    const size_t o = (size_t)b * stride + j;
+    in_view[o] = 0;
+    if (!valid[o]) return;
+    const FrustumPose P = frustum_pose(F.Tcw + (size_t)b * 16);
+    float SP[3], EP[3];
+    for (int k = 0; k < 3; k++) { SP[k] = (float)xw6[6 * o + k]; EP[k] = (float)xw6[6 * o + 3 + k]; }
+    const float SPcX = gemm3_row(P.Rcw[0], P.Rcw[1], P.Rcw[2], SP, P.tcw[0]), SPcY = gemm3_row(P.Rcw[3], P.Rcw[4], P.Rcw[5], SP, P.tcw[1]);
+    const float SPcZ = gemm3_row(P.Rcw[6], P.Rcw[7], P.Rcw[8], SP, P.tcw[2]);
+    const float EPcX = gemm3_row(P.Rcw[0], P.Rcw[1], P.Rcw[2], EP, P.tcw[0]), EPcY = gemm3_row(P.Rcw[3], P.Rcw[4], P.Rcw[5], EP, P.tcw[1]);
+    const float EPcZ = gemm3_row(P.Rcw[6], P.Rcw[7], P.Rcw[8], EP, P.tcw[2]);
+    if (SPcZ < 0.0f || EPcZ < 0.0f) return;
+    const float invz1 = 1.0f / SPcZ;
+    const float u1 = F.fx * SPcX * invz1 + F.cx, v1 = F.fy * SPcY * invz1 + F.cy;
+    if (u1 < F.min_x || u1 > F.max_x) return;
+    if (v1 < F.min_y || v1 > F.max_y) return;
+    const float invz2 = 1.0f / EPcZ;
+    const float u2 = F.fx * EPcX * invz2 + F.cx, v2 = F.fy * EPcY * invz2 + F.cy;
+    if (u2 < F.min_x || u2 > F.max_x) return;
+    if (v2 < F.min_y || v2 > F.max_y) return;
+    const float maxDistance = 1.2f * max_dist[o], minDistance = 0.8f * min_dist[o];
+    float OM[3];
+    for (int k = 0; k < 3; k++) OM[k] = (float)((double)(SP[k] + EP[k]) * 0.5) - P.Ow[k];
+    const float dist = norm3(OM);
+    if (dist < minDistance || dist > maxDistance) return;
+    const float pn[3] = {(float)normal[3 * o], (float)normal[3 * o + 1], (float)normal[3 * o + 2]};
+    const float viewCos = (float)(dot3(OM, pn) / (double)dist);
+    if (viewCos < limit) return;
+    const float ratio = max_dist[o] / dist;   // MapLine::PredictScale (src/MapLine.cpp:381-390): not clamped
+    in_view[o] = 1;
+    proj[4 * o] = u1; proj[4 * o + 1] = v1; proj[4 * o + 2] = u2; proj[4 * o + 3] = v2;
+    level[o] = (int)ceilf((float)log((double)ratio) / lsf);
+    view_cos[o] = viewCos;
 }
 
 static int check_view(const planar_frame_view* f) {
@@ -785,6 +875,78 @@ int planar_search_by_projection_map(planar_ctx* ctx, const planar_frame_view* fr
     dp.n = s.dev<int32_t>(p0); dp.in_view = s.dev<uint8_t>(p1); dp.proj_x = s.dev<float>(p2); dp.proj_y = s.dev<float>(p3); dp.proj_xr = s.dev<float>(p4);
     dp.level = s.dev<int32_t>(p5); dp.view_cos = s.dev<float>(p6); dp.desc = s.dev<uint8_t>(p7); dp.observed = s.dev<uint8_t>(p8);
     rc = planar_search_by_projection_map_dev(ctx, &df, &dp, th, nn_ratio, s.dev<int32_t>(om), s.dev<int32_t>(on));
+    if (rc) return rc;
+    return s.download(ctx->stream);
+}
+
+int planar_is_in_frustum_points_dev(planar_ctx* ctx, const planar_frame_view* f, float log_scale_factor, int n_levels, const int32_t* d_n, int stride,
+                                    const uint8_t* d_valid, const float* d_xw, const float* d_normal, const float* d_min_dist, const float* d_max_dist,
+                                    float viewing_cos_limit, uint8_t* d_in_view, float* d_proj_x, float* d_proj_y, float* d_proj_xr, int32_t* d_level,
+                                    float* d_view_cos) {
+    PLANAR_REQUIRE(ctx && f && f->Tcw && d_n && d_valid && d_xw && d_normal && d_min_dist && d_max_dist && d_in_view && d_proj_x && d_proj_y && d_proj_xr &&
+                       d_level && d_view_cos, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(f->B >= 1 && stride >= 1 && n_levels >= 1 && n_levels <= PLANAR_MAX_LEVELS, PLANAR_EINVAL, "bad sizes");
+    hipLaunchKernelGGL(guided::frustum_points_kernel, dim3((stride + 255) / 256, f->B), dim3(256), 0, ctx->stream, *f, log_scale_factor, n_levels, d_n, stride,
+                       d_valid, d_xw, d_normal, d_min_dist, d_max_dist, viewing_cos_limit, d_in_view, d_proj_x, d_proj_y, d_proj_xr, d_level, d_view_cos);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_is_in_frustum_points(planar_ctx* ctx, const planar_frame_view* f, float log_scale_factor, int n_levels, const int32_t* n, int stride,
+                                const uint8_t* valid, const float* xw, const float* normal, const float* min_dist, const float* max_dist,
+                                float viewing_cos_limit, uint8_t* in_view, float* proj_x, float* proj_y, float* proj_xr, int32_t* level, float* view_cos) {
+    PLANAR_REQUIRE(ctx && f && f->Tcw && n && valid && xw && normal && min_dist && max_dist && in_view && proj_x && proj_y && proj_xr && level && view_cos,
+                   PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(f->B >= 1 && stride >= 1, PLANAR_EINVAL, "bad sizes");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    const size_t N = (size_t)f->B * stride;
+    const int t = s.in(f->Tcw, (size_t)f->B * 64), a0 = s.in(n, (size_t)f->B * 4), a1 = s.in(valid, N), a2 = s.in(xw, N * 12), a3 = s.in(normal, N * 12),
+              a4 = s.in(min_dist, N * 4), a5 = s.in(max_dist, N * 4);
+    const int o0 = s.inout(in_view, N), o1 = s.inout(proj_x, N * 4), o2 = s.inout(proj_y, N * 4), o3 = s.inout(proj_xr, N * 4), o4 = s.inout(level, N * 4),
+              o5 = s.inout(view_cos, N * 4);
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    planar_frame_view d = *f;
+    d.Tcw = s.dev<float>(t);
+    rc = planar_is_in_frustum_points_dev(ctx, &d, log_scale_factor, n_levels, s.dev<int32_t>(a0), stride, s.dev<uint8_t>(a1), s.dev<float>(a2), s.dev<float>(a3),
+                                         s.dev<float>(a4), s.dev<float>(a5), viewing_cos_limit, s.dev<uint8_t>(o0), s.dev<float>(o1), s.dev<float>(o2),
+                                         s.dev<float>(o3), s.dev<int32_t>(o4), s.dev<float>(o5));
+    if (rc) return rc;
+    return s.download(ctx->stream);
+}
+
+int planar_is_in_frustum_lines_dev(planar_ctx* ctx, const planar_frame_view* f, float log_scale_factor, const int32_t* d_n, int stride, const uint8_t* d_valid,
+                                   const double* d_xw6, const double* d_normal, const float* d_min_dist, const float* d_max_dist, float viewing_cos_limit,
+                                   uint8_t* d_in_view, float* d_proj, int32_t* d_level, float* d_view_cos) {
+    PLANAR_REQUIRE(ctx && f && f->Tcw && d_n && d_valid && d_xw6 && d_normal && d_min_dist && d_max_dist && d_in_view && d_proj && d_level && d_view_cos,
+                   PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(f->B >= 1 && stride >= 1, PLANAR_EINVAL, "bad sizes");
+    hipLaunchKernelGGL(guided::frustum_lines_kernel, dim3((stride + 255) / 256, f->B), dim3(256), 0, ctx->stream, *f, log_scale_factor, d_n, stride, d_valid, d_xw6,
+                       d_normal, d_min_dist, d_max_dist, viewing_cos_limit, d_in_view, d_proj, d_level, d_view_cos);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_is_in_frustum_lines(planar_ctx* ctx, const planar_frame_view* f, float log_scale_factor, const int32_t* n, int stride, const uint8_t* valid,
+                               const double* xw6, const double* normal, const float* min_dist, const float* max_dist, float viewing_cos_limit, uint8_t* in_view,
+                               float* proj, int32_t* level, float* view_cos) {
+    PLANAR_REQUIRE(ctx && f && f->Tcw && n && valid && xw6 && normal && min_dist && max_dist && in_view && proj && level && view_cos, PLANAR_EINVAL,
+                   "null argument");
+    PLANAR_REQUIRE(f->B >= 1 && stride >= 1, PLANAR_EINVAL, "bad sizes");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    const size_t N = (size_t)f->B * stride;
+    const int t = s.in(f->Tcw, (size_t)f->B * 64), a0 = s.in(n, (size_t)f->B * 4), a1 = s.in(valid, N), a2 = s.in(xw6, N * 48), a3 = s.in(normal, N * 24),
+              a4 = s.in(min_dist, N * 4), a5 = s.in(max_dist, N * 4);
+    const int o0 = s.inout(in_view, N), o1 = s.inout(proj, N * 16), o2 = s.inout(level, N * 4), o3 = s.inout(view_cos, N * 4);
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    planar_frame_view d = *f;
+    d.Tcw = s.dev<float>(t);
+    rc = planar_is_in_frustum_lines_dev(ctx, &d, log_scale_factor, s.dev<int32_t>(a0), stride, s.dev<uint8_t>(a1), s.dev<double>(a2), s.dev<double>(a3),
+                                        s.dev<float>(a4), s.dev<float>(a5), viewing_cos_limit, s.dev<uint8_t>(o0), s.dev<float>(o1), s.dev<int32_t>(o2),
+                                        s.dev<float>(o3));
     if (rc) return rc;
     return s.download(ctx->stream);
 }

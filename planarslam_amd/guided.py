@@ -157,3 +157,49 @@ class PlaneMatcher:
                                                         mn.ctypes.data, M, mv.ctypes.data, mc.ctypes.data, mnp.ctypes.data, P, mp.ctypes.data,
                                                         self.th.ctypes.data, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, nm.ctypes.data))
         return out[0], out[1], out[2], nm
+
+
+class Frame:
+    """The two Frame::isInFrustum overloads (reference src/Frame.cc:312-367, :369-438), batched over frames.  They fill the MapPoint /
+    MapLine tracking fields that SearchByProjection(F, vpMapPoints / vpMapLines, th) reads, returned here as the probe dicts those take."""
+
+    def __init__(self, frame: dict, log_scale_factor: float | None = None, n_levels: int | None = None, ctx: Context | None = None):
+        self.frame, self.ctx = frame, ctx or Context(0)
+        sf = np.asarray(frame["scale_factors"], np.float32)
+        self.n_levels = n_levels or len(sf)
+        # Frame::mfLogScaleFactor = log(mfScaleFactor), float (src/Frame.cc:67)
+        self.log_scale_factor = float(np.float32(np.log(np.float32(sf[1])))) if log_scale_factor is None else log_scale_factor
+
+    def isInFrustumPoints(self, mp: dict, viewingCosLimit: float = 0.5):
+        """mp: n[B], valid, xw[B,S,3], normal[B,S,3], min_dist, max_dist (+ desc, observed passed through)."""
+        fv, keep = frame_view(self.frame)
+        a = dict(n=_c(mp["n"], np.int32), valid=_c(mp["valid"], np.uint8), xw=_c(mp["xw"], np.float32), normal=_c(mp["normal"], np.float32),
+                 min_dist=_c(mp["min_dist"], np.float32), max_dist=_c(mp["max_dist"], np.float32))
+        B, S = a["valid"].shape
+        out = dict(n=a["n"], in_view=np.zeros((B, S), np.uint8), proj_x=np.zeros((B, S), np.float32), proj_y=np.zeros((B, S), np.float32),
+                   proj_xr=np.zeros((B, S), np.float32), level=np.zeros((B, S), np.int32), view_cos=np.zeros((B, S), np.float32))
+        check(lib().planar_is_in_frustum_points(self.ctx.h, C.byref(fv), self.log_scale_factor, self.n_levels, a["n"].ctypes.data, S, a["valid"].ctypes.data,
+                                                a["xw"].ctypes.data, a["normal"].ctypes.data, a["min_dist"].ctypes.data, a["max_dist"].ctypes.data,
+                                                viewingCosLimit, out["in_view"].ctypes.data, out["proj_x"].ctypes.data, out["proj_y"].ctypes.data,
+                                                out["proj_xr"].ctypes.data, out["level"].ctypes.data, out["view_cos"].ctypes.data))
+        for k in ("desc", "observed"):
+            if k in mp:
+                out[k] = mp[k]
+        return out
+
+    def isInFrustumLines(self, ml: dict, viewingCosLimit: float = 0.5):
+        """ml: n[B], valid, xw6[B,S,6] float64, normal[B,S,3] float64, min_dist, max_dist (+ desc, observed passed through)."""
+        fv, keep = frame_view(self.frame)
+        a = dict(n=_c(ml["n"], np.int32), valid=_c(ml["valid"], np.uint8), xw6=_c(ml["xw6"], np.float64), normal=_c(ml["normal"], np.float64),
+                 min_dist=_c(ml["min_dist"], np.float32), max_dist=_c(ml["max_dist"], np.float32))
+        B, S = a["valid"].shape
+        out = dict(n=a["n"], in_view=np.zeros((B, S), np.uint8), proj=np.zeros((B, S, 4), np.float32), level=np.zeros((B, S), np.int32),
+                   view_cos=np.zeros((B, S), np.float32))
+        check(lib().planar_is_in_frustum_lines(self.ctx.h, C.byref(fv), self.log_scale_factor, a["n"].ctypes.data, S, a["valid"].ctypes.data,
+                                               a["xw6"].ctypes.data, a["normal"].ctypes.data, a["min_dist"].ctypes.data, a["max_dist"].ctypes.data,
+                                               viewingCosLimit, out["in_view"].ctypes.data, out["proj"].ctypes.data, out["level"].ctypes.data,
+                                               out["view_cos"].ctypes.data))
+        for k in ("desc", "observed"):
+            if k in ml:
+                out[k] = ml[k]
+        return out

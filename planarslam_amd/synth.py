@@ -496,3 +496,45 @@ def guided_planes(B=4, n_planes=8, n_map=40, n_pts=600, seed=12, shared=False):
             # camera-frame coefficients: pi_c = Tcw^-T pi_w  (so that Tcw^T pi_c = pi_w)
             fr["coef"][b, i] = np.linalg.inv(T).T @ pw
     return fr, mp
+
+
+def guided_local_map(frame, seed=14, n_points=2500, n_lines=300):
+    """Local-map points / lines in world coordinates around a posed frame, for Frame::isInFrustum: most project into the image,
+    some fall behind the camera, outside the image, outside the scale-invariance range or are seen too obliquely."""
+    rng = np.random.default_rng(seed)
+    B = frame["keys_un"].shape[0]
+    Tcw = np.zeros((B, 16), np.float32)
+    mp = dict(n=np.zeros(B, np.int32), valid=np.zeros((B, n_points), np.uint8), xw=np.zeros((B, n_points, 3), np.float32),
+              normal=np.zeros((B, n_points, 3), np.float32), min_dist=np.zeros((B, n_points), np.float32), max_dist=np.zeros((B, n_points), np.float32),
+              desc=rng.integers(0, 256, (B, n_points, 32), dtype=np.uint8), observed=(rng.random((B, n_points)) < 0.8).astype(np.uint8))
+    ml = dict(n=np.zeros(B, np.int32), valid=np.zeros((B, n_lines), np.uint8), xw6=np.zeros((B, n_lines, 6)), normal=np.zeros((B, n_lines, 3)),
+              min_dist=np.zeros((B, n_lines), np.float32), max_dist=np.zeros((B, n_lines), np.float32),
+              desc=rng.integers(0, 256, (B, n_lines, 32), dtype=np.uint8), observed=(rng.random((B, n_lines)) < 0.8).astype(np.uint8))
+    for b in range(B):
+        T = _se3(rng, 0.3, rng.normal(0, 0.5, 3))
+        Tcw[b] = T.astype(np.float32).ravel()
+        Twc = np.linalg.inv(T)
+        Ow = Twc[:3, 3]
+
+        def world(n):
+            u = rng.uniform(-120, 760, n); v = rng.uniform(-100, 580, n); z = rng.uniform(-1.0, 7.0, n)
+            z[np.abs(z) < 0.2] = 0.5
+            Xc = np.stack([(u - frame["cx"]) * z / frame["fx"], (v - frame["cy"]) * z / frame["fy"], z, np.ones(n)], 1)
+            return (Twc @ Xc.T).T[:, :3]
+        m = n_points if b == 0 else int(rng.integers(n_points // 2, n_points + 1))
+        X = world(m)
+        d = np.linalg.norm(X - Ow, axis=1)
+        nrm = (Ow - X) / d[:, None] * -1.0            # PO = P - Ow; make the stored normal roughly parallel to PO, with outliers
+        nrm = nrm + rng.normal(0, 0.5, nrm.shape); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        mp["n"][b] = m; mp["valid"][b, :m] = rng.random(m) < 0.95
+        mp["xw"][b, :m] = X; mp["normal"][b, :m] = nrm
+        mp["max_dist"][b, :m] = d * rng.uniform(0.6, 4.0, m); mp["min_dist"][b, :m] = mp["max_dist"][b, :m] / (1.2 ** 7) * rng.uniform(0.8, 1.5, m)
+        k = n_lines if b == 0 else int(rng.integers(n_lines // 2, n_lines + 1))
+        S = world(k); E = S + rng.normal(0, 0.4, (k, 3))
+        M = 0.5 * (S + E); dm = np.linalg.norm(M - Ow, axis=1)
+        ln = (M - Ow) / dm[:, None] + rng.normal(0, 0.5, (k, 3)); ln /= np.linalg.norm(ln, axis=1, keepdims=True)
+        ml["n"][b] = k; ml["valid"][b, :k] = rng.random(k) < 0.95
+        ml["xw6"][b, :k] = np.concatenate([S, E], 1); ml["normal"][b, :k] = ln
+        ml["max_dist"][b, :k] = dm * rng.uniform(0.6, 4.0, k); ml["min_dist"][b, :k] = ml["max_dist"][b, :k] / (1.2 ** 7) * rng.uniform(0.8, 1.5, k)
+    frame = dict(frame); frame["Tcw"] = Tcw
+    return frame, mp, ml

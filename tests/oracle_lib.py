@@ -472,3 +472,30 @@ def ref_lsd_search_by_descriptor(kf_desc, cur_desc, kf_has_ml):
     blocks = [np.zeros(1, np.float32), np.ascontiguousarray(kf_desc, np.uint8), np.ascontiguousarray(cur_desc, np.uint8), np.asarray(kf_has_ml, np.uint8)]
     m, n = _run_ref_match("lsd_desc", blocks, 2)
     return m, int(n[0])
+
+
+def is_in_frustum_points(frame, mp, log_scale_factor, n_levels, limit=0.5):
+    G = _g(); L = lib()
+    fv, keep = G.frame_view(frame)
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    a = [c(mp["n"], np.int32), c(mp["valid"], np.uint8), c(mp["xw"], np.float32), c(mp["normal"], np.float32), c(mp["min_dist"], np.float32), c(mp["max_dist"], np.float32)]
+    B, S = a[1].shape
+    out = dict(in_view=np.zeros((B, S), np.uint8), proj_x=np.zeros((B, S), np.float32), proj_y=np.zeros((B, S), np.float32), proj_xr=np.zeros((B, S), np.float32),
+               level=np.zeros((B, S), np.int32), view_cos=np.zeros((B, S), np.float32))
+    L.orc_is_in_frustum_points(C.byref(fv), C.c_float(log_scale_factor), int(n_levels), p(a[0]), S, p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), C.c_float(limit),
+                               p(out["in_view"]), p(out["proj_x"]), p(out["proj_y"]), p(out["proj_xr"]), p(out["level"]), p(out["view_cos"]))
+    return out
+
+
+def is_in_frustum_lines(frame, ml, log_scale_factor, limit=0.5):
+    G = _g(); L = lib()
+    fv, keep = G.frame_view(frame)
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    a = [c(ml["n"], np.int32), c(ml["valid"], np.uint8), c(ml["xw6"], np.float64), c(ml["normal"], np.float64), c(ml["min_dist"], np.float32), c(ml["max_dist"], np.float32)]
+    B, S = a[1].shape
+    out = dict(in_view=np.zeros((B, S), np.uint8), proj=np.zeros((B, S, 4), np.float32), level=np.zeros((B, S), np.int32), view_cos=np.zeros((B, S), np.float32))
+    L.orc_is_in_frustum_lines(C.byref(fv), C.c_float(log_scale_factor), p(a[0]), S, p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), C.c_float(limit),
+                              p(out["in_view"]), p(out["proj"]), p(out["level"]), p(out["view_cos"]))
+    return out

@@ -133,3 +133,29 @@ def test_against_real_reference_fixtures(ctx):
     lines, ml = synth.guided_lines(B=3, n_lines=150, n_ml=400, seed=seed + 5)
     m, n = LSDmatcher(0.6, ctx).SearchByProjection(lines, ml, synth.scale_factors(), th=3.0)
     np.testing.assert_array_equal(m, g["lsd_proj_match"]); np.testing.assert_array_equal(n, g["lsd_proj_n"])
+
+
+def test_is_in_frustum_then_search_by_projection(ctx):
+    """TrackLocalMap's front end: Frame::isInFrustum for every local map point / line, then the guided search on its output."""
+    from planarslam_amd.guided import Frame, LSDmatcher, ORBmatcher
+    fr = synth.guided_frame(B=3, N=1000, seed=121)
+    fr, mp, ml = synth.guided_local_map(fr, seed=122, n_points=4000, n_lines=500)
+    F = Frame(fr, ctx=ctx)
+    ref = O.is_in_frustum_points(fr, mp, F.log_scale_factor, F.n_levels)
+    got = F.isInFrustumPoints(mp)
+    np.testing.assert_array_equal(got["in_view"], ref["in_view"])
+    iv = ref["in_view"] > 0
+    assert 0.1 < iv.mean() < 0.9
+    for k in ("proj_x", "proj_y", "proj_xr", "level", "view_cos"):
+        np.testing.assert_array_equal(got[k][iv], ref[k][iv], err_msg=k)
+    refl = O.is_in_frustum_lines(fr, ml, F.log_scale_factor)
+    gotl = F.isInFrustumLines(ml)
+    np.testing.assert_array_equal(gotl["in_view"], refl["in_view"])
+    il = refl["in_view"] > 0
+    for k in ("proj", "level", "view_cos"):
+        np.testing.assert_array_equal(gotl[k][il], refl[k][il], err_msg=k)
+    # the probes feed SearchByProjection unchanged (fields not written for out-of-view points are never read)
+    fr2 = dict(fr); fr2["blocked"] = np.zeros(fr["keys_un"].shape, np.uint8)
+    m, n = ORBmatcher(0.8, True, ctx).SearchByProjectionMap(fr2, got, th=3.0)
+    rm, rn = O.search_by_projection_map(fr2, {**ref, "n": mp["n"], "desc": mp["desc"], "observed": mp["observed"]}, th=3.0, nn_ratio=0.8)
+    np.testing.assert_array_equal(m, rm); np.testing.assert_array_equal(n, rn)

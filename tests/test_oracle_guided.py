@@ -138,3 +138,25 @@ def test_lsd_search_by_projection_and_plane_matcher_small():
     fr2, mp2 = synth.guided_planes(B=3, seed=53, shared=True)
     a2, _, _, n2 = O.plane_search_by_coefficients(fr2, mp2)
     assert n2.sum() >= 3
+
+
+def test_is_in_frustum_points_and_lines_properties():
+    fr = synth.guided_frame(B=2, N=300, seed=61)
+    fr, mp, ml = synth.guided_local_map(fr, seed=62)
+    lsf = float(np.float32(np.log(np.float32(1.2))))
+    o = O.is_in_frustum_points(fr, mp, lsf, 8)
+    iv = o["in_view"] > 0
+    assert 0.1 < iv[mp["valid"] > 0].mean() < 0.9 and not iv[mp["valid"] == 0].any()
+    assert (o["proj_x"][iv] >= 0).all() and (o["proj_x"][iv] <= 640).all() and (o["proj_y"][iv] >= 0).all() and (o["proj_y"][iv] <= 480).all()
+    assert (o["view_cos"][iv] >= 0.5).all() and (o["level"][iv] >= 0).all() and (o["level"][iv] <= 7).all()
+    # independent float64 projection agrees to float32 accuracy
+    for b in range(2):
+        T = fr["Tcw"][b].reshape(4, 4).astype(np.float64)
+        j = np.nonzero(iv[b])[0][:200]
+        Xc = (T[:3, :3] @ mp["xw"][b, j].T.astype(np.float64)).T + T[:3, 3]
+        np.testing.assert_allclose(o["proj_x"][b, j], fr["fx"] * Xc[:, 0] / Xc[:, 2] + fr["cx"], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(o["proj_xr"][b, j], o["proj_x"][b, j] - fr["bf"] / Xc[:, 2], rtol=0, atol=2e-3)
+    ol = O.is_in_frustum_lines(fr, ml, lsf)
+    il = ol["in_view"] > 0
+    assert 0.05 < il[ml["valid"] > 0].mean() < 0.9
+    assert (ol["proj"][il] >= 0).all() and (ol["proj"][il][:, [0, 2]] <= 640).all()
