@@ -1100,13 +1100,17 @@ static void host_taps_q8(int ksize, double sigma, int* taps) {
 static bool host_exact_coefs(double inv_scale, int srcsize, int dstsize, std::vector<lsd::Coef>& out) {
     const double scale = 1.0 / inv_scale;
     out.assign(dstsize, lsd::Coef{0, 0, 0});
+    if (srcsize < 2) return false;
     for (int val = 0; val < dstsize; val++) {
         const double fval = scale * ((double)val + 0.5) - 0.5;
         const int ival = (int)std::floor(fval);
-        if (!(ival >= 0 && ival < srcsize - 1)) return false;   // border replication never triggers for a 0.8x downscale
-        out[val].ofs = ival;
-        out[val].c1 = (int)std::nearbyint((fval - (double)ival) * 256.0);
-        out[val].c0 = 256 - out[val].c1;
+        if (ival < 0) out[val] = lsd::Coef{0, 256, 0};                               // left of minofst: the first pixel (src[0] << 8)
+        else if (ival >= srcsize - 1) out[val] = lsd::Coef{srcsize - 2, 0, 256};     // from maxofst on: the last pixel (src[n-1] << 8)
+        else {
+            out[val].ofs = ival;
+            out[val].c1 = (int)std::nearbyint((fval - (double)ival) * 256.0);
+            out[val].c0 = 256 - out[val].c1;
+        }
     }
     return true;
 }
@@ -1146,7 +1150,7 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     }
     std::vector<lsd::Coef> cx, cy;
     if (!host_exact_coefs(SCALE, width, P.w, cx) || !host_exact_coefs(SCALE, height, P.h, cy)) {
-        delete o; set_error("planar_lsd_create: resample table hit the border path"); return PLANAR_EINVAL;
+        delete o; set_error("planar_lsd_create: image too small to resample"); return PLANAR_EINVAL;
     }
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o2 = off; off = align_up(off + bytes, (size_t)256); return o2; };

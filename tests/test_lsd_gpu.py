@@ -123,3 +123,18 @@ def test_many_segments_sort_in_global_scratch(ctx):
     for f in rk.dtype.names:
         np.testing.assert_array_equal(kl[0][f], rk[f], err_msg=f)
     np.testing.assert_array_equal(desc[0], rd)
+
+
+@pytest.mark.parametrize("size", [(752, 480), (320, 240), (500, 375)])
+def test_other_image_sizes(ctx, size):
+    from planarslam_amd.lines import LineSegment
+    W, H = size
+    img = synth.gray_image(31, w=W, h=H)
+    ls = LineSegment(W, H, 2, ctx)
+    kl, desc, eq, n = ls.ExtractLineSegment(np.stack([img, img[::-1].copy()]))
+    for b, im in enumerate((img, img[::-1].copy())):
+        rk, rd, re, _, nd = O.extract_line_segment(im, tie_order=1)
+        assert n[b] == len(rk) > 5
+        assert kl[b, :n[b]].tobytes() == rk.tobytes()
+        np.testing.assert_array_equal(desc[b, :n[b]], rd)
+        np.testing.assert_array_equal(eq[b, :n[b]], re)
