@@ -140,7 +140,7 @@ struct Layout {   // per-frame workspace (element offsets), identical for every 
     int W, H, Nw, Nh, NB, NB2;   // NB2 = 2*NB: initial blocks + merged nodes
     int pool_cap, q_cap;
     size_t off_stats, off_geo, off_N, off_rid, off_flags, off_nb_off, off_nb_cnt, off_nb_cap, off_pool, off_parent, off_size,
-        off_member, off_dist, off_blkmap, off_queue, off_seedcnt, frame_bytes;
+        off_member, off_dist, off_blkmap, off_queue, off_seedcnt, off_ver, off_tag, off_cint, off_cdbl, frame_bytes;
 };
 
 struct Intr { float fx, fy, cx, cy, factor; };
@@ -237,6 +237,10 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     float* distMap = (float*)(F + L.off_dist);
     int2* queue = (int2*)(F + L.off_queue);
     int* seedcnt = (int*)(F + L.off_seedcnt);
+    unsigned* g_ver = (unsigned*)(F + L.off_ver);
+    unsigned* g_tag = (unsigned*)(F + L.off_tag);
+    int* g_cint = (int*)(F + L.off_cint);
+    double* g_cdbl = (double*)(F + L.off_cdbl);
     const uint16_t* D = depth + (size_t)frame * frame_stride_px;
     int32_t* lab = labels + (size_t)frame * label_stride;
     const int NB = L.NB, Nw = L.Nw, Nh = L.Nh, W = L.W, H = L.H;
@@ -260,11 +264,19 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     __shared__ int s_slot[1024];
     __shared__ int s_wcnt[4];
     __shared__ int s_scalar[4];   // [0] n_ext, [1] err, [2] q_tail, [3] scratch
+    constexpr int EVAL_MAX = 64;   // nodes evaluated per cooperative phase
+    __shared__ int s_cmd, s_nlist;
+    __shared__ unsigned short s_lnode[EVAL_MAX];
+    __shared__ unsigned char s_lwave[EVAL_MAX], s_loff[EVAL_MAX];
     long long tphase[8];
     int nph = 0;
     auto mark = [&]() { if (nph < 8) tphase[nph++] = (long long)wall_clock64(); };
     mark();
-    auto wfence = [&]() { __threadfence_block(); };   // single-wave sections: LDS ops of one wave are in order
+    // Single-wave sections: the LDS traffic of one wavefront is processed in program order, so lanes only need the compiler to keep
+    // that order (wavefront-scope fence, no s_waitcnt).  gfence additionally waits for the wave's global stores (workgroup scope):
+    // used where lane 0 publishes a new node's moments / plane in global memory.
+    auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    auto gfence = [&]() { __threadfence_block(); };
 
     auto geo_of = [&](int id) { return g_geo + (size_t)id * 7; };
     auto nsim = [&](int a, int b) {
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     // ---- init (all threads) ----
     for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.nb_cap[b] = 4; S.rid[b] = (u16)b; }
     for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) S.nouse[t] = 0;
+    for (int t = tid; t < L.NB2; t += NT) { g_ver[t] = 0; g_tag[t] = 0; }
     for (int t = tid; t < MAX_PLANES; t += NT) { s_valid[t] = 0; s_plidmap[t] = -1; }
     for (int t = tid; t < MAX_PLANES * (MAX_PLANES / 32); t += NT) (&s_adj[0][0])[t] = 0;
     if (tid < 4) s_scalar[tid] = 0;
@@ -370,199 +383,324 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     };
     // ahCluster (:983-1189)
     long long cyc[6] = {0, 0, 0, 0, 0, 0};
-    auto ah_cluster = [&]() {
-        int step = 0;
-        while (heap_n > 0 && step <= MAX_STEP && !err) {
-            long long c0 = clock64();
-            const int p = heap_pop();
-            cyc[0] += clock64() - c0; c0 = clock64();
-            if (is_dead(p)) continue;                           // nouse
-            const int cnt = S.nb_cnt[p];
-            const u16* lst = S.pool + S.nb_off[p];
-            const double* sp = g_stats + (size_t)p * 9;
-            const int Np = node_N(p);
-            const double* gp = geo_of(p) + 3;
-            const double pn0 = gp[0], pn1 = gp[1], pn2 = gp[2];
-            double ps[9];
-            for (int t = 0; t < 9; t++) ps[t] = sp[t];
-            // candidate merges, one per lane; the in-order fold reproduces "first minimum wins (+ the N<mse quirk)"
-            double best_mse = 0; int best_nb = -1, best_N = 0; bool have = false;
-            double best_stats[9]; Geo best_geo;
-            for (int k0 = 0; k0 < cnt; k0 += 64) {
-                const int k = k0 + lane;
-                bool ok = false;
-                double ms[9]; Geo mg; int mN = 0, nb = -1;
-                mg.mse = 0;
-                if (k < cnt && !is_dead(lst[k])) {
-                    nb = lst[k];
-                    // one memory round trip: the neighbour's normal and moments are fetched together
-                    const double* gn = geo_of(nb) + 3;
-                    const double* sb = g_stats + (size_t)nb * 9;
-                    const double n0 = gn[0], n1 = gn[1], n2 = gn[2];
-                    for (int t = 0; t < 9; t++) ms[t] = sb[t];
-                    if (!(fabs(pn0 * n0 + pn1 * n1 + pn2 * n2) < C.cos_merge)) {
-                        for (int t = 0; t < 9; t++) ms[t] = ps[t] + ms[t];
-                        mN = Np + node_N(nb);
-                        stats_compute(ms, mN, mg);
-                        ok = true;
-                    }
-                }
-                // Reference rule (:1043-1049), candidates in ascending node id: take a candidate if none yet, or its mse is
-                // smaller, or (equal mse and best.N < mse — quirk).  Without exact ties that is "first minimum": a butterfly
-                // arg-min on (mse, lane); exact ties among this round's candidates fall back to the in-order scan.
-                unsigned long long okm = __ballot(ok);
-                if (okm) {
-                    double rm = ok ? mg.mse : 1.7976931348623157e308;
-                    int rl = ok ? lane : 64;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const double om = __shfl_xor(rm, o); const int ol = __shfl_xor(rl, o);
-                        if (om < rm || (om == rm && ol < rl)) { rm = om; rl = ol; }
-                    }
-                    const bool tie = __popcll(__ballot(ok && mg.mse == rm)) > 1;
-                    unsigned long long scan = tie ? okm : (1ull << rl);
-                    while (scan) {
-                        const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)scan) - 1);
-                        scan &= scan - 1;
-                        const double c_mse = __shfl(mg.mse, src);
-                        if (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse)) {   // quirk :1045
-                            have = true; best_mse = c_mse; best_nb = __shfl(nb, src); best_N = __shfl(mN, src);
-                            for (int t = 0; t < 9; t++) best_stats[t] = __shfl(ms[t], src);
-                            for (int t = 0; t < 3; t++) { best_geo.center[t] = __shfl(mg.center[t], src); best_geo.normal[t] = __shfl(mg.normal[t], src); }
-                            best_geo.mse = c_mse;
-                        }
-                    }
+    int dbg_hits = 0, dbg_phases = 0, dbg_nodes = 0;
+    // ahCluster (:983-1189).  coop = true: called by ALL four wavefronts.  The candidate evaluation of a popped node (one 3x3
+    // eigen-solve per neighbour, ~27k cycles of latency however few lanes it uses) dominates this loop, but its result is a pure
+    // function of the node's live-neighbour set.  So every time wavefront 0 pops a node without a valid cached result, all four
+    // wavefronts evaluate it TOGETHER WITH the next nodes of the heap (up to 64 nodes, one lane per (node, neighbour) pair) and
+    // store each result tagged with the node's version; versions are bumped whenever a node's live-neighbour set changes.
+    // Later pops find their result in the cache unless a merge touched their neighbourhood.  Phases are separated by workgroup
+    // barriers, so the schedule - and with it every bit of the output - is deterministic.
+    auto eval_phase = [&]() {
+        const int nl = s_nlist;
+        int my_node = -1, my_k = 0, seg_first = 0, seg_cnt = 0;
+        for (int i = 0; i < nl; i++)
+            if (s_lwave[i] == wave) {
+                const int off = s_loff[i], nd = s_lnode[i], c = S.nb_cnt[nd];
+                if (lane >= off && lane < off + c) { my_node = nd; my_k = lane - off; seg_first = off; seg_cnt = c; }
+            }
+        bool ok = false;
+        double ms[9]; Geo mg; int mN = 0, nb = -1;
+        for (int t = 0; t < 9; t++) ms[t] = 0;
+        for (int t = 0; t < 3; t++) { mg.center[t] = 0; mg.normal[t] = 0; }
+        mg.mse = 0;
+        if (my_node >= 0) {
+            const int x = (S.pool + S.nb_off[my_node])[my_k];
+            if (!is_dead(x)) {
+                nb = x;
+                const double* sp = g_stats + (size_t)my_node * 9;
+                const double* gp = geo_of(my_node) + 3;
+                const double* gn = geo_of(nb) + 3;
+                const double* sb = g_stats + (size_t)nb * 9;
+                const double pn0 = gp[0], pn1 = gp[1], pn2 = gp[2], n0 = gn[0], n1 = gn[1], n2 = gn[2];
+                double ps[9];
+                for (int t = 0; t < 9; t++) { ps[t] = sp[t]; ms[t] = sb[t]; }
+                if (!(fabs(pn0 * n0 + pn1 * n1 + pn2 * n2) < C.cos_merge)) {
+                    for (int t = 0; t < 9; t++) ms[t] = ps[t] + ms[t];
+                    mN = node_N(my_node) + node_N(nb);
+                    stats_compute(ms, mN, mg);
+                    ok = true;
                 }
             }
-            cyc[1] += clock64() - c0; c0 = clock64();
-            if (have && best_mse < T_mse_merge(best_geo.center[2])) {
-                const int m = n_nodes++;
-                const int nb = best_nb;
-                if (m >= L.NB2) { err = 1; break; }
-                const int rp = S.rid[p], rn = S.rid[nb];
-                const int Nn = node_N(nb);
-                if (lane == 0) {
-                    for (int t = 0; t < 9; t++) g_stats[(size_t)m * 9 + t] = best_stats[t];
-                    for (int t = 0; t < 3; t++) { g_geo[(size_t)m * 7 + t] = best_geo.center[t]; g_geo[(size_t)m * 7 + 3 + t] = best_geo.normal[t]; }
-                    g_geo[(size_t)m * 7 + 6] = best_geo.mse;
-                    g_N[m] = best_N;
-                    S.rid[m] = (u16)(Np >= Nn ? rp : rn);
-                    S.nouse[p >> 5] |= 1u << (p & 31);
-                    S.nouse[nb >> 5] |= 1u << (nb & 31);
-                    // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:64-84)
-                    const int xr = lds_find(S.dsp, rp), yr = lds_find(S.dsp, rn);
-                    if (xr != yr) {
-                        if (S.dss[xr] < S.dss[yr]) { S.dsp[xr] = (u16)yr; S.dss[yr] += S.dss[xr]; }
-                        else { S.dsp[yr] = (u16)xr; S.dss[xr] += S.dss[yr]; }
-                    }
-                }
-                wfence();
-                heap_push(m, best_geo.mse);
-                cyc[2] += clock64() - c0; c0 = clock64();
-                // mergeNbsFrom (AHCPlaneSeg.hpp:379-404): union of the two sorted lists minus {p, nb} (both dead by now),
-                // built cooperatively: prefix counts of the surviving entries, then every entry writes itself to its rank.
-                const int ca = S.nb_cnt[p], cb = S.nb_cnt[nb];
-                const int need = 2 * (ca + cb) + 2 + (ca + cb) / 4 + 8;
-                if (pool_top + need > L.pool_cap) {             // compact the pool: live merged nodes only (rare)
-                    if (lane == 0) {
-                        int top = 4 * NB;
-                        for (int id = NB; id < m; id++) {
-                            if (is_dead(id) && id != p && id != nb) { S.nb_cnt[id] = 0; continue; }
-                            const int c = S.nb_cnt[id], o = S.nb_off[id];
-                            int n2 = 0;
-                            for (int t = 0; t < c; t++) { const int v = S.pool[o + t]; if (!is_dead(v) || id == p || id == nb) S.pool[top + n2++] = (u16)v; }
-                            S.nb_off[id] = (u16)top; S.nb_cnt[id] = (u16)n2;
-                            if (id != p && id != nb) { const int cap = n2 + max(8, n2 / 4); S.nb_cap[id] = (u16)cap; top += cap; } else top += n2;
-                        }
-                        s_scalar[3] = top;
-                    }
-                    wfence();
-                    pool_top = s_scalar[3];
-                }
-                const int ca2 = S.nb_cnt[p], cb2 = S.nb_cnt[nb];
-                if (pool_top + 2 * (ca2 + cb2) + 2 + (ca2 + cb2) / 4 + 8 > L.pool_cap) { err = 2; break; }
-                const u16* A = S.pool + S.nb_off[p];
-                const u16* Bl = S.pool + S.nb_off[nb];
-                u16* PA = S.pool + pool_top;                    // [ca2+1] exclusive counts of surviving A entries
-                u16* PB = PA + ca2 + 1;                         // [cb2+1] ... of surviving, non-duplicate B entries
-                u16* out = PB + cb2 + 1;
-                int na = 0, nbk = 0;
-                for (int i0 = 0; i0 < ca2; i0 += 64) {
-                    const int i = i0 + lane;
-                    const bool keep = i < ca2 && !is_dead(A[i]);
-                    const unsigned long long mk = __ballot(keep);
-                    if (i < ca2) PA[i] = (u16)(na + __popcll(mk & ((1ull << lane) - 1ull)));
-                    na += __popcll(mk);
-                }
-                for (int j0 = 0; j0 < cb2; j0 += 64) {
-                    const int j = j0 + lane;
-                    bool keep = false;
-                    if (j < cb2) {
-                        const int x = Bl[j];
-                        if (!is_dead(x)) {
-                            int lo = 0, hi = ca2;               // duplicate test: x in A (then it is alive there too)
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
-                            keep = !(lo < ca2 && A[lo] == x);
-                        }
-                    }
-                    const unsigned long long mk = __ballot(keep);
-                    if (j < cb2) PB[j] = (u16)(nbk + __popcll(mk & ((1ull << lane) - 1ull)));
-                    nbk += __popcll(mk);
-                }
-                if (lane == 0) { PA[ca2] = (u16)na; PB[cb2] = (u16)nbk; }
-                wfence();
-                for (int i0 = 0; i0 < ca2; i0 += 64) {
-                    const int i = i0 + lane;
-                    if (i < ca2 && PA[i + 1] != PA[i]) {
-                        const int x = A[i];
-                        int lo = 0, hi = cb2;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (Bl[mid] < x) lo = mid + 1; else hi = mid; }
-                        out[PA[i] + PB[lo]] = (u16)x;
-                    }
-                }
-                for (int j0 = 0; j0 < cb2; j0 += 64) {
-                    const int j = j0 + lane;
-                    if (j < cb2 && PB[j + 1] != PB[j]) {
-                        const int x = Bl[j];
-                        int lo = 0, hi = ca2;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
-                        out[PB[j] + PA[lo]] = (u16)x;
-                    }
-                }
-                wfence();
-                const int n = na + nbk;
-                // move the list down over the scratch counters and reserve some slack for later appends
-                const int off = pool_top;
-                for (int k0 = 0; k0 < n; k0 += 64) {            // forward copy, destination below source: chunk-safe
-                    const int k = k0 + lane;
-                    const int v = k < n ? out[k] : 0;
-                    wfence();
-                    if (k < n) S.pool[off + k] = (u16)v;
-                    wfence();
-                }
-                const int cap = n + max(8, n / 4);
-                pool_top = off + cap;
-                if (lane == 0) { S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n; S.nb_cap[m] = (u16)cap; S.nb_cnt[p] = 0; S.nb_cnt[nb] = 0; }
-                wfence();
-                cyc[3] += clock64() - c0; c0 = clock64();
-                {   // nb->nbs.insert(this): m is the largest id so far -> append; a full list is compacted first
-                    const u16* lstm = S.pool + off;
-                    for (int k = lane; k < n; k += 64) {
-                        const int q = lstm[k];
-                        u16* ql = S.pool + S.nb_off[q];
-                        int c = S.nb_cnt[q];
-                        if (c >= S.nb_cap[q]) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
-                        ql[c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
-                    }
-                }
-                wfence();
-                cyc[5] += clock64() - c0;
-            } else {
-                extract(p);
-                mark_dead(p);
-            }
-            ++step;
         }
+        // the reference's in-order rule (:1043-1049) inside every node's lane segment
+        int maxc = seg_cnt;
+        for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+        bool have = false; double best_mse = 0; int best_k = 0, best_N = 0;
+        for (int k = 0; k < maxc; k++) {
+            const int src = min(seg_first + k, 63);
+            const int c_ok = __shfl((int)ok, src); const double c_mse = __shfl(mg.mse, src); const int c_N = __shfl(mN, src);
+            if (k < seg_cnt && c_ok && (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse))) {   // quirk :1045
+                have = true; best_mse = c_mse; best_k = k; best_N = c_N;
+            }
+        }
+        const int bl = min(seg_first + best_k, 63);
+        const int w_nb = __shfl(nb, bl);
+        double w[15];
+        for (int t = 0; t < 9; t++) w[t] = __shfl(ms[t], bl);
+        for (int t = 0; t < 3; t++) { w[9 + t] = __shfl(mg.center[t], bl); w[12 + t] = __shfl(mg.normal[t], bl); }
+        if (my_node >= 0 && my_k == 0) {
+            int* ci = g_cint + (size_t)my_node * 4;
+            double* cd = g_cdbl + (size_t)my_node * 16;
+            ci[0] = have ? 1 : 0; ci[1] = w_nb; ci[2] = best_N;
+            cd[0] = best_mse;
+            for (int t = 0; t < 15; t++) cd[1 + t] = w[t];
+            g_tag[my_node] = g_ver[my_node] + 1;
+        }
+    };
+    auto ah_cluster = [&](const bool coop) {
+        int step = 0, pending = -1;
+        while (true) {
+            bool need_eval = false;
+            long long e0 = 0;
+            if (wave == 0) {
+                while ((pending >= 0 || heap_n > 0) && step <= MAX_STEP && !err) {
+                    long long c0 = clock64();
+                    int p;
+                    if (pending >= 0) { p = pending; pending = -1; }
+                    else {
+                        p = heap_pop();
+                        cyc[0] += clock64() - c0; c0 = clock64();
+                        if (is_dead(p)) continue;                           // nouse
+                    }
+                    const int cnt = S.nb_cnt[p];
+                    const u16* lst = S.pool + S.nb_off[p];
+                    const double* sp = g_stats + (size_t)p * 9;
+                    const int Np = node_N(p);
+                    const double* gp = geo_of(p) + 3;
+                    const double pn0 = gp[0], pn1 = gp[1], pn2 = gp[2];
+                    double ps[9];
+                    for (int t = 0; t < 9; t++) ps[t] = sp[t];
+                    // candidate merges, one per lane; the in-order fold reproduces "first minimum wins (+ the N<mse quirk)"
+                    double best_mse = 0; int best_nb = -1, best_N = 0; bool have = false;
+                    double best_stats[9]; Geo best_geo;
+                    bool from_cache = false;
+                    if (coop && cnt > 0 && cnt <= 64) {
+                        if (g_tag[p] == g_ver[p] + 1) {
+                            const int* ci = g_cint + (size_t)p * 4;
+                            const double* cd = g_cdbl + (size_t)p * 16;
+                            have = ci[0] != 0; best_nb = ci[1]; best_N = ci[2]; best_mse = cd[0];
+                            for (int t = 0; t < 9; t++) best_stats[t] = cd[1 + t];
+                            for (int t = 0; t < 3; t++) { best_geo.center[t] = cd[10 + t]; best_geo.normal[t] = cd[13 + t]; }
+                            best_geo.mse = best_mse;
+                            from_cache = true; dbg_hits++;
+                        } else {
+                            // miss: evaluate p and the nodes waiting at the top of the heap (live, uncached, <= 64 neighbours), packed
+                            // into the 4 x 64 lanes; p goes first
+                            const int hp = lane < heap_n ? (int)S.h_id[lane] : -1;
+                            int hc = 0;
+                            bool cand = false;
+                            if (hp >= 0 && !is_dead(hp)) { hc = S.nb_cnt[hp]; cand = hc > 0 && hc <= 64 && g_tag[hp] != g_ver[hp] + 1; }
+                            unsigned long long cm = __ballot(cand);
+                            int nl = 0, cw = 0, co = cnt;
+                            if (lane == 0) { s_lnode[0] = (unsigned short)p; s_lwave[0] = 0; s_loff[0] = 0; }
+                            nl = 1;
+                            while (cm && nl < EVAL_MAX) {
+                                const int src = __ffsll((long long)cm) - 1;
+                                cm &= cm - 1;
+                                const int nd = __shfl(hp, src), c = __shfl(hc, src);
+                                if (co + c > 64) { cw++; co = 0; if (cw >= NT / 64) break; }
+                                if (lane == 0) { s_lnode[nl] = (unsigned short)nd; s_lwave[nl] = (unsigned char)cw; s_loff[nl] = (unsigned char)co; }
+                                nl++; co += c;
+                            }
+                            if (lane == 0) s_nlist = nl;
+                            pending = p;
+                            need_eval = true;
+                            break;
+                        }
+                    }
+                    if (!from_cache) {
+                        for (int k0 = 0; k0 < cnt; k0 += 64) {
+                            const int k = k0 + lane;
+                            bool ok = false;
+                            double ms[9]; Geo mg; int mN = 0, nb = -1;
+                            mg.mse = 0;
+                            if (k < cnt && !is_dead(lst[k])) {
+                                nb = lst[k];
+                                // one memory round trip: the neighbour's normal and moments are fetched together
+                                const double* gn = geo_of(nb) + 3;
+                                const double* sb = g_stats + (size_t)nb * 9;
+                                const double n0 = gn[0], n1 = gn[1], n2 = gn[2];
+                                for (int t = 0; t < 9; t++) ms[t] = sb[t];
+                                if (!(fabs(pn0 * n0 + pn1 * n1 + pn2 * n2) < C.cos_merge)) {
+                                    for (int t = 0; t < 9; t++) ms[t] = ps[t] + ms[t];
+                                    mN = Np + node_N(nb);
+                                    stats_compute(ms, mN, mg);
+                                    ok = true;
+                                }
+                            }
+                            // Reference rule (:1043-1049), candidates in ascending node id: take a candidate if none yet, or its mse is
+                            // smaller, or (equal mse and best.N < mse — quirk).  Without exact ties that is "first minimum": a butterfly
+                            // arg-min on (mse, lane); exact ties among this round's candidates fall back to the in-order scan.
+                            unsigned long long okm = __ballot(ok);
+                            if (okm) {
+                                double rm = ok ? mg.mse : 1.7976931348623157e308;
+                                int rl = ok ? lane : 64;
+            #pragma unroll
+                                for (int o = 32; o > 0; o >>= 1) {
+                                    const double om = __shfl_xor(rm, o); const int ol = __shfl_xor(rl, o);
+                                    if (om < rm || (om == rm && ol < rl)) { rm = om; rl = ol; }
+                                }
+                                const bool tie = __popcll(__ballot(ok && mg.mse == rm)) > 1;
+                                unsigned long long scan = tie ? okm : (1ull << rl);
+                                while (scan) {
+                                    const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)scan) - 1);
+                                    scan &= scan - 1;
+                                    const double c_mse = __shfl(mg.mse, src);
+                                    if (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse)) {   // quirk :1045
+                                        have = true; best_mse = c_mse; best_nb = __shfl(nb, src); best_N = __shfl(mN, src);
+                                        for (int t = 0; t < 9; t++) best_stats[t] = __shfl(ms[t], src);
+                                        for (int t = 0; t < 3; t++) { best_geo.center[t] = __shfl(mg.center[t], src); best_geo.normal[t] = __shfl(mg.normal[t], src); }
+                                        best_geo.mse = c_mse;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    cyc[1] += clock64() - c0; c0 = clock64();
+                    if (have && best_mse < T_mse_merge(best_geo.center[2])) {
+                        const int m = n_nodes++;
+                        const int nb = best_nb;
+                        if (m >= L.NB2) { err = 1; break; }
+                        const int rp = S.rid[p], rn = S.rid[nb];
+                        const int Nn = node_N(nb);
+                        if (lane == 0) {
+                            for (int t = 0; t < 9; t++) g_stats[(size_t)m * 9 + t] = best_stats[t];
+                            for (int t = 0; t < 3; t++) { g_geo[(size_t)m * 7 + t] = best_geo.center[t]; g_geo[(size_t)m * 7 + 3 + t] = best_geo.normal[t]; }
+                            g_geo[(size_t)m * 7 + 6] = best_geo.mse;
+                            g_N[m] = best_N;
+                            S.rid[m] = (u16)(Np >= Nn ? rp : rn);
+                            S.nouse[p >> 5] |= 1u << (p & 31);
+                            S.nouse[nb >> 5] |= 1u << (nb & 31);
+                            // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:64-84)
+                            const int xr = lds_find(S.dsp, rp), yr = lds_find(S.dsp, rn);
+                            if (xr != yr) {
+                                if (S.dss[xr] < S.dss[yr]) { S.dsp[xr] = (u16)yr; S.dss[yr] += S.dss[xr]; }
+                                else { S.dsp[yr] = (u16)xr; S.dss[xr] += S.dss[yr]; }
+                            }
+                        }
+                        gfence();
+                        heap_push(m, best_geo.mse);
+                        cyc[2] += clock64() - c0; c0 = clock64();
+                        // mergeNbsFrom (AHCPlaneSeg.hpp:379-404): union of the two sorted lists minus {p, nb} (both dead by now),
+                        // built cooperatively: prefix counts of the surviving entries, then every entry writes itself to its rank.
+                        const int ca = S.nb_cnt[p], cb = S.nb_cnt[nb];
+                        const int need = 2 * (ca + cb) + 2 + (ca + cb) / 4 + 8;
+                        if (pool_top + need > L.pool_cap) {             // compact the pool: live merged nodes only (rare)
+                            if (lane == 0) {
+                                int top = 4 * NB;
+                                for (int id = NB; id < m; id++) {
+                                    if (is_dead(id) && id != p && id != nb) { S.nb_cnt[id] = 0; continue; }
+                                    const int c = S.nb_cnt[id], o = S.nb_off[id];
+                                    int n2 = 0;
+                                    for (int t = 0; t < c; t++) { const int v = S.pool[o + t]; if (!is_dead(v) || id == p || id == nb) S.pool[top + n2++] = (u16)v; }
+                                    S.nb_off[id] = (u16)top; S.nb_cnt[id] = (u16)n2;
+                                    if (id != p && id != nb) { const int cap = n2 + max(8, n2 / 4); S.nb_cap[id] = (u16)cap; top += cap; } else top += n2;
+                                }
+                                s_scalar[3] = top;
+                            }
+                            wfence();
+                            pool_top = s_scalar[3];
+                        }
+                        const int ca2 = S.nb_cnt[p], cb2 = S.nb_cnt[nb];
+                        if (pool_top + 2 * (ca2 + cb2) + 2 + (ca2 + cb2) / 4 + 8 > L.pool_cap) { err = 2; break; }
+                        const u16* A = S.pool + S.nb_off[p];
+                        const u16* Bl = S.pool + S.nb_off[nb];
+                        u16* PA = S.pool + pool_top;                    // [ca2+1] exclusive counts of surviving A entries
+                        u16* PB = PA + ca2 + 1;                         // [cb2+1] ... of surviving, non-duplicate B entries
+                        u16* out = PB + cb2 + 1;
+                        int na = 0, nbk = 0;
+                        for (int i0 = 0; i0 < ca2; i0 += 64) {
+                            const int i = i0 + lane;
+                            const bool keep = i < ca2 && !is_dead(A[i]);
+                            const unsigned long long mk = __ballot(keep);
+                            if (i < ca2) PA[i] = (u16)(na + __popcll(mk & ((1ull << lane) - 1ull)));
+                            na += __popcll(mk);
+                        }
+                        for (int j0 = 0; j0 < cb2; j0 += 64) {
+                            const int j = j0 + lane;
+                            bool keep = false;
+                            if (j < cb2) {
+                                const int x = Bl[j];
+                                if (!is_dead(x)) {
+                                    int lo = 0, hi = ca2;               // duplicate test: x in A (then it is alive there too)
+                                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
+                                    keep = !(lo < ca2 && A[lo] == x);
+                                }
+                            }
+                            const unsigned long long mk = __ballot(keep);
+                            if (j < cb2) PB[j] = (u16)(nbk + __popcll(mk & ((1ull << lane) - 1ull)));
+                            nbk += __popcll(mk);
+                        }
+                        if (lane == 0) { PA[ca2] = (u16)na; PB[cb2] = (u16)nbk; }
+                        wfence();
+                        for (int i0 = 0; i0 < ca2; i0 += 64) {
+                            const int i = i0 + lane;
+                            if (i < ca2 && PA[i + 1] != PA[i]) {
+                                const int x = A[i];
+                                int lo = 0, hi = cb2;
+                                while (lo < hi) { const int mid = (lo + hi) >> 1; if (Bl[mid] < x) lo = mid + 1; else hi = mid; }
+                                out[PA[i] + PB[lo]] = (u16)x;
+                            }
+                        }
+                        for (int j0 = 0; j0 < cb2; j0 += 64) {
+                            const int j = j0 + lane;
+                            if (j < cb2 && PB[j + 1] != PB[j]) {
+                                const int x = Bl[j];
+                                int lo = 0, hi = ca2;
+                                while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
+                                out[PB[j] + PA[lo]] = (u16)x;
+                            }
+                        }
+                        wfence();
+                        const int n = na + nbk;
+                        // move the list down over the scratch counters and reserve some slack for later appends
+                        const int off = pool_top;
+                        for (int k0 = 0; k0 < n; k0 += 64) {            // forward copy, destination below source: chunk-safe
+                            const int k = k0 + lane;
+                            const int v = k < n ? out[k] : 0;
+                            wfence();
+                            if (k < n) S.pool[off + k] = (u16)v;
+                            wfence();
+                        }
+                        const int cap = n + max(8, n / 4);
+                        pool_top = off + cap;
+                        if (lane == 0) { S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n; S.nb_cap[m] = (u16)cap; S.nb_cnt[p] = 0; S.nb_cnt[nb] = 0; }
+                        wfence();
+                        cyc[3] += clock64() - c0; c0 = clock64();
+                        {   // nb->nbs.insert(this): m is the largest id so far -> append; a full list is compacted first
+                            const u16* lstm = S.pool + off;
+                            for (int k = lane; k < n; k += 64) {
+                                const int q = lstm[k];
+                                u16* ql = S.pool + S.nb_off[q];
+                                int c = S.nb_cnt[q];
+                                if (c >= S.nb_cap[q]) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
+                                ql[c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
+                                g_ver[q]++;                              // q's live-neighbour set changed: its cached candidates are stale
+                            }
+                        }
+                        wfence();
+                        cyc[5] += clock64() - c0;
+                    } else {
+                        extract(p);
+                        for (int k = lane; k < cnt; k += 64) { const int q = lst[k]; if (!is_dead(q)) g_ver[q]++; }   // p leaves their live sets
+                        mark_dead(p);
+                    }
+                    ++step;
+                }
+                if (lane == 0) s_cmd = need_eval ? 1 : 0;
+                gfence();
+            }
+            if (!coop) break;
+            __syncthreads();
+            if (s_cmd == 0) break;
+            e0 = clock64();
+            eval_phase();
+            __threadfence_block();
+            __syncthreads();
+            cyc[4] += clock64() - e0; dbg_phases++; dbg_nodes += s_nlist;
+        }
+        if (wave != 0) return;
         while (heap_n > 0 && !err) { const int p = heap_pop(); extract(p); mark_dead(p); }
         wfence();
         if (lane == 0) {   // std::sort(extractedPlanes, b->N < a->N): insertion sort (stable)
@@ -588,9 +726,9 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
             }
         }
         mark();
-        ah_cluster();
-        if (lane == 0) { s_scalar[0] = n_ext; s_scalar[1] = err; }
     } else mark();
+    ah_cluster(true);            // all four wavefronts (cooperative candidate evaluation)
+    if (wave == 0 && lane == 0) { s_scalar[0] = n_ext; s_scalar[1] = err; }
     __syncthreads();
     n_ext = s_scalar[0]; err = s_scalar[1];
     mark();
@@ -755,7 +893,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
         n_ext = 0;
         heap_n = 0;
         for (int q = 0; q < n_old; q++) if (s_valid[q]) heap_push(s_old[q], geo_of(s_old[q])[6]);
-        if (!err) ah_cluster();
+        if (!err) ah_cluster(false);
         for (int q = lane; q < n_old; q += 64) {
             int m = -1;
             if (s_valid[q]) {
@@ -788,6 +926,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
         if (timing) {
             for (int t = 0; t < 8; t++) timing[(size_t)frame * 16 + t] = t < nph ? tphase[t] - tphase[0] : 0;
             timing[(size_t)frame * 16 + 8] = s_scalar[2]; timing[(size_t)frame * 16 + 9] = n_nodes;
+            timing[(size_t)frame * 16 + 7] = ((long long)dbg_phases << 40) | ((long long)dbg_nodes << 20) | dbg_hits;   // cooperative ahCluster: phases, nodes evaluated, cache hits
             for (int t = 0; t < 6; t++) timing[(size_t)frame * 16 + 10 + t] = cyc[t];
         }
     }
@@ -834,6 +973,9 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     L.off_parent = carve((size_t)L.NB * 4); L.off_size = carve((size_t)L.NB * 4); L.off_member = carve((size_t)width * height * 4);
     L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 8);
     L.off_seedcnt = carve((size_t)L.NB * 4);
+    // candidate cache of the cooperative ahCluster: per node a version of its live-neighbour set, the tag (version + 1) the cached result
+    // was computed for, 4 ints {have, best_nb, best_N, -} and 16 doubles {mse, stats[9], center[3], normal[3]}
+    L.off_ver = carve((size_t)L.NB2 * 4); L.off_tag = carve((size_t)L.NB2 * 4); L.off_cint = carve((size_t)L.NB2 * 16); L.off_cdbl = carve((size_t)L.NB2 * 16 * 8);
     L.frame_bytes = off;
     o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 6 + L.NB * 4 + L.NB2 * 2 + ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
