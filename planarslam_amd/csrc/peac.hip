@@ -200,7 +200,7 @@ constexpr int NT = 256;
 typedef unsigned short u16;
 
 struct Lds {
-    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; u16* nb_cap; u16* dsp; u16* dss; u16* rid; unsigned* nouse; signed char* blk;
+    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; u16* dsp; u16* dss; u16* rid; unsigned* nouse; signed char* blk;
 };
 
 __device__ __forceinline__ int lds_find(u16* parent, int x) {   // DisjointSet::Find with path compression
@@ -251,8 +251,10 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     S.pool = S.h_id + NB;
     S.nb_off = S.pool + L.pool_cap;
     S.nb_cnt = S.nb_off + L.NB2;
-    S.nb_cap = S.nb_cnt + L.NB2;
-    S.dsp = S.nb_cap + L.NB2;
+    S.dsp = S.nb_cnt + L.NB2;
+    // list capacities are only consulted when a node is appended to a full list: they live in global memory so that this workgroup leaves
+    // room in LDS for the line detector's wavefront (lsd_detect, 8 KB) on the same CU
+    u16* g_nbcap = (u16*)(F + L.off_nb_cap);
     S.dss = S.dsp + NB;
     S.rid = S.dss + NB;                       // rid of every node (root block id)
     S.nouse = (unsigned*)(S.rid + L.NB2);     // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     };
 
     // ---- init (all threads) ----
-    for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.nb_cap[b] = 4; S.rid[b] = (u16)b; }
+    for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; g_nbcap[b] = 4; S.rid[b] = (u16)b; }
     for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) S.nouse[t] = 0;
     for (int t = tid; t < L.NB2; t += NT) { g_ver[t] = 0; g_tag[t] = 0; }
     for (int t = tid; t < MAX_PLANES; t += NT) { s_valid[t] = 0; s_plidmap[t] = -1; }
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                                     int n2 = 0;
                                     for (int t = 0; t < c; t++) { const int v = S.pool[o + t]; if (!is_dead(v) || id == p || id == nb) S.pool[top + n2++] = (u16)v; }
                                     S.nb_off[id] = (u16)top; S.nb_cnt[id] = (u16)n2;
-                                    if (id != p && id != nb) { const int cap = n2 + max(8, n2 / 4); S.nb_cap[id] = (u16)cap; top += cap; } else top += n2;
+                                    if (id != p && id != nb) { const int cap = n2 + max(8, n2 / 4); g_nbcap[id] = (u16)cap; top += cap; } else top += n2;
                                 }
                                 s_scalar[3] = top;
                             }
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                         }
                         const int cap = n + max(8, n / 4);
                         pool_top = off + cap;
-                        if (lane == 0) { S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n; S.nb_cap[m] = (u16)cap; S.nb_cnt[p] = 0; S.nb_cnt[nb] = 0; }
+                        if (lane == 0) { S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n; g_nbcap[m] = (u16)cap; S.nb_cnt[p] = 0; S.nb_cnt[nb] = 0; }
                         wfence();
                         cyc[3] += clock64() - c0; c0 = clock64();
                         {   // nb->nbs.insert(this): m is the largest id so far -> append; a full list is compacted first
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                                 const int q = lstm[k];
                                 u16* ql = S.pool + S.nb_off[q];
                                 int c = S.nb_cnt[q];
-                                if (c >= S.nb_cap[q]) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
+                                if (c >= g_nbcap[q]) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
                                 ql[c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
                                 g_ver[q]++;                              // q's live-neighbour set changed: its cached candidates are stale
                             }
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
             int c = 0;
             for (int r = 0; r < n_old; r++)
                 if (s_adj[q][r >> 5] & (1u << (r & 31))) lst_insert(S.pool + off, c, s_old[r]);
-            S.nb_off[id] = (u16)off; S.nb_cnt[id] = (u16)c; S.nb_cap[id] = (u16)n_old;
+            S.nb_off[id] = (u16)off; S.nb_cnt[id] = (u16)c; g_nbcap[id] = (u16)n_old;
             atomicAnd(&S.nouse[id >> 5], ~(1u << (id & 31)));   // back in the graph
         }
         pool_top = n_old * n_old;
@@ -977,7 +979,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     // was computed for, 4 ints {have, best_nb, best_N, -} and 16 doubles {mse, stats[9], center[3], normal[3]}
     L.off_ver = carve((size_t)L.NB2 * 4); L.off_tag = carve((size_t)L.NB2 * 4); L.off_cint = carve((size_t)L.NB2 * 16); L.off_cdbl = carve((size_t)L.NB2 * 16 * 8);
     L.frame_bytes = off;
-    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 6 + L.NB * 4 + L.NB2 * 2 + ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
+    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 4 + L.NB * 4 + L.NB2 * 2 + ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
     const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
