@@ -31,3 +31,35 @@ def test_version_and_error_string_without_gpu():
     L = _lib.lib()
     assert L.planar_abi_version() >= 100
     assert isinstance(L.planar_last_error(), bytes)
+
+
+def test_argument_errors_are_reported_without_touching_a_device():
+    """Error convention of the boundary: negative code + planar_last_error(), never a crash.  Null / out-of-range arguments are
+    rejected before any HIP call, so this runs on a machine without a GPU."""
+    import numpy as np
+    from planarslam_amd import _lib
+    from planarslam_amd._lib import FrameView, LastFrameView, MapProbes
+    L = _lib.lib()
+    EINVAL = -1
+    one = np.zeros(16, np.int32)
+    p = one.ctypes.data
+    fv, lv, mp = FrameView(), LastFrameView(), MapProbes()
+    calls = [
+        lambda: L.planar_hamming_knn(None, p, p, 1, p, p, 1, 1, 1, p, p),
+        lambda: L.planar_match_orb_points(None, p, p, 1, p, p, 1, p, p, 1, p, p),
+        lambda: L.planar_search_by_projection_frame(None, ctypes.byref(fv), ctypes.byref(lv), 15.0, 0, 1, p, p),
+        lambda: L.planar_search_by_projection_map(None, ctypes.byref(fv), ctypes.byref(mp), 1.0, 0.8, p, p),
+        lambda: L.planar_search_by_bow(None, 1, p, 1, p, p, p, p, p, 1, p, p, p, 0.7, 1, p, p),
+        lambda: L.planar_lsd_search_by_projection(None, 1, p, 1, p, p, p, p, 1, p, p, p, p, p, p, p, 8, 1.0, 0.6, p, p),
+        lambda: L.planar_plane_search_by_coefficients(None, 1, p, 1, p, p, 0, p, 1, p, p, p, 1, p, p, p, p, p, p),
+        lambda: L.planar_is_in_frustum_points(None, ctypes.byref(fv), 0.18, 8, p, 1, p, p, p, p, p, 0.5, p, p, p, p, p, p),
+        lambda: L.planar_lsd_extract(None, p, 1, 640, 640 * 480, 40, p, p, p, p),
+        lambda: L.planar_lsd_create(None, 640, 480, 1, ctypes.byref(ctypes.c_void_p())),
+        lambda: L.planar_peac_create(None, 640, 480, 1, ctypes.byref(ctypes.c_void_p())),
+        lambda: L.planar_pose_opt(None, None, None, 0, 4, 10),
+        lambda: L.planar_local_ba(None, None, None, 5, 10, None, None, None),
+    ]
+    for i, c in enumerate(calls):
+        rc = c()
+        assert rc == EINVAL, (i, rc)
+        assert len(L.planar_last_error()) > 0
