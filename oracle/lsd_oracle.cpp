@@ -7,7 +7,8 @@
 //     -> cv::line_descriptor::BinaryDescriptor::compute (LBD, 32 bytes)     (opencv_contrib line_descriptor)
 //     -> homogeneous line sp x ep / |.|                                       (src/LSDextractor.cpp:30-38)
 //
-// PARITY UNPINNED.  opencv / opencv_contrib 3.4.x are not vendored in the reference and not present in this
+// The wrapper (ExtractLineSegment) is pinned against the real src/LSDextractor.cpp through oracle/_ref/ref_lsd (oracle/ref_lsd_main.cpp).
+// PARITY UNPINNED below the wrapper.  opencv / opencv_contrib 3.4.x are not vendored in the reference and not present in this
 // container, and the reference has no golden vectors for this path.  Everything below the
 // LSDextractor.cpp wrapper is restated from the published 3.4 sources (lsd.cpp, LSDDetector.cpp,
 // binary_descriptor.cpp) as read; choices that could not be cross-checked are marked [assumed]:
@@ -606,6 +607,18 @@ int extract_line_segment(const uint8_t* img, int w, int h, int step, int tie_ord
         out_eq[3 * i] = l[0] / nrm; out_eq[3 * i + 1] = l[1] / nrm; out_eq[3 * i + 2] = l[2] / nrm;
     }
     return (int)kls.size();
+}
+
+// entry points for oracle/ref_lsd_main.cpp's stand-ins of cv::line_descriptor::LSDDetector / BinaryDescriptor
+void lsd_detect_keylines(const uint8_t* img, int w, int h, int step, int tie_order, std::vector<planar_keyline>& out) {
+    Lsd lsd;
+    lsd.tie_order = tie_order;
+    std::vector<LsdLine> lines;
+    lsd.detect(img, w, h, step, lines);
+    make_keylines(lines, w, h, out);
+}
+void lbd_compute_keylines(const uint8_t* img, int w, int h, int step, const std::vector<planar_keyline>& kls, uint8_t* desc) {
+    if (!kls.empty()) lbd_compute(img, w, h, step, kls, desc, nullptr);
 }
 
 }  // namespace orc

@@ -16,6 +16,14 @@ template <typename T, int R, int C, int Opt = ColMajor> struct Matrix {
     const T& operator[](int i) const { return d[i]; }
     T& operator()(int i) { return d[i]; }
     const T& operator()(int i) const { return d[i]; }
+    // (v << a, b, c), v.cross(w), v / s as the reference's LSDextractor.cpp uses them (Eigen evaluates them coefficient-wise)
+    struct CommaInit { Matrix* m; int i; template <typename U> CommaInit& operator,(U v) { m->d[i++] = (T)v; return *this; }
+                       CommaInit& operator,(const Matrix& o) { for (int k = 0; k < R * C; k++) m->d[i++] = o.d[k]; return *this; } };
+    template <typename U> CommaInit operator<<(U v) { d[0] = (T)v; return CommaInit{this, 1}; }
+    CommaInit operator<<(const Matrix& o) { for (int k = 0; k < R * C; k++) d[k] = o.d[k]; return CommaInit{this, R * C}; }
+    Matrix cross(const Matrix& o) const { static_assert(R * C == 3, "cross"); Matrix r; r.d[0] = d[1] * o.d[2] - d[2] * o.d[1]; r.d[1] = d[2] * o.d[0] - d[0] * o.d[2]; r.d[2] = d[0] * o.d[1] - d[1] * o.d[0]; return r; }
+    Matrix operator/(T s) const { Matrix r; for (int k = 0; k < R * C; k++) r.d[k] = d[k] / s; return r; }
+    T* data() { return d; }
     T& operator()(int r, int c) { return Opt == RowMajor ? d[r * C + c] : d[c * R + r]; }
     const T& operator()(int r, int c) const { return Opt == RowMajor ? d[r * C + c] : d[c * R + r]; }
 };

@@ -499,3 +499,24 @@ def is_in_frustum_lines(frame, ml, log_scale_factor, limit=0.5):
     L.orc_is_in_frustum_lines(C.byref(fv), C.c_float(log_scale_factor), p(a[0]), S, p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), C.c_float(limit),
                               p(out["in_view"]), p(out["proj"]), p(out["level"]), p(out["view_cos"]))
     return out
+
+
+def ref_lsd_path():
+    return os.path.join(ORACLE_DIR, "_ref", "ref_lsd")
+
+
+def run_ref_lsd(gray, tie_order=1):
+    """The REAL LineSegment::ExtractLineSegment (src/LSDextractor.cpp) over the restated LSD / LBD.  Returns (keylines, ldesc, eq)."""
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.raw"), os.path.join(d, "out.bin")
+        gray.tofile(fin)
+        subprocess.check_call([ref_lsd_path(), fin, str(W), str(H), str(int(tie_order)), fout])
+        buf = open(fout, "rb").read()
+    n = int(np.frombuffer(buf, "<i4", 1, 0)[0]); off = 4
+    kl = np.frombuffer(buf, KEYLINE_DTYPE, n, off).copy(); off += 68 * n
+    desc = np.frombuffer(buf, np.uint8, 32 * n, off).reshape(n, 32).copy(); off += 32 * n
+    eq = np.frombuffer(buf, "<f8", 3 * n, off).reshape(n, 3).copy()
+    return kl, desc, eq

@@ -53,3 +53,29 @@ def test_extract_line_segment_contract():
     # blank image: nothing
     kl3, *_ , nd3 = O.extract_line_segment(np.full((480, 640), 90, np.uint8))
     assert nd3 == 0 and len(kl3) == 0
+
+
+def test_wrapper_vs_real_reference_LSDextractor():
+    """LineSegment::ExtractLineSegment itself is reference code: src/LSDextractor.cpp compiled where it lies (oracle/_ref/ref_lsd) with
+    LSDDetector / BinaryDescriptor forwarding to the restatement.  Pins the call sequence, the std::sort by response (ties included:
+    the grid image below has hundreds of equal-length edges), the cut to 40, class ids and the line equations."""
+    import os
+    import pytest
+    if not os.path.exists(O.ref_lsd_path()):
+        pytest.skip("oracle/_ref/ref_lsd not built (reference tree absent)")
+    rng = np.random.default_rng(23)
+    grid = np.full((480, 640), 60, np.uint8)
+    for gy in range(0, 480, 24):
+        for gx in range(0, 640, 24):
+            if rng.random() < 0.9:
+                w, h = rng.integers(12, 20, 2)
+                grid[gy + 2:gy + 2 + h, gx + 2:gx + 2 + w] = rng.integers(120, 255)
+    rect = np.full((480, 640), 40, np.uint8); rect[100:300, 150:450] = 200
+    for img in (synth.gray_image(1234), synth.gray_image(77), grid, rect, np.full((480, 640), 90, np.uint8)):
+        for tie in (0, 1):
+            kl, desc, eq, _, _ = O.extract_line_segment(img, tie_order=tie)
+            rk, rd, re = O.run_ref_lsd(img, tie_order=tie)
+            assert len(rk) == len(kl)
+            assert rk.tobytes() == kl.tobytes()
+            np.testing.assert_array_equal(rd, desc)
+            np.testing.assert_array_equal(re, eq)
