@@ -160,13 +160,20 @@ def main():
 
     stage_names = ["orb_extract"] + (["search_by_projection", "match_orb_points", "wait_lines_planes", "pose_opt_4x10"] if full else [])
     nst = len(stage_names)
-    fork, fork2, join_p, join_l = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+    fork, fork2, fork3, join_p, join_l = (torch.cuda.Event() for _ in range(5))
 
     def step(i, evs=None, side=None):
-        # ORB and the point matchers first (they need most of a CU's LDS and would otherwise queue behind the plane kernel),
-        # then the two sequential extractors side by side: one PEAC workgroup (150 KB LDS) and one LSD wavefront (8 KB) share a CU.
+        # Three streams, as the reference's three extraction threads.  The line detector's preprocessing (Gaussians, gradients, pixel ordering:
+        # throughput kernels with large LDS tiles) runs beside ORB + the point matchers; then the two sequential extractors run side by side
+        # on every CU: one PEAC workgroup (149 KB LDS) and one LSD wavefront (8 KB).  PoseOptimization waits for all of them.
         cur, prev = i & 1, (i & 1) ^ 1
         if evs: evs[0].record(stream)
+        if full:
+            fork.record(stream)
+            s_lsd.wait_event(fork)
+            if side: side[2].record(s_lsd)
+            check(L.planar_lsd_preprocess_dev(ls.h, frames.data_ptr(), B, W, W * H))                                     # stream s_lsd
+            fork2.record(s_lsd)
         ex.extract_dev(frames.data_ptr(), d_kps.data_ptr(), d_desc[cur].data_ptr(), d_n[cur].data_ptr(), B)
         if evs: evs[1].record(stream)
         if full:
@@ -178,14 +185,11 @@ def main():
                                                 d_n[prev].data_ptr(), ex.kp_cap, has_mp.data_ptr(), outl.data_ptr(), B, cur_match.data_ptr(),
                                                 npair.data_ptr()))
             if evs: evs[3].record(stream)
-            fork.record(stream)
-            s_lsd.wait_event(fork)
-            if side: side[2].record(s_lsd)
-            check(L.planar_lsd_preprocess_dev(ls.h, frames.data_ptr(), B, W, W * H))                                     # stream s_lsd (throughput kernels)
-            fork2.record(s_lsd)
-            s_peac.wait_event(fork2)
+            fork3.record(stream)
+            s_peac.wait_event(fork2); s_peac.wait_event(fork3)        # after the throughput kernels of both other streams
             if side: side[0].record(s_peac)
             pd.segment_dev(depth.data_ptr(), d_lab.data_ptr(), d_pl.data_ptr(), d_npl.data_ptr(), B)                       # stream s_peac
+            s_lsd.wait_event(fork3)
             check(L.planar_lsd_detect_dev(ls.h, B, 40, d_kl.data_ptr(), d_ldesc.data_ptr(), d_leq.data_ptr(), d_nl.data_ptr()))  # stream s_lsd
             if side: side[1].record(s_peac); side[3].record(s_lsd)
             join_p.record(s_peac); join_l.record(s_lsd)
@@ -297,7 +301,7 @@ def main():
             i = n % nsrc
             t1 = time.perf_counter(); kp, de = o.extract(gray_src[i]); per["orb"] += time.perf_counter() - t1
             if full:
-                t1 = time.perf_counter(); ol.extract_line_segment(gray_src[i], tie_order=1); per["lsd"] += time.perf_counter() - t1
+                t1 = time.perf_counter(); ol.extract_line_segment(gray_src[i], tie_order=0); per["lsd"] += time.perf_counter() - t1
                 t1 = time.perf_counter(); ol.peac_run(depth_src[i]); per["peac"] += time.perf_counter() - t1
                 t1 = time.perf_counter()
                 ol.match_orb_points(de, prev_desc, np.ones(len(prev_desc), np.uint8), np.zeros(len(prev_desc), np.uint8), np.full(len(de), -1, np.int32))

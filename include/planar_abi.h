@@ -356,12 +356,14 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
 void planar_lsd_destroy(planar_lsd* lsd);
 int planar_lsd_max_segments(void);   /* raw LSD segments kept per frame before the top-`max_lines` cut (2048) */
 int planar_lsd_scaled_size(planar_lsd* lsd, int* w, int* h);   /* the 0.8x working resolution */
+int planar_lsd_set_tie_order(planar_lsd* lsd, int tie_order);   /* 0 (default): libstdc++ std::sort order, 1: raster order */
 /* gray     : B frames of 8-bit gray (the `img` argument), pitch / frame_stride in bytes
  * max_lines: lsdNFeatures (40 in the reference); per-frame stride of the outputs
  * keylines : [B][max_lines] cv::line_descriptor::KeyLine records   ldesc: [B][max_lines][32] LBD bytes
  * line_eq  : [B][max_lines][3] keylineFunctions (sp x ep, normalised)   n_lines: [B] keylines.size()
- * Pixels of equal gradient bin are visited in raster order (the reference library's std::sort leaves that order
- * to libstdc++). */
+ * Pixels of equal gradient bin are visited in the order libstdc++'s std::sort leaves them, as in the reference library
+ * (lsd.cpp sorts with std::sort); planar_lsd_set_tie_order(lsd, 1) selects raster order inside a bin instead (the original
+ * LSD's list order). */
 int planar_lsd_extract(planar_lsd* lsd, const uint8_t* gray, int B, int pitch, int64_t frame_stride, int max_lines, planar_keyline* keylines,
                        uint8_t* ldesc, double* line_eq, int32_t* n_lines);
 int planar_lsd_extract_dev(planar_lsd* lsd, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride, int max_lines,

@@ -174,25 +174,385 @@ __device__ inline int block_exscan256(int v, int* wsum, int* total) {
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
-    __shared__ int cnt[32 * 256];
+__device__ __forceinline__ void wave_sync();
+__device__ __forceinline__ void lds_sync();
+// libstdc++ std::sort(ordered_points, compare_norm) reproduced in parallel (tie_order 0).  lsd.cpp sorts all (w-1)(h-1) pixels by their
+// 1024-bin gradient norm with std::sort, so pixels of equal bin end up in the order libstdc++'s introsort leaves them.  That order is a
+// deterministic function of the bin sequence:
+//   * __introsort_loop: every Hoare partition (median of first+1 / mid / last-1 moved to the front, unguarded scans) swaps the k-th element
+//     that stops the left scan (bin <= pivot, ascending position) with the k-th that stops the right scan (bin >= pivot, descending position)
+//     for k < m = #{k : L_k < R_k}, and cuts at min(L_m, R_{m-1}).  Stops, m and the swaps are prefix-scan / ballot computations;
+//     the recursion tree is walked level by level (ranges are disjoint), ranges of <= 4096 elements are finished inside LDS by one wavefront
+//     (<= 64 elements: in registers, one element per lane, all sub-ranges of the window stepping together);
+//   * __final_insertion_sort is a stable sort of the arrangement the partitions leave = the two radix passes below.
+// Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py).  A depth-limit overflow (heap-sort fallback of introsort)
+// cannot be reproduced this way and raises status 2; it needs ~34 unbalanced partitions in a row and does not occur on 10-bit keys.
+constexpr int SORT_SMALL = 4096;    // finished by one wavefront
+constexpr int SORT_STAGE = 16384;   // staged in LDS by the workgroup
+struct SortRange { int f, l, d; };
+
+// one wavefront; arr[f, l) in LDS, l - f > 16; Lb / Rb are LDS scratch arrays indexed like arr.  Returns the cut.
+__device__ __forceinline__ int partition_step(uint32_t* arr, uint16_t* Lb, uint16_t* Rb, int f, int l, int lane) {
+    {   // __move_median_to_first(first, first + 1, mid, last - 1), comp(a, b) = a.norm > b.norm
+        const int A = f + 1, B = f + (l - f) / 2, C = l - 1;
+        const uint32_t a = arr[A] >> 20, bq = arr[B] >> 20, c = arr[C] >> 20;
+        int t;
+        if (a > bq) { if (bq > c) t = B; else if (a > c) t = C; else t = A; }
+        else if (a > c) t = A;
+        else if (bq > c) t = C;
+        else t = B;
+        if (lane == 0) { const uint32_t x = arr[f]; arr[f] = arr[t]; arr[t] = x; }
+        lds_sync();
+    }
+    const uint32_t pv = arr[f] >> 20;
+    constexpr int U = 4;                                      // chunks per iteration: the LDS reads are issued together
+    int cntL = 0, cntR = 0;
+    for (int base = f + 1; base < l; base += 64 * U) {        // stops of the left scan: !(x > pivot), ascending
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < l ? arr[i] >> 20 : 0xffffffffu; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + 64 * u + lane;
+            const bool isL = i < l && !(v[u] > pv);
+            const unsigned long long m = __ballot(isL);
+            if (isL) Lb[f + 1 + cntL + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            cntL += __popcll(m);
+        }
+    }
+    for (int base = l - 1; base >= f + 1; base -= 64 * U) {   // stops of the right scan: !(pivot > x), descending
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = base - 64 * u - lane; v[u] = i >= f + 1 ? arr[i] >> 20 : 0u; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base - 64 * u - lane;
+            const bool isR = i >= f + 1 && !(pv > v[u]);
+            const unsigned long long m = __ballot(isR);
+            if (isR) Rb[f + 1 + cntR + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            cntR += __popcll(m);
+        }
+    }
+    lds_sync();
+    const int kmax = min(cntL, cntR);
+    int m = 0;
+    for (int kb = 0; kb < kmax; kb += 64) {
+        const int k = kb + lane;
+        int Lk = 0, Rk = 0;
+        bool good = false;
+        if (k < kmax) { Lk = Lb[f + 1 + k]; Rk = Rb[f + 1 + k]; good = Lk < Rk; }
+        const int ng = __popcll(__ballot(good));              // L ascending, R descending: the good pairs are a prefix
+        if (good) { const uint32_t x = arr[Lk]; arr[Lk] = arr[Rk]; arr[Rk] = x; }
+        m += ng;
+        if (ng < min(64, kmax - kb)) break;
+    }
+    lds_sync();
+    int cut = 0x7fffffff;
+    if (m < cntL) cut = min(cut, (int)Lb[f + 1 + m]);
+    if (m > 0) cut = min(cut, (int)Rb[f + 1 + m - 1]);
+    return cut;
+}
+
+__device__ __forceinline__ int nth_set_from_bottom(unsigned long long m, int k) {   // position of the (k+1)-th set bit from the LSB
+    int pos = 0;
+    for (int width = 32; width >= 1; width >>= 1) {
+        const unsigned long long low = m & ((1ull << width) - 1ull);
+        const int c = __popcll(low);
+        if (k >= c) { k -= c; m >>= width; pos += width; } else m = low;
+    }
+    return pos;
+}
+__device__ __forceinline__ int nth_set_from_top(unsigned long long m, int k) { return 63 - nth_set_from_bottom(__brevll(m), k); }
+
+// A window of <= 64 elements, one per lane, finished in registers: every lane carries the bounds [sf, sl) and the depth budget of the
+// range it currently belongs to, and all ranges of the window take their next partition step at the same time (same arithmetic as
+// partition_step: median to the front, k-th left stop <-> k-th right stop for k < m, cut = min(L_m, R_{m-1})).
+__device__ bool sort_window(uint32_t* buf, int f, int l, int d0, int lane) {
+    const int sz = l - f;
+    uint32_t x = lane < sz ? buf[f + lane] : 0u;
+    int sf = 0, sl = lane < sz ? sz : 0, d = d0;
+    bool overflow = false;
+    while (true) {
+        const bool active = sl - sf > 16;
+        if (!__ballot(active)) break;
+        if (active && d == 0) overflow = true;
+        --d;
+        // __move_median_to_first
+        const int A = sf + 1, Bm = sf + (sl - sf) / 2, Cc = sl - 1;
+        const uint32_t a = (uint32_t)__shfl((int)x, A & 63, 64) >> 20, bq = (uint32_t)__shfl((int)x, Bm & 63, 64) >> 20, c = (uint32_t)__shfl((int)x, Cc & 63, 64) >> 20;
+        int t;
+        if (a > bq) { if (bq > c) t = Bm; else if (a > c) t = Cc; else t = A; }
+        else if (a > c) t = A;
+        else if (bq > c) t = Cc;
+        else t = Bm;
+        const uint32_t xf = (uint32_t)__shfl((int)x, sf & 63, 64), xt = (uint32_t)__shfl((int)x, t & 63, 64);
+        if (active && lane == sf) x = xt; else if (active && lane == t) x = xf;
+        const uint32_t pv = (uint32_t)__shfl((int)x, sf & 63, 64) >> 20;
+        const bool inside = active && lane > sf && lane < sl;
+        const unsigned long long segmask = active ? (((sl >= 64 ? ~0ull : ((1ull << sl) - 1ull)) >> (sf + 1)) << (sf + 1)) : 0ull;
+        const bool isL = inside && !((x >> 20) > pv), isR = inside && !(pv > (x >> 20));
+        const unsigned long long mL = __ballot(isL) & segmask, mR = __ballot(isR) & segmask;
+        const int cntL = __popcll(mL), cntR = __popcll(mR);
+        int src = lane;
+        bool goodL = false;
+        if (isL) { const int k = __popcll(mL & ((1ull << lane) - 1ull)); if (k < cntR) { const int pr = nth_set_from_top(mR, k); if (lane < pr) { goodL = true; src = pr; } } }
+        if (isR && !goodL) { const int k = lane == 63 ? 0 : __popcll(mR >> (lane + 1)); if (k < cntL) { const int pl = nth_set_from_bottom(mL, k); if (pl < lane) src = pl; } }
+        const int m = __popcll(__ballot(goodL) & segmask);
+        x = (uint32_t)__shfl((int)x, src, 64);
+        int cut = 0x7fffffff;
+        if (active) {
+            if (m < cntL) cut = min(cut, nth_set_from_bottom(mL, m));
+            if (m > 0) cut = min(cut, nth_set_from_top(mR, m - 1));
+            if (lane < cut) sl = cut; else sf = cut;
+        }
+    }
+    if (lane < sz) buf[f + lane] = x;
+    return !__ballot(overflow);
+}
+
+// One Hoare partition of arr[f, l) by the whole workgroup (256 threads); same arithmetic as partition_step.  Works on global memory
+// (IdxT = uint32_t) and on a range staged in LDS (IdxT = uint16_t); one instantiation per address space.  Returns the cut in every thread.
+// bc[0..3]: pivot, swapped position t, old arr[f], old arr[t] (threads patch their reads instead of waiting for the median swap to land).
+template <typename IdxT>
+__device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, int f, int l, int tid, int* s_wl, int* s_wr, int* bc) {
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {   // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
+        const uint32_t xa = arr[A], xb = arr[Bm], xc = arr[Cc], xf = arr[f];
+        const uint32_t a = xa >> 20, bq = xb >> 20, c = xc >> 20;
+        int t; uint32_t xt;
+        if (a > bq) { if (bq > c) { t = Bm; xt = xb; } else if (a > c) { t = Cc; xt = xc; } else { t = A; xt = xa; } }
+        else if (a > c) { t = A; xt = xa; }
+        else if (bq > c) { t = Cc; xt = xc; }
+        else { t = Bm; xt = xb; }
+        arr[f] = xt; arr[t] = xf;
+        bc[0] = (int)(xt >> 20); bc[1] = t; bc[2] = (int)xf;
+    }
+    __syncthreads();
+    const uint32_t pv = (uint32_t)bc[0];
+    const int tpos = bc[1];
+    const uint32_t tval = (uint32_t)bc[2] >> 20;                  // the element now at position t (the old front)
+    // each wavefront owns a contiguous quarter of [f+1, l) and walks it in coalesced chunks, 8 chunks of loads in flight
+    constexpr int U = 8;
+    const int len = l - (f + 1), qlen = (len + 3) / 4;
+    const int q0 = f + 1 + min(len, wave * qlen), q1 = f + 1 + min(len, wave * qlen + qlen);
+    int cl = 0, cr = 0;
+    for (int base = q0; base < q1; base += 64 * U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : arr[i] >> 20) : 0xffffffffu; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool in = base + 64 * u + lane < q1;
+            cl += __popcll(__ballot(in && !(v[u] > pv)));
+            cr += __popcll(__ballot(in && !(pv > v[u])));
+        }
+    }
+    if (lane == 0) { s_wl[wave] = cl; s_wr[wave] = cr; }
+    __syncthreads();
+    int totL = 0, totR = 0, wl = f + 1, ra = 0;
+    for (int q = 0; q < 4; q++) { totL += s_wl[q]; totR += s_wr[q]; if (q < wave) { wl += s_wl[q]; ra += s_wr[q]; } }
+    for (int base = q0; base < q1; base += 64 * U) {             // one pass writes both stop lists; R is descending: slot = totR - 1 - ascending rank
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : arr[i] >> 20) : 0xffffffffu; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + 64 * u + lane;
+            const bool isL = i < q1 && !(v[u] > pv), isR = i < q1 && !(pv > v[u]);
+            const unsigned long long mkL = __ballot(isL), mkR = __ballot(isR);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (isL) Lb[wl + __popcll(mkL & below)] = (IdxT)i;
+            if (isR) Rb[f + 1 + (totR - 1 - (ra + __popcll(mkR & below)))] = (IdxT)i;
+            wl += __popcll(mkL); ra += __popcll(mkR);
+        }
+    }
+    if (tid == 0) bc[3] = 0;
+    __syncthreads();
+    const int kmax = min(totL, totR);
+    int good = 0;
+    constexpr int PU = 4;                                         // pairs in flight per thread (two dependent round trips each)
+    for (int k0 = tid; k0 < kmax; k0 += 256 * PU) {
+        int Lk[PU], Rk[PU];
+        uint32_t xl[PU], xr[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) { const int k = k0 + 256 * u; Lk[u] = k < kmax ? (int)Lb[f + 1 + k] : 1; Rk[u] = k < kmax ? (int)Rb[f + 1 + k] : 0; }
+#pragma unroll
+        for (int u = 0; u < PU; u++) if (Lk[u] < Rk[u]) { xl[u] = arr[Lk[u]]; xr[u] = arr[Rk[u]]; }
+#pragma unroll
+        for (int u = 0; u < PU; u++) if (Lk[u] < Rk[u]) { arr[Lk[u]] = xr[u]; arr[Rk[u]] = xl[u]; good++; }
+    }
+    for (int o = 32; o >= 1; o >>= 1) good += __shfl_xor(good, o, 64);
+    if (lane == 0 && good) atomicAdd(&bc[3], good);
+    __syncthreads();
+    const int m = bc[3];                                          // the swapped pairs are a prefix of the pair list
+    int cut = 0x7fffffff;
+    if (m < totL) cut = min(cut, (int)Lb[f + 1 + m]);
+    if (m > 0) cut = min(cut, (int)Rb[f + 1 + m - 1]);
+    __syncthreads();
+    return cut;
+}
+
+// ---- K3: the visiting order: descending 1024-bin order; ties per plan->tie_order ---------------------------------------------------
+__global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int tie_order) {
+    extern __shared__ __align__(16) uint8_t sort_lds[];
     __shared__ int wsum[4];
+    __shared__ int s_ncur, s_nnext, s_nsmall, s_wl[4], s_wr[4], s_bc[4];
+    __shared__ int s_loc[2][16][3], s_nloc[2], s_wave[64][3], s_nwave;
+    __shared__ int s_stack[4][48][3];
+    __shared__ short s_leaf[4][288][3];
+    int* cnt = (int*)sort_lds;                                  // [32 * 256] radix counters (passes A / B)
     const Plan& P = *plan;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
     const float* ang = (const float*)(F + P.off_ang);
     const uint32_t* g2a = (const uint32_t*)(F + P.off_g2);
-    uint32_t* tmp = (uint32_t*)(F + P.off_tmp);
+    uint32_t* arr = (uint32_t*)(F + P.off_tmp);                 // bin << 20 | pixel, all (w-1)(h-1) gradient pixels
     uint32_t* ord = (uint32_t*)(F + P.off_ord);
+    uint32_t* ordr = (uint32_t*)(F + P.off_ordr);
+    uint32_t* tmpA = (uint32_t*)(F + P.off_reg);                // pass A output (the range lists are dead by then)
     Misc* misc = miscs + b;
-    const int NP = P.w * P.h;
+    const int w1 = P.w - 1, n = w1 * (P.h - 1);
     const double max_grad = misc->g2max ? sqrt(misc->g2max / 4.0) : -1.0;
     const double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
-    // pass A: pixels (raster) -> tmp, by the low 5 bits of key = 1023 - bin
-    const int segA = (NP + 255) / 256, a0 = min(NP, tid * segA), a1 = min(NP, a0 + segA);
+    for (int i = tid; i < n; i += 256) {
+        const int y = i / w1, x = i - y * w1, pix = y * P.w + x;
+        arr[i] = ((uint32_t)int(sqrt(g2a[pix] / 4.0) * bin_coef) << 20) | (uint32_t)pix;
+    }
+    __threadfence_block();
+    __syncthreads();
+    long long ts0 = __builtin_readcyclecounter(), ts1 = ts0, ts2 = ts0;
+    if (tie_order == 0 && n > 16) {
+        const int cap = n / 17 + 16;
+        SortRange* cur = (SortRange*)(F + P.off_reg);
+        SortRange* next = cur + cap;
+        SortRange* staged = next + cap;
+        if (tid == 0) { int lg = 0; for (int t = n; t > 1; t >>= 1) lg++; cur[0] = SortRange{0, n, 2 * lg}; s_ncur = 1; s_nnext = 0; s_nsmall = 0; }
+        __syncthreads();
+        // tier 1: ranges too large for LDS, partitioned in global memory by the whole workgroup, one recursion level per iteration
+        while (true) {
+            const int ncur = s_ncur;
+            if (ncur == 0) break;
+            for (int r = 0; r < ncur; r++) {
+                const SortRange R = cur[r];
+                if (R.l - R.f <= 16) continue;
+                if (R.l - R.f <= SORT_STAGE) { if (tid == 0) staged[atomicAdd(&s_nsmall, 1)] = R; continue; }
+                if (R.d == 0) { if (tid == 0) misc->status = 2; continue; }
+                const int cut = wg_partition<uint32_t>(arr, ord, ordr, R.f, R.l, tid, s_wl, s_wr, s_bc);
+                if (tid == 0) { const int k = atomicAdd(&s_nnext, 2); next[k] = SortRange{cut, R.l, R.d - 1}; next[k + 1] = SortRange{R.f, cut, R.d - 1}; }
+            }
+            __syncthreads();
+            if (tid == 0) { s_ncur = s_nnext; s_nnext = 0; }
+            SortRange* t = cur; cur = next; next = t;
+            __syncthreads();
+        }
+        ts1 = __builtin_readcyclecounter();
+        // tier 2: a range of <= 16384 elements is staged in LDS once and its whole recursion finished there:
+        //   > 4096: workgroup partitions;  <= 4096: one wavefront per sub-range (ballot partitions);  <= 64: one LANE per sub-range.
+        uint32_t* sbuf = (uint32_t*)sort_lds;
+        uint16_t* Ls = (uint16_t*)(sbuf + SORT_STAGE);
+        uint16_t* Rs = Ls + SORT_STAGE;
+        const int nstaged = s_nsmall;
+        for (int sr = 0; sr < nstaged; sr++) {
+            const SortRange R = staged[sr];
+            const int sz = R.l - R.f;
+            for (int i = tid; i < sz; i += 256) sbuf[i] = arr[R.f + i];
+            if (tid == 0) { s_loc[0][0][0] = 0; s_loc[0][0][1] = sz; s_loc[0][0][2] = R.d; s_nloc[0] = 1; s_nloc[1] = 0; s_nwave = 0; }
+            __syncthreads();
+            for (int lev = 0;; lev ^= 1) {
+                const int nc = s_nloc[lev];
+                if (nc == 0) break;
+                for (int r = 0; r < nc; r++) {
+                    const int f = s_loc[lev][r][0], l = s_loc[lev][r][1], d = s_loc[lev][r][2];
+                    if (l - f <= 16) continue;
+                    if (l - f <= SORT_SMALL) { if (tid == 0) { const int k = s_nwave++; s_wave[k][0] = f; s_wave[k][1] = l; s_wave[k][2] = d; } continue; }
+                    if (d == 0) { if (tid == 0) misc->status = 2; continue; }
+                    const int cut = wg_partition<uint16_t>(sbuf, Ls, Rs, f, l, tid, s_wl, s_wr, s_bc);
+                    if (tid == 0) {
+                        const int k = s_nloc[lev ^ 1]; s_nloc[lev ^ 1] = k + 2;
+                        s_loc[lev ^ 1][k][0] = cut; s_loc[lev ^ 1][k][1] = l; s_loc[lev ^ 1][k][2] = d - 1;
+                        s_loc[lev ^ 1][k + 1][0] = f; s_loc[lev ^ 1][k + 1][1] = cut; s_loc[lev ^ 1][k + 1][2] = d - 1;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) s_nloc[lev] = 0;
+                __syncthreads();
+            }
+            const int nwave = s_nwave;
+            for (int r = wave; r < nwave; r += 4) {
+                int sp = 0;
+                if (lane == 0) { s_stack[wave][0][0] = s_wave[r][0]; s_stack[wave][0][1] = s_wave[r][1]; s_stack[wave][0][2] = s_wave[r][2]; }
+                sp = 1;
+                int nleaf = 0;                                    // sub-ranges of <= 64 elements, finished below one per LANE
+                lds_sync();
+                while (sp > 0) {
+                    sp--;
+                    int f = ((volatile int*)s_stack[wave][sp])[0], l = ((volatile int*)s_stack[wave][sp])[1], d = ((volatile int*)s_stack[wave][sp])[2];
+                    while (l - f > 16) {
+                        if (l - f <= 64) { if (lane == 0) { s_leaf[wave][nleaf][0] = (short)f; s_leaf[wave][nleaf][1] = (short)l; s_leaf[wave][nleaf][2] = (short)d; } nleaf++; break; }
+                        if (d == 0) { if (lane == 0) misc->status = 2; break; }
+                        --d;
+                        const int cut = partition_step(sbuf, Ls, Rs, f, l, lane);
+                        if (sp < 47) { if (lane == 0) { s_stack[wave][sp][0] = cut; s_stack[wave][sp][1] = l; s_stack[wave][sp][2] = d; } sp++; }
+                        else if (lane == 0) misc->status = 2;
+                        lds_sync();
+                        l = cut;
+                    }
+                }
+                lds_sync();
+                // leaves: 64 at a time, every lane runs libstdc++'s sequential __introsort_loop on its own <= 64 elements (in LDS)
+                for (int l0 = 0; l0 < nleaf; l0 += 64) {
+                    if (l0 + lane < nleaf) {
+                        int stf[6], stl[6], std_[6], q = 0;
+                        stf[0] = s_leaf[wave][l0 + lane][0]; stl[0] = s_leaf[wave][l0 + lane][1]; std_[0] = s_leaf[wave][l0 + lane][2]; q = 1;
+                        while (q > 0) {
+                            q--;
+                            int f = stf[q], l = stl[q], d = std_[q];
+                            while (l - f > 16) {
+                                if (d == 0) { misc->status = 2; break; }
+                                --d;
+                                const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
+                                const uint32_t a = sbuf[A] >> 20, bq = sbuf[Bm] >> 20, c = sbuf[Cc] >> 20;
+                                int t;
+                                if (a > bq) { if (bq > c) t = Bm; else if (a > c) t = Cc; else t = A; }
+                                else if (a > c) t = A;
+                                else if (bq > c) t = Cc;
+                                else t = Bm;
+                                { const uint32_t x = sbuf[f]; sbuf[f] = sbuf[t]; sbuf[t] = x; }
+                                const uint32_t pv = sbuf[f] >> 20;
+                                int lo = f + 1, hi = l;
+                                while (true) {                    // __unguarded_partition
+                                    while ((sbuf[lo] >> 20) > pv) ++lo;
+                                    --hi;
+                                    while (pv > (sbuf[hi] >> 20)) --hi;
+                                    if (!(lo < hi)) break;
+                                    const uint32_t x = sbuf[lo]; sbuf[lo] = sbuf[hi]; sbuf[hi] = x;
+                                    ++lo;
+                                }
+                                if (q < 6) { stf[q] = lo; stl[q] = l; std_[q] = d; q++; } else misc->status = 2;
+                                l = lo;
+                            }
+                        }
+                    }
+                }
+                lds_sync();
+            }
+            __syncthreads();
+            for (int i = tid; i < sz; i += 256) arr[R.f + i] = sbuf[i];
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    ts2 = __builtin_readcyclecounter();
+    // __final_insertion_sort == stable sort of the current arrangement by descending bin: two 5-bit LSD radix passes with thread-contiguous
+    // segments (order inside a bin = array order).  Undefined pixels took part in the partitions above; they are dropped here.
+    const int segA = (n + 255) / 256, a0 = min(n, tid * segA), a1 = min(n, a0 + segA);
     for (int d = 0; d < 32; d++) cnt[d * 256 + tid] = 0;
-    for (int i = a0; i < a1; i++)
-        if (ang[i] != NOTDEF_F) { const int key = (N_BINS - 1) - int(sqrt(g2a[i] / 4.0) * bin_coef); cnt[(key & 31) * 256 + tid]++; }
+    for (int i = a0; i < a1; i++) {
+        const uint32_t e = arr[i];
+        if (ang[e & 0xfffffu] != NOTDEF_F) cnt[(((N_BINS - 1) - (int)(e >> 20)) & 31) * 256 + tid]++;
+    }
     __syncthreads();
     int total;
     {
@@ -202,22 +562,24 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
         for (int k = 0; k < 32; k++) { const int c = cnt[tid * 32 + k]; cnt[tid * 32 + k] = run; run += c; }
     }
     __syncthreads();
-    for (int i = a0; i < a1; i++)
-        if (ang[i] != NOTDEF_F) {
-            const int key = (N_BINS - 1) - int(sqrt(g2a[i] / 4.0) * bin_coef);
-            // the slot in tmp doubles as the pixel's compact index among the defined pixels (its `used` flag lives there)
+    for (int i = a0; i < a1; i++) {
+        const uint32_t e = arr[i];
+        const uint32_t pix = e & 0xfffffu;
+        if (ang[pix] != NOTDEF_F) {
+            const int key = (N_BINS - 1) - (int)(e >> 20);
+            // the slot doubles as the pixel's compact index among the defined pixels (its `used` flag lives there)
             const int slot = cnt[(key & 31) * 256 + tid]++;
-            tmp[slot] = ((uint32_t)key << 20) | (uint32_t)i;
-            ((float*)(F + P.off_pix))[(size_t)i * 4 + 3] = __uint_as_float((uint32_t)slot);
+            tmpA[slot] = ((uint32_t)key << 20) | pix;
+            ((float*)(F + P.off_pix))[(size_t)pix * 4 + 3] = __uint_as_float((uint32_t)slot);
         }
+    }
     const int N = total;
     __threadfence_block();
     __syncthreads();
-    // pass B: tmp -> ord, by the high 5 bits
     const int segB = (N + 255) / 256, b0 = min(N, tid * segB), b1 = min(N, b0 + segB);
     for (int d = 0; d < 32; d++) cnt[d * 256 + tid] = 0;
     __syncthreads();
-    for (int i = b0; i < b1; i++) cnt[((tmp[i] >> 25) & 31) * 256 + tid]++;
+    for (int i = b0; i < b1; i++) cnt[((tmpA[i] >> 25) & 31) * 256 + tid]++;
     __syncthreads();
     {
         int local = 0;
@@ -226,14 +588,13 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
         for (int k = 0; k < 32; k++) { const int c = cnt[tid * 32 + k]; cnt[tid * 32 + k] = run; run += c; }
     }
     __syncthreads();
-    uint32_t* ordr = (uint32_t*)(F + P.off_ordr);
     for (int i = b0; i < b1; i++) {
-        const uint32_t e = tmp[i];
+        const uint32_t e = tmpA[i];
         const int pos = cnt[((e >> 25) & 31) * 256 + tid]++;
         ord[pos] = e & 0xfffffu;
         ordr[pos] = (uint32_t)i;
     }
-    if (tid == 0) misc->n_ord = N;
+    if (tid == 0) { misc->n_ord = N; misc->t[5] = ts1 - ts0; misc->t[6] = ts2 - ts1; misc->t[7] = __builtin_readcyclecounter() - ts2; }
 }
 
 // ---- K4: the sequential detector, one wavefront per frame -----------------------------------------------------------
@@ -1086,6 +1447,8 @@ struct planar_lsd {
     DevBuf d_in, d_kl, d_desc, d_eq, d_n;   // staging for the host-pointer entry point
     int stage_lines = 0;
     int pre_B = 0;
+    int tie_order = 0;   // 0: libstdc++ std::sort order inside a gradient bin (what the reference library produces), 1: raster order
+    int sort_smem = 0;
 };
 
 // host mirrors of the oracle's coefficient tables (same expressions, same libm)
@@ -1193,7 +1556,9 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     if (e == hipSuccess) e = hipMemcpy(o->d_cx.p, cx.data(), cx.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_cy.p, cy.data(), cy.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_taps.p, taps, sizeof(taps), hipMemcpyHostToDevice);
+    o->sort_smem = std::max(32 * 256 * 4, lsd::SORT_STAGE * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_detect, hipFuncAttributeMaxDynamicSharedMemorySize, o->detect_smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_sort, hipFuncAttributeMaxDynamicSharedMemorySize, o->sort_smem);
     if (e != hipSuccess) { delete o; set_error("planar_lsd_create: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
     *out = o;
     return PLANAR_OK;
@@ -1216,7 +1581,7 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     hipLaunchKernelGGL(lsd::lsd_gauss<5>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>() + 8, ws, P.frame_bytes, P.off_blur5);
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
     hipLaunchKernelGGL(lsd::lbd_sobel, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, dP, ws);
-    hipLaunchKernelGGL(lsd::lsd_sort, dim3(B), dim3(256), 0, st, dP, ws, dm);
+    hipLaunchKernelGGL(lsd::lsd_sort, dim3(B), dim3(256), o->sort_smem, st, dP, ws, dm, o->tie_order);
     PLANAR_HIP_CHECK(hipGetLastError());
     o->pre_B = B;
     return PLANAR_OK;
@@ -1302,6 +1667,7 @@ int planar_lsd_read_stage(planar_lsd* o, int frame, int stage, void* out, int64_
             long long* o64 = (long long*)out;
             for (int i = 0; i < 5; i++) o64[i] = m.t[i];
             o64[5] = m.n_ord; o64[6] = m.n_grown_px;
+            if (out_bytes >= 80) { o64[7] = m.t[5]; o64[8] = m.t[6]; o64[9] = m.t[7]; }   // lsd_sort: workgroup tier, LDS tier, radix passes
             return PLANAR_OK;
         }
         default: set_error("planar_lsd_read_stage: unknown stage"); return PLANAR_EINVAL;
@@ -1309,6 +1675,12 @@ int planar_lsd_read_stage(planar_lsd* o, int frame, int stage, void* out, int64_
     PLANAR_REQUIRE((int64_t)bytes <= out_bytes, PLANAR_EINVAL, "buffer too small");
     if (bytes) PLANAR_HIP_CHECK(hipMemcpy(out, F + off, bytes, hipMemcpyDeviceToHost));
     return ret;
+}
+
+int planar_lsd_set_tie_order(planar_lsd* o, int tie_order) {
+    PLANAR_REQUIRE(o && (tie_order == 0 || tie_order == 1), PLANAR_EINVAL, "tie_order must be 0 (libstdc++ std::sort order) or 1 (raster order)");
+    o->tie_order = tie_order;
+    return PLANAR_OK;
 }
 
 int planar_lsd_scaled_size(planar_lsd* o, int* w, int* h) {

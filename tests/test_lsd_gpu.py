@@ -1,4 +1,4 @@
-"""GPU parity: the HIP line extractor through the C ABI against oracle/lsd_oracle.cpp (tie_order = 1).
+"""GPU parity: the HIP line extractor through the C ABI against oracle/lsd_oracle.cpp (both tie orders; 0 = the real std::sort).
 Rows a10, a11, a12 of SURVEY.md §8.  Integer stages, the visiting order, keyline fields and LBD bytes must be
 identical; segment endpoints are float32 roundings of FP64 results whose only cross-platform difference is the
 last-bit behaviour of libm (cos/sin/log/exp/pow), so they are compared exactly as well and any mismatch is reported."""
@@ -34,12 +34,14 @@ def test_device_std_sort_matches_libstdcxx(ctx):
         np.testing.assert_array_equal(perm, rp)
 
 
+@pytest.mark.parametrize("tie", [0, 1])
 @pytest.mark.parametrize("seed", [1234, 77])
-def test_lsd_stages_and_segments(ctx, seed):
+def test_lsd_stages_and_segments(ctx, seed, tie):
+    """tie = 0: pixels of one gradient bin in the order the REAL libstdc++ std::sort leaves them (oracle runs std::sort); 1: raster order."""
     from planarslam_amd.lines import LineSegment
     img = synth.gray_image(seed)
-    ref = O.lsd_detect(img, tie_order=1, want_stages=True)
-    ls = LineSegment(640, 480, 1, ctx)
+    ref = O.lsd_detect(img, tie_order=tie, want_stages=True)
+    ls = LineSegment(640, 480, 1, ctx, tie_order=tie)
     ls.ExtractLineSegment(img)
     ang = ls.read_stage(0, 0)
     ref_deg_defined = ref["angles"] != -1024.0
@@ -62,7 +64,7 @@ def test_extract_line_segment_batch(ctx):
     from planarslam_amd.lines import LineSegment
     imgs = np.stack([synth.gray_image(1234), synth.gray_image(5), np.full((480, 640), 90, np.uint8), synth.gray_image(9)])
     imgs[1, 100:300, 150:450] = 220
-    ls = LineSegment(640, 480, 4, ctx)
+    ls = LineSegment(640, 480, 4, ctx, tie_order=1)
     kl, desc, eq, n = ls.ExtractLineSegment(imgs)
     for b in range(4):
         rk, rd, re, _, nd = O.extract_line_segment(imgs[b], tie_order=1)
@@ -80,7 +82,7 @@ def test_few_lines_keep_detection_order(ctx):
     img[100:300, 150:450] = 200
     ls = LineSegment(640, 480, 1, ctx)
     kl, desc, eq, n = ls.ExtractLineSegment(img)
-    rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=1)
+    rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=0)
     assert n[0] == len(rk) == nd and 1 <= nd <= 40
     np.testing.assert_array_equal(kl[0, :nd]["class_id"], np.arange(nd))
     np.testing.assert_array_equal(desc[0, :nd], rd)
@@ -92,14 +94,14 @@ def test_noisy_image_uses_global_used_tail(ctx):
     rng = np.random.default_rng(17)
     img = synth.gray_image(3).astype(np.int32) + rng.integers(-40, 41, (480, 640))
     img = np.clip(img, 0, 255).astype(np.uint8)
-    ref = O.lsd_detect(img, tie_order=1, want_stages=True)
+    ref = O.lsd_detect(img, tie_order=0, want_stages=True)
     assert (ref["angles"] != -1024.0).sum() > 40000
     ls = LineSegment(640, 480, 1, ctx)
     kl, desc, eq, n = ls.ExtractLineSegment(img)
     segs = ls.read_stage(0, 3)
     got = np.stack([segs["x1"], segs["y1"], segs["x2"], segs["y2"]], 1)
     np.testing.assert_array_equal(got, ref["xy"])
-    rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=1)
+    rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=0)
     assert n[0] == len(rk)
     np.testing.assert_array_equal(desc[0, :n[0]], rd)
 
@@ -118,7 +120,7 @@ def test_many_segments_sort_in_global_scratch(ctx):
     kl, desc, eq, n = ls.ExtractLineSegment(img)
     segs = ls.read_stage(0, 3)
     assert len(segs) > 1024
-    rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=1)
+    rk, rd, re, _, nd = O.extract_line_segment(img, tie_order=0)
     assert nd == len(segs) and n[0] == 40
     for f in rk.dtype.names:
         np.testing.assert_array_equal(kl[0][f], rk[f], err_msg=f)
@@ -133,7 +135,7 @@ def test_other_image_sizes(ctx, size):
     ls = LineSegment(W, H, 2, ctx)
     kl, desc, eq, n = ls.ExtractLineSegment(np.stack([img, img[::-1].copy()]))
     for b, im in enumerate((img, img[::-1].copy())):
-        rk, rd, re, _, nd = O.extract_line_segment(im, tie_order=1)
+        rk, rd, re, _, nd = O.extract_line_segment(im, tie_order=0)
         assert n[b] == len(rk) > 5
         assert kl[b, :n[b]].tobytes() == rk.tobytes()
         np.testing.assert_array_equal(desc[b, :n[b]], rd)
