@@ -295,14 +295,26 @@ def main():
         o = ol.OrbOracle()
         o.extract(gray_src[0])
         n, t0 = 0, time.perf_counter()
-        per = {"orb": 0.0, "lsd": 0.0, "peac": 0.0, "match": 0.0, "pose": 0.0}
+        per = {"orb": 0.0, "lsd": 0.0, "peac": 0.0, "proj": 0.0, "match": 0.0, "pose": 0.0}
         prev_desc = o.extract(gray_src[-1])[1]
+        if full:   # the same SearchByProjection problem as the GPU leg, frame by frame (host copies of the device inputs)
+            hp = {k: pj[k].cpu().numpy() for k in ("u_right", "Tcw", "usable", "xw", "octave", "angle", "observed")}
+            h_desc = d_desc[0].cpu().numpy()
+            sfs = scale_factors()
         while time.perf_counter() - t0 < args.cpu_seconds:
             i = n % nsrc
             t1 = time.perf_counter(); kp, de = o.extract(gray_src[i]); per["orb"] += time.perf_counter() - t1
             if full:
                 t1 = time.perf_counter(); ol.extract_line_segment(gray_src[i], tie_order=0); per["lsd"] += time.perf_counter() - t1
                 t1 = time.perf_counter(); ol.peac_run(depth_src[i]); per["peac"] += time.perf_counter() - t1
+                j = i % B
+                nj = int(h_n[j])
+                curv = dict(n=np.array([nj], np.int32), keys_un=h_kps[j:j + 1, :nj].copy().view(ol.KP_DTYPE).reshape(1, nj), u_right=hp["u_right"][j:j + 1, :nj],
+                            desc=h_desc[j:j + 1, :nj], Tcw=hp["Tcw"][j:j + 1], min_x=0.0, max_x=float(W), min_y=0.0, max_y=float(H), fx=TUM3["fx"], fy=TUM3["fy"],
+                            cx=TUM3["cx"], cy=TUM3["cy"], bf=TUM3["bf"], b=TUM3["bf"] / TUM3["fx"], scale_factors=sfs)
+                lastv = dict(n=np.array([nj], np.int32), Tcw=hp["Tcw"][j:j + 1], usable=hp["usable"][j:j + 1, :nj], xw=hp["xw"][j:j + 1, :nj],
+                             octave=hp["octave"][j:j + 1, :nj], angle=hp["angle"][j:j + 1, :nj], mp_desc=h_desc[j:j + 1, :nj], mp_observed=hp["observed"][j:j + 1, :nj])
+                t1 = time.perf_counter(); ol.search_by_projection_frame(curv, lastv, 15.0); per["proj"] += time.perf_counter() - t1
                 t1 = time.perf_counter()
                 ol.match_orb_points(de, prev_desc, np.ones(len(prev_desc), np.uint8), np.zeros(len(prev_desc), np.uint8), np.full(len(de), -1, np.int32))
                 per["match"] += time.perf_counter() - t1
@@ -312,7 +324,7 @@ def main():
             n += 1
         dt = time.perf_counter() - t0
         cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{n} frames of the same synthetic set through the oracle/ restatements of the same stages except SearchByProjection (1 thread, {dt:.1f} s)",
+               "sample": f"{n} frames of the same synthetic set through the oracle/ restatements of the same stages (1 thread, {dt:.1f} s)",
                "ms_per_frame": {k: round(v / n * 1e3, 2) for k, v in per.items() if v > 0}, "host_cores": os.cpu_count()}
 
     workload = ("configs[2]+[3]: full extract (ORB + LSD/LBD lines + PEAC planes, 3 streams) + SearchByProjection + MatchORBPoints + PoseOptimization 4x10 "
