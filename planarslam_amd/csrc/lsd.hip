@@ -9,8 +9,9 @@
 //   K1 lsd_gauss        8U fixed-point Gaussian (7x7 sigma 0.75 for LSD, 5x5 sigma 1 for LBD), LDS tile, pixel-parallel
 //   K2 lsd_grad         0.8x INTER_LINEAR_EXACT resample fused with the 2x2 gradient: level-line angle (float degrees,
 //                       exactly what fastAtan2 returned), squared gradient (u32), per-frame max, pixel-parallel
-//   K3 lsd_sort         per frame: drop undefined pixels, 1024-bin descending stable order (two 5-bit LSD radix passes
-//                       with per-thread contiguous segments so that raster order survives inside a bin)
+//   K3 lsd_sort         per frame: the visiting order = std::sort by 1024-bin gradient norm.  The order libstdc++'s introsort leaves among equal
+//                       bins is reproduced with parallel Hoare partitions (global memory -> ranges staged in LDS -> one wavefront ->
+//                       one lane per small range), then two stable 5-bit radix passes drop undefined pixels and finish the sort
 //   K4 lsd_detect       ONE WAVEFRONT PER FRAME, the sequential part: region growing in the reference's visiting order
 //                       (the level-line angle of a region is updated after every accepted pixel, so acceptance is a
 //                       chain), rectangle fit, density refinement, NFA validation.  The wave hides memory latency by
@@ -35,7 +36,6 @@ constexpr int N_BINS = 1024;
 constexpr int MAX_SEGS = 2048;     // raw LSD segments kept per frame
 constexpr int RING = 512;          // recent region points kept in LDS
 constexpr int USED_LDS_BITS = 32768;   // `used` flags of the first 32768 defined pixels live in LDS, the rest in global memory
-constexpr int MAX_ROWS = 1024;     // scaled image height limit (rect_nfa row table)
 
 struct Plan {
     int W, H, w, h;                // input and 0.8x sizes
@@ -183,7 +183,7 @@ __device__ __forceinline__ void lds_sync();
 //     that stops the left scan (bin <= pivot, ascending position) with the k-th that stops the right scan (bin >= pivot, descending position)
 //     for k < m = #{k : L_k < R_k}, and cuts at min(L_m, R_{m-1}).  Stops, m and the swaps are prefix-scan / ballot computations;
 //     the recursion tree is walked level by level (ranges are disjoint), ranges of <= 4096 elements are finished inside LDS by one wavefront
-//     (<= 64 elements: in registers, one element per lane, all sub-ranges of the window stepping together);
+//     (<= 64 elements: one LANE per sub-range runs the sequential loop on its own elements);
 //   * __final_insertion_sort is a stable sort of the arrangement the partitions leave = the two radix passes below.
 // Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py).  A depth-limit overflow (heap-sort fallback of introsort)
 // cannot be reproduced this way and raises status 2; it needs ~34 unbalanced partitions in a row and does not occur on 10-bit keys.
@@ -251,63 +251,6 @@ __device__ __forceinline__ int partition_step(uint32_t* arr, uint16_t* Lb, uint1
     if (m < cntL) cut = min(cut, (int)Lb[f + 1 + m]);
     if (m > 0) cut = min(cut, (int)Rb[f + 1 + m - 1]);
     return cut;
-}
-
-__device__ __forceinline__ int nth_set_from_bottom(unsigned long long m, int k) {   // position of the (k+1)-th set bit from the LSB
-    int pos = 0;
-    for (int width = 32; width >= 1; width >>= 1) {
-        const unsigned long long low = m & ((1ull << width) - 1ull);
-        const int c = __popcll(low);
-        if (k >= c) { k -= c; m >>= width; pos += width; } else m = low;
-    }
-    return pos;
-}
-__device__ __forceinline__ int nth_set_from_top(unsigned long long m, int k) { return 63 - nth_set_from_bottom(__brevll(m), k); }
-
-// A window of <= 64 elements, one per lane, finished in registers: every lane carries the bounds [sf, sl) and the depth budget of the
-// range it currently belongs to, and all ranges of the window take their next partition step at the same time (same arithmetic as
-// partition_step: median to the front, k-th left stop <-> k-th right stop for k < m, cut = min(L_m, R_{m-1})).
-__device__ bool sort_window(uint32_t* buf, int f, int l, int d0, int lane) {
-    const int sz = l - f;
-    uint32_t x = lane < sz ? buf[f + lane] : 0u;
-    int sf = 0, sl = lane < sz ? sz : 0, d = d0;
-    bool overflow = false;
-    while (true) {
-        const bool active = sl - sf > 16;
-        if (!__ballot(active)) break;
-        if (active && d == 0) overflow = true;
-        --d;
-        // __move_median_to_first
-        const int A = sf + 1, Bm = sf + (sl - sf) / 2, Cc = sl - 1;
-        const uint32_t a = (uint32_t)__shfl((int)x, A & 63, 64) >> 20, bq = (uint32_t)__shfl((int)x, Bm & 63, 64) >> 20, c = (uint32_t)__shfl((int)x, Cc & 63, 64) >> 20;
-        int t;
-        if (a > bq) { if (bq > c) t = Bm; else if (a > c) t = Cc; else t = A; }
-        else if (a > c) t = A;
-        else if (bq > c) t = Cc;
-        else t = Bm;
-        const uint32_t xf = (uint32_t)__shfl((int)x, sf & 63, 64), xt = (uint32_t)__shfl((int)x, t & 63, 64);
-        if (active && lane == sf) x = xt; else if (active && lane == t) x = xf;
-        const uint32_t pv = (uint32_t)__shfl((int)x, sf & 63, 64) >> 20;
-        const bool inside = active && lane > sf && lane < sl;
-        const unsigned long long segmask = active ? (((sl >= 64 ? ~0ull : ((1ull << sl) - 1ull)) >> (sf + 1)) << (sf + 1)) : 0ull;
-        const bool isL = inside && !((x >> 20) > pv), isR = inside && !(pv > (x >> 20));
-        const unsigned long long mL = __ballot(isL) & segmask, mR = __ballot(isR) & segmask;
-        const int cntL = __popcll(mL), cntR = __popcll(mR);
-        int src = lane;
-        bool goodL = false;
-        if (isL) { const int k = __popcll(mL & ((1ull << lane) - 1ull)); if (k < cntR) { const int pr = nth_set_from_top(mR, k); if (lane < pr) { goodL = true; src = pr; } } }
-        if (isR && !goodL) { const int k = lane == 63 ? 0 : __popcll(mR >> (lane + 1)); if (k < cntL) { const int pl = nth_set_from_bottom(mL, k); if (pl < lane) src = pl; } }
-        const int m = __popcll(__ballot(goodL) & segmask);
-        x = (uint32_t)__shfl((int)x, src, 64);
-        int cut = 0x7fffffff;
-        if (active) {
-            if (m < cntL) cut = min(cut, nth_set_from_bottom(mL, m));
-            if (m > 0) cut = min(cut, nth_set_from_top(mR, m - 1));
-            if (lane < cut) sl = cut; else sf = cut;
-        }
-    }
-    if (lane < sz) buf[f + lane] = x;
-    return !__ballot(overflow);
 }
 
 // One Hoare partition of arr[f, l) by the whole workgroup (256 threads); same arithmetic as partition_step.  Works on global memory
@@ -1523,7 +1466,7 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     P.off_segs = carve((size_t)lsd::MAX_SEGS * sizeof(lsd::Seg)); P.off_kl = carve((size_t)lsd::MAX_SEGS * sizeof(planar_keyline));
     P.frame_bytes = off;
     o->detect_smem = 64 * 3 * 8 + lsd::USED_LDS_BITS / 8 + lsd::RING * 4 + 16;
-    if (o->detect_smem > 150 * 1024 || P.h + 2 > lsd::MAX_ROWS || NPs > (1u << 20)) { delete o; set_error("planar_lsd_create: image too large for the LDS-resident used map"); return PLANAR_EINVAL; }
+    if (o->detect_smem > 150 * 1024 || NPs > (1u << 20)) { delete o; set_error("planar_lsd_create: image too large for the LDS-resident used map"); return PLANAR_EINVAL; }
     // log_gamma(x) (lsd.cpp: Windschitl for x > 15, Lanczos otherwise) at every integer argument nfa() can see, and log(p), log(1-p),
     // log10(p) for p = P.p / 2^j: evaluated here with the host libm, exactly as the reference library evaluates them
     std::vector<double> lgam(NPs + 3, 0.0);
