@@ -165,3 +165,50 @@ private:
     cv::Mat depth_;
     float factor_ = 0, fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0;
 };
+
+// ---- LineSegment (reference include/LSDextractor.h:344-352, src/LSDextractor.cpp:12-39).  Opt-in: define PLANAR_ADAPTERS_WITH_LINES
+//      before including this header in a build that has opencv_contrib's line_descriptor and Eigen (the types of the signature). ------
+#ifdef PLANAR_ADAPTERS_WITH_LINES
+#include <opencv2/line_descriptor/descriptor.hpp>
+#include <eigen3/Eigen/Core>
+namespace Planar_SLAM {
+class LineSegment {
+public:
+    LineSegment() {}
+    ~LineSegment() { if (lsd_) planar_lsd_destroy(lsd_); }
+    LineSegment(const LineSegment&) = delete;
+    LineSegment& operator=(const LineSegment&) = delete;
+
+    // scale / numOctaves are accepted for signature compatibility; the reference passes 1.2f -> (int)1 and 1 (one octave, full resolution)
+    void ExtractLineSegment(const cv::Mat& img, std::vector<cv::line_descriptor::KeyLine>& keylines, cv::Mat& ldesc,
+                            std::vector<Eigen::Vector3d>& keylineFunctions, float scale = 1.2, int numOctaves = 1) {
+        (void)scale; (void)numOctaves;
+        static_assert(sizeof(cv::line_descriptor::KeyLine) == sizeof(planar_keyline), "cv::line_descriptor::KeyLine layout");
+        static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double), "Eigen::Vector3d layout");
+        assert(img.type() == CV_8UC1);
+        const int W = img.cols, H = img.rows;
+        if (!lsd_ || W != w_ || H != h_) {
+            if (lsd_) planar_lsd_destroy(lsd_);
+            if (planar_lsd_create(planar_adapter::shared_ctx(), W, H, 1, &lsd_) != PLANAR_OK) { lsd_ = nullptr; throw std::runtime_error(planar_last_error()); }
+            w_ = W; h_ = H;
+        }
+        const int lsdNFeatures = 40;                                   // src/LSDextractor.cpp:18
+        keylines.resize(lsdNFeatures);
+        std::vector<unsigned char> desc((size_t)lsdNFeatures * 32);
+        const size_t first = keylineFunctions.size();                  // the reference push_backs
+        keylineFunctions.resize(first + lsdNFeatures);
+        int32_t n = 0;
+        if (planar_lsd_extract(lsd_, img.data, 1, (int)img.step, (int64_t)img.step * H, lsdNFeatures, (planar_keyline*)keylines.data(), desc.data(),
+                               (double*)(keylineFunctions.data() + first), &n) != PLANAR_OK)
+            throw std::runtime_error(planar_last_error());
+        keylines.resize(n);
+        keylineFunctions.resize(first + n);
+        if (n) { ldesc = cv::Mat(n, 32, CV_8UC1); std::memcpy(ldesc.data, desc.data(), (size_t)n * 32); }   // BinaryDescriptor::compute leaves ldesc untouched when there are no lines
+    }
+
+private:
+    planar_lsd* lsd_ = nullptr;
+    int w_ = 0, h_ = 0;
+};
+}  // namespace Planar_SLAM
+#endif

@@ -8,6 +8,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SRC = r'''
+#define PLANAR_ADAPTERS_WITH_LINES
 #include "planar_adapters.hpp"
 int main(int argc, char**) {
     if (argc > 100) {   // never executed here: there is no GPU in the test container; this only has to compile and link
@@ -20,7 +21,10 @@ int main(int argc, char**) {
         cv::Mat depth(480, 640, CV_16U), K(3, 3, CV_32F);
         pd.readDepthImage(depth, K, 1.0f / 5000);
         pd.runPlaneDetection(480, 640);
-        return pd.plane_num_ + (int)pd.plane_vertices_.size() + (int)pd.plane_filter.extractedPlanes.size();
+        Planar_SLAM::LineSegment ls;
+        std::vector<cv::line_descriptor::KeyLine> kl; cv::Mat ldesc; std::vector<Eigen::Vector3d> eqs;
+        ls.ExtractLineSegment(img, kl, ldesc, eqs);
+        return pd.plane_num_ + (int)pd.plane_vertices_.size() + (int)pd.plane_filter.extractedPlanes.size() + (int)kl.size();
     }
     return 0;
 }
