@@ -795,75 +795,95 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     __syncthreads();
     mark();
 
-    // ---- floodFill (:428-476), all threads.  Per step: 64 queue entries x 4 neighbours, one (entry, neighbour) pair per
-    //      thread.  Pairs that hit the same pixel are replayed in thread (== reference) order; plane-plane connect() is a
-    //      commutative set insertion and goes to an LDS bit matrix; queue pushes are appended in thread order.
+    // ---- floodFill (:428-476), all threads.  Per step: 128 queue entries x 4 neighbours = 512 (entry, neighbour) pairs, two per thread
+    //      (pair p = entry * 4 + direction is the reference's processing order).  Pairs that hit the same pixel are replayed in pair order;
+    //      plane-plane connect() is a commutative set insertion and goes to an LDS bit matrix; queue pushes are appended in pair order.
     {
+        constexpr int FJ = 2;                                      // pairs per thread and step
         const double factor = (double)K.factor;
         int q_head = 0, q_tail = s_scalar[2];
         while (q_head < q_tail && !err) {
-            const int nent = min(NT / 4, q_tail - q_head);
-            const int e = tid >> 2, dir = tid & 3;
-            bool act = e < nent;
-            int cIdx = -1, plid = -1, cx = 0, cy = 0;
-            if (act) {
-                const int2 ent = queue[q_head + e];
-                plid = ent.y;
-                const int sy = ent.x / W, sx = ent.x - sy * W;
-                // getValid4Neighbor order (:398-410): left, right, up, down, invalid ones skipped
-                if (dir == 0) { act = sx > 0; cIdx = ent.x - 1; }
-                else if (dir == 1) { act = sx < W - 1; cIdx = ent.x + 1; }
-                else if (dir == 2) { act = sy > 0; cIdx = ent.x - W; }
-                else { act = sy < H - 1; cIdx = ent.x + W; }
-                if (act) { cy = cIdx / W; cx = cIdx - cy * W; }
-            }
-            bool geo_ok = false; float cdist = -1.f;
-            if (act) {
-                const int by = cy / WIN, bx = cx / WIN;
-                const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
-                if (blkid >= 0 && S.blk[blkid] >= 0) act = false;          // only "black" blocks are refined
-            }
-            if (act) {
-                const double z = (double)D[(size_t)cy * pitch_px + cx] * factor;
-                if (z != 0) {
-                    const double x = ((double)cx - (double)K.cx) * z / (double)K.fx;
-                    const double y = ((double)cy - (double)K.cy) * z / (double)K.fy;
-                    const double* g = geo_of(s_ext[plid]);
-                    const double sd = g[3] * (x - g[0]) + g[4] * (y - g[1]) + g[5] * (z - g[2]);
-                    cdist = (float)fabs(sd);
-                    geo_ok = (double)cdist * (double)cdist < 9 * g[6] + 1e-5;
+            const int nent = min(FJ * NT / 4, q_tail - q_head);
+            bool act[FJ], geo_ok[FJ], done[FJ], push[FJ];
+            int cIdx[FJ], plid[FJ], pidx[FJ];
+            float cdist[FJ];
+#pragma unroll
+            for (int j = 0; j < FJ; j++) {
+                pidx[j] = tid + NT * j;
+                const int e = pidx[j] >> 2, dir = pidx[j] & 3;
+                act[j] = e < nent; cIdx[j] = -1; plid[j] = -1; geo_ok[j] = false; cdist[j] = -1.f; push[j] = false;
+                int cx = 0, cy = 0;
+                if (act[j]) {
+                    const int2 ent = queue[q_head + e];
+                    plid[j] = ent.y;
+                    const int sy = ent.x / W, sx = ent.x - sy * W;
+                    // getValid4Neighbor order (:398-410): left, right, up, down, invalid ones skipped
+                    if (dir == 0) { act[j] = sx > 0; cIdx[j] = ent.x - 1; }
+                    else if (dir == 1) { act[j] = sx < W - 1; cIdx[j] = ent.x + 1; }
+                    else if (dir == 2) { act[j] = sy > 0; cIdx[j] = ent.x - W; }
+                    else { act[j] = sy < H - 1; cIdx[j] = ent.x + W; }
+                    if (act[j]) { cy = cIdx[j] / W; cx = cIdx[j] - cy * W; }
                 }
-            }
-            bool done = !act, push = false;
-            while (__syncthreads_or(!done)) {
-                for (int t = tid; t < 1024; t += NT) s_slot[t] = NT;
-                __syncthreads();
-                if (!done) atomicMin(&s_slot[cIdx & 1023], tid);
-                __syncthreads();
-                if (!done && s_slot[cIdx & 1023] == tid) {
-                    const int trail = member[cIdx];
-                    if (!(trail <= -6) && !(trail >= 0 && trail == plid)) {
-                        if (geo_ok) {
-                            if (trail >= 0 && nsim(s_ext[plid], s_ext[trail]) >= C.cos_refine) {   // n_pl.connect(pl)
-                                atomicOr(&s_adj[trail][plid >> 5], 1u << (plid & 31));
-                                atomicOr(&s_adj[plid][trail >> 5], 1u << (trail & 31));
-                            }
-                            if (cdist < distMap[cIdx]) { member[cIdx] = plid; distMap[cIdx] = cdist; push = true; }
-                            else if (trail < 0) member[cIdx] = trail - 1;
-                        } else if (trail < 0) member[cIdx] = trail - 1;
+                if (act[j]) {
+                    const int by = cy / WIN, bx = cx / WIN;
+                    const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
+                    if (blkid >= 0 && S.blk[blkid] >= 0) act[j] = false;          // only "black" blocks are refined
+                }
+                if (act[j]) {
+                    const double z = (double)D[(size_t)cy * pitch_px + cx] * factor;
+                    if (z != 0) {
+                        const double x = ((double)cx - (double)K.cx) * z / (double)K.fx;
+                        const double y = ((double)cy - (double)K.cy) * z / (double)K.fy;
+                        const double* g = geo_of(s_ext[plid[j]]);
+                        const double sd = g[3] * (x - g[0]) + g[4] * (y - g[1]) + g[5] * (z - g[2]);
+                        cdist[j] = (float)fabs(sd);
+                        geo_ok[j] = (double)cdist[j] * (double)cdist[j] < 9 * g[6] + 1e-5;
                     }
-                    done = true;
+                }
+                done[j] = !act[j];
+            }
+            while (__syncthreads_or(!done[0] || !done[1])) {
+                for (int t = tid; t < 1024; t += NT) s_slot[t] = FJ * NT;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < FJ; j++) if (!done[j]) atomicMin(&s_slot[cIdx[j] & 1023], pidx[j]);
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < FJ; j++) {
+                    if (!done[j] && s_slot[cIdx[j] & 1023] == pidx[j]) {
+                        const int trail = member[cIdx[j]];
+                        if (!(trail <= -6) && !(trail >= 0 && trail == plid[j])) {
+                            if (geo_ok[j]) {
+                                if (trail >= 0 && nsim(s_ext[plid[j]], s_ext[trail]) >= C.cos_refine) {   // n_pl.connect(pl)
+                                    atomicOr(&s_adj[trail][plid[j] >> 5], 1u << (plid[j] & 31));
+                                    atomicOr(&s_adj[plid[j]][trail >> 5], 1u << (trail & 31));
+                                }
+                                if (cdist[j] < distMap[cIdx[j]]) { member[cIdx[j]] = plid[j]; distMap[cIdx[j]] = cdist[j]; push[j] = true; }
+                                else if (trail < 0) member[cIdx[j]] = trail - 1;
+                            } else if (trail < 0) member[cIdx[j]] = trail - 1;
+                        }
+                        done[j] = true;
+                    }
+                    // the thread's second pair may target the pixel its first pair just wrote: it lost the slot (smaller pair index wins) and
+                    // is replayed in the next round, after the fence below
                 }
                 __threadfence_block();
             }
-            const unsigned long long pm = __ballot(push);
-            if (lane == 0) s_wcnt[wave] = __popcll(pm);
-            __syncthreads();
-            int before = 0, total = 0;
-            for (int w = 0; w < 4; w++) { const int c = s_wcnt[w]; if (w < wave) before += c; total += c; }
-            if (q_tail + total > L.q_cap) { err = 5; }
-            else if (push) queue[q_tail + before + __popcll(pm & ((1ull << lane) - 1ull))] = make_int2(cIdx, plid);
-            q_tail += total;
+            // pushes in pair order: all round-0 pairs (p < NT) precede the round-1 pairs
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < FJ; j++) {
+                const unsigned long long pm = __ballot(push[j]);
+                if (lane == 0) s_wcnt[wave] = __popcll(pm);
+                __syncthreads();
+                int before = 0, total = 0;
+                for (int w = 0; w < 4; w++) { const int c = s_wcnt[w]; if (w < wave) before += c; total += c; }
+                if (q_tail + base + total > L.q_cap) err = 5;
+                else if (push[j]) queue[q_tail + base + before + __popcll(pm & ((1ull << lane) - 1ull))] = make_int2(cIdx[j], plid[j]);
+                base += total;
+                __syncthreads();
+            }
+            q_tail += base;
             q_head += nent;
             __threadfence_block();
             __syncthreads();
