@@ -183,12 +183,13 @@ __device__ __forceinline__ void lds_sync();
 //     that stops the left scan (bin <= pivot, ascending position) with the k-th that stops the right scan (bin >= pivot, descending position)
 //     for k < m = #{k : L_k < R_k}, and cuts at min(L_m, R_{m-1}).  Stops, m and the swaps are prefix-scan / ballot computations;
 //     the recursion tree is walked level by level (ranges are disjoint), ranges of <= 4096 elements are finished inside LDS by one wavefront
-//     (<= 64 elements: one LANE per sub-range runs the sequential loop on its own elements);
+//     (<= SORT_LEAF elements: one LANE per sub-range runs the sequential loop on its own elements);
 //   * __final_insertion_sort is a stable sort of the arrangement the partitions leave = the two radix passes below.
 // Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py).  A depth-limit overflow (heap-sort fallback of introsort)
 // cannot be reproduced this way and raises status 2; it needs ~34 unbalanced partitions in a row and does not occur on 10-bit keys.
 constexpr int SORT_SMALL = 4096;    // finished by one wavefront
 constexpr int SORT_STAGE = 16384;   // staged in LDS by the workgroup
+constexpr int SORT_LEAF = 64;       // finished by one lane
 struct SortRange { int f, l, d; };
 
 // one wavefront; arr[f, l) in LDS, l - f > 16; Lb / Rb are LDS scratch arrays indexed like arr.  Returns the cut.
@@ -207,40 +208,31 @@ __device__ __forceinline__ int partition_step(uint32_t* arr, uint16_t* Lb, uint1
     const uint32_t pv = arr[f] >> 20;
     constexpr int U = 4;                                      // chunks per iteration: the LDS reads are issued together
     int cntL = 0, cntR = 0;
-    for (int base = f + 1; base < l; base += 64 * U) {        // stops of the left scan: !(x > pivot), ascending
+    // one ascending pass finds the stops of both scans: left scan !(x > pivot), right scan !(pivot > x).  The right scan walks downwards,
+    // so its k-th stop is Rb[f + 1 + cntR - 1 - k].
+    for (int base = f + 1; base < l; base += 64 * U) {
         uint32_t v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < l ? arr[i] >> 20 : 0xffffffffu; }
+        for (int u = 0; u < U; u++) v[u] = arr[min(base + 64 * u + lane, l - 1)];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = base + 64 * u + lane;
-            const bool isL = i < l && !(v[u] > pv);
-            const unsigned long long m = __ballot(isL);
-            if (isL) Lb[f + 1 + cntL + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-            cntL += __popcll(m);
-        }
-    }
-    for (int base = l - 1; base >= f + 1; base -= 64 * U) {   // stops of the right scan: !(pivot > x), descending
-        uint32_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) { const int i = base - 64 * u - lane; v[u] = i >= f + 1 ? arr[i] >> 20 : 0u; }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = base - 64 * u - lane;
-            const bool isR = i >= f + 1 && !(pv > v[u]);
-            const unsigned long long m = __ballot(isR);
-            if (isR) Rb[f + 1 + cntR + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-            cntR += __popcll(m);
+            const uint32_t k = v[u] >> 20;
+            const bool isL = i < l && !(k > pv), isR = i < l && !(pv > k);
+            const unsigned long long mL = __ballot(isL), mR = __ballot(isR), below = (1ull << lane) - 1ull;
+            if (isL) Lb[f + 1 + cntL + __popcll(mL & below)] = (uint16_t)i;
+            if (isR) Rb[f + 1 + cntR + __popcll(mR & below)] = (uint16_t)i;
+            cntL += __popcll(mL); cntR += __popcll(mR);
         }
     }
     lds_sync();
-    const int kmax = min(cntL, cntR);
+    const int kmax = min(cntL, cntR), rtop = f + cntR;        // Rb[rtop - k] = k-th stop of the right scan
     int m = 0;
     for (int kb = 0; kb < kmax; kb += 64) {
         const int k = kb + lane;
         int Lk = 0, Rk = 0;
         bool good = false;
-        if (k < kmax) { Lk = Lb[f + 1 + k]; Rk = Rb[f + 1 + k]; good = Lk < Rk; }
+        if (k < kmax) { Lk = Lb[f + 1 + k]; Rk = Rb[rtop - k]; good = Lk < Rk; }
         const int ng = __popcll(__ballot(good));              // L ascending, R descending: the good pairs are a prefix
         if (good) { const uint32_t x = arr[Lk]; arr[Lk] = arr[Rk]; arr[Rk] = x; }
         m += ng;
@@ -249,7 +241,7 @@ __device__ __forceinline__ int partition_step(uint32_t* arr, uint16_t* Lb, uint1
     lds_sync();
     int cut = 0x7fffffff;
     if (m < cntL) cut = min(cut, (int)Lb[f + 1 + m]);
-    if (m > 0) cut = min(cut, (int)Rb[f + 1 + m - 1]);
+    if (m > 0) cut = min(cut, (int)Rb[rtop - (m - 1)]);
     return cut;
 }
 
@@ -275,15 +267,17 @@ __device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, i
     const uint32_t pv = (uint32_t)bc[0];
     const int tpos = bc[1];
     const uint32_t tval = (uint32_t)bc[2] >> 20;                  // the element now at position t (the old front)
-    // each wavefront owns a contiguous quarter of [f+1, l) and walks it in coalesced chunks, 8 chunks of loads in flight
-    constexpr int U = 8;
+    // each wavefront owns a contiguous quarter of [f+1, l) and walks it in coalesced chunks, U chunks of loads in flight
+    constexpr int U = 16;
     const int len = l - (f + 1), qlen = (len + 3) / 4;
     const int q0 = f + 1 + min(len, wave * qlen), q1 = f + 1 + min(len, wave * qlen + qlen);
     int cl = 0, cr = 0;
     for (int base = q0; base < q1; base += 64 * U) {
         uint32_t v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : arr[i] >> 20) : 0xffffffffu; }
+        for (int u = 0; u < U; u++) v[u] = arr[min(base + 64 * u + lane, q1 - 1)];          // unconditional loads: all U in flight
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : v[u] >> 20) : 0xffffffffu; }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const bool in = base + 64 * u + lane < q1;
@@ -298,7 +292,9 @@ __device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, i
     for (int base = q0; base < q1; base += 64 * U) {             // one pass writes both stop lists; R is descending: slot = totR - 1 - ascending rank
         uint32_t v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : arr[i] >> 20) : 0xffffffffu; }
+        for (int u = 0; u < U; u++) v[u] = arr[min(base + 64 * u + lane, q1 - 1)];          // unconditional loads: all U in flight
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : v[u] >> 20) : 0xffffffffu; }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = base + 64 * u + lane;
@@ -314,14 +310,16 @@ __device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, i
     __syncthreads();
     const int kmax = min(totL, totR);
     int good = 0;
-    constexpr int PU = 4;                                         // pairs in flight per thread (two dependent round trips each)
+    constexpr int PU = 8;                                         // pairs in flight per thread (two dependent round trips each)
     for (int k0 = tid; k0 < kmax; k0 += 256 * PU) {
         int Lk[PU], Rk[PU];
         uint32_t xl[PU], xr[PU];
 #pragma unroll
-        for (int u = 0; u < PU; u++) { const int k = k0 + 256 * u; Lk[u] = k < kmax ? (int)Lb[f + 1 + k] : 1; Rk[u] = k < kmax ? (int)Rb[f + 1 + k] : 0; }
+        for (int u = 0; u < PU; u++) { const int k = min(k0 + 256 * u, kmax - 1); Lk[u] = (int)Lb[f + 1 + k]; Rk[u] = (int)Rb[f + 1 + k]; }
 #pragma unroll
-        for (int u = 0; u < PU; u++) if (Lk[u] < Rk[u]) { xl[u] = arr[Lk[u]]; xr[u] = arr[Rk[u]]; }
+        for (int u = 0; u < PU; u++) if (k0 + 256 * u >= kmax) { Lk[u] = 1; Rk[u] = 0; }
+#pragma unroll
+        for (int u = 0; u < PU; u++) { xl[u] = arr[max(Lk[u], f)]; xr[u] = arr[max(Rk[u], f)]; }      // unconditional: all loads in flight
 #pragma unroll
         for (int u = 0; u < PU; u++) if (Lk[u] < Rk[u]) { arr[Lk[u]] = xr[u]; arr[Rk[u]] = xl[u]; good++; }
     }
@@ -426,13 +424,13 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
                 int sp = 0;
                 if (lane == 0) { s_stack[wave][0][0] = s_wave[r][0]; s_stack[wave][0][1] = s_wave[r][1]; s_stack[wave][0][2] = s_wave[r][2]; }
                 sp = 1;
-                int nleaf = 0;                                    // sub-ranges of <= 64 elements, finished below one per LANE
+                int nleaf = 0;                                    // sub-ranges of <= SORT_LEAF elements, finished below one per LANE
                 lds_sync();
                 while (sp > 0) {
                     sp--;
                     int f = ((volatile int*)s_stack[wave][sp])[0], l = ((volatile int*)s_stack[wave][sp])[1], d = ((volatile int*)s_stack[wave][sp])[2];
                     while (l - f > 16) {
-                        if (l - f <= 64) { if (lane == 0) { s_leaf[wave][nleaf][0] = (short)f; s_leaf[wave][nleaf][1] = (short)l; s_leaf[wave][nleaf][2] = (short)d; } nleaf++; break; }
+                        if (l - f <= SORT_LEAF) { if (lane == 0) { s_leaf[wave][nleaf][0] = (short)f; s_leaf[wave][nleaf][1] = (short)l; s_leaf[wave][nleaf][2] = (short)d; } nleaf++; break; }
                         if (d == 0) { if (lane == 0) misc->status = 2; break; }
                         --d;
                         const int cut = partition_step(sbuf, Ls, Rs, f, l, lane);
@@ -491,10 +489,17 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
     // __final_insertion_sort == stable sort of the current arrangement by descending bin: two 5-bit LSD radix passes with thread-contiguous
     // segments (order inside a bin = array order).  Undefined pixels took part in the partitions above; they are dropped here.
     const int segA = (n + 255) / 256, a0 = min(n, tid * segA), a1 = min(n, a0 + segA);
+    constexpr int RU = 8;                                      // elements per iteration: their loads (two dependent gathers) are issued together
     for (int d = 0; d < 32; d++) cnt[d * 256 + tid] = 0;
-    for (int i = a0; i < a1; i++) {
-        const uint32_t e = arr[i];
-        if (ang[e & 0xfffffu] != NOTDEF_F) cnt[(((N_BINS - 1) - (int)(e >> 20)) & 31) * 256 + tid]++;
+    for (int i0 = a0; i0 < a1; i0 += RU) {
+        uint32_t e[RU]; float an[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) e[u] = arr[min(i0 + u, a1 - 1)];
+#pragma unroll
+        for (int u = 0; u < RU; u++) an[u] = ang[e[u] & 0xfffffu];
+#pragma unroll
+        for (int u = 0; u < RU; u++)
+            if (i0 + u < a1 && an[u] != NOTDEF_F) cnt[(((N_BINS - 1) - (int)(e[u] >> 20)) & 31) * 256 + tid]++;
     }
     __syncthreads();
     int total;
@@ -505,15 +510,22 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
         for (int k = 0; k < 32; k++) { const int c = cnt[tid * 32 + k]; cnt[tid * 32 + k] = run; run += c; }
     }
     __syncthreads();
-    for (int i = a0; i < a1; i++) {
-        const uint32_t e = arr[i];
-        const uint32_t pix = e & 0xfffffu;
-        if (ang[pix] != NOTDEF_F) {
-            const int key = (N_BINS - 1) - (int)(e >> 20);
-            // the slot doubles as the pixel's compact index among the defined pixels (its `used` flag lives there)
-            const int slot = cnt[(key & 31) * 256 + tid]++;
-            tmpA[slot] = ((uint32_t)key << 20) | pix;
-            ((float*)(F + P.off_pix))[(size_t)pix * 4 + 3] = __uint_as_float((uint32_t)slot);
+    for (int i0 = a0; i0 < a1; i0 += RU) {
+        uint32_t e[RU]; float an[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) e[u] = arr[min(i0 + u, a1 - 1)];
+#pragma unroll
+        for (int u = 0; u < RU; u++) an[u] = ang[e[u] & 0xfffffu];
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            if (i0 + u < a1 && an[u] != NOTDEF_F) {
+                const uint32_t pix = e[u] & 0xfffffu;
+                const int key = (N_BINS - 1) - (int)(e[u] >> 20);
+                // the slot doubles as the pixel's compact index among the defined pixels (its `used` flag lives there)
+                const int slot = cnt[(key & 31) * 256 + tid]++;
+                tmpA[slot] = ((uint32_t)key << 20) | pix;
+                ((float*)(F + P.off_pix))[(size_t)pix * 4 + 3] = __uint_as_float((uint32_t)slot);
+            }
         }
     }
     const int N = total;
@@ -522,7 +534,13 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
     const int segB = (N + 255) / 256, b0 = min(N, tid * segB), b1 = min(N, b0 + segB);
     for (int d = 0; d < 32; d++) cnt[d * 256 + tid] = 0;
     __syncthreads();
-    for (int i = b0; i < b1; i++) cnt[((tmpA[i] >> 25) & 31) * 256 + tid]++;
+    for (int i0 = b0; i0 < b1; i0 += RU) {
+        uint32_t e[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) e[u] = tmpA[min(i0 + u, b1 - 1)];
+#pragma unroll
+        for (int u = 0; u < RU; u++) if (i0 + u < b1) cnt[((e[u] >> 25) & 31) * 256 + tid]++;
+    }
     __syncthreads();
     {
         int local = 0;
@@ -531,11 +549,18 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
         for (int k = 0; k < 32; k++) { const int c = cnt[tid * 32 + k]; cnt[tid * 32 + k] = run; run += c; }
     }
     __syncthreads();
-    for (int i = b0; i < b1; i++) {
-        const uint32_t e = tmpA[i];
-        const int pos = cnt[((e >> 25) & 31) * 256 + tid]++;
-        ord[pos] = e & 0xfffffu;
-        ordr[pos] = (uint32_t)i;
+    for (int i0 = b0; i0 < b1; i0 += RU) {
+        uint32_t e[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) e[u] = tmpA[min(i0 + u, b1 - 1)];
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            if (i0 + u < b1) {
+                const int pos = cnt[((e[u] >> 25) & 31) * 256 + tid]++;
+                ord[pos] = e[u] & 0xfffffu;
+                ordr[pos] = (uint32_t)(i0 + u);
+            }
+        }
     }
     if (tid == 0) { misc->n_ord = N; misc->t[5] = ts1 - ts0; misc->t[6] = ts2 - ts1; misc->t[7] = __builtin_readcyclecounter() - ts2; }
 }
