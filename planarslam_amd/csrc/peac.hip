@@ -17,6 +17,14 @@
 // order-independent work is spread over the 64 lanes.
 #include "common.h"
 
+// Per-step cycle counters of the ahCluster loop (tools/peac_timing.py).  s_memtime drains the LDS queue every time it is read, so the
+// counters are compiled in only with -DPLANAR_PEAC_TIMING; the eight phase marks (wall clock) are always recorded.
+#ifdef PLANAR_PEAC_TIMING
+#define PEAC_CYCLES() ((long long)clock64())
+#else
+#define PEAC_CYCLES() 0ll
+#endif
+
 namespace planar {
 namespace peac {
 
@@ -337,41 +345,64 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     int heap_n = 0, n_nodes = NB, n_ext = 0, pool_top = 4 * NB, err = 0;
     // libstdc++ binary heap (std::priority_queue with PlaneSegMinMSECmp: comp(a,b) = b.mse < a.mse); entries carry
     // their key so a comparison is one LDS read.
-    auto heap_push = [&](int id, double mse) {
-        int hole = heap_n, parent = (hole - 1) / 2;
-        heap_n++;
-        while (hole > 0 && mse < S.h_mse[parent]) {
-            if (lane == 0) { S.h_mse[hole] = S.h_mse[parent]; S.h_id[hole] = S.h_id[parent]; }
-            wfence(); hole = parent; parent = (hole - 1) / 2;
-        }
-        if (lane == 0) { S.h_mse[hole] = mse; S.h_id[hole] = (u16)id; }
+    // __push_heap: the value climbs from `hole` while it is smaller than the parent.  The <= 12 ancestors are read by one lane each in a
+    // single LDS round trip; the leading run of larger ancestors moves down one level in parallel.
+    auto heap_sift_up = [&](int hole, int id, double mse) {
+        const int anc = lane < 16 ? ((hole + 1) >> lane) - 1 : -1;                          // lane j: the j-th ancestor of the hole (lane 0: the hole)
+        const bool isanc = lane >= 1 && anc >= 0;
+        double K = 0; int I = 0;
+        if (isanc) { K = S.h_mse[anc]; I = S.h_id[anc]; }
+        const unsigned long long up = __ballot(isanc && mse < K) >> 1;       // bit j-1: ancestor j is larger than the value
+        const int n = __builtin_ctzll(~up);                                  // the loop stops at the first ancestor that is not
+        if (lane >= 1 && lane <= n) { const int dst = ((hole + 1) >> (lane - 1)) - 1; S.h_mse[dst] = K; S.h_id[dst] = (u16)I; }
+        if (lane == 0) { const int dst = ((hole + 1) >> n) - 1; S.h_mse[dst] = mse; S.h_id[dst] = (u16)id; }
         wfence();
     };
+    auto heap_push = [&](int id, double mse) {
+        heap_n++;
+        heap_sift_up(heap_n - 1, id, mse);
+    };
+    // pop_heap = __adjust_heap(first, 0, len, last value): the hole sinks to the bottom along the smaller child (no early exit), then
+    // the value climbs back.  Lane t = 1..63 holds node t of the 6-level subtree under the hole and, for t < 32, compares its two children
+    // (one LDS round trip for everything); the five decisions are then bit operations on the ballot of those comparisons (scalar unit) and
+    // the chosen nodes move up in one parallel store.
     auto heap_pop = [&]() -> int {
         const int top = S.h_id[0];
         const double vm = S.h_mse[heap_n - 1]; const int vi = S.h_id[heap_n - 1];
         heap_n--;
         const int len = heap_n;
         if (len == 0) return top;
-        int hole = 0, second = 0;
-        while (second < (len - 1) / 2) {
-            second = 2 * (second + 1);
-            if (S.h_mse[second - 1] < S.h_mse[second]) second--;          // comp(first[second], first[second-1])
-            if (lane == 0) { S.h_mse[hole] = S.h_mse[second]; S.h_id[hole] = S.h_id[second]; }
-            wfence(); hole = second;
+        const int half = (len - 1) / 2;                                      // nodes below `half` have two children
+        const int dl = 31 - __clz(max(lane, 1));                             // level of local node `lane`; its heap index is (hole << dl) + lane - 1
+        int hole = 0;
+        while (hole < half) {
+            const int g = (hole << dl) + lane - 1;
+            const bool valid = lane >= 1 && g < len, inner = lane >= 1 && lane < 32 && g < half;
+            double K = 0, kl = 0, kr = 0; int I = 0;
+            if (valid) { K = S.h_mse[g]; I = S.h_id[g]; }
+            if (inner) { kl = S.h_mse[2 * g + 1]; kr = S.h_mse[2 * g + 2]; }
+            const unsigned long long two = __ballot(inner);
+            const unsigned long long takel = __ballot(inner && kl < kr);     // comp(first[second], first[second - 1]): take second - 1
+            int cur = 1;
+            unsigned long long path = 0;
+#pragma unroll
+            for (int d = 0; d < 5; d++) {
+                if (!((two >> cur) & 1ull)) break;
+                cur = 2 * cur + 1 - (int)((takel >> cur) & 1ull);
+                path |= 1ull << cur;
+            }
+            if (valid && ((path >> lane) & 1ull)) { const int gp = (hole << (dl - 1)) + (lane >> 1) - 1; S.h_mse[gp] = K; S.h_id[gp] = (u16)I; }
+            const int dc = 31 - __clz(cur);
+            hole = (hole << dc) + cur - 1;
         }
-        if ((len & 1) == 0 && second == (len - 2) / 2) {
-            second = 2 * (second + 1);
-            if (lane == 0) { S.h_mse[hole] = S.h_mse[second - 1]; S.h_id[hole] = S.h_id[second - 1]; }
-            wfence(); hole = second - 1;
-        }
-        int parent = (hole - 1) / 2;
-        while (hole > 0 && vm < S.h_mse[parent]) {
-            if (lane == 0) { S.h_mse[hole] = S.h_mse[parent]; S.h_id[hole] = S.h_id[parent]; }
-            wfence(); hole = parent; parent = (hole - 1) / 2;
-        }
-        if (lane == 0) { S.h_mse[hole] = vm; S.h_id[hole] = (u16)vi; }
         wfence();
+        if ((len & 1) == 0 && hole == (len - 2) / 2) {                       // a last node with a single (left) child
+            const int c = 2 * hole + 1;
+            const double cm = S.h_mse[c]; const int ci = S.h_id[c];
+            if (lane == 0) { S.h_mse[hole] = cm; S.h_id[hole] = (u16)ci; }
+            wfence(); hole = c;
+        }
+        heap_sift_up(hole, vi, vm);
         return top;
     };
     // Neighbour lists use LAZY deletion: a node that leaves the graph (merged away or disconnected) only gets its
@@ -457,12 +488,12 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
             long long e0 = 0;
             if (wave == 0) {
                 while ((pending >= 0 || heap_n > 0) && step <= MAX_STEP && !err) {
-                    long long c0 = clock64();
+                    long long c0 = PEAC_CYCLES();
                     int p;
                     if (pending >= 0) { p = pending; pending = -1; }
                     else {
                         p = heap_pop();
-                        cyc[0] += clock64() - c0; c0 = clock64();
+                        cyc[0] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
                         if (is_dead(p)) continue;                           // nouse
                     }
                     const int cnt = S.nb_cnt[p];
@@ -559,7 +590,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                             }
                         }
                     }
-                    cyc[1] += clock64() - c0; c0 = clock64();
+                    cyc[1] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
                     if (have && best_mse < T_mse_merge(best_geo.center[2])) {
                         const int m = n_nodes++;
                         const int nb = best_nb;
@@ -583,7 +614,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                         }
                         gfence();
                         heap_push(m, best_geo.mse);
-                        cyc[2] += clock64() - c0; c0 = clock64();
+                        cyc[2] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
                         // mergeNbsFrom (AHCPlaneSeg.hpp:379-404): union of the two sorted lists minus {p, nb} (both dead by now),
                         // built cooperatively: prefix counts of the surviving entries, then every entry writes itself to its rank.
                         const int ca = S.nb_cnt[p], cb = S.nb_cnt[nb];
@@ -669,7 +700,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                         pool_top = off + cap;
                         if (lane == 0) { S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n; g_nbcap[m] = (u16)cap; S.nb_cnt[p] = 0; S.nb_cnt[nb] = 0; }
                         wfence();
-                        cyc[3] += clock64() - c0; c0 = clock64();
+                        cyc[3] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
                         {   // nb->nbs.insert(this): m is the largest id so far -> append; a full list is compacted first
                             const u16* lstm = S.pool + off;
                             for (int k = lane; k < n; k += 64) {
@@ -682,7 +713,7 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
                             }
                         }
                         wfence();
-                        cyc[5] += clock64() - c0;
+                        cyc[5] += PEAC_CYCLES() - c0;
                     } else {
                         extract(p);
                         for (int k = lane; k < cnt; k += 64) { const int q = lst[k]; if (!is_dead(q)) g_ver[q]++; }   // p leaves their live sets
@@ -696,11 +727,11 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
             if (!coop) break;
             __syncthreads();
             if (s_cmd == 0) break;
-            e0 = clock64();
+            e0 = PEAC_CYCLES();
             eval_phase();
             __threadfence_block();
             __syncthreads();
-            cyc[4] += clock64() - e0; dbg_phases++; dbg_nodes += s_nlist;
+            cyc[4] += PEAC_CYCLES() - e0; dbg_phases++; dbg_nodes += s_nlist;
         }
         if (wave != 0) return;
         while (heap_n > 0 && !err) { const int p = heap_pop(); extract(p); mark_dead(p); }
