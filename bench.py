@@ -4,10 +4,13 @@
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
 A "step" = one pass of the hot path over one batch of `--batch` synthetic 640x480 RGB-D frames that are already
-resident in HBM: ORB extraction, LSD+LBD line extraction and PEAC plane segmentation (extract; three HIP streams,
+resident in HBM: ORB extraction, LSD+LBD line extraction and PEAC plane segmentation (extract; separate HIP streams,
 mirroring the reference's three extraction threads, src/Frame.cc:90-95), SearchByProjection(Cur, Last) and
 MatchORBPoints against the previous batch (match) and the 4x10 PoseOptimization protocol on a config-4-shaped
-problem per frame (pose-opt), which waits for all three extractors.
+problem per frame (pose-opt), which waits for all three extractors of its own step.
+Steps are software-pipelined one deep (frames are independent): the line / plane launches of step i overlap the tail
+of step i-1's, and PoseOptimization of step i-1 is enqueued behind the point stages of step i.  Every one of the K
+timed steps is complete - including its PoseOptimization - before the closing barrier.
 Frames are independent, so ranks shard them with no data-path collective ("scaling": "weak": every rank processes
 its own `--batch` frames per step).  Rank 0 prints ONE JSON line: whole-job frames/s, per-stage times, the roofline
 of the dominant kernel (HIP events on the stream the kernels run on, inside the timed region) and a CPU baseline
@@ -51,6 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--workload", choices=["full", "orb"], default="full")
+    ap.add_argument("--prio", default="-1,0,0", help="stream priorities: ORB/match/pose stream, LSD streams, PEAC streams (lower = higher priority)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -74,11 +78,15 @@ def main():
 
     B = args.batch
     full = args.workload == "full"
-    stream = torch.cuda.Stream(device=local_rank)
+    prio = [int(x) for x in args.prio.split(',')]
+    stream = torch.cuda.Stream(device=local_rank, priority=prio[0])
     ctx = Context(local_rank, stream=stream.cuda_stream)
     # the reference extracts ORB / lines / planes on three threads (src/Frame.cc:90-95): three HIP streams here
-    s_peac, s_lsd = torch.cuda.Stream(device=local_rank), torch.cuda.Stream(device=local_rank)
-    ctx_peac, ctx_lsd = Context(local_rank, stream=s_peac.cuda_stream), Context(local_rank, stream=s_lsd.cuda_stream)
+    # two PEAC streams and two LSD streams (even / odd steps): consecutive launches of the sequential extractors overlap (see step())
+    s_peacs = [torch.cuda.Stream(device=local_rank, priority=prio[2]) for _ in range(2)]
+    s_lsds = [torch.cuda.Stream(device=local_rank, priority=prio[1]) for _ in range(2)]
+    ctx_peacs = [Context(local_rank, stream=q.cuda_stream) for q in s_peacs]
+    ctx_lsds = [Context(local_rank, stream=q.cuda_stream) for q in s_lsds]
     L = lib()
 
     # ---- inputs resident in HBM (synthetic; distinct per rank, 16 distinct frames tiled over the batch) ----
@@ -93,10 +101,12 @@ def main():
     if full:
         depth_src = np.stack([depth_image(4321 + 16 * rank + i) for i in range(nsrc)])
         depth = torch.from_numpy(rep(depth_src).view(np.int16)).to(dev)
-        pd = PlaneDetection(W, H, max_batch=B, ctx=ctx_peac)
-        d_lab = torch.zeros((B, H * W), dtype=torch.int32, device=dev)
-        d_pl = torch.zeros((B, pd.max_planes, 8), dtype=torch.float64, device=dev)
-        d_npl = torch.zeros(B, dtype=torch.int32, device=dev)
+        pds = [PlaneDetection(W, H, max_batch=B, ctx=c) for c in ctx_peacs]                     # one workspace per step in flight
+        pd = pds[0]
+        d_labs = [torch.zeros((B, H * W), dtype=torch.int32, device=dev) for _ in range(2)]
+        d_pls = [torch.zeros((B, pd.max_planes, 8), dtype=torch.float64, device=dev) for _ in range(2)]
+        d_npls = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_lab, d_pl, d_npl = d_labs[0], d_pls[0], d_npls[0]
         # matcher state
         has_mp = torch.ones((B, ex.kp_cap), dtype=torch.uint8, device=dev)
         outl = torch.zeros((B, ex.kp_cap), dtype=torch.uint8, device=dev)
@@ -123,11 +133,13 @@ def main():
         from planarslam_amd._lib import KEYLINE_DTYPE, FrameView, LastFrameView
         from planarslam_amd.lines import LineSegment
         from planarslam_amd.synth import scale_factors
-        ls = LineSegment(W, H, B, ctx_lsd)
-        d_kl = torch.zeros(B * 40 * KEYLINE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        d_ldesc = torch.zeros((B, 40, 32), dtype=torch.uint8, device=dev)
-        d_leq = torch.zeros((B, 40, 3), dtype=torch.float64, device=dev)
-        d_nl = torch.zeros(B, dtype=torch.int32, device=dev)
+        lss = [LineSegment(W, H, B, c) for c in ctx_lsds]
+        ls = lss[0]
+        d_kls = [torch.zeros(B * 40 * KEYLINE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_ldescs = [torch.zeros((B, 40, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_leqs = [torch.zeros((B, 40, 3), dtype=torch.float64, device=dev) for _ in range(2)]
+        d_nls = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_kl, d_ldesc, d_leq, d_nl = d_kls[0], d_ldescs[0], d_leqs[0], d_nls[0]
         # SearchByProjection(Cur, Last): the last frame's map points are the back-projections of the keypoints ORB finds on
         # the same images (identity motion), so every probe has a realistic window of candidates and a true match.
         with torch.cuda.stream(stream):
@@ -160,20 +172,35 @@ def main():
 
     stage_names = ["orb_extract"] + (["search_by_projection", "match_orb_points", "wait_lines_planes", "pose_opt_4x10"] if full else [])
     nst = len(stage_names)
-    fork, fork2, fork3, join_p, join_l = (torch.cuda.Event() for _ in range(5))
+    join_p, join_l, pose_done = ([torch.cuda.Event() for _ in range(2)] for _ in range(3))
+    pending = []          # steps whose PoseOptimization is still to be enqueued (software pipeline, depth 1)
+
+    def pose(k, evs=None):
+        if evs: evs[6].record(stream)
+        stream.wait_event(join_p[k]); stream.wait_event(join_l[k])      # PoseOptimization consumes points, lines and planes
+        if evs: evs[4].record(stream)
+        opt.enqueue_dev(pb, 0, 4, 10)
+        if evs: evs[5].record(stream)
+        pose_done[k].record(stream)
 
     def step(i, evs=None, side=None):
-        # Three streams, as the reference's three extraction threads.  The line detector's preprocessing (Gaussians, gradients, pixel ordering:
-        # throughput kernels with large LDS tiles) runs beside ORB + the point matchers; then the two sequential extractors run side by side
-        # on every CU: one PEAC workgroup (149 KB LDS) and one LSD wavefront (8 KB).  PoseOptimization waits for all of them.
-        cur, prev = i & 1, (i & 1) ^ 1
+        # Five streams.  The reference runs its three extractors as three threads per frame; here the two sequential extractors (PEAC: one
+        # workgroup per frame, 149 KB LDS; LSD: one wavefront per frame, 8 KB) of step i run on their own streams beside the ORB stream,
+        # and - frames being independent - beside the tail of step i-1's launches (alternating streams, one workspace per step in flight):
+        # a PEAC launch ends with its slowest frame (1.5x the mean), and the next launch fills the CUs the finished frames left.
+        # PoseOptimization of step i-1 is enqueued after the point stages of step i, when its lines and planes have had a full step to finish.
+        cur, prev, k = i & 1, (i & 1) ^ 1, i & 1
+        sp, sl = s_peacs[k], s_lsds[k]
         if evs: evs[0].record(stream)
         if full:
-            fork.record(stream)
-            s_lsd.wait_event(fork)
-            if side: side[2].record(s_lsd)
-            check(L.planar_lsd_preprocess_dev(ls.h, frames.data_ptr(), B, W, W * H))                                     # stream s_lsd
-            fork2.record(s_lsd)
+            sl.wait_event(pose_done[k]); sp.wait_event(pose_done[k])      # their outputs of step i-2 have been consumed
+            if side: side[2].record(sl)
+            check(L.planar_lsd_preprocess_dev(lss[k].h, frames.data_ptr(), B, W, W * H))
+            if side: side[0].record(sp)
+            pds[k].segment_dev(depth.data_ptr(), d_labs[k].data_ptr(), d_pls[k].data_ptr(), d_npls[k].data_ptr(), B)
+            check(L.planar_lsd_detect_dev(lss[k].h, B, 40, d_kls[k].data_ptr(), d_ldescs[k].data_ptr(), d_leqs[k].data_ptr(), d_nls[k].data_ptr()))
+            if side: side[1].record(sp); side[3].record(sl)
+            join_p[k].record(sp); join_l[k].record(sl)
         ex.extract_dev(frames.data_ptr(), d_kps.data_ptr(), d_desc[cur].data_ptr(), d_n[cur].data_ptr(), B)
         if evs: evs[1].record(stream)
         if full:
@@ -185,18 +212,15 @@ def main():
                                                 d_n[prev].data_ptr(), ex.kp_cap, has_mp.data_ptr(), outl.data_ptr(), B, cur_match.data_ptr(),
                                                 npair.data_ptr()))
             if evs: evs[3].record(stream)
-            fork3.record(stream)
-            s_peac.wait_event(fork2); s_peac.wait_event(fork3)        # after the throughput kernels of both other streams
-            if side: side[0].record(s_peac)
-            pd.segment_dev(depth.data_ptr(), d_lab.data_ptr(), d_pl.data_ptr(), d_npl.data_ptr(), B)                       # stream s_peac
-            s_lsd.wait_event(fork3)
-            check(L.planar_lsd_detect_dev(ls.h, B, 40, d_kl.data_ptr(), d_ldesc.data_ptr(), d_leq.data_ptr(), d_nl.data_ptr()))  # stream s_lsd
-            if side: side[1].record(s_peac); side[3].record(s_lsd)
-            join_p.record(s_peac); join_l.record(s_lsd)
-            stream.wait_event(join_p); stream.wait_event(join_l)      # PoseOptimization consumes points, lines and planes
-            if evs: evs[4].record(stream)
-            opt.enqueue_dev(pb, 0, 4, 10)
-            if evs: evs[5].record(stream)
+            if pending:
+                pk, pevs = pending.pop()
+                pose(pk, pevs)
+            pending.append((k, evs))
+
+    def drain():
+        while pending:
+            pk, pevs = pending.pop()
+            pose(pk, pevs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,6 +230,7 @@ def main():
     with torch.cuda.stream(stream):
         for i in range(args.warmup):
             step(i)
+        if full: drain()
         standalone = {}
         if full:   # calibration: each sequential extractor alone on the device (not part of the timed region)
             for name, fn in (("peac_segment_alone_ms", lambda: pd.segment_dev(depth.data_ptr(), d_lab.data_ptr(), d_pl.data_ptr(), d_npl.data_ptr(), B)),
@@ -215,20 +240,24 @@ def main():
                 t1 = time.perf_counter(); fn(); torch.cuda.synchronize()
                 standalone[name] = round((time.perf_counter() - t1) * 1e3, 3)
         ex.set_profiling(True)
-        evsets = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(args.steps)]
+        evsets = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 2)] for _ in range(args.steps)]
         sides = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i, evsets[i], sides[i])
+        if full: drain()               # the last step's PoseOptimization: all K steps are complete inside the timed region
         barrier()
         elapsed = time.perf_counter() - t0
         prof, calls = ex.get_profile()
         ex.set_profiling(False)
     if full:
-        pd.L.planar_peac_check(pd.h, B)
+        for q in pds:
+            q.L.planar_peac_check(q.h, B)
 
     stage_ms = {n: sum(e[k].elapsed_time(e[k + 1]) for e in evsets) / args.steps for k, n in enumerate(stage_names)}
+    if full:   # the pose stage of step i is enqueued during step i+1: its wait starts at event 6, not at the end of step i's matchers
+        stage_ms["wait_lines_planes"] = sum(e[6].elapsed_time(e[4]) for e in evsets) / args.steps
     if full:   # the two side streams run concurrently with the ORB stream
         stage_ms["peac_extract(stream 2)"] = sum(e[0].elapsed_time(e[1]) for e in sides) / args.steps
         stage_ms["lsd_lbd_extract(stream 3)"] = sum(e[2].elapsed_time(e[3]) for e in sides) / args.steps
@@ -327,7 +356,7 @@ def main():
                "sample": f"{n} frames of the same synthetic set through the oracle/ restatements of the same stages (1 thread, {dt:.1f} s)",
                "ms_per_frame": {k: round(v / n * 1e3, 2) for k, v in per.items() if v > 0}, "host_cores": os.cpu_count()}
 
-    workload = ("configs[2]+[3]: full extract (ORB + LSD/LBD lines + PEAC planes, 3 streams) + SearchByProjection + MatchORBPoints + PoseOptimization 4x10 "
+    workload = ("configs[2]+[3]: full extract (ORB + LSD/LBD lines + PEAC planes on separate streams, pose of step i-1 pipelined behind step i) + SearchByProjection + MatchORBPoints + PoseOptimization 4x10 "
                 "(1000 pt + 150 line-endpoint + 12 plane edges)"
                 if full else "configs[1]: ORB only, 640x480 gray, 8-level pyramid, 1000 keypoints + 256-bit rBRIEF")
     out = {

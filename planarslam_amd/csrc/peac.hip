@@ -230,12 +230,12 @@ __device__ __forceinline__ void lst_insert(u16* lst, int& cnt, int v) {
     lst[i] = (u16)v; cnt++;
 }
 
-__global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
-                                                   int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
-                                                   int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
-                                                   int32_t* __restrict__ status, long long* __restrict__ timing) {
+__device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, const Consts& C, const uint16_t* __restrict__ depth, int pitch_px,
+                                              int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
+                                              int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
+                                              int32_t* __restrict__ status, long long* __restrict__ timing, const int frame) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* F = ws + (size_t)frame * L.frame_bytes;
     double* g_stats = (double*)(F + L.off_stats);
     double* g_geo = (double*)(F + L.off_geo);
@@ -985,6 +985,20 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
     }
 }
 
+// One workgroup per frame, one workgroup per CU at a time (the merge heap fills its LDS).  A workgroup takes the next frame from a counter
+// when it STARTS instead of using its block index: frames differ by up to 1.7x in merge steps, the dispatcher deals block indices
+// round-robin over the 8 XCDs, and a periodic mix of frames would otherwise send every slow frame to the same XCD.
+// (A persistent one-workgroup-per-CU loop costs ~50 more VGPRs and with them the co-residency of lsd_detect's wavefront on the same SIMDs.)
+__global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
+                                                   int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
+                                                   int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
+                                                   int32_t* __restrict__ status, long long* __restrict__ timing, int* __restrict__ next_frame) {
+    __shared__ int s_frame;
+    if (threadIdx.x == 0) s_frame = atomicAdd(next_frame, 1);
+    __syncthreads();
+    segment_frame(L, K, C, depth, pitch_px, frame_stride_px, ws, labels, label_stride, planes, n_planes, status, timing, s_frame);
+}
+
 }  // namespace peac
 }  // namespace planar
 
@@ -999,7 +1013,7 @@ struct planar_peac {
     peac::Layout L{};
     peac::Consts C{};
     int smem = 0;
-    DevBuf d_ws, d_status, d_timing;
+    DevBuf d_ws, d_status, d_timing, d_next;
     DevBuf d_depth, d_labels, d_planes, d_nplanes;   // staging for the host-pointer entry point
 };
 
@@ -1041,7 +1055,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     o->C.cos_refine = std::cos(30.0 * deg);
     int rc;
     if ((rc = o->d_ws.alloc((size_t)max_batch * L.frame_bytes)) || (rc = o->d_status.alloc((size_t)max_batch * 4)) ||
-        (rc = o->d_timing.alloc((size_t)max_batch * 128))) { delete o; return rc; }
+        (rc = o->d_timing.alloc((size_t)max_batch * 128)) || (rc = o->d_next.alloc(256))) { delete o; return rc; }
     if (o->smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)peac::peac_segment, hipFuncAttributeMaxDynamicSharedMemorySize, o->smem);
         if (e != hipSuccess) { delete o; set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
@@ -1061,8 +1075,10 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     hipStream_t st = p->ctx->stream;
     const peac::Intr K{fx, fy, cx, cy, depth_factor};
     hipLaunchKernelGGL(peac::peac_blocks, dim3((p->L.NB + 63) / 64, B), dim3(64), 0, st, p->L, K, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>());
-    hipLaunchKernelGGL(peac::peac_segment, dim3(B), dim3(peac::NT), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>(),
-                       d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
+    PLANAR_HIP_CHECK(hipMemsetAsync(p->d_next.p, 0, 4, st));
+    hipLaunchKernelGGL(peac::peac_segment, dim3(B), dim3(peac::NT), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+                       p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>(),
+                       p->d_next.as<int>());
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
 }
