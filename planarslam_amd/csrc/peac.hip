@@ -62,13 +62,43 @@ __device__ __forceinline__ void make_givens(double p, double q, double& c, doubl
     else if (fabs(p) > fabs(q)) { const double t = q / p; double u = sqrt(1.0 + t * t); if (p < 0) u = -u; c = 1.0 / u; s = -t * c; }
     else { const double t = p / q; double u = sqrt(1.0 + t * t); if (q < 0) u = -u; s = -1.0 / u; c = -t * s; }
 }
+// One implicit symmetric QR step on the unreduced block [START, END] of the tridiagonal matrix (Eigen's tridiagonal_qr_step).  The block
+// bounds are template parameters so that diag / sub / Q are indexed by constants and stay in registers: a 3x3 matrix has only the three
+// blocks (0,2), (1,2), (0,1).  Same operations in the same order as the loop form.
+template <int START, int END>
+__device__ __forceinline__ void eig_qr_step(double (&diag)[3], double (&sub)[2], double (&Q)[3][3]) {
+    const double td = (diag[END - 1] - diag[END]) * 0.5, e = sub[END - 1];
+    double mu = diag[END];
+    if (td == 0) mu -= fabs(e);
+    else {
+        const double e2 = e * e, h = eig_hypot(td, e);
+        if (e2 == 0) mu -= (e / (td + (td > 0 ? 1.0 : -1.0))) * (e / h);
+        else mu -= e2 / (td + (td > 0 ? h : -h));
+    }
+    double x = diag[START] - mu, z = sub[START];
+#pragma unroll
+    for (int k = START; k < END; ++k) {
+        double c, s;
+        make_givens(x, z, c, s);
+        const double sdk = s * diag[k] + c * sub[k];
+        const double dkp1 = s * sub[k] + c * diag[k + 1];
+        diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+        diag[k + 1] = s * sdk + c * dkp1;
+        sub[k] = c * sdk - s * dkp1;
+        if (k > START) sub[k - 1] = c * sub[k - 1] - s * z;
+        x = sub[k];
+        if (k < END - 1) { z = -s * sub[k + 1]; sub[k + 1] = c * sub[k + 1]; }
+#pragma unroll
+        for (int r = 0; r < 3; r++) { const double xi = Q[r][k], yi = Q[r][k + 1]; Q[r][k] = c * xi - s * yi; Q[r][k + 1] = s * xi + c * yi; }
+    }
+}
 // lower triangle a00,a10,a11,a20,a21,a22 -> smallest eigenvalue ev0 (+ev1, ev2) and its eigenvector v0
 __device__ void eig33(double a00, double a10, double a11, double a20, double a21, double a22, double ev[3], double v0[3]) {
     double scale = fmax(fmax(fmax(fabs(a00), fabs(a10)), fmax(fabs(a11), fabs(a20))), fmax(fabs(a21), fabs(a22)));
     if (scale == 0) scale = 1;
     a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
     double d0, d1, d2, s0, s1;
-    double q00 = 1, q01 = 0, q02 = 0, q10 = 0, q11 = 1, q12 = 0, q20 = 0, q21 = 0, q22 = 1;
+    double q11 = 1, q12 = 0, q21 = 0, q22 = 1;
     d0 = a00;
     const double v1norm2 = a20 * a20;
     if (v1norm2 <= 2.2250738585072014e-308) { d1 = a11; d2 = a22; s0 = a10; s1 = a21; }
@@ -81,49 +111,31 @@ __device__ void eig33(double a00, double a10, double a11, double a20, double a21
         q11 = m01; q12 = m02; q21 = m02; q22 = -m01;
     }
     double diag[3] = {d0, d1, d2}, sub[2] = {s0, s1};
-    double Q[3][3] = {{q00, q01, q02}, {q10, q11, q12}, {q20, q21, q22}};
+    double Q[3][3] = {{1, 0, 0}, {0, q11, q12}, {0, q21, q22}};
     int end = 2, start = 0, iter = 0;
     const double considerAsZero = 2.2250738585072014e-308, precision = 2.0 * 2.220446049250313e-16;
     while (end > 0) {
-        for (int i = start; i < end; ++i)
-            if (fabs(sub[i]) <= (fabs(diag[i]) + fabs(diag[i + 1])) * precision || fabs(sub[i]) <= considerAsZero) sub[i] = 0;
-        while (end > 0 && sub[end - 1] == 0) end--;
+        // for (i = start; i < end; ++i) deflate sub[i]
+        if (start <= 0 && 0 < end && (fabs(sub[0]) <= (fabs(diag[0]) + fabs(diag[1])) * precision || fabs(sub[0]) <= considerAsZero)) sub[0] = 0;
+        if (start <= 1 && 1 < end && (fabs(sub[1]) <= (fabs(diag[1]) + fabs(diag[2])) * precision || fabs(sub[1]) <= considerAsZero)) sub[1] = 0;
+        if (end == 2 && sub[1] == 0) end = 1;                 // while (end > 0 && sub[end - 1] == 0) end--
+        if (end == 1 && sub[0] == 0) end = 0;
         if (end <= 0) break;
         iter++;
         if (iter > 90) break;
         start = end - 1;
-        while (start > 0 && sub[start - 1] != 0) start--;
-        const double td = (diag[end - 1] - diag[end]) * 0.5, e = sub[end - 1];
-        double mu = diag[end];
-        if (td == 0) mu -= fabs(e);
-        else {
-            const double e2 = e * e, h = eig_hypot(td, e);
-            if (e2 == 0) mu -= (e / (td + (td > 0 ? 1.0 : -1.0))) * (e / h);
-            else mu -= e2 / (td + (td > 0 ? h : -h));
-        }
-        double x = diag[start] - mu, z = sub[start];
-        for (int k = start; k < end; ++k) {
-            double c, s;
-            make_givens(x, z, c, s);
-            const double sdk = s * diag[k] + c * sub[k];
-            const double dkp1 = s * sub[k] + c * diag[k + 1];
-            diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
-            diag[k + 1] = s * sdk + c * dkp1;
-            sub[k] = c * sdk - s * dkp1;
-            if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
-            x = sub[k];
-            if (k < end - 1) { z = -s * sub[k + 1]; sub[k + 1] = c * sub[k + 1]; }
-            for (int r = 0; r < 3; r++) { const double xi = Q[r][k], yi = Q[r][k + 1]; Q[r][k] = c * xi - s * yi; Q[r][k + 1] = s * xi + c * yi; }
-        }
+        if (start == 1 && sub[0] != 0) start = 0;             // while (start > 0 && sub[start - 1] != 0) start--
+        if (end == 2) { if (start == 0) eig_qr_step<0, 2>(diag, sub, Q); else eig_qr_step<1, 2>(diag, sub, Q); }
+        else eig_qr_step<0, 1>(diag, sub, Q);
     }
-    if (iter <= 90) {
+    if (iter <= 90) {   // selection sort of the eigenvalues (increasing), eigenvector columns follow
+#pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int k = 0;
-            for (int j = 1; j < 3 - i; j++) if (diag[i + j] < diag[i + k]) k = j;
-            if (k > 0) {
-                const double t = diag[i]; diag[i] = diag[k + i]; diag[k + i] = t;
-                for (int r = 0; r < 3; r++) { const double u = Q[r][i]; Q[r][i] = Q[r][k + i]; Q[r][k + i] = u; }
-            }
+            if (i == 0) {
+                const int k = diag[2] < (diag[1] < diag[0] ? diag[1] : diag[0]) ? 2 : (diag[1] < diag[0] ? 1 : 0);
+                if (k == 1) { const double t = diag[0]; diag[0] = diag[1]; diag[1] = t; for (int r = 0; r < 3; r++) { const double u = Q[r][0]; Q[r][0] = Q[r][1]; Q[r][1] = u; } }
+                if (k == 2) { const double t = diag[0]; diag[0] = diag[2]; diag[2] = t; for (int r = 0; r < 3; r++) { const double u = Q[r][0]; Q[r][0] = Q[r][2]; Q[r][2] = u; } }
+            } else if (diag[2] < diag[1]) { const double t = diag[1]; diag[1] = diag[2]; diag[2] = t; for (int r = 0; r < 3; r++) { const double u = Q[r][1]; Q[r][1] = Q[r][2]; Q[r][2] = u; } }
         }
     }
     for (int i = 0; i < 3; i++) ev[i] = diag[i] * scale;
