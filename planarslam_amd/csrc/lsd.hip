@@ -34,6 +34,7 @@ constexpr double DEG_TO_RADS = LSD_PI / 180;
 constexpr double RELATIVE_ERROR_FACTOR = 100.0;
 constexpr int N_BINS = 1024;
 constexpr int MAX_SEGS = 2048;     // raw LSD segments kept per frame
+constexpr int MAX_RECTS = 4096;    // regions that reach the NFA stage, per frame
 constexpr int RING = 512;          // recent region points kept in LDS
 constexpr int USED_LDS_BITS = 32768;   // `used` flags of the first 32768 defined pixels live in LDS, the rest in global memory
 
@@ -43,14 +44,14 @@ struct Plan {
     double rho, prec, p, log_nt, density_th, log_eps;
     int min_reg_size;
     // per-frame workspace offsets (bytes)
-    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_pix, off_seed, off_ord, off_ordr, off_gused, off_tmp, off_reg, off_segs, off_kl, frame_bytes;
+    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_pix, off_seed, off_ord, off_ordr, off_gused, off_tmp, off_reg, off_segs, off_kl, off_rects, off_res, frame_bytes;
     // host-evaluated tables (glibc, as the reference library would): log_gamma(x) for integer x, and per halving j of p
     const double* lgamma_tab;   // [w*h + 3]
     double p_log[12], p1_log[12], p_log10[12];
     double gaussCoefL[21], gaussCoefG[63];
 };
 
-struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int pad; long long t[8]; };
+struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; };
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2: 7th-order odd polynomial, degrees; plain mul/add (no FMA), see oracle/cvprim.cpp
@@ -1051,9 +1052,9 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
     wave_sync();
     const uint32_t* ord = (const uint32_t*)(F + P.off_ord);
     const uint32_t* ordr = (const uint32_t*)(F + P.off_ordr);
-    Seg* segs = (Seg*)(F + P.off_segs);
+    Rect* rects = (Rect*)(F + P.off_rects);
     const int n_ord = misc->n_ord;
-    int n_seg = 0, n_regions = 0, n_px = 0;
+    int n_rect = 0, n_regions = 0, n_px = 0;
     long long t_grow = 0, t_rect = 0, t_refine = 0, t_nfa = 0;
     const long long t_begin = __builtin_readcyclecounter();
     for (int base = 0; base < n_ord; base += 64) {
@@ -1081,20 +1082,57 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
             const bool keep = refine(D, n, reg_angle, P.prec, P.p, rec, P.density_th);
             c1 = __builtin_readcyclecounter(); t_refine += c1 - c0;
             if (!keep) continue;
-            const double log_nfa = rect_improve(D, rec, P.log_eps);
-            c0 = __builtin_readcyclecounter(); t_nfa += c0 - c1;
-            if (log_nfa <= P.log_eps) continue;
-            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
-            rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8; rec.width /= 0.8;
-            if (lane == 0 && n_seg < MAX_SEGS) segs[n_seg] = Seg{float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2), rec.width, rec.p, log_nfa};
-            n_seg++;
+            // the NFA stage (rect_improve) reads only the angle image: it runs for all regions in parallel in lsd_improve
+            if (lane == 0 && n_rect < MAX_RECTS) rects[n_rect] = rec;
+            n_rect++;
         }
     }
     if (lane == 0) {
-        misc->n_seg = n_seg; misc->n_regions = n_regions; misc->n_grown_px = n_px;
-        if (n_seg > MAX_SEGS) misc->status = 1;
+        misc->n_rect = min(n_rect, MAX_RECTS); misc->n_regions = n_regions; misc->n_grown_px = n_px;
+        if (n_rect > MAX_RECTS) misc->status = 1;
         misc->t[0] = __builtin_readcyclecounter() - t_begin; misc->t[1] = t_grow; misc->t[2] = t_rect; misc->t[3] = t_refine; misc->t[4] = t_nfa;
     }
+}
+
+// ---- K4b: NFA stage of every region that survived refine(): one wavefront per region, all regions of all frames in parallel ---------
+__global__ __launch_bounds__(256) void lsd_improve(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, const Misc* __restrict__ miscs) {
+    const Plan& P = *plan;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    Det D{};
+    D.ang = (const float*)(F + P.off_ang); D.plan = plan; D.w = P.w; D.h = P.h; D.log_nt = P.log_nt; D.lane = lane;
+    const Rect* rects = (const Rect*)(F + P.off_rects);
+    Seg* res = (Seg*)(F + P.off_res);
+    const int n = miscs[b].n_rect;
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        Rect rec = rects[i];
+        const double log_nfa = rect_improve(D, rec, P.log_eps);
+        rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+        rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8; rec.width /= 0.8;
+        if (lane == 0) res[i] = Seg{float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2), rec.width, rec.p, log_nfa};
+    }
+}
+
+// ---- K4c: the accepted segments (NFA above the threshold), in region order -----------------------------------------------------------
+__global__ __launch_bounds__(64) void lsd_accept(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    const Plan& P = *plan;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    const Seg* res = (const Seg*)(F + P.off_res);
+    Seg* segs = (Seg*)(F + P.off_segs);
+    const int n = miscs[b].n_rect;
+    int n_seg = 0;
+    for (int base = 0; base < n; base += 64) {
+        Seg sg{};
+        const bool in = base + lane < n;
+        if (in) sg = res[base + lane];
+        const bool ok = in && sg.nfa > P.log_eps;
+        const unsigned long long m = __ballot(ok);
+        const int pos = n_seg + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && pos < MAX_SEGS) segs[pos] = sg;
+        n_seg += __popcll(m);
+    }
+    if (lane == 0) { miscs[b].n_seg = n_seg; if (n_seg > MAX_SEGS) miscs[b].status = 1; }
 }
 
 // ---- K5: Sobel 3x3 (cv::Sobel CV_16S, BORDER_REFLECT_101) of the 5x5-blurred image ------------------------------------
@@ -1489,6 +1527,7 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     P.off_blur7 = carve(NPf); P.off_blur5 = carve(NPf); P.off_dx = carve(NPf * 2); P.off_dy = carve(NPf * 2);
     P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_pix = carve(NPs * 16); P.off_seed = carve(NPs * 8); P.off_ordr = carve(NPs * 4); P.off_gused = carve((NPs + 31) / 32 * 4 + 256); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
     P.off_segs = carve((size_t)lsd::MAX_SEGS * sizeof(lsd::Seg)); P.off_kl = carve((size_t)lsd::MAX_SEGS * sizeof(planar_keyline));
+    P.off_rects = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Rect)); P.off_res = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Seg));
     P.frame_bytes = off;
     o->detect_smem = 64 * 3 * 8 + lsd::USED_LDS_BITS / 8 + lsd::RING * 4 + 16;
     if (o->detect_smem > 150 * 1024 || NPs > (1u << 20)) { delete o; set_error("planar_lsd_create: image too large for the LDS-resident used map"); return PLANAR_EINVAL; }
@@ -1564,6 +1603,8 @@ int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d
     uint8_t* ws = o->d_ws.as<uint8_t>();
     lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
     hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, st, dP, ws, dm);
+    hipLaunchKernelGGL(lsd::lsd_improve, dim3(32, B), dim3(256), 0, st, dP, ws, dm);
+    hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm);
     hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines);
     hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
     PLANAR_HIP_CHECK(hipGetLastError());

@@ -39,5 +39,5 @@ regs = [int(ls.read_stage(b, 4)[0]) for b in range(min(B, 8))]
 segs = [len(ls.read_stage(b, 3)) for b in range(min(B, 8))]
 print(f"LSD+LBD B={B}: {dt * 1e3:.1f} ms/batch = {B / dt:.0f} frames/s | regions/frame {regs} | raw segments/frame {segs} | kept {n[:8].tolist()}")
 t = ls.read_stage(0, 5)
-print("frame 0 detect cycles: total %d | grow %d | region2rect %d | refine %d | rect_improve %d | ordered px %d | grown px %d" % tuple(t[:7]))
+print("frame 0 detect cycles: total %d | grow %d | region2rect %d | refine %d | (rect_improve: separate kernel) %d | ordered px %d | grown px %d" % tuple(t[:7]))
 print("frame 0 sort cycles: workgroup tier %d | LDS tier %d | radix passes %d" % tuple(t[7:10]))
