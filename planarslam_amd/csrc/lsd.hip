@@ -622,55 +622,84 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SE
 // LDS traffic of one wavefront is processed in program order, so lanes only need the compiler to keep that order
 __device__ __forceinline__ void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-// region_grow: returns the region size; reg_angle in/out per the reference (out: final level-line angle)
-__device__ int region_grow(const Det& D, int seed_pix, uint32_t seed_rank, double prec, double& reg_angle) {
+// region_grow: returns the region size; reg_angle in/out per the reference (out: final level-line angle).
+// Queue entries are expanded 7 at a time (63 lanes = 7 entries x 9 neighbours, in the reference's order).  The neighbour records of the
+// NEXT batch (entries already queued behind the current one; any batching gives the same sequence) are requested before the current
+// batch is resolved, so their memory latency hides behind the sequential accept loop.  Inside the loop nothing waits on LDS: `used` is read
+// once per batch, duplicates of an accepted pixel inside the batch are masked by comparing compact indices in registers.
+struct GrowBatch { bool ok; uint32_t nxy; float4 rec4; };
+__device__ __forceinline__ GrowBatch grow_fetch(const Det& D, int head, int nb, int reg_n) {
     const int lane = D.lane, w = D.w, h = D.h;
+    const int e = lane / 9, k = lane - e * 9;
+    GrowBatch g;
+    g.ok = false; g.nxy = 0; g.rec4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
+    if (lane < 63 && e < nb && k != 4) {
+        const int i = head + e;
+        uint32_t pxy;
+        if (reg_n - i <= RING) pxy = ((volatile uint32_t*)D.ring)[i & (RING - 1)];
+        else pxy = __builtin_nontemporal_load(D.reg + i);
+        const int xx = (int)(pxy & 0xffff) + (k % 3) - 1, yy = (int)(pxy >> 16) + (k / 3) - 1;
+        if (xx >= 0 && xx < w && yy >= 0 && yy < h) { g.ok = true; g.nxy = (uint32_t)xx | ((uint32_t)yy << 16); g.rec4 = D.pix4[yy * w + xx]; }
+    }
+    return g;
+}
+__device__ int region_grow(const Det& D, int seed_pix, uint32_t seed_rank, double prec, double& reg_angle) {
+    const int lane = D.lane;
     reg_angle = (double)D.ang[seed_pix] * DEG_TO_RADS;
     const float2 scs = D.seedcs[seed_pix];
     float sumdx = scs.x, sumdy = scs.y;
-    const uint32_t seed_xy = (uint32_t)(seed_pix % w) | ((uint32_t)(seed_pix / w) << 16);
+    const uint32_t seed_xy = (uint32_t)(seed_pix % D.w) | ((uint32_t)(seed_pix / D.w) << 16);
     if (lane == 0) { D.reg[0] = seed_xy; D.ring[0] = seed_xy; used_set(D, seed_rank); }
     wave_sync();
-    int reg_n = 1, head = 0;
-    while (head < reg_n) {
-        const int nb = min(7, reg_n - head);
-        if (reg_n - head > RING) wave_sync();      // (rare) the batch reads entries that left the LDS ring: make the global copies visible
-        const int e = lane / 9, k = lane - e * 9;
-        bool ok = false;
-        int pix = 0;
-        uint32_t nxy = 0;
-        if (lane < 63 && e < nb && k != 4) {
-            const int i = head + e;
-            uint32_t pxy;
-            if (reg_n - i <= RING) pxy = ((volatile uint32_t*)D.ring)[i & (RING - 1)];
-            else pxy = __builtin_nontemporal_load(D.reg + i);
-            const int xx = (int)(pxy & 0xffff) + (k % 3) - 1, yy = (int)(pxy >> 16) + (k / 3) - 1;
-            if (xx >= 0 && xx < w && yy >= 0 && yy < h) { ok = true; pix = yy * w + xx; nxy = (uint32_t)xx | ((uint32_t)yy << 16); }
-        }
-        float4 rec4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
-        if (ok) rec4 = D.pix4[pix];
-        const float deg = rec4.x, c = rec4.y, s = rec4.z;
-        const uint32_t rk = __float_as_uint(rec4.w);
-        ok = ok && deg != NOTDEF_F;
-        const double a = (double)deg * DEG_TO_RADS;
-        int cursor = 0;
-        while (true) {
-            const bool cand = ok && lane >= cursor && !used_get(D, rk) && aligned_rad(a, reg_angle, prec);
-            const unsigned long long m = __ballot(cand);
-            if (!m) break;
-            const int f = __ffsll((long long)m) - 1;
-            const uint32_t axy = (uint32_t)__shfl((int)nxy, f, 64);
-            if (lane == f) used_set(D, rk);
-            if (lane == 0) { D.reg[reg_n] = axy; D.ring[reg_n & (RING - 1)] = axy; }
-            reg_n++;
-            sumdx += __shfl(c, f, 64);
-            sumdy += __shfl(s, f, 64);
-            reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * DEG_TO_RADS;
-            cursor = f + 1;
-            lds_sync();
-        }
-        head += nb;
+    int reg_n = 1, head = 0, nb = 1;
+    GrowBatch cur = grow_fetch(D, 0, 1, 1);
+    // Most regions are a few dozen pixels and their frontier is too short to prefetch from: touch the cache lines of the 16x16 window around
+    // the seed now (issued behind the first batch, never waited for before the region is done), so the following batches hit the L2.
+    float4 warm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < 48) {
+        const int wy = min(max((int)(seed_xy >> 16) - 8 + lane / 3, 0), D.h - 1), wx = min(max((int)(seed_xy & 0xffff) - 8 + (lane % 3) * 8, 0), D.w - 1);
+        warm = D.pix4[wy * D.w + wx];
     }
+    while (true) {
+        const int head_n = head + nb;
+        int nb_n = min(7, reg_n - head_n);
+        if (reg_n - head_n > RING) nb_n = 0;       // (rare) entries that left the LDS ring are fetched after the wave_sync below
+        GrowBatch nxt;
+        if (nb_n > 0) nxt = grow_fetch(D, head_n, nb_n, reg_n);
+        {
+            const float deg = cur.rec4.x, c = cur.rec4.y, sn = cur.rec4.z;
+            const uint32_t rk = __float_as_uint(cur.rec4.w);
+            bool ok = cur.ok && deg != NOTDEF_F;
+            ok = ok && !used_get(D, rk);
+            const double a = (double)deg * DEG_TO_RADS;
+            int cursor = 0;
+            while (true) {
+                const bool cand = ok && lane >= cursor && aligned_rad(a, reg_angle, prec);
+                const unsigned long long m = __ballot(cand);
+                if (!m) break;
+                const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                const uint32_t axy = (uint32_t)__builtin_amdgcn_readlane((int)cur.nxy, f);
+                const uint32_t ark = (uint32_t)__builtin_amdgcn_readlane((int)rk, f);
+                if (lane == 0) { used_set(D, ark); D.reg[reg_n] = axy; D.ring[reg_n & (RING - 1)] = axy; }
+                reg_n++;
+                sumdx += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), f));
+                sumdy += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), f));
+                reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * DEG_TO_RADS;
+                ok = ok && rk != ark;              // the same pixel as a neighbour of another entry of this batch: now used
+                cursor = f + 1;
+            }
+        }
+        lds_sync();                                // ring / used updates of this batch before the next batch reads them
+        head = head_n;
+        if (head >= reg_n) break;
+        if (nb_n > 0) { cur = nxt; nb = nb_n; }
+        else {
+            if (reg_n - head > RING) wave_sync();  // the batch reads entries that left the LDS ring: make the global copies visible
+            nb = min(7, reg_n - head);
+            cur = grow_fetch(D, head, nb, reg_n);
+        }
+    }
+    asm volatile("" :: "v"(warm.x));               // keeps the window loads alive
     wave_sync();
     return reg_n;
 }
