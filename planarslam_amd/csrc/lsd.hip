@@ -954,8 +954,7 @@ __device__ int rect_counts(const Det& D, const Rect& rec, const double* precs, i
     for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
     int alg[NP];
     for (int q = 0; q < NP; q++) alg[q] = 0;
-    auto test = [&](int pix) {
-        const float deg = D.ang[pix];
+    auto test = [&](float deg) {
         if (deg == NOTDEF_F) return;
         double n_theta = rec.theta - (double)deg * DEG_TO_RADS;
         if (n_theta < 0) n_theta = -n_theta;
@@ -965,20 +964,34 @@ __device__ int rect_counts(const Det& D, const Rect& rec, const double* precs, i
         }
         for (int q = 0; q < NP; q++) if (n_theta <= precs[q]) alg[q]++;
     };
+    constexpr int RU = 4;                                    // gathers in flight per lane (unconditional loads of a clamped index)
     if (wmax > 0 && wmax <= 64) {
         int wp = 1; while (wp < wmax) wp <<= 1;
         const int rps = 64 / wp, sub = lane / wp, xo = lane & (wp - 1);
-        for (int kb = 0; kb < nrows; kb += rps) {
-            const int k = kb + sub;
-            if (k < nrows) {
-                int xa; const int c = row_span(k, xa);
-                if (xo < c) test((ylo + k) * D.w + xa + xo);
+        for (int kb = 0; kb < nrows; kb += rps * RU) {
+            int pix[RU]; float deg[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int k = kb + u * rps + sub;
+                pix[u] = -1;
+                if (k < nrows) { int xa; const int c = row_span(k, xa); if (xo < c) pix[u] = (ylo + k) * D.w + xa + xo; }
             }
+#pragma unroll
+            for (int u = 0; u < RU; u++) deg[u] = D.ang[max(pix[u], 0)];
+#pragma unroll
+            for (int u = 0; u < RU; u++) if (pix[u] >= 0) test(deg[u]);
         }
     } else if (wmax > 64) {
         for (int k = 0; k < nrows; k++) {
             int xa; const int c = row_span(k, xa);
-            for (int xo = lane; xo < c; xo += 64) test((ylo + k) * D.w + xa + xo);
+            const int base = (ylo + k) * D.w + xa;
+            for (int x0 = 0; x0 < c; x0 += 64 * RU) {
+                float deg[RU];
+#pragma unroll
+                for (int u = 0; u < RU; u++) deg[u] = D.ang[base + min(x0 + 64 * u + lane, c - 1)];
+#pragma unroll
+                for (int u = 0; u < RU; u++) if (x0 + 64 * u + lane < c) test(deg[u]);
+            }
         }
     }
     for (int q = 0; q < NP; q++) alg_out[q] = wave_sum_i(alg[q]);
@@ -1123,17 +1136,18 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
     }
 }
 
-// ---- K4b: NFA stage of every region that survived refine(): one wavefront per region, all regions of all frames in parallel ---------
-__global__ __launch_bounds__(256) void lsd_improve(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, const Misc* __restrict__ miscs) {
+// ---- K4b: NFA stage of every region that survived refine(): one wavefront (= one workgroup) per region, all regions of all frames in
+// parallel; 128 wavefronts per frame share the frame's regions round-robin
+__global__ __launch_bounds__(64) void lsd_improve(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, const Misc* __restrict__ miscs) {
     const Plan& P = *plan;
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
     Det D{};
     D.ang = (const float*)(F + P.off_ang); D.plan = plan; D.w = P.w; D.h = P.h; D.log_nt = P.log_nt; D.lane = lane;
     const Rect* rects = (const Rect*)(F + P.off_rects);
     Seg* res = (Seg*)(F + P.off_res);
     const int n = miscs[b].n_rect;
-    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
         Rect rec = rects[i];
         const double log_nfa = rect_improve(D, rec, P.log_eps);
         rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
@@ -1632,7 +1646,7 @@ int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d
     uint8_t* ws = o->d_ws.as<uint8_t>();
     lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
     hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, st, dP, ws, dm);
-    hipLaunchKernelGGL(lsd::lsd_improve, dim3(32, B), dim3(256), 0, st, dP, ws, dm);
+    hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm);
     hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm);
     hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines);
     hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
