@@ -8,8 +8,8 @@ resident in HBM: ORB extraction, LSD+LBD line extraction and PEAC plane segmenta
 mirroring the reference's three extraction threads, src/Frame.cc:90-95), SearchByProjection(Cur, Last) and
 MatchORBPoints against the previous batch (match) and the 4x10 PoseOptimization protocol on a config-4-shaped
 problem per frame (pose-opt), which waits for all three extractors of its own step.
-Steps are software-pipelined one deep (frames are independent): the line / plane launches of step i overlap the tail
-of step i-1's, and PoseOptimization of step i-1 is enqueued behind the point stages of step i.  Every one of the K
+Steps are software-pipelined `--depth` deep (default 2; frames are independent): the line / plane launches of step i
+overlap the tails of the previous steps', and PoseOptimization of step i-depth is enqueued behind the point stages of step i.  Every one of the K
 timed steps is complete - including its PoseOptimization - before the closing barrier.
 Frames are independent, so ranks shard them with no data-path collective ("scaling": "weak": every rank processes
 its own `--batch` frames per step).  Rank 0 prints ONE JSON line: whole-job frames/s, per-stage times, the roofline
@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--workload", choices=["full", "orb"], default="full")
+    ap.add_argument("--depth", type=int, default=2, help="software-pipeline depth: PoseOptimization of step i is enqueued during step i+depth")
     ap.add_argument("--prio", default="-1,0,0", help="stream priorities: ORB/match/pose stream, LSD streams, PEAC streams (lower = higher priority)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
@@ -82,9 +83,10 @@ def main():
     stream = torch.cuda.Stream(device=local_rank, priority=prio[0])
     ctx = Context(local_rank, stream=stream.cuda_stream)
     # the reference extracts ORB / lines / planes on three threads (src/Frame.cc:90-95): three HIP streams here
-    # two PEAC streams and two LSD streams (even / odd steps): consecutive launches of the sequential extractors overlap (see step())
-    s_peacs = [torch.cuda.Stream(device=local_rank, priority=prio[2]) for _ in range(2)]
-    s_lsds = [torch.cuda.Stream(device=local_rank, priority=prio[1]) for _ in range(2)]
+    # depth+1 PEAC streams and LSD streams (used round-robin): consecutive launches of the sequential extractors overlap (see step())
+    NBUF = args.depth + 1                                     # steps in flight on the line / plane streams
+    s_peacs = [torch.cuda.Stream(device=local_rank, priority=prio[2]) for _ in range(NBUF)]
+    s_lsds = [torch.cuda.Stream(device=local_rank, priority=prio[1]) for _ in range(NBUF)]
     ctx_peacs = [Context(local_rank, stream=q.cuda_stream) for q in s_peacs]
     ctx_lsds = [Context(local_rank, stream=q.cuda_stream) for q in s_lsds]
     L = lib()
@@ -103,9 +105,9 @@ def main():
         depth = torch.from_numpy(rep(depth_src).view(np.int16)).to(dev)
         pds = [PlaneDetection(W, H, max_batch=B, ctx=c) for c in ctx_peacs]                     # one workspace per step in flight
         pd = pds[0]
-        d_labs = [torch.zeros((B, H * W), dtype=torch.int32, device=dev) for _ in range(2)]
-        d_pls = [torch.zeros((B, pd.max_planes, 8), dtype=torch.float64, device=dev) for _ in range(2)]
-        d_npls = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_labs = [torch.zeros((B, H * W), dtype=torch.int32, device=dev) for _ in range(NBUF)]
+        d_pls = [torch.zeros((B, pd.max_planes, 8), dtype=torch.float64, device=dev) for _ in range(NBUF)]
+        d_npls = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NBUF)]
         d_lab, d_pl, d_npl = d_labs[0], d_pls[0], d_npls[0]
         # matcher state
         has_mp = torch.ones((B, ex.kp_cap), dtype=torch.uint8, device=dev)
@@ -135,10 +137,10 @@ def main():
         from planarslam_amd.synth import scale_factors
         lss = [LineSegment(W, H, B, c) for c in ctx_lsds]
         ls = lss[0]
-        d_kls = [torch.zeros(B * 40 * KEYLINE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
-        d_ldescs = [torch.zeros((B, 40, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
-        d_leqs = [torch.zeros((B, 40, 3), dtype=torch.float64, device=dev) for _ in range(2)]
-        d_nls = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_kls = [torch.zeros(B * 40 * KEYLINE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+        d_ldescs = [torch.zeros((B, 40, 32), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+        d_leqs = [torch.zeros((B, 40, 3), dtype=torch.float64, device=dev) for _ in range(NBUF)]
+        d_nls = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NBUF)]
         d_kl, d_ldesc, d_leq, d_nl = d_kls[0], d_ldescs[0], d_leqs[0], d_nls[0]
         # SearchByProjection(Cur, Last): the last frame's map points are the back-projections of the keypoints ORB finds on
         # the same images (identity motion), so every probe has a realistic window of candidates and a true match.
@@ -172,8 +174,8 @@ def main():
 
     stage_names = ["orb_extract"] + (["search_by_projection", "match_orb_points", "wait_lines_planes", "pose_opt_4x10"] if full else [])
     nst = len(stage_names)
-    join_p, join_l, pose_done = ([torch.cuda.Event() for _ in range(2)] for _ in range(3))
-    pending = []          # steps whose PoseOptimization is still to be enqueued (software pipeline, depth 1)
+    join_p, join_l, pose_done = ([torch.cuda.Event() for _ in range(NBUF)] for _ in range(3))
+    pending = []          # steps whose PoseOptimization is still to be enqueued (software pipeline, FIFO of length --depth)
 
     def pose(k, evs=None):
         if evs: evs[6].record(stream)
@@ -188,12 +190,12 @@ def main():
         # workgroup per frame, 149 KB LDS; LSD: one wavefront per frame, 8 KB) of step i run on their own streams beside the ORB stream,
         # and - frames being independent - beside the tail of step i-1's launches (alternating streams, one workspace per step in flight):
         # a PEAC launch ends with its slowest frame (1.5x the mean), and the next launch fills the CUs the finished frames left.
-        # PoseOptimization of step i-1 is enqueued after the point stages of step i, when its lines and planes have had a full step to finish.
-        cur, prev, k = i & 1, (i & 1) ^ 1, i & 1
+        # PoseOptimization of step i-depth is enqueued after the point stages of step i, when its lines and planes have had `depth` steps to finish.
+        cur, prev, k = i & 1, (i & 1) ^ 1, i % NBUF
         sp, sl = s_peacs[k], s_lsds[k]
         if evs: evs[0].record(stream)
         if full:
-            sl.wait_event(pose_done[k]); sp.wait_event(pose_done[k])      # their outputs of step i-2 have been consumed
+            sl.wait_event(pose_done[k]); sp.wait_event(pose_done[k])      # their outputs of step i-NBUF have been consumed
             if side: side[2].record(sl)
             check(L.planar_lsd_preprocess_dev(lss[k].h, frames.data_ptr(), B, W, W * H))
             if side: side[0].record(sp)
@@ -212,15 +214,13 @@ def main():
                                                 d_n[prev].data_ptr(), ex.kp_cap, has_mp.data_ptr(), outl.data_ptr(), B, cur_match.data_ptr(),
                                                 npair.data_ptr()))
             if evs: evs[3].record(stream)
-            if pending:
-                pk, pevs = pending.pop()
-                pose(pk, pevs)
             pending.append((k, evs))
+            if len(pending) > args.depth:
+                pose(*pending.pop(0))
 
     def drain():
         while pending:
-            pk, pevs = pending.pop()
-            pose(pk, pevs)
+            pose(*pending.pop(0))
 
     def barrier():
         torch.cuda.synchronize()
@@ -356,7 +356,7 @@ def main():
                "sample": f"{n} frames of the same synthetic set through the oracle/ restatements of the same stages (1 thread, {dt:.1f} s)",
                "ms_per_frame": {k: round(v / n * 1e3, 2) for k, v in per.items() if v > 0}, "host_cores": os.cpu_count()}
 
-    workload = ("configs[2]+[3]: full extract (ORB + LSD/LBD lines + PEAC planes on separate streams, pose of step i-1 pipelined behind step i) + SearchByProjection + MatchORBPoints + PoseOptimization 4x10 "
+    workload = ("configs[2]+[3]: full extract (ORB + LSD/LBD lines + PEAC planes on separate streams, pose of step i-depth pipelined behind step i) + SearchByProjection + MatchORBPoints + PoseOptimization 4x10 "
                 "(1000 pt + 150 line-endpoint + 12 plane edges)"
                 if full else "configs[1]: ORB only, 640x480 gray, 8-level pyramid, 1000 keypoints + 256-bit rBRIEF")
     out = {

@@ -48,3 +48,21 @@ def test_hip_other_size():
     op, olab = ol.peac_run(d)
     planes, labels = PlaneDetection(320, 240).run(d)
     assert np.array_equal(labels, olab) and np.array_equal(planes, op)
+
+
+def test_hip_more_frames_than_cus_and_repeated_calls():
+    """Workgroups take their frame from a start-order counter: more frames than CUs (several dispatch rounds) and a second call on the
+    same handle (counter reset) must give, frame by frame, what a single-frame call gives."""
+    from planarslam_amd import PlaneDetection
+    src = np.stack([depth_image(900 + i) for i in range(3)])
+    one = PlaneDetection(640, 480, max_batch=1)
+    want = [one.run(src[i]) for i in range(3)]
+    B = 300
+    pd = PlaneDetection(640, 480, max_batch=B)
+    depths = src[np.arange(B) % 3]
+    for _ in range(2):
+        res = pd.run(depths)
+        for b in range(B):
+            wp, wl = want[b % 3]
+            assert np.array_equal(res[b][1], wl), f"labels frame {b}"
+            assert res[b][0].shape == wp.shape and np.array_equal(res[b][0], wp), f"planes frame {b}"
