@@ -159,7 +159,7 @@ __device__ void stats_compute(const double s[9], int N, Geo& g) {
 struct Layout {   // per-frame workspace (element offsets), identical for every frame
     int W, H, Nw, Nh, NB, NB2;   // NB2 = 2*NB: initial blocks + merged nodes
     int pool_cap, q_cap;
-    size_t off_stats, off_geo, off_N, off_rid, off_flags, off_nb_off, off_nb_cnt, off_nb_cap, off_pool, off_parent, off_size,
+    size_t off_stats, off_geo, off_N, off_rid, off_flags, off_nb_off, off_nb_cnt, off_pool, off_parent, off_size,
         off_member, off_dist, off_blkmap, off_queue, off_seedcnt, off_ver, off_tag, off_cint, off_cdbl, frame_bytes;
 };
 
@@ -272,9 +272,11 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     S.nb_off = S.pool + L.pool_cap;
     S.nb_cnt = S.nb_off + L.NB2;
     S.dsp = S.nb_cnt + L.NB2;
-    // list capacities are only consulted when a node is appended to a full list: they live in global memory so that this workgroup leaves
-    // room in LDS for the line detector's wavefront (lsd_detect, 8 KB) on the same CU
-    u16* g_nbcap = (u16*)(F + L.off_nb_cap);
+    // list capacities are only consulted when a node is appended to a full list: the 4-slot lists of the initial blocks have it implicit,
+    // every other list keeps it in the pool slot in front of its first entry (no LDS array: the line detector's wavefront, lsd_detect,
+    // needs 8 KB on the same CU; no global array: the append would wait a memory round trip per merge)
+    bool hdr_all = false;                                     // second ahCluster: every list has the header slot
+    auto list_cap = [&](int q) -> int { return (q < NB && !hdr_all) ? 4 : (int)S.pool[S.nb_off[q] - 1]; };
     S.dss = S.dsp + NB;
     S.rid = S.dss + NB;                       // rid of every node (root block id)
     S.nouse = (unsigned*)(S.rid + L.NB2);     // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
@@ -301,13 +303,15 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     auto gfence = [&]() { __threadfence_block(); };
 
     auto geo_of = [&](int id) { return g_geo + (size_t)id * 7; };
+    // versions are bumped by no-return atomics (performed at the L2): read them there too
+    auto ver_of = [&](int id) -> unsigned { return __hip_atomic_load(g_ver + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto nsim = [&](int a, int b) {
         const double* ga = geo_of(a) + 3; const double* gb = geo_of(b) + 3;
         return fabs(ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]);
     };
 
     // ---- init (all threads) ----
-    for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; g_nbcap[b] = 4; S.rid[b] = (u16)b; }
+    for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.rid[b] = (u16)b; }
     for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) S.nouse[t] = 0;
     for (int t = tid; t < L.NB2; t += NT) { g_ver[t] = 0; g_tag[t] = 0; }
     for (int t = tid; t < MAX_PLANES; t += NT) { s_valid[t] = 0; s_plidmap[t] = -1; }
@@ -490,7 +494,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
             ci[0] = have ? 1 : 0; ci[1] = w_nb; ci[2] = best_N;
             cd[0] = best_mse;
             for (int t = 0; t < 15; t++) cd[1 + t] = w[t];
-            g_tag[my_node] = g_ver[my_node] + 1;
+            g_tag[my_node] = ver_of(my_node) + 1;
         }
     };
     auto ah_cluster = [&](const bool coop) {
@@ -521,12 +525,17 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                     double best_stats[9]; Geo best_geo;
                     bool from_cache = false;
                     if (coop && cnt > 0 && cnt <= 64) {
-                        if (g_tag[p] == g_ver[p] + 1) {
-                            const int* ci = g_cint + (size_t)p * 4;
-                            const double* cd = g_cdbl + (size_t)p * 16;
-                            have = ci[0] != 0; best_nb = ci[1]; best_N = ci[2]; best_mse = cd[0];
-                            for (int t = 0; t < 9; t++) best_stats[t] = cd[1 + t];
-                            for (int t = 0; t < 3; t++) { best_geo.center[t] = cd[10 + t]; best_geo.normal[t] = cd[13 + t]; }
+                        // tag, version and the cached record are requested together (one memory round trip, hit or miss)
+                        const unsigned tg = g_tag[p], vr = ver_of(p);
+                        const int* ci = g_cint + (size_t)p * 4;
+                        const double* cd = g_cdbl + (size_t)p * 16;
+                        const int c_have = ci[0], c_nb = ci[1], c_N = ci[2];
+                        double cv[16];
+                        for (int t = 0; t < 16; t++) cv[t] = cd[t];
+                        if (tg == vr + 1) {
+                            have = c_have != 0; best_nb = c_nb; best_N = c_N; best_mse = cv[0];
+                            for (int t = 0; t < 9; t++) best_stats[t] = cv[1 + t];
+                            for (int t = 0; t < 3; t++) { best_geo.center[t] = cv[10 + t]; best_geo.normal[t] = cv[13 + t]; }
                             best_geo.mse = best_mse;
                             from_cache = true; dbg_hits++;
                         } else {
@@ -535,7 +544,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                             const int hp = lane < heap_n ? (int)S.h_id[lane] : -1;
                             int hc = 0;
                             bool cand = false;
-                            if (hp >= 0 && !is_dead(hp)) { hc = S.nb_cnt[hp]; cand = hc > 0 && hc <= 64 && g_tag[hp] != g_ver[hp] + 1; }
+                            if (hp >= 0 && !is_dead(hp)) { hc = S.nb_cnt[hp]; cand = hc > 0 && hc <= 64 && g_tag[hp] != ver_of(hp) + 1; }
                             unsigned long long cm = __ballot(cand);
                             int nl = 0, cw = 0, co = cnt;
                             if (lane == 0) { s_lnode[0] = (unsigned short)p; s_lwave[0] = 0; s_loff[0] = 0; }
@@ -624,31 +633,35 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                                 else { S.dsp[yr] = (u16)xr; S.dss[xr] += S.dss[yr]; }
                             }
                         }
-                        gfence();
+                        // no wait for these stores: later loads of this wavefront are performed behind them in order, and the other
+                        // wavefronts only read them behind the fence + barrier that starts an evaluation phase
                         heap_push(m, best_geo.mse);
                         cyc[2] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
                         // mergeNbsFrom (AHCPlaneSeg.hpp:379-404): union of the two sorted lists minus {p, nb} (both dead by now),
                         // built cooperatively: prefix counts of the surviving entries, then every entry writes itself to its rank.
                         const int ca = S.nb_cnt[p], cb = S.nb_cnt[nb];
-                        const int need = 2 * (ca + cb) + 2 + (ca + cb) / 4 + 8;
+                        const int need = 2 * (ca + cb) + 3 + (ca + cb) / 4 + 8;
                         if (pool_top + need > L.pool_cap) {             // compact the pool: live merged nodes only (rare)
                             if (lane == 0) {
-                                int top = 4 * NB;
+                                int top = 4 * NB + 1;                    // first list entry (its capacity header sits at top - 1)
                                 for (int id = NB; id < m; id++) {
                                     if (is_dead(id) && id != p && id != nb) { S.nb_cnt[id] = 0; continue; }
                                     const int c = S.nb_cnt[id], o = S.nb_off[id];
+                                    if (top > o) { top = 0x7fff0000; break; }   // a list would grow over unread ones: report a capacity error
                                     int n2 = 0;
-                                    for (int t = 0; t < c; t++) { const int v = S.pool[o + t]; if (!is_dead(v) || id == p || id == nb) S.pool[top + n2++] = (u16)v; }
-                                    S.nb_off[id] = (u16)top; S.nb_cnt[id] = (u16)n2;
-                                    if (id != p && id != nb) { const int cap = n2 + max(8, n2 / 4); g_nbcap[id] = (u16)cap; top += cap; } else top += n2;
+                                    for (int t = 0; t < c; t++) { const int v = S.pool[o + t]; if (!is_dead(v) || id == p || id == nb) S.pool[top + n2++] = (u16)v; }   // top <= o: in place
+                                    const int cap = (id != p && id != nb) ? n2 + max(8, n2 / 4) : n2;
+                                    S.pool[top - 1] = (u16)cap; S.nb_off[id] = (u16)top; S.nb_cnt[id] = (u16)n2;
+                                    top += cap + 1;
                                 }
-                                s_scalar[3] = top;
+                                s_scalar[3] = top - 1;
                             }
                             wfence();
                             pool_top = s_scalar[3];
+                            if (pool_top > L.pool_cap) { err = 2; break; }
                         }
                         const int ca2 = S.nb_cnt[p], cb2 = S.nb_cnt[nb];
-                        if (pool_top + 2 * (ca2 + cb2) + 2 + (ca2 + cb2) / 4 + 8 > L.pool_cap) { err = 2; break; }
+                        if (pool_top + 2 * (ca2 + cb2) + 3 + (ca2 + cb2) / 4 + 8 > L.pool_cap) { err = 2; break; }
                         const u16* A = S.pool + S.nb_off[p];
                         const u16* Bl = S.pool + S.nb_off[nb];
                         u16* PA = S.pool + pool_top;                    // [ca2+1] exclusive counts of surviving A entries
@@ -700,7 +713,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                         wfence();
                         const int n = na + nbk;
                         // move the list down over the scratch counters and reserve some slack for later appends
-                        const int off = pool_top;
+                        const int off = pool_top + 1;                   // pool_top itself becomes the capacity header
                         for (int k0 = 0; k0 < n; k0 += 64) {            // forward copy, destination below source: chunk-safe
                             const int k = k0 + lane;
                             const int v = k < n ? out[k] : 0;
@@ -710,7 +723,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                         }
                         const int cap = n + max(8, n / 4);
                         pool_top = off + cap;
-                        if (lane == 0) { S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n; g_nbcap[m] = (u16)cap; S.nb_cnt[p] = 0; S.nb_cnt[nb] = 0; }
+                        if (lane == 0) { S.pool[off - 1] = (u16)cap; S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n; S.nb_cnt[p] = 0; S.nb_cnt[nb] = 0; }
                         wfence();
                         cyc[3] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
                         {   // nb->nbs.insert(this): m is the largest id so far -> append; a full list is compacted first
@@ -719,16 +732,16 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                                 const int q = lstm[k];
                                 u16* ql = S.pool + S.nb_off[q];
                                 int c = S.nb_cnt[q];
-                                if (c >= g_nbcap[q]) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
+                                if (c >= list_cap(q)) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
                                 ql[c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
-                                g_ver[q]++;                              // q's live-neighbour set changed: its cached candidates are stale
+                                atomicAdd(&g_ver[q], 1u);                // q's live-neighbour set changed: its cached candidates are stale (no return value: nothing waits)
                             }
                         }
                         wfence();
                         cyc[5] += PEAC_CYCLES() - c0;
                     } else {
                         extract(p);
-                        for (int k = lane; k < cnt; k += 64) { const int q = lst[k]; if (!is_dead(q)) g_ver[q]++; }   // p leaves their live sets
+                        for (int k = lane; k < cnt; k += 64) { const int q = lst[k]; if (!is_dead(q)) atomicAdd(&g_ver[q], 1u); }   // p leaves their live sets
                         mark_dead(p);
                     }
                     ++step;
@@ -946,14 +959,15 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         // after the first ahCluster (all nodes were disconnected), so the pool is reused from the start.
         for (int q = lane; q < n_old; q += 64) {
             const int id = s_old[q];
-            const int off = q * n_old;
+            const int off = q * (n_old + 1) + 1;
             int c = 0;
             for (int r = 0; r < n_old; r++)
                 if (s_adj[q][r >> 5] & (1u << (r & 31))) lst_insert(S.pool + off, c, s_old[r]);
-            S.nb_off[id] = (u16)off; S.nb_cnt[id] = (u16)c; g_nbcap[id] = (u16)n_old;
+            S.pool[off - 1] = (u16)n_old; S.nb_off[id] = (u16)off; S.nb_cnt[id] = (u16)c;
             atomicAnd(&S.nouse[id >> 5], ~(1u << (id & 31)));   // back in the graph
         }
-        pool_top = n_old * n_old;
+        pool_top = n_old * (n_old + 1);
+        hdr_all = true;
         wfence();
         n_ext = 0;
         heap_n = 0;
@@ -1048,7 +1062,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     auto carve = [&](size_t bytes) { size_t o2 = off; off = align_up(off + bytes, (size_t)256); return o2; };
     L.off_stats = carve((size_t)L.NB2 * 9 * 8); L.off_geo = carve((size_t)L.NB2 * 7 * 8); L.off_N = carve((size_t)L.NB2 * 4);
     L.off_rid = carve((size_t)L.NB2 * 4); L.off_flags = carve((size_t)L.NB2); L.off_nb_off = carve((size_t)L.NB2 * 4);
-    L.off_nb_cnt = carve((size_t)L.NB2 * 4); L.off_nb_cap = carve((size_t)L.NB2 * 4); L.off_pool = carve((size_t)L.pool_cap * 4);
+    L.off_nb_cnt = carve((size_t)L.NB2 * 4); L.off_pool = carve((size_t)L.pool_cap * 4);
     L.off_parent = carve((size_t)L.NB * 4); L.off_size = carve((size_t)L.NB * 4); L.off_member = carve((size_t)width * height * 4);
     L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 8);
     L.off_seedcnt = carve((size_t)L.NB * 4);
