@@ -472,15 +472,34 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                 }
             }
         }
-        // the reference's in-order rule (:1043-1049) inside every node's lane segment
-        int maxc = seg_cnt;
-        for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+        // the reference's in-order rule (:1043-1049) inside every node's lane segment.  Without exact ties (and NaNs) the rule keeps the
+        // minimum mse: a segmented prefix-min over (mse, k) in 6 shuffle steps; a tie anywhere in the wavefront falls back to the scan.
         bool have = false; double best_mse = 0; int best_k = 0, best_N = 0;
-        for (int k = 0; k < maxc; k++) {
-            const int src = min(seg_first + k, 63);
-            const int c_ok = __shfl((int)ok, src); const double c_mse = __shfl(mg.mse, src); const int c_N = __shfl(mN, src);
-            if (k < seg_cnt && c_ok && (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse))) {   // quirk :1045
-                have = true; best_mse = c_mse; best_k = k; best_N = c_N;
+        {
+            double rm = ok ? mg.mse : 1.7976931348623157e308;
+            int rk = ok ? my_k : 64;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double om = __shfl_up(rm, o); const int ok2 = __shfl_up(rk, o);
+                if (my_node >= 0 && lane - o >= seg_first && (om < rm || (om == rm && ok2 < rk))) { rm = om; rk = ok2; }
+            }
+            const int last = min(seg_first + max(seg_cnt, 1) - 1, 63);
+            const double min_m = __shfl(rm, last); const int min_k = __shfl(rk, last);
+            const bool odd = ok && (mg.mse != mg.mse || (mg.mse == min_m && my_k != min_k));
+            if (!__ballot(odd)) {
+                have = min_k < 64; best_k = have ? min_k : 0; best_mse = have ? min_m : 0;
+                best_N = __shfl(mN, min(seg_first + best_k, 63));
+                if (!have) best_N = 0;
+            } else {
+                int maxc = seg_cnt;
+                for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+                for (int k = 0; k < maxc; k++) {
+                    const int src = min(seg_first + k, 63);
+                    const int c_ok = __shfl((int)ok, src); const double c_mse = __shfl(mg.mse, src); const int c_N = __shfl(mN, src);
+                    if (k < seg_cnt && c_ok && (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse))) {   // quirk :1045
+                        have = true; best_mse = c_mse; best_k = k; best_N = c_N;
+                    }
+                }
             }
         }
         const int bl = min(seg_first + best_k, 63);
