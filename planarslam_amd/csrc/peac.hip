@@ -683,62 +683,88 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                         if (pool_top + 2 * (ca2 + cb2) + 3 + (ca2 + cb2) / 4 + 8 > L.pool_cap) { err = 2; break; }
                         const u16* A = S.pool + S.nb_off[p];
                         const u16* Bl = S.pool + S.nb_off[nb];
-                        u16* PA = S.pool + pool_top;                    // [ca2+1] exclusive counts of surviving A entries
-                        u16* PB = PA + ca2 + 1;                         // [cb2+1] ... of surviving, non-duplicate B entries
-                        u16* out = PB + cb2 + 1;
-                        int na = 0, nbk = 0;
-                        for (int i0 = 0; i0 < ca2; i0 += 64) {
-                            const int i = i0 + lane;
-                            const bool keep = i < ca2 && !is_dead(A[i]);
-                            const unsigned long long mk = __ballot(keep);
-                            if (i < ca2) PA[i] = (u16)(na + __popcll(mk & ((1ull << lane) - 1ull)));
-                            na += __popcll(mk);
-                        }
-                        for (int j0 = 0; j0 < cb2; j0 += 64) {
-                            const int j = j0 + lane;
-                            bool keep = false;
-                            if (j < cb2) {
-                                const int x = Bl[j];
-                                if (!is_dead(x)) {
-                                    int lo = 0, hi = ca2;               // duplicate test: x in A (then it is alive there too)
-                                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
-                                    keep = !(lo < ca2 && A[lo] == x);
+                        const int off = pool_top + 1;                   // pool_top itself becomes the capacity header
+                        int n;
+                        if (ca2 <= 64 && cb2 <= 64) {
+                            // both lists fit the wavefront: lane i owns A[i] and B[i]; the two lower-bound searches (A[i] in B, B[i] in A) run
+                            // interleaved, the ranks of the survivors are popcounts of two ballots and every survivor is written straight to
+                            // its final slot (no prefix arrays, no second pass, no copy)
+                            const bool inA = lane < ca2, inB = lane < cb2;
+                            const int xa = inA ? (int)A[lane] : 0, xb = inB ? (int)Bl[lane] : 0;
+                            const bool liveA = inA && !is_dead(xa), liveB = inB && !is_dead(xb);
+                            int loA = 0, hiA = liveA ? cb2 : 0;         // lower bound of xa in B
+                            int loB = 0, hiB = liveB ? ca2 : 0;         // lower bound of xb in A
+                            while (__ballot(loA < hiA || loB < hiB)) {
+                                const int mA = (loA + hiA) >> 1, mB = (loB + hiB) >> 1;
+                                const int vB = Bl[min(mA, max(cb2 - 1, 0))], vA = A[min(mB, max(ca2 - 1, 0))];
+                                if (loA < hiA) { if (vB < xa) loA = mA + 1; else hiA = mA; }
+                                if (loB < hiB) { if (vA < xb) loB = mB + 1; else hiB = mB; }
+                            }
+                            const bool dup = liveB && loB < ca2 && (int)A[min(loB, max(ca2 - 1, 0))] == xb;   // then it is alive in A too
+                            const bool keepB = liveB && !dup;
+                            const unsigned long long mkA = __ballot(liveA), mkB = __ballot(keepB);
+                            auto below = [](int k) -> unsigned long long { return k >= 64 ? ~0ull : (1ull << k) - 1ull; };
+                            if (liveA) S.pool[off + __popcll(mkA & below(lane)) + __popcll(mkB & below(loA))] = (u16)xa;
+                            if (keepB) S.pool[off + __popcll(mkB & below(lane)) + __popcll(mkA & below(loB))] = (u16)xb;
+                            n = __popcll(mkA) + __popcll(mkB);
+                            wfence();
+                        } else {
+                            u16* PA = S.pool + pool_top;                    // [ca2+1] exclusive counts of surviving A entries
+                            u16* PB = PA + ca2 + 1;                         // [cb2+1] ... of surviving, non-duplicate B entries
+                            u16* out = PB + cb2 + 1;
+                            int na = 0, nbk = 0;
+                            for (int i0 = 0; i0 < ca2; i0 += 64) {
+                                const int i = i0 + lane;
+                                const bool keep = i < ca2 && !is_dead(A[i]);
+                                const unsigned long long mk = __ballot(keep);
+                                if (i < ca2) PA[i] = (u16)(na + __popcll(mk & ((1ull << lane) - 1ull)));
+                                na += __popcll(mk);
+                            }
+                            for (int j0 = 0; j0 < cb2; j0 += 64) {
+                                const int j = j0 + lane;
+                                bool keep = false;
+                                if (j < cb2) {
+                                    const int x = Bl[j];
+                                    if (!is_dead(x)) {
+                                        int lo = 0, hi = ca2;               // duplicate test: x in A (then it is alive there too)
+                                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
+                                        keep = !(lo < ca2 && A[lo] == x);
+                                    }
+                                }
+                                const unsigned long long mk = __ballot(keep);
+                                if (j < cb2) PB[j] = (u16)(nbk + __popcll(mk & ((1ull << lane) - 1ull)));
+                                nbk += __popcll(mk);
+                            }
+                            if (lane == 0) { PA[ca2] = (u16)na; PB[cb2] = (u16)nbk; }
+                            wfence();
+                            for (int i0 = 0; i0 < ca2; i0 += 64) {
+                                const int i = i0 + lane;
+                                if (i < ca2 && PA[i + 1] != PA[i]) {
+                                    const int x = A[i];
+                                    int lo = 0, hi = cb2;
+                                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (Bl[mid] < x) lo = mid + 1; else hi = mid; }
+                                    out[PA[i] + PB[lo]] = (u16)x;
                                 }
                             }
-                            const unsigned long long mk = __ballot(keep);
-                            if (j < cb2) PB[j] = (u16)(nbk + __popcll(mk & ((1ull << lane) - 1ull)));
-                            nbk += __popcll(mk);
-                        }
-                        if (lane == 0) { PA[ca2] = (u16)na; PB[cb2] = (u16)nbk; }
-                        wfence();
-                        for (int i0 = 0; i0 < ca2; i0 += 64) {
-                            const int i = i0 + lane;
-                            if (i < ca2 && PA[i + 1] != PA[i]) {
-                                const int x = A[i];
-                                int lo = 0, hi = cb2;
-                                while (lo < hi) { const int mid = (lo + hi) >> 1; if (Bl[mid] < x) lo = mid + 1; else hi = mid; }
-                                out[PA[i] + PB[lo]] = (u16)x;
+                            for (int j0 = 0; j0 < cb2; j0 += 64) {
+                                const int j = j0 + lane;
+                                if (j < cb2 && PB[j + 1] != PB[j]) {
+                                    const int x = Bl[j];
+                                    int lo = 0, hi = ca2;
+                                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
+                                    out[PB[j] + PA[lo]] = (u16)x;
+                                }
                             }
-                        }
-                        for (int j0 = 0; j0 < cb2; j0 += 64) {
-                            const int j = j0 + lane;
-                            if (j < cb2 && PB[j + 1] != PB[j]) {
-                                const int x = Bl[j];
-                                int lo = 0, hi = ca2;
-                                while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] < x) lo = mid + 1; else hi = mid; }
-                                out[PB[j] + PA[lo]] = (u16)x;
+                            wfence();
+                            n = na + nbk;
+                            // move the list down over the scratch counters and reserve some slack for later appends
+                            for (int k0 = 0; k0 < n; k0 += 64) {            // forward copy, destination below source: chunk-safe
+                                const int k = k0 + lane;
+                                const int v = k < n ? out[k] : 0;
+                                wfence();
+                                if (k < n) S.pool[off + k] = (u16)v;
+                                wfence();
                             }
-                        }
-                        wfence();
-                        const int n = na + nbk;
-                        // move the list down over the scratch counters and reserve some slack for later appends
-                        const int off = pool_top + 1;                   // pool_top itself becomes the capacity header
-                        for (int k0 = 0; k0 < n; k0 += 64) {            // forward copy, destination below source: chunk-safe
-                            const int k = k0 + lane;
-                            const int v = k < n ? out[k] : 0;
-                            wfence();
-                            if (k < n) S.pool[off + k] = (u16)v;
-                            wfence();
                         }
                         const int cap = n + max(8, n / 4);
                         pool_top = off + cap;
