@@ -160,7 +160,7 @@ struct Layout {   // per-frame workspace (element offsets), identical for every 
     int W, H, Nw, Nh, NB, NB2;   // NB2 = 2*NB: initial blocks + merged nodes
     int pool_cap, q_cap;
     size_t off_stats, off_geo, off_N, off_rid, off_flags, off_nb_off, off_nb_cnt, off_pool, off_parent, off_size,
-        off_member, off_dist, off_blkmap, off_queue, off_seedcnt, off_ver, off_tag, off_cint, off_cdbl, frame_bytes;
+        off_member, off_dist, off_blkmap, off_queue, off_seedcnt, off_cint, off_cdbl, frame_bytes;
 };
 
 struct Intr { float fx, fy, cx, cy, factor; };
@@ -220,7 +220,7 @@ constexpr int NT = 256;
 typedef unsigned short u16;
 
 struct Lds {
-    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; u16* dsp; u16* dss; u16* rid; unsigned* nouse; signed char* blk;
+    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; u16* dsp; u16* dss; u16* rid; unsigned* nouse; unsigned* cval; signed char* blk;
 };
 
 __device__ __forceinline__ int lds_find(u16* parent, int x) {   // DisjointSet::Find with path compression
@@ -257,8 +257,6 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     float* distMap = (float*)(F + L.off_dist);
     int2* queue = (int2*)(F + L.off_queue);
     int* seedcnt = (int*)(F + L.off_seedcnt);
-    unsigned* g_ver = (unsigned*)(F + L.off_ver);
-    unsigned* g_tag = (unsigned*)(F + L.off_tag);
     int* g_cint = (int*)(F + L.off_cint);
     double* g_cdbl = (double*)(F + L.off_cdbl);
     const uint16_t* D = depth + (size_t)frame * frame_stride_px;
@@ -280,7 +278,8 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     S.dss = S.dsp + NB;
     S.rid = S.dss + NB;                       // rid of every node (root block id)
     S.nouse = (unsigned*)(S.rid + L.NB2);     // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
-    S.blk = (signed char*)(S.nouse + (L.NB2 + 31) / 32);
+    S.cval = S.nouse + (L.NB2 + 31) / 32;     // bit per node: its cached candidate record (g_cint / g_cdbl) is valid for its current live-neighbour set
+    S.blk = (signed char*)(S.cval + (L.NB2 + 31) / 32);
 
     __shared__ int s_ext[MAX_PLANES], s_old[MAX_PLANES], s_plidmap[MAX_PLANES];
     __shared__ uint8_t s_valid[MAX_PLANES];
@@ -303,8 +302,8 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     auto gfence = [&]() { __threadfence_block(); };
 
     auto geo_of = [&](int id) { return g_geo + (size_t)id * 7; };
-    // versions are bumped by no-return atomics (performed at the L2): read them there too
-    auto ver_of = [&](int id) -> unsigned { return __hip_atomic_load(g_ver + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto cvalid = [&](int id) { return (S.cval[id >> 5] >> (id & 31)) & 1u; };
+    auto cinval = [&](int id) { atomicAnd(&S.cval[id >> 5], ~(1u << (id & 31))); };
     auto nsim = [&](int a, int b) {
         const double* ga = geo_of(a) + 3; const double* gb = geo_of(b) + 3;
         return fabs(ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]);
@@ -312,8 +311,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
 
     // ---- init (all threads) ----
     for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.rid[b] = (u16)b; }
-    for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) S.nouse[t] = 0;
-    for (int t = tid; t < L.NB2; t += NT) { g_ver[t] = 0; g_tag[t] = 0; }
+    for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) { S.nouse[t] = 0; S.cval[t] = 0; }
     for (int t = tid; t < MAX_PLANES; t += NT) { s_valid[t] = 0; s_plidmap[t] = -1; }
     for (int t = tid; t < MAX_PLANES * (MAX_PLANES / 32); t += NT) (&s_adj[0][0])[t] = 0;
     if (tid < 4) s_scalar[tid] = 0;
@@ -437,7 +435,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     // eigen-solve per neighbour, ~27k cycles of latency however few lanes it uses) dominates this loop, but its result is a pure
     // function of the node's live-neighbour set.  So every time wavefront 0 pops a node without a valid cached result, all four
     // wavefronts evaluate it TOGETHER WITH the next nodes of the heap (up to 64 nodes, one lane per (node, neighbour) pair) and
-    // store each result tagged with the node's version; versions are bumped whenever a node's live-neighbour set changes.
+    // store each result and set the node's `valid` bit (LDS); the bit is cleared whenever the node's live-neighbour set changes.
     // Later pops find their result in the cache unless a merge touched their neighbourhood.  Phases are separated by workgroup
     // barriers, so the schedule - and with it every bit of the output - is deterministic.
     auto eval_phase = [&]() {
@@ -513,7 +511,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
             ci[0] = have ? 1 : 0; ci[1] = w_nb; ci[2] = best_N;
             cd[0] = best_mse;
             for (int t = 0; t < 15; t++) cd[1 + t] = w[t];
-            g_tag[my_node] = ver_of(my_node) + 1;
+            atomicOr(&S.cval[my_node >> 5], 1u << (my_node & 31));
         }
     };
     auto ah_cluster = [&](const bool coop) {
@@ -544,14 +542,13 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                     double best_stats[9]; Geo best_geo;
                     bool from_cache = false;
                     if (coop && cnt > 0 && cnt <= 64) {
-                        // tag, version and the cached record are requested together (one memory round trip, hit or miss)
-                        const unsigned tg = g_tag[p], vr = ver_of(p);
+                        const bool hit = cvalid(p) != 0;
                         const int* ci = g_cint + (size_t)p * 4;
                         const double* cd = g_cdbl + (size_t)p * 16;
                         const int c_have = ci[0], c_nb = ci[1], c_N = ci[2];
                         double cv[16];
                         for (int t = 0; t < 16; t++) cv[t] = cd[t];
-                        if (tg == vr + 1) {
+                        if (hit) {
                             have = c_have != 0; best_nb = c_nb; best_N = c_N; best_mse = cv[0];
                             for (int t = 0; t < 9; t++) best_stats[t] = cv[1 + t];
                             for (int t = 0; t < 3; t++) { best_geo.center[t] = cv[10 + t]; best_geo.normal[t] = cv[13 + t]; }
@@ -563,7 +560,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                             const int hp = lane < heap_n ? (int)S.h_id[lane] : -1;
                             int hc = 0;
                             bool cand = false;
-                            if (hp >= 0 && !is_dead(hp)) { hc = S.nb_cnt[hp]; cand = hc > 0 && hc <= 64 && g_tag[hp] != ver_of(hp) + 1; }
+                            if (hp >= 0 && !is_dead(hp)) { hc = S.nb_cnt[hp]; cand = hc > 0 && hc <= 64 && !cvalid(hp); }
                             unsigned long long cm = __ballot(cand);
                             int nl = 0, cw = 0, co = cnt;
                             if (lane == 0) { s_lnode[0] = (unsigned short)p; s_lwave[0] = 0; s_loff[0] = 0; }
@@ -779,14 +776,14 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                                 int c = S.nb_cnt[q];
                                 if (c >= list_cap(q)) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
                                 ql[c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
-                                atomicAdd(&g_ver[q], 1u);                // q's live-neighbour set changed: its cached candidates are stale (no return value: nothing waits)
+                                cinval(q);                               // q's live-neighbour set changed: its cached candidates are stale
                             }
                         }
                         wfence();
                         cyc[5] += PEAC_CYCLES() - c0;
                     } else {
                         extract(p);
-                        for (int k = lane; k < cnt; k += 64) { const int q = lst[k]; if (!is_dead(q)) atomicAdd(&g_ver[q], 1u); }   // p leaves their live sets
+                        for (int k = lane; k < cnt; k += 64) { const int q = lst[k]; if (!is_dead(q)) cinval(q); }   // p leaves their live sets
                         mark_dead(p);
                     }
                     ++step;
@@ -1111,11 +1108,11 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     L.off_parent = carve((size_t)L.NB * 4); L.off_size = carve((size_t)L.NB * 4); L.off_member = carve((size_t)width * height * 4);
     L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 8);
     L.off_seedcnt = carve((size_t)L.NB * 4);
-    // candidate cache of the cooperative ahCluster: per node a version of its live-neighbour set, the tag (version + 1) the cached result
-    // was computed for, 4 ints {have, best_nb, best_N, -} and 16 doubles {mse, stats[9], center[3], normal[3]}
-    L.off_ver = carve((size_t)L.NB2 * 4); L.off_tag = carve((size_t)L.NB2 * 4); L.off_cint = carve((size_t)L.NB2 * 16); L.off_cdbl = carve((size_t)L.NB2 * 16 * 8);
+    // candidate cache of the cooperative ahCluster: per node 4 ints {have, best_nb, best_N, -} and 16 doubles {mse, stats[9], center[3],
+    // normal[3]}; whether a record is valid for the node's current live-neighbour set is a bit in LDS
+    L.off_cint = carve((size_t)L.NB2 * 16); L.off_cdbl = carve((size_t)L.NB2 * 16 * 8);
     L.frame_bytes = off;
-    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 4 + L.NB * 4 + L.NB2 * 2 + ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
+    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 4 + L.NB * 4 + L.NB2 * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
     const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
