@@ -285,7 +285,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     __shared__ uint8_t s_valid[MAX_PLANES];
     __shared__ unsigned s_adj[MAX_PLANES][MAX_PLANES / 32];
     __shared__ int s_slot[1024];
-    __shared__ int s_wcnt[4];
+    __shared__ int s_pcnt[16];
     __shared__ int s_scalar[4];   // [0] n_ext, [1] err, [2] q_tail, [3] scratch
     constexpr int EVAL_MAX = 64;   // nodes evaluated per cooperative phase
     __shared__ int s_cmd, s_nlist;
@@ -893,11 +893,17 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     __syncthreads();
     mark();
 
-    // ---- floodFill (:428-476), all threads.  Per step: 128 queue entries x 4 neighbours = 512 (entry, neighbour) pairs, two per thread
-    //      (pair p = entry * 4 + direction is the reference's processing order).  Pairs that hit the same pixel are replayed in pair order;
-    //      plane-plane connect() is a commutative set insertion and goes to an LDS bit matrix; queue pushes are appended in pair order.
+    // ---- floodFill (:428-476), all threads.  Per step: 256 queue entries x 4 neighbours = 1024 (entry, neighbour) pairs, four per thread
+    //      (pair p = entry * 4 + direction is the reference's processing order).  Pairs that hit the same pixel are replayed in pair order:
+    //      per round the smallest pair index wins the pixel's slot (atomicMin on a key whose high bits count the rounds DOWN, so stale
+    //      entries of earlier rounds lose by themselves and the slots are never reset); plane-plane connect() is a commutative set
+    //      insertion and goes to an LDS bit matrix; queue pushes are appended in pair order.
     {
-        constexpr int FJ = 2;                                      // pairs per thread and step
+        constexpr int FJ = 4;                                      // pairs per thread and step
+        unsigned* slot = (unsigned*)s_slot;
+        for (int t = tid; t < 1024; t += NT) slot[t] = 0xffffffffu;
+        __syncthreads();
+        unsigned epoch = 0;
         const double factor = (double)K.factor;
         int q_head = 0, q_tail = s_scalar[2];
         while (q_head < q_tail && !err) {
@@ -940,15 +946,19 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                 }
                 done[j] = !act[j];
             }
-            while (__syncthreads_or(!done[0] || !done[1])) {
-                for (int t = tid; t < 1024; t += NT) s_slot[t] = FJ * NT;
-                __syncthreads();
+            while (true) {
+                bool pend = false;
 #pragma unroll
-                for (int j = 0; j < FJ; j++) if (!done[j]) atomicMin(&s_slot[cIdx[j] & 1023], pidx[j]);
+                for (int j = 0; j < FJ; j++) pend = pend || !done[j];
+                if (!__syncthreads_or(pend)) break;
+                const unsigned ek = (0xfffffu - epoch) << 12;           // pair indices are < 4096
+                epoch++;
+#pragma unroll
+                for (int j = 0; j < FJ; j++) if (!done[j]) atomicMin(&slot[cIdx[j] & 1023], ek | (unsigned)pidx[j]);
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < FJ; j++) {
-                    if (!done[j] && s_slot[cIdx[j] & 1023] == pidx[j]) {
+                    if (!done[j] && slot[cIdx[j] & 1023] == (ek | (unsigned)pidx[j])) {
                         const int trail = member[cIdx[j]];
                         if (!(trail <= -6) && !(trail >= 0 && trail == plid[j])) {
                             if (geo_ok[j]) {
@@ -962,24 +972,25 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                         }
                         done[j] = true;
                     }
-                    // the thread's second pair may target the pixel its first pair just wrote: it lost the slot (smaller pair index wins) and
-                    // is replayed in the next round, after the fence below
+                    // a later pair of this thread may target the pixel an earlier one just wrote: it lost the slot (smaller pair index wins)
+                    // and is replayed in the next round, after the fence below
                 }
                 __threadfence_block();
             }
-            // pushes in pair order: all round-0 pairs (p < NT) precede the round-1 pairs
-            int base = 0;
+            // pushes in pair order (pair p = tid + NT * j): j-major, then wavefront, then lane
+            unsigned long long pm[FJ];
 #pragma unroll
-            for (int j = 0; j < FJ; j++) {
-                const unsigned long long pm = __ballot(push[j]);
-                if (lane == 0) s_wcnt[wave] = __popcll(pm);
-                __syncthreads();
-                int before = 0, total = 0;
-                for (int w = 0; w < 4; w++) { const int c = s_wcnt[w]; if (w < wave) before += c; total += c; }
-                if (q_tail + base + total > L.q_cap) err = 5;
-                else if (push[j]) queue[q_tail + base + before + __popcll(pm & ((1ull << lane) - 1ull))] = make_int2(cIdx[j], plid[j]);
-                base += total;
-                __syncthreads();
+            for (int j = 0; j < FJ; j++) { pm[j] = __ballot(push[j]); if (lane == 0) s_pcnt[j * 4 + wave] = __popcll(pm[j]); }
+            __syncthreads();
+            int base = 0, mybase[FJ];
+#pragma unroll
+            for (int j = 0; j < FJ; j++)
+                for (int w = 0; w < 4; w++) { if (w == wave) mybase[j] = base; base += s_pcnt[j * 4 + w]; }
+            if (q_tail + base > L.q_cap) err = 5;
+            else {
+#pragma unroll
+                for (int j = 0; j < FJ; j++)
+                    if (push[j]) queue[q_tail + mybase[j] + __popcll(pm[j] & ((1ull << lane) - 1ull))] = make_int2(cIdx[j], plid[j]);
             }
             q_tail += base;
             q_head += nent;
