@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void lsd_grad(const Plan* __restrict__ plan, c
 }
 
 // ---- K3: descending 1024-bin order, raster order inside a bin -------------------------------------------------------
-__device__ inline int block_exscan256(int v, int* wsum, int* total) {
+template <int NW>   // exclusive scan over a workgroup of NW wavefronts
+__device__ inline int block_exscan(int v, int* wsum, int* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = v;
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
@@ -170,7 +171,7 @@ __device__ inline int block_exscan256(int v, int* wsum, int* total) {
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
     int base = 0, tot = 0;
-    for (int i = 0; i < 4; i++) { if (i < w) base += wsum[i]; tot += wsum[i]; }
+    for (int i = 0; i < NW; i++) { if (i < w) base += wsum[i]; tot += wsum[i]; }
     *total = tot;
     return base + inc - v;
 }
@@ -188,7 +189,9 @@ __device__ __forceinline__ void lds_sync();
 //   * __final_insertion_sort is a stable sort of the arrangement the partitions leave = the two radix passes below.
 // Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py).  A depth-limit overflow (heap-sort fallback of introsort)
 // cannot be reproduced this way and raises status 2; it needs ~34 unbalanced partitions in a row and does not occur on 10-bit keys.
-constexpr int SORT_SMALL = 4096;    // finished by one wavefront
+constexpr int SORT_NT = 1024;       // threads of lsd_sort: 16 wavefronts keep 16 sub-ranges (or 16 shares of a big one) in flight
+constexpr int SORT_NW = SORT_NT / 64;
+constexpr int SORT_SMALL = 1024;    // finished by one wavefront
 constexpr int SORT_STAGE = 16384;   // staged in LDS by the workgroup
 constexpr int SORT_LEAF = 64;       // finished by one lane
 struct SortRange { int f, l, d; };
@@ -246,7 +249,7 @@ __device__ __forceinline__ int partition_step(uint32_t* arr, uint16_t* Lb, uint1
     return cut;
 }
 
-// One Hoare partition of arr[f, l) by the whole workgroup (256 threads); same arithmetic as partition_step.  Works on global memory
+// One Hoare partition of arr[f, l) by the whole workgroup (SORT_NT threads); same arithmetic as partition_step.  Works on global memory
 // (IdxT = uint32_t) and on a range staged in LDS (IdxT = uint16_t); one instantiation per address space.  Returns the cut in every thread.
 // bc[0..3]: pivot, swapped position t, old arr[f], old arr[t] (threads patch their reads instead of waiting for the median swap to land).
 template <typename IdxT>
@@ -268,9 +271,9 @@ __device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, i
     const uint32_t pv = (uint32_t)bc[0];
     const int tpos = bc[1];
     const uint32_t tval = (uint32_t)bc[2] >> 20;                  // the element now at position t (the old front)
-    // each wavefront owns a contiguous quarter of [f+1, l) and walks it in coalesced chunks, U chunks of loads in flight
-    constexpr int U = 16;
-    const int len = l - (f + 1), qlen = (len + 3) / 4;
+    // each wavefront owns a contiguous share of [f+1, l) and walks it in coalesced chunks, U chunks of loads in flight
+    constexpr int U = 8;
+    const int len = l - (f + 1), qlen = (len + SORT_NW - 1) / SORT_NW;
     const int q0 = f + 1 + min(len, wave * qlen), q1 = f + 1 + min(len, wave * qlen + qlen);
     int cl = 0, cr = 0;
     for (int base = q0; base < q1; base += 64 * U) {
@@ -289,7 +292,7 @@ __device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, i
     if (lane == 0) { s_wl[wave] = cl; s_wr[wave] = cr; }
     __syncthreads();
     int totL = 0, totR = 0, wl = f + 1, ra = 0;
-    for (int q = 0; q < 4; q++) { totL += s_wl[q]; totR += s_wr[q]; if (q < wave) { wl += s_wl[q]; ra += s_wr[q]; } }
+    for (int q = 0; q < SORT_NW; q++) { totL += s_wl[q]; totR += s_wr[q]; if (q < wave) { wl += s_wl[q]; ra += s_wr[q]; } }
     for (int base = q0; base < q1; base += 64 * U) {             // one pass writes both stop lists; R is descending: slot = totR - 1 - ascending rank
         uint32_t v[U];
 #pragma unroll
@@ -311,14 +314,14 @@ __device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, i
     __syncthreads();
     const int kmax = min(totL, totR);
     int good = 0;
-    constexpr int PU = 8;                                         // pairs in flight per thread (two dependent round trips each)
-    for (int k0 = tid; k0 < kmax; k0 += 256 * PU) {
+    constexpr int PU = 4;                                         // pairs in flight per thread (two dependent round trips each)
+    for (int k0 = tid; k0 < kmax; k0 += SORT_NT * PU) {
         int Lk[PU], Rk[PU];
         uint32_t xl[PU], xr[PU];
 #pragma unroll
-        for (int u = 0; u < PU; u++) { const int k = min(k0 + 256 * u, kmax - 1); Lk[u] = (int)Lb[f + 1 + k]; Rk[u] = (int)Rb[f + 1 + k]; }
+        for (int u = 0; u < PU; u++) { const int k = min(k0 + SORT_NT * u, kmax - 1); Lk[u] = (int)Lb[f + 1 + k]; Rk[u] = (int)Rb[f + 1 + k]; }
 #pragma unroll
-        for (int u = 0; u < PU; u++) if (k0 + 256 * u >= kmax) { Lk[u] = 1; Rk[u] = 0; }
+        for (int u = 0; u < PU; u++) if (k0 + SORT_NT * u >= kmax) { Lk[u] = 1; Rk[u] = 0; }
 #pragma unroll
         for (int u = 0; u < PU; u++) { xl[u] = arr[max(Lk[u], f)]; xr[u] = arr[max(Rk[u], f)]; }      // unconditional: all loads in flight
 #pragma unroll
@@ -336,14 +339,14 @@ __device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, i
 }
 
 // ---- K3: the visiting order: descending 1024-bin order; ties per plan->tie_order ---------------------------------------------------
-__global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int tie_order) {
+__global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int tie_order) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
-    __shared__ int wsum[4];
-    __shared__ int s_ncur, s_nnext, s_nsmall, s_wl[4], s_wr[4], s_bc[4];
-    __shared__ int s_loc[2][16][3], s_nloc[2], s_wave[64][3], s_nwave;
-    __shared__ int s_stack[4][48][3];
-    __shared__ short s_leaf[4][288][3];
-    int* cnt = (int*)sort_lds;                                  // [32 * 256] radix counters (passes A / B)
+    __shared__ int wsum[SORT_NW];
+    __shared__ int s_ncur, s_nnext, s_nsmall, s_wl[SORT_NW], s_wr[SORT_NW], s_bc[4];
+    __shared__ int s_loc[2][2 * SORT_STAGE / SORT_SMALL + 8][3], s_nloc[2], s_wave[2 * SORT_STAGE / SORT_SMALL + 8][3], s_nwave;
+    __shared__ int s_stack[SORT_NW][48][3];
+    __shared__ short s_leaf[SORT_NW][SORT_SMALL / 16][3];
+    int* cnt = (int*)sort_lds;                                  // [32 * SORT_NT] radix counters (passes A / B)
     const Plan& P = *plan;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
     const int w1 = P.w - 1, n = w1 * (P.h - 1);
     const double max_grad = misc->g2max ? sqrt(misc->g2max / 4.0) : -1.0;
     const double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += SORT_NT) {
         const int y = i / w1, x = i - y * w1, pix = y * P.w + x;
         arr[i] = ((uint32_t)int(sqrt(g2a[pix] / 4.0) * bin_coef) << 20) | (uint32_t)pix;
     }
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
         }
         ts1 = __builtin_readcyclecounter();
         // tier 2: a range of <= 16384 elements is staged in LDS once and its whole recursion finished there:
-        //   > 4096: workgroup partitions;  <= 4096: one wavefront per sub-range (ballot partitions);  <= 64: one LANE per sub-range.
+        //   > SORT_SMALL: workgroup partitions;  <= SORT_SMALL: one wavefront per sub-range (ballot partitions);  <= 64: one LANE per sub-range.
         uint32_t* sbuf = (uint32_t*)sort_lds;
         uint16_t* Ls = (uint16_t*)(sbuf + SORT_STAGE);
         uint16_t* Rs = Ls + SORT_STAGE;
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
         for (int sr = 0; sr < nstaged; sr++) {
             const SortRange R = staged[sr];
             const int sz = R.l - R.f;
-            for (int i = tid; i < sz; i += 256) sbuf[i] = arr[R.f + i];
+            for (int i = tid; i < sz; i += SORT_NT) sbuf[i] = arr[R.f + i];
             if (tid == 0) { s_loc[0][0][0] = 0; s_loc[0][0][1] = sz; s_loc[0][0][2] = R.d; s_nloc[0] = 1; s_nloc[1] = 0; s_nwave = 0; }
             __syncthreads();
             for (int lev = 0;; lev ^= 1) {
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
                 __syncthreads();
             }
             const int nwave = s_nwave;
-            for (int r = wave; r < nwave; r += 4) {
+            for (int r = wave; r < nwave; r += SORT_NW) {
                 int sp = 0;
                 if (lane == 0) { s_stack[wave][0][0] = s_wave[r][0]; s_stack[wave][0][1] = s_wave[r][1]; s_stack[wave][0][2] = s_wave[r][2]; }
                 sp = 1;
@@ -480,89 +483,80 @@ __global__ __launch_bounds__(256) void lsd_sort(const Plan* __restrict__ plan, u
                 lds_sync();
             }
             __syncthreads();
-            for (int i = tid; i < sz; i += 256) arr[R.f + i] = sbuf[i];
+            for (int i = tid; i < sz; i += SORT_NT) arr[R.f + i] = sbuf[i];
             __syncthreads();
         }
         __threadfence_block();
         __syncthreads();
     }
     ts2 = __builtin_readcyclecounter();
-    // __final_insertion_sort == stable sort of the current arrangement by descending bin: two 5-bit LSD radix passes with thread-contiguous
-    // segments (order inside a bin = array order).  Undefined pixels took part in the partitions above; they are dropped here.
-    const int segA = (n + 255) / 256, a0 = min(n, tid * segA), a1 = min(n, a0 + segA);
-    constexpr int RU = 8;                                      // elements per iteration: their loads (two dependent gathers) are issued together
-    for (int d = 0; d < 32; d++) cnt[d * 256 + tid] = 0;
-    for (int i0 = a0; i0 < a1; i0 += RU) {
-        uint32_t e[RU]; float an[RU];
+    // __final_insertion_sort == stable sort of the current arrangement by descending bin: two 5-bit LSD radix passes.  Every wavefront owns
+    // a contiguous part of the array and walks it 64 elements at a time (coalesced); the rank of an element among the equal digits of its
+    // chunk is a popcount over the match mask built from five ballots, the running (digit, wavefront) counters live in LDS.  Order inside
+    // a bin = array order.  Undefined pixels took part in the partitions above; they are dropped in the first pass.
+    int* wcnt = cnt;                                          // [32][SORT_NW] counters, digit-major = output order
+    auto radix_pass = [&](const uint32_t* in, int M, auto digit_of, auto keep, auto emit) -> int {
+        const int seg = ((M + SORT_NW - 1) / SORT_NW + 63) & ~63, w0 = min(M, wave * seg), w1 = min(M, w0 + seg);
+        for (int t = tid; t < 32 * SORT_NW; t += SORT_NT) wcnt[t] = 0;
+        __syncthreads();
+        auto match = [&](bool valid, int d) -> unsigned long long {
+            unsigned long long same = __ballot(valid);
 #pragma unroll
-        for (int u = 0; u < RU; u++) e[u] = arr[min(i0 + u, a1 - 1)];
-#pragma unroll
-        for (int u = 0; u < RU; u++) an[u] = ang[e[u] & 0xfffffu];
-#pragma unroll
-        for (int u = 0; u < RU; u++)
-            if (i0 + u < a1 && an[u] != NOTDEF_F) cnt[(((N_BINS - 1) - (int)(e[u] >> 20)) & 31) * 256 + tid]++;
-    }
-    __syncthreads();
-    int total;
-    {
-        int local = 0;
-        for (int k = 0; k < 32; k++) local += cnt[tid * 32 + k];
-        int run = block_exscan256(local, wsum, &total);
-        for (int k = 0; k < 32; k++) { const int c = cnt[tid * 32 + k]; cnt[tid * 32 + k] = run; run += c; }
-    }
-    __syncthreads();
-    for (int i0 = a0; i0 < a1; i0 += RU) {
-        uint32_t e[RU]; float an[RU];
-#pragma unroll
-        for (int u = 0; u < RU; u++) e[u] = arr[min(i0 + u, a1 - 1)];
-#pragma unroll
-        for (int u = 0; u < RU; u++) an[u] = ang[e[u] & 0xfffffu];
-#pragma unroll
-        for (int u = 0; u < RU; u++) {
-            if (i0 + u < a1 && an[u] != NOTDEF_F) {
-                const uint32_t pix = e[u] & 0xfffffu;
-                const int key = (N_BINS - 1) - (int)(e[u] >> 20);
-                // the slot doubles as the pixel's compact index among the defined pixels (its `used` flag lives there)
-                const int slot = cnt[(key & 31) * 256 + tid]++;
-                tmpA[slot] = ((uint32_t)key << 20) | pix;
-                ((float*)(F + P.off_pix))[(size_t)pix * 4 + 3] = __uint_as_float((uint32_t)slot);
-            }
+            for (int bit = 0; bit < 5; bit++) { const unsigned long long bm = __ballot(valid && ((d >> bit) & 1)); same &= ((d >> bit) & 1) ? bm : ~bm; }
+            return same;
+        };
+        for (int i0 = w0; i0 < w1; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t e = in[min(i, w1 - 1)];
+            const bool valid = i < w1 && keep(e);
+            const int d = digit_of(e);
+            const unsigned long long same = match(valid, d);
+            if (valid && (same & ((1ull << lane) - 1ull)) == 0) wcnt[d * SORT_NW + wave] += __popcll(same);   // leader of its digit group
+            lds_sync();
         }
-    }
-    const int N = total;
+        __syncthreads();
+        int total;
+        {   // exclusive scan of the 32 x SORT_NW counters in (digit, wavefront) order by the first wavefronts
+            const int v = tid < 32 * SORT_NW ? wcnt[tid] : 0;
+            const int ex = block_exscan<SORT_NW>(v, wsum, &total);
+            if (tid < 32 * SORT_NW) wcnt[tid] = ex;
+        }
+        __syncthreads();
+        for (int i0 = w0; i0 < w1; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t e = in[min(i, w1 - 1)];
+            const bool valid = i < w1 && keep(e);
+            const int d = digit_of(e);
+            const unsigned long long same = match(valid, d);
+            const unsigned long long below = same & ((1ull << lane) - 1ull);
+            int base = 0;
+            if (valid) base = wcnt[d * SORT_NW + wave];
+            lds_sync();
+            if (valid) {
+                emit(e, i, base + __popcll(below));
+                if (below == 0) wcnt[d * SORT_NW + wave] = base + __popcll(same);
+            }
+            lds_sync();
+        }
+        __syncthreads();
+        return total;
+    };
+    static_assert(32 * SORT_NW <= SORT_NT, "one thread per radix counter");
+    float* pixw = (float*)(F + P.off_pix);
+    const int N = radix_pass(arr, n,
+        [&](uint32_t e) { return ((N_BINS - 1) - (int)(e >> 20)) & 31; },
+        [&](uint32_t e) { return ang[e & 0xfffffu] != NOTDEF_F; },
+        [&](uint32_t e, int, int slot) {
+            const uint32_t pix = e & 0xfffffu;
+            tmpA[slot] = ((uint32_t)((N_BINS - 1) - (int)(e >> 20)) << 20) | pix;
+            pixw[(size_t)pix * 4 + 3] = __uint_as_float((uint32_t)slot);   // the slot doubles as the pixel's compact index (its `used` flag lives there)
+        });
     __threadfence_block();
     __syncthreads();
-    const int segB = (N + 255) / 256, b0 = min(N, tid * segB), b1 = min(N, b0 + segB);
-    for (int d = 0; d < 32; d++) cnt[d * 256 + tid] = 0;
-    __syncthreads();
-    for (int i0 = b0; i0 < b1; i0 += RU) {
-        uint32_t e[RU];
-#pragma unroll
-        for (int u = 0; u < RU; u++) e[u] = tmpA[min(i0 + u, b1 - 1)];
-#pragma unroll
-        for (int u = 0; u < RU; u++) if (i0 + u < b1) cnt[((e[u] >> 25) & 31) * 256 + tid]++;
-    }
-    __syncthreads();
-    {
-        int local = 0;
-        for (int k = 0; k < 32; k++) local += cnt[tid * 32 + k];
-        int run = block_exscan256(local, wsum, &total);
-        for (int k = 0; k < 32; k++) { const int c = cnt[tid * 32 + k]; cnt[tid * 32 + k] = run; run += c; }
-    }
-    __syncthreads();
-    for (int i0 = b0; i0 < b1; i0 += RU) {
-        uint32_t e[RU];
-#pragma unroll
-        for (int u = 0; u < RU; u++) e[u] = tmpA[min(i0 + u, b1 - 1)];
-#pragma unroll
-        for (int u = 0; u < RU; u++) {
-            if (i0 + u < b1) {
-                const int pos = cnt[((e[u] >> 25) & 31) * 256 + tid]++;
-                ord[pos] = e[u] & 0xfffffu;
-                ordr[pos] = (uint32_t)(i0 + u);
-            }
-        }
-    }
+    radix_pass(tmpA, N,
+        [&](uint32_t e) { return (int)((e >> 25) & 31); },
+        [&](uint32_t) { return true; },
+        [&](uint32_t e, int i, int pos) { ord[pos] = e & 0xfffffu; ordr[pos] = (uint32_t)i; });
     if (tid == 0) { misc->n_ord = N; misc->t[5] = ts1 - ts0; misc->t[6] = ts2 - ts1; misc->t[7] = __builtin_readcyclecounter() - ts2; }
 }
 
@@ -1606,7 +1600,7 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     if (e == hipSuccess) e = hipMemcpy(o->d_cx.p, cx.data(), cx.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_cy.p, cy.data(), cy.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_taps.p, taps, sizeof(taps), hipMemcpyHostToDevice);
-    o->sort_smem = std::max(32 * 256 * 4, lsd::SORT_STAGE * 8);
+    o->sort_smem = std::max(32 * lsd::SORT_NT * 4, lsd::SORT_STAGE * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_detect, hipFuncAttributeMaxDynamicSharedMemorySize, o->detect_smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_sort, hipFuncAttributeMaxDynamicSharedMemorySize, o->sort_smem);
     if (e != hipSuccess) { delete o; set_error("planar_lsd_create: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
@@ -1631,7 +1625,7 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     hipLaunchKernelGGL(lsd::lsd_gauss<5>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>() + 8, ws, P.frame_bytes, P.off_blur5);
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
     hipLaunchKernelGGL(lsd::lbd_sobel, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, dP, ws);
-    hipLaunchKernelGGL(lsd::lsd_sort, dim3(B), dim3(256), o->sort_smem, st, dP, ws, dm, o->tie_order);
+    hipLaunchKernelGGL(lsd::lsd_sort, dim3(B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order);
     PLANAR_HIP_CHECK(hipGetLastError());
     o->pre_B = B;
     return PLANAR_OK;
