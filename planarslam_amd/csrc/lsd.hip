@@ -191,7 +191,7 @@ __device__ __forceinline__ void lds_sync();
 // cannot be reproduced this way and raises status 2; it needs ~34 unbalanced partitions in a row and does not occur on 10-bit keys.
 constexpr int SORT_NT = 1024;       // threads of lsd_sort: 16 wavefronts keep 16 sub-ranges (or 16 shares of a big one) in flight
 constexpr int SORT_NW = SORT_NT / 64;
-constexpr int SORT_SMALL = 1024;    // finished by one wavefront
+constexpr int SORT_SMALL = 2048;    // finished by one wavefront
 constexpr int SORT_STAGE = 16384;   // staged in LDS by the workgroup
 constexpr int SORT_LEAF = 64;       // finished by one lane
 struct SortRange { int f, l, d; };
