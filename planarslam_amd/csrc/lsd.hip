@@ -710,9 +710,18 @@ __device__ inline void chains3(const Det& D, int n, double out[3], bool sub2, F 
         lds_sync();
         const int cnt = min(64, n - base);
         if (lane < 3) {
-            const volatile double* st = D.stage;
-            if (lane == 2 && sub2) for (int j = 0; j < cnt; j++) acc -= st[j * 3 + 2];
-            else for (int j = 0; j < cnt; j++) acc += st[j * 3 + lane];
+            // the additions are a chain, the LDS reads are not: eight values are requested at a time
+            const double* st = D.stage + lane;
+            const bool neg = lane == 2 && sub2;
+            int j = 0;
+            for (; j + 8 <= cnt; j += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = st[(j + u) * 3];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { if (neg) acc -= v[u]; else acc += v[u]; }
+            }
+            for (; j < cnt; j++) { if (neg) acc -= st[j * 3]; else acc += st[j * 3]; }
         }
         lds_sync();
     }
