@@ -637,14 +637,15 @@ __device__ __forceinline__ GrowBatch grow_fetch(const Det& D, int head, int nb, 
     }
     return g;
 }
-__device__ int region_grow(const Det& D, int seed_pix, uint32_t seed_rank, double prec, double& reg_angle) {
+// seed_deg / seed_cs: ang[seed_pix] and seedcs[seed_pix] (the caller fetches them for 64 seed candidates at a time).  The region list in
+// global memory (D.reg) is written by lane 0 and read back by other lanes of this wavefront: callers that read it issue wave_sync() first.
+__device__ int region_grow(const Det& D, int seed_pix, uint32_t seed_rank, float seed_deg, float2 seed_cs, double prec, double& reg_angle) {
     const int lane = D.lane;
-    reg_angle = (double)D.ang[seed_pix] * DEG_TO_RADS;
-    const float2 scs = D.seedcs[seed_pix];
-    float sumdx = scs.x, sumdy = scs.y;
+    reg_angle = (double)seed_deg * DEG_TO_RADS;
+    float sumdx = seed_cs.x, sumdy = seed_cs.y;
     const uint32_t seed_xy = (uint32_t)(seed_pix % D.w) | ((uint32_t)(seed_pix / D.w) << 16);
     if (lane == 0) { D.reg[0] = seed_xy; D.ring[0] = seed_xy; used_set(D, seed_rank); }
-    wave_sync();
+    lds_sync();
     int reg_n = 1, head = 0, nb = 1;
     GrowBatch cur = grow_fetch(D, 0, 1, 1);
     // Most regions are a few dozen pixels and their frontier is too short to prefetch from: touch the cache lines of the 16x16 window around
@@ -694,7 +695,7 @@ __device__ int region_grow(const Det& D, int seed_pix, uint32_t seed_rank, doubl
         }
     }
     asm volatile("" :: "v"(warm.x));               // keeps the window loads alive
-    wave_sync();
+    lds_sync();
     return reg_n;
 }
 
@@ -845,7 +846,8 @@ __device__ bool refine(const Det& D, int& n, double& reg_angle, double prec, dou
     const double mean_angle = sum / double(cnt);
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / double(cnt) + mean_angle * mean_angle);
     wave_sync();
-    n = region_grow(D, seed_pix, rank_of(D, seed_pix), tau, reg_angle);
+    n = region_grow(D, seed_pix, rank_of(D, seed_pix), D.ang[seed_pix], D.seedcs[seed_pix], tau, reg_angle);
+    wave_sync();
     if (n < 2) return false;
     region2rect(D, n, reg_angle, prec, p, rec);
     density = double(n) / (sqrt(dist2(rec.x1, rec.y1, rec.x2, rec.y2)) * rec.width);
@@ -1105,22 +1107,28 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
     for (int base = 0; base < n_ord; base += 64) {
         const int pix = base + lane < n_ord ? (int)ord[base + lane] : -1;
         const uint32_t prk = base + lane < n_ord ? ordr[base + lane] : 0u;
+        const float sdeg = pix >= 0 ? D.ang[pix] : 0.f;             // seed angle / (cos, sin) of the 64 candidates of this block
+        const float2 scs = pix >= 0 ? D.seedcs[pix] : make_float2(0.f, 0.f);
         int cursor = 0;
         while (true) {
             const bool cand = pix >= 0 && lane >= cursor && !used_get(D, prk);
             const unsigned long long m = __ballot(cand);
             if (!m) break;
-            const int f = __ffsll((long long)m) - 1;
+            const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
             cursor = f + 1;
-            const int seed = __shfl(pix, f, 64);
-            const uint32_t seed_rank = (uint32_t)__shfl((int)prk, f, 64);
+            const int seed = __builtin_amdgcn_readlane(pix, f);
+            const uint32_t seed_rank = (uint32_t)__builtin_amdgcn_readlane((int)prk, f);
+            const float seed_deg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdeg), f));
+            const float2 seed_cs = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(scs.x), f)),
+                                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scs.y), f)));
             double reg_angle;
             long long c0 = __builtin_readcyclecounter();
-            int n = region_grow(D, seed, seed_rank, P.prec, reg_angle);
+            int n = region_grow(D, seed, seed_rank, seed_deg, seed_cs, P.prec, reg_angle);
             long long c1 = __builtin_readcyclecounter();
             t_grow += c1 - c0;
             n_regions++; n_px += n;
             if (n < P.min_reg_size) continue;
+            wave_sync();                                            // region list written by lane 0, read by all lanes below
             Rect rec;
             region2rect(D, n, reg_angle, P.prec, P.p, rec);
             c0 = __builtin_readcyclecounter(); t_rect += c0 - c1;
