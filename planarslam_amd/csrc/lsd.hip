@@ -432,7 +432,7 @@ __global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ pla
                 lds_sync();
                 while (sp > 0) {
                     sp--;
-                    int f = ((volatile int*)s_stack[wave][sp])[0], l = ((volatile int*)s_stack[wave][sp])[1], d = ((volatile int*)s_stack[wave][sp])[2];
+                    int f = s_stack[wave][sp][0], l = s_stack[wave][sp][1], d = s_stack[wave][sp][2];   // (plain LDS reads: a volatile cast turns them into FLAT loads, which also wait for every outstanding global access)
                     while (l - f > 16) {
                         if (l - f <= SORT_LEAF) { if (lane == 0) { s_leaf[wave][nleaf][0] = (short)f; s_leaf[wave][nleaf][1] = (short)l; s_leaf[wave][nleaf][2] = (short)d; } nleaf++; break; }
                         if (d == 0) { if (lane == 0) misc->status = 2; break; }
@@ -584,7 +584,7 @@ struct Det {
 // `used` flags, addressed by the compact index r of a defined pixel.  The global tail is only touched by images with more than
 // USED_LDS_BITS defined pixels; there every update is followed by an agent-scope fence and reads are agent-scope atomic loads.
 __device__ __forceinline__ bool used_get(const Det& D, uint32_t r) {
-    if (r < (uint32_t)USED_LDS_BITS) return (((volatile uint32_t*)D.used)[r >> 5] >> (r & 31)) & 1u;
+    if (r < (uint32_t)USED_LDS_BITS) return (D.used[r >> 5] >> (r & 31)) & 1u;      // plain ds_read: callers order it with lds_sync()
     return (__hip_atomic_load(D.gused + (r >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (r & 31)) & 1u;
 }
 __device__ __forceinline__ void used_set(const Det& D, uint32_t r) {
@@ -629,9 +629,11 @@ __device__ __forceinline__ GrowBatch grow_fetch(const Det& D, int head, int nb, 
     g.ok = false; g.nxy = 0; g.rec4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
     if (lane < 63 && e < nb && k != 4) {
         const int i = head + e;
-        uint32_t pxy;
-        if (reg_n - i <= RING) pxy = ((volatile uint32_t*)D.ring)[i & (RING - 1)];
-        else pxy = __builtin_nontemporal_load(D.reg + i);
+        // the LDS read is unconditional: if both sources sit behind one branch the compiler selects the ADDRESS and emits a single FLAT
+        // load, whose wait also covers every outstanding global load (the next batch's records requested ahead)
+        uint32_t pxy = D.ring[i & (RING - 1)];
+        asm volatile("" : "+v"(pxy));                                         // (keeps the two loads apart)
+        if (reg_n - i > RING) pxy = __builtin_nontemporal_load(D.reg + i);   // (rare) the entry left the ring
         const int xx = (int)(pxy & 0xffff) + (k % 3) - 1, yy = (int)(pxy >> 16) + (k / 3) - 1;
         if (xx >= 0 && xx < w && yy >= 0 && yy < h) { g.ok = true; g.nxy = (uint32_t)xx | ((uint32_t)yy << 16); g.rec4 = D.pix4[yy * w + xx]; }
     }
