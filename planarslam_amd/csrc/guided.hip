@@ -207,11 +207,10 @@ __device__ inline int rot_bin(float a_from, float a_to) {
 // Order-bound part: wavefront 0 resolves probes [0, m) of the current chunk in order.
 //   MODE_FRAME: best only, TH_HIGH;  MODE_MAP: best + second with the same-level ratio test;  MODE_BOW: TH_LOW + ratio.
 template <int MODE>
-__device__ void resolve_chunk(Lds& s, int m, const Args& a, int b, const float* from_angle, const float* to_angle_f,
+__device__ void resolve_chunk(Lds& s, int m, const Args& a, int32_t* match, int b, const float* from_angle, const float* to_angle_f,
                               const planar_keypoint* keys, const uint8_t* observed) {
     const int lane = threadIdx.x;
     volatile uint32_t* blk = s.blocked;
-    int32_t* match = a.match;
     for (int q = 0; q < m; q++) {
         const int id = s.pid[q];
         const int off = s.poff[q], cnt = s.poff[q + 1] - off;
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(NT) void projection_kernel(Args a) {
     const planar_keypoint* keys = f.keys_un + (size_t)b * f.stride;
     const float* uR = f.u_right + (size_t)b * f.stride;
     const uint8_t* desc = f.desc + (size_t)b * f.stride * 32;
-    a.match += (size_t)b * f.stride;
+    int32_t* const match_b = a.match + (size_t)b * f.stride;     // (the by-value argument struct is never written: a modified copy would live in scratch)
 
     for (int w = tid; w < MAXN / 32; w += NT) s.blocked[w] = 0;
     if (tid == 0) { s.n_ev = 0; s.nmatches = 0; }
@@ -415,11 +414,11 @@ __global__ __launch_bounds__(NT) void projection_kernel(Args a) {
         }
         __syncthreads();
         // ---- order-bound
-        if (tid < 64) resolve_chunk<MODE>(s, m, a, b, MODE == MODE_FRAME ? a.last.angle + po : nullptr, nullptr, keys, observed);
+        if (tid < 64) resolve_chunk<MODE>(s, m, a, match_b, b, MODE == MODE_FRAME ? a.last.angle + po : nullptr, nullptr, keys, observed);
         __syncthreads();
         base += m;
     }
-    if (MODE == MODE_FRAME && a.check_orientation) rotation_filter(s, a.match);
+    if (MODE == MODE_FRAME && a.check_orientation) rotation_filter(s, match_b);
     __syncthreads();
     if (tid == 0) a.nmatches[b] = s.nmatches;
 }
@@ -460,10 +459,10 @@ __global__ __launch_bounds__(NT) void bow_kernel(BowArgs g, Args a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int NK = g.n_kf[b], NF = g.n_f[b];
     const size_t ko = (size_t)b * g.kf_stride, fo = (size_t)b * g.f_stride;
-    a.match += fo;
+    int32_t* const match_b = a.match + fo;
     for (int w = tid; w < MAXN / 32; w += NT) s.blocked[w] = 0;
     if (tid == 0) { s.n_ev = 0; s.nmatches = 0; }
-    for (int i = tid; i < NF; i += NT) a.match[i] = -1;   // vpMapPointMatches = vector<MapPoint*>(F.N, NULL)
+    for (int i = tid; i < NF; i += NT) match_b[i] = -1;   // vpMapPointMatches = vector<MapPoint*>(F.N, NULL)
     int pk = 1; while (pk < NK) pk <<= 1;
     int pf = 1; while (pf < NF) pf <<= 1;
     for (int i = tid; i < pk; i += NT) {
@@ -517,11 +516,11 @@ __global__ __launch_bounds__(NT) void bow_kernel(BowArgs g, Args a) {
             }
         }
         __syncthreads();
-        if (tid < 64) resolve_chunk<MODE_BOW>(s, m, a, b, g.kf_angle + ko, g.f_angle + fo, nullptr, nullptr);
+        if (tid < 64) resolve_chunk<MODE_BOW>(s, m, a, match_b, b, g.kf_angle + ko, g.f_angle + fo, nullptr, nullptr);
         __syncthreads();
         base += m;
     }
-    if (a.check_orientation) rotation_filter(s, a.match);
+    if (a.check_orientation) rotation_filter(s, match_b);
     __syncthreads();
     if (tid == 0) a.nmatches[b] = s.nmatches;
 }

@@ -27,54 +27,103 @@ namespace pose {
 using namespace geomd;
 
 // ---- pivoted LDLT 6x6 (Eigen::LDLT semantics: isPositive gate, pseudo-inverse of D) ----
+// The pivot row is data dependent; every step is instantiated for its K and dispatches the symmetric swap on the pivot index, so that
+// the matrix is indexed by constants only and stays in registers instead of scratch memory (same operations in the same order as the
+// loop form).
+__device__ __forceinline__ void dswap(double& a, double& b) { const double t = a; a = b; b = t; }
+template <int K, int BIG>
+__device__ __forceinline__ void ldlt_swap(double (&A)[6][6]) {
+    if constexpr (BIG > K && BIG < 6) {
+#pragma unroll
+        for (int j = 0; j < K; j++) dswap(A[K][j], A[BIG][j]);
+#pragma unroll
+        for (int i = BIG + 1; i < 6; i++) dswap(A[i][K], A[i][BIG]);
+        dswap(A[K][K], A[BIG][BIG]);
+#pragma unroll
+        for (int i = K + 1; i < BIG; i++) dswap(A[i][K], A[BIG][i]);
+    }
+}
+template <int K>
+__device__ __forceinline__ bool ldlt_step(double (&A)[6][6], int (&tr)[6], int& sign) {   // true: the factorisation stops (zero matrix)
+    int big = K; double bv = fabs(A[K][K]);
+#pragma unroll
+    for (int i = K + 1; i < 6; i++) if (fabs(A[i][i]) > bv) { bv = fabs(A[i][i]); big = i; }
+    tr[K] = big;
+    if (big == K + 1) ldlt_swap<K, K + 1>(A);
+    else if (big == K + 2) ldlt_swap<K, K + 2>(A);
+    else if (big == K + 3) ldlt_swap<K, K + 3>(A);
+    else if (big == K + 4) ldlt_swap<K, K + 4>(A);
+    else if (big == K + 5) ldlt_swap<K, K + 5>(A);
+    if constexpr (K > 0) {
+        double temp[6];
+#pragma unroll
+        for (int j = 0; j < K; j++) temp[j] = A[j][j] * A[K][j];
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < K; j++) s += A[K][j] * temp[j];
+        A[K][K] -= s;
+#pragma unroll
+        for (int i = K + 1; i < 6; i++) {
+            double t = 0;
+#pragma unroll
+            for (int j = 0; j < K; j++) t += A[i][j] * temp[j];
+            A[i][K] -= t;
+        }
+    }
+    const double akk = A[K][K];
+    const bool valid = fabs(akk) > 0;
+    if (K == 0 && !valid) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) tr[j] = j;
+        return true;
+    }
+    if (valid) {
+#pragma unroll
+        for (int i = K + 1; i < 6; i++) A[i][K] /= akk;
+    }
+    if (sign == 1) { if (akk < 0) sign = 3; }
+    else if (sign == 2) { if (akk > 0) sign = 3; }
+    else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = 2; }
+    return false;
+}
+template <int K>
+__device__ __forceinline__ void perm_swap(double (&y)[6], int t) {   // y[K] <-> y[t], t >= K
+#pragma unroll
+    for (int j = K + 1; j < 6; j++) if (t == j) dswap(y[K], y[j]);
+}
 __device__ bool ldlt_solve6(const double* Hu /*21 upper, row-major*/, double lambda, const double b[6], double x[6]) {
     double A[6][6];
     {
         int k = 0;
+#pragma unroll
         for (int i = 0; i < 6; i++)
+#pragma unroll
             for (int j = i; j < 6; j++, k++) { A[i][j] = Hu[k]; A[j][i] = Hu[k]; }
+#pragma unroll
         for (int i = 0; i < 6; i++) A[i][i] += lambda;
     }
     int tr[6];
     int sign = 0;   // 0 zero, 1 pos-semidef, 2 neg-semidef, 3 indefinite
-    for (int k = 0; k < 6; k++) {
-        int big = k; double bv = fabs(A[k][k]);
-        for (int i = k + 1; i < 6; i++) if (fabs(A[i][i]) > bv) { bv = fabs(A[i][i]); big = i; }
-        tr[k] = big;
-        if (k != big) {
-            for (int j = 0; j < k; j++) { const double t = A[k][j]; A[k][j] = A[big][j]; A[big][j] = t; }
-            for (int i = big + 1; i < 6; i++) { const double t = A[i][k]; A[i][k] = A[i][big]; A[i][big] = t; }
-            { const double t = A[k][k]; A[k][k] = A[big][big]; A[big][big] = t; }
-            for (int i = k + 1; i < big; i++) { const double t = A[i][k]; A[i][k] = A[big][i]; A[big][i] = t; }
-        }
-        if (k > 0) {
-            double temp[6];
-            for (int j = 0; j < k; j++) temp[j] = A[j][j] * A[k][j];
-            double s = 0;
-            for (int j = 0; j < k; j++) s += A[k][j] * temp[j];
-            A[k][k] -= s;
-            for (int i = k + 1; i < 6; i++) {
-                double t = 0;
-                for (int j = 0; j < k; j++) t += A[i][j] * temp[j];
-                A[i][k] -= t;
-            }
-        }
-        const double akk = A[k][k];
-        const bool valid = fabs(akk) > 0;
-        if (k == 0 && !valid) { for (int j = 0; j < 6; j++) tr[j] = j; break; }
-        if (valid) for (int i = k + 1; i < 6; i++) A[i][k] /= akk;
-        if (sign == 1) { if (akk < 0) sign = 3; }
-        else if (sign == 2) { if (akk > 0) sign = 3; }
-        else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = 2; }
+    if (!ldlt_step<0>(A, tr, sign)) {
+        ldlt_step<1>(A, tr, sign); ldlt_step<2>(A, tr, sign); ldlt_step<3>(A, tr, sign); ldlt_step<4>(A, tr, sign); ldlt_step<5>(A, tr, sign);
     }
     if (!(sign == 1 || sign == 0)) return false;
     double y[6];
+#pragma unroll
     for (int i = 0; i < 6; i++) y[i] = b[i];
-    for (int k = 0; k < 6; k++) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
-    for (int i = 0; i < 6; i++) for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
+    perm_swap<0>(y, tr[0]); perm_swap<1>(y, tr[1]); perm_swap<2>(y, tr[2]); perm_swap<3>(y, tr[3]); perm_swap<4>(y, tr[4]); perm_swap<5>(y, tr[5]);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
+#pragma unroll
     for (int i = 0; i < 6; i++) y[i] = fabs(A[i][i]) > 5.562684646268003e-309 ? y[i] / A[i][i] : 0.0;   // 1/DBL_MAX
-    for (int i = 5; i >= 0; i--) for (int j = i + 1; j < 6; j++) y[i] -= A[j][i] * y[j];
-    for (int k = 5; k >= 0; k--) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+#pragma unroll
+    for (int i = 5; i >= 0; i--)
+#pragma unroll
+        for (int j = i + 1; j < 6; j++) y[i] -= A[j][i] * y[j];
+    perm_swap<5>(y, tr[5]); perm_swap<4>(y, tr[4]); perm_swap<3>(y, tr[3]); perm_swap<2>(y, tr[2]); perm_swap<1>(y, tr[1]); perm_swap<0>(y, tr[0]);
+#pragma unroll
     for (int i = 0; i < 6; i++) x[i] = y[i];
     return true;
 }
@@ -108,12 +157,16 @@ __device__ __forceinline__ void robustify(double c2, double delta, double& rho0,
 // accumulate one edge into H (upper), b and robust chi
 __device__ __forceinline__ void accumulate(Acc& a, int dim, const double err[3], const double J[3][6], const double info[3],
                                            bool robust, double delta) {
+    // rows are addressed by constants (a `for (i < dim)` loop would index err / J / info dynamically and push them to scratch memory)
     double c2 = 0;
-    for (int i = 0; i < dim; i++) c2 += err[i] * (info[i] * err[i]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) if (i < dim) c2 += err[i] * (info[i] * err[i]);
     double rho0 = c2, w = 1.0;
     if (robust) robustify(c2, delta, rho0, w);
     a.chi += rho0;
-    for (int i = 0; i < dim; i++) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (i >= dim) continue;
         const double oi = info[i];
         int k = 0;
 #pragma unroll
@@ -128,7 +181,8 @@ __device__ __forceinline__ void accumulate(Acc& a, int dim, const double err[3],
 
 __device__ __forceinline__ double edge_chi(int dim, const double err[3], const double info[3], bool robust, double delta) {
     double c2 = 0;
-    for (int i = 0; i < dim; i++) c2 += err[i] * (info[i] * err[i]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) if (i < dim) c2 += err[i] * (info[i] * err[i]);
     if (!robust) return c2;
     double rho0, w;
     robustify(c2, delta, rho0, w);
@@ -346,8 +400,9 @@ __global__ __launch_bounds__(NT) void pose_opt_kernel(BatchDev Bt, ParamsDev P) 
                 const int pe = task / 12, r = task - pe * 12;
                 if (lvl_pl[pe] != 0) continue;
                 const int kind = pe / F.nm, i = pe - kind * F.nm;
-                double add[6] = {0, 0, 0, 0, 0, 0};
-                add[r >> 1] = (r & 1) ? -1e-9 : 1e-9;
+                double add[6];
+#pragma unroll
+                for (int dd = 0; dd < 6; dd++) add[dd] = (dd == (r >> 1)) ? ((r & 1) ? -1e-9 : 1e-9) : 0.0;
                 const SE3 Tp = se3_mul(se3_exp(add), Tc);
                 const Plane local = plane_local(Tp, load_map_plane(F, P, i, kind), P.mode == 1);
                 double err[3];
@@ -475,7 +530,8 @@ __global__ __launch_bounds__(NT) void pose_opt_kernel(BatchDev Bt, ParamsDev P) 
             double err[3];
             plane_error(kind, local, plane_from_float(F.pl_meas + 4 * i), err);
             double c2 = 0;
-            for (int r = 0; r < dim; r++) c2 += err[r] * (info[r] * err[r]);
+#pragma unroll
+            for (int r = 0; r < 3; r++) if (r < dim) c2 += err[r] * (info[r] * err[r]);
             const bool out = (double)(float)c2 > (kind == 0 ? P.planeChi : P.vpChi);
             lvl_pl[pe] = out ? 1 : 0; o_pl[3 * i + kind] = out ? 1 : 0;
             bad[0] += out;
