@@ -98,7 +98,8 @@ __device__ void edge_error(const Dev& D, int type, const SE3& T, const LmV& L, c
 __device__ __forceinline__ int edge_dim(int type) { return (type == BE_MONO || type >= BE_VER) ? 2 : 3; }
 __device__ __forceinline__ double edge_chi2(int dim, const double* err, const double* info) {
     double s = 0;
-    for (int i = 0; i < dim; i++) s += err[i] * (info[i] * err[i]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) if (i < dim) s += err[i] * (info[i] * err[i]);   // constant row indices: no scratch copies
     return s;
 }
 __device__ __forceinline__ void huber(double c2, double delta, double& r0, double& r1) {
@@ -196,14 +197,16 @@ __global__ __launch_bounds__(NT) void ba_build(Dev D, int robust) {
                     double add[3] = {0, 0, 0}, e1[3], e2[3];
                     add[d] = delta; LmV Lp = Lm; lm_oplus(Lp, add); edge_error(D, type, T, Lp, meas, e1);
                     add[d] = -delta; LmV Lq = Lm; lm_oplus(Lq, add); edge_error(D, type, T, Lq, meas, e2);
-                    for (int i = 0; i < dim; i++) A[i][d] = scalar * (e1[i] - e2[i]);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) if (i < dim) A[i][d] = scalar * (e1[i] - e2[i]);
                 }
                 if (p >= 0) {
                     for (int d = 0; d < 6; d++) {
                         double add[6] = {0, 0, 0, 0, 0, 0}, e1[3], e2[3];
                         add[d] = delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e1);
                         add[d] = -delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e2);
-                        for (int i = 0; i < dim; i++) B[i][d] = scalar * (e1[i] - e2[i]);
+#pragma unroll
+                        for (int i = 0; i < 3; i++) if (i < dim) B[i][d] = scalar * (e1[i] - e2[i]);
                     }
                 }
             }
@@ -211,7 +214,9 @@ __global__ __launch_bounds__(NT) void ba_build(Dev D, int robust) {
             if (robust) { double r0; huber(edge_chi2(dim, err, info), info[3], r0, w); }
             double Wb[18];
             for (int i = 0; i < 18; i++) Wb[i] = 0;
-            for (int i = 0; i < dim; i++) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                if (i >= dim) continue;
                 const double wo = w * info[i], r = -info[i] * err[i] * w;
                 for (int a = 0; a < 3; a++) {
                     bl[a] += A[i][a] * r;
