@@ -879,26 +879,33 @@ __device__ double nfa(const Plan& P, int n, int k, double p, int pj, int lane) {
     }
     double bin_tail = term;
     const double tolerance = 0.1;
-    // The tail is a sequential recurrence (term *= mult; bin_tail += term), but the stopping rule of iteration i only reads
-    // iteration i's values: every lane runs the cheap recurrence for a block of 64 iterations, keeps the values of "its" i and
-    // evaluates the expensive rule (pow, log10) for it; the first lane whose rule fires is where the reference breaks.
+    // The tail is a sequential recurrence (term *= mult; bin_tail += term), but the stopping rule of iteration i only reads iteration i's
+    // values.  Per block of 64 iterations: lane j computes the multiplier of "its" iteration (the division is the expensive part and is
+    // independent), the chain then runs over the 64 multipliers broadcast by readlane (two FP64 operations per step), every lane keeps the
+    // values of its own step and evaluates the expensive rule (pow, log10) for it - only in blocks that contain a step with bin_term < 1;
+    // the first lane whose rule fires is where the reference breaks.
     for (int i = k + 1; i <= n;) {
         const int cnt = min(64, n - i + 1);
-        double t = term, bt = bin_tail, my_term = 0, my_tail = 0, my_bin = 2, my_mult = 0;
+        const double my_bin = lane < cnt ? double(n - (i + lane) + 1) / double(i + lane) : 2.0;
+        const double my_mult = my_bin * p_term;
+        const int mlo = __double2loint(my_mult), mhi = __double2hiint(my_mult);
+        double t = term, bt = bin_tail, my_term = 0, my_tail = 0;
         for (int j = 0; j < cnt; j++) {
-            const double bin_term = double(n - (i + j) + 1) / double(i + j);
-            const double mult_term = bin_term * p_term;
+            const double mult_term = __hiloint2double(__builtin_amdgcn_readlane(mhi, j), __builtin_amdgcn_readlane(mlo, j));
             t *= mult_term;
             bt += t;
-            if (j == lane) { my_term = t; my_tail = bt; my_bin = bin_term; my_mult = mult_term; }
+            if (j == lane) { my_term = t; my_tail = bt; }
         }
-        bool brk = false;
-        if (lane < cnt && my_bin < 1) {
-            const double err = my_term * ((1 - pow(my_mult, double(n - (i + lane) + 1))) / (1 - my_mult) - 1);
-            brk = err < tolerance * fabs(-log10(my_tail) - LOG_NT) * my_tail;
+        const bool rule = lane < cnt && my_bin < 1;
+        if (__ballot(rule)) {
+            bool brk = false;
+            if (rule) {
+                const double err = my_term * ((1 - pow(my_mult, double(n - (i + lane) + 1))) / (1 - my_mult) - 1);
+                brk = err < tolerance * fabs(-log10(my_tail) - LOG_NT) * my_tail;
+            }
+            const unsigned long long m = __ballot(brk);
+            if (m) { bin_tail = __shfl(my_tail, __ffsll((long long)m) - 1, 64); return -log10(bin_tail) - LOG_NT; }
         }
-        const unsigned long long m = __ballot(brk);
-        if (m) { bin_tail = __shfl(my_tail, __ffsll((long long)m) - 1, 64); return -log10(bin_tail) - LOG_NT; }
         term = t; bin_tail = bt; i += cnt;
     }
     return -log10(bin_tail) - LOG_NT;
