@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step (one workspace set per step in flight: ~25 GB at 1024)")
     ap.add_argument("--workload", choices=["full", "orb"], default="full")
     ap.add_argument("--depth", type=int, default=2, help="software-pipeline depth: PoseOptimization of step i is enqueued during step i+depth")
     ap.add_argument("--prio", default="-1,0,0", help="stream priorities: ORB/match/pose stream, LSD streams, PEAC streams (lower = higher priority)")
@@ -298,18 +298,18 @@ def main():
     dom_ms, dom_bytes = cand[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     per_frame = 1961064 + (1843200 + 312160 if full else 0) + (72000 + 118000 + 65130 * 2 * 20 if full else 0)
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01i_pmc_*.csv: separate --pmc FETCH_SIZE and
-    # --pmc WRITE_SIZE runs of this same command at B=256, KB per launch); scaled to this run's batch.  Raw counter sums: the gfx950
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01j_pmc_*.csv: separate --pmc FETCH_SIZE and
+    # --pmc WRITE_SIZE runs of this same command at B=1024, KB per launch); scaled to this run's batch.  Raw counter sums: the gfx950
     # "FETCH_SIZE reports half of a wide streaming read" correction is NOT applied because these kernels gather narrow records.
     traffic, traffic_note = None, None
-    pmc_csv = os.path.join(ROOT, "profiles", "r01i_pmc_fetch_write_kb_per_launch.csv")
+    pmc_csv = os.path.join(ROOT, "profiles", "r01j_pmc_fetch_write_kb_per_launch.csv")
     pmc_key = {"peac_blocks+peac_segment": "planar::peac::peac_segment", "lsd_detect(+7 small kernels)": "planar::lsd::lsd_detect"}.get(dom, "planar::orb::" + dom)
     if os.path.exists(pmc_csv):
         for line in open(pmc_csv).read().splitlines()[1:]:
             k, _, f_kb, w_kb = line.rsplit(",", 3)
             if k == pmc_key:
-                traffic = int((float(f_kb) + float(w_kb)) * 1024 * B / 256)
-                traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, B=256): {float(f_kb) / 1024:.0f} MB read + {float(w_kb) / 1024:.0f} MB written per launch"
+                traffic = int((float(f_kb) + float(w_kb)) * 1024 * B / 1024)
+                traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, B=1024): {float(f_kb) / 1024:.0f} MB read + {float(w_kb) / 1024:.0f} MB written per launch"
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(dom_ms, 4),
                 "algorithmic_bytes_per_launch": int(dom_bytes), "pipeline_algorithmic_GBps": round(per_frame * fps / 1e9, 2),
