@@ -318,7 +318,7 @@ def main():
 
     # ---- CPU baseline: the oracle restatement of the same stages on this box's host cores (1 thread) ----
     cpu = None
-    if args.cpu_seconds > 0:
+    if args.cpu_seconds > 0 and world == 1:        # rank 0 at N = 1 only
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
         o = ol.OrbOracle()
