@@ -377,9 +377,9 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         heap_sift_up(heap_n - 1, id, mse);
     };
     // pop_heap = __adjust_heap(first, 0, len, last value): the hole sinks to the bottom along the smaller child (no early exit), then
-    // the value climbs back.  Lane t = 1..63 holds node t of the 6-level subtree under the hole and, for t < 32, compares its two children
-    // (one LDS round trip for everything); the five decisions are then bit operations on the ballot of those comparisons (scalar unit) and
-    // the chosen nodes move up in one parallel store.
+    // the value climbs back.  Lane t = 1..63 stands for node t of the subtree under the hole and compares its two children (one LDS round
+    // trip for everything); the six decisions are then bit operations on the ballot of those comparisons (scalar unit) and every node on
+    // the path pulls its chosen child up in one parallel store.
     auto heap_pop = [&]() -> int {
         const int top = S.h_id[0];
         const double vm = S.h_mse[heap_n - 1]; const int vi = S.h_id[heap_n - 1];
@@ -390,22 +390,26 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         const int dl = 31 - __clz(max(lane, 1));                             // level of local node `lane`; its heap index is (hole << dl) + lane - 1
         int hole = 0;
         while (hole < half) {
+            // lane t = 1..63 is node t of the subtree under the hole: it reads its two children, decides which one it would pull up, and the
+            // nodes that turn out to lie on the path do so - six levels per LDS round trip
             const int g = (hole << dl) + lane - 1;
-            const bool valid = lane >= 1 && g < len, inner = lane >= 1 && lane < 32 && g < half;
-            double K = 0, kl = 0, kr = 0; int I = 0;
-            if (valid) { K = S.h_mse[g]; I = S.h_id[g]; }
-            if (inner) { kl = S.h_mse[2 * g + 1]; kr = S.h_mse[2 * g + 2]; }
+            const bool inner = lane >= 1 && g < half;
+            double kl = 0, kr = 0; int il = 0, ir = 0;
+            if (inner) { kl = S.h_mse[2 * g + 1]; kr = S.h_mse[2 * g + 2]; il = S.h_id[2 * g + 1]; ir = S.h_id[2 * g + 2]; }
             const unsigned long long two = __ballot(inner);
             const unsigned long long takel = __ballot(inner && kl < kr);     // comp(first[second], first[second - 1]): take second - 1
             int cur = 1;
             unsigned long long path = 0;
 #pragma unroll
-            for (int d = 0; d < 5; d++) {
+            for (int d = 0; d < 6; d++) {
                 if (!((two >> cur) & 1ull)) break;
-                cur = 2 * cur + 1 - (int)((takel >> cur) & 1ull);
                 path |= 1ull << cur;
+                cur = 2 * cur + 1 - (int)((takel >> cur) & 1ull);
             }
-            if (valid && ((path >> lane) & 1ull)) { const int gp = (hole << (dl - 1)) + (lane >> 1) - 1; S.h_mse[gp] = K; S.h_id[gp] = (u16)I; }
+            if ((path >> lane) & 1ull) {
+                const bool left = (takel >> lane) & 1ull;
+                S.h_mse[g] = left ? kl : kr; S.h_id[g] = (u16)(left ? il : ir);
+            }
             const int dc = 31 - __clz(cur);
             hole = (hole << dc) + cur - 1;
         }
