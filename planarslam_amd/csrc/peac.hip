@@ -646,8 +646,9 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                             S.rid[m] = (u16)(Np >= Nn ? rp : rn);
                             S.nouse[p >> 5] |= 1u << (p & 31);
                             S.nouse[nb >> 5] |= 1u << (nb & 31);
-                            // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:64-84)
-                            const int xr = lds_find(S.dsp, rp), yr = lds_find(S.dsp, rn);
+                            // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:64-84).  The rid of a live node is its set's root (node_N relies on the
+                            // same invariant), so the two Find() calls return their arguments and compress nothing.
+                            const int xr = rp, yr = rn;
                             if (xr != yr) {
                                 if (S.dss[xr] < S.dss[yr]) { S.dsp[xr] = (u16)yr; S.dss[yr] += S.dss[xr]; }
                                 else { S.dsp[yr] = (u16)xr; S.dss[xr] += S.dss[yr]; }
