@@ -890,14 +890,23 @@ __device__ double nfa(const Plan& P, int n, int k, double p, int pj, int lane) {
         const double my_mult = my_bin * p_term;
         const int mlo = __double2loint(my_mult), mhi = __double2hiint(my_mult);
         double t = term, bt = bin_tail, my_term = 0, my_tail = 0;
-        for (int j = 0; j < cnt; j++) {
-            const double mult_term = __hiloint2double(__builtin_amdgcn_readlane(mhi, j), __builtin_amdgcn_readlane(mlo, j));
-            t *= mult_term;
-            bt += t;
-            if (j == lane) { my_term = t; my_tail = bt; }
-        }
         const bool rule = lane < cnt && my_bin < 1;
-        if (__ballot(rule)) {
+        const bool any_rule = __ballot(rule) != 0;
+        if (any_rule) {
+            for (int j = 0; j < cnt; j++) {
+                const double mult_term = __hiloint2double(__builtin_amdgcn_readlane(mhi, j), __builtin_amdgcn_readlane(mlo, j));
+                t *= mult_term;
+                bt += t;
+                if (j == lane) { my_term = t; my_tail = bt; }
+            }
+        } else {   // no step of this block can stop the loop: only the end of the chain is needed
+            for (int j = 0; j < cnt; j++) {
+                const double mult_term = __hiloint2double(__builtin_amdgcn_readlane(mhi, j), __builtin_amdgcn_readlane(mlo, j));
+                t *= mult_term;
+                bt += t;
+            }
+        }
+        if (any_rule) {
             bool brk = false;
             if (rule) {
                 const double err = my_term * ((1 - pow(my_mult, double(n - (i + lane) + 1))) / (1 - my_mult) - 1);
