@@ -1076,11 +1076,27 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
 __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
                                                    int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
                                                    int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
-                                                   int32_t* __restrict__ status, long long* __restrict__ timing, int* __restrict__ next_frame) {
+                                                   int32_t* __restrict__ status, long long* __restrict__ timing, int* __restrict__ next_frame,
+                                                   const int* __restrict__ order) {
     __shared__ int s_frame;
-    if (threadIdx.x == 0) s_frame = atomicAdd(next_frame, 1);
+    if (threadIdx.x == 0) { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
     __syncthreads();
     segment_frame(L, K, C, depth, pitch_px, frame_stride_px, ws, labels, label_stride, planes, n_planes, status, timing, s_frame);
+}
+
+// Longest-first order for the NEXT call with the same batch size: slot b of a batch is one camera stream, consecutive frames of a stream cost
+// about the same, and a launch ends with its slowest frames - so they should start first.  order[rank] = frame, rank by the duration the
+// last call measured (ties by frame index).  Only the schedule depends on it, never a result.
+__global__ void peac_order(const long long* __restrict__ timing, int B, int* __restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const long long ci = timing[(size_t)i * 16 + 6];         // clock ticks from kernel entry to the end of floodFill
+    int rank = 0;
+    for (int j = 0; j < B; j++) {
+        const long long cj = timing[(size_t)j * 16 + 6];
+        rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0;
+    }
+    order[rank] = i;
 }
 
 }  // namespace peac
@@ -1097,7 +1113,8 @@ struct planar_peac {
     peac::Layout L{};
     peac::Consts C{};
     int smem = 0;
-    DevBuf d_ws, d_status, d_timing, d_next;
+    DevBuf d_ws, d_status, d_timing, d_next, d_order;
+    int order_B = 0;                                          // batch size d_order was computed for (0: none yet)
     DevBuf d_depth, d_labels, d_planes, d_nplanes;   // staging for the host-pointer entry point
 };
 
@@ -1139,7 +1156,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     o->C.cos_refine = std::cos(30.0 * deg);
     int rc;
     if ((rc = o->d_ws.alloc((size_t)max_batch * L.frame_bytes)) || (rc = o->d_status.alloc((size_t)max_batch * 4)) ||
-        (rc = o->d_timing.alloc((size_t)max_batch * 128)) || (rc = o->d_next.alloc(256))) { delete o; return rc; }
+        (rc = o->d_timing.alloc((size_t)max_batch * 128)) || (rc = o->d_next.alloc(256)) || (rc = o->d_order.alloc((size_t)max_batch * 4))) { delete o; return rc; }
     if (o->smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)peac::peac_segment, hipFuncAttributeMaxDynamicSharedMemorySize, o->smem);
         if (e != hipSuccess) { delete o; set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
@@ -1162,7 +1179,9 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     PLANAR_HIP_CHECK(hipMemsetAsync(p->d_next.p, 0, 4, st));
     hipLaunchKernelGGL(peac::peac_segment, dim3(B), dim3(peac::NT), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
                        p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>(),
-                       p->d_next.as<int>());
+                       p->d_next.as<int>(), p->order_B == B ? p->d_order.as<int>() : nullptr);
+    hipLaunchKernelGGL(peac::peac_order, dim3((B + 255) / 256), dim3(256), 0, st, p->d_timing.as<long long>(), B, p->d_order.as<int>());
+    p->order_B = B;
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
 }
