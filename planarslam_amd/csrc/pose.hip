@@ -312,8 +312,8 @@ __global__ __launch_bounds__(NT) void pose_opt_kernel(BatchDev Bt, ParamsDev P) 
 
     // LDS carve: reduction scratch, numeric-Jacobian scratch, levels
     double* red = (double*)smem;                              // [4][28]
-    double* pj = red + 4 * 28;                                // [MAX_PLANE_EDGES][12][3] perturbed errors
-    uint8_t* lvl_pt = (uint8_t*)(pj + MAX_PLANE_EDGES * 36);  // [max_points] 0 active, 1 outlier, 2 absent
+    double* pj = red + 4 * 28;                                // [3 * max_planes][12][3] perturbed errors
+    uint8_t* lvl_pt = (uint8_t*)(pj + (size_t)Bt.max_planes * 3 * 36);   // [max_points] 0 active, 1 outlier, 2 absent (pj is sized by the batch's plane capacity)
     uint8_t* lvl_ln = lvl_pt + Bt.max_points;                 // [max_lines]
     uint8_t* lvl_pl = lvl_ln + Bt.max_lines;                  // [max_planes*3]
     const int kinds = P.mode == 0 ? 3 : 1;
@@ -346,9 +346,10 @@ __global__ __launch_bounds__(NT) void pose_opt_kernel(BatchDev Bt, ParamsDev P) 
     const int nInitial = (int)cnt[0] + (int)cntp[0];
     const int nEdges = (int)cnt[1] + (int)cntp[1];
     float* Tout = Bt.Tcw_out + (size_t)b * 16;
-    if (early_translation || nInitial < 3 || npe > MAX_PLANE_EDGES) {   // :985 / :3199
+    const bool too_many = npe > MAX_PLANE_EDGES || F.nm > Bt.max_planes;
+    if (early_translation || nInitial < 3 || too_many) {   // :985 / :3199
         if (tid < 16) Tout[tid] = Tin[tid];
-        if (tid == 0) { Bt.n_inliers[b] = npe > MAX_PLANE_EDGES ? -1 : 0; if (Bt.lm_iters) Bt.lm_iters[b] = 0; }
+        if (tid == 0) { Bt.n_inliers[b] = too_many ? -1 : 0; if (Bt.lm_iters) Bt.lm_iters[b] = 0; }
         return;
     }
 
@@ -587,7 +588,7 @@ static int pose_launch(planar_ctx* ctx, const planar_pose_batch* bt, const plana
     P.dMono = (double)(float)sqrt(5.991); P.dStereo = (double)(float)sqrt(7.815);            // const float delta* (:583-584)
     P.dPlane = (double)(float)sqrt(prm->plane_chi); P.dVP = (double)(float)sqrt(prm->vp_chi);   // (:780,:783)
     P.mode = mode; P.rounds = rounds; P.its = its;
-    const size_t smem = (4 * 28 + pose::MAX_PLANE_EDGES * 36) * sizeof(double) + (size_t)bt->max_points + bt->max_lines + 3 * (size_t)bt->max_planes + 16;
+    const size_t smem = (4 * 28 + (size_t)bt->max_planes * 3 * 36) * sizeof(double) + (size_t)bt->max_points + bt->max_lines + 3 * (size_t)bt->max_planes + 16;
     PLANAR_REQUIRE(smem <= 160 * 1024, PLANAR_EINVAL, "problem too large for LDS");
     if (smem > 64 * 1024)
         PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
