@@ -293,7 +293,7 @@ __device__ void block_reduce(double* v, double* lds /* [4][N] */) {
     for (int k = 0; k < N; k++) v[k] = (lds[k] + lds[N + k]) + (lds[2 * N + k] + lds[3 * N + k]);
 }
 
-__global__ __launch_bounds__(NT) void pose_opt_kernel(BatchDev Bt, ParamsDev P) {
+__global__ __launch_bounds__(NT, 2) void pose_opt_kernel(BatchDev Bt, ParamsDev P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     Frame F;
