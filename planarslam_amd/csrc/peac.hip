@@ -284,7 +284,8 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     __shared__ int s_ext[MAX_PLANES], s_old[MAX_PLANES], s_plidmap[MAX_PLANES];
     __shared__ uint8_t s_valid[MAX_PLANES];
     __shared__ unsigned s_adj[MAX_PLANES][MAX_PLANES / 32];
-    __shared__ int s_slot[1024];
+    constexpr int NSLOT = 2048;                               // pixel -> slot hash of the flood fill (pairs of one step: 1024)
+    __shared__ int s_slot[NSLOT];
     __shared__ int s_pcnt[16];
     __shared__ int s_scalar[4];   // [0] n_ext, [1] err, [2] q_tail, [3] scratch
     constexpr int EVAL_MAX = 64;   // nodes evaluated per cooperative phase
@@ -906,7 +907,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     {
         constexpr int FJ = 4;                                      // pairs per thread and step
         unsigned* slot = (unsigned*)s_slot;
-        for (int t = tid; t < 1024; t += NT) slot[t] = 0xffffffffu;
+        for (int t = tid; t < NSLOT; t += NT) slot[t] = 0xffffffffu;
         __syncthreads();
         unsigned epoch = 0;
         const double factor = (double)K.factor;
@@ -959,11 +960,11 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                 const unsigned ek = (0xfffffu - epoch) << 12;           // pair indices are < 4096
                 epoch++;
 #pragma unroll
-                for (int j = 0; j < FJ; j++) if (!done[j]) atomicMin(&slot[cIdx[j] & 1023], ek | (unsigned)pidx[j]);
+                for (int j = 0; j < FJ; j++) if (!done[j]) atomicMin(&slot[cIdx[j] & (NSLOT - 1)], ek | (unsigned)pidx[j]);
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < FJ; j++) {
-                    if (!done[j] && slot[cIdx[j] & 1023] == (ek | (unsigned)pidx[j])) {
+                    if (!done[j] && slot[cIdx[j] & (NSLOT - 1)] == (ek | (unsigned)pidx[j])) {
                         const int trail = member[cIdx[j]];
                         if (!(trail <= -6) && !(trail >= 0 && trail == plid[j])) {
                             if (geo_ok[j]) {
