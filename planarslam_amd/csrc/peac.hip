@@ -915,7 +915,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         while (q_head < q_tail && !err) {
             const int nent = min(FJ * NT / 4, q_tail - q_head);
             bool act[FJ], geo_ok[FJ], done[FJ], push[FJ];
-            int cIdx[FJ], plid[FJ], pidx[FJ];
+            int cIdx[FJ], plid[FJ], pidx[FJ], hsl[FJ];
             float cdist[FJ];
 #pragma unroll
             for (int j = 0; j < FJ; j++) {
@@ -934,6 +934,9 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                     else { act[j] = sy < H - 1; cIdx[j] = ent.x + W; }
                     if (act[j]) { cy = cIdx[j] / W; cx = cIdx[j] - cy * W; }
                 }
+                // slot of the target pixel: x + (W | 1) * y: an odd row stride, so neither a horizontal nor a vertical run of the frontier
+                // folds onto a few slots (with stride W = 640 a vertical run of 256 pixels has 16 distinct slots)
+                hsl[j] = (cIdx[j] + ((W & 1) ? 0 : cy)) & (NSLOT - 1);
                 if (act[j]) {
                     const int by = cy / WIN, bx = cx / WIN;
                     const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
@@ -960,11 +963,11 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                 const unsigned ek = (0xfffffu - epoch) << 12;           // pair indices are < 4096
                 epoch++;
 #pragma unroll
-                for (int j = 0; j < FJ; j++) if (!done[j]) atomicMin(&slot[cIdx[j] & (NSLOT - 1)], ek | (unsigned)pidx[j]);
+                for (int j = 0; j < FJ; j++) if (!done[j]) atomicMin(&slot[hsl[j]], ek | (unsigned)pidx[j]);
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < FJ; j++) {
-                    if (!done[j] && slot[cIdx[j] & (NSLOT - 1)] == (ek | (unsigned)pidx[j])) {
+                    if (!done[j] && slot[hsl[j]] == (ek | (unsigned)pidx[j])) {
                         const int trail = member[cIdx[j]];
                         if (!(trail <= -6) && !(trail >= 0 && trail == plid[j])) {
                             if (geo_ok[j]) {
