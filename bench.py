@@ -298,11 +298,11 @@ def main():
     dom_ms, dom_bytes = cand[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     per_frame = 1961064 + (1843200 + 312160 if full else 0) + (72000 + 118000 + 65130 * 2 * 20 if full else 0)
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01j_pmc_*.csv: separate --pmc FETCH_SIZE and
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01m_pmc_*.csv: separate --pmc FETCH_SIZE and
     # --pmc WRITE_SIZE runs of this same command at B=1024, KB per launch); scaled to this run's batch.  Raw counter sums: the gfx950
     # "FETCH_SIZE reports half of a wide streaming read" correction is NOT applied because these kernels gather narrow records.
     traffic, traffic_note = None, None
-    pmc_csv = os.path.join(ROOT, "profiles", "r01j_pmc_fetch_write_kb_per_launch.csv")
+    pmc_csv = os.path.join(ROOT, "profiles", "r01m_pmc_fetch_write_kb_per_launch.csv")
     pmc_key = {"peac_blocks+peac_segment": "planar::peac::peac_segment", "lsd_detect(+7 small kernels)": "planar::lsd::lsd_detect"}.get(dom, "planar::orb::" + dom)
     if os.path.exists(pmc_csv):
         for line in open(pmc_csv).read().splitlines()[1:]:
