@@ -454,6 +454,24 @@ typedef struct planar_ba_result {
 int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* problem, const planar_pose_params* params, int its1, int its2,
                     planar_ba_result* result, volatile int* stop_flag, planar_comm* comm);
 
+/* ---- Manhattan-frame tracking (replaces Tracking::TrackManhattanFrame, src/Tracking.cc:963-1138, with its helpers
+ *      ProjectSN2Conic :886-953, ProjectSN2MF :757-884 and MeanShift :1140-1157; called once per frame by Tracking::Track, :248) ----
+ * R_last   : [B][9]   row-major 3x3 float, mLastRcm (camera <- Manhattan frame)
+ * normals  : [B][sn_stride][3] float, Frame::vSurfaceNormal[i].normal; n_normals[b] of them are valid
+ * line_dirs: [B][ln_stride][3] double, Frame::mVF3DLines[i].direction; n_lines[b] valid
+ * R_out    : [B][9]   the returned rotation (U * Vt of the updated axes; the input, possibly with one column replaced, if fewer
+ *                     than two directions were found - the reference returns that too)
+ * member   : [B][sn_stride + ln_stride] or NULL: bit a-1 set iff the element was pushed to Frame::vSurfaceNormalx/y/z resp.
+ *            vVanishingLinex/y/z by ProjectSN2MF for axis a (surface normals first, vanishing directions from offset sn_stride)
+ * info     : [B][8] or NULL: numDirectionFound, found mask (bit a-1), numInCone[3], points given to MeanShift per axis [3]
+ * density  : [B][3] or NULL: s_j_density of the axes that were found                                                            */
+int planar_track_manhattan_frame(planar_ctx* ctx, int B, const float* R_last, const float* normals, const int32_t* n_normals, int sn_stride,
+                                 const double* line_dirs, const int32_t* n_lines, int ln_stride, float* R_out, uint8_t* member, int32_t* info,
+                                 float* density);
+int planar_track_manhattan_frame_dev(planar_ctx* ctx, int B, const float* d_R_last, const float* d_normals, const int32_t* d_n_normals, int sn_stride,
+                                     const double* d_line_dirs, const int32_t* d_n_lines, int ln_stride, float* d_R_out, uint8_t* d_member,
+                                     int32_t* d_info, float* d_density);
+
 #ifdef __cplusplus
 }
 #endif

@@ -538,3 +538,44 @@ def guided_local_map(frame, seed=14, n_points=2500, n_lines=300):
         ml["max_dist"][b, :k] = dm * rng.uniform(0.6, 4.0, k); ml["min_dist"][b, :k] = ml["max_dist"][b, :k] / (1.2 ** 7) * rng.uniform(0.8, 1.5, k)
     frame = dict(frame); frame["Tcw"] = Tcw
     return frame, mp, ml
+
+
+def manhattan_scene(B=4, n_normals=8500, n_lines=40, seed=21, tilt_deg=4.0, noise=0.04, clutter=0.25, drop_axis=None):
+    """Surface normals and vanishing directions of a Manhattan world seen from B cameras (Tracking::TrackManhattanFrame input).
+
+    Per frame: a true rotation R_true (camera <- Manhattan frame), `n_normals` unit normals (float32, as PCL's integral-image
+    normals feed `Frame::vSurfaceNormal`) clustered around +-columns of R_true plus `clutter` uniformly random ones, `n_lines`
+    3-D line directions (float64, `FrameLine::direction`), and the previous estimate R_last = R_true perturbed by `tilt_deg`.
+    drop_axis (0..2): that axis gets no support (exercises the two-axes + cross-product branch).  Counts are ragged."""
+    rng = np.random.default_rng(seed)
+
+    def rand_rot(max_deg):
+        v = rng.normal(size=3); v /= np.linalg.norm(v)
+        a = np.deg2rad(rng.uniform(0.3 * max_deg, max_deg))
+        K = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+
+    normals = np.zeros((B, n_normals, 3), np.float32)
+    lines = np.zeros((B, n_lines, 3), np.float64)
+    nn = np.zeros(B, np.int32); nl = np.zeros(B, np.int32)
+    R_true = np.zeros((B, 3, 3), np.float32); R_last = np.zeros((B, 3, 3), np.float32)
+    for b in range(B):
+        Rt = rand_rot(180.0)
+        R_true[b] = Rt.astype(np.float32)
+        R_last[b] = (Rt @ rand_rot(tilt_deg)).astype(np.float32)
+        n = int(n_normals * rng.uniform(0.6, 1.0)) if b else n_normals
+        m = int(n_lines * rng.uniform(0.3, 1.0)) if b else n_lines
+        nn[b], nl[b] = n, m
+        axes = [a for a in range(3) if a != drop_axis]
+        pick = rng.choice(axes, size=n)
+        sign = rng.choice([-1.0, 1.0], size=n)
+        v = Rt[:, pick].T * sign[:, None] + rng.normal(scale=noise, size=(n, 3))
+        rnd = rng.random(n) < clutter
+        v[rnd] = rng.normal(size=(int(rnd.sum()), 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        normals[b, :n] = v.astype(np.float32)
+        pick = rng.choice(axes, size=m)
+        d = Rt[:, pick].T * rng.choice([-1.0, 1.0], size=m)[:, None] + rng.normal(scale=noise * 0.5, size=(m, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        lines[b, :m] = d
+    return dict(normals=normals, n_normals=nn, lines=lines, n_lines=nl, R_last=R_last, R_true=R_true)

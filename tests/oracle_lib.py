@@ -520,3 +520,17 @@ def run_ref_lsd(gray, tie_order=1):
     desc = np.frombuffer(buf, np.uint8, 32 * n, off).reshape(n, 32).copy(); off += 32 * n
     eq = np.frombuffer(buf, "<f8", 3 * n, off).reshape(n, 3).copy()
     return kl, desc, eq
+
+
+def track_manhattan_frame(R_last, normals, lines):
+    """Tracking::TrackManhattanFrame (src/Tracking.cc:963) for one frame -> dict(R, member, info, density)."""
+    L = lib()
+    L.orc_track_manhattan.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    R_last = np.ascontiguousarray(R_last, np.float32)
+    normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    lines = np.ascontiguousarray(lines, np.float64).reshape(-1, 3)
+    n, nl = len(normals), len(lines)
+    R = np.zeros((3, 3), np.float32); member = np.zeros(n + nl, np.uint8); info = np.zeros(8, np.int32); dens = np.zeros(3, np.float32)
+    L.orc_track_manhattan(R_last.ctypes.data, normals.ctypes.data, n, lines.ctypes.data, nl, R.ctypes.data, member.ctypes.data,
+                          info.ctypes.data, dens.ctypes.data)
+    return dict(R=R, member=member, info=info, density=dens)

@@ -1,0 +1,53 @@
+"""GPU parity: planar_track_manhattan_frame vs the oracle restatement of Tracking::TrackManhattanFrame.
+
+Cone membership (threshold tests on float arithmetic that is identical on both sides) must match exactly; the rotation goes through
+exp / asin / tan and a Jacobi SVD whose device and host libm differ in the last bits, so it is compared to 1e-5 (the tolerance the
+task states for SE3 quantities)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from planarslam_amd.synth import manhattan_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(sc, B):
+    from planarslam_amd.manhattan import Tracking
+    out = Tracking().TrackManhattanFrame(sc["R_last"], sc["normals"], sc["n_normals"], sc["lines"], sc["n_lines"])
+    for b in range(B):
+        n, m = int(sc["n_normals"][b]), int(sc["n_lines"][b])
+        want = ol.track_manhattan_frame(sc["R_last"][b], sc["normals"][b, :n], sc["lines"][b, :m])
+        assert np.array_equal(out["info"][b], want["info"]), f"frame {b}: counts"
+        assert np.array_equal(out["member_normals"][b, :n], want["member"][:n]), f"frame {b}: normal membership"
+        assert np.array_equal(out["member_lines"][b, :m], want["member"][n:]), f"frame {b}: line membership"
+        assert not out["member_normals"][b, n:].any() and not out["member_lines"][b, m:].any()
+        assert np.allclose(out["R"][b], want["R"], atol=1e-5, rtol=0), f"frame {b}: rotation {np.abs(out['R'][b] - want['R']).max()}"
+        assert np.allclose(out["density"][b], want["density"], atol=1e-6, rtol=1e-6)
+    return out
+
+
+def test_three_axes_ragged_batch():
+    B = 12
+    _check(manhattan_scene(B=B, seed=31), B)
+
+
+def test_two_axes_branch_and_small_inputs():
+    _check(manhattan_scene(B=4, seed=5, drop_axis=2, clutter=0.0), 4)
+    _check(manhattan_scene(B=4, seed=6, drop_axis=0, clutter=0.1, n_normals=700, n_lines=7), 4)
+    _check(manhattan_scene(B=3, seed=8, drop_axis=1, n_normals=300, n_lines=3), 3)
+
+
+def test_nothing_found_returns_the_input():
+    from planarslam_amd.manhattan import Tracking
+    R_last = np.tile(np.eye(3, dtype=np.float32), (2, 1, 1))
+    out = Tracking().TrackManhattanFrame(R_last, np.zeros((2, 0, 3), np.float32), np.zeros(2, np.int32), np.zeros((2, 0, 3)), np.zeros(2, np.int32))
+    assert (out["info"][:, 0] == 0).all() and np.array_equal(out["R"], R_last)
+
+
+def test_argument_errors():
+    from planarslam_amd._lib import Context, PlanarError, lib
+    ctx = Context(0)
+    with pytest.raises(PlanarError):
+        from planarslam_amd._lib import check
+        check(lib().planar_track_manhattan_frame(ctx.h, 1, None, None, None, 1, None, None, 1, None, None, None, None))
