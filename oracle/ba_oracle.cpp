@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -294,6 +296,7 @@ struct BA {
                 } else { lambda *= ni; ni *= 2; st = backup; }
                 qmax++;
             } while (rho < 0 && qmax < 10);
+            if (std::getenv("ORC_BA_TRACE")) std::fprintf(stderr, "oracle it %d chi2 %.6f lambda %.6f trials %d edges %zu\n", it, currentChi, lambda, qmax, active.size());
             if (qmax == 10 || rho == 0) break;
             if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
             if (nBad >= 3) break;

@@ -106,4 +106,15 @@ int orc_pose_optimize_batch(int B, int max_points, int max_lines, int max_planes
     }
     return 0;
 }
+// n cases x 12 edge classes, same record layout as `ref_opt edges`: err[3], chi2, J[3][6] (22 doubles per class)
+int orc_pose_edges_eval(int n, const float* Tcw, const double* X, const double* obs, const double* lobs, const float* pw, const float* pm,
+                        const orc::PoseParams* prm, double* out) {
+    for (int c = 0; c < n; c++)
+        for (int cls = 0; cls < 12; cls++) {
+            double* o = out + ((size_t)c * 12 + cls) * 22;
+            const bool line = cls == 4 || cls == 5;
+            orc::pose_edge_eval(cls, Tcw + 16 * c, X + 3 * c, (line ? lobs : obs) + 3 * c, pw + 4 * c, pm + 4 * c, *prm, o, o + 3, o + 4);
+        }
+    return 0;
+}
 }

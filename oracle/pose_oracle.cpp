@@ -21,6 +21,8 @@
 #include "geom.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -74,8 +76,16 @@ void compute_error(Edge& e, const SE3& T, const Ctx& c) {
             ominus(local, e.pm, e.err);
             break;
         }
-        case E_PAR: { Plane local = plane_transform(T, e.pw); ominus_par(local, e.pm, e.err); break; }   // EdgeParallelPlane.h:117-122
-        case E_VER: { Plane local = plane_transform(T, e.pw); ominus_ver(local, e.pm, e.err); break; }   // EdgeVerticalPlane.h:118-123
+        case E_PAR: {   // EdgeParallelPlane.h:117-122 / :199-206 (the translation variant exists but Optimizer.cc never instantiates it)
+            Plane local = c.mode == MODE_POSE ? plane_transform(T, e.pw) : plane_translate(T, e.pw);
+            ominus_par(local, e.pm, e.err);
+            break;
+        }
+        case E_VER: {   // EdgeVerticalPlane.h:118-123 / :200-207
+            Plane local = c.mode == MODE_POSE ? plane_transform(T, e.pw) : plane_translate(T, e.pw);
+            ominus_ver(local, e.pm, e.err);
+            break;
+        }
     }
 }
 
@@ -278,6 +288,7 @@ void optimize(Problem& P, int iterations) {
             }
             qmax++;
         } while (rho < 0 && qmax < 10);
+        if (std::getenv("ORC_POSE_TRACE")) std::fprintf(stderr, "oracle it %d chi2 %.6f lambda %.6f trials %d edges %zu\n", it, currentChi, lambda, qmax, P.active.size());
         if (qmax == 10 || rho == 0) break;                       // Terminate
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
         if (nBad >= 3) break;                                    // Terminate
@@ -296,21 +307,49 @@ SE3 to_se3(const float* T) {
 
 }  // namespace
 
+// One pose-only edge at one pose: error, chi2 (identity information) and the Jacobian linearizeOplus() leaves (row-major [3][6]).
+// cls: 0 mono pose, 1 stereo pose, 2 mono translation, 3 stereo translation, 4 line pose, 5 line translation, 6 plane pose,
+// 7 plane translation, 8 parallel pose, 9 parallel translation, 10 vertical pose, 11 vertical translation — the order
+// oracle/ref_opt_main.cpp (mode "edges") dumps the reference's own classes in.
+void pose_edge_eval(int cls, const float* Tcw, const double* X, const double* obs, const float* pw, const float* pm, const PoseParams& prm,
+                    double* err, double* chi2_out, double* J) {
+    static const int type_of[12] = {E_MONO, E_STEREO, E_MONO, E_STEREO, E_LINE, E_LINE, E_PLANE, E_PLANE, E_PAR, E_PAR, E_VER, E_VER};
+    static const int mode_of[12] = {0, 0, 1, 1, 0, 1, 0, 1, 0, 1, 0, 1};
+    static const int dim_of[12] = {2, 3, 2, 3, 3, 3, 3, 3, 2, 2, 2, 2};
+    Ctx c{(double)prm.fx, (double)prm.fy, (double)prm.cx, (double)prm.cy, (double)prm.bf, mode_of[cls]};
+    Edge e;
+    e.type = type_of[cls]; e.dim = dim_of[cls];
+    e.info[0] = e.info[1] = 1; e.info[2] = e.dim == 3 ? 1 : 0;
+    e.X = {X[0], X[1], X[2]};
+    for (int k = 0; k < 3; k++) e.obs[k] = obs[k];
+    e.pw = plane_from_float(pw); e.pm = plane_from_float(pm);
+    const SE3 T = to_se3(Tcw);
+    compute_error(e, T, c);
+    for (int i = 0; i < 3; i++) err[i] = i < e.dim ? e.err[i] : 0.0;
+    *chi2_out = chi2(e);
+    double Jm[3][6];
+    linearize(e, T, c, Jm);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 6; j++) J[i * 6 + j] = i < e.dim ? Jm[i][j] : 0.0;
+}
+
 void pose_optimize(const PoseProblem& p, const PoseParams& prm, int mode, int rounds, int its, PoseResult& out) {
     Problem P;
     P.c = Ctx{(double)prm.fx, (double)prm.fy, (double)prm.cx, (double)prm.cy, (double)prm.bf, mode};
     const float deltaMono = std::sqrt(5.991), deltaStereo = std::sqrt(7.815);   // float, as in the reference (:583-584)
     int nInitial = 0;
-    // float32 rotation for the translation-only variant (:3021); cv::gemm accumulates float products in double
+    // float32 rotation for the translation-only variant (:3021, :3067 `R_cw * Xw`): a 3x3 by 3x1 CV_32F product takes cv::gemm's
+    // small-matrix path (inner length 3 == output height): the three products are summed in float, left to right (the same rule
+    // oracle/shim/cvalgebra.hpp gives the real Optimizer.cc in oracle/_ref/ref_opt).
     float Rcw[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rcw[3 * i + j] = p.Tcw[4 * i + j];
     auto rot_f32 = [&](const float X[3]) {
         V3 r;
         double v[3];
         for (int i = 0; i < 3; i++) {
-            double s = 0;
-            for (int k = 0; k < 3; k++) s += (double)Rcw[3 * i + k] * (double)X[k];
-            v[i] = (double)(float)s;
+            float t = Rcw[3 * i] * X[0];
+            t = t + Rcw[3 * i + 1] * X[1];
+            t = t + Rcw[3 * i + 2] * X[2];
+            v[i] = (double)t;
         }
         r = {v[0], v[1], v[2]};
         return r;

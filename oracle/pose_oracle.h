@@ -44,4 +44,8 @@ enum PoseMode { MODE_POSE = 0, MODE_TRANSLATION = 1 };
 // "one optimize(10) round" shape.
 void pose_optimize(const PoseProblem& p, const PoseParams& prm, int mode, int rounds, int its, PoseResult& out);
 
+// edge-level check against oracle/_ref/ref_opt "edges" (see pose_oracle.cpp)
+void pose_edge_eval(int cls, const float* Tcw, const double* X, const double* obs, const float* pw, const float* pm, const PoseParams& prm,
+                    double* err, double* chi2_out, double* J);
+
 }  // namespace orc

@@ -105,6 +105,15 @@ static inline void transpose(const Mat& src, Mat& dst) {
     dst = d;
 }
 
+// debug prints only (std::cout << mat.t()): the text is never compared
+template <class OS> static inline OS& operator<<(OS& os, const Mat& m) {
+    os << "[";
+    for (int y = 0; y < m.rows; y++) { for (int x = 0; x < m.cols; x++) os << (x ? ", " : "") << m.at<float>(y, x); os << (y + 1 < m.rows ? ";\n " : ""); }
+    os << "]";
+    return os;
+}
+template <class OS> static inline OS& operator<<(OS& os, const MatExpr& e) { return os << e.eval(); }
+
 // (Mat_<float>(r, c) << a, b, ...) as used by the reference
 template <typename T> struct MatCommaInit {
     Mat m; int i = 0;

@@ -154,6 +154,7 @@ public:
         dst.create(rows, cols, type_);
         for (int y = 0; y < rows; y++) std::memmove(dst.data + (size_t)y * dst.step.v, data + (size_t)y * step.v, (size_t)cols * cvElemSize(type_));
     }
+    void copyTo(Mat&& dst) const { Mat d = dst; copyTo(d); }   // destination is a view expression (m.rowRange(..)): same shape, written in place
     template <typename T> T& at(int y, int x) { return *(T*)(data + (size_t)y * step.v + (size_t)x * sizeof(T)); }
     template <typename T> const T& at(int y, int x) const { return *(const T*)(data + (size_t)y * step.v + (size_t)x * sizeof(T)); }
     template <typename T> T& at(int i) { assert(isContinuous()); return ((T*)data)[i]; }
@@ -188,6 +189,12 @@ public:
         return *this;
     }
     static MatOnesExpr ones(int r, int c, int t) { return MatOnesExpr{r, c, t}; }
+    static Mat eye(int r, int c, int t) {   // CV_32F only (what src/Optimizer.cc / Converter.cc build)
+        assert(t == CV_32F);
+        Mat m(r, c, t);
+        for (int y = 0; y < r; y++) for (int x = 0; x < c; x++) m.at<float>(y, x) = (x == y) ? 1.f : 0.f;
+        return m;
+    }
     Mat& operator=(const MatOnesExpr& e) { create(e.rows, e.cols, e.type); return setTo(1); }
     // geometry of the view inside its allocation (for copyMakeBorder without BORDER_ISOLATED)
     int parent_w_ = 0, parent_h_ = 0, off_x_ = 0, off_y_ = 0;

@@ -197,11 +197,14 @@ struct Frame {   // per-workgroup view of one problem
     float Rcw[9];
 };
 
-__device__ __forceinline__ V3 rot_f32(const float* R, float x, float y, float z) {   // cv::Mat float gemm: double accumulate, float store
+// `R_cw * Xw` (src/Optimizer.cc:3067): a 3x3 by 3x1 CV_32F product is cv::gemm's small-matrix case, three float products summed in
+// float from left to right (no contraction: -ffp-contract=off).  Pinned by the reference's own TranslationOptimization (tests/golden/opt_ref.npz).
+__device__ __forceinline__ V3 rot_f32(const float* R, float x, float y, float z) {
     V3 r;
-    r.x = (double)(float)((double)R[0] * (double)x + (double)R[1] * (double)y + (double)R[2] * (double)z);
-    r.y = (double)(float)((double)R[3] * (double)x + (double)R[4] * (double)y + (double)R[5] * (double)z);
-    r.z = (double)(float)((double)R[6] * (double)x + (double)R[7] * (double)y + (double)R[8] * (double)z);
+    float t;
+    t = R[0] * x; t = t + R[1] * y; t = t + R[2] * z; r.x = (double)t;
+    t = R[3] * x; t = t + R[4] * y; t = t + R[5] * z; r.y = (double)t;
+    t = R[6] * x; t = t + R[7] * y; t = t + R[8] * z; r.z = (double)t;
     return r;
 }
 

@@ -194,10 +194,13 @@ BE_MONO, BE_STEREO, BE_LINE, BE_PLANE, BE_VER, BE_PAR = range(6)
 
 
 def ba_problem(seed=99, n_kf=10, n_points=2400, n_lines=500, n_planes=100, n_fixed_extra=2, outlier_frac=0.03, pose_noise=(0.01, 0.03),
-               point_noise=0.02):
+               point_noise=0.02, lines_on_kf=None):
     """Keyframes on a 2 m arc looking at a cloud of points / line segments / planes 2-6 m away.  KF 0 is fixed, plus
     `n_fixed_extra` fixed observers at the end.  Every landmark is seen by 4-10 keyframes.  Returns a dict of numpy arrays
-    (+ 'T_gt' [n_kf,4,4], 'lm_gt' [n_lm,4])."""
+    (+ 'T_gt' [n_kf,4,4], 'lm_gt' [n_lm,4]).
+    lines_on_kf = k reproduces the graph the reference's LocalBundleAdjustment(pKF = k) really builds: every line edge hangs on
+    keyframe k's vertex and measures k's line function (src/Optimizer.cc:2170-2194 use pKF, not the observer pKFi); the observing
+    keyframe of each edge is kept in 'e_obs_kf' (it owns the erase verdict)."""
     rng = np.random.default_rng(seed)
     P = TUM3
     K = n_kf + n_fixed_extra
@@ -215,7 +218,7 @@ def ba_problem(seed=99, n_kf=10, n_points=2400, n_lines=500, n_planes=100, n_fix
         Xc = T[:3, :3] @ X + T[:3, 3]
         return np.array([Xc[0] / Xc[2] * P["fx"] + P["cx"], Xc[1] / Xc[2] * P["fy"] + P["cy"]]), Xc[2]
 
-    lm_type, lm_gt, e_kf, e_lm, e_type, e_meas, e_is2 = [], [], [], [], [], [], []
+    lm_type, lm_gt, e_kf, e_lm, e_type, e_meas, e_is2, e_obs = [], [], [], [], [], [], [], []
 
     def observers():
         n = rng.integers(4, min(10, K) + 1)
@@ -235,19 +238,22 @@ def ba_problem(seed=99, n_kf=10, n_points=2400, n_lines=500, n_planes=100, n_fix
             if rng.random() < outlier_frac:
                 uv = uv + rng.uniform(-40, 40, 2)
             stereo = rng.random() < 0.85
-            e_kf.append(k); e_lm.append(l); e_type.append(BE_STEREO if stereo else BE_MONO)
-            e_meas.append([uv[0], uv[1], (uv[0] - P["bf"] / z + rng.normal() * 0.5 * s) if stereo else -1, 0]); e_is2.append(1.0 / np.float32(s) ** 2)
+            ur = (uv[0] - P["bf"] / z + rng.normal() * 0.5 * s) if stereo else -1
+            stereo = stereo and ur >= 0          # the reference reads the edge class off mvuRight < 0 (src/Optimizer.cc:2063)
+            e_kf.append(k); e_obs.append(k); e_lm.append(l); e_type.append(BE_STEREO if stereo else BE_MONO)
+            e_meas.append([uv[0], uv[1], ur if stereo else -1, 0]); e_is2.append(1.0 / np.float32(s) ** 2)
     for _ in range(n_lines):
         A = sample_point(); Bp = A + rng.normal(size=3) * 0.4
         la = len(lm_gt); lm_type += [0, 0]; lm_gt += [np.append(A, 0), np.append(Bp, 0)]
         for k in observers():
-            (pa, za), (pb, zb) = proj(T_gt[k], A), proj(T_gt[k], Bp)
+            kk = k if lines_on_kf is None else lines_on_kf     # the vertex the edge hangs on (and whose view is measured)
+            (pa, za), (pb, zb) = proj(T_gt[kk], A), proj(T_gt[kk], Bp)
             if min(za, zb) < 0.3:
                 continue
             pa = pa + rng.normal(size=2) * 0.7; pb = pb + rng.normal(size=2) * 0.7
             ln = np.cross(np.append(pa, 1), np.append(pb, 1)); ln /= np.linalg.norm(ln)
             for lmi in (la, la + 1):          # start edge then end edge, consecutive (the reference pairs them)
-                e_kf.append(k); e_lm.append(lmi); e_type.append(BE_LINE); e_meas.append([ln[0], ln[1], ln[2], 0]); e_is2.append(1.0)
+                e_kf.append(kk); e_obs.append(k); e_lm.append(lmi); e_type.append(BE_LINE); e_meas.append([ln[0], ln[1], ln[2], 0]); e_is2.append(1.0)
     for _ in range(n_planes):
         n = rng.normal(size=3); n /= np.linalg.norm(n); d = rng.uniform(1.0, 4.0)
         l = len(lm_gt); lm_type.append(1); lm_gt.append(np.append(n, d))
@@ -256,13 +262,13 @@ def ba_problem(seed=99, n_kf=10, n_points=2400, n_lines=500, n_planes=100, n_fix
             nc = R @ n; dc = d - t @ nc
             a = rng.normal(size=3); a -= a.dot(nc) * nc; a /= np.linalg.norm(a)
             nm = nc * np.cos(0.004) + a * np.sin(0.004) * rng.normal(); nm /= np.linalg.norm(nm)
-            e_kf.append(k); e_lm.append(l); e_type.append(BE_PLANE); e_meas.append([*nm, dc + rng.normal() * 0.004]); e_is2.append(1.0)
+            e_kf.append(k); e_obs.append(k); e_lm.append(l); e_type.append(BE_PLANE); e_meas.append([*nm, dc + rng.normal() * 0.004]); e_is2.append(1.0)
             if rng.random() < 0.3:      # an extra parallel / vertical association of the same map plane from this keyframe
                 if rng.random() < 0.5:
-                    e_kf.append(k); e_lm.append(l); e_type.append(BE_PAR); e_meas.append([*nm, dc + rng.uniform(0.3, 1.0)]); e_is2.append(1.0)
+                    e_kf.append(k); e_obs.append(k); e_lm.append(l); e_type.append(BE_PAR); e_meas.append([*nm, dc + rng.uniform(0.3, 1.0)]); e_is2.append(1.0)
                 else:
                     v = np.cross(nm, a); v /= np.linalg.norm(v)
-                    e_kf.append(k); e_lm.append(l); e_type.append(BE_VER); e_meas.append([*v, rng.uniform(0.5, 2.0)]); e_is2.append(1.0)
+                    e_kf.append(k); e_obs.append(k); e_lm.append(l); e_type.append(BE_VER); e_meas.append([*v, rng.uniform(0.5, 2.0)]); e_is2.append(1.0)
     lm_gt = np.array(lm_gt)
     lm_init = lm_gt.copy()
     pts = np.array(lm_type) == 0
@@ -274,7 +280,7 @@ def ba_problem(seed=99, n_kf=10, n_points=2400, n_lines=500, n_planes=100, n_fix
             kf_T[k, :3, :3] = _rodrigues(rng.normal(size=3) * pose_noise[0]) @ T_gt[k, :3, :3]
             kf_T[k, :3, 3] += rng.normal(size=3) * pose_noise[1]
     return dict(kf_Tcw=kf_T.astype(np.float32).reshape(K, 16), kf_fixed=fixed, lm_type=np.array(lm_type, np.uint8), lm_init=np.ascontiguousarray(lm_init),
-                e_kf=np.array(e_kf, np.int32), e_lm=np.array(e_lm, np.int32), e_type=np.array(e_type, np.uint8),
+                e_kf=np.array(e_kf, np.int32), e_obs_kf=np.array(e_obs, np.int32), e_lm=np.array(e_lm, np.int32), e_type=np.array(e_type, np.uint8),
                 e_meas=np.array(e_meas, np.float64), e_inv_sigma2=np.array(e_is2, np.float32), T_gt=T_gt, lm_gt=lm_gt)
 
 
@@ -579,3 +585,21 @@ def manhattan_scene(B=4, n_normals=8500, n_lines=40, seed=21, tilt_deg=4.0, nois
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         lines[b, :m] = d
     return dict(normals=normals, n_normals=nn, lines=lines, n_lines=nl, R_last=R_last, R_true=R_true)
+
+
+def ba_local_only(prob):
+    """Drop the edges of landmarks no optimised (non-fixed) keyframe observes: Optimizer::LocalBundleAdjustment collects its landmarks
+    from the local keyframes' matches (src/Optimizer.cc:1869-1921), so such landmarks never enter the reference's graph."""
+    fixed = np.asarray(prob["kf_fixed"]).astype(bool)
+    seen = np.zeros(len(prob["lm_type"]), bool)
+    np.logical_or.at(seen, prob["e_lm"], ~fixed[prob["e_obs_kf"]])
+    # the two end points of a line are one map object
+    is_line = np.zeros(len(seen), bool); is_line[prob["e_lm"][prob["e_type"] == BE_LINE]] = True
+    idx = np.nonzero(is_line)[0]
+    for a, b in zip(idx[0::2], idx[1::2]):
+        seen[a] = seen[b] = seen[a] or seen[b]
+    keep = seen[prob["e_lm"]]
+    out = dict(prob)
+    for k in ("e_kf", "e_obs_kf", "e_lm", "e_type", "e_meas", "e_inv_sigma2"):
+        out[k] = np.ascontiguousarray(prob[k][keep])
+    return out

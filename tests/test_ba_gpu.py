@@ -49,3 +49,26 @@ def test_ba_rejects_bad_input():
     pr["e_lm"] = pr["e_lm"].copy(); pr["e_lm"][0] = 10 ** 6
     with pytest.raises(PlanarError):
         local_bundle_adjustment(pr, TUM3)
+
+
+# ---- against the REAL reference (tests/golden/opt_ref.npz = Optimizer::LocalBundleAdjustment built as oracle/_ref/ref_opt) ----
+import os
+
+import opt_cases as cases
+from test_oracle_opt_ref import check_ba, golden_ba
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "opt_ref.npz"))
+
+
+@pytest.mark.parametrize("name", list(cases.BA_CASES))
+def test_ba_hip_equals_reference_fixture(golden, name):
+    """HIP local BA vs the keyframe poses, landmarks and erase lists the reference's own LocalBundleAdjustment left behind
+    (graphs as that function builds them: line edges on the current keyframe, only landmarks a local keyframe sees)."""
+    from planarslam_amd import local_bundle_adjustment
+    build, cur = cases.BA_CASES[name]
+    pr = build()
+    got = local_bundle_adjustment(pr, TUM3)
+    check_ba(golden_ba(golden, name, pr), got, pr)

@@ -67,3 +67,32 @@ def test_pose_too_few_correspondences_returns_zero():
 
 def test_pose_only_points():
     _compare(pose_batch(B=3, n_lines=0, n_planes=0, seed=9, max_lines=4, max_planes=2), 0)
+
+
+# ---- against the REAL reference (tests/golden/opt_ref.npz = outputs of src/Optimizer.cc + vendored g2o built as oracle/_ref/ref_opt) ----
+import os
+
+import opt_cases as cases
+from test_oracle_opt_ref import golden_pose
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "opt_ref.npz"))
+
+
+@pytest.mark.parametrize("name", list(cases.POSE_CASES))
+def test_pose_hip_equals_reference_fixture(golden, name):
+    """HIP PoseOptimization / TranslationOptimization vs what the reference's own functions returned on the same frames:
+    1e-5 on the pose, identical outlier flags and return values.  c4_b256 is BASELINE config 4 at its batch size."""
+    from planarslam_amd import Optimizer
+    build, modes = cases.POSE_CASES[name]
+    b = build()
+    opt = Optimizer(TUM3)
+    for mode in modes:
+        got = (opt.PoseOptimization if mode == 0 else opt.TranslationOptimization)(b, 4, 10)
+        want = golden_pose(golden, name, mode, b)
+        assert np.abs(got["Tcw"] - want["Tcw"]).max() <= POSE_TOL
+        assert np.array_equal(got["n_inliers"], want["n_inliers"])
+        for k in ("pt_outlier", "ln_outlier", "pl_outlier"):
+            assert np.array_equal(got[k], want[k]), k
