@@ -323,3 +323,68 @@ void sobel3_s16(const uint8_t* src, int w, int h, int sstep, int dx, int dy, int
     }
 }
 }  // namespace orc
+
+namespace orc {
+void jacobi_svd3_f32(float At[3][3], float W_[3], float Vt[3][3]) {
+    const float eps = 1.1920929e-07f * 2;
+    const double minval = 1.17549435e-38;
+    double W[3];
+    for (int i = 0; i < 3; i++) {
+        double sd = 0;
+        for (int k = 0; k < 3; k++) { const float t = At[i][k]; sd += (double)t * t; }
+        W[i] = sd;
+        for (int k = 0; k < 3; k++) Vt[i][k] = 0;
+        Vt[i][i] = 1;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        for (int i = 0; i < 2; i++)
+            for (int j = i + 1; j < 3; j++) {
+                float* Ai = At[i]; float* Aj = At[j];
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < 3; k++) p += (double)Ai[k] * Aj[k];
+                if (std::abs(p) <= eps * std::sqrt((double)a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = hypot((double)p, beta);
+                float c, s;
+                if (beta < 0) { const double delta = (gamma - beta) * 0.5; s = (float)std::sqrt(delta / gamma); c = (float)(p / (gamma * s * 2)); }
+                else { c = (float)std::sqrt((gamma + beta) / (gamma * 2)); s = (float)(p / (gamma * c * 2)); }
+                a = b = 0;
+                for (int k = 0; k < 3; k++) {
+                    const float t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += (double)t0 * t0; b += (double)t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+                float* Vi = Vt[i]; float* Vj = Vt[j];
+                for (int k = 0; k < 3; k++) { const float t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k]; Vi[k] = t0; Vj[k] = t1; }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < 3; i++) {
+        double sd = 0;
+        for (int k = 0; k < 3; k++) { const float t = At[i][k]; sd += (double)t * t; }
+        W[i] = std::sqrt(sd);
+    }
+    for (int i = 0; i < 2; i++) {
+        int j = i;
+        for (int k = i + 1; k < 3; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            std::swap(W[i], W[j]);
+            for (int k = 0; k < 3; k++) { std::swap(At[i][k], At[j][k]); std::swap(Vt[i][k], Vt[j][k]); }
+        }
+    }
+    for (int i = 0; i < 3; i++) W_[i] = (float)W[i];
+    for (int i = 0; i < 3; i++) {   // normalise the left singular vectors (zero singular values do not occur for a near-rotation)
+        const double sd = W[i];
+        const float s = (float)(sd > minval ? 1 / sd : 0.);
+        for (int k = 0; k < 3; k++) At[i][k] *= s;
+    }
+}
+
+double det3_f32(const float m[3][3]) {
+    return m[0][0] * ((double)m[1][1] * m[2][2] - (double)m[1][2] * m[2][1]) - m[0][1] * ((double)m[1][0] * m[2][2] - (double)m[1][2] * m[2][0]) +
+           m[0][2] * ((double)m[1][0] * m[2][1] - (double)m[1][1] * m[2][0]);
+}
+}  // namespace orc

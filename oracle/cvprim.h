@@ -62,3 +62,11 @@ void resize_linear_exact_u8(const uint8_t* src, int sw, int sh, int sstep, doubl
 // cv::Sobel(src, dst, CV_16S, dx, dy, 3) with BORDER_REFLECT_101 (dx,dy) in {(1,0),(0,1)}
 void sobel3_s16(const uint8_t* src, int w, int h, int sstep, int dx, int dy, int16_t* dst);
 }  // namespace orc
+
+namespace orc {
+// JacobiSVDImpl_<float>(At, W, Vt, m = n = n1 = 3, minval = FLT_MIN, eps = 2 FLT_EPSILON) (modules/core/src/lapack.cpp): one-sided Jacobi on
+// the rows of At (= columns of A); on return the rows of At are the left singular vectors, W descending, Vt the right ones.
+void jacobi_svd3_f32(float At[3][3], float W[3], float Vt[3][3]);
+// cv::determinant of a 3x3 CV_32F matrix: the det3 macro of lapack.cpp (inner 2x2 products in double, result double)
+double det3_f32(const float m[3][3]);
+}  // namespace orc

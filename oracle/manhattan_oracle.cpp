@@ -7,97 +7,40 @@
 //   TrackManhattanFrame  src/Tracking.cc:963-1138  three axes in turn (the matrix is updated IN PLACE: `cv::Mat R_cm = R_cm_update`
 //                                                   shares the buffer, so axis 2 / 3 see the columns axis 1 / 2 wrote), completion
 //                                                   of a missing axis by a cross product, SVD re-orthogonalisation R = U * Vt
-// OpenCV pieces restated from the library (3.4.x): Mat::cross / determinant 3x3 in float, cv::norm (double accumulation),
-// JacobiSVDImpl_<float> (modules/core/src/lapack.cpp), 3x3 * 3x3 gemm with double accumulation.
-// PARITY UNPINNED: src/Tracking.cc cannot be compiled here (it pulls in the whole System / viewer stack and real OpenCV).
+// OpenCV pieces restated from the library (3.4.x): Mat::cross in float, cv::determinant (double inner products), cv::sum / cv::norm (double
+// accumulation), JacobiSVDImpl_<float> (modules/core/src/lapack.cpp, shared through oracle/cvprim.cpp), plain small CV_32F products summed in float.
+// PINNED against the reference's own function bodies: src/Tracking.cc:763-1157 is extracted at build time and compiled against the cv::Mat
+// stand-in into oracle/_ref/ref_frame (recipe: oracle/Makefile); tests/test_oracle_frame_ref.py compares rotation (bit-exact) and cone
+// membership.  What stays unpinned are the OpenCV primitives named above.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
 #include <algorithm>
 
+#include "cvprim.h"
+
 namespace {
 
 struct M3 { float m[3][3]; };
-
-// JacobiSVDImpl_<float>(At, W, Vt, m = n = n1 = 3, minval = FLT_MIN, eps = 2 * FLT_EPSILON); At holds A^T (rows = columns of A)
-void jacobi_svd3(float At[3][3], float W_[3], float Vt[3][3]) {
-    const float eps = 1.1920929e-07f * 2;
-    const double minval = 1.17549435e-38;
-    double W[3];
-    for (int i = 0; i < 3; i++) {
-        double sd = 0;
-        for (int k = 0; k < 3; k++) { const float t = At[i][k]; sd += (double)t * t; }
-        W[i] = sd;
-        for (int k = 0; k < 3; k++) Vt[i][k] = 0;
-        Vt[i][i] = 1;
-    }
-    for (int iter = 0; iter < 30; iter++) {
-        bool changed = false;
-        for (int i = 0; i < 2; i++)
-            for (int j = i + 1; j < 3; j++) {
-                float* Ai = At[i]; float* Aj = At[j];
-                double a = W[i], p = 0, b = W[j];
-                for (int k = 0; k < 3; k++) p += (double)Ai[k] * Aj[k];
-                if (std::abs(p) <= eps * std::sqrt((double)a * b)) continue;
-                p *= 2;
-                const double beta = a - b, gamma = hypot((double)p, beta);
-                float c, s;
-                if (beta < 0) { const double delta = (gamma - beta) * 0.5; s = (float)std::sqrt(delta / gamma); c = (float)(p / (gamma * s * 2)); }
-                else { c = (float)std::sqrt((gamma + beta) / (gamma * 2)); s = (float)(p / (gamma * c * 2)); }
-                a = b = 0;
-                for (int k = 0; k < 3; k++) {
-                    const float t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k];
-                    Ai[k] = t0; Aj[k] = t1;
-                    a += (double)t0 * t0; b += (double)t1 * t1;
-                }
-                W[i] = a; W[j] = b;
-                changed = true;
-                float* Vi = Vt[i]; float* Vj = Vt[j];
-                for (int k = 0; k < 3; k++) { const float t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k]; Vi[k] = t0; Vj[k] = t1; }
-            }
-        if (!changed) break;
-    }
-    for (int i = 0; i < 3; i++) {
-        double sd = 0;
-        for (int k = 0; k < 3; k++) { const float t = At[i][k]; sd += (double)t * t; }
-        W[i] = std::sqrt(sd);
-    }
-    for (int i = 0; i < 2; i++) {
-        int j = i;
-        for (int k = i + 1; k < 3; k++) if (W[j] < W[k]) j = k;
-        if (i != j) {
-            std::swap(W[i], W[j]);
-            for (int k = 0; k < 3; k++) { std::swap(At[i][k], At[j][k]); std::swap(Vt[i][k], Vt[j][k]); }
-        }
-    }
-    for (int i = 0; i < 3; i++) W_[i] = (float)W[i];
-    for (int i = 0; i < 3; i++) {   // normalise the left singular vectors (zero singular values do not occur for a near-rotation)
-        const double sd = W[i];
-        const float s = (float)(sd > minval ? 1 / sd : 0.);
-        for (int k = 0; k < 3; k++) At[i][k] *= s;
-    }
-}
 
 // SVD::compute(R, W, U, Vt) for a 3x3 CV_32F matrix followed by R = U * Vt
 void svd_orthogonalise(M3& R) {
     float At[3][3], W[3], Vt[3][3];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[i][j] = R.m[j][i];      // transpose(src, temp_a)
-    jacobi_svd3(At, W, Vt);
-    // u = temp_a^T: U(r, c) = At[c][r]; result(r, c) = sum_k U(r, k) * Vt[k][c] (gemm, double accumulation, rounded to float)
+    orc::jacobi_svd3_f32(At, W, Vt);
+    // u = temp_a^T: U(r, c) = At[c][r]; result(r, c) = sum_k U(r, k) * Vt[k][c]: a plain 3x3 by 3x3 CV_32F product is cv::gemm's small-matrix
+    // case (inner length 3 == output width): float products summed in float, left to right
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) {
-            double s = 0;
-            for (int k = 0; k < 3; k++) s += (double)At[k][r] * (double)Vt[k][c];
-            R.m[r][c] = (float)s;
+            float t = At[0][r] * Vt[0][c];
+            t = t + At[1][r] * Vt[1][c];
+            t = t + At[2][r] * Vt[2][c];
+            R.m[r][c] = t;
         }
 }
 
-float det3(const M3& A) {
-    const float (*m)[3] = A.m;
-    return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
-           m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
-}
+double det3(const M3& A) { return orc::det3_f32(A.m); }   // cv::determinant: double inner products (cvprim.cpp)
 
 inline void axis_cols(int a, int& c1, int& c2, int& c3) { c1 = (a + 3) % 3; c2 = (a + 4) % 3; c3 = (a + 5) % 3; }
 
@@ -175,14 +118,18 @@ int orc_track_manhattan(const float* R_last, const float* normals, int n, const 
             const float alfa = (float)std::sqrt(sx * sx + sy * sy);
             const float ma_x = (float)(std::tan(alfa) / alfa * sx), ma_y = (float)(std::tan(alfa) / alfa * sy);   // tan(float) / float * double
             float col[3];
-            for (int r = 0; r < 3; r++)                        // R_mc * [ma_x, ma_y, 1]^T (gemm, double accumulation)
-                col[r] = (float)((double)R.m[r][c1] * (double)ma_x + (double)R.m[r][c2] * (double)ma_y + (double)R.m[r][c3] * 1.0);
+            for (int r = 0; r < 3; r++) {                      // rtemp * temp1 (:877-878): 3x3 by 3x1, cv::gemm's small-matrix case, float sums
+                float t = R.m[r][c1] * ma_x;
+                t = t + R.m[r][c2] * ma_y;
+                t = t + R.m[r][c3] * 1.0f;
+                col[r] = t;
+            }
             double nn = 0;
             for (int r = 0; r < 3; r++) nn += (double)col[r] * col[r];
             nn = std::sqrt(nn);
             const float inv = (float)(1.0 / nn);               // Mat / double -> scale by 1/s, float multiply
             for (int r = 0; r < 3; r++) col[r] = col[r] * inv;
-            if (col[0] + col[1] + col[2] != 0) {               // sum(R_cm_Rec)[0] != 0
+            if ((double)col[0] + (double)col[1] + (double)col[2] != 0) {   // sum(R_cm_Rec)[0] != 0 (cv::sum accumulates in double)
                 nfound++; found_mask |= 1 << (a - 1);
                 for (int r = 0; r < 3; r++) R.m[r][a - 1] = col[r];
                 dens[a - 1] = s_j_density;
@@ -195,7 +142,7 @@ int orc_track_manhattan(const float* R_last, const float* normals, int n, const 
                 const float a0 = R.m[0][ca], a1 = R.m[1][ca], a2 = R.m[2][ca], b0 = R.m[0][cb], b1 = R.m[1][cb], b2 = R.m[2][cb];
                 const float v0 = a1 * b2 - a2 * b1, v1 = a2 * b0 - a0 * b2, v2 = a0 * b1 - a1 * b0;
                 R.m[0][cdst] = v0; R.m[1][cdst] = v1; R.m[2][cdst] = v2;
-                if (std::abs((double)det3(R) + 1) < 0.5) { R.m[0][cdst] = -v0; R.m[1][cdst] = -v1; R.m[2][cdst] = -v2; }
+                if (std::abs(det3(R) + 1) < 0.5) { R.m[0][cdst] = -v0; R.m[1][cdst] = -v1; R.m[2][cdst] = -v2; }
             };
             if ((found_mask & 3) == 3) cross_into(0, 1, 2);            // v3 = v1 x v2
             else if ((found_mask & 6) == 6) cross_into(2, 1, 0);       // v1 = v3 x v2

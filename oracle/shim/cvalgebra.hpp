@@ -4,7 +4,8 @@
 //   * A*B [+ C] is one lazy cv::gemm.  For CV_32F with no transpose flag and inner length 2..4 equal to the output's width or
 //     height it takes the small-matrix path: products summed in float, left to right, then (float)(t*alpha + c*beta) in
 //     double.  Otherwise (e.g. -A.t()*B) GEMMSingleMul<float,double>: products accumulated in double, (float)(s*alpha + c*beta).
-//   * alpha*A, A/s, -A, A.t(): elementwise (float)(a*alpha) with alpha in double.
+//   * alpha*A, A/s, -A: convertTo with a scale = cvtScale32f, the scale cast to float and multiplied in float; alpha*A + beta*C without a
+//     product: addWeighted in float.
 //   * A+B, A-B: float.   norm(), dot(): double accumulation.
 //   * BFMatcher(NORM_HAMMING).match: smallest distance, lowest train index on ties.
 #pragma once
@@ -23,9 +24,12 @@ struct MatExpr {
         const int ar = tr ? a.cols : a.rows, ac = tr ? a.rows : a.cols;
         auto A = [&](int i, int k) -> float { return tr ? a.at<float>(k, i) : a.at<float>(i, k); };
         if (!has_b) {
+            // alpha*A: convertTo(CV_32F, alpha) = cvtScale32f, scale cast to float, float multiply.  alpha*A + beta*C: addWeighted on
+            // CV_32F, weights cast to float, a*alpha + c*beta in float.
             Mat d(ar, ac, CV_32F);
+            const float fa = (float)alpha, fb = (float)beta;
             for (int i = 0; i < ar; i++)
-                for (int j = 0; j < ac; j++) d.at<float>(i, j) = (float)((double)A(i, j) * alpha + (has_c ? (double)c.at<float>(i, j) * beta : 0.0));
+                for (int j = 0; j < ac; j++) d.at<float>(i, j) = has_c ? (A(i, j) * fa + c.at<float>(i, j) * fb) : (A(i, j) * fa);
             return d;
         }
         assert(ac == b.rows);
@@ -99,6 +103,45 @@ static inline double norm(const Mat& m) {
     return std::sqrt(s);
 }
 static inline double norm(const MatExpr& e) { return norm(e.eval()); }
+// Mat::cross for two CV_32F 3-vectors: float products and differences
+inline Mat Mat::cross(const Mat& m) const {
+    Mat d(rows, cols, CV_32F);
+    const float a0 = at<float>(0), a1 = at<float>(1), a2 = at<float>(2), b0 = m.at<float>(0), b1 = m.at<float>(1), b2 = m.at<float>(2);
+    d.at<float>(0) = a1 * b2 - a2 * b1; d.at<float>(1) = a2 * b0 - a0 * b2; d.at<float>(2) = a0 * b1 - a1 * b0;
+    return d;
+}
+// cv::sum / cv::trace: double accumulation, element order
+static inline Scalar sum(const Mat& m) {
+    double s = 0;
+    for (int y = 0; y < m.rows; y++) for (int x = 0; x < m.cols; x++) s += (double)m.at<float>(y, x);
+    return Scalar(s);
+}
+static inline Scalar sum(const MatExpr& e) { return sum(e.eval()); }
+static inline Scalar trace(const Mat& m) {
+    double s = 0;
+    for (int i = 0; i < std::min(m.rows, m.cols); i++) s += (double)m.at<float>(i, i);
+    return Scalar(s);
+}
+static inline Scalar trace(const MatExpr& e) { return trace(e.eval()); }
+static inline double determinant(const Mat& m) {
+    assert(m.rows == 3 && m.cols == 3 && m.type() == CV_32F);
+    float a[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = m.at<float>(i, j);
+    return orc::det3_f32(a);
+}
+// cv::SVD::compute(src, w, u, vt) for a 3x3 CV_32F matrix: transpose, JacobiSVDImpl_<float>, u = transposed rows, vt as computed
+class SVD {
+public:
+    SVD() {}
+    static void compute(const Mat& src, Mat& w, Mat& u, Mat& vt, int = 0) {
+        assert(src.rows == 3 && src.cols == 3 && src.type() == CV_32F);
+        float At[3][3], W[3], Vt[3][3];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[i][j] = src.at<float>(j, i);
+        orc::jacobi_svd3_f32(At, W, Vt);
+        w.create(3, 1, CV_32F); u.create(3, 3, CV_32F); vt.create(3, 3, CV_32F);
+        for (int i = 0; i < 3; i++) { w.at<float>(i) = W[i]; for (int j = 0; j < 3; j++) { u.at<float>(i, j) = At[j][i]; vt.at<float>(i, j) = Vt[i][j]; } }
+    }
+};
 static inline void transpose(const Mat& src, Mat& dst) {
     Mat d(src.cols, src.rows, CV_32F);
     for (int y = 0; y < src.rows; y++) for (int x = 0; x < src.cols; x++) d.at<float>(x, y) = src.at<float>(y, x);

@@ -54,6 +54,8 @@ template <typename T> static inline Point_<T>& operator*=(Point_<T>& a, float b)
     a.x = (T)(a.x * b); a.y = (T)(a.y * b); return a;
 }
 template <typename T> static inline bool operator==(const Point_<T>& a, const Point_<T>& b) { return a.x == b.x && a.y == b.y; }
+template <typename T> static inline Point_<T> operator/(const Point_<T>& a, double b) { return Point_<T>((T)(a.x / b), (T)(a.y / b)); }
+template <typename T> static inline double norm(const Point_<T>& p) { return std::sqrt((double)p.x * p.x + (double)p.y * p.y); }
 
 template <typename T> struct Point3_ { T x, y, z; Point3_() : x(0), y(0), z(0) {} Point3_(T a, T b, T c) : x(a), y(b), z(c) {} };
 typedef Point3_<float> Point3f;
@@ -74,7 +76,8 @@ struct Size { int width, height; Size() : width(0), height(0) {} Size(int w, int
               int area() const { return width * height; } };
 struct Rect { int x, y, width, height; Rect() : x(0), y(0), width(0), height(0) {}
               Rect(int _x, int _y, int w, int h) : x(_x), y(_y), width(w), height(h) {} };
-struct Scalar { double v[4]; Scalar(double a = 0, double b = 0, double c = 0, double d = 0) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; } };
+struct Scalar { double v[4]; Scalar(double a = 0, double b = 0, double c = 0, double d = 0) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; }
+                double operator[](int i) const { return v[i]; } };
 
 struct KeyPoint {
     Point2f pt; float size, angle, response; int octave, class_id;
@@ -143,6 +146,7 @@ public:
     Mat col(int x) const { return colRange(x, x + 1); }
     inline MatExpr t() const;                 // cvalgebra.hpp
     inline double dot(const Mat& m) const;    // cvalgebra.hpp
+    inline Mat cross(const Mat& m) const;     // cvalgebra.hpp
     inline Mat(const MatExpr& e);             // cvalgebra.hpp
     inline Mat& operator=(const MatExpr& e);  // cvalgebra.hpp
     Mat clone() const {
@@ -164,6 +168,7 @@ public:
     template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step.v); }
     template <typename T> const T* ptr(int y = 0) const { return (const T*)(data + (size_t)y * step.v); }
     static MatZerosExpr zeros(int r, int c, int t) { return MatZerosExpr{r, c, t}; }
+    static MatZerosExpr zeros(Size s, int t) { return MatZerosExpr{s.height, s.width, t}; }
     // cv::Mat::operator=(const MatExpr&) for zeros: create() (a no-op when shape/type match, so a
     // view stays a view) followed by setTo(0).
     Mat& operator=(const MatZerosExpr& e) {

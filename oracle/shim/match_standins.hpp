@@ -3,8 +3,11 @@
 // (src/ORBmatcher.cc, src/PlaneMatcher.cpp) compile where they lie and run in oracle/_ref/ref_match.  Force-included
 // (-include) with the real headers' include guards pre-defined, so include/ORBmatcher.h and include/PlaneMatcher.h are
 // the reference's own.  Only members those two files touch exist; methods return what the harness stored.
-// Frame::GetFeaturesInArea / PosInGrid / ComputePlaneWorldCoeff live in src/Frame.cc, which cannot be built here (PCL,
-// threads, the extractors): they are restated below from src/Frame.cc:440-489, 526-535, 815-820.
+// Frame::AssignFeaturesToGrid / lineDescriptorMAD / GetFeaturesInArea / GetLinesInArea / PosInGrid / ComputePlaneWorldCoeff live in
+// src/Frame.cc, which cannot be built as a whole here (PCL, threads, the extractors).  With -DSTANDINS_REAL_FRAME_FUNCS (how
+// oracle/Makefile builds ref_match) they are only DECLARED here and their bodies are the reference's own: lines 155-168, 269-293,
+// 440-535, 815-820 of src/Frame.cc extracted at build time into oracle/_ref/gen/frame_extract_match.cpp.  Without the macro the
+// restated bodies below are used.  KeyFrame's copies (src/KeyFrame.cc, same text) stay restated.
 #pragma once
 #define MAPPOINT_H
 #define KEYFRAME_H
@@ -163,15 +166,28 @@ public:
     cv::Mat mLdesc;
     std::vector<MapLine*> mvpMapLines;
     std::vector<bool> mvbLineOutlier;
+#ifdef STANDINS_REAL_FRAME_FUNCS
+    vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r, const int minLevel = -1,
+                                  const int maxLevel = -1) const;
+    void lineDescriptorMAD(vector<vector<cv::DMatch>> line_matches, double& nn_mad, double& nn12_mad) const;
+#else
     vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r, const int minLevel = -1,
                                   const int maxLevel = -1) const { return lines_in_area(mvKeylinesUn, x1, y1, x2, y2, r, minLevel, maxLevel); }
     void lineDescriptorMAD(vector<vector<cv::DMatch>> m, double& a, double& b) const { line_descriptor_mad(m, a, b); }
+#endif
     // planes
     std::vector<cv::Mat> mvPlaneCoefficients;
     std::vector<MapPlane*> mvpMapPlanes, mvpParallelPlanes, mvpVerticalPlanes;
     int mnPlaneNum = 0;
     bool mbNewPlane = false;
 
+    cv::Mat mOw;   // read (unused result) by ComputePlaneWorldCoeff
+#ifdef STANDINS_REAL_FRAME_FUNCS
+    bool PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY);
+    void AssignFeaturesToGrid();
+    vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel = -1, const int maxLevel = -1) const;
+    cv::Mat ComputePlaneWorldCoeff(const int& idx);
+#else
     // restated: src/Frame.cc:526-535, 155-166
     bool PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY) {
         posX = round((kp.pt.x - mnMinX) * mfGridElementWidthInv);
@@ -219,6 +235,7 @@ public:
         cv::transpose(mTcw, temp);
         return temp * mvPlaneCoefficients[idx];
     }
+#endif
 };
 
 class KeyFrame {

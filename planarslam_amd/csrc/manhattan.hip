@@ -40,11 +40,14 @@ __device__ __forceinline__ void rotate_ln(const float* R, int c1, int c2, int c3
     z = (float)((double)R[c3] * vx + (double)R[3 + c3] * vy + (double)R[6 + c3] * vz);
 }
 
-__device__ float det3(const float* m) {
-    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+// cv::determinant of a 3x3 CV_32F matrix (lapack.cpp det3): the inner 2x2 products in double, result double
+__device__ double det3(const float* m) {
+    return m[0] * ((double)m[4] * m[8] - (double)m[5] * m[7]) - m[1] * ((double)m[3] * m[8] - (double)m[5] * m[6]) +
+           m[2] * ((double)m[3] * m[7] - (double)m[4] * m[6]);
 }
 
-// OpenCV JacobiSVDImpl_<float> for m = n = 3 (At = A^T), then R = U * Vt with double accumulation
+// OpenCV JacobiSVDImpl_<float> for m = n = 3 (At = A^T), then R = U * Vt: a plain 3x3 by 3x3 CV_32F product is cv::gemm's small-matrix case,
+// float products summed in float from left to right (pinned by the reference's own TrackManhattanFrame, tests/golden/frame_ref.npz)
 __device__ void svd_orthogonalise(float* R) {
     float At[3][3], Vt[3][3];
     double W[3];
@@ -109,9 +112,10 @@ __device__ void svd_orthogonalise(float* R) {
     }
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) {
-            double s = 0;
-            for (int k = 0; k < 3; k++) s += (double)At[k][r] * (double)Vt[k][c];
-            R[3 * r + c] = (float)s;
+            float t = At[0][r] * Vt[0][c];
+            t = t + At[1][r] * Vt[1][c];
+            t = t + At[2][r] * Vt[2][c];
+            R[3 * r + c] = t;
         }
 }
 
@@ -216,14 +220,18 @@ __global__ __launch_bounds__(NT) void track_manhattan_kernel(Args A) {
             const float alfa = (float)sqrt(sx * sx + sy * sy);
             const float ma_x = (float)((double)(tanf(alfa) / alfa) * sx), ma_y = (float)((double)(tanf(alfa) / alfa) * sy);
             float col[3];
-            for (int r = 0; r < 3; r++)
-                col[r] = (float)((double)s_R[3 * r + c1] * (double)ma_x + (double)s_R[3 * r + c2] * (double)ma_y + (double)s_R[3 * r + c3] * 1.0);
+            for (int r = 0; r < 3; r++) {   // rtemp * temp1 (src/Tracking.cc:877-878): 3x3 by 3x1, the small-matrix gemm case, float sums
+                float t = s_R[3 * r + c1] * ma_x;
+                t = t + s_R[3 * r + c2] * ma_y;
+                t = t + s_R[3 * r + c3] * 1.0f;
+                col[r] = t;
+            }
             double nn = 0;
             for (int r = 0; r < 3; r++) nn += (double)col[r] * col[r];
             nn = sqrt(nn);
             const float inv = (float)(1.0 / nn);
             for (int r = 0; r < 3; r++) col[r] = col[r] * inv;
-            if (col[0] + col[1] + col[2] != 0) {
+            if ((double)col[0] + (double)col[1] + (double)col[2] != 0) {   // cv::sum accumulates in double
                 for (int r = 0; r < 3; r++) s_R[3 * r + (a - 1)] = col[r];
                 s_sum[0] = 1.0; s_sum[1] = (double)s_j_density;
             } else s_sum[0] = 0.0;
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(NT) void track_manhattan_kernel(Args A) {
                     const float a0 = R[ca], a1 = R[3 + ca], a2 = R[6 + ca], b0 = R[cb], b1 = R[3 + cb], b2 = R[6 + cb];
                     const float v0 = a1 * b2 - a2 * b1, v1 = a2 * b0 - a0 * b2, v2 = a0 * b1 - a1 * b0;
                     R[cd] = v0; R[3 + cd] = v1; R[6 + cd] = v2;
-                    if (fabs((double)det3(R) + 1) < 0.5) { R[cd] = -v0; R[3 + cd] = -v1; R[6 + cd] = -v2; }
+                    if (fabs(det3(R) + 1) < 0.5) { R[cd] = -v0; R[3 + cd] = -v1; R[6 + cd] = -v2; }
                 };
                 if ((found_mask & 3) == 3) cross_into(0, 1, 2);
                 else if ((found_mask & 6) == 6) cross_into(2, 1, 0);

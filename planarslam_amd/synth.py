@@ -552,7 +552,7 @@ def manhattan_scene(B=4, n_normals=8500, n_lines=40, seed=21, tilt_deg=4.0, nois
     Per frame: a true rotation R_true (camera <- Manhattan frame), `n_normals` unit normals (float32, as PCL's integral-image
     normals feed `Frame::vSurfaceNormal`) clustered around +-columns of R_true plus `clutter` uniformly random ones, `n_lines`
     3-D line directions (float64, `FrameLine::direction`), and the previous estimate R_last = R_true perturbed by `tilt_deg`.
-    drop_axis (0..2): that axis gets no support (exercises the two-axes + cross-product branch).  Counts are ragged."""
+    drop_axis (0..2, or a tuple of them): those axes get no support (exercises the two-axes + cross-product branch, and the one-axis case).  Counts are ragged."""
     rng = np.random.default_rng(seed)
 
     def rand_rot(max_deg):
@@ -572,7 +572,8 @@ def manhattan_scene(B=4, n_normals=8500, n_lines=40, seed=21, tilt_deg=4.0, nois
         n = int(n_normals * rng.uniform(0.6, 1.0)) if b else n_normals
         m = int(n_lines * rng.uniform(0.3, 1.0)) if b else n_lines
         nn[b], nl[b] = n, m
-        axes = [a for a in range(3) if a != drop_axis]
+        dropped = () if drop_axis is None else (tuple(drop_axis) if isinstance(drop_axis, (tuple, list)) else (drop_axis,))
+        axes = [a for a in range(3) if a not in dropped]
         pick = rng.choice(axes, size=n)
         sign = rng.choice([-1.0, 1.0], size=n)
         v = Rt[:, pick].T * sign[:, None] + rng.normal(scale=noise, size=(n, 3))

@@ -1,0 +1,24 @@
+"""Seeded problems shared by tools/gen_golden_frame.py (which runs the REAL reference function bodies, oracle/_ref/ref_frame, on them and stores
+their outputs in tests/golden/frame_ref.npz), tests/test_oracle_frame_ref.py (oracle vs those outputs) and the GPU tests (HIP vs those outputs)."""
+from planarslam_amd import synth
+
+# Tracking::TrackManhattanFrame: name -> manhattan_scene kwargs
+MANHATTAN_CASES = {
+    "three_axes": dict(B=12, seed=31),
+    "no_z": dict(B=4, seed=5, drop_axis=2, clutter=0.0),                       # v3 = v1 x v2
+    "no_x_small": dict(B=4, seed=6, drop_axis=0, clutter=0.1, n_normals=700, n_lines=7),   # v1 = v3 x v2
+    "no_y_tiny": dict(B=3, seed=8, drop_axis=1, n_normals=300, n_lines=3),     # v2 = v1 x v3
+    "one_axis_only": dict(B=4, seed=13, drop_axis=(0, 2), clutter=0.0),        # numDirectionFound < 2: the aliased R_cm comes back (Tracking.cc:1066-1074)
+    "mostly_clutter": dict(B=4, seed=9, n_normals=300, clutter=0.9),
+    "big_tilt": dict(B=4, seed=17, tilt_deg=11.0),
+}
+
+
+def frustum_case():
+    fr = synth.guided_frame(B=3, N=1000, seed=121)
+    return synth.guided_local_map(fr, seed=122, n_points=4000, n_lines=500)
+
+
+def frustum_scale():
+    import numpy as np
+    return float(np.float32(np.log(np.float32(1.2)))), 8       # Frame::mfLogScaleFactor = log(mfScaleFactor) (float), mnScaleLevels

@@ -633,3 +633,55 @@ def pose_edges_eval(cases, params):
     p = lambda x: x.ctypes.data_as(C.c_void_p)
     L.orc_pose_edges_eval(C.c_int(n), p(a["Tcw"]), p(a["X"]), p(a["obs"]), p(a["lobs"]), p(a["pw"]), p(a["pm"]), C.byref(prm), p(out))
     return out
+
+
+# ---- REAL reference Frame / Tracking function bodies (oracle/_ref/ref_frame: line ranges of src/Frame.cc, MapPoint.cc, MapLine.cpp, Tracking.cc) ----
+def ref_frame_path():
+    return os.path.join(ORACLE_DIR, "_ref", "ref_frame")
+
+
+def _run_ref_frame(mode, payload):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(payload)
+        subprocess.check_call([ref_frame_path(), mode, fin, fout], stdout=subprocess.DEVNULL)
+        return open(fout, "rb").read()
+
+
+def run_ref_manhattan(R_last, normals, lines):
+    """The reference's own Tracking::TrackManhattanFrame for one frame -> dict(R [3,3] f32, member [n+nl] u8)."""
+    R_last = np.ascontiguousarray(R_last, np.float32); normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    lines = np.ascontiguousarray(lines, np.float64).reshape(-1, 3)
+    n, nl = len(normals), len(lines)
+    buf = _run_ref_frame("manhattan", np.int32(1).tobytes() + R_last.tobytes() + np.array([n, nl], np.int32).tobytes() + normals.tobytes() + lines.tobytes())
+    return dict(R=np.frombuffer(buf, "<f4", 9, 0).reshape(3, 3).copy(), member=np.frombuffer(buf, np.uint8, n + nl, 36).copy())
+
+
+def _camera_block(frame, log_scale_factor, n_levels):
+    cam = np.array([frame["fx"], frame["fy"], frame["cx"], frame["cy"], frame["bf"], frame["min_x"], frame["max_x"], frame["min_y"], frame["max_y"],
+                    log_scale_factor], np.float32)
+    return cam.tobytes() + np.int32(n_levels).tobytes()
+
+
+def run_ref_frustum_points(frame, mp, b, log_scale_factor, n_levels, limit=0.5):
+    """Frame::isInFrustum(MapPoint*, limit) of the reference for every valid map point of frame b."""
+    n = int(mp["n"][b])
+    idx = np.nonzero(mp["valid"][b, :n])[0]
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    pay = (_camera_block(frame, log_scale_factor, n_levels) + c(frame["Tcw"][b], np.float32).tobytes() + np.float32(limit).tobytes() + np.int32(len(idx)).tobytes() +
+           c(mp["xw"][b, idx], np.float32).tobytes() + c(mp["normal"][b, idx], np.float32).tobytes() + c(mp["min_dist"][b, idx], np.float32).tobytes() +
+           c(mp["max_dist"][b, idx], np.float32).tobytes())
+    rec = np.frombuffer(_run_ref_frame("frustum_points", pay), np.dtype([("ret", "u1"), ("in_view", "u1"), ("px", "<f4"), ("py", "<f4"), ("pxr", "<f4"), ("level", "<i4"), ("vc", "<f4")]))
+    return idx, rec
+
+
+def run_ref_frustum_lines(frame, ml, b, log_scale_factor, limit=0.5):
+    n = int(ml["n"][b])
+    idx = np.nonzero(ml["valid"][b, :n])[0]
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    pay = (_camera_block(frame, log_scale_factor, 8) + c(frame["Tcw"][b], np.float32).tobytes() + np.float32(limit).tobytes() + np.int32(len(idx)).tobytes() +
+           c(ml["xw6"][b, idx], np.float64).tobytes() + c(ml["normal"][b, idx], np.float64).tobytes() + c(ml["min_dist"][b, idx], np.float32).tobytes() +
+           c(ml["max_dist"][b, idx], np.float32).tobytes())
+    rec = np.frombuffer(_run_ref_frame("frustum_lines", pay), np.dtype([("ret", "u1"), ("p", "<f4", 4), ("level", "<i4"), ("vc", "<f4")]))
+    return idx, rec

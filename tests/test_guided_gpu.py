@@ -159,3 +159,25 @@ def test_is_in_frustum_then_search_by_projection(ctx):
     m, n = ORBmatcher(0.8, True, ctx).SearchByProjectionMap(fr2, got, th=3.0)
     rm, rn = O.search_by_projection_map(fr2, {**ref, "n": mp["n"], "desc": mp["desc"], "observed": mp["observed"]}, th=3.0, nn_ratio=0.8)
     np.testing.assert_array_equal(m, rm); np.testing.assert_array_equal(n, rn)
+
+
+def test_is_in_frustum_hip_equals_reference_fixture(ctx, golden_dir):
+    """Frame::isInFrustum (points and lines) on the GPU vs the fields the reference's own function bodies wrote
+    (tests/golden/frame_ref.npz = src/Frame.cc:296-438 + MapPoint / MapLine::PredictScale built as oracle/_ref/ref_frame): every bit."""
+    import os
+    import frame_cases as cases
+    from planarslam_amd.guided import Frame
+    g = np.load(os.path.join(golden_dir, "frame_ref.npz"))
+    fr, mp, ml = cases.frustum_case()
+    lsf, nlev = cases.frustum_scale()
+    F = Frame(fr, log_scale_factor=lsf, n_levels=nlev, ctx=ctx)
+    got = F.isInFrustumPoints(mp)
+    iv = g["frustum/points/in_view"]
+    np.testing.assert_array_equal(got["in_view"], iv)
+    for k in ("proj_x", "proj_y", "proj_xr", "level", "view_cos"):
+        np.testing.assert_array_equal(got[k][iv > 0], g[f"frustum/points/{k}"][iv > 0], err_msg=k)
+    gotl = F.isInFrustumLines(ml)
+    il = g["frustum/lines/in_view"]
+    np.testing.assert_array_equal(gotl["in_view"], il)
+    for k in ("proj", "level", "view_cos"):
+        np.testing.assert_array_equal(gotl[k][il > 0], g[f"frustum/lines/{k}"][il > 0], err_msg=k)

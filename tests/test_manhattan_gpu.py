@@ -51,3 +51,26 @@ def test_argument_errors():
     with pytest.raises(PlanarError):
         from planarslam_amd._lib import check
         check(lib().planar_track_manhattan_frame(ctx.h, 1, None, None, None, 1, None, None, 1, None, None, None, None))
+
+
+# ---- against the REAL reference (tests/golden/frame_ref.npz = src/Tracking.cc:763-1157 built as oracle/_ref/ref_frame) ----
+import os
+
+import frame_cases as cases
+
+
+@pytest.mark.parametrize("name", list(cases.MANHATTAN_CASES))
+def test_manhattan_hip_equals_reference_fixture(golden_dir, name):
+    """HIP TrackManhattanFrame vs what the reference's own function returned on the same normals: cone membership identical, rotation to
+    1e-5 (device exp / asin / tan differ from glibc in the last bits).  Includes the one-axis case that hands back the aliased input."""
+    from planarslam_amd.manhattan import Tracking
+    g = np.load(os.path.join(golden_dir, "frame_ref.npz"))
+    sc = manhattan_scene(**cases.MANHATTAN_CASES[name])
+    out = Tracking().TrackManhattanFrame(sc["R_last"], sc["normals"], sc["n_normals"], sc["lines"], sc["n_lines"])
+    R, member = g[f"manhattan/{name}/R"], g[f"manhattan/{name}/member"]
+    S = sc["normals"].shape[1]
+    for b in range(len(sc["n_normals"])):
+        n, m = int(sc["n_normals"][b]), int(sc["n_lines"][b])
+        assert np.array_equal(out["member_normals"][b, :n], member[b, :n]), f"frame {b}: normal membership"
+        assert np.array_equal(out["member_lines"][b, :m], member[b, S:S + m]), f"frame {b}: line membership"
+        assert np.allclose(out["R"][b], R[b], atol=1e-5, rtol=0), f"frame {b}: rotation {np.abs(out['R'][b] - R[b]).max()}"
