@@ -56,8 +56,20 @@ def main():
     ap.add_argument("--workload", choices=["full", "orb"], default="full")
     ap.add_argument("--depth", type=int, default=2, help="software-pipeline depth: PoseOptimization of step i is enqueued during step i+depth")
     ap.add_argument("--prio", default="-1,0,0", help="stream priorities: ORB/match/pose stream, LSD streams, PEAC streams (lower = higher priority)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the cpu_baseline leg, split over its three variants (0 = skip)")
+    ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 latency block (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU, RCCL rendezvous on 127.0.0.1) and pass the line through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import numpy as np
     import torch
@@ -65,7 +77,7 @@ def main():
     from planarslam_amd.dist import Ranks, whole_job_fps
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -316,45 +328,52 @@ def main():
                 "note": "latency/occupancy-bound sequential stage (one workgroup per frame); see DESIGN.md" if dom.startswith(("peac", "lsd")) else None,
                 "kernels": kernels}
 
-    # ---- CPU baseline: the oracle restatement of the same stages on this box's host cores (1 thread) ----
+    # ---- CPU baseline: the oracle restatement of the same stages on this box's host cores (tools/cpu_baseline.py) ----
+    # value = all host cores (frames shard over processes, as they do over GPUs); next to it the one-thread figure and the reference's own
+    # arrangement: three extraction threads per frame (src/Frame.cc:90-95), matching and LM on the calling thread.
     cpu = None
     if args.cpu_seconds > 0 and world == 1:        # rank 0 at N = 1 only
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as ol
-        o = ol.OrbOracle()
-        o.extract(gray_src[0])
-        n, t0 = 0, time.perf_counter()
-        per = {"orb": 0.0, "lsd": 0.0, "peac": 0.0, "proj": 0.0, "match": 0.0, "pose": 0.0}
-        prev_desc = o.extract(gray_src[-1])[1]
-        if full:   # the same SearchByProjection problem as the GPU leg, frame by frame (host copies of the device inputs)
-            hp = {k: pj[k].cpu().numpy() for k in ("u_right", "Tcw", "usable", "xw", "octave", "angle", "observed")}
-            h_desc = d_desc[0].cpu().numpy()
-            sfs = scale_factors()
-        while time.perf_counter() - t0 < args.cpu_seconds:
-            i = n % nsrc
-            t1 = time.perf_counter(); kp, de = o.extract(gray_src[i]); per["orb"] += time.perf_counter() - t1
-            if full:
-                t1 = time.perf_counter(); ol.extract_line_segment(gray_src[i], tie_order=0); per["lsd"] += time.perf_counter() - t1
-                t1 = time.perf_counter(); ol.peac_run(depth_src[i]); per["peac"] += time.perf_counter() - t1
-                j = i % B
-                nj = int(h_n[j])
-                curv = dict(n=np.array([nj], np.int32), keys_un=h_kps[j:j + 1, :nj].copy().view(ol.KP_DTYPE).reshape(1, nj), u_right=hp["u_right"][j:j + 1, :nj],
-                            desc=h_desc[j:j + 1, :nj], Tcw=hp["Tcw"][j:j + 1], min_x=0.0, max_x=float(W), min_y=0.0, max_y=float(H), fx=TUM3["fx"], fy=TUM3["fy"],
-                            cx=TUM3["cx"], cy=TUM3["cy"], bf=TUM3["bf"], b=TUM3["bf"] / TUM3["fx"], scale_factors=sfs)
-                lastv = dict(n=np.array([nj], np.int32), Tcw=hp["Tcw"][j:j + 1], usable=hp["usable"][j:j + 1, :nj], xw=hp["xw"][j:j + 1, :nj],
-                             octave=hp["octave"][j:j + 1, :nj], angle=hp["angle"][j:j + 1, :nj], mp_desc=h_desc[j:j + 1, :nj], mp_observed=hp["observed"][j:j + 1, :nj])
-                t1 = time.perf_counter(); ol.search_by_projection_frame(curv, lastv, 15.0); per["proj"] += time.perf_counter() - t1
-                t1 = time.perf_counter()
-                ol.match_orb_points(de, prev_desc, np.ones(len(prev_desc), np.uint8), np.zeros(len(prev_desc), np.uint8), np.full(len(de), -1, np.int32))
-                per["match"] += time.perf_counter() - t1
-                one = {k: (v[i:i + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (nsrc,) else v) for k, v in pbn.items()}
-                t1 = time.perf_counter(); ol.pose_optimize(one, TUM3, 0, 4, 10); per["pose"] += time.perf_counter() - t1
-                prev_desc = de
-            n += 1
-        dt = time.perf_counter() - t0
-        cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{n} frames of the same synthetic set through the oracle/ restatements of the same stages (1 thread, {dt:.1f} s)",
-               "ms_per_frame": {k: round(v / n * 1e3, 2) for k, v in per.items() if v > 0}, "host_cores": os.cpu_count()}
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import cpu_baseline as cb
+        t_each = args.cpu_seconds / 3.0
+        r1 = cb.run(t_each, seed=rank, full=full)
+        r3 = cb.run(t_each, seed=rank, threads3=True, full=full) if full else None
+        ncores = os.cpu_count()
+        fps_all, nworkers, _ = cb.all_cores(t_each, workers=ncores, full=full)
+        cpu = {"value": round(fps_all, 2), "unit": "frames/s", "cores": nworkers, "kind": "port",
+               "sample": f"{nworkers} worker processes (one per host core), each looping the oracle/ restatements of the same stages over its own synthetic frames for {t_each:.1f} s",
+               "one_thread": {"value": round(r1["frames"] / r1["seconds"], 2), "cores": 1, "frames": r1["frames"], "ms_per_frame": cb.summarize(r1)},
+               "threads3": None if r3 is None else {"value": round(r3["frames"] / r3["seconds"], 2), "cores": 3, "frames": r3["frames"], "ms_per_frame": cb.summarize(r3),
+                                                     "note": "extraction on 3 threads per frame as src/Frame.cc:90-95; matching + LM single-threaded"},
+               "host_cores": ncores}
+
+    # ---- single-frame latency (B = 1, host-pointer entry points: H2D + kernels + D2H + sync; the reference is a live B = 1 tracker) ----
+    latency = None
+    if world == 1 and full and args.latency_reps > 0:
+        from planarslam_amd.lines import LineSegment as LS1
+        c1 = Context(local_rank)
+        ex1 = ORBextractor(1000, 1.2, 8, 20, 7, width=W, height=H, max_batch=1, ctx=c1)
+        ls1 = LS1(W, H, 1, c1)
+        pd1 = PlaneDetection(W, H, max_batch=1, ctx=c1)
+        opt1 = Optimizer(TUM3, ctx=c1)
+        g1, dp1 = gray_src[0], depth_src[0]
+        pb1 = {k: (v[:1].copy() if isinstance(v, np.ndarray) and v.shape[:1] == (nsrc,) else v) for k, v in pbn.items()}
+        kp1, de1 = ex1(g1)
+        from planarslam_amd.matcher import ORBmatcher as OM1
+        om1 = OM1(ctx=c1)
+
+        def med(fn):
+            fn(); fn()
+            ts = []
+            for _ in range(args.latency_reps):
+                t1 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t1) * 1e3)
+            return round(float(np.median(ts)), 3)
+        latency = {"orb_extract": med(lambda: ex1(g1)), "lsd_lbd_extract": med(lambda: ls1.ExtractLineSegment(g1)),
+                   "peac_segment": med(lambda: pd1.run(dp1[None])), "pose_opt_4x10": med(lambda: opt1.PoseOptimization(pb1, 4, 10)),
+                   "match_orb_points": med(lambda: om1.MatchORBPoints(de1[None], np.array([len(de1)], np.int32), de1[None], np.array([len(de1)], np.int32),
+                                                                       np.ones((1, len(de1)), np.uint8), np.zeros((1, len(de1)), np.uint8))),
+                   "reps": args.latency_reps, "note": "median wall ms per call, one frame, host buffers in and out"}
+        latency["extract_3_streams_serial_sum"] = round(latency["orb_extract"] + latency["lsd_lbd_extract"] + latency["peac_segment"], 3)
 
     workload = ("configs[2]+[3]: full extract (ORB + LSD/LBD lines + PEAC planes on separate streams, pose of step i-depth pipelined behind step i) + SearchByProjection + MatchORBPoints + PoseOptimization 4x10 "
                 "(1000 pt + 150 line-endpoint + 12 plane edges)"
@@ -369,7 +388,7 @@ def main():
                    "not_yet_in_workload": ([] if full else
                                            ["LSD/LBD lines", "PEAC planes", "matching", "pose optimisation"]),
                    "parallelism": f"frame-sharded x{world}, no collective"},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "latency_b1_ms": latency,
     }
     if full:
         out["config"]["avg_planes_per_frame"] = round(avg_planes, 2)

@@ -1,0 +1,128 @@
+"""CPU baseline of bench.py: the oracle/ restatements of the hot-path stages, timed on the host cores of the box the bench runs on.
+
+TEST / MEASUREMENT INFRASTRUCTURE: this is the only place besides tests/ and __graft_entry__.smoke() that imports oracle/.  The same
+per-frame work list as the reference's Tracking thread: ORB + LSD/LBD + PEAC extraction, SearchByProjection(Cur, Last), MatchORBPoints,
+PoseOptimization 4x10 on a config-4-shaped problem.  Three variants:
+  one_thread   everything on one thread
+  threads3     extraction on three threads per frame as src/Frame.cc:90-95 does (ORB / LSD / PEAC), matching and LM on the calling thread
+  all_cores    `os.cpu_count()` independent worker processes, each running the one-thread loop on its own frames (frames shard trivially)
+Run as a script it is one all_cores worker:  python tools/cpu_baseline.py --seconds 8 --seed 3   -> one JSON line."""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+W, H = 640, 480
+NPTS, NLINES, NPLANES = 1000, 75, 4
+
+
+def _inputs(seed, nsrc):
+    import numpy as np
+    from planarslam_amd.synth import depth_image, gray_image, pose_batch
+    gray = np.stack([gray_image(1234 + seed * 1000 + i) for i in range(nsrc)])
+    depth = np.stack([depth_image(4321 + seed * 1000 + i) for i in range(nsrc)])
+    pbn = pose_batch(B=nsrc, n_points=NPTS, n_lines=NLINES, n_planes=NPLANES, seed=7 + seed)
+    return gray, depth, pbn
+
+
+def run(seconds, seed=0, nsrc=4, threads3=False, full=True):
+    """Process frames for about `seconds`; returns dict(frames, seconds, per-stage seconds)."""
+    import numpy as np
+    import oracle_lib as ol
+    from planarslam_amd.synth import TUM3, scale_factors
+    gray, depth, pbn = _inputs(seed, nsrc)
+    o = ol.OrbOracle()
+    sfs = scale_factors()
+    rng = np.random.default_rng(11 + seed)
+    per = {"orb": 0.0, "lsd": 0.0, "peac": 0.0, "extract_wall": 0.0, "proj": 0.0, "match": 0.0, "pose": 0.0}
+    prev = None
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        i = n % nsrc
+        res = {}
+
+        def t_orb():
+            t1 = time.perf_counter(); res["orb"] = o.extract(gray[i]); per["orb"] += time.perf_counter() - t1
+
+        def t_lsd():
+            t1 = time.perf_counter(); res["lsd"] = ol.extract_line_segment(gray[i], tie_order=0); per["lsd"] += time.perf_counter() - t1
+
+        def t_peac():
+            t1 = time.perf_counter(); res["peac"] = ol.peac_run(depth[i]); per["peac"] += time.perf_counter() - t1
+
+        tw = time.perf_counter()
+        if not full:
+            t_orb()
+        elif threads3:          # ctypes releases the GIL inside the oracle calls: the three extractors really run side by side
+            th = [threading.Thread(target=f) for f in (t_lsd, t_peac)]
+            for t in th: t.start()
+            t_orb()
+            for t in th: t.join()
+        else:
+            t_orb(); t_lsd(); t_peac()
+        per["extract_wall"] += time.perf_counter() - tw
+        kp, de = res["orb"]
+        if full:
+            nj = len(kp)
+            if prev is not None:
+                pkp, pde, pxw, pur = prev
+                npv = len(pkp)
+                eye = np.eye(4, dtype=np.float32).reshape(1, 16)
+                curv = dict(n=np.array([nj], np.int32), keys_un=kp.reshape(1, nj), u_right=np.full((1, nj), -1, np.float32), desc=de.reshape(1, nj, 32), Tcw=eye,
+                            min_x=0.0, max_x=float(W), min_y=0.0, max_y=float(H), fx=TUM3["fx"], fy=TUM3["fy"], cx=TUM3["cx"], cy=TUM3["cy"], bf=TUM3["bf"],
+                            b=TUM3["bf"] / TUM3["fx"], scale_factors=sfs)
+                lastv = dict(n=np.array([npv], np.int32), Tcw=eye, usable=np.ones((1, npv), np.uint8), xw=pxw.reshape(1, npv, 3),
+                             octave=np.ascontiguousarray(pkp["octave"]).reshape(1, npv), angle=np.ascontiguousarray(pkp["angle"]).reshape(1, npv),
+                             mp_desc=pde.reshape(1, npv, 32), mp_observed=np.ones((1, npv), np.uint8))
+                t1 = time.perf_counter(); ol.search_by_projection_frame(curv, lastv, 15.0); per["proj"] += time.perf_counter() - t1
+                t1 = time.perf_counter()
+                ol.match_orb_points(de, pde, np.ones(npv, np.uint8), np.zeros(npv, np.uint8), np.full(nj, -1, np.int32))
+                per["match"] += time.perf_counter() - t1
+            one = {k: (v[i:i + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (nsrc,) else v) for k, v in pbn.items()}
+            t1 = time.perf_counter(); ol.pose_optimize(one, TUM3, 0, 4, 10); per["pose"] += time.perf_counter() - t1
+            z = rng.uniform(0.8, 5.0, nj).astype(np.float32)
+            xw = np.stack([(kp["x"] - TUM3["cx"]) * z / TUM3["fx"], (kp["y"] - TUM3["cy"]) * z / TUM3["fy"], z], -1).astype(np.float32)
+            prev = (kp, de, xw, None)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(frames=n, seconds=dt, per=per)
+
+
+def all_cores(seconds, workers=None, full=True):
+    """`workers` processes of this script, one per host core; returns (frames/s summed over workers, workers, details)."""
+    import subprocess
+    workers = workers or os.cpu_count()
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--seconds", str(seconds), "--seed", str(100 + w)] + ([] if full else ["--orb-only"]),
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for w in range(workers)]
+    outs = []
+    for p in procs:
+        so, _ = p.communicate()
+        try:
+            outs.append(json.loads(so.decode().strip().splitlines()[-1]))
+        except Exception:
+            pass
+    fps = sum(o["frames"] / o["seconds"] for o in outs)
+    return fps, len(outs), outs
+
+
+def summarize(r):
+    n = max(1, r["frames"])
+    return {k: round(v / n * 1e3, 2) for k, v in r["per"].items() if v > 0}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=8.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--orb-only", action="store_true")
+    a = ap.parse_args()
+    r = run(a.seconds, a.seed, nsrc=2, full=not a.orb_only)
+    print(json.dumps(dict(frames=r["frames"], seconds=r["seconds"])))
