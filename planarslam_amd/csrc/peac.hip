@@ -161,6 +161,8 @@ struct Layout {   // per-frame workspace (element offsets), identical for every 
     int pool_cap, q_cap;
     size_t off_stats, off_geo, off_N, off_rid, off_flags, off_nb_off, off_nb_cnt, off_pool, off_parent, off_size,
         off_member, off_dist, off_blkmap, off_queue, off_seedcnt, off_cint, off_cdbl, frame_bytes;
+    // state the clustering kernel (peac_ahc) leaves for the refinement kernel (peac_refine): disjoint set, root ids, dead bits, extracted planes
+    size_t off_h_dsp, off_h_dss, off_h_rid, off_h_nouse, off_h_cval, off_h_hand, off_h_nboff, off_h_nbcnt, off_h_pool;
 };
 
 struct Intr { float fx, fy, cx, cy, factor; };
@@ -242,6 +244,11 @@ __device__ __forceinline__ void lst_insert(u16* lst, int& cnt, int v) {
     lst[i] = (u16)v; cnt++;
 }
 
+// PHASE 0 = peac_ahc: initGraph + the first ahCluster (heap, neighbour lists, set sizes, root ids in LDS).  PHASE 1 = peac_refine:
+// refineDetails (block membership, erosion, seeds, flood fill), the final ahCluster over the <= 128 extracted planes and the relabelling;
+// its node-indexed arrays live in the frame's global workspace (a handful of nodes are touched), so it needs ~17 KB of LDS and runs
+// beside the clustering workgroups of other frames.  The code of ahCluster is shared: the pointers of `Lds` point into LDS or global memory.
+template <int PHASE>
 __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, const Consts& C, const uint16_t* __restrict__ depth, int pitch_px,
                                               int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
                                               int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
@@ -263,29 +270,42 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     int32_t* lab = labels + (size_t)frame * label_stride;
     const int NB = L.NB, Nw = L.Nw, Nh = L.Nh, W = L.W, H = L.H;
 
+    __shared__ double s_hm[PHASE == 1 ? MAX_PLANES : 1];     // refinement: the heap of the final clustering holds <= MAX_PLANES nodes
+    __shared__ u16 s_hi[PHASE == 1 ? MAX_PLANES : 1];
+    __shared__ signed char s_blk[PHASE == 1 ? 3072 : 1];      // block -> plane id (NB <= 3072 is checked at create time for this path)
     Lds S;
-    S.h_mse = (double*)smem;
-    S.h_id = (u16*)(S.h_mse + NB);
-    S.pool = S.h_id + NB;
-    S.nb_off = S.pool + L.pool_cap;
-    S.nb_cnt = S.nb_off + L.NB2;
-    S.dsp = S.nb_cnt + L.NB2;
+    if (PHASE == 0) {
+        S.h_mse = (double*)smem;
+        S.h_id = (u16*)(S.h_mse + NB);
+        S.pool = S.h_id + NB;
+        S.nb_off = S.pool + L.pool_cap;
+        S.nb_cnt = S.nb_off + L.NB2;
+        S.dss = S.nb_cnt + L.NB2;
+        S.rid = S.dss + NB;                       // rid of every node (root block id)
+        S.nouse = (unsigned*)(S.rid + L.NB2);     // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
+        S.cval = S.nouse + (L.NB2 + 31) / 32;     // bit per node: its cached candidate record (g_cint / g_cdbl) is valid for its current live-neighbour set
+        S.dsp = (u16*)(F + L.off_h_dsp);          // DisjointSet parents: only written here (Union), read by the refinement kernel
+        S.blk = nullptr;
+    } else {
+        S.h_mse = s_hm; S.h_id = s_hi;
+        S.pool = (u16*)(F + L.off_h_pool); S.nb_off = (u16*)(F + L.off_h_nboff); S.nb_cnt = (u16*)(F + L.off_h_nbcnt);
+        S.dsp = (u16*)(F + L.off_h_dsp); S.dss = (u16*)(F + L.off_h_dss); S.rid = (u16*)(F + L.off_h_rid);
+        S.nouse = (unsigned*)(F + L.off_h_nouse); S.cval = (unsigned*)(F + L.off_h_cval);
+        S.blk = s_blk;
+    }
+    int* g_hand = (int*)(F + L.off_h_hand);       // [0] n_ext, [1] err, [2] n_nodes, [4 + q] extracted node ids
     // list capacities are only consulted when a node is appended to a full list: the 4-slot lists of the initial blocks have it implicit,
     // every other list keeps it in the pool slot in front of its first entry (no LDS array: the line detector's wavefront, lsd_detect,
     // needs 8 KB on the same CU; no global array: the append would wait a memory round trip per merge)
     bool hdr_all = false;                                     // second ahCluster: every list has the header slot
     auto list_cap = [&](int q) -> int { return (q < NB && !hdr_all) ? 4 : (int)S.pool[S.nb_off[q] - 1]; };
-    S.dss = S.dsp + NB;
-    S.rid = S.dss + NB;                       // rid of every node (root block id)
-    S.nouse = (unsigned*)(S.rid + L.NB2);     // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
-    S.cval = S.nouse + (L.NB2 + 31) / 32;     // bit per node: its cached candidate record (g_cint / g_cdbl) is valid for its current live-neighbour set
-    S.blk = (signed char*)(S.cval + (L.NB2 + 31) / 32);
 
-    __shared__ int s_ext[MAX_PLANES], s_old[MAX_PLANES], s_plidmap[MAX_PLANES];
-    __shared__ uint8_t s_valid[MAX_PLANES];
-    __shared__ unsigned s_adj[MAX_PLANES][MAX_PLANES / 32];
+    constexpr int RP = PHASE == 1 ? MAX_PLANES : 1;           // refinement-only arrays take no LDS in the clustering kernel
+    __shared__ int s_ext[MAX_PLANES], s_old[RP], s_plidmap[RP];
+    __shared__ uint8_t s_valid[RP];
+    __shared__ unsigned s_adj[RP][MAX_PLANES / 32];
     constexpr int NSLOT = 2048;                               // pixel -> slot hash of the flood fill (pairs of one step: 1024)
-    __shared__ int s_slot[NSLOT];
+    __shared__ int s_slot[PHASE == 1 ? NSLOT : 1];
     __shared__ int s_pcnt[16];
     __shared__ int s_scalar[4];   // [0] n_ext, [1] err, [2] q_tail, [3] scratch
     constexpr int EVAL_MAX = 64;   // nodes evaluated per cooperative phase
@@ -311,11 +331,15 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     };
 
     // ---- init (all threads) ----
-    for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.rid[b] = (u16)b; }
-    for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) { S.nouse[t] = 0; S.cval[t] = 0; }
-    for (int t = tid; t < MAX_PLANES; t += NT) { s_valid[t] = 0; s_plidmap[t] = -1; }
-    for (int t = tid; t < MAX_PLANES * (MAX_PLANES / 32); t += NT) (&s_adj[0][0])[t] = 0;
-    if (tid < 4) s_scalar[tid] = 0;
+    if (PHASE == 0) {
+        for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.rid[b] = (u16)b; }
+        for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) { S.nouse[t] = 0; S.cval[t] = 0; }
+        if (tid < 4) s_scalar[tid] = 0;
+    } else {
+        for (int t = tid; t < MAX_PLANES; t += NT) { s_valid[t] = 0; s_plidmap[t] = -1; s_ext[t] = g_hand[4 + t]; }
+        for (int t = tid; t < MAX_PLANES * (MAX_PLANES / 32); t += NT) (&s_adj[0][0])[t] = 0;
+        if (tid < 4) s_scalar[tid] = tid == 1 ? g_hand[1] : 0;
+    }
     __syncthreads();
 
     // ---- initGraph edges (AHCPlaneFitter.hpp:896-954).  The horizontal pass only links nodes of one row and the
@@ -326,6 +350,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         int cb = S.nb_cnt[b]; lst_insert(S.pool + S.nb_off[b], cb, a); S.nb_cnt[b] = (u16)cb;
     };
     auto inG = [&](int idx) { return (g_flags[idx] & 1) != 0; };
+    if (PHASE == 0) {
     for (int i = tid; i < Nh; i += NT) {
         for (int j = 1; j < Nw; j += 2) {
             const int c = i * Nw + j;
@@ -354,10 +379,11 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         }
     }
     __syncthreads();
+    }
     mark();
 
     // =========================== sequential section: wave 0 only ===========================
-    int heap_n = 0, n_nodes = NB, n_ext = 0, pool_top = 4 * NB, err = 0;
+    int heap_n = 0, n_nodes = PHASE == 0 ? NB : g_hand[2], n_ext = PHASE == 0 ? 0 : g_hand[0], pool_top = 4 * NB, err = PHASE == 0 ? 0 : g_hand[1];
     // libstdc++ binary heap (std::priority_queue with PlaneSegMinMSECmp: comp(a,b) = b.mse < a.mse); entries carry
     // their key so a comparison is one LDS read.
     // __push_heap: the value climbs from `hole` while it is smaller than the parent.  The <= 12 ancestors are read by one lane each in a
@@ -819,6 +845,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         }
         wfence();
     };
+    if (PHASE == 0) {
     if (wave == 0) {
         for (int b0 = 0; b0 < NB; b0 += 64) {   // minQ.push in block order (:809); 64 blocks fetched per round
             const int b = b0 + lane;
@@ -834,10 +861,30 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         mark();
     } else mark();
     ah_cluster(true);            // all four wavefronts (cooperative candidate evaluation)
-    if (wave == 0 && lane == 0) { s_scalar[0] = n_ext; s_scalar[1] = err; }
+    if (wave == 0 && lane == 0) { s_scalar[0] = n_ext; s_scalar[1] = err; g_hand[0] = n_ext; g_hand[1] = err; g_hand[2] = n_nodes; }
     __syncthreads();
     n_ext = s_scalar[0]; err = s_scalar[1];
     mark();
+    // hand the clustering state over to peac_refine: set sizes, root ids, dead bits, the extracted planes
+    {
+        u16* o_dss = (u16*)(F + L.off_h_dss); u16* o_rid = (u16*)(F + L.off_h_rid);
+        unsigned* o_nouse = (unsigned*)(F + L.off_h_nouse); unsigned* o_cval = (unsigned*)(F + L.off_h_cval);
+        for (int b = tid; b < NB; b += NT) o_dss[b] = S.dss[b];
+        for (int b = tid; b < L.NB2; b += NT) o_rid[b] = S.rid[b];
+        for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) { o_nouse[t] = S.nouse[t]; o_cval[t] = 0; }
+        for (int t = tid; t < MAX_PLANES; t += NT) g_hand[4 + t] = t < n_ext ? s_ext[t] : 0;
+    }
+    if (tid == 0) {
+        status[frame] = err;
+        if (timing) {
+            for (int t = 0; t < 4; t++) timing[(size_t)frame * 16 + t] = t < nph ? tphase[t] - tphase[0] : 0;
+            timing[(size_t)frame * 16 + 9] = n_nodes;
+            timing[(size_t)frame * 16 + 7] = ((long long)dbg_phases << 40) | ((long long)dbg_nodes << 20) | dbg_hits;   // cooperative ahCluster: phases, nodes evaluated, cache hits
+            for (int t = 0; t < 6; t++) timing[(size_t)frame * 16 + 10 + t] = cyc[t];
+        }
+    }
+    return;
+    }
 
     // ---- refineDetails (:299-379): findBlockMembership (:485-587), all threads ----
     for (int i = tid; i < W * H; i += NT) { member[i] = -1; distMap[i] = 3.4028234663852886e38f; }
@@ -1064,28 +1111,33 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     mark();
     if (tid == 0) {
         n_planes[frame] = n_ext; status[frame] = err;
-        if (timing) {
-            for (int t = 0; t < 8; t++) timing[(size_t)frame * 16 + t] = t < nph ? tphase[t] - tphase[0] : 0;
-            timing[(size_t)frame * 16 + 8] = s_scalar[2]; timing[(size_t)frame * 16 + 9] = n_nodes;
-            timing[(size_t)frame * 16 + 7] = ((long long)dbg_phases << 40) | ((long long)dbg_nodes << 20) | dbg_hits;   // cooperative ahCluster: phases, nodes evaluated, cache hits
-            for (int t = 0; t < 6; t++) timing[(size_t)frame * 16 + 10 + t] = cyc[t];
+        if (timing) {   // marks of this kernel: [1] seeds done, [2] floodFill done, [3] end; stored behind the clustering kernel's [0..3]
+            const long long base = timing[(size_t)frame * 16 + 3];
+            for (int t = 2; t < 5; t++) timing[(size_t)frame * 16 + 2 + t] = base + (t < nph ? tphase[t] - tphase[0] : 0);
+            timing[(size_t)frame * 16 + 8] = s_scalar[2];
         }
     }
 }
 
-// One workgroup per frame, one workgroup per CU at a time (the merge heap fills its LDS).  A workgroup takes the next frame from a counter
-// when it STARTS instead of using its block index: frames differ by up to 1.7x in merge steps, the dispatcher deals block indices
-// round-robin over the 8 XCDs, and a periodic mix of frames would otherwise send every slow frame to the same XCD.
+// peac_ahc: one workgroup per frame, one workgroup per CU at a time (the merge heap and the neighbour lists fill its LDS).  A workgroup takes
+// the next frame from a counter when it STARTS instead of using its block index: frames differ by up to 1.7x in merge steps, the dispatcher
+// deals block indices round-robin over the 8 XCDs, and a periodic mix of frames would otherwise send every slow frame to the same XCD.
 // (A persistent one-workgroup-per-CU loop costs ~50 more VGPRs and with them the co-residency of lsd_detect's wavefront on the same SIMDs.)
-__global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
-                                                   int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
-                                                   int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
-                                                   int32_t* __restrict__ status, long long* __restrict__ timing, int* __restrict__ next_frame,
-                                                   const int* __restrict__ order) {
+__global__ __launch_bounds__(NT) void peac_ahc(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
+                                               int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
+                                               long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order) {
     __shared__ int s_frame;
     if (threadIdx.x == 0) { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
     __syncthreads();
-    segment_frame(L, K, C, depth, pitch_px, frame_stride_px, ws, labels, label_stride, planes, n_planes, status, timing, s_frame);
+    segment_frame<0>(L, K, C, depth, pitch_px, frame_stride_px, ws, nullptr, 0, nullptr, nullptr, status, timing, s_frame);
+}
+
+// peac_refine: one workgroup per frame, ~17 KB of LDS: several per CU, and beside the clustering workgroups of the next launch.
+__global__ __launch_bounds__(NT) void peac_refine(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
+                                                  int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
+                                                  int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
+                                                  int32_t* __restrict__ status, long long* __restrict__ timing) {
+    segment_frame<1>(L, K, C, depth, pitch_px, frame_stride_px, ws, labels, label_stride, planes, n_planes, status, timing, (int)blockIdx.x);
 }
 
 // Longest-first order for the NEXT call with the same batch size: slot b of a batch is one camera stream, consecutive frames of a stream cost
@@ -1094,10 +1146,10 @@ __global__ __launch_bounds__(NT) void peac_segment(Layout L, Intr K, Consts C, c
 __global__ void peac_order(const long long* __restrict__ timing, int B, int* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
-    const long long ci = timing[(size_t)i * 16 + 6];         // clock ticks from kernel entry to the end of floodFill
+    const long long ci = timing[(size_t)i * 16 + 3];         // clock ticks of the clustering kernel (entry to the end of ahCluster)
     int rank = 0;
     for (int j = 0; j < B; j++) {
-        const long long cj = timing[(size_t)j * 16 + 6];
+        const long long cj = timing[(size_t)j * 16 + 3];
         rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0;
     }
     order[rank] = i;
@@ -1148,9 +1200,14 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     // candidate cache of the cooperative ahCluster: per node 4 ints {have, best_nb, best_N, -} and 16 doubles {mse, stats[9], center[3],
     // normal[3]}; whether a record is valid for the node's current live-neighbour set is a bit in LDS
     L.off_cint = carve((size_t)L.NB2 * 16); L.off_cdbl = carve((size_t)L.NB2 * 16 * 8);
+    L.off_h_dsp = carve((size_t)L.NB * 2); L.off_h_dss = carve((size_t)L.NB * 2); L.off_h_rid = carve((size_t)L.NB2 * 2);
+    L.off_h_nouse = carve((size_t)((L.NB2 + 31) / 32) * 4); L.off_h_cval = carve((size_t)((L.NB2 + 31) / 32) * 4);
+    L.off_h_hand = carve((size_t)(4 + peac::MAX_PLANES) * 4);
+    L.off_h_nboff = carve((size_t)L.NB2 * 2); L.off_h_nbcnt = carve((size_t)L.NB2 * 2); L.off_h_pool = carve((size_t)L.pool_cap * 2);
     L.frame_bytes = off;
-    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 4 + L.NB * 4 + L.NB2 * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
-    if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
+    // peac_ahc: heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
+    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 4 + L.NB * 2 + L.NB2 * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + 16;
+    if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
     const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
     o->C.ang_near = 15.0 * deg;
@@ -1162,7 +1219,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     if ((rc = o->d_ws.alloc((size_t)max_batch * L.frame_bytes)) || (rc = o->d_status.alloc((size_t)max_batch * 4)) ||
         (rc = o->d_timing.alloc((size_t)max_batch * 128)) || (rc = o->d_next.alloc(256)) || (rc = o->d_order.alloc((size_t)max_batch * 4))) { delete o; return rc; }
     if (o->smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)peac::peac_segment, hipFuncAttributeMaxDynamicSharedMemorySize, o->smem);
+        hipError_t e = hipFuncSetAttribute((const void*)peac::peac_ahc, hipFuncAttributeMaxDynamicSharedMemorySize, o->smem);
         if (e != hipSuccess) { delete o; set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
     }
     *out = o;
@@ -1181,10 +1238,12 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     const peac::Intr K{fx, fy, cx, cy, depth_factor};
     hipLaunchKernelGGL(peac::peac_blocks, dim3((p->L.NB + 63) / 64, B), dim3(64), 0, st, p->L, K, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>());
     PLANAR_HIP_CHECK(hipMemsetAsync(p->d_next.p, 0, 4, st));
-    hipLaunchKernelGGL(peac::peac_segment, dim3(B), dim3(peac::NT), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
-                       p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>(),
-                       p->d_next.as<int>(), p->order_B == B ? p->d_order.as<int>() : nullptr);
+    hipLaunchKernelGGL(peac::peac_ahc, dim3(B), dim3(peac::NT), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+                       p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(), p->d_timing.as<long long>(), p->d_next.as<int>(),
+                       p->order_B == B ? p->d_order.as<int>() : nullptr);
     hipLaunchKernelGGL(peac::peac_order, dim3((B + 255) / 256), dim3(256), 0, st, p->d_timing.as<long long>(), B, p->d_order.as<int>());
+    hipLaunchKernelGGL(peac::peac_refine, dim3(B), dim3(peac::NT), 0, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+                       p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
     p->order_B = B;
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
