@@ -277,8 +277,8 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     if (PHASE == 0) {
         S.h_mse = (double*)smem;
         S.h_id = (u16*)(S.h_mse + NB);
-        S.pool = S.h_id + NB;
-        S.nb_off = S.pool + L.pool_cap;
+        S.pool = (u16*)(F + L.off_h_pool);        // neighbour lists: global memory (L2 resident); LDS holds what every pop / merge chases
+        S.nb_off = S.h_id + NB;
         S.nb_cnt = S.nb_off + L.NB2;
         S.dss = S.nb_cnt + L.NB2;
         S.rid = S.dss + NB;                       // rid of every node (root block id)
@@ -310,6 +310,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     __shared__ int s_scalar[4];   // [0] n_ext, [1] err, [2] q_tail, [3] scratch
     constexpr int EVAL_MAX = 64;   // nodes evaluated per cooperative phase
     __shared__ int s_cmd, s_nlist;
+    __shared__ u16 s_stageA[64], s_stageB[64];                // the two neighbour lists of a merge (read once from global memory)
     __shared__ unsigned short s_lnode[EVAL_MAX];
     __shared__ unsigned char s_lwave[EVAL_MAX], s_loff[EVAL_MAX];
     long long tphase[8];
@@ -717,9 +718,13 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                         if (ca2 <= 64 && cb2 <= 64) {
                             // both lists fit the wavefront: lane i owns A[i] and B[i]; the two lower-bound searches (A[i] in B, B[i] in A) run
                             // interleaved, the ranks of the survivors are popcounts of two ballots and every survivor is written straight to
-                            // its final slot (no prefix arrays, no second pass, no copy)
+                            // its final slot (no prefix arrays, no second pass, no copy).  The lists live in global memory: one round trip
+                            // brings both into an LDS stage, the searches then run on LDS.
                             const bool inA = lane < ca2, inB = lane < cb2;
                             const int xa = inA ? (int)A[lane] : 0, xb = inB ? (int)Bl[lane] : 0;
+                            s_stageA[lane] = (u16)xa; s_stageB[lane] = (u16)xb;
+                            wfence();
+                            const u16* A = s_stageA; const u16* Bl = s_stageB;
                             const bool liveA = inA && !is_dead(xa), liveB = inB && !is_dead(xb);
                             int loA = 0, hiA = liveA ? cb2 : 0;         // lower bound of xa in B
                             int loB = 0, hiB = liveB ? ca2 : 0;         // lower bound of xb in A
@@ -806,7 +811,19 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                                 const int q = lstm[k];
                                 u16* ql = S.pool + S.nb_off[q];
                                 int c = S.nb_cnt[q];
-                                if (c >= list_cap(q)) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
+                                if (q < NB && !hdr_all) {
+                                    // a block's list: four u16 in one 8-byte word (offset 4 * q).  One load, compaction in registers, one store.
+                                    if (c >= 4) {
+                                        const uint2 w = *(const uint2*)ql;
+                                        const int e0 = w.x & 0xffff, e1 = w.x >> 16, e2 = w.y & 0xffff, e3 = w.y >> 16;
+                                        int n2 = 0;
+                                        if (!is_dead(e0)) { ql[n2] = (u16)e0; n2++; }
+                                        if (!is_dead(e1)) { ql[n2] = (u16)e1; n2++; }
+                                        if (!is_dead(e2)) { ql[n2] = (u16)e2; n2++; }
+                                        if (!is_dead(e3)) { ql[n2] = (u16)e3; n2++; }
+                                        c = n2;
+                                    }
+                                } else if (c >= list_cap(q)) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
                                 ql[c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
                                 cinval(q);                               // q's live-neighbour set changed: its cached candidates are stale
                             }
@@ -1206,7 +1223,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     L.off_h_nboff = carve((size_t)L.NB2 * 2); L.off_h_nbcnt = carve((size_t)L.NB2 * 2); L.off_h_pool = carve((size_t)L.pool_cap * 2);
     L.frame_bytes = off;
     // peac_ahc: heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
-    o->smem = L.NB * 8 + L.NB * 2 + L.pool_cap * 2 + L.NB2 * 4 + L.NB * 2 + L.NB2 * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + 16;
+    o->smem = L.NB * 8 + L.NB * 2 + L.NB2 * 4 + L.NB * 2 + L.NB2 * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
     const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
