@@ -222,7 +222,7 @@ constexpr int NT = 256;
 typedef unsigned short u16;
 
 struct Lds {
-    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; u16* dsp; u16* dss; u16* rid; unsigned* nouse; unsigned* cval; signed char* blk;
+    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; unsigned char* nb_cntb; u16* dsp; u16* dss; u16* rid; unsigned* nouse; unsigned* cval; signed char* blk;
 };
 
 __device__ __forceinline__ int lds_find(u16* parent, int x) {   // DisjointSet::Find with path compression
@@ -278,17 +278,19 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         S.h_mse = (double*)smem;
         S.h_id = (u16*)(S.h_mse + NB);
         S.pool = (u16*)(F + L.off_h_pool);        // neighbour lists: global memory (L2 resident); LDS holds what every pop / merge chases
-        S.nb_off = S.h_id + NB;
-        S.nb_cnt = S.nb_off + L.NB2;
-        S.dss = S.nb_cnt + L.NB2;
-        S.rid = S.dss + NB;                       // rid of every node (root block id)
-        S.nouse = (unsigned*)(S.rid + L.NB2);     // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
+        // LDS holds what every pop / merge chases: the heap, the list offsets / counts of the MERGED nodes (a block's list sits at
+        // 4 * id, its count fits a byte) and the dead / cache-valid bits.  Set sizes, root ids and DisjointSet parents are only written
+        // here (the node's own N travels with its moments), so they live in the frame workspace where peac_refine reads them.
+        S.nb_off = S.h_id + NB;                   // [NB] merged node NB + i
+        S.nb_cnt = S.nb_off + NB;                 // [NB] merged node NB + i
+        S.nouse = (unsigned*)(S.nb_cnt + NB);     // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
         S.cval = S.nouse + (L.NB2 + 31) / 32;     // bit per node: its cached candidate record (g_cint / g_cdbl) is valid for its current live-neighbour set
-        S.dsp = (u16*)(F + L.off_h_dsp);          // DisjointSet parents: only written here (Union), read by the refinement kernel
+        S.nb_cntb = (unsigned char*)(S.cval + (L.NB2 + 31) / 32);   // [NB] blocks
+        S.dss = (u16*)(F + L.off_h_dss); S.rid = (u16*)(F + L.off_h_rid); S.dsp = (u16*)(F + L.off_h_dsp);
         S.blk = nullptr;
     } else {
         S.h_mse = s_hm; S.h_id = s_hi;
-        S.pool = (u16*)(F + L.off_h_pool); S.nb_off = (u16*)(F + L.off_h_nboff); S.nb_cnt = (u16*)(F + L.off_h_nbcnt);
+        S.pool = (u16*)(F + L.off_h_pool); S.nb_off = (u16*)(F + L.off_h_nboff); S.nb_cnt = (u16*)(F + L.off_h_nbcnt); S.nb_cntb = nullptr;
         S.dsp = (u16*)(F + L.off_h_dsp); S.dss = (u16*)(F + L.off_h_dss); S.rid = (u16*)(F + L.off_h_rid);
         S.nouse = (unsigned*)(F + L.off_h_nouse); S.cval = (unsigned*)(F + L.off_h_cval);
         S.blk = s_blk;
@@ -298,7 +300,11 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     // every other list keeps it in the pool slot in front of its first entry (no LDS array: the line detector's wavefront, lsd_detect,
     // needs 8 KB on the same CU; no global array: the append would wait a memory round trip per merge)
     bool hdr_all = false;                                     // second ahCluster: every list has the header slot
-    auto list_cap = [&](int q) -> int { return (q < NB && !hdr_all) ? 4 : (int)S.pool[S.nb_off[q] - 1]; };
+    auto noff = [&](int q) -> int { return PHASE == 0 ? (q < NB ? 4 * q : (int)S.nb_off[q - NB]) : (int)S.nb_off[q]; };
+    auto set_noff = [&](int q, int v) { if (PHASE == 0) S.nb_off[q - NB] = (u16)v; else S.nb_off[q] = (u16)v; };
+    auto ncnt = [&](int q) -> int { return PHASE == 0 ? (q < NB ? (int)S.nb_cntb[q] : (int)S.nb_cnt[q - NB]) : (int)S.nb_cnt[q]; };
+    auto set_ncnt = [&](int q, int v) { if (PHASE == 0) { if (q < NB) S.nb_cntb[q] = (unsigned char)v; else S.nb_cnt[q - NB] = (u16)v; } else S.nb_cnt[q] = (u16)v; };
+    auto list_cap = [&](int q) -> int { return (q < NB && !hdr_all) ? 4 : (int)S.pool[noff(q) - 1]; };
 
     constexpr int RP = PHASE == 1 ? MAX_PLANES : 1;           // refinement-only arrays take no LDS in the clustering kernel
     __shared__ int s_ext[MAX_PLANES], s_old[RP], s_plidmap[RP];
@@ -333,7 +339,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
 
     // ---- init (all threads) ----
     if (PHASE == 0) {
-        for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_off[b] = (u16)(4 * b); S.nb_cnt[b] = 0; S.rid[b] = (u16)b; }
+        for (int b = tid; b < NB; b += NT) { S.dsp[b] = (u16)b; S.dss[b] = 1; S.nb_cntb[b] = 0; S.rid[b] = (u16)b; }
         for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) { S.nouse[t] = 0; S.cval[t] = 0; }
         if (tid < 4) s_scalar[tid] = 0;
     } else {
@@ -347,8 +353,8 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     //      vertical pass nodes of one column, each a sequential scan with the reference's --j/++j skip logic, so a
     //      thread owns a whole row / column.  Every block has its own 4-slot list.
     auto connect = [&](int a, int b) {
-        int ca = S.nb_cnt[a]; lst_insert(S.pool + S.nb_off[a], ca, b); S.nb_cnt[a] = (u16)ca;
-        int cb = S.nb_cnt[b]; lst_insert(S.pool + S.nb_off[b], cb, a); S.nb_cnt[b] = (u16)cb;
+        int ca = ncnt(a); lst_insert(S.pool + noff(a), ca, b); set_ncnt(a, ca);
+        int cb = ncnt(b); lst_insert(S.pool + noff(b), cb, a); set_ncnt(b, cb);
     };
     auto inG = [&](int idx) { return (g_flags[idx] & 1) != 0; };
     if (PHASE == 0) {
@@ -456,7 +462,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     // id because new ids are always the largest.
     auto is_dead = [&](int id) { return (S.nouse[id >> 5] >> (id & 31)) & 1u; };
     auto mark_dead = [&](int id) { if (lane == 0) S.nouse[id >> 5] |= 1u << (id & 31); wfence(); };   // PlaneSeg::disconnectAllNbs
-    auto node_N = [&](int id) { return (int)S.dss[S.rid[id]] * (WIN * WIN); };   // live node: rid is its set's root
+    auto node_N = [&](int id) { return g_N[id]; };   // == dss[rid[id]] * 100 for a live node (its rid is its set's root); one load, fetched with the moments
     auto extract = [&](int p) {
         if (node_N(p) >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
     };
@@ -475,7 +481,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         int my_node = -1, my_k = 0, seg_first = 0, seg_cnt = 0;
         for (int i = 0; i < nl; i++)
             if (s_lwave[i] == wave) {
-                const int off = s_loff[i], nd = s_lnode[i], c = S.nb_cnt[nd];
+                const int off = s_loff[i], nd = s_lnode[i], c = ncnt(nd);
                 if (lane >= off && lane < off + c) { my_node = nd; my_k = lane - off; seg_first = off; seg_cnt = c; }
             }
         bool ok = false;
@@ -484,7 +490,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         for (int t = 0; t < 3; t++) { mg.center[t] = 0; mg.normal[t] = 0; }
         mg.mse = 0;
         if (my_node >= 0) {
-            const int x = (S.pool + S.nb_off[my_node])[my_k];
+            const int x = (S.pool + noff(my_node))[my_k];
             if (!is_dead(x)) {
                 nb = x;
                 const double* sp = g_stats + (size_t)my_node * 9;
@@ -561,8 +567,8 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                         cyc[0] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
                         if (is_dead(p)) continue;                           // nouse
                     }
-                    const int cnt = S.nb_cnt[p];
-                    const u16* lst = S.pool + S.nb_off[p];
+                    const int cnt = ncnt(p);
+                    const u16* lst = S.pool + noff(p);
                     const double* sp = g_stats + (size_t)p * 9;
                     const int Np = node_N(p);
                     const double* gp = geo_of(p) + 3;
@@ -592,7 +598,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                             const int hp = lane < heap_n ? (int)S.h_id[lane] : -1;
                             int hc = 0;
                             bool cand = false;
-                            if (hp >= 0 && !is_dead(hp)) { hc = S.nb_cnt[hp]; cand = hc > 0 && hc <= 64 && !cvalid(hp); }
+                            if (hp >= 0 && !is_dead(hp)) { hc = ncnt(hp); cand = hc > 0 && hc <= 64 && !cvalid(hp); }
                             unsigned long long cm = __ballot(cand);
                             int nl = 0, cw = 0, co = cnt;
                             if (lane == 0) { s_lnode[0] = (unsigned short)p; s_lwave[0] = 0; s_loff[0] = 0; }
@@ -676,10 +682,12 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                             S.nouse[nb >> 5] |= 1u << (nb & 31);
                             // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:64-84).  The rid of a live node is its set's root (node_N relies on the
                             // same invariant), so the two Find() calls return their arguments and compress nothing.
+                            // Union by size: size(root) * 100 is the N of the live node whose rid the root is, i.e. Np and Nn
                             const int xr = rp, yr = rn;
                             if (xr != yr) {
-                                if (S.dss[xr] < S.dss[yr]) { S.dsp[xr] = (u16)yr; S.dss[yr] += S.dss[xr]; }
-                                else { S.dsp[yr] = (u16)xr; S.dss[xr] += S.dss[yr]; }
+                                const u16 sz = (u16)((Np + Nn) / (WIN * WIN));
+                                if (Np < Nn) { S.dsp[xr] = (u16)yr; S.dss[yr] = sz; }
+                                else { S.dsp[yr] = (u16)xr; S.dss[xr] = sz; }
                             }
                         }
                         // no wait for these stores: later loads of this wavefront are performed behind them in order, and the other
@@ -688,19 +696,19 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                         cyc[2] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
                         // mergeNbsFrom (AHCPlaneSeg.hpp:379-404): union of the two sorted lists minus {p, nb} (both dead by now),
                         // built cooperatively: prefix counts of the surviving entries, then every entry writes itself to its rank.
-                        const int ca = S.nb_cnt[p], cb = S.nb_cnt[nb];
+                        const int ca = ncnt(p), cb = ncnt(nb);
                         const int need = 2 * (ca + cb) + 3 + (ca + cb) / 4 + 8;
                         if (pool_top + need > L.pool_cap) {             // compact the pool: live merged nodes only (rare)
                             if (lane == 0) {
                                 int top = 4 * NB + 1;                    // first list entry (its capacity header sits at top - 1)
                                 for (int id = NB; id < m; id++) {
-                                    if (is_dead(id) && id != p && id != nb) { S.nb_cnt[id] = 0; continue; }
-                                    const int c = S.nb_cnt[id], o = S.nb_off[id];
+                                    if (is_dead(id) && id != p && id != nb) { set_ncnt(id, 0); continue; }
+                                    const int c = ncnt(id), o = noff(id);
                                     if (top > o) { top = 0x7fff0000; break; }   // a list would grow over unread ones: report a capacity error
                                     int n2 = 0;
                                     for (int t = 0; t < c; t++) { const int v = S.pool[o + t]; if (!is_dead(v) || id == p || id == nb) S.pool[top + n2++] = (u16)v; }   // top <= o: in place
                                     const int cap = (id != p && id != nb) ? n2 + max(8, n2 / 4) : n2;
-                                    S.pool[top - 1] = (u16)cap; S.nb_off[id] = (u16)top; S.nb_cnt[id] = (u16)n2;
+                                    S.pool[top - 1] = (u16)cap; set_noff(id, top); set_ncnt(id, n2);
                                     top += cap + 1;
                                 }
                                 s_scalar[3] = top - 1;
@@ -709,10 +717,10 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                             pool_top = s_scalar[3];
                             if (pool_top > L.pool_cap) { err = 2; break; }
                         }
-                        const int ca2 = S.nb_cnt[p], cb2 = S.nb_cnt[nb];
+                        const int ca2 = ncnt(p), cb2 = ncnt(nb);
                         if (pool_top + 2 * (ca2 + cb2) + 3 + (ca2 + cb2) / 4 + 8 > L.pool_cap) { err = 2; break; }
-                        const u16* A = S.pool + S.nb_off[p];
-                        const u16* Bl = S.pool + S.nb_off[nb];
+                        const u16* A = S.pool + noff(p);
+                        const u16* Bl = S.pool + noff(nb);
                         const int off = pool_top + 1;                   // pool_top itself becomes the capacity header
                         int n;
                         if (ca2 <= 64 && cb2 <= 64) {
@@ -802,15 +810,15 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                         }
                         const int cap = n + max(8, n / 4);
                         pool_top = off + cap;
-                        if (lane == 0) { S.pool[off - 1] = (u16)cap; S.nb_off[m] = (u16)off; S.nb_cnt[m] = (u16)n; S.nb_cnt[p] = 0; S.nb_cnt[nb] = 0; }
+                        if (lane == 0) { S.pool[off - 1] = (u16)cap; set_noff(m, off); set_ncnt(m, n); set_ncnt(p, 0); set_ncnt(nb, 0); }
                         wfence();
                         cyc[3] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
                         {   // nb->nbs.insert(this): m is the largest id so far -> append; a full list is compacted first
                             const u16* lstm = S.pool + off;
                             for (int k = lane; k < n; k += 64) {
                                 const int q = lstm[k];
-                                u16* ql = S.pool + S.nb_off[q];
-                                int c = S.nb_cnt[q];
+                                u16* ql = S.pool + noff(q);
+                                int c = ncnt(q);
                                 if (q < NB && !hdr_all) {
                                     // a block's list: four u16 in one 8-byte word (offset 4 * q).  One load, compaction in registers, one store.
                                     if (c >= 4) {
@@ -824,7 +832,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                                         c = n2;
                                     }
                                 } else if (c >= list_cap(q)) { int n2 = 0; for (int t = 0; t < c; t++) { const int v = ql[t]; if (!is_dead(v)) ql[n2++] = (u16)v; } c = n2; }
-                                ql[c] = (u16)m; S.nb_cnt[q] = (u16)(c + 1);
+                                ql[c] = (u16)m; set_ncnt(q, c + 1);
                                 cinval(q);                               // q's live-neighbour set changed: its cached candidates are stale
                             }
                         }
@@ -884,10 +892,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     mark();
     // hand the clustering state over to peac_refine: set sizes, root ids, dead bits, the extracted planes
     {
-        u16* o_dss = (u16*)(F + L.off_h_dss); u16* o_rid = (u16*)(F + L.off_h_rid);
         unsigned* o_nouse = (unsigned*)(F + L.off_h_nouse); unsigned* o_cval = (unsigned*)(F + L.off_h_cval);
-        for (int b = tid; b < NB; b += NT) o_dss[b] = S.dss[b];
-        for (int b = tid; b < L.NB2; b += NT) o_rid[b] = S.rid[b];
         for (int t = tid; t < (L.NB2 + 31) / 32; t += NT) { o_nouse[t] = S.nouse[t]; o_cval[t] = 0; }
         for (int t = tid; t < MAX_PLANES; t += NT) g_hand[4 + t] = t < n_ext ? s_ext[t] : 0;
     }
@@ -1089,7 +1094,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
             int c = 0;
             for (int r = 0; r < n_old; r++)
                 if (s_adj[q][r >> 5] & (1u << (r & 31))) lst_insert(S.pool + off, c, s_old[r]);
-            S.pool[off - 1] = (u16)n_old; S.nb_off[id] = (u16)off; S.nb_cnt[id] = (u16)c;
+            S.pool[off - 1] = (u16)n_old; set_noff(id, off); set_ncnt(id, c);
             atomicAnd(&S.nouse[id >> 5], ~(1u << (id & 31)));   // back in the graph
         }
         pool_top = n_old * (n_old + 1);
@@ -1223,7 +1228,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     L.off_h_nboff = carve((size_t)L.NB2 * 2); L.off_h_nbcnt = carve((size_t)L.NB2 * 2); L.off_h_pool = carve((size_t)L.pool_cap * 2);
     L.frame_bytes = off;
     // peac_ahc: heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
-    o->smem = L.NB * 8 + L.NB * 2 + L.NB2 * 4 + L.NB * 2 + L.NB2 * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + 16;
+    o->smem = L.NB * 8 + L.NB * 2 + L.NB * 4 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
     const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
