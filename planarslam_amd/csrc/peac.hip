@@ -218,7 +218,8 @@ __global__ __launch_bounds__(64) void peac_blocks(Layout L, Intr K, const uint16
 // K2: one 256-thread workgroup per frame.  Everything the sequential part chases pointers through lives in LDS
 // (merge heap with its MSE keys, the neighbour lists as u16, the disjoint set, the block map); the per-node
 // moments / plane parameters stay in the frame's global workspace and are read once per merge step.
-constexpr int NT = 256;
+constexpr int NT_AHC = 64;       // clustering: two wavefronts per frame (LDS and VGPRs allow three such workgroups per CU)
+constexpr int NT_REFINE = 256;   // refinement: four wavefronts per frame
 typedef unsigned short u16;
 
 struct Lds {
@@ -248,7 +249,7 @@ __device__ __forceinline__ void lst_insert(u16* lst, int& cnt, int v) {
 // refineDetails (block membership, erosion, seeds, flood fill), the final ahCluster over the <= 128 extracted planes and the relabelling;
 // its node-indexed arrays live in the frame's global workspace (a handful of nodes are touched), so it needs ~17 KB of LDS and runs
 // beside the clustering workgroups of other frames.  The code of ahCluster is shared: the pointers of `Lds` point into LDS or global memory.
-template <int PHASE>
+template <int PHASE, int NT>
 __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, const Consts& C, const uint16_t* __restrict__ depth, int pitch_px,
                                               int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
                                               int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
@@ -1145,21 +1146,21 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
 // the next frame from a counter when it STARTS instead of using its block index: frames differ by up to 1.7x in merge steps, the dispatcher
 // deals block indices round-robin over the 8 XCDs, and a periodic mix of frames would otherwise send every slow frame to the same XCD.
 // (A persistent one-workgroup-per-CU loop costs ~50 more VGPRs and with them the co-residency of lsd_detect's wavefront on the same SIMDs.)
-__global__ __launch_bounds__(NT) void peac_ahc(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
+__global__ __launch_bounds__(NT_AHC) void peac_ahc(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
                                                int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
                                                long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order) {
     __shared__ int s_frame;
     if (threadIdx.x == 0) { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
     __syncthreads();
-    segment_frame<0>(L, K, C, depth, pitch_px, frame_stride_px, ws, nullptr, 0, nullptr, nullptr, status, timing, s_frame);
+    segment_frame<0, NT_AHC>(L, K, C, depth, pitch_px, frame_stride_px, ws, nullptr, 0, nullptr, nullptr, status, timing, s_frame);
 }
 
 // peac_refine: one workgroup per frame, ~17 KB of LDS: several per CU, and beside the clustering workgroups of the next launch.
-__global__ __launch_bounds__(NT) void peac_refine(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
+__global__ __launch_bounds__(NT_REFINE) void peac_refine(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
                                                   int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
                                                   int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
                                                   int32_t* __restrict__ status, long long* __restrict__ timing) {
-    segment_frame<1>(L, K, C, depth, pitch_px, frame_stride_px, ws, labels, label_stride, planes, n_planes, status, timing, (int)blockIdx.x);
+    segment_frame<1, NT_REFINE>(L, K, C, depth, pitch_px, frame_stride_px, ws, labels, label_stride, planes, n_planes, status, timing, (int)blockIdx.x);
 }
 
 // Longest-first order for the NEXT call with the same batch size: slot b of a batch is one camera stream, consecutive frames of a stream cost
@@ -1260,11 +1261,11 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     const peac::Intr K{fx, fy, cx, cy, depth_factor};
     hipLaunchKernelGGL(peac::peac_blocks, dim3((p->L.NB + 63) / 64, B), dim3(64), 0, st, p->L, K, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>());
     PLANAR_HIP_CHECK(hipMemsetAsync(p->d_next.p, 0, 4, st));
-    hipLaunchKernelGGL(peac::peac_ahc, dim3(B), dim3(peac::NT), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+    hipLaunchKernelGGL(peac::peac_ahc, dim3(B), dim3(peac::NT_AHC), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
                        p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(), p->d_timing.as<long long>(), p->d_next.as<int>(),
                        p->order_B == B ? p->d_order.as<int>() : nullptr);
     hipLaunchKernelGGL(peac::peac_order, dim3((B + 255) / 256), dim3(256), 0, st, p->d_timing.as<long long>(), B, p->d_order.as<int>());
-    hipLaunchKernelGGL(peac::peac_refine, dim3(B), dim3(peac::NT), 0, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+    hipLaunchKernelGGL(peac::peac_refine, dim3(B), dim3(peac::NT_REFINE), 0, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
                        p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
     p->order_B = B;
     PLANAR_HIP_CHECK(hipGetLastError());
