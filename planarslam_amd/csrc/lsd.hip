@@ -189,10 +189,10 @@ __device__ __forceinline__ void lds_sync();
 //   * __final_insertion_sort is a stable sort of the arrangement the partitions leave = the two radix passes below.
 // Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py).  A depth-limit overflow (heap-sort fallback of introsort)
 // cannot be reproduced this way and raises status 2; it needs ~34 unbalanced partitions in a row and does not occur on 10-bit keys.
-constexpr int SORT_NT = 1024;       // threads of lsd_sort: 16 wavefronts keep 16 sub-ranges (or 16 shares of a big one) in flight
+constexpr int SORT_NT = 256;        // threads of lsd_sort: 16 wavefronts keep 16 sub-ranges (or 16 shares of a big one) in flight
 constexpr int SORT_NW = SORT_NT / 64;
 constexpr int SORT_SMALL = 2048;    // finished by one wavefront
-constexpr int SORT_STAGE = 16384;   // staged in LDS by the workgroup
+constexpr int SORT_STAGE = 4096;    // staged in LDS by the workgroup
 constexpr int SORT_LEAF = 64;       // finished by one lane
 struct SortRange { int f, l, d; };
 
@@ -1635,7 +1635,7 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     if (e == hipSuccess) e = hipMemcpy(o->d_cx.p, cx.data(), cx.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_cy.p, cy.data(), cy.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_taps.p, taps, sizeof(taps), hipMemcpyHostToDevice);
-    o->sort_smem = std::max(32 * lsd::SORT_NT * 4, lsd::SORT_STAGE * 8);
+    o->sort_smem = std::max(32 * lsd::SORT_NW * 4, lsd::SORT_STAGE * 8);   // radix counters [32][SORT_NW] | staged range + the two stop lists
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_detect, hipFuncAttributeMaxDynamicSharedMemorySize, o->detect_smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_sort, hipFuncAttributeMaxDynamicSharedMemorySize, o->sort_smem);
     if (e != hipSuccess) { delete o; set_error("planar_lsd_create: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
