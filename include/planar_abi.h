@@ -472,6 +472,60 @@ int planar_track_manhattan_frame_dev(planar_ctx* ctx, int B, const float* d_R_la
                                      const double* d_line_dirs, const int32_t* d_n_lines, int ln_stride, float* d_R_out, uint8_t* d_member,
                                      int32_t* d_info, float* d_density);
 
+/* ---- Frame-side glue of Tracking::Track (frame.hip) ---------------------------------------------------------------------------
+ * Frame::ComputeStereoFromRGBD (src/Frame.cc:603-621) + Frame::UnprojectStereo (:623-634) for every keypoint of B frames.
+ *   keys / keys_un : [B][stride] mvKeys (the depth image is read at the DISTORTED position, truncated to int) / mvKeysUn
+ *   depth          : B frames of 16-bit depth, row pitch `pitch_px`, frame stride `frame_stride_px` (pixels); the float image the
+ *                    reference indexes is depth * depth_factor in float (imDepth.convertTo(CV_32F, mDepthMapFactor), src/Tracking.cc:174)
+ *   Tcw            : [B][16] the pose UnprojectStereo uses (mRwc, mOw are derived as Frame::UpdatePoseMatrices does)
+ *   u_right, depth_out : [B][stride] mvuRight / mvDepth (-1 where the depth is not positive)
+ *   xw             : [B][stride][3] UnprojectStereo(i) (zeros where it returns an empty Mat), valid[B][stride] = depth > 0          */
+int planar_stereo_from_rgbd(planar_ctx* ctx, int B, const planar_keypoint* keys, const planar_keypoint* keys_un, const int32_t* n, int stride,
+                            const uint16_t* depth, int pitch_px, int64_t frame_stride_px, float depth_factor, float fx, float fy, float cx, float cy,
+                            float bf, const float* Tcw, float* u_right, float* depth_out, float* xw, uint8_t* valid);
+int planar_stereo_from_rgbd_dev(planar_ctx* ctx, int B, const planar_keypoint* d_keys, const planar_keypoint* d_keys_un, const int32_t* d_n, int stride,
+                                const uint16_t* d_depth, int pitch_px, int64_t frame_stride_px, float depth_factor, float fx, float fy, float cx,
+                                float cy, float bf, const float* d_Tcw, float* d_u_right, float* d_depth_out, float* d_xw, uint8_t* d_valid);
+
+/* What Optimizer::PoseOptimization / TranslationOptimization read from the Frame once the matchers have filled mvpMapPoints / mvpMapLines /
+ * mvpMapPlanes / mvpParallelPlanes / mvpVerticalPlanes (src/Optimizer.cc:593-668, 689-745, 859-981), as match INDICES into the arrays of
+ * the matched-against objects.  -1 = no association.                                                                                 */
+typedef struct planar_track_matches {
+    int32_t B;
+    /* points */
+    int32_t stride, mp_stride, n_levels;
+    const int32_t* n;                /* [B]                 Frame::N                                                              */
+    const planar_keypoint* keys_un;  /* [B][stride]         mvKeysUn                                                              */
+    const float* u_right;            /* [B][stride]         mvuRight                                                              */
+    const int32_t* pt_match;         /* [B][stride]         index of the matched map point (what the matchers wrote), -1 = NULL   */
+    const float* mp_xw;              /* [B][mp_stride][3]   GetWorldPos() of the candidate map points                             */
+    const uint8_t* mp_valid;         /* [B][mp_stride] or NULL: the map point exists (e.g. planar_stereo_from_rgbd's `valid`)      */
+    float inv_level_sigma2[PLANAR_MAX_LEVELS]; /* mvInvLevelSigma2                                                                 */
+    /* lines (n_lines == NULL: no lines) */
+    int32_t ln_stride, ml_stride;
+    const int32_t* n_lines;          /* [B]                 Frame::NL                                                             */
+    const double* line_eq;           /* [B][ln_stride][3]   mvKeyLineFunctions                                                    */
+    const int32_t* ln_match;         /* [B][ln_stride]      index of the matched map line                                         */
+    const double* ml_xw6;            /* [B][ml_stride][6]   MapLine::mWorldPos                                                    */
+    /* planes (n_planes == NULL: no planes) */
+    int32_t pl_stride, mpl_stride, mpl_shared;   /* mpl_shared != 0: one map-plane array for all frames                            */
+    const int32_t* n_planes;         /* [B]                 Frame::mnPlaneNum                                                     */
+    const float* pl_coef;            /* [B][pl_stride][4]   mvPlaneCoefficients                                                   */
+    const int32_t* pl_match;         /* [3][B][pl_stride]   matched / parallel / vertical map plane (PlaneMatcher's three outputs) */
+    const float* mpl_coef;           /* [B or 1][mpl_stride][4] MapPlane::GetWorldPos()                                           */
+    const float* Tcw;                /* [B][16]             Frame::mTcw the optimiser starts from                                 */
+} planar_track_matches;
+/* Fills the INPUT arrays of `out` (n_points .. Tcw_in; they are written although the struct declares them const) for planar_pose_opt.
+ * Frame b gets min(n[b], out->max_points) points, likewise lines / planes.  Host pointers / device pointers as usual.              */
+int planar_pose_assemble(planar_ctx* ctx, const planar_track_matches* matches, const planar_pose_batch* out);
+int planar_pose_assemble_dev(planar_ctx* ctx, const planar_track_matches* d_matches, const planar_pose_batch* d_out);
+
+/* The loop that follows the optimiser in Tracking::TranslationWithMotionModel / TrackLocalMap (src/Tracking.cc:1784-1812): a match whose
+ * outlier flag is set is dropped (match = -1, flag cleared); kept[b] (or NULL) = matches left.  outlier has row stride flag_stride.  */
+int planar_discard_outliers(planar_ctx* ctx, int B, const int32_t* n, int stride, int flag_stride, int32_t* match, uint8_t* outlier, int32_t* kept);
+int planar_discard_outliers_dev(planar_ctx* ctx, int B, const int32_t* d_n, int stride, int flag_stride, int32_t* d_match, uint8_t* d_outlier,
+                                int32_t* d_kept);
+
 #ifdef __cplusplus
 }
 #endif

@@ -509,3 +509,39 @@ int orc_plane_search_by_coefficients(int B, const int32_t* n_planes, int pl_stri
     return 0;
 }
 }
+
+// ---- Frame::ComputeStereoFromRGBD (src/Frame.cc:603-621) + Frame::UnprojectStereo (:623-634) -----------------------------------------
+// depth: the u16 image; imDepth = convertTo(CV_32F, factor) (src/Tracking.cc:174-175: cvtScale16u32f, float scale, float multiply).
+// Pinned through oracle/_ref/ref_frame "stereo" (the two function bodies extracted from src/Frame.cc); tests/test_oracle_frame_ref.py.
+namespace orc {
+void stereo_from_rgbd(const planar_keypoint* keys, const planar_keypoint* keys_un, int n, const uint16_t* depth, int pitch_px, float factor,
+                      float fx, float fy, float cx, float cy, float bf, const float* Tcw, float* u_right, float* z_out, float* xw, uint8_t* valid) {
+    const FrustumPose P = frustum_pose(Tcw);
+    const float invfx = 1.0f / fx, invfy = 1.0f / fy;        // src/Frame.cc:127-128
+    for (int i = 0; i < n; i++) {
+        const int v = (int)keys[i].y, u = (int)keys[i].x;      // imDepth.at<float>(v, u): float coordinates truncate
+        const float d = (float)depth[(size_t)v * pitch_px + u] * factor;
+        u_right[i] = -1.f; z_out[i] = -1.f; valid[i] = 0;
+        xw[3 * i] = xw[3 * i + 1] = xw[3 * i + 2] = 0.f;
+        if (d > 0) {
+            z_out[i] = d;
+            u_right[i] = keys_un[i].x - bf / d;
+            const float z = d, x = (keys_un[i].x - cx) * z * invfx, y = (keys_un[i].y - cy) * z * invfy;
+            // mRwc * x3Dc + mOw: mRwc = mRcw.t() materialised, plain 3x3 by 3x1 product = small-matrix gemm (float sums), + C in double
+            const float xc[3] = {x, y, z};
+            for (int r = 0; r < 3; r++) {
+                float t = P.Rcw[r] * xc[0];                    // Rwc(r, k) = Rcw(k, r)
+                t = t + P.Rcw[3 + r] * xc[1];
+                t = t + P.Rcw[6 + r] * xc[2];
+                xw[3 * i + r] = (float)((double)t * 1.0 + (double)P.Ow[r] * 1.0);
+            }
+            valid[i] = 1;
+        }
+    }
+}
+}  // namespace orc
+extern "C" int orc_stereo_from_rgbd(const planar_keypoint* keys, const planar_keypoint* keys_un, int n, const uint16_t* depth, int pitch_px, float factor,
+                                    float fx, float fy, float cx, float cy, float bf, const float* Tcw, float* u_right, float* z_out, float* xw, uint8_t* valid) {
+    orc::stereo_from_rgbd(keys, keys_un, n, depth, pitch_px, factor, fx, fy, cx, cy, bf, Tcw, u_right, z_out, xw, valid);
+    return 0;
+}

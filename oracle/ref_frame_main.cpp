@@ -6,6 +6,7 @@
 //   frustum_lines    Frame::isInFrustum(MapLine*, limit)   (+ MapLine::PredictScale, ...)
 //   area             Frame::AssignFeaturesToGrid + GetFeaturesInArea queries, GetLinesInArea queries
 //   plane_world      Frame::ComputePlaneWorldCoeff
+//   stereo           Frame::ComputeStereoFromRGBD + UnprojectStereo
 // This file only moves data; every computed number comes out of the reference's own function bodies.
 #include <cstdio>
 #include <cstdlib>
@@ -151,6 +152,32 @@ int run_area(Reader& r, Writer& w) {
     return 0;
 }
 
+// Frame::ComputeStereoFromRGBD + UnprojectStereo.  The depth image arrives as the float image Tracking::GrabImageRGBD hands to the Frame
+// (imDepth.convertTo(CV_32F, mDepthMapFactor), src/Tracking.cc:174-175); that conversion is OpenCV's and done by the caller of this harness.
+int run_stereo(Reader& r, Writer& w) {
+    Frame F;
+    set_camera(F, r);
+    Frame::invfx = 1.0f / Frame::fx; Frame::invfy = 1.0f / Frame::fy;       // src/Frame.cc:127-128
+    const float* Tcw = r.arr<float>(16);
+    const int W = r.get<int>(), H = r.get<int>(), N = r.get<int>();
+    const float* depth = r.arr<float>((size_t)W * H);
+    const float* kp = r.arr<float>((size_t)N * 2);
+    F.SetPose(mat_f32(4, 4, Tcw));
+    F.N = N; F.mvKeys.resize(N); F.mvKeysUn.resize(N);
+    for (int i = 0; i < N; i++) { F.mvKeys[i].pt.x = kp[2 * i]; F.mvKeys[i].pt.y = kp[2 * i + 1]; F.mvKeysUn[i] = F.mvKeys[i]; }
+    cv::Mat im(H, W, CV_32F);
+    memcpy(im.data, depth, sizeof(float) * W * H);
+    F.ComputeStereoFromRGBD(im);
+    for (int i = 0; i < N; i++) {
+        w.put(F.mvuRight[i]); w.put(F.mvDepth[i]);
+        cv::Mat x = F.UnprojectStereo(i);
+        float o[3] = {0, 0, 0};
+        if (!x.empty()) for (int k = 0; k < 3; k++) o[k] = x.at<float>(k);
+        w.arr(o, 3);
+    }
+    return 0;
+}
+
 int run_plane_world(Reader& r, Writer& w) {
     Frame F;
     const float* Tcw = r.arr<float>(16);
@@ -172,5 +199,6 @@ int main(int argc, char** argv) {
     if (m == "frustum_lines") return run_frustum_lines(r, w);
     if (m == "area") return run_area(r, w);
     if (m == "plane_world") return run_plane_world(r, w);
+    if (m == "stereo") return run_stereo(r, w);
     return 2;
 }

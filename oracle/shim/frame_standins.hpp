@@ -5,6 +5,7 @@
 //   src/Frame.cc:155-168    Frame::AssignFeaturesToGrid            src/Frame.cc:296-310   SetPose / UpdatePoseMatrices
 //   src/Frame.cc:312-438    Frame::isInFrustum (MapPoint*, MapLine*)
 //   src/Frame.cc:440-535    GetFeaturesInArea / GetLinesInArea / PosInGrid               src/Frame.cc:815-820   ComputePlaneWorldCoeff
+//   src/Frame.cc:603-634    ComputeStereoFromRGBD / UnprojectStereo
 //   src/MapPoint.cc:390-434 Get{Min,Max}DistanceInvariance, PredictScale x2             src/MapLine.cpp:369-390 the same for lines
 //   src/Tracking.cc:763-1157 ProjectSN2MF (5 arguments), ProjectSN2Conic, TrackManhattanFrame, MeanShift
 // The member names and types are the real headers' (include/Frame.h, MapPoint.h, MapLine.h, Tracking.h, LSDextractor.h:33-57,141-199); the
@@ -98,13 +99,16 @@ public:
                                   const int maxLevel = -1) const;
     bool PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY);
     cv::Mat ComputePlaneWorldCoeff(const int& idx);
+    void ComputeStereoFromRGBD(const cv::Mat& imDepth);
+    cv::Mat UnprojectStereo(const int& i);
 
     static float fx, fy, cx, cy, invfx, invfy;
     static float mnMinX, mnMaxX, mnMinY, mnMaxY;
     static float mfGridElementWidthInv, mfGridElementHeightInv;
     float mbf = 0, mb = 0;
     int N = 0;
-    std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    std::vector<float> mvuRight, mvDepth;
     std::vector<cv::line_descriptor::KeyLine> mvKeylinesUn;
     std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
     cv::Mat mTcw, mRcw, mtcw, mRwc, mOw, mTwc;

@@ -69,6 +69,14 @@ class MapProbes(C.Structure):
                                                                    "observed")]
 
 
+class TrackMatches(C.Structure):
+    _fields_ = [("B", C.c_int32), ("stride", C.c_int32), ("mp_stride", C.c_int32), ("n_levels", C.c_int32), ("n", C.c_void_p), ("keys_un", C.c_void_p),
+                ("u_right", C.c_void_p), ("pt_match", C.c_void_p), ("mp_xw", C.c_void_p), ("mp_valid", C.c_void_p), ("inv_level_sigma2", C.c_float * MAX_LEVELS),
+                ("ln_stride", C.c_int32), ("ml_stride", C.c_int32), ("n_lines", C.c_void_p), ("line_eq", C.c_void_p), ("ln_match", C.c_void_p), ("ml_xw6", C.c_void_p),
+                ("pl_stride", C.c_int32), ("mpl_stride", C.c_int32), ("mpl_shared", C.c_int32), ("n_planes", C.c_void_p), ("pl_coef", C.c_void_p),
+                ("pl_match", C.c_void_p), ("mpl_coef", C.c_void_p), ("Tcw", C.c_void_p)]
+
+
 class BAResult(C.Structure):
     _fields_ = [("kf_Tcw", C.c_void_p), ("lm", C.c_void_p), ("e_outlier", C.c_void_p), ("lm_iterations", C.c_int32), ("stopped", C.c_int32)]
 
@@ -147,6 +155,12 @@ _SIGS = {
     "planar_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_comm_destroy": (None, [C.c_void_p]),
     "planar_local_ba": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(PoseParams), C.c_int, C.c_int, C.POINTER(BAResult), C.c_void_p, C.c_void_p]),
+    "planar_stereo_from_rgbd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_float] * 6 + [C.c_void_p] * 5),
+    "planar_stereo_from_rgbd_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_float] * 6 + [C.c_void_p] * 5),
+    "planar_pose_assemble": (C.c_int, [C.c_void_p, C.POINTER(TrackMatches), C.POINTER(PoseBatch)]),
+    "planar_pose_assemble_dev": (C.c_int, [C.c_void_p, C.POINTER(TrackMatches), C.POINTER(PoseBatch)]),
+    "planar_discard_outliers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_discard_outliers_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_pose_opt": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
     "planar_pose_opt_dev": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
 }

@@ -1,0 +1,282 @@
+// planarslam_amd/csrc/frame.hip — the Frame-side glue of Tracking::Track on the device, batched over B independent frames (MI355X / gfx950).
+//
+//   planar_stereo_from_rgbd    Frame::ComputeStereoFromRGBD (reference src/Frame.cc:603-621) + Frame::UnprojectStereo (:623-634): depth and
+//                              virtual right coordinate of every keypoint, and its back-projection to world coordinates
+//   planar_pose_assemble       what Optimizer::PoseOptimization / TranslationOptimization read from the Frame after the matchers ran
+//                              (src/Optimizer.cc:593-668, 689-745, 859-981): mvpMapPoints[i] -> world position, mvKeysUn / mvuRight /
+//                              mvInvLevelSigma2, mvpMapLines[i] -> end points, mvKeyLineFunctions, the three plane associations; i.e. the
+//                              gather from match indices into the structure-of-arrays pose problem (planar_pose_batch)
+//   planar_discard_outliers    the loop after the optimiser (src/Tracking.cc:1784-1812): matches flagged as outliers are dropped
+// All three are gathers over small records: HBM-bound (a few hundred bytes per keypoint), one thread per element, no LDS.
+#include "common.h"
+
+namespace planar {
+namespace frame {
+
+struct Cam { float fx, fy, cx, cy, bf; };
+
+__global__ __launch_bounds__(256) void stereo_kernel(const planar_keypoint* __restrict__ keys, const planar_keypoint* __restrict__ keys_un,
+                                                     const int32_t* __restrict__ n, int stride, const uint16_t* __restrict__ depth, int pitch_px,
+                                                     int64_t frame_stride_px, float factor, Cam K, const float* __restrict__ Tcw,
+                                                     float* __restrict__ u_right, float* __restrict__ z_out, float* __restrict__ xw,
+                                                     uint8_t* __restrict__ valid) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= stride) return;
+    const size_t o = (size_t)b * stride + i;
+    float ur = -1.f, zz = -1.f, X[3] = {0.f, 0.f, 0.f};
+    uint8_t ok = 0;
+    if (i < n[b]) {
+        const float* T = Tcw + (size_t)b * 16;
+        const planar_keypoint kp = keys[o], ku = keys_un[o];
+        const int v = (int)kp.y, u = (int)kp.x;                                    // imDepth.at<float>(v, u)
+        const float d = (float)depth[(size_t)b * frame_stride_px + (size_t)v * pitch_px + u] * factor;   // convertTo(CV_32F, factor): float multiply
+        if (d > 0) {
+            const float invfx = 1.0f / K.fx, invfy = 1.0f / K.fy;
+            zz = d;
+            ur = ku.x - K.bf / d;
+            const float x = (ku.x - K.cx) * d * invfx, y = (ku.y - K.cy) * d * invfy;
+            // mOw = -mRcw.t() * mtcw: transposed operand -> general gemm, double accumulation; mRwc * x3Dc + mOw: small-matrix gemm, float sums
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const double s = (double)T[r] * (double)T[3] + (double)T[4 + r] * (double)T[7] + (double)T[8 + r] * (double)T[11];
+                const float Ow = (float)(s * -1.0);
+                float t = T[r] * x;
+                t = t + T[4 + r] * y;
+                t = t + T[8 + r] * d;
+                X[r] = (float)((double)t * 1.0 + (double)Ow * 1.0);
+            }
+            ok = 1;
+        }
+    }
+    u_right[o] = ur; z_out[o] = zz; valid[o] = ok;
+    xw[3 * o] = X[0]; xw[3 * o + 1] = X[1]; xw[3 * o + 2] = X[2];
+}
+
+struct Assemble {
+    int B;
+    // points
+    int stride, mp_stride;
+    const int32_t* n; const planar_keypoint* keys_un; const float* u_right; const int32_t* pt_match; const float* mp_xw; const uint8_t* mp_valid;
+    float inv_level_sigma2[PLANAR_MAX_LEVELS];
+    // lines
+    int ln_stride, ml_stride;
+    const int32_t* n_lines; const double* line_eq; const int32_t* ln_match; const double* ml_xw6;
+    // planes
+    int pl_stride, mpl_stride, mpl_shared;
+    const int32_t* n_planes; const float* pl_coef; const int32_t* pl_match; const float* mpl_coef;
+    const float* Tcw;
+};
+
+// grid.y = frame, grid.x covers max(max_points, max_lines, max_planes) slots
+__global__ __launch_bounds__(256) void assemble_kernel(Assemble A, int max_points, int max_lines, int max_planes, int32_t* __restrict__ o_np,
+                                                       int32_t* __restrict__ o_nl, int32_t* __restrict__ o_npl, uint8_t* __restrict__ pt_valid,
+                                                       float* __restrict__ pt_xw, float* __restrict__ pt_obs, float* __restrict__ pt_is2,
+                                                       uint8_t* __restrict__ ln_valid, double* __restrict__ ln_obs, double* __restrict__ ln_xw,
+                                                       float* __restrict__ pl_meas, uint8_t* __restrict__ pl_valid, float* __restrict__ pl_world,
+                                                       float* __restrict__ Tcw_in) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int np = min(A.n[b], max_points), nl = A.n_lines ? min(A.n_lines[b], max_lines) : 0, npl = A.n_planes ? min(A.n_planes[b], max_planes) : 0;
+    if (i == 0) { o_np[b] = np; o_nl[b] = nl; o_npl[b] = npl; }
+    if (i < 16) Tcw_in[(size_t)b * 16 + i] = A.Tcw[(size_t)b * 16 + i];
+    if (i < max_points) {
+        const size_t o = (size_t)b * max_points + i;
+        uint8_t ok = 0;
+        float X[3] = {0, 0, 0}, ob[3] = {0, 0, -1.f}, is2 = 1.f;
+        if (i < np) {
+            const size_t k = (size_t)b * A.stride + i;
+            const planar_keypoint kp = A.keys_un[k];
+            ob[0] = kp.x; ob[1] = kp.y; ob[2] = A.u_right[k];
+            is2 = A.inv_level_sigma2[min(max(kp.octave, 0), PLANAR_MAX_LEVELS - 1)];
+            const int m = A.pt_match[k];
+            if (m >= 0 && m < A.mp_stride && (!A.mp_valid || A.mp_valid[(size_t)b * A.mp_stride + m])) {
+                const float* s = A.mp_xw + ((size_t)b * A.mp_stride + m) * 3;
+                X[0] = s[0]; X[1] = s[1]; X[2] = s[2];
+                ok = 1;
+            }
+        }
+        pt_valid[o] = ok; pt_is2[o] = is2;
+        for (int t = 0; t < 3; t++) { pt_xw[3 * o + t] = X[t]; pt_obs[3 * o + t] = ob[t]; }
+    }
+    if (i < max_lines) {
+        const size_t o = (size_t)b * max_lines + i;
+        uint8_t ok = 0;
+        double eq[3] = {0, 0, 0}, X6[6] = {0, 0, 0, 0, 0, 0};
+        if (i < nl) {
+            const size_t k = (size_t)b * A.ln_stride + i;
+            for (int t = 0; t < 3; t++) eq[t] = A.line_eq[3 * k + t];
+            const int m = A.ln_match[k];
+            if (m >= 0 && m < A.ml_stride) { const double* s = A.ml_xw6 + ((size_t)b * A.ml_stride + m) * 6; for (int t = 0; t < 6; t++) X6[t] = s[t]; ok = 1; }
+        }
+        ln_valid[o] = ok;
+        for (int t = 0; t < 3; t++) ln_obs[3 * o + t] = eq[t];
+        for (int t = 0; t < 6; t++) ln_xw[6 * o + t] = X6[t];
+    }
+    if (i < max_planes) {
+        const size_t o = (size_t)b * max_planes + i;
+        float me[4] = {0, 0, 0, 0};
+        if (i < npl) { const float* s = A.pl_coef + ((size_t)b * A.pl_stride + i) * 4; for (int t = 0; t < 4; t++) me[t] = s[t]; }
+        for (int t = 0; t < 4; t++) pl_meas[4 * o + t] = me[t];
+        for (int kind = 0; kind < 3; kind++) {
+            uint8_t ok = 0;
+            float w[4] = {0, 0, 0, 0};
+            if (i < npl) {
+                const int m = A.pl_match[((size_t)kind * A.B + b) * A.pl_stride + i];
+                if (m >= 0 && m < A.mpl_stride) {
+                    const float* s = A.mpl_coef + ((size_t)(A.mpl_shared ? 0 : b) * A.mpl_stride + m) * 4;
+                    for (int t = 0; t < 4; t++) w[t] = s[t];
+                    ok = 1;
+                }
+            }
+            pl_valid[3 * o + kind] = ok;
+            for (int t = 0; t < 4; t++) pl_world[(3 * o + kind) * 4 + t] = w[t];
+        }
+    }
+}
+
+// match[i] = -1 where the optimiser flagged element i as an outlier (and the flag is cleared); kept[b] = matches left
+__global__ __launch_bounds__(256) void discard_kernel(const int32_t* __restrict__ n, int stride, int flag_stride, int32_t* __restrict__ match,
+                                                      uint8_t* __restrict__ outlier, int32_t* __restrict__ kept) {
+    const int b = blockIdx.x;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < min(n[b], stride); i += blockDim.x) {
+        const size_t k = (size_t)b * stride + i;
+        if (match[k] >= 0) {
+            if (i < flag_stride && outlier[(size_t)b * flag_stride + i]) { match[k] = -1; outlier[(size_t)b * flag_stride + i] = 0; }
+            else cnt++;
+        }
+    }
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && kept) kept[b] = s_cnt;
+}
+
+}  // namespace frame
+}  // namespace planar
+
+using namespace planar;
+
+extern "C" {
+
+int planar_stereo_from_rgbd_dev(planar_ctx* ctx, int B, const planar_keypoint* d_keys, const planar_keypoint* d_keys_un, const int32_t* d_n, int stride,
+                                const uint16_t* d_depth, int pitch_px, int64_t frame_stride_px, float depth_factor, float fx, float fy, float cx,
+                                float cy, float bf, const float* d_Tcw, float* d_u_right, float* d_depth_out, float* d_xw, uint8_t* d_valid) {
+    PLANAR_REQUIRE(ctx && d_keys && d_keys_un && d_n && d_depth && d_Tcw && d_u_right && d_depth_out && d_xw && d_valid, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && stride >= 1 && pitch_px >= 1, PLANAR_EINVAL, "bad size");
+    const frame::Cam K{fx, fy, cx, cy, bf};
+    hipLaunchKernelGGL(frame::stereo_kernel, dim3((stride + 255) / 256, B), dim3(256), 0, ctx->stream, d_keys, d_keys_un, d_n, stride, d_depth, pitch_px,
+                       frame_stride_px, depth_factor, K, d_Tcw, d_u_right, d_depth_out, d_xw, d_valid);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_pose_assemble_dev(planar_ctx* ctx, const planar_track_matches* m, const planar_pose_batch* out) {
+    PLANAR_REQUIRE(ctx && m && out, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(m->B >= 1 && m->B == out->B, PLANAR_EINVAL, "batch sizes differ");
+    PLANAR_REQUIRE(m->n && m->keys_un && m->u_right && m->pt_match && m->mp_xw && m->Tcw, PLANAR_EINVAL, "null point arrays");
+    PLANAR_REQUIRE(out->max_points >= 1 && out->max_lines >= 0 && out->max_planes >= 0, PLANAR_EINVAL, "bad capacities");
+    PLANAR_REQUIRE(m->n_levels >= 1 && m->n_levels <= PLANAR_MAX_LEVELS, PLANAR_EINVAL, "n_levels out of range");
+    frame::Assemble A{};
+    A.B = m->B; A.stride = m->stride; A.mp_stride = m->mp_stride;
+    A.n = m->n; A.keys_un = m->keys_un; A.u_right = m->u_right; A.pt_match = m->pt_match; A.mp_xw = m->mp_xw; A.mp_valid = m->mp_valid;
+    for (int l = 0; l < PLANAR_MAX_LEVELS; l++) A.inv_level_sigma2[l] = l < m->n_levels ? m->inv_level_sigma2[l] : 1.f;
+    A.ln_stride = m->ln_stride; A.ml_stride = m->ml_stride; A.n_lines = m->n_lines; A.line_eq = m->line_eq; A.ln_match = m->ln_match; A.ml_xw6 = m->ml_xw6;
+    A.pl_stride = m->pl_stride; A.mpl_stride = m->mpl_stride; A.mpl_shared = m->mpl_shared; A.n_planes = m->n_planes; A.pl_coef = m->pl_coef;
+    A.pl_match = m->pl_match; A.mpl_coef = m->mpl_coef; A.Tcw = m->Tcw;
+    if (out->max_lines > 0) PLANAR_REQUIRE(!A.n_lines || (A.line_eq && A.ln_match && A.ml_xw6), PLANAR_EINVAL, "null line arrays");
+    if (out->max_planes > 0) PLANAR_REQUIRE(!A.n_planes || (A.pl_coef && A.pl_match && A.mpl_coef), PLANAR_EINVAL, "null plane arrays");
+    const int cover = std::max(std::max(out->max_points, out->max_lines), std::max(out->max_planes, 16));
+    hipLaunchKernelGGL(frame::assemble_kernel, dim3((cover + 255) / 256, m->B), dim3(256), 0, ctx->stream, A, out->max_points, out->max_lines, out->max_planes,
+                       const_cast<int32_t*>(out->n_points), const_cast<int32_t*>(out->n_lines), const_cast<int32_t*>(out->n_planes),
+                       const_cast<uint8_t*>(out->pt_valid), const_cast<float*>(out->pt_xw), const_cast<float*>(out->pt_obs), const_cast<float*>(out->pt_inv_sigma2),
+                       const_cast<uint8_t*>(out->ln_valid), const_cast<double*>(out->ln_obs), const_cast<double*>(out->ln_xw), const_cast<float*>(out->pl_meas),
+                       const_cast<uint8_t*>(out->pl_valid), const_cast<float*>(out->pl_world), const_cast<float*>(out->Tcw_in));
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_discard_outliers_dev(planar_ctx* ctx, int B, const int32_t* d_n, int stride, int flag_stride, int32_t* d_match, uint8_t* d_outlier, int32_t* d_kept) {
+    PLANAR_REQUIRE(ctx && d_n && d_match && d_outlier, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && stride >= 1 && flag_stride >= 1, PLANAR_EINVAL, "bad size");
+    hipLaunchKernelGGL(frame::discard_kernel, dim3(B), dim3(256), 0, ctx->stream, d_n, stride, flag_stride, d_match, d_outlier, d_kept);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+// ---- host-pointer versions: stage in, run, stage out, synchronous ----
+int planar_stereo_from_rgbd(planar_ctx* ctx, int B, const planar_keypoint* keys, const planar_keypoint* keys_un, const int32_t* n, int stride,
+                            const uint16_t* depth, int pitch_px, int64_t frame_stride_px, float depth_factor, float fx, float fy, float cx, float cy,
+                            float bf, const float* Tcw, float* u_right, float* depth_out, float* xw, uint8_t* valid) {
+    PLANAR_REQUIRE(ctx && keys && keys_un && n && depth && Tcw && u_right && depth_out && xw && valid, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && stride >= 1 && pitch_px >= 1 && frame_stride_px >= pitch_px, PLANAR_EINVAL, "bad size");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    const size_t ns = (size_t)B * stride;
+    const int i0 = s.in(keys, ns * sizeof(planar_keypoint)), i1 = keys_un == keys ? i0 : s.in(keys_un, ns * sizeof(planar_keypoint)), i2 = s.in(n, (size_t)B * 4);
+    const int i3 = s.in(depth, (size_t)B * frame_stride_px * 2), i4 = s.in(Tcw, (size_t)B * 64);
+    const int o0 = s.out(u_right, ns * 4), o1 = s.out(depth_out, ns * 4), o2 = s.out(xw, ns * 12), o3 = s.out(valid, ns);
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    rc = planar_stereo_from_rgbd_dev(ctx, B, s.dev<planar_keypoint>(i0), s.dev<planar_keypoint>(i1), s.dev<int32_t>(i2), stride, s.dev<uint16_t>(i3), pitch_px,
+                                     frame_stride_px, depth_factor, fx, fy, cx, cy, bf, s.dev<float>(i4), s.dev<float>(o0), s.dev<float>(o1), s.dev<float>(o2),
+                                     s.dev<uint8_t>(o3));
+    if (rc) return rc;
+    return s.download(ctx->stream);
+}
+
+int planar_pose_assemble(planar_ctx* ctx, const planar_track_matches* m, const planar_pose_batch* out) {
+    PLANAR_REQUIRE(ctx && m && out, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(m->B >= 1 && m->B == out->B, PLANAR_EINVAL, "batch sizes differ");
+    PLANAR_REQUIRE(m->n && m->keys_un && m->u_right && m->pt_match && m->mp_xw && m->Tcw, PLANAR_EINVAL, "null point arrays");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    const size_t B = (size_t)m->B;
+    planar_track_matches d = *m;
+    planar_pose_batch o = *out;
+    const int a0 = s.in(m->n, B * 4), a1 = s.in(m->keys_un, B * m->stride * sizeof(planar_keypoint)), a2 = s.in(m->u_right, B * m->stride * 4);
+    const int a3 = s.in(m->pt_match, B * m->stride * 4), a4 = s.in(m->mp_xw, B * m->mp_stride * 12), a5 = m->mp_valid ? s.in(m->mp_valid, B * m->mp_stride) : -1;
+    const bool ln = m->n_lines != nullptr && out->max_lines > 0, pl = m->n_planes != nullptr && out->max_planes > 0;
+    int b0 = -1, b1 = -1, b2 = -1, b3 = -1, c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+    if (ln) { b0 = s.in(m->n_lines, B * 4); b1 = s.in(m->line_eq, B * m->ln_stride * 24); b2 = s.in(m->ln_match, B * m->ln_stride * 4); b3 = s.in(m->ml_xw6, B * m->ml_stride * 48); }
+    if (pl) { c0 = s.in(m->n_planes, B * 4); c1 = s.in(m->pl_coef, B * m->pl_stride * 16); c2 = s.in(m->pl_match, 3 * B * m->pl_stride * 4);
+              c3 = s.in(m->mpl_coef, (m->mpl_shared ? 1 : B) * (size_t)m->mpl_stride * 16); }
+    const int t0 = s.in(m->Tcw, B * 64);
+    const size_t MP = out->max_points, ML = std::max(out->max_lines, 1), MM = std::max(out->max_planes, 1);
+    const int o0 = s.out((void*)out->n_points, B * 4), o1 = s.out((void*)out->n_lines, B * 4), o2 = s.out((void*)out->n_planes, B * 4);
+    const int o3 = s.out((void*)out->pt_valid, B * MP), o4 = s.out((void*)out->pt_xw, B * MP * 12), o5 = s.out((void*)out->pt_obs, B * MP * 12), o6 = s.out((void*)out->pt_inv_sigma2, B * MP * 4);
+    const int o7 = s.out((void*)out->ln_valid, out->max_lines ? B * ML : 0), o8 = s.out((void*)out->ln_obs, out->max_lines ? B * ML * 24 : 0), o9 = s.out((void*)out->ln_xw, out->max_lines ? B * ML * 48 : 0);
+    const int p0 = s.out((void*)out->pl_meas, out->max_planes ? B * MM * 16 : 0), p1 = s.out((void*)out->pl_valid, out->max_planes ? B * MM * 3 : 0), p2 = s.out((void*)out->pl_world, out->max_planes ? B * MM * 48 : 0);
+    const int p3 = s.out((void*)out->Tcw_in, B * 64);
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    d.n = s.dev<int32_t>(a0); d.keys_un = s.dev<planar_keypoint>(a1); d.u_right = s.dev<float>(a2); d.pt_match = s.dev<int32_t>(a3); d.mp_xw = s.dev<float>(a4);
+    d.mp_valid = a5 >= 0 ? s.dev<uint8_t>(a5) : nullptr;
+    d.n_lines = ln ? s.dev<int32_t>(b0) : nullptr; d.line_eq = ln ? s.dev<double>(b1) : nullptr; d.ln_match = ln ? s.dev<int32_t>(b2) : nullptr; d.ml_xw6 = ln ? s.dev<double>(b3) : nullptr;
+    d.n_planes = pl ? s.dev<int32_t>(c0) : nullptr; d.pl_coef = pl ? s.dev<float>(c1) : nullptr; d.pl_match = pl ? s.dev<int32_t>(c2) : nullptr; d.mpl_coef = pl ? s.dev<float>(c3) : nullptr;
+    d.Tcw = s.dev<float>(t0);
+    o.n_points = s.dev<int32_t>(o0); o.n_lines = s.dev<int32_t>(o1); o.n_planes = s.dev<int32_t>(o2); o.pt_valid = s.dev<uint8_t>(o3); o.pt_xw = s.dev<float>(o4);
+    o.pt_obs = s.dev<float>(o5); o.pt_inv_sigma2 = s.dev<float>(o6); o.ln_valid = s.dev<uint8_t>(o7); o.ln_obs = s.dev<double>(o8); o.ln_xw = s.dev<double>(o9);
+    o.pl_meas = s.dev<float>(p0); o.pl_valid = s.dev<uint8_t>(p1); o.pl_world = s.dev<float>(p2); o.Tcw_in = s.dev<float>(p3);
+    rc = planar_pose_assemble_dev(ctx, &d, &o);
+    if (rc) return rc;
+    return s.download(ctx->stream);
+}
+
+int planar_discard_outliers(planar_ctx* ctx, int B, const int32_t* n, int stride, int flag_stride, int32_t* match, uint8_t* outlier, int32_t* kept) {
+    PLANAR_REQUIRE(ctx && n && match && outlier, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && stride >= 1 && flag_stride >= 1, PLANAR_EINVAL, "bad size");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    const int i0 = s.in(n, (size_t)B * 4), i1 = s.inout(match, (size_t)B * stride * 4), i2 = s.inout(outlier, (size_t)B * flag_stride);
+    const int o0 = kept ? s.out(kept, (size_t)B * 4) : s.add(nullptr, nullptr, (size_t)B * 4);
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    rc = planar_discard_outliers_dev(ctx, B, s.dev<int32_t>(i0), stride, flag_stride, s.dev<int32_t>(i1), s.dev<uint8_t>(i2), s.dev<int32_t>(o0));
+    if (rc) return rc;
+    return s.download(ctx->stream);
+}
+
+}  // extern "C"

@@ -22,3 +22,19 @@ def frustum_case():
 def frustum_scale():
     import numpy as np
     return float(np.float32(np.log(np.float32(1.2)))), 8       # Frame::mfLogScaleFactor = log(mfScaleFactor) (float), mnScaleLevels
+
+
+def stereo_case():
+    """Keypoints (incl. image-border positions and zero-depth holes), a depth frame and a pose for Frame::ComputeStereoFromRGBD / UnprojectStereo."""
+    import numpy as np
+    from planarslam_amd._lib import KP_DTYPE
+    rng = np.random.default_rng(33)
+    B, S = 3, 1100
+    depth = np.stack([synth.depth_image(4321 + i) for i in range(B)])
+    keys = np.zeros((B, S), KP_DTYPE)
+    keys["x"] = rng.uniform(0, 639.99, (B, S)).astype(np.float32); keys["y"] = rng.uniform(0, 479.99, (B, S)).astype(np.float32)
+    keys["x"][:, :4] = [0.0, 639.0, 0.49, 638.51]; keys["y"][:, :4] = [0.0, 479.0, 478.51, 0.49]
+    keys["octave"] = rng.integers(0, 8, (B, S))
+    n = np.array([S, 1000, 37], np.int32)
+    Tcw = np.stack([synth._se3(rng, 0.3, rng.normal(0, 0.5, 3)).astype(np.float32).ravel() for _ in range(B)])
+    return keys, n, depth, Tcw

@@ -685,3 +685,28 @@ def run_ref_frustum_lines(frame, ml, b, log_scale_factor, limit=0.5):
            c(ml["max_dist"][b, idx], np.float32).tobytes())
     rec = np.frombuffer(_run_ref_frame("frustum_lines", pay), np.dtype([("ret", "u1"), ("p", "<f4", 4), ("level", "<i4"), ("vc", "<f4")]))
     return idx, rec
+
+
+def stereo_from_rgbd(keys, depth, Tcw, cam, depth_factor=1.0 / 5000.0):
+    """CPU oracle of Frame::ComputeStereoFromRGBD + UnprojectStereo for ONE frame: keys [n] KP_DTYPE, depth [H, W] uint16."""
+    L = lib()
+    keys = np.ascontiguousarray(keys, KP_DTYPE); depth = np.ascontiguousarray(depth, np.uint16); Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    n = len(keys)
+    out = dict(u_right=np.zeros(n, np.float32), depth=np.zeros(n, np.float32), xw=np.zeros((n, 3), np.float32), valid=np.zeros(n, np.uint8))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.orc_stereo_from_rgbd(p(keys), p(keys), C.c_int(n), p(depth), C.c_int(depth.shape[1]), C.c_float(np.float32(depth_factor)), C.c_float(cam["fx"]), C.c_float(cam["fy"]),
+                           C.c_float(cam["cx"]), C.c_float(cam["cy"]), C.c_float(cam["bf"]), p(Tcw), p(out["u_right"]), p(out["depth"]), p(out["xw"]), p(out["valid"]))
+    return out
+
+
+def run_ref_stereo(keys, depth, Tcw, cam, depth_factor=1.0 / 5000.0):
+    """The reference's own Frame::ComputeStereoFromRGBD + UnprojectStereo (oracle/_ref/ref_frame stereo) for one frame.  The float depth image
+    is what imDepth.convertTo(CV_32F, factor) produces: float(u16) * float(factor)."""
+    keys = np.ascontiguousarray(keys, KP_DTYPE); depth = np.ascontiguousarray(depth, np.uint16)
+    H, W = depth.shape
+    imf = (depth.astype(np.float32) * np.float32(depth_factor)).astype(np.float32)
+    frame = dict(fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], bf=cam["bf"], min_x=0.0, max_x=float(W), min_y=0.0, max_y=float(H))
+    kp = np.stack([keys["x"], keys["y"]], 1).astype(np.float32)
+    pay = (_camera_block(frame, 0.18, 8) + np.ascontiguousarray(Tcw, np.float32).tobytes() + np.array([W, H, len(keys)], np.int32).tobytes() + imf.tobytes() + kp.tobytes())
+    rec = np.frombuffer(_run_ref_frame("stereo", pay), np.dtype([("u_right", "<f4"), ("depth", "<f4"), ("xw", "<f4", 3)]))
+    return rec

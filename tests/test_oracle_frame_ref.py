@@ -56,6 +56,18 @@ def test_frustum_oracle_equals_reference_fixture(golden):
         assert np.array_equal(o[k][il > 0], golden[f"frustum/lines/{k}"][il > 0]), k
 
 
+def test_stereo_oracle_equals_reference_fixture(golden):
+    """Frame::ComputeStereoFromRGBD + UnprojectStereo (src/Frame.cc:603-634): mvuRight, mvDepth and the world point, every bit."""
+    from planarslam_amd.synth import TUM3
+    keys, n, depth, Tcw = cases.stereo_case()
+    for b in range(len(n)):
+        o = ol.stereo_from_rgbd(keys[b, :n[b]], depth[b], Tcw[b], TUM3)
+        assert 0.5 < o["valid"].mean() <= 1.0
+        for k in ("u_right", "depth", "xw"):
+            assert np.array_equal(o[k], golden[f"stereo/{k}"][b, :n[b]]), k
+        assert np.array_equal(o["valid"] > 0, golden["stereo/depth"][b, :n[b]] > 0)
+
+
 @pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref/ref_frame not built")
 def test_fixtures_are_what_the_reference_produces_now(golden):
     sc = synth.manhattan_scene(**cases.MANHATTAN_CASES["no_z"])

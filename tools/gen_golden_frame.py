@@ -41,6 +41,14 @@ for k, v in pt.items():
     out[f"frustum/points/{k}"] = v
 for k, v in ln.items():
     out[f"frustum/lines/{k}"] = v
+keys, n, depth, Tcw = cases.stereo_case()
+B, S = keys.shape
+st = dict(u_right=np.full((B, S), -1, np.float32), depth=np.full((B, S), -1, np.float32), xw=np.zeros((B, S, 3), np.float32))
+for b in range(B):
+    rec = O.run_ref_stereo(keys[b, :n[b]], depth[b], Tcw[b], synth.TUM3)
+    st["u_right"][b, :n[b]] = rec["u_right"]; st["depth"][b, :n[b]] = rec["depth"]; st["xw"][b, :n[b]] = rec["xw"]
+for k, v in st.items():
+    out[f"stereo/{k}"] = v
 path = os.path.join(ROOT, "tests", "golden", "frame_ref.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
