@@ -604,3 +604,30 @@ def ba_local_only(prob):
     for k in ("e_kf", "e_obs_kf", "e_lm", "e_type", "e_meas", "e_inv_sigma2"):
         out[k] = np.ascontiguousarray(prob[k][keep])
     return out
+
+
+# ---- camera streams for bench.py: larger canvases a 640x480 window pans over (consecutive frames of a stream overlap like video) --------
+def _canvas_job(args):
+    kind, seed, w, h = args
+    return gray_image(seed, w, h) if kind == 0 else depth_image(seed, w, h)
+
+
+def stream_canvases(P, seed, w, h, procs=None):
+    """P gray (uint8) and P depth (uint16) canvases of w x h, generated on `procs` worker processes (call before CUDA is initialised)."""
+    import multiprocessing as mp
+    import os
+    jobs = [(0, 1234 + seed * 4096 + i, w, h) for i in range(P)] + [(1, 4321 + seed * 4096 + i, w, h) for i in range(P)]
+    procs = procs or min(32, os.cpu_count() or 1)
+    if procs <= 1:
+        res = [_canvas_job(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(procs) as pool:
+            res = pool.map(_canvas_job, jobs, chunksize=max(1, len(jobs) // (4 * procs)))
+    return np.stack(res[:P]), np.stack(res[P:])
+
+
+def pan_offset(i, margin=48, amp=20):
+    """Top-left corner of the window at step i: a slow Lissajous path inside the margin (<= ~8 px per step)."""
+    ox = margin // 2 + int(round(amp * np.sin(2 * np.pi * i / 17.0)))
+    oy = margin // 2 + int(round(amp * np.sin(2 * np.pi * i / 23.0 + 1.0)))
+    return ox, oy

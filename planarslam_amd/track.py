@@ -1,0 +1,357 @@
+"""Device-resident Tracking::Track over B independent camera streams (one frame per stream per step), software-pipelined.
+
+The sequence of the reference's tracking thread for one RGB-D frame (src/Tracking.cc), every stage a batched HIP kernel behind the C ABI:
+
+    Frame::Frame (src/Frame.cc:55-152)        ORBextractor, LineSegment::ExtractLineSegment, PlaneDetection (three streams, as its three
+                                              threads :90-95), ComputeStereoFromRGBD
+    Track (:248)                              TrackManhattanFrame(mLastRcm, surface normals, 3-D line directions)
+    TranslationWithMotionModel (:1739-1790)   SearchByProjection(Cur, Last, 15) - LSDmatcher::SearchByDescriptor(refKF) - MatchORBPoints
+                                              (the reference runs it only when < 50 projection matches; here for every frame: a superset) -
+                                              PlaneMatcher::SearchMapByCoefficients - TranslationOptimization - discard outliers
+    TrackLocalMap / SearchLocalPoints         Frame::isInFrustum for the local map points and lines - SearchByProjection(F, vpMapPoints, 3) -
+    (:1954-2040)                              LSDmatcher::SearchByProjection - PoseOptimization - UnprojectStereo of the new frame's keypoints
+                                              (the next frame's "last frame" map points)
+
+What is NOT the reference's code path and only stands in for the map it maintains (Map / KeyFrame / LocalMapping are out of scope):
+the local map of a stream is the previous two frames' own back-projected keypoints, the reference key frame's lines and the map planes are
+fixed per stream (set_map), the surface normals of the Manhattan tracker are a resident array (their PCL producer is not built), and
+MapPoint::UpdateNormalAndDepth / the plane coefficient (n, -n.c) of Frame::ComputePlanes are a few torch element-wise ops here.
+
+PyTorch supplies device memory, streams and events only.  Frame-batch parallelism: steps are pipelined `depth` deep - the tracking chain of
+step i - depth runs behind the extraction launches of step i, whose line / plane kernels fill the CUs meanwhile."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import KEYLINE_DTYPE, FrameView, LastFrameView, MapProbes, PoseBatch, TrackMatches, check, lib
+
+
+class TrackPipeline:
+    MAX_POSE_PLANES = 16
+
+    def __init__(self, B, torch, device_index=0, depth=2, prio=(-1, 0, 0), cam=None, W=640, H=480, n_map_planes=8, n_plane_pts=128, n_normals=4096,
+                 run_fallback_matcher=True):
+        from . import Context, ORBextractor, Optimizer, PlaneDetection
+        from .lines import LineSegment
+        from .synth import TUM3
+        self.torch, self.B, self.W, self.H, self.depth = torch, B, W, H, depth
+        self.cam = dict(cam or TUM3)
+        self.dev = torch.device("cuda", device_index)
+        self.NB = depth + 2                      # buffer sets: a step's extractor outputs live until the tracking chain `depth` steps later has used them as "last frame"
+        self.L = lib()
+        self.stream = torch.cuda.Stream(device=device_index, priority=prio[0])
+        self.ctx = Context(device_index, stream=self.stream.cuda_stream)
+        self.s_peacs = [torch.cuda.Stream(device=device_index, priority=prio[2]) for _ in range(self.NB)]
+        self.s_lsds = [torch.cuda.Stream(device=device_index, priority=prio[1]) for _ in range(self.NB)]
+        self.ctx_peacs = [Context(device_index, stream=q.cuda_stream) for q in self.s_peacs]
+        self.ctx_lsds = [Context(device_index, stream=q.cuda_stream) for q in self.s_lsds]
+        self.ex = ORBextractor(1000, 1.2, 8, 20, 7, width=W, height=H, max_batch=B, ctx=self.ctx)
+        self.S = S = self.ex.kp_cap
+        self.pds = [PlaneDetection(W, H, max_batch=B, ctx=c) for c in self.ctx_peacs]
+        self.lss = [LineSegment(W, H, B, c) for c in self.ctx_lsds]
+        self.opt = Optimizer(self.cam, ctx=self.ctx)
+        self.PS = self.pds[0].max_planes
+        self.run_fallback_matcher = run_fallback_matcher
+        sf = np.asarray(self.ex.GetScaleFactors(), np.float32)
+        self.sf = sf
+        self.nlev = len(sf)
+        self.lsf = float(np.float32(np.log(np.float32(sf[1]))))
+        self.inv_sigma2 = np.asarray(self.ex.GetInverseScaleSigmaSquares(), np.float32)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)
+        t = torch
+        NB = self.NB
+        # ---- per-step buffers ----
+        self.kps = [z((B, S, 7), t.float32) for _ in range(NB)]
+        self.desc = [z((B, S, 32), t.uint8) for _ in range(NB)]
+        self.n = [z((B,), t.int32) for _ in range(NB)]
+        self.ur = [z((B, S), t.float32) for _ in range(NB)]
+        self.zd = [z((B, S), t.float32) for _ in range(NB)]
+        self.lab = [z((B, H * W), t.int32) for _ in range(NB)]
+        self.pls = [z((B, self.PS, 8), t.float64) for _ in range(NB)]
+        self.npl = [z((B,), t.int32) for _ in range(NB)]
+        self.kls = [z((B * 40 * KEYLINE_DTYPE.itemsize,), t.uint8) for _ in range(NB)]
+        self.ldesc = [z((B, 40, 32), t.uint8) for _ in range(NB)]
+        self.leq = [z((B, 40, 3), t.float64) for _ in range(NB)]
+        self.nl = [z((B,), t.int32) for _ in range(NB)]
+        self.ev_in = [t.cuda.Event() for _ in range(NB)]
+        self.join_p = [t.cuda.Event() for _ in range(NB)]
+        self.join_l = [t.cuda.Event() for _ in range(NB)]
+        self.done = [t.cuda.Event() for _ in range(NB)]
+        # ---- per-stream state: the last two frames' back-projected keypoints (slot-major: one contiguous [B, S] array per slot) ----
+        self.h_xw = z((2, B, S, 3), t.float32); self.h_valid = z((2, B, S), t.uint8); self.h_normal = z((2, B, S, 3), t.float32)
+        self.h_mind = z((2, B, S), t.float32); self.h_maxd = z((2, B, S), t.float32); self.h_desc = z((2, B, S, 32), t.uint8)
+        self.h_oct = z((2, B, S), t.int32); self.h_ang = z((2, B, S), t.float32); self.h_n = z((2, B), t.int32)
+        self.pose = t.eye(4, dtype=t.float32, device=self.dev).reshape(1, 16).repeat(B, 1).contiguous()
+        self.Rcm = t.eye(3, dtype=t.float32, device=self.dev).reshape(1, 9).repeat(B, 1).contiguous()
+        self.ones_S = t.ones((B, S), dtype=t.uint8, device=self.dev)
+        self.zeros_S = z((B, S), t.uint8)
+        # ---- match / optimiser buffers (one set: the tracking chains run in step order on one stream) ----
+        self.pm = z((B, S), t.int32); self.nm = z((B,), t.int32)
+        self.cm2 = z((B, S), t.int32); self.npair = z((B,), t.int32)
+        self.lm = z((B, 40), t.int32); self.nlm = z((B,), t.int32)
+        self.plm = z((3, B, self.PS), t.int32); self.nplm = z((B,), t.int32)
+        self.pl_coef = z((B, self.PS, 4), t.float32)
+        self.mm = z((B, S), t.int32); self.nmm = z((B,), t.int32)
+        self.blocked = z((B, S), t.uint8); self.lblocked = z((B, 40), t.uint8)
+        self.pm_all = z((B, S), t.int32)
+        self.xw_all = z((B, 2 * S, 3), t.float32); self.valid_all = z((B, 2 * S), t.uint8)
+        self.xw_tmp = z((B, S, 3), t.float32); self.valid_tmp = z((B, S), t.uint8)
+        self.pr = dict(in_view=z((B, S), t.uint8), proj_x=z((B, S), t.float32), proj_y=z((B, S), t.float32), proj_xr=z((B, S), t.float32),
+                       level=z((B, S), t.int32), view_cos=z((B, S), t.float32))
+        self.lpr = dict(in_view=z((B, 40), t.uint8), proj=z((B, 40, 4), t.float32), level=z((B, 40), t.int32), view_cos=z((B, 40), t.float32))
+        self.kept = z((B,), t.int32)
+        self.Rcm_new = z((B, 9), t.float32)
+        MP, ML, MM = S, 40, self.MAX_POSE_PLANES
+        self.pb_arrays = []
+        self.pbs = []
+        for _ in range(2):      # [0] translation problem, [1] pose problem
+            a = dict(n_points=z((B,), t.int32), n_lines=z((B,), t.int32), n_planes=z((B,), t.int32), pt_valid=z((B, MP), t.uint8), pt_xw=z((B, MP, 3), t.float32),
+                     pt_obs=z((B, MP, 3), t.float32), pt_inv_sigma2=z((B, MP), t.float32), ln_valid=z((B, ML), t.uint8), ln_obs=z((B, ML, 3), t.float64),
+                     ln_xw=z((B, ML, 6), t.float64), pl_meas=z((B, MM, 4), t.float32), pl_valid=z((B, MM, 3), t.uint8), pl_world=z((B, MM, 3, 4), t.float32),
+                     Tcw_in=z((B, 16), t.float32), Tcw_out=z((B, 16), t.float32), pt_outlier=z((B, MP), t.uint8), ln_outlier=z((B, ML), t.uint8),
+                     pl_outlier=z((B, MM, 3), t.uint8), n_inliers=z((B,), t.int32), lm_iters=z((B,), t.int32))
+            pb = PoseBatch()
+            pb.B, pb.max_points, pb.max_lines, pb.max_planes = B, MP, ML, MM
+            for k, v in a.items():
+                setattr(pb, k, v.data_ptr())
+            self.pb_arrays.append(a); self.pbs.append(pb)
+        self.pending = []
+        self.map_set = False
+        self.step_count = 0
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def set_map(self, kf_lines: dict, map_planes: dict, normals: dict):
+        """Per-stream stand-ins for the map (host numpy, uploaded once):
+        kf_lines   : n [B], ldesc [B,40,32], xw6 [B,40,6] f64, normal [B,40,3] f64, min_dist, max_dist [B,40] f32 (reference key frame's map lines)
+        map_planes : n [B], valid [B,M] u8, coef [B,M,4] f32 (world), npts [B,M] i32, pts [B,M,P,3] f32
+        normals    : normals [B,SN,3] f32, n_normals [B], lines [B,40,3] f64, n_lines [B]  (Frame::vSurfaceNormal, mVF3DLines directions)"""
+        t = self.torch
+        up = lambda a, dt: t.from_numpy(np.ascontiguousarray(a, dt)).to(self.dev)
+        self.kf = dict(n=up(kf_lines["n"], np.int32), ldesc=up(kf_lines["ldesc"], np.uint8), xw6=up(kf_lines["xw6"], np.float64), normal=up(kf_lines["normal"], np.float64),
+                       min_dist=up(kf_lines["min_dist"], np.float32), max_dist=up(kf_lines["max_dist"], np.float32))
+        self.kf["has_ml"] = t.ones((self.B, 40), dtype=t.uint8, device=self.dev)
+        self.mp = dict(n=up(map_planes["n"], np.int32), valid=up(map_planes["valid"], np.uint8), coef=up(map_planes["coef"], np.float32), npts=up(map_planes["npts"], np.int32),
+                       pts=up(map_planes["pts"], np.float32))
+        self.sn = dict(normals=up(normals["normals"], np.float32), n_normals=up(normals["n_normals"], np.int32), lines=up(normals["lines"], np.float64),
+                       n_lines=up(normals["n_lines"], np.int32))
+        if normals.get("R_last") is not None:
+            self.Rcm = up(np.asarray(normals["R_last"], np.float32).reshape(self.B, 9), np.float32)
+        self.plane_th = np.array([0.1, 0.86, 0.08716, 0.9962], np.float32)      # include/PlaneMatcher.h:19
+        self.map_set = True
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def _frame_view(self, k, Tcw, blocked=None):
+        fv = FrameView()
+        fv.B, fv.stride = self.B, self.S
+        fv.n, fv.keys_un, fv.u_right, fv.desc = self.n[k].data_ptr(), self.kps[k].data_ptr(), self.ur[k].data_ptr(), self.desc[k].data_ptr()
+        fv.blocked = blocked.data_ptr() if blocked is not None else None
+        fv.Tcw = Tcw.data_ptr()
+        fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(self.W), 0.0, float(self.H)
+        fv.grid_w_inv, fv.grid_h_inv = 64.0 / self.W, 48.0 / self.H
+        c = self.cam
+        fv.fx, fv.fy, fv.cx, fv.cy, fv.bf, fv.b = c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], c["bf"] / c["fx"]
+        for i, v in enumerate(self.sf):
+            fv.scale_factors[i] = float(v)
+        return fv
+
+    def _stereo(self, k, Tcw, depth, ur, zd, xw, valid):
+        c = self.cam
+        check(self.L.planar_stereo_from_rgbd_dev(self.ctx.h, self.B, self.kps[k].data_ptr(), self.kps[k].data_ptr(), self.n[k].data_ptr(), self.S, depth.data_ptr(),
+                                                 self.W, self.W * self.H, float(np.float32(1.0 / 5000.0)), c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], Tcw.data_ptr(),
+                                                 ur.data_ptr(), zd.data_ptr(), xw.data_ptr(), valid.data_ptr()))
+
+    def _assemble(self, which, k, pt_match, mp_xw, mp_valid, mp_stride, Tcw):
+        m = TrackMatches()
+        m.B, m.stride, m.mp_stride, m.n_levels = self.B, self.S, mp_stride, self.nlev
+        m.n, m.keys_un, m.u_right = self.n[k].data_ptr(), self.kps[k].data_ptr(), self.ur[k].data_ptr()
+        m.pt_match, m.mp_xw, m.mp_valid = pt_match.data_ptr(), mp_xw.data_ptr(), mp_valid.data_ptr()
+        for i, v in enumerate(self.inv_sigma2):
+            m.inv_level_sigma2[i] = float(v)
+        m.ln_stride, m.ml_stride = 40, 40
+        m.n_lines, m.line_eq, m.ln_match, m.ml_xw6 = self.nl[k].data_ptr(), self.leq[k].data_ptr(), self.lm.data_ptr(), self.kf["xw6"].data_ptr()
+        m.pl_stride, m.mpl_stride, m.mpl_shared = self.PS, self.mp["coef"].shape[1], 0
+        m.n_planes, m.pl_coef, m.pl_match, m.mpl_coef = self.npl[k].data_ptr(), self.pl_coef.data_ptr(), self.plm.data_ptr(), self.mp["coef"].data_ptr()
+        m.Tcw = Tcw.data_ptr()
+        check(self.L.planar_pose_assemble_dev(self.ctx.h, C.byref(m), C.byref(self.pbs[which])))
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def step(self, i, gray, depth, evs=None, side=None):
+        """Enqueue step i: extraction of `gray` [B,H,W] u8 / `depth` [B,H,W] i16-as-u16 (device tensors that stay valid until the step's
+        tracking chain has run) on the three streams, then the tracking chain of step i - depth.  evs / side: optional timing events."""
+        t, L, B, k = self.torch, self.L, self.B, i % self.NB
+        sp, sl = self.s_peacs[k], self.s_lsds[k]
+        st = self.stream
+        st.wait_event(self.done[k])                         # the buffers of step i - NB have been consumed
+        self.ev_in[k].record(st)                            # the caller gathered this step's frames on the main stream
+        if evs: evs["start"].record(st)
+        sl.wait_event(self.ev_in[k]); sp.wait_event(self.ev_in[k])
+        if side: side[2].record(sl)
+        check(L.planar_lsd_preprocess_dev(self.lss[k].h, gray.data_ptr(), B, self.W, self.W * self.H))
+        if side: side[0].record(sp)
+        self.pds[k].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), B)
+        check(L.planar_lsd_detect_dev(self.lss[k].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
+        if side: side[1].record(sp); side[3].record(sl)
+        self.join_p[k].record(sp); self.join_l[k].record(sl)
+        self.ex.extract_dev(gray.data_ptr(), self.kps[k].data_ptr(), self.desc[k].data_ptr(), self.n[k].data_ptr(), B)
+        if evs: evs["orb"].record(st)
+        # Frame::ComputeStereoFromRGBD: mvuRight / mvDepth of the new keypoints (the world points come after the pose is known)
+        self._stereo(k, self.pose, depth, self.ur[k], self.zd[k], self.xw_tmp, self.valid_tmp)
+        if evs: evs["stereo"].record(st)
+        self.pending.append((i, depth, evs))
+        if len(self.pending) > self.depth:
+            self._track(*self.pending.pop(0))
+        self.step_count += 1
+
+    def drain(self):
+        while self.pending:
+            self._track(*self.pending.pop(0))
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def _track(self, j, depth, evs):
+        t, L, B, S, k = self.torch, self.L, self.B, self.S, j % self.NB
+        st = self.stream
+        l, o = (j - 1) % 2, j % 2                           # history slots: last frame / the one before (overwritten by this frame at the end)
+        if evs: evs["wait0"].record(st)
+        st.wait_event(self.join_p[k]); st.wait_event(self.join_l[k])
+        if evs: evs["wait1"].record(st)
+        if j >= 2 and self.map_set:
+            # ---- Track(): Manhattan frame ----
+            check(L.planar_track_manhattan_frame_dev(self.ctx.h, B, self.Rcm.data_ptr(), self.sn["normals"].data_ptr(), self.sn["n_normals"].data_ptr(),
+                                                     self.sn["normals"].shape[1], self.sn["lines"].data_ptr(), self.sn["n_lines"].data_ptr(), self.sn["lines"].shape[1],
+                                                     self.Rcm_new.data_ptr(), None, None, None))
+            if evs: evs["manhattan"].record(st)
+            # ---- TranslationWithMotionModel ----
+            fv = self._frame_view(k, self.pose)             # zero-velocity motion model: predicted pose = last pose
+            lv = LastFrameView()
+            lv.stride = S
+            lv.n, lv.Tcw, lv.usable, lv.xw = self.h_n[l].data_ptr(), self.pose.data_ptr(), self.h_valid[l].data_ptr(), self.h_xw[l].data_ptr()
+            lv.octave, lv.angle, lv.mp_desc, lv.mp_observed = self.h_oct[l].data_ptr(), self.h_ang[l].data_ptr(), self.h_desc[l].data_ptr(), self.ones_S.data_ptr()
+            self.pm.fill_(-1)
+            check(L.planar_search_by_projection_frame_dev(self.ctx.h, C.byref(fv), C.byref(lv), 15.0, 0, 1, self.pm.data_ptr(), self.nm.data_ptr()))
+            if evs: evs["proj"].record(st)
+            self.lm.fill_(-1)
+            check(L.planar_lsd_search_by_descriptor_dev(self.ctx.h, self.kf["ldesc"].data_ptr(), self.kf["n"].data_ptr(), 40, self.ldesc[k].data_ptr(), self.nl[k].data_ptr(), 40,
+                                                        self.kf["has_ml"].data_ptr(), B, self.lm.data_ptr(), self.nlm.data_ptr()))
+            if self.run_fallback_matcher:
+                self.cm2.fill_(-1)
+                check(L.planar_match_orb_points_dev(self.ctx.h, self.desc[k].data_ptr(), self.n[k].data_ptr(), S, self.h_desc[l].data_ptr(), self.h_n[l].data_ptr(), S,
+                                                    self.h_valid[l].data_ptr(), self.zeros_S.data_ptr(), B, self.cm2.data_ptr(), self.npair.data_ptr()))
+            if evs: evs["bf"].record(st)
+            # plane coefficients (n, -n.c) of Frame::ComputePlanes (src/Frame.cc:664-672) from the PEAC planes {N, normal, centre, mse}
+            P = self.pls[k]
+            self.pl_coef[..., :3] = P[..., 1:4].float()
+            self.pl_coef[..., 3] = (-(P[..., 1:4] * P[..., 4:7]).sum(-1)).float()
+            self.plm.fill_(-1)
+            check(L.planar_plane_search_by_coefficients_dev(self.ctx.h, B, self.npl[k].data_ptr(), self.PS, self.pl_coef.data_ptr(), self.pose.data_ptr(), 0,
+                                                            self.mp["n"].data_ptr(), self.mp["coef"].shape[1], self.mp["valid"].data_ptr(), self.mp["coef"].data_ptr(),
+                                                            self.mp["npts"].data_ptr(), self.mp["pts"].shape[2], self.mp["pts"].data_ptr(), self.plane_th.ctypes.data,
+                                                            self.plm[0].data_ptr(), self.plm[2].data_ptr(), self.plm[1].data_ptr(), self.nplm.data_ptr()))
+            if evs: evs["planes"].record(st)
+            self._assemble(0, k, self.pm, self.h_xw[l], self.h_valid[l], S, self.pose)
+            self.opt.enqueue_dev(self.pbs[0], 1, 4, 10)     # TranslationOptimization
+            A0 = self.pb_arrays[0]
+            check(L.planar_discard_outliers_dev(self.ctx.h, B, self.n[k].data_ptr(), S, S, self.pm.data_ptr(), A0["pt_outlier"].data_ptr(), self.kept.data_ptr()))
+            check(L.planar_discard_outliers_dev(self.ctx.h, B, self.nl[k].data_ptr(), 40, 40, self.lm.data_ptr(), A0["ln_outlier"].data_ptr(), None))
+            if evs: evs["transl"].record(st)
+            # ---- TrackLocalMap: SearchLocalPoints + PoseOptimization ----
+            T1 = A0["Tcw_out"]
+            t.ge(self.pm, 0, out=self.blocked.view(t.bool))
+            fv2 = self._frame_view(k, T1, self.blocked)
+            pr = self.pr
+            check(L.planar_is_in_frustum_points_dev(self.ctx.h, C.byref(fv2), self.lsf, self.nlev, self.h_n[o].data_ptr(), S, self.h_valid[o].data_ptr(), self.h_xw[o].data_ptr(),
+                                                    self.h_normal[o].data_ptr(), self.h_mind[o].data_ptr(), self.h_maxd[o].data_ptr(), 0.5, pr["in_view"].data_ptr(),
+                                                    pr["proj_x"].data_ptr(), pr["proj_y"].data_ptr(), pr["proj_xr"].data_ptr(), pr["level"].data_ptr(), pr["view_cos"].data_ptr()))
+            mpv = MapProbes()
+            mpv.stride = S
+            mpv.n, mpv.in_view, mpv.proj_x, mpv.proj_y, mpv.proj_xr = self.h_n[o].data_ptr(), pr["in_view"].data_ptr(), pr["proj_x"].data_ptr(), pr["proj_y"].data_ptr(), pr["proj_xr"].data_ptr()
+            mpv.level, mpv.view_cos, mpv.desc, mpv.observed = pr["level"].data_ptr(), pr["view_cos"].data_ptr(), self.h_desc[o].data_ptr(), self.ones_S.data_ptr()
+            self.mm.fill_(-1)
+            check(L.planar_search_by_projection_map_dev(self.ctx.h, C.byref(fv2), C.byref(mpv), 3.0, 0.8, self.mm.data_ptr(), self.nmm.data_ptr()))
+            lp = self.lpr
+            check(L.planar_is_in_frustum_lines_dev(self.ctx.h, C.byref(fv2), self.lsf, self.kf["n"].data_ptr(), 40, self.kf["has_ml"].data_ptr(), self.kf["xw6"].data_ptr(),
+                                                   self.kf["normal"].data_ptr(), self.kf["min_dist"].data_ptr(), self.kf["max_dist"].data_ptr(), 0.5, lp["in_view"].data_ptr(),
+                                                   lp["proj"].data_ptr(), lp["level"].data_ptr(), lp["view_cos"].data_ptr()))
+            t.ge(self.lm, 0, out=self.lblocked.view(t.bool))
+            check(L.planar_lsd_search_by_projection_dev(self.ctx.h, B, self.nl[k].data_ptr(), 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.lblocked.data_ptr(),
+                                                        self.kf["n"].data_ptr(), 40, lp["in_view"].data_ptr(), lp["proj"].data_ptr(), lp["level"].data_ptr(), lp["view_cos"].data_ptr(),
+                                                        self.kf["ldesc"].data_ptr(), self.kf["has_ml"].data_ptr(), self.sf.ctypes.data, self.nlev, 3.0, 0.6, self.lm.data_ptr(),
+                                                        self.nlm.data_ptr()))
+            if evs: evs["local"].record(st)
+            # one index space for the optimiser: [last frame's points | the older frame's points]
+            t.where(self.pm >= 0, self.pm, t.where(self.mm >= 0, self.mm + S, self.mm), out=self.pm_all)
+            self.xw_all[:, :S] = self.h_xw[l]; self.xw_all[:, S:] = self.h_xw[o]
+            self.valid_all[:, :S] = self.h_valid[l]; self.valid_all[:, S:] = self.h_valid[o]
+            self._assemble(1, k, self.pm_all, self.xw_all, self.valid_all, 2 * S, T1)
+            self.opt.enqueue_dev(self.pbs[1], 0, 4, 10)     # PoseOptimization
+            self.pose.copy_(self.pb_arrays[1]["Tcw_out"])
+            self.Rcm.copy_(self.Rcm_new)
+            if evs: evs["pose"].record(st)
+        elif evs:
+            for name in ("manhattan", "proj", "bf", "planes", "transl", "local", "pose"):
+                evs[name].record(st)
+        # ---- the new frame becomes a "last frame": back-projected keypoints (UnprojectStereo) and what MapPoint::UpdateNormalAndDepth keeps ----
+        self._stereo(k, self.pose, depth, self.ur[k], self.zd[k], self.h_xw[o], self.h_valid[o])
+        T = self.pose.view(B, 4, 4)
+        Ow = -(T[:, :3, :3].transpose(1, 2) @ T[:, :3, 3:4]).squeeze(-1)
+        v = self.h_xw[o] - Ow[:, None, :]
+        dist = v.norm(dim=-1).clamp_min(1e-6)
+        self.h_normal[o] = v / dist[..., None]
+        octave = self.kps[k][..., 5].contiguous().view(t.int32)
+        sft = t.from_numpy(self.sf).to(self.dev)
+        self.h_maxd[o] = dist * sft[octave.clamp(0, self.nlev - 1).long()]
+        self.h_mind[o] = self.h_maxd[o] / float(self.sf[self.nlev - 1])
+        self.h_desc[o].copy_(self.desc[k]); self.h_oct[o].copy_(octave); self.h_ang[o].copy_(self.kps[k][..., 3]); self.h_n[o].copy_(self.n[k])
+        if evs: evs["state"].record(st)
+        self.done[k].record(st)
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def check(self):
+        for q in self.pds:
+            q.L.planar_peac_check(q.h, self.B)
+
+
+def build_map(gray0, depth0, cam, torch_dev=None, seed=0, n_map_planes=8, n_plane_pts=128, n_normals=4096):
+    """Host-side stand-in for the map of each stream, built from its first frame with the product extractors (numpy in, numpy out):
+    the reference key frame's lines (end points back-projected with the depth at the end points, as Frame::isLineGood does when the depth is
+    valid), the map planes (PEAC planes of the first frame at the identity pose with sampled member points) and synthetic surface normals."""
+    from . import PlaneDetection
+    from .lines import LineSegment
+    from .synth import manhattan_scene
+    B, H, W = gray0.shape
+    ls = LineSegment(W, H, B)
+    kl, ldesc, eq, nl = ls.ExtractLineSegment(gray0)
+    fx, fy, cx, cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    xw6 = np.zeros((B, 40, 6)); normal = np.zeros((B, 40, 3)); mind = np.zeros((B, 40), np.float32); maxd = np.zeros((B, 40), np.float32)
+    dm = depth0.astype(np.float64) / 5000.0
+    for b in range(B):
+        for i in range(int(nl[b])):
+            pts = []
+            for (x, y) in ((kl[b, i]["start_x"], kl[b, i]["start_y"]), (kl[b, i]["end_x"], kl[b, i]["end_y"])):
+                xi, yi = int(min(max(x, 0), W - 1)), int(min(max(y, 0), H - 1))
+                zz = dm[b, yi, xi] if dm[b, yi, xi] > 0 else 2.0
+                pts.append([(x - cx) * zz / fx, (y - cy) * zz / fy, zz])
+            xw6[b, i] = np.concatenate(pts)
+            mid = 0.5 * (np.array(pts[0]) + np.array(pts[1])); d = np.linalg.norm(mid)
+            normal[b, i] = mid / max(d, 1e-9); maxd[b, i] = d * 1.2 ** 3; mind[b, i] = maxd[b, i] / 1.2 ** 7
+    kf_lines = dict(n=nl.astype(np.int32), ldesc=ldesc, xw6=xw6, normal=normal, min_dist=mind, max_dist=maxd)
+    pd = PlaneDetection(W, H, max_batch=B)
+    res = pd.run(depth0.astype(np.uint16))
+    M, P = n_map_planes, n_plane_pts
+    mp = dict(n=np.zeros(B, np.int32), valid=np.zeros((B, M), np.uint8), coef=np.zeros((B, M, 4), np.float32), npts=np.zeros((B, M), np.int32), pts=np.zeros((B, M, P, 3), np.float32))
+    ys, xs = np.mgrid[4:H:16, 4:W:16]
+    for b in range(B):
+        planes, labels = res[b]
+        m = min(len(planes), M)
+        mp["n"][b] = m
+        for q in range(m):
+            nrm, c = np.asarray(planes[q][1:4]), np.asarray(planes[q][4:7])
+            mp["coef"][b, q] = [*nrm, -float(nrm @ c)]
+            sel = labels[ys, xs] == q
+            yy, xx = ys[sel][:P], xs[sel][:P]
+            zz = dm[b, yy, xx]
+            pp = np.stack([(xx - cx) * zz / fx, (yy - cy) * zz / fy, zz], -1)
+            mp["npts"][b, q] = len(pp); mp["pts"][b, q, :len(pp)] = pp; mp["valid"][b, q] = 1
+    sc = manhattan_scene(B=B, n_normals=n_normals, n_lines=40, seed=21 + seed)
+    return kf_lines, mp, dict(normals=sc["normals"], n_normals=sc["n_normals"], lines=sc["lines"], n_lines=sc["n_lines"], R_last=sc["R_last"])
