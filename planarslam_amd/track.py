@@ -120,6 +120,8 @@ class TrackPipeline:
         self.pending = []
         self.map_set = False
         self.step_count = 0
+        self.capture_steps = set()      # tests: steps whose stage inputs / outputs are cloned (on the stream) into self.captured[j]
+        self.captured = {}
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def set_map(self, kf_lines: dict, map_planes: dict, normals: dict):
@@ -216,6 +218,16 @@ class TrackPipeline:
         if evs: evs["wait0"].record(st)
         st.wait_event(self.join_p[k]); st.wait_event(self.join_l[k])
         if evs: evs["wait1"].record(st)
+        cap = None
+        if j in self.capture_steps:
+            cap = self.captured[j] = {}
+            snap = lambda name, x: cap.__setitem__(name, x.clone())
+            for name, x in (("kps", self.kps[k]), ("desc", self.desc[k]), ("n", self.n[k]), ("ur", self.ur[k]), ("zd", self.zd[k]), ("kls", self.kls[k]), ("ldesc", self.ldesc[k]),
+                            ("leq", self.leq[k]), ("nl", self.nl[k]), ("lab", self.lab[k]), ("pls", self.pls[k]), ("npl", self.npl[k]), ("pose_in", self.pose), ("Rcm_in", self.Rcm),
+                            ("last_xw", self.h_xw[l]), ("last_valid", self.h_valid[l]), ("last_desc", self.h_desc[l]), ("last_oct", self.h_oct[l]), ("last_ang", self.h_ang[l]),
+                            ("last_n", self.h_n[l]), ("old_xw", self.h_xw[o]), ("old_valid", self.h_valid[o]), ("old_desc", self.h_desc[o]), ("old_normal", self.h_normal[o]),
+                            ("old_mind", self.h_mind[o]), ("old_maxd", self.h_maxd[o]), ("old_n", self.h_n[o])):
+                snap(name, x)
         if j >= 2 and self.map_set:
             # ---- Track(): Manhattan frame ----
             check(L.planar_track_manhattan_frame_dev(self.ctx.h, B, self.Rcm.data_ptr(), self.sn["normals"].data_ptr(), self.sn["n_normals"].data_ptr(),
@@ -231,6 +243,7 @@ class TrackPipeline:
             self.pm.fill_(-1)
             check(L.planar_search_by_projection_frame_dev(self.ctx.h, C.byref(fv), C.byref(lv), 15.0, 0, 1, self.pm.data_ptr(), self.nm.data_ptr()))
             if evs: evs["proj"].record(st)
+            if cap is not None: snap("pm0", self.pm); snap("nm", self.nm)
             self.lm.fill_(-1)
             check(L.planar_lsd_search_by_descriptor_dev(self.ctx.h, self.kf["ldesc"].data_ptr(), self.kf["n"].data_ptr(), 40, self.ldesc[k].data_ptr(), self.nl[k].data_ptr(), 40,
                                                         self.kf["has_ml"].data_ptr(), B, self.lm.data_ptr(), self.nlm.data_ptr()))
@@ -239,6 +252,7 @@ class TrackPipeline:
                 check(L.planar_match_orb_points_dev(self.ctx.h, self.desc[k].data_ptr(), self.n[k].data_ptr(), S, self.h_desc[l].data_ptr(), self.h_n[l].data_ptr(), S,
                                                     self.h_valid[l].data_ptr(), self.zeros_S.data_ptr(), B, self.cm2.data_ptr(), self.npair.data_ptr()))
             if evs: evs["bf"].record(st)
+            if cap is not None: snap("lm0", self.lm); snap("nlm0", self.nlm); snap("cm2", self.cm2); snap("npair", self.npair)
             # plane coefficients (n, -n.c) of Frame::ComputePlanes (src/Frame.cc:664-672) from the PEAC planes {N, normal, centre, mse}
             P = self.pls[k]
             self.pl_coef[..., :3] = P[..., 1:4].float()
@@ -249,12 +263,15 @@ class TrackPipeline:
                                                             self.mp["npts"].data_ptr(), self.mp["pts"].shape[2], self.mp["pts"].data_ptr(), self.plane_th.ctypes.data,
                                                             self.plm[0].data_ptr(), self.plm[2].data_ptr(), self.plm[1].data_ptr(), self.nplm.data_ptr()))
             if evs: evs["planes"].record(st)
+            if cap is not None: snap("pl_coef", self.pl_coef); snap("plm", self.plm); snap("nplm", self.nplm); snap("Rcm_new", self.Rcm_new)
             self._assemble(0, k, self.pm, self.h_xw[l], self.h_valid[l], S, self.pose)
             self.opt.enqueue_dev(self.pbs[0], 1, 4, 10)     # TranslationOptimization
             A0 = self.pb_arrays[0]
+            if cap is not None: cap["pbT"] = {kk: v.clone() for kk, v in A0.items()}
             check(L.planar_discard_outliers_dev(self.ctx.h, B, self.n[k].data_ptr(), S, S, self.pm.data_ptr(), A0["pt_outlier"].data_ptr(), self.kept.data_ptr()))
             check(L.planar_discard_outliers_dev(self.ctx.h, B, self.nl[k].data_ptr(), 40, 40, self.lm.data_ptr(), A0["ln_outlier"].data_ptr(), None))
             if evs: evs["transl"].record(st)
+            if cap is not None: snap("pm1", self.pm); snap("lm1", self.lm); snap("kept", self.kept)
             # ---- TrackLocalMap: SearchLocalPoints + PoseOptimization ----
             T1 = A0["Tcw_out"]
             t.ge(self.pm, 0, out=self.blocked.view(t.bool))
@@ -279,12 +296,16 @@ class TrackPipeline:
                                                         self.kf["ldesc"].data_ptr(), self.kf["has_ml"].data_ptr(), self.sf.ctypes.data, self.nlev, 3.0, 0.6, self.lm.data_ptr(),
                                                         self.nlm.data_ptr()))
             if evs: evs["local"].record(st)
+            if cap is not None:
+                cap["pr"] = {kk: v.clone() for kk, v in self.pr.items()}; cap["lpr"] = {kk: v.clone() for kk, v in self.lpr.items()}
+                snap("mm", self.mm); snap("nmm", self.nmm); snap("lm2", self.lm); snap("nlm2", self.nlm)
             # one index space for the optimiser: [last frame's points | the older frame's points]
             t.where(self.pm >= 0, self.pm, t.where(self.mm >= 0, self.mm + S, self.mm), out=self.pm_all)
             self.xw_all[:, :S] = self.h_xw[l]; self.xw_all[:, S:] = self.h_xw[o]
             self.valid_all[:, :S] = self.h_valid[l]; self.valid_all[:, S:] = self.h_valid[o]
             self._assemble(1, k, self.pm_all, self.xw_all, self.valid_all, 2 * S, T1)
             self.opt.enqueue_dev(self.pbs[1], 0, 4, 10)     # PoseOptimization
+            if cap is not None: cap["pbP"] = {kk: v.clone() for kk, v in self.pb_arrays[1].items()}; snap("pm_all", self.pm_all)
             self.pose.copy_(self.pb_arrays[1]["Tcw_out"])
             self.Rcm.copy_(self.Rcm_new)
             if evs: evs["pose"].record(st)
@@ -303,6 +324,7 @@ class TrackPipeline:
         self.h_maxd[o] = dist * sft[octave.clamp(0, self.nlev - 1).long()]
         self.h_mind[o] = self.h_maxd[o] / float(self.sf[self.nlev - 1])
         self.h_desc[o].copy_(self.desc[k]); self.h_oct[o].copy_(octave); self.h_ang[o].copy_(self.kps[k][..., 3]); self.h_n[o].copy_(self.n[k])
+        if cap is not None: snap("pose_out", self.pose); snap("new_xw", self.h_xw[o]); snap("new_valid", self.h_valid[o]); snap("new_ur", self.ur[k])
         if evs: evs["state"].record(st)
         self.done[k].record(st)
 

@@ -1,0 +1,189 @@
+"""The bench's pipelined schedule (planarslam_amd/track.py: five streams, buffer sets reused across steps, the tracking chain of step i - depth
+enqueued behind the extraction of step i) checked against the CPU oracle, stage by stage and frame by frame.
+
+B = 64 camera streams, five steps; the last two steps (both with a full tracking chain, overlapping the extraction launches of later steps) have
+every stage's inputs and outputs cloned on the stream (TrackPipeline.capture_steps).  Each oracle stage is fed the DEVICE's inputs of that stage
+(so a 1e-5 difference of an optimiser cannot snowball into different matches downstream) and must reproduce the device's outputs: bit-exact for
+extraction, stereo, all matchers, frustum, assembly; 1e-5 on poses / rotation with identical outlier flags for the optimisers and the Manhattan tracker.
+This is where a race between streams or a buffer reused too early would show."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from planarslam_amd.synth import TUM3, pan_offset, scale_factors
+
+pytestmark = pytest.mark.gpu
+B, W, H, MARGIN, STEPS, DEPTH = 64, 640, 480, 48, 5, 2
+
+
+@pytest.fixture(scope="module")
+def run():
+    import torch
+    from planarslam_amd.synth import stream_canvases
+    from planarslam_amd.track import TrackPipeline, build_map
+    cg, cd = stream_canvases(16, 3, W + 2 * MARGIN, H + 2 * MARGIN, procs=8)
+    dev = torch.device("cuda", 0)
+    dg, dd = torch.from_numpy(cg).to(dev), torch.from_numpy(cd.view(np.int16)).to(dev)
+    goff = [(24 * (g & 1), 24 * ((g >> 1) & 1)) for g in range(4)]
+
+    def window_np(i):
+        ox, oy = pan_offset(i, MARGIN)
+        g = np.zeros((B, H, W), np.uint8); d = np.zeros((B, H, W), np.uint16)
+        for q in range(4):
+            x0, y0 = ox + goff[q][0], oy + goff[q][1]
+            g[q * 16:(q + 1) * 16] = cg[:, y0:y0 + H, x0:x0 + W]; d[q * 16:(q + 1) * 16] = cd[:, y0:y0 + H, x0:x0 + W]
+        return g, d
+    tp = TrackPipeline(B, torch, 0, depth=DEPTH)
+    g0, d0 = window_np(0)
+    kf, mp, sn = build_map(g0[:16], d0[:16], TUM3, seed=1)
+    rep = lambda a: np.concatenate([a] * 4)[:B]
+    maps = ({k: rep(v) for k, v in kf.items()}, {k: rep(v) for k, v in mp.items()}, {k: rep(v) for k, v in sn.items()})
+    tp.set_map(*maps)
+    tp.capture_steps = {STEPS - 2, STEPS - 1}
+    frames = [torch.zeros((B, H, W), dtype=torch.uint8, device=dev) for _ in range(tp.NB)]
+    depths = [torch.zeros((B, H, W), dtype=torch.int16, device=dev) for _ in range(tp.NB)]
+    inputs = {}
+    with torch.cuda.stream(tp.stream):
+        for i in range(STEPS):
+            k = i % tp.NB
+            tp.stream.wait_event(tp.done[k])
+            g, d = window_np(i)
+            inputs[i] = (g, d)
+            frames[k].copy_(torch.from_numpy(g), non_blocking=False); depths[k].copy_(torch.from_numpy(d.view(np.int16)), non_blocking=False)
+            tp.step(i, frames[k], depths[k])
+        tp.drain()
+    torch.cuda.synchronize()
+    tp.check()
+    cap = {j: {k: ({kk: vv.cpu().numpy() for kk, vv in v.items()} if isinstance(v, dict) else v.cpu().numpy()) for k, v in c.items()} for j, c in tp.captured.items()}
+    return dict(tp=tp, cap=cap, inputs=inputs, maps=maps, S=tp.S, PS=tp.PS, sf=np.asarray(tp.sf, np.float32), lsf=tp.lsf)
+
+
+def _frame_dict(c, Tcw, blocked=None):
+    d = dict(n=c["n"], keys_un=c["kps"].view(ol.KP_DTYPE).reshape(B, -1), u_right=c["ur"], desc=c["desc"], Tcw=Tcw, min_x=0.0, max_x=float(W), min_y=0.0, max_y=float(H),
+             fx=TUM3["fx"], fy=TUM3["fy"], cx=TUM3["cx"], cy=TUM3["cy"], bf=TUM3["bf"], b=TUM3["bf"] / TUM3["fx"], scale_factors=scale_factors())
+    if blocked is not None:
+        d["blocked"] = blocked
+    return d
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_extraction_of_a_pipelined_step(run, which):
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    j = STEPS - 2 + which
+    c, (g, d) = run["cap"][j], run["inputs"][j]
+    o = ol.OrbOracle()
+    kl = c["kls"].view(KEYLINE_DTYPE).reshape(B, 40)
+    for b in range(0, B, 5):                     # every fifth stream: the oracle extractors cost ~60 ms per frame
+        kp, de = o.extract(g[b])
+        n = int(c["n"][b])
+        assert n == len(kp) and c["kps"][b, :n].tobytes() == kp.tobytes() and np.array_equal(c["desc"][b, :n], de)
+        rk, rd, re, _, _ = ol.extract_line_segment(g[b], tie_order=0)
+        nl = int(c["nl"][b])
+        assert nl == len(rk) and kl[b, :nl].tobytes() == rk.tobytes() and np.array_equal(c["ldesc"][b, :nl], rd) and np.array_equal(c["leq"][b, :nl], re)
+        planes, labels = ol.peac_run(d[b])
+        assert int(c["npl"][b]) == len(planes) and np.array_equal(c["lab"][b].reshape(H, W), labels)
+        assert np.array_equal(c["pls"][b, :len(planes)], planes)
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_tracking_chain_of_a_pipelined_step(run, which):
+    j = STEPS - 2 + which
+    c, (g, d) = run["cap"][j], run["inputs"][j]
+    S, PS, sf, lsf = run["S"], run["PS"], run["sf"], run["lsf"]
+    kf, mp, sn = run["maps"]
+    keys = c["kps"].view(ol.KP_DTYPE).reshape(B, S)
+    # the previous chain's result is this chain's start: pose / rotation hand-over between pipelined steps
+    if which == 1:
+        prev = run["cap"][j - 1]
+        assert np.array_equal(c["pose_in"], prev["pose_out"]) and np.array_equal(c["last_xw"], prev["new_xw"]) and np.array_equal(c["Rcm_in"], prev["Rcm_new"])
+    # ---- TrackManhattanFrame ----
+    for b in range(0, B, 7):
+        n, m = int(sn["n_normals"][b]), int(sn["n_lines"][b])
+        w = ol.track_manhattan_frame(c["Rcm_in"][b].reshape(3, 3), sn["normals"][b, :n], sn["lines"][b, :m])
+        assert np.abs(w["R"].ravel() - c["Rcm_new"][b]).max() <= 1e-5
+    # ---- SearchByProjection(Cur, Last) ----
+    cur = _frame_dict(c, c["pose_in"])
+    last = dict(n=c["last_n"], Tcw=c["pose_in"], usable=c["last_valid"], xw=c["last_xw"], octave=c["last_oct"], angle=c["last_ang"], mp_desc=c["last_desc"],
+                mp_observed=np.ones((B, S), np.uint8))
+    m, nm = ol.search_by_projection_frame(cur, last, 15.0)
+    assert np.array_equal(m, c["pm0"]) and np.array_equal(nm, c["nm"]) and nm.mean() > 300
+    # ---- LSDmatcher::SearchByDescriptor, MatchORBPoints ----
+    for b in range(B):
+        nk, nc = int(kf["n"][b]), int(c["nl"][b])
+        wm, wn = ol.lsd_search_by_descriptor(kf["ldesc"][b, :nk], c["ldesc"][b, :nc], np.ones(nk, np.uint8))
+        assert np.array_equal(wm, c["lm0"][b, :nc]) and wn == c["nlm0"][b]
+    for b in range(0, B, 9):
+        n, nlst = int(c["n"][b]), int(c["last_n"][b])
+        wm, wn = ol.match_orb_points(c["desc"][b, :n], c["last_desc"][b, :nlst], c["last_valid"][b, :nlst], np.zeros(nlst, np.uint8), np.full(n, -1, np.int32))
+        assert np.array_equal(wm, c["cm2"][b, :n]) and wn == c["npair"][b]
+    # ---- plane coefficients + PlaneMatcher ----
+    P = c["pls"]
+    coef = np.zeros((B, PS, 4), np.float32)
+    coef[..., :3] = P[..., 1:4].astype(np.float32); coef[..., 3] = (-(P[..., 1:4] * P[..., 4:7]).sum(-1)).astype(np.float32)
+    assert np.array_equal(coef, c["pl_coef"])
+    a, v, p, npm = ol.plane_search_by_coefficients(dict(n=c["npl"], coef=coef, Tcw=c["pose_in"]), dict(n=mp["n"], valid=mp["valid"], coef=mp["coef"], npts=mp["npts"], pts=mp["pts"]))
+    assert np.array_equal(a, c["plm"][0]) and np.array_equal(p, c["plm"][1]) and np.array_equal(v, c["plm"][2]) and np.array_equal(npm, c["nplm"])
+    # ---- assembled translation problem + TranslationOptimization ----
+    T = c["pbT"]
+    for b in range(0, B, 11):
+        n = int(c["n"][b])
+        ok = c["pm0"][b, :n] >= 0
+        ok &= c["last_valid"][b][np.clip(c["pm0"][b, :n], 0, S - 1)] > 0
+        assert np.array_equal(T["pt_valid"][b, :n] > 0, ok)
+        assert np.array_equal(T["pt_xw"][b, :n][ok], c["last_xw"][b][c["pm0"][b, :n][ok]])
+        assert np.array_equal(T["pt_obs"][b, :n, 0], keys["x"][b, :n]) and np.array_equal(T["pt_obs"][b, :n, 2], c["ur"][b, :n])
+    pbT = {k: T[k] for k in ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid", "ln_obs", "ln_xw", "pl_meas", "pl_valid", "pl_world")}
+    pbT["Tcw"] = T["Tcw_in"]
+    w = ol.pose_optimize(pbT, TUM3, 1, 4, 10)
+    dT = np.abs(w["Tcw"] - T["Tcw_out"]).max(1)
+    same_its = w["lm_iters"] == T["lm_iters"]
+    assert (dT <= 1e-5).mean() >= 0.95 and dT.max() <= 1e-4 and np.array_equal(w["n_inliers"], T["n_inliers"])   # (iteration counts differ in ~10 % of the frames: knife-edge stop tests)
+    # (the device cleared the flags of the matches it then dropped; compare what the optimiser wrote through the matches that survived)
+    dropped = (c["pm0"] >= 0) & (c["pm1"] < 0)
+    assert np.array_equal(dropped, (w["pt_outlier"] > 0) & (c["pm0"] >= 0))
+    assert np.array_equal(c["kept"], ((c["pm0"] >= 0) & ~dropped).sum(1))
+    # ---- TrackLocalMap: isInFrustum, SearchByProjection(map), line search ----
+    T1 = T["Tcw_out"]
+    fr2 = _frame_dict(c, T1, blocked=(c["pm1"] >= 0).astype(np.uint8))
+    old = dict(n=c["old_n"], valid=c["old_valid"], xw=c["old_xw"], normal=c["old_normal"], min_dist=c["old_mind"], max_dist=c["old_maxd"])
+    pr = ol.is_in_frustum_points(fr2, old, lsf, len(sf), 0.5)
+    inrange = np.arange(S)[None, :] < c["old_n"][:, None]          # rows beyond n[b] are never written (stale values of earlier steps on the device)
+    iv = (pr["in_view"] > 0) & inrange
+    assert np.array_equal(pr["in_view"][inrange], c["pr"]["in_view"][inrange]) and iv.mean() > 0.05
+    for k in ("proj_x", "proj_y", "proj_xr", "level", "view_cos"):
+        assert np.array_equal(pr[k][iv], c["pr"][k][iv]), k
+    probes = dict({k: np.where(inrange, c["pr"][k], 0).astype(c["pr"][k].dtype) for k in c["pr"]}, n=c["old_n"], desc=c["old_desc"], observed=np.ones((B, S), np.uint8))
+    mm, nmm = ol.search_by_projection_map(fr2, probes, 3.0, 0.8)
+    assert np.array_equal(mm, c["mm"]) and np.array_equal(nmm, c["nmm"])
+    ml = dict(n=kf["n"], valid=np.ones((B, 40), np.uint8), xw6=kf["xw6"], normal=kf["normal"], min_dist=kf["min_dist"], max_dist=kf["max_dist"])
+    lp = ol.is_in_frustum_lines(fr2, ml, lsf, 0.5)
+    lrange = np.arange(40)[None, :] < kf["n"][:, None]
+    il = (lp["in_view"] > 0) & lrange
+    assert np.array_equal(lp["in_view"][lrange], c["lpr"]["in_view"][lrange]) and np.array_equal(lp["proj"][il], c["lpr"]["proj"][il])
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    lines = dict(n=c["nl"], keylines=c["kls"].view(KEYLINE_DTYPE).reshape(B, 40), ldesc=c["ldesc"], blocked=(c["lm1"] >= 0).astype(np.uint8))
+    maplines = dict(n=kf["n"], in_view=lp["in_view"], proj=lp["proj"], level=lp["level"], view_cos=lp["view_cos"], desc=kf["ldesc"], observed=np.ones((B, 40), np.uint8))
+    lm2, nlm2 = ol.lsd_search_by_projection(lines, maplines, sf, 3.0, 0.6, match=c["lm1"])
+    assert np.array_equal(lm2, c["lm2"]) and np.array_equal(nlm2, c["nlm2"])
+    # ---- merged matches, assembled pose problem, PoseOptimization, new map points ----
+    want_all = np.where(c["pm1"] >= 0, c["pm1"], np.where(c["mm"] >= 0, c["mm"] + S, -1))
+    assert np.array_equal(want_all, c["pm_all"])
+    Pp = c["pbP"]
+    pbP = {k: Pp[k] for k in ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid", "ln_obs", "ln_xw", "pl_meas", "pl_valid", "pl_world")}
+    pbP["Tcw"] = Pp["Tcw_in"]
+    assert np.array_equal(Pp["Tcw_in"], T1)
+    w = ol.pose_optimize(pbP, TUM3, 0, 4, 10)
+    dT = np.abs(w["Tcw"] - Pp["Tcw_out"]).max(1)
+    same_its = w["lm_iters"] == Pp["lm_iters"]
+    # At a flat minimum the accept / reject decisions of the LM trials (rho > 0 on chi2 differences in the 9th digit) are knife edges: the device, the
+    # oracle and the reference's own g2o (checked on such a frame: device - reference 5e-10, oracle - reference 1.4e-5) can take different
+    # trial sequences to equivalent poses ~1e-5 apart.  1e-5 for at least 95 % of the frames, 1e-4 for every frame, identical inlier counts.
+    assert (dT <= 1e-5).mean() >= 0.95 and dT.max() <= 1e-4
+    assert np.array_equal(w["n_inliers"], Pp["n_inliers"])
+    v = Pp["pt_valid"] > 0
+    assert np.array_equal(w["pt_outlier"][v], Pp["pt_outlier"][v])          # rows without a map point are never written
+    assert np.array_equal(c["pose_out"], Pp["Tcw_out"]) and Pp["n_inliers"].mean() > 300
+    for b in range(0, B, 13):
+        n = int(c["n"][b])
+        s = ol.stereo_from_rgbd(keys[b, :n], d[b], c["pose_out"][b], TUM3)
+        assert np.array_equal(s["xw"], c["new_xw"][b, :n]) and np.array_equal(s["valid"], c["new_valid"][b, :n]) and np.array_equal(s["u_right"], c["new_ur"][b, :n])
