@@ -1,8 +1,9 @@
 """CPU baseline of bench.py: the oracle/ restatements of the hot-path stages, timed on the host cores of the box the bench runs on.
 
 TEST / MEASUREMENT INFRASTRUCTURE: this is the only place besides tests/ and __graft_entry__.smoke() that imports oracle/.  The same
-per-frame work list as the reference's Tracking thread: ORB + LSD/LBD + PEAC extraction, SearchByProjection(Cur, Last), MatchORBPoints,
-PoseOptimization 4x10 on a config-4-shaped problem.  Three variants:
+per-frame work list as bench.py's GPU step (the reference's Track()): ORB + LSD/LBD + PEAC extraction, ComputeStereoFromRGBD, TrackManhattanFrame,
+SearchByProjection(Cur, Last), MatchORBPoints, line SearchByDescriptor, PlaneMatcher, isInFrustum + SearchByProjection(map), TranslationOptimization
+and PoseOptimization 4x10 on a config-4-shaped problem.  Three variants:
   one_thread   everything on one thread
   threads3     extraction on three threads per frame as src/Frame.cc:90-95 does (ORB / LSD / PEAC), matching and LM on the calling thread
   all_cores    `os.cpu_count()` independent worker processes, each running the one-thread loop on its own frames (frames shard trivially)
@@ -41,7 +42,9 @@ def run(seconds, seed=0, nsrc=4, threads3=False, full=True):
     o = ol.OrbOracle()
     sfs = scale_factors()
     rng = np.random.default_rng(11 + seed)
-    per = {"orb": 0.0, "lsd": 0.0, "peac": 0.0, "extract_wall": 0.0, "proj": 0.0, "match": 0.0, "pose": 0.0}
+    per = {"orb": 0.0, "lsd": 0.0, "peac": 0.0, "extract_wall": 0.0, "stereo": 0.0, "manhattan": 0.0, "proj": 0.0, "match": 0.0, "planes": 0.0, "local": 0.0, "pose": 0.0}
+    from planarslam_amd.synth import manhattan_scene
+    scene = manhattan_scene(B=1, n_normals=4096, n_lines=40, seed=21 + seed)
     prev = None
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
@@ -71,25 +74,47 @@ def run(seconds, seed=0, nsrc=4, threads3=False, full=True):
         kp, de = res["orb"]
         if full:
             nj = len(kp)
+            eye = np.eye(4, dtype=np.float32).reshape(1, 16)
+            tm = time.perf_counter
+            t1 = tm(); st = ol.stereo_from_rgbd(kp, depth[i], eye[0], TUM3); per["stereo"] += tm() - t1
+            t1 = tm(); ol.track_manhattan_frame(scene["R_last"][0], scene["normals"][0, :scene["n_normals"][0]], scene["lines"][0, :scene["n_lines"][0]]); per["manhattan"] += tm() - t1
+            kl, ld, leq = res["lsd"][0], res["lsd"][1], res["lsd"][2]
+            planes = res["peac"][0]
             if prev is not None:
-                pkp, pde, pxw, pur = prev
+                pkp, pde, pst, pld, ppl = prev
                 npv = len(pkp)
-                eye = np.eye(4, dtype=np.float32).reshape(1, 16)
-                curv = dict(n=np.array([nj], np.int32), keys_un=kp.reshape(1, nj), u_right=np.full((1, nj), -1, np.float32), desc=de.reshape(1, nj, 32), Tcw=eye,
+                curv = dict(n=np.array([nj], np.int32), keys_un=kp.reshape(1, nj), u_right=st["u_right"].reshape(1, nj), desc=de.reshape(1, nj, 32), Tcw=eye,
                             min_x=0.0, max_x=float(W), min_y=0.0, max_y=float(H), fx=TUM3["fx"], fy=TUM3["fy"], cx=TUM3["cx"], cy=TUM3["cy"], bf=TUM3["bf"],
                             b=TUM3["bf"] / TUM3["fx"], scale_factors=sfs)
-                lastv = dict(n=np.array([npv], np.int32), Tcw=eye, usable=np.ones((1, npv), np.uint8), xw=pxw.reshape(1, npv, 3),
+                lastv = dict(n=np.array([npv], np.int32), Tcw=eye, usable=pst["valid"].reshape(1, npv), xw=pst["xw"].reshape(1, npv, 3),
                              octave=np.ascontiguousarray(pkp["octave"]).reshape(1, npv), angle=np.ascontiguousarray(pkp["angle"]).reshape(1, npv),
                              mp_desc=pde.reshape(1, npv, 32), mp_observed=np.ones((1, npv), np.uint8))
-                t1 = time.perf_counter(); ol.search_by_projection_frame(curv, lastv, 15.0); per["proj"] += time.perf_counter() - t1
-                t1 = time.perf_counter()
+                t1 = tm(); pm, _ = ol.search_by_projection_frame(curv, lastv, 15.0); per["proj"] += tm() - t1
+                t1 = tm()
                 ol.match_orb_points(de, pde, np.ones(npv, np.uint8), np.zeros(npv, np.uint8), np.full(nj, -1, np.int32))
-                per["match"] += time.perf_counter() - t1
+                if len(pld) and len(ld): ol.lsd_search_by_descriptor(pld, ld, np.ones(len(pld), np.uint8))
+                per["match"] += tm() - t1
+                if len(planes) and len(ppl):
+                    t1 = tm()
+                    coef = np.concatenate([planes[:, 1:4], -(planes[:, 1:4] * planes[:, 4:7]).sum(1, keepdims=True)], 1).astype(np.float32)[None]
+                    mcoef = np.concatenate([ppl[:, 1:4], -(ppl[:, 1:4] * ppl[:, 4:7]).sum(1, keepdims=True)], 1).astype(np.float32)[None]
+                    mpts = np.repeat(ppl[:, 4:7].astype(np.float32)[None, :, None, :], 64, 2)
+                    ol.plane_search_by_coefficients(dict(n=np.array([len(planes)], np.int32), coef=coef, Tcw=eye),
+                                                    dict(n=np.array([len(ppl)], np.int32), valid=np.ones((1, len(ppl)), np.uint8), coef=mcoef,
+                                                         npts=np.full((1, len(ppl)), 64, np.int32), pts=mpts))
+                    per["planes"] += tm() - t1
+                # the local map of this frame: the previous frame's points once more (the same count of probes as the GPU step's older generation)
+                t1 = tm()
+                dist = np.linalg.norm(pst["xw"], axis=1).astype(np.float32) + 1e-6
+                mpd = dict(n=np.array([npv], np.int32), valid=pst["valid"].reshape(1, npv), xw=pst["xw"].reshape(1, npv, 3), normal=(pst["xw"] / dist[:, None]).reshape(1, npv, 3),
+                           min_dist=(dist * 0.3).reshape(1, npv), max_dist=(dist * 3.0).reshape(1, npv))
+                curv2 = dict(curv, blocked=(pm >= 0).astype(np.uint8))
+                pr = ol.is_in_frustum_points(curv2, mpd, float(np.float32(np.log(np.float32(1.2)))), 8, 0.5)
+                ol.search_by_projection_map(curv2, dict(pr, n=mpd["n"], desc=pde.reshape(1, npv, 32), observed=np.ones((1, npv), np.uint8)), 3.0, 0.8)
+                per["local"] += tm() - t1
             one = {k: (v[i:i + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (nsrc,) else v) for k, v in pbn.items()}
-            t1 = time.perf_counter(); ol.pose_optimize(one, TUM3, 0, 4, 10); per["pose"] += time.perf_counter() - t1
-            z = rng.uniform(0.8, 5.0, nj).astype(np.float32)
-            xw = np.stack([(kp["x"] - TUM3["cx"]) * z / TUM3["fx"], (kp["y"] - TUM3["cy"]) * z / TUM3["fy"], z], -1).astype(np.float32)
-            prev = (kp, de, xw, None)
+            t1 = tm(); ol.pose_optimize(one, TUM3, 1, 4, 10); ol.pose_optimize(one, TUM3, 0, 4, 10); per["pose"] += tm() - t1
+            prev = (kp, de, st, ld, planes)
         n += 1
     dt = time.perf_counter() - t0
     return dict(frames=n, seconds=dt, per=per)
