@@ -1,10 +1,21 @@
-// planar_adapters.hpp — drop-in C++ classes with the reference's own signatures over the C ABI (planar_abi.h).
+// planar_adapters.hpp — drop-in C++ classes / member functions with the reference's own signatures over the C ABI (planar_abi.h).
 //
-// Build PlanarSLAM with these instead of src/ORBextractor.cc / src/PlaneExtractor.cpp and link libplanar_hip.so.
-// Requires the OpenCV headers PlanarSLAM already uses (cv::Mat, cv::KeyPoint); nothing else.
-//   Planar_SLAM::ORBextractor   <- include/ORBextractor.h:45-112, src/ORBextractor.cc
-//   PlaneDetection              <- include/PlaneExtractor.h:36-56,  src/PlaneExtractor.cpp
-// The matcher / optimizer entry points take Frame*; their gather/scatter glue is shown in INTEGRATION.md.
+// Build PlanarSLAM with these instead of src/ORBextractor.cc, src/PlaneExtractor.cpp, src/LSDextractor.cpp, src/ORBmatcher.cc,
+// src/LSDmatcher.cpp, src/PlaneMatcher.cpp and the two pose functions of src/Optimizer.cc, and link libplanar_hip.so.
+//   Planar_SLAM::ORBextractor   <- include/ORBextractor.h:45-112, src/ORBextractor.cc                 (always)
+//   PlaneDetection              <- include/PlaneExtractor.h:36-56, src/PlaneExtractor.cpp             (always)
+//   Planar_SLAM::LineSegment    <- include/LSDextractor.h:344-352, src/LSDextractor.cpp               (PLANAR_ADAPTERS_WITH_LINES)
+//   ORBmatcher / LSDmatcher / PlaneMatcher / Optimizer member functions                                (PLANAR_ADAPTERS_WITH_TRACKING:
+//       include this header AFTER the reference's Frame.h, KeyFrame.h, MapPoint.h, MapLine.h, MapPlane.h, ORBmatcher.h, LSDmatcher.h,
+//       PlaneMatcher.h and Optimizer.h; it then DEFINES the member functions those headers declare - gather the Frame fields into flat
+//       arrays, call the ABI, scatter the result back)
+//
+// Threading and lifetime.  The reference starts three std::threads per Frame (src/Frame.cc:90-95: ExtractLSD / ExtractORB / ComputePlanes),
+// copies Frames (and the PlaneDetection inside them) by value (src/Tracking.cc:177) and calls LineSegment::ExtractLineSegment through a
+// pointer it never initialises (include/Frame.h:123, src/Frame.cc:172).  Therefore NO adapter object owns a device resource: contexts and
+// plans live in one process-wide runtime (planar_adapter::Runtime), one context + stream + mutex per ROLE (points, lines, planes,
+// tracking), so the three extraction threads run concurrently and nothing is created or leaked per frame or per thread; plans are cached
+// by image size (and ORB parameters).  The adapter classes hold only host data and are freely copyable.
 #pragma once
 #include <opencv2/core/core.hpp>
 #include <opencv2/features2d/features2d.hpp>
@@ -12,17 +23,73 @@
 #include <cassert>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
+#include <tuple>
 #include <vector>
 
 #include "planar_abi.h"
 
 namespace planar_adapter {
-inline planar_ctx* shared_ctx() {   // one context per host thread (the ABI's re-entrancy rule)
-    static thread_local planar_ctx* ctx = nullptr;
-    if (!ctx && planar_ctx_create(&ctx, 0) != PLANAR_OK) throw std::runtime_error(planar_last_error());
-    return ctx;
-}
+
+enum Role { POINTS = 0, LINES = 1, PLANES = 2, TRACKING = 3, NROLES = 4 };
+
+class Runtime {
+public:
+    static Runtime& get() { static Runtime r; return r; }           // destroyed at process exit: plans first, then contexts
+    struct Lane { std::mutex mu; planar_ctx* ctx = nullptr; };
+    // the role's context (created on first use) - hold lane(role).mu while a call on it is in flight
+    Lane& lane(Role r) {
+        Lane& l = lanes_[r];
+        std::lock_guard<std::mutex> g(create_mu_);
+        if (!l.ctx && planar_ctx_create(&l.ctx, device_) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        return l;
+    }
+    typedef std::tuple<int, int, int, int, int, int, int> OrbKey;   // w, h, nfeatures, scale * 1e6, nlevels, ini, min
+    planar_orb* orb(const planar_orb_params& p, int w, int h) {     // call with lane(POINTS).mu held
+        const OrbKey k(w, h, p.nfeatures, (int)(p.scale_factor * 1e6f), p.nlevels, p.ini_th_fast, p.min_th_fast);
+        auto it = orbs_.find(k);
+        if (it != orbs_.end()) return it->second;
+        planar_orb* o = nullptr;
+        if (planar_orb_create(lanes_[POINTS].ctx, &p, w, h, 1, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        return orbs_[k] = o;
+    }
+    planar_lsd* lsd(int w, int h) {                                 // call with lane(LINES).mu held
+        auto it = lsds_.find({w, h});
+        if (it != lsds_.end()) return it->second;
+        planar_lsd* o = nullptr;
+        if (planar_lsd_create(lanes_[LINES].ctx, w, h, 1, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        return lsds_[{w, h}] = o;
+    }
+    planar_peac* peac(int w, int h) {                               // call with lane(PLANES).mu held
+        auto it = peacs_.find({w, h});
+        if (it != peacs_.end()) return it->second;
+        planar_peac* o = nullptr;
+        if (planar_peac_create(lanes_[PLANES].ctx, w, h, 1, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        return peacs_[{w, h}] = o;
+    }
+    void set_device(int d) { device_ = d; }
+private:
+    Runtime() {}
+    ~Runtime() {
+        for (auto& kv : orbs_) planar_orb_destroy(kv.second);
+        for (auto& kv : lsds_) planar_lsd_destroy(kv.second);
+        for (auto& kv : peacs_) planar_peac_destroy(kv.second);
+        for (Lane& l : lanes_) if (l.ctx) planar_ctx_destroy(l.ctx);
+    }
+    Runtime(const Runtime&) = delete;
+    Runtime& operator=(const Runtime&) = delete;
+    int device_ = 0;
+    std::mutex create_mu_;
+    Lane lanes_[NROLES];
+    std::map<OrbKey, planar_orb*> orbs_;
+    std::map<std::pair<int, int>, planar_lsd*> lsds_;
+    std::map<std::pair<int, int>, planar_peac*> peacs_;
+};
+
+inline void check(int rc) { if (rc != PLANAR_OK) throw std::runtime_error(planar_last_error()); }
+
 }  // namespace planar_adapter
 
 namespace Planar_SLAM {
@@ -35,34 +102,35 @@ public:
         : nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST), minThFAST(minThFAST) {
         mvImagePyramid.resize(nlevels);
     }
-    ~ORBextractor() { if (orb_) planar_orb_destroy(orb_); }
 
     // Same contract as the reference operator() (src/ORBextractor.cc:1043-1105); mask is ignored there too.
     void operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors) {
         if (_image.empty()) return;
         cv::Mat image = _image.getMat();
         assert(image.type() == CV_8UC1);   // src/ORBextractor.cc:1050
-        ensure(image.cols, image.rows);
-        const int cap = planar_orb_max_keypoints(orb_);
-        kps_.resize(cap);
-        desc_.resize((size_t)cap * 32);
+        planar_adapter::Runtime& R = planar_adapter::Runtime::get();
+        planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::POINTS);
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_orb* orb = R.orb(params(), image.cols, image.rows);
+        const int cap = planar_orb_max_keypoints(orb);
+        std::vector<planar_keypoint> kps(cap);
+        std::vector<uint8_t> desc((size_t)cap * 32);
         int32_t n = 0;
-        if (planar_orb_extract(orb_, image.data, 1, (int)image.step, (int64_t)image.step * image.rows, kps_.data(), desc_.data(), &n) != PLANAR_OK)
-            throw std::runtime_error(planar_last_error());
+        planar_adapter::check(planar_orb_extract(orb, image.data, 1, (int)image.step, (int64_t)image.step * image.rows, kps.data(), desc.data(), &n));
         static_assert(sizeof(cv::KeyPoint) == sizeof(planar_keypoint), "cv::KeyPoint layout");
         _keypoints.resize(n);
-        if (n) std::memcpy((void*)_keypoints.data(), kps_.data(), (size_t)n * sizeof(planar_keypoint));
+        if (n) std::memcpy((void*)_keypoints.data(), kps.data(), (size_t)n * sizeof(planar_keypoint));
         if (n == 0) { _descriptors.release(); }
         else {
             _descriptors.create(n, 32, CV_8U);
             cv::Mat d = _descriptors.getMat();
-            for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), &desc_[(size_t)i * 32], 32);
+            for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
         }
         for (int l = 0; l < nlevels; l++) {      // public member of the reference class (include/ORBextractor.h:85)
             int w, h;
-            planar_orb_level_size(orb_, l, &w, &h);
+            planar_orb_level_size(orb, l, &w, &h);
             mvImagePyramid[l].create(h, w, CV_8UC1);
-            planar_orb_read_level(orb_, 0, l, mvImagePyramid[l].data);
+            planar_orb_read_level(orb, 0, l, mvImagePyramid[l].data);
         }
     }
 
@@ -76,34 +144,36 @@ public:
     std::vector<cv::Mat> mvImagePyramid;
 
 protected:
-    void ensure(int w, int h) {
-        if (orb_ && w == w_ && h == h_) return;
-        if (orb_) planar_orb_destroy(orb_);
-        planar_orb_params p{nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST};
-        if (planar_orb_create(planar_adapter::shared_ctx(), &p, w, h, 1, &orb_) != PLANAR_OK) { orb_ = nullptr; throw std::runtime_error(planar_last_error()); }
-        w_ = w; h_ = h;
-    }
+    planar_orb_params params() const { return planar_orb_params{nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST}; }
     std::vector<float> factors(int which) {
-        // the scale tables depend only on the constructor arguments; a 64x64 plan is enough to read them
-        if (!orb_) ensure(640, 480);
+        // the scale tables depend only on the constructor arguments; any cached plan with these parameters can answer
+        planar_adapter::Runtime& R = planar_adapter::Runtime::get();
+        planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::POINTS);
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_orb* orb = R.orb(params(), 640, 480);
         std::vector<float> v[4];
         for (auto& x : v) x.resize(nlevels);
-        planar_orb_get_scale_factors(orb_, v[0].data(), v[1].data(), v[2].data(), v[3].data());
+        planar_orb_get_scale_factors(orb, v[0].data(), v[1].data(), v[2].data(), v[3].data());
         return v[which];
     }
     int nfeatures; double scaleFactor; int nlevels, iniThFAST, minThFAST;
-    planar_orb* orb_ = nullptr;
-    int w_ = 0, h_ = 0;
-    std::vector<planar_keypoint> kps_;
-    std::vector<uint8_t> desc_;
 };
 
 }  // namespace Planar_SLAM
 
 // ---- PlaneDetection (include/PlaneExtractor.h:36-56).  Frame::ComputePlanes (src/Frame.cc:647-672) reads plane_num_,
 // plane_vertices_[i], cloud.vertices[j] and plane_filter.extractedPlanes[i]->normal/center; the same members exist here.
+// A PlaneDetection is a by-value member of every Frame and is copied with it: it owns no device handle, and its
+// extractedPlanes pointers are re-seated on copy.
 struct PlanarPlaneSeg { double normal[3], center[3], mse; int N; };
-struct PlanarPlaneFilter { std::vector<PlanarPlaneSeg*> extractedPlanes; std::vector<PlanarPlaneSeg> storage; };
+struct PlanarPlaneFilter {
+    std::vector<PlanarPlaneSeg*> extractedPlanes;
+    std::vector<PlanarPlaneSeg> storage;
+    PlanarPlaneFilter() {}
+    PlanarPlaneFilter(const PlanarPlaneFilter& o) : storage(o.storage) { reseat(); }
+    PlanarPlaneFilter& operator=(const PlanarPlaneFilter& o) { if (this != &o) { storage = o.storage; reseat(); } return *this; }
+    void reseat() { extractedPlanes.resize(storage.size()); for (size_t i = 0; i < storage.size(); i++) extractedPlanes[i] = &storage[i]; }
+};
 struct PlanarVertex { double v[3]; double operator[](int i) const { return v[i]; } };
 struct ImagePointCloud { std::vector<PlanarVertex> vertices; int w = 0, h = 0; };
 
@@ -115,7 +185,6 @@ public:
     cv::Mat seg_img_, color_img_;
     int plane_num_ = 0;
 
-    ~PlaneDetection() { if (peac_) planar_peac_destroy(peac_); }
     bool readColorImage(cv::Mat RGBImg) { color_img_ = RGBImg; return !(color_img_.empty() || color_img_.depth() != CV_8U); }
 
     // src/PlaneExtractor.cpp:26-57: keeps the depth and the intrinsics; the XYZ cloud is produced with the same FP64 arithmetic.
@@ -135,33 +204,30 @@ public:
     }
 
     void runPlaneDetection(int H, int W) {   // src/PlaneExtractor.cpp:59-65
-        if (!peac_ || W != w_ || H != h_) {
-            if (peac_) planar_peac_destroy(peac_);
-            if (planar_peac_create(planar_adapter::shared_ctx(), W, H, 1, &peac_) != PLANAR_OK) { peac_ = nullptr; throw std::runtime_error(planar_last_error()); }
-            w_ = W; h_ = H;
-        }
         std::vector<int32_t> labels((size_t)W * H);
         std::vector<double> planes((size_t)planar_peac_max_planes() * 8);
         int32_t n = 0;
-        if (planar_peac_segment(peac_, (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_, cx_, cy_, factor_,
-                                labels.data(), planes.data(), &n) != PLANAR_OK)
-            throw std::runtime_error(planar_last_error());
+        {
+            planar_adapter::Runtime& R = planar_adapter::Runtime::get();
+            planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::PLANES);
+            std::lock_guard<std::mutex> g(L.mu);
+            planar_adapter::check(planar_peac_segment(R.peac(W, H), (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_, cx_, cy_,
+                                                      factor_, labels.data(), planes.data(), &n));
+        }
         plane_num_ = n;
         plane_vertices_.assign(n, std::vector<int>());
         for (size_t i = 0; i < labels.size(); i++) if (labels[i] >= 0) plane_vertices_[labels[i]].push_back((int)i);   // raster order, as :362-372
-        plane_filter.storage.resize(n); plane_filter.extractedPlanes.resize(n);
+        plane_filter.storage.resize(n);
         for (int i = 0; i < n; i++) {
             PlanarPlaneSeg& s = plane_filter.storage[i];
             const double* p = &planes[(size_t)i * 8];
             s.N = (int)p[0]; for (int k = 0; k < 3; k++) { s.normal[k] = p[1 + k]; s.center[k] = p[4 + k]; } s.mse = p[7];
-            plane_filter.extractedPlanes[i] = &s;
         }
+        plane_filter.reseat();
         seg_img_ = cv::Mat(H, W, CV_8UC3);   // visualisation only (colours are out of scope)
     }
 
 private:
-    planar_peac* peac_ = nullptr;
-    int w_ = 0, h_ = 0;
     cv::Mat depth_;
     float factor_ = 0, fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0;
 };
@@ -172,13 +238,8 @@ private:
 #include <opencv2/line_descriptor/descriptor.hpp>
 #include <eigen3/Eigen/Core>
 namespace Planar_SLAM {
-class LineSegment {
+class LineSegment {   // no data members: Frame calls this through an uninitialised pointer (include/Frame.h:123), which only works for a method that never touches `this`
 public:
-    LineSegment() {}
-    ~LineSegment() { if (lsd_) planar_lsd_destroy(lsd_); }
-    LineSegment(const LineSegment&) = delete;
-    LineSegment& operator=(const LineSegment&) = delete;
-
     // scale / numOctaves are accepted for signature compatibility; the reference passes 1.2f -> (int)1 and 1 (one octave, full resolution)
     void ExtractLineSegment(const cv::Mat& img, std::vector<cv::line_descriptor::KeyLine>& keylines, cv::Mat& ldesc,
                             std::vector<Eigen::Vector3d>& keylineFunctions, float scale = 1.2, int numOctaves = 1) {
@@ -187,28 +248,340 @@ public:
         static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double), "Eigen::Vector3d layout");
         assert(img.type() == CV_8UC1);
         const int W = img.cols, H = img.rows;
-        if (!lsd_ || W != w_ || H != h_) {
-            if (lsd_) planar_lsd_destroy(lsd_);
-            if (planar_lsd_create(planar_adapter::shared_ctx(), W, H, 1, &lsd_) != PLANAR_OK) { lsd_ = nullptr; throw std::runtime_error(planar_last_error()); }
-            w_ = W; h_ = H;
-        }
         const int lsdNFeatures = 40;                                   // src/LSDextractor.cpp:18
         keylines.resize(lsdNFeatures);
         std::vector<unsigned char> desc((size_t)lsdNFeatures * 32);
         const size_t first = keylineFunctions.size();                  // the reference push_backs
         keylineFunctions.resize(first + lsdNFeatures);
         int32_t n = 0;
-        if (planar_lsd_extract(lsd_, img.data, 1, (int)img.step, (int64_t)img.step * H, lsdNFeatures, (planar_keyline*)keylines.data(), desc.data(),
-                               (double*)(keylineFunctions.data() + first), &n) != PLANAR_OK)
-            throw std::runtime_error(planar_last_error());
+        {
+            planar_adapter::Runtime& R = planar_adapter::Runtime::get();
+            planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::LINES);
+            std::lock_guard<std::mutex> g(L.mu);
+            planar_adapter::check(planar_lsd_extract(R.lsd(W, H), img.data, 1, (int)img.step, (int64_t)img.step * H, lsdNFeatures, (planar_keyline*)keylines.data(), desc.data(),
+                                                     (double*)(keylineFunctions.data() + first), &n));
+        }
         keylines.resize(n);
         keylineFunctions.resize(first + n);
         if (n) { ldesc = cv::Mat(n, 32, CV_8UC1); std::memcpy(ldesc.data, desc.data(), (size_t)n * 32); }   // BinaryDescriptor::compute leaves ldesc untouched when there are no lines
     }
-
-private:
-    planar_lsd* lsd_ = nullptr;
-    int w_ = 0, h_ = 0;
 };
 }  // namespace Planar_SLAM
 #endif
+
+// ---- matchers and pose optimisers: definitions of the member functions the reference headers declare -----------------------------------
+#ifdef PLANAR_ADAPTERS_WITH_TRACKING
+namespace planar_adapter {
+
+// Frame fields of the guided matchers -> planar_frame_view (the vectors keep the storage alive)
+struct FrameGather {
+    int32_t n;
+    std::vector<planar_keypoint> keys;
+    std::vector<float> ur;
+    std::vector<uint8_t> desc, blocked;
+    float Tcw[16];
+    planar_frame_view view;
+    template <class FrameT> explicit FrameGather(FrameT& F, bool want_blocked) {
+        n = F.N;
+        keys.resize(n > 0 ? n : 1); ur.resize(keys.size()); desc.resize(keys.size() * 32); blocked.assign(keys.size(), 0);
+        for (int i = 0; i < n; i++) {
+            std::memcpy(&keys[i], &F.mvKeysUn[i], sizeof(planar_keypoint));
+            ur[i] = F.mvuRight.empty() ? -1.f : F.mvuRight[i];
+            std::memcpy(&desc[(size_t)i * 32], F.mDescriptors.ptr(i), 32);
+            if (want_blocked && F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) blocked[i] = 1;
+        }
+        std::memset(&view, 0, sizeof(view));
+        view.B = 1; view.stride = (int32_t)keys.size(); view.n = &n; view.keys_un = keys.data(); view.u_right = ur.data(); view.desc = desc.data();
+        view.blocked = want_blocked ? blocked.data() : nullptr;
+        if (!F.mTcw.empty()) { for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw[4 * r + c] = F.mTcw.template at<float>(r, c); view.Tcw = Tcw; }
+        view.min_x = FrameT::mnMinX; view.max_x = FrameT::mnMaxX; view.min_y = FrameT::mnMinY; view.max_y = FrameT::mnMaxY;
+        view.grid_w_inv = FrameT::mfGridElementWidthInv; view.grid_h_inv = FrameT::mfGridElementHeightInv;
+        view.fx = FrameT::fx; view.fy = FrameT::fy; view.cx = FrameT::cx; view.cy = FrameT::cy; view.bf = F.mbf; view.b = F.mb;
+        for (size_t l = 0; l < F.mvScaleFactors.size() && l < PLANAR_MAX_LEVELS; l++) view.scale_factors[l] = F.mvScaleFactors[l];
+    }
+};
+inline Runtime::Lane& tracking_lane() { return Runtime::get().lane(TRACKING); }
+
+}  // namespace planar_adapter
+
+namespace Planar_SLAM {
+
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)  (src/ORBmatcher.cc:1396-1535)
+inline int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
+    planar_adapter::FrameGather cur(CurrentFrame, true);
+    const int NL = LastFrame.N;
+    int32_t nl = NL;
+    std::vector<uint8_t> usable(NL > 0 ? NL : 1, 0), observed(usable.size(), 0), mpd(usable.size() * 32, 0);
+    std::vector<float> xw(usable.size() * 3, 0.f), ang(usable.size(), 0.f);
+    std::vector<int32_t> oct(usable.size(), 0);
+    float Tl[16];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tl[4 * r + c] = LastFrame.mTcw.at<float>(r, c);
+    for (int i = 0; i < NL; i++) {
+        MapPoint* pMP = LastFrame.mvpMapPoints[i];
+        oct[i] = LastFrame.mvKeys[i].octave; ang[i] = LastFrame.mvKeysUn[i].angle;
+        if (pMP && !LastFrame.mvbOutlier[i]) {
+            usable[i] = 1;
+            cv::Mat x = pMP->GetWorldPos(), d = pMP->GetDescriptor();
+            for (int k = 0; k < 3; k++) xw[3 * i + k] = x.at<float>(k);
+            std::memcpy(&mpd[(size_t)i * 32], d.ptr(0), 32);
+            observed[i] = pMP->Observations() > 0;
+        }
+    }
+    planar_last_frame_view last;
+    last.stride = (int32_t)usable.size(); last.n = &nl; last.Tcw = Tl; last.usable = usable.data(); last.xw = xw.data(); last.octave = oct.data(); last.angle = ang.data();
+    last.mp_desc = mpd.data(); last.mp_observed = observed.data();
+    const int32_t UNTOUCHED = -2;
+    std::vector<int32_t> match(cur.keys.size(), UNTOUCHED);
+    int32_t nmatches = 0;
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_search_by_projection_frame(L.ctx, &cur.view, &last, th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, match.data(), &nmatches));
+    }
+    for (int i = 0; i < CurrentFrame.N; i++) {
+        if (match[i] == UNTOUCHED) continue;
+        CurrentFrame.mvpMapPoints[i] = match[i] >= 0 ? LastFrame.mvpMapPoints[match[i]] : static_cast<MapPoint*>(NULL);
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)  (src/ORBmatcher.cc:46-130)
+inline int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th) {
+    planar_adapter::FrameGather fr(F, true);
+    const size_t M = vpMapPoints.size();
+    int32_t nm = (int32_t)M;
+    std::vector<uint8_t> inview(M ? M : 1, 0), obs(inview.size(), 0), desc(inview.size() * 32, 0);
+    std::vector<float> px(inview.size(), 0.f), py(inview.size(), 0.f), pxr(inview.size(), 0.f), vc(inview.size(), 0.f);
+    std::vector<int32_t> lvl(inview.size(), 0);
+    for (size_t j = 0; j < M; j++) {
+        MapPoint* p = vpMapPoints[j];
+        if (!p->mbTrackInView || p->isBad()) continue;
+        inview[j] = 1; px[j] = p->mTrackProjX; py[j] = p->mTrackProjY; pxr[j] = p->mTrackProjXR; lvl[j] = p->mnTrackScaleLevel; vc[j] = p->mTrackViewCos;
+        cv::Mat d = p->GetDescriptor();
+        std::memcpy(&desc[j * 32], d.ptr(0), 32);
+        obs[j] = p->Observations() > 0;
+    }
+    planar_map_probes pr;
+    pr.stride = (int32_t)inview.size(); pr.n = &nm; pr.in_view = inview.data(); pr.proj_x = px.data(); pr.proj_y = py.data(); pr.proj_xr = pxr.data(); pr.level = lvl.data();
+    pr.view_cos = vc.data(); pr.desc = desc.data(); pr.observed = obs.data();
+    const int32_t UNTOUCHED = -2;
+    std::vector<int32_t> match(fr.keys.size(), UNTOUCHED);
+    int32_t nmatches = 0;
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_search_by_projection_map(L.ctx, &fr.view, &pr, th, mfNNratio, match.data(), &nmatches));
+    }
+    for (int i = 0; i < F.N; i++) if (match[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[match[i]];
+    return nmatches;
+}
+
+// ORBmatcher::MatchORBPoints(Frame&, const Frame&)  (src/ORBmatcher.cc:1332-1394)
+inline int ORBmatcher::MatchORBPoints(Frame& CurrentFrame, const Frame& LastFrame) {
+    int32_t nc = CurrentFrame.N, nl = LastFrame.N;
+    std::vector<uint8_t> cd((size_t)(nc > 0 ? nc : 1) * 32), ld((size_t)(nl > 0 ? nl : 1) * 32), has(nl > 0 ? nl : 1, 0), outl(has.size(), 0);
+    for (int i = 0; i < nc; i++) std::memcpy(&cd[(size_t)i * 32], CurrentFrame.mDescriptors.ptr(i), 32);
+    for (int j = 0; j < nl; j++) {
+        std::memcpy(&ld[(size_t)j * 32], LastFrame.mDescriptors.ptr(j), 32);
+        has[j] = LastFrame.mvpMapPoints[j] != NULL;
+        outl[j] = (size_t)j < LastFrame.mvbOutlier.size() && LastFrame.mvbOutlier[j];
+    }
+    const int32_t UNTOUCHED = -2;
+    std::vector<int32_t> match(nc > 0 ? nc : 1, UNTOUCHED);
+    int32_t npair = 0;
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_match_orb_points(L.ctx, cd.data(), &nc, nc > 0 ? nc : 1, ld.data(), &nl, nl > 0 ? nl : 1, has.data(), outl.data(), 1, match.data(), &npair));
+    }
+    for (int i = 0; i < nc; i++) if (match[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[match[i]];
+    return npair;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)  (src/ORBmatcher.cc:160-292).  A DBoW2::FeatureVector maps node id ->
+// feature indices; every feature is in at most one node, so it is passed as one node id per feature.
+inline int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
+    const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
+    int32_t nk = (int32_t)vpMapPointsKF.size(), nf = F.N;
+    if (nk == 0 || nf == 0) return 0;
+    std::vector<int32_t> knode(nk, -1), fnode(nf, -1);
+    for (const auto& kv : pKF->mFeatVec) for (unsigned int i : kv.second) if ((int)i < nk) knode[i] = (int32_t)kv.first;
+    for (const auto& kv : F.mFeatVec) for (unsigned int i : kv.second) if ((int)i < nf) fnode[i] = (int32_t)kv.first;
+    std::vector<uint8_t> kus(nk, 0), kd((size_t)nk * 32), fd((size_t)nf * 32);
+    std::vector<float> kang(nk), fang(nf);
+    for (int i = 0; i < nk; i++) {
+        kus[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
+        kang[i] = pKF->mvKeysUn[i].angle;
+        std::memcpy(&kd[(size_t)i * 32], pKF->mDescriptors.ptr(i), 32);
+    }
+    for (int i = 0; i < nf; i++) { fang[i] = F.mvKeys[i].angle; std::memcpy(&fd[(size_t)i * 32], F.mDescriptors.ptr(i), 32); }
+    std::vector<int32_t> match(nf, -1);
+    int32_t nmatches = 0;
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_search_by_bow(L.ctx, 1, &nk, nk, knode.data(), kus.data(), kang.data(), kd.data(), &nf, nf, fnode.data(), fang.data(), fd.data(), mfNNratio,
+                                                   mbCheckOrientation ? 1 : 0, match.data(), &nmatches));
+    }
+    for (int i = 0; i < nf; i++) if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
+    return nmatches;
+}
+
+// LSDmatcher::SearchByDescriptor(KeyFrame*, Frame&, vector<MapLine*>&)  (src/LSDmatcher.cpp:242-279)
+inline int LSDmatcher::SearchByDescriptor(KeyFrame* pKF, Frame& currentF, std::vector<MapLine*>& vpMapLineMatches) {
+    const std::vector<MapLine*> vpMapLinesKF = pKF->GetMapLineMatches();
+    int32_t nk = pKF->mLineDescriptors.rows, nc = currentF.mLdesc.rows;
+    vpMapLineMatches = std::vector<MapLine*>(currentF.NL, static_cast<MapLine*>(NULL));
+    if (nk == 0 || nc == 0) return 0;
+    std::vector<uint8_t> kd((size_t)nk * 32), cd((size_t)nc * 32), has(nk, 0);
+    for (int i = 0; i < nk; i++) { std::memcpy(&kd[(size_t)i * 32], pKF->mLineDescriptors.ptr(i), 32); has[i] = vpMapLinesKF[i] != NULL; }
+    for (int i = 0; i < nc; i++) std::memcpy(&cd[(size_t)i * 32], currentF.mLdesc.ptr(i), 32);
+    std::vector<int32_t> match(nc, -1);
+    int32_t nmatches = 0;
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_lsd_search_by_descriptor(L.ctx, kd.data(), &nk, nk, cd.data(), &nc, nc, has.data(), 1, match.data(), &nmatches));
+    }
+    for (int i = 0; i < nc && i < currentF.NL; i++) if (match[i] >= 0) vpMapLineMatches[i] = vpMapLinesKF[match[i]];
+    return nmatches;
+}
+
+// LSDmatcher::SearchByProjection(Frame&, const vector<MapLine*>&, th)  (src/LSDmatcher.cpp:141-211)
+inline int LSDmatcher::SearchByProjection(Frame& F, const std::vector<MapLine*>& vpMapLines, const float th) {
+    int32_t nl = F.NL, nm = (int32_t)vpMapLines.size();
+    if (nl == 0 || nm == 0) return 0;
+    static_assert(sizeof(cv::line_descriptor::KeyLine) == sizeof(planar_keyline), "KeyLine layout");
+    std::vector<uint8_t> ldesc((size_t)nl * 32), blocked(nl, 0), inview(nm, 0), obs(nm, 0), mdesc((size_t)nm * 32, 0);
+    std::vector<float> proj((size_t)nm * 4, 0.f), vc(nm, 0.f);
+    std::vector<int32_t> lvl(nm, 0);
+    for (int i = 0; i < nl; i++) { std::memcpy(&ldesc[(size_t)i * 32], F.mLdesc.ptr(i), 32); blocked[i] = F.mvpMapLines[i] && F.mvpMapLines[i]->Observations() > 0; }
+    for (int j = 0; j < nm; j++) {
+        MapLine* p = vpMapLines[j];
+        if (!p || p->isBad() || !p->mbTrackInView) continue;
+        inview[j] = 1; proj[4 * j] = p->mTrackProjX1; proj[4 * j + 1] = p->mTrackProjY1; proj[4 * j + 2] = p->mTrackProjX2; proj[4 * j + 3] = p->mTrackProjY2;
+        lvl[j] = p->mnTrackScaleLevel; vc[j] = p->mTrackViewCos;
+        cv::Mat d = p->GetDescriptor();
+        std::memcpy(&mdesc[(size_t)j * 32], d.ptr(0), 32);
+        obs[j] = p->Observations() > 0;
+    }
+    const int32_t UNTOUCHED = -2;
+    std::vector<int32_t> match(nl, UNTOUCHED);
+    int32_t nmatches = 0;
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_lsd_search_by_projection(L.ctx, 1, &nl, nl, (const planar_keyline*)F.mvKeylinesUn.data(), ldesc.data(), blocked.data(), &nm, nm, inview.data(),
+                                                              proj.data(), lvl.data(), vc.data(), mdesc.data(), obs.data(), F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), th,
+                                                              mfNNratio, match.data(), &nmatches));
+    }
+    for (int i = 0; i < nl; i++) if (match[i] >= 0) F.mvpMapLines[i] = vpMapLines[match[i]];
+    return nmatches;
+}
+
+// PlaneMatcher::SearchMapByCoefficients(Frame&, const vector<MapPlane*>&)  (src/PlaneMatcher.cpp:10-66)
+inline int PlaneMatcher::SearchMapByCoefficients(Frame& pF, const std::vector<MapPlane*>& vpMapPlanes) {
+    pF.mbNewPlane = false;
+    int32_t np = pF.mnPlaneNum, nm = (int32_t)vpMapPlanes.size();
+    if (np == 0) return 0;
+    std::vector<float> coef((size_t)np * 4), T(16), mcoef((size_t)(nm ? nm : 1) * 4, 0.f);
+    for (int i = 0; i < np; i++) for (int k = 0; k < 4; k++) coef[4 * i + k] = pF.mvPlaneCoefficients[i].template at<float>(k);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[4 * r + c] = pF.mTcw.template at<float>(r, c);
+    std::vector<uint8_t> valid(nm ? nm : 1, 0);
+    std::vector<int32_t> npts(nm ? nm : 1, 0);
+    int maxp = 1;
+    for (int j = 0; j < nm; j++) if (!vpMapPlanes[j]->isBad() && vpMapPlanes[j]->mvPlanePoints) maxp = std::max(maxp, (int)vpMapPlanes[j]->mvPlanePoints->points.size());
+    std::vector<float> pts((size_t)(nm ? nm : 1) * maxp * 3, 0.f);
+    for (int j = 0; j < nm; j++) {
+        MapPlane* p = vpMapPlanes[j];
+        if (p->isBad()) continue;
+        valid[j] = 1;
+        cv::Mat c = p->GetWorldPos();
+        for (int k = 0; k < 4; k++) mcoef[4 * j + k] = c.at<float>(k);
+        if (p->mvPlanePoints) {
+            npts[j] = (int32_t)p->mvPlanePoints->points.size();
+            for (int k = 0; k < npts[j]; k++) { const auto& q = p->mvPlanePoints->points[k]; float* o = &pts[((size_t)j * maxp + k) * 3]; o[0] = q.x; o[1] = q.y; o[2] = q.z; }
+        }
+    }
+    const float th[4] = {dTh, aTh, verTh, parTh};
+    std::vector<int32_t> a(np, -1), v(np, -1), par(np, -1);
+    int32_t nmatches = 0;
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_plane_search_by_coefficients(L.ctx, 1, &np, np, coef.data(), T.data(), 0, &nm, nm ? nm : 1, valid.data(), mcoef.data(), npts.data(), maxp, pts.data(),
+                                                                  th, a.data(), v.data(), par.data(), &nmatches));
+    }
+    for (int i = 0; i < np; i++) {
+        if (a[i] >= 0) pF.mvpMapPlanes[i] = vpMapPlanes[a[i]];
+        if (v[i] >= 0) pF.mvpVerticalPlanes[i] = vpMapPlanes[v[i]];
+        if (par[i] >= 0) pF.mvpParallelPlanes[i] = vpMapPlanes[par[i]];
+    }
+    return nmatches;
+}
+
+// Optimizer::PoseOptimization(Frame*) (src/Optimizer.cc:550-1275) / TranslationOptimization(Frame*) (:2995-3738).  cfg = the six Plane.* values
+// Config::Get<double> returns (Plane.AngleInfo, DistanceInfo, ParallelInfo, VerticalInfo, Chi, VPChi).
+namespace planar_detail {
+template <class FrameT> inline int pose_opt(FrameT* pFrame, int mode) {
+    const int N = pFrame->N, NL = pFrame->NL, M = pFrame->mnPlaneNum;
+    const int MP = N > 0 ? N : 1, ML = NL > 0 ? NL : 1, MM = M > 0 ? M : 1;
+    int32_t n_points = N, n_lines = NL, n_planes = M, n_inliers = 0;
+    std::vector<uint8_t> pt_valid(MP, 0), ln_valid(ML, 0), pl_valid((size_t)MM * 3, 0), pt_out(MP, 0), ln_out(ML, 0), pl_out((size_t)MM * 3, 0);
+    std::vector<float> pt_xw((size_t)MP * 3, 0.f), pt_obs((size_t)MP * 3, 0.f), pt_is2(MP, 1.f), pl_meas((size_t)MM * 4, 0.f), pl_world((size_t)MM * 12, 0.f), Tin(16), Tout(16);
+    std::vector<double> ln_obs((size_t)ML * 3, 0.0), ln_xw((size_t)ML * 6, 0.0);
+    for (int i = 0; i < N; i++) {
+        const cv::KeyPoint& kp = pFrame->mvKeysUn[i];
+        pt_obs[3 * i] = kp.pt.x; pt_obs[3 * i + 1] = kp.pt.y; pt_obs[3 * i + 2] = pFrame->mvuRight[i];
+        pt_is2[i] = pFrame->mvInvLevelSigma2[kp.octave];
+        if (MapPoint* p = pFrame->mvpMapPoints[i]) { pt_valid[i] = 1; cv::Mat x = p->GetWorldPos(); for (int k = 0; k < 3; k++) pt_xw[3 * i + k] = x.at<float>(k); }
+    }
+    for (int i = 0; i < NL; i++) {
+        for (int k = 0; k < 3; k++) ln_obs[3 * i + k] = pFrame->mvKeyLineFunctions[i][k];
+        if (MapLine* p = pFrame->mvpMapLines[i]) { ln_valid[i] = 1; for (int k = 0; k < 6; k++) ln_xw[6 * i + k] = p->mWorldPos[k]; }
+    }
+    for (int i = 0; i < M; i++) {
+        for (int k = 0; k < 4; k++) pl_meas[4 * i + k] = pFrame->mvPlaneCoefficients[i].template at<float>(k);
+        MapPlane* three[3] = {pFrame->mvpMapPlanes[i], pFrame->mvpParallelPlanes[i], pFrame->mvpVerticalPlanes[i]};
+        for (int j = 0; j < 3; j++) if (three[j]) { pl_valid[3 * i + j] = 1; cv::Mat c = three[j]->GetWorldPos(); for (int k = 0; k < 4; k++) pl_world[(3 * i + j) * 4 + k] = c.at<float>(k); }
+    }
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tin[4 * r + c] = pFrame->mTcw.template at<float>(r, c);
+    planar_pose_batch pb;
+    std::memset(&pb, 0, sizeof(pb));
+    pb.B = 1; pb.max_points = MP; pb.max_lines = ML; pb.max_planes = MM;
+    pb.n_points = &n_points; pb.n_lines = &n_lines; pb.n_planes = &n_planes; pb.pt_valid = pt_valid.data(); pb.pt_xw = pt_xw.data(); pb.pt_obs = pt_obs.data();
+    pb.pt_inv_sigma2 = pt_is2.data(); pb.ln_valid = ln_valid.data(); pb.ln_obs = ln_obs.data(); pb.ln_xw = ln_xw.data(); pb.pl_meas = pl_meas.data(); pb.pl_valid = pl_valid.data();
+    pb.pl_world = pl_world.data(); pb.Tcw_in = Tin.data(); pb.Tcw_out = Tout.data(); pb.pt_outlier = pt_out.data(); pb.ln_outlier = ln_out.data(); pb.pl_outlier = pl_out.data();
+    pb.n_inliers = &n_inliers; pb.lm_iters = nullptr;
+    planar_pose_params prm;
+    prm.fx = FrameT::fx; prm.fy = FrameT::fy; prm.cx = FrameT::cx; prm.cy = FrameT::cy; prm.bf = pFrame->mbf;
+    prm.angle_info = Config::Get<double>("Plane.AngleInfo"); prm.distance_info = Config::Get<double>("Plane.DistanceInfo");
+    prm.parallel_info = Config::Get<double>("Plane.ParallelInfo"); prm.vertical_info = Config::Get<double>("Plane.VerticalInfo");
+    prm.plane_chi = Config::Get<double>("Plane.Chi"); prm.vp_chi = Config::Get<double>("Plane.VPChi");
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_pose_opt(L.ctx, &pb, &prm, mode, 4, 10));
+    }
+    // the reference writes the flags of the correspondences it used and the pose through Frame::SetPose
+    for (int i = 0; i < N; i++) if (pt_valid[i]) pFrame->mvbOutlier[i] = pt_out[i] != 0;
+    for (int i = 0; i < NL; i++) if (ln_valid[i]) pFrame->mvbLineOutlier[i] = ln_out[i] != 0;
+    for (int i = 0; i < M; i++) {
+        if (pl_valid[3 * i]) pFrame->mvbPlaneOutlier[i] = pl_out[3 * i] != 0;
+        if (mode == PLANAR_POSE_FULL) {
+            if (pl_valid[3 * i + 1]) pFrame->mvbParPlaneOutlier[i] = pl_out[3 * i + 1] != 0;
+            if (pl_valid[3 * i + 2]) pFrame->mvbVerPlaneOutlier[i] = pl_out[3 * i + 2] != 0;
+        }
+    }
+    cv::Mat pose(4, 4, CV_32F);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose.at<float>(r, c) = Tout[4 * r + c];
+    pFrame->SetPose(pose);
+    return n_inliers;
+}
+}  // namespace planar_detail
+inline int Optimizer::PoseOptimization(Frame* pFrame) { return planar_detail::pose_opt(pFrame, PLANAR_POSE_FULL); }
+inline int Optimizer::TranslationOptimization(Frame* pFrame) { return planar_detail::pose_opt(pFrame, PLANAR_POSE_TRANSLATION); }
+
+}  // namespace Planar_SLAM
+#endif   // PLANAR_ADAPTERS_WITH_TRACKING

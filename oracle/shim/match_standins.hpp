@@ -25,9 +25,22 @@
 #include "eigenshim.hpp"
 #include "opencv2/line_descriptor/descriptor.hpp"
 #include "pcl/point_types.h"
+#ifndef STANDINS_NO_REFERENCE
 #include "auxiliar.h"   // the reference's own (sort comparators, Vector6d)
 #include "Thirdparty/DBoW2/DBoW2/BowVector.h"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+#else
+// -DSTANDINS_NO_REFERENCE: the GPU box has no /root/reference; tests/adapter_shim builds the harness against include/planar_adapters.hpp
+// there, which needs only the data members below (the Frame-side search functions run on the device).
+typedef Eigen::Matrix<double, 6, 1> Vector6d;
+namespace DBoW2 {
+typedef unsigned int NodeId;
+class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {
+public:
+    void addFeature(NodeId id, unsigned int i_feature) { (*this)[id].push_back(i_feature); }
+};
+}  // namespace DBoW2
+#endif
 
 #define FRAME_GRID_ROWS 48
 #define FRAME_GRID_COLS 64
@@ -69,7 +82,7 @@ public:
 
 class MapLine {
 public:
-    Vector6d GetWorldPos() { return pos; }
+    Vector6d GetWorldPos() { return mWorldPos; }
     Eigen::Vector3d GetNormal() { return normal; }
     cv::Mat GetDescriptor() { return mLDescriptor.clone(); }
     bool isBad() { return bad; }
@@ -89,13 +102,14 @@ public:
     float mTrackViewCos = 0;
     long unsigned int mnFuseCandidateForKF = 0, mnId = 0;
     cv::Mat mLDescriptor;
-    Vector6d pos;
+    Vector6d mWorldPos;
     Eigen::Vector3d normal;
     bool bad = false;
     int nobs = 0;
     int index = -1;
 };
 
+#ifndef STANDINS_NO_REFERENCE
 // restated: src/Frame.cc:269-293 (also KeyFrame::lineDescriptorMAD, same body)
 static inline void line_descriptor_mad(vector<vector<cv::DMatch>> line_matches, double& nn_mad, double& nn12_mad) {
     vector<vector<cv::DMatch>> matches_nn = line_matches, matches_12 = line_matches;
@@ -131,6 +145,8 @@ static inline vector<size_t> lines_in_area(const vector<cv::line_descriptor::Key
     }
     return vIndices;
 }
+
+#endif   // STANDINS_NO_REFERENCE
 
 class MapPlane {
 public:
@@ -170,11 +186,16 @@ public:
     vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r, const int minLevel = -1,
                                   const int maxLevel = -1) const;
     void lineDescriptorMAD(vector<vector<cv::DMatch>> line_matches, double& nn_mad, double& nn12_mad) const;
-#else
+#elif !defined(STANDINS_NO_REFERENCE)
     vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r, const int minLevel = -1,
                                   const int maxLevel = -1) const { return lines_in_area(mvKeylinesUn, x1, y1, x2, y2, r, minLevel, maxLevel); }
     void lineDescriptorMAD(vector<vector<cv::DMatch>> m, double& a, double& b) const { line_descriptor_mad(m, a, b); }
 #endif
+    // pose optimisation (only the adapter harness, tests/adapter_shim, uses these)
+    std::vector<float> mvInvLevelSigma2;
+    std::vector<Eigen::Vector3d> mvKeyLineFunctions;
+    std::vector<bool> mvbPlaneOutlier, mvbParPlaneOutlier, mvbVerPlaneOutlier;
+    void SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); }
     // planes
     std::vector<cv::Mat> mvPlaneCoefficients;
     std::vector<MapPlane*> mvpMapPlanes, mvpParallelPlanes, mvpVerticalPlanes;
@@ -257,9 +278,11 @@ public:
     std::set<MapLine*> GetMapLines() { return std::set<MapLine*>(); }
     MapLine* GetMapLine(const size_t& i) { return mls[i]; }
     void AddMapLine(MapLine*, const size_t&) {}
+#ifndef STANDINS_NO_REFERENCE
     vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r, const int minLevel = -1,
                                   const int maxLevel = -1) const { return lines_in_area(mvKeyLines, x1, y1, x2, y2, r, minLevel, maxLevel); }
     void lineDescriptorMAD(vector<vector<cv::DMatch>> m, double& a, double& b) const { line_descriptor_mad(m, a, b); }
+#endif
     std::vector<MapPoint*> GetMapPointMatches() { return mps; }
     std::set<MapPoint*> GetMapPoints() { return std::set<MapPoint*>(); }
     MapPoint* GetMapPoint(const size_t& i) { return mps[i]; }

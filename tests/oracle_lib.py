@@ -381,8 +381,11 @@ def std_sort_desc(keys):
 
 
 # ---- the REAL reference matchers (oracle/_ref/ref_match: src/ORBmatcher.cc, src/PlaneMatcher.cpp) ----
+BINARY_OVERRIDE = {}   # tests/test_adapters_gpu.py points "ref_match" / "ref_opt" at the harness built over include/planar_adapters.hpp
+
+
 def ref_match_path():
-    return os.path.join(ORACLE_DIR, "_ref", "ref_match")
+    return BINARY_OVERRIDE.get("ref_match") or os.path.join(ORACLE_DIR, "_ref", "ref_match")
 
 
 def _run_ref_match(mode, blocks, n_out):
@@ -538,7 +541,7 @@ def track_manhattan_frame(R_last, normals, lines):
 
 # ---- REAL reference optimiser (oracle/_ref/ref_opt: src/Optimizer.cc + vendored g2o + g2oAddition over the mini-Eigen stand-in) ----
 def ref_opt_path():
-    return os.path.join(ORACLE_DIR, "_ref", "ref_opt")
+    return BINARY_OVERRIDE.get("ref_opt") or os.path.join(ORACLE_DIR, "_ref", "ref_opt")
 
 
 def _cam_cfg(params):
