@@ -413,6 +413,12 @@ typedef struct planar_comm planar_comm;
 typedef struct planar_comm_id { char internal[128]; } planar_comm_id;   /* == ncclUniqueId */
 int planar_comm_unique_id(planar_comm_id* out);
 int planar_comm_create(planar_ctx* ctx, const planar_comm_id* id, int nranks, int rank, planar_comm** out);
+/* The same exchange over a transport the embedding program owns (MPI, gloo, shared memory ...): the library stages the buffer
+ * through host memory and calls allreduce(user, buf, n, op) (op 0 = sum, 1 = max; in place; 0 = success) on every rank.
+ * It is how several PROCESSES that share ONE GPU (which RCCL refuses) run the partitioned solve - tests/test_ba_gpu.py does that
+ * with torch.distributed/gloo on the 1-GPU box - and a way to use the library where RCCL is not wanted. */
+typedef int (*planar_allreduce_fn)(void* user, double* buf, size_t n, int op);
+int planar_comm_create_hosted(planar_ctx* ctx, planar_allreduce_fn allreduce, void* user, int nranks, int rank, planar_comm** out);
 void planar_comm_destroy(planar_comm* comm);
 
 #define PLANAR_BA_MONO 0      /* g2o::EdgeSE3ProjectXYZ        (types_six_dof_expmap.cpp:103-139)  meas = u, v            */

@@ -6,4 +6,4 @@ from .orb import ORBextractor  # noqa: F401
 from .optimizer import Optimizer  # noqa: F401
 from .matcher import LSDmatcher, ORBmatcher, hamming_knn  # noqa: F401
 from .planes import PlaneDetection  # noqa: F401
-from .ba import Communicator, local_bundle_adjustment, shard_problem  # noqa: F401
+from .ba import Communicator, HostedCommunicator, local_bundle_adjustment, shard_problem  # noqa: F401

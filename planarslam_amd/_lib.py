@@ -153,6 +153,7 @@ _SIGS = {
     "planar_peac_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "planar_comm_unique_id": (C.c_int, [C.c_void_p]),
     "planar_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "planar_comm_create_hosted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_comm_destroy": (None, [C.c_void_p]),
     "planar_local_ba": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(PoseParams), C.c_int, C.c_int, C.POINTER(BAResult), C.c_void_p, C.c_void_p]),
     "planar_stereo_from_rgbd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64] + [C.c_float] * 6 + [C.c_void_p] * 5),

@@ -57,8 +57,46 @@ class Communicator:
             self.h = None
 
 
-def local_bundle_adjustment(prob: dict, params: dict, its1: int = 5, its2: int = 10, ctx: Context | None = None, comm: Communicator | None = None):
-    """Runs planar_local_ba on a synth.ba_problem()-style dict (or a shard of it).  Returns kf_Tcw, lm, e_outlier, lm_iters."""
+class HostedCommunicator:
+    """planar_comm over a transport this program owns: all_reduce(buf: np.ndarray[float64], op: 'sum' | 'max') in place.
+    `HostedCommunicator.torch(ctx)` uses the default torch.distributed group (gloo or nccl) - several processes may then share one GPU."""
+
+    def __init__(self, ctx: Context, all_reduce, nranks: int, rank: int):
+        self.L = lib()
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_int)
+
+        def _cb(_user, buf, n, op):
+            try:
+                all_reduce(np.ctypeslib.as_array(buf, shape=(n,)), "sum" if op == 0 else "max")
+                return 0
+            except Exception:   # an exception must not unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = FN(_cb)
+        h = C.c_void_p()
+        check(self.L.planar_comm_create_hosted(ctx.h, self._cb, None, nranks, rank, C.byref(h)))
+        self.h, self.nranks, self.rank = h, nranks, rank
+
+    @classmethod
+    def torch(cls, ctx: Context):
+        import torch
+        import torch.distributed as dist
+
+        def ar(a, op):
+            t = torch.from_numpy(a)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+        return cls(ctx, ar, dist.get_world_size(), dist.get_rank())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.planar_comm_destroy(self.h)
+            self.h = None
+
+
+def local_bundle_adjustment(prob: dict, params: dict, its1: int = 5, its2: int = 10, ctx: Context | None = None, comm=None, stop_flag=None):
+    """Runs planar_local_ba on a synth.ba_problem()-style dict (or a shard of it).  Returns kf_Tcw, lm, e_outlier, lm_iters.
+    comm: Communicator (RCCL) or HostedCommunicator; stop_flag: a ctypes.c_int the caller may set (pbStopFlag of the reference)."""
     L = lib()
     ctx = ctx or Context(0)
     a = {k: np.ascontiguousarray(prob[k]) for k in _KEYS}
@@ -68,6 +106,6 @@ def local_bundle_adjustment(prob: dict, params: dict, its1: int = 5, its2: int =
                   a["e_kf"].ctypes.data, a["e_lm"].ctypes.data, a["e_type"].ctypes.data, a["e_meas"].ctypes.data, a["e_inv_sigma2"].ctypes.data)
     R = BAResult(out["kf_Tcw"].ctypes.data, out["lm"].ctypes.data, out["e_outlier"].ctypes.data, 0, 0)
     prm = make_params(params)
-    check(L.planar_local_ba(ctx.h, C.byref(P), C.byref(prm), its1, its2, C.byref(R), None, comm.h if comm else None))
+    check(L.planar_local_ba(ctx.h, C.byref(P), C.byref(prm), its1, its2, C.byref(R), C.byref(stop_flag) if stop_flag is not None else None, comm.h if comm else None))
     out["lm_iters"], out["stopped"] = R.lm_iterations, R.stopped
     return out

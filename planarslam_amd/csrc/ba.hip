@@ -14,12 +14,20 @@
 //                across GPUs, every GPU then solves the same 6K x 6K system redundantly (29 KB payload)
 //   ba_solve     one workgroup        dense Cholesky of the reduced system in LDS, pose increments
 //   ba_update    thread = landmark    back-substitution x_l = Dinv (bl - W^T x_p), oplus on poses / points / planes
-// LM control (lambda schedule, rho test, retries, stop rules of optimization_algorithm_levenberg.cpp:61-164) runs on the
-// host: one small read-back per trial (BA is ONE problem, not a batch; the exchange is latency-bound anyway).
+//   ba_decide    one thread           the Levenberg-Marquardt bookkeeping of optimization_algorithm_levenberg.cpp:61-164 (rho test, lambda
+//                                     schedule, <= 10 retries, stop rules) ON THE DEVICE, from the all-reduced [chi2, scale, stop] triple
+// One LM trial = one fixed launch sequence ("step") whose kernels read the LM state (lambda, need_build, done ...) from device memory, so
+// the host never waits inside the trial loop: it enqueues a chunk of steps and reads the 64-byte state once per chunk.  Per trial there
+// are two collectives, both issued unconditionally by every rank (identical control flow by construction - the decision inputs are the
+// all-reduced values, so every rank takes the same branch, and the caller's stop flag only acts through the reduced triple):
+//   A  [Hpp | bp | chi2(x) | S | b]   np*36 + 6np + 2 + (6np)^2 + 6np doubles (4 402 for 10 keyframes)  before the solve
+//   B  [chi2(x+dx), landmark part of the gain denominator, stop]                  3 doubles              after the update
+// (they cannot be one: B is a function of the solve of A).  The first trial of each optimize() adds a 2-double MAX for computeLambdaInit.
 #include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <numeric>
 
@@ -50,11 +58,25 @@ struct Dev {
     uint8_t* e_level;                        // 0 active, 1 outlier
     uint8_t* e_out;                          // final "to erase" flag
     double* Hll; double* bl; double* Dinv; double* W; double* xl;   // [L][9] [L][3] [L][9] [E][18] [L][3]
-    double* red;                             // [np*36 Hpp | 6np bp | chi | pad] : summed over ranks at build time
-    double* red2;                            // [NP*NP Schur terms | NP rhs terms | trial chi | landmark scale | pad]
+    double* red;                             // this rank's [np*36 Hpp | 6np bp | chi | pad], rebuilt at the start of an LM iteration
+    double* redg;                            // exchange buffer A, first part: the same layout, summed over ranks
+    double* red2;                            // exchange buffer A, second part (contiguous with redg): [NP*NP Schur terms | NP rhs terms]
+    double* trial;                           // exchange buffer B: [chi2 at the trial state, landmark part of computeScale(), stop]
     double* xp;                              // [NP] + [NP] ok flag / pose scale at the end
-    double* scal;                            // [0] max |diag Hll|
+    double* scal;                            // [0] max |diag Hll|, [1] stop  (MAX over ranks, first trial of an optimize() only)
+    struct LmState* st;
     Cam cam;
+};
+
+// Levenberg-Marquardt state of OptimizationAlgorithmLevenberg::solve / SparseOptimizer::optimize, kept on the device
+struct LmState {
+    double lambda, ni, currentChi, iniChi, rho;
+    int it, iterations, qmax, nBad;
+    int need_build;      // 1: the next step starts a new LM iteration (errors + linearisation), 0: it retries with a larger lambda
+    int restore;         // the last trial was rejected: ba_restore puts the backup back
+    int done, stopped;   // optimize() has returned / because of the stop flag
+    int lm_iters;        // iterations started (diagnostic)
+    int pad;
 };
 
 __device__ __forceinline__ SE3 load_T(const double* T, int k) {
@@ -121,8 +143,10 @@ __device__ __forceinline__ int edge_landmark(const Dev& D, int e) {
     return lo;
 }
 
-__global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_out) {
+// at_iteration_start = 1: only when the step opens an LM iteration (chi2(x) into red); 0: every live trial (chi2(x + dx) into trial[0])
+__global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_out, int at_iteration_start) {
     __shared__ double s4[4];
+    if (D.st->done || (at_iteration_start && !D.st->need_build)) return;
     const int e = blockIdx.x * NT + threadIdx.x;
     double chi = 0;
     if (e < D.E && D.e_level[e] == 0) {
@@ -138,9 +162,17 @@ __global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_o
     if (threadIdx.x == 0 && tot != 0) atomicAdd(chi_out, tot);
 }
 
+// opens an LM iteration: clears this rank's partial sums
+__global__ __launch_bounds__(NT) void ba_begin(Dev D, int nred) {
+    if (D.st->done || !D.st->need_build) return;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < nred; i += gridDim.x * NT) D.red[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) D.scal[0] = 0;
+}
+
 __global__ __launch_bounds__(NT) void ba_build(Dev D, int robust) {
     extern __shared__ __attribute__((aligned(16))) double s_pp[];   // [np][42]: Hpp (36) + bp (6)
     __shared__ double s4[4];
+    if (D.st->done || !D.st->need_build) return;
     const int l = blockIdx.x * NT + threadIdx.x;
     for (int i = threadIdx.x; i < D.np * 42; i += NT) s_pp[i] = 0;
     __syncthreads();
@@ -256,8 +288,10 @@ __device__ __forceinline__ void inv3(const double* H, double lambda, double Di[9
     Di[6] = (d * h - e * g) * id; Di[7] = (b * g - a * h) * id; Di[8] = (a * e - b * d) * id;
 }
 
-__global__ __launch_bounds__(NT) void ba_schur(Dev D, double lambda) {
+__global__ __launch_bounds__(NT) void ba_schur(Dev D) {
     extern __shared__ __attribute__((aligned(16))) double s_S[];    // [NP*NP + NP]
+    if (D.st->done) return;
+    const double lambda = D.st->lambda;
     const int NP = 6 * D.np, tot = NP * NP + NP;
     for (int i = threadIdx.x; i < tot; i += NT) s_S[i] = 0;
     __syncthreads();
@@ -297,19 +331,27 @@ __global__ __launch_bounds__(NT) void ba_schur(Dev D, double lambda) {
 }
 
 // One workgroup: A = blockdiag(Hpp) + lambda I + Schur terms, rhs = bp + Schur rhs; dense Cholesky in LDS.
-__global__ __launch_bounds__(NT) void ba_solve(Dev D, double lambda) {
+__global__ __launch_bounds__(NT) void ba_solve(Dev D) {
     extern __shared__ __attribute__((aligned(16))) double s_A[];    // [NP*NP] + x[NP]
     __shared__ int s_ok;
+    if (D.st->done) return;
     const int NP = 6 * D.np, tid = threadIdx.x;
+    if (tid == 0 && D.st->need_build) {      // the step opened an LM iteration: chi2(x) summed over ranks has just arrived
+        LmState& S = *D.st;
+        S.currentChi = S.iniChi = D.redg[(size_t)D.np * 36 + NP];
+        S.need_build = 0; S.qmax = 0; S.lm_iters++;
+    }
+    __syncthreads();
+    const double lambda = D.st->lambda;
     double* x = s_A + NP * NP;
     for (int i = tid; i < NP * NP; i += NT) {
         const int r = i / NP, c = i - r * NP;
         double v = D.red2[i];
-        if (r / 6 == c / 6) v += D.red[(size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
+        if (r / 6 == c / 6) v += D.redg[(size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
         if (r == c) v += lambda;
         s_A[i] = v;
     }
-    for (int i = tid; i < NP; i += NT) x[i] = D.red[(size_t)D.np * 36 + i] + D.red2[NP * NP + i];
+    for (int i = tid; i < NP; i += NT) x[i] = D.redg[(size_t)D.np * 36 + i] + D.red2[NP * NP + i];
     if (tid == 0) s_ok = 1;
     __syncthreads();
     for (int j = 0; j < NP; j++) {              // right-looking Cholesky, lower triangle
@@ -330,16 +372,20 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D, double lambda) {
         if (s_ok) {
             for (int i = 0; i < NP; i++) { double v = x[i]; for (int k = 0; k < i; k++) v -= s_A[i * NP + k] * x[k]; x[i] = v / s_A[i * NP + i]; }
             for (int i = NP - 1; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < NP; k++) v -= s_A[k * NP + i] * x[k]; x[i] = v / s_A[i * NP + i]; }
-            for (int i = 0; i < NP; i++) { D.xp[i] = x[i]; scale += x[i] * (lambda * x[i] + D.red[(size_t)D.np * 36 + i]); }
+            for (int i = 0; i < NP; i++) { D.xp[i] = x[i]; scale += x[i] * (lambda * x[i] + D.redg[(size_t)D.np * 36 + i]); }
         }
         D.xp[NP] = s_ok ? 1.0 : 0.0;
         D.xp[NP + 1] = scale;        // pose part of computeScale()
     }
 }
 
-__global__ __launch_bounds__(NT) void ba_update(Dev D, double lambda, double* lmscale_out) {
+__global__ __launch_bounds__(NT) void ba_update(Dev D, int stop) {
     __shared__ double s4[4];
+    if (D.st->done) return;
+    const double lambda = D.st->lambda;
+    double* lmscale_out = D.trial + 1;
     const int i = blockIdx.x * NT + threadIdx.x;
+    if (i == 0) D.trial[2] = stop ? 1.0 : 0.0;
     const int NP = 6 * D.np;
     const bool ok = D.xp[NP] != 0.0;
     if (i < D.K) {
@@ -375,7 +421,53 @@ __global__ __launch_bounds__(NT) void ba_update(Dev D, double lambda, double* lm
     if (threadIdx.x == 0 && tot != 0) atomicAdd(lmscale_out, tot);
 }
 
+// computeLambdaInit (optimization_algorithm_levenberg.cpp:132-149) from the summed Hpp and the MAX-reduced landmark diagonal; the stop word
+// (MAX over ranks) ends optimize() before its first iteration, as SparseOptimizer::optimize does when terminate() is already set.
+__global__ void ba_lambda_init(Dev D) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    LmState& S = *D.st;
+    if (D.scal[1] > 0) { S.done = 1; S.stopped = 1; return; }
+    double mx = D.scal[0];
+    for (int p = 0; p < D.np; p++) for (int a = 0; a < 6; a++) mx = fmax(mx, fabs(D.redg[(size_t)p * 36 + a * 7]));
+    S.lambda = 1e-5 * mx; S.ni = 2; S.nBad = 0;
+}
+
+// after the trial's exchange B: OptimizationAlgorithmLevenberg::solve :84-128 and the stop rules of SparseOptimizer::optimize
+__global__ void ba_decide(Dev D) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    LmState& S = *D.st;
+    S.restore = 0;
+    if (S.done) return;
+    const int NP = 6 * D.np;
+    const bool ok2 = D.xp[NP] != 0.0;
+    const double tempChi = ok2 ? D.trial[0] : 1.7976931348623157e308;
+    const bool stop = D.trial[2] > 0;
+    double rho = S.currentChi - tempChi;
+    rho /= D.xp[NP + 1] + D.trial[1] + 1e-3;
+    if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        S.lambda *= fmax(1. / 3., alpha); S.ni = 2; S.currentChi = tempChi;
+    } else {
+        S.lambda *= S.ni; S.ni *= 2; S.restore = 1;
+    }
+    S.rho = rho;
+    S.qmax++;
+    if (rho < 0 && S.qmax < 10 && !stop) return;       // retry with the larger lambda: same linearisation
+    bool finished = (S.qmax == 10 || rho == 0);
+    if (!finished) {
+        if ((S.iniChi - S.currentChi) * 1e3 < S.iniChi) S.nBad++; else S.nBad = 0;
+        finished = S.nBad >= 3;
+    }
+    S.it++;
+    if (!finished && S.it < S.iterations && stop) { finished = true; S.stopped = 1; }   // terminate() is polled when the next iteration starts
+    if (S.it >= S.iterations) finished = true;
+    S.need_build = 1;
+    if (finished) S.done = 1;
+}
+
 __global__ __launch_bounds__(NT) void ba_restore(Dev D) {
+    if (!D.st->restore) return;
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i < D.K) for (int a = 0; a < 8; a++) D.T[(size_t)i * 8 + a] = D.Tbak[(size_t)i * 8 + a];
     if (i < D.L) for (int a = 0; a < 4; a++) D.lm[(size_t)i * 4 + a] = D.lmbak[(size_t)i * 4 + a];
@@ -431,7 +523,7 @@ struct Rccl {
 constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;   // ncclDataType_t / ncclRedOp_t values (rccl.h)
 }  // namespace
 
-struct planar_comm { planar_ctx* ctx; void* comm; int nranks, rank; };
+struct planar_comm { planar_ctx* ctx; void* comm; int nranks, rank; planar_allreduce_fn hosted; void* user; };
 
 using namespace planar;
 
@@ -453,7 +545,14 @@ int planar_comm_create(planar_ctx* ctx, const planar_comm_id* id, int nranks, in
     void* c = nullptr;
     const int rc = g_rccl.CommInitRank(&c, nranks, *id, rank);
     if (rc != 0) { set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return PLANAR_EDEVICE; }
-    *out = new planar_comm{ctx, c, nranks, rank};
+    *out = new planar_comm{ctx, c, nranks, rank, nullptr, nullptr};
+    return PLANAR_OK;
+}
+
+int planar_comm_create_hosted(planar_ctx* ctx, planar_allreduce_fn allreduce, void* user, int nranks, int rank, planar_comm** out) {
+    PLANAR_REQUIRE(ctx && allreduce && out, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, PLANAR_EINVAL, "bad rank / nranks");
+    *out = new planar_comm{ctx, nullptr, nranks, rank, allreduce, user};
     return PLANAR_OK;
 }
 
@@ -546,14 +645,14 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     }
 
     // ---- device block ----
-    const size_t nred = (size_t)np * 36 + NP + 2, nred2 = (size_t)NP * NP + NP + 2;
+    const size_t nred = (size_t)np * 36 + NP + 2, nS = (size_t)NP * NP + NP, nA = nred + nS;
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 8), (size_t)256); return o; };
     const size_t oT = carve((size_t)K * 64), oTb = carve((size_t)K * 64), oP = carve((size_t)K * 4), oLm = carve((size_t)L * 32), oLb = carve((size_t)L * 32),
                  oLt = carve(L), oLs = carve((size_t)(L + 1) * 4), oEk = carve((size_t)E * 4), oEt = carve(E), oEp = carve((size_t)E * 4),
                  oEm = carve((size_t)E * 32), oEi = carve((size_t)E * 32), oEe = carve((size_t)E * 24), oEl = carve(E), oEo = carve(E),
                  oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oDi = carve((size_t)L * 72), oW = carve((size_t)E * 144), oXl = carve((size_t)L * 24),
-                 oR = carve(nred * 8), oR2 = carve(nred2 * 8), oXp = carve((size_t)(NP + 2) * 8), oSc = carve(64);
+                 oR = carve(nred * 8), oA = carve(nA * 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8), oSc = carve(64), oSt = carve(sizeof(LmState));
     DevBuf buf;
     int rc = buf.alloc(off);
     if (rc) return rc;
@@ -570,7 +669,8 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     D.lm_type = base + oLt; D.lm_start = (const int*)(base + oLs); D.e_kf = (const int*)(base + oEk); D.e_type = base + oEt; D.e_partner = (const int*)(base + oEp);
     D.e_meas = (const double*)(base + oEm); D.e_info = (const double*)(base + oEi); D.e_err = (double*)(base + oEe); D.e_level = base + oEl; D.e_out = base + oEo;
     D.Hll = (double*)(base + oH); D.bl = (double*)(base + oB); D.Dinv = (double*)(base + oDi); D.W = (double*)(base + oW); D.xl = (double*)(base + oXl);
-    D.red = (double*)(base + oR); D.red2 = (double*)(base + oR2); D.xp = (double*)(base + oXp); D.scal = (double*)(base + oSc);
+    D.red = (double*)(base + oR); D.redg = (double*)(base + oA); D.red2 = D.redg + nred; D.trial = (double*)(base + oTr); D.xp = (double*)(base + oXp);
+    D.scal = (double*)(base + oSc); D.st = (LmState*)(base + oSt);
     D.cam = Cam{(double)prm->fx, (double)prm->fy, (double)prm->cx, (double)prm->cy, (double)prm->bf};
 
     const size_t smem_schur = ((size_t)NP * NP + NP) * 8, smem_solve = ((size_t)NP * NP + NP) * 8, smem_build = (size_t)np * 42 * 8;
@@ -579,87 +679,80 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
         PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_solve));
     }
     const dim3 gE((E + NT - 1) / NT ? (E + NT - 1) / NT : 1), gL((L + NT - 1) / NT ? (L + NT - 1) / NT : 1), gU((std::max(L, K) + NT - 1) / NT);
+    // a communicator of ONE rank still goes through ncclAllReduce (the same code path as N ranks); no communicator = single GPU, no exchange
+    std::vector<double> staged;
     auto allreduce = [&](double* p, size_t n, int op) -> int {
-        if (!comm || comm->nranks == 1) return PLANAR_OK;
+        if (!comm) return PLANAR_OK;
+        if (comm->hosted) {                      // transport owned by the embedding program: stage through the host
+            staged.resize(n);
+            PLANAR_HIP_CHECK(hipMemcpyAsync(staged.data(), p, n * 8, hipMemcpyDeviceToHost, st));
+            PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+            if (comm->hosted(comm->user, staged.data(), n, op == NCCL_SUM ? 0 : 1) != 0) { set_error("hosted all-reduce callback failed"); return PLANAR_EDEVICE; }
+            PLANAR_HIP_CHECK(hipMemcpyAsync(p, staged.data(), n * 8, hipMemcpyHostToDevice, st));
+            PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+            return PLANAR_OK;
+        }
         const int r = g_rccl.AllReduce(p, p, n, NCCL_FLOAT64, op, comm->comm, st);
         if (r != 0) { set_error("ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PLANAR_EDEVICE; }
         return PLANAR_OK;
     };
-    auto d2h = [&](void* dst, const void* src, size_t bytes) -> int {
-        PLANAR_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
-        PLANAR_HIP_CHECK(hipStreamSynchronize(st));
-        return PLANAR_OK;
-    };
     int lm_iters = 0;
     bool stopped = false;
+    auto stop_now = [&]() { return stop_flag && *stop_flag ? 1 : 0; };
 
-    // errors at the current state -> robust chi2 summed over ranks (slot `slot` of red / red2)
-    auto eval_chi = [&](int robust, double* slot, double& chi) -> int {
-        PLANAR_HIP_CHECK(hipMemsetAsync(slot, 0, 8, st));
-        if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, slot);
-        int r = allreduce(slot, 1, NCCL_SUM);
-        if (r) return r;
-        return d2h(&chi, slot, 8);
+    // the launches that open an LM iteration; every kernel is predicated on the device state (need_build && !done)
+    auto enqueue_open = [&](int robust) {
+        hipLaunchKernelGGL(ba_begin, dim3(4), dim3(NT), 0, st, D, (int)nred);
+        if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.red + (size_t)np * 36 + NP, 1);
+        if (L) hipLaunchKernelGGL(ba_build, gL, dim3(NT), smem_build, st, D, robust);
+    };
+    // one LM trial.  No host decision inside: open (if the state says so), Schur, exchange A, solve, update, errors, exchange B, decide, restore.
+    auto enqueue_step = [&](int robust, bool opened) -> int {
+        int r;
+        if (!opened) enqueue_open(robust);
+        PLANAR_HIP_CHECK(hipMemcpyAsync(D.redg, D.red, nred * 8, hipMemcpyDeviceToDevice, st));
+        PLANAR_HIP_CHECK(hipMemsetAsync(D.red2, 0, nS * 8, st));
+        PLANAR_HIP_CHECK(hipMemsetAsync(D.trial, 0, 32, st));
+        if (L && NP) hipLaunchKernelGGL(ba_schur, gL, dim3(NT), smem_schur, st, D);
+        if ((r = allreduce(D.redg, nA, NCCL_SUM))) return r;                                            // exchange A
+        hipLaunchKernelGGL(ba_solve, dim3(1), dim3(NT), smem_solve, st, D);
+        if (NP == 0 && L) hipLaunchKernelGGL(ba_schur, gL, dim3(NT), 8, st, D);                         // Dinv only
+        hipLaunchKernelGGL(ba_update, gU, dim3(NT), 0, st, D, stop_now());
+        if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.trial, 0);
+        if ((r = allreduce(D.trial, 3, NCCL_SUM))) return r;                                            // exchange B
+        hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, st, D);
+        hipLaunchKernelGGL(ba_restore, gU, dim3(NT), 0, st, D);
+        return PLANAR_OK;
     };
     // SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg
     auto optimize = [&](int iterations, int robust) -> int {
-        double lambda = -1, ni = 2;
-        int nBad = 0;
-        for (int it = 0; it < iterations; it++) {
-            if (stop_flag && *stop_flag) { stopped = true; break; }          // SparseOptimizer::terminate()
-            lm_iters++;
-            double currentChi = 0;
-            int r;
-            PLANAR_HIP_CHECK(hipMemsetAsync(D.red, 0, nred * 8, st));
-            PLANAR_HIP_CHECK(hipMemsetAsync(D.scal, 0, 8, st));
-            if ((r = eval_chi(robust, D.red + (size_t)np * 36 + NP, currentChi))) return r;
-            PLANAR_HIP_CHECK(hipMemsetAsync(D.red + (size_t)np * 36 + NP, 0, 8, st));
-            if (L) hipLaunchKernelGGL(ba_build, gL, dim3(NT), smem_build, st, D, robust);
-            if ((r = allreduce(D.red, (size_t)np * 36 + NP, NCCL_SUM))) return r;
-            double tempChi = currentChi;
-            const double iniChi = currentChi;
-            std::vector<double> hred((size_t)np * 36 + NP);
-            if (it == 0) {                                                   // computeLambdaInit
-                if ((r = allreduce(D.scal, 1, NCCL_MAX))) return r;
-                double mx = 0;
-                if ((r = d2h(&mx, D.scal, 8))) return r;
-                if (!hred.empty() && (r = d2h(hred.data(), D.red, hred.size() * 8))) return r;
-                for (int p = 0; p < np; p++) for (int a = 0; a < 6; a++) mx = std::max(mx, std::fabs(hred[(size_t)p * 36 + a * 7]));
-                lambda = 1e-5 * mx; ni = 2; nBad = 0;
-            }
-            double rho = 0;
-            int qmax = 0;
-            do {
-                PLANAR_HIP_CHECK(hipMemsetAsync(D.red2, 0, nred2 * 8, st));
-                if (L && NP) hipLaunchKernelGGL(ba_schur, gL, dim3(NT), smem_schur, st, D, lambda);
-                if ((r = allreduce(D.red2, (size_t)NP * NP + NP, NCCL_SUM))) return r;
-                hipLaunchKernelGGL(ba_solve, dim3(1), dim3(NT), smem_solve, st, D, lambda);
-                if (NP == 0 && L) hipLaunchKernelGGL(ba_schur, gL, dim3(NT), 8, st, D, lambda);   // Dinv only
-                hipLaunchKernelGGL(ba_update, gU, dim3(NT), 0, st, D, lambda, D.red2 + (size_t)NP * NP + NP + 1);
-                if ((r = allreduce(D.red2 + (size_t)NP * NP + NP + 1, 1, NCCL_SUM))) return r;
-                if ((r = eval_chi(robust, D.red2 + (size_t)NP * NP + NP, tempChi))) return r;
-                double tail[2], lmscale;
-                if ((r = d2h(tail, D.xp + NP, 16))) return r;
-                if ((r = d2h(&lmscale, D.red2 + (size_t)NP * NP + NP + 1, 8))) return r;
-                const bool ok2 = tail[0] != 0.0;
-                if (!ok2) tempChi = std::numeric_limits<double>::max();
-                rho = currentChi - tempChi;
-                double scale = tail[1] + lmscale + 1e-3;
-                rho /= scale;
-                if (rho > 0 && std::isfinite(tempChi)) {
-                    double alpha = 1. - std::pow((2 * rho - 1), 3);
-                    alpha = std::min(alpha, 2. / 3.);
-                    lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
-                } else {
-                    lambda *= ni; ni *= 2;
-                    hipLaunchKernelGGL(ba_restore, gU, dim3(NT), 0, st, D);
-                }
-                qmax++;
-            } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
-            if (qmax == 10 || rho == 0) break;
-            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-            if (nBad >= 3) break;
+        if (iterations <= 0) return PLANAR_OK;
+        LmState h;
+        std::memset(&h, 0, sizeof(h));
+        h.lambda = -1; h.ni = 2; h.iterations = iterations; h.need_build = 1;
+        PLANAR_HIP_CHECK(hipMemcpyAsync(D.st, &h, sizeof(h), hipMemcpyHostToDevice, st));
+        int r;
+        // first trial: computeLambdaInit needs max |diag| over BOTH block families of the summed Hessian before the first Schur complement
+        enqueue_open(robust);
+        const double stop0[1] = {(double)stop_now()};
+        PLANAR_HIP_CHECK(hipMemcpyAsync(D.scal + 1, stop0, 8, hipMemcpyHostToDevice, st));
+        PLANAR_HIP_CHECK(hipMemcpyAsync(D.redg, D.red, nred * 8, hipMemcpyDeviceToDevice, st));
+        if ((r = allreduce(D.redg, nred, NCCL_SUM))) return r;
+        if ((r = allreduce(D.scal, 2, NCCL_MAX))) return r;
+        hipLaunchKernelGGL(ba_lambda_init, dim3(1), dim3(64), 0, st, D);
+        bool opened = true;
+        const int max_steps = iterations * 10;
+        int steps = 0;
+        while (steps < max_steps) {
+            const int chunk = std::min(max_steps - steps, steps == 0 ? iterations : 4);      // the common case (every first trial accepted) is ONE chunk
+            for (int i = 0; i < chunk; i++) { if ((r = enqueue_step(robust, opened))) return r; opened = false; }
+            steps += chunk;
+            PLANAR_HIP_CHECK(hipMemcpyAsync(&h, D.st, sizeof(h), hipMemcpyDeviceToHost, st));
+            PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+            if (h.done) break;
         }
+        lm_iters += h.lm_iters;
+        stopped = h.stopped != 0;
         PLANAR_HIP_CHECK(hipGetLastError());
         return PLANAR_OK;
     };
