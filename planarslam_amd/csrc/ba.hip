@@ -5,10 +5,12 @@
 // KeyFrame / MapPoint / MapLine / MapPlane objects arrives as plain arrays (planar_ba_problem).
 //
 //   ba_errors    thread = edge        FP64 residuals of the active edges (stored, like g2o's _error) + robust chi2
-//   ba_build     thread = landmark    linearise its edges (analytic point/line, numeric plane Jacobians), Hll (3x3), bl,
-//                                     per-edge coupling block W = B^T (w Omega) A (6x3); pose blocks Hpp / bp are summed
-//                                     in LDS per workgroup, then flushed with FP64 atomics
-//   ba_schur     thread = landmark    Dinv = (Hll + lambda I)^-1; S -= W_e Dinv W_f^T, b -= W_e Dinv bl, accumulated in an
+//   ba_linearize thread = edge        Jacobians (analytic point/line, numeric plane), the edge's coupling block W = B^T (w Omega) A (6x3) and
+//                                     its landmark-block contribution; pose blocks Hpp / bp are summed in LDS per workgroup, then flushed
+//                                     with FP64 atomics
+//   ba_gather    thread = landmark    Hll (3x3), bl = sum of its edges' contributions in edge order
+//   ba_dinv      thread = landmark    Dinv = (Hll + lambda I)^-1, Dinv bl
+//   ba_schur     thread = edge        S[p(e)][q(f)] -= W_e Dinv W_f^T over the edges f of e's landmark, b -= W_e Dinv bl, accumulated in an
 //                                     LDS copy of the reduced system (<= 120 x 120 doubles) per workgroup, then flushed
 //   [exchange]   RCCL all-reduce (sum) of the reduced camera system: landmarks (and all their edges) are partitioned
 //                across GPUs, every GPU then solves the same 6K x 6K system redundantly (29 KB payload)
@@ -57,7 +59,8 @@ struct Dev {
     double* e_err;                           // [E][3]
     uint8_t* e_level;                        // 0 active, 1 outlier
     uint8_t* e_out;                          // final "to erase" flag
-    double* Hll; double* bl; double* Dinv; double* W; double* xl;   // [L][9] [L][3] [L][9] [E][18] [L][3]
+    double* Hll; double* bl; double* Dinv; double* W; double* xl;   // [L][9] [L][3] [L][9] [E][18] [L][3] (xl: Dinv * bl)
+    double* He;                              // [E][12]: the edge's A^T w Omega A (9) and -A^T w Omega e (3)
     double* red;                             // this rank's [np*36 Hpp | 6np bp | chi | pad], rebuilt at the start of an LM iteration
     double* redg;                            // exchange buffer A, first part: the same layout, summed over ranks
     double* red2;                            // exchange buffer A, second part (contiguous with redg): [NP*NP Schur terms | NP rhs terms]
@@ -169,21 +172,20 @@ __global__ __launch_bounds__(NT) void ba_begin(Dev D, int nred) {
     if (blockIdx.x == 0 && threadIdx.x == 0) D.scal[0] = 0;
 }
 
-__global__ __launch_bounds__(NT) void ba_build(Dev D, int robust) {
+// thread = EDGE: Jacobians, the edge's coupling block W = B^T (w Omega) A, its contribution to the landmark block (A^T w Omega A, -A^T w Omega e) and,
+// through LDS, to the pose blocks.  (One thread per landmark left a plane vertex - ~30 numeric-Jacobian edges - as the long pole of the launch.)
+__global__ __launch_bounds__(NT) void ba_linearize(Dev D, int robust) {
     extern __shared__ __attribute__((aligned(16))) double s_pp[];   // [np][42]: Hpp (36) + bp (6)
-    __shared__ double s4[4];
     if (D.st->done || !D.st->need_build) return;
-    const int l = blockIdx.x * NT + threadIdx.x;
+    const int e = blockIdx.x * NT + threadIdx.x;
     for (int i = threadIdx.x; i < D.np * 42; i += NT) s_pp[i] = 0;
     __syncthreads();
-    double maxd = 0;
-    if (l < D.L) {
-        double Hll[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-        const LmV Lm = load_lm(D, D.lm, l);
-        bool any = false;
-        for (int e = D.lm_start[l]; e < D.lm_start[l + 1]; e++) {
-            if (D.e_level[e] != 0) { for (int i = 0; i < 18; i++) D.W[(size_t)e * 18 + i] = 0; continue; }
-            any = true;
+    if (e < D.E) {
+        double Wb[18], He[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, be[3] = {0, 0, 0};
+        for (int i = 0; i < 18; i++) Wb[i] = 0;
+        if (D.e_level[e] == 0) {
+            const int l = edge_landmark(D, e);
+            const LmV Lm = load_lm(D, D.lm, l);
             const int type = D.e_type[e], dim = edge_dim(type), kf = D.e_kf[e], p = D.pidx[kf];
             const SE3 T = load_T(D.T, kf);
             const double* meas = D.e_meas + (size_t)e * 4;
@@ -244,15 +246,13 @@ __global__ __launch_bounds__(NT) void ba_build(Dev D, int robust) {
             }
             double w = 1;
             if (robust) { double r0; huber(edge_chi2(dim, err, info), info[3], r0, w); }
-            double Wb[18];
-            for (int i = 0; i < 18; i++) Wb[i] = 0;
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 if (i >= dim) continue;
                 const double wo = w * info[i], r = -info[i] * err[i] * w;
                 for (int a = 0; a < 3; a++) {
-                    bl[a] += A[i][a] * r;
-                    for (int cc = 0; cc < 3; cc++) Hll[a * 3 + cc] += A[i][a] * wo * A[i][cc];
+                    be[a] += A[i][a] * r;
+                    for (int cc = 0; cc < 3; cc++) He[a * 3 + cc] += A[i][a] * wo * A[i][cc];
                 }
                 if (p >= 0) {
                     for (int a = 0; a < 6; a++) {
@@ -262,11 +262,10 @@ __global__ __launch_bounds__(NT) void ba_build(Dev D, int robust) {
                     }
                 }
             }
-            for (int i = 0; i < 18; i++) D.W[(size_t)e * 18 + i] = Wb[i];
         }
-        for (int i = 0; i < 9; i++) D.Hll[(size_t)l * 9 + i] = Hll[i];
-        for (int i = 0; i < 3; i++) D.bl[(size_t)l * 3 + i] = bl[i];
-        if (any) maxd = fmax(fabs(Hll[0]), fmax(fabs(Hll[4]), fabs(Hll[8])));
+        for (int i = 0; i < 18; i++) D.W[(size_t)e * 18 + i] = Wb[i];
+        for (int i = 0; i < 9; i++) D.He[(size_t)e * 12 + i] = He[i];
+        for (int i = 0; i < 3; i++) D.He[(size_t)e * 12 + 9 + i] = be[i];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < D.np * 42; i += NT) {
@@ -274,9 +273,29 @@ __global__ __launch_bounds__(NT) void ba_build(Dev D, int robust) {
         const double v = s_pp[i];
         if (v != 0) atomicAdd(k < 36 ? &D.red[(size_t)p * 36 + k] : &D.red[(size_t)D.np * 36 + p * 6 + (k - 36)], v);
     }
+}
+
+// thread = landmark: its block Hll / bl = the sum of its edges' contributions IN EDGE ORDER (deterministic), max |diag| for computeLambdaInit
+__global__ __launch_bounds__(NT) void ba_gather(Dev D) {
+    if (D.st->done || !D.st->need_build) return;
+    const int l = blockIdx.x * NT + threadIdx.x;
+    double maxd = 0;
+    if (l < D.L) {
+        double Hll[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+        bool any = false;
+        for (int e = D.lm_start[l]; e < D.lm_start[l + 1]; e++) {
+            if (D.e_level[e] != 0) continue;
+            any = true;
+            const double* h = D.He + (size_t)e * 12;
+            for (int i = 0; i < 9; i++) Hll[i] += h[i];
+            for (int i = 0; i < 3; i++) bl[i] += h[9 + i];
+        }
+        for (int i = 0; i < 9; i++) D.Hll[(size_t)l * 9 + i] = Hll[i];
+        for (int i = 0; i < 3; i++) D.bl[(size_t)l * 3 + i] = bl[i];
+        if (any) maxd = fmax(fabs(Hll[0]), fmax(fabs(Hll[4]), fabs(Hll[8])));
+    }
     for (int o = 32; o > 0; o >>= 1) maxd = fmax(maxd, __shfl_xor(maxd, o));
     if ((threadIdx.x & 63) == 0 && maxd > 0) atomicMax((unsigned long long*)&D.scal[0], (unsigned long long)__double_as_longlong(maxd));
-    (void)s4;
 }
 
 __device__ __forceinline__ void inv3(const double* H, double lambda, double Di[9]) {   // Matrix3d::inverse (cofactors)
@@ -288,41 +307,49 @@ __device__ __forceinline__ void inv3(const double* H, double lambda, double Di[9
     Di[6] = (d * h - e * g) * id; Di[7] = (b * g - a * h) * id; Di[8] = (a * e - b * d) * id;
 }
 
+// thread = landmark: Dinv = (Hll + lambda I)^-1 and Dinv * bl
+__global__ __launch_bounds__(NT) void ba_dinv(Dev D) {
+    if (D.st->done) return;
+    const double lambda = D.st->lambda;
+    const int l = blockIdx.x * NT + threadIdx.x;
+    if (l >= D.L) return;
+    bool any = false;
+    for (int e = D.lm_start[l]; e < D.lm_start[l + 1]; e++) any |= D.e_level[e] == 0;
+    if (!any) return;
+    double Di[9];
+    inv3(D.Hll + (size_t)l * 9, lambda, Di);
+    for (int i = 0; i < 9; i++) D.Dinv[(size_t)l * 9 + i] = Di[i];
+    const double* bl = D.bl + (size_t)l * 3;
+    for (int a = 0; a < 3; a++) D.xl[(size_t)l * 3 + a] = Di[a * 3] * bl[0] + Di[a * 3 + 1] * bl[1] + Di[a * 3 + 2] * bl[2];
+}
+
+// thread = EDGE e of landmark l: row block p(e) of the Schur terms, S[p][q(f)] -= W_e Dinv W_f^T for every edge f of l, b[p] -= W_e Dinv bl
 __global__ __launch_bounds__(NT) void ba_schur(Dev D) {
     extern __shared__ __attribute__((aligned(16))) double s_S[];    // [NP*NP + NP]
     if (D.st->done) return;
-    const double lambda = D.st->lambda;
     const int NP = 6 * D.np, tot = NP * NP + NP;
     for (int i = threadIdx.x; i < tot; i += NT) s_S[i] = 0;
     __syncthreads();
-    const int l = blockIdx.x * NT + threadIdx.x;
-    if (l < D.L) {
-        const int e0 = D.lm_start[l], e1 = D.lm_start[l + 1];
-        bool any = false;
-        for (int e = e0; e < e1; e++) any |= D.e_level[e] == 0;
-        if (any) {
-            double Di[9];
-            inv3(D.Hll + (size_t)l * 9, lambda, Di);
-            for (int i = 0; i < 9; i++) D.Dinv[(size_t)l * 9 + i] = Di[i];
-            const double* bl = D.bl + (size_t)l * 3;
-            const double db[3] = {Di[0] * bl[0] + Di[1] * bl[1] + Di[2] * bl[2], Di[3] * bl[0] + Di[4] * bl[1] + Di[5] * bl[2],
-                                  Di[6] * bl[0] + Di[7] * bl[1] + Di[8] * bl[2]};
-            for (int e = e0; e < e1; e++) {
-                const int p = D.pidx[D.e_kf[e]];
-                if (p < 0 || D.e_level[e] != 0) continue;
-                const double* We = D.W + (size_t)e * 18;
-                double BD[18];
+    const int e = blockIdx.x * NT + threadIdx.x;
+    if (e < D.E && D.e_level[e] == 0) {
+        const int p = D.pidx[D.e_kf[e]];
+        if (p >= 0) {
+            const int l = edge_landmark(D, e);
+            const int e0 = D.lm_start[l], e1 = D.lm_start[l + 1];
+            const double* Di = D.Dinv + (size_t)l * 9;
+            const double* db = D.xl + (size_t)l * 3;
+            const double* We = D.W + (size_t)e * 18;
+            double BD[18];
+            for (int a = 0; a < 6; a++)
+                for (int c = 0; c < 3; c++) BD[a * 3 + c] = We[a * 3] * Di[c] + We[a * 3 + 1] * Di[3 + c] + We[a * 3 + 2] * Di[6 + c];
+            for (int a = 0; a < 6; a++) atomicAdd(&s_S[NP * NP + p * 6 + a], -(We[a * 3] * db[0] + We[a * 3 + 1] * db[1] + We[a * 3 + 2] * db[2]));
+            for (int f = e0; f < e1; f++) {
+                const int q = D.pidx[D.e_kf[f]];
+                if (q < 0 || D.e_level[f] != 0) continue;
+                const double* Wf = D.W + (size_t)f * 18;
                 for (int a = 0; a < 6; a++)
-                    for (int c = 0; c < 3; c++) BD[a * 3 + c] = We[a * 3] * Di[c] + We[a * 3 + 1] * Di[3 + c] + We[a * 3 + 2] * Di[6 + c];
-                for (int a = 0; a < 6; a++) atomicAdd(&s_S[NP * NP + p * 6 + a], -(We[a * 3] * db[0] + We[a * 3 + 1] * db[1] + We[a * 3 + 2] * db[2]));
-                for (int f = e0; f < e1; f++) {
-                    const int q = D.pidx[D.e_kf[f]];
-                    if (q < 0 || D.e_level[f] != 0) continue;
-                    const double* Wf = D.W + (size_t)f * 18;
-                    for (int a = 0; a < 6; a++)
-                        for (int c = 0; c < 6; c++)
-                            atomicAdd(&s_S[(p * 6 + a) * NP + q * 6 + c], -(BD[a * 3] * Wf[c * 3] + BD[a * 3 + 1] * Wf[c * 3 + 1] + BD[a * 3 + 2] * Wf[c * 3 + 2]));
-                }
+                    for (int c = 0; c < 6; c++)
+                        atomicAdd(&s_S[(p * 6 + a) * NP + q * 6 + c], -(BD[a * 3] * Wf[c * 3] + BD[a * 3 + 1] * Wf[c * 3 + 1] + BD[a * 3 + 2] * Wf[c * 3 + 2]));
             }
         }
     }
@@ -367,11 +394,26 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
         }
         __syncthreads();
     }
+    __syncthreads();
+    if (s_ok) {                                 // column-oriented substitutions: L y = rhs, then L^T x = y
+        for (int i = 0; i < NP; i++) {
+            if (tid == 0) x[i] /= s_A[i * NP + i];
+            __syncthreads();
+            const double xi = x[i];
+            for (int k = i + 1 + tid; k < NP; k += NT) x[k] -= s_A[k * NP + i] * xi;
+            __syncthreads();
+        }
+        for (int i = NP - 1; i >= 0; i--) {
+            if (tid == 0) x[i] /= s_A[i * NP + i];
+            __syncthreads();
+            const double xi = x[i];
+            for (int k = tid; k < i; k += NT) x[k] -= s_A[i * NP + k] * xi;
+            __syncthreads();
+        }
+    }
     if (tid == 0) {
         double scale = 0;
         if (s_ok) {
-            for (int i = 0; i < NP; i++) { double v = x[i]; for (int k = 0; k < i; k++) v -= s_A[i * NP + k] * x[k]; x[i] = v / s_A[i * NP + i]; }
-            for (int i = NP - 1; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < NP; k++) v -= s_A[k * NP + i] * x[k]; x[i] = v / s_A[i * NP + i]; }
             for (int i = 0; i < NP; i++) { D.xp[i] = x[i]; scale += x[i] * (lambda * x[i] + D.redg[(size_t)D.np * 36 + i]); }
         }
         D.xp[NP] = s_ok ? 1.0 : 0.0;
@@ -651,7 +693,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     const size_t oT = carve((size_t)K * 64), oTb = carve((size_t)K * 64), oP = carve((size_t)K * 4), oLm = carve((size_t)L * 32), oLb = carve((size_t)L * 32),
                  oLt = carve(L), oLs = carve((size_t)(L + 1) * 4), oEk = carve((size_t)E * 4), oEt = carve(E), oEp = carve((size_t)E * 4),
                  oEm = carve((size_t)E * 32), oEi = carve((size_t)E * 32), oEe = carve((size_t)E * 24), oEl = carve(E), oEo = carve(E),
-                 oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oDi = carve((size_t)L * 72), oW = carve((size_t)E * 144), oXl = carve((size_t)L * 24),
+                 oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oDi = carve((size_t)L * 72), oW = carve((size_t)E * 144), oHe = carve((size_t)E * 96), oXl = carve((size_t)L * 24),
                  oR = carve(nred * 8), oA = carve(nA * 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8), oSc = carve(64), oSt = carve(sizeof(LmState));
     DevBuf buf;
     int rc = buf.alloc(off);
@@ -668,7 +710,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     D.T = (double*)(base + oT); D.Tbak = (double*)(base + oTb); D.pidx = (const int*)(base + oP); D.lm = (double*)(base + oLm); D.lmbak = (double*)(base + oLb);
     D.lm_type = base + oLt; D.lm_start = (const int*)(base + oLs); D.e_kf = (const int*)(base + oEk); D.e_type = base + oEt; D.e_partner = (const int*)(base + oEp);
     D.e_meas = (const double*)(base + oEm); D.e_info = (const double*)(base + oEi); D.e_err = (double*)(base + oEe); D.e_level = base + oEl; D.e_out = base + oEo;
-    D.Hll = (double*)(base + oH); D.bl = (double*)(base + oB); D.Dinv = (double*)(base + oDi); D.W = (double*)(base + oW); D.xl = (double*)(base + oXl);
+    D.Hll = (double*)(base + oH); D.bl = (double*)(base + oB); D.Dinv = (double*)(base + oDi); D.W = (double*)(base + oW); D.He = (double*)(base + oHe); D.xl = (double*)(base + oXl);
     D.red = (double*)(base + oR); D.redg = (double*)(base + oA); D.red2 = D.redg + nred; D.trial = (double*)(base + oTr); D.xp = (double*)(base + oXp);
     D.scal = (double*)(base + oSc); D.st = (LmState*)(base + oSt);
     D.cam = Cam{(double)prm->fx, (double)prm->fy, (double)prm->cx, (double)prm->cy, (double)prm->bf};
@@ -704,7 +746,8 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     auto enqueue_open = [&](int robust) {
         hipLaunchKernelGGL(ba_begin, dim3(4), dim3(NT), 0, st, D, (int)nred);
         if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.red + (size_t)np * 36 + NP, 1);
-        if (L) hipLaunchKernelGGL(ba_build, gL, dim3(NT), smem_build, st, D, robust);
+        if (E) hipLaunchKernelGGL(ba_linearize, gE, dim3(NT), smem_build, st, D, robust);
+        if (L) hipLaunchKernelGGL(ba_gather, gL, dim3(NT), 0, st, D);
     };
     // one LM trial.  No host decision inside: open (if the state says so), Schur, exchange A, solve, update, errors, exchange B, decide, restore.
     auto enqueue_step = [&](int robust, bool opened) -> int {
@@ -713,10 +756,10 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
         PLANAR_HIP_CHECK(hipMemcpyAsync(D.redg, D.red, nred * 8, hipMemcpyDeviceToDevice, st));
         PLANAR_HIP_CHECK(hipMemsetAsync(D.red2, 0, nS * 8, st));
         PLANAR_HIP_CHECK(hipMemsetAsync(D.trial, 0, 32, st));
-        if (L && NP) hipLaunchKernelGGL(ba_schur, gL, dim3(NT), smem_schur, st, D);
+        if (L) hipLaunchKernelGGL(ba_dinv, gL, dim3(NT), 0, st, D);
+        if (E && NP) hipLaunchKernelGGL(ba_schur, gE, dim3(NT), smem_schur, st, D);
         if ((r = allreduce(D.redg, nA, NCCL_SUM))) return r;                                            // exchange A
         hipLaunchKernelGGL(ba_solve, dim3(1), dim3(NT), smem_solve, st, D);
-        if (NP == 0 && L) hipLaunchKernelGGL(ba_schur, gL, dim3(NT), 8, st, D);                         // Dinv only
         hipLaunchKernelGGL(ba_update, gU, dim3(NT), 0, st, D, stop_now());
         if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.trial, 0);
         if ((r = allreduce(D.trial, 3, NCCL_SUM))) return r;                                            // exchange B

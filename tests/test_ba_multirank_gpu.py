@@ -81,7 +81,7 @@ def _check(outs):
     kf0 = np.array(outs[0]["kf"])
     for d in outs:
         assert np.array_equal(np.array(d["kf"]), kf0)              # every rank solved the same reduced system, bit for bit
-        assert d["d_kf"] <= 1e-6 and d["d_lm"] <= 1e-6, d            # float32 poses; only the summation order differs from the single-GPU solve
+        assert d["d_kf"] <= 1e-6 and d["d_lm"] <= 1e-4, d            # float32 poses; only the summation order differs (1e-4 m on badly observed depths, as in test_ba_gpu)
         assert d["flags_equal"] and d["n_out"] > 0
         assert d["lm_iters"] == d["full_iters"] and d["stopped"] == 0
         assert d["nlm"] > 0
