@@ -94,6 +94,11 @@ int planar_orb_extract(planar_orb* orb, const uint8_t* gray, int B, int pitch, i
 int planar_orb_extract_dev(planar_orb* orb, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride,
                            planar_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n_out);
 
+/* Synchronises; PLANAR_ECAPACITY if a FAST cell produced more non-max-suppressed corners than its candidate slots since the last check
+ * (the slot count is the mathematical bound on strict 8-neighbour maxima, so this reports a broken invariant, not a tuning limit).
+ * The host-pointer entry point calls it itself. */
+int planar_orb_check(planar_orb* orb);
+
 /* Stage read-back for parity tests and for the adapter's public mvImagePyramid member
  * (include/ORBextractor.h:85).  Valid after an extract call; host output buffers. */
 int planar_orb_read_level(planar_orb* orb, int frame, int level, uint8_t* out /* w*h */);

@@ -16,7 +16,7 @@
 //   * lsd.cpp orders pixels with std::sort on the 1024-bin gradient norm (normPoint/compare_norm).  std::sort's
 //     order among equal bins is libstdc++'s introsort order: tie_order = 0 runs the real std::sort;
 //     tie_order = 1 keeps raster order inside a bin (the original LSD coorlist behaviour).  The HIP path
-//     implements tie_order = 1 (LSD section).
+//     implements both (planar_lsd_set_tie_order; 0 = libstdc++ order is its default, lsd_sort in lsd.hip).
 //   * cos(float(angle)) / sin(float(angle)) in region_grow and cos/sin(direction) in computeLBD resolve to the
 //     float overloads; both sides evaluate them as (float)cos((double)x)                            [assumed]
 //   * BinaryDescriptor's `combinations` band-pair table                                              [assumed]

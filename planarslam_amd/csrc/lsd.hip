@@ -189,7 +189,7 @@ __device__ __forceinline__ void lds_sync();
 //   * __final_insertion_sort is a stable sort of the arrangement the partitions leave = the two radix passes below.
 // Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py).  A depth-limit overflow (heap-sort fallback of introsort)
 // cannot be reproduced this way and raises status 2; it needs ~34 unbalanced partitions in a row and does not occur on 10-bit keys.
-constexpr int SORT_NT = 256;        // threads of lsd_sort: 16 wavefronts keep 16 sub-ranges (or 16 shares of a big one) in flight
+constexpr int SORT_NT = 256;        // threads of lsd_sort: 4 wavefronts keep 4 sub-ranges (or 4 shares of a big one) in flight; 38 KB LDS, so four frames share a CU
 constexpr int SORT_NW = SORT_NT / 64;
 constexpr int SORT_SMALL = 2048;    // finished by one wavefront
 constexpr int SORT_STAGE = 4096;    // staged in LDS by the workgroup

@@ -181,7 +181,7 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int stride, int 
 
 __global__ __launch_bounds__(256) void orb_fast_cells(const PlanDev* __restrict__ plan, const CellDev* __restrict__ cells,
                                                       const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
-                                                      int* __restrict__ cell_count) {
+                                                      int* __restrict__ cell_count, int* __restrict__ dropped) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_wave_cnt[4];
     __shared__ int s_any_ini;
@@ -254,7 +254,11 @@ __global__ __launch_bounds__(256) void orb_fast_cells(const PlanDev* __restrict_
         base += total;
         __syncthreads();
     }
-    if (tid == 0) *out_count = base;
+    if (tid == 0) {
+        *out_count = min(base, C.slot_cap);
+        // slot_cap = ceil(w/2) * ceil(h/2) bounds the strict 8-neighbour maxima of a cell, so this never fires; counted (planar_orb_check), not assumed
+        if (base > C.slot_cap) atomicAdd(dropped, base - C.slot_cap);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -750,7 +754,7 @@ struct planar_orb {
     int fast_smem = 0, node_cap = 0, oct_smem = 0;
     int last_B = 0;
     DevBuf d_plan, d_cells, d_tiles, d_tabs, d_pyr, d_blur, d_cand, d_cell_count, d_sortA, d_sortB, d_level_count,
-        d_kept, d_kept_count;
+        d_kept, d_kept_count, d_dropped;
     // staging for the host-pointer entry point
     DevBuf d_in, d_kps, d_desc, d_nout;
     // optional per-launch HIP-event timing (planar_orb_set_profiling)
@@ -933,11 +937,12 @@ int planar_orb_create(planar_ctx* ctx, const planar_orb_params* p, int W, int H,
         (rc = o->d_cand.alloc(B * P.cand_stride * sizeof(uint32_t))) || (rc = o->d_cell_count.alloc(B * P.ncells_total * sizeof(int))) ||
         (rc = o->d_sortA.alloc(B * P.cand_stride * sizeof(uint64_t))) || (rc = o->d_sortB.alloc(B * P.cand_stride * sizeof(uint64_t))) ||
         (rc = o->d_level_count.alloc(B * MAX_LEVELS * sizeof(int))) || (rc = o->d_kept.alloc(B * P.kept_stride * sizeof(uint32_t))) ||
-        (rc = o->d_kept_count.alloc(B * MAX_LEVELS * sizeof(int)))) {
+        (rc = o->d_kept_count.alloc(B * MAX_LEVELS * sizeof(int))) || (rc = o->d_dropped.alloc(64))) {
         delete o;
         return rc;
     }
     hipError_t e = hipMemcpy(o->d_plan.p, &P, sizeof(P), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(o->d_dropped.p, 0, 64);
     if (e == hipSuccess) e = hipMemcpy(o->d_cells.p, o->cells.data(), o->cells.size() * sizeof(CellDev), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_tiles.p, o->tiles.data(), o->tiles.size() * sizeof(TileDev), hipMemcpyHostToDevice);
     if (e == hipSuccess && !tabs.empty()) e = hipMemcpy(o->d_tabs.p, tabs.data(), tabs.size() * sizeof(short4), hipMemcpyHostToDevice);
@@ -1041,7 +1046,7 @@ int planar_orb_extract_dev(planar_orb* o, const uint8_t* d_gray, int B, int pitc
         mark();
     }
     hipLaunchKernelGGL(orb_fast_cells, dim3(P.ncells_total, B), dim3(256), o->fast_smem, st, dp, o->d_cells.as<CellDev>(), pyr,
-                       o->d_cand.as<uint32_t>(), o->d_cell_count.as<int>());
+                       o->d_cand.as<uint32_t>(), o->d_cell_count.as<int>(), o->d_dropped.as<int>());
     mark();
     hipLaunchKernelGGL(orb_sort, dim3(P.nlevels, B), dim3(256), 0, st, dp, o->d_cells.as<CellDev>(), o->d_cand.as<uint32_t>(),
                        o->d_cell_count.as<int>(), o->d_sortA.as<uint64_t>(), o->d_sortB.as<uint64_t>(), o->d_level_count.as<int>());
@@ -1056,6 +1061,19 @@ int planar_orb_extract_dev(planar_orb* o, const uint8_t* d_gray, int B, int pitc
     mark();
     PLANAR_HIP_CHECK(hipGetLastError());
     o->last_B = B;
+    return PLANAR_OK;
+}
+
+int planar_orb_check(planar_orb* o) {
+    PLANAR_REQUIRE(o != nullptr, PLANAR_EINVAL, "orb is null");
+    int dropped = 0;
+    PLANAR_HIP_CHECK(hipMemcpyAsync(&dropped, o->d_dropped.p, 4, hipMemcpyDeviceToHost, o->ctx->stream));
+    PLANAR_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
+    if (dropped != 0) {
+        (void)hipMemsetAsync(o->d_dropped.p, 0, 4, o->ctx->stream);
+        set_error("planar_orb: %d FAST candidates did not fit their cell's slot array", dropped);
+        return PLANAR_ECAPACITY;
+    }
     return PLANAR_OK;
 }
 
@@ -1082,8 +1100,7 @@ int planar_orb_extract(planar_orb* o, const uint8_t* gray, int B, int pitch, int
     PLANAR_HIP_CHECK(hipMemcpyAsync(kps, o->d_kps.p, (size_t)B * cap * sizeof(planar_keypoint), hipMemcpyDeviceToHost, st));
     PLANAR_HIP_CHECK(hipMemcpyAsync(desc, o->d_desc.p, (size_t)B * cap * 32, hipMemcpyDeviceToHost, st));
     PLANAR_HIP_CHECK(hipMemcpyAsync(n_out, o->d_nout.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PLANAR_HIP_CHECK(hipStreamSynchronize(st));
-    return PLANAR_OK;
+    return planar_orb_check(o);
 }
 
 static int read_plane(planar_orb* o, const DevBuf& buf, int frame, int level, uint8_t* out) {

@@ -5,16 +5,19 @@
 // B independent depth frames.  Plane labels, plane normals/centres/MSE are bit-exact against the CPU oracle, which
 // is pinned label-for-label against the real reference sources.
 //
-//   K1 peac_blocks   one THREAD per 10x10 block: depth -> XYZ in FP64, validity / depth-discontinuity tests,
-//                    the nine moment sums accumulated in the reference's raster order (bit-exact FP64 sums),
-//                    PCA by the iterative 3x3 symmetric eigen-solver (Eigen's algorithm, restated)        (a13-a15)
-//   K2 peac_segment  one WAVE per frame, the order-dependent part:
-//                      initGraph edges -> ahCluster (libstdc++-exact binary min-MSE heap in LDS, the candidate
-//                      merges of one node evaluated one-per-lane) -> block erosion + seed queue (prefix sums) ->
-//                      floodFill (16 queue entries x 4 neighbours per wave step, same-pixel conflicts replayed in
-//                      order) -> final ahCluster over the surviving planes -> relabel                     (a16-a17)
-// Frame-level batch parallelism supplies the occupancy; inside a frame only the
-// order-independent work is spread over the 64 lanes.
+//   peac_blocks   one THREAD per 10x10 block: depth -> XYZ in FP64, validity / depth-discontinuity tests, the nine moment sums
+//                 accumulated in the reference's raster order (bit-exact FP64 sums), PCA by the iterative 3x3 symmetric
+//                 eigen-solver (Eigen's algorithm, restated)                                                            (a13-a15)
+//   peac_ahc      one WAVEFRONT (64 lanes) per frame, the order-dependent clustering: initGraph edges -> ahCluster with a
+//                 libstdc++-exact binary min-MSE heap.  47 KB LDS per frame (heap keys 24.5 K, heap ids 6 K, neighbour-list
+//                 offsets / counts 6 K + 6 K + 3 K, flag bits 1.5 K); the neighbour-list POOL lives in the frame's global
+//                 workspace and is staged through LDS when two lists are merged.  Three frames share a CU.
+//   peac_order    ranks the frames by the clustering time of the previous call (longest first) for the next launch
+//   peac_refine   256 threads per frame (16.6 KB LDS): block erosion + seed queue (prefix sums) -> floodFill (queue entries x
+//                 4 neighbours per step, same-pixel conflicts replayed in order) -> final ahCluster over the surviving planes ->
+//                 relabel; the node arrays stay in the global workspace                                                  (a16-a17)
+// Frame-level batch parallelism supplies the occupancy: the clustering is a chain of dependent FP64 operations, so a
+// frame is latency-bound and the launch time is (frames / resident frames) x the slowest frame.  DESIGN.md §PEAC has the numbers.
 #include "common.h"
 
 // Per-step cycle counters of the ahCluster loop (tools/peac_timing.py).  s_memtime drains the LDS queue every time it is read, so the

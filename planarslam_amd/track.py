@@ -330,8 +330,11 @@ class TrackPipeline:
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def check(self):
+        """Capacity flags of the extractors (synchronises): raises if a frame overflowed an internal capacity."""
+        from ._lib import check
+        check(self.ex.L.planar_orb_check(self.ex.h))
         for q in self.pds:
-            q.L.planar_peac_check(q.h, self.B)
+            check(q.L.planar_peac_check(q.h, self.B))
 
 
 def build_map(gray0, depth0, cam, torch_dev=None, seed=0, n_map_planes=8, n_plane_pts=128, n_normals=4096):
