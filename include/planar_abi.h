@@ -465,6 +465,22 @@ typedef struct planar_ba_result {
 int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* problem, const planar_pose_params* params, int its1, int its2,
                     planar_ba_result* result, volatile int* stop_flag, planar_comm* comm);
 
+/* ---- surface normals (replaces the tail of Frame::ComputePlanes, src/Frame.cc:694-751: the depth image sampled every 3rd pixel ->
+ *      pcl::IntegralImageNormalEstimation(AVERAGE_3D_GRADIENT, MaxDepthChangeFactor 0.05, NormalSmoothingSize 10) -> vSurfaceNormal) ----
+ * Output per frame: planar_normals_count() entries in the reference's push_back order (odd rows m, odd columns n of the
+ * ceil(W/3) x ceil(H/3) grid, row-major; 8 560 for 640x480): normals[b][i] = SurfaceNormal::normal (NaN where PCL yields none),
+ * points[b][i] = SurfaceNormal::cameraPosition (or NULL); FramePosition is (3n, 3m).  The normals array is what
+ * planar_track_manhattan_frame takes (n_normals = count, sn_stride = out_stride). */
+typedef struct planar_normals planar_normals;
+int planar_normals_create(planar_ctx* ctx, int width, int height, int max_batch, planar_normals** out);
+void planar_normals_destroy(planar_normals* nrm);
+int planar_normals_count(const planar_normals* nrm);
+int planar_normals_grid(const planar_normals* nrm, int* grid_w, int* grid_h, int* out_w, int* out_h);
+int planar_normals_compute(planar_normals* nrm, const uint16_t* depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy, float cx,
+                           float cy, float depth_factor, float* normals /* [B][count][3] */, float* points /* [B][count][3] or NULL */);
+int planar_normals_compute_dev(planar_normals* nrm, const uint16_t* d_depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy,
+                               float cx, float cy, float depth_factor, float* d_normals, float* d_points, int out_stride);
+
 /* ---- Manhattan-frame tracking (replaces Tracking::TrackManhattanFrame, src/Tracking.cc:963-1138, with its helpers
  *      ProjectSN2Conic :886-953, ProjectSN2MF :757-884 and MeanShift :1140-1157; called once per frame by Tracking::Track, :248) ----
  * R_last   : [B][9]   row-major 3x3 float, mLastRcm (camera <- Manhattan frame)

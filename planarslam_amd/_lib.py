@@ -154,6 +154,13 @@ _SIGS = {
     "planar_peac_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "planar_comm_unique_id": (C.c_int, [C.c_void_p]),
     "planar_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "planar_normals_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "planar_normals_destroy": (None, [C.c_void_p]),
+    "planar_normals_count": (C.c_int, [C.c_void_p]),
+    "planar_normals_grid": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "planar_normals_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "planar_normals_compute_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                            C.c_void_p, C.c_int]),
     "planar_comm_create_hosted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_comm_destroy": (None, [C.c_void_p]),
     "planar_local_ba": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(PoseParams), C.c_int, C.c_int, C.POINTER(BAResult), C.c_void_p, C.c_void_p]),

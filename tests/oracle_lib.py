@@ -713,3 +713,18 @@ def run_ref_stereo(keys, depth, Tcw, cam, depth_factor=1.0 / 5000.0):
     pay = (_camera_block(frame, 0.18, 8) + np.ascontiguousarray(Tcw, np.float32).tobytes() + np.array([W, H, len(keys)], np.int32).tobytes() + imf.tobytes() + kp.tobytes())
     rec = np.frombuffer(_run_ref_frame("stereo", pay), np.dtype([("u_right", "<f4"), ("depth", "<f4"), ("xw", "<f4", 3)]))
     return rec
+
+
+def surface_normals(depth, cam=(535.4, 539.2, 320.1, 247.6), factor=1.0 / 5000.0, want_dist=False):
+    """Frame::ComputePlanes' surface normals (oracle/normals_oracle.cpp) of one u16 depth frame -> normals [n,3], points [n,3] (+ chamfer map)."""
+    L = lib()
+    depth = np.ascontiguousarray(depth, np.uint16)
+    H, W = depth.shape
+    gw, gh = -(-W // 3), -(-H // 3)
+    cap = (gw // 2) * (gh // 2)
+    nrm = np.zeros((cap, 3), np.float32); pts = np.zeros((cap, 3), np.float32); dist = np.zeros((gh, gw), np.float32)
+    L.orc_surface_normals.restype = C.c_int
+    n = L.orc_surface_normals(C.c_void_p(depth.ctypes.data), W, H, W, C.c_float(np.float32(factor)), C.c_float(cam[0]), C.c_float(cam[1]), C.c_float(cam[2]), C.c_float(cam[3]),
+                              C.c_void_p(nrm.ctypes.data), C.c_void_p(pts.ctypes.data), cap, C.c_void_p(dist.ctypes.data) if want_dist else None)
+    assert n == cap, (n, cap)
+    return (nrm, pts, dist) if want_dist else (nrm, pts)
