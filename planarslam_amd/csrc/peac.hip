@@ -1213,7 +1213,9 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     o->ctx = ctx; o->W = width; o->H = height; o->max_batch = max_batch;
     peac::Layout& L = o->L;
     L.W = width; L.H = height; L.Nw = width / peac::WIN; L.Nh = height / peac::WIN; L.NB = L.Nw * L.Nh; L.NB2 = 2 * L.NB;
-    L.pool_cap = 4 * L.NB + std::max(4 * L.NB, peac::MAX_PLANES * peac::MAX_PLANES);   // u16 entries, in LDS
+    // neighbour-list pool (u16 entries, global memory; list offsets are u16 in LDS, hence < 65536): the blocks' 4-entry lists, then the merged nodes'
+    // lists (live entries + 8..n/4 slack + a capacity header each; dead lists are reclaimed by compaction when the pool runs full)
+    L.pool_cap = std::min(65535 - 64, 4 * L.NB + std::max(16 * L.NB, peac::MAX_PLANES * peac::MAX_PLANES));
     L.q_cap = 2 * width * height;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o2 = off; off = align_up(off + bytes, (size_t)256); return o2; };

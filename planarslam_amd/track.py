@@ -14,7 +14,7 @@ The sequence of the reference's tracking thread for one RGB-D frame (src/Trackin
 
 What is NOT the reference's code path and only stands in for the map it maintains (Map / KeyFrame / LocalMapping are out of scope):
 the local map of a stream is the previous two frames' own back-projected keypoints, the reference key frame's lines and the map planes are
-fixed per stream (set_map), the surface normals of the Manhattan tracker are a resident array (their PCL producer is not built), and
+fixed per stream (set_map), the 3-D line directions of the Manhattan tracker are a resident array (Frame::isLineGood is not built), and
 MapPoint::UpdateNormalAndDepth / the plane coefficient (n, -n.c) of Frame::ComputePlanes are a few torch element-wise ops here.
 
 PyTorch supplies device memory, streams and events only.  Frame-batch parallelism: steps are pipelined `depth` deep - the tracking chain of
@@ -35,6 +35,7 @@ class TrackPipeline:
                  run_fallback_matcher=True):
         from . import Context, ORBextractor, Optimizer, PlaneDetection
         from .lines import LineSegment
+        from .planes import SurfaceNormals
         from .synth import TUM3
         self.torch, self.B, self.W, self.H, self.depth = torch, B, W, H, depth
         self.cam = dict(cam or TUM3)
@@ -51,6 +52,8 @@ class TrackPipeline:
         self.S = S = self.ex.kp_cap
         self.pds = [PlaneDetection(W, H, max_batch=B, ctx=c) for c in self.ctx_peacs]
         self.lss = [LineSegment(W, H, B, c) for c in self.ctx_lsds]
+        self.sns = [SurfaceNormals(W, H, B, c) for c in self.ctx_peacs]     # Frame::ComputePlanes: PEAC, then the surface normals, on the plane thread
+        self.SN = self.sns[0].count
         self.opt = Optimizer(self.cam, ctx=self.ctx)
         self.PS = self.pds[0].max_planes
         self.run_fallback_matcher = run_fallback_matcher
@@ -71,6 +74,8 @@ class TrackPipeline:
         self.lab = [z((B, H * W), t.int32) for _ in range(NB)]
         self.pls = [z((B, self.PS, 8), t.float64) for _ in range(NB)]
         self.npl = [z((B,), t.int32) for _ in range(NB)]
+        self.snrm = [z((B, self.SN, 3), t.float32) for _ in range(NB)]
+        self.n_snrm = t.full((B,), self.SN, dtype=t.int32, device=self.dev)
         self.kls = [z((B * 40 * KEYLINE_DTYPE.itemsize,), t.uint8) for _ in range(NB)]
         self.ldesc = [z((B, 40, 32), t.uint8) for _ in range(NB)]
         self.leq = [z((B, 40, 3), t.float64) for _ in range(NB)]
@@ -193,6 +198,7 @@ class TrackPipeline:
         check(L.planar_lsd_preprocess_dev(self.lss[k].h, gray.data_ptr(), B, self.W, self.W * self.H))
         if side: side[0].record(sp)
         self.pds[k].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), B)
+        self.sns[k].compute_dev(depth.data_ptr(), self.snrm[k].data_ptr(), B, K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
         check(L.planar_lsd_detect_dev(self.lss[k].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
         if side: side[1].record(sp); side[3].record(sl)
         self.join_p[k].record(sp); self.join_l[k].record(sl)
@@ -223,15 +229,16 @@ class TrackPipeline:
             cap = self.captured[j] = {}
             snap = lambda name, x: cap.__setitem__(name, x.clone())
             for name, x in (("kps", self.kps[k]), ("desc", self.desc[k]), ("n", self.n[k]), ("ur", self.ur[k]), ("zd", self.zd[k]), ("kls", self.kls[k]), ("ldesc", self.ldesc[k]),
-                            ("leq", self.leq[k]), ("nl", self.nl[k]), ("lab", self.lab[k]), ("pls", self.pls[k]), ("npl", self.npl[k]), ("pose_in", self.pose), ("Rcm_in", self.Rcm),
+                            ("leq", self.leq[k]), ("nl", self.nl[k]), ("lab", self.lab[k]), ("pls", self.pls[k]), ("npl", self.npl[k]), ("snrm", self.snrm[k]), ("pose_in", self.pose), ("Rcm_in", self.Rcm),
                             ("last_xw", self.h_xw[l]), ("last_valid", self.h_valid[l]), ("last_desc", self.h_desc[l]), ("last_oct", self.h_oct[l]), ("last_ang", self.h_ang[l]),
                             ("last_n", self.h_n[l]), ("old_xw", self.h_xw[o]), ("old_valid", self.h_valid[o]), ("old_desc", self.h_desc[o]), ("old_normal", self.h_normal[o]),
                             ("old_mind", self.h_mind[o]), ("old_maxd", self.h_maxd[o]), ("old_n", self.h_n[o])):
                 snap(name, x)
         if j >= 2 and self.map_set:
             # ---- Track(): Manhattan frame ----
-            check(L.planar_track_manhattan_frame_dev(self.ctx.h, B, self.Rcm.data_ptr(), self.sn["normals"].data_ptr(), self.sn["n_normals"].data_ptr(),
-                                                     self.sn["normals"].shape[1], self.sn["lines"].data_ptr(), self.sn["n_lines"].data_ptr(), self.sn["lines"].shape[1],
+            # the frame's own surface normals (Frame::vSurfaceNormal); the 3-D line directions (mVF3DLines) are still a per-stream resident array
+            check(L.planar_track_manhattan_frame_dev(self.ctx.h, B, self.Rcm.data_ptr(), self.snrm[k].data_ptr(), self.n_snrm.data_ptr(), self.SN,
+                                                     self.sn["lines"].data_ptr(), self.sn["n_lines"].data_ptr(), self.sn["lines"].shape[1],
                                                      self.Rcm_new.data_ptr(), None, None, None))
             if evs: evs["manhattan"].record(st)
             # ---- TranslationWithMotionModel ----

@@ -98,8 +98,10 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
         assert np.array_equal(c["pose_in"], prev["pose_out"]) and np.array_equal(c["last_xw"], prev["new_xw"]) and np.array_equal(c["Rcm_in"], prev["Rcm_new"])
     # ---- TrackManhattanFrame ----
     for b in range(0, B, 7):
-        n, m = int(sn["n_normals"][b]), int(sn["n_lines"][b])
-        w = ol.track_manhattan_frame(c["Rcm_in"][b].reshape(3, 3), sn["normals"][b, :n], sn["lines"][b, :m])
+        m = int(sn["n_lines"][b])
+        nrm, _ = ol.surface_normals(d[b])                  # Frame::ComputePlanes' normals of THIS frame's depth, every bit (NaN pattern included)
+        assert np.array_equal(np.isnan(nrm), np.isnan(c["snrm"][b])) and np.array_equal(nrm[~np.isnan(nrm)], c["snrm"][b][~np.isnan(nrm)])
+        w = ol.track_manhattan_frame(c["Rcm_in"][b].reshape(3, 3), nrm, sn["lines"][b, :m])
         assert np.abs(w["R"].ravel() - c["Rcm_new"][b]).max() <= 1e-5
     # ---- SearchByProjection(Cur, Last) ----
     cur = _frame_dict(c, c["pose_in"])
