@@ -226,7 +226,7 @@ constexpr int NT_REFINE = 256;   // refinement: four wavefronts per frame
 typedef unsigned short u16;
 
 struct Lds {
-    double* h_mse; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; unsigned char* nb_cntb; u16* dsp; u16* dss; u16* rid; unsigned* nouse; unsigned* cval; signed char* blk;
+    float* h_key; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; unsigned char* nb_cntb; u16* dsp; u16* dss; u16* rid; unsigned* nouse; unsigned* cval; signed char* blk;
 };
 
 __device__ __forceinline__ int lds_find(u16* parent, int x) {   // DisjointSet::Find with path compression
@@ -274,13 +274,13 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     int32_t* lab = labels + (size_t)frame * label_stride;
     const int NB = L.NB, Nw = L.Nw, Nh = L.Nh, W = L.W, H = L.H;
 
-    __shared__ double s_hm[PHASE == 1 ? MAX_PLANES : 1];     // refinement: the heap of the final clustering holds <= MAX_PLANES nodes
+    __shared__ float s_hm[PHASE == 1 ? MAX_PLANES : 1];      // refinement: the heap of the final clustering holds <= MAX_PLANES nodes
     __shared__ u16 s_hi[PHASE == 1 ? MAX_PLANES : 1];
     __shared__ signed char s_blk[PHASE == 1 ? 3072 : 1];      // block -> plane id (NB <= 3072 is checked at create time for this path)
     Lds S;
     if (PHASE == 0) {
-        S.h_mse = (double*)smem;
-        S.h_id = (u16*)(S.h_mse + NB);
+        S.h_key = (float*)smem;
+        S.h_id = (u16*)(S.h_key + NB);
         S.pool = (u16*)(F + L.off_h_pool);        // neighbour lists: global memory (L2 resident); LDS holds what every pop / merge chases
         // LDS holds what every pop / merge chases: the heap, the list offsets / counts of the MERGED nodes (a block's list sits at
         // 4 * id, its count fits a byte) and the dead / cache-valid bits.  Set sizes, root ids and DisjointSet parents are only written
@@ -293,7 +293,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         S.dss = (u16*)(F + L.off_h_dss); S.rid = (u16*)(F + L.off_h_rid); S.dsp = (u16*)(F + L.off_h_dsp);
         S.blk = nullptr;
     } else {
-        S.h_mse = s_hm; S.h_id = s_hi;
+        S.h_key = s_hm; S.h_id = s_hi;
         S.pool = (u16*)(F + L.off_h_pool); S.nb_off = (u16*)(F + L.off_h_nboff); S.nb_cnt = (u16*)(F + L.off_h_nbcnt); S.nb_cntb = nullptr;
         S.dsp = (u16*)(F + L.off_h_dsp); S.dss = (u16*)(F + L.off_h_dss); S.rid = (u16*)(F + L.off_h_rid);
         S.nouse = (unsigned*)(F + L.off_h_nouse); S.cval = (unsigned*)(F + L.off_h_cval);
@@ -395,24 +395,31 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
 
     // =========================== sequential section: wave 0 only ===========================
     int heap_n = 0, n_nodes = PHASE == 0 ? NB : g_hand[2], n_ext = PHASE == 0 ? 0 : g_hand[0], pool_top = 4 * NB, err = PHASE == 0 ? 0 : g_hand[1];
-    // libstdc++ binary heap (std::priority_queue with PlaneSegMinMSECmp: comp(a,b) = b.mse < a.mse); entries carry
-    // their key so a comparison is one LDS read.
+    // libstdc++ binary heap (std::priority_queue with PlaneSegMinMSECmp: comp(a,b) = b.mse < a.mse).  Entries carry their key ROUNDED TO FLOAT
+    // (rounding is monotonic: two different floats order like the doubles they came from) so a comparison is one LDS read and the heap is
+    // 6 bytes per node; only when two floats are EQUAL are the FP64 keys fetched from the nodes' records in the frame workspace.  The
+    // comparisons, hence the heap layout and the pop order, are those of the FP64 heap.
     // __push_heap: the value climbs from `hole` while it is smaller than the parent.  The <= 12 ancestors are read by one lane each in a
     // single LDS round trip; the leading run of larger ancestors moves down one level in parallel.
-    auto heap_sift_up = [&](int hole, int id, double mse) {
+    auto heap_sift_up = [&](int hole, int id, float mf) {
         const int anc = lane < 16 ? ((hole + 1) >> lane) - 1 : -1;                          // lane j: the j-th ancestor of the hole (lane 0: the hole)
         const bool isanc = lane >= 1 && anc >= 0;
-        double K = 0; int I = 0;
-        if (isanc) { K = S.h_mse[anc]; I = S.h_id[anc]; }
-        const unsigned long long up = __ballot(isanc && mse < K) >> 1;       // bit j-1: ancestor j is larger than the value
+        float K = 0; int I = 0;
+        if (isanc) { K = S.h_key[anc]; I = S.h_id[anc]; }
+        bool less = isanc && mf < K;
+        if (__ballot(isanc && mf == K)) {                                    // float tie somewhere on the path: decide those on the doubles
+            const double dv = geo_of(id)[6];
+            if (isanc && mf == K) less = dv < geo_of(I)[6];
+        }
+        const unsigned long long up = __ballot(less) >> 1;                   // bit j-1: ancestor j is larger than the value
         const int n = __builtin_ctzll(~up);                                  // the loop stops at the first ancestor that is not
-        if (lane >= 1 && lane <= n) { const int dst = ((hole + 1) >> (lane - 1)) - 1; S.h_mse[dst] = K; S.h_id[dst] = (u16)I; }
-        if (lane == 0) { const int dst = ((hole + 1) >> n) - 1; S.h_mse[dst] = mse; S.h_id[dst] = (u16)id; }
+        if (lane >= 1 && lane <= n) { const int dst = ((hole + 1) >> (lane - 1)) - 1; S.h_key[dst] = K; S.h_id[dst] = (u16)I; }
+        if (lane == 0) { const int dst = ((hole + 1) >> n) - 1; S.h_key[dst] = mf; S.h_id[dst] = (u16)id; }
         wfence();
     };
-    auto heap_push = [&](int id, double mse) {
+    auto heap_push = [&](int id, double mse) {      // the node's record (geo_of(id)[6] == mse) has been written before
         heap_n++;
-        heap_sift_up(heap_n - 1, id, mse);
+        heap_sift_up(heap_n - 1, id, (float)mse);
     };
     // pop_heap = __adjust_heap(first, 0, len, last value): the hole sinks to the bottom along the smaller child (no early exit), then
     // the value climbs back.  Lane t = 1..63 stands for node t of the subtree under the hole and compares its two children (one LDS round
@@ -420,7 +427,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     // the path pulls its chosen child up in one parallel store.
     auto heap_pop = [&]() -> int {
         const int top = S.h_id[0];
-        const double vm = S.h_mse[heap_n - 1]; const int vi = S.h_id[heap_n - 1];
+        const float vm = S.h_key[heap_n - 1]; const int vi = S.h_id[heap_n - 1];
         heap_n--;
         const int len = heap_n;
         if (len == 0) return top;
@@ -432,10 +439,12 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
             // nodes that turn out to lie on the path do so - six levels per LDS round trip
             const int g = (hole << dl) + lane - 1;
             const bool inner = lane >= 1 && g < half;
-            double kl = 0, kr = 0; int il = 0, ir = 0;
-            if (inner) { kl = S.h_mse[2 * g + 1]; kr = S.h_mse[2 * g + 2]; il = S.h_id[2 * g + 1]; ir = S.h_id[2 * g + 2]; }
+            float kl = 0, kr = 0; int il = 0, ir = 0;
+            if (inner) { kl = S.h_key[2 * g + 1]; kr = S.h_key[2 * g + 2]; il = S.h_id[2 * g + 1]; ir = S.h_id[2 * g + 2]; }
+            bool lt = inner && kl < kr;
+            if (inner && kl == kr) lt = geo_of(il)[6] < geo_of(ir)[6];       // float tie: the FP64 keys decide
             const unsigned long long two = __ballot(inner);
-            const unsigned long long takel = __ballot(inner && kl < kr);     // comp(first[second], first[second - 1]): take second - 1
+            const unsigned long long takel = __ballot(lt);                   // comp(first[second], first[second - 1]): take second - 1
             int cur = 1;
             unsigned long long path = 0;
 #pragma unroll
@@ -446,7 +455,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
             }
             if ((path >> lane) & 1ull) {
                 const bool left = (takel >> lane) & 1ull;
-                S.h_mse[g] = left ? kl : kr; S.h_id[g] = (u16)(left ? il : ir);
+                S.h_key[g] = left ? kl : kr; S.h_id[g] = (u16)(left ? il : ir);
             }
             const int dc = 31 - __clz(cur);
             hole = (hole << dc) + cur - 1;
@@ -454,8 +463,8 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         wfence();
         if ((len & 1) == 0 && hole == (len - 2) / 2) {                       // a last node with a single (left) child
             const int c = 2 * hole + 1;
-            const double cm = S.h_mse[c]; const int ci = S.h_id[c];
-            if (lane == 0) { S.h_mse[hole] = cm; S.h_id[hole] = (u16)ci; }
+            const float cm = S.h_key[c]; const int ci = S.h_id[c];
+            if (lane == 0) { S.h_key[hole] = cm; S.h_id[hole] = (u16)ci; }
             wfence(); hole = c;
         }
         heap_sift_up(hole, vi, vm);
@@ -1234,7 +1243,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     L.off_h_nboff = carve((size_t)L.NB2 * 2); L.off_h_nbcnt = carve((size_t)L.NB2 * 2); L.off_h_pool = carve((size_t)L.pool_cap * 2);
     L.frame_bytes = off;
     // peac_ahc: heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
-    o->smem = L.NB * 8 + L.NB * 2 + L.NB * 4 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
+    o->smem = L.NB * 4 + L.NB * 2 + L.NB * 4 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
     const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
