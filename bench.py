@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--workload", choices=["full", "orb", "ba"], default="full",
                     help="full: the per-frame path (BASELINE metric); orb: config[1] only; ba: config[4], ONE local bundle adjustment partitioned over the ranks")
     ap.add_argument("--depth", type=int, default=2, help="software-pipeline depth: the tracking chain of step i runs during step i + depth")
-    ap.add_argument("--prio", default="-1,0,0", help="stream priorities: point stream, LSD streams, PEAC streams (lower = higher priority)")
+    ap.add_argument("--prio", default="-1,0,0", help="stream priorities: point stream, LSD streams, PEAC streams[, tracking stream] (lower = higher priority)")
     ap.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the cpu_baseline leg, split over its three variants (0 = skip)")
     ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 latency block (0 = skip)")
     ap.add_argument("--pcie-steps", type=int, default=4, help="steps of the PCIe-inclusive loop (0 = skip)")
@@ -290,7 +290,7 @@ def main():
                 j = i - args.depth                   # its tracking chain has just been enqueued: drain its outputs
                 if q >= args.depth:
                     kj = j % NB
-                    ev_dn[kj].record(stream)
+                    ev_dn[kj].record(tp.s_track)
                     with torch.cuda.stream(s_out):
                         s_out.wait_event(ev_dn[kj])
                         o = h_out[q & 1]

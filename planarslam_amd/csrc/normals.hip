@@ -11,7 +11,7 @@
 //      evaluated as min over k <= 11 of (t[c-k] +1 +1 ... k times), each sum formed in the reference's order, which is exact for every value
 //      <= 10 (a chain of k steps costs >= k) - and only min(distance, 10) is ever read.  PCL's row-wrapping reads are reproduced.
 //   C  first-order integral images of the two gradient fields  FP64, PCL's recurrence cur[c+1] = prev[c+1] + cur[c] - prev[c] + e[c], whose rounding
-//      depends on the order: six lanes (2 images x 3 components) walk each row in sequence from LDS, all threads stage the row in and out
+//      depends on the order: six lanes (2 images x 3 components) walk each row in sequence in LDS (in place), all threads stage the row in and out
 //   D  box sums, cross product, normalisation, flip towards the viewpoint    one thread per output normal
 // Everything is FP32 / FP64 in the reference's operation order (-ffp-contract=off); outputs are bit-identical to the oracle.
 #include <algorithm>
@@ -116,10 +116,9 @@ __global__ __launch_bounds__(NT) void normals_kernel(Geo G, const uint16_t* __re
     }
 
     // ---- C: integral images ----
-    double* s_prevI = (double*)smem;                        // [iw][6]
-    double* s_curI = s_prevI + (size_t)iw * 6;              // [iw][6]
-    float* s_e = (float*)(s_curI + (size_t)iw * 6);         // [gw][6]
-    for (int i = tid; i < iw * 6; i += NT) s_prevI[i] = 0.0;
+    double* s_I = (double*)smem;                            // [iw][6]: the previous row, overwritten in place by the current one
+    float* s_e = (float*)(s_I + (size_t)iw * 6);            // [gw][6]
+    for (int i = tid; i < iw * 6; i += NT) s_I[i] = 0.0;
     for (int i = tid; i < iw; i += NT) for (int k = 0; k < 3; k++) { I[(size_t)i * 3 + k] = 0.0; I[img_stride + (size_t)i * 3 + k] = 0.0; }
     __syncthreads();
     for (int r = 0; r < gh; r++) {
@@ -136,25 +135,37 @@ __global__ __launch_bounds__(NT) void normals_kernel(Geo G, const uint16_t* __re
         __syncthreads();
         if (tid < 6) {
             double run = 0.0;                               // current_row[0] = 0
-            s_curI[tid] = 0.0;
-            double pl = s_prevI[tid];
-            for (int c = 0; c < gw; c++) {
-                const double pr = s_prevI[(c + 1) * 6 + tid];
+            double pl = s_I[tid];                           // previous_row[0]
+            s_I[tid] = 0.0;
+            int c = 0;
+            for (; c + 4 <= gw; c += 4) {                   // the loads do not depend on the chain: four columns are fetched ahead of it
+                double pr[4]; float ee[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { pr[u] = s_I[(c + u + 1) * 6 + tid]; ee[u] = s_e[(c + u) * 6 + tid]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    double v = pr[u] + run - pl;
+                    v += (double)ee[u];
+                    s_I[(c + u + 1) * 6 + tid] = v;
+                    run = v; pl = pr[u];
+                }
+            }
+            for (; c < gw; c++) {
+                const double pr = s_I[(c + 1) * 6 + tid];
                 double v = pr + run - pl;
                 v += (double)s_e[c * 6 + tid];
-                s_curI[(c + 1) * 6 + tid] = v;
+                s_I[(c + 1) * 6 + tid] = v;
                 run = v; pl = pr;
             }
         }
         __syncthreads();
         for (int i = tid; i < iw * 6; i += NT) {
             const int c = i / 6, k = i - c * 6;
-            const double v = s_curI[i];
-            I[(size_t)(k / 3) * img_stride + ((size_t)(r + 1) * iw + c) * 3 + (k % 3)] = v;
-            s_prevI[i] = v;
+            I[(size_t)(k / 3) * img_stride + ((size_t)(r + 1) * iw + c) * 3 + (k % 3)] = s_I[i];
         }
-        __syncthreads();
+        // the next row's s_e writes and this row's s_I reads touch different arrays; the barrier after the s_e fill orders the chain behind both
     }
+    __syncthreads();
 
     // ---- D: the normals Frame.cc:728-749 keeps ----
     const float bad = __builtin_nanf("");
@@ -218,7 +229,7 @@ int planar_normals_create(planar_ctx* ctx, int width, int height, int max_batch,
     const size_t dist_bytes = align_up((size_t)G.gw * G.gh * 4, (size_t)256);
     G.off_I = dist_bytes;
     G.ws_stride = dist_bytes + align_up((size_t)2 * (G.gh + 1) * G.iw * 3 * 8, (size_t)256);
-    p->smem = std::max((size_t)(2 * G.gw + 2) * 4, (size_t)G.iw * 6 * 8 * 2 + (size_t)G.gw * 6 * 4);
+    p->smem = std::max((size_t)(2 * G.gw + 2) * 4, (size_t)G.iw * 6 * 8 + (size_t)G.gw * 6 * 4);      // 15.4 KB at 640x480: fits beside four peac_ahc frames on a CU
     int rc = p->ws.alloc(G.ws_stride * (size_t)max_batch);
     if (rc) { delete p; return rc; }
     if (p->smem > 48 * 1024) {

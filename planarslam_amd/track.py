@@ -18,7 +18,7 @@ fixed per stream (set_map), the 3-D line directions of the Manhattan tracker are
 MapPoint::UpdateNormalAndDepth / the plane coefficient (n, -n.c) of Frame::ComputePlanes are a few torch element-wise ops here.
 
 PyTorch supplies device memory, streams and events only.  Frame-batch parallelism: steps are pipelined `depth` deep - the tracking chain of
-step i - depth runs behind the extraction launches of step i, whose line / plane kernels fill the CUs meanwhile."""
+step i - depth runs on its own stream beside the extraction launches of step i (points on the main stream, lines and planes on theirs)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -44,6 +44,9 @@ class TrackPipeline:
         self.L = lib()
         self.stream = torch.cuda.Stream(device=device_index, priority=prio[0])
         self.ctx = Context(device_index, stream=self.stream.cuda_stream)
+        # the tracking chain of step i - depth runs on its own stream, beside the point extraction of step i (they share nothing but buffers guarded by events)
+        self.s_track = torch.cuda.Stream(device=device_index, priority=prio[3] if len(prio) > 3 else prio[0])
+        self.ctx_t = Context(device_index, stream=self.s_track.cuda_stream)
         self.s_peacs = [torch.cuda.Stream(device=device_index, priority=prio[2]) for _ in range(self.NB)]
         self.s_lsds = [torch.cuda.Stream(device=device_index, priority=prio[1]) for _ in range(self.NB)]
         self.ctx_peacs = [Context(device_index, stream=q.cuda_stream) for q in self.s_peacs]
@@ -54,7 +57,7 @@ class TrackPipeline:
         self.lss = [LineSegment(W, H, B, c) for c in self.ctx_lsds]
         self.sns = [SurfaceNormals(W, H, B, c) for c in self.ctx_peacs]     # Frame::ComputePlanes: PEAC, then the surface normals, on the plane thread
         self.SN = self.sns[0].count
-        self.opt = Optimizer(self.cam, ctx=self.ctx)
+        self.opt = Optimizer(self.cam, ctx=self.ctx_t)
         self.PS = self.pds[0].max_planes
         self.run_fallback_matcher = run_fallback_matcher
         sf = np.asarray(self.ex.GetScaleFactors(), np.float32)
@@ -81,6 +84,7 @@ class TrackPipeline:
         self.leq = [z((B, 40, 3), t.float64) for _ in range(NB)]
         self.nl = [z((B,), t.int32) for _ in range(NB)]
         self.ev_in = [t.cuda.Event() for _ in range(NB)]
+        self.ev_orb = [t.cuda.Event() for _ in range(NB)]
         self.join_p = [t.cuda.Event() for _ in range(NB)]
         self.join_l = [t.cuda.Event() for _ in range(NB)]
         self.done = [t.cuda.Event() for _ in range(NB)]
@@ -89,6 +93,7 @@ class TrackPipeline:
         self.h_mind = z((2, B, S), t.float32); self.h_maxd = z((2, B, S), t.float32); self.h_desc = z((2, B, S, 32), t.uint8)
         self.h_oct = z((2, B, S), t.int32); self.h_ang = z((2, B, S), t.float32); self.h_n = z((2, B), t.int32)
         self.pose = t.eye(4, dtype=t.float32, device=self.dev).reshape(1, 16).repeat(B, 1).contiguous()
+        self.pose0 = self.pose.clone()          # ComputeStereoFromRGBD at extraction time needs no pose (its world points are discarded)
         self.Rcm = t.eye(3, dtype=t.float32, device=self.dev).reshape(1, 9).repeat(B, 1).contiguous()
         self.ones_S = t.ones((B, S), dtype=t.uint8, device=self.dev)
         self.zeros_S = z((B, S), t.uint8)
@@ -163,9 +168,9 @@ class TrackPipeline:
             fv.scale_factors[i] = float(v)
         return fv
 
-    def _stereo(self, k, Tcw, depth, ur, zd, xw, valid):
+    def _stereo(self, ctx, k, Tcw, depth, ur, zd, xw, valid):
         c = self.cam
-        check(self.L.planar_stereo_from_rgbd_dev(self.ctx.h, self.B, self.kps[k].data_ptr(), self.kps[k].data_ptr(), self.n[k].data_ptr(), self.S, depth.data_ptr(),
+        check(self.L.planar_stereo_from_rgbd_dev(ctx.h, self.B, self.kps[k].data_ptr(), self.kps[k].data_ptr(), self.n[k].data_ptr(), self.S, depth.data_ptr(),
                                                  self.W, self.W * self.H, float(np.float32(1.0 / 5000.0)), c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], Tcw.data_ptr(),
                                                  ur.data_ptr(), zd.data_ptr(), xw.data_ptr(), valid.data_ptr()))
 
@@ -181,7 +186,7 @@ class TrackPipeline:
         m.pl_stride, m.mpl_stride, m.mpl_shared = self.PS, self.mp["coef"].shape[1], 0
         m.n_planes, m.pl_coef, m.pl_match, m.mpl_coef = self.npl[k].data_ptr(), self.pl_coef.data_ptr(), self.plm.data_ptr(), self.mp["coef"].data_ptr()
         m.Tcw = Tcw.data_ptr()
-        check(self.L.planar_pose_assemble_dev(self.ctx.h, C.byref(m), C.byref(self.pbs[which])))
+        check(self.L.planar_pose_assemble_dev(self.ctx_t.h, C.byref(m), C.byref(self.pbs[which])))
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def step(self, i, gray, depth, evs=None, side=None):
@@ -205,8 +210,9 @@ class TrackPipeline:
         self.ex.extract_dev(gray.data_ptr(), self.kps[k].data_ptr(), self.desc[k].data_ptr(), self.n[k].data_ptr(), B)
         if evs: evs["orb"].record(st)
         # Frame::ComputeStereoFromRGBD: mvuRight / mvDepth of the new keypoints (the world points come after the pose is known)
-        self._stereo(k, self.pose, depth, self.ur[k], self.zd[k], self.xw_tmp, self.valid_tmp)
+        self._stereo(self.ctx, k, self.pose0, depth, self.ur[k], self.zd[k], self.xw_tmp, self.valid_tmp)
         if evs: evs["stereo"].record(st)
+        self.ev_orb[k].record(st)
         self.pending.append((i, depth, evs))
         if len(self.pending) > self.depth:
             self._track(*self.pending.pop(0))
@@ -218,8 +224,13 @@ class TrackPipeline:
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def _track(self, j, depth, evs):
+        with self.torch.cuda.stream(self.s_track):          # torch's element-wise glue ops follow the current stream
+            self._track_on_stream(j, depth, evs)
+
+    def _track_on_stream(self, j, depth, evs):
         t, L, B, S, k = self.torch, self.L, self.B, self.S, j % self.NB
-        st = self.stream
+        st = self.s_track
+        st.wait_event(self.ev_orb[k])                       # this frame's keypoints / descriptors / mvuRight (main stream)
         l, o = (j - 1) % 2, j % 2                           # history slots: last frame / the one before (overwritten by this frame at the end)
         if evs: evs["wait0"].record(st)
         st.wait_event(self.join_p[k]); st.wait_event(self.join_l[k])
@@ -237,7 +248,7 @@ class TrackPipeline:
         if j >= 2 and self.map_set:
             # ---- Track(): Manhattan frame ----
             # the frame's own surface normals (Frame::vSurfaceNormal); the 3-D line directions (mVF3DLines) are still a per-stream resident array
-            check(L.planar_track_manhattan_frame_dev(self.ctx.h, B, self.Rcm.data_ptr(), self.snrm[k].data_ptr(), self.n_snrm.data_ptr(), self.SN,
+            check(L.planar_track_manhattan_frame_dev(self.ctx_t.h, B, self.Rcm.data_ptr(), self.snrm[k].data_ptr(), self.n_snrm.data_ptr(), self.SN,
                                                      self.sn["lines"].data_ptr(), self.sn["n_lines"].data_ptr(), self.sn["lines"].shape[1],
                                                      self.Rcm_new.data_ptr(), None, None, None))
             if evs: evs["manhattan"].record(st)
@@ -248,15 +259,15 @@ class TrackPipeline:
             lv.n, lv.Tcw, lv.usable, lv.xw = self.h_n[l].data_ptr(), self.pose.data_ptr(), self.h_valid[l].data_ptr(), self.h_xw[l].data_ptr()
             lv.octave, lv.angle, lv.mp_desc, lv.mp_observed = self.h_oct[l].data_ptr(), self.h_ang[l].data_ptr(), self.h_desc[l].data_ptr(), self.ones_S.data_ptr()
             self.pm.fill_(-1)
-            check(L.planar_search_by_projection_frame_dev(self.ctx.h, C.byref(fv), C.byref(lv), 15.0, 0, 1, self.pm.data_ptr(), self.nm.data_ptr()))
+            check(L.planar_search_by_projection_frame_dev(self.ctx_t.h, C.byref(fv), C.byref(lv), 15.0, 0, 1, self.pm.data_ptr(), self.nm.data_ptr()))
             if evs: evs["proj"].record(st)
             if cap is not None: snap("pm0", self.pm); snap("nm", self.nm)
             self.lm.fill_(-1)
-            check(L.planar_lsd_search_by_descriptor_dev(self.ctx.h, self.kf["ldesc"].data_ptr(), self.kf["n"].data_ptr(), 40, self.ldesc[k].data_ptr(), self.nl[k].data_ptr(), 40,
+            check(L.planar_lsd_search_by_descriptor_dev(self.ctx_t.h, self.kf["ldesc"].data_ptr(), self.kf["n"].data_ptr(), 40, self.ldesc[k].data_ptr(), self.nl[k].data_ptr(), 40,
                                                         self.kf["has_ml"].data_ptr(), B, self.lm.data_ptr(), self.nlm.data_ptr()))
             if self.run_fallback_matcher:
                 self.cm2.fill_(-1)
-                check(L.planar_match_orb_points_dev(self.ctx.h, self.desc[k].data_ptr(), self.n[k].data_ptr(), S, self.h_desc[l].data_ptr(), self.h_n[l].data_ptr(), S,
+                check(L.planar_match_orb_points_dev(self.ctx_t.h, self.desc[k].data_ptr(), self.n[k].data_ptr(), S, self.h_desc[l].data_ptr(), self.h_n[l].data_ptr(), S,
                                                     self.h_valid[l].data_ptr(), self.zeros_S.data_ptr(), B, self.cm2.data_ptr(), self.npair.data_ptr()))
             if evs: evs["bf"].record(st)
             if cap is not None: snap("lm0", self.lm); snap("nlm0", self.nlm); snap("cm2", self.cm2); snap("npair", self.npair)
@@ -265,7 +276,7 @@ class TrackPipeline:
             self.pl_coef[..., :3] = P[..., 1:4].float()
             self.pl_coef[..., 3] = (-(P[..., 1:4] * P[..., 4:7]).sum(-1)).float()
             self.plm.fill_(-1)
-            check(L.planar_plane_search_by_coefficients_dev(self.ctx.h, B, self.npl[k].data_ptr(), self.PS, self.pl_coef.data_ptr(), self.pose.data_ptr(), 0,
+            check(L.planar_plane_search_by_coefficients_dev(self.ctx_t.h, B, self.npl[k].data_ptr(), self.PS, self.pl_coef.data_ptr(), self.pose.data_ptr(), 0,
                                                             self.mp["n"].data_ptr(), self.mp["coef"].shape[1], self.mp["valid"].data_ptr(), self.mp["coef"].data_ptr(),
                                                             self.mp["npts"].data_ptr(), self.mp["pts"].shape[2], self.mp["pts"].data_ptr(), self.plane_th.ctypes.data,
                                                             self.plm[0].data_ptr(), self.plm[2].data_ptr(), self.plm[1].data_ptr(), self.nplm.data_ptr()))
@@ -275,8 +286,8 @@ class TrackPipeline:
             self.opt.enqueue_dev(self.pbs[0], 1, 4, 10)     # TranslationOptimization
             A0 = self.pb_arrays[0]
             if cap is not None: cap["pbT"] = {kk: v.clone() for kk, v in A0.items()}
-            check(L.planar_discard_outliers_dev(self.ctx.h, B, self.n[k].data_ptr(), S, S, self.pm.data_ptr(), A0["pt_outlier"].data_ptr(), self.kept.data_ptr()))
-            check(L.planar_discard_outliers_dev(self.ctx.h, B, self.nl[k].data_ptr(), 40, 40, self.lm.data_ptr(), A0["ln_outlier"].data_ptr(), None))
+            check(L.planar_discard_outliers_dev(self.ctx_t.h, B, self.n[k].data_ptr(), S, S, self.pm.data_ptr(), A0["pt_outlier"].data_ptr(), self.kept.data_ptr()))
+            check(L.planar_discard_outliers_dev(self.ctx_t.h, B, self.nl[k].data_ptr(), 40, 40, self.lm.data_ptr(), A0["ln_outlier"].data_ptr(), None))
             if evs: evs["transl"].record(st)
             if cap is not None: snap("pm1", self.pm); snap("lm1", self.lm); snap("kept", self.kept)
             # ---- TrackLocalMap: SearchLocalPoints + PoseOptimization ----
@@ -284,7 +295,7 @@ class TrackPipeline:
             t.ge(self.pm, 0, out=self.blocked.view(t.bool))
             fv2 = self._frame_view(k, T1, self.blocked)
             pr = self.pr
-            check(L.planar_is_in_frustum_points_dev(self.ctx.h, C.byref(fv2), self.lsf, self.nlev, self.h_n[o].data_ptr(), S, self.h_valid[o].data_ptr(), self.h_xw[o].data_ptr(),
+            check(L.planar_is_in_frustum_points_dev(self.ctx_t.h, C.byref(fv2), self.lsf, self.nlev, self.h_n[o].data_ptr(), S, self.h_valid[o].data_ptr(), self.h_xw[o].data_ptr(),
                                                     self.h_normal[o].data_ptr(), self.h_mind[o].data_ptr(), self.h_maxd[o].data_ptr(), 0.5, pr["in_view"].data_ptr(),
                                                     pr["proj_x"].data_ptr(), pr["proj_y"].data_ptr(), pr["proj_xr"].data_ptr(), pr["level"].data_ptr(), pr["view_cos"].data_ptr()))
             mpv = MapProbes()
@@ -292,13 +303,13 @@ class TrackPipeline:
             mpv.n, mpv.in_view, mpv.proj_x, mpv.proj_y, mpv.proj_xr = self.h_n[o].data_ptr(), pr["in_view"].data_ptr(), pr["proj_x"].data_ptr(), pr["proj_y"].data_ptr(), pr["proj_xr"].data_ptr()
             mpv.level, mpv.view_cos, mpv.desc, mpv.observed = pr["level"].data_ptr(), pr["view_cos"].data_ptr(), self.h_desc[o].data_ptr(), self.ones_S.data_ptr()
             self.mm.fill_(-1)
-            check(L.planar_search_by_projection_map_dev(self.ctx.h, C.byref(fv2), C.byref(mpv), 3.0, 0.8, self.mm.data_ptr(), self.nmm.data_ptr()))
+            check(L.planar_search_by_projection_map_dev(self.ctx_t.h, C.byref(fv2), C.byref(mpv), 3.0, 0.8, self.mm.data_ptr(), self.nmm.data_ptr()))
             lp = self.lpr
-            check(L.planar_is_in_frustum_lines_dev(self.ctx.h, C.byref(fv2), self.lsf, self.kf["n"].data_ptr(), 40, self.kf["has_ml"].data_ptr(), self.kf["xw6"].data_ptr(),
+            check(L.planar_is_in_frustum_lines_dev(self.ctx_t.h, C.byref(fv2), self.lsf, self.kf["n"].data_ptr(), 40, self.kf["has_ml"].data_ptr(), self.kf["xw6"].data_ptr(),
                                                    self.kf["normal"].data_ptr(), self.kf["min_dist"].data_ptr(), self.kf["max_dist"].data_ptr(), 0.5, lp["in_view"].data_ptr(),
                                                    lp["proj"].data_ptr(), lp["level"].data_ptr(), lp["view_cos"].data_ptr()))
             t.ge(self.lm, 0, out=self.lblocked.view(t.bool))
-            check(L.planar_lsd_search_by_projection_dev(self.ctx.h, B, self.nl[k].data_ptr(), 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.lblocked.data_ptr(),
+            check(L.planar_lsd_search_by_projection_dev(self.ctx_t.h, B, self.nl[k].data_ptr(), 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.lblocked.data_ptr(),
                                                         self.kf["n"].data_ptr(), 40, lp["in_view"].data_ptr(), lp["proj"].data_ptr(), lp["level"].data_ptr(), lp["view_cos"].data_ptr(),
                                                         self.kf["ldesc"].data_ptr(), self.kf["has_ml"].data_ptr(), self.sf.ctypes.data, self.nlev, 3.0, 0.6, self.lm.data_ptr(),
                                                         self.nlm.data_ptr()))
@@ -320,7 +331,7 @@ class TrackPipeline:
             for name in ("manhattan", "proj", "bf", "planes", "transl", "local", "pose"):
                 evs[name].record(st)
         # ---- the new frame becomes a "last frame": back-projected keypoints (UnprojectStereo) and what MapPoint::UpdateNormalAndDepth keeps ----
-        self._stereo(k, self.pose, depth, self.ur[k], self.zd[k], self.h_xw[o], self.h_valid[o])
+        self._stereo(self.ctx_t, k, self.pose, depth, self.ur[k], self.zd[k], self.h_xw[o], self.h_valid[o])
         T = self.pose.view(B, 4, 4)
         Ow = -(T[:, :3, :3].transpose(1, 2) @ T[:, :3, 3:4]).squeeze(-1)
         v = self.h_xw[o] - Ow[:, None, :]
