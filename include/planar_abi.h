@@ -465,6 +465,24 @@ typedef struct planar_ba_result {
 int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* problem, const planar_pose_params* params, int its1, int its2,
                     planar_ba_result* result, volatile int* stop_flag, planar_comm* comm);
 
+/* ---- DBoW2 vocabulary transform (replaces ORBVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) as Frame::ComputeBoW and
+ *      KeyFrame::ComputeBoW call it with levelsup = 4; Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1124-1180, :1203-1250; include/ORBVocabulary.h:31) ----
+ * The vocabulary arrives as the rows of the text format TemplatedVocabulary::loadFromTextFile reads (ORBvoc.txt): for node 1..n in file order its
+ * parent id, isLeaf flag, 32 descriptor bytes and weight; header values k and L.  TF_IDF weighting with L1 normalisation (header "k L 0 0").
+ *   word / weight [B][stride]: WordId and idf weight of every feature (the per-feature transform);  node [B][stride]: the id of its ancestor at level
+ *   L - levelsup (0 = root when levelsup >= L), -1 for a stopped word (weight 0), i.e. the FeatureVector as one node id per feature - the form
+ *   planar_search_by_bow takes;  bow_word / bow_value [B][stride] + bow_n [B]: the BowVector, ascending word id, L1-normalised. */
+typedef struct planar_vocab planar_vocab;
+int planar_vocab_create(planar_ctx* ctx, int k, int L, int n_nodes, const int32_t* parent, const uint8_t* is_leaf, const uint8_t* desc /* [n][32] */,
+                        const double* weight, planar_vocab** out);
+void planar_vocab_destroy(planar_vocab* voc);
+int planar_vocab_words(const planar_vocab* voc);
+int planar_bow_transform(planar_vocab* voc, const uint8_t* desc, const int32_t* n, int B, int stride, int levelsup, int32_t* word, double* weight,
+                         int32_t* node, int32_t* bow_word, double* bow_value, int32_t* bow_n);
+/* the three BowVector outputs may be NULL together (FeatureVector only) */
+int planar_bow_transform_dev(planar_vocab* voc, const uint8_t* d_desc, const int32_t* d_n, int B, int stride, int levelsup, int32_t* d_word,
+                             double* d_weight, int32_t* d_node, int32_t* d_bow_word, double* d_bow_value, int32_t* d_bow_n);
+
 /* ---- surface normals (replaces the tail of Frame::ComputePlanes, src/Frame.cc:694-751: the depth image sampled every 3rd pixel ->
  *      pcl::IntegralImageNormalEstimation(AVERAGE_3D_GRADIENT, MaxDepthChangeFactor 0.05, NormalSmoothingSize 10) -> vSurfaceNormal) ----
  * Output per frame: planar_normals_count() entries in the reference's push_back order (odd rows m, odd columns n of the

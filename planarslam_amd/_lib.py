@@ -154,6 +154,11 @@ _SIGS = {
     "planar_peac_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "planar_comm_unique_id": (C.c_int, [C.c_void_p]),
     "planar_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "planar_vocab_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "planar_vocab_destroy": (None, [C.c_void_p]),
+    "planar_vocab_words": (C.c_int, [C.c_void_p]),
+    "planar_bow_transform": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "planar_bow_transform_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "planar_normals_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_normals_destroy": (None, [C.c_void_p]),
     "planar_normals_count": (C.c_int, [C.c_void_p]),

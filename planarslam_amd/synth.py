@@ -631,3 +631,45 @@ def pan_offset(i, margin=48, amp=20):
     ox = margin // 2 + int(round(amp * np.sin(2 * np.pi * i / 17.0)))
     oy = margin // 2 + int(round(amp * np.sin(2 * np.pi * i / 23.0 + 1.0)))
     return ox, oy
+
+
+def vocabulary(k=10, L=3, seed=77, bits=40, stop_frac=0.02):
+    """A synthetic DBoW2 vocabulary tree (complete k-ary, depth L) in the node order of the text format TemplatedVocabulary::loadFromTextFile reads
+    (node ids 1.. in file order, breadth first; word ids in order of leaf appearance).  A child's descriptor is its parent's with `bits` random bit flips;
+    leaf weights are idf-like positive doubles, a few words are stopped (weight 0).  Returns dict(k, L, parent [n], is_leaf [n], desc [n,32], weight [n])
+    for nodes 1..n (node 0, the root, is implicit)."""
+    rng = np.random.default_rng(seed)
+    parent, is_leaf, desc, weight = [], [], [], []
+    frontier = [(0, rng.integers(0, 256, 32, dtype=np.uint8))]
+    nid = 0
+    for level in range(1, L + 1):
+        nxt = []
+        for pid, pdesc in frontier:
+            for _ in range(k):
+                nid += 1
+                d = _flip_bits(rng, pdesc[None], bits if level > 1 else 128)[0]
+                leaf = level == L
+                parent.append(pid); is_leaf.append(1 if leaf else 0); desc.append(d)
+                weight.append(0.0 if not leaf or rng.random() < stop_frac else float(rng.uniform(0.5, 9.0)))
+                nxt.append((nid, d))
+        frontier = nxt
+    return dict(k=k, L=L, parent=np.array(parent, np.int32), is_leaf=np.array(is_leaf, np.uint8), desc=np.stack(desc), weight=np.array(weight, np.float64))
+
+
+def write_vocabulary_text(voc, path):
+    """ORBvoc.txt's format: header 'k L scoring weighting' (0 0 = L1_NORM, TF_IDF), then per node 'parent isLeaf d0 .. d31 weight'.  No trailing newline: the
+    reference's reader would append a node for an empty last line."""
+    lines = [f"{voc['k']} {voc['L']} 0 0"]
+    for p, lf, d, w in zip(voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"]):
+        lines.append(f"{int(p)} {int(lf)} " + " ".join(str(int(x)) for x in d) + f" {float(w)!r}")
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+
+
+def vocabulary_queries(voc, n=1000, seed=5, bits=25):
+    """Descriptors near the vocabulary's leaves (noisy copies), so the tree descent is not arbitrary; some leaves are hit several times."""
+    rng = np.random.default_rng(seed)
+    leaves = np.nonzero(voc["is_leaf"])[0]
+    pick = leaves[rng.integers(0, len(leaves), n)]
+    pick[: n // 5] = pick[n // 5: 2 * (n // 5)]          # repeated words: term frequency > 1
+    return _flip_bits(rng, voc["desc"][pick], bits)

@@ -728,3 +728,50 @@ def surface_normals(depth, cam=(535.4, 539.2, 320.1, 247.6), factor=1.0 / 5000.0
                               C.c_void_p(nrm.ctypes.data), C.c_void_p(pts.ctypes.data), cap, C.c_void_p(dist.ctypes.data) if want_dist else None)
     assert n == cap, (n, cap)
     return (nrm, pts, dist) if want_dist else (nrm, pts)
+
+
+# ---- DBoW2 vocabulary transform (oracle/bow_oracle.cpp; the REAL Thirdparty/DBoW2 through oracle/_ref/ref_bow) ----
+class VocabOracle:
+    def __init__(self, voc):
+        L = lib()
+        L.orc_vocab_create.restype = C.c_void_p
+        self.L = L
+        a = {k: np.ascontiguousarray(voc[k]) for k in ("parent", "is_leaf", "desc", "weight")}
+        self.h = C.c_void_p(L.orc_vocab_create(int(voc["k"]), int(voc["L"]), len(a["parent"]), C.c_void_p(a["parent"].ctypes.data), C.c_void_p(a["is_leaf"].ctypes.data),
+                                               C.c_void_p(a["desc"].ctypes.data), C.c_void_p(a["weight"].ctypes.data)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_vocab_destroy(self.h); self.h = None
+
+    def transform(self, desc, levelsup=4):
+        """-> dict(word [n], weight [n], node [n] (-1: stopped word), bow_word [m], bow_value [m])"""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        word = np.zeros(n, np.int32); wt = np.zeros(n); node = np.zeros(n, np.int32); bw = np.zeros(max(n, 1), np.int32); bv = np.zeros(max(n, 1))
+        m = self.L.orc_bow_transform(self.h, C.c_void_p(desc.ctypes.data), n, int(levelsup), C.c_void_p(word.ctypes.data), C.c_void_p(wt.ctypes.data),
+                                     C.c_void_p(node.ctypes.data), C.c_void_p(bw.ctypes.data), C.c_void_p(bv.ctypes.data))
+        return dict(word=word, weight=wt, node=node, bow_word=bw[:m].copy(), bow_value=bv[:m].copy())
+
+
+def ref_bow_path():
+    return os.path.join(ORACLE_DIR, "_ref", "ref_bow")
+
+
+def run_ref_bow(voc_txt, desc, levelsup=4):
+    """The real DBoW2 TemplatedVocabulary::transform on a vocabulary text file -> same dict as VocabOracle.transform."""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(desc)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.array([levelsup, n], np.int32).tobytes()); f.write(desc.tobytes())
+        subprocess.check_call([ref_bow_path(), voc_txt, fin, fout])
+        buf = open(fout, "rb").read()
+    m = int(np.frombuffer(buf, "<i4", 1, 0)[0]); off = 4
+    pairs = np.frombuffer(buf, np.dtype([("w", "<u4"), ("v", "<f8")]), m, off); off += 12 * m
+    node = np.frombuffer(buf, "<i4", n, off).copy(); off += 4 * n
+    word = np.frombuffer(buf, "<u4", n, off).astype(np.int32); off += 4 * n
+    wt = np.frombuffer(buf, "<f8", n, off).copy(); off += 8 * n
+    assert off == len(buf)
+    return dict(word=word, weight=wt, node=node, bow_word=pairs["w"].astype(np.int32), bow_value=pairs["v"].copy())
