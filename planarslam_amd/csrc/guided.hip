@@ -26,7 +26,7 @@ namespace guided {
 constexpr int NT = 256;
 constexpr int NCELL = PLANAR_GRID_COLS * PLANAR_GRID_ROWS;
 constexpr int MAXN = PLANAR_MAX_FRAME_KEYS;
-constexpr int CAND_CAP = 12288;
+constexpr int CAND_CAP = 8192;       // candidates of one chunk of probes; with it the workgroup needs 61 KB of LDS (two per CU)
 constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:38-40
 
 enum { MODE_FRAME = 0, MODE_MAP = 1, MODE_BOW = 2 };

@@ -18,6 +18,8 @@
 //     re-evaluates.
 // No MFMA: there is no dense contraction here (6x6 per frame).  Roofline is HBM/L2 streaming
 // of the edge arrays (65 KB per frame per LM evaluation), in practice latency/FP64-issue bound.
+#include <cstdlib>
+
 #include "common.h"
 #include "geom_dev.h"
 
@@ -296,7 +298,10 @@ __device__ void block_reduce(double* v, double* lds /* [4][N] */) {
     for (int k = 0; k < N; k++) v[k] = (lds[k] + lds[N + k]) + (lds[2 * N + k] + lds[3 * N + k]);
 }
 
-__global__ __launch_bounds__(NT, 2) void pose_opt_kernel(BatchDev Bt, ParamsDev P) {
+// WAVES = minimum waves per SIMD the register allocator must leave room for: 2 -> 256 VGPRs, two frames per CU, 92 VGPRs spilled to scratch;
+// 1 -> 256 VGPRs + AGPRs as spill space (no scratch traffic), one frame per CU.  planar_pose_opt_dev picks (see there).
+template <int WAVES>
+__global__ __launch_bounds__(NT, WAVES) void pose_opt_kernel(BatchDev Bt, ParamsDev P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     Frame F;
@@ -594,8 +599,13 @@ static int pose_launch(planar_ctx* ctx, const planar_pose_batch* bt, const plana
     const size_t smem = (4 * 28 + (size_t)bt->max_planes * 3 * 36) * sizeof(double) + (size_t)bt->max_points + bt->max_lines + 3 * (size_t)bt->max_planes + 16;
     PLANAR_REQUIRE(smem <= 160 * 1024, PLANAR_EINVAL, "problem too large for LDS");
     if (smem > 64 * 1024)
-        PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(pose::pose_opt_kernel, dim3(bt->B), dim3(pose::NT), smem, ctx->stream, B, P);
+        PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    static const int waves = [] { const char* e = getenv("PLANAR_POSE_WAVES"); return e ? atoi(e) : 2; }();   // measurement switch (tools/pose_waves.py); default = the faster one
+    if (waves == 1) {
+        if (smem > 64 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(pose::pose_opt_kernel<1>, dim3(bt->B), dim3(pose::NT), smem, ctx->stream, B, P);
+    } else
+        hipLaunchKernelGGL(pose::pose_opt_kernel<2>, dim3(bt->B), dim3(pose::NT), smem, ctx->stream, B, P);
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
 }
