@@ -483,6 +483,24 @@ int planar_bow_transform(planar_vocab* voc, const uint8_t* desc, const int32_t* 
 int planar_bow_transform_dev(planar_vocab* voc, const uint8_t* d_desc, const int32_t* d_n, int B, int stride, int levelsup, int32_t* d_word,
                              double* d_weight, int32_t* d_node, int32_t* d_bow_word, double* d_bow_value, int32_t* d_bow_n);
 
+/* ---- 3-D line back-projection (replaces Frame::isLineGood, src/Frame.cc:189-267, with compPt3dCov / extract3dline_mahdist / verify3dLine /
+ *      mah_dist3d_pt_line / computeLine3d_svd of src/LineExtractor.cpp:1157-1470) ----
+ * keylines [B][ln_stride] = Frame::mvKeylinesUn, depth = the u16 depth image (imDepth = value * depth_factor), fx.. = Frame::fx.. (K(0,0) of compPt3dCov is fx).
+ * seeds [B]: line i of frame b draws from the glibc rand() stream of srand(seeds[b] + i) - the reference uses the process-global rand() state, which
+ * is not reproducible; with this seeding a CPU run of the reference that calls srand(seed + i) before line i gives the same draws.
+ *   depth_line [B][ln_stride] float   mvDepthLine (-1: no reliable 3-D line)          lines3d [B][ln_stride][6]  mvLines3D (A xyz, B xyz; zeros if none)
+ *   good [B][ln_stride] u8            the line was pushed to mVF3DLines                 direction [B][ln_stride][3] FrameLine::direction
+ *   n_inliers [B][ln_stride]          tmpLine.pts.size()
+ *   packed_dirs [B][ln_stride][3] (or NULL in the _dev form) + n_good [B]: the directions of the good lines in line order = mVF3DLines, the
+ *   line_dirs / n_lines arguments of planar_track_manhattan_frame. */
+int planar_is_line_good(planar_ctx* ctx, int B, const planar_keyline* keylines, const int32_t* n_lines, int ln_stride, const uint16_t* depth, int width,
+                        int height, int pitch_px, int64_t frame_stride_px, float depth_factor, float fx, float fy, float cx, float cy, const uint32_t* seeds,
+                        float* depth_line, double* lines3d, uint8_t* good, double* direction, int32_t* n_inliers, double* packed_dirs, int32_t* n_good);
+int planar_is_line_good_dev(planar_ctx* ctx, int B, const planar_keyline* d_keylines, const int32_t* d_n_lines, int ln_stride, const uint16_t* d_depth,
+                            int width, int height, int pitch_px, int64_t frame_stride_px, float depth_factor, float fx, float fy, float cx, float cy,
+                            const uint32_t* d_seeds, float* d_depth_line, double* d_lines3d, uint8_t* d_good, double* d_direction, int32_t* d_n_inliers,
+                            double* d_packed_dirs, int32_t* d_n_good);
+
 /* ---- surface normals (replaces the tail of Frame::ComputePlanes, src/Frame.cc:694-751: the depth image sampled every 3rd pixel ->
  *      pcl::IntegralImageNormalEstimation(AVERAGE_3D_GRADIENT, MaxDepthChangeFactor 0.05, NormalSmoothingSize 10) -> vSurfaceNormal) ----
  * Output per frame: planar_normals_count() entries in the reference's push_back order (odd rows m, odd columns n of the

@@ -159,6 +159,8 @@ _SIGS = {
     "planar_vocab_words": (C.c_int, [C.c_void_p]),
     "planar_bow_transform": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "planar_bow_transform_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "planar_is_line_good": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 8),
+    "planar_is_line_good_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 8),
     "planar_normals_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_normals_destroy": (None, [C.c_void_p]),
     "planar_normals_count": (C.c_int, [C.c_void_p]),

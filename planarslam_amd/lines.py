@@ -69,3 +69,23 @@ class LineSegment:
             self.close()
         except Exception:
             pass
+
+
+def is_line_good(keylines, n_lines, depth, seeds, cam=(535.4, 539.2, 320.1, 247.6), depth_factor=1.0 / 5000.0, ctx: Context | None = None):
+    """Frame::isLineGood (reference src/Frame.cc:189-267) for a batch: keylines [B,S] KEYLINE_DTYPE, n_lines [B], depth [B,H,W] u16, seeds [B] u32.
+    Returns dict(depth_line [B,S] f32, lines3d [B,S,6], good [B,S] u8, direction [B,S,3], n_inliers [B,S], packed_dirs [B,S,3], n_good [B])."""
+    import ctypes as C
+
+    from ._lib import KEYLINE_DTYPE
+    L = lib()
+    ctx = ctx or Context(0)
+    kl = np.ascontiguousarray(keylines, KEYLINE_DTYPE)
+    B, S = kl.shape
+    d = np.ascontiguousarray(depth, np.uint16)
+    H, W = d.shape[1:]
+    nl = np.ascontiguousarray(n_lines, np.int32); sd = np.ascontiguousarray(seeds, np.uint32)
+    out = dict(depth_line=np.zeros((B, S), np.float32), lines3d=np.zeros((B, S, 6)), good=np.zeros((B, S), np.uint8), direction=np.zeros((B, S, 3)),
+               n_inliers=np.zeros((B, S), np.int32), packed_dirs=np.zeros((B, S, 3)), n_good=np.zeros(B, np.int32))
+    check(L.planar_is_line_good(ctx.h, B, kl.ctypes.data, nl.ctypes.data, S, d.ctypes.data, W, H, W, W * H, np.float32(depth_factor), cam[0], cam[1], cam[2], cam[3],
+                                sd.ctypes.data, *[out[k].ctypes.data for k in ("depth_line", "lines3d", "good", "direction", "n_inliers", "packed_dirs", "n_good")]))
+    return out

@@ -775,3 +775,27 @@ def run_ref_bow(voc_txt, desc, levelsup=4):
     wt = np.frombuffer(buf, "<f8", n, off).copy(); off += 8 * n
     assert off == len(buf)
     return dict(word=word, weight=wt, node=node, bow_word=pairs["w"].astype(np.int32), bow_value=pairs["v"].copy())
+
+
+# ---- 3-D line back-projection (oracle/line3d_oracle.cpp: Frame::isLineGood + extract3dline_mahdist) ----
+def glibc_rand(seed, count):
+    out = np.zeros(count, np.int32)
+    lib().orc_glibc_rand(C.c_uint32(seed), count, C.c_void_p(out.ctypes.data))
+    return out
+
+
+def is_line_good(keylines, depth, seed, cam=(535.4, 539.2, 320.1, 247.6), factor=1.0 / 5000.0):
+    """Frame::isLineGood for one frame -> dict(depth_line [n] f32, lines3d [n,6] f64, good [n] u8, direction [n,3] f64, n_inliers [n], n_samples [n])."""
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    L = lib()
+    kl = np.ascontiguousarray(keylines, KEYLINE_DTYPE)
+    depth = np.ascontiguousarray(depth, np.uint16)
+    H, W = depth.shape
+    n = len(kl)
+    m = max(n, 1)
+    out = dict(depth_line=np.zeros(m, np.float32), lines3d=np.zeros((m, 6)), good=np.zeros(m, np.uint8), direction=np.zeros((m, 3)), n_inliers=np.zeros(m, np.int32),
+               n_samples=np.zeros(m, np.int32))
+    L.orc_is_line_good.restype = C.c_int
+    L.orc_is_line_good(C.c_void_p(kl.ctypes.data), n, C.c_void_p(depth.ctypes.data), W, H, W, C.c_float(np.float32(factor)), C.c_float(cam[0]), C.c_float(cam[1]),
+                       C.c_float(cam[2]), C.c_float(cam[3]), C.c_uint32(seed), *[C.c_void_p(out[k].ctypes.data) for k in ("depth_line", "lines3d", "good", "direction", "n_inliers", "n_samples")])
+    return {k: v[:n] for k, v in out.items()}
