@@ -356,8 +356,7 @@ def main():
                 "SearchByProjection(Cur, Last) + LSD SearchByDescriptor + MatchORBPoints + PlaneMatcher -> TranslationOptimization 4x10 -> isInFrustum + SearchByProjection(map) + "
                 "LSD SearchByProjection -> PoseOptimization 4x10 -> UnprojectStereo; pose problems assembled on the device from the matchers' outputs"
                 if full else "configs[1]: ORB only, 640x480 gray, 8-level pyramid, 1000 keypoints + 256-bit rBRIEF")
-    nyi = (["3-D line back-projection (Frame::isLineGood): the Manhattan tracker reads the frames' own surface normals but a resident array of line directions",
-            "PCL voxel-grid / RANSAC refit of the plane coefficients (Frame::ComputePlanes)",
+    nyi = (["PCL voxel-grid / RANSAC refit of the plane coefficients (Frame::ComputePlanes)",
             "map maintenance: the local map is the previous two frames' keypoints, key-frame lines and map planes are fixed per stream"]
            if full else ["LSD/LBD lines", "PEAC planes", "matching", "pose optimisation"])
     out = {

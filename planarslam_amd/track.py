@@ -14,7 +14,7 @@ The sequence of the reference's tracking thread for one RGB-D frame (src/Trackin
 
 What is NOT the reference's code path and only stands in for the map it maintains (Map / KeyFrame / LocalMapping are out of scope):
 the local map of a stream is the previous two frames' own back-projected keypoints, the reference key frame's lines and the map planes are
-fixed per stream (set_map), the 3-D line directions of the Manhattan tracker are a resident array (Frame::isLineGood is not built), and
+fixed per stream (set_map), and
 MapPoint::UpdateNormalAndDepth / the plane coefficient (n, -n.c) of Frame::ComputePlanes are a few torch element-wise ops here.
 
 PyTorch supplies device memory, streams and events only.  Frame-batch parallelism: steps are pipelined `depth` deep - the tracking chain of
@@ -83,6 +83,10 @@ class TrackPipeline:
         self.ldesc = [z((B, 40, 32), t.uint8) for _ in range(NB)]
         self.leq = [z((B, 40, 3), t.float64) for _ in range(NB)]
         self.nl = [z((B,), t.int32) for _ in range(NB)]
+        # Frame::isLineGood outputs: mvDepthLine, mvLines3D, the packed FrameLine directions (mVF3DLines) and their count
+        self.l3 = [dict(depth_line=z((B, 40), t.float32), lines3d=z((B, 40, 6), t.float64), good=z((B, 40), t.uint8), direction=z((B, 40, 3), t.float64),
+                        n_inliers=z((B, 40), t.int32), packed=z((B, 40, 3), t.float64), n_good=z((B,), t.int32), seeds=z((B,), t.int32)) for _ in range(NB)]
+        self.seed_base = t.arange(B, dtype=t.int32, device=self.dev) * 64
         self.ev_in = [t.cuda.Event() for _ in range(NB)]
         self.ev_orb = [t.cuda.Event() for _ in range(NB)]
         self.join_p = [t.cuda.Event() for _ in range(NB)]
@@ -205,6 +209,15 @@ class TrackPipeline:
         self.pds[k].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), B)
         self.sns[k].compute_dev(depth.data_ptr(), self.snrm[k].data_ptr(), B, K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
         check(L.planar_lsd_detect_dev(self.lss[k].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
+        # Frame::ExtractLSD: isLineGood right behind ExtractLineSegment, same thread; every (stream, step, line) has its own rand() seed
+        l3 = self.l3[k]
+        with t.cuda.stream(sl):
+            t.add(self.seed_base, (i * B * 64) & 0x3fffffff, out=l3["seeds"])
+        c = self.cam
+        check(L.planar_is_line_good_dev(self.ctx_lsds[k].h, B, self.kls[k].data_ptr(), self.nl[k].data_ptr(), 40, depth.data_ptr(), self.W, self.H, self.W, self.W * self.H,
+                                        float(np.float32(1.0 / 5000.0)), c["fx"], c["fy"], c["cx"], c["cy"], l3["seeds"].data_ptr(), l3["depth_line"].data_ptr(),
+                                        l3["lines3d"].data_ptr(), l3["good"].data_ptr(), l3["direction"].data_ptr(), l3["n_inliers"].data_ptr(), l3["packed"].data_ptr(),
+                                        l3["n_good"].data_ptr()))
         if side: side[1].record(sp); side[3].record(sl)
         self.join_p[k].record(sp); self.join_l[k].record(sl)
         self.ex.extract_dev(gray.data_ptr(), self.kps[k].data_ptr(), self.desc[k].data_ptr(), self.n[k].data_ptr(), B)
@@ -240,16 +253,17 @@ class TrackPipeline:
             cap = self.captured[j] = {}
             snap = lambda name, x: cap.__setitem__(name, x.clone())
             for name, x in (("kps", self.kps[k]), ("desc", self.desc[k]), ("n", self.n[k]), ("ur", self.ur[k]), ("zd", self.zd[k]), ("kls", self.kls[k]), ("ldesc", self.ldesc[k]),
-                            ("leq", self.leq[k]), ("nl", self.nl[k]), ("lab", self.lab[k]), ("pls", self.pls[k]), ("npl", self.npl[k]), ("snrm", self.snrm[k]), ("pose_in", self.pose), ("Rcm_in", self.Rcm),
+                            ("leq", self.leq[k]), ("nl", self.nl[k]), ("lab", self.lab[k]), ("pls", self.pls[k]), ("npl", self.npl[k]), ("snrm", self.snrm[k]), ("l3_packed", self.l3[k]["packed"]), ("l3_n_good", self.l3[k]["n_good"]), ("l3_seeds", self.l3[k]["seeds"]),
+                            ("l3_lines3d", self.l3[k]["lines3d"]), ("l3_depth_line", self.l3[k]["depth_line"]), ("pose_in", self.pose), ("Rcm_in", self.Rcm),
                             ("last_xw", self.h_xw[l]), ("last_valid", self.h_valid[l]), ("last_desc", self.h_desc[l]), ("last_oct", self.h_oct[l]), ("last_ang", self.h_ang[l]),
                             ("last_n", self.h_n[l]), ("old_xw", self.h_xw[o]), ("old_valid", self.h_valid[o]), ("old_desc", self.h_desc[o]), ("old_normal", self.h_normal[o]),
                             ("old_mind", self.h_mind[o]), ("old_maxd", self.h_maxd[o]), ("old_n", self.h_n[o])):
                 snap(name, x)
         if j >= 2 and self.map_set:
             # ---- Track(): Manhattan frame ----
-            # the frame's own surface normals (Frame::vSurfaceNormal); the 3-D line directions (mVF3DLines) are still a per-stream resident array
+            # the frame's own surface normals (Frame::vSurfaceNormal) and 3-D line directions (Frame::mVF3DLines)
             check(L.planar_track_manhattan_frame_dev(self.ctx_t.h, B, self.Rcm.data_ptr(), self.snrm[k].data_ptr(), self.n_snrm.data_ptr(), self.SN,
-                                                     self.sn["lines"].data_ptr(), self.sn["n_lines"].data_ptr(), self.sn["lines"].shape[1],
+                                                     self.l3[k]["packed"].data_ptr(), self.l3[k]["n_good"].data_ptr(), 40,
                                                      self.Rcm_new.data_ptr(), None, None, None))
             if evs: evs["manhattan"].record(st)
             # ---- TranslationWithMotionModel ----

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
+from planarslam_amd._lib import KEYLINE_DTYPE
 from planarslam_amd.synth import TUM3, pan_offset, scale_factors
 
 pytestmark = pytest.mark.gpu
@@ -68,7 +69,6 @@ def _frame_dict(c, Tcw, blocked=None):
 
 @pytest.mark.parametrize("which", [0, 1])
 def test_extraction_of_a_pipelined_step(run, which):
-    from planarslam_amd._lib import KEYLINE_DTYPE
     j = STEPS - 2 + which
     c, (g, d) = run["cap"][j], run["inputs"][j]
     o = ol.OrbOracle()
@@ -98,10 +98,14 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
         assert np.array_equal(c["pose_in"], prev["pose_out"]) and np.array_equal(c["last_xw"], prev["new_xw"]) and np.array_equal(c["Rcm_in"], prev["Rcm_new"])
     # ---- TrackManhattanFrame ----
     for b in range(0, B, 7):
-        m = int(sn["n_lines"][b])
         nrm, _ = ol.surface_normals(d[b])                  # Frame::ComputePlanes' normals of THIS frame's depth, every bit (NaN pattern included)
         assert np.array_equal(np.isnan(nrm), np.isnan(c["snrm"][b])) and np.array_equal(nrm[~np.isnan(nrm)], c["snrm"][b][~np.isnan(nrm)])
-        w = ol.track_manhattan_frame(c["Rcm_in"][b].reshape(3, 3), nrm, sn["lines"][b, :m])
+        nlb = int(c["nl"][b])                              # Frame::isLineGood on THIS frame's key lines and depth, with the seed the pipeline used
+        l3 = ol.is_line_good(c["kls"].view(KEYLINE_DTYPE).reshape(B, 40)[b, :nlb], d[b], int(np.uint32(c["l3_seeds"][b])))
+        gl = l3["good"] > 0
+        assert int(c["l3_n_good"][b]) == gl.sum() and np.array_equal(c["l3_lines3d"][b, :nlb], l3["lines3d"]) and np.array_equal(c["l3_depth_line"][b, :nlb], l3["depth_line"])
+        assert np.abs(c["l3_packed"][b, :gl.sum()] - l3["direction"][gl]).max(initial=0) <= 1e-9
+        w = ol.track_manhattan_frame(c["Rcm_in"][b].reshape(3, 3), nrm, c["l3_packed"][b, :gl.sum()])
         assert np.abs(w["R"].ravel() - c["Rcm_new"][b]).max() <= 1e-5
     # ---- SearchByProjection(Cur, Last) ----
     cur = _frame_dict(c, c["pose_in"])
@@ -162,7 +166,6 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
     lrange = np.arange(40)[None, :] < kf["n"][:, None]
     il = (lp["in_view"] > 0) & lrange
     assert np.array_equal(lp["in_view"][lrange], c["lpr"]["in_view"][lrange]) and np.array_equal(lp["proj"][il], c["lpr"]["proj"][il])
-    from planarslam_amd._lib import KEYLINE_DTYPE
     lines = dict(n=c["nl"], keylines=c["kls"].view(KEYLINE_DTYPE).reshape(B, 40), ldesc=c["ldesc"], blocked=(c["lm1"] >= 0).astype(np.uint8))
     maplines = dict(n=kf["n"], in_view=lp["in_view"], proj=lp["proj"], level=lp["level"], view_cos=lp["view_cos"], desc=kf["ldesc"], observed=np.ones((B, 40), np.uint8))
     lm2, nlm2 = ol.lsd_search_by_projection(lines, maplines, sf, 3.0, 0.6, match=c["lm1"])
