@@ -69,4 +69,7 @@ namespace orc {
 void jacobi_svd3_f32(float At[3][3], float W[3], float Vt[3][3]);
 // cv::determinant of a 3x3 CV_32F matrix: the det3 macro of lapack.cpp (inner 2x2 products in double, result double)
 double det3_f32(const float m[3][3]);
+// cv::SVD for CV_64F (JacobiSVDImpl_<double>, OpenCV 3.4 core/src/lapack.cpp): At = the n columns of A stored as n rows of length m (m >= n), orthogonalised in
+// place and normalised (the left singular vectors), W descending, Vt (n x n) the right singular vectors as rows
+void jacobi_svd_f64(double* At, int astep, double* W, double* Vt, int vstep, int m, int n);
 }  // namespace orc

@@ -7,8 +7,10 @@
 // Reproducibility: the reference draws from the process-global rand(); here every line draws from its own glibc-rand() stream seeded with
 // (frame seed + line index), i.e. what `srand(seed + i)` before line i would give (glibc TYPE_3 generator restated below and checked against libc in
 // tests/test_oracle_line3d.py).
-// PARITY UNPINNED below the reference's own arithmetic: cv::SVD (JacobiSVDImpl_<double>, OpenCV 3.4 core/src/lapack.cpp) and the cv::gemm summation
-// order are restated as read (oracle/cvprim.cpp), OpenCV is not in the reference tree.
+// Pinned against the reference's own code: oracle/_ref/ref_line3d compiles src/Frame.cc:189-267 and the src/LineExtractor.cpp / include/LSDextractor.h
+// functions above where they lie (extracted by line range) and tests/test_oracle_line3d.py requires every output bit to agree (fixtures in
+// tests/golden/line3d_ref.npz).  What stays unpinned is OpenCV underneath: cv::SVD (JacobiSVDImpl_<double>, core/src/lapack.cpp) and the cv::gemm
+// summation order are restated as read (oracle/cvprim.cpp, oracle/shim/cvalgebra.hpp) for both sides of that comparison.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -16,6 +18,7 @@
 #include <vector>
 
 #include "../include/planar_abi.h"
+#include "cvprim.h"
 
 namespace orc {
 
@@ -45,66 +48,6 @@ struct GlibcRand {
         return (int)(v >> 1);
     }
 };
-
-// ---- cv::SVD for CV_64F: JacobiSVDImpl_<double>(At, W, Vt, m, n, n1 = n), rows of At (n x m) are the columns of A ----
-void jacobi_svd_f64(double* At, int astep, double* W_, double* Vt, int vstep, int m, int n) {
-    const double eps = 2.220446049250313e-16 * 10, minval = 2.2250738585072014e-308;
-    std::vector<double> W(n);
-    for (int i = 0; i < n; i++) {
-        double sd = 0;
-        for (int k = 0; k < m; k++) { const double t = At[i * astep + k]; sd += t * t; }
-        W[i] = sd;
-        for (int k = 0; k < n; k++) Vt[i * vstep + k] = 0;
-        Vt[i * vstep + i] = 1;
-    }
-    const int max_iter = std::max(m, 30);
-    for (int iter = 0; iter < max_iter; iter++) {
-        bool changed = false;
-        for (int i = 0; i < n - 1; i++)
-            for (int j = i + 1; j < n; j++) {
-                double* Ai = At + i * astep; double* Aj = At + j * astep;
-                double a = W[i], p = 0, b = W[j];
-                for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
-                if (std::abs(p) <= eps * std::sqrt(a * b)) continue;
-                p *= 2;
-                const double beta = a - b, gamma = hypot(p, beta);
-                double c, s;
-                if (beta < 0) { const double delta = (gamma - beta) * 0.5; s = std::sqrt(delta / gamma); c = (p / (gamma * s * 2)); }
-                else { c = std::sqrt((gamma + beta) / (gamma * 2)); s = (p / (gamma * c * 2)); }
-                a = b = 0;
-                for (int k = 0; k < m; k++) {
-                    const double t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k];
-                    Ai[k] = t0; Aj[k] = t1;
-                    a += t0 * t0; b += t1 * t1;
-                }
-                W[i] = a; W[j] = b;
-                changed = true;
-                double* Vi = Vt + i * vstep; double* Vj = Vt + j * vstep;
-                for (int k = 0; k < n; k++) { const double t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k]; Vi[k] = t0; Vj[k] = t1; }
-            }
-        if (!changed) break;
-    }
-    for (int i = 0; i < n; i++) {
-        double sd = 0;
-        for (int k = 0; k < m; k++) { const double t = At[i * astep + k]; sd += t * t; }
-        W[i] = std::sqrt(sd);
-    }
-    for (int i = 0; i < n - 1; i++) {
-        int j = i;
-        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
-        if (i != j) {
-            std::swap(W[i], W[j]);
-            for (int k = 0; k < m; k++) std::swap(At[i * astep + k], At[j * astep + k]);
-            for (int k = 0; k < n; k++) std::swap(Vt[i * vstep + k], Vt[j * vstep + k]);
-        }
-    }
-    for (int i = 0; i < n; i++) W_[i] = W[i];
-    for (int i = 0; i < n; i++) {      // left singular vectors = normalised rows (a zero singular value does not occur on this path)
-        const double sd = W[i];
-        const double s = sd > minval ? 1 / sd : 0.;
-        for (int k = 0; k < m; k++) At[i * astep + k] *= s;
-    }
-}
 
 struct P3 { double x = 0, y = 0, z = 0; };
 static inline P3 operator-(const P3& a, const P3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }

@@ -20,7 +20,30 @@ struct MatExpr {
     Mat a, b, c;
     bool tr = false, has_b = false, has_c = false;
     double alpha = 1, beta = 1;
+    // CV_64F operands (the 3-D line code, src/LineExtractor.cpp): every product element is the k = 0, 1, 2 ... sum of double products, in order, on
+    // both the small-matrix path and the general path (GEMMSingleMul<double, double>; its 4-way unrolled block only starts at inner length 4, which the
+    // 3 x 3 products never reach); alpha * A = cvtScale64f.
+    Mat eval64() const {
+        const int ar = tr ? a.cols : a.rows, ac = tr ? a.rows : a.cols;
+        auto A = [&](int i, int k) -> double { return tr ? a.at<double>(k, i) : a.at<double>(i, k); };
+        if (!has_b) {
+            Mat d(ar, ac, CV_64F);
+            for (int i = 0; i < ar; i++)
+                for (int j = 0; j < ac; j++) d.at<double>(i, j) = has_c ? (A(i, j) * alpha + c.at<double>(i, j) * beta) : (alpha == 1 ? A(i, j) : A(i, j) * alpha);
+            return d;
+        }
+        assert(ac == b.rows && b.type() == CV_64F);
+        Mat d(ar, b.cols, CV_64F);
+        for (int i = 0; i < ar; i++)
+            for (int j = 0; j < b.cols; j++) {
+                double s0 = 0;
+                for (int k = 0; k < ac; k++) s0 += A(i, k) * b.at<double>(k, j);
+                d.at<double>(i, j) = has_c ? s0 * alpha + c.at<double>(i, j) * beta : s0 * alpha;
+            }
+        return d;
+    }
     Mat eval() const {
+        if (a.type() == CV_64F) return eval64();
         const int ar = tr ? a.cols : a.rows, ac = tr ? a.rows : a.cols;
         auto A = [&](int i, int k) -> float { return tr ? a.at<float>(k, i) : a.at<float>(i, k); };
         if (!has_b) {
@@ -73,6 +96,7 @@ static inline MatExpr operator*(const MatExpr& x, const Mat& b) {
     MatExpr e = x; e.b = b; e.has_b = true; return e;
 }
 static inline MatExpr operator*(const Mat& a, const MatExpr& y) { return a * y.eval(); }
+static inline MatExpr operator*(const MatExpr& x, const MatExpr& y) { return x.eval() * y.eval(); }
 static inline MatExpr operator*(double s, const Mat& a) { MatExpr e; e.a = a; e.alpha = s; return e; }
 static inline MatExpr operator*(const Mat& a, double s) { return s * a; }
 static inline MatExpr operator*(double s, const MatExpr& x) { if (x.has_c) return s * x.eval(); MatExpr e = x; e.alpha *= s; return e; }
@@ -132,8 +156,22 @@ static inline double determinant(const Mat& m) {
 // cv::SVD::compute(src, w, u, vt) for a 3x3 CV_32F matrix: transpose, JacobiSVDImpl_<float>, u = transposed rows, vt as computed
 class SVD {
 public:
+    enum { MODIFY_A = 1, NO_UV = 2, FULL_UV = 4 };
+    Mat u, w, vt;
     SVD() {}
+    SVD(const Mat& src, int flags = 0) { compute(src, w, u, vt, flags); }
+    SVD(const MatExpr& src, int flags = 0) { compute(src.eval(), w, u, vt, flags); }
     static void compute(const Mat& src, Mat& w, Mat& u, Mat& vt, int = 0) {
+        if (src.type() == CV_64F) {      // m x n with m >= n: temp_a = src^T (n rows of length m), JacobiSVDImpl_<double>, u = transposed rows, vt as computed
+            const int m = src.rows, n = src.cols;
+            assert(m >= n);
+            std::vector<double> At((size_t)n * m), W(n), Vt((size_t)n * n);
+            for (int i = 0; i < n; i++) for (int k = 0; k < m; k++) At[(size_t)i * m + k] = src.at<double>(k, i);
+            orc::jacobi_svd_f64(At.data(), m, W.data(), Vt.data(), n, m, n);
+            w.create(n, 1, CV_64F); u.create(m, n, CV_64F); vt.create(n, n, CV_64F);
+            for (int i = 0; i < n; i++) { w.at<double>(i) = W[i]; for (int k = 0; k < m; k++) u.at<double>(k, i) = At[(size_t)i * m + k]; for (int j = 0; j < n; j++) vt.at<double>(i, j) = Vt[(size_t)i * n + j]; }
+            return;
+        }
         assert(src.rows == 3 && src.cols == 3 && src.type() == CV_32F);
         float At[3][3], W[3], Vt[3][3];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[i][j] = src.at<float>(j, i);

@@ -57,7 +57,22 @@ template <typename T> static inline bool operator==(const Point_<T>& a, const Po
 template <typename T> static inline Point_<T> operator/(const Point_<T>& a, double b) { return Point_<T>((T)(a.x / b), (T)(a.y / b)); }
 template <typename T> static inline double norm(const Point_<T>& p) { return std::sqrt((double)p.x * p.x + (double)p.y * p.y); }
 
-template <typename T> struct Point3_ { T x, y, z; Point3_() : x(0), y(0), z(0) {} Point3_(T a, T b, T c) : x(a), y(b), z(c) {} };
+template <typename T> static inline Point_<T> operator+(const Point_<T>& a, const Point_<T>& b) { return Point_<T>((T)(a.x + b.x), (T)(a.y + b.y)); }
+template <typename T> static inline Point_<T> operator-(const Point_<T>& a, const Point_<T>& b) { return Point_<T>((T)(a.x - b.x), (T)(a.y - b.y)); }
+template <typename T> static inline Point_<T> operator*(const Point_<T>& a, double b) { return Point_<T>((T)(a.x * b), (T)(a.y * b)); }   // saturate_cast<T>(a.x * b)
+template <typename T> struct Point3_ {
+    T x, y, z;
+    Point3_() : x(0), y(0), z(0) {}
+    Point3_(T a, T b, T c) : x(a), y(b), z(c) {}
+    T dot(const Point3_& o) const { return (T)(x * o.x + y * o.y + z * o.z); }
+    Point3_ cross(const Point3_& o) const { return Point3_(y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x); }
+};
+template <typename T> static inline Point3_<T> operator+(const Point3_<T>& a, const Point3_<T>& b) { return Point3_<T>((T)(a.x + b.x), (T)(a.y + b.y), (T)(a.z + b.z)); }
+template <typename T> static inline Point3_<T> operator-(const Point3_<T>& a, const Point3_<T>& b) { return Point3_<T>((T)(a.x - b.x), (T)(a.y - b.y), (T)(a.z - b.z)); }
+template <typename T> static inline Point3_<T> operator*(const Point3_<T>& a, double b) { return Point3_<T>((T)(a.x * b), (T)(a.y * b), (T)(a.z * b)); }
+template <typename T> static inline Point3_<T> operator*(double b, const Point3_<T>& a) { return Point3_<T>((T)(a.x * b), (T)(a.y * b), (T)(a.z * b)); }
+template <typename T> static inline Point3_<T> operator/(const Point3_<T>& a, double b) { return Point3_<T>((T)(a.x / b), (T)(a.y / b), (T)(a.z / b)); }
+template <typename T> static inline double norm(const Point3_<T>& p) { return std::sqrt((double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z); }
 typedef Point3_<float> Point3f;
 typedef Point3_<double> Point3d;
 template <typename T, int N> struct Vec {

@@ -12,6 +12,7 @@ template <typename T, int R, int C, int Opt = ColMajor> struct Matrix {
     T d[R * C];
     Matrix() { for (int i = 0; i < R * C; i++) d[i] = T(0); }
     Matrix(T x, T y, T z) { static_assert(R * C == 3, "vector3 ctor"); d[0] = x; d[1] = y; d[2] = z; }
+    static Matrix Zero() { return Matrix(); }
     T& operator[](int i) { return d[i]; }
     const T& operator[](int i) const { return d[i]; }
     T& operator()(int i) { return d[i]; }

@@ -799,3 +799,25 @@ def is_line_good(keylines, depth, seed, cam=(535.4, 539.2, 320.1, 247.6), factor
     L.orc_is_line_good(C.c_void_p(kl.ctypes.data), n, C.c_void_p(depth.ctypes.data), W, H, W, C.c_float(np.float32(factor)), C.c_float(cam[0]), C.c_float(cam[1]),
                        C.c_float(cam[2]), C.c_float(cam[3]), C.c_uint32(seed), *[C.c_void_p(out[k].ctypes.data) for k in ("depth_line", "lines3d", "good", "direction", "n_inliers", "n_samples")])
     return {k: v[:n] for k, v in out.items()}
+
+
+def ref_line3d_path():
+    return os.path.join(ORACLE_DIR, "_ref", "ref_line3d")
+
+
+def run_ref_line3d(keylines, depth, seed, cam=(535.4, 539.2, 320.1, 247.6), factor=1.0 / 5000.0):
+    """The reference's own Frame::isLineGood (+ src/LineExtractor.cpp helpers), srand(seed + i) before line i -> the fields of is_line_good() (no n_samples)."""
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    kl = np.ascontiguousarray(keylines, KEYLINE_DTYPE)
+    depth = np.ascontiguousarray(depth, np.uint16)
+    H, W = depth.shape
+    n = len(kl)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.array([n, W, H], np.int32).tobytes()); f.write(np.array([seed], np.uint32).tobytes())
+            f.write(np.array([cam[0], cam[1], cam[2], cam[3], factor], np.float32).tobytes()); f.write(kl.tobytes()); f.write(depth.tobytes())
+        subprocess.check_call([ref_line3d_path(), fin, fout], stdout=subprocess.DEVNULL)
+        buf = open(fout, "rb").read()
+    rec = np.frombuffer(buf, np.dtype([("depth_line", "<f4"), ("lines3d", "<f8", 6), ("good", "u1"), ("direction", "<f8", 3), ("n_inliers", "<i4")]), n)
+    return {k: rec[k].copy() for k in rec.dtype.names}
