@@ -172,6 +172,8 @@ def main():
                 t1 = time.perf_counter(); fn(); torch.cuda.synchronize()
                 standalone[name] = round((time.perf_counter() - t1) * 1e3, 3)
         ex.set_profiling(True)
+        if full:
+            for q in tp.pds: check(L.planar_peac_set_profiling(q.h, 1))
         evsets = [{n: torch.cuda.Event(enable_timing=True) for n in EV} for _ in range(args.steps)]
         sides = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
         barrier()
@@ -183,6 +185,14 @@ def main():
         elapsed = time.perf_counter() - t0
         prof, calls = ex.get_profile()
         ex.set_profiling(False)
+        peac_ms, peac_calls = np.zeros(4), 0
+        if full:
+            import ctypes as C
+            for q in tp.pds:                       # one plan per buffer set: HIP events right before / after each of the four launches, on the stream they run on
+                tot = np.zeros(4); nc = C.c_int64()
+                check(L.planar_peac_get_profile(q.h, tot.ctypes.data, C.byref(nc)))
+                check(L.planar_peac_set_profiling(q.h, 0))
+                peac_ms += tot; peac_calls += nc.value
     if full:
         tp.check()
 
@@ -212,9 +222,14 @@ def main():
     if full:
         # PEAC: read u16 depth + write int32 labels (1 843 200 B/frame); peac_blocks + peac_ahc + peac_order + peac_refine bracketed together
         pk = "peac_blocks+peac_ahc+peac_refine"
-        cand[pk] = (stage_ms["peac(stream 2)"], 1843200 * B)
-        kernels[pk] = {"ms_per_step": round(stage_ms["peac(stream 2)"], 4), "launches_per_step": 4, "alone_ms": standalone["peac_alone_ms"],
-                       "note": "HIP events on the PEAC stream: latency of one launch with up to depth+2 launches in flight"}
+        pav = peac_ms / max(1, peac_calls)          # average duration of each launch, HIP events tight around it (co-run: other streams share the CUs)
+        cand[pk] = (float(pav.sum()), 1843200 * B)
+        kernels[pk] = {"ms_per_step": round(float(pav.sum()), 4), "launches_per_step": 4, "alone_ms": standalone["peac_alone_ms"],
+                       "avg_launch_ms": {"peac_blocks": round(float(pav[0]), 3), "peac_ahc": round(float(pav[1]), 3), "peac_order": round(float(pav[2]), 3),
+                                         "peac_refine": round(float(pav[3]), 3)},
+                       "stream_bracket_ms": round(stage_ms["peac(stream 2)"], 3),
+                       "note": "avg_launch_ms: HIP events right before / after each launch on the PEAC stream, inside the timed region (what rocprofv3's AverageNs measures); "
+                               "stream_bracket_ms also holds the surface-normal kernel and the queueing between launches with up to depth+2 launch sets in flight"}
         lk = "lsd_detect(+7 small kernels)"
         cand[lk] = (standalone["lsd_lbd_alone_ms"], (307200 + 40 * 124) * B)
         kernels[lk] = {"ms_per_step": round(stage_ms["lsd_lbd(stream 3)"], 4), "launches_per_step": 8, "alone_ms": standalone["lsd_lbd_alone_ms"]}
@@ -237,7 +252,9 @@ def main():
     per_frame = 1961064 + (1843200 + 312160 if full else 0) + (72000 + 118000 + 65130 * 2 * 40 if full else 0)
     # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this
     # command, KB per launch, summed over the stage's kernels); raw counter sums (narrow gathers: no wide-read correction applied)
-    traffic, traffic_note = None, None
+    traffic = None
+    traffic_note = ("null: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes did not complete on the MI355X pool in round 2 (five attempts, each killed by its timeout - the "
+                    "ORB-only workload that profiled in round 1 included; profiles/README.md); round-1 figure for the plane stage: 8.4 MB read + 8.7 MB written per frame")
     pmc_csv = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_kb_per_launch.csv")
     pmc_keys = {"peac_blocks+peac_ahc+peac_refine": ("planar::peac::peac_blocks", "planar::peac::peac_ahc", "planar::peac::peac_refine"),
                 "lsd_detect(+7 small kernels)": ("planar::lsd::lsd_detect",)}.get(dom, ("planar::orb::" + dom,))

@@ -405,6 +405,10 @@ int planar_peac_segment_dev(planar_peac* peac, const uint16_t* d_depth, int B, i
 /* Synchronises and returns PLANAR_ECAPACITY if any of the last B frames overflowed an internal capacity
  * (more than max_planes planes, flood-fill queue, neighbour pool); the host-pointer entry point calls it itself. */
 int planar_peac_check(planar_peac* peac, int B);
+/* Per-launch timing with HIP events on the context stream (bench.py's roofline leg), as planar_orb_set_profiling: get_profile synchronises and returns the
+ * summed milliseconds of the four launches of the recorded calls (total_ms[4] = peac_blocks, peac_ahc, peac_order, peac_refine), their number, and resets. */
+int planar_peac_set_profiling(planar_peac* peac, int enable);
+int planar_peac_get_profile(planar_peac* peac, double* total_ms, int64_t* calls);
 /* Profiling aid: per-frame phase timestamps of the last call, out[B][16] (100 MHz ticks since kernel entry:
  * [1] graph edges, [2] heap built, [3] ahCluster, [4] seeds, [5] floodFill, [6] end; [8] flood-fill queue entries, [9] nodes). */
 int planar_peac_read_timing(planar_peac* peac, int B, int64_t* out);

@@ -93,6 +93,8 @@ _SIGS = {
     "planar_orb_create": (C.c_int, [C.c_void_p, C.POINTER(OrbParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_orb_destroy": (None, [C.c_void_p]),
     "planar_orb_check": (C.c_int, [C.c_void_p]),
+    "planar_peac_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "planar_peac_get_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "planar_orb_max_keypoints": (C.c_int, [C.c_void_p]),
     "planar_orb_get_scale_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_orb_level_size": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -1207,6 +1207,10 @@ struct planar_peac {
     DevBuf d_ws, d_status, d_timing, d_next, d_order;
     int order_B = 0;                                          // batch size d_order was computed for (0: none yet)
     DevBuf d_depth, d_labels, d_planes, d_nplanes;   // staging for the host-pointer entry point
+    bool profiling = false;                                   // planar_peac_set_profiling: five events per recorded call
+    std::vector<std::vector<hipEvent_t>> ev_sets;
+    size_t ev_used = 0;
+    ~planar_peac() { for (auto& v : ev_sets) for (hipEvent_t e : v) (void)hipEventDestroy(e); }
 };
 
 extern "C" {
@@ -1273,16 +1277,56 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     PLANAR_REQUIRE(pitch_px >= p->W && frame_stride_px >= (int64_t)pitch_px * p->H, PLANAR_EINVAL, "pitch/frame_stride too small");
     hipStream_t st = p->ctx->stream;
     const peac::Intr K{fx, fy, cx, cy, depth_factor};
-    hipLaunchKernelGGL(peac::peac_blocks, dim3((p->L.NB + 63) / 64, B), dim3(64), 0, st, p->L, K, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>());
+    // optional HIP-event timing of each launch (planar_peac_set_profiling): events on the stream the kernels run on, right before / after each launch
+    std::vector<hipEvent_t>* evs = nullptr;
+    if (p->profiling) {
+        if (p->ev_used == p->ev_sets.size()) {
+            std::vector<hipEvent_t> v(5);
+            for (hipEvent_t& e : v) PLANAR_HIP_CHECK(hipEventCreate(&e));
+            p->ev_sets.push_back(v);
+        }
+        evs = &p->ev_sets[p->ev_used++];
+    }
+    int li = 0;
+    auto mark = [&]() { if (evs) (void)hipEventRecord((*evs)[li], st); li++; };
     PLANAR_HIP_CHECK(hipMemsetAsync(p->d_next.p, 0, 4, st));
+    mark();
+    hipLaunchKernelGGL(peac::peac_blocks, dim3((p->L.NB + 63) / 64, B), dim3(64), 0, st, p->L, K, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>());
+    mark();
     hipLaunchKernelGGL(peac::peac_ahc, dim3(B), dim3(peac::NT_AHC), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
                        p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(), p->d_timing.as<long long>(), p->d_next.as<int>(),
                        p->order_B == B ? p->d_order.as<int>() : nullptr);
+    mark();
     hipLaunchKernelGGL(peac::peac_order, dim3((B + 255) / 256), dim3(256), 0, st, p->d_timing.as<long long>(), B, p->d_order.as<int>());
+    mark();
     hipLaunchKernelGGL(peac::peac_refine, dim3(B), dim3(peac::NT_REFINE), 0, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
                        p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
+    mark();
     p->order_B = B;
     PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+// Per-launch HIP-event timing (bench.py's roofline leg): slots peac_blocks, peac_ahc, peac_order, peac_refine
+int planar_peac_set_profiling(planar_peac* p, int enable) {
+    PLANAR_REQUIRE(p != nullptr, PLANAR_EINVAL, "peac is null");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    p->profiling = enable != 0;
+    p->ev_used = 0;
+    return PLANAR_OK;
+}
+int planar_peac_get_profile(planar_peac* p, double* total_ms /* [4] */, int64_t* calls) {
+    PLANAR_REQUIRE(p && total_ms && calls, PLANAR_EINVAL, "null argument");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    for (int i = 0; i < 4; i++) total_ms[i] = 0;
+    for (size_t c = 0; c < p->ev_used; c++)
+        for (int i = 0; i < 4; i++) {
+            float ms = 0;
+            PLANAR_HIP_CHECK(hipEventElapsedTime(&ms, p->ev_sets[c][i], p->ev_sets[c][i + 1]));
+            total_ms[i] += ms;
+        }
+    *calls = (int64_t)p->ev_used;
+    p->ev_used = 0;
     return PLANAR_OK;
 }
 
