@@ -285,9 +285,11 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         // LDS holds what every pop / merge chases: the heap, the list offsets / counts of the MERGED nodes (a block's list sits at
         // 4 * id, its count fits a byte) and the dead / cache-valid bits.  Set sizes, root ids and DisjointSet parents are only written
         // here (the node's own N travels with its moments), so they live in the frame workspace where peac_refine reads them.
-        S.nb_off = S.h_id + NB;                   // [NB] merged node NB + i
-        S.nb_cnt = S.nb_off + NB;                 // [NB] merged node NB + i
-        S.nouse = (unsigned*)(S.nb_cnt + NB);     // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
+        // list offsets / counts of the merged nodes: frame workspace too (12 KB of LDS less per frame: with 25 KB the four clustering wavefronts of a CU leave
+        // 60 KB to the kernels of the other streams); a merge reads them in the same round trip as the list heads
+        S.nb_off = (u16*)(F + L.off_h_nboff);     // [NB] merged node NB + i
+        S.nb_cnt = (u16*)(F + L.off_h_nbcnt);     // [NB] merged node NB + i
+        S.nouse = (unsigned*)(S.h_id + NB);       // bit per node: out of the graph (merged away = PlaneSeg::nouse, or disconnected)
         S.cval = S.nouse + (L.NB2 + 31) / 32;     // bit per node: its cached candidate record (g_cint / g_cdbl) is valid for its current live-neighbour set
         S.nb_cntb = (unsigned char*)(S.cval + (L.NB2 + 31) / 32);   // [NB] blocks
         S.dss = (u16*)(F + L.off_h_dss); S.rid = (u16*)(F + L.off_h_rid); S.dsp = (u16*)(F + L.off_h_dsp);
@@ -1247,7 +1249,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     L.off_h_nboff = carve((size_t)L.NB2 * 2); L.off_h_nbcnt = carve((size_t)L.NB2 * 2); L.off_h_pool = carve((size_t)L.pool_cap * 2);
     L.frame_bytes = off;
     // peac_ahc: heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
-    o->smem = L.NB * 4 + L.NB * 2 + L.NB * 4 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
+    o->smem = L.NB * 4 + L.NB * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
     const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD

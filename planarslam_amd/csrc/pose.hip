@@ -601,7 +601,10 @@ static int pose_launch(planar_ctx* ctx, const planar_pose_batch* bt, const plana
     if (smem > 64 * 1024)
         PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     static const int waves = [] { const char* e = getenv("PLANAR_POSE_WAVES"); return e ? atoi(e) : 2; }();   // measurement switch (tools/pose_waves.py); default = the faster one
-    if (waves == 1) {
+    if (waves == 4) {
+        if (smem > 64 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(pose::pose_opt_kernel<4>, dim3(bt->B), dim3(pose::NT), smem, ctx->stream, B, P);
+    } else if (waves == 1) {
         if (smem > 64 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(pose::pose_opt_kernel<1>, dim3(bt->B), dim3(pose::NT), smem, ctx->stream, B, P);
     } else
