@@ -128,6 +128,35 @@ void gaussian7_s2_u8(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, 
     }
 }
 
+// The other variant SURVEY A4 asks for, written out on its own: OpenCV 3.4.1's fixed-point path (imgproc/src/smooth.cpp, GaussianBlurFixedPoint<uint8_t,
+// ufixedpoint16>): taps as ufixedpoint16 (Q8.8, cvRound(k * 256)), horizontal pass u8 x Q8.8 -> Q8.8 with SATURATING 16-bit adds, vertical pass Q8.8 x Q8.8 ->
+// Q16.16 with saturating 32-bit adds, then (v + 2^15) >> 16 saturated to u8.  tests/test_oracle_orb.py shows it returns the same bytes as gaussian7_s2_u8 on
+// adversarial inputs (all-255 images put the horizontal sum exactly at 65535, the largest ufixedpoint16); orc_gaussian7_variant selects it.
+void gaussian7_s2_u8_fixedpoint341(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep) {
+    int taps[7];
+    gaussian_taps(taps);
+    auto sat16 = [](uint32_t a, uint32_t b) -> uint16_t { const uint32_t s = a + b; return (uint16_t)(s > 65535u ? 65535u : s); };
+    auto sat32 = [](uint32_t a, uint32_t b) -> uint32_t { const uint64_t s = (uint64_t)a + b; return (uint32_t)(s > 0xffffffffull ? 0xffffffffull : s); };
+    std::vector<uint16_t> hbuf((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src + (size_t)y * sstep;
+        for (int x = 0; x < w; x++) {
+            uint16_t acc = 0;
+            for (int k = 0; k < 7; k++) acc = sat16(acc, (uint32_t)((uint16_t)taps[k] * (uint32_t)S[reflect101(x + k - 3, w)]) & 0xffffffffu);
+            hbuf[(size_t)y * w + x] = acc;
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        uint8_t* D = dst + (size_t)y * dstep;
+        for (int x = 0; x < w; x++) {
+            uint32_t acc = 0;
+            for (int k = 0; k < 7; k++) acc = sat32(acc, (uint32_t)taps[k] * (uint32_t)hbuf[(size_t)reflect101(y + k - 3, h) * w + x]);
+            const uint32_t v = (uint32_t)(((uint64_t)acc + (1u << 15)) >> 16);
+            D[x] = (uint8_t)std::min<uint32_t>(v, 255u);
+        }
+    }
+}
+
 // --- A1: cv::FAST TYPE_9_16 (modules/features2d/src/fast.cpp, fast_score.cpp) ------------
 static void make_offsets(int pixel[25], int step) {
     static const int off[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},

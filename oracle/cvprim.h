@@ -38,6 +38,7 @@ void resize_linear_u8(const uint8_t* src, int sw, int sh, int sstep,
 // cv::GaussianBlur(src, dst, Size(7,7), 2, 2, BORDER_REFLECT_101) for CV_8UC1 (A4).
 // dst may alias src (the reference blurs a clone in place).
 void gaussian7_s2_u8(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep);
+void gaussian7_s2_u8_fixedpoint341(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep);   // the OpenCV 3.4.1 ufixedpoint16 variant, written out separately
 
 struct FastKp { int x, y, score; };
 // cv::FAST(img, kps, threshold, nonmaxSuppression) TYPE_9_16 on the ROI it is given (A1).

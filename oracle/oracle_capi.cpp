@@ -60,6 +60,9 @@ void orc_resize_linear_u8(const uint8_t* s, int sw, int sh, int sstep, uint8_t* 
     resize_linear_u8(s, sw, sh, sstep, d, dw, dh, dstep);
 }
 void orc_gaussian7_s2_u8(const uint8_t* s, int w, int h, int sstep, uint8_t* d, int dstep) { gaussian7_s2_u8(s, w, h, sstep, d, dstep); }
+void orc_gaussian7_variant(int variant, const uint8_t* s, int w, int h, int sstep, uint8_t* d, int dstep) {   // 0: <= 3.4.0 integer filter, 1: 3.4.1 ufixedpoint16
+    if (variant == 1) gaussian7_s2_u8_fixedpoint341(s, w, h, sstep, d, dstep); else gaussian7_s2_u8(s, w, h, sstep, d, dstep);
+}
 int orc_fast9_16(const uint8_t* img, int w, int h, int step, int th, int nms, int32_t* xys, int cap) {
     std::vector<FastKp> out;
     fast9_16(img, w, h, step, th, nms != 0, out);

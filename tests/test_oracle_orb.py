@@ -1,6 +1,7 @@
 """CPU tests: the ORB oracle against (a) committed outputs of the REAL reference ORBextractor
 (tests/golden/orb_*.npz, made by tools/gen_golden_orb.py from oracle/_ref/ref_orb) and (b) the
 live oracle/_ref/ref_orb binary when it is present."""
+import ctypes
 import glob
 import os
 
@@ -101,3 +102,22 @@ def test_resize_identity_and_half():
     blk = img.reshape(15, 2, 20, 2).astype(np.int32)
     want = (blk.sum(axis=(1, 3)) + 2) >> 2
     assert np.abs(half.astype(np.int32) - want).max() <= 1
+
+
+def test_both_gaussian_variants_of_survey_a4_return_the_same_bytes():
+    """OpenCV <= 3.4.0 (integer SymmSmall filters, one rounding at the end) and 3.4.1 (ufixedpoint16 per pass, saturating adds) are two code paths.
+    With the Q8 taps {18, 34, 49, 55, 49, 34, 18} (sum 257) the horizontal sums never exceed 65535 = 257 * 255, so neither saturation nor a per-pass rounding
+    occurs and both reduce to the same integers - checked here on the inputs where they could differ (saturated, alternating, random, tiny images)."""
+    L = ol.lib()
+    L.orc_gaussian7_variant.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    rng = np.random.default_rng(3)
+    imgs = [np.full((40, 56), 255, np.uint8), np.zeros((9, 9), np.uint8), (np.indices((33, 47)).sum(0) % 2 * 255).astype(np.uint8),
+            rng.integers(0, 256, (64, 80), dtype=np.uint8), rng.integers(250, 256, (31, 29), dtype=np.uint8), np.full((7, 7), 255, np.uint8)]
+    imgs[1][4, 4] = 255
+    for img in imgs:
+        h, w = img.shape
+        a, b = np.zeros_like(img), np.zeros_like(img)
+        L.orc_gaussian7_variant(0, img.ctypes.data, w, h, w, a.ctypes.data, w)
+        L.orc_gaussian7_variant(1, img.ctypes.data, w, h, w, b.ctypes.data, w)
+        np.testing.assert_array_equal(a, b)
+    assert a.max() == 255       # 257 / 256 gain: an all-255 image stays at 255 after saturation
