@@ -465,9 +465,10 @@ typedef struct planar_ba_result {
 } planar_ba_result;
 
 /* its1 = 5, its2 = 10 reproduce the reference.  `params` supplies fx, fy, cx, cy, bf and the Plane.* configuration.
- * comm may be NULL (single GPU).  Synchronous. */
+ * stop_flag (or NULL) is the reference's `bool* pbStopFlag` (one byte, polled while the solve runs; with several ranks the decision is taken on the
+ * all-reduced value).  comm may be NULL (single GPU).  Synchronous. */
 int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* problem, const planar_pose_params* params, int its1, int its2,
-                    planar_ba_result* result, volatile int* stop_flag, planar_comm* comm);
+                    planar_ba_result* result, const volatile unsigned char* stop_flag, planar_comm* comm);
 
 /* ---- DBoW2 vocabulary transform (replaces ORBVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) as Frame::ComputeBoW and
  *      KeyFrame::ComputeBoW call it with levelsup = 4; Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1124-1180, :1203-1250; include/ORBVocabulary.h:31) ----

@@ -585,3 +585,161 @@ inline int Optimizer::TranslationOptimization(Frame* pFrame) { return planar_det
 
 }  // namespace Planar_SLAM
 #endif   // PLANAR_ADAPTERS_WITH_TRACKING
+
+// ---- Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*)  (src/Optimizer.cc:1853-2680): the graph the reference assembles from the covisibility
+//      list and the observation maps becomes a planar_ba_problem, planar_local_ba solves it, the erase lists and the optimised values go back.
+//      Define PLANAR_ADAPTERS_WITH_LOCAL_BA after including KeyFrame.h, MapPoint.h, MapLine.h, MapPlane.h, Map.h, Optimizer.h, Config.h. --------------
+#ifdef PLANAR_ADAPTERS_WITH_LOCAL_BA
+#include <list>
+namespace Planar_SLAM {
+inline void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap) {
+    // local key frames, local landmarks, fixed cameras: the reference's traversal (:1855-1974), marks included
+    std::vector<KeyFrame*> kfs;
+    kfs.push_back(pKF);
+    pKF->mnBALocalForKF = pKF->mnId;
+    for (KeyFrame* k : pKF->GetVectorCovisibleKeyFrames()) { k->mnBALocalForKF = pKF->mnId; if (!k->isBad()) kfs.push_back(k); }
+    const size_t n_local = kfs.size();
+    std::vector<MapPoint*> pts; std::vector<MapLine*> lns; std::vector<MapPlane*> pls;
+    for (size_t i = 0; i < n_local; i++) {
+        for (MapPoint* p : kfs[i]->GetMapPointMatches()) if (p && !p->isBad() && p->mnBALocalForKF != pKF->mnId) { pts.push_back(p); p->mnBALocalForKF = pKF->mnId; }
+    }
+    for (size_t i = 0; i < n_local; i++) {
+        for (MapLine* p : kfs[i]->GetMapLineMatches()) if (p && !p->isBad() && p->mnBALocalForKF != pKF->mnId) { lns.push_back(p); p->mnBALocalForKF = pKF->mnId; }
+    }
+    for (size_t i = 0; i < n_local; i++) {
+        for (MapPlane* p : kfs[i]->GetMapPlaneMatches()) if (p && !p->isBad() && p->mnBALocalForKF != pKF->mnId) { pls.push_back(p); p->mnBALocalForKF = pKF->mnId; }
+    }
+    auto fix_observers = [&](const std::map<KeyFrame*, size_t>& obs) {
+        for (const auto& o : obs) {
+            KeyFrame* k = o.first;
+            if (k->mnBALocalForKF != pKF->mnId && k->mnBAFixedForKF != pKF->mnId) { k->mnBAFixedForKF = pKF->mnId; if (!k->isBad()) kfs.push_back(k); }
+        }
+    };
+    for (MapPoint* p : pts) fix_observers(p->GetObservations());
+    for (MapLine* p : lns) fix_observers(p->GetObservations());
+    for (MapPlane* p : pls) fix_observers(p->GetObservations());
+    const int K = (int)kfs.size();
+    std::map<KeyFrame*, int> kf_index;
+    std::vector<float> kf_Tcw((size_t)K * 16);
+    std::vector<uint8_t> kf_fixed(K);
+    unsigned long maxKFid = 0;
+    for (int k = 0; k < K; k++) {
+        kf_index[kfs[k]] = k;
+        cv::Mat T = kfs[k]->GetPose();
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) kf_Tcw[(size_t)k * 16 + 4 * r + c] = T.at<float>(r, c);
+        kf_fixed[k] = (size_t)k >= n_local || kfs[k]->mnId == 0;
+        if (kfs[k]->mnId > maxKFid) maxKFid = kfs[k]->mnId;
+    }
+    // landmarks and edges
+    std::vector<uint8_t> lm_type, e_type;
+    std::vector<double> lm_init, e_meas;
+    std::vector<int32_t> e_kf, e_lm;
+    std::vector<float> e_is2;
+    struct Assoc { KeyFrame* kf; void* lm; };                 // what an erased edge removes
+    std::vector<Assoc> assoc;
+    auto add_lm = [&](int type, double a, double b, double c, double d) { lm_type.push_back((uint8_t)type); lm_init.insert(lm_init.end(), {a, b, c, d}); return (int32_t)lm_type.size() - 1; };
+    auto add_edge = [&](int kf, int lm, int type, double m0, double m1, double m2, double m3, float is2, KeyFrame* okf, void* olm) {
+        e_kf.push_back(kf); e_lm.push_back(lm); e_type.push_back((uint8_t)type); e_meas.insert(e_meas.end(), {m0, m1, m2, m3}); e_is2.push_back(is2); assoc.push_back(Assoc{okf, olm});
+    };
+    std::vector<int32_t> pt_lm(pts.size()), ln_lm(lns.size()), pl_lm(pls.size());
+    for (size_t i = 0; i < pts.size(); i++) {
+        cv::Mat X = pts[i]->GetWorldPos();
+        pt_lm[i] = add_lm(0, X.at<float>(0), X.at<float>(1), X.at<float>(2), 0);
+        const std::map<KeyFrame*, size_t> obs = pts[i]->GetObservations();
+        for (const auto& o : obs) {
+            KeyFrame* k = o.first;
+            if (k->isBad()) continue;
+            const cv::KeyPoint& kp = k->mvKeysUn[o.second];
+            const float ur = k->mvuRight[o.second], is2 = k->mvInvLevelSigma2[kp.octave];
+            if (ur < 0) add_edge(kf_index.at(k), pt_lm[i], PLANAR_BA_MONO, kp.pt.x, kp.pt.y, 0, 0, is2, k, pts[i]);
+            else add_edge(kf_index.at(k), pt_lm[i], PLANAR_BA_STEREO, kp.pt.x, kp.pt.y, ur, 0, is2, k, pts[i]);
+        }
+    }
+    for (size_t i = 0; i < lns.size(); i++) {
+        const auto W = lns[i]->GetWorldPos();                  // Vector6d: start xyz, end xyz
+        ln_lm[i] = add_lm(0, W[0], W[1], W[2], 0);
+        add_lm(0, W[3], W[4], W[5], 0);
+        const std::map<KeyFrame*, size_t> obs = lns[i]->GetObservations();
+        for (const auto& o : obs) {
+            if (o.first->isBad()) continue;
+            // both end-point edges hang on the CURRENT key frame's vertex and use its line function at the observer's slot (:2170-2194)
+            const auto f = pKF->mvKeyLineFunctions[o.second];
+            add_edge(0, ln_lm[i], PLANAR_BA_LINE, f[0], f[1], f[2], 0, 1.f, o.first, lns[i]);
+            add_edge(0, ln_lm[i] + 1, PLANAR_BA_LINE, f[0], f[1], f[2], 0, 1.f, o.first, lns[i]);
+        }
+    }
+    for (size_t i = 0; i < pls.size(); i++) {
+        cv::Mat C = pls[i]->GetWorldPos();
+        pl_lm[i] = add_lm(1, C.at<float>(0), C.at<float>(1), C.at<float>(2), C.at<float>(3));
+        auto plane_edges = [&](const std::map<KeyFrame*, size_t>& obs, int type) {
+            for (const auto& o : obs) {
+                KeyFrame* k = o.first;
+                if (k->isBad() || k->mnId > maxKFid) continue;
+                auto it = kf_index.find(k);
+                if (it == kf_index.end()) continue;            // (the reference would dereference a null vertex here)
+                const cv::Mat& m = k->mvPlaneCoefficients[o.second];
+                add_edge(it->second, pl_lm[i], type, m.at<float>(0), m.at<float>(1), m.at<float>(2), m.at<float>(3), 1.f, k, pls[i]);
+            }
+        };
+        plane_edges(pls[i]->GetObservations(), PLANAR_BA_PLANE);
+        plane_edges(pls[i]->GetVerObservations(), PLANAR_BA_VERTICAL);
+        plane_edges(pls[i]->GetParObservations(), PLANAR_BA_PARALLEL);
+    }
+    if (pbStopFlag && *pbStopFlag) return;
+    const int NL = (int)lm_type.size(), NE = (int)e_type.size();
+    std::vector<float> out_T((size_t)K * 16);
+    std::vector<double> out_lm((size_t)std::max(NL, 1) * 4);
+    std::vector<uint8_t> out_e(std::max(NE, 1));
+    planar_ba_problem P{K, kf_Tcw.data(), kf_fixed.data(), NL, lm_type.data(), lm_init.data(), NE, e_kf.data(), e_lm.data(), e_type.data(), e_meas.data(), e_is2.data()};
+    planar_ba_result R{out_T.data(), out_lm.data(), out_e.data(), 0, 0};
+    planar_pose_params prm;
+    prm.fx = pKF->fx; prm.fy = pKF->fy; prm.cx = pKF->cx; prm.cy = pKF->cy; prm.bf = pKF->mbf;
+    prm.angle_info = Config::Get<double>("Plane.AngleInfo"); prm.distance_info = Config::Get<double>("Plane.DistanceInfo");
+    prm.parallel_info = Config::Get<double>("Plane.ParallelInfo"); prm.vertical_info = Config::Get<double>("Plane.VerticalInfo");
+    prm.plane_chi = Config::Get<double>("Plane.Chi"); prm.vp_chi = Config::Get<double>("Plane.VPChi");
+    static_assert(sizeof(bool) == 1, "bool* pbStopFlag is passed as a byte flag");
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::Runtime::get().lane(planar_adapter::TRACKING);
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_local_ba(L.ctx, &P, &prm, 5, 10, &R, reinterpret_cast<const volatile unsigned char*>(pbStopFlag), nullptr));
+    }
+    // erase lists (:2471-2620) and write-back (:2622-2680) under the map mutex
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+    for (int e = 0; e < NE; e++) {
+        if (!out_e[e]) continue;
+        KeyFrame* k = assoc[e].kf;
+        switch (e_type[e]) {
+            case PLANAR_BA_MONO: case PLANAR_BA_STEREO: { MapPoint* p = (MapPoint*)assoc[e].lm; if (p->isBad()) break; k->EraseMapPointMatch(p); p->EraseObservation(k); break; }
+            case PLANAR_BA_LINE: {
+                if (e > 0 && e_type[e - 1] == PLANAR_BA_LINE && assoc[e - 1].lm == assoc[e].lm && assoc[e - 1].kf == k && e_lm[e - 1] + 1 == e_lm[e]) break;   // the end-point twin
+                MapLine* p = (MapLine*)assoc[e].lm; if (p->isBad()) break; k->EraseMapLineMatch(p); p->EraseObservation(k); break;
+            }
+            case PLANAR_BA_PLANE: { MapPlane* p = (MapPlane*)assoc[e].lm; if (p->isBad()) break; k->EraseMapPlaneMatch(p); p->EraseObservation(k); break; }
+            case PLANAR_BA_VERTICAL: { MapPlane* p = (MapPlane*)assoc[e].lm; if (p->isBad()) break; k->EraseMapVerticalPlaneMatch(p); p->EraseVerObservation(k); break; }
+            default: { MapPlane* p = (MapPlane*)assoc[e].lm; if (p->isBad()) break; k->EraseMapParallelPlaneMatch(p); p->EraseParObservation(k); break; }
+        }
+    }
+    for (size_t k = 0; k < n_local; k++) {
+        cv::Mat T(4, 4, CV_32F);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T.at<float>(r, c) = out_T[k * 16 + 4 * r + c];
+        kfs[k]->SetPose(T);
+    }
+    for (size_t i = 0; i < pts.size(); i++) {
+        cv::Mat X(3, 1, CV_32F);
+        for (int j = 0; j < 3; j++) X.at<float>(j) = (float)out_lm[(size_t)pt_lm[i] * 4 + j];
+        pts[i]->SetWorldPos(X); pts[i]->UpdateNormalAndDepth();
+    }
+    for (size_t i = 0; i < lns.size(); i++) {
+        auto W = lns[i]->GetWorldPos();
+        for (int j = 0; j < 3; j++) { W[j] = (double)(float)out_lm[(size_t)ln_lm[i] * 4 + j]; W[3 + j] = (double)(float)out_lm[(size_t)(ln_lm[i] + 1) * 4 + j]; }   // through Converter::toCvMat (float)
+        lns[i]->SetWorldPos(W); lns[i]->UpdateAverageDir();
+    }
+    for (size_t i = 0; i < pls.size(); i++) {
+        cv::Mat C(4, 1, CV_32F);
+        for (int j = 0; j < 4; j++) C.at<float>(j) = (float)out_lm[(size_t)pl_lm[i] * 4 + j];
+        pls[i]->SetWorldPos(C); pls[i]->UpdateCoefficientsAndPoints();
+    }
+}
+}  // namespace Planar_SLAM
+#endif   // PLANAR_ADAPTERS_WITH_LOCAL_BA
+

@@ -31,36 +31,9 @@ using namespace Planar_SLAM;
 float Frame::fx, Frame::fy, Frame::cx, Frame::cy;
 std::mutex MapPoint::mGlobalMutex, MapLine::mGlobalMutex, MapPlane::mGlobalMutex;
 
+#include "ref_opt_harness.hpp"
+
 namespace {
-struct Reader {
-    std::vector<unsigned char> buf;
-    size_t off = 0;
-    explicit Reader(const char* path) {
-        FILE* f = fopen(path, "rb");
-        if (!f) { perror(path); exit(2); }
-        fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
-        buf.resize((size_t)n);
-        if (fread(buf.data(), 1, (size_t)n, f) != (size_t)n) exit(2);
-        fclose(f);
-    }
-    template <class T> T get() { T v; memcpy(&v, buf.data() + off, sizeof(T)); off += sizeof(T); return v; }
-    template <class T> const T* arr(size_t n) { const T* p = (const T*)(buf.data() + off); off += n * sizeof(T); if (off > buf.size()) { fprintf(stderr, "short input\n"); exit(2); } return p; }
-};
-struct Writer {
-    FILE* f;
-    explicit Writer(const char* path) { f = fopen(path, "wb"); if (!f) { perror(path); exit(2); } }
-    ~Writer() { fclose(f); }
-    template <class T> void put(const T& v) { fwrite(&v, sizeof(T), 1, f); }
-    template <class T> void arr(const T* p, size_t n) { fwrite(p, sizeof(T), n, f); }
-};
-
-cv::Mat mat_f32(int r, int c, const float* p) { cv::Mat m(r, c, CV_32F); memcpy(m.data, p, sizeof(float) * r * c); return m; }
-
-void set_config(const double* cfg) {
-    auto& t = Config::table();
-    t["Plane.AngleInfo"] = cfg[0]; t["Plane.DistanceInfo"] = cfg[1]; t["Plane.ParallelInfo"] = cfg[2];
-    t["Plane.VerticalInfo"] = cfg[3]; t["Plane.Chi"] = cfg[4]; t["Plane.VPChi"] = cfg[5];
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 int run_pose(const char* in, const char* out) {
@@ -129,133 +102,6 @@ int run_pose(const char* in, const char* out) {
         for (int i = 0; i < M; i++) { fl[i * 3] = F.mvbPlaneOutlier[i]; fl[i * 3 + 1] = F.mvbParPlaneOutlier[i]; fl[i * 3 + 2] = F.mvbVerPlaneOutlier[i]; }
         w.arr(fl.data(), fl.size());
     }
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Local BA.  Input = synth.ba_problem arrays.  Edge types: 0 mono, 1 stereo, 2 line end-point, 3 plane, 4 vertical, 5 parallel.
-// Landmarks of type 0 that carry line edges come in (start, end) pairs; cur_kf is the keyframe LocalBundleAdjustment is
-// called for.  The reference attaches every line edge to cur_kf's vertex and reads cur_kf's line function at the OBSERVER's
-// slot index (src/Optimizer.cc:2170-2176, 2192-2194), so a line edge has e_kf == cur_kf and e_obs_kf = the keyframe whose
-// observation it came from; slot j of cur_kf->mvKeyLineFunctions holds the j-th line observation's function.
-int run_ba(const char* in, const char* out) {
-    Reader r(in);
-    const int K = r.get<int>(), NLM = r.get<int>(), NE = r.get<int>(), cur_kf = r.get<int>();
-    const float* cam = r.arr<float>(5);
-    const double* cfg = r.arr<double>(6);
-    set_config(cfg);
-    const float* kf_Tcw = r.arr<float>((size_t)K * 16);
-    const unsigned char* kf_fixed = r.arr<unsigned char>(K);
-    const unsigned char* lm_type = r.arr<unsigned char>(NLM);
-    const double* lm_init = r.arr<double>((size_t)NLM * 4);
-    const int* e_kf = r.arr<int>(NE); const int* e_obs_kf = r.arr<int>(NE); const int* e_lm = r.arr<int>(NE);
-    const unsigned char* e_type = r.arr<unsigned char>(NE);
-    const double* e_meas = r.arr<double>((size_t)NE * 4);
-    const float* e_is2 = r.arr<float>(NE);
-
-    // keyframes in one array => std::map<KeyFrame*, size_t> iterates in keyframe order
-    std::vector<KeyFrame> kfs(K);
-    // Which keyframes are optimised is decided by the reference from the covisibility list (local) versus "sees a local
-    // landmark" (fixed); mnId == 0 is fixed as well.  kf_fixed[k] => not in the covisibility list of cur_kf.
-    for (int k = 0; k < K; k++) {
-        KeyFrame& kf = kfs[k];
-        kf.mnId = (unsigned long)k;
-        kf.fx = cam[0]; kf.fy = cam[1]; kf.cx = cam[2]; kf.cy = cam[3]; kf.mbf = cam[4];
-        kf.pose = mat_f32(4, 4, kf_Tcw + (size_t)k * 16);
-    }
-    for (int k = 0; k < K; k++) if (k != cur_kf && !kf_fixed[k]) kfs[cur_kf].covisible.push_back(&kfs[k]);
-    // landmark objects
-    std::vector<int> lm_obj(NLM, -1);   // index into mps / mls / mpls
-    std::vector<char> is_line_pt(NLM, 0);
-    for (int e = 0; e < NE; e++) if (e_type[e] == 2) is_line_pt[e_lm[e]] = 1;
-    int n_pt = 0, n_ln = 0, n_pl = 0;
-    for (int l = 0; l < NLM; l++) {
-        if (lm_type[l] == 1) lm_obj[l] = n_pl++;
-        else if (is_line_pt[l]) { if (l > 0 && is_line_pt[l - 1] && lm_obj[l - 1] >= 0 && (l < 2 || !(is_line_pt[l - 2] && lm_obj[l - 2] == lm_obj[l - 1]))) lm_obj[l] = lm_obj[l - 1]; else lm_obj[l] = n_ln++; }
-        else lm_obj[l] = n_pt++;
-    }
-    std::vector<MapPoint> mps(n_pt);
-    std::vector<MapLine> mls(n_ln);
-    std::vector<MapPlane> mpls(n_pl);
-    std::vector<int> line_first(n_ln, -1);
-    {
-        int ip = 0, ipl = 0;
-        for (int l = 0; l < NLM; l++) {
-            if (lm_type[l] == 1) {
-                MapPlane& p = mpls[lm_obj[l]]; p.mnId = (unsigned long)ipl++;
-                float c[4] = {(float)lm_init[l * 4], (float)lm_init[l * 4 + 1], (float)lm_init[l * 4 + 2], (float)lm_init[l * 4 + 3]};
-                p.mWorldPos = mat_f32(4, 1, c);
-            } else if (is_line_pt[l]) {
-                MapLine& m = mls[lm_obj[l]];
-                if (line_first[lm_obj[l]] < 0) { line_first[lm_obj[l]] = l; m.mnId = (unsigned long)lm_obj[l]; for (int j = 0; j < 3; j++) m.mWorldPos[j] = lm_init[l * 4 + j]; }
-                else for (int j = 0; j < 3; j++) m.mWorldPos[3 + j] = lm_init[l * 4 + j];
-            } else {
-                MapPoint& p = mps[lm_obj[l]]; p.mnId = (unsigned long)ip++;
-                float c[3] = {(float)lm_init[l * 4], (float)lm_init[l * 4 + 1], (float)lm_init[l * 4 + 2]};
-                p.mWorldPos = mat_f32(3, 1, c);
-            }
-        }
-    }
-    // observations: one feature slot per edge in its keyframe
-    for (int e = 0; e < NE; e++) {
-        KeyFrame& kf = kfs[e_obs_kf[e]];
-        const int l = e_lm[e];
-        if (e_type[e] == 2 ? e_kf[e] != cur_kf : e_kf[e] != e_obs_kf[e]) { fprintf(stderr, "edge %d: not expressible in the reference's LocalBundleAdjustment\n", e); return 3; }
-        switch (e_type[e]) {
-            case 0: case 1: {
-                cv::KeyPoint kp; kp.pt.x = (float)e_meas[e * 4]; kp.pt.y = (float)e_meas[e * 4 + 1]; kp.octave = (int)kf.mvKeysUn.size();
-                kf.mvKeysUn.push_back(kp);
-                kf.mvuRight.push_back(e_type[e] == 1 ? (float)e_meas[e * 4 + 2] : -1.f);
-                kf.mvInvLevelSigma2.push_back(e_is2[e]);
-                kf.mps.push_back(&mps[lm_obj[l]]);
-                mps[lm_obj[l]].mObservations[&kf] = kf.mvKeysUn.size() - 1;
-                break;
-            }
-            case 2: {
-                if (l != line_first[lm_obj[l]]) break;   // the end-point edge shares the observation of the start-point edge
-                KeyFrame& cur = kfs[cur_kf];
-                cur.mvKeyLineFunctions.push_back(Eigen::Vector3d(e_meas[e * 4], e_meas[e * 4 + 1], e_meas[e * 4 + 2]));
-                kf.mls.push_back(&mls[lm_obj[l]]);
-                mls[lm_obj[l]].mObservations[&kf] = cur.mvKeyLineFunctions.size() - 1;
-                break;
-            }
-            default: {
-                float c[4] = {(float)e_meas[e * 4], (float)e_meas[e * 4 + 1], (float)e_meas[e * 4 + 2], (float)e_meas[e * 4 + 3]};
-                kf.mvPlaneCoefficients.push_back(mat_f32(4, 1, c));
-                MapPlane& p = mpls[lm_obj[l]];
-                const size_t idx = kf.mvPlaneCoefficients.size() - 1;
-                if (e_type[e] == 3) { p.mObservations[&kf] = idx; kf.mpls.push_back(&p); }
-                else if (e_type[e] == 4) p.mVerObservations[&kf] = idx;
-                else p.mParObservations[&kf] = idx;
-                break;
-            }
-        }
-    }
-    Map map;
-    bool stop = false;
-    Optimizer::LocalBundleAdjustment(&kfs[cur_kf], &stop, &map);
-    Writer w(out);
-    for (int k = 0; k < K; k++) w.arr((const float*)kfs[k].pose.data, 16);
-    for (int l = 0; l < NLM; l++) {
-        double v[4] = {0, 0, 0, 0};
-        if (lm_type[l] == 1) { cv::Mat c = mpls[lm_obj[l]].mWorldPos; for (int j = 0; j < 4; j++) v[j] = c.at<float>(j); }
-        else if (is_line_pt[l]) { const int o = (l == line_first[lm_obj[l]]) ? 0 : 3; for (int j = 0; j < 3; j++) v[j] = mls[lm_obj[l]].mWorldPos[o + j]; }
-        else { cv::Mat c = mps[lm_obj[l]].mWorldPos; for (int j = 0; j < 3; j++) v[j] = c.at<float>(j); }
-        w.arr(v, 4);
-    }
-    // erased associations per edge (the reference's outlier verdict after the second round)
-    std::vector<unsigned char> er(NE, 0);
-    for (int e = 0; e < NE; e++) {
-        KeyFrame* kf = &kfs[e_obs_kf[e]];
-        const int l = e_lm[e];
-        auto has = [&](const std::vector<KeyFrame*>& v) { for (KeyFrame* k : v) if (k == kf) return true; return false; };
-        if (e_type[e] <= 1) er[e] = has(mps[lm_obj[l]].erased);
-        else if (e_type[e] == 2) er[e] = has(mls[lm_obj[l]].erased);
-        else if (e_type[e] == 3) er[e] = has(mpls[lm_obj[l]].erased);
-        else if (e_type[e] == 4) er[e] = has(mpls[lm_obj[l]].erasedVer);
-        else er[e] = has(mpls[lm_obj[l]].erasedPar);
-    }
-    w.arr(er.data(), er.size());
     return 0;
 }
 

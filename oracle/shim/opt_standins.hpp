@@ -27,7 +27,9 @@
 #include <Eigen/Geometry>
 #include "opencv2/line_descriptor/descriptor.hpp"
 #include "pcl/point_types.h"
+#ifndef STANDINS_NO_REFERENCE   // -DSTANDINS_NO_REFERENCE: the GPU box has no /root/reference; tests/adapter_shim builds the BA harness against include/planar_adapters.hpp there
 #include "Thirdparty/g2o/g2o/types/types_seven_dof_expmap.h"
+#endif
 
 namespace Planar_SLAM {
 using namespace std;
@@ -50,10 +52,12 @@ public:
     template <typename T> static T Get(const std::string& key) { return T(table().at(key)); }
 };
 
+#ifndef STANDINS_NO_REFERENCE
 class LoopClosing {
 public:
     typedef map<KeyFrame*, g2o::Sim3, std::less<KeyFrame*>, Eigen::aligned_allocator<std::pair<KeyFrame* const, g2o::Sim3>>> KeyFrameAndPose;
 };
+#endif
 
 class MapPoint {
 public:

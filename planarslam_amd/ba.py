@@ -96,7 +96,7 @@ class HostedCommunicator:
 
 def local_bundle_adjustment(prob: dict, params: dict, its1: int = 5, its2: int = 10, ctx: Context | None = None, comm=None, stop_flag=None):
     """Runs planar_local_ba on a synth.ba_problem()-style dict (or a shard of it).  Returns kf_Tcw, lm, e_outlier, lm_iters.
-    comm: Communicator (RCCL) or HostedCommunicator; stop_flag: a ctypes.c_int the caller may set (pbStopFlag of the reference)."""
+    comm: Communicator (RCCL) or HostedCommunicator; stop_flag: a ctypes.c_ubyte the caller may set (bool* pbStopFlag of the reference)."""
     L = lib()
     ctx = ctx or Context(0)
     a = {k: np.ascontiguousarray(prob[k]) for k in _KEYS}

@@ -605,7 +605,7 @@ void planar_comm_destroy(planar_comm* c) {
 }
 
 int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_pose_params* prm, int its1, int its2, planar_ba_result* R,
-                    volatile int* stop_flag, planar_comm* comm) {
+                    const volatile unsigned char* stop_flag, planar_comm* comm) {
     using namespace planar::ba;
     PLANAR_REQUIRE(ctx && P && prm && R, PLANAR_EINVAL, "null argument");
     PLANAR_REQUIRE(P->n_kf >= 1 && P->n_lm >= 0 && P->n_edges >= 0, PLANAR_EINVAL, "bad sizes");

@@ -8,6 +8,8 @@ the same inputs the real reference processed.
                     (outputs of the real reference on the same seeds): every index identical.
   adapter_pose    = Optimizer::PoseOptimization / TranslationOptimization(Frame*) adapters on stand-in Frames; expected tests/golden/opt_ref.npz
                     (real src/Optimizer.cc + g2o): pose within 1e-5, flags and return values identical.
+  adapter_ba      = Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*) adapter (graph collection from covisibility / observation maps -> planar_local_ba ->
+                    erase lists + write-back); expected tests/golden/opt_ref.npz (the real LocalBundleAdjustment): poses 1e-5, erase flags identical.
   adapter_extract = ORBextractor / LineSegment / PlaneDetection used as src/Frame.cc:90-97 does (three threads per frame, by-value copies,
                     LineSegment through a null pointer); expected: the oracle's output on the same images.
 """
@@ -28,12 +30,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "tests", "adapter_shim")
 
 
-def _build(tmp, name, sources, standins=True):
+def _build(tmp, name, sources, standins="match"):
     lib = os.path.join(ROOT, "planarslam_amd", "libplanar_hip.so")
     exe = os.path.join(tmp, name)
-    cmd = ["g++", "-O1", "-std=c++14", "-w", "-pthread", "-DCVSHIM_ALGEBRA", "-I" + SHIM, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle", "shim")]
+    cmd = ["g++", "-O1", "-std=c++14", "-w", "-pthread", "-DCVSHIM_ALGEBRA", "-I" + SHIM, "-I" + os.path.join(ROOT, "include")]
+    if standins == "opt":        # the optimiser stand-ins use the mini-Eigen (must precede oracle/shim, whose <Eigen/Core> is the 3-type stub)
+        cmd += ["-I" + os.path.join(ROOT, "oracle"), "-I" + os.path.join(ROOT, "oracle", "shim", "minieigen")]
+    cmd += ["-I" + os.path.join(ROOT, "oracle", "shim")]
     if standins:
-        cmd += ["-DSTANDINS_NO_REFERENCE", "-include", os.path.join(ROOT, "oracle", "shim", "match_standins.hpp")]
+        cmd += ["-DSTANDINS_NO_REFERENCE", "-include", os.path.join(ROOT, "oracle", "shim", standins + "_standins.hpp")]
     cmd += ["-o", exe] + sources + [os.path.join(ROOT, "oracle", "cvprim.cpp"), lib, "-Wl,-rpath," + os.path.dirname(lib), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return exe
@@ -44,13 +49,14 @@ def bins(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("adapters"))
     return dict(match=_build(d, "adapter_match", [os.path.join(ROOT, "oracle", "ref_match_main.cpp")]),
                 pose=_build(d, "adapter_pose", [os.path.join(SHIM, "adapter_pose_main.cpp")]),
-                extract=_build(d, "adapter_extract", [os.path.join(SHIM, "adapter_extract_main.cpp")], standins=False), dir=d)
+                extract=_build(d, "adapter_extract", [os.path.join(SHIM, "adapter_extract_main.cpp")], standins=None),
+                ba=_build(d, "adapter_ba", [os.path.join(SHIM, "adapter_ba_main.cpp")], standins="opt"), dir=d)
 
 
 @pytest.fixture()
 def as_reference(bins):
     """Route oracle_lib's ref_match / ref_opt runners (file formats shared with the real-reference binaries) to the adapter executables."""
-    O.BINARY_OVERRIDE.update(ref_match=bins["match"], ref_opt=bins["pose"])
+    O.BINARY_OVERRIDE.update(ref_match=bins["match"], ref_opt=bins["pose"])      # ref_opt: `pose` mode here, the `ba` test swaps in its own binary
     yield
     O.BINARY_OVERRIDE.clear()
 
@@ -114,6 +120,22 @@ def test_pose_adapters_equal_real_reference_fixtures(as_reference, golden_dir, n
         assert np.array_equal(got["n_inliers"], want["n_inliers"])
         for k in ("pt_outlier", "ln_outlier", "pl_outlier"):
             assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("name", list(cases.BA_CASES))
+def test_local_ba_adapter_equals_real_reference_fixtures(bins, golden_dir, name):
+    """Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*) as defined by the adapter header, on KeyFrame / MapPoint / MapLine / MapPlane stand-ins built by the same
+    harness that drives the real src/Optimizer.cc (oracle/ref_opt_harness.hpp): poses, landmarks and erased observations vs tests/golden/opt_ref.npz."""
+    from test_oracle_opt_ref import check_ba, golden_ba
+    golden = np.load(os.path.join(golden_dir, "opt_ref.npz"))
+    build, cur = cases.BA_CASES[name]
+    pr = build()
+    O.BINARY_OVERRIDE["ref_opt"] = bins["ba"]
+    try:
+        got = O.run_ref_local_ba(pr, TUM3, cur)
+    finally:
+        O.BINARY_OVERRIDE.clear()
+    check_ba(golden_ba(golden, name, pr), got, pr)
 
 
 def test_extractor_adapters_three_threads_per_frame(bins):

@@ -43,7 +43,7 @@ WORKER = textwrap.dedent('''
     stop = None
     if stop_rank >= 0:                       # only ONE rank's caller raises the flag: the others must still leave the loop with it
         import ctypes
-        stop = ctypes.c_int(1 if rank == stop_rank else 0)
+        stop = ctypes.c_ubyte(1 if rank == stop_rank else 0)
     got = local_bundle_adjustment(sh, TUM3, ctx=ctx, comm=comm, stop_flag=stop)
     full = local_bundle_adjustment(prob, TUM3, ctx=ctx) if stop_rank < 0 else None
     out = dict(rank=rank, kf=got["kf_Tcw"].astype(float).tolist(), lm_iters=int(got["lm_iters"]), stopped=int(got["stopped"]), nlm=len(sh["lm_ids"]))
