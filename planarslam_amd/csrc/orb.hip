@@ -596,39 +596,66 @@ struct TileDev { short level, tx, ty, pad; };
 
 __global__ __launch_bounds__(256) void orb_blur(const PlanDev* __restrict__ plan, const TileDev* __restrict__ tiles,
                                                 const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    __shared__ uint8_t s_px[22][72];
-    __shared__ uint16_t s_h[22][64];
+    // 22 input rows x 18 words (columns x0 - 4 .. x0 + 67) as 32-bit words; horizontal sums as u16 with a row stride of 68 (8-byte aligned, banks spread)
+    __shared__ uint32_t s_pw[22][19];
+    __shared__ __attribute__((aligned(8))) uint16_t s_h[22][68];
     const TileDev T = tiles[blockIdx.x];
     const LevelDev& L = plan->lv[T.level];
     const int tid = threadIdx.x;
     const int x0 = T.tx * 64, y0 = T.ty * 16;
     const uint8_t* img = pyr + (int64_t)blockIdx.y * plan->pyr_stride + L.off;
-    for (int i = tid; i < 22 * 70; i += 256) {
-        const int r = i / 70, c = i - r * 70;
-        int y = y0 + r - 3, x = x0 + c - 3;
+    for (int i = tid; i < 22 * 18; i += 256) {
+        const int r = i / 18, wq = i - r * 18;
+        int y = y0 + r - 3;
         // reflect-101; tiles may overhang the right/bottom edge, where the values are unused
         y = y < 0 ? -y : y; y = y >= L.h ? 2 * L.h - 2 - y : y; y = max(0, min(y, L.h - 1));
-        x = x < 0 ? -x : x; x = x >= L.w ? 2 * L.w - 2 - x : x; x = max(0, min(x, L.w - 1));
-        s_px[r][c] = img[(int64_t)y * L.pitch + x];
+        const uint8_t* row = img + (int64_t)y * L.pitch;
+        const int xs = x0 - 4 + 4 * wq;
+        uint32_t w;
+        if (xs >= 0 && xs + 3 < L.w) w = *(const uint32_t*)(row + xs);          // rows and xs are 4-byte aligned
+        else {
+            w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int x = xs + k;
+                x = x < 0 ? -x : x; x = x >= L.w ? 2 * L.w - 2 - x : x; x = max(0, min(x, L.w - 1));
+                w |= (uint32_t)row[x] << (8 * k);
+            }
+        }
+        s_pw[r][wq] = w;
     }
     __syncthreads();
-    for (int i = tid; i < 22 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &s_px[r][c];
-        const uint32_t s = 18u * (p[0] + p[6]) + 34u * (p[1] + p[5]) + 49u * (p[2] + p[4]) + 55u * p[3];
-        s_h[r][c] = (uint16_t)min(s, 65535u);
+    for (int i = tid; i < 22 * 16; i += 256) {
+        const int r = i >> 4, q = i & 15;
+        const uint32_t w0 = s_pw[r][q], w1 = s_pw[r][q + 1], w2 = s_pw[r][q + 2];
+        // bytes 1 .. 10 of the 12 = input columns 4q - 3 .. 4q + 6 of the tile
+        uint32_t b[10];
+        b[0] = (w0 >> 8) & 255u; b[1] = (w0 >> 16) & 255u; b[2] = w0 >> 24;
+        b[3] = w1 & 255u; b[4] = (w1 >> 8) & 255u; b[5] = (w1 >> 16) & 255u; b[6] = w1 >> 24;
+        b[7] = w2 & 255u; b[8] = (w2 >> 8) & 255u; b[9] = (w2 >> 16) & 255u;
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t v = 18u * (b[j] + b[j + 6]) + 34u * (b[j + 1] + b[j + 5]) + 49u * (b[j + 2] + b[j + 4]) + 55u * b[j + 3];
+            o[j] = min(v, 65535u);
+        }
+        *(uint2*)&s_h[r][4 * q] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
     __syncthreads();
     {
         const int c4 = (tid & 15) * 4, r = tid >> 4;    // 16 rows x 16 quads
+        uint32_t acc[4] = {0, 0, 0, 0};
+        const uint32_t taps[7] = {18u, 34u, 49u, 55u, 49u, 34u, 18u};
+        // (the sum below adds the seven products in the order 18 (r, r+6), 34 (r+1, r+5), 49 (r+2, r+4), 55 (r+3): integer arithmetic, any order gives the same value)
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const uint2 v = *(const uint2*)&s_h[r + k][c4];
+            acc[0] += taps[k] * (v.x & 0xffffu); acc[1] += taps[k] * (v.x >> 16);
+            acc[2] += taps[k] * (v.y & 0xffffu); acc[3] += taps[k] * (v.y >> 16);
+        }
         uint32_t packed = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int c = c4 + i;
-            const uint32_t s = 18u * (s_h[r][c] + s_h[r + 6][c]) + 34u * (s_h[r + 1][c] + s_h[r + 5][c]) +
-                               49u * (s_h[r + 2][c] + s_h[r + 4][c]) + 55u * s_h[r + 3][c];
-            packed |= min((s + 32768u) >> 16, 255u) << (8 * i);
-        }
+        for (int i = 0; i < 4; i++) packed |= min((acc[i] + 32768u) >> 16, 255u) << (8 * i);
         const int y = y0 + r, x = x0 + c4;
         if (y < L.h && x < L.pitch)
             *(uint32_t*)(blur + (int64_t)blockIdx.y * plan->pyr_stride + L.off + (int64_t)y * L.pitch + x) = packed;
