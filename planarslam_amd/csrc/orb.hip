@@ -150,6 +150,12 @@ __device__ __forceinline__ bool has9(uint32_t m16) {
 
 __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int stride, int min_th) {
     const int v = c[0];
+    {   // a run of 9 of the 16 circle pixels contains one pixel of every opposite pair: two pairs decide most non-corners with four reads (cv::FAST does the same)
+        const int a0 = v - c[3 * stride], a8 = v - c[-3 * stride], a4 = v - c[3], a12 = v - c[-3];
+        const bool dark = (a0 > min_th || a8 > min_th) && (a4 > min_th || a12 > min_th);
+        const bool bright = (a0 < -min_th || a8 < -min_th) && (a4 < -min_th || a12 < -min_th);
+        if (!dark && !bright) return 0;
+    }
     int d[16];
     d[0] = v - c[3 * stride];       d[1] = v - c[3 * stride + 1];   d[2] = v - c[2 * stride + 2];   d[3] = v - c[stride + 3];
     d[4] = v - c[3];                d[5] = v - c[-stride + 3];      d[6] = v - c[-2 * stride + 2];  d[7] = v - c[-3 * stride + 1];

@@ -131,6 +131,8 @@ class TrackPipeline:
             for k, v in a.items():
                 setattr(pb, k, v.data_ptr())
             self.pb_arrays.append(a); self.pbs.append(pb)
+        import os
+        self.skip = set(os.environ.get("PLANAR_TRACK_SKIP", "").split(","))     # timing diagnosis only (tools): leave a stage's launches out, results are then meaningless
         self.pending = []
         self.map_set = False
         self.step_count = 0
@@ -204,11 +206,15 @@ class TrackPipeline:
         if evs: evs["start"].record(st)
         sl.wait_event(self.ev_in[k]); sp.wait_event(self.ev_in[k])
         if side: side[2].record(sl)
-        check(L.planar_lsd_preprocess_dev(self.lss[k].h, gray.data_ptr(), B, self.W, self.W * self.H))
+        if "lsd" not in self.skip:
+            check(L.planar_lsd_preprocess_dev(self.lss[k].h, gray.data_ptr(), B, self.W, self.W * self.H))
         if side: side[0].record(sp)
-        self.pds[k].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), B)
-        self.sns[k].compute_dev(depth.data_ptr(), self.snrm[k].data_ptr(), B, K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
-        check(L.planar_lsd_detect_dev(self.lss[k].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
+        if "peac" not in self.skip:
+            self.pds[k].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), B)
+        if "normals" not in self.skip:
+            self.sns[k].compute_dev(depth.data_ptr(), self.snrm[k].data_ptr(), B, K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
+        if "lsd" not in self.skip:
+            check(L.planar_lsd_detect_dev(self.lss[k].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
         # Frame::ExtractLSD: isLineGood right behind ExtractLineSegment, same thread; every (stream, step, line) has its own rand() seed
         l3 = self.l3[k]
         with t.cuda.stream(sl):
@@ -220,7 +226,8 @@ class TrackPipeline:
                                         l3["n_good"].data_ptr()))
         if side: side[1].record(sp); side[3].record(sl)
         self.join_p[k].record(sp); self.join_l[k].record(sl)
-        self.ex.extract_dev(gray.data_ptr(), self.kps[k].data_ptr(), self.desc[k].data_ptr(), self.n[k].data_ptr(), B)
+        if "orb" not in self.skip:
+            self.ex.extract_dev(gray.data_ptr(), self.kps[k].data_ptr(), self.desc[k].data_ptr(), self.n[k].data_ptr(), B)
         if evs: evs["orb"].record(st)
         # Frame::ComputeStereoFromRGBD: mvuRight / mvDepth of the new keypoints (the world points come after the pose is known)
         self._stereo(self.ctx, k, self.pose0, depth, self.ur[k], self.zd[k], self.xw_tmp, self.valid_tmp)
