@@ -9,13 +9,15 @@ timeout 200 python bench.py --workload ba --steps 20 --warmup 3 > $O/${tag}_benc
 cd /tmp && export TMPDIR=/tmp
 FL="--steps 6 --warmup 3 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
+if [ "$2" = "pmc" ]; then   # the counter passes hung on the pool in round 2 (profiles/README.md): opt-in
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_write -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 > /dev/null 2>&1
+python $R/tools/pmc_summary.py $O/${tag}_pmc_fetch $O/${tag}_pmc_write > $O/${tag}_pmc_fetch_write_kb_per_launch.csv 2>> $O/${tag}_bench.err
+fi
 cd $R
-python tools/pmc_summary.py $O/${tag}_pmc_fetch $O/${tag}_pmc_write > $O/${tag}_pmc_fetch_write_kb_per_launch.csv 2>> $O/${tag}_bench.err
 f=$(ls $O/${tag}_trace/*/*kernel_stats.csv | head -1); cp $f $O/${tag}_kernel_stats.csv
 t=$(ls $O/${tag}_trace/*/*kernel_trace.csv | head -1); (head -1 $t; tail -80 $t) > $O/${tag}_kernel_trace_tail.csv
 rm -rf $O/${tag}_trace $O/${tag}_pmc_fetch $O/${tag}_pmc_write
 timeout 900 python -m pytest tests -m gpu -q > $O/${tag}_gpu_tests.log 2>&1
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${tag}_smoke.log 2>&1
-tail -3 $O/${tag}_gpu_tests.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"; grep -c . $O/${tag}_pmc_fetch_write_kb_per_launch.csv; tail -1 $O/${tag}_smoke.log; cut -c1-250 $O/${tag}_bench.json
+grep -a "passed\|failed" $O/${tag}_gpu_tests.log; tail -1 $O/${tag}_smoke.log; cut -c1-250 $O/${tag}_bench.json
