@@ -94,19 +94,19 @@ static RandomPoint3d compPt3dCov(const P3& pt, double f) {
 }
 
 static double mah_dist3d_pt_line(const RandomPoint3d& pt, const P3& q1, const P3& q2) {
-    const double xa = q1.x, ya = q1.y, za = q1.z, xb = q2.x, yb = q2.y, zb = q2.z;
-    const double c1 = pt.DU[0], c2 = pt.DU[1], c3 = pt.DU[2], c4 = pt.DU[3], c5 = pt.DU[4], c6 = pt.DU[5], c7 = pt.DU[6], c8 = pt.DU[7], c9 = pt.DU[8];
-    const double x1 = pt.pos.x, x2 = pt.pos.y, x3 = pt.pos.z;
-    const double term1 = ((c1 * (x1 - xa) + c2 * (x2 - ya) + c3 * (x3 - za)) * (c4 * (x1 - xb) + c5 * (x2 - yb) + c6 * (x3 - zb)) -
-                          (c4 * (x1 - xa) + c5 * (x2 - ya) + c6 * (x3 - za)) * (c1 * (x1 - xb) + c2 * (x2 - yb) + c3 * (x3 - zb))),
-                 term2 = ((c1 * (x1 - xa) + c2 * (x2 - ya) + c3 * (x3 - za)) * (c7 * (x1 - xb) + c8 * (x2 - yb) + c9 * (x3 - zb)) -
-                          (c7 * (x1 - xa) + c8 * (x2 - ya) + c9 * (x3 - za)) * (c1 * (x1 - xb) + c2 * (x2 - yb) + c3 * (x3 - zb))),
-                 term3 = ((c4 * (x1 - xa) + c5 * (x2 - ya) + c6 * (x3 - za)) * (c7 * (x1 - xb) + c8 * (x2 - yb) + c9 * (x3 - zb)) -
-                          (c7 * (x1 - xa) + c8 * (x2 - ya) + c9 * (x3 - za)) * (c4 * (x1 - xb) + c5 * (x2 - yb) + c6 * (x3 - zb))),
-                 term4 = (c1 * (x1 - xa) - c1 * (x1 - xb) + c2 * (x2 - ya) - c2 * (x2 - yb) + c3 * (x3 - za) - c3 * (x3 - zb)),
-                 term5 = (c4 * (x1 - xa) - c4 * (x1 - xb) + c5 * (x2 - ya) - c5 * (x2 - yb) + c6 * (x3 - za) - c6 * (x3 - zb)),
-                 term6 = (c7 * (x1 - xa) - c7 * (x1 - xb) + c8 * (x2 - ya) - c8 * (x2 - yb) + c9 * (x3 - za) - c9 * (x3 - zb));
-    return std::sqrt((term1 * term1 + term2 * term2 + term3 * term3) / (term4 * term4 + term5 * term5 + term6 * term6));
+    // u = DU (x - q1), w = DU (x - q2) (each component a left-to-right three-term sum, as the reference writes them out); the distance is
+    // |u x w| / |u - w| with u - w accumulated term by term in the reference's order
+    const double ax = pt.pos.x - q1.x, ay = pt.pos.y - q1.y, az = pt.pos.z - q1.z, bx = pt.pos.x - q2.x, by = pt.pos.y - q2.y, bz = pt.pos.z - q2.z;
+    const double* D = pt.DU;
+    double u[3], w[3], dif[3];
+    for (int r = 0; r < 3; r++) {
+        const double pa0 = D[3 * r] * ax, pa1 = D[3 * r + 1] * ay, pa2 = D[3 * r + 2] * az, pb0 = D[3 * r] * bx, pb1 = D[3 * r + 1] * by, pb2 = D[3 * r + 2] * bz;
+        u[r] = pa0 + pa1 + pa2;
+        w[r] = pb0 + pb1 + pb2;
+        dif[r] = pa0 - pb0 + pa1 - pb1 + pa2 - pb2;
+    }
+    const double n01 = u[0] * w[1] - u[1] * w[0], n02 = u[0] * w[2] - u[2] * w[0], n12 = u[1] * w[2] - u[2] * w[1];
+    return std::sqrt((n01 * n01 + n02 * n02 + n12 * n12) / (dif[0] * dif[0] + dif[1] * dif[1] + dif[2] * dif[2]));
 }
 
 static P3 projectPt3d2Ln3d(const P3& P, const P3& mid, const P3& drct) {
