@@ -540,6 +540,46 @@ int planar_track_manhattan_frame_dev(planar_ctx* ctx, int B, const float* d_R_la
                                      const double* d_line_dirs, const int32_t* d_n_lines, int ln_stride, float* d_R_out, uint8_t* d_member,
                                      int32_t* d_info, float* d_density);
 
+/* ---- plane post-processing (planepost.hip; replaces the head of Frame::ComputePlanes, src/Frame.cc:652-692, with
+ *      Frame::MaxPointDistanceFromPlane, src/Frame.cc:755-812) -----------------------------------------------------------------------
+ * For every plane PlaneDetection extracted (labels / planes / n_planes exactly as planar_peac_segment delivers them): the member pixels' camera points
+ * as float -> pcl::VoxelGrid(leaf) centroids -> coefficient (n, -n.c) in float -> a plane with a centroid farther than dist_th
+ * (Plane.DistanceThreshold) is dropped -> pcl::SACSegmentation (plane, RANSAC, optimised coefficients, threshold dist_th) refits the coefficient.
+ *   n_out  [B]                     Frame::mnPlaneNum: planes kept
+ *   coef   [B][pl_stride][4]       mvPlaneCoefficients (pl_stride = planar_peac_max_planes())
+ *   src    [B][pl_stride]          index of the detector plane each kept plane came from
+ *   pt_off [B][pl_stride + 1]      mvPlanePoints[k] = points[b][pt_off[k] .. pt_off[k + 1])
+ *   points [B][max_points][3]      the kept planes' voxel centroids, concatenated, each plane in PCL's output order
+ *   status [B] (_dev only)         0, or 3 = more than max_points voxels / voxel coordinate out of range, 4 = sampler table exhausted: the frame's
+ *                                  outputs are then empty; the host-pointer entry point turns it into PLANAR_ECAPACITY
+ *   state / nvox / info (optional, per DETECTOR plane, stride pl_stride / pl_stride / pl_stride * 12): 0 kept, 1 distance, 2 no inliers; voxels;
+ *                                  {RANSAC iterations, best count, best sample[3], inliers, inliers after the refit, sampler draws, model[4] bits}  */
+typedef struct planar_plane_clouds planar_plane_clouds;
+int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* power of two, <= 8192 */, planar_plane_clouds** out);
+void planar_plane_clouds_destroy(planar_plane_clouds* pc);
+int planar_plane_clouds_stride(const planar_plane_clouds* pc, int* pl_stride, int* max_points);
+int planar_plane_clouds_compute(planar_plane_clouds* pc, const uint16_t* depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy, float cx,
+                                float cy, float depth_factor, const int32_t* labels, const double* planes, const int32_t* n_planes, double dist_th, float leaf,
+                                int32_t* n_out, float* coef, int32_t* src, int32_t* pt_off, float* points, int32_t* state, int32_t* nvox, int32_t* info);
+int planar_plane_clouds_compute_dev(planar_plane_clouds* pc, const uint16_t* d_depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy,
+                                    float cx, float cy, float depth_factor, const int32_t* d_labels, const double* d_planes, const int32_t* d_n_planes,
+                                    double dist_th, float leaf, int32_t* d_n_out, float* d_coef, int32_t* d_src, int32_t* d_pt_off, float* d_points,
+                                    int32_t* d_status, int32_t* d_state, int32_t* d_nvox, int32_t* d_info);
+/* Frame::MaxPointDistanceFromPlane on given clouds (host pointers): planes [n_clouds][4] in/out (written when state == 0), cloud q = points[pt_off[q] ..
+ * pt_off[q + 1]); state / info as above. */
+int planar_plane_refit(planar_plane_clouds* pc, int n_clouds, const float* points, const int32_t* pt_off, double dist_th, float* planes, int32_t* state,
+                       int32_t* info);
+/* Map::FlagMatchedPlanePoints (src/Map.cc:366-393): flags[b][j] = 1 for every map point j within 0.5 of the WORLD coefficient (Frame::ComputePlaneWorldCoeff)
+ * of a plane i < n_planes[b] with matched[b][i] != 0 (mvpMapPlanes[i] non-null).  xw: [B or 1][n_points][3]; flags are only ever set; n_matches (or NULL): nMatches. */
+int planar_flag_matched_plane_points(planar_ctx* ctx, int B, const float* Tcw, const float* coef, const uint8_t* matched, const int32_t* n_planes, int pl_stride,
+                                     const float* xw, int n_points, int points_shared, uint8_t* flags, int32_t* n_matches);
+int planar_flag_matched_plane_points_dev(planar_ctx* ctx, int B, const float* d_Tcw, const float* d_coef, const uint8_t* d_matched, const int32_t* d_n_planes,
+                                         int pl_stride, const float* d_xw, int n_points, int points_shared, uint8_t* d_flags, int32_t* d_n_matches);
+/* The cloud half of MapPlane::UpdateCoefficientsAndPoints (src/MapPlane.cc:335-352): the frame plane's points through Twc (row-major 4x4 double, what
+ * Converter::toSE3Quat(mTcw).inverse() yields; pcl::transformPointCloud: double arithmetic, float store), the map plane's points appended, VoxelGrid(leaf). */
+int planar_merge_plane_points(planar_plane_clouds* pc, const double* Twc, const float* frame_points, int n_frame, const float* map_points, int n_map, float leaf,
+                              float* out_points, int out_cap, int32_t* n_out);
+
 /* ---- Frame-side glue of Tracking::Track (frame.hip) ---------------------------------------------------------------------------
  * Frame::ComputeStereoFromRGBD (src/Frame.cc:603-621) + Frame::UnprojectStereo (:623-634) for every keypoint of B frames.
  *   keys / keys_un : [B][stride] mvKeys (the depth image is read at the DISTORTED position, truncated to int) / mvKeysUn

@@ -1,0 +1,778 @@
+// planarslam_amd/csrc/planepost.hip — plane post-processing for MI355X (gfx950).
+//
+// Replaces the head of Frame::ComputePlanes (reference src/Frame.cc:652-692) with Frame::MaxPointDistanceFromPlane (:755-812): for every plane the
+// detector extracted, the member pixels' camera points (float) -> pcl::VoxelGrid(0.1 m) centroids (mvPlanePoints) -> coefficient (n, -n.c) ->
+// all centroids within Plane.DistanceThreshold or the plane is dropped -> pcl::SACSegmentation (plane model, RANSAC, optimised coefficients) refits
+// the coefficient (mvPlaneCoefficients).  Also Map::FlagMatchedPlanePoints (src/Map.cc:366-393) and the cloud merge of
+// MapPlane::UpdateCoefficientsAndPoints (src/MapPlane.cc:335-352).  PCL is un-vendored: the arithmetic follows the published PCL 1.7-1.9 sources as
+// oracle/planepost_oracle.cpp restates them (PARITY UNPINNED there, with the assumed Eigen evaluation orders listed).
+//
+// plane_clouds_kernel: one workgroup of 512 lanes per FRAME.
+//   B  voxel sums every lane walks runs of 8 consecutive pixels (labels read as 2 x int4) with the PCL voxel coordinates floor(x / leaf) (float arithmetic
+//                 as published); runs of equal (plane, voxel) are summed in registers and flushed to a 16 K-slot open-addressing table in the frame's
+//                 workspace (64-bit CAS on the key, then 4 fire-and-forget atomics): about one flush per 8 pixels.  Sums are 64-bit fixed point
+//                 (2^-36 m): integer addition is associative, so the centroids do not depend on the order the hardware retires the atomics in.
+//                 PCL sums floats in std::sort's (unstable) order; a centroid here is the correctly rounded mean, within the float-summation
+//                 error of the reference's (a few 1e-6 m), and reproducible.  PCL's bounding-box pass (getMinMax3D) is not needed: see voxel_key.
+//   C  order      occupied slots -> LDS list of (plane, i2, i1, i0, slot) -> bitonic sort = PCL's output order (ascending voxel index).
+//   D  centroids  -> workspace, per-plane [first, last).
+//   E  refit      one WAVEFRONT per plane: distance gate (ballot), RANSAC with PCL's deterministic sampler (mt19937 seeded 12345: the stream is the
+//                 same for every plane, so it is a table made at create time), counts by ballot + popcount, the covariance sums as nine float
+//                 chains (lane t owns accumulator t, all lanes walk the points together), eigen33 in float.
+//   F  compaction of the kept planes into the output arrays.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace planar {
+namespace planepost {
+
+constexpr int NT = 512;
+constexpr int MAXP = 128;                 // planar_peac_max_planes()
+constexpr int TCAP = 16384;               // hash slots per frame
+constexpr int NRNG = 32768;               // sampler values kept (a refit that needs more reports PLANAR_ECAPACITY)
+constexpr double FIX_SCALE = 68719476736.0;   // 2^36: the voxel sums are fixed point, exact for every float of magnitude 2^-13 .. 2^7 m
+constexpr int VOX_BIAS = 8192;            // voxel coordinates floor(x / leaf) are kept in 14 bits each
+constexpr unsigned long long EMPTY = ~0ull;
+
+struct Geo {
+    int W, H, max_points, pl_stride;
+    float fx, fy, cx, cy, factor, leaf;
+    double dist_th, log_probability;
+    size_t ws_stride, off_cnt, off_sum, off_cent;
+};
+
+struct Pt { float x, y, z; };
+// PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:45-52) in double, narrowed as Frame.cc:659-661 does
+__device__ __forceinline__ Pt cam_point(const Geo& G, unsigned short d, int px, int py) {
+    const double z = (double)d * (double)G.factor;
+    const double x = ((double)px - (double)G.cx) * z / (double)G.fx;
+    const double y = ((double)py - (double)G.cy) * z / (double)G.fy;
+    return {(float)x, (float)y, (float)z};
+}
+
+// PCL's voxel index is idx = (i0 - min_b0) + (i1 - min_b1) * div_b0 + (i2 - min_b2) * div_b0 * div_b1 with i = floor(x * inv_leaf) (the float subtraction
+// floor(..) - (float)min_b is exact): a voxel is identified by (i0, i1, i2) alone, and ascending idx is the lexicographic order of (i2, i1, i0).  The
+// bounding box (getMinMax3D) is therefore not needed: the key carries the three coordinates, biased, 14 bits each.  false: out of the 14-bit range.
+__device__ __forceinline__ bool voxel_key(float x, float y, float z, float inv, unsigned plane, unsigned long long& key) {
+    const int i0 = (int)floorf(x * inv) + VOX_BIAS, i1 = (int)floorf(y * inv) + VOX_BIAS, i2 = (int)floorf(z * inv) + VOX_BIAS;
+    key = ((unsigned long long)plane << 42) | ((unsigned long long)(unsigned)i2 << 28) | ((unsigned long long)(unsigned)i1 << 14) | (unsigned long long)(unsigned)i0;
+    return ((unsigned)i0 | (unsigned)i1 | (unsigned)i2) < 2u * VOX_BIAS;
+}
+
+__device__ __forceinline__ float red4(float a0, float a1, float a2, float a3) { return (a0 + a2) + (a1 + a3); }
+__device__ __forceinline__ float plane_dot(const float m[4], float x, float y, float z) { return red4(m[0] * x, m[1] * y, m[2] * z, m[3] * 1.0f); }
+
+__device__ __forceinline__ void roots2(float b, float c, float roots[3]) {
+    roots[0] = 0.f;
+    float d = (float)((double)(b * b) - 4.0 * (double)c);
+    if (d < 0.0f) d = 0.0f;
+    const float sd = sqrtf(d);
+    roots[2] = 0.5f * (b + sd);
+    roots[1] = 0.5f * (b - sd);
+}
+__device__ __forceinline__ void roots3(const float m[9], float roots[3]) {
+    const float c0 = m[0] * m[4] * m[8] + 2.f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+    const float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+    const float c2 = m[0] + m[4] + m[8];
+    if (fabsf(c0) < 1.1920929e-07f) { roots2(c2, c1, roots); return; }
+    const float s_inv3 = (float)(1.0 / 3.0), s_sqrt3 = sqrtf(3.0f);
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.f) a_over_3 = 0.f;
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.f) q = 0.f;
+    const float rho = sqrtf(-a_over_3);
+    const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+    const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+    roots[0] = c2_over_3 + 2.f * rho * cos_theta;
+    roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    float t;
+    if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+    if (roots[1] >= roots[2]) {
+        t = roots[1]; roots[1] = roots[2]; roots[2] = t;
+        if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+    }
+    if (roots[0] <= 0) roots2(c2, c1, roots);
+}
+// pcl::eigen33(mat, eigenvalue, eigenvector): eigenvector of the smallest eigenvalue
+__device__ __forceinline__ void eigen33_smallest(const float cov[9], float vec[3]) {
+    float scale = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) scale = fmaxf(scale, fabsf(cov[k]));
+    if (scale <= 1.17549435e-38f) scale = 1.0f;
+    float m[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[k] = cov[k] / scale;
+    float roots[3];
+    roots3(m, roots);
+    m[0] -= roots[0]; m[4] -= roots[0]; m[8] -= roots[0];
+    float v1[3], v2[3], v3[3];
+    v1[0] = m[1] * m[5] - m[2] * m[4]; v1[1] = m[2] * m[3] - m[0] * m[5]; v1[2] = m[0] * m[4] - m[1] * m[3];      // row0 x row1
+    v2[0] = m[1] * m[8] - m[2] * m[7]; v2[1] = m[2] * m[6] - m[0] * m[8]; v2[2] = m[0] * m[7] - m[1] * m[6];      // row0 x row2
+    v3[0] = m[4] * m[8] - m[5] * m[7]; v3[1] = m[5] * m[6] - m[3] * m[8]; v3[2] = m[3] * m[7] - m[4] * m[6];      // row1 x row2
+    const float l1 = v1[0] * v1[0] + (v1[1] * v1[1] + v1[2] * v1[2]), l2 = v2[0] * v2[0] + (v2[1] * v2[1] + v2[2] * v2[2]),
+                l3 = v3[0] * v3[0] + (v3[1] * v3[1] + v3[2] * v3[2]);
+    if (l1 >= l2 && l1 >= l3) { const float s = sqrtf(l1); vec[0] = v1[0] / s; vec[1] = v1[1] / s; vec[2] = v1[2] / s; }
+    else if (l2 >= l1 && l2 >= l3) { const float s = sqrtf(l2); vec[0] = v2[0] / s; vec[1] = v2[1] / s; vec[2] = v2[2] / s; }
+    else { const float s = sqrtf(l3); vec[0] = v3[0] / s; vec[1] = v3[1] / s; vec[2] = v3[2] / s; }
+}
+
+// pcl::SACSegmentation::segment as Frame::MaxPointDistanceFromPlane configures it, by one wavefront.  pts: n voxel centroids (global), shuf: n u16 in LDS.
+// Returns 0 ok, 2 no inliers, 4 sampler table exhausted; info (or NULL): [12] as oracle/planepost_oracle.cpp documents.
+__device__ __forceinline__ int sac_plane(const Geo& G, const float* __restrict__ pts, int n, unsigned short* shuf, const int* __restrict__ rng, float coef[4], int* info) {
+    const int lane = threadIdx.x & 63;
+    auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (int i = lane; i < n; i += 64) shuf[i] = (unsigned short)i;
+    wfence();
+    const double threshold = G.dist_th, one_over_indices = 1.0 / (double)n;
+    int iterations = 0, best = -2147483647, draws = 0, bs0 = -1, bs1 = -1, bs2 = -1;
+    double k = 1.0;
+    unsigned skipped = 0;
+    float bm[4] = {0.f, 0.f, 0.f, 0.f};
+    bool have = false, exhausted = false;
+    auto count_within = [&](const float m[4]) {
+        int c = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            bool in = false;
+            if (i < n) in = (double)fabsf(plane_dot(m, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2])) < threshold;
+            c += __popcll(__ballot(in));
+        }
+        return c;
+    };
+    while ((double)iterations < k && skipped < 500u) {
+        int s0 = 0, s1 = 0, s2 = 0;
+        bool got = false;
+        if (n >= 3) {
+            for (unsigned t = 0; t < 1000u && !got; t++) {
+                if (draws + 3 > NRNG) { exhausted = true; break; }
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int j = i + (int)((unsigned)rng[draws + i] % (unsigned)(n - i));
+                    const unsigned short a = shuf[i], b = shuf[j];
+                    if (lane == 0) { shuf[i] = b; shuf[j] = a; }
+                    wfence();
+                }
+                draws += 3;
+                s0 = shuf[0]; s1 = shuf[1]; s2 = shuf[2];
+                float r[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) r[c] = (pts[s1 * 3 + c] - pts[s0 * 3 + c]) / (pts[s2 * 3 + c] - pts[s0 * 3 + c]);
+                got = (r[0] != r[1]) || (r[2] != r[1]);
+            }
+        }
+        if (!got) break;
+        float a[3], b[3], r[3], m[4];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { a[c] = pts[s1 * 3 + c] - pts[s0 * 3 + c]; b[c] = pts[s2 * 3 + c] - pts[s0 * 3 + c]; r[c] = a[c] / b[c]; }
+        if ((r[0] == r[1]) && (r[2] == r[1])) { ++skipped; continue; }
+        m[0] = a[1] * b[2] - a[2] * b[1];
+        m[1] = a[2] * b[0] - a[0] * b[2];
+        m[2] = a[0] * b[1] - a[1] * b[0];
+        m[3] = 0.f;
+        const float nrm = sqrtf(red4(m[0] * m[0], m[1] * m[1], m[2] * m[2], 0.f));
+#pragma unroll
+        for (int c = 0; c < 4; c++) m[c] = m[c] / nrm;
+        m[3] = -1 * red4(m[0] * pts[s0 * 3], m[1] * pts[s0 * 3 + 1], m[2] * pts[s0 * 3 + 2], m[3] * 1.0f);
+        const int cnt = count_within(m);
+        if (cnt > best) {
+            best = cnt; have = true;
+#pragma unroll
+            for (int c = 0; c < 4; c++) bm[c] = m[c];
+            bs0 = s0; bs1 = s1; bs2 = s2;
+            const double w = (double)best * one_over_indices;
+            double p_no_outliers = 1.0 - pow(w, 3.0);
+            p_no_outliers = fmax(2.220446049250313e-16, p_no_outliers);
+            p_no_outliers = fmin(1.0 - 2.220446049250313e-16, p_no_outliers);
+            k = G.log_probability / log(p_no_outliers);
+        }
+        ++iterations;
+        if (iterations > 50) break;
+    }
+    if (info && lane == 0) {
+        info[0] = iterations; info[1] = have ? best : 0; info[2] = bs0; info[3] = bs1; info[4] = bs2; info[5] = 0; info[6] = 0; info[7] = draws;
+#pragma unroll
+        for (int c = 0; c < 4; c++) info[8 + c] = __float_as_int(bm[c]);
+    }
+    if (exhausted) return 4;
+    if (!have) return 2;
+    // selectWithinDistance + computeMeanAndCovarianceMatrix: nine float chains over the inliers in index order, lane t owns accumulator t
+    float acc = 0.f;
+    int n_inl = 0;
+    for (int i = 0; i < n; i++) {
+        const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+        if ((double)fabsf(plane_dot(bm, x, y, z)) < threshold) {
+            n_inl++;
+            const float u = lane < 3 ? x : (lane < 5 ? y : (lane == 5 ? z : (lane == 6 ? x : (lane == 7 ? y : z))));
+            const float v = (lane == 0) ? x : ((lane == 1 || lane == 3) ? y : ((lane == 2 || lane == 4 || lane == 5) ? z : 1.0f));
+            acc += lane < 6 ? u * v : u;
+        }
+    }
+    float refined[4];
+    if (n_inl < 4) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) refined[c] = bm[c];
+    } else {
+        acc = acc / (float)n_inl;
+        float a[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) a[t] = __shfl(acc, t);
+        float cov[9];
+        cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
+        cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
+        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+        float v[3];
+        eigen33_smallest(cov, v);
+        refined[0] = v[0]; refined[1] = v[1]; refined[2] = v[2]; refined[3] = 0.f;
+        refined[3] = -1 * red4(refined[0] * a[6], refined[1] * a[7], refined[2] * a[8], refined[3] * 1.0f);
+    }
+    const int nref = count_within(refined);
+    if (info && lane == 0) { info[5] = n_inl; info[6] = nref; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) coef[c] = refined[c];
+    return nref != 0 ? 0 : 2;
+}
+
+// Frame::MaxPointDistanceFromPlane, one wavefront: plane in/out; returns the state (0 kept, 1 distance, 2 no inliers, 4 sampler exhausted)
+__device__ __forceinline__ int max_point_distance(const Geo& G, float plane[4], const float* __restrict__ pts, int n, unsigned short* shuf, const int* __restrict__ rng, int* info) {
+    const int lane = threadIdx.x & 63;
+    bool far = false;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool f = false;
+        if (i < n) f = (double)fabsf(plane[0] * pts[i * 3] + plane[1] * pts[i * 3 + 1] + plane[2] * pts[i * 3 + 2] + plane[3]) > G.dist_th;
+        far = far || (__ballot(f) != 0ull);
+    }
+    if (info && lane == 0) for (int c = 0; c < 12; c++) info[c] = c >= 2 && c <= 4 ? -1 : 0;
+    if (far) return 1;
+    float c[4];
+    const int st = sac_plane(G, pts, n, shuf, rng, c, info);
+    if (st) return st;
+    const float oldVal = plane[3], newVal = c[3];
+    const bool flip = (newVal < 0 && oldVal > 0) || (newVal > 0 && oldVal < 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) plane[t] = flip ? -c[t] : c[t];
+    return 0;
+}
+
+__device__ __forceinline__ unsigned hash64(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33;
+    return (unsigned)k;
+}
+
+// LDS bitonic sort of n2 (power of two) keys
+__device__ __forceinline__ void bitonic(unsigned long long* a, int n2) {
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < n2 / 2; t += NT) {
+                const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long x = a[lo], y = a[hi];
+                if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
+                                                          const int* __restrict__ labels_all, const double* __restrict__ planes_all, int planes_stride,
+                                                          const int* __restrict__ n_planes, const int* __restrict__ rng, unsigned char* ws_all, int* n_out,
+                                                          float* coef_out, int* src_out, int* off_out, float* pts_out, int* status, int* state_out,
+                                                          int* nvox_out, int* info_out) {
+    extern __shared__ unsigned long long s_list[];        // max_points keys; the refit's shuffle array (u16) reuses it
+    __shared__ int s_first[MAXP], s_last[MAXP], s_state[MAXP], s_k[MAXP], s_o[MAXP + 1];
+    __shared__ float s_coef[MAXP][4];
+    __shared__ int s_n, s_err, s_kept;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = G.W * G.H;
+    const unsigned short* D = depth_all + (size_t)b * frame_stride_px;
+    const int* lab = labels_all + (size_t)b * HW;
+    const double* planes = planes_all + (size_t)b * planes_stride * 8;
+    unsigned char* ws = ws_all + (size_t)b * G.ws_stride;
+    unsigned long long* tkey = (unsigned long long*)ws;
+    unsigned* tcnt = (unsigned*)(ws + G.off_cnt);
+    unsigned long long* tsum = (unsigned long long*)(ws + G.off_sum);
+    float* cent = (float*)(ws + G.off_cent);
+    int npl = n_planes[b];
+    if (npl > MAXP) npl = MAXP;
+    if (npl > G.pl_stride) npl = G.pl_stride;
+    const float inv = 1.0f / G.leaf;
+
+    for (int i = tid; i < TCAP; i += NT) { tkey[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TCAP + i] = 0ull; tsum[2 * TCAP + i] = 0ull; }
+    for (int i = tid; i < MAXP; i += NT) { s_first[i] = 0; s_last[i] = 0; s_state[i] = 0; }
+    if (tid == 0) { s_n = 0; s_err = 0; s_kept = 0; }
+    __threadfence();
+    __syncthreads();
+
+    // ---- B: voxel sums ----
+    if (!s_err)
+    for (int base = tid * 8; base < HW; base += NT * 8) {
+        int l8[8];
+        if (base + 8 <= HW) {
+            const int4 u = *(const int4*)(lab + base), v = *(const int4*)(lab + base + 4);
+            l8[0] = u.x; l8[1] = u.y; l8[2] = u.z; l8[3] = u.w; l8[4] = v.x; l8[5] = v.y; l8[6] = v.z; l8[7] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) l8[q] = base + q < HW ? lab[base + q] : -1;
+        }
+        int py = base / G.W, px = base - py * G.W;
+        unsigned long long cur = EMPTY;
+        unsigned cnt = 0;
+        long long sx = 0, sy = 0, sz = 0;
+        auto flush = [&]() {
+            if (cur == EMPTY) return;
+            unsigned h = hash64(cur) & (TCAP - 1);
+            for (int probe = 0; probe < TCAP; probe++) {
+                const unsigned long long k = atomicCAS(&tkey[h], EMPTY, cur);
+                if (k == EMPTY) { if (atomicAdd(&s_n, 1) >= G.max_points) s_err = 3; }
+                if (k == EMPTY || k == cur) {
+                    atomicAdd(&tcnt[h], cnt);
+                    atomicAdd(&tsum[h], (unsigned long long)sx); atomicAdd(&tsum[TCAP + h], (unsigned long long)sy); atomicAdd(&tsum[2 * TCAP + h], (unsigned long long)sz);
+                    return;
+                }
+                h = (h + 1) & (TCAP - 1);
+            }
+            s_err = 3;
+        };
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int l = l8[q];
+            if (l >= 0 && l < npl) {
+                const Pt p = cam_point(G, D[(size_t)py * pitch_px + px], px, py);
+                unsigned long long key;
+                if (!voxel_key(p.x, p.y, p.z, inv, (unsigned)l, key)) s_err = 3;
+                else {
+                    if (key != cur) { flush(); cur = key; cnt = 0; sx = sy = sz = 0; }
+                    cnt++;
+                    sx += __double2ll_rn((double)p.x * FIX_SCALE); sy += __double2ll_rn((double)p.y * FIX_SCALE); sz += __double2ll_rn((double)p.z * FIX_SCALE);
+                }
+            }
+            if (++px == G.W) { px = 0; py++; }
+        }
+        flush();
+    }
+    __threadfence();
+    __syncthreads();
+    int err = s_err;
+    const int M = err ? 0 : s_n;
+
+    // ---- C: occupied slots in PCL's output order ----
+    int n2 = 1;
+    while (n2 < M) n2 <<= 1;
+    if (!err) {
+        for (int i = tid; i < n2; i += NT) s_list[i] = EMPTY;
+        __syncthreads();
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (int s = tid; s < TCAP; s += NT) {
+            const unsigned long long k = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k != EMPTY) { const int pos = atomicAdd(&s_n, 1); s_list[pos] = (k << 14) | (unsigned long long)s; }
+        }
+        __syncthreads();
+        bitonic(s_list, n2);
+        // ---- D: centroids, per-plane ranges ----
+        for (int r = tid; r < M; r += NT) {
+            const unsigned long long e = s_list[r];
+            const int s = (int)(e & 0x3fffull), p = (int)(e >> 56);
+            const double cnt = (double)__hip_atomic_load(&tcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const long long S = (long long)__hip_atomic_load(&tsum[c * TCAP + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cent[(size_t)r * 3 + c] = (float)(((double)S * (1.0 / FIX_SCALE)) / cnt);
+            }
+            if (r == 0 || (int)(s_list[r - 1] >> 56) != p) s_first[p] = r;
+            if (r == M - 1 || (int)(s_list[r + 1] >> 56) != p) s_last[p] = r + 1;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+
+    // ---- E: distance gate + RANSAC refit, one wavefront per plane ----
+    unsigned short* shuf = (unsigned short*)s_list;
+    if (!err)
+    for (int p = wave; p < npl; p += NT / 64) {
+        const double* P = planes + (size_t)p * 8;
+        const double nx = P[1], ny = P[2], nz = P[3];
+        float c[4] = {(float)nx, (float)ny, (float)nz, (float)-(nx * P[4] + ny * P[5] + nz * P[6])};
+        const int first = s_first[p], n = s_last[p] - first;
+        int* info = info_out ? info_out + ((size_t)b * G.pl_stride + p) * 12 : nullptr;
+        const int st = max_point_distance(G, c, cent + (size_t)first * 3, n, shuf + first, rng, info);
+        if (lane == 0) {
+            s_state[p] = st;
+#pragma unroll
+            for (int t = 0; t < 4; t++) s_coef[p][t] = c[t];
+            if (st == 4) s_err = 4;
+        }
+    }
+    __syncthreads();
+    if (!err) err = s_err;
+
+    // ---- F: the kept planes, in detector order ----
+    if (tid == 0) {
+        int k = 0, o = 0;
+        s_o[0] = 0;
+        for (int p = 0; p < npl && !err; p++) {
+            s_k[p] = -1;
+            if (s_state[p] != 0) continue;
+            s_k[p] = k;
+            o += s_last[p] - s_first[p];
+            k++;
+            s_o[k] = o;
+        }
+        s_kept = k;
+        n_out[b] = k;
+        status[b] = err;
+    }
+    __syncthreads();
+    const int kept = s_kept;
+    for (int p = tid; p < npl; p += NT) {
+        if (state_out) state_out[(size_t)b * G.pl_stride + p] = err ? -2 : s_state[p];
+        if (nvox_out) nvox_out[(size_t)b * G.pl_stride + p] = s_last[p] - s_first[p];
+        if (err || s_k[p] < 0) continue;
+        const int k = s_k[p];
+#pragma unroll
+        for (int t = 0; t < 4; t++) coef_out[((size_t)b * G.pl_stride + k) * 4 + t] = s_coef[p][t];
+        src_out[(size_t)b * G.pl_stride + k] = p;
+    }
+    for (int k = tid; k <= kept; k += NT) off_out[(size_t)b * (G.pl_stride + 1) + k] = s_o[k];
+    for (int p = 0; p < npl && !err; p++) {
+        if (s_k[p] < 0) continue;
+        const int first = s_first[p], n = s_last[p] - first, o = s_o[s_k[p]];
+        for (int i = tid; i < n * 3; i += NT) pts_out[((size_t)b * G.max_points + o) * 3 + i] = cent[(size_t)first * 3 + i];
+    }
+}
+
+// Standalone refit of given clouds (Frame::MaxPointDistanceFromPlane): one wavefront per cloud
+__global__ __launch_bounds__(64) void refit_kernel(Geo G, int n_clouds, const float* __restrict__ pts, const int* __restrict__ off, const int* __restrict__ rng,
+                                                   float* plane, int* state, int* info) {
+    extern __shared__ unsigned long long s_list[];
+    const int q = blockIdx.x;
+    if (q >= n_clouds) return;
+    float c[4];
+    for (int t = 0; t < 4; t++) c[t] = plane[q * 4 + t];
+    const int n = off[q + 1] - off[q];
+    const int st = max_point_distance(G, c, pts + (size_t)off[q] * 3, n, (unsigned short*)s_list, rng, info ? info + q * 12 : nullptr);
+    if ((threadIdx.x & 63) == 0) {
+        state[q] = st;
+        if (st == 0) for (int t = 0; t < 4; t++) plane[q * 4 + t] = c[t];
+    }
+}
+
+// Map::FlagMatchedPlanePoints: thread = map point, loop over the frame's matched planes
+__global__ void flag_points_kernel(int B, const float* __restrict__ Tcw, const float* __restrict__ coef, const unsigned char* __restrict__ matched,
+                                   const int* __restrict__ n_planes, int pl_stride, const float* __restrict__ xw, int n_points, int points_shared,
+                                   unsigned char* flags, int* n_matches) {
+    const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* T = Tcw + (size_t)b * 16;
+    int nm = 0;
+    bool hit = false;
+    if (j < n_points) {
+        const float* pW = xw + ((size_t)(points_shared ? 0 : b) * n_points + j) * 3;
+        const float X = pW[0], Y = pW[1], Z = pW[2];
+        for (int i = 0; i < n_planes[b]; i++) {
+            if (!matched[(size_t)b * pl_stride + i]) continue;
+            const float* c = coef + ((size_t)b * pl_stride + i) * 4;
+            float pM[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {      // cv::transpose(mTcw) * coef: cv::gemm's float small-matrix path
+                const float t = T[r] * c[0] + T[4 + r] * c[1] + T[8 + r] * c[2] + T[12 + r] * c[3];
+                pM[r] = (float)((double)t * 1.0);
+            }
+            const double dis = (double)fabsf(pM[0] * X + pM[1] * Y + pM[2] * Z + pM[3]);
+            if (dis < 0.5) { hit = true; nm++; }
+        }
+        if (hit) flags[(size_t)b * n_points + j] = 1;
+    }
+    // nMatches of the frame
+    for (int o = 32; o > 0; o >>= 1) nm += __shfl_down(nm, o);
+    if ((threadIdx.x & 63) == 0 && nm && n_matches) atomicAdd(&n_matches[b], nm);
+}
+
+// pcl::transformPointCloud with a double 4x4 (src/MapPlane.cc:340) fused with the append of the map plane's points
+__global__ void merge_gather_kernel(const double* __restrict__ T, const float* __restrict__ fp, int nf, const float* __restrict__ mp, int nm, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nf) {
+        const double x = fp[i * 3], y = fp[i * 3 + 1], z = fp[i * 3 + 2];
+#pragma unroll
+        for (int r = 0; r < 3; r++) out[i * 3 + r] = (float)(T[r * 4 + 0] * x + T[r * 4 + 1] * y + T[r * 4 + 2] * z + T[r * 4 + 3]);
+    } else if (i < nf + nm) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) out[i * 3 + r] = mp[(i - nf) * 3 + r];
+    }
+}
+
+// pcl::VoxelGrid of one free-standing cloud (the map-side merge): the same table / sort / centroid steps as plane_clouds_kernel, one workgroup
+__global__ __launch_bounds__(NT) void voxel_cloud_kernel(Geo G, const float* __restrict__ pts, int n, unsigned char* ws, float* out, int* n_out, int* status) {
+    extern __shared__ unsigned long long s_list[];
+    __shared__ int s_n, s_err;
+    const int tid = threadIdx.x;
+    unsigned long long* tkey = (unsigned long long*)ws;
+    unsigned* tcnt = (unsigned*)(ws + G.off_cnt);
+    unsigned long long* tsum = (unsigned long long*)(ws + G.off_sum);
+    const float inv = 1.0f / G.leaf;
+    for (int i = tid; i < TCAP; i += NT) { tkey[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TCAP + i] = 0ull; tsum[2 * TCAP + i] = 0ull; }
+    if (tid == 0) { s_n = 0; s_err = 0; }
+    __threadfence();
+    __syncthreads();
+    if (!s_err)
+    for (int i = tid; i < n; i += NT) {
+        const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+        unsigned long long key;
+        if (!voxel_key(x, y, z, inv, 0u, key)) { s_err = 3; continue; }
+        unsigned h = hash64(key) & (TCAP - 1);
+        bool done = false;
+        for (int probe = 0; probe < TCAP && !done; probe++) {
+            const unsigned long long k = atomicCAS(&tkey[h], EMPTY, key);
+            if (k == EMPTY) { if (atomicAdd(&s_n, 1) >= G.max_points) s_err = 3; }
+            if (k == EMPTY || k == key) {
+                atomicAdd(&tcnt[h], 1u);
+                atomicAdd(&tsum[h], (unsigned long long)__double2ll_rn((double)x * FIX_SCALE));
+                atomicAdd(&tsum[TCAP + h], (unsigned long long)__double2ll_rn((double)y * FIX_SCALE));
+                atomicAdd(&tsum[2 * TCAP + h], (unsigned long long)__double2ll_rn((double)z * FIX_SCALE));
+                done = true;
+            }
+            h = (h + 1) & (TCAP - 1);
+        }
+        if (!done) s_err = 3;
+    }
+    __threadfence();
+    __syncthreads();
+    const int err = s_err, M = err ? 0 : s_n;
+    int n2 = 1;
+    while (n2 < M) n2 <<= 1;
+    if (!err) {
+        for (int i = tid; i < n2; i += NT) s_list[i] = EMPTY;
+        __syncthreads();
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (int s = tid; s < TCAP; s += NT) {
+            const unsigned long long k = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k != EMPTY) { const int pos = atomicAdd(&s_n, 1); s_list[pos] = (k << 14) | (unsigned long long)s; }
+        }
+        __syncthreads();
+        bitonic(s_list, n2);
+        for (int r = tid; r < M; r += NT) {
+            const int s = (int)(s_list[r] & 0x3fffull);
+            const double cnt = (double)__hip_atomic_load(&tcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const long long S = (long long)__hip_atomic_load(&tsum[c * TCAP + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out[(size_t)r * 3 + c] = (float)(((double)S * (1.0 / FIX_SCALE)) / cnt);
+            }
+        }
+    }
+    if (tid == 0) { *n_out = M; *status = err; }
+}
+
+// boost::mt19937 seeded 12345 (SampleConsensusModel with random = false) through uniform_int<>(0, INT_MAX): engine() / 2
+static void sampler_table(std::vector<int>& tab) {
+    std::vector<uint32_t> s(624);
+    s[0] = 12345u;
+    for (int i = 1; i < 624; i++) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + (uint32_t)i;
+    int at = 624;
+    tab.resize(NRNG);
+    for (int q = 0; q < NRNG; q++) {
+        if (at >= 624) {
+            for (int i = 0; i < 624; i++) {
+                const uint32_t y = (s[i] & 0x80000000u) | (s[(i + 1) % 624] & 0x7fffffffu);
+                s[i] = s[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            at = 0;
+        }
+        uint32_t y = s[at++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        tab[q] = (int)(y >> 1);
+    }
+}
+
+}  // namespace planepost
+}  // namespace planar
+
+struct planar_plane_clouds {
+    planar_ctx* ctx = nullptr;
+    int max_batch = 0;
+    planar::planepost::Geo G{};
+    size_t smem = 0;
+    planar::DevBuf ws, rng, dbg;
+};
+
+using namespace planar;
+
+extern "C" {
+
+int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points, planar_plane_clouds** out) {
+    PLANAR_REQUIRE(ctx && out, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(width >= 16 && height >= 16 && width <= 4096 && height <= 4096 && max_batch >= 1, PLANAR_EINVAL, "bad size");
+    PLANAR_REQUIRE(max_points >= 64 && max_points <= 8192 && (max_points & (max_points - 1)) == 0, PLANAR_EINVAL, "max_points must be a power of two in [64, 8192]");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    planar_plane_clouds* p = new planar_plane_clouds;
+    p->ctx = ctx; p->max_batch = max_batch;
+    planepost::Geo& G = p->G;
+    G.W = width; G.H = height; G.max_points = max_points; G.pl_stride = planepost::MAXP;
+    G.leaf = 0.1f; G.dist_th = 0.05;
+    G.log_probability = std::log(1.0 - 0.99);
+    G.off_cnt = (size_t)planepost::TCAP * 8;
+    G.off_sum = G.off_cnt + (size_t)planepost::TCAP * 4;
+    G.off_cent = G.off_sum + (size_t)planepost::TCAP * 24;
+    G.ws_stride = align_up(G.off_cent + (size_t)max_points * 12, (size_t)256);
+    p->smem = (size_t)max_points * 8;
+    int rc = p->ws.alloc(G.ws_stride * (size_t)max_batch);
+    if (!rc) rc = p->rng.alloc((size_t)planepost::NRNG * 4);
+    if (rc) { delete p; return rc; }
+    std::vector<int> tab;
+    planepost::sampler_table(tab);
+    if (hipMemcpy(p->rng.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("plane_clouds: sampler table upload failed"); delete p; return PLANAR_EDEVICE; }
+    if (p->smem > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)planepost::plane_clouds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::voxel_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
+        if (e != hipSuccess) { set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", p->smem); delete p; return PLANAR_EINVAL; }
+    }
+    *out = p;
+    return PLANAR_OK;
+}
+
+void planar_plane_clouds_destroy(planar_plane_clouds* p) { delete p; }
+
+int planar_plane_clouds_stride(const planar_plane_clouds* p, int* pl_stride, int* max_points) {
+    PLANAR_REQUIRE(p != nullptr, PLANAR_EINVAL, "null argument");
+    if (pl_stride) *pl_stride = p->G.pl_stride;
+    if (max_points) *max_points = p->G.max_points;
+    return PLANAR_OK;
+}
+
+int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy, float cx,
+                                    float cy, float depth_factor, const int32_t* d_labels, const double* d_planes, const int32_t* d_n_planes, double dist_th,
+                                    float leaf, int32_t* d_n_out, float* d_coef, int32_t* d_src, int32_t* d_pt_off, float* d_points, int32_t* d_status,
+                                    int32_t* d_state, int32_t* d_nvox, int32_t* d_info) {
+    PLANAR_REQUIRE(p && d_depth && d_labels && d_planes && d_n_planes && d_n_out && d_coef && d_src && d_pt_off && d_points && d_status, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "B must be in [1, max_batch]");
+    PLANAR_REQUIRE(pitch_px >= p->G.W && frame_stride_px >= (int64_t)pitch_px * p->G.H, PLANAR_EINVAL, "pitch/frame_stride too small");
+    PLANAR_REQUIRE(leaf > 0.f && dist_th >= 0.0, PLANAR_EINVAL, "leaf / dist_th");
+    // the fixed-point voxel sums hold 2^19 points of magnitude < 2^7 m
+    PLANAR_REQUIRE(65535.0 * (double)depth_factor * std::max(1.0, std::max(p->G.W / (double)fx, p->G.H / (double)fy)) < 128.0, PLANAR_EINVAL, "depth range too large");
+    planepost::Geo G = p->G;
+    G.fx = fx; G.fy = fy; G.cx = cx; G.cy = cy; G.factor = depth_factor; G.leaf = leaf; G.dist_th = dist_th;
+    hipLaunchKernelGGL(planepost::plane_clouds_kernel, dim3(B), dim3(planepost::NT), p->smem, p->ctx->stream, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, d_planes,
+                       planar_peac_max_planes(), d_n_planes, p->rng.as<int>(), p->ws.as<unsigned char>(), d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox,
+                       d_info);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_plane_clouds_compute(planar_plane_clouds* p, const uint16_t* depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy, float cx, float cy,
+                                float depth_factor, const int32_t* labels, const double* planes, const int32_t* n_planes, double dist_th, float leaf, int32_t* n_out,
+                                float* coef, int32_t* src, int32_t* pt_off, float* points, int32_t* state, int32_t* nvox, int32_t* info) {
+    PLANAR_REQUIRE(p && depth && labels && planes && n_planes && n_out && coef && src && pt_off && points, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "B must be in [1, max_batch]");
+    PLANAR_REQUIRE(pitch_px >= p->G.W && frame_stride_px >= (int64_t)pitch_px * p->G.H, PLANAR_EINVAL, "pitch/frame_stride too small");
+    PLANAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    const int PS = p->G.pl_stride, MP = p->G.max_points, HW = p->G.W * p->G.H;
+    Stager s;
+    const int i_depth = s.in(depth, ((size_t)frame_stride_px * (B - 1) + (size_t)pitch_px * p->G.H) * 2), i_lab = s.in(labels, (size_t)B * HW * 4),
+              i_pl = s.in(planes, (size_t)B * planar_peac_max_planes() * 64), i_np = s.in(n_planes, (size_t)B * 4);
+    const int o_n = s.out(n_out, (size_t)B * 4), o_coef = s.out(coef, (size_t)B * PS * 16), o_src = s.out(src, (size_t)B * PS * 4),
+              o_off = s.out(pt_off, (size_t)B * (PS + 1) * 4), o_pts = s.out(points, (size_t)B * MP * 12);
+    std::vector<int32_t> h_status(B);
+    const int o_st = s.out(h_status.data(), (size_t)B * 4);
+    const int o_state = state ? s.out(state, (size_t)B * PS * 4) : -1, o_nvox = nvox ? s.out(nvox, (size_t)B * PS * 4) : -1,
+              o_info = info ? s.out(info, (size_t)B * PS * 48) : -1;
+    hipStream_t st = p->ctx->stream;
+    int rc = s.upload(st);
+    if (rc) return rc;
+    // outputs not written for dropped planes are defined (zero)
+    PLANAR_HIP_CHECK(hipMemsetAsync(s.dev<uint8_t>(o_n), 0, s.total - s.items[o_n].off, st));
+    if ((rc = planar_plane_clouds_compute_dev(p, s.dev<uint16_t>(i_depth), B, pitch_px, frame_stride_px, fx, fy, cx, cy, depth_factor, s.dev<int32_t>(i_lab), s.dev<double>(i_pl),
+                                              s.dev<int32_t>(i_np), dist_th, leaf, s.dev<int32_t>(o_n), s.dev<float>(o_coef), s.dev<int32_t>(o_src), s.dev<int32_t>(o_off),
+                                              s.dev<float>(o_pts), s.dev<int32_t>(o_st), state ? s.dev<int32_t>(o_state) : nullptr, nvox ? s.dev<int32_t>(o_nvox) : nullptr,
+                                              info ? s.dev<int32_t>(o_info) : nullptr)))
+        return rc;
+    if ((rc = s.download(st))) return rc;
+    for (int b = 0; b < B; b++)
+        if (h_status[b]) { set_error("plane_clouds: frame %d exceeded a capacity (code %d: 3 = voxels / index range, 4 = sampler table)", b, h_status[b]); return PLANAR_ECAPACITY; }
+    return PLANAR_OK;
+}
+
+int planar_plane_refit(planar_plane_clouds* p, int n_clouds, const float* points, const int32_t* pt_off, double dist_th, float* planes, int32_t* state, int32_t* info) {
+    PLANAR_REQUIRE(p && points && pt_off && planes && state, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(n_clouds >= 1, PLANAR_EINVAL, "n_clouds");
+    PLANAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    int max_n = 0;
+    for (int q = 0; q < n_clouds; q++) { PLANAR_REQUIRE(pt_off[q + 1] >= pt_off[q], PLANAR_EINVAL, "pt_off must be non-decreasing"); max_n = std::max(max_n, pt_off[q + 1] - pt_off[q]); }
+    PLANAR_REQUIRE(max_n <= 32768 && pt_off[0] == 0, PLANAR_EINVAL, "a cloud may hold at most 32768 points");
+    Stager s;
+    const int i_pts = s.in(points, (size_t)pt_off[n_clouds] * 12), i_off = s.in(pt_off, (size_t)(n_clouds + 1) * 4), io_pl = s.inout(planes, (size_t)n_clouds * 16),
+              o_st = s.out(state, (size_t)n_clouds * 4), o_info = info ? s.out(info, (size_t)n_clouds * 48) : -1;
+    hipStream_t st = p->ctx->stream;
+    int rc = s.upload(st);
+    if (rc) return rc;
+    planepost::Geo G = p->G;
+    G.dist_th = dist_th;
+    const size_t smem = align_up((size_t)std::max(max_n, 1) * 2, (size_t)16);
+    if (smem > 40 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)planepost::refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(planepost::refit_kernel, dim3(n_clouds), dim3(64), smem, st, G, n_clouds, s.dev<float>(i_pts), s.dev<int>(i_off), p->rng.as<int>(), s.dev<float>(io_pl),
+                       s.dev<int>(o_st), info ? s.dev<int>(o_info) : nullptr);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return s.download(st);
+}
+
+int planar_flag_matched_plane_points_dev(planar_ctx* ctx, int B, const float* d_Tcw, const float* d_coef, const uint8_t* d_matched, const int32_t* d_n_planes,
+                                         int pl_stride, const float* d_xw, int n_points, int points_shared, uint8_t* d_flags, int32_t* d_n_matches) {
+    PLANAR_REQUIRE(ctx && d_Tcw && d_coef && d_matched && d_n_planes && d_xw && d_flags, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && n_points >= 0 && pl_stride >= 1, PLANAR_EINVAL, "bad size");
+    if (d_n_matches) PLANAR_HIP_CHECK(hipMemsetAsync(d_n_matches, 0, (size_t)B * 4, ctx->stream));
+    if (n_points == 0) return PLANAR_OK;
+    hipLaunchKernelGGL(planepost::flag_points_kernel, dim3((n_points + 255) / 256, B), dim3(256), 0, ctx->stream, B, d_Tcw, d_coef, d_matched, d_n_planes, pl_stride, d_xw,
+                       n_points, points_shared, d_flags, d_n_matches);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_flag_matched_plane_points(planar_ctx* ctx, int B, const float* Tcw, const float* coef, const uint8_t* matched, const int32_t* n_planes, int pl_stride,
+                                     const float* xw, int n_points, int points_shared, uint8_t* flags, int32_t* n_matches) {
+    PLANAR_REQUIRE(ctx && Tcw && coef && matched && n_planes && xw && flags, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && n_points >= 0 && pl_stride >= 1, PLANAR_EINVAL, "bad size");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    const int i_T = s.in(Tcw, (size_t)B * 64), i_c = s.in(coef, (size_t)B * pl_stride * 16), i_m = s.in(matched, (size_t)B * pl_stride), i_n = s.in(n_planes, (size_t)B * 4),
+              i_x = s.in(xw, (size_t)(points_shared ? 1 : B) * n_points * 12), io_f = s.inout(flags, (size_t)B * n_points), o_nm = n_matches ? s.out(n_matches, (size_t)B * 4) : -1;
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    if ((rc = planar_flag_matched_plane_points_dev(ctx, B, s.dev<float>(i_T), s.dev<float>(i_c), s.dev<uint8_t>(i_m), s.dev<int32_t>(i_n), pl_stride, s.dev<float>(i_x), n_points,
+                                                   points_shared, s.dev<uint8_t>(io_f), n_matches ? s.dev<int32_t>(o_nm) : nullptr)))
+        return rc;
+    return s.download(ctx->stream);
+}
+
+int planar_merge_plane_points(planar_plane_clouds* p, const double* Twc, const float* frame_points, int n_frame, const float* map_points, int n_map, float leaf,
+                              float* out_points, int out_cap, int32_t* n_out) {
+    PLANAR_REQUIRE(p && Twc && n_out && out_points && (frame_points || !n_frame) && (map_points || !n_map), PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(n_frame >= 0 && n_map >= 0 && n_frame + n_map <= 65536 && leaf > 0.f, PLANAR_EINVAL, "bad size (at most 65536 points)");
+    PLANAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    const int n = n_frame + n_map;
+    Stager s;
+    const int i_T = s.in(Twc, 128), i_f = s.in(frame_points, (size_t)n_frame * 12), i_m = s.in(map_points, (size_t)n_map * 12), t_all = s.add(nullptr, nullptr, (size_t)std::max(n, 1) * 12),
+              t_out = s.add(nullptr, nullptr, (size_t)p->G.max_points * 12);
+    int32_t h[2] = {0, 0};
+    const int o_h = s.out(h, 8);
+    hipStream_t st = p->ctx->stream;
+    int rc = s.upload(st);
+    if (rc) return rc;
+    planepost::Geo G = p->G;
+    G.leaf = leaf;
+    if (n) hipLaunchKernelGGL(planepost::merge_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.dev<double>(i_T), s.dev<float>(i_f), n_frame, s.dev<float>(i_m), n_map, s.dev<float>(t_all));
+    hipLaunchKernelGGL(planepost::voxel_cloud_kernel, dim3(1), dim3(planepost::NT), p->smem, st, G, s.dev<float>(t_all), n, p->ws.as<unsigned char>(), s.dev<float>(t_out),
+                       s.dev<int>(o_h), s.dev<int>(o_h) + 1);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    if ((rc = s.download(st))) return rc;
+    if (h[1]) { set_error("merge_plane_points: more than %d voxels (or voxel index overflow)", p->G.max_points); return PLANAR_ECAPACITY; }
+    PLANAR_REQUIRE(h[0] <= out_cap, PLANAR_ECAPACITY, "out_cap too small");
+    *n_out = h[0];
+    if (h[0]) PLANAR_HIP_CHECK(hipMemcpy(out_points, s.dev<float>(t_out), (size_t)h[0] * 12, hipMemcpyDeviceToHost));
+    return PLANAR_OK;
+}
+
+}  // extern "C"

@@ -92,3 +92,104 @@ class SurfaceNormals:
     def compute_dev(self, d_depth, d_normals, B, K=(535.4, 539.2, 320.1, 247.6), depth_factor=1.0 / 5000.0, d_points=None, out_stride=None):
         check(self.L.planar_normals_compute_dev(self.h, d_depth, B, self.width, self.width * self.height, K[0], K[1], K[2], K[3], np.float32(depth_factor),
                                                 d_normals, d_points, out_stride or self.count))
+
+
+REFIT_INFO = ("iterations", "best_count", "s0", "s1", "s2", "n_inliers", "n_inliers_refined", "draws")
+
+
+def _refit_info(raw):
+    raw = np.asarray(raw, np.int32)
+    d = {k: int(raw[i]) for i, k in enumerate(REFIT_INFO)}
+    d["model"] = raw[8:12].copy().view(np.float32)
+    return d
+
+
+class PlaneClouds:
+    """The head of Frame::ComputePlanes (reference src/Frame.cc:652-692) with Frame::MaxPointDistanceFromPlane (:755-812): the detector's planes ->
+    mvPlanePoints (0.1 m voxel centroids) and mvPlaneCoefficients (RANSAC refit), planes failing Plane.DistanceThreshold dropped."""
+
+    def __init__(self, width: int = 640, height: int = 480, max_batch: int = 1, max_points: int = 8192, ctx: Context | None = None):
+        self.L = lib()
+        self.ctx = ctx or Context(0)
+        self.width, self.height, self.max_batch, self.max_points = width, height, max_batch, max_points
+        h = C.c_void_p()
+        check(self.L.planar_plane_clouds_create(self.ctx.h, width, height, max_batch, max_points, C.byref(h)))
+        self.h = h
+        ps = C.c_int()
+        check(self.L.planar_plane_clouds_stride(self.h, C.byref(ps), None))
+        self.pl_stride = ps.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.planar_plane_clouds_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def compute(self, depth, labels, planes, n_planes, dist_th=0.05, leaf=0.1, K=(535.4, 539.2, 320.1, 247.6), depth_factor=1.0 / 5000.0, debug=False):
+        """depth [B,H,W] u16, labels [B,H,W] i32, planes [B,max_planes,8] f64, n_planes [B] (PlaneDetection's outputs) -> per frame
+        dict(n, coef [n,4], src [n], pt_off [n+1], points [m,3]) (+ state / nvox / info per detector plane with debug=True)."""
+        d = np.ascontiguousarray(depth, np.uint16); lab = np.ascontiguousarray(labels, np.int32); pl = np.ascontiguousarray(planes, np.float64)
+        npl = np.ascontiguousarray(n_planes, np.int32)
+        B, H, W = d.shape
+        PS, MP = self.pl_stride, self.max_points
+        assert pl.shape == (B, PS, 8), pl.shape
+        n = np.zeros(B, np.int32); coef = np.zeros((B, PS, 4), np.float32); src = np.zeros((B, PS), np.int32); off = np.zeros((B, PS + 1), np.int32)
+        pts = np.zeros((B, MP, 3), np.float32)
+        state = np.zeros((B, PS), np.int32); nvox = np.zeros((B, PS), np.int32); info = np.zeros((B, PS, 12), np.int32)
+        check(self.L.planar_plane_clouds_compute(self.h, d.ctypes.data, B, W, W * H, K[0], K[1], K[2], K[3], np.float32(depth_factor), lab.ctypes.data, pl.ctypes.data,
+                                                 npl.ctypes.data, float(dist_th), np.float32(leaf), n.ctypes.data, coef.ctypes.data, src.ctypes.data, off.ctypes.data,
+                                                 pts.ctypes.data, state.ctypes.data if debug else None, nvox.ctypes.data if debug else None,
+                                                 info.ctypes.data if debug else None))
+        out = []
+        for b in range(B):
+            k = int(n[b])
+            r = dict(n=k, coef=coef[b, :k].copy(), src=src[b, :k].copy(), pt_off=off[b, :k + 1].copy(), points=pts[b, :off[b, k]].copy())
+            if debug:
+                P = int(npl[b])
+                r.update(state=state[b, :P].copy(), nvox=nvox[b, :P].copy(), info=[_refit_info(info[b, i]) for i in range(P)])
+            out.append(r)
+        return out
+
+    def compute_dev(self, d_depth, d_labels, d_planes, d_n_planes, B, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, dist_th=0.05, leaf=0.1,
+                    K=(535.4, 539.2, 320.1, 247.6), depth_factor=1.0 / 5000.0):
+        check(self.L.planar_plane_clouds_compute_dev(self.h, d_depth, B, self.width, self.width * self.height, K[0], K[1], K[2], K[3], np.float32(depth_factor), d_labels,
+                                                     d_planes, d_n_planes, float(dist_th), np.float32(leaf), d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, None, None, None))
+
+    def refit(self, planes, clouds, dist_th=0.05):
+        """Frame::MaxPointDistanceFromPlane on given clouds: planes [q,4], clouds: list of [n,3] -> (state [q], planes [q,4], info list)."""
+        planes = np.array(planes, np.float32).reshape(-1, 4).copy()
+        q = len(planes)
+        off = np.zeros(q + 1, np.int32)
+        off[1:] = np.cumsum([len(c) for c in clouds])
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float32).reshape(-1, 3) for c in clouds] + [np.zeros((1, 3), np.float32)]), np.float32)
+        state = np.zeros(q, np.int32); info = np.zeros((q, 12), np.int32)
+        check(self.L.planar_plane_refit(self.h, q, pts.ctypes.data, off.ctypes.data, float(dist_th), planes.ctypes.data, state.ctypes.data, info.ctypes.data))
+        return state, planes, [_refit_info(info[i]) for i in range(q)]
+
+    def merge(self, Twc, frame_points, map_points, leaf=0.1):
+        """The cloud half of MapPlane::UpdateCoefficientsAndPoints: -> merged voxel centroids [m,3]."""
+        T = np.ascontiguousarray(Twc, np.float64).reshape(16)
+        f = np.ascontiguousarray(frame_points, np.float32).reshape(-1, 3); m = np.ascontiguousarray(map_points, np.float32).reshape(-1, 3)
+        out = np.zeros((self.max_points, 3), np.float32); n = C.c_int32()
+        check(self.L.planar_merge_plane_points(self.h, T.ctypes.data, f.ctypes.data if len(f) else None, len(f), m.ctypes.data if len(m) else None, len(m), np.float32(leaf),
+                                               out.ctypes.data, self.max_points, C.byref(n)))
+        return out[:n.value].copy()
+
+
+def flag_matched_plane_points(Tcw, coef, matched, n_planes, xw, ctx: Context | None = None):
+    """Map::FlagMatchedPlanePoints for B frames: Tcw [B,16], coef [B,S,4], matched [B,S] u8, n_planes [B], xw [n,3] (shared) or [B,n,3] -> (flags [B,n] u8, n_matches [B])."""
+    L = lib(); ctx = ctx or Context(0)
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(-1, 16); B = len(Tcw)
+    coef = np.ascontiguousarray(coef, np.float32); matched = np.ascontiguousarray(matched, np.uint8); npl = np.ascontiguousarray(n_planes, np.int32)
+    xw = np.ascontiguousarray(xw, np.float32)
+    shared = xw.ndim == 2
+    npts = xw.shape[-2]
+    flags = np.zeros((B, npts), np.uint8); nm = np.zeros(B, np.int32)
+    check(L.planar_flag_matched_plane_points(ctx.h, B, Tcw.ctypes.data, coef.ctypes.data, matched.ctypes.data, npl.ctypes.data, coef.shape[1], xw.ctypes.data, npts, int(shared),
+                                             flags.ctypes.data, nm.ctypes.data))
+    return flags, nm

@@ -15,7 +15,7 @@ The sequence of the reference's tracking thread for one RGB-D frame (src/Trackin
 What is NOT the reference's code path and only stands in for the map it maintains (Map / KeyFrame / LocalMapping are out of scope):
 the local map of a stream is the previous two frames' own back-projected keypoints, the reference key frame's lines and the map planes are
 fixed per stream (set_map), and
-MapPoint::UpdateNormalAndDepth / the plane coefficient (n, -n.c) of Frame::ComputePlanes are a few torch element-wise ops here.
+MapPoint::UpdateNormalAndDepth is a few torch element-wise ops here.
 
 PyTorch supplies device memory, streams and events only.  Frame-batch parallelism: steps are pipelined `depth` deep - the tracking chain of
 step i - depth runs on its own stream beside the extraction launches of step i (points on the main stream, lines and planes on theirs)."""
@@ -35,7 +35,7 @@ class TrackPipeline:
                  run_fallback_matcher=True):
         from . import Context, ORBextractor, Optimizer, PlaneDetection
         from .lines import LineSegment
-        from .planes import SurfaceNormals
+        from .planes import PlaneClouds, SurfaceNormals
         from .synth import TUM3
         self.torch, self.B, self.W, self.H, self.depth = torch, B, W, H, depth
         self.cam = dict(cam or TUM3)
@@ -57,6 +57,8 @@ class TrackPipeline:
         self.lss = [LineSegment(W, H, B, c) for c in self.ctx_lsds]
         self.sns = [SurfaceNormals(W, H, B, c) for c in self.ctx_peacs]     # Frame::ComputePlanes: PEAC, then the surface normals, on the plane thread
         self.SN = self.sns[0].count
+        self.pcs = [PlaneClouds(W, H, B, ctx=c) for c in self.ctx_peacs]       # ... and before them the voxel clouds + RANSAC refit of every plane (Frame.cc:655-692)
+        self.plane_dist_th = 0.05                                               # Plane.DistanceThreshold (Examples/RGB-D/TUM*.yaml)
         self.opt = Optimizer(self.cam, ctx=self.ctx_t)
         self.PS = self.pds[0].max_planes
         self.run_fallback_matcher = run_fallback_matcher
@@ -78,6 +80,9 @@ class TrackPipeline:
         self.pls = [z((B, self.PS, 8), t.float64) for _ in range(NB)]
         self.npl = [z((B,), t.int32) for _ in range(NB)]
         self.snrm = [z((B, self.SN, 3), t.float32) for _ in range(NB)]
+        # Frame::mnPlaneNum / mvPlaneCoefficients / mvPlanePoints (+ the detector plane every kept plane came from)
+        self.pc = [dict(n=z((B,), t.int32), coef=z((B, self.PS, 4), t.float32), src=z((B, self.PS), t.int32), off=z((B, self.PS + 1), t.int32),
+                        pts=z((B, self.pcs[0].max_points, 3), t.float32), status=z((B,), t.int32)) for _ in range(NB)]
         self.n_snrm = t.full((B,), self.SN, dtype=t.int32, device=self.dev)
         self.kls = [z((B * 40 * KEYLINE_DTYPE.itemsize,), t.uint8) for _ in range(NB)]
         self.ldesc = [z((B, 40, 32), t.uint8) for _ in range(NB)]
@@ -106,7 +111,6 @@ class TrackPipeline:
         self.cm2 = z((B, S), t.int32); self.npair = z((B,), t.int32)
         self.lm = z((B, 40), t.int32); self.nlm = z((B,), t.int32)
         self.plm = z((3, B, self.PS), t.int32); self.nplm = z((B,), t.int32)
-        self.pl_coef = z((B, self.PS, 4), t.float32)
         self.mm = z((B, S), t.int32); self.nmm = z((B,), t.int32)
         self.blocked = z((B, S), t.uint8); self.lblocked = z((B, 40), t.uint8)
         self.pm_all = z((B, S), t.int32)
@@ -190,7 +194,7 @@ class TrackPipeline:
         m.ln_stride, m.ml_stride = 40, 40
         m.n_lines, m.line_eq, m.ln_match, m.ml_xw6 = self.nl[k].data_ptr(), self.leq[k].data_ptr(), self.lm.data_ptr(), self.kf["xw6"].data_ptr()
         m.pl_stride, m.mpl_stride, m.mpl_shared = self.PS, self.mp["coef"].shape[1], 0
-        m.n_planes, m.pl_coef, m.pl_match, m.mpl_coef = self.npl[k].data_ptr(), self.pl_coef.data_ptr(), self.plm.data_ptr(), self.mp["coef"].data_ptr()
+        m.n_planes, m.pl_coef, m.pl_match, m.mpl_coef = self.pc[k]["n"].data_ptr(), self.pc[k]["coef"].data_ptr(), self.plm.data_ptr(), self.mp["coef"].data_ptr()
         m.Tcw = Tcw.data_ptr()
         check(self.L.planar_pose_assemble_dev(self.ctx_t.h, C.byref(m), C.byref(self.pbs[which])))
 
@@ -211,6 +215,11 @@ class TrackPipeline:
         if side: side[0].record(sp)
         if "peac" not in self.skip:
             self.pds[k].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), B)
+        if "planepost" not in self.skip:
+            pc = self.pc[k]
+            self.pcs[k].compute_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), B, pc["n"].data_ptr(), pc["coef"].data_ptr(),
+                                    pc["src"].data_ptr(), pc["off"].data_ptr(), pc["pts"].data_ptr(), pc["status"].data_ptr(), dist_th=self.plane_dist_th,
+                                    K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
         if "normals" not in self.skip:
             self.sns[k].compute_dev(depth.data_ptr(), self.snrm[k].data_ptr(), B, K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
         if "lsd" not in self.skip:
@@ -292,17 +301,15 @@ class TrackPipeline:
                                                     self.h_valid[l].data_ptr(), self.zeros_S.data_ptr(), B, self.cm2.data_ptr(), self.npair.data_ptr()))
             if evs: evs["bf"].record(st)
             if cap is not None: snap("lm0", self.lm); snap("nlm0", self.nlm); snap("cm2", self.cm2); snap("npair", self.npair)
-            # plane coefficients (n, -n.c) of Frame::ComputePlanes (src/Frame.cc:664-672) from the PEAC planes {N, normal, centre, mse}
-            P = self.pls[k]
-            self.pl_coef[..., :3] = P[..., 1:4].float()
-            self.pl_coef[..., 3] = (-(P[..., 1:4] * P[..., 4:7]).sum(-1)).float()
+            # mvPlaneCoefficients / mnPlaneNum: the refitted coefficients of the planes Frame::ComputePlanes kept (planepost.hip, on the plane stream)
+            pc = self.pc[k]
             self.plm.fill_(-1)
-            check(L.planar_plane_search_by_coefficients_dev(self.ctx_t.h, B, self.npl[k].data_ptr(), self.PS, self.pl_coef.data_ptr(), self.pose.data_ptr(), 0,
+            check(L.planar_plane_search_by_coefficients_dev(self.ctx_t.h, B, pc["n"].data_ptr(), self.PS, pc["coef"].data_ptr(), self.pose.data_ptr(), 0,
                                                             self.mp["n"].data_ptr(), self.mp["coef"].shape[1], self.mp["valid"].data_ptr(), self.mp["coef"].data_ptr(),
                                                             self.mp["npts"].data_ptr(), self.mp["pts"].shape[2], self.mp["pts"].data_ptr(), self.plane_th.ctypes.data,
                                                             self.plm[0].data_ptr(), self.plm[2].data_ptr(), self.plm[1].data_ptr(), self.nplm.data_ptr()))
             if evs: evs["planes"].record(st)
-            if cap is not None: snap("pl_coef", self.pl_coef); snap("plm", self.plm); snap("nplm", self.nplm); snap("Rcm_new", self.Rcm_new)
+            if cap is not None: snap("pl_coef", pc["coef"]); snap("pl_n", pc["n"]); snap("pl_src", pc["src"]); snap("pl_off", pc["off"]); snap("pl_pts", pc["pts"]); snap("pl_status", pc["status"]); snap("plm", self.plm); snap("nplm", self.nplm); snap("Rcm_new", self.Rcm_new)
             self._assemble(0, k, self.pm, self.h_xw[l], self.h_valid[l], S, self.pose)
             self.opt.enqueue_dev(self.pbs[0], 1, 4, 10)     # TranslationOptimization
             A0 = self.pb_arrays[0]
@@ -374,6 +381,11 @@ class TrackPipeline:
         check(self.ex.L.planar_orb_check(self.ex.h))
         for q in self.pds:
             check(q.L.planar_peac_check(q.h, self.B))
+        for k, pc in enumerate(self.pc):
+            bad = pc["status"].nonzero()
+            if len(bad):
+                raise RuntimeError(f"plane post-processing: buffer set {k}, frame {int(bad[0])} reported code {int(pc['status'][bad[0]])} "
+                                   "(3 = more voxels than max_points / coordinate range, 4 = sampler table exhausted)")
 
 
 def build_map(gray0, depth0, cam, torch_dev=None, seed=0, n_map_planes=8, n_plane_pts=128, n_normals=4096):

@@ -821,3 +821,82 @@ def run_ref_line3d(keylines, depth, seed, cam=(535.4, 539.2, 320.1, 247.6), fact
         buf = open(fout, "rb").read()
     rec = np.frombuffer(buf, np.dtype([("depth_line", "<f4"), ("lines3d", "<f8", 6), ("good", "u1"), ("direction", "<f8", 3), ("n_inliers", "<i4")]), n)
     return {k: rec[k].copy() for k in rec.dtype.names}
+
+
+# ---- plane post-processing (oracle/planepost_oracle.cpp; PCL VoxelGrid + SACSegmentation restated, PARITY UNPINNED) ----
+REFIT_INFO = ("iterations", "best_count", "s0", "s1", "s2", "n_inliers", "n_inliers_refined", "draws")
+
+
+def _refit_info(raw):
+    raw = np.asarray(raw, np.int32)
+    d = {k: int(raw[i]) for i, k in enumerate(REFIT_INFO)}
+    d["model"] = raw[8:12].copy().view(np.float32)
+    return d
+
+
+def voxel_grid(pts, leaf=0.1, want_exact=False):
+    """pcl::VoxelGrid centroids [m,3] float32 of pts [n,3] (+ exact double centroids and point counts of the same voxels)."""
+    L = lib()
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+    n = len(pts)
+    out = np.zeros((max(n, 1), 3), np.float32); ex = np.zeros((max(n, 1), 3)); cnt = np.zeros(max(n, 1), np.int32)
+    L.orc_voxel_grid.restype = C.c_int
+    m = L.orc_voxel_grid(C.c_void_p(pts.ctypes.data), n, C.c_float(leaf), C.c_void_p(out.ctypes.data), max(n, 1), C.c_void_p(ex.ctypes.data) if want_exact else None,
+                         C.c_void_p(cnt.ctypes.data) if want_exact else None)
+    assert m >= 0, m
+    return (out[:m].copy(), ex[:m].copy(), cnt[:m].copy()) if want_exact else out[:m].copy()
+
+
+def plane_refit(plane, pts, dis_th):
+    """Frame::MaxPointDistanceFromPlane -> (state: 0 kept / 1 distance / 2 no inliers, plane [4] f32, info)."""
+    L = lib()
+    plane = np.array(plane, np.float32).reshape(4).copy(); pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+    info = np.zeros(12, np.int32)
+    L.orc_plane_refit.restype = C.c_int
+    st = L.orc_plane_refit(C.c_void_p(plane.ctypes.data), C.c_void_p(pts.ctypes.data), len(pts), C.c_double(dis_th), C.c_void_p(info.ctypes.data))
+    return st, plane, _refit_info(info)
+
+
+def plane_clouds(depth, labels, planes, dis_th=0.05, leaf=0.1, cam=(535.4, 539.2, 320.1, 247.6), factor=1.0 / 5000.0):
+    """The head of Frame::ComputePlanes for one frame: dict(n, coef [n,4], src [n], pt_off [n+1], points [m,3], state [P], nvox [P], info [P])."""
+    L = lib()
+    depth = np.ascontiguousarray(depth, np.uint16); labels = np.ascontiguousarray(labels, np.int32); planes = np.ascontiguousarray(planes, np.float64).reshape(-1, 8)
+    H, W = depth.shape
+    P = len(planes)
+    capP, capN = max(P, 1), 1 << 16
+    coef = np.zeros((capP, 4), np.float32); src = np.zeros(capP, np.int32); off = np.zeros(capP + 1, np.int32); pts = np.zeros((capN, 3), np.float32)
+    state = np.zeros(capP, np.int32); nvox = np.zeros(capP, np.int32); info = np.zeros((capP, 12), np.int32)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    L.orc_plane_clouds.restype = C.c_int
+    n = L.orc_plane_clouds(p(depth), W, H, W, C.c_float(np.float32(factor)), C.c_float(cam[0]), C.c_float(cam[1]), C.c_float(cam[2]), C.c_float(cam[3]), p(labels), p(planes), P,
+                           C.c_double(dis_th), C.c_float(leaf), p(coef), p(src), p(off), p(pts), capP, capN, p(state), p(nvox), p(info))
+    assert n >= 0, n
+    return dict(n=n, coef=coef[:n].copy(), src=src[:n].copy(), pt_off=off[:n + 1].copy(), points=pts[:off[n]].copy(), state=state[:P].copy(), nvox=nvox[:P].copy(),
+                info=[_refit_info(info[i]) for i in range(P)])
+
+
+def flag_matched_plane_points(Tcw, coef, matched, xw):
+    L = lib()
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16); coef = np.ascontiguousarray(coef, np.float32).reshape(-1, 4)
+    matched = np.ascontiguousarray(matched, np.uint8); xw = np.ascontiguousarray(xw, np.float32).reshape(-1, 3)
+    flags = np.zeros(len(xw), np.uint8)
+    L.orc_flag_matched_plane_points.restype = C.c_int
+    nm = L.orc_flag_matched_plane_points(C.c_void_p(Tcw.ctypes.data), C.c_void_p(coef.ctypes.data), C.c_void_p(matched.ctypes.data), len(coef), C.c_void_p(xw.ctypes.data),
+                                         len(xw), C.c_void_p(flags.ctypes.data))
+    return flags, nm
+
+
+def merge_plane_points(T, frame_pts, map_pts, leaf=0.1):
+    L = lib()
+    T = np.ascontiguousarray(T, np.float64).reshape(16); f = np.ascontiguousarray(frame_pts, np.float32).reshape(-1, 3); m = np.ascontiguousarray(map_pts, np.float32).reshape(-1, 3)
+    out = np.zeros((len(f) + len(m) + 1, 3), np.float32)
+    L.orc_merge_plane_points.restype = C.c_int
+    n = L.orc_merge_plane_points(C.c_void_p(T.ctypes.data), C.c_void_p(f.ctypes.data), len(f), C.c_void_p(m.ctypes.data), len(m), C.c_float(leaf), C.c_void_p(out.ctypes.data), len(out))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def sac_rnd(n, seed=12345):
+    out = np.zeros(n, np.int32)
+    lib().orc_sac_rnd(C.c_uint32(seed), n, C.c_void_p(out.ctypes.data))
+    return out

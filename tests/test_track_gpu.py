@@ -122,12 +122,22 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
         n, nlst = int(c["n"][b]), int(c["last_n"][b])
         wm, wn = ol.match_orb_points(c["desc"][b, :n], c["last_desc"][b, :nlst], c["last_valid"][b, :nlst], np.zeros(nlst, np.uint8), np.full(n, -1, np.int32))
         assert np.array_equal(wm, c["cm2"][b, :n]) and wn == c["npair"][b]
-    # ---- plane coefficients + PlaneMatcher ----
-    P = c["pls"]
-    coef = np.zeros((B, PS, 4), np.float32)
-    coef[..., :3] = P[..., 1:4].astype(np.float32); coef[..., 3] = (-(P[..., 1:4] * P[..., 4:7]).sum(-1)).astype(np.float32)
-    assert np.array_equal(coef, c["pl_coef"])
-    a, v, p, npm = ol.plane_search_by_coefficients(dict(n=c["npl"], coef=coef, Tcw=c["pose_in"]), dict(n=mp["n"], valid=mp["valid"], coef=mp["coef"], npts=mp["npts"], pts=mp["pts"]))
+    # ---- Frame::ComputePlanes' voxel clouds + refit (mvPlaneCoefficients, mnPlaneNum), then PlaneMatcher on exactly those ----
+    assert not c["pl_status"].any()
+    for b in range(0, B, 5):
+        npl = int(c["npl"][b])
+        want = ol.plane_clouds(d[b], c["lab"][b].reshape(H, W), c["pls"][b, :npl])
+        k = want["n"]
+        assert int(c["pl_n"][b]) == k and np.array_equal(c["pl_src"][b, :k], want["src"]) and np.array_equal(c["pl_off"][b, :k + 1], want["pt_off"])
+        assert np.abs(c["pl_pts"][b, :want["pt_off"][k]] - want["points"]).max(initial=0) < 2e-5
+        for q in range(k):                      # the refit equals the oracle's on the kernel's own cloud (tests/test_planepost_gpu.py explains the two tolerances)
+            P = c["pls"][b, want["src"][q]]
+            c0 = np.array([P[1], P[2], P[3], -(P[1] * P[4] + P[2] * P[5] + P[3] * P[6])]).astype(np.float32)
+            st, pl, _ = ol.plane_refit(c0, c["pl_pts"][b, want["pt_off"][q]:want["pt_off"][q + 1]], 0.05)
+            assert st == 0 and np.abs(pl - c["pl_coef"][b, q]).max() < 1e-6
+        assert np.abs(c["pl_coef"][b, :k] - want["coef"]).max(initial=0) < 2e-3
+    coef = c["pl_coef"]
+    a, v, p, npm = ol.plane_search_by_coefficients(dict(n=c["pl_n"], coef=coef, Tcw=c["pose_in"]), dict(n=mp["n"], valid=mp["valid"], coef=mp["coef"], npts=mp["npts"], pts=mp["pts"]))
     assert np.array_equal(a, c["plm"][0]) and np.array_equal(p, c["plm"][1]) and np.array_equal(v, c["plm"][2]) and np.array_equal(npm, c["nplm"])
     # ---- assembled translation problem + TranslationOptimization ----
     T = c["pbT"]
