@@ -222,6 +222,7 @@ def main():
     alg = orb_algorithmic_bytes(ex, avg_kp)
     cand = {k: (v[0] / max(1, v[1]), alg.get(k, 0) * B) for k, v in prof.items()}          # (avg launch ms, algorithmic bytes per launch)
     quality = None
+    t_pc_pts = lambda q: torch.gather(q.pc[0]["off"], 1, q.pc[0]["n"].long().unsqueeze(1)).float().mean().item()     # pt_off[b][n[b]] = voxel centroids kept
     if full:
         # PEAC: read u16 depth + write int32 labels (1 843 200 B/frame); peac_blocks + peac_ahc + peac_order + peac_refine bracketed together
         pk = "peac_blocks+peac_ahc+peac_refine"
@@ -242,7 +243,8 @@ def main():
         lm_it = float(A1["lm_iters"].float().mean().item())
         cand["pose_opt_kernel"] = (stage_ms["assemble+pose_opt_4x10"], 65130 * B * 2 * max(lm_it, 1.0))
         kernels["pose_opt_kernel"] = {"ms_per_step": round(stage_ms["assemble+pose_opt_4x10"], 4), "launches_per_step": 2, "avg_lm_iterations": round(lm_it, 2)}
-        quality = {"avg_planes_per_frame": round(float(tp.npl[0].float().mean().item()), 2), "avg_lines_per_frame": round(float(tp.nl[0].float().mean().item()), 2),
+        quality = {"avg_planes_per_frame": round(float(tp.npl[0].float().mean().item()), 2), "avg_planes_kept_per_frame": round(float(tp.pc[0]["n"].float().mean().item()), 2),
+                   "avg_plane_cloud_points_per_frame": round(float(t_pc_pts(tp)), 1), "avg_lines_per_frame": round(float(tp.nl[0].float().mean().item()), 2),
                    "avg_projection_matches_per_frame": round(float(tp.nm.float().mean().item()), 1),
                    "avg_local_map_matches_per_frame": round(float(tp.nmm.float().mean().item()), 1),
                    "avg_line_matches_per_frame": round(float((tp.lm >= 0).float().sum(1).mean().item()), 1),
@@ -252,7 +254,8 @@ def main():
     dom = max(cand, key=lambda k: cand[k][0] * (kernels[k]["launches_per_step"] if k in prof else 1))
     dom_ms, dom_bytes = cand[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    per_frame = 1961064 + (1843200 + 312160 if full else 0) + (72000 + 118000 + 65130 * 2 * 40 if full else 0)
+    # ORB; + PEAC (depth in, labels out) + normals; + plane clouds (labels + depth in); + matchers + two pose problems
+    per_frame = 1961064 + (1843200 + 312160 if full else 0) + (1843200 if full else 0) + (72000 + 118000 + 65130 * 2 * 40 if full else 0)
     # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this
     # command, KB per launch, summed over the stage's kernels); raw counter sums (narrow gathers: no wide-read correction applied)
     traffic = None
@@ -287,7 +290,8 @@ def main():
         h_out = [dict(kps=torch.empty((B, S, 7), dtype=torch.float32).pin_memory(), desc=torch.empty((B, S, 32), dtype=torch.uint8).pin_memory(),
                       kls=torch.empty(tp.kls[0].shape, dtype=torch.uint8).pin_memory(), ldesc=torch.empty((B, 40, 32), dtype=torch.uint8).pin_memory(),
                       lab=torch.empty((B, H * W), dtype=torch.int32).pin_memory(), pls=torch.empty(tp.pls[0].shape, dtype=torch.float64).pin_memory(),
-                      pose=torch.empty((B, 16), dtype=torch.float32).pin_memory()) for _ in range(2)]
+                      pose=torch.empty((B, 16), dtype=torch.float32).pin_memory(), plc=torch.empty((B, tp.PS, 4), dtype=torch.float32).pin_memory(),
+                      plp=torch.empty((B, 1024, 3), dtype=torch.float32).pin_memory()) for _ in range(2)]
         s_in, s_out = torch.cuda.Stream(device=local_rank), torch.cuda.Stream(device=local_rank)
         ev_up = [torch.cuda.Event() for _ in range(NB)]
         ev_dn = [torch.cuda.Event() for _ in range(NB)]
@@ -316,15 +320,15 @@ def main():
                         o = h_out[q & 1]
                         o["kps"].copy_(tp.kps[kj], non_blocking=True); o["desc"].copy_(tp.desc[kj], non_blocking=True); o["kls"].copy_(tp.kls[kj], non_blocking=True)
                         o["ldesc"].copy_(tp.ldesc[kj], non_blocking=True); o["lab"].copy_(tp.lab[kj], non_blocking=True); o["pls"].copy_(tp.pls[kj], non_blocking=True)
-                        o["pose"].copy_(tp.pose, non_blocking=True)
+                        o["pose"].copy_(tp.pose, non_blocking=True); o["plc"].copy_(tp.pc[kj]["coef"], non_blocking=True); o["plp"].copy_(tp.pc[kj]["pts"][:, :1024], non_blocking=True)
                         ev_out[kj].record(s_out)
             tp.drain()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-        per_frame_in, per_frame_out = W * H * 3, S * 60 + 40 * 100 + W * H * 4 + 128 * 64 + 64
+        per_frame_in, per_frame_out = W * H * 3, S * 60 + 40 * 100 + W * H * 4 + 128 * 64 + 64 + 128 * 16 + 1024 * 12
         pcie = {"value": round(B * args.pcie_steps / dt, 1), "unit": "frames/s", "steps": args.pcie_steps,
                 "h2d_bytes_per_frame": per_frame_in, "d2h_bytes_per_frame": per_frame_out,
-                "note": "pinned host buffers; gray + depth up, keypoints / descriptors / key lines / label image / planes / pose down, on copy streams beside the step"}
+                "note": "pinned host buffers; gray + depth up, keypoints / descriptors / key lines / label image / planes / plane coefficients + first 1024 cloud points / pose down, on copy streams beside the step"}
 
     # ---- CPU baseline: the oracle restatement of the same stages on this box's host cores (tools/cpu_baseline.py) ----
     cpu = None
@@ -372,12 +376,11 @@ def main():
                    "reps": args.latency_reps, "note": "median wall ms per call, one frame, host buffers in and out"}
         latency["extract_3_stages_serial_sum"] = round(latency["orb_extract"] + latency["lsd_lbd_extract"] + latency["peac_segment"], 3)
 
-    workload = ("configs[2]+[3] as the reference's per-frame Track(): extract (ORB + LSD/LBD lines + PEAC planes on three streams, ComputeStereoFromRGBD) -> TrackManhattanFrame -> "
+    workload = ("configs[2]+[3] as the reference's per-frame Track(): extract (ORB + LSD/LBD lines + isLineGood + PEAC planes + voxel clouds / RANSAC refit + surface normals on three streams, ComputeStereoFromRGBD) -> TrackManhattanFrame -> "
                 "SearchByProjection(Cur, Last) + LSD SearchByDescriptor + MatchORBPoints + PlaneMatcher -> TranslationOptimization 4x10 -> isInFrustum + SearchByProjection(map) + "
                 "LSD SearchByProjection -> PoseOptimization 4x10 -> UnprojectStereo; pose problems assembled on the device from the matchers' outputs"
                 if full else "configs[1]: ORB only, 640x480 gray, 8-level pyramid, 1000 keypoints + 256-bit rBRIEF")
-    nyi = (["PCL voxel-grid / RANSAC refit of the plane coefficients (Frame::ComputePlanes)",
-            "map maintenance: the local map is the previous two frames' keypoints, key-frame lines and map planes are fixed per stream"]
+    nyi = (["map maintenance: the local map is the previous two frames' keypoints, key-frame lines and map planes are fixed per stream"]
            if full else ["LSD/LBD lines", "PEAC planes", "matching", "pose optimisation"])
     out = {
         "metric": "RGB-D frames/sec (extract+match+pose-opt) @640x480; 1->8-GPU batch scaling",

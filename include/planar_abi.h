@@ -555,9 +555,14 @@ int planar_track_manhattan_frame_dev(planar_ctx* ctx, int B, const float* d_R_la
  *   state / nvox / info (optional, per DETECTOR plane, stride pl_stride / pl_stride / pl_stride * 12): 0 kept, 1 distance, 2 no inliers; voxels;
  *                                  {RANSAC iterations, best count, best sample[3], inliers, inliers after the refit, sampler draws, model[4] bits}  */
 typedef struct planar_plane_clouds planar_plane_clouds;
-int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* power of two, <= 8192 */, planar_plane_clouds** out);
+int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* voxels per frame: a power of two <= 4096; the kernel holds 16 * max_points + 41 K bytes of LDS */, planar_plane_clouds** out);
 void planar_plane_clouds_destroy(planar_plane_clouds* pc);
 int planar_plane_clouds_stride(const planar_plane_clouds* pc, int* pl_stride, int* max_points);
+/* Profiling aid, as planar_peac_read_timing: per-frame phase timestamps of the last call, out[B][16] (100 MHz ticks: [0] entry, [1] table cleared, [2] voxel sums,
+ * [3] sorted + centroids, [4] refit, [5] end; [6] voxels, [7] planes; [8..11] shader-clock cycles of wavefront 0 in the voxel-sum phase: row loops, tile ends,
+ * executions of the parked-run insertion and the cycles in it). */
+int planar_plane_clouds_set_timing(planar_plane_clouds* pc, int enable);
+int planar_plane_clouds_read_timing(planar_plane_clouds* pc, int B, int64_t* out);
 int planar_plane_clouds_compute(planar_plane_clouds* pc, const uint16_t* depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy, float cx,
                                 float cy, float depth_factor, const int32_t* labels, const double* planes, const int32_t* n_planes, double dist_th, float leaf,
                                 int32_t* n_out, float* coef, int32_t* src, int32_t* pt_off, float* points, int32_t* state, int32_t* nvox, int32_t* info);

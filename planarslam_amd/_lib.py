@@ -172,6 +172,8 @@ _SIGS = {
                                             C.c_void_p, C.c_int]),
     "planar_plane_clouds_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_plane_clouds_destroy": (None, [C.c_void_p]),
+    "planar_plane_clouds_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "planar_plane_clouds_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "planar_plane_clouds_stride": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "planar_plane_clouds_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_double, C.c_float] + [C.c_void_p] * 8),

@@ -30,26 +30,39 @@ namespace planepost {
 
 constexpr int NT = 512;
 constexpr int MAXP = 128;                 // planar_peac_max_planes()
-constexpr int TCAP = 16384;               // hash slots per frame
 constexpr int NRNG = 32768;               // sampler values kept (a refit that needs more reports PLANAR_ECAPACITY)
 constexpr double FIX_SCALE = 68719476736.0;   // 2^36: the voxel sums are fixed point, exact for every float of magnitude 2^-13 .. 2^7 m
 constexpr int VOX_BIAS = 8192;            // voxel coordinates floor(x / leaf) are kept in 14 bits each
 constexpr unsigned long long EMPTY = ~0ull;
 
 struct Geo {
-    int W, H, max_points, pl_stride;
+    int W, H, max_points, pl_stride, tcap;      // tcap = 2 * max_points key slots (LDS)
     float fx, fy, cx, cy, factor, leaf;
-    double dist_th, log_probability;
+    double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
     size_t ws_stride, off_cnt, off_sum, off_cent;
 };
 
 struct Pt { float x, y, z; };
-// PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:45-52) in double, narrowed as Frame.cc:659-661 does
+// PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:45-52) in double, narrowed as Frame.cc:659-661 does: x = (float)(((double)px - cx) * z / fx).
+// The double division is replaced by a multiplication with 1 / fx where that provably gives the same FLOAT: the product is within 2.5 double ulps of
+// the correctly rounded quotient, so the two can only round to different floats when a float rounding boundary (low 29 mantissa bits = 0x10000000)
+// lies that close; those rare values take the division.
+__device__ __forceinline__ double mul_rcp(double n, double rd, bool& near) {
+    const double t = n * rd;
+    const int low = (int)((unsigned)__double_as_longlong(t) & 0x1fffffffu) - 0x10000000;
+    near = low >= -8 && low <= 8;
+    return t;
+}
 __device__ __forceinline__ Pt cam_point(const Geo& G, unsigned short d, int px, int py) {
     const double z = (double)d * (double)G.factor;
-    const double x = ((double)px - (double)G.cx) * z / (double)G.fx;
-    const double y = ((double)py - (double)G.cy) * z / (double)G.fy;
-    return {(float)x, (float)y, (float)z};
+    const double nx = ((double)px - (double)G.cx) * z, ny = ((double)py - (double)G.cy) * z;
+    bool near_x, near_y;
+    double tx = mul_rcp(nx, G.rfx, near_x), ty = mul_rcp(ny, G.rfy, near_y);
+    if (__ballot(near_x || near_y) != 0ull) {         // a wave-level branch (about one wavefront in 10^5 takes it): the divisions stay out of the common path
+        if (near_x) tx = nx / (double)G.fx;
+        if (near_y) ty = ny / (double)G.fy;
+    }
+    return {(float)tx, (float)ty, (float)z};
 }
 
 // PCL's voxel index is idx = (i0 - min_b0) + (i1 - min_b1) * div_b0 + (i2 - min_b2) * div_b0 * div_b1 with i = floor(x * inv_leaf) (the float subtraction
@@ -203,12 +216,19 @@ __device__ __forceinline__ int sac_plane(const Geo& G, const float* __restrict__
     // selectWithinDistance + computeMeanAndCovarianceMatrix: nine float chains over the inliers in index order, lane t owns accumulator t
     float acc = 0.f;
     int n_inl = 0;
-    for (int i = 0; i < n; i++) {
-        const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-        if ((double)fabsf(plane_dot(bm, x, y, z)) < threshold) {
-            n_inl++;
-            const float u = lane < 3 ? x : (lane < 5 ? y : (lane == 5 ? z : (lane == 6 ? x : (lane == 7 ? y : z))));
-            const float v = (lane == 0) ? x : ((lane == 1 || lane == 3) ? y : ((lane == 2 || lane == 4 || lane == 5) ? z : 1.0f));
+    for (int i0 = 0; i0 < n; i0 += 64) {            // 64 points per coalesced read; the inliers among them are then walked in index order
+        const int i = i0 + lane;
+        float x = 0.f, y = 0.f, z = 0.f;
+        bool in = false;
+        if (i < n) { x = pts[i * 3]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2]; in = (double)fabsf(plane_dot(bm, x, y, z)) < threshold; }
+        unsigned long long mask = __ballot(in);
+        n_inl += __popcll(mask);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float qx = __shfl(x, j), qy = __shfl(y, j), qz = __shfl(z, j);
+            const float u = lane < 3 ? qx : (lane < 5 ? qy : (lane == 5 ? qz : (lane == 6 ? qx : (lane == 7 ? qy : qz))));
+            const float v = (lane == 0) ? qx : ((lane == 1 || lane == 3) ? qy : ((lane == 2 || lane == 4 || lane == 5) ? qz : 1.0f));
             acc += lane < 6 ? u * v : u;
         }
     }
@@ -282,7 +302,7 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
                                                           const int* __restrict__ labels_all, const double* __restrict__ planes_all, int planes_stride,
                                                           const int* __restrict__ n_planes, const int* __restrict__ rng, unsigned char* ws_all, int* n_out,
                                                           float* coef_out, int* src_out, int* off_out, float* pts_out, int* status, int* state_out,
-                                                          int* nvox_out, int* info_out) {
+                                                          int* nvox_out, int* info_out, long long* timing) {
     extern __shared__ unsigned long long s_list[];        // max_points keys; the refit's shuffle array (u16) reuses it
     __shared__ int s_first[MAXP], s_last[MAXP], s_state[MAXP], s_k[MAXP], s_o[MAXP + 1];
     __shared__ float s_coef[MAXP][4];
@@ -293,7 +313,6 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
     const int* lab = labels_all + (size_t)b * HW;
     const double* planes = planes_all + (size_t)b * planes_stride * 8;
     unsigned char* ws = ws_all + (size_t)b * G.ws_stride;
-    unsigned long long* tkey = (unsigned long long*)ws;
     unsigned* tcnt = (unsigned*)(ws + G.off_cnt);
     unsigned long long* tsum = (unsigned long long*)(ws + G.off_sum);
     float* cent = (float*)(ws + G.off_cent);
@@ -301,79 +320,139 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
     if (npl > MAXP) npl = MAXP;
     if (npl > G.pl_stride) npl = G.pl_stride;
     const float inv = 1.0f / G.leaf;
+    const int TC = G.tcap;
+    long long* tmark = timing ? timing + (size_t)b * 16 : nullptr;     // 100 MHz ticks at the phase boundaries (profiling aid)
+    auto mark = [&](int q) { if (tmark && tid == 0) tmark[q] = wall_clock64(); };
+    mark(0);
 
-    for (int i = tid; i < TCAP; i += NT) { tkey[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TCAP + i] = 0ull; tsum[2 * TCAP + i] = 0ull; }
+    for (int i = tid; i < TC; i += NT) { s_list[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TC + i] = 0ull; tsum[2 * TC + i] = 0ull; }
     for (int i = tid; i < MAXP; i += NT) { s_first[i] = 0; s_last[i] = 0; s_state[i] = 0; }
     if (tid == 0) { s_n = 0; s_err = 0; s_kept = 0; }
     __threadfence();
     __syncthreads();
 
-    // ---- B: voxel sums ----
-    if (!s_err)
-    for (int base = tid * 8; base < HW; base += NT * 8) {
-        int l8[8];
-        if (base + 8 <= HW) {
-            const int4 u = *(const int4*)(lab + base), v = *(const int4*)(lab + base + 4);
-            l8[0] = u.x; l8[1] = u.y; l8[2] = u.z; l8[3] = u.w; l8[4] = v.x; l8[5] = v.y; l8[6] = v.z; l8[7] = v.w;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; q++) l8[q] = base + q < HW ? lab[base + q] : -1;
-        }
-        int py = base / G.W, px = base - py * G.W;
-        unsigned long long cur = EMPTY;
-        unsigned cnt = 0;
-        long long sx = 0, sy = 0, sz = 0;
-        auto flush = [&]() {
-            if (cur == EMPTY) return;
-            unsigned h = hash64(cur) & (TCAP - 1);
-            for (int probe = 0; probe < TCAP; probe++) {
-                const unsigned long long k = atomicCAS(&tkey[h], EMPTY, cur);
+    mark(1);
+    // ---- B: voxel sums.  A wavefront takes a tile of 64 columns x ROWS rows and every lane walks DOWN its column: the 64 labels / depths of a row are
+    //      one coalesced read, and a lane sums its run of equal (plane, voxel) in registers.  A finished run goes to the wavefront's own 128-entry LDS
+    //      table (CAS on the key, four LDS atomics); at the end of the tile the table's entries - one per voxel the tile touched - go to the frame's
+    //      tables: an LDS CAS on the key table for the slot, then four fire-and-forget global atomics on the slot's count and sums.  A run that finds the
+    //      small table crowded goes to the frame's tables directly.  All sums are integers: the path taken does not change the result. ----
+    {
+        constexpr int ROWS = 60, UNR = 4, MINI = 128;
+        __shared__ unsigned long long s_mk[NT / 64][MINI], s_ms[NT / 64][3][MINI];
+        __shared__ unsigned s_mc[NT / 64][MINI];
+        unsigned long long* mk = s_mk[wave];
+        unsigned* mc = s_mc[wave];
+        auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+        auto to_frame = [&](unsigned long long key, unsigned cnt, unsigned long long sx, unsigned long long sy, unsigned long long sz) {
+            unsigned h = hash64(key) & (unsigned)(TC - 1);
+            for (int probe = 0; probe < TC; probe++) {
+                const unsigned long long k = atomicCAS(&s_list[h], EMPTY, key);
                 if (k == EMPTY) { if (atomicAdd(&s_n, 1) >= G.max_points) s_err = 3; }
-                if (k == EMPTY || k == cur) {
+                if (k == EMPTY || k == key) {
                     atomicAdd(&tcnt[h], cnt);
-                    atomicAdd(&tsum[h], (unsigned long long)sx); atomicAdd(&tsum[TCAP + h], (unsigned long long)sy); atomicAdd(&tsum[2 * TCAP + h], (unsigned long long)sz);
+                    atomicAdd(&tsum[h], sx); atomicAdd(&tsum[TC + h], sy); atomicAdd(&tsum[2 * TC + h], sz);
                     return;
                 }
-                h = (h + 1) & (TCAP - 1);
+                h = (h + 1) & (unsigned)(TC - 1);
             }
             s_err = 3;
         };
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int l = l8[q];
-            if (l >= 0 && l < npl) {
-                const Pt p = cam_point(G, D[(size_t)py * pitch_px + px], px, py);
-                unsigned long long key;
-                if (!voxel_key(p.x, p.y, p.z, inv, (unsigned)l, key)) s_err = 3;
-                else {
-                    if (key != cur) { flush(); cur = key; cnt = 0; sx = sy = sz = 0; }
-                    cnt++;
-                    sx += __double2ll_rn((double)p.x * FIX_SCALE); sy += __double2ll_rn((double)p.y * FIX_SCALE); sz += __double2ll_rn((double)p.z * FIX_SCALE);
+        long long c_rows = 0, c_end = 0, c_park = 0, n_park = 0;
+        const int strips = (G.W + 63) / 64, tiles = strips * ((G.H + ROWS - 1) / ROWS);
+        for (int tile = wave; tile < tiles; tile += NT / 64) {
+            const int px = (tile % strips) * 64 + lane, y0 = (tile / strips) * ROWS, y1 = min(y0 + ROWS, G.H);
+            const bool col = px < G.W;
+            for (int e = lane; e < MINI; e += 64) { mk[e] = EMPTY; mc[e] = 0u; s_ms[wave][0][e] = 0ull; s_ms[wave][1][e] = 0ull; s_ms[wave][2][e] = 0ull; }
+            wfence();
+            // the run being summed (cur) and the last finished one (pend).  Finished runs are parked: the insertion code below runs - for every lane
+            // that has something parked, together - only when some lane finishes a second run, i.e. every ten rows or so instead of at every row
+            unsigned long long cur = EMPTY, pend = EMPTY;
+            unsigned cnt = 0, pcnt = 0;
+            double sx = 0, sy = 0, sz = 0;               // a run's sums: doubles (a run is at most ROWS floats of one voxel), fixed point from there on
+            long long psx = 0, psy = 0, psz = 0;
+            auto flush_parked = [&]() {
+                if (pend != EMPTY) {
+                    unsigned h = (hash64(pend) >> 7) & (MINI - 1);
+                    bool done = false;
+                    for (int probe = 0; probe < 8 && !done; probe++) {
+                        const unsigned long long k = atomicCAS(&mk[h], EMPTY, pend);
+                        if (k == EMPTY || k == pend) {
+                            atomicAdd(&mc[h], pcnt);
+                            atomicAdd(&s_ms[wave][0][h], (unsigned long long)psx); atomicAdd(&s_ms[wave][1][h], (unsigned long long)psy); atomicAdd(&s_ms[wave][2][h], (unsigned long long)psz);
+                            done = true;
+                        }
+                        h = (h + 1) & (MINI - 1);
+                    }
+                    if (!done) to_frame(pend, pcnt, (unsigned long long)psx, (unsigned long long)psy, (unsigned long long)psz);
+                    pend = EMPTY;
                 }
+            };
+            int l4[UNR], ln[UNR];
+            unsigned short d4[UNR], dn[UNR];
+            const int pxc = min(px, G.W - 1);
+            auto load = [&](int yb, int* l, unsigned short* d) {        // rows / columns outside the tile read a clamped address and are masked
+#pragma unroll
+                for (int q = 0; q < UNR; q++) {
+                    const int yy = min(yb + q, G.H - 1);
+                    const int lv = lab[(size_t)yy * G.W + pxc];
+                    d[q] = D[(size_t)yy * pitch_px + pxc];
+                    l[q] = (col && yb + q < y1) ? lv : -1;
+                }
+            };
+            const long long t_r0 = clock64();
+            load(y0, l4, d4);
+            for (int yb = y0; yb < y1; yb += UNR) {
+                load(yb + UNR, ln, dn);                       // the next rows are in flight while these are summed
+#pragma unroll
+                for (int q = 0; q < UNR; q++) {
+                    const int l = l4[q];
+                    const bool on = l >= 0 && l < npl;
+                    Pt p = {0.f, 0.f, 0.f};
+                    unsigned long long key = cur;
+                    bool fin = false;
+                    if (on) {
+                        p = cam_point(G, d4[q], px, yb + q);
+                        if (!voxel_key(p.x, p.y, p.z, inv, (unsigned)l, key)) { s_err = 3; key = cur; }
+                        fin = key != cur;
+                    }
+                    if (__ballot(fin && cur != EMPTY && pend != EMPTY) != 0ull) { const long long t_p = clock64(); flush_parked(); c_park += clock64() - t_p; n_park++; }
+                    if (fin) {
+                        if (cur != EMPTY) { pend = cur; pcnt = cnt; psx = __double2ll_rn(sx * FIX_SCALE); psy = __double2ll_rn(sy * FIX_SCALE); psz = __double2ll_rn(sz * FIX_SCALE); }
+                        cur = key; cnt = 0; sx = sy = sz = 0;
+                    }
+                    if (on && key == cur && cur != EMPTY) {
+                        cnt++;
+                        sx += (double)p.x; sy += (double)p.y; sz += (double)p.z;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < UNR; q++) { l4[q] = ln[q]; d4[q] = dn[q]; }
             }
-            if (++px == G.W) { px = 0; py++; }
+            const long long t_r1 = clock64();
+            c_rows += t_r1 - t_r0;
+            flush_parked();
+            pend = cur; pcnt = cnt; psx = __double2ll_rn(sx * FIX_SCALE); psy = __double2ll_rn(sy * FIX_SCALE); psz = __double2ll_rn(sz * FIX_SCALE);
+            flush_parked();
+            wfence();
+            for (int e = lane; e < MINI; e += 64)
+                if (mk[e] != EMPTY) to_frame(mk[e], mc[e], s_ms[wave][0][e], s_ms[wave][1][e], s_ms[wave][2][e]);
+            wfence();
+            c_end += clock64() - t_r1;
         }
-        flush();
+        if (tmark && tid == 0) { tmark[8] = c_rows; tmark[9] = c_end; tmark[10] = n_park; tmark[11] = c_park; }
     }
     __threadfence();
     __syncthreads();
     int err = s_err;
     const int M = err ? 0 : s_n;
+    mark(2);
 
-    // ---- C: occupied slots in PCL's output order ----
-    int n2 = 1;
-    while (n2 < M) n2 <<= 1;
+    // ---- C: the key table, tagged with its slot numbers, sorted in place = PCL's output order (empty slots sort to the end) ----
     if (!err) {
-        for (int i = tid; i < n2; i += NT) s_list[i] = EMPTY;
+        for (int i = tid; i < TC; i += NT) { const unsigned long long k = s_list[i]; if (k != EMPTY) s_list[i] = (k << 14) | (unsigned long long)i; }
         __syncthreads();
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        for (int s = tid; s < TCAP; s += NT) {
-            const unsigned long long k = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k != EMPTY) { const int pos = atomicAdd(&s_n, 1); s_list[pos] = (k << 14) | (unsigned long long)s; }
-        }
-        __syncthreads();
-        bitonic(s_list, n2);
+        bitonic(s_list, TC);
         // ---- D: centroids, per-plane ranges ----
         for (int r = tid; r < M; r += NT) {
             const unsigned long long e = s_list[r];
@@ -381,7 +460,7 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
             const double cnt = (double)__hip_atomic_load(&tcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const long long S = (long long)__hip_atomic_load(&tsum[c * TCAP + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long S = (long long)__hip_atomic_load(&tsum[c * TC + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 cent[(size_t)r * 3 + c] = (float)(((double)S * (1.0 / FIX_SCALE)) / cnt);
             }
             if (r == 0 || (int)(s_list[r - 1] >> 56) != p) s_first[p] = r;
@@ -391,6 +470,7 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
     __threadfence();
     __syncthreads();
 
+    mark(3);
     // ---- E: distance gate + RANSAC refit, one wavefront per plane ----
     unsigned short* shuf = (unsigned short*)s_list;
     if (!err)
@@ -410,6 +490,7 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
     }
     __syncthreads();
     if (!err) err = s_err;
+    mark(4);
 
     // ---- F: the kept planes, in detector order ----
     if (tid == 0) {
@@ -444,6 +525,8 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
         const int first = s_first[p], n = s_last[p] - first, o = s_o[s_k[p]];
         for (int i = tid; i < n * 3; i += NT) pts_out[((size_t)b * G.max_points + o) * 3 + i] = cent[(size_t)first * 3 + i];
     }
+    mark(5);
+    if (tmark && tid == 0) { tmark[6] = M; tmark[7] = npl; }
 }
 
 // Standalone refit of given clouds (Frame::MaxPointDistanceFromPlane): one wavefront per cloud
@@ -509,58 +592,47 @@ __global__ void merge_gather_kernel(const double* __restrict__ T, const float* _
 __global__ __launch_bounds__(NT) void voxel_cloud_kernel(Geo G, const float* __restrict__ pts, int n, unsigned char* ws, float* out, int* n_out, int* status) {
     extern __shared__ unsigned long long s_list[];
     __shared__ int s_n, s_err;
-    const int tid = threadIdx.x;
-    unsigned long long* tkey = (unsigned long long*)ws;
+    const int tid = threadIdx.x, TC = G.tcap;
     unsigned* tcnt = (unsigned*)(ws + G.off_cnt);
     unsigned long long* tsum = (unsigned long long*)(ws + G.off_sum);
     const float inv = 1.0f / G.leaf;
-    for (int i = tid; i < TCAP; i += NT) { tkey[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TCAP + i] = 0ull; tsum[2 * TCAP + i] = 0ull; }
+    for (int i = tid; i < TC; i += NT) { s_list[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TC + i] = 0ull; tsum[2 * TC + i] = 0ull; }
     if (tid == 0) { s_n = 0; s_err = 0; }
     __threadfence();
     __syncthreads();
-    if (!s_err)
     for (int i = tid; i < n; i += NT) {
         const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
         unsigned long long key;
         if (!voxel_key(x, y, z, inv, 0u, key)) { s_err = 3; continue; }
-        unsigned h = hash64(key) & (TCAP - 1);
+        unsigned h = hash64(key) & (unsigned)(TC - 1);
         bool done = false;
-        for (int probe = 0; probe < TCAP && !done; probe++) {
-            const unsigned long long k = atomicCAS(&tkey[h], EMPTY, key);
+        for (int probe = 0; probe < TC && !done; probe++) {
+            const unsigned long long k = atomicCAS(&s_list[h], EMPTY, key);
             if (k == EMPTY) { if (atomicAdd(&s_n, 1) >= G.max_points) s_err = 3; }
             if (k == EMPTY || k == key) {
                 atomicAdd(&tcnt[h], 1u);
                 atomicAdd(&tsum[h], (unsigned long long)__double2ll_rn((double)x * FIX_SCALE));
-                atomicAdd(&tsum[TCAP + h], (unsigned long long)__double2ll_rn((double)y * FIX_SCALE));
-                atomicAdd(&tsum[2 * TCAP + h], (unsigned long long)__double2ll_rn((double)z * FIX_SCALE));
+                atomicAdd(&tsum[TC + h], (unsigned long long)__double2ll_rn((double)y * FIX_SCALE));
+                atomicAdd(&tsum[2 * TC + h], (unsigned long long)__double2ll_rn((double)z * FIX_SCALE));
                 done = true;
             }
-            h = (h + 1) & (TCAP - 1);
+            h = (h + 1) & (unsigned)(TC - 1);
         }
         if (!done) s_err = 3;
     }
     __threadfence();
     __syncthreads();
     const int err = s_err, M = err ? 0 : s_n;
-    int n2 = 1;
-    while (n2 < M) n2 <<= 1;
     if (!err) {
-        for (int i = tid; i < n2; i += NT) s_list[i] = EMPTY;
+        for (int i = tid; i < TC; i += NT) { const unsigned long long k = s_list[i]; if (k != EMPTY) s_list[i] = (k << 14) | (unsigned long long)i; }
         __syncthreads();
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        for (int s = tid; s < TCAP; s += NT) {
-            const unsigned long long k = __hip_atomic_load(&tkey[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k != EMPTY) { const int pos = atomicAdd(&s_n, 1); s_list[pos] = (k << 14) | (unsigned long long)s; }
-        }
-        __syncthreads();
-        bitonic(s_list, n2);
+        bitonic(s_list, TC);
         for (int r = tid; r < M; r += NT) {
             const int s = (int)(s_list[r] & 0x3fffull);
             const double cnt = (double)__hip_atomic_load(&tcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const long long S = (long long)__hip_atomic_load(&tsum[c * TCAP + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long S = (long long)__hip_atomic_load(&tsum[c * TC + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 out[(size_t)r * 3 + c] = (float)(((double)S * (1.0 / FIX_SCALE)) / cnt);
             }
         }
@@ -598,6 +670,7 @@ struct planar_plane_clouds {
     planar::planepost::Geo G{};
     size_t smem = 0;
     planar::DevBuf ws, rng, dbg;
+    bool timing = false;
 };
 
 using namespace planar;
@@ -607,7 +680,7 @@ extern "C" {
 int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points, planar_plane_clouds** out) {
     PLANAR_REQUIRE(ctx && out, PLANAR_EINVAL, "null argument");
     PLANAR_REQUIRE(width >= 16 && height >= 16 && width <= 4096 && height <= 4096 && max_batch >= 1, PLANAR_EINVAL, "bad size");
-    PLANAR_REQUIRE(max_points >= 64 && max_points <= 8192 && (max_points & (max_points - 1)) == 0, PLANAR_EINVAL, "max_points must be a power of two in [64, 8192]");
+    PLANAR_REQUIRE(max_points >= 64 && max_points <= 4096 && (max_points & (max_points - 1)) == 0, PLANAR_EINVAL, "max_points must be a power of two in [64, 4096]");
     PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
     planar_plane_clouds* p = new planar_plane_clouds;
     p->ctx = ctx; p->max_batch = max_batch;
@@ -615,11 +688,12 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
     G.W = width; G.H = height; G.max_points = max_points; G.pl_stride = planepost::MAXP;
     G.leaf = 0.1f; G.dist_th = 0.05;
     G.log_probability = std::log(1.0 - 0.99);
-    G.off_cnt = (size_t)planepost::TCAP * 8;
-    G.off_sum = G.off_cnt + (size_t)planepost::TCAP * 4;
-    G.off_cent = G.off_sum + (size_t)planepost::TCAP * 24;
+    G.tcap = 2 * max_points;
+    G.off_cnt = 0;
+    G.off_sum = (size_t)G.tcap * 4;
+    G.off_cent = G.off_sum + (size_t)G.tcap * 24;
     G.ws_stride = align_up(G.off_cent + (size_t)max_points * 12, (size_t)256);
-    p->smem = (size_t)max_points * 8;
+    p->smem = (size_t)G.tcap * 8;                                                     // the key table: 64 KB at the default 4096 voxels per frame
     int rc = p->ws.alloc(G.ws_stride * (size_t)max_batch);
     if (!rc) rc = p->rng.alloc((size_t)planepost::NRNG * 4);
     if (rc) { delete p; return rc; }
@@ -629,13 +703,28 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
     if (p->smem > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)planepost::plane_clouds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::voxel_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
-        if (e != hipSuccess) { set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", p->smem); delete p; return PLANAR_EINVAL; }
+        if (e != hipSuccess) { (void)hipGetLastError(); set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", p->smem); delete p; return PLANAR_EINVAL; }
     }
     *out = p;
     return PLANAR_OK;
 }
 
 void planar_plane_clouds_destroy(planar_plane_clouds* p) { delete p; }
+
+// Profiling aid: per-frame phase timestamps of the last call, out[B][8] (100 MHz ticks: [0] entry, [1] table cleared, [2] voxel sums, [3] sorted + centroids,
+// [4] refit, [5] end; [6] voxels, [7] planes).  Enabling allocates the buffer.
+int planar_plane_clouds_set_timing(planar_plane_clouds* p, int enable) {
+    PLANAR_REQUIRE(p != nullptr, PLANAR_EINVAL, "null argument");
+    if (enable && !p->dbg.p) { int rc = p->dbg.alloc((size_t)p->max_batch * 128); if (rc) return rc; }
+    p->timing = enable != 0;
+    return PLANAR_OK;
+}
+int planar_plane_clouds_read_timing(planar_plane_clouds* p, int B, int64_t* out) {
+    PLANAR_REQUIRE(p && out && p->dbg.p && B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "timing not enabled / bad B");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    PLANAR_HIP_CHECK(hipMemcpy(out, p->dbg.p, (size_t)B * 128, hipMemcpyDeviceToHost));
+    return PLANAR_OK;
+}
 
 int planar_plane_clouds_stride(const planar_plane_clouds* p, int* pl_stride, int* max_points) {
     PLANAR_REQUIRE(p != nullptr, PLANAR_EINVAL, "null argument");
@@ -656,9 +745,10 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     PLANAR_REQUIRE(65535.0 * (double)depth_factor * std::max(1.0, std::max(p->G.W / (double)fx, p->G.H / (double)fy)) < 128.0, PLANAR_EINVAL, "depth range too large");
     planepost::Geo G = p->G;
     G.fx = fx; G.fy = fy; G.cx = cx; G.cy = cy; G.factor = depth_factor; G.leaf = leaf; G.dist_th = dist_th;
+    G.rfx = 1.0 / (double)fx; G.rfy = 1.0 / (double)fy;
     hipLaunchKernelGGL(planepost::plane_clouds_kernel, dim3(B), dim3(planepost::NT), p->smem, p->ctx->stream, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, d_planes,
                        planar_peac_max_planes(), d_n_planes, p->rng.as<int>(), p->ws.as<unsigned char>(), d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox,
-                       d_info);
+                       d_info, p->timing ? p->dbg.as<long long>() : nullptr);
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
 }

@@ -108,7 +108,7 @@ class PlaneClouds:
     """The head of Frame::ComputePlanes (reference src/Frame.cc:652-692) with Frame::MaxPointDistanceFromPlane (:755-812): the detector's planes ->
     mvPlanePoints (0.1 m voxel centroids) and mvPlaneCoefficients (RANSAC refit), planes failing Plane.DistanceThreshold dropped."""
 
-    def __init__(self, width: int = 640, height: int = 480, max_batch: int = 1, max_points: int = 8192, ctx: Context | None = None):
+    def __init__(self, width: int = 640, height: int = 480, max_batch: int = 1, max_points: int = 4096, ctx: Context | None = None):
         self.L = lib()
         self.ctx = ctx or Context(0)
         self.width, self.height, self.max_batch, self.max_points = width, height, max_batch, max_points

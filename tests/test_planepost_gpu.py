@@ -53,7 +53,7 @@ def test_refit_many_iterations_exact():
     assert max(its) >= 8 and sum(its) >= 50, its
 
 
-def _gpu_frames(depths, dist_th=0.05, max_points=8192, debug=True):
+def _gpu_frames(depths, dist_th=0.05, max_points=4096, debug=True):
     from planarslam_amd import PlaneClouds, PlaneDetection
     B = len(depths)
     det = PlaneDetection(640, 480, max_batch=B)

@@ -42,7 +42,7 @@ def run(seconds, seed=0, nsrc=4, threads3=False, full=True):
     o = ol.OrbOracle()
     sfs = scale_factors()
     rng = np.random.default_rng(11 + seed)
-    per = {"orb": 0.0, "lsd": 0.0, "lines3d": 0.0, "peac": 0.0, "normals": 0.0, "extract_wall": 0.0, "stereo": 0.0, "manhattan": 0.0, "proj": 0.0, "match": 0.0, "planes": 0.0, "local": 0.0, "pose": 0.0}
+    per = {"orb": 0.0, "lsd": 0.0, "lines3d": 0.0, "peac": 0.0, "planepost": 0.0, "normals": 0.0, "extract_wall": 0.0, "stereo": 0.0, "manhattan": 0.0, "proj": 0.0, "match": 0.0, "planes": 0.0, "local": 0.0, "pose": 0.0}
     from planarslam_amd.synth import manhattan_scene
     scene = manhattan_scene(B=1, n_normals=4096, n_lines=40, seed=21 + seed)
     prev = None
@@ -60,6 +60,7 @@ def run(seconds, seed=0, nsrc=4, threads3=False, full=True):
 
         def t_peac():
             t1 = time.perf_counter(); res["peac"] = ol.peac_run(depth[i]); per["peac"] += time.perf_counter() - t1
+            t1 = time.perf_counter(); res["clouds"] = ol.plane_clouds(depth[i], res["peac"][1], res["peac"][0]); per["planepost"] += time.perf_counter() - t1   # voxel clouds + refit
             t1 = time.perf_counter(); res["normals"] = ol.surface_normals(depth[i])[0]; per["normals"] += time.perf_counter() - t1     # Frame::ComputePlanes tail, same thread
 
         tw = time.perf_counter()
@@ -98,10 +99,10 @@ def run(seconds, seed=0, nsrc=4, threads3=False, full=True):
                 per["match"] += tm() - t1
                 if len(planes) and len(ppl):
                     t1 = tm()
-                    coef = np.concatenate([planes[:, 1:4], -(planes[:, 1:4] * planes[:, 4:7]).sum(1, keepdims=True)], 1).astype(np.float32)[None]
+                    coef = res["clouds"]["coef"][None] if res["clouds"]["n"] else np.zeros((1, 1, 4), np.float32)
                     mcoef = np.concatenate([ppl[:, 1:4], -(ppl[:, 1:4] * ppl[:, 4:7]).sum(1, keepdims=True)], 1).astype(np.float32)[None]
                     mpts = np.repeat(ppl[:, 4:7].astype(np.float32)[None, :, None, :], 64, 2)
-                    ol.plane_search_by_coefficients(dict(n=np.array([len(planes)], np.int32), coef=coef, Tcw=eye),
+                    ol.plane_search_by_coefficients(dict(n=np.array([res["clouds"]["n"]], np.int32), coef=coef, Tcw=eye),
                                                     dict(n=np.array([len(ppl)], np.int32), valid=np.ones((1, len(ppl)), np.uint8), coef=mcoef,
                                                          npts=np.full((1, len(ppl)), 64, np.int32), pts=mpts))
                     per["planes"] += tm() - t1
