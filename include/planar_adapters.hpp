@@ -69,6 +69,13 @@ public:
         if (planar_peac_create(lanes_[PLANES].ctx, w, h, 1, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());
         return peacs_[{w, h}] = o;
     }
+    planar_plane_clouds* clouds(int w, int h) {                     // call with lane(PLANES).mu held
+        auto it = clouds_.find({w, h});
+        if (it != clouds_.end()) return it->second;
+        planar_plane_clouds* o = nullptr;
+        if (planar_plane_clouds_create(lanes_[PLANES].ctx, w, h, 1, 4096, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        return clouds_[{w, h}] = o;
+    }
     void set_device(int d) { device_ = d; }
 private:
     Runtime() {}
@@ -76,6 +83,7 @@ private:
         for (auto& kv : orbs_) planar_orb_destroy(kv.second);
         for (auto& kv : lsds_) planar_lsd_destroy(kv.second);
         for (auto& kv : peacs_) planar_peac_destroy(kv.second);
+        for (auto& kv : clouds_) planar_plane_clouds_destroy(kv.second);
         for (Lane& l : lanes_) if (l.ctx) planar_ctx_destroy(l.ctx);
     }
     Runtime(const Runtime&) = delete;
@@ -86,6 +94,7 @@ private:
     std::map<OrbKey, planar_orb*> orbs_;
     std::map<std::pair<int, int>, planar_lsd*> lsds_;
     std::map<std::pair<int, int>, planar_peac*> peacs_;
+    std::map<std::pair<int, int>, planar_plane_clouds*> clouds_;
 };
 
 inline void check(int rc) { if (rc != PLANAR_OK) throw std::runtime_error(planar_last_error()); }
@@ -204,8 +213,10 @@ public:
     }
 
     void runPlaneDetection(int H, int W) {   // src/PlaneExtractor.cpp:59-65
-        std::vector<int32_t> labels((size_t)W * H);
-        std::vector<double> planes((size_t)planar_peac_max_planes() * 8);
+        std::vector<int32_t>& labels = labels_;
+        std::vector<double>& planes = planes_;
+        labels.assign((size_t)W * H, -1);
+        planes.assign((size_t)planar_peac_max_planes() * 8, 0.0);
         int32_t n = 0;
         {
             planar_adapter::Runtime& R = planar_adapter::Runtime::get();
@@ -227,9 +238,41 @@ public:
         seg_img_ = cv::Mat(H, W, CV_8UC3);   // visualisation only (colours are out of scope)
     }
 
+    // NOT a member of the reference class: the loop of Frame::ComputePlanes over the detected planes (src/Frame.cc:655-692: pcl::VoxelGrid(0.1) of every
+    // plane's points, coefficient (n, -n.c), Frame::MaxPointDistanceFromPlane with its pcl::SACSegmentation refit) as one call.  In Frame::ComputePlanes:
+    //     planeDetector.ComputePlaneClouds(Config::Get<double>("Plane.DistanceThreshold"), mvPlanePoints, mvPlaneCoefficients);
+    // CloudT: pcl::PointCloud<pcl::PointXYZRGB> or anything with a `points` vector whose elements have float x, y, z.  Returns mnPlaneNum.
+    template <class CloudT>
+    int ComputePlaneClouds(double disTh, std::vector<CloudT>& planePoints, std::vector<cv::Mat>& planeCoefficients, float leaf = 0.1f) {
+        const int W = cloud.w, H = cloud.h, PS = planar_peac_max_planes(), MP = 4096;
+        std::vector<float> coef((size_t)PS * 4), pts((size_t)MP * 3);
+        std::vector<int32_t> src(PS), off(PS + 1);
+        int32_t n_in = plane_num_, n_out = 0;
+        {
+            planar_adapter::Runtime& R = planar_adapter::Runtime::get();
+            planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::PLANES);
+            std::lock_guard<std::mutex> g(L.mu);
+            planar_adapter::check(planar_plane_clouds_compute(R.clouds(W, H), (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_,
+                                                              cx_, cy_, factor_, labels_.data(), planes_.data(), &n_in, disTh, leaf, &n_out, coef.data(), src.data(), off.data(),
+                                                              pts.data(), nullptr, nullptr, nullptr));
+        }
+        for (int k = 0; k < n_out; k++) {
+            CloudT c;
+            c.points.resize(off[k + 1] - off[k]);
+            for (int i = off[k]; i < off[k + 1]; i++) { auto& p = c.points[i - off[k]]; p.x = pts[(size_t)i * 3]; p.y = pts[(size_t)i * 3 + 1]; p.z = pts[(size_t)i * 3 + 2]; }
+            planePoints.push_back(c);
+            cv::Mat m(4, 1, CV_32F);
+            for (int t = 0; t < 4; t++) m.at<float>(t, 0) = coef[(size_t)k * 4 + t];
+            planeCoefficients.push_back(m);
+        }
+        return n_out;
+    }
+
 private:
     cv::Mat depth_;
     float factor_ = 0, fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0;
+    std::vector<int32_t> labels_;       // what planar_peac_segment delivered (plane_vertices_ / plane_filter are views of these)
+    std::vector<double> planes_;
 };
 
 // ---- LineSegment (reference include/LSDextractor.h:344-352, src/LSDextractor.cpp:12-39).  Opt-in: define PLANAR_ADAPTERS_WITH_LINES

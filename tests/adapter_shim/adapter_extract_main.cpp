@@ -3,7 +3,8 @@
 // the PlaneDetection inside) copied by value, LineSegment called without a usable object - here through include/planar_adapters.hpp.
 //   adapter_extract <in.bin> <out.bin>    in: int32 W, H, nframes; per frame gray u8 [H*W], depth u16 [H*W]
 //   out per frame: int32 nkp, kps (28 B each), desc; int32 nlines, keylines (68 B each), ldesc, eqs (3 doubles each);
-//                  int32 nplanes, per plane {int32 npix; double normal[3], center[3]}, labels int32 [H*W] (from plane_vertices_)
+//                  int32 nplanes, per plane {int32 npix; double normal[3], center[3]}, labels int32 [H*W] (from plane_vertices_);
+//                  int32 mnPlaneNum, per kept plane {float coef[4]; int32 npts; float xyz[npts][3]} (the Frame::ComputePlanes loop, on the COPY)
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -12,12 +13,16 @@
 #define PLANAR_ADAPTERS_WITH_LINES
 #include "planar_adapters.hpp"
 
+struct CloudLike { struct P { float x, y, z; }; std::vector<P> points; };   // stands in for pcl::PointCloud<pcl::PointXYZRGB>
+
 struct FrameLike {   // the members of Planar_SLAM::Frame the extraction threads write
     std::vector<cv::KeyPoint> mvKeys;
     cv::Mat mDescriptors, mLdesc;
     std::vector<cv::line_descriptor::KeyLine> mvKeylinesUn;
     std::vector<Eigen::Vector3d> mvKeyLineFunctions;
     PlaneDetection planeDetector;
+    std::vector<CloudLike> mvPlanePoints;
+    std::vector<cv::Mat> mvPlaneCoefficients;
 };
 
 int main(int argc, char** argv) {
@@ -40,7 +45,10 @@ int main(int argc, char** argv) {
         Planar_SLAM::LineSegment* mpLineSegment = nullptr;   // include/Frame.h:123 - never initialised by the reference
         std::thread threadLines([&] { mpLineSegment->ExtractLineSegment(gray, F.mvKeylinesUn, F.mLdesc, F.mvKeyLineFunctions); });
         std::thread threadPoints([&] { (*orb)(gray, cv::Mat(), F.mvKeys, F.mDescriptors); });
-        std::thread threadPlanes([&] { F.planeDetector.readDepthImage(depth, K, 1.0f / 5000); F.planeDetector.runPlaneDetection(H, W); });
+        std::thread threadPlanes([&] {        // Frame::ComputePlanes
+            F.planeDetector.readDepthImage(depth, K, 1.0f / 5000); F.planeDetector.runPlaneDetection(H, W);
+            F.planeDetector.ComputePlaneClouds(0.05, F.mvPlanePoints, F.mvPlaneCoefficients);
+        });
         threadPoints.join(); threadLines.join(); threadPlanes.join();
         history.push_back(F);                 // by-value copy
         const FrameLike& G = history.back();  // everything below reads the COPY
@@ -64,6 +72,14 @@ int main(int argc, char** argv) {
             for (int v : G.planeDetector.plane_vertices_[i]) labels[v] = i;
         }
         std::fwrite(labels.data(), 4, labels.size(), fo);
+        n = (int32_t)G.mvPlanePoints.size();
+        std::fwrite(&n, 4, 1, fo);
+        for (int i = 0; i < n; i++) {
+            for (int t = 0; t < 4; t++) { const float c = G.mvPlaneCoefficients[i].at<float>(t, 0); std::fwrite(&c, 4, 1, fo); }
+            const int32_t np = (int32_t)G.mvPlanePoints[i].points.size();
+            std::fwrite(&np, 4, 1, fo);
+            std::fwrite(G.mvPlanePoints[i].points.data(), 12, np, fo);
+        }
     }
     history.clear();
     delete orb;

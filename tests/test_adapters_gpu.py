@@ -179,4 +179,17 @@ def test_extractor_adapters_three_threads_per_frame(bins):
             np.testing.assert_array_equal(nc, planes[i, 1:7])
         lab = np.frombuffer(buf, "<i4", W * H, off).reshape(H, W); off += 4 * W * H
         np.testing.assert_array_equal(lab, labels)
+        # the Frame::ComputePlanes loop (voxel clouds + refit): same planes kept, the clouds within the float-summation error, the refit the oracle's on them
+        want = O.plane_clouds(d, labels, planes)
+        k = int(np.frombuffer(buf, "<i4", 1, off)[0]); off += 4
+        assert k == want["n"]
+        for q in range(k):
+            coef = np.frombuffer(buf, "<f4", 4, off); off += 16
+            npts = int(np.frombuffer(buf, "<i4", 1, off)[0]); off += 4
+            cloud = np.frombuffer(buf, "<f4", npts * 3, off).reshape(npts, 3); off += npts * 12
+            assert npts == want["pt_off"][q + 1] - want["pt_off"][q] and np.abs(cloud - want["points"][want["pt_off"][q]:want["pt_off"][q + 1]]).max() < 2e-5
+            P = planes[want["src"][q]]
+            c0 = np.array([P[1], P[2], P[3], -(P[1] * P[4] + P[2] * P[5] + P[3] * P[6])]).astype(np.float32)
+            st, pl, _ = O.plane_refit(c0, cloud, 0.05)
+            assert st == 0 and np.abs(pl - coef).max() < 1e-6
     assert off == len(buf)
