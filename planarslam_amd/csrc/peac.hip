@@ -264,9 +264,13 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     double* g_geo = (double*)(F + L.off_geo);
     int* g_N = (int*)(F + L.off_N);
     uint8_t* g_flags = F + L.off_flags;
-    int* member = (int*)(F + L.off_member);
+    // membershipImg as signed bytes (plane ids 0..127, -1 = none, -2..-6 = the flood fill's rejection trail), the distance map WITHOUT its FLT_MAX fill (a
+    // pixel carries a distance exactly when the flood fill made it a member: read as FLT_MAX otherwise), queue entries packed pixel | plane << 24:
+    // the reference's int32 image, float image and (index, plane) pairs cost 2.3x the bytes per frame
+    signed char* member = (signed char*)(F + L.off_member);
     float* distMap = (float*)(F + L.off_dist);
-    int2* queue = (int2*)(F + L.off_queue);
+    unsigned* queue = (unsigned*)(F + L.off_queue);
+    auto qent = [](int pixel, int plane) { return (unsigned)pixel | ((unsigned)plane << 24); };
     int* seedcnt = (int*)(F + L.off_seedcnt);
     int* g_cint = (int*)(F + L.off_cint);
     double* g_cdbl = (double*)(F + L.off_cdbl);
@@ -924,7 +928,10 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     }
 
     // ---- refineDetails (:299-379): findBlockMembership (:485-587), all threads ----
-    for (int i = tid; i < W * H; i += NT) { member[i] = -1; distMap[i] = 3.4028234663852886e38f; }
+    {
+        unsigned* m4 = (unsigned*)member;
+        for (int i = tid; i < (W * H + 3) / 4; i += NT) m4[i] = 0xffffffffu;
+    }
     for (int b = tid; b < NB; b += NT) {
         const int i = b / Nw, j = b - i * Nw;
         const int setid = lds_find(S.dsp, b);   // concurrent path compression only ever stores true roots: benign
@@ -970,13 +977,13 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
         const int i = b / Nw, j = b - i * Nw, me = S.blk[b];
         int o = seedcnt[b];
         if (me >= 0)   // membershipImg(block) = plid
-            for (int y = i * WIN; y < (i + 1) * WIN; y++) for (int x = j * WIN; x < (j + 1) * WIN; x++) member[y * W + x] = me;
+            for (int y = i * WIN; y < (i + 1) * WIN; y++) for (int x = j * WIN; x < (j + 1) * WIN; x++) member[y * W + x] = (signed char)me;
         if (me < 0) {
-            if (i > 0 && S.blk[b - Nw] >= 0) { const int up = S.blk[b - Nw]; const int sp = (i * WIN - 1) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = make_int2(sp + k, up); }
-            if (j > 0 && S.blk[b - 1] >= 0) { const int lp = S.blk[b - 1]; const int sp = (i * WIN) * W + j * WIN - 1; for (int k = 0; k < WIN - 1; ++k) queue[o++] = make_int2(sp + k * W, lp); }
+            if (i > 0 && S.blk[b - Nw] >= 0) { const int up = S.blk[b - Nw]; const int sp = (i * WIN - 1) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = qent(sp + k, up); }
+            if (j > 0 && S.blk[b - 1] >= 0) { const int lp = S.blk[b - 1]; const int sp = (i * WIN) * W + j * WIN - 1; for (int k = 0; k < WIN - 1; ++k) queue[o++] = qent(sp + k * W, lp); }
         } else {
-            if (i > 0 && S.blk[b - Nw] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 0; k < WIN - 1; ++k) queue[o++] = make_int2(sp + k, me); }
-            if (j > 0 && S.blk[b - 1] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = make_int2(sp + k * W, me); }
+            if (i > 0 && S.blk[b - Nw] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 0; k < WIN - 1; ++k) queue[o++] = qent(sp + k, me); }
+            if (j > 0 && S.blk[b - 1] != me) { const int sp = (i * WIN) * W + j * WIN; for (int k = 1; k < WIN; ++k) queue[o++] = qent(sp + k * W, me); }
         }
     }
     __threadfence_block();
@@ -1008,7 +1015,8 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
                 act[j] = e < nent; cIdx[j] = -1; plid[j] = -1; geo_ok[j] = false; cdist[j] = -1.f; push[j] = false;
                 int cx = 0, cy = 0;
                 if (act[j]) {
-                    const int2 ent = queue[q_head + e];
+                    const unsigned ent_p = queue[q_head + e];
+                    const int2 ent = make_int2((int)(ent_p & 0xffffffu), (int)(ent_p >> 24));
                     plid[j] = ent.y;
                     const int sy = ent.x / W, sx = ent.x - sy * W;
                     // getValid4Neighbor order (:398-410): left, right, up, down, invalid ones skipped
@@ -1052,16 +1060,16 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
 #pragma unroll
                 for (int j = 0; j < FJ; j++) {
                     if (!done[j] && slot[hsl[j]] == (ek | (unsigned)pidx[j])) {
-                        const int trail = member[cIdx[j]];
+                        const int trail = (int)member[cIdx[j]];
                         if (!(trail <= -6) && !(trail >= 0 && trail == plid[j])) {
                             if (geo_ok[j]) {
                                 if (trail >= 0 && nsim(s_ext[plid[j]], s_ext[trail]) >= C.cos_refine) {   // n_pl.connect(pl)
                                     atomicOr(&s_adj[trail][plid[j] >> 5], 1u << (plid[j] & 31));
                                     atomicOr(&s_adj[plid[j]][trail >> 5], 1u << (trail & 31));
                                 }
-                                if (cdist[j] < distMap[cIdx[j]]) { member[cIdx[j]] = plid[j]; distMap[cIdx[j]] = cdist[j]; push[j] = true; }
-                                else if (trail < 0) member[cIdx[j]] = trail - 1;
-                            } else if (trail < 0) member[cIdx[j]] = trail - 1;
+                                if (cdist[j] < (trail >= 0 ? distMap[cIdx[j]] : 3.4028234663852886e38f)) { member[cIdx[j]] = (signed char)plid[j]; distMap[cIdx[j]] = cdist[j]; push[j] = true; }
+                                else if (trail < 0) member[cIdx[j]] = (signed char)(trail - 1);
+                            } else if (trail < 0) member[cIdx[j]] = (signed char)(trail - 1);
                         }
                         done[j] = true;
                     }
@@ -1083,7 +1091,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
             else {
 #pragma unroll
                 for (int j = 0; j < FJ; j++)
-                    if (push[j]) queue[q_tail + mybase[j] + __popcll(pm[j] & ((1ull << lane) - 1ull))] = make_int2(cIdx[j], plid[j]);
+                    if (push[j]) queue[q_tail + mybase[j] + __popcll(pm[j] & ((1ull << lane) - 1ull))] = qent(cIdx[j], plid[j]);
             }
             q_tail += base;
             q_head += nent;
@@ -1135,7 +1143,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
 
     // ---- relabel (:327-372) and plane parameters, all threads ----
     for (int i = tid; i < W * H; i += NT) {
-        const int plid = member[i];
+        const int plid = (int)member[i];
         lab[i] = (plid >= 0 && s_plidmap[plid] >= 0) ? s_plidmap[plid] : -1;
     }
     for (int j = tid; j < n_ext; j += NT) {
@@ -1237,8 +1245,8 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     L.off_stats = carve((size_t)L.NB2 * 9 * 8); L.off_geo = carve((size_t)L.NB2 * 7 * 8); L.off_N = carve((size_t)L.NB2 * 4);
     L.off_rid = carve((size_t)L.NB2 * 4); L.off_flags = carve((size_t)L.NB2); L.off_nb_off = carve((size_t)L.NB2 * 4);
     L.off_nb_cnt = carve((size_t)L.NB2 * 4); L.off_pool = carve((size_t)L.pool_cap * 4);
-    L.off_parent = carve((size_t)L.NB * 4); L.off_size = carve((size_t)L.NB * 4); L.off_member = carve((size_t)width * height * 4);
-    L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 8);
+    L.off_parent = carve((size_t)L.NB * 4); L.off_size = carve((size_t)L.NB * 4); L.off_member = carve((size_t)width * height + 4);
+    L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 4);
     L.off_seedcnt = carve((size_t)L.NB * 4);
     // candidate cache of the cooperative ahCluster: per node 4 ints {have, best_nb, best_N, -} and 16 doubles {mse, stats[9], center[3],
     // normal[3]}; whether a record is valid for the node's current live-neighbour set is a bit in LDS
