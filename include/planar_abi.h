@@ -555,7 +555,7 @@ int planar_track_manhattan_frame_dev(planar_ctx* ctx, int B, const float* d_R_la
  *   state / nvox / info (optional, per DETECTOR plane, stride pl_stride / pl_stride / pl_stride * 12): 0 kept, 1 distance, 2 no inliers; voxels;
  *                                  {RANSAC iterations, best count, best sample[3], inliers, inliers after the refit, sampler draws, model[4] bits}  */
 typedef struct planar_plane_clouds planar_plane_clouds;
-int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* voxels per frame: a power of two <= 4096; the kernel holds 16 * max_points + 41 K bytes of LDS */, planar_plane_clouds** out);
+int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* voxels per frame: a power of two <= 8192; the kernel holds 101 KB of LDS up to 4096, 146 KB at 8192 */, planar_plane_clouds** out);
 void planar_plane_clouds_destroy(planar_plane_clouds* pc);
 int planar_plane_clouds_stride(const planar_plane_clouds* pc, int* pl_stride, int* max_points);
 /* Profiling aid, as planar_peac_read_timing: per-frame phase timestamps of the last call, out[B][16] (100 MHz ticks: [0] entry, [1] table cleared, [2] voxel sums,

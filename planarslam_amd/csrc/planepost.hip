@@ -36,7 +36,7 @@ constexpr int VOX_BIAS = 8192;            // voxel coordinates floor(x / leaf) a
 constexpr unsigned long long EMPTY = ~0ull;
 
 struct Geo {
-    int W, H, max_points, pl_stride, tcap;      // tcap = 2 * max_points key slots (LDS)
+    int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (LDS); mini: entries of a wavefront's tile table
     float fx, fy, cx, cy, factor, leaf;
     double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
     size_t ws_stride, off_cnt, off_sum, off_cent;
@@ -338,11 +338,11 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
     //      tables: an LDS CAS on the key table for the slot, then four fire-and-forget global atomics on the slot's count and sums.  A run that finds the
     //      small table crowded goes to the frame's tables directly.  All sums are integers: the path taken does not change the result. ----
     {
-        constexpr int ROWS = 60, UNR = 4, MINI = 128;
-        __shared__ unsigned long long s_mk[NT / 64][MINI], s_ms[NT / 64][3][MINI];
-        __shared__ unsigned s_mc[NT / 64][MINI];
-        unsigned long long* mk = s_mk[wave];
-        unsigned* mc = s_mc[wave];
+        constexpr int ROWS = 60, UNR = 4;
+        const int MINI = G.mini;                                    // 128 entries per wavefront (64 when the key table takes 128 KB), behind the key table
+        unsigned long long* mk = s_list + TC + (size_t)wave * 4 * MINI;      // keys, then the three sums
+        unsigned long long* ms0 = mk + MINI; unsigned long long* ms1 = ms0 + MINI; unsigned long long* ms2 = ms1 + MINI;
+        unsigned* mc = (unsigned*)(s_list + TC + (size_t)(NT / 64) * 4 * MINI) + (size_t)wave * MINI;
         auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
         auto to_frame = [&](unsigned long long key, unsigned cnt, unsigned long long sx, unsigned long long sy, unsigned long long sz) {
             unsigned h = hash64(key) & (unsigned)(TC - 1);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
         for (int tile = wave; tile < tiles; tile += NT / 64) {
             const int px = (tile % strips) * 64 + lane, y0 = (tile / strips) * ROWS, y1 = min(y0 + ROWS, G.H);
             const bool col = px < G.W;
-            for (int e = lane; e < MINI; e += 64) { mk[e] = EMPTY; mc[e] = 0u; s_ms[wave][0][e] = 0ull; s_ms[wave][1][e] = 0ull; s_ms[wave][2][e] = 0ull; }
+            for (int e = lane; e < MINI; e += 64) { mk[e] = EMPTY; mc[e] = 0u; ms0[e] = 0ull; ms1[e] = 0ull; ms2[e] = 0ull; }
             wfence();
             // the run being summed (cur) and the last finished one (pend).  Finished runs are parked: the insertion code below runs - for every lane
             // that has something parked, together - only when some lane finishes a second run, i.e. every ten rows or so instead of at every row
@@ -373,16 +373,16 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
             long long psx = 0, psy = 0, psz = 0;
             auto flush_parked = [&]() {
                 if (pend != EMPTY) {
-                    unsigned h = (hash64(pend) >> 7) & (MINI - 1);
+                    unsigned h = (hash64(pend) >> 7) & (unsigned)(MINI - 1);
                     bool done = false;
                     for (int probe = 0; probe < 8 && !done; probe++) {
                         const unsigned long long k = atomicCAS(&mk[h], EMPTY, pend);
                         if (k == EMPTY || k == pend) {
                             atomicAdd(&mc[h], pcnt);
-                            atomicAdd(&s_ms[wave][0][h], (unsigned long long)psx); atomicAdd(&s_ms[wave][1][h], (unsigned long long)psy); atomicAdd(&s_ms[wave][2][h], (unsigned long long)psz);
+                            atomicAdd(&ms0[h], (unsigned long long)psx); atomicAdd(&ms1[h], (unsigned long long)psy); atomicAdd(&ms2[h], (unsigned long long)psz);
                             done = true;
                         }
-                        h = (h + 1) & (MINI - 1);
+                        h = (h + 1) & (unsigned)(MINI - 1);
                     }
                     if (!done) to_frame(pend, pcnt, (unsigned long long)psx, (unsigned long long)psy, (unsigned long long)psz);
                     pend = EMPTY;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
             flush_parked();
             wfence();
             for (int e = lane; e < MINI; e += 64)
-                if (mk[e] != EMPTY) to_frame(mk[e], mc[e], s_ms[wave][0][e], s_ms[wave][1][e], s_ms[wave][2][e]);
+                if (mk[e] != EMPTY) to_frame(mk[e], mc[e], ms0[e], ms1[e], ms2[e]);
             wfence();
             c_end += clock64() - t_r1;
         }
@@ -680,7 +680,7 @@ extern "C" {
 int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points, planar_plane_clouds** out) {
     PLANAR_REQUIRE(ctx && out, PLANAR_EINVAL, "null argument");
     PLANAR_REQUIRE(width >= 16 && height >= 16 && width <= 4096 && height <= 4096 && max_batch >= 1, PLANAR_EINVAL, "bad size");
-    PLANAR_REQUIRE(max_points >= 64 && max_points <= 4096 && (max_points & (max_points - 1)) == 0, PLANAR_EINVAL, "max_points must be a power of two in [64, 4096]");
+    PLANAR_REQUIRE(max_points >= 64 && max_points <= 8192 && (max_points & (max_points - 1)) == 0, PLANAR_EINVAL, "max_points must be a power of two in [64, 8192]");
     PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
     planar_plane_clouds* p = new planar_plane_clouds;
     p->ctx = ctx; p->max_batch = max_batch;
@@ -693,7 +693,9 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
     G.off_sum = (size_t)G.tcap * 4;
     G.off_cent = G.off_sum + (size_t)G.tcap * 24;
     G.ws_stride = align_up(G.off_cent + (size_t)max_points * 12, (size_t)256);
-    p->smem = (size_t)G.tcap * 8;                                                     // the key table: 64 KB at the default 4096 voxels per frame
+    G.mini = max_points > 4096 ? 64 : 128;
+    // the key table (64 KB at the default 4096 voxels per frame) + eight tile tables of `mini` entries x 36 B: 101 KB; 146 KB at 8192 voxels
+    p->smem = (size_t)G.tcap * 8 + (size_t)(planepost::NT / 64) * G.mini * 36;
     int rc = p->ws.alloc(G.ws_stride * (size_t)max_batch);
     if (!rc) rc = p->rng.alloc((size_t)planepost::NRNG * 4);
     if (rc) { delete p; return rc; }

@@ -172,3 +172,13 @@ def test_merge_plane_points_matches_oracle():
         e32 = exact.astype(np.float32)
         assert (np.abs(got - e32) <= np.spacing(np.abs(e32))).all()
     assert len(pcz.merge(np.eye(4), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))) == 0
+
+
+def test_plane_clouds_8192_voxels_same_result():
+    """The largest table (128 KB of LDS for the keys, 64-entry tile tables) gives what the default gives."""
+    depths = np.stack([depth_image(60 + i) for i in range(2)])
+    _, a = _gpu_frames(depths, max_points=4096, debug=False)
+    _, b = _gpu_frames(depths, max_points=8192, debug=False)
+    for x, y in zip(a, b):
+        for k in ("coef", "src", "pt_off", "points"):
+            assert np.array_equal(x[k], y[k]), k
