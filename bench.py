@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the cpu_baseline leg, split over its three variants (0 = skip)")
     ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 latency block (0 = skip)")
     ap.add_argument("--pcie-steps", type=int, default=4, help="steps of the PCIe-inclusive loop (0 = skip)")
+    ap.add_argument("--canvases", type=int, default=NCANVAS, help="distinct synthetic canvases per GPU (the streams tile over them)")
+    ap.add_argument("--gen-procs", type=int, default=0, help="worker processes that synthesise the canvases (0 = up to 32; 1 = in this process: rocprofv3 --pmc hangs in "
+                                                             "forked children, profiles/README.md)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -82,9 +85,9 @@ def main():
     full = args.workload == "full"
     # ---- inputs: generated on worker processes BEFORE the GPU runtime is initialised (fork) ----
     from planarslam_amd.synth import TUM3, pan_offset, stream_canvases
-    ncanv = min(NCANVAS, B)
+    ncanv = min(args.canvases, B)
     t_gen = time.perf_counter()
-    canv_g, canv_d = stream_canvases(ncanv, rank_env, W + 2 * MARGIN, H + 2 * MARGIN, procs=max(1, min(32, (os.cpu_count() or 1) // max(1, world_env))))
+    canv_g, canv_d = stream_canvases(ncanv, rank_env, W + 2 * MARGIN, H + 2 * MARGIN, procs=args.gen_procs or max(1, min(32, (os.cpu_count() or 1) // max(1, world_env))))
     t_gen = time.perf_counter() - t_gen
 
     import torch

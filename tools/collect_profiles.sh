@@ -9,11 +9,12 @@ timeout 200 python bench.py --workload ba --steps 20 --warmup 3 > $O/${tag}_benc
 cd /tmp && export TMPDIR=/tmp
 FL="--steps 6 --warmup 3 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
-if [ "$2" = "pmc" ]; then   # the counter passes hung on the pool in round 2 (profiles/README.md): opt-in
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_write -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 > /dev/null 2>&1
+# counter passes: separate runs, --kernel-trace only.  The canvases are synthesised in-process (--gen-procs 1, 16 of them): rocprofv3 --pmc hangs when the
+# profiled process forks worker processes (what killed every counter pass earlier in round 2, profiles/README.md)
+PF="--gen-procs 1 --canvases 16 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_fetch -- python $R/bench.py $PF > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_write -- python $R/bench.py $PF > /dev/null 2>&1
 python $R/tools/pmc_summary.py $O/${tag}_pmc_fetch $O/${tag}_pmc_write > $O/${tag}_pmc_fetch_write_kb_per_launch.csv 2>> $O/${tag}_bench.err
-fi
 cd $R
 f=$(ls $O/${tag}_trace/*/*kernel_stats.csv | head -1); cp $f $O/${tag}_kernel_stats.csv
 t=$(ls $O/${tag}_trace/*/*kernel_trace.csv | head -1); (head -1 $t; tail -80 $t) > $O/${tag}_kernel_trace_tail.csv
