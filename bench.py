@@ -262,8 +262,7 @@ def main():
     # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this
     # command, KB per launch, summed over the stage's kernels); raw counter sums (narrow gathers: no wide-read correction applied)
     traffic = None
-    traffic_note = ("null: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes did not complete on the MI355X pool in round 2 (five attempts, each killed by its timeout - the "
-                    "ORB-only workload that profiled in round 1 included; profiles/README.md); round-1 figure for the plane stage: 8.4 MB read + 8.7 MB written per frame")
+    traffic_note = "null: profiles/r02_pmc_fetch_write_kb_per_launch.csv (tools/collect_profiles.sh) not found"
     pmc_csv = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_kb_per_launch.csv")
     pmc_keys = {"peac_blocks+peac_ahc+peac_refine": ("planar::peac::peac_blocks", "planar::peac::peac_ahc", "planar::peac::peac_refine"),
                 "lsd_detect(+7 small kernels)": ("planar::lsd::lsd_detect",)}.get(dom, ("planar::orb::" + dom,))
