@@ -322,6 +322,14 @@ static void put_info(const orc::RefitInfo& I, int32_t* info) {
     std::memcpy(info + 8, I.model, 16);
 }
 
+// pcl::SACSegmentation::segment alone (what tools/pcl_golden/ dumps from PCL itself): returns 1 if it yields inliers; coef [4], info as below
+int orc_sac_plane(const float* pts, int n, double threshold, float* coef, int32_t* info) {
+    orc::RefitInfo I;
+    const bool ok = orc::sac_plane(pts, n, threshold, coef, &I);
+    put_info(I, info);
+    return ok ? 1 : 0;
+}
+
 // Frame::MaxPointDistanceFromPlane: returns the state (0 kept, 1 distance, 2 no inliers); plane in/out
 int orc_plane_refit(float* plane, const float* pts, int n, double disTh, int32_t* info) {
     orc::RefitInfo I;
