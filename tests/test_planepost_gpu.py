@@ -182,3 +182,33 @@ def test_plane_clouds_8192_voxels_same_result():
     for x, y in zip(a, b):
         for k in ("coef", "src", "pt_off", "points"):
             assert np.array_equal(x[k], y[k]), k
+
+
+def test_plane_clouds_other_size_and_row_pitch():
+    """320 x 240 (5 column strips, 4 row tiles) against the oracle, and a padded depth buffer (pitch > width) through the ABI directly."""
+    import ctypes as C
+    from planarslam_amd import PlaneClouds, PlaneDetection
+    from planarslam_amd._lib import check, lib
+    W, H = 320, 240
+    cam = (267.7, 269.6, 160.05, 123.8)
+    d = depth_image(77, W, H)
+    planes, labels = PlaneDetection(W, H).run(d, K=cam)
+    op, olab = ol.peac_run(d, *cam)
+    assert np.array_equal(labels, olab) and len(planes) >= 1
+    pl = np.zeros((1, 128, 8)); pl[0, :len(planes)] = planes
+    npl = np.array([len(planes)], np.int32)
+    pcz = PlaneClouds(W, H)
+    got = pcz.compute(d[None], labels[None], pl, npl, K=cam, debug=True)[0]
+    want = ol.plane_clouds(d, labels, planes, cam=cam)
+    assert got["n"] == want["n"] and np.array_equal(got["state"], want["state"]) and np.array_equal(got["pt_off"], want["pt_off"]) and np.array_equal(got["nvox"], want["nvox"])
+    assert np.abs(got["points"] - want["points"]).max(initial=0) < 2e-5
+    # the same frame with 24 bytes of padding per depth row
+    pitch = W + 12
+    dp = np.zeros((H, pitch), np.uint16); dp[:, :W] = d; dp[:, W:] = 12345
+    PS, MP = pcz.pl_stride, pcz.max_points
+    n = np.zeros(1, np.int32); coef = np.zeros((1, PS, 4), np.float32); src = np.zeros((1, PS), np.int32); off = np.zeros((1, PS + 1), np.int32); pts = np.zeros((1, MP, 3), np.float32)
+    lab = np.ascontiguousarray(labels[None], np.int32)
+    check(lib().planar_plane_clouds_compute(pcz.h, dp.ctypes.data, 1, pitch, pitch * H, cam[0], cam[1], cam[2], cam[3], np.float32(1.0 / 5000.0), lab.ctypes.data, pl.ctypes.data,
+                                            npl.ctypes.data, 0.05, np.float32(0.1), n.ctypes.data, coef.ctypes.data, src.ctypes.data, off.ctypes.data, pts.ctypes.data, None, None, None))
+    k = got["n"]
+    assert n[0] == k and np.array_equal(off[0, :k + 1], got["pt_off"]) and np.array_equal(coef[0, :k], got["coef"]) and np.array_equal(pts[0, :off[0, k]], got["points"])
