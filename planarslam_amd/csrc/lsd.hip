@@ -338,6 +338,104 @@ __device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, i
     return cut;
 }
 
+// The same partition for ranges in GLOBAL memory, with less traffic: wavefront w writes the stops of its own share [q0_w, q1_w) of the range into Lb / Rb
+// at the share's own positions, as 16-bit offsets from q0_w, in ONE pass over the keys.  There is no counting pass: the k-th stop of the left scan
+// (ascending) and of the right scan (descending) are found through the per-wavefront counts.  Needs shares of < 65536 elements.
+__device__ __forceinline__ int wg_partition_rel(uint32_t* arr, uint16_t* Lb, uint16_t* Rb, int f, int l, int tid, int* s_wl, int* s_wr, int* bc) {
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {   // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
+        const uint32_t xa = arr[A], xb = arr[Bm], xc = arr[Cc], xf = arr[f];
+        const uint32_t a = xa >> 20, bq = xb >> 20, c = xc >> 20;
+        int t; uint32_t xt;
+        if (a > bq) { if (bq > c) { t = Bm; xt = xb; } else if (a > c) { t = Cc; xt = xc; } else { t = A; xt = xa; } }
+        else if (a > c) { t = A; xt = xa; }
+        else if (bq > c) { t = Cc; xt = xc; }
+        else { t = Bm; xt = xb; }
+        arr[f] = xt; arr[t] = xf;
+        bc[0] = (int)(xt >> 20); bc[1] = t; bc[2] = (int)xf;
+    }
+    __syncthreads();
+    const uint32_t pv = (uint32_t)bc[0];
+    const int tpos = bc[1];
+    const uint32_t tval = (uint32_t)bc[2] >> 20;                  // the element now at position t (the old front)
+    constexpr int U = 8;
+    const int len = l - (f + 1), qlen = (len + SORT_NW - 1) / SORT_NW;
+    const int q0 = f + 1 + min(len, wave * qlen), q1 = f + 1 + min(len, wave * qlen + qlen);
+    int cl = 0, cr = 0;
+    for (int base = q0; base < q1; base += 64 * U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = arr[min(base + 64 * u + lane, q1 - 1)];          // unconditional loads: all U in flight
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : v[u] >> 20) : 0xffffffffu; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + 64 * u + lane;
+            const bool isL = i < q1 && !(v[u] > pv), isR = i < q1 && !(pv > v[u]);
+            const unsigned long long mkL = __ballot(isL), mkR = __ballot(isR);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (isL) Lb[q0 + cl + __popcll(mkL & below)] = (uint16_t)(i - q0);
+            if (isR) Rb[q0 + cr + __popcll(mkR & below)] = (uint16_t)(i - q0);
+            cl += __popcll(mkL); cr += __popcll(mkR);
+        }
+    }
+    if (lane == 0) { s_wl[wave] = cl; s_wr[wave] = cr; }
+    if (tid == 0) bc[3] = 0;
+    __syncthreads();
+    int pl[SORT_NW + 1], sr[SORT_NW + 1], wq0[SORT_NW], wcr[SORT_NW];      // pl[w]: left stops before wavefront w; sr[w]: right stops behind it
+    pl[0] = 0;
+#pragma unroll
+    for (int q = 0; q < SORT_NW; q++) { pl[q + 1] = pl[q] + s_wl[q]; wcr[q] = s_wr[q]; wq0[q] = f + 1 + min(len, q * qlen); }
+    sr[SORT_NW - 1] = 0;
+#pragma unroll
+    for (int q = SORT_NW - 2; q >= 0; q--) sr[q] = sr[q + 1] + wcr[q + 1];
+    const int totL = pl[SORT_NW], totR = sr[0] + wcr[0];
+    auto Lat = [&](int k) {                                       // k-th stop of the left scan
+        int w = 0;
+#pragma unroll
+        for (int q = 1; q < SORT_NW; q++) w += k >= pl[q];
+        int b0 = wq0[0], p0 = pl[0];
+#pragma unroll
+        for (int q = 1; q < SORT_NW; q++) if (w == q) { b0 = wq0[q]; p0 = pl[q]; }
+        return b0 + (int)Lb[b0 + (k - p0)];
+    };
+    auto Rat = [&](int k) {                                       // k-th stop of the right scan (it walks downwards)
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < SORT_NW - 1; q++) c += k >= sr[q];
+        const int w = SORT_NW - 1 - c;
+        int b0 = wq0[0], s0 = sr[0], c0 = wcr[0];
+#pragma unroll
+        for (int q = 1; q < SORT_NW; q++) if (w == q) { b0 = wq0[q]; s0 = sr[q]; c0 = wcr[q]; }
+        return b0 + (int)Rb[b0 + (c0 - 1 - (k - s0))];
+    };
+    const int kmax = min(totL, totR);
+    int good = 0;
+    constexpr int PU = 4;                                         // pairs in flight per thread (two dependent round trips each)
+    for (int k0 = tid; k0 < kmax; k0 += SORT_NT * PU) {
+        int Lk[PU], Rk[PU];
+        uint32_t xl[PU], xr[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) { const int k = min(k0 + SORT_NT * u, kmax - 1); Lk[u] = Lat(k); Rk[u] = Rat(k); }
+#pragma unroll
+        for (int u = 0; u < PU; u++) if (k0 + SORT_NT * u >= kmax) { Lk[u] = 1; Rk[u] = 0; }
+#pragma unroll
+        for (int u = 0; u < PU; u++) { xl[u] = arr[max(Lk[u], f)]; xr[u] = arr[max(Rk[u], f)]; }      // unconditional: all loads in flight
+#pragma unroll
+        for (int u = 0; u < PU; u++) if (Lk[u] < Rk[u]) { arr[Lk[u]] = xr[u]; arr[Rk[u]] = xl[u]; good++; }
+    }
+    for (int o = 32; o >= 1; o >>= 1) good += __shfl_xor(good, o, 64);
+    if (lane == 0 && good) atomicAdd(&bc[3], good);
+    __syncthreads();
+    const int m = bc[3];                                          // the swapped pairs are a prefix of the pair list
+    int cut = 0x7fffffff;
+    if (m < totL) cut = min(cut, Lat(m));
+    if (m > 0) cut = min(cut, Rat(m - 1));
+    __syncthreads();
+    return cut;
+}
+
 // ---- K3: the visiting order: descending 1024-bin order; ties per plan->tie_order ---------------------------------------------------
 __global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int tie_order) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
@@ -383,7 +481,8 @@ __global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ pla
                 if (R.l - R.f <= 16) continue;
                 if (R.l - R.f <= SORT_STAGE) { if (tid == 0) staged[atomicAdd(&s_nsmall, 1)] = R; continue; }
                 if (R.d == 0) { if (tid == 0) misc->status = 2; continue; }
-                const int cut = wg_partition<uint32_t>(arr, ord, ordr, R.f, R.l, tid, s_wl, s_wr, s_bc);
+                const int cut = (R.l - R.f - 1 + SORT_NW - 1) / SORT_NW < 65536 ? wg_partition_rel(arr, (uint16_t*)ord, (uint16_t*)ordr, R.f, R.l, tid, s_wl, s_wr, s_bc)
+                                                                              : wg_partition<uint32_t>(arr, ord, ordr, R.f, R.l, tid, s_wl, s_wr, s_bc);
                 if (tid == 0) { const int k = atomicAdd(&s_nnext, 2); next[k] = SortRange{cut, R.l, R.d - 1}; next[k + 1] = SortRange{R.f, cut, R.d - 1}; }
             }
             __syncthreads();
