@@ -320,9 +320,9 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     __shared__ int s_ext[MAX_PLANES], s_old[RP], s_plidmap[RP];
     __shared__ uint8_t s_valid[RP];
     __shared__ unsigned s_adj[RP][MAX_PLANES / 32];
-    constexpr int NSLOT = 2048;                               // pixel -> slot hash of the flood fill (pairs of one step: 1024)
+    constexpr int NSLOT = 4096;                               // pixel -> slot hash of the flood fill (pairs of one step: 2048)
     __shared__ int s_slot[PHASE == 1 ? NSLOT : 1];
-    __shared__ int s_pcnt[16];
+    __shared__ int s_pcnt[32];
     __shared__ int s_scalar[4];   // [0] n_ext, [1] err, [2] q_tail, [3] scratch
     constexpr int EVAL_MAX = 64;   // nodes evaluated per cooperative phase
     __shared__ int s_cmd, s_nlist;
@@ -990,13 +990,13 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     __syncthreads();
     mark();
 
-    // ---- floodFill (:428-476), all threads.  Per step: 256 queue entries x 4 neighbours = 1024 (entry, neighbour) pairs, four per thread
+    // ---- floodFill (:428-476), all threads.  Per step: 512 queue entries x 4 neighbours = 2048 (entry, neighbour) pairs, eight per thread
     //      (pair p = entry * 4 + direction is the reference's processing order).  Pairs that hit the same pixel are replayed in pair order:
     //      per round the smallest pair index wins the pixel's slot (atomicMin on a key whose high bits count the rounds DOWN, so stale
     //      entries of earlier rounds lose by themselves and the slots are never reset); plane-plane connect() is a commutative set
     //      insertion and goes to an LDS bit matrix; queue pushes are appended in pair order.
     {
-        constexpr int FJ = 4;                                      // pairs per thread and step
+        constexpr int FJ = 8;                                      // pairs per thread and step (512 queue entries per step: the step count, not the work, sets the time)
         unsigned* slot = (unsigned*)s_slot;
         for (int t = tid; t < NSLOT; t += NT) slot[t] = 0xffffffffu;
         __syncthreads();
