@@ -174,6 +174,13 @@ int planar_hamming_knn(planar_ctx* ctx, const uint8_t* q, const int32_t* nq, int
 int planar_hamming_knn_dev(planar_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, int q_stride, const uint8_t* d_t,
                            const int32_t* d_nt, int t_stride, int B, int k, int32_t* d_idx, int32_t* d_dist);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:259-324) for n_points map points at once: point p observes the descriptors
+ * desc[off[p] .. off[p + 1]) (the rows pKF->mDescriptors.row(idx) of its non-bad key frames, in the order of the observation map); best[p] = index within that
+ * list of the descriptor with the least median Hamming distance to all of them (first minimum; -1 without observations), median[p] (or NULL) that median.
+ * _dev: max_obs = an upper bound of the observations per point (<= 2047; a point with more gets best = -2). */
+int planar_distinctive_descriptors(planar_ctx* ctx, int n_points, const uint8_t* desc, const int32_t* off, int32_t* best, int32_t* median);
+int planar_distinctive_descriptors_dev(planar_ctx* ctx, int n_points, const uint8_t* d_desc, const int32_t* d_off, int max_obs, int32_t* d_best, int32_t* d_median);
+
 /* ORBmatcher::MatchORBPoints(Frame& Current, const Frame& Last) (src/ORBmatcher.cc:1332-1394).
  *   last_has_mp[j]   LastFrame.mvpMapPoints[j] != NULL        last_outlier[j]  LastFrame.mvbOutlier[j]
  *   cur_match[q]     (in/out) index j of the last-frame keypoint whose MapPoint the reference copies into

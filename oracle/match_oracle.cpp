@@ -76,9 +76,26 @@ int lsd_search_by_descriptor(const uint8_t* kf, int n_kf, const uint8_t* cur, in
     return nmatches;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:259-324): among the n observed descriptors, the one whose median Hamming
+// distance to all of them (itself included: 0) is least; median = sorted[int(0.5 * (n - 1))]; the first such descriptor wins.  Returns its index
+// (-1 for n == 0) and the median.
+int distinctive_descriptor(const uint8_t* desc, int n, int* median_out) {
+    int best_median = INT32_MAX, best = n > 0 ? 0 : -1;
+    std::vector<int> row(n);
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) row[j] = i == j ? 0 : descriptor_distance(desc + 32 * (size_t)i, desc + 32 * (size_t)j);
+        std::sort(row.begin(), row.end());
+        const int median = row[(size_t)(0.5 * (n - 1))];
+        if (median < best_median) { best_median = median; best = i; }
+    }
+    if (median_out) *median_out = n > 0 ? best_median : 0;
+    return best;
+}
+
 }  // namespace orc
 
 extern "C" {
+int orc_distinctive_descriptor(const uint8_t* desc, int n, int* median) { return orc::distinctive_descriptor(desc, n, median); }
 int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return orc::descriptor_distance(a, b); }
 void orc_bf_knn(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, int32_t* dist) { orc::bf_knn(q, nq, t, nt, k, idx, dist); }
 int orc_match_orb_points(const uint8_t* cur, int n_cur, const uint8_t* last, int n_last, const uint8_t* has_mp, const uint8_t* outl, int32_t* m) {

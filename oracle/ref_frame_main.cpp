@@ -7,6 +7,7 @@
 //   area             Frame::AssignFeaturesToGrid + GetFeaturesInArea queries, GetLinesInArea queries
 //   plane_world      Frame::ComputePlaneWorldCoeff
 //   stereo           Frame::ComputeStereoFromRGBD + UnprojectStereo
+//   distinctive      MapPoint::ComputeDistinctiveDescriptors (+ ORBmatcher::DescriptorDistance)
 // This file only moves data; every computed number comes out of the reference's own function bodies.
 #include <cstdio>
 #include <cstdlib>
@@ -187,6 +188,29 @@ int run_plane_world(Reader& r, Writer& w) {
     for (int i = 0; i < n; i++) { cv::Mat c = F.ComputePlaneWorldCoeff(i); w.arr((const float*)c.data, 4); }
     return 0;
 }
+// in: int32 npoints; per point int32 nobs, uint8 bad[nobs], uint8 desc[nobs][32].  out: per point uint8 mDescriptor[32] (zeros if it stays empty).
+// The observing key frames live in one array, so the std::map<KeyFrame*, size_t> iterates them in index order.
+int run_distinctive(Reader& r, Writer& w) {
+    const int np = r.get<int>();
+    for (int p = 0; p < np; p++) {
+        const int n = r.get<int>();
+        const unsigned char* bad = r.arr<unsigned char>(n);
+        const unsigned char* d = r.arr<unsigned char>((size_t)n * 32);
+        std::vector<KeyFrame> kfs(n);
+        MapPoint mp;
+        for (int i = 0; i < n; i++) {
+            kfs[i].mDescriptors = cv::Mat(1, 32, CV_8U);
+            memcpy(kfs[i].mDescriptors.data, d + (size_t)i * 32, 32);
+            kfs[i].mbBad = bad[i] != 0;
+            mp.mObservations[&kfs[i]] = 0;
+        }
+        mp.ComputeDistinctiveDescriptors();
+        unsigned char out[32] = {0};
+        if (!mp.mDescriptor.empty()) memcpy(out, mp.mDescriptor.data, 32);
+        w.arr(out, 32);
+    }
+    return 0;
+}
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -200,5 +224,6 @@ int main(int argc, char** argv) {
     if (m == "area") return run_area(r, w);
     if (m == "plane_world") return run_plane_world(r, w);
     if (m == "stereo") return run_stereo(r, w);
+    if (m == "distinctive") return run_distinctive(r, w);
     return 2;
 }

@@ -7,12 +7,16 @@
 //   src/Frame.cc:440-535    GetFeaturesInArea / GetLinesInArea / PosInGrid               src/Frame.cc:815-820   ComputePlaneWorldCoeff
 //   src/Frame.cc:603-634    ComputeStereoFromRGBD / UnprojectStereo
 //   src/MapPoint.cc:390-434 Get{Min,Max}DistanceInvariance, PredictScale x2             src/MapLine.cpp:369-390 the same for lines
+//   src/MapPoint.cc:259-324 MapPoint::ComputeDistinctiveDescriptors                       src/ORBmatcher.cc:1710-1728 ORBmatcher::DescriptorDistance
 //   src/Tracking.cc:763-1157 ProjectSN2MF (5 arguments), ProjectSN2Conic, TrackManhattanFrame, MeanShift
 // The member names and types are the real headers' (include/Frame.h, MapPoint.h, MapLine.h, Tracking.h, LSDextractor.h:33-57,141-199); the
 // function bodies are the reference's own.  The whole files cannot be built here: they need PCL, the extractors, the viewer stack.
 #pragma once
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <iostream>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -51,6 +55,14 @@ class KeyFrame {
 public:
     float mfLogScaleFactor = 0;
     int mnScaleLevels = 0;
+    cv::Mat mDescriptors;                        // include/KeyFrame.h: one row per keypoint
+    bool mbBad = false;
+    bool isBad() { return mbBad; }
+};
+
+class ORBmatcher {
+public:
+    static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);     // include/ORBmatcher.h:44
 };
 
 class MapPoint {
@@ -68,6 +80,11 @@ public:
     cv::Mat mWorldPos, mNormalVector;
     float mfMinDistance = 0, mfMaxDistance = 0;
     std::mutex mMutexPos;
+    void ComputeDistinctiveDescriptors();
+    std::map<KeyFrame*, size_t> mObservations;   // include/MapPoint.h: keyframe -> index of the observing keypoint
+    cv::Mat mDescriptor;
+    bool mbBad = false;
+    std::mutex mMutexFeatures;
 };
 
 class MapLine {

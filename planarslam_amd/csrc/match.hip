@@ -11,6 +11,8 @@
 // (10^6 pairs = 4x10^6 64-bit popcounts per 1000x1000 frame pair), not HBM bound.
 #include "common.h"
 
+#include <algorithm>
+
 namespace planar {
 namespace match {
 
@@ -136,6 +138,43 @@ static int launch_knn(planar_ctx* ctx, const uint8_t* q, const int32_t* nq, int 
     return PLANAR_OK;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:259-324) for a batch of map points: one wavefront per point.  The point's n descriptors are
+// staged in LDS; lane i owns rows i, i + 64, ...: the median of row i (sorted[(n - 1) / 2], the row includes the zero of the diagonal) is the smallest v with
+// #{j : d(i, j) <= v} > (n - 1) / 2, found by bisection over v in [0, 256] (nine passes over the row, distances recomputed: 8 popcounts each); the winner is the
+// smallest (median, index).  best: index within the point's list, -1 without observations, -2 if it has more than max_obs.
+__global__ __launch_bounds__(64) void distinctive_kernel(const unsigned char* __restrict__ desc, const int* __restrict__ off, int max_obs, int* __restrict__ best,
+                                                         int* __restrict__ median) {
+    extern __shared__ unsigned s_desc[];                          // [n][8] words
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int o0 = off[p], n = off[p + 1] - o0;
+    if (n <= 0 || n > max_obs) { if (lane == 0) { best[p] = n <= 0 ? -1 : -2; if (median) median[p] = 0; } return; }
+    const unsigned* src = (const unsigned*)(desc + (size_t)o0 * 32);
+    for (int t = lane; t < n * 8; t += 64) s_desc[t] = src[t];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const int r = (n - 1) >> 1;                                   // int(0.5 * (n - 1))
+    unsigned key = 0xffffffffu;                                   // median << 11 | row, smallest wins
+    for (int i = lane; i < n; i += 64) {
+        unsigned a[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) a[w] = s_desc[i * 8 + w];
+        int lo = 0, hi = 256;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int j = 0; j < n; j++) {
+                int d = 0;
+#pragma unroll
+                for (int w = 0; w < 8; w++) d += __popc(a[w] ^ s_desc[j * 8 + w]);
+                c += d <= mid;
+            }
+            if (c > r) hi = mid; else lo = mid + 1;
+        }
+        key = min(key, ((unsigned)lo << 11) | (unsigned)i);
+    }
+    for (int o = 32; o >= 1; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o, 64));
+    if (lane == 0) { best[p] = (int)(key & 2047u); if (median) median[p] = (int)(key >> 11); }
+}
+
 }  // namespace match
 }  // namespace planar
 
@@ -237,6 +276,32 @@ int planar_lsd_search_by_descriptor(planar_ctx* ctx, const uint8_t* kf, const in
     rc = planar_lsd_search_by_descriptor_dev(ctx, s.dev<uint8_t>(a), s.dev<int32_t>(b), kf_stride, s.dev<uint8_t>(c), s.dev<int32_t>(d),
                                              cur_stride, s.dev<uint8_t>(e), B, s.dev<int32_t>(g), s.dev<int32_t>(h));
     if (rc) return rc;
+    return s.download(ctx->stream);
+}
+
+int planar_distinctive_descriptors_dev(planar_ctx* ctx, int n_points, const uint8_t* d_desc, const int32_t* d_off, int max_obs, int32_t* d_best, int32_t* d_median) {
+    PLANAR_REQUIRE(ctx && d_desc && d_off && d_best, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(n_points >= 1 && max_obs >= 1 && max_obs <= 2047, PLANAR_EINVAL, "n_points >= 1, 1 <= max_obs <= 2047");
+    const size_t smem = (size_t)max_obs * 32;
+    if (smem > 40 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)match::distinctive_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(match::distinctive_kernel, dim3(n_points), dim3(64), smem, ctx->stream, d_desc, d_off, max_obs, d_best, d_median);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_distinctive_descriptors(planar_ctx* ctx, int n_points, const uint8_t* desc, const int32_t* off, int32_t* best, int32_t* median) {
+    PLANAR_REQUIRE(ctx && desc && off && best, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(n_points >= 1 && off[0] == 0, PLANAR_EINVAL, "n_points >= 1, off[0] == 0");
+    int max_obs = 1;
+    for (int p = 0; p < n_points; p++) { PLANAR_REQUIRE(off[p + 1] >= off[p], PLANAR_EINVAL, "off must be non-decreasing"); max_obs = std::max(max_obs, off[p + 1] - off[p]); }
+    PLANAR_REQUIRE(max_obs <= 2047, PLANAR_EINVAL, "a map point may have at most 2047 observations");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    const int i_d = s.in(desc, (size_t)off[n_points] * 32), i_o = s.in(off, (size_t)(n_points + 1) * 4), o_b = s.out(best, (size_t)n_points * 4),
+              o_m = median ? s.out(median, (size_t)n_points * 4) : -1;
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    if ((rc = planar_distinctive_descriptors_dev(ctx, n_points, s.dev<uint8_t>(i_d), s.dev<int32_t>(i_o), max_obs, s.dev<int32_t>(o_b), median ? s.dev<int32_t>(o_m) : nullptr))) return rc;
     return s.download(ctx->stream);
 }
 

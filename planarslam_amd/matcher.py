@@ -27,6 +27,19 @@ def hamming_knn(q, nq, t, nt, k=1, ctx: Context | None = None):
     return idx, dist
 
 
+def distinctive_descriptors(observations, ctx: Context | None = None):
+    """MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:259-324) for a batch of map points: observations = list of [n_p, 32] uint8 arrays (the
+    descriptors of the point's non-bad observing key frames, in observation-map order) -> (best [P] index per point, -1 = none; median [P])."""
+    ctx = ctx or Context(0)
+    P = len(observations)
+    off = np.zeros(P + 1, np.int32)
+    off[1:] = np.cumsum([len(o) for o in observations])
+    desc = np.ascontiguousarray(np.concatenate([np.asarray(o, np.uint8).reshape(-1, 32) for o in observations] + [np.zeros((1, 32), np.uint8)]), np.uint8)
+    best = np.zeros(P, np.int32); med = np.zeros(P, np.int32)
+    check(lib().planar_distinctive_descriptors(ctx.h, P, desc.ctypes.data, off.ctypes.data, best.ctypes.data, med.ctypes.data))
+    return best, med
+
+
 class ORBmatcher:
     TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
 

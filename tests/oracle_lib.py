@@ -900,3 +900,22 @@ def sac_rnd(n, seed=12345):
     out = np.zeros(n, np.int32)
     lib().orc_sac_rnd(C.c_uint32(seed), n, C.c_void_p(out.ctypes.data))
     return out
+
+
+# ---- MapPoint::ComputeDistinctiveDescriptors (oracle/match_oracle.cpp; the REAL src/MapPoint.cc:259-324 through oracle/_ref/ref_frame) ----
+def distinctive_descriptor(desc):
+    """-> (index of the chosen descriptor (-1: none), its median distance)"""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    med = C.c_int()
+    L = lib()
+    L.orc_distinctive_descriptor.restype = C.c_int
+    return L.orc_distinctive_descriptor(C.c_void_p(desc.ctypes.data), len(desc), C.byref(med)), med.value
+
+
+def run_ref_distinctive(points):
+    """points: list of (desc [n,32] u8, bad [n] u8) -> [len(points), 32] u8: mDescriptor after the reference's own ComputeDistinctiveDescriptors (zeros if unset)."""
+    pay = np.int32(len(points)).tobytes()
+    for desc, bad in points:
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); bad = np.ascontiguousarray(bad, np.uint8)
+        pay += np.int32(len(desc)).tobytes() + bad.tobytes() + desc.tobytes()
+    return np.frombuffer(_run_ref_frame("distinctive", pay), np.uint8).reshape(len(points), 32).copy()
