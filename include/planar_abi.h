@@ -607,6 +607,20 @@ int planar_stereo_from_rgbd_dev(planar_ctx* ctx, int B, const planar_keypoint* d
                                 const uint16_t* d_depth, int pitch_px, int64_t frame_stride_px, float depth_factor, float fx, float fy, float cx,
                                 float cy, float bf, const float* d_Tcw, float* d_u_right, float* d_depth_out, float* d_xw, uint8_t* d_valid);
 
+/* MapPoint::UpdateNormalAndDepth (src/MapPoint.cc:347-388) for G groups of map points; group g = the points whose reference key frame (mpRefKF) has the pose
+ * ref_Tcw[g] - e.g. the back-projected keypoints of one frame.  Its camera centre is formed as KeyFrame::SetPose does (src/KeyFrame.cc:85-86).
+ *   n [G], xw [G][stride][3] (GetWorldPos), valid [G][stride] or NULL (0 = no point: its outputs are left alone)
+ *   keys_un [G][stride]: the point's keypoint in the reference key frame (its octave selects mvScaleFactors[level])
+ *   obs_off [G * stride + 1], obs_ow [obs_off[G * stride]][3]: camera centres of the key frames observing each point, in observation-map order; both NULL:
+ *            every point is observed by its reference key frame only
+ *   normal [G][stride][3] (mNormalVector), min_dist / max_dist [G][stride] (mfMinDistance / mfMaxDistance); a point without observations keeps its values */
+int planar_update_normal_and_depth(planar_ctx* ctx, int G, const int32_t* n, int stride, const float* xw, const uint8_t* valid, const float* ref_Tcw,
+                                   const planar_keypoint* keys_un, const int32_t* obs_off, const float* obs_ow, const float* scale_factors, int n_levels,
+                                   float* normal, float* min_dist, float* max_dist);
+int planar_update_normal_and_depth_dev(planar_ctx* ctx, int G, const int32_t* d_n, int stride, const float* d_xw, const uint8_t* d_valid, const float* d_ref_Tcw,
+                                       const planar_keypoint* d_keys_un, const int32_t* d_obs_off, const float* d_obs_ow, const float* scale_factors,
+                                       int n_levels, float* d_normal, float* d_min_dist, float* d_max_dist);
+
 /* What Optimizer::PoseOptimization / TranslationOptimization read from the Frame once the matchers have filled mvpMapPoints / mvpMapLines /
  * mvpMapPlanes / mvpParallelPlanes / mvpVerticalPlanes (src/Optimizer.cc:593-668, 689-745, 859-981), as match INDICES into the arrays of
  * the matched-against objects.  -1 = no association.                                                                                 */

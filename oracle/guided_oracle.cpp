@@ -545,3 +545,36 @@ extern "C" int orc_stereo_from_rgbd(const planar_keypoint* keys, const planar_ke
     orc::stereo_from_rgbd(keys, keys_un, n, depth, pitch_px, factor, fx, fy, cx, cy, bf, Tcw, u_right, z_out, xw, valid);
     return 0;
 }
+
+// ---- MapPoint::UpdateNormalAndDepth (reference src/MapPoint.cc:347-388) with KeyFrame::SetPose's camera centre (src/KeyFrame.cc:79-86) ----
+// Ow = -Rwc * tcw with Rwc = Rcw.t() materialised: cv::gemm's float small-matrix path (products summed in float, left to right), negated.
+extern "C" void orc_keyframe_center(const float* Tcw, float* Ow) {
+    for (int r = 0; r < 3; r++) {
+        float t = Tcw[0 * 4 + r] * Tcw[3];
+        t = t + Tcw[1 * 4 + r] * Tcw[7];
+        t = t + Tcw[2 * 4 + r] * Tcw[11];
+        Ow[r] = (float)((double)t * -1.0);
+    }
+}
+// pos [3]; obs_ow [nobs][3]: camera centres of the observing key frames in observation-map order; ref_ow: mpRefKF's; level: octave of the point's keypoint there.
+// normal: sum of normali * (float)(1 / |normali|) (cv::norm accumulates in double; Mat / double is a convertTo with the scale cast to float; the running sum is
+// alpha * A + beta * C in float), times (float)(1.0 / n); dist = (float)|Pos - Ow_ref|; max = dist * sf[level]; min = max / sf[nlev - 1].
+extern "C" void orc_update_normal_and_depth(const float* pos, const float* obs_ow, int nobs, const float* ref_ow, int level, const float* sf, int nlev, float* normal,
+                                            float* min_d, float* max_d) {
+    if (nobs <= 0) return;
+    float nrm[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < nobs; i++) {
+        float d[3];
+        double s = 0;
+        for (int k = 0; k < 3; k++) { d[k] = pos[k] - obs_ow[i * 3 + k]; s += (double)d[k] * (double)d[k]; }
+        const float fa = (float)(1.0 / std::sqrt(s));
+        for (int k = 0; k < 3; k++) nrm[k] = d[k] * fa + nrm[k] * 1.0f;
+    }
+    double s = 0;
+    for (int k = 0; k < 3; k++) { const float pc = pos[k] - ref_ow[k]; s += (double)pc * (double)pc; }
+    const float dist = (float)std::sqrt(s);
+    *max_d = dist * sf[level];
+    *min_d = *max_d / sf[nlev - 1];
+    const float fn = (float)(1.0 / (double)nobs);
+    for (int k = 0; k < 3; k++) normal[k] = nrm[k] * fn;
+}

@@ -8,6 +8,7 @@
 //   plane_world      Frame::ComputePlaneWorldCoeff
 //   stereo           Frame::ComputeStereoFromRGBD + UnprojectStereo
 //   distinctive      MapPoint::ComputeDistinctiveDescriptors (+ ORBmatcher::DescriptorDistance)
+//   normal_depth     MapPoint::UpdateNormalAndDepth (+ KeyFrame::SetPose, GetCameraCenter)
 // This file only moves data; every computed number comes out of the reference's own function bodies.
 #include <cstdio>
 #include <cstdlib>
@@ -211,6 +212,34 @@ int run_distinctive(Reader& r, Writer& w) {
     }
     return 0;
 }
+// in: int32 nkf, nlev; float sf[nlev]; per key frame float Tcw[16]; int32 npoints; per point float pos[3], int32 ref (index of mpRefKF), level (octave of its
+// keypoint there), nobs, int32 obs[nobs] (observing key frames).  out: per point float normal[3], min, max.
+int run_normal_depth(Reader& r, Writer& w) {
+    const int nkf = r.get<int>(), nlev = r.get<int>();
+    const float* sf = r.arr<float>(nlev);
+    std::vector<KeyFrame> kfs(nkf);
+    for (int k = 0; k < nkf; k++) {
+        kfs[k].SetPose(mat_f32(4, 4, r.arr<float>(16)));
+        kfs[k].mvScaleFactors.assign(sf, sf + nlev);
+        kfs[k].mnScaleLevels = nlev;
+        kfs[k].mvKeysUn.resize(1);
+    }
+    const int np = r.get<int>();
+    for (int p = 0; p < np; p++) {
+        MapPoint mp;
+        mp.mWorldPos = mat_f32(3, 1, r.arr<float>(3));
+        const int ref = r.get<int>(), level = r.get<int>(), nobs = r.get<int>();
+        const int* obs = r.arr<int>(nobs);
+        for (int i = 0; i < nobs; i++) mp.mObservations[&kfs[obs[i]]] = 0;
+        mp.mpRefKF = &kfs[ref];
+        kfs[ref].mvKeysUn[0].octave = level;
+        mp.mNormalVector = cv::Mat::zeros(3, 1, CV_32F);
+        mp.UpdateNormalAndDepth();
+        w.arr((const float*)mp.mNormalVector.data, 3);
+        w.put(mp.mfMinDistance); w.put(mp.mfMaxDistance);
+    }
+    return 0;
+}
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -225,5 +254,6 @@ int main(int argc, char** argv) {
     if (m == "plane_world") return run_plane_world(r, w);
     if (m == "stereo") return run_stereo(r, w);
     if (m == "distinctive") return run_distinctive(r, w);
+    if (m == "normal_depth") return run_normal_depth(r, w);
     return 2;
 }

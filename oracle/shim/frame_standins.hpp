@@ -8,6 +8,7 @@
 //   src/Frame.cc:603-634    ComputeStereoFromRGBD / UnprojectStereo
 //   src/MapPoint.cc:390-434 Get{Min,Max}DistanceInvariance, PredictScale x2             src/MapLine.cpp:369-390 the same for lines
 //   src/MapPoint.cc:259-324 MapPoint::ComputeDistinctiveDescriptors                       src/ORBmatcher.cc:1710-1728 ORBmatcher::DescriptorDistance
+//   src/MapPoint.cc:347-388 MapPoint::UpdateNormalAndDepth                                src/KeyFrame.cc:79-93, 107-111 KeyFrame::SetPose, GetCameraCenter
 //   src/Tracking.cc:763-1157 ProjectSN2MF (5 arguments), ProjectSN2Conic, TrackManhattanFrame, MeanShift
 // The member names and types are the real headers' (include/Frame.h, MapPoint.h, MapLine.h, Tracking.h, LSDextractor.h:33-57,141-199); the
 // function bodies are the reference's own.  The whole files cannot be built here: they need PCL, the extractors, the viewer stack.
@@ -58,6 +59,13 @@ public:
     cv::Mat mDescriptors;                        // include/KeyFrame.h: one row per keypoint
     bool mbBad = false;
     bool isBad() { return mbBad; }
+    void SetPose(const cv::Mat& Tcw);
+    cv::Mat GetCameraCenter();
+    std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<float> mvScaleFactors;
+    cv::Mat Tcw, Twc, Ow, Cw;
+    float mHalfBaseline = 0;
+    std::mutex mMutexPose;
 };
 
 class ORBmatcher {
@@ -81,6 +89,8 @@ public:
     float mfMinDistance = 0, mfMaxDistance = 0;
     std::mutex mMutexPos;
     void ComputeDistinctiveDescriptors();
+    void UpdateNormalAndDepth();
+    KeyFrame* mpRefKF = nullptr;
     std::map<KeyFrame*, size_t> mObservations;   // include/MapPoint.h: keyframe -> index of the observing keypoint
     cv::Mat mDescriptor;
     bool mbBad = false;

@@ -186,6 +186,8 @@ _SIGS = {
     "planar_merge_plane_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "planar_distinctive_descriptors": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_distinctive_descriptors_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "planar_update_normal_and_depth": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 3),
+    "planar_update_normal_and_depth_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 3),
     "planar_comm_create_hosted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_comm_destroy": (None, [C.c_void_p]),
     "planar_local_ba": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(PoseParams), C.c_int, C.c_int, C.POINTER(BAResult), C.c_void_p, C.c_void_p]),

@@ -154,6 +154,52 @@ __global__ __launch_bounds__(256) void discard_kernel(const int32_t* __restrict_
     if (threadIdx.x == 0 && kept) kept[b] = s_cnt;
 }
 
+// MapPoint::UpdateNormalAndDepth (reference src/MapPoint.cc:347-388): thread = map point.  Group g = the points whose reference key frame has pose ref_Tcw[g];
+// its camera centre is KeyFrame::SetPose's Ow = -Rwc * tcw (src/KeyFrame.cc:85-86: Rwc materialised -> cv::gemm's float small-matrix path, negated).
+struct Scales { float sf[PLANAR_MAX_LEVELS]; int n_levels; };
+__global__ __launch_bounds__(256) void normal_depth_kernel(const int32_t* __restrict__ n, int stride, const float* __restrict__ xw, const uint8_t* __restrict__ valid,
+                                                           const float* __restrict__ ref_Tcw, const planar_keypoint* __restrict__ keys_un,
+                                                           const int32_t* __restrict__ obs_off, const float* __restrict__ obs_ow, Scales S,
+                                                           float* __restrict__ normal, float* __restrict__ min_dist, float* __restrict__ max_dist) {
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= stride || i >= n[g]) return;
+    const size_t o = (size_t)g * stride + i;
+    if (valid && !valid[o]) return;
+    const float* T = ref_Tcw + (size_t)g * 16;
+    float Ow[3], pos[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float t = T[r] * T[3];
+        t = t + T[4 + r] * T[7];
+        t = t + T[8 + r] * T[11];
+        Ow[r] = (float)((double)t * -1.0);
+        pos[r] = xw[o * 3 + r];
+    }
+    float nrm[3] = {0.f, 0.f, 0.f};
+    const int o0 = obs_off ? obs_off[o] : 0, nobs = obs_off ? obs_off[o + 1] - o0 : 1;
+    if (nobs <= 0) return;                                             // observations.empty(): the point keeps what it had
+    for (int q = 0; q < nobs; q++) {
+        float d[3];
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { d[k] = pos[k] - (obs_off ? obs_ow[(size_t)(o0 + q) * 3 + k] : Ow[k]); s += (double)d[k] * (double)d[k]; }
+        const float fa = (float)(1.0 / sqrt(s));                       // normali / cv::norm(normali): the scale cast to float, float multiply
+#pragma unroll
+        for (int k = 0; k < 3; k++) nrm[k] = d[k] * fa + nrm[k] * 1.0f;
+    }
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const float pc = pos[k] - Ow[k]; s += (double)pc * (double)pc; }
+    const float dist = (float)sqrt(s);
+    const int level = keys_un[o].octave;
+    const float mx = dist * S.sf[level];
+    max_dist[o] = mx;
+    min_dist[o] = mx / S.sf[S.n_levels - 1];
+    const float fn = (float)(1.0 / (double)nobs);
+#pragma unroll
+    for (int k = 0; k < 3; k++) normal[o * 3 + k] = nrm[k] * fn;
+}
+
 }  // namespace frame
 }  // namespace planar
 
@@ -276,6 +322,42 @@ int planar_discard_outliers(planar_ctx* ctx, int B, const int32_t* n, int stride
     if (rc) return rc;
     rc = planar_discard_outliers_dev(ctx, B, s.dev<int32_t>(i0), stride, flag_stride, s.dev<int32_t>(i1), s.dev<uint8_t>(i2), s.dev<int32_t>(o0));
     if (rc) return rc;
+    return s.download(ctx->stream);
+}
+
+int planar_update_normal_and_depth_dev(planar_ctx* ctx, int G, const int32_t* d_n, int stride, const float* d_xw, const uint8_t* d_valid, const float* d_ref_Tcw,
+                                       const planar_keypoint* d_keys_un, const int32_t* d_obs_off, const float* d_obs_ow, const float* scale_factors, int n_levels,
+                                       float* d_normal, float* d_min_dist, float* d_max_dist) {
+    PLANAR_REQUIRE(ctx && d_n && d_xw && d_ref_Tcw && d_keys_un && scale_factors && d_normal && d_min_dist && d_max_dist, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(G >= 1 && stride >= 1 && n_levels >= 1 && n_levels <= PLANAR_MAX_LEVELS, PLANAR_EINVAL, "bad size");
+    PLANAR_REQUIRE((d_obs_off == nullptr) == (d_obs_ow == nullptr), PLANAR_EINVAL, "obs_off and obs_ow go together");
+    frame::Scales S{};
+    for (int l = 0; l < PLANAR_MAX_LEVELS; l++) S.sf[l] = l < n_levels ? scale_factors[l] : 1.f;
+    S.n_levels = n_levels;
+    hipLaunchKernelGGL(frame::normal_depth_kernel, dim3((stride + 255) / 256, G), dim3(256), 0, ctx->stream, d_n, stride, d_xw, d_valid, d_ref_Tcw, d_keys_un, d_obs_off, d_obs_ow,
+                       S, d_normal, d_min_dist, d_max_dist);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_update_normal_and_depth(planar_ctx* ctx, int G, const int32_t* n, int stride, const float* xw, const uint8_t* valid, const float* ref_Tcw,
+                                   const planar_keypoint* keys_un, const int32_t* obs_off, const float* obs_ow, const float* scale_factors, int n_levels, float* normal,
+                                   float* min_dist, float* max_dist) {
+    PLANAR_REQUIRE(ctx && n && xw && ref_Tcw && keys_un && scale_factors && normal && min_dist && max_dist, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(G >= 1 && stride >= 1, PLANAR_EINVAL, "bad size");
+    PLANAR_REQUIRE((obs_off == nullptr) == (obs_ow == nullptr), PLANAR_EINVAL, "obs_off and obs_ow go together");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t N = (size_t)G * stride;
+    Stager s;
+    const int i_n = s.in(n, (size_t)G * 4), i_x = s.in(xw, N * 12), i_v = valid ? s.in(valid, N) : -1, i_T = s.in(ref_Tcw, (size_t)G * 64), i_k = s.in(keys_un, N * sizeof(planar_keypoint));
+    const int i_oo = obs_off ? s.in(obs_off, (N + 1) * 4) : -1, i_ow = obs_off ? s.in(obs_ow, (size_t)obs_off[N] * 12) : -1;
+    const int io_nr = s.inout(normal, N * 12), io_mn = s.inout(min_dist, N * 4), io_mx = s.inout(max_dist, N * 4);
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    if ((rc = planar_update_normal_and_depth_dev(ctx, G, s.dev<int32_t>(i_n), stride, s.dev<float>(i_x), valid ? s.dev<uint8_t>(i_v) : nullptr, s.dev<float>(i_T),
+                                                 s.dev<planar_keypoint>(i_k), obs_off ? s.dev<int32_t>(i_oo) : nullptr, obs_off ? s.dev<float>(i_ow) : nullptr, scale_factors,
+                                                 n_levels, s.dev<float>(io_nr), s.dev<float>(io_mn), s.dev<float>(io_mx))))
+        return rc;
     return s.download(ctx->stream);
 }
 

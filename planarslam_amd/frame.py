@@ -98,3 +98,20 @@ def discard_outliers(n, match, outlier, ctx: Context | None = None):
     kept = np.zeros(len(n), np.int32)
     check(lib().planar_discard_outliers(ctx.h, len(n), n.ctypes.data, m.shape[1], o.shape[1], m.ctypes.data, o.ctypes.data, kept.ctypes.data))
     return m, o, kept
+
+
+def update_normal_and_depth(n, xw, ref_Tcw, keys_un, scale_factors, valid=None, obs_off=None, obs_ow=None, ctx: Context | None = None):
+    """MapPoint::UpdateNormalAndDepth (reference src/MapPoint.cc:347-388) for G groups of points (group = the points of one reference key frame):
+    n [G], xw [G, stride, 3], ref_Tcw [G, 16], keys_un [G, stride] KP_DTYPE, optional per-point observer centres (obs_off [G*stride+1], obs_ow [m, 3]).
+    Returns normal [G, stride, 3], min_dist, max_dist [G, stride] (zeros where nothing was written)."""
+    ctx = ctx or Context(0)
+    n = _c(n, np.int32); xw = _c(xw, np.float32); T = _c(ref_Tcw, np.float32).reshape(len(n), 16); ku = _c(keys_un, KP_DTYPE); sf = _c(scale_factors, np.float32)
+    G, S = xw.shape[:2]
+    v = None if valid is None else _c(valid, np.uint8)
+    oo = None if obs_off is None else _c(obs_off, np.int32)
+    ow = None if obs_ow is None else _c(obs_ow, np.float32)
+    nrm = np.zeros((G, S, 3), np.float32); mn = np.zeros((G, S), np.float32); mx = np.zeros((G, S), np.float32)
+    check(lib().planar_update_normal_and_depth(ctx.h, G, n.ctypes.data, S, xw.ctypes.data, None if v is None else v.ctypes.data, T.ctypes.data, ku.ctypes.data,
+                                               None if oo is None else oo.ctypes.data, None if ow is None else ow.ctypes.data, sf.ctypes.data, len(sf), nrm.ctypes.data,
+                                               mn.ctypes.data, mx.ctypes.data))
+    return nrm, mn, mx

@@ -14,8 +14,7 @@ The sequence of the reference's tracking thread for one RGB-D frame (src/Trackin
 
 What is NOT the reference's code path and only stands in for the map it maintains (Map / KeyFrame / LocalMapping are out of scope):
 the local map of a stream is the previous two frames' own back-projected keypoints, the reference key frame's lines and the map planes are
-fixed per stream (set_map), and
-MapPoint::UpdateNormalAndDepth is a few torch element-wise ops here.
+fixed per stream (set_map); every new "map point" has one observation, its own frame (MapPoint::UpdateNormalAndDepth: planar_update_normal_and_depth).
 
 PyTorch supplies device memory, streams and events only.  Frame-batch parallelism: steps are pipelined `depth` deep - the tracking chain of
 step i - depth runs on its own stream beside the extraction launches of step i (points on the main stream, lines and planes on theirs)."""
@@ -360,17 +359,12 @@ class TrackPipeline:
                 evs[name].record(st)
         # ---- the new frame becomes a "last frame": back-projected keypoints (UnprojectStereo) and what MapPoint::UpdateNormalAndDepth keeps ----
         self._stereo(self.ctx_t, k, self.pose, depth, self.ur[k], self.zd[k], self.h_xw[o], self.h_valid[o])
-        T = self.pose.view(B, 4, 4)
-        Ow = -(T[:, :3, :3].transpose(1, 2) @ T[:, :3, 3:4]).squeeze(-1)
-        v = self.h_xw[o] - Ow[:, None, :]
-        dist = v.norm(dim=-1).clamp_min(1e-6)
-        self.h_normal[o] = v / dist[..., None]
+        check(L.planar_update_normal_and_depth_dev(self.ctx_t.h, B, self.n[k].data_ptr(), S, self.h_xw[o].data_ptr(), self.h_valid[o].data_ptr(), self.pose.data_ptr(),
+                                                   self.kps[k].data_ptr(), None, None, self.sf.ctypes.data, self.nlev, self.h_normal[o].data_ptr(), self.h_mind[o].data_ptr(),
+                                                   self.h_maxd[o].data_ptr()))
         octave = self.kps[k][..., 5].contiguous().view(t.int32)
-        sft = t.from_numpy(self.sf).to(self.dev)
-        self.h_maxd[o] = dist * sft[octave.clamp(0, self.nlev - 1).long()]
-        self.h_mind[o] = self.h_maxd[o] / float(self.sf[self.nlev - 1])
         self.h_desc[o].copy_(self.desc[k]); self.h_oct[o].copy_(octave); self.h_ang[o].copy_(self.kps[k][..., 3]); self.h_n[o].copy_(self.n[k])
-        if cap is not None: snap("pose_out", self.pose); snap("new_xw", self.h_xw[o]); snap("new_valid", self.h_valid[o]); snap("new_ur", self.ur[k])
+        if cap is not None: snap("pose_out", self.pose); snap("new_xw", self.h_xw[o]); snap("new_valid", self.h_valid[o]); snap("new_ur", self.ur[k]); snap("new_normal", self.h_normal[o]); snap("new_mind", self.h_mind[o]); snap("new_maxd", self.h_maxd[o])
         if evs: evs["state"].record(st)
         self.done[k].record(st)
 

@@ -919,3 +919,28 @@ def run_ref_distinctive(points):
         desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); bad = np.ascontiguousarray(bad, np.uint8)
         pay += np.int32(len(desc)).tobytes() + bad.tobytes() + desc.tobytes()
     return np.frombuffer(_run_ref_frame("distinctive", pay), np.uint8).reshape(len(points), 32).copy()
+
+
+# ---- MapPoint::UpdateNormalAndDepth (oracle/guided_oracle.cpp; the REAL src/MapPoint.cc:347-388 + KeyFrame::SetPose through oracle/_ref/ref_frame) ----
+def keyframe_center(Tcw):
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16); ow = np.zeros(3, np.float32)
+    lib().orc_keyframe_center(C.c_void_p(Tcw.ctypes.data), C.c_void_p(ow.ctypes.data))
+    return ow
+
+
+def update_normal_and_depth(pos, obs_ow, ref_ow, level, sf):
+    pos = np.ascontiguousarray(pos, np.float32).reshape(3); obs_ow = np.ascontiguousarray(obs_ow, np.float32).reshape(-1, 3); ref_ow = np.ascontiguousarray(ref_ow, np.float32).reshape(3)
+    sf = np.ascontiguousarray(sf, np.float32)
+    nrm = np.zeros(3, np.float32); mn = C.c_float(); mx = C.c_float()
+    lib().orc_update_normal_and_depth(C.c_void_p(pos.ctypes.data), C.c_void_p(obs_ow.ctypes.data), len(obs_ow), C.c_void_p(ref_ow.ctypes.data), int(level), C.c_void_p(sf.ctypes.data),
+                                      len(sf), C.c_void_p(nrm.ctypes.data), C.byref(mn), C.byref(mx))
+    return nrm, np.float32(mn.value), np.float32(mx.value)
+
+
+def run_ref_normal_depth(Tcws, sf, points):
+    """Tcws [nkf,16]; points: list of (pos [3], ref, level, obs list) -> [np, 5] f32 (normal, min, max) from the reference's own UpdateNormalAndDepth."""
+    Tcws = np.ascontiguousarray(Tcws, np.float32).reshape(-1, 16); sf = np.ascontiguousarray(sf, np.float32)
+    pay = np.array([len(Tcws), len(sf)], np.int32).tobytes() + sf.tobytes() + Tcws.tobytes() + np.int32(len(points)).tobytes()
+    for pos, ref, level, obs in points:
+        pay += np.ascontiguousarray(pos, np.float32).tobytes() + np.array([ref, level, len(obs)], np.int32).tobytes() + np.ascontiguousarray(obs, np.int32).tobytes()
+    return np.frombuffer(_run_ref_frame("normal_depth", pay), np.float32).reshape(len(points), 5).copy()

@@ -202,3 +202,9 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
         n = int(c["n"][b])
         s = ol.stereo_from_rgbd(keys[b, :n], d[b], c["pose_out"][b], TUM3)
         assert np.array_equal(s["xw"], c["new_xw"][b, :n]) and np.array_equal(s["valid"], c["new_valid"][b, :n]) and np.array_equal(s["u_right"], c["new_ur"][b, :n])
+        # MapPoint::UpdateNormalAndDepth of the new "map points" (one observation each: this frame)
+        ow = ol.keyframe_center(c["pose_out"][b])
+        for i in range(0, n, 37):
+            if c["new_valid"][b, i]:
+                wn, wmn, wmx = ol.update_normal_and_depth(c["new_xw"][b, i], ow[None], ow, keys["octave"][b, i], sf)
+                assert np.array_equal(wn, c["new_normal"][b, i]) and wmn == c["new_mind"][b, i] and wmx == c["new_maxd"][b, i]
