@@ -9,13 +9,13 @@
 //                 accumulated in the reference's raster order (bit-exact FP64 sums), PCA by the iterative 3x3 symmetric
 //                 eigen-solver (Eigen's algorithm, restated)                                                            (a13-a15)
 //   peac_ahc      one WAVEFRONT (64 lanes) per frame, the order-dependent clustering: initGraph edges -> ahCluster with a
-//                 libstdc++-exact binary min-MSE heap.  47 KB LDS per frame (heap keys 24.5 K, heap ids 6 K, neighbour-list
-//                 offsets / counts 6 K + 6 K + 3 K, flag bits 1.5 K); the neighbour-list POOL lives in the frame's global
-//                 workspace and is staged through LDS when two lists are merged.  Three frames share a CU.
+//                 libstdc++-exact binary min-MSE heap.  24.5 KB LDS per frame (heap keys as floats 12 K, heap ids 6 K, DisjointSet parents / sizes,
+//                 flag bits); the neighbour-list POOL, list offsets / counts and the candidate cache live in the frame's global
+//                 workspace, lists are staged through LDS when two are merged.  234 VGPRs: two such wavefronts per SIMD, up to six frames per CU.
 //   peac_order    ranks the frames by the clustering time of the previous call (longest first) for the next launch
-//   peac_refine   256 threads per frame (16.6 KB LDS): block erosion + seed queue (prefix sums) -> floodFill (queue entries x
-//                 4 neighbours per step, same-pixel conflicts replayed in order) -> final ahCluster over the surviving planes ->
-//                 relabel; the node arrays stay in the global workspace                                                  (a16-a17)
+//   peac_refine   256 threads per frame (24.5 KB LDS): block erosion + seed queue (prefix sums) -> floodFill (512 queue entries x
+//                 4 neighbours per step, same-pixel conflicts replayed in order; membership image in bytes, 4-byte queue entries) -> final
+//                 ahCluster over the surviving planes -> relabel; the node arrays stay in the global workspace            (a16-a17)
 // Frame-level batch parallelism supplies the occupancy: the clustering is a chain of dependent FP64 operations, so a
 // frame is latency-bound and the launch time is (frames / resident frames) x the slowest frame.  DESIGN.md §PEAC has the numbers.
 #include "common.h"
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void peac_blocks(Layout L, Intr K, const uint16
 // K2: one 256-thread workgroup per frame.  Everything the sequential part chases pointers through lives in LDS
 // (merge heap with its MSE keys, the neighbour lists as u16, the disjoint set, the block map); the per-node
 // moments / plane parameters stay in the frame's global workspace and are read once per merge step.
-constexpr int NT_AHC = 64;       // clustering: two wavefronts per frame (LDS and VGPRs allow three such workgroups per CU)
+constexpr int NT_AHC = 64;       // clustering: one wavefront per frame (a second one, 128 threads, leaves the chain as long and costs 12 ms per step: measured)
 constexpr int NT_REFINE = 256;   // refinement: four wavefronts per frame
 typedef unsigned short u16;
 
@@ -1164,7 +1164,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     }
 }
 
-// peac_ahc: one workgroup per frame, one workgroup per CU at a time (the merge heap and the neighbour lists fill its LDS).  A workgroup takes
+// peac_ahc: one workgroup (one wavefront) per frame, up to six per CU.  A workgroup takes
 // the next frame from a counter when it STARTS instead of using its block index: frames differ by up to 1.7x in merge steps, the dispatcher
 // deals block indices round-robin over the 8 XCDs, and a periodic mix of frames would otherwise send every slow frame to the same XCD.
 // (A persistent one-workgroup-per-CU loop costs ~50 more VGPRs and with them the co-residency of lsd_detect's wavefront on the same SIMDs.)
