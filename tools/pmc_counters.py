@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-kernel averages of arbitrary rocprofv3 counters from one or more `--pmc` passes (each pass its own directory, `--kernel-trace` only).
+
+    python tools/pmc_counters.py <dir> [<dir> ...] > profiles/rNN_pmc_sq_per_launch.csv
+
+Sums a counter over the rows of one dispatch (rocprofv3 writes one row per counter instance / dimension), averages over the dispatches of a kernel without
+its first one, and adds two ratios when their inputs are present: wait = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (share of its resident time a wavefront waits for
+an instruction to complete) and active = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    vals = defaultdict(lambda: defaultdict(float))      # (file, dispatch) -> counter -> sum
+    name = {}
+    for d in sys.argv[1:]:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                key = (f, int(row["Dispatch_Id"]))
+                vals[key][row["Counter_Name"]] += float(row["Counter_Value"])
+                name[key] = row["Kernel_Name"].split("(")[0]
+    per = defaultdict(lambda: defaultdict(list))
+    for key in sorted(vals):
+        for c, v in vals[key].items():
+            per[name[key]][c].append(v)
+    counters = sorted({c for k in per for c in per[k]})
+    print(",".join(["kernel", "launches_seen"] + counters + ["wait", "active"]))
+    rows = []
+    for k, cs in per.items():
+        if not k.startswith(("planar::", "void planar::")):
+            continue
+        avg = {c: (sum(v[1:]) / len(v[1:]) if len(v) > 1 else v[0]) for c, v in cs.items()}
+        n = max(len(v) for v in cs.values())
+        wc = avg.get("SQ_WAVE_CYCLES", 0.0)
+        wait = avg["SQ_WAIT_INST_ANY"] / wc if wc and "SQ_WAIT_INST_ANY" in avg else float("nan")
+        act = avg["SQ_ACTIVE_INST_ANY"] / wc if wc and "SQ_ACTIVE_INST_ANY" in avg else float("nan")
+        rows.append((avg.get("SQ_WAVE_CYCLES", 0.0), ",".join([k, str(n)] + [f"{avg.get(c, float('nan')):.0f}" for c in counters] + [f"{wait:.3f}", f"{act:.3f}"])))
+    for _, r in sorted(rows, reverse=True):
+        print(r)
+
+
+if __name__ == "__main__":
+    main()
