@@ -58,6 +58,18 @@ def test_argument_errors_are_reported_without_touching_a_device():
         lambda: L.planar_peac_create(None, 640, 480, 1, ctypes.byref(ctypes.c_void_p())),
         lambda: L.planar_pose_opt(None, None, None, 0, 4, 10),
         lambda: L.planar_local_ba(None, None, None, 5, 10, None, None, None),
+        # round-2 entry points
+        lambda: L.planar_normals_create(None, 640, 480, 1, ctypes.byref(ctypes.c_void_p())),
+        lambda: L.planar_plane_clouds_create(None, 640, 480, 1, 4096, ctypes.byref(ctypes.c_void_p())),
+        lambda: L.planar_plane_clouds_compute(None, p, 1, 640, 640 * 480, 535.4, 539.2, 320.1, 247.6, 0.0002, p, p, p, 0.05, 0.1, p, p, p, p, p, None, None, None),
+        lambda: L.planar_plane_refit(None, 1, p, p, 0.05, p, p, None),
+        lambda: L.planar_flag_matched_plane_points(None, 1, p, p, p, p, 1, p, 1, 1, p, None),
+        lambda: L.planar_merge_plane_points(None, p, p, 1, p, 1, 0.1, p, 1, p),
+        lambda: L.planar_distinctive_descriptors(None, 1, p, p, p, None),
+        lambda: L.planar_update_normal_and_depth(None, 1, p, 1, p, None, p, p, None, None, p, 8, p, p, p),
+        lambda: L.planar_is_line_good(None, 1, p, p, 40, p, 640, 480, 640, 640 * 480, 0.0002, 535.4, 539.2, 320.1, 247.6, p, p, p, p, p, p, p, p),
+        lambda: L.planar_bow_transform(None, None, p, 1, 1, 4, p, p, p, p, p, p),
+        lambda: L.planar_track_manhattan_frame(None, 1, p, p, p, 1, p, p, 1, p, None, None, None),
     ]
     for i, c in enumerate(calls):
         rc = c()
