@@ -411,6 +411,10 @@ int planar_peac_segment_dev(planar_peac* peac, const uint16_t* d_depth, int B, i
                             float cx, float cy, float depth_factor, int32_t* d_labels, double* d_planes, int32_t* d_n_planes);
 /* Synchronises and returns PLANAR_ECAPACITY if any of the last B frames overflowed an internal capacity
  * (more than max_planes planes, flood-fill queue, neighbour pool); the host-pointer entry point calls it itself. */
+/* Debug aids (tools/peac_ab.py; not part of the drop-in surface): workspace layout {frame_bytes, NB, NB2, off_stats, off_geo, off_N, off_dsp, off_dss,
+ * off_rid, off_nouse, off_hand, off_crec} and a raw read of one frame's workspace after the last call. */
+int planar_peac_debug_layout(planar_peac* peac, int64_t* out /* [12] */);
+int planar_peac_debug_read(planar_peac* peac, int frame, int64_t offset, int64_t bytes, void* out);
 int planar_peac_check(planar_peac* peac, int B);
 /* Per-launch timing with HIP events on the context stream (bench.py's roofline leg), as planar_orb_set_profiling: get_profile synchronises and returns the
  * summed milliseconds of the four launches of the recorded calls (total_ms[4] = peac_blocks, peac_ahc, peac_order, peac_refine), their number, and resets. */

@@ -429,4 +429,40 @@ int orc_peac_run(const uint16_t* depth, int W, int H, float fx, float fy, float 
     }
     return n;
 }
+
+// State of the first ahCluster (AHCPlaneFitter.hpp:983-1189) for kernel-level checks (tests/test_peac_emul.py, tools/peac_ab.py): every PlaneSeg ever
+// created, in creation order.  nodes: [cap][18] = N, rid, mse, center[3], normal[3], stats[9]; extracted: node ids in extractedPlanes order (after the
+// size sort); set_root / set_size: DisjointSet::Find / getSetSize of every block.  Returns the number of nodes; *n_extracted the number of planes.
+int orc_peac_cluster_state(const uint16_t* depth, int W, int H, float fx, float fy, float cx, float cy, float factor, double* nodes, int cap,
+                           int32_t* extracted, int32_t* n_extracted, int32_t* set_root, int32_t* set_size) {
+    using namespace orc;
+    Cloud cloud;
+    cloud.w = W; cloud.h = H; cloud.xyz.resize((size_t)W * H * 3);
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const double z = (double)depth[(size_t)i * W + j] * factor;
+            double* p = &cloud.xyz[((size_t)i * W + j) * 3];
+            p[0] = ((double)j - cx) * z / fx; p[1] = ((double)i - cy) * z / fy; p[2] = z;
+        }
+    Fitter f;
+    f.pts = &cloud; f.width = W; f.height = H;
+    const int Nh = H / f.prm.windowHeight, Nw = W / f.prm.windowWidth;
+    f.ds.reset(new DisjointSet(Nh * Nw));
+    f.initGraph();
+    f.ahCluster();
+    const int n = (int)f.segs.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        const Seg& g = f.segs[i];
+        double* o = nodes + (size_t)i * 18;
+        o[0] = g.N; o[1] = g.rid; o[2] = g.mse;
+        for (int k = 0; k < 3; k++) { o[3 + k] = g.center[k]; o[6 + k] = g.normal[k]; }
+        const Stats& t = g.stats;
+        const double st[9] = {t.sx, t.sy, t.sz, t.sxx, t.syy, t.szz, t.sxy, t.syz, t.sxz};
+        for (int k = 0; k < 9; k++) o[9 + k] = st[k];
+    }
+    *n_extracted = (int)f.extracted.size();
+    for (size_t i = 0; i < f.extracted.size(); i++) extracted[i] = f.extracted[i];
+    for (int b = 0; b < Nh * Nw; b++) { set_root[b] = f.ds->Find(b); set_size[b] = f.ds->getSetSize(b); }
+    return n;
+}
 }

@@ -20,202 +20,10 @@
 // frame is latency-bound and the launch time is (frames / resident frames) x the slowest frame.  DESIGN.md §PEAC has the numbers.
 #include "common.h"
 
-// Per-step cycle counters of the ahCluster loop (tools/peac_timing.py).  s_memtime drains the LDS queue every time it is read, so the
-// counters are compiled in only with -DPLANAR_PEAC_TIMING; the eight phase marks (wall clock) are always recorded.
-#ifdef PLANAR_PEAC_TIMING
-#define PEAC_CYCLES() ((long long)clock64())
-#else
-#define PEAC_CYCLES() 0ll
-#endif
+#include "peac_common.h"
 
 namespace planar {
 namespace peac {
-
-constexpr int WIN = 10;             // windowWidth == windowHeight (AHCPlaneFitter.hpp:156)
-constexpr int MIN_SUPPORT = 3000;   // minSupport (:155)
-constexpr int MAX_PLANES = 128;
-constexpr int MAX_STEP = 100000;
-
-// ---- thresholds (AHCParamSet.hpp) ----
-__device__ __forceinline__ double T_mse_init(double z) { const double t = 1.6e-6 * z * z + 5; return t * t; }
-__device__ __forceinline__ double T_mse_merge(double z) { const double t = 1.6e-6 * z * z + 8; return t * t; }
-__device__ __forceinline__ double T_dz(double z) { return 0.04 * fabs(z) + 0.02; }
-
-struct Consts {   // values the reference computes with libm at run time; passed in from the host so both sides agree
-    double ang_near, ang_factor, cos_init_near, cos_merge, cos_refine;
-};
-__device__ __forceinline__ double T_ang_init(const Consts& c, double z) {   // AHCParamSet.hpp:112-122
-    double cz = fmax(z, 500.0);
-    cz = fmin(cz, 4000.0);
-    if (cz == 500.0) return c.cos_init_near;   // every depth in metres lands here (the thresholds are in mm)
-    return cos(c.ang_factor * cz + c.ang_near - c.ang_factor * 500.0);
-}
-
-// ---- Eigen 3.3 SelfAdjointEigenSolver<Matrix3d>::compute, restated (see oracle/eigprim.cpp for the citations) ----
-__device__ __forceinline__ double eig_hypot(double x, double y) {
-    const double ax = fabs(x), ay = fabs(y);
-    double p, qp;
-    if (ax > ay) { p = ax; qp = ay / p; } else { p = ay; qp = ax / p; }
-    if (p == 0) return 0;
-    return p * sqrt(1.0 + qp * qp);
-}
-__device__ __forceinline__ void make_givens(double p, double q, double& c, double& s) {
-    if (q == 0) { c = p < 0 ? -1.0 : 1.0; s = 0; }
-    else if (p == 0) { c = 0; s = q < 0 ? 1.0 : -1.0; }
-    else if (fabs(p) > fabs(q)) { const double t = q / p; double u = sqrt(1.0 + t * t); if (p < 0) u = -u; c = 1.0 / u; s = -t * c; }
-    else { const double t = p / q; double u = sqrt(1.0 + t * t); if (q < 0) u = -u; s = -1.0 / u; c = -t * s; }
-}
-// One implicit symmetric QR step on the unreduced block [START, END] of the tridiagonal matrix (Eigen's tridiagonal_qr_step).  The block
-// bounds are template parameters so that diag / sub / Q are indexed by constants and stay in registers: a 3x3 matrix has only the three
-// blocks (0,2), (1,2), (0,1).  Same operations in the same order as the loop form.
-template <int START, int END>
-__device__ __forceinline__ void eig_qr_step(double (&diag)[3], double (&sub)[2], double (&Q)[3][3]) {
-    const double td = (diag[END - 1] - diag[END]) * 0.5, e = sub[END - 1];
-    double mu = diag[END];
-    if (td == 0) mu -= fabs(e);
-    else {
-        const double e2 = e * e, h = eig_hypot(td, e);
-        if (e2 == 0) mu -= (e / (td + (td > 0 ? 1.0 : -1.0))) * (e / h);
-        else mu -= e2 / (td + (td > 0 ? h : -h));
-    }
-    double x = diag[START] - mu, z = sub[START];
-#pragma unroll
-    for (int k = START; k < END; ++k) {
-        double c, s;
-        make_givens(x, z, c, s);
-        const double sdk = s * diag[k] + c * sub[k];
-        const double dkp1 = s * sub[k] + c * diag[k + 1];
-        diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
-        diag[k + 1] = s * sdk + c * dkp1;
-        sub[k] = c * sdk - s * dkp1;
-        if (k > START) sub[k - 1] = c * sub[k - 1] - s * z;
-        x = sub[k];
-        if (k < END - 1) { z = -s * sub[k + 1]; sub[k + 1] = c * sub[k + 1]; }
-#pragma unroll
-        for (int r = 0; r < 3; r++) { const double xi = Q[r][k], yi = Q[r][k + 1]; Q[r][k] = c * xi - s * yi; Q[r][k + 1] = s * xi + c * yi; }
-    }
-}
-// lower triangle a00,a10,a11,a20,a21,a22 -> smallest eigenvalue ev0 (+ev1, ev2) and its eigenvector v0
-__device__ void eig33(double a00, double a10, double a11, double a20, double a21, double a22, double ev[3], double v0[3]) {
-    double scale = fmax(fmax(fmax(fabs(a00), fabs(a10)), fmax(fabs(a11), fabs(a20))), fmax(fabs(a21), fabs(a22)));
-    if (scale == 0) scale = 1;
-    a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
-    double d0, d1, d2, s0, s1;
-    double q11 = 1, q12 = 0, q21 = 0, q22 = 1;
-    d0 = a00;
-    const double v1norm2 = a20 * a20;
-    if (v1norm2 <= 2.2250738585072014e-308) { d1 = a11; d2 = a22; s0 = a10; s1 = a21; }
-    else {
-        const double beta = sqrt(a10 * a10 + v1norm2);
-        const double invBeta = 1.0 / beta;
-        const double m01 = a10 * invBeta, m02 = a20 * invBeta;
-        const double q = 2.0 * m01 * a21 + m02 * (a22 - a11);
-        d1 = a11 + m02 * q; d2 = a22 - m02 * q; s0 = beta; s1 = a21 - m01 * q;
-        q11 = m01; q12 = m02; q21 = m02; q22 = -m01;
-    }
-    double diag[3] = {d0, d1, d2}, sub[2] = {s0, s1};
-    double Q[3][3] = {{1, 0, 0}, {0, q11, q12}, {0, q21, q22}};
-    int end = 2, start = 0, iter = 0;
-    const double considerAsZero = 2.2250738585072014e-308, precision = 2.0 * 2.220446049250313e-16;
-    while (end > 0) {
-        // for (i = start; i < end; ++i) deflate sub[i]
-        if (start <= 0 && 0 < end && (fabs(sub[0]) <= (fabs(diag[0]) + fabs(diag[1])) * precision || fabs(sub[0]) <= considerAsZero)) sub[0] = 0;
-        if (start <= 1 && 1 < end && (fabs(sub[1]) <= (fabs(diag[1]) + fabs(diag[2])) * precision || fabs(sub[1]) <= considerAsZero)) sub[1] = 0;
-        if (end == 2 && sub[1] == 0) end = 1;                 // while (end > 0 && sub[end - 1] == 0) end--
-        if (end == 1 && sub[0] == 0) end = 0;
-        if (end <= 0) break;
-        iter++;
-        if (iter > 90) break;
-        start = end - 1;
-        if (start == 1 && sub[0] != 0) start = 0;             // while (start > 0 && sub[start - 1] != 0) start--
-        if (end == 2) { if (start == 0) eig_qr_step<0, 2>(diag, sub, Q); else eig_qr_step<1, 2>(diag, sub, Q); }
-        else eig_qr_step<0, 1>(diag, sub, Q);
-    }
-    if (iter <= 90) {   // selection sort of the eigenvalues (increasing), eigenvector columns follow
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i == 0) {
-                const int k = diag[2] < (diag[1] < diag[0] ? diag[1] : diag[0]) ? 2 : (diag[1] < diag[0] ? 1 : 0);
-                if (k == 1) { const double t = diag[0]; diag[0] = diag[1]; diag[1] = t; for (int r = 0; r < 3; r++) { const double u = Q[r][0]; Q[r][0] = Q[r][1]; Q[r][1] = u; } }
-                if (k == 2) { const double t = diag[0]; diag[0] = diag[2]; diag[2] = t; for (int r = 0; r < 3; r++) { const double u = Q[r][0]; Q[r][0] = Q[r][2]; Q[r][2] = u; } }
-            } else if (diag[2] < diag[1]) { const double t = diag[1]; diag[1] = diag[2]; diag[2] = t; for (int r = 0; r < 3; r++) { const double u = Q[r][1]; Q[r][1] = Q[r][2]; Q[r][2] = u; } }
-        }
-    }
-    for (int i = 0; i < 3; i++) ev[i] = diag[i] * scale;
-    v0[0] = Q[0][0]; v0[1] = Q[1][0]; v0[2] = Q[2][0];
-}
-
-// Stats: sx sy sz sxx syy szz sxy syz sxz (9 doubles) + N.  PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:125-156)
-struct Geo { double center[3], normal[3], mse; };
-__device__ void stats_compute(const double s[9], int N, Geo& g) {
-    const double sc = 1.0 / N;
-    g.center[0] = s[0] * sc; g.center[1] = s[1] * sc; g.center[2] = s[2] * sc;
-    const double k00 = s[3] - s[0] * s[0] * sc, k01 = s[6] - s[0] * s[1] * sc, k02 = s[8] - s[0] * s[2] * sc;
-    const double k11 = s[4] - s[1] * s[1] * sc, k12 = s[7] - s[1] * s[2] * sc, k22 = s[5] - s[2] * s[2] * sc;
-    double ev[3], v[3];
-    eig33(k00, k01, k11, k02, k12, k22, ev, v);   // lower triangle of the symmetric K
-    if (v[0] * g.center[0] + v[1] * g.center[1] + v[2] * g.center[2] <= 0) { g.normal[0] = v[0]; g.normal[1] = v[1]; g.normal[2] = v[2]; }
-    else { g.normal[0] = -v[0]; g.normal[1] = -v[1]; g.normal[2] = -v[2]; }
-    g.mse = ev[0] * sc;
-}
-
-struct Layout {   // per-frame workspace (element offsets), identical for every frame
-    int W, H, Nw, Nh, NB, NB2;   // NB2 = 2*NB: initial blocks + merged nodes
-    int pool_cap, q_cap;
-    size_t off_stats, off_geo, off_N, off_rid, off_flags, off_nb_off, off_nb_cnt, off_pool, off_parent, off_size,
-        off_member, off_dist, off_blkmap, off_queue, off_seedcnt, off_cint, off_cdbl, frame_bytes;
-    // state the clustering kernel (peac_ahc) leaves for the refinement kernel (peac_refine): disjoint set, root ids, dead bits, extracted planes
-    size_t off_h_dsp, off_h_dss, off_h_rid, off_h_nouse, off_h_cval, off_h_hand, off_h_nboff, off_h_nbcnt, off_h_pool;
-};
-
-struct Intr { float fx, fy, cx, cy, factor; };
-
-// ------------------------------------------------------------------------------------------------------------
-// K1: one thread per block.
-__global__ __launch_bounds__(64) void peac_blocks(Layout L, Intr K, const uint16_t* __restrict__ depth, int pitch_px, int64_t frame_stride_px,
-                                                  uint8_t* __restrict__ ws) {
-    const int blk = blockIdx.x * blockDim.x + threadIdx.x, frame = blockIdx.y;
-    if (blk >= L.NB) return;
-    uint8_t* F = ws + (size_t)frame * L.frame_bytes;
-    double* stats = (double*)(F + L.off_stats) + (size_t)blk * 9;
-    double* geo = (double*)(F + L.off_geo) + (size_t)blk * 7;
-    int* Narr = (int*)(F + L.off_N);
-    int* rid = (int*)(F + L.off_rid);
-    uint8_t* flags = F + L.off_flags;   // bit0: in graph (pushed to minQ), bit1: nouse
-    const uint16_t* D = depth + (size_t)frame * frame_stride_px;
-    const int bi = blk / L.Nw, bj = blk - bi * L.Nw;
-    const int r0 = bi * WIN, c0 = bj * WIN;
-    const double factor = (double)K.factor;
-    bool valid = true;
-    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = r0; i < r0 + WIN; i++) {
-        for (int j = c0; j < c0 + WIN; j++) {
-            const double z = (double)D[(size_t)i * pitch_px + j] * factor;      // src/PlaneExtractor.cpp:45
-            if (z == 0) { valid = false; continue; }                              // ImagePointCloud::get (PlaneExtractor.h:29)
-            if (j + 1 < L.W) { const double zn = (double)D[(size_t)i * pitch_px + j + 1] * factor; if (zn != 0 && fabs(z - zn) > T_dz(z)) valid = false; }
-            if (i + 1 < L.H) { const double zn = (double)D[(size_t)(i + 1) * pitch_px + j] * factor; if (zn != 0 && fabs(z - zn) > T_dz(z)) valid = false; }
-            const double x = ((double)j - (double)K.cx) * z / (double)K.fx;     // :51-52
-            const double y = ((double)i - (double)K.cy) * z / (double)K.fy;
-            s[0] += x; s[1] += y; s[2] += z; s[3] += x * x; s[4] += y * y; s[5] += z * z; s[6] += x * y; s[7] += y * z; s[8] += x * z;
-        }
-    }
-    Geo g;
-    for (int k = 0; k < 3; k++) { g.center[k] = 0; g.normal[k] = 0; }
-    g.mse = 0;
-    bool in_graph = false;
-    if (valid) {
-        stats_compute(s, WIN * WIN, g);
-        in_graph = g.mse < T_mse_init(g.center[2]);                              // AHCPlaneFitter.hpp:807
-    } else {
-        for (int k = 0; k < 9; k++) s[k] = 0;
-    }
-    for (int k = 0; k < 9; k++) stats[k] = s[k];
-    for (int k = 0; k < 3; k++) { geo[k] = g.center[k]; geo[3 + k] = g.normal[k]; }
-    geo[6] = g.mse;
-    Narr[blk] = valid ? WIN * WIN : 0;
-    rid[blk] = blk;
-    flags[blk] = (in_graph ? 1 : 0) | (valid ? 0 : 2);
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // K2: one 256-thread workgroup per frame.  Everything the sequential part chases pointers through lives in LDS
@@ -223,31 +31,18 @@ __global__ __launch_bounds__(64) void peac_blocks(Layout L, Intr K, const uint16
 // moments / plane parameters stay in the frame's global workspace and are read once per merge step.
 constexpr int NT_AHC = 64;       // clustering: one wavefront per frame (a second one, 128 threads, leaves the chain as long and costs 12 ms per step: measured)
 constexpr int NT_REFINE = 256;   // refinement: four wavefronts per frame
-typedef unsigned short u16;
 
 struct Lds {
     float* h_key; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; unsigned char* nb_cntb; u16* dsp; u16* dss; u16* rid; unsigned* nouse; unsigned* cval; signed char* blk;
 };
 
 __device__ __forceinline__ int lds_find(u16* parent, int x) {   // DisjointSet::Find with path compression
-    int r = x;
-    while (parent[r] != r) r = parent[r];
-    while (parent[x] != r) { const int nx = parent[x]; parent[x] = (u16)r; x = nx; }
+    int r = x, guard = 0;
+    while (parent[r] != r && ++guard < 8192) r = parent[r];           // bounded: a corrupted workspace must not hang the GPU
+    guard = 0;
+    while (parent[x] != r && ++guard < 8192) { const int nx = parent[x]; parent[x] = (u16)r; x = nx; }
     return r;
 }
-__device__ __forceinline__ void lst_erase(u16* lst, int& cnt, int v) {
-    int i = 0;
-    while (i < cnt && lst[i] < v) i++;
-    if (i < cnt && lst[i] == v) { for (; i + 1 < cnt; i++) lst[i] = lst[i + 1]; cnt--; }
-}
-__device__ __forceinline__ void lst_insert(u16* lst, int& cnt, int v) {
-    int i = 0;
-    while (i < cnt && lst[i] < v) i++;
-    if (i < cnt && lst[i] == v) return;
-    for (int j = cnt; j > i; j--) lst[j] = lst[j - 1];
-    lst[i] = (u16)v; cnt++;
-}
-
 // PHASE 0 = peac_ahc: initGraph + the first ahCluster (heap, neighbour lists, set sizes, root ids in LDS).  PHASE 1 = peac_refine:
 // refineDetails (block membership, erosion, seeds, flood fill), the final ahCluster over the <= 128 extracted planes and the relabelling;
 // its node-indexed arrays live in the frame's global workspace (a handful of nodes are touched), so it needs ~17 KB of LDS and runs
@@ -1203,6 +998,8 @@ __global__ void peac_order(const long long* __restrict__ timing, int B, int* __r
 }  // namespace peac
 }  // namespace planar
 
+#include "peac_ahc2.h"
+
 // ==========================================================================================================
 // host side
 // ==========================================================================================================
@@ -1213,7 +1010,8 @@ struct planar_peac {
     int W = 0, H = 0, max_batch = 0;
     peac::Layout L{};
     peac::Consts C{};
-    int smem = 0;
+    int smem = 0, smem2 = 0;
+    bool legacy_ahc = false;                                  // PLANAR_PEAC_AHC=legacy: the round-2 clustering kernel (eager neighbour lists), for A/B runs
     DevBuf d_ws, d_status, d_timing, d_next, d_order;
     int order_B = 0;                                          // batch size d_order was computed for (0: none yet)
     DevBuf d_depth, d_labels, d_planes, d_nplanes;   // staging for the host-pointer entry point
@@ -1234,38 +1032,14 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     planar_peac* o = new (std::nothrow) planar_peac();
     PLANAR_REQUIRE(o != nullptr, PLANAR_ENOMEM, "host allocation failed");
     o->ctx = ctx; o->W = width; o->H = height; o->max_batch = max_batch;
-    peac::Layout& L = o->L;
-    L.W = width; L.H = height; L.Nw = width / peac::WIN; L.Nh = height / peac::WIN; L.NB = L.Nw * L.Nh; L.NB2 = 2 * L.NB;
-    // neighbour-list pool (u16 entries, global memory; list offsets are u16 in LDS, hence < 65536): the blocks' 4-entry lists, then the merged nodes'
-    // lists (live entries + 8..n/4 slack + a capacity header each; dead lists are reclaimed by compaction when the pool runs full)
-    L.pool_cap = std::min(65535 - 64, 4 * L.NB + std::max(16 * L.NB, peac::MAX_PLANES * peac::MAX_PLANES));
-    L.q_cap = 2 * width * height;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o2 = off; off = align_up(off + bytes, (size_t)256); return o2; };
-    L.off_stats = carve((size_t)L.NB2 * 9 * 8); L.off_geo = carve((size_t)L.NB2 * 7 * 8); L.off_N = carve((size_t)L.NB2 * 4);
-    L.off_rid = carve((size_t)L.NB2 * 4); L.off_flags = carve((size_t)L.NB2); L.off_nb_off = carve((size_t)L.NB2 * 4);
-    L.off_nb_cnt = carve((size_t)L.NB2 * 4); L.off_pool = carve((size_t)L.pool_cap * 4);
-    L.off_parent = carve((size_t)L.NB * 4); L.off_size = carve((size_t)L.NB * 4); L.off_member = carve((size_t)width * height + 4);
-    L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 4);
-    L.off_seedcnt = carve((size_t)L.NB * 4);
-    // candidate cache of the cooperative ahCluster: per node 4 ints {have, best_nb, best_N, -} and 16 doubles {mse, stats[9], center[3],
-    // normal[3]}; whether a record is valid for the node's current live-neighbour set is a bit in LDS
-    L.off_cint = carve((size_t)L.NB2 * 16); L.off_cdbl = carve((size_t)L.NB2 * 16 * 8);
-    L.off_h_dsp = carve((size_t)L.NB * 2); L.off_h_dss = carve((size_t)L.NB * 2); L.off_h_rid = carve((size_t)L.NB2 * 2);
-    L.off_h_nouse = carve((size_t)((L.NB2 + 31) / 32) * 4); L.off_h_cval = carve((size_t)((L.NB2 + 31) / 32) * 4);
-    L.off_h_hand = carve((size_t)(4 + peac::MAX_PLANES) * 4);
-    L.off_h_nboff = carve((size_t)L.NB2 * 2); L.off_h_nbcnt = carve((size_t)L.NB2 * 2); L.off_h_pool = carve((size_t)L.pool_cap * 2);
-    L.frame_bytes = off;
-    // peac_ahc: heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
+    o->L = peac::make_layout(width, height);
+    o->C = peac::make_consts();
+    const peac::Layout& L = o->L;
+    o->smem2 = peac::ahc2_smem_bytes(L);
+    { const char* e = getenv("PLANAR_PEAC_AHC"); o->legacy_ahc = e && !strcmp(e, "legacy"); }
+    // peac_ahc (legacy): heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
     o->smem = L.NB * 4 + L.NB * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
-    // AHCParamSet defaults (include/peac/AHCParamSet.hpp:55-66), evaluated with the host libm as the reference does
-    const double deg = 3.14159265358979323846 / 180.0;   // MACRO_DEG2RAD
-    o->C.ang_near = 15.0 * deg;
-    o->C.ang_factor = (90.0 * deg - 15.0 * deg) / (4000.0 - 500.0);
-    o->C.cos_init_near = std::cos(o->C.ang_factor * 500.0 + o->C.ang_near - o->C.ang_factor * 500.0);
-    o->C.cos_merge = std::cos(60.0 * deg);
-    o->C.cos_refine = std::cos(30.0 * deg);
     int rc;
     if ((rc = o->d_ws.alloc((size_t)max_batch * L.frame_bytes)) || (rc = o->d_status.alloc((size_t)max_batch * 4)) ||
         (rc = o->d_timing.alloc((size_t)max_batch * 128)) || (rc = o->d_next.alloc(256)) || (rc = o->d_order.alloc((size_t)max_batch * 4))) { delete o; return rc; }
@@ -1303,9 +1077,13 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     mark();
     hipLaunchKernelGGL(peac::peac_blocks, dim3((p->L.NB + 63) / 64, B), dim3(64), 0, st, p->L, K, d_depth, pitch_px, frame_stride_px, p->d_ws.as<uint8_t>());
     mark();
-    hipLaunchKernelGGL(peac::peac_ahc, dim3(B), dim3(peac::NT_AHC), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
-                       p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(), p->d_timing.as<long long>(), p->d_next.as<int>(),
-                       p->order_B == B ? p->d_order.as<int>() : nullptr);
+    if (p->legacy_ahc)
+        hipLaunchKernelGGL(peac::peac_ahc, dim3(B), dim3(peac::NT_AHC), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+                           p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(), p->d_timing.as<long long>(), p->d_next.as<int>(),
+                           p->order_B == B ? p->d_order.as<int>() : nullptr);
+    else
+        hipLaunchKernelGGL(peac::peac_ahc2, dim3(B), dim3(64), p->smem2, st, p->L, p->C, p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(),
+                           p->d_timing.as<long long>(), p->d_next.as<int>(), p->order_B == B ? p->d_order.as<int>() : nullptr);
     mark();
     hipLaunchKernelGGL(peac::peac_order, dim3((B + 255) / 256), dim3(256), 0, st, p->d_timing.as<long long>(), B, p->d_order.as<int>());
     mark();
@@ -1347,6 +1125,23 @@ int planar_peac_read_timing(planar_peac* p, int B, int64_t* out) {
     PLANAR_REQUIRE(p && out && B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "bad argument");
     PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
     PLANAR_HIP_CHECK(hipMemcpy(out, p->d_timing.p, (size_t)B * 128, hipMemcpyDeviceToHost));
+    return PLANAR_OK;
+}
+
+// Debug aid (tools/peac_ab.py): the per-frame workspace layout {frame_bytes, NB, NB2, off_stats, off_geo, off_N, off_h_dsp, off_h_dss, off_h_rid,
+// off_h_nouse, off_h_hand, off_crec} and a raw read of one frame's workspace after the last call.
+int planar_peac_debug_layout(planar_peac* p, int64_t* out /* [12] */) {
+    PLANAR_REQUIRE(p && out, PLANAR_EINVAL, "null argument");
+    const peac::Layout& L = p->L;
+    const int64_t v[12] = {(int64_t)L.frame_bytes, L.NB, L.NB2, (int64_t)L.off_stats, (int64_t)L.off_geo, (int64_t)L.off_N, (int64_t)L.off_h_dsp,
+                           (int64_t)L.off_h_dss, (int64_t)L.off_h_rid, (int64_t)L.off_h_nouse, (int64_t)L.off_h_hand, (int64_t)L.off_crec};
+    for (int i = 0; i < 12; i++) out[i] = v[i];
+    return PLANAR_OK;
+}
+int planar_peac_debug_read(planar_peac* p, int frame, int64_t offset, int64_t bytes, void* out) {
+    PLANAR_REQUIRE(p && out && frame >= 0 && frame < p->max_batch && offset >= 0 && bytes >= 0 && (size_t)(offset + bytes) <= p->L.frame_bytes, PLANAR_EINVAL, "bad argument");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    PLANAR_HIP_CHECK(hipMemcpy(out, p->d_ws.as<uint8_t>() + (size_t)frame * p->L.frame_bytes + offset, (size_t)bytes, hipMemcpyDeviceToHost));
     return PLANAR_OK;
 }
 

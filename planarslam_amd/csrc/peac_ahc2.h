@@ -1,0 +1,688 @@
+// planarslam_amd/csrc/peac_ahc2.h — the order-dependent clustering of PEAC (ahCluster, reference include/peac/AHCPlaneFitter.hpp:983-1189,
+// PlaneSeg::mergeNbsFrom / disconnectAllNbs include/peac/AHCPlaneSeg.hpp:379-404) for ONE wavefront per frame, with LAZY adjacency.
+// Included by peac.hip; also compiled for the host by tests/host_shim (wave64 emulator), so it only depends on peac_common.h.
+//
+// The reference keeps std::set<PlaneSeg*> neighbour sets and, on every merge m = p + nb, erases p and nb from all their neighbours' sets and
+// inserts m: for a wavefront that is a chain of dependent global-memory round trips per merge (the previous kernel spent 13 % of a frame in
+// those appends and 18 % in list unions).  Here a node's neighbour list is written ONCE, when the node is created ("bag"), and is never
+// touched by later merges.  What a bag entry x stands for NOW is found through merge-parent pointers in LDS:
+//     mp[x] == x      x is alive              mp[x] == m   x was merged into m (follow the chain)
+//     mp[x] == TOMB   x left the graph without a merge (disconnectAllNbs): the adjacency is gone
+// By induction over the merge sequence, { live end of the chain of x : x in bag(a) } is exactly the reference's nbs(a) for every live a:
+// a merge replaces its two nodes by m in every neighbour's set, which is what following mp does; a disconnect erases the node from every
+// set, which is what TOMB does.  Chains are shortened by path halving (only ever re-pointing a node to one of its ancestors: results do not
+// depend on it).  The union of a merge is a 6144-bit LDS bitmap: both bags' resolved entries set their bit, rank = prefix popcount, so the
+// new bag comes out deduplicated and in ascending node id (= the reference's std::set order) with no searches.
+//
+// Candidate merges of a node are a pure function of its live-neighbour set, so they are evaluated ahead of time (the popped node together
+// with the not-yet-evaluated nodes at the top of the heap, one lane per (node, bag entry): one 3x3 eigen-solve of latency for all of them)
+// and kept in the node's candidate record; a `valid` bit per node (LDS) is cleared for every neighbour of a merge / disconnect, exactly when
+// the reference's candidate loop would see a different set.  A pop of an evaluated node costs: heap pop (LDS), one 272-byte record load,
+// the partner's record load, bitmap union (LDS), stores.
+//
+// Candidate record, 68 dwords per node (frame workspace, L2-resident):
+//   d0      n_roots (low 16: entries of the bag) | flags << 16   (1 have: some neighbour passed the normal test; 2 merge_ok: best mse below
+//           T_mse(merge); 4 big: more than 64 entries, the bag lives in the pool at d3)
+//   d1      best neighbour (low 16) | own N / 100 << 16          d2  own rid (DisjointSet root id)     d3  pool offset of a big bag
+//   d4,d5   mse of the best merge (double)
+//   d6..37  the bag: 64 x u16, resolved in place whenever the node is evaluated (TOMB = dropped)
+//   d38..67 moments[9], centre[3], normal[3] of the best merge: they become node m's record when the merge is taken
+#pragma once
+#include "peac_common.h"
+
+namespace planar {
+namespace peac {
+
+constexpr unsigned TOMB = 0xFFFFu;
+
+__device__ __forceinline__ void stats_compute_u(const double s[9], int N, Geo& g) {   // PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:125-156), wavefront eigen-solver
+    const double sc = 1.0 / N;
+    g.center[0] = s[0] * sc; g.center[1] = s[1] * sc; g.center[2] = s[2] * sc;
+    const double k00 = s[3] - s[0] * s[0] * sc, k01 = s[6] - s[0] * s[1] * sc, k02 = s[8] - s[0] * s[2] * sc;
+    const double k11 = s[4] - s[1] * s[1] * sc, k12 = s[7] - s[1] * s[2] * sc, k22 = s[5] - s[2] * s[2] * sc;
+    double ev[3], v[3];
+    eig33u(k00, k01, k11, k02, k12, k22, ev, v);
+    const bool keep = v[0] * g.center[0] + v[1] * g.center[1] + v[2] * g.center[2] <= 0;
+    g.normal[0] = keep ? v[0] : -v[0]; g.normal[1] = keep ? v[1] : -v[1]; g.normal[2] = keep ? v[2] : -v[2];
+    g.mse = ev[0] * sc;
+}
+
+__host__ __device__ static inline size_t al8(size_t v) { return (v + 7) & ~(size_t)7; }
+// LDS bytes of peac_ahc2 for a layout
+static inline int ahc2_smem_bytes(const Layout& L) {
+    const int W32 = (L.NB2 + 31) / 32;
+    return (int)(al8((size_t)L.NB * 6) + al8((size_t)L.NB2 * 2) + (size_t)W32 * 4 * 2 + al8((size_t)W32 * 2));
+}
+
+__global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
+                                                long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order) {
+    PLANAR_DYN_SMEM(smem);
+    __shared__ int s_frame;
+    __shared__ int s_ext[MAX_PLANES];
+    __shared__ u16 s_mark[64];
+    const int lane = threadIdx.x;
+    // frames are taken from a start-order counter (longest first, see peac_order), not from the block index
+    if (lane == 0) { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
+    __syncthreads();
+    const int frame = s_frame;
+    uint8_t* F = ws + (size_t)frame * L.frame_bytes;
+    double* g_stats = (double*)(F + L.off_stats);
+    double* g_geo = (double*)(F + L.off_geo);
+    int* g_N = (int*)(F + L.off_N);
+    const uint8_t* g_flags = F + L.off_flags;
+    uint32_t* crec = (uint32_t*)(F + L.off_crec);
+    u16* bpool = (u16*)(F + L.off_bpool);
+    u16* h_dsp = (u16*)(F + L.off_h_dsp); u16* h_dss = (u16*)(F + L.off_h_dss); u16* h_rid = (u16*)(F + L.off_h_rid);
+    int* g_hand = (int*)(F + L.off_h_hand);
+    const int NB = L.NB, NB2 = L.NB2, Nw = L.Nw, Nh = L.Nh, W32 = (NB2 + 31) / 32;
+
+    float* h_key = (float*)smem;                                                        // merge heap: keys rounded to float ...
+    u16* h_id = (u16*)(h_key + NB);                                                     // ... and node ids
+    u16* mp = (u16*)(smem + al8((size_t)NB * 6));                       // merge-parent pointers
+    unsigned* cval = (unsigned*)((uint8_t*)mp + al8((size_t)NB2 * 2));  // bit per node: its candidate record is valid
+    unsigned* bmp = cval + W32;                                                         // union bitmap (all zero between merges)
+    u16* pre = (u16*)(bmp + W32);                                                       // exclusive popcount prefix of the bitmap words
+
+    long long tphase[4];
+    int nph = 0;
+    auto mark = [&]() { if (nph < 4) tphase[nph++] = (long long)wall_clock64(); };
+    mark();
+    auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    auto gfence = [&]() { __threadfence_block(); };
+    auto rec = [&](int id) -> uint32_t* { return crec + (size_t)id * CREC_DW; };
+    auto roots_of = [&](int id) -> u16* { return (u16*)(rec(id) + 6); };
+    auto geo_of = [&](int id) -> double* { return g_geo + (size_t)id * 7; };
+    auto nsim = [&](int a, int b) {
+        const double* ga = geo_of(a) + 3; const double* gb = geo_of(b) + 3;
+        return fabs(ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]);
+    };
+    auto is_valid = [&](int id) { return (cval[id >> 5] >> (id & 31)) & 1u; };
+    auto inval = [&](unsigned id) { atomicAnd(&cval[id >> 5], ~(1u << (id & 31))); };
+    auto lane_below = [&](int k) -> unsigned long long { return k >= 64 ? ~0ull : (1ull << k) - 1ull; };
+
+    // ---- init ----
+    unsigned char* cnt8 = (unsigned char*)h_id;              // bag sizes while the graph is built (the heap is built afterwards)
+    for (int b = lane; b < NB; b += 64) { cnt8[b] = 0; h_dsp[b] = (u16)b; h_dss[b] = 1; h_rid[b] = (u16)b; }
+    for (int t = lane; t < NB2; t += 64) mp[t] = (u16)t;
+    for (int t = lane; t < W32; t += 64) { cval[t] = 0; bmp[t] = 0; }
+    __syncthreads();
+
+    // ---- initGraph edges (AHCPlaneFitter.hpp:896-954): a lane owns a whole row, then a whole column (the reference's --j / ++j skip logic is a
+    //      sequential scan of one row / column).  A block's bag (<= 4 entries, ascending) goes straight into its candidate record.
+    auto connect = [&](int a, int b) {
+        int ca = cnt8[a]; lst_insert(roots_of(a), ca, b); cnt8[a] = (unsigned char)ca;
+        int cb = cnt8[b]; lst_insert(roots_of(b), cb, a); cnt8[b] = (unsigned char)cb;
+    };
+    auto inG = [&](int idx) { return (g_flags[idx] & 1) != 0; };
+    for (int i = lane; i < Nh; i += 64) {
+        for (int j = 1; j < Nw; j += 2) {
+            const int c = i * Nw + j;
+            if (!inG(c - 1)) { --j; continue; }
+            if (!inG(c)) continue;
+            if (j < Nw - 1 && !inG(c + 1)) { ++j; continue; }
+            const double th = T_ang_init(C, geo_of(c)[2]);
+            if ((j < Nw - 1 && nsim(c - 1, c + 1) >= th) || (j == Nw - 1 && nsim(c, c - 1) >= th)) {
+                connect(c, c - 1);
+                if (j < Nw - 1) connect(c, c + 1);
+            } else --j;
+        }
+    }
+    __syncthreads();
+    for (int j = lane; j < Nw; j += 64) {
+        for (int i = 1; i < Nh; i += 2) {
+            const int c = i * Nw + j;
+            if (!inG(c - Nw)) { --i; continue; }
+            if (!inG(c)) continue;
+            if (i < Nh - 1 && !inG(c + Nw)) { ++i; continue; }
+            const double th = T_ang_init(C, geo_of(c)[2]);
+            if ((i < Nh - 1 && nsim(c - Nw, c + Nw) >= th) || (i == Nh - 1 && nsim(c, c - Nw) >= th)) {
+                connect(c, c - Nw);
+                if (i < Nh - 1) connect(c, c + Nw);
+            } else --i;
+        }
+    }
+    __syncthreads();
+    for (int b = lane; b < NB; b += 64) {
+        uint32_t* r = rec(b);
+        r[0] = (uint32_t)cnt8[b];
+        r[1] = (uint32_t)(g_N[b] / (WIN * WIN)) << 16;
+        r[2] = (uint32_t)b;
+        r[3] = 0;
+    }
+    __syncthreads();
+    mark();
+
+    int heap_n = 0, n_nodes = NB, n_ext = 0, err = 0;
+    unsigned pool_top = 0;
+    // ---- libstdc++ binary heap (std::priority_queue with PlaneSegMinMSECmp), keys rounded to float; equal floats fall back to the FP64 keys in the
+    //      node records, so the comparisons - hence layout and pop order - are those of the FP64 heap.  __push_heap: the <= 12 ancestors of the hole
+    //      are read by one lane each; the leading run of larger ancestors moves down one level in parallel.
+    auto heap_sift_up = [&](int hole, int id, float mf) {
+        const int anc = lane < 16 ? ((hole + 1) >> lane) - 1 : -1;
+        const bool isanc = lane >= 1 && anc >= 0;
+        float K = 0; int I = 0;
+        if (isanc) { K = h_key[anc]; I = h_id[anc]; }
+        bool less = isanc && mf < K;
+        if (__ballot(isanc && mf == K)) {
+            gfence();
+            const double dv = geo_of(id)[6];
+            if (isanc && mf == K) less = dv < geo_of(I)[6];
+        }
+        const unsigned long long up = __ballot(less) >> 1;
+        const int n = __builtin_ctzll(~up);
+        if (lane >= 1 && lane <= n) { const int dst = ((hole + 1) >> (lane - 1)) - 1; h_key[dst] = K; h_id[dst] = (u16)I; }
+        if (lane == 0) { const int dst = ((hole + 1) >> n) - 1; h_key[dst] = mf; h_id[dst] = (u16)id; }
+        wfence();
+    };
+    auto heap_push = [&](int id, double mse) { heap_n++; heap_sift_up(heap_n - 1, id, (float)mse); };
+    // pop_heap = __adjust_heap(first, 0, len, last value): the hole sinks to the bottom along the smaller child (no early exit), then the value
+    // climbs back.  Lane t = 1..63 stands for node t of the subtree under the hole: six levels per LDS round trip.
+    auto heap_pop = [&]() -> int {
+        const int top = h_id[0];
+        const float vm = h_key[heap_n - 1]; const int vi = h_id[heap_n - 1];
+        heap_n--;
+        const int len = heap_n;
+        if (len == 0) return top;
+        const int half = (len - 1) / 2;
+        const int dl = 31 - __clz(max(lane, 1));
+        int hole = 0;
+        while (hole < half) {
+            const int g = (hole << dl) + lane - 1;
+            const bool inner = lane >= 1 && g < half;
+            float kl = 0, kr = 0; int il = 0, ir = 0;
+            if (inner) { kl = h_key[2 * g + 1]; kr = h_key[2 * g + 2]; il = h_id[2 * g + 1]; ir = h_id[2 * g + 2]; }
+            bool lt = inner && kl < kr;
+            if (__ballot(inner && kl == kr)) { gfence(); if (inner && kl == kr) lt = geo_of(il)[6] < geo_of(ir)[6]; }
+            const unsigned long long two = __ballot(inner);
+            const unsigned long long takel = __ballot(lt);
+            int cur = 1;
+            unsigned long long path = 0;
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+                if (!((two >> cur) & 1ull)) break;
+                path |= 1ull << cur;
+                cur = 2 * cur + 1 - (int)((takel >> cur) & 1ull);
+            }
+            if ((path >> lane) & 1ull) {
+                const bool left = (takel >> lane) & 1ull;
+                h_key[g] = left ? kl : kr; h_id[g] = (u16)(left ? il : ir);
+            }
+            const int dc = 31 - __clz(cur);
+            hole = (hole << dc) + cur - 1;
+        }
+        wfence();
+        if ((len & 1) == 0 && hole == (len - 2) / 2) {
+            const int c = 2 * hole + 1;
+            const float cm = h_key[c]; const int ci = h_id[c];
+            if (lane == 0) { h_key[hole] = cm; h_id[hole] = (u16)ci; }
+            wfence(); hole = c;
+        }
+        heap_sift_up(hole, vi, vm);
+        return top;
+    };
+
+    // ---- what a bag entry stands for now: follow mp to the live node (or TOMB), halving the path on the way.  All 64 lanes call it together.
+    auto chase = [&](unsigned x) -> unsigned {
+        bool done = x == TOMB;
+        int guard = 0;
+        while (__ballot(!done)) {
+            if (++guard > 8192) { err = 7; break; }            // mp only ever points to newer nodes: cannot happen; keeps a corrupted workspace from hanging the GPU
+            if (!done) {
+                const unsigned par = mp[x];
+                if (par == x) done = true;
+                else if (par == TOMB) { x = TOMB; done = true; }
+                else {
+                    const unsigned g = mp[par];
+                    if (g == par) { x = par; done = true; }
+                    else { mp[x] = (u16)g; x = g; if (g == TOMB) done = true; }
+                }
+            }
+        }
+        return x;
+    };
+    // exclusive prefix of the bitmap words' popcounts -> pre[]; returns the number of set bits.  Lane j owns words 3j .. 3j+2.
+    unsigned bw[3];
+    auto bitmap_prefix = [&]() -> int {
+        int c[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int w = 3 * lane + k; bw[k] = w < W32 ? bmp[w] : 0u; c[k] = __popc(bw[k]); }
+        const int tot = c[0] + c[1] + c[2];
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int ex = incl - tot;
+        if (3 * lane < W32) pre[3 * lane] = (u16)ex;
+        if (3 * lane + 1 < W32) pre[3 * lane + 1] = (u16)(ex + c[0]);
+        if (3 * lane + 2 < W32) pre[3 * lane + 2] = (u16)(ex + c[0] + c[1]);
+        wfence();
+        return __shfl(incl, 63);
+    };
+    // the lanes that own bitmap words write their set bits, ascending, to dst[ex ...] and clear the words; with_inval: the ids' valid bits are cleared
+    auto bitmap_emit = [&](u16* dst, bool with_inval) {
+        int o = (int)pre[min(3 * lane, W32 - 1)];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            unsigned w = bw[k];
+            const int base = (3 * lane + k) * 32;
+            while (w) {
+                const int b = __ffs((int)w) - 1;
+                w &= w - 1;
+                dst[o++] = (u16)(base + b);
+                if (with_inval) inval((unsigned)(base + b));
+            }
+            if (bw[k]) bmp[3 * lane + k] = 0;
+        }
+        wfence();
+    };
+    auto set_bit = [&](unsigned id) { atomicOr(&bmp[id >> 5], 1u << (id & 31)); };
+
+    long long cyc[6] = {0, 0, 0, 0, 0, 0};
+    int dbg_hits = 0, dbg_phases = 0, dbg_nodes = 0, dbg_big = 0;
+
+    // One candidate merge per lane: node `nd` with its live neighbour `r` (or r == TOMB: none).
+    // Returns ok (the neighbour passed the normal-similarity test) and the merged moments / plane / N.
+    auto eval_pair = [&](int nd, unsigned r, double ms[9], Geo& mg, int& mN) -> bool {
+        bool ok = false;
+        mN = 0; mg.mse = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) ms[t] = 0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) { mg.center[t] = 0; mg.normal[t] = 0; }
+        if (r != TOMB) {
+            const double* sp = g_stats + (size_t)nd * 9;
+            const double* gp = geo_of(nd) + 3;
+            const double* gn = geo_of((int)r) + 3;
+            const double* sb = g_stats + (size_t)r * 9;
+            const double pn0 = gp[0], pn1 = gp[1], pn2 = gp[2], n0 = gn[0], n1 = gn[1], n2 = gn[2];
+            double ps[9];
+#pragma unroll
+            for (int t = 0; t < 9; t++) { ps[t] = sp[t]; ms[t] = sb[t]; }
+            const int Na = g_N[nd], Nb = g_N[r];
+            if (!(fabs(pn0 * n0 + pn1 * n1 + pn2 * n2) < C.cos_merge)) {        // AHCPlaneFitter.hpp:1035
+#pragma unroll
+                for (int t = 0; t < 9; t++) ms[t] = ps[t] + ms[t];
+                mN = Na + Nb;
+                ok = true;
+            }
+        }
+        if (__ballot(ok)) {
+            Geo g2;
+            double s2[9];
+#pragma unroll
+            for (int t = 0; t < 9; t++) s2[t] = ok ? ms[t] : (t >= 3 && t < 6 ? 1.0 : 0.0);   // idle lanes solve a harmless diagonal matrix
+            stats_compute_u(s2, ok ? mN : 1, g2);
+            if (ok) mg = g2;
+        }
+        return ok;
+    };
+    // the winner's record: merged moments / centre / normal into dwords 38..67 of node nd's candidate record
+    auto write_merged = [&](int nd, const double ms[9], const Geo& mg) {
+        double* o = (double*)(rec(nd) + 38);
+#pragma unroll
+        for (int t = 0; t < 9; t++) o[t] = ms[t];
+#pragma unroll
+        for (int t = 0; t < 3; t++) { o[9 + t] = mg.center[t]; o[12 + t] = mg.normal[t]; }
+    };
+
+    // ---- evaluation phase for a popped node p with a small bag (cp entries) whose record is not valid: p and the live, not-yet-valid small
+    //      nodes among the first 64 heap slots are packed into the 64 lanes (one lane per bag entry), resolved, evaluated and folded.
+    auto eval_phase = [&](int p, int cp) {
+        const int hq = lane < heap_n ? (int)h_id[lane] : -1;
+        int hc = 0;
+        bool cand = false;
+        if (hq >= 0 && mp[hq] == hq && !is_valid(hq)) { const unsigned h0 = rec(hq)[0]; hc = (int)(h0 & 0xffffu); cand = hc >= 1 && !((h0 >> 16) & 4u); }
+        const int v = cand ? hc : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const bool sel = cand && cp + incl <= 64;             // the prefix is monotonic: the selected nodes are a prefix of the candidates
+        const unsigned long long selm = __ballot(sel);
+        const int total = cp + (selm ? __shfl(incl, 63 - __builtin_clzll(selm | 1ull)) : 0);
+        s_mark[lane] = lane == 0 ? (u16)65 : (u16)0;          // 65: the popped node's segment starts at lane 0
+        wfence();
+        if (sel) s_mark[cp + incl - v] = (u16)(lane + 1);     // segment head: 1 + the lane that holds the node
+        wfence();
+        const int mk = s_mark[lane];
+        const unsigned long long heads = __ballot(mk != 0);
+        const int hp = 63 - __builtin_clzll(heads & (lane_below(lane) | (1ull << lane)));   // my segment's first lane
+        const int mkh = __shfl(mk, hp);
+        const int src = mkh == 65 ? 0 : mkh - 1;
+        const int q_nd = __shfl(hq, src), q_c = __shfl(hc, src);
+        const int nd = mkh == 65 ? p : q_nd;
+        const int cnt = mkh == 65 ? cp : q_c;
+        const int k = lane - hp;
+        const bool active = lane < total;
+        unsigned e = TOMB;
+        if (active) e = roots_of(nd)[k];
+        const unsigned r = chase(e);
+        if (active && r != e) roots_of(nd)[k] = (u16)r;       // the bag is resolved in place
+        double ms[9]; Geo mg; int mN;
+        const bool ok = eval_pair(active ? nd : 0, active ? r : TOMB, ms, mg, mN);
+        // fold per segment.  The reference scans the neighbours in ascending id (:1043-1049): take a candidate if none yet, or its mse is smaller, or
+        // (equal mse and best.N < mse - quirk).  Without exact ties / NaNs that is the minimum mse.  Key (mse, id, lane): entries that resolved to the
+        // same node are equal in (mse, id) and the first lane stands for them.
+        double rm = ok ? mg.mse : 1.7976931348623157e308;
+        int ri = ok ? (int)r : 0x7fffffff, rl = lane;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double om = __shfl_up(rm, o); const int oi = __shfl_up(ri, o), ol = __shfl_up(rl, o);
+            if (lane - o >= hp && (om < rm || (om == rm && (oi < ri || (oi == ri && ol < rl))))) { rm = om; ri = oi; rl = ol; }
+        }
+        const int last = min(hp + max(cnt, 1) - 1, 63);
+        double min_m = __shfl(rm, last);
+        int min_i = __shfl(ri, last), win = __shfl(rl, last);
+        bool have = min_i != 0x7fffffff;
+        const bool odd = active && ok && (mg.mse != mg.mse || (mg.mse == min_m && (int)r != min_i));
+        unsigned long long oddm = __ballot(odd);
+        while (oddm) {   // exact ties or NaNs inside a segment: the reference's in-order rule over the DISTINCT neighbours in ascending id (rare)
+            const int ol = __ffsll((long long)oddm) - 1;
+            const int shp = __shfl(hp, ol), scnt = __shfl(cnt, ol);
+            const bool mine = active && lane >= shp && lane < shp + scnt;
+            bool f_have = false; double f_mse = 0; int f_N = 0, f_lane = 0, last_id = -1;
+            while (true) {
+                int cid = (mine && ok && (int)r > last_id) ? (int)r : 0x7fffffff;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cid = min(cid, __shfl_xor(cid, o));
+                if (cid == 0x7fffffff) break;
+                const unsigned long long who = __ballot(mine && ok && (int)r == cid);
+                const int sl = __ffsll((long long)who) - 1;
+                const double c_mse = __shfl(mg.mse, sl); const int c_N = __shfl(mN, sl);
+                if (!f_have || f_mse > c_mse || (f_mse == c_mse && (double)f_N < c_mse)) { f_have = true; f_mse = c_mse; f_N = c_N; f_lane = sl; }   // quirk :1045
+                last_id = cid;
+            }
+            if (mine) { have = f_have; win = f_lane; min_m = f_mse; }
+            oddm &= ~(lane_below(shp + scnt) & ~lane_below(shp));
+        }
+        // the winner lane publishes the merged record; the segment's first lane the header
+        const int w_nb = __shfl((int)r, win);
+        const double w_z = __shfl(mg.center[2], win);
+        const double w_mse = __shfl(mg.mse, win);
+        if (active && have && lane == win) write_merged(nd, ms, mg);
+        if (active && k == 0) {
+            uint32_t* rr = rec(nd);
+            const bool mok = have && w_mse < T_mse_merge(w_z);                     // AHCPlaneFitter.hpp:1057
+            const int ownN = g_N[nd] / (WIN * WIN);
+            rr[0] = (uint32_t)cnt | ((have ? 1u : 0u) | (mok ? 2u : 0u)) << 16;
+            rr[1] = (uint32_t)(have ? w_nb : 0) | (uint32_t)ownN << 16;
+            *(double*)(rr + 4) = have ? w_mse : 0.0;
+            atomicOr(&cval[nd >> 5], 1u << (nd & 31));
+        }
+        dbg_phases++; dbg_nodes += __popcll(heads & lane_below(total));
+    };
+
+    // ---- a popped node whose bag lives in the pool (more than 64 entries when it was created): resolve + deduplicate + sort the bag in place
+    //      through the bitmap, evaluate it 64 entries at a time in ascending id, write the result to its candidate record.
+    auto eval_big = [&](int p, int cp, unsigned off) -> int {
+        for (int k0 = 0; k0 < cp; k0 += 64) {
+            const unsigned e = k0 + lane < cp ? (unsigned)bpool[off + k0 + lane] : TOMB;
+            const unsigned r = chase(e);
+            if (r != TOMB) set_bit(r);
+        }
+        wfence();
+        const int n2 = bitmap_prefix();
+        bitmap_emit(bpool + off, false);
+        gfence();
+        bool have = false; double best_mse = 0; int best_nb = 0, best_N = 0;
+        double best_stats[9]; Geo best_geo;
+#pragma unroll
+        for (int t = 0; t < 9; t++) best_stats[t] = 0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) { best_geo.center[t] = 0; best_geo.normal[t] = 0; }
+        best_geo.mse = 0;
+        for (int k0 = 0; k0 < n2; k0 += 64) {
+            const unsigned r = k0 + lane < n2 ? (unsigned)bpool[off + k0 + lane] : TOMB;
+            double ms[9]; Geo mg; int mN;
+            const bool ok = eval_pair(p, r, ms, mg, mN);
+            const unsigned long long okm = __ballot(ok);
+            if (okm) {
+                double rm = ok ? mg.mse : 1.7976931348623157e308;
+                int rl = ok ? lane : 64;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double om = __shfl_xor(rm, o); const int ol = __shfl_xor(rl, o);
+                    if (om < rm || (om == rm && ol < rl)) { rm = om; rl = ol; }
+                }
+                const bool tie = __popcll(__ballot(ok && mg.mse == rm)) > 1 || __ballot(ok && mg.mse != mg.mse);
+                unsigned long long scan = tie ? okm : (1ull << rl);
+                while (scan) {   // lanes are in ascending id: this is the reference's scan
+                    const int src = __ffsll((long long)scan) - 1;
+                    scan &= scan - 1;
+                    const double c_mse = __shfl(mg.mse, src);
+                    if (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse)) {   // quirk :1045
+                        have = true; best_mse = c_mse; best_nb = __shfl((int)r, src); best_N = __shfl(mN, src);
+#pragma unroll
+                        for (int t = 0; t < 9; t++) best_stats[t] = __shfl(ms[t], src);
+#pragma unroll
+                        for (int t = 0; t < 3; t++) { best_geo.center[t] = __shfl(mg.center[t], src); best_geo.normal[t] = __shfl(mg.normal[t], src); }
+                        best_geo.mse = c_mse;
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            uint32_t* rr = rec(p);
+            const bool mok = have && best_mse < T_mse_merge(best_geo.center[2]);
+            if (have) write_merged(p, best_stats, best_geo);
+            rr[0] = (uint32_t)n2 | ((have ? 1u : 0u) | (mok ? 2u : 0u) | 4u) << 16;
+            rr[1] = (uint32_t)(have ? best_nb : 0) | (rr[1] & 0xffff0000u);
+            *(double*)(rr + 4) = have ? best_mse : 0.0;
+        }
+        dbg_big++;
+        return n2;
+    };
+
+    // ---- heap of the initial blocks, in block order (:809) ----
+    for (int b0 = 0; b0 < NB; b0 += 64) {
+        const int b = b0 + lane;
+        const bool in = b < NB && (g_flags[b] & 1);
+        const double m = in ? geo_of(b)[6] : 0.0;
+        unsigned long long mask = __ballot(in);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            heap_push(b0 + src, __shfl(m, src));
+        }
+    }
+    mark();
+
+    // ---- ahCluster (:983-1189) ----
+    int step = 0;
+    while (heap_n > 0 && step <= MAX_STEP && !err) {
+        long long c0 = PEAC_CYCLES();
+        const int p = heap_pop();
+        const uint32_t* rp = rec(p);
+        uint32_t dw = rp[lane];                                   // dwords 0..63 of p's record, one per lane (issued before p is known to be alive)
+        uint32_t dwt = lane < 4 ? rp[64 + lane] : 0u;             // dwords 64..67
+        cyc[0] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
+        if (mp[p] != p) continue;                                 // nouse (merged away earlier)
+        unsigned d0 = __builtin_amdgcn_readlane(dw, 0);
+        int n = (int)(d0 & 0xffffu);
+        if (n > 0 && !((d0 >> 16) & 4u) && !is_valid(p)) {
+            eval_phase(p, n);
+            gfence();
+            dw = rp[lane]; dwt = lane < 4 ? rp[64 + lane] : 0u;
+            d0 = __builtin_amdgcn_readlane(dw, 0);
+            cyc[4] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
+        } else if (n > 0 && ((d0 >> 16) & 4u)) {
+            eval_big(p, n, __builtin_amdgcn_readlane(dw, 3));
+            gfence();
+            dw = rp[lane]; dwt = lane < 4 ? rp[64 + lane] : 0u;
+            d0 = __builtin_amdgcn_readlane(dw, 0);
+            n = (int)(d0 & 0xffffu);
+            cyc[5] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
+        } else dbg_hits++;
+        const unsigned fl = n > 0 ? d0 >> 16 : 0u;
+        const bool bigA = (fl & 4u) != 0;
+        const unsigned d1 = __builtin_amdgcn_readlane(dw, 1);
+        const int N100p = (int)(d1 >> 16);
+        const unsigned offA = __builtin_amdgcn_readlane(dw, 3);
+        // bag entry `lane` of a record held one dword per lane (a shuffle: called by ALL lanes, whatever the bag's size)
+        auto root_in = [&](uint32_t regs) -> unsigned { const uint32_t w = __shfl(regs, 6 + (lane >> 1)); return (lane & 1) ? (w >> 16) : (w & 0xffffu); };
+        const unsigned rootA = root_in(dw);                         // p's entry: alive or TOMB (the record is valid)
+        if (fl & 2u) {
+            // ---------------- merge p with its best neighbour ----------------
+            const int nb = (int)(d1 & 0xffffu);
+            const int ridp = (int)(__builtin_amdgcn_readlane(dw, 2) & 0xffffu);
+            const uint32_t* rq = rec(nb);
+            const uint32_t ew = lane < 38 ? rq[lane] : 0u;          // the partner's header and bag
+            const unsigned e0 = __builtin_amdgcn_readlane(ew, 0), e1 = __builtin_amdgcn_readlane(ew, 1);
+            const int nbn = (int)(e0 & 0xffffu);
+            const bool bigB = ((e0 >> 16) & 4u) != 0;
+            const int N100n = (int)(e1 >> 16);
+            const int ridn = (int)(__builtin_amdgcn_readlane(ew, 2) & 0xffffu);
+            const unsigned offB = __builtin_amdgcn_readlane(ew, 3);
+            const unsigned rootB = root_in(ew);
+            const int m = n_nodes++;
+            if (m >= NB2) { err = 1; break; }
+            int nm;
+            unsigned offM = 0;
+            bool bigM = false;
+            if (!bigA && !bigB) {
+                // both bags in registers: set bits, prefix, every entry writes itself to its rank
+                unsigned ra = lane < n ? rootA : TOMB;
+                unsigned rb = chase(lane < nbn ? rootB : TOMB);
+                if (ra == (unsigned)nb || ra == (unsigned)p) ra = TOMB;
+                if (rb == (unsigned)p || rb == (unsigned)nb) rb = TOMB;
+                if (ra != TOMB) set_bit(ra);
+                if (rb != TOMB) set_bit(rb);
+                wfence();
+                nm = bitmap_prefix();
+                u16* dst;
+                if (nm <= 64) dst = roots_of(m);
+                else {
+                    const int cap = nm + nm / 4 + 16;
+                    if (pool_top + 1 + cap > (unsigned)L.bpool_cap) { err = 2; break; }
+                    if (lane == 0) bpool[pool_top] = (u16)cap;
+                    offM = pool_top + 1; pool_top += 1 + cap; bigM = true;
+                    dst = bpool + offM;
+                }
+                if (ra != TOMB) { const unsigned w = ra >> 5; dst[pre[w] + __popc(bmp[w] & ((1u << (ra & 31)) - 1u))] = (u16)ra; inval(ra); }
+                if (rb != TOMB) { const unsigned w = rb >> 5; dst[pre[w] + __popc(bmp[w] & ((1u << (rb & 31)) - 1u))] = (u16)rb; inval(rb); }
+                wfence();
+                if (ra != TOMB) bmp[ra >> 5] = 0;
+                if (rb != TOMB) bmp[rb >> 5] = 0;
+                wfence();
+            } else {
+                // a bag in the pool on either side: chunks of 64 entries set their bits, the lanes that own bitmap words emit the result
+                for (int k0 = 0; k0 < n; k0 += 64) {
+                    unsigned e = TOMB;
+                    if (k0 + lane < n) e = bigA ? (unsigned)bpool[offA + k0 + lane] : rootA;
+                    const unsigned r = chase(e);
+                    if (r != TOMB && r != (unsigned)p && r != (unsigned)nb) set_bit(r);
+                }
+                for (int k0 = 0; k0 < nbn; k0 += 64) {
+                    unsigned e = TOMB;
+                    if (k0 + lane < nbn) e = bigB ? (unsigned)bpool[offB + k0 + lane] : rootB;
+                    const unsigned r = chase(e);
+                    if (r != TOMB && r != (unsigned)p && r != (unsigned)nb) set_bit(r);
+                }
+                wfence();
+                nm = bitmap_prefix();
+                u16* dst;
+                if (nm <= 64) dst = roots_of(m);
+                else {
+                    // reuse a dying bag's slot when the new bag fits (a region that absorbs its neighbours one by one keeps its slot)
+                    const int capA = bigA ? (int)bpool[offA - 1] : 0, capB = bigB ? (int)bpool[offB - 1] : 0;
+                    if (capA >= nm && (capA <= capB || capB < nm)) offM = offA;
+                    else if (capB >= nm) offM = offB;
+                    else {
+                        const int cap = nm + nm / 4 + 16;
+                        if (pool_top + 1 + cap > (unsigned)L.bpool_cap) { err = 2; break; }
+                        if (lane == 0) bpool[pool_top] = (u16)cap;
+                        offM = pool_top + 1; pool_top += 1 + cap;
+                    }
+                    bigM = true;
+                    dst = bpool + offM;
+                }
+                bitmap_emit(dst, true);
+            }
+            cyc[2] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
+            // node m: its moments / plane are the best merge of p's record (AHCPlaneSeg.hpp:301-315)
+            {
+                uint32_t* gs = (uint32_t*)(g_stats + (size_t)m * 9);
+                uint32_t* gg = (uint32_t*)(g_geo + (size_t)m * 7);
+                if (lane >= 38 && lane < 56) gs[lane - 38] = dw;            // moments
+                if (lane >= 56 && lane < 62) gg[lane - 56] = dw;            // centre
+                if (lane >= 62) gg[6 + lane - 62] = dw;                     // normal[0]
+                if (lane < 4) gg[8 + lane] = dwt;                           // normal[1], normal[2]
+                if (lane == 4 || lane == 5) gg[12 + lane - 4] = dw;         // mse
+            }
+            const int N100m = N100p + N100n;
+            const int ridm = N100p >= N100n ? ridp : ridn;
+            if (lane == 0) {
+                g_N[m] = N100m * (WIN * WIN);
+                uint32_t* rm = rec(m);
+                rm[0] = (uint32_t)nm | (bigM ? 4u << 16 : 0u);
+                rm[1] = (uint32_t)N100m << 16;
+                rm[2] = (uint32_t)ridm;
+                rm[3] = offM;
+                h_rid[m] = (u16)ridm;
+                // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:64-84): the rid of a live node is its set's root, so Find() returns its argument;
+                // union by size, size(root) * 100 == N of the live node whose rid it is
+                if (ridp != ridn) {
+                    if (N100p < N100n) { h_dsp[ridp] = (u16)ridn; h_dss[ridn] = (u16)N100m; }
+                    else { h_dsp[ridn] = (u16)ridp; h_dss[ridp] = (u16)N100m; }
+                }
+                mp[p] = (u16)m; mp[nb] = (u16)m;
+            }
+            wfence();
+            const double mse = __hiloint2double((int)__builtin_amdgcn_readlane(dw, 5), (int)__builtin_amdgcn_readlane(dw, 4));
+            heap_push(m, mse);
+            cyc[3] += PEAC_CYCLES() - c0;
+        } else {
+            // ---------------- no merge: extract p if it is large enough, disconnect it (:1160-1170) ----------------
+            if (N100p * (WIN * WIN) >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
+            for (int k0 = 0; k0 < n; k0 += 64) {
+                unsigned e = TOMB;
+                if (k0 + lane < n) e = bigA ? (unsigned)bpool[offA + k0 + lane] : rootA;
+                if (e != TOMB) inval(e);                                // p leaves their live-neighbour sets
+            }
+            if (lane == 0) mp[p] = (u16)TOMB;
+            wfence();
+            cyc[1] += PEAC_CYCLES() - c0;
+        }
+        ++step;
+    }
+    while (heap_n > 0 && !err) {                                   // only after MAX_STEP: the reference extracts what is left without looking at nouse
+        const int p = heap_pop();
+        if (g_N[p] >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
+        if (lane == 0 && mp[p] == p) mp[p] = (u16)TOMB;
+        wfence();
+    }
+    gfence();
+    if (lane == 0) {   // std::sort(extractedPlanes, b->N < a->N): insertion sort (stable)
+        for (int i = 1; i < n_ext; i++) {
+            const int v = s_ext[i];
+            int j = i;
+            while (j > 0 && g_N[s_ext[j - 1]] < g_N[v]) { s_ext[j] = s_ext[j - 1]; j--; }
+            s_ext[j] = v;
+        }
+    }
+    wfence();
+    mark();
+    // ---- hand the clustering state over to peac_refine: set sizes / root ids / parents are in the workspace already; dead bits, extracted planes
+    {
+        unsigned* o_nouse = (unsigned*)(F + L.off_h_nouse); unsigned* o_cval = (unsigned*)(F + L.off_h_cval);
+        for (int b0 = 0; b0 < NB2; b0 += 64) {
+            const int id = b0 + lane;
+            const unsigned long long dead = __ballot(id < NB2 && mp[id] != id);
+            if (lane == 0) { o_nouse[b0 >> 5] = (unsigned)dead; if ((b0 >> 5) + 1 < W32) o_nouse[(b0 >> 5) + 1] = (unsigned)(dead >> 32); }
+        }
+        for (int t = lane; t < W32; t += 64) o_cval[t] = 0;
+        for (int t = lane; t < MAX_PLANES; t += 64) g_hand[4 + t] = t < n_ext ? s_ext[t] : 0;
+        if (lane == 0) {
+            g_hand[0] = n_ext; g_hand[1] = err; g_hand[2] = n_nodes;
+            status[frame] = err;
+            if (timing) {
+                for (int t = 0; t < 4; t++) timing[(size_t)frame * 16 + t] = t < nph ? tphase[t] - tphase[0] : 0;
+                timing[(size_t)frame * 16 + 9] = n_nodes;
+                timing[(size_t)frame * 16 + 7] = ((long long)dbg_phases << 40) | ((long long)dbg_nodes << 20) | dbg_hits;
+                timing[(size_t)frame * 16 + 8] = dbg_big;
+                for (int t = 0; t < 6; t++) timing[(size_t)frame * 16 + 10 + t] = cyc[t];
+            }
+        }
+    }
+}
+
+}  // namespace peac
+}  // namespace planar

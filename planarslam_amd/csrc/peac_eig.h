@@ -1,0 +1,144 @@
+// planarslam_amd/csrc/peac_eig.h — Eigen 3.3 SelfAdjointEigenSolver<Matrix3d>::compute for a wavefront.
+//
+// Same operations in the same order as Eigen's iterative solver (Tridiagonalization 3x3 real specialisation,
+// computeFromTridiagonal_impl, tridiagonal_qr_step, JacobiRotation::makeGivens; restated with citations in
+// oracle/eigprim.cpp), hence bit-identical eigenvalues / eigenvectors - but written so that the 64 lanes of a wavefront
+// run ONE instruction stream: PlaneSeg::Stats::compute (reference include/peac/AHCPlaneSeg.hpp:125-156) is evaluated for
+// 64 different candidate merges at a time, and with the textbook control flow every lane's (start, end) block and every
+// makeGivens branch serialises (three block shapes x two Givens branches: the solve was ~27k cycles per wavefront).
+// Here an iteration is: shift (one hypot, one division), a rotation at k = start, and - under the lanes' mask - a second
+// rotation at k = 1 for the lanes whose block is (0, 2); makeGivens and hypot select their operands instead of branching.
+// The header also compiles with g++ (tests/test_peac_eig.py checks it against the oracle bit for bit on the CPU).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define PLANAR_HD __host__ __device__ __forceinline__
+#else
+#define PLANAR_HD static inline
+#endif
+
+namespace planar {
+namespace peac {
+
+// numext::hypot: p * sqrt(1 + (q/p)^2) with p the larger magnitude
+PLANAR_HD double eigu_hypot(double x, double y) {
+    const double ax = fabs(x), ay = fabs(y);
+    const bool xl = ax > ay;
+    const double p = xl ? ax : ay, q = xl ? ay : ax;
+    const double qp = q / p;                       // 0/0 only when p == 0, overridden below
+    const double r = p * sqrt(1.0 + qp * qp);
+    return p == 0 ? 0.0 : r;
+}
+
+// JacobiRotation::makeGivens (real).  Both |p| > |q| and |p| <= |q| are "t = small / large, u = +-sqrt(1 + t^2), 1 / u".
+PLANAR_HD void eigu_givens(double p, double q, double& c, double& s) {
+    const bool big = fabs(p) > fabs(q);
+    const double num = big ? q : p, den = big ? p : q;
+    const double t = num / den;
+    double u = sqrt(1.0 + t * t);
+    if (den < 0) u = -u;
+    const double r = 1.0 / u;
+    const double cA = r, sA = -t * cA;             // |p| > |q|:  c = 1/u, s = -t * c
+    const double sB = -r, cB = -t * sB;            // otherwise:  s = -1/u, c = -t * s
+    c = big ? cA : cB; s = big ? sA : sB;
+    if (p == 0) { c = 0; s = q < 0 ? 1.0 : -1.0; }
+    if (q == 0) { c = p < 0 ? -1.0 : 1.0; s = 0; }
+}
+
+// lower triangle a00,a10,a11,a20,a21,a22 -> eigenvalues ev[0] <= ev[1] <= ev[2] and the eigenvector v0 of ev[0]
+PLANAR_HD void eig33u(double a00, double a10, double a11, double a20, double a21, double a22, double ev[3], double v0[3]) {
+    double scale = fmax(fmax(fmax(fabs(a00), fabs(a10)), fmax(fabs(a11), fabs(a20))), fmax(fabs(a21), fabs(a22)));
+    if (scale == 0) scale = 1;
+    a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
+    double d0 = a00, d1, d2, s0, s1;
+    double q00 = 1, q01 = 0, q02 = 0, q10 = 0, q11 = 1, q12 = 0, q20 = 0, q21 = 0, q22 = 1;
+    {
+        const double v1norm2 = a20 * a20;
+        const bool plain = v1norm2 <= 2.2250738585072014e-308;
+        const double beta = sqrt(a10 * a10 + v1norm2);
+        const double invBeta = 1.0 / beta;
+        const double m01 = a10 * invBeta, m02 = a20 * invBeta;
+        const double q = 2.0 * m01 * a21 + m02 * (a22 - a11);
+        d1 = plain ? a11 : a11 + m02 * q; d2 = plain ? a22 : a22 - m02 * q;
+        s0 = plain ? a10 : beta; s1 = plain ? a21 : a21 - m01 * q;
+        if (!plain) { q11 = m01; q12 = m02; q21 = m02; q22 = -m01; }
+    }
+    const double considerAsZero = 2.2250738585072014e-308, precision = 2.0 * 2.220446049250313e-16;
+    int end = 2, start = 0, iter = 0;
+    while (end > 0) {
+        // for (i = start; i < end; ++i) deflate sub[i]
+        if (start <= 0 && 0 < end && (fabs(s0) <= (fabs(d0) + fabs(d1)) * precision || fabs(s0) <= considerAsZero)) s0 = 0;
+        if (start <= 1 && 1 < end && (fabs(s1) <= (fabs(d1) + fabs(d2)) * precision || fabs(s1) <= considerAsZero)) s1 = 0;
+        if (end == 2 && s1 == 0) end = 1;                      // while (end > 0 && sub[end - 1] == 0) end--
+        if (end == 1 && s0 == 0) end = 0;
+        if (end <= 0) break;
+        iter++;
+        if (iter > 90) break;
+        start = end - 1;
+        if (start == 1 && s0 != 0) start = 0;                  // while (start > 0 && sub[start - 1] != 0) start--
+        const bool e2blk = end == 2, s0blk = start == 0;
+        const bool two = s0blk && e2blk;                       // block (0, 2): rotations at k = 0 and k = 1
+        // tridiagonal_qr_step: Wilkinson shift from the trailing 2x2 of the block
+        const double dEm1 = e2blk ? d1 : d0, dE = e2blk ? d2 : d1, e = e2blk ? s1 : s0;
+        const double td = (dEm1 - dE) * 0.5;
+        double mu = dE;
+        {
+            const double e2 = e * e, h = eigu_hypot(td, e);
+            double dm = e2 / (td + (td > 0 ? h : -h));
+            if (e2 == 0) dm = (e / (td + (td > 0 ? 1.0 : -1.0))) * (e / h);
+            if (td == 0) dm = fabs(e);
+            mu -= dm;
+        }
+        // rotation at k = start on (diag[k], diag[k+1], sub[k]) and the columns k, k+1 of Q
+        double x = (s0blk ? d0 : d1) - mu, z = s0blk ? s0 : s1;
+        double z2 = 0;
+        {
+            const double A = s0blk ? d0 : d1, B = s0blk ? d1 : d2, S = s0blk ? s0 : s1;
+            double c, s;
+            eigu_givens(x, z, c, s);
+            const double sdk = s * A + c * S;
+            const double dkp1 = s * S + c * B;
+            const double nA = c * (c * A - s * S) - s * (c * S - s * B);
+            const double nB = s * sdk + c * dkp1;
+            const double nS = c * sdk - s * dkp1;
+            x = nS;
+            if (two) { z2 = -s * s1; s1 = c * s1; }            // k < end - 1
+            if (s0blk) { d0 = nA; d1 = nB; s0 = nS; } else { d1 = nA; d2 = nB; s1 = nS; }
+            const double x0 = s0blk ? q00 : q01, y0 = s0blk ? q01 : q02;
+            const double x1 = s0blk ? q10 : q11, y1 = s0blk ? q11 : q12;
+            const double x2 = s0blk ? q20 : q21, y2 = s0blk ? q21 : q22;
+            const double n0x = c * x0 - s * y0, n0y = s * x0 + c * y0;
+            const double n1x = c * x1 - s * y1, n1y = s * x1 + c * y1;
+            const double n2x = c * x2 - s * y2, n2y = s * x2 + c * y2;
+            if (s0blk) { q00 = n0x; q01 = n0y; q10 = n1x; q11 = n1y; q20 = n2x; q21 = n2y; }
+            else { q01 = n0x; q02 = n0y; q11 = n1x; q12 = n1y; q21 = n2x; q22 = n2y; }
+        }
+        if (two) {                                             // rotation at k = 1 (= end - 1)
+            double c, s;
+            eigu_givens(x, z2, c, s);
+            const double sdk = s * d1 + c * s1;
+            const double dkp1 = s * s1 + c * d2;
+            const double nA = c * (c * d1 - s * s1) - s * (c * s1 - s * d2);
+            const double nB = s * sdk + c * dkp1;
+            const double nS = c * sdk - s * dkp1;
+            d1 = nA; d2 = nB; s1 = nS;
+            s0 = c * s0 - s * z2;                              // k > start
+            const double n0x = c * q01 - s * q02, n0y = s * q01 + c * q02;
+            const double n1x = c * q11 - s * q12, n1y = s * q11 + c * q12;
+            const double n2x = c * q21 - s * q22, n2y = s * q21 + c * q22;
+            q01 = n0x; q02 = n0y; q11 = n1x; q12 = n1y; q21 = n2x; q22 = n2y;
+        }
+    }
+    if (iter <= 90) {   // selection sort of the eigenvalues (increasing); only column 0 of Q is returned
+        const int k = d2 < (d1 < d0 ? d1 : d0) ? 2 : (d1 < d0 ? 1 : 0);
+        if (k == 1) { double t = d0; d0 = d1; d1 = t; t = q00; q00 = q01; q01 = t; t = q10; q10 = q11; q11 = t; t = q20; q20 = q21; q21 = t; }
+        if (k == 2) { double t = d0; d0 = d2; d2 = t; t = q00; q00 = q02; q02 = t; t = q10; q10 = q12; q12 = t; t = q20; q20 = q22; q22 = t; }
+        if (d2 < d1) { const double t = d1; d1 = d2; d2 = t; }
+    }
+    ev[0] = d0 * scale; ev[1] = d1 * scale; ev[2] = d2 * scale;
+    v0[0] = q00; v0[1] = q10; v0[2] = q20;
+}
+
+}  // namespace peac
+}  // namespace planar

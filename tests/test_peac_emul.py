@@ -1,0 +1,88 @@
+"""The product's PEAC block kernel + clustering kernel (planarslam_amd/csrc/peac_common.h, peac_ahc2.h: the very source hipcc compiles for gfx950)
+compiled with g++ and run on the host-side wave64 emulator (tests/host_shim/wave_emul.h), against the oracle's state after the first ahCluster
+(orc_peac_cluster_state): every node's N / rid / mse / centre / normal / moments bit for bit, the extracted planes in order, the DisjointSet partition.
+The emulator also fails the run when a cross-lane operation is reached by only part of a wavefront - the bug class a GPU run shows as garbage or a hang."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from planarslam_amd.synth import depth_image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tests", "host_shim")
+SO = os.path.join(SHIM, "libpeac_emul_host.so")
+K = (535.4, 539.2, 320.1, 247.6, 1.0 / 5000.0)
+
+
+@pytest.fixture(scope="module")
+def libs():
+    src = os.path.join(SHIM, "peac_emul_host.cpp")
+    csrc = os.path.join(ROOT, "planarslam_amd", "csrc")
+    deps = [src, os.path.join(SHIM, "wave_emul.h")] + [os.path.join(csrc, f) for f in ("peac_ahc2.h", "peac_common.h", "peac_eig.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", SO, src])
+    E = C.CDLL(SO)
+    import oracle_lib as ol
+    O = ol.lib() if hasattr(ol, "lib") else C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    vp = C.c_void_p
+    E.peac_emul_cluster.argtypes = [vp, C.c_int, C.c_int] + [C.c_float] * 5 + [vp] * 7 + [C.c_int]
+    O.orc_peac_cluster_state.argtypes = [vp, C.c_int, C.c_int] + [C.c_float] * 5 + [vp, C.c_int, vp, vp, vp, vp]
+    O.orc_peac_cluster_state.restype = C.c_int
+    return E, O
+
+
+def _run(libs, d):
+    E, O = libs
+    H, W = d.shape
+    NB, NB2 = C.c_int(), C.c_int()
+    E.peac_emul_dims(W, H, C.byref(NB), C.byref(NB2))
+    NB, NB2 = NB.value, NB2.value
+    nodes = np.zeros((NB2, 18)); hand = np.zeros(132, np.int32); dsp = np.zeros(NB, np.uint16); dss = np.zeros(NB, np.uint16)
+    nouse = np.zeros((NB2 + 31) // 32, np.uint32); st = np.zeros(4, np.int64)
+    err = C.create_string_buffer(512)
+    rc = E.peac_emul_cluster(d.ctypes.data, W, H, *K, nodes.ctypes.data, hand.ctypes.data, dsp.ctypes.data, dss.ctypes.data, nouse.ctypes.data, st.ctypes.data, err, 512)
+    assert rc == 0, err.value.decode()
+    onodes = np.zeros((NB2, 18)); oext = np.zeros(4096, np.int32); onext = C.c_int(); oroot = np.zeros(NB, np.int32); osize = np.zeros(NB, np.int32)
+    n = O.orc_peac_cluster_state(d.ctypes.data, W, H, *K, onodes.ctypes.data, NB2, oext.ctypes.data, C.byref(onext), oroot.ctypes.data, osize.ctypes.data)
+    assert st[0] == 0 and hand[1] == 0, f"kernel status {st[0]} / {hand[1]}"
+    assert hand[2] == n, f"nodes: kernel {hand[2]}, oracle {n}"
+    live = onodes[:n, 0] > 0                      # blocks that never held a plane: the oracle keeps NaN there, the kernel zeros
+    same = (nodes[:n].view(np.uint64) == onodes[:n].view(np.uint64)).all(1) | ~live
+    assert same.all(), f"first differing node {int(np.argmin(same))}: kernel {nodes[np.argmin(same)]} oracle {onodes[np.argmin(same)]}"
+    assert hand[0] == onext.value and np.array_equal(hand[4:4 + hand[0]], oext[:onext.value]), "extracted planes differ"
+
+    def find(x):
+        while dsp[x] != x:
+            x = dsp[x]
+        return x
+    roots = np.array([find(b) for b in range(NB)])
+    assert np.array_equal(roots, oroot) and np.array_equal(dss[roots], osize), "DisjointSet partition differs"
+    dead = np.array([(nouse[i >> 5] >> (i & 31)) & 1 for i in range(n)], bool)
+    assert dead[live].all(), "a node of the graph is still marked alive after the clustering"
+    return dict(phases=int(st[2] >> 40), evaluated=int((st[2] >> 20) & 0xFFFFF), hits=int(st[2] & 0xFFFFF), big=int(st[3]), nodes=int(n), planes=int(hand[0]))
+
+
+@pytest.mark.parametrize("w,h,seed,noise,holes", [(160, 120, 5, True, True), (320, 240, 77, True, True), (320, 240, 78, False, True), (640, 480, 4321, True, True),
+                                                  (640, 480, 51, False, False)])
+def test_emulated_kernel_matches_oracle(libs, w, h, seed, noise, holes):
+    info = _run(libs, depth_image(seed, w, h, noise=noise, holes=holes))
+    assert info["nodes"] > (w // 10) * (h // 10)          # something was merged
+
+
+def test_emulated_kernel_edge_cases(libs):
+    z = np.zeros((120, 160), np.uint16)
+    assert _run(libs, z)["planes"] == 0                   # no valid block at all
+    flat = np.full((240, 320), 10000, np.uint16)
+    info = _run(libs, flat)                               # one fronto-parallel wall: exact mse ties all over the heap, one region with a long boundary
+    assert info["planes"] == 1
+    ramp = (6000 + 9 * np.arange(320)[None, :] + np.zeros((240, 1))).astype(np.uint16)
+    assert _run(libs, ramp)["planes"] == 1
+
+
+def test_big_bags_go_through_the_pool(libs):
+    """a noise-free scene grows regions with more than 64 neighbours: the bags in the pool, their compaction and slot reuse are exercised"""
+    info = _run(libs, depth_image(51, 640, 480, noise=False, holes=False))
+    assert info["big"] > 0
