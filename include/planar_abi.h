@@ -420,8 +420,10 @@ int planar_peac_check(planar_peac* peac, int B);
  * summed milliseconds of the four launches of the recorded calls (total_ms[4] = peac_blocks, peac_ahc, peac_order, peac_refine), their number, and resets. */
 int planar_peac_set_profiling(planar_peac* peac, int enable);
 int planar_peac_get_profile(planar_peac* peac, double* total_ms, int64_t* calls);
-/* Profiling aid: per-frame phase timestamps of the last call, out[B][16] (100 MHz ticks since kernel entry:
- * [1] graph edges, [2] heap built, [3] ahCluster, [4] seeds, [5] floodFill, [6] end; [8] flood-fill queue entries, [9] nodes). */
+/* Profiling aid: per-frame record of the last call, out[B][48] (100 MHz ticks since kernel entry:
+ * [1] graph edges, [2] heap built, [3] ahCluster, [4] seeds, [5] floodFill, [6] end; [7] evaluation phases << 40 | nodes evaluated << 20 | valid-record pops;
+ * [8] flood-fill queue entries, [9] nodes, [10] pops of nodes whose bag lives in the pool; [16..39] shader-cycle buckets of the clustering kernel, zero
+ * unless the library was built with -DPLANAR_PEAC_TIMING: tools/peac_ab.py names them). */
 int planar_peac_read_timing(planar_peac* peac, int B, int64_t* out);
 
 /* ---- local bundle adjustment (replaces the numerical core of Optimizer::LocalBundleAdjustment,

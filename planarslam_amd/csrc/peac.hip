@@ -713,10 +713,10 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     if (tid == 0) {
         status[frame] = err;
         if (timing) {
-            for (int t = 0; t < 4; t++) timing[(size_t)frame * 16 + t] = t < nph ? tphase[t] - tphase[0] : 0;
-            timing[(size_t)frame * 16 + 9] = n_nodes;
-            timing[(size_t)frame * 16 + 7] = ((long long)dbg_phases << 40) | ((long long)dbg_nodes << 20) | dbg_hits;   // cooperative ahCluster: phases, nodes evaluated, cache hits
-            for (int t = 0; t < 6; t++) timing[(size_t)frame * 16 + 10 + t] = cyc[t];
+            for (int t = 0; t < 4; t++) timing[(size_t)frame * TSLOTS + t] = t < nph ? tphase[t] - tphase[0] : 0;
+            timing[(size_t)frame * TSLOTS + 9] = n_nodes;
+            timing[(size_t)frame * TSLOTS + 7] = ((long long)dbg_phases << 40) | ((long long)dbg_nodes << 20) | dbg_hits;   // cooperative ahCluster: phases, nodes evaluated, cache hits
+            for (int t = 0; t < 6; t++) timing[(size_t)frame * TSLOTS + 10 + t] = cyc[t];
         }
     }
     return;
@@ -952,9 +952,9 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     if (tid == 0) {
         n_planes[frame] = n_ext; status[frame] = err;
         if (timing) {   // marks of this kernel: [1] seeds done, [2] floodFill done, [3] end; stored behind the clustering kernel's [0..3]
-            const long long base = timing[(size_t)frame * 16 + 3];
-            for (int t = 2; t < 5; t++) timing[(size_t)frame * 16 + 2 + t] = base + (t < nph ? tphase[t] - tphase[0] : 0);
-            timing[(size_t)frame * 16 + 8] = s_scalar[2];
+            const long long base = timing[(size_t)frame * TSLOTS + 3];
+            for (int t = 2; t < 5; t++) timing[(size_t)frame * TSLOTS + 2 + t] = base + (t < nph ? tphase[t] - tphase[0] : 0);
+            timing[(size_t)frame * TSLOTS + 8] = s_scalar[2];
         }
     }
 }
@@ -986,10 +986,10 @@ __global__ __launch_bounds__(NT_REFINE) void peac_refine(Layout L, Intr K, Const
 __global__ void peac_order(const long long* __restrict__ timing, int B, int* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
-    const long long ci = timing[(size_t)i * 16 + 3];         // clock ticks of the clustering kernel (entry to the end of ahCluster)
+    const long long ci = timing[(size_t)i * TSLOTS + 3];         // clock ticks of the clustering kernel (entry to the end of ahCluster)
     int rank = 0;
     for (int j = 0; j < B; j++) {
-        const long long cj = timing[(size_t)j * 16 + 3];
+        const long long cj = timing[(size_t)j * TSLOTS + 3];
         rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0;
     }
     order[rank] = i;
@@ -1042,7 +1042,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
     int rc;
     if ((rc = o->d_ws.alloc((size_t)max_batch * L.frame_bytes)) || (rc = o->d_status.alloc((size_t)max_batch * 4)) ||
-        (rc = o->d_timing.alloc((size_t)max_batch * 128)) || (rc = o->d_next.alloc(256)) || (rc = o->d_order.alloc((size_t)max_batch * 4))) { delete o; return rc; }
+        (rc = o->d_timing.alloc((size_t)max_batch * peac::TSLOTS * 8)) || (rc = o->d_next.alloc(256)) || (rc = o->d_order.alloc((size_t)max_batch * 4))) { delete o; return rc; }
     if (o->smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)peac::peac_ahc, hipFuncAttributeMaxDynamicSharedMemorySize, o->smem);
         if (e != hipSuccess) { delete o; set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
@@ -1124,7 +1124,7 @@ int planar_peac_get_profile(planar_peac* p, double* total_ms /* [4] */, int64_t*
 int planar_peac_read_timing(planar_peac* p, int B, int64_t* out) {
     PLANAR_REQUIRE(p && out && B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "bad argument");
     PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
-    PLANAR_HIP_CHECK(hipMemcpy(out, p->d_timing.p, (size_t)B * 128, hipMemcpyDeviceToHost));
+    PLANAR_HIP_CHECK(hipMemcpy(out, p->d_timing.p, (size_t)B * peac::TSLOTS * 8, hipMemcpyDeviceToHost));
     return PLANAR_OK;
 }
 

@@ -17,8 +17,12 @@
 // Candidate merges of a node are a pure function of its live-neighbour set, so they are evaluated ahead of time (the popped node together
 // with the not-yet-evaluated nodes at the top of the heap, one lane per (node, bag entry): one 3x3 eigen-solve of latency for all of them)
 // and kept in the node's candidate record; a `valid` bit per node (LDS) is cleared for every neighbour of a merge / disconnect, exactly when
-// the reference's candidate loop would see a different set.  A pop of an evaluated node costs: heap pop (LDS), one 272-byte record load,
-// the partner's record load, bitmap union (LDS), stores.
+// the reference's candidate loop would see a different set.  A pop of an evaluated node costs: heap pop (LDS; the node's 272-byte record is
+// requested before the pop and arrives behind it), the partner's record load, bitmap union (LDS), stores.
+//
+// What bounds the kernel: a lone wavefront issues about one instruction every five cycles (profiles/README.md, -DPLANAR_PEAC_TIMING buckets), so
+// the code is written for instruction count: heap entries are one 64-bit LDS word (float key | node id | bag size), wave-uniform values are kept in
+// SGPRs (wave_ops.h), prefix sums run on DPP, and the common cases (bag entries still alive, both bags in registers) have straight-line paths.
 //
 // Candidate record, 68 dwords per node (frame workspace, L2-resident):
 //   d0      n_roots (low 16: entries of the bag) | flags << 16   (1 have: some neighbour passed the normal test; 2 merge_ok: best mse below
@@ -29,6 +33,7 @@
 //   d38..67 moments[9], centre[3], normal[3] of the best merge: they become node m's record when the merge is taken
 #pragma once
 #include "peac_common.h"
+#include "wave_ops.h"
 
 namespace planar {
 namespace peac {
@@ -51,15 +56,17 @@ __host__ __device__ static inline size_t al8(size_t v) { return (v + 7) & ~(size
 // LDS bytes of peac_ahc2 for a layout
 static inline int ahc2_smem_bytes(const Layout& L) {
     const int W32 = (L.NB2 + 31) / 32;
-    return (int)(al8((size_t)L.NB * 6) + al8((size_t)L.NB2 * 2) + (size_t)W32 * 4 * 2 + al8((size_t)W32 * 2));
+    return (int)((size_t)L.NB * 8 + al8((size_t)L.NB2 * 2) + (size_t)W32 * 4 * 2 + al8((size_t)W32 * 2));
 }
+
+typedef unsigned long long u64;
 
 __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
                                                 long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order) {
     PLANAR_DYN_SMEM(smem);
     __shared__ int s_frame;
     __shared__ int s_ext[MAX_PLANES];
-    __shared__ u16 s_mark[64];
+    __shared__ unsigned s_mark[64];
     const int lane = threadIdx.x;
     // frames are taken from a start-order counter (longest first, see peac_order), not from the block index
     if (lane == 0) { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
@@ -76,10 +83,10 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
     int* g_hand = (int*)(F + L.off_h_hand);
     const int NB = L.NB, NB2 = L.NB2, Nw = L.Nw, Nh = L.Nh, W32 = (NB2 + 31) / 32;
 
-    float* h_key = (float*)smem;                                                        // merge heap: keys rounded to float ...
-    u16* h_id = (u16*)(h_key + NB);                                                     // ... and node ids
-    u16* mp = (u16*)(smem + al8((size_t)NB * 6));                       // merge-parent pointers
-    unsigned* cval = (unsigned*)((uint8_t*)mp + al8((size_t)NB2 * 2));  // bit per node: its candidate record is valid
+    // merge heap: one 64-bit word per entry = key rounded to float (bits 0..31) | node id (32..47) | bag size at creation, 255 = in the pool (48..55)
+    u64* hp = (u64*)smem;
+    u16* mp = (u16*)(smem + (size_t)NB * 8);                                            // merge-parent pointers
+    unsigned* cval = (unsigned*)((uint8_t*)mp + al8((size_t)NB2 * 2));                  // bit per node: its candidate record is valid
     unsigned* bmp = cval + W32;                                                         // union bitmap (all zero between merges)
     u16* pre = (u16*)(bmp + W32);                                                       // exclusive popcount prefix of the bitmap words
 
@@ -98,10 +105,14 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
     };
     auto is_valid = [&](int id) { return (cval[id >> 5] >> (id & 31)) & 1u; };
     auto inval = [&](unsigned id) { atomicAnd(&cval[id >> 5], ~(1u << (id & 31))); };
-    auto lane_below = [&](int k) -> unsigned long long { return k >= 64 ? ~0ull : (1ull << k) - 1ull; };
+    auto lane_below = [&](int k) -> u64 { return k >= 64 ? ~0ull : (1ull << k) - 1ull; };
+    auto e_key = [](u64 e) -> float { return __uint_as_float((unsigned)e); };
+    auto e_id = [](u64 e) -> int { return (int)((e >> 32) & 0xffffu); };
+    auto e_cnt = [](u64 e) -> int { return (int)((e >> 48) & 0xffu); };
+    auto e_make = [](float key, int id, int cnt) -> u64 { return (u64)__float_as_uint(key) | (u64)(unsigned)id << 32 | (u64)(unsigned)(cnt > 64 ? 255 : cnt) << 48; };
 
     // ---- init ----
-    unsigned char* cnt8 = (unsigned char*)h_id;              // bag sizes while the graph is built (the heap is built afterwards)
+    unsigned char* cnt8 = (unsigned char*)hp;                // bag sizes while the graph is built (the heap is built afterwards)
     for (int b = lane; b < NB; b += 64) { cnt8[b] = 0; h_dsp[b] = (u16)b; h_dss[b] = 1; h_rid[b] = (u16)b; }
     for (int t = lane; t < NB2; t += 64) mp[t] = (u16)t;
     for (int t = lane; t < W32; t += 64) { cval[t] = 0; bmp[t] = 0; }
@@ -154,89 +165,93 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
 
     int heap_n = 0, n_nodes = NB, n_ext = 0, err = 0;
     unsigned pool_top = 0;
+    long long cyc[24] = {0}, c0 = 0;   // cycle buckets (PEAC_TICK)
+    (void)c0;
     // ---- libstdc++ binary heap (std::priority_queue with PlaneSegMinMSECmp), keys rounded to float; equal floats fall back to the FP64 keys in the
     //      node records, so the comparisons - hence layout and pop order - are those of the FP64 heap.  __push_heap: the <= 12 ancestors of the hole
     //      are read by one lane each; the leading run of larger ancestors moves down one level in parallel.
-    auto heap_sift_up = [&](int hole, int id, float mf) {
+    auto heap_sift_up = [&](int hole, u64 ent) {
+        const float mf = e_key(ent);
         const int anc = lane < 16 ? ((hole + 1) >> lane) - 1 : -1;
         const bool isanc = lane >= 1 && anc >= 0;
-        float K = 0; int I = 0;
-        if (isanc) { K = h_key[anc]; I = h_id[anc]; }
+        u64 E = 0;
+        if (isanc) E = hp[anc];
+        const float K = e_key(E);
         bool less = isanc && mf < K;
         if (__ballot(isanc && mf == K)) {
             gfence();
-            const double dv = geo_of(id)[6];
-            if (isanc && mf == K) less = dv < geo_of(I)[6];
+            const double dv = geo_of(e_id(ent))[6];
+            if (isanc && mf == K) less = dv < geo_of(e_id(E))[6];
         }
-        const unsigned long long up = __ballot(less) >> 1;
+        const u64 up = __ballot(less) >> 1;
         const int n = __builtin_ctzll(~up);
-        if (lane >= 1 && lane <= n) { const int dst = ((hole + 1) >> (lane - 1)) - 1; h_key[dst] = K; h_id[dst] = (u16)I; }
-        if (lane == 0) { const int dst = ((hole + 1) >> n) - 1; h_key[dst] = mf; h_id[dst] = (u16)id; }
+        if (lane >= 1 && lane <= n) hp[((hole + 1) >> (lane - 1)) - 1] = E;
+        if (lane == 0) hp[((hole + 1) >> n) - 1] = ent;
         wfence();
     };
-    auto heap_push = [&](int id, double mse) { heap_n++; heap_sift_up(heap_n - 1, id, (float)mse); };
+    auto heap_push = [&](int id, double mse, int cnt) { heap_n++; heap_sift_up(heap_n - 1, e_make((float)mse, id, cnt)); };
     // pop_heap = __adjust_heap(first, 0, len, last value): the hole sinks to the bottom along the smaller child (no early exit), then the value
     // climbs back.  Lane t = 1..63 stands for node t of the subtree under the hole: six levels per LDS round trip.
-    auto heap_pop = [&]() -> int {
-        const int top = h_id[0];
-        const float vm = h_key[heap_n - 1]; const int vi = h_id[heap_n - 1];
+    const int dl = 31 - __clz(max(lane, 1));                 // level of local node `lane` in the 63-node subtree
+    auto heap_pop = [&]() {
+        const u64 vlast = hp[heap_n - 1];
         heap_n--;
         const int len = heap_n;
-        if (len == 0) return top;
+        if (len == 0) return;
         const int half = (len - 1) / 2;
-        const int dl = 31 - __clz(max(lane, 1));
         int hole = 0;
         while (hole < half) {
             const int g = (hole << dl) + lane - 1;
             const bool inner = lane >= 1 && g < half;
-            float kl = 0, kr = 0; int il = 0, ir = 0;
-            if (inner) { kl = h_key[2 * g + 1]; kr = h_key[2 * g + 2]; il = h_id[2 * g + 1]; ir = h_id[2 * g + 2]; }
+            u64 el = 0, er = 0;
+            if (inner) { el = hp[2 * g + 1]; er = hp[2 * g + 2]; }
+            const float kl = e_key(el), kr = e_key(er);
             bool lt = inner && kl < kr;
-            if (__ballot(inner && kl == kr)) { gfence(); if (inner && kl == kr) lt = geo_of(il)[6] < geo_of(ir)[6]; }
-            const unsigned long long two = __ballot(inner);
-            const unsigned long long takel = __ballot(lt);
+            if (__ballot(inner && kl == kr)) { gfence(); if (inner && kl == kr) lt = geo_of(e_id(el))[6] < geo_of(e_id(er))[6]; }
+            const u64 two = __ballot(inner);
+            const u64 takel = __ballot(lt);
             int cur = 1;
-            unsigned long long path = 0;
+            u64 path = 0;
 #pragma unroll
             for (int d = 0; d < 6; d++) {
                 if (!((two >> cur) & 1ull)) break;
                 path |= 1ull << cur;
                 cur = 2 * cur + 1 - (int)((takel >> cur) & 1ull);
             }
-            if ((path >> lane) & 1ull) {
-                const bool left = (takel >> lane) & 1ull;
-                h_key[g] = left ? kl : kr; h_id[g] = (u16)(left ? il : ir);
-            }
+            if ((path >> lane) & 1ull) hp[g] = ((takel >> lane) & 1ull) ? el : er;
             const int dc = 31 - __clz(cur);
             hole = (hole << dc) + cur - 1;
         }
         wfence();
+        PEAC_TICK(0);
         if ((len & 1) == 0 && hole == (len - 2) / 2) {
             const int c = 2 * hole + 1;
-            const float cm = h_key[c]; const int ci = h_id[c];
-            if (lane == 0) { h_key[hole] = cm; h_id[hole] = (u16)ci; }
+            const u64 ce = hp[c];
+            if (lane == 0) hp[hole] = ce;
             wfence(); hole = c;
         }
-        heap_sift_up(hole, vi, vm);
-        return top;
+        heap_sift_up(hole, vlast);
+        PEAC_TICK(1);
     };
 
     // ---- what a bag entry stands for now: follow mp to the live node (or TOMB), halving the path on the way.  All 64 lanes call it together.
     auto chase = [&](unsigned x) -> unsigned {
-        bool done = x == TOMB;
+        unsigned par = x == TOMB ? TOMB : (unsigned)mp[x];
+        if (!__ballot(par != x)) return x;                     // every entry is alive (or a tombstone): the common case
+        bool done = par == x;
         int guard = 0;
-        while (__ballot(!done)) {
-            if (++guard > 8192) { err = 7; break; }            // mp only ever points to newer nodes: cannot happen; keeps a corrupted workspace from hanging the GPU
+        while (true) {
             if (!done) {
-                const unsigned par = mp[x];
-                if (par == x) done = true;
-                else if (par == TOMB) { x = TOMB; done = true; }
+                if (par == TOMB) { x = TOMB; done = true; }
                 else {
                     const unsigned g = mp[par];
                     if (g == par) { x = par; done = true; }
                     else { mp[x] = (u16)g; x = g; if (g == TOMB) done = true; }
                 }
             }
+            if (!__ballot(!done)) break;
+            if (++guard > 8192) { err = 7; break; }            // mp only ever points to newer nodes: cannot happen; keeps a corrupted workspace from hanging the GPU
+            if (!done) { par = mp[x]; if (par == x) done = true; }
         }
         return x;
     };
@@ -247,15 +262,13 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
 #pragma unroll
         for (int k = 0; k < 3; k++) { const int w = 3 * lane + k; bw[k] = w < W32 ? bmp[w] : 0u; c[k] = __popc(bw[k]); }
         const int tot = c[0] + c[1] + c[2];
-        int incl = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int incl = wave_scan_add(tot);
         const int ex = incl - tot;
         if (3 * lane < W32) pre[3 * lane] = (u16)ex;
         if (3 * lane + 1 < W32) pre[3 * lane + 1] = (u16)(ex + c[0]);
         if (3 * lane + 2 < W32) pre[3 * lane + 2] = (u16)(ex + c[0] + c[1]);
         wfence();
-        return __shfl(incl, 63);
+        return wave_lane(incl, 63);
     };
     // the lanes that own bitmap words write their set bits, ascending, to dst[ex ...] and clear the words; with_inval: the ids' valid bits are cleared
     auto bitmap_emit = [&](u16* dst, bool with_inval) {
@@ -276,7 +289,6 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
     };
     auto set_bit = [&](unsigned id) { atomicOr(&bmp[id >> 5], 1u << (id & 31)); };
 
-    long long cyc[6] = {0, 0, 0, 0, 0, 0};
     int dbg_hits = 0, dbg_phases = 0, dbg_nodes = 0, dbg_big = 0;
 
     // One candidate merge per lane: node `nd` with its live neighbour `r` (or r == TOMB: none).
@@ -305,7 +317,9 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
                 ok = true;
             }
         }
-        if (__ballot(ok)) {
+        const u64 any_ok = __ballot(ok);
+        PEAC_TICK(14);
+        if (any_ok) {
             Geo g2;
             double s2[9];
 #pragma unroll
@@ -327,84 +341,85 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
     // ---- evaluation phase for a popped node p with a small bag (cp entries) whose record is not valid: p and the live, not-yet-valid small
     //      nodes among the first 64 heap slots are packed into the 64 lanes (one lane per bag entry), resolved, evaluated and folded.
     auto eval_phase = [&](int p, int cp) {
-        const int hq = lane < heap_n ? (int)h_id[lane] : -1;
-        int hc = 0;
-        bool cand = false;
-        if (hq >= 0 && mp[hq] == hq && !is_valid(hq)) { const unsigned h0 = rec(hq)[0]; hc = (int)(h0 & 0xffffu); cand = hc >= 1 && !((h0 >> 16) & 4u); }
+        const u64 he = lane < heap_n ? hp[lane] : 0ull;
+        const int hq = e_id(he), hc = e_cnt(he);
+        const bool cand = lane < heap_n && hc >= 1 && hc <= 64 && mp[hq] == hq && !is_valid(hq);
         const int v = cand ? hc : 0;
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int incl = wave_scan_add(v);
         const bool sel = cand && cp + incl <= 64;             // the prefix is monotonic: the selected nodes are a prefix of the candidates
-        const unsigned long long selm = __ballot(sel);
-        const int total = cp + (selm ? __shfl(incl, 63 - __builtin_clzll(selm | 1ull)) : 0);
-        s_mark[lane] = lane == 0 ? (u16)65 : (u16)0;          // 65: the popped node's segment starts at lane 0
+        const u64 selm = __ballot(sel);
+        const int total = cp + (selm ? wave_lane(incl, 63 - __builtin_clzll(selm | 1ull)) : 0);
+        // segment heads: node | bag size << 16 | 1 << 31 at the segment's first lane; the popped node's segment starts at lane 0
+        s_mark[lane] = lane == 0 ? ((unsigned)p | (unsigned)cp << 16 | 0x80000000u) : 0u;
         wfence();
-        if (sel) s_mark[cp + incl - v] = (u16)(lane + 1);     // segment head: 1 + the lane that holds the node
+        if (sel) s_mark[cp + incl - v] = (unsigned)hq | (unsigned)hc << 16 | 0x80000000u;
         wfence();
-        const int mk = s_mark[lane];
-        const unsigned long long heads = __ballot(mk != 0);
-        const int hp = 63 - __builtin_clzll(heads & (lane_below(lane) | (1ull << lane)));   // my segment's first lane
-        const int mkh = __shfl(mk, hp);
-        const int src = mkh == 65 ? 0 : mkh - 1;
-        const int q_nd = __shfl(hq, src), q_c = __shfl(hc, src);
-        const int nd = mkh == 65 ? p : q_nd;
-        const int cnt = mkh == 65 ? cp : q_c;
-        const int k = lane - hp;
+        const unsigned mk = s_mark[lane];
+        const u64 heads = __ballot(mk != 0);
+        const int hpos = 63 - __builtin_clzll(heads & (lane_below(lane) | (1ull << lane)));   // my segment's first lane
+        const unsigned mkh = __shfl(mk, hpos);
+        const int nd = (int)(mkh & 0xffffu), cnt = (int)((mkh >> 16) & 0xffu);
+        const int k = lane - hpos;
         const bool active = lane < total;
+        PEAC_TICK(12);
         unsigned e = TOMB;
         if (active) e = roots_of(nd)[k];
         const unsigned r = chase(e);
         if (active && r != e) roots_of(nd)[k] = (u16)r;       // the bag is resolved in place
+        PEAC_TICK(13);
         double ms[9]; Geo mg; int mN;
         const bool ok = eval_pair(active ? nd : 0, active ? r : TOMB, ms, mg, mN);
+        PEAC_TICK(15);
         // fold per segment.  The reference scans the neighbours in ascending id (:1043-1049): take a candidate if none yet, or its mse is smaller, or
-        // (equal mse and best.N < mse - quirk).  Without exact ties / NaNs that is the minimum mse.  Key (mse, id, lane): entries that resolved to the
-        // same node are equal in (mse, id) and the first lane stands for them.
+        // (equal mse and best.N < mse - quirk).  Without exact ties / NaNs that is the minimum mse: a segmented prefix-min of the mse alone; the
+        // winner is the first lane of the segment that holds the minimum (entries that resolved to the same node hold equal values).
         double rm = ok ? mg.mse : 1.7976931348623157e308;
-        int ri = ok ? (int)r : 0x7fffffff, rl = lane;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const double om = __shfl_up(rm, o); const int oi = __shfl_up(ri, o), ol = __shfl_up(rl, o);
-            if (lane - o >= hp && (om < rm || (om == rm && (oi < ri || (oi == ri && ol < rl))))) { rm = om; ri = oi; rl = ol; }
+            const double om = __shfl_up(rm, o);
+            if (lane - o >= hpos && om < rm) rm = om;
         }
-        const int last = min(hp + max(cnt, 1) - 1, 63);
+        const int last = min(hpos + max(cnt, 1) - 1, 63);
         double min_m = __shfl(rm, last);
-        int min_i = __shfl(ri, last), win = __shfl(rl, last);
-        bool have = min_i != 0x7fffffff;
-        const bool odd = active && ok && (mg.mse != mg.mse || (mg.mse == min_m && (int)r != min_i));
-        unsigned long long oddm = __ballot(odd);
+        const u64 segm = lane_below(hpos + max(cnt, 1)) & ~lane_below(hpos);
+        const u64 eqm = __ballot(ok && mg.mse == min_m) & segm;
+        bool have = eqm != 0;
+        int win = have ? __ffsll((long long)eqm) - 1 : hpos;
+        int w_nb = __shfl((int)r, win);
+        const bool odd = active && ok && (mg.mse != mg.mse || (mg.mse == min_m && (int)r != w_nb));
+        u64 oddm = __ballot(odd);
         while (oddm) {   // exact ties or NaNs inside a segment: the reference's in-order rule over the DISTINCT neighbours in ascending id (rare)
             const int ol = __ffsll((long long)oddm) - 1;
-            const int shp = __shfl(hp, ol), scnt = __shfl(cnt, ol);
+            const int shp = wave_lane(hpos, ol), scnt = wave_lane(cnt, ol);
             const bool mine = active && lane >= shp && lane < shp + scnt;
             bool f_have = false; double f_mse = 0; int f_N = 0, f_lane = 0, last_id = -1;
             while (true) {
                 int cid = (mine && ok && (int)r > last_id) ? (int)r : 0x7fffffff;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) cid = min(cid, __shfl_xor(cid, o));
+                cid = wave_uni(cid);
                 if (cid == 0x7fffffff) break;
-                const unsigned long long who = __ballot(mine && ok && (int)r == cid);
+                const u64 who = __ballot(mine && ok && (int)r == cid);
                 const int sl = __ffsll((long long)who) - 1;
-                const double c_mse = __shfl(mg.mse, sl); const int c_N = __shfl(mN, sl);
+                const double c_mse = wave_lane(mg.mse, sl); const int c_N = wave_lane(mN, sl);
                 if (!f_have || f_mse > c_mse || (f_mse == c_mse && (double)f_N < c_mse)) { f_have = true; f_mse = c_mse; f_N = c_N; f_lane = sl; }   // quirk :1045
                 last_id = cid;
             }
             if (mine) { have = f_have; win = f_lane; min_m = f_mse; }
             oddm &= ~(lane_below(shp + scnt) & ~lane_below(shp));
+            w_nb = __shfl((int)r, win);
         }
+        PEAC_TICK(16);
         // the winner lane publishes the merged record; the segment's first lane the header
-        const int w_nb = __shfl((int)r, win);
         const double w_z = __shfl(mg.center[2], win);
-        const double w_mse = __shfl(mg.mse, win);
         if (active && have && lane == win) write_merged(nd, ms, mg);
         if (active && k == 0) {
             uint32_t* rr = rec(nd);
-            const bool mok = have && w_mse < T_mse_merge(w_z);                     // AHCPlaneFitter.hpp:1057
+            const bool mok = have && min_m < T_mse_merge(w_z);                     // AHCPlaneFitter.hpp:1057
             const int ownN = g_N[nd] / (WIN * WIN);
             rr[0] = (uint32_t)cnt | ((have ? 1u : 0u) | (mok ? 2u : 0u)) << 16;
             rr[1] = (uint32_t)(have ? w_nb : 0) | (uint32_t)ownN << 16;
-            *(double*)(rr + 4) = have ? w_mse : 0.0;
+            *(double*)(rr + 4) = have ? min_m : 0.0;
             atomicOr(&cval[nd >> 5], 1u << (nd & 31));
         }
         dbg_phases++; dbg_nodes += __popcll(heads & lane_below(total));
@@ -422,6 +437,7 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
         const int n2 = bitmap_prefix();
         bitmap_emit(bpool + off, false);
         gfence();
+        PEAC_TICK(19);
         bool have = false; double best_mse = 0; int best_nb = 0, best_N = 0;
         double best_stats[9]; Geo best_geo;
 #pragma unroll
@@ -433,7 +449,8 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
             const unsigned r = k0 + lane < n2 ? (unsigned)bpool[off + k0 + lane] : TOMB;
             double ms[9]; Geo mg; int mN;
             const bool ok = eval_pair(p, r, ms, mg, mN);
-            const unsigned long long okm = __ballot(ok);
+            PEAC_TICK(15);
+            const u64 okm = __ballot(ok);
             if (okm) {
                 double rm = ok ? mg.mse : 1.7976931348623157e308;
                 int rl = ok ? lane : 64;
@@ -442,18 +459,19 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
                     const double om = __shfl_xor(rm, o); const int ol = __shfl_xor(rl, o);
                     if (om < rm || (om == rm && ol < rl)) { rm = om; rl = ol; }
                 }
+                rl = wave_uni(rl);
                 const bool tie = __popcll(__ballot(ok && mg.mse == rm)) > 1 || __ballot(ok && mg.mse != mg.mse);
-                unsigned long long scan = tie ? okm : (1ull << rl);
+                u64 scan = tie ? okm : (1ull << rl);
                 while (scan) {   // lanes are in ascending id: this is the reference's scan
                     const int src = __ffsll((long long)scan) - 1;
                     scan &= scan - 1;
-                    const double c_mse = __shfl(mg.mse, src);
+                    const double c_mse = wave_lane(mg.mse, src);
                     if (!have || best_mse > c_mse || (best_mse == c_mse && (double)best_N < c_mse)) {   // quirk :1045
-                        have = true; best_mse = c_mse; best_nb = __shfl((int)r, src); best_N = __shfl(mN, src);
+                        have = true; best_mse = c_mse; best_nb = wave_lane((int)r, src); best_N = wave_lane(mN, src);
 #pragma unroll
-                        for (int t = 0; t < 9; t++) best_stats[t] = __shfl(ms[t], src);
+                        for (int t = 0; t < 9; t++) best_stats[t] = wave_lane(ms[t], src);
 #pragma unroll
-                        for (int t = 0; t < 3; t++) { best_geo.center[t] = __shfl(mg.center[t], src); best_geo.normal[t] = __shfl(mg.normal[t], src); }
+                        for (int t = 0; t < 3; t++) { best_geo.center[t] = wave_lane(mg.center[t], src); best_geo.normal[t] = wave_lane(mg.normal[t], src); }
                         best_geo.mse = c_mse;
                     }
                 }
@@ -476,11 +494,12 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
         const int b = b0 + lane;
         const bool in = b < NB && (g_flags[b] & 1);
         const double m = in ? geo_of(b)[6] : 0.0;
-        unsigned long long mask = __ballot(in);
+        const int c = in ? (int)(rec(b)[0] & 0xffffu) : 0;      // bag size (cnt8 shares its LDS with the heap)
+        u64 mask = __ballot(in);
         while (mask) {
             const int src = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            heap_push(b0 + src, __shfl(m, src));
+            heap_push(b0 + src, wave_lane(m, src), wave_lane(c, src));
         }
     }
     mark();
@@ -488,50 +507,55 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
     // ---- ahCluster (:983-1189) ----
     int step = 0;
     while (heap_n > 0 && step <= MAX_STEP && !err) {
-        long long c0 = PEAC_CYCLES();
-        const int p = heap_pop();
+        c0 = PEAC_CYCLES();
+        // the top of the heap is the node this iteration pops: its record is requested now and arrives while the heap is being repaired
+        const int p = e_id(hp[0]);
         const uint32_t* rp = rec(p);
-        uint32_t dw = rp[lane];                                   // dwords 0..63 of p's record, one per lane (issued before p is known to be alive)
+        uint32_t dw = rp[lane];                                   // dwords 0..63 of p's record, one per lane
         uint32_t dwt = lane < 4 ? rp[64 + lane] : 0u;             // dwords 64..67
-        cyc[0] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
-        if (mp[p] != p) continue;                                 // nouse (merged away earlier)
-        unsigned d0 = __builtin_amdgcn_readlane(dw, 0);
+        const bool dead_p = mp[p] != p;
+        PEAC_TICK(2);
+        heap_pop();
+        if (dead_p) continue;                                     // nouse (merged away earlier)
+        unsigned d0 = wave_lane(dw, 0);
+        PEAC_TICK(3);
         int n = (int)(d0 & 0xffffu);
         if (n > 0 && !((d0 >> 16) & 4u) && !is_valid(p)) {
             eval_phase(p, n);
             gfence();
             dw = rp[lane]; dwt = lane < 4 ? rp[64 + lane] : 0u;
-            d0 = __builtin_amdgcn_readlane(dw, 0);
-            cyc[4] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
+            d0 = wave_lane(dw, 0);
+            PEAC_TICK(17);
         } else if (n > 0 && ((d0 >> 16) & 4u)) {
-            eval_big(p, n, __builtin_amdgcn_readlane(dw, 3));
+            eval_big(p, n, wave_lane(dw, 3));
             gfence();
             dw = rp[lane]; dwt = lane < 4 ? rp[64 + lane] : 0u;
-            d0 = __builtin_amdgcn_readlane(dw, 0);
+            d0 = wave_lane(dw, 0);
             n = (int)(d0 & 0xffffu);
-            cyc[5] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
+            PEAC_TICK(18);
         } else dbg_hits++;
         const unsigned fl = n > 0 ? d0 >> 16 : 0u;
         const bool bigA = (fl & 4u) != 0;
-        const unsigned d1 = __builtin_amdgcn_readlane(dw, 1);
+        const unsigned d1 = wave_lane(dw, 1);
         const int N100p = (int)(d1 >> 16);
-        const unsigned offA = __builtin_amdgcn_readlane(dw, 3);
+        const unsigned offA = wave_lane(dw, 3);
         // bag entry `lane` of a record held one dword per lane (a shuffle: called by ALL lanes, whatever the bag's size)
         auto root_in = [&](uint32_t regs) -> unsigned { const uint32_t w = __shfl(regs, 6 + (lane >> 1)); return (lane & 1) ? (w >> 16) : (w & 0xffffu); };
         const unsigned rootA = root_in(dw);                         // p's entry: alive or TOMB (the record is valid)
         if (fl & 2u) {
             // ---------------- merge p with its best neighbour ----------------
             const int nb = (int)(d1 & 0xffffu);
-            const int ridp = (int)(__builtin_amdgcn_readlane(dw, 2) & 0xffffu);
+            const int ridp = (int)(wave_lane(dw, 2) & 0xffffu);
             const uint32_t* rq = rec(nb);
             const uint32_t ew = lane < 38 ? rq[lane] : 0u;          // the partner's header and bag
-            const unsigned e0 = __builtin_amdgcn_readlane(ew, 0), e1 = __builtin_amdgcn_readlane(ew, 1);
+            const unsigned e0 = wave_lane(ew, 0), e1 = wave_lane(ew, 1);
             const int nbn = (int)(e0 & 0xffffu);
             const bool bigB = ((e0 >> 16) & 4u) != 0;
             const int N100n = (int)(e1 >> 16);
-            const int ridn = (int)(__builtin_amdgcn_readlane(ew, 2) & 0xffffu);
-            const unsigned offB = __builtin_amdgcn_readlane(ew, 3);
+            const int ridn = (int)(wave_lane(ew, 2) & 0xffffu);
+            const unsigned offB = wave_lane(ew, 3);
             const unsigned rootB = root_in(ew);
+            PEAC_TICK(4);
             const int m = n_nodes++;
             if (m >= NB2) { err = 1; break; }
             int nm;
@@ -541,12 +565,14 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
                 // both bags in registers: set bits, prefix, every entry writes itself to its rank
                 unsigned ra = lane < n ? rootA : TOMB;
                 unsigned rb = chase(lane < nbn ? rootB : TOMB);
+                PEAC_TICK(5);
                 if (ra == (unsigned)nb || ra == (unsigned)p) ra = TOMB;
                 if (rb == (unsigned)p || rb == (unsigned)nb) rb = TOMB;
                 if (ra != TOMB) set_bit(ra);
                 if (rb != TOMB) set_bit(rb);
                 wfence();
                 nm = bitmap_prefix();
+                PEAC_TICK(6);
                 u16* dst;
                 if (nm <= 64) dst = roots_of(m);
                 else {
@@ -562,6 +588,7 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
                 if (ra != TOMB) bmp[ra >> 5] = 0;
                 if (rb != TOMB) bmp[rb >> 5] = 0;
                 wfence();
+                PEAC_TICK(7);
             } else {
                 // a bag in the pool on either side: chunks of 64 entries set their bits, the lanes that own bitmap words emit the result
                 for (int k0 = 0; k0 < n; k0 += 64) {
@@ -595,8 +622,8 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
                     dst = bpool + offM;
                 }
                 bitmap_emit(dst, true);
+                PEAC_TICK(8);
             }
-            cyc[2] += PEAC_CYCLES() - c0; c0 = PEAC_CYCLES();
             // node m: its moments / plane are the best merge of p's record (AHCPlaneSeg.hpp:301-315)
             {
                 uint32_t* gs = (uint32_t*)(g_stats + (size_t)m * 9);
@@ -611,11 +638,7 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
             const int ridm = N100p >= N100n ? ridp : ridn;
             if (lane == 0) {
                 g_N[m] = N100m * (WIN * WIN);
-                uint32_t* rm = rec(m);
-                rm[0] = (uint32_t)nm | (bigM ? 4u << 16 : 0u);
-                rm[1] = (uint32_t)N100m << 16;
-                rm[2] = (uint32_t)ridm;
-                rm[3] = offM;
+                *(uint4*)rec(m) = make_uint4((uint32_t)nm | (bigM ? 4u << 16 : 0u), (uint32_t)N100m << 16, (uint32_t)ridm, offM);
                 h_rid[m] = (u16)ridm;
                 // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:64-84): the rid of a live node is its set's root, so Find() returns its argument;
                 // union by size, size(root) * 100 == N of the live node whose rid it is
@@ -626,9 +649,9 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
                 mp[p] = (u16)m; mp[nb] = (u16)m;
             }
             wfence();
-            const double mse = __hiloint2double((int)__builtin_amdgcn_readlane(dw, 5), (int)__builtin_amdgcn_readlane(dw, 4));
-            heap_push(m, mse);
-            cyc[3] += PEAC_CYCLES() - c0;
+            PEAC_TICK(9);
+            heap_push(m, __hiloint2double((int)wave_lane(dw, 5), (int)wave_lane(dw, 4)), nm);
+            PEAC_TICK(10);
         } else {
             // ---------------- no merge: extract p if it is large enough, disconnect it (:1160-1170) ----------------
             if (N100p * (WIN * WIN) >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
@@ -639,12 +662,13 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
             }
             if (lane == 0) mp[p] = (u16)TOMB;
             wfence();
-            cyc[1] += PEAC_CYCLES() - c0;
+            PEAC_TICK(11);
         }
         ++step;
     }
     while (heap_n > 0 && !err) {                                   // only after MAX_STEP: the reference extracts what is left without looking at nouse
-        const int p = heap_pop();
+        const int p = e_id(hp[0]);
+        heap_pop();
         if (g_N[p] >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
         if (lane == 0 && mp[p] == p) mp[p] = (u16)TOMB;
         wfence();
@@ -665,7 +689,7 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
         unsigned* o_nouse = (unsigned*)(F + L.off_h_nouse); unsigned* o_cval = (unsigned*)(F + L.off_h_cval);
         for (int b0 = 0; b0 < NB2; b0 += 64) {
             const int id = b0 + lane;
-            const unsigned long long dead = __ballot(id < NB2 && mp[id] != id);
+            const u64 dead = __ballot(id < NB2 && mp[id] != id);
             if (lane == 0) { o_nouse[b0 >> 5] = (unsigned)dead; if ((b0 >> 5) + 1 < W32) o_nouse[(b0 >> 5) + 1] = (unsigned)(dead >> 32); }
         }
         for (int t = lane; t < W32; t += 64) o_cval[t] = 0;
@@ -674,11 +698,11 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
             g_hand[0] = n_ext; g_hand[1] = err; g_hand[2] = n_nodes;
             status[frame] = err;
             if (timing) {
-                for (int t = 0; t < 4; t++) timing[(size_t)frame * 16 + t] = t < nph ? tphase[t] - tphase[0] : 0;
-                timing[(size_t)frame * 16 + 9] = n_nodes;
-                timing[(size_t)frame * 16 + 7] = ((long long)dbg_phases << 40) | ((long long)dbg_nodes << 20) | dbg_hits;
-                timing[(size_t)frame * 16 + 8] = dbg_big;
-                for (int t = 0; t < 6; t++) timing[(size_t)frame * 16 + 10 + t] = cyc[t];
+                for (int t = 0; t < 4; t++) timing[(size_t)frame * TSLOTS + t] = t < nph ? tphase[t] - tphase[0] : 0;
+                timing[(size_t)frame * TSLOTS + 9] = n_nodes;
+                timing[(size_t)frame * TSLOTS + 7] = ((long long)dbg_phases << 40) | ((long long)dbg_nodes << 20) | dbg_hits;
+                timing[(size_t)frame * TSLOTS + 10] = dbg_big;
+                for (int t = 0; t < 24; t++) timing[(size_t)frame * TSLOTS + 16 + t] = cyc[t];
             }
         }
     }

@@ -12,8 +12,10 @@
 // counters are compiled in only with -DPLANAR_PEAC_TIMING; the eight phase marks (wall clock) are always recorded.
 #ifdef PLANAR_PEAC_TIMING
 #define PEAC_CYCLES() ((long long)clock64())
+#define PEAC_TICK(i) do { const long long t_ = (long long)clock64(); cyc[i] += t_ - c0; c0 = t_; } while (0)   // bucket i gets the cycles since the last tick
 #else
 #define PEAC_CYCLES() 0ll
+#define PEAC_TICK(i) do { } while (0)
 #endif
 
 namespace planar {
@@ -23,6 +25,7 @@ constexpr int WIN = 10;             // windowWidth == windowHeight (AHCPlaneFitt
 constexpr int MIN_SUPPORT = 3000;   // minSupport (:155)
 constexpr int MAX_PLANES = 128;
 constexpr int MAX_STEP = 100000;
+constexpr int TSLOTS = 48;         // int64 slots per frame of the timing record: [0..15] phase marks / counters, [16..47] cycle buckets of peac_ahc2 (-DPLANAR_PEAC_TIMING)
 
 // ---- thresholds (AHCParamSet.hpp) ----
 __device__ __forceinline__ double T_mse_init(double z) { const double t = 1.6e-6 * z * z + 5; return t * t; }

@@ -36,7 +36,7 @@ int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, f
             wave_emul::launch_block(blocks_entry, &ba, 64, bi, bd, 0);
         }
         int32_t status = -1; int next = 0;
-        long long timing[16] = {0};
+        long long timing[TSLOTS] = {0};
         AhcArgs aa{L, C, ws.data(), &status, timing, &next};
         wave_emul::Dim3 bi, bd; bd.x = 64; bd.y = 1; bd.z = 1;
         wave_emul::launch_block(ahc_entry, &aa, 64, bi, bd, (size_t)ahc2_smem_bytes(L));
@@ -55,7 +55,7 @@ int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, f
         memcpy(hand, g_hand, (4 + MAX_PLANES) * 4);
         memcpy(dsp, F + L.off_h_dsp, (size_t)L.NB * 2); memcpy(dss, F + L.off_h_dss, (size_t)L.NB * 2);
         memcpy(nouse, F + L.off_h_nouse, (size_t)((L.NB2 + 31) / 32) * 4);
-        if (stats_out) { stats_out[0] = status; stats_out[1] = wave_emul::S().n_sync; stats_out[2] = timing[7]; stats_out[3] = timing[8]; }
+        if (stats_out) { stats_out[0] = status; stats_out[1] = wave_emul::S().n_sync; stats_out[2] = timing[7]; stats_out[3] = timing[10]; }
         return 0;
     } catch (const std::exception& e) {
         snprintf(err, errlen, "%s", e.what());

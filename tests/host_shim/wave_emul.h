@@ -172,6 +172,21 @@ inline void launch_block(void (*fn)(void*), void* arg, int nthreads, Dim3 bidx, 
 
 }  // namespace wave_emul
 
+// ---- planarslam_amd/csrc/wave_ops.h for the emulator ----
+#define PLANAR_WAVE_EMUL 1
+namespace planar {
+inline int wave_uni(int v) { return ::wave_emul::shfl(900001, v, 0); }
+inline unsigned wave_uni(unsigned v) { return ::wave_emul::shfl(900002, v, 0); }
+inline int wave_lane(int v, int l) { return ::wave_emul::shfl(900003, v, l); }
+inline unsigned wave_lane(unsigned v, int l) { return ::wave_emul::shfl(900004, v, l); }
+inline double wave_lane(double v, int l) { return ::wave_emul::shfl(900005, v, l); }
+inline int wave_scan_add(int v) {
+    const int l = ::wave_emul::S().cur & 63;
+    for (int o = 1; o < 64; o <<= 1) { const int t = ::wave_emul::shfl(900010 + o, v, l - o >= 0 ? l - o : l); if (l >= o) v += t; }
+    return v;
+}
+}  // namespace planar
+
 // ---- the HIP device functions the kernels use ----
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
@@ -179,6 +194,10 @@ inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 inline double __hiloint2double(int hi, int lo) { const uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; memcpy(&d, &u, 8); return d; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+struct uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 inline long long wall_clock64() { return 0; }
 inline long long clock64() { return 0; }
 template <typename T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }

@@ -21,7 +21,7 @@ def run(kind):
     except Exception as e:   # capacity errors etc.
         res = None; err = e
     lay = np.zeros(12, np.int64); check(pd.L.planar_peac_debug_layout(pd.h, lay.ctypes.data))
-    t = np.zeros((B, 16), np.int64); check(pd.L.planar_peac_read_timing(pd.h, B, t.ctypes.data))
+    t = np.zeros((B, 48), np.int64); check(pd.L.planar_peac_read_timing(pd.h, B, t.ctypes.data))
     def rd(frame, off, n, dt):
         a = np.zeros(n, dt); check(pd.L.planar_peac_debug_read(pd.h, frame, int(off), a.nbytes, a.ctypes.data)); return a
     NB2 = int(lay[2])
@@ -62,5 +62,11 @@ for b in range(B):
 for name, t in (("legacy", ta), ("new", tb)):
     tot = t[:, 3] / 1e5
     print(f"{name}: clustering kernel per frame ms: " + " ".join("%.1f" % x for x in tot[:16]), "| graph %.2f heap %.2f" % (t[0, 1] / 1e5, (t[0, 2] - t[0, 1]) / 1e5),
-          "| phases %d nodes %d hits %d big %d" % (t[0, 7] >> 40, (t[0, 7] >> 20) & 0xfffff, t[0, 7] & 0xfffff, t[0, 8] if name == "new" else 0),
-          "| Mcyc " + " ".join("%.1f" % (x / 1e6) for x in t[0, 10:16]))
+          "| phases %d nodes %d hits %d big %d" % (t[0, 7] >> 40, (t[0, 7] >> 20) & 0xfffff, t[0, 7] & 0xfffff, t[0, 10] if name == "new" else 0))
+    if name == "new":
+        names = ["pop-sink", "pop-siftup", "issue+dead", "wait-rec", "partner", "chase", "bits+prefix", "rank+write", "big-union", "create", "push", "no-merge",
+                 "ev-select", "ev-roots", "ev-loads", "ev-eigen", "ev-fold", "ev-publish", "ev-big"]
+        for b in range(min(B, 2)):
+            print(f"  frame {b} Mcyc: " + "  ".join(f"{n} {t[b, 16 + i] / 1e6:.2f}" for i, n in enumerate(names)), "| sum %.1f" % (t[b, 16:40].sum() / 1e6))
+    else:
+        print("  Mcyc " + " ".join("%.1f" % (x / 1e6) for x in t[0, 10:16]))

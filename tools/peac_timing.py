@@ -7,7 +7,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 pd = PlaneDetection(640,480,max_batch=B)
 d = np.stack([depth_image(4321+i) for i in range(B)])
 res = pd.run(d)
-t = np.zeros((B,16), np.int64)
+t = np.zeros((B,48), np.int64)
 check(pd.L.planar_peac_read_timing(pd.h, B, t.ctypes.data))
 for b in range(min(B, 8)):
     ph = np.diff(t[b,:7])/100.0  # us (slot 7 carries the cooperative-ahCluster counters)
