@@ -1011,6 +1011,7 @@ struct planar_peac {
     peac::Layout L{};
     peac::Consts C{};
     int smem = 0, smem2 = 0;
+    bool exact_only = false;                                  // PLANAR_PEAC_AHC=exact: skip the fast attempt (tests / A-B runs)
     bool legacy_ahc = false;                                  // PLANAR_PEAC_AHC=legacy: the round-2 clustering kernel (eager neighbour lists), for A/B runs
     DevBuf d_ws, d_status, d_timing, d_next, d_order;
     int order_B = 0;                                          // batch size d_order was computed for (0: none yet)
@@ -1036,7 +1037,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     o->C = peac::make_consts();
     const peac::Layout& L = o->L;
     o->smem2 = peac::ahc2_smem_bytes(L);
-    { const char* e = getenv("PLANAR_PEAC_AHC"); o->legacy_ahc = e && !strcmp(e, "legacy"); }
+    { const char* e = getenv("PLANAR_PEAC_AHC"); o->legacy_ahc = e && !strcmp(e, "legacy"); o->exact_only = e && !strcmp(e, "exact"); }
     // peac_ahc (legacy): heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
     o->smem = L.NB * 4 + L.NB * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
@@ -1081,9 +1082,14 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
         hipLaunchKernelGGL(peac::peac_ahc, dim3(B), dim3(peac::NT_AHC), p->smem, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
                            p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(), p->d_timing.as<long long>(), p->d_next.as<int>(),
                            p->order_B == B ? p->d_order.as<int>() : nullptr);
-    else
+    else {
+        // the fast attempt (tournament queue), then the exact kernel for the frames it gave up on (bit-equal keys of two live nodes: degenerate input)
+        if (!p->exact_only)
+            hipLaunchKernelGGL(peac::peac_ahc3, dim3(B), dim3(64), p->smem2, st, p->L, p->C, p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(),
+                               p->d_timing.as<long long>(), p->d_next.as<int>(), p->order_B == B ? p->d_order.as<int>() : nullptr);
         hipLaunchKernelGGL(peac::peac_ahc2, dim3(B), dim3(64), p->smem2, st, p->L, p->C, p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(),
-                           p->d_timing.as<long long>(), p->d_next.as<int>(), p->order_B == B ? p->d_order.as<int>() : nullptr);
+                           p->d_timing.as<long long>(), p->d_next.as<int>(), p->order_B == B ? p->d_order.as<int>() : nullptr, p->exact_only ? 0 : 1);
+    }
     mark();
     hipLaunchKernelGGL(peac::peac_order, dim3((B + 255) / 256), dim3(256), 0, st, p->d_timing.as<long long>(), B, p->d_order.as<int>());
     mark();

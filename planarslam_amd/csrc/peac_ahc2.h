@@ -61,17 +61,25 @@ static inline int ahc2_smem_bytes(const Layout& L) {
 
 typedef unsigned long long u64;
 
-__global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
-                                                long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order) {
+constexpr int ST_RETRY = 100;              // status of a frame the fast kernel gave up on (exact FP64 tie between live nodes): peac_ahc2 redoes it
+constexpr unsigned K_EMPTY = 0x7f800000u;  // tournament queue: +inf, no node
+
+// FAST = false: the queue is libstdc++'s binary heap, restated exactly (layout, hence the pop order among EQUAL keys, is the reference's).
+// FAST = true:  as long as no two live nodes have bit-equal mse the pop order does not depend on the heap's layout at all - it is "smallest key
+//               first" - so the queue may be anything.  Here: K[id] (LDS) = key rounded to float, low 7 mantissa bits replaced by the node's bag
+//               size (a monotonic proxy of the FP64 key: proxy(a) < proxy(b) implies a < b; equal proxies are decided on the FP64 keys), +inf =
+//               absent.  Lane L keeps the minimum of column L = ids congruent L mod 64 in registers; top = DPP minimum over the 64 lanes; removing
+//               a node clears its slot and recomputes one column (one LDS round trip).  Nodes that die are removed at once, so there are no pops
+//               of dead nodes (the reference pops and skips ~2600 of them per 640x480 frame).  Wherever equal proxies meet (inside a column when
+//               it is recomputed, across columns at the top, at a push) the FP64 keys are compared, and bit-equal FP64 keys of two live nodes
+//               end the attempt with ST_RETRY: the launch of peac_ahc2 that follows redoes exactly those frames with the exact heap.
+template <bool FAST>
+__device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
+                                          long long* __restrict__ timing, const int frame) {
     PLANAR_DYN_SMEM(smem);
-    __shared__ int s_frame;
     __shared__ int s_ext[MAX_PLANES];
     __shared__ unsigned s_mark[64];
     const int lane = threadIdx.x;
-    // frames are taken from a start-order counter (longest first, see peac_order), not from the block index
-    if (lane == 0) { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
-    __syncthreads();
-    const int frame = s_frame;
     uint8_t* F = ws + (size_t)frame * L.frame_bytes;
     double* g_stats = (double*)(F + L.off_stats);
     double* g_geo = (double*)(F + L.off_geo);
@@ -234,6 +242,69 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
         PEAC_TICK(1);
     };
 
+
+    // ---- FAST: the tournament queue ----
+    unsigned* K = (unsigned*)smem;                            // [NB2] (the heap's LDS)
+    unsigned cm_v = K_EMPTY;                                  // this lane's column minimum: raw K value ...
+    int cm_id = -1;                                           // ... and node id
+    auto kproxy = [](unsigned v) -> float { return __uint_as_float(v & ~0x7fu); };
+    struct Pick { int id; double d; bool any, tie; };
+    auto pick_add = [&](Pick& P, int id) {                    // smallest FP64 key among nodes whose proxies are equal; bit-equal keys are a tie
+        const double d = geo_of(id)[6];
+        if (!P.any || d < P.d) { P.d = d; P.id = id; P.any = true; P.tie = false; }
+        else if (d == P.d) P.tie = true;
+    };
+    auto col_recompute = [&](int Lc) {                        // Lc wave-uniform
+        const int i1 = Lc + 64 * lane, i2 = i1 + 4096;
+        const unsigned v1 = i1 < NB2 ? K[i1] : K_EMPTY, v2 = i2 < NB2 ? K[i2] : K_EMPTY;
+        const float p1 = kproxy(v1), p2 = kproxy(v2);
+        const float mn = wave_min_f32(fminf(p1, p2));
+        int id = -1; unsigned v = K_EMPTY;
+        if (mn < 3.0e38f) {
+            const u64 e1 = __ballot(p1 == mn), e2 = __ballot(p2 == mn);
+            if (__popcll(e1) + __popcll(e2) == 1) {
+                const int j = e1 ? __ffsll((long long)e1) - 1 : __ffsll((long long)e2) - 1;
+                id = Lc + 64 * j + (e1 ? 0 : 4096);
+                v = e1 ? wave_lane(v1, j) : wave_lane(v2, j);
+            } else {
+                gfence();
+                Pick P{-1, 0.0, false, false};
+                for (u64 m = e1; m; m &= m - 1) pick_add(P, Lc + 64 * (__ffsll((long long)m) - 1));
+                for (u64 m = e2; m; m &= m - 1) pick_add(P, Lc + 64 * (__ffsll((long long)m) - 1) + 4096);
+                if (P.tie) err = ST_RETRY;
+                id = P.id; v = K[id];
+            }
+        }
+        if (lane == Lc) { cm_v = v; cm_id = id; }
+    };
+    auto pq_top = [&]() -> int {                              // the live node with the smallest key, -1: the queue is empty
+        const float pm = kproxy(cm_v);
+        const float mn = wave_min_f32(pm);
+        if (!(mn < 3.0e38f)) return -1;
+        const u64 eq = __ballot(pm == mn);
+        if (__popcll(eq) == 1) return wave_lane(cm_id, __ffsll((long long)eq) - 1);
+        gfence();
+        Pick P{-1, 0.0, false, false};
+        for (u64 m = eq; m; m &= m - 1) pick_add(P, wave_lane(cm_id, __ffsll((long long)m) - 1));
+        if (P.tie) err = ST_RETRY;
+        return P.id;
+    };
+    auto pq_remove = [&](int id) {                            // id wave-uniform; its column is recomputed when it was the column's minimum
+        if (lane == 0) K[id] = K_EMPTY;
+        wfence();
+        if (wave_lane(cm_id, id & 63) == id) col_recompute(id & 63);
+    };
+    auto pq_push = [&](int id, double mse, int cnt) {
+        if (!(mse < 3.0e38) || !(mse > -3.0e38)) err = ST_RETRY;   // NaN / infinite key: leave it to the exact kernel
+        const unsigned v = (__float_as_uint((float)mse) & ~0x7fu) | (unsigned)(cnt > 64 ? 127 : cnt);
+        if (lane == 0) K[id] = v;
+        wfence();
+        const int Lc = id & 63;
+        const float pn = kproxy(v), pc = kproxy(wave_lane(cm_v, Lc));
+        if (pn < pc) { if (lane == Lc) { cm_v = v; cm_id = id; } }
+        else if (pn == pc) col_recompute(Lc);
+    };
+
     // ---- what a bag entry stands for now: follow mp to the live node (or TOMB), halving the path on the way.  All 64 lanes call it together.
     auto chase = [&](unsigned x) -> unsigned {
         unsigned par = x == TOMB ? TOMB : (unsigned)mp[x];
@@ -341,9 +412,15 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
     // ---- evaluation phase for a popped node p with a small bag (cp entries) whose record is not valid: p and the live, not-yet-valid small
     //      nodes among the first 64 heap slots are packed into the 64 lanes (one lane per bag entry), resolved, evaluated and folded.
     auto eval_phase = [&](int p, int cp) {
-        const u64 he = lane < heap_n ? hp[lane] : 0ull;
-        const int hq = e_id(he), hc = e_cnt(he);
-        const bool cand = lane < heap_n && hc >= 1 && hc <= 64 && mp[hq] == hq && !is_valid(hq);
+        // lookahead candidates: the first 64 heap slots / the 64 column minima
+        int hq, hc;
+        bool cand;
+        if constexpr (FAST) { hq = cm_id; hc = (int)(cm_v & 0x7fu); cand = hq >= 0 && hc >= 1 && hc <= 64 && !is_valid(hq); }
+        else {
+            const u64 he = lane < heap_n ? hp[lane] : 0ull;
+            hq = e_id(he); hc = e_cnt(he);
+            cand = lane < heap_n && hc >= 1 && hc <= 64 && mp[hq] == hq && !is_valid(hq);
+        }
         const int v = cand ? hc : 0;
         const int incl = wave_scan_add(v);
         const bool sel = cand && cp + incl <= 64;             // the prefix is monotonic: the selected nodes are a prefix of the candidates
@@ -489,7 +566,27 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
         return n2;
     };
 
-    // ---- heap of the initial blocks, in block order (:809) ----
+    // ---- the queue of the initial blocks ----
+    if constexpr (FAST) {
+        for (int b = lane; b < NB2; b += 64) {
+            unsigned v = K_EMPTY;
+            if (b < NB && (g_flags[b] & 1)) v = (__float_as_uint((float)geo_of(b)[6]) & ~0x7fu) | (rec(b)[0] & 0x7fu);
+            K[b] = v;
+        }
+        wfence();
+        bool tie = false;
+        for (int i = lane; i < NB2; i += 64) {                 // every lane scans its own column
+            const unsigned v = K[i];
+            const float pv = kproxy(v), pc = kproxy(cm_v);
+            if (pv < pc) { cm_v = v; cm_id = i; }
+            else if (pv == pc && pv < 3.0e38f) {
+                const double a = geo_of(i)[6], b = geo_of(cm_id)[6];
+                if (a < b) { cm_v = v; cm_id = i; } else if (a == b) tie = true;
+            }
+        }
+        if (__ballot(tie)) err = ST_RETRY;
+    } else
+    // heap of the initial blocks, in block order (:809)
     for (int b0 = 0; b0 < NB; b0 += 64) {
         const int b = b0 + lane;
         const bool in = b < NB && (g_flags[b] & 1);
@@ -506,16 +603,19 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
 
     // ---- ahCluster (:983-1189) ----
     int step = 0;
-    while (heap_n > 0 && step <= MAX_STEP && !err) {
+    while (step <= MAX_STEP && !err) {
         c0 = PEAC_CYCLES();
-        // the top of the heap is the node this iteration pops: its record is requested now and arrives while the heap is being repaired
-        const int p = e_id(hp[0]);
+        // the node this iteration pops: its record is requested now and arrives while the queue is being repaired
+        int p;
+        if constexpr (FAST) { p = pq_top(); if (p < 0 || err) break; }
+        else { if (heap_n <= 0) break; p = e_id(hp[0]); }
         const uint32_t* rp = rec(p);
         uint32_t dw = rp[lane];                                   // dwords 0..63 of p's record, one per lane
         uint32_t dwt = lane < 4 ? rp[64 + lane] : 0u;             // dwords 64..67
-        const bool dead_p = mp[p] != p;
+        bool dead_p = false;
+        if constexpr (!FAST) dead_p = mp[p] != p;
         PEAC_TICK(2);
-        heap_pop();
+        if constexpr (FAST) { pq_remove(p); PEAC_TICK(0); } else heap_pop();
         if (dead_p) continue;                                     // nouse (merged away earlier)
         unsigned d0 = wave_lane(dw, 0);
         PEAC_TICK(3);
@@ -548,6 +648,7 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
             const int ridp = (int)(wave_lane(dw, 2) & 0xffffu);
             const uint32_t* rq = rec(nb);
             const uint32_t ew = lane < 38 ? rq[lane] : 0u;          // the partner's header and bag
+            if constexpr (FAST) { pq_remove(nb); PEAC_TICK(1); }  // nb dies with this merge (behind the load's latency)
             const unsigned e0 = wave_lane(ew, 0), e1 = wave_lane(ew, 1);
             const int nbn = (int)(e0 & 0xffffu);
             const bool bigB = ((e0 >> 16) & 4u) != 0;
@@ -650,7 +751,8 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
             }
             wfence();
             PEAC_TICK(9);
-            heap_push(m, __hiloint2double((int)wave_lane(dw, 5), (int)wave_lane(dw, 4)), nm);
+            if constexpr (FAST) pq_push(m, __hiloint2double((int)wave_lane(dw, 5), (int)wave_lane(dw, 4)), nm);
+            else heap_push(m, __hiloint2double((int)wave_lane(dw, 5), (int)wave_lane(dw, 4)), nm);
             PEAC_TICK(10);
         } else {
             // ---------------- no merge: extract p if it is large enough, disconnect it (:1160-1170) ----------------
@@ -666,7 +768,8 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
         }
         ++step;
     }
-    while (heap_n > 0 && !err) {                                   // only after MAX_STEP: the reference extracts what is left without looking at nouse
+    if constexpr (FAST) { if (!err && step > MAX_STEP) err = ST_RETRY; }   // maxStep reached (never for NB <= 3072): the exact kernel knows what to do
+    while (!FAST && heap_n > 0 && !err) {                          // only after MAX_STEP: the reference extracts what is left without looking at nouse
         const int p = e_id(hp[0]);
         heap_pop();
         if (g_N[p] >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
@@ -706,6 +809,27 @@ __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __r
             }
         }
     }
+}
+
+// The fast attempt: every frame of the batch, taken from a start-order counter (longest first, see peac_order), not from the block index.
+__global__ __launch_bounds__(64) void peac_ahc3(Layout L, Consts C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
+                                                long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order) {
+    __shared__ int s_frame;
+    if (threadIdx.x == 0) { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
+    __syncthreads();
+    ahc_frame<true>(L, C, ws, status, timing, s_frame);
+}
+// The exact kernel.  only_retry != 0: workgroup b redoes frame b if the fast attempt left ST_RETRY there and exits at once otherwise.
+__global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
+                                                long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order, int only_retry) {
+    __shared__ int s_frame;
+    if (threadIdx.x == 0) {
+        if (only_retry) s_frame = status[blockIdx.x] == ST_RETRY ? (int)blockIdx.x : -1;
+        else { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
+    }
+    __syncthreads();
+    if (s_frame < 0) return;
+    ahc_frame<false>(L, C, ws, status, timing, s_frame);
 }
 
 }  // namespace peac

@@ -13,7 +13,8 @@ namespace {
 struct BlocksArgs { Layout L; Intr K; const uint16_t* depth; int pitch; int64_t stride; uint8_t* ws; };
 void blocks_entry(void* a) { auto* A = (BlocksArgs*)a; peac_blocks(A->L, A->K, A->depth, A->pitch, A->stride, A->ws); }
 struct AhcArgs { Layout L; Consts C; uint8_t* ws; int32_t* status; long long* timing; int* next; };
-void ahc_entry(void* a) { auto* A = (AhcArgs*)a; peac_ahc2(A->L, A->C, A->ws, A->status, A->timing, A->next, nullptr); }
+void ahc_exact_entry(void* a) { auto* A = (AhcArgs*)a; peac_ahc2(A->L, A->C, A->ws, A->status, A->timing, A->next, nullptr, 0); }
+void ahc_fast_entry(void* a) { auto* A = (AhcArgs*)a; peac_ahc3(A->L, A->C, A->ws, A->status, A->timing, A->next, nullptr); }
 }  // namespace
 
 extern "C" {
@@ -21,7 +22,9 @@ extern "C" {
 // stats[9]; hand [4 + 128] = n_ext, err, n_nodes, -, extracted ids; dsp / dss [NB] as the kernel leaves them; nouse [(NB2 + 31) / 32].
 // Returns 0, or -1 with a message in err.
 int peac_emul_dims(int W, int H, int* NB, int* NB2) { const Layout L = make_layout(W, H); *NB = L.NB; *NB2 = L.NB2; return 0; }
-int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, float cx, float cy, float factor, double* nodes, int32_t* hand,
+// mode 0: what the library does (the fast kernel, then the exact kernel if it left ST_RETRY); 1: exact kernel only; 2: fast kernel only.
+// stats_out: [0] status, [1] rendezvous count, [2] phases << 40 | nodes evaluated << 20 | valid-record pops, [3] pops of pool bags, [4] 1 if the fast kernel gave up
+int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, float cx, float cy, float factor, int mode, double* nodes, int32_t* hand,
                       uint16_t* dsp, uint16_t* dss, uint32_t* nouse, int64_t* stats_out, char* err, int errlen) {
     try {
         const Layout L = make_layout(W, H);
@@ -39,7 +42,12 @@ int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, f
         long long timing[TSLOTS] = {0};
         AhcArgs aa{L, C, ws.data(), &status, timing, &next};
         wave_emul::Dim3 bi, bd; bd.x = 64; bd.y = 1; bd.z = 1;
-        wave_emul::launch_block(ahc_entry, &aa, 64, bi, bd, (size_t)ahc2_smem_bytes(L));
+        bool retried = false;
+        if (mode != 1) {
+            wave_emul::launch_block(ahc_fast_entry, &aa, 64, bi, bd, (size_t)ahc2_smem_bytes(L));
+            retried = status == ST_RETRY;
+        }
+        if (mode == 1 || (mode == 0 && retried)) { next = 0; wave_emul::launch_block(ahc_exact_entry, &aa, 64, bi, bd, (size_t)ahc2_smem_bytes(L)); }
         const uint8_t* F = ws.data();
         const double* st = (const double*)(F + L.off_stats); const double* ge = (const double*)(F + L.off_geo);
         const int* N = (const int*)(F + L.off_N); const uint16_t* rid = (const uint16_t*)(F + L.off_h_rid);
@@ -55,7 +63,7 @@ int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, f
         memcpy(hand, g_hand, (4 + MAX_PLANES) * 4);
         memcpy(dsp, F + L.off_h_dsp, (size_t)L.NB * 2); memcpy(dss, F + L.off_h_dss, (size_t)L.NB * 2);
         memcpy(nouse, F + L.off_h_nouse, (size_t)((L.NB2 + 31) / 32) * 4);
-        if (stats_out) { stats_out[0] = status; stats_out[1] = wave_emul::S().n_sync; stats_out[2] = timing[7]; stats_out[3] = timing[10]; }
+        if (stats_out) { stats_out[0] = status; stats_out[1] = wave_emul::S().n_sync; stats_out[2] = timing[7]; stats_out[3] = timing[10]; stats_out[4] = retried; }
         return 0;
     } catch (const std::exception& e) {
         snprintf(err, errlen, "%s", e.what());

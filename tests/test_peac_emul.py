@@ -28,22 +28,22 @@ def libs():
     import oracle_lib as ol
     O = ol.lib() if hasattr(ol, "lib") else C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
     vp = C.c_void_p
-    E.peac_emul_cluster.argtypes = [vp, C.c_int, C.c_int] + [C.c_float] * 5 + [vp] * 7 + [C.c_int]
+    E.peac_emul_cluster.argtypes = [vp, C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_int] + [vp] * 7 + [C.c_int]
     O.orc_peac_cluster_state.argtypes = [vp, C.c_int, C.c_int] + [C.c_float] * 5 + [vp, C.c_int, vp, vp, vp, vp]
     O.orc_peac_cluster_state.restype = C.c_int
     return E, O
 
 
-def _run(libs, d):
+def _run(libs, d, mode=0):
     E, O = libs
     H, W = d.shape
     NB, NB2 = C.c_int(), C.c_int()
     E.peac_emul_dims(W, H, C.byref(NB), C.byref(NB2))
     NB, NB2 = NB.value, NB2.value
     nodes = np.zeros((NB2, 18)); hand = np.zeros(132, np.int32); dsp = np.zeros(NB, np.uint16); dss = np.zeros(NB, np.uint16)
-    nouse = np.zeros((NB2 + 31) // 32, np.uint32); st = np.zeros(4, np.int64)
+    nouse = np.zeros((NB2 + 31) // 32, np.uint32); st = np.zeros(8, np.int64)
     err = C.create_string_buffer(512)
-    rc = E.peac_emul_cluster(d.ctypes.data, W, H, *K, nodes.ctypes.data, hand.ctypes.data, dsp.ctypes.data, dss.ctypes.data, nouse.ctypes.data, st.ctypes.data, err, 512)
+    rc = E.peac_emul_cluster(d.ctypes.data, W, H, *K, mode, nodes.ctypes.data, hand.ctypes.data, dsp.ctypes.data, dss.ctypes.data, nouse.ctypes.data, st.ctypes.data, err, 512)
     assert rc == 0, err.value.decode()
     onodes = np.zeros((NB2, 18)); oext = np.zeros(4096, np.int32); onext = C.c_int(); oroot = np.zeros(NB, np.int32); osize = np.zeros(NB, np.int32)
     n = O.orc_peac_cluster_state(d.ctypes.data, W, H, *K, onodes.ctypes.data, NB2, oext.ctypes.data, C.byref(onext), oroot.ctypes.data, osize.ctypes.data)
@@ -62,14 +62,24 @@ def _run(libs, d):
     assert np.array_equal(roots, oroot) and np.array_equal(dss[roots], osize), "DisjointSet partition differs"
     dead = np.array([(nouse[i >> 5] >> (i & 31)) & 1 for i in range(n)], bool)
     assert dead[live].all(), "a node of the graph is still marked alive after the clustering"
-    return dict(phases=int(st[2] >> 40), evaluated=int((st[2] >> 20) & 0xFFFFF), hits=int(st[2] & 0xFFFFF), big=int(st[3]), nodes=int(n), planes=int(hand[0]))
+    return dict(retried=bool(st[4]), phases=int(st[2] >> 40), evaluated=int((st[2] >> 20) & 0xFFFFF), hits=int(st[2] & 0xFFFFF), big=int(st[3]), nodes=int(n), planes=int(hand[0]))
 
 
 @pytest.mark.parametrize("w,h,seed,noise,holes", [(160, 120, 5, True, True), (320, 240, 77, True, True), (320, 240, 78, False, True), (640, 480, 4321, True, True),
                                                   (640, 480, 51, False, False)])
 def test_emulated_kernel_matches_oracle(libs, w, h, seed, noise, holes):
-    info = _run(libs, depth_image(seed, w, h, noise=noise, holes=holes))
+    d = depth_image(seed, w, h, noise=noise, holes=holes)
+    info = _run(libs, d)                                  # the library's flow: fast kernel (tournament queue), exact kernel if it gave up
     assert info["nodes"] > (w // 10) * (h // 10)          # something was merged
+    if w <= 320:
+        _run(libs, d, mode=1)                             # the exact-heap kernel alone
+
+
+def test_fast_kernel_alone_handles_generic_frames(libs):
+    """noisy depth has no bit-equal mse values: the fast kernel must finish on its own (mode 2 does not fall back)"""
+    for seed in (5, 6, 7):
+        info = _run(libs, depth_image(seed, 320, 240), mode=2)
+        assert not info["retried"]
 
 
 def test_emulated_kernel_edge_cases(libs):
@@ -77,7 +87,7 @@ def test_emulated_kernel_edge_cases(libs):
     assert _run(libs, z)["planes"] == 0                   # no valid block at all
     flat = np.full((240, 320), 10000, np.uint16)
     info = _run(libs, flat)                               # one fronto-parallel wall: exact mse ties all over the heap, one region with a long boundary
-    assert info["planes"] == 1
+    assert info["planes"] == 1 and info["retried"]        # bit-equal keys: the fast kernel hands the frame to the exact one
     ramp = (6000 + 9 * np.arange(320)[None, :] + np.zeros((240, 1))).astype(np.uint16)
     assert _run(libs, ramp)["planes"] == 1
 

@@ -64,7 +64,7 @@ for name, t in (("legacy", ta), ("new", tb)):
     print(f"{name}: clustering kernel per frame ms: " + " ".join("%.1f" % x for x in tot[:16]), "| graph %.2f heap %.2f" % (t[0, 1] / 1e5, (t[0, 2] - t[0, 1]) / 1e5),
           "| phases %d nodes %d hits %d big %d" % (t[0, 7] >> 40, (t[0, 7] >> 20) & 0xfffff, t[0, 7] & 0xfffff, t[0, 10] if name == "new" else 0))
     if name == "new":
-        names = ["pop-sink", "pop-siftup", "issue+dead", "wait-rec", "partner", "chase", "bits+prefix", "rank+write", "big-union", "create", "push", "no-merge",
+        names = ["q-pop", "q-kill/siftup", "issue+dead", "wait-rec", "partner", "chase", "bits+prefix", "rank+write", "big-union", "create", "push", "no-merge",
                  "ev-select", "ev-roots", "ev-loads", "ev-eigen", "ev-fold", "ev-publish", "ev-big"]
         for b in range(min(B, 2)):
             print(f"  frame {b} Mcyc: " + "  ".join(f"{n} {t[b, 16 + i] / 1e6:.2f}" for i, n in enumerate(names)), "| sum %.1f" % (t[b, 16:40].sum() / 1e6))
