@@ -39,6 +39,11 @@ namespace planar {
 namespace peac {
 
 constexpr unsigned TOMB = 0xFFFFu;
+// Single-wavefront code: the LDS traffic of one wavefront is processed in program order, so lanes only need the compiler to keep that order
+// (wavefront-scope fence, no s_waitcnt).  GFENCE additionally waits for the wavefront's global stores (workgroup scope): used where lanes read
+// global memory other lanes have just written.  Macros, so that the host emulator's divergence check sees the call site.
+#define WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define GFENCE() __threadfence_block()
 
 __device__ __forceinline__ void stats_compute_u(const double s[9], int N, Geo& g) {   // PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:125-156), wavefront eigen-solver
     const double sc = 1.0 / N;
@@ -102,8 +107,6 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
     int nph = 0;
     auto mark = [&]() { if (nph < 4) tphase[nph++] = (long long)wall_clock64(); };
     mark();
-    auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    auto gfence = [&]() { __threadfence_block(); };
     auto rec = [&](int id) -> uint32_t* { return crec + (size_t)id * CREC_DW; };
     auto roots_of = [&](int id) -> u16* { return (u16*)(rec(id) + 6); };
     auto geo_of = [&](int id) -> double* { return g_geo + (size_t)id * 7; };
@@ -187,7 +190,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
         const float K = e_key(E);
         bool less = isanc && mf < K;
         if (__ballot(isanc && mf == K)) {
-            gfence();
+            GFENCE();
             const double dv = geo_of(e_id(ent))[6];
             if (isanc && mf == K) less = dv < geo_of(e_id(E))[6];
         }
@@ -195,7 +198,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
         const int n = __builtin_ctzll(~up);
         if (lane >= 1 && lane <= n) hp[((hole + 1) >> (lane - 1)) - 1] = E;
         if (lane == 0) hp[((hole + 1) >> n) - 1] = ent;
-        wfence();
+        WFENCE();
     };
     auto heap_push = [&](int id, double mse, int cnt) { heap_n++; heap_sift_up(heap_n - 1, e_make((float)mse, id, cnt)); };
     // pop_heap = __adjust_heap(first, 0, len, last value): the hole sinks to the bottom along the smaller child (no early exit), then the value
@@ -215,7 +218,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             if (inner) { el = hp[2 * g + 1]; er = hp[2 * g + 2]; }
             const float kl = e_key(el), kr = e_key(er);
             bool lt = inner && kl < kr;
-            if (__ballot(inner && kl == kr)) { gfence(); if (inner && kl == kr) lt = geo_of(e_id(el))[6] < geo_of(e_id(er))[6]; }
+            if (__ballot(inner && kl == kr)) { GFENCE(); if (inner && kl == kr) lt = geo_of(e_id(el))[6] < geo_of(e_id(er))[6]; }
             const u64 two = __ballot(inner);
             const u64 takel = __ballot(lt);
             int cur = 1;
@@ -230,13 +233,13 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             const int dc = 31 - __clz(cur);
             hole = (hole << dc) + cur - 1;
         }
-        wfence();
+        WFENCE();
         PEAC_TICK(0);
         if ((len & 1) == 0 && hole == (len - 2) / 2) {
             const int c = 2 * hole + 1;
             const u64 ce = hp[c];
             if (lane == 0) hp[hole] = ce;
-            wfence(); hole = c;
+            WFENCE(); hole = c;
         }
         heap_sift_up(hole, vlast);
         PEAC_TICK(1);
@@ -245,6 +248,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
 
     // ---- FAST: the tournament queue ----
     unsigned* K = (unsigned*)smem;                            // [NB2] (the heap's LDS)
+    float top_key = 0.f, la_margin = 0.5f;                    // proxy key of the node being popped; lookahead margin (eval_phase)
     unsigned cm_v = K_EMPTY;                                  // this lane's column minimum: raw K value ...
     int cm_id = -1;                                           // ... and node id
     auto kproxy = [](unsigned v) -> float { return __uint_as_float(v & ~0x7fu); };
@@ -267,7 +271,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                 id = Lc + 64 * j + (e1 ? 0 : 4096);
                 v = e1 ? wave_lane(v1, j) : wave_lane(v2, j);
             } else {
-                gfence();
+                GFENCE();
                 Pick P{-1, 0.0, false, false};
                 for (u64 m = e1; m; m &= m - 1) pick_add(P, Lc + 64 * (__ffsll((long long)m) - 1));
                 for (u64 m = e2; m; m &= m - 1) pick_add(P, Lc + 64 * (__ffsll((long long)m) - 1) + 4096);
@@ -281,9 +285,10 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
         const float pm = kproxy(cm_v);
         const float mn = wave_min_f32(pm);
         if (!(mn < 3.0e38f)) return -1;
+        top_key = mn;
         const u64 eq = __ballot(pm == mn);
         if (__popcll(eq) == 1) return wave_lane(cm_id, __ffsll((long long)eq) - 1);
-        gfence();
+        GFENCE();
         Pick P{-1, 0.0, false, false};
         for (u64 m = eq; m; m &= m - 1) pick_add(P, wave_lane(cm_id, __ffsll((long long)m) - 1));
         if (P.tie) err = ST_RETRY;
@@ -291,14 +296,14 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
     };
     auto pq_remove = [&](int id) {                            // id wave-uniform; its column is recomputed when it was the column's minimum
         if (lane == 0) K[id] = K_EMPTY;
-        wfence();
+        WFENCE();
         if (wave_lane(cm_id, id & 63) == id) col_recompute(id & 63);
     };
     auto pq_push = [&](int id, double mse, int cnt) {
         if (!(mse < 3.0e38) || !(mse > -3.0e38)) err = ST_RETRY;   // NaN / infinite key: leave it to the exact kernel
         const unsigned v = (__float_as_uint((float)mse) & ~0x7fu) | (unsigned)(cnt > 64 ? 127 : cnt);
         if (lane == 0) K[id] = v;
-        wfence();
+        WFENCE();
         const int Lc = id & 63;
         const float pn = kproxy(v), pc = kproxy(wave_lane(cm_v, Lc));
         if (pn < pc) { if (lane == Lc) { cm_v = v; cm_id = id; } }
@@ -338,7 +343,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
         if (3 * lane < W32) pre[3 * lane] = (u16)ex;
         if (3 * lane + 1 < W32) pre[3 * lane + 1] = (u16)(ex + c[0]);
         if (3 * lane + 2 < W32) pre[3 * lane + 2] = (u16)(ex + c[0] + c[1]);
-        wfence();
+        WFENCE();
         return wave_lane(incl, 63);
     };
     // the lanes that own bitmap words write their set bits, ascending, to dst[ex ...] and clear the words; with_inval: the ids' valid bits are cleared
@@ -356,7 +361,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             }
             if (bw[k]) bmp[3 * lane + k] = 0;
         }
-        wfence();
+        WFENCE();
     };
     auto set_bit = [&](unsigned id) { atomicOr(&bmp[id >> 5], 1u << (id & 31)); };
 
@@ -421,16 +426,30 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             hq = e_id(he); hc = e_cnt(he);
             cand = lane < heap_n && hc >= 1 && hc <= 64 && mp[hq] == hq && !is_valid(hq);
         }
+        if constexpr (FAST) {
+            // The column minima are not the 64 smallest keys; evaluating a node long before it pops is wasted when a neighbour dies in between.
+            // Only minima within a margin above the popped node's key are taken: the margin tunes itself towards ~16 candidates per phase
+            // (the choice affects nothing but the number of phases).
+            const float kp = kproxy(cm_v), span = fabsf(top_key) + 1e-20f;
+            bool c2 = cand;
+            for (int it = 0; it < 4; it++) {
+                c2 = cand && kp <= top_key + la_margin * span;
+                const int nc = __popcll(__ballot(c2));
+                if (nc < 5) la_margin *= 1.6f; else if (nc > 10) la_margin *= 0.7f; else break;
+            }
+            cand = c2;
+        }
         const int v = cand ? hc : 0;
         const int incl = wave_scan_add(v);
         const bool sel = cand && cp + incl <= 64;             // the prefix is monotonic: the selected nodes are a prefix of the candidates
         const u64 selm = __ballot(sel);
         const int total = cp + (selm ? wave_lane(incl, 63 - __builtin_clzll(selm | 1ull)) : 0);
+        const int mypos = cp + incl - v;
         // segment heads: node | bag size << 16 | 1 << 31 at the segment's first lane; the popped node's segment starts at lane 0
         s_mark[lane] = lane == 0 ? ((unsigned)p | (unsigned)cp << 16 | 0x80000000u) : 0u;
-        wfence();
-        if (sel) s_mark[cp + incl - v] = (unsigned)hq | (unsigned)hc << 16 | 0x80000000u;
-        wfence();
+        WFENCE();
+        if (sel) s_mark[mypos] = (unsigned)hq | (unsigned)hc << 16 | 0x80000000u;
+        WFENCE();
         const unsigned mk = s_mark[lane];
         const u64 heads = __ballot(mk != 0);
         const int hpos = 63 - __builtin_clzll(heads & (lane_below(lane) | (1ull << lane)));   // my segment's first lane
@@ -510,10 +529,10 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             const unsigned r = chase(e);
             if (r != TOMB) set_bit(r);
         }
-        wfence();
+        WFENCE();
         const int n2 = bitmap_prefix();
         bitmap_emit(bpool + off, false);
-        gfence();
+        GFENCE();
         PEAC_TICK(19);
         bool have = false; double best_mse = 0; int best_nb = 0, best_N = 0;
         double best_stats[9]; Geo best_geo;
@@ -573,7 +592,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             if (b < NB && (g_flags[b] & 1)) v = (__float_as_uint((float)geo_of(b)[6]) & ~0x7fu) | (rec(b)[0] & 0x7fu);
             K[b] = v;
         }
-        wfence();
+        WFENCE();
         bool tie = false;
         for (int i = lane; i < NB2; i += 64) {                 // every lane scans its own column
             const unsigned v = K[i];
@@ -602,6 +621,17 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
     mark();
 
     // ---- ahCluster (:983-1189) ----
+    // A record is read the way it is used: the header as wave-uniform loads (every lane the same address: the values land in SGPRs without
+    // shuffles), bag entry `lane` and dword `lane` of the best merge per lane.
+    struct RecView { uint4 h; double mse; unsigned root; uint32_t mw; };
+    auto load_rec = [&](const uint32_t* rp) -> RecView {
+        RecView r;
+        r.h = *(const uint4*)rp;                               // d0..d3
+        r.mse = *(const double*)(rp + 4);                      // d4, d5
+        r.root = ((const u16*)(rp + 6))[lane];                 // bag entry `lane` (the bag area holds 64 entries)
+        r.mw = lane < 30 ? rp[38 + lane] : 0u;                 // moments / centre / normal of the best merge, one dword per lane
+        return r;
+    };
     int step = 0;
     while (step <= MAX_STEP && !err) {
         c0 = PEAC_CYCLES();
@@ -610,52 +640,45 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
         if constexpr (FAST) { p = pq_top(); if (p < 0 || err) break; }
         else { if (heap_n <= 0) break; p = e_id(hp[0]); }
         const uint32_t* rp = rec(p);
-        uint32_t dw = rp[lane];                                   // dwords 0..63 of p's record, one per lane
-        uint32_t dwt = lane < 4 ? rp[64 + lane] : 0u;             // dwords 64..67
+        RecView A = load_rec(rp);
         bool dead_p = false;
         if constexpr (!FAST) dead_p = mp[p] != p;
+        WFENCE();                                                 // every lane has looked at mp[p] before lane 0 may change it below
         PEAC_TICK(2);
         if constexpr (FAST) { pq_remove(p); PEAC_TICK(0); } else heap_pop();
         if (dead_p) continue;                                     // nouse (merged away earlier)
-        unsigned d0 = wave_lane(dw, 0);
+        int n = (int)(A.h.x & 0xffffu);
         PEAC_TICK(3);
-        int n = (int)(d0 & 0xffffu);
-        if (n > 0 && !((d0 >> 16) & 4u) && !is_valid(p)) {
+        if (n > 0 && !((A.h.x >> 16) & 4u) && !is_valid(p)) {
             eval_phase(p, n);
-            gfence();
-            dw = rp[lane]; dwt = lane < 4 ? rp[64 + lane] : 0u;
-            d0 = wave_lane(dw, 0);
+            GFENCE();
+            A = load_rec(rp);
             PEAC_TICK(17);
-        } else if (n > 0 && ((d0 >> 16) & 4u)) {
-            eval_big(p, n, wave_lane(dw, 3));
-            gfence();
-            dw = rp[lane]; dwt = lane < 4 ? rp[64 + lane] : 0u;
-            d0 = wave_lane(dw, 0);
-            n = (int)(d0 & 0xffffu);
+        } else if (n > 0 && ((A.h.x >> 16) & 4u)) {
+            eval_big(p, n, A.h.w);
+            GFENCE();
+            A = load_rec(rp);
+            n = (int)(A.h.x & 0xffffu);
             PEAC_TICK(18);
         } else dbg_hits++;
-        const unsigned fl = n > 0 ? d0 >> 16 : 0u;
+        const unsigned fl = n > 0 ? A.h.x >> 16 : 0u;
         const bool bigA = (fl & 4u) != 0;
-        const unsigned d1 = wave_lane(dw, 1);
-        const int N100p = (int)(d1 >> 16);
-        const unsigned offA = wave_lane(dw, 3);
-        // bag entry `lane` of a record held one dword per lane (a shuffle: called by ALL lanes, whatever the bag's size)
-        auto root_in = [&](uint32_t regs) -> unsigned { const uint32_t w = __shfl(regs, 6 + (lane >> 1)); return (lane & 1) ? (w >> 16) : (w & 0xffffu); };
-        const unsigned rootA = root_in(dw);                         // p's entry: alive or TOMB (the record is valid)
+        const int N100p = (int)(A.h.y >> 16);
+        const unsigned offA = A.h.w;
+        const unsigned rootA = A.root;                              // p's entry: alive or TOMB (the record is valid)
         if (fl & 2u) {
             // ---------------- merge p with its best neighbour ----------------
-            const int nb = (int)(d1 & 0xffffu);
-            const int ridp = (int)(wave_lane(dw, 2) & 0xffffu);
+            const int nb = (int)(A.h.y & 0xffffu);
+            const int ridp = (int)(A.h.z & 0xffffu);
             const uint32_t* rq = rec(nb);
-            const uint32_t ew = lane < 38 ? rq[lane] : 0u;          // the partner's header and bag
-            if constexpr (FAST) { pq_remove(nb); PEAC_TICK(1); }  // nb dies with this merge (behind the load's latency)
-            const unsigned e0 = wave_lane(ew, 0), e1 = wave_lane(ew, 1);
-            const int nbn = (int)(e0 & 0xffffu);
-            const bool bigB = ((e0 >> 16) & 4u) != 0;
-            const int N100n = (int)(e1 >> 16);
-            const int ridn = (int)(wave_lane(ew, 2) & 0xffffu);
-            const unsigned offB = wave_lane(ew, 3);
-            const unsigned rootB = root_in(ew);
+            const uint4 hB = *(const uint4*)rq;                     // the partner's header ...
+            const unsigned rootB = ((const u16*)(rq + 6))[lane];    // ... and bag
+            if constexpr (FAST) { pq_remove(nb); PEAC_TICK(1); }    // nb dies with this merge (behind the load's latency)
+            const int nbn = (int)(hB.x & 0xffffu);
+            const bool bigB = ((hB.x >> 16) & 4u) != 0;
+            const int N100n = (int)(hB.y >> 16);
+            const int ridn = (int)(hB.z & 0xffffu);
+            const unsigned offB = hB.w;
             PEAC_TICK(4);
             const int m = n_nodes++;
             if (m >= NB2) { err = 1; break; }
@@ -671,7 +694,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                 if (rb == (unsigned)p || rb == (unsigned)nb) rb = TOMB;
                 if (ra != TOMB) set_bit(ra);
                 if (rb != TOMB) set_bit(rb);
-                wfence();
+                WFENCE();
                 nm = bitmap_prefix();
                 PEAC_TICK(6);
                 u16* dst;
@@ -685,10 +708,10 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                 }
                 if (ra != TOMB) { const unsigned w = ra >> 5; dst[pre[w] + __popc(bmp[w] & ((1u << (ra & 31)) - 1u))] = (u16)ra; inval(ra); }
                 if (rb != TOMB) { const unsigned w = rb >> 5; dst[pre[w] + __popc(bmp[w] & ((1u << (rb & 31)) - 1u))] = (u16)rb; inval(rb); }
-                wfence();
+                WFENCE();
                 if (ra != TOMB) bmp[ra >> 5] = 0;
                 if (rb != TOMB) bmp[rb >> 5] = 0;
-                wfence();
+                WFENCE();
                 PEAC_TICK(7);
             } else {
                 // a bag in the pool on either side: chunks of 64 entries set their bits, the lanes that own bitmap words emit the result
@@ -704,7 +727,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                     const unsigned r = chase(e);
                     if (r != TOMB && r != (unsigned)p && r != (unsigned)nb) set_bit(r);
                 }
-                wfence();
+                WFENCE();
                 nm = bitmap_prefix();
                 u16* dst;
                 if (nm <= 64) dst = roots_of(m);
@@ -729,15 +752,13 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             {
                 uint32_t* gs = (uint32_t*)(g_stats + (size_t)m * 9);
                 uint32_t* gg = (uint32_t*)(g_geo + (size_t)m * 7);
-                if (lane >= 38 && lane < 56) gs[lane - 38] = dw;            // moments
-                if (lane >= 56 && lane < 62) gg[lane - 56] = dw;            // centre
-                if (lane >= 62) gg[6 + lane - 62] = dw;                     // normal[0]
-                if (lane < 4) gg[8 + lane] = dwt;                           // normal[1], normal[2]
-                if (lane == 4 || lane == 5) gg[12 + lane - 4] = dw;         // mse
+                uint32_t* dstw = lane < 18 ? gs + lane : gg + (lane - 18);     // 18 dwords of moments, then centre and normal
+                if (lane < 30) *dstw = A.mw;
             }
             const int N100m = N100p + N100n;
             const int ridm = N100p >= N100n ? ridp : ridn;
             if (lane == 0) {
+                geo_of(m)[6] = A.mse;
                 g_N[m] = N100m * (WIN * WIN);
                 *(uint4*)rec(m) = make_uint4((uint32_t)nm | (bigM ? 4u << 16 : 0u), (uint32_t)N100m << 16, (uint32_t)ridm, offM);
                 h_rid[m] = (u16)ridm;
@@ -749,10 +770,10 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                 }
                 mp[p] = (u16)m; mp[nb] = (u16)m;
             }
-            wfence();
+            WFENCE();
             PEAC_TICK(9);
-            if constexpr (FAST) pq_push(m, __hiloint2double((int)wave_lane(dw, 5), (int)wave_lane(dw, 4)), nm);
-            else heap_push(m, __hiloint2double((int)wave_lane(dw, 5), (int)wave_lane(dw, 4)), nm);
+            if constexpr (FAST) pq_push(m, A.mse, nm);
+            else heap_push(m, A.mse, nm);
             PEAC_TICK(10);
         } else {
             // ---------------- no merge: extract p if it is large enough, disconnect it (:1160-1170) ----------------
@@ -763,7 +784,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                 if (e != TOMB) inval(e);                                // p leaves their live-neighbour sets
             }
             if (lane == 0) mp[p] = (u16)TOMB;
-            wfence();
+            WFENCE();
             PEAC_TICK(11);
         }
         ++step;
@@ -774,9 +795,9 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
         heap_pop();
         if (g_N[p] >= MIN_SUPPORT) { if (n_ext < MAX_PLANES) { if (lane == 0) s_ext[n_ext] = p; n_ext++; } else err = 4; }
         if (lane == 0 && mp[p] == p) mp[p] = (u16)TOMB;
-        wfence();
+        WFENCE();
     }
-    gfence();
+    GFENCE();
     if (lane == 0) {   // std::sort(extractedPlanes, b->N < a->N): insertion sort (stable)
         for (int i = 1; i < n_ext; i++) {
             const int v = s_ext[i];
@@ -785,7 +806,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             s_ext[j] = v;
         }
     }
-    wfence();
+    WFENCE();
     mark();
     // ---- hand the clustering state over to peac_refine: set sizes / root ids / parents are in the workspace already; dead bits, extracted planes
     {
