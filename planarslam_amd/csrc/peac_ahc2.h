@@ -67,13 +67,13 @@ static inline int ahc2_smem_bytes(const Layout& L) {
 typedef unsigned long long u64;
 
 constexpr int ST_RETRY = 100;              // status of a frame the fast kernel gave up on (exact FP64 tie between live nodes): peac_ahc2 redoes it
-constexpr unsigned K_EMPTY = 0x7f800000u;  // tournament queue: +inf, no node
+constexpr unsigned K_EMPTY = 0xffffff80u;  // tournament queue: no node (above every key)
 
 // FAST = false: the queue is libstdc++'s binary heap, restated exactly (layout, hence the pop order among EQUAL keys, is the reference's).
 // FAST = true:  as long as no two live nodes have bit-equal mse the pop order does not depend on the heap's layout at all - it is "smallest key
-//               first" - so the queue may be anything.  Here: K[id] (LDS) = key rounded to float, low 7 mantissa bits replaced by the node's bag
-//               size (a monotonic proxy of the FP64 key: proxy(a) < proxy(b) implies a < b; equal proxies are decided on the FP64 keys), +inf =
-//               absent.  Lane L keeps the minimum of column L = ids congruent L mod 64 in registers; top = DPP minimum over the 64 lanes; removing
+//               first" - so the queue may be anything.  Here: K[id] (LDS) = key rounded to float, mapped to an unsigned integer of the same
+//               order, low 7 bits replaced by the node's bag size (a monotonic proxy of the FP64 key: proxy(a) < proxy(b) implies a < b; equal
+//               proxies are decided on the FP64 keys), K_EMPTY = absent.  Lane L keeps the minimum of column L = ids congruent L mod 64 in registers; top = DPP minimum over the 64 lanes; removing
 //               a node clears its slot and recomputes one column (one LDS round trip).  Nodes that die are removed at once, so there are no pops
 //               of dead nodes (the reference pops and skips ~2600 of them per 640x480 frame).  Wherever equal proxies meet (inside a column when
 //               it is recomputed, across columns at the top, at a push) the FP64 keys are compared, and bit-equal FP64 keys of two live nodes
@@ -251,7 +251,12 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
     float top_key = 0.f, la_margin = 0.5f;                    // proxy key of the node being popped; lookahead margin (eval_phase)
     unsigned cm_v = K_EMPTY;                                  // this lane's column minimum: raw K value ...
     int cm_id = -1;                                           // ... and node id
-    auto kproxy = [](unsigned v) -> float { return __uint_as_float(v & ~0x7fu); };
+    auto kproxy = [](unsigned v) -> unsigned { return v & ~0x7fu; };
+    auto k_of = [](double mse, int cnt) -> unsigned {         // float bits -> unsigned of the same order (sign flip / complement), bag size in the low bits
+        const unsigned b = __float_as_uint((float)mse);
+        return ((b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) & ~0x7fu) | (unsigned)(cnt > 64 ? 127 : cnt);
+    };
+    auto k_float = [](unsigned v) -> float { const unsigned o = v & ~0x7fu; return __uint_as_float((o >> 31) ? (o ^ 0x80000000u) : ~o); };
     struct Pick { int id; double d; bool any, tie; };
     auto pick_add = [&](Pick& P, int id) {                    // smallest FP64 key among nodes whose proxies are equal; bit-equal keys are a tie
         const double d = geo_of(id)[6];
@@ -261,10 +266,10 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
     auto col_recompute = [&](int Lc) {                        // Lc wave-uniform
         const int i1 = Lc + 64 * lane, i2 = i1 + 4096;
         const unsigned v1 = i1 < NB2 ? K[i1] : K_EMPTY, v2 = i2 < NB2 ? K[i2] : K_EMPTY;
-        const float p1 = kproxy(v1), p2 = kproxy(v2);
-        const float mn = wave_min_f32(fminf(p1, p2));
+        const unsigned p1 = kproxy(v1), p2 = kproxy(v2);
+        const unsigned mn = wave_min_u32(min(p1, p2));
         int id = -1; unsigned v = K_EMPTY;
-        if (mn < 3.0e38f) {
+        if (mn != K_EMPTY) {
             const u64 e1 = __ballot(p1 == mn), e2 = __ballot(p2 == mn);
             if (__popcll(e1) + __popcll(e2) == 1) {
                 const int j = e1 ? __ffsll((long long)e1) - 1 : __ffsll((long long)e2) - 1;
@@ -282,10 +287,10 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
         if (lane == Lc) { cm_v = v; cm_id = id; }
     };
     auto pq_top = [&]() -> int {                              // the live node with the smallest key, -1: the queue is empty
-        const float pm = kproxy(cm_v);
-        const float mn = wave_min_f32(pm);
-        if (!(mn < 3.0e38f)) return -1;
-        top_key = mn;
+        const unsigned pm = kproxy(cm_v);
+        const unsigned mn = wave_min_u32(pm);
+        if (mn == K_EMPTY) return -1;
+        top_key = k_float(mn);
         const u64 eq = __ballot(pm == mn);
         if (__popcll(eq) == 1) return wave_lane(cm_id, __ffsll((long long)eq) - 1);
         GFENCE();
@@ -301,33 +306,29 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
     };
     auto pq_push = [&](int id, double mse, int cnt) {
         if (!(mse < 3.0e38) || !(mse > -3.0e38)) err = ST_RETRY;   // NaN / infinite key: leave it to the exact kernel
-        const unsigned v = (__float_as_uint((float)mse) & ~0x7fu) | (unsigned)(cnt > 64 ? 127 : cnt);
+        const unsigned v = k_of(mse, cnt);
         if (lane == 0) K[id] = v;
         WFENCE();
         const int Lc = id & 63;
-        const float pn = kproxy(v), pc = kproxy(wave_lane(cm_v, Lc));
+        const unsigned pn = kproxy(v), pc = kproxy(wave_lane(cm_v, Lc));
         if (pn < pc) { if (lane == Lc) { cm_v = v; cm_id = id; } }
         else if (pn == pc) col_recompute(Lc);
     };
 
     // ---- what a bag entry stands for now: follow mp to the live node (or TOMB), halving the path on the way.  All 64 lanes call it together.
     auto chase = [&](unsigned x) -> unsigned {
-        unsigned par = x == TOMB ? TOMB : (unsigned)mp[x];
-        if (!__ballot(par != x)) return x;                     // every entry is alive (or a tombstone): the common case
-        bool done = par == x;
+        bool done = x == TOMB;
         int guard = 0;
-        while (true) {
+        while (true) {                                         // two levels per round: an entry that is alive, or whose owner is, is settled in the first
+            const unsigned par = done ? x : (unsigned)mp[x];
+            const unsigned g = mp[(done || par == TOMB) ? 0u : par];
             if (!done) {
                 if (par == TOMB) { x = TOMB; done = true; }
-                else {
-                    const unsigned g = mp[par];
-                    if (g == par) { x = par; done = true; }
-                    else { mp[x] = (u16)g; x = g; if (g == TOMB) done = true; }
-                }
+                else if (g == par) { x = par; done = true; }   // par is alive (par == x: the entry itself)
+                else { mp[x] = (u16)g; x = g; if (g == TOMB) done = true; }
             }
             if (!__ballot(!done)) break;
             if (++guard > 8192) { err = 7; break; }            // mp only ever points to newer nodes: cannot happen; keeps a corrupted workspace from hanging the GPU
-            if (!done) { par = mp[x]; if (par == x) done = true; }
         }
         return x;
     };
@@ -430,7 +431,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             // The column minima are not the 64 smallest keys; evaluating a node long before it pops is wasted when a neighbour dies in between.
             // Only minima within a margin above the popped node's key are taken: the margin tunes itself towards ~16 candidates per phase
             // (the choice affects nothing but the number of phases).
-            const float kp = kproxy(cm_v), span = fabsf(top_key) + 1e-20f;
+            const float kp = k_float(cm_v), span = fabsf(top_key) + 1e-20f;
             bool c2 = cand;
             for (int it = 0; it < 4; it++) {
                 c2 = cand && kp <= top_key + la_margin * span;
@@ -589,16 +590,16 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
     if constexpr (FAST) {
         for (int b = lane; b < NB2; b += 64) {
             unsigned v = K_EMPTY;
-            if (b < NB && (g_flags[b] & 1)) v = (__float_as_uint((float)geo_of(b)[6]) & ~0x7fu) | (rec(b)[0] & 0x7fu);
+            if (b < NB && (g_flags[b] & 1)) v = k_of(geo_of(b)[6], (int)(rec(b)[0] & 0x7fu));
             K[b] = v;
         }
         WFENCE();
         bool tie = false;
         for (int i = lane; i < NB2; i += 64) {                 // every lane scans its own column
             const unsigned v = K[i];
-            const float pv = kproxy(v), pc = kproxy(cm_v);
+            const unsigned pv = kproxy(v), pc = kproxy(cm_v);
             if (pv < pc) { cm_v = v; cm_id = i; }
-            else if (pv == pc && pv < 3.0e38f) {
+            else if (pv == pc && pv != K_EMPTY) {
                 const double a = geo_of(i)[6], b = geo_of(cm_id)[6];
                 if (a < b) { cm_v = v; cm_id = i; } else if (a == b) tie = true;
             }

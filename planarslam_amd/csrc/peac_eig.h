@@ -6,8 +6,9 @@
 // run ONE instruction stream: PlaneSeg::Stats::compute (reference include/peac/AHCPlaneSeg.hpp:125-156) is evaluated for
 // 64 different candidate merges at a time, and with the textbook control flow every lane's (start, end) block and every
 // makeGivens branch serialises (three block shapes x two Givens branches: the solve was ~27k cycles per wavefront).
-// Here an iteration is: shift (one hypot, one division), a rotation at k = start, and - under the lanes' mask - a second
-// rotation at k = 1 for the lanes whose block is (0, 2); makeGivens and hypot select their operands instead of branching.
+// Here an iteration is: shift (one hypot, one division), a rotation at k = 0 for the lanes whose block starts at row 0 and a
+// rotation at k = 1 for the lanes whose block ends at row 2, each on fixed registers; makeGivens and hypot select their
+// operands instead of branching.
 // The header also compiles with g++ (tests/test_peac_eig.py checks it against the oracle bit for bit on the CPU).
 #pragma once
 #include <math.h>
@@ -86,44 +87,43 @@ PLANAR_HD void eig33u(double a00, double a10, double a11, double a20, double a21
         {
             const double e2 = e * e, h = eigu_hypot(td, e);
             double dm = e2 / (td + (td > 0 ? h : -h));
-            if (e2 == 0) dm = (e / (td + (td > 0 ? 1.0 : -1.0))) * (e / h);
+            if (e2 == 0) {                                     // underflow of e * e: a real branch (two more divisions), never taken in practice
+#if defined(__HIPCC__) || defined(__GNUC__)
+                asm volatile("");
+#endif
+                dm = (e / (td + (td > 0 ? 1.0 : -1.0))) * (e / h);
+            }
             if (td == 0) dm = fabs(e);
             mu -= dm;
         }
-        // rotation at k = start on (diag[k], diag[k+1], sub[k]) and the columns k, k+1 of Q
-        double x = (s0blk ? d0 : d1) - mu, z = s0blk ? s0 : s1;
-        double z2 = 0;
-        {
-            const double A = s0blk ? d0 : d1, B = s0blk ? d1 : d2, S = s0blk ? s0 : s1;
+        // The block is (0, 2), (0, 1) or (1, 2): a rotation at k = 0 for the lanes whose block starts at 0, then a rotation at k = 1 for the lanes
+        // whose block ends at 2.  Each works on fixed registers (no operand selection); a lane skips the one its block does not have.
+        double xB = d1 - mu, zB = s1;                          // (1, 2): x = diag[start] - mu, z = sub[start]
+        if (s0blk) {                                           // rotation at k = 0 on (d0, d1, s0) and the columns 0, 1 of Q
             double c, s;
-            eigu_givens(x, z, c, s);
-            const double sdk = s * A + c * S;
-            const double dkp1 = s * S + c * B;
-            const double nA = c * (c * A - s * S) - s * (c * S - s * B);
+            eigu_givens(d0 - mu, s0, c, s);
+            const double sdk = s * d0 + c * s0;
+            const double dkp1 = s * s0 + c * d1;
+            const double nA = c * (c * d0 - s * s0) - s * (c * s0 - s * d1);
             const double nB = s * sdk + c * dkp1;
             const double nS = c * sdk - s * dkp1;
-            x = nS;
-            if (two) { z2 = -s * s1; s1 = c * s1; }            // k < end - 1
-            if (s0blk) { d0 = nA; d1 = nB; s0 = nS; } else { d1 = nA; d2 = nB; s1 = nS; }
-            const double x0 = s0blk ? q00 : q01, y0 = s0blk ? q01 : q02;
-            const double x1 = s0blk ? q10 : q11, y1 = s0blk ? q11 : q12;
-            const double x2 = s0blk ? q20 : q21, y2 = s0blk ? q21 : q22;
-            const double n0x = c * x0 - s * y0, n0y = s * x0 + c * y0;
-            const double n1x = c * x1 - s * y1, n1y = s * x1 + c * y1;
-            const double n2x = c * x2 - s * y2, n2y = s * x2 + c * y2;
-            if (s0blk) { q00 = n0x; q01 = n0y; q10 = n1x; q11 = n1y; q20 = n2x; q21 = n2y; }
-            else { q01 = n0x; q02 = n0y; q11 = n1x; q12 = n1y; q21 = n2x; q22 = n2y; }
+            if (two) { zB = -s * s1; s1 = c * s1; xB = nS; }   // k < end - 1: the bulge for the next rotation
+            d0 = nA; d1 = nB; s0 = nS;
+            const double n0x = c * q00 - s * q01, n0y = s * q00 + c * q01;
+            const double n1x = c * q10 - s * q11, n1y = s * q10 + c * q11;
+            const double n2x = c * q20 - s * q21, n2y = s * q20 + c * q21;
+            q00 = n0x; q01 = n0y; q10 = n1x; q11 = n1y; q20 = n2x; q21 = n2y;
         }
-        if (two) {                                             // rotation at k = 1 (= end - 1)
+        if (e2blk) {                                           // rotation at k = 1 on (d1, d2, s1) and the columns 1, 2 of Q
             double c, s;
-            eigu_givens(x, z2, c, s);
+            eigu_givens(xB, zB, c, s);
             const double sdk = s * d1 + c * s1;
             const double dkp1 = s * s1 + c * d2;
             const double nA = c * (c * d1 - s * s1) - s * (c * s1 - s * d2);
             const double nB = s * sdk + c * dkp1;
             const double nS = c * sdk - s * dkp1;
             d1 = nA; d2 = nB; s1 = nS;
-            s0 = c * s0 - s * z2;                              // k > start
+            if (two) s0 = c * s0 - s * zB;                     // k > start
             const double n0x = c * q01 - s * q02, n0y = s * q01 + c * q02;
             const double n1x = c * q11 - s * q12, n1y = s * q11 + c * q12;
             const double n2x = c * q21 - s * q22, n2y = s * q21 + c * q22;

@@ -30,16 +30,16 @@ __device__ __forceinline__ int wave_scan_add(int v) {
     return v;
 }
 
-// minimum over the 64 lanes (the same DPP ladder with v_min_f32; lanes without a source see +inf), as a wave-uniform value
-__device__ __forceinline__ float wave_min_f32(float v) {
-    const int inf = 0x7f800000;
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x111, 0xf, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x112, 0xf, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x114, 0xf, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x118, 0xf, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x142, 0xa, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x143, 0xc, 0xf, false)));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+// minimum over the 64 lanes, as a wave-uniform value: the same DPP ladder with v_min_u32 (lanes without a source see ~0)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    const int top = -1;
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(top, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(top, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(top, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(top, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(top, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(top, (int)v, 0x143, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 }  // namespace planar

@@ -185,8 +185,8 @@ inline int wave_scan_add(int v) {
     for (int o = 1; o < 64; o <<= 1) { const int t = ::wave_emul::shfl(900010 + o, v, l - o >= 0 ? l - o : l); if (l >= o) v += t; }
     return v;
 }
-inline float wave_min_f32(float v) {
-    for (int o = 32; o > 0; o >>= 1) { const float t = ::wave_emul::shfl(900100 + o, v, (::wave_emul::S().cur & 63) ^ o); v = t < v ? t : v; }
+inline unsigned wave_min_u32(unsigned v) {
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = ::wave_emul::shfl(900100 + o, v, (::wave_emul::S().cur & 63) ^ o); v = t < v ? t : v; }
     return v;
 }
 }  // namespace planar
