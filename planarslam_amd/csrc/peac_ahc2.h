@@ -687,16 +687,20 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             unsigned offM = 0;
             bool bigM = false;
             if (!bigA && !bigB) {
-                // both bags in registers: set bits, prefix, every entry writes itself to its rank
+                // both bags in registers.  Deduplication through the bitmap: an entry whose bit was clear before its own atomic OR is the
+                // first of its node and stays; the survivors are packed in lane order (ballot + popcount: no prefix arrays).  The new bag is
+                // NOT sorted by id: nothing reads a bag in order (the fold takes the minimum mse, exact ties sort by id themselves).
                 unsigned ra = lane < n ? rootA : TOMB;
                 unsigned rb = chase(lane < nbn ? rootB : TOMB);
                 PEAC_TICK(5);
                 if (ra == (unsigned)nb || ra == (unsigned)p) ra = TOMB;
                 if (rb == (unsigned)p || rb == (unsigned)nb) rb = TOMB;
-                if (ra != TOMB) set_bit(ra);
-                if (rb != TOMB) set_bit(rb);
-                WFENCE();
-                nm = bitmap_prefix();
+                bool keepA = false, keepB = false;
+                if (ra != TOMB) { const unsigned bit = 1u << (ra & 31); keepA = !(atomicOr(&bmp[ra >> 5], bit) & bit); }
+                if (rb != TOMB) { const unsigned bit = 1u << (rb & 31); keepB = !(atomicOr(&bmp[rb >> 5], bit) & bit); }
+                const u64 mA = __ballot(keepA), mB = __ballot(keepB);
+                const int nA = __popcll(mA);
+                nm = nA + __popcll(mB);
                 PEAC_TICK(6);
                 u16* dst;
                 if (nm <= 64) dst = roots_of(m);
@@ -707,11 +711,8 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                     offM = pool_top + 1; pool_top += 1 + cap; bigM = true;
                     dst = bpool + offM;
                 }
-                if (ra != TOMB) { const unsigned w = ra >> 5; dst[pre[w] + __popc(bmp[w] & ((1u << (ra & 31)) - 1u))] = (u16)ra; inval(ra); }
-                if (rb != TOMB) { const unsigned w = rb >> 5; dst[pre[w] + __popc(bmp[w] & ((1u << (rb & 31)) - 1u))] = (u16)rb; inval(rb); }
-                WFENCE();
-                if (ra != TOMB) bmp[ra >> 5] = 0;
-                if (rb != TOMB) bmp[rb >> 5] = 0;
+                if (keepA) { dst[__popcll(mA & lane_below(lane))] = (u16)ra; inval(ra); bmp[ra >> 5] = 0; }
+                if (keepB) { dst[nA + __popcll(mB & lane_below(lane))] = (u16)rb; inval(rb); bmp[rb >> 5] = 0; }
                 WFENCE();
                 PEAC_TICK(7);
             } else {
