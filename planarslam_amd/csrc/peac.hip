@@ -30,7 +30,8 @@ namespace peac {
 // (merge heap with its MSE keys, the neighbour lists as u16, the disjoint set, the block map); the per-node
 // moments / plane parameters stay in the frame's global workspace and are read once per merge step.
 constexpr int NT_AHC = 64;       // clustering: one wavefront per frame (a second one, 128 threads, leaves the chain as long and costs 12 ms per step: measured)
-constexpr int NT_REFINE = 256;   // refinement: four wavefronts per frame
+constexpr int NT_REFINE = 256;   // refinement: four wavefronts per frame (throughput: several frames per CU)
+constexpr int NT_REFINE_WIDE = 1024;   // few frames in the batch (the reference's one-camera operating point): sixteen wavefronts per frame, the flood fill takes a quarter of the steps
 
 struct Lds {
     float* h_key; u16* h_id; u16* pool; u16* nb_off; u16* nb_cnt; unsigned char* nb_cntb; u16* dsp; u16* dss; u16* rid; unsigned* nouse; unsigned* cval; signed char* blk;
@@ -115,9 +116,10 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
     __shared__ int s_ext[MAX_PLANES], s_old[RP], s_plidmap[RP];
     __shared__ uint8_t s_valid[RP];
     __shared__ unsigned s_adj[RP][MAX_PLANES / 32];
-    constexpr int NSLOT = 4096;                               // pixel -> slot hash of the flood fill (pairs of one step: 2048)
+    constexpr int NW = NT / 64;                               // wavefronts of the workgroup
+    constexpr int NSLOT = 16 * NT;                            // pixel -> slot hash of the flood fill (pairs of one step: 8 * NT)
     __shared__ int s_slot[PHASE == 1 ? NSLOT : 1];
-    __shared__ int s_pcnt[32];
+    __shared__ int s_pcnt[8 * NW];
     __shared__ int s_scalar[4];   // [0] n_ext, [1] err, [2] q_tail, [3] scratch
     constexpr int EVAL_MAX = 64;   // nodes evaluated per cooperative phase
     __shared__ int s_cmd, s_nlist;
@@ -847,7 +849,7 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
 #pragma unroll
                 for (int j = 0; j < FJ; j++) pend = pend || !done[j];
                 if (!__syncthreads_or(pend)) break;
-                const unsigned ek = (0xfffffu - epoch) << 12;           // pair indices are < 4096
+                const unsigned ek = (0x7ffffu - epoch) << 13;           // pair indices are < 8192 (NT <= 1024)
                 epoch++;
 #pragma unroll
                 for (int j = 0; j < FJ; j++) if (!done[j]) atomicMin(&slot[hsl[j]], ek | (unsigned)pidx[j]);
@@ -876,12 +878,12 @@ __device__ __forceinline__ void segment_frame(const Layout& L, const Intr& K, co
             // pushes in pair order (pair p = tid + NT * j): j-major, then wavefront, then lane
             unsigned long long pm[FJ];
 #pragma unroll
-            for (int j = 0; j < FJ; j++) { pm[j] = __ballot(push[j]); if (lane == 0) s_pcnt[j * 4 + wave] = __popcll(pm[j]); }
+            for (int j = 0; j < FJ; j++) { pm[j] = __ballot(push[j]); if (lane == 0) s_pcnt[j * NW + wave] = __popcll(pm[j]); }
             __syncthreads();
             int base = 0, mybase[FJ];
 #pragma unroll
             for (int j = 0; j < FJ; j++)
-                for (int w = 0; w < 4; w++) { if (w == wave) mybase[j] = base; base += s_pcnt[j * 4 + w]; }
+                for (int w = 0; w < NW; w++) { if (w == wave) mybase[j] = base; base += s_pcnt[j * NW + w]; }
             if (q_tail + base > L.q_cap) err = 5;
             else {
 #pragma unroll
@@ -980,6 +982,15 @@ __global__ __launch_bounds__(NT_REFINE) void peac_refine(Layout L, Intr K, Const
     segment_frame<1, NT_REFINE>(L, K, C, depth, pitch_px, frame_stride_px, ws, labels, label_stride, planes, n_planes, status, timing, (int)blockIdx.x);
 }
 
+// The same refinement with 1024 threads per frame, for small batches: the flood fill processes 2048 queue entries per step instead of 512 (its result does not
+// depend on the step size: pairs that meet at a pixel are replayed in the reference's order), one frame per CU.
+__global__ __launch_bounds__(NT_REFINE_WIDE) void peac_refine_wide(Layout L, Intr K, Consts C, const uint16_t* __restrict__ depth, int pitch_px,
+                                                  int64_t frame_stride_px, uint8_t* __restrict__ ws, int32_t* __restrict__ labels,
+                                                  int64_t label_stride, double* __restrict__ planes, int32_t* __restrict__ n_planes,
+                                                  int32_t* __restrict__ status, long long* __restrict__ timing) {
+    segment_frame<1, NT_REFINE_WIDE>(L, K, C, depth, pitch_px, frame_stride_px, ws, labels, label_stride, planes, n_planes, status, timing, (int)blockIdx.x);
+}
+
 // Longest-first order for the NEXT call with the same batch size: slot b of a batch is one camera stream, consecutive frames of a stream cost
 // about the same, and a launch ends with its slowest frames - so they should start first.  order[rank] = frame, rank by the duration the
 // last call measured (ties by frame index).  Only the schedule depends on it, never a result.
@@ -1011,6 +1022,7 @@ struct planar_peac {
     peac::Layout L{};
     peac::Consts C{};
     int smem = 0, smem2 = 0;
+    int wide_below = 64;                                      // batches up to this size refine with 1024 threads per frame (PLANAR_PEAC_WIDE overrides; 0 = never)
     bool exact_only = false;                                  // PLANAR_PEAC_AHC=exact: skip the fast attempt (tests / A-B runs)
     bool legacy_ahc = false;                                  // PLANAR_PEAC_AHC=legacy: the round-2 clustering kernel (eager neighbour lists), for A/B runs
     DevBuf d_ws, d_status, d_timing, d_next, d_order;
@@ -1038,6 +1050,7 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     const peac::Layout& L = o->L;
     o->smem2 = peac::ahc2_smem_bytes(L);
     { const char* e = getenv("PLANAR_PEAC_AHC"); o->legacy_ahc = e && !strcmp(e, "legacy"); o->exact_only = e && !strcmp(e, "exact"); }
+    { const char* e = getenv("PLANAR_PEAC_WIDE"); if (e) o->wide_below = atoi(e); }
     // peac_ahc (legacy): heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
     o->smem = L.NB * 4 + L.NB * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
@@ -1093,8 +1106,12 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     mark();
     hipLaunchKernelGGL(peac::peac_order, dim3((B + 255) / 256), dim3(256), 0, st, p->d_timing.as<long long>(), B, p->d_order.as<int>());
     mark();
-    hipLaunchKernelGGL(peac::peac_refine, dim3(B), dim3(peac::NT_REFINE), 0, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
-                       p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
+    if (B <= p->wide_below)
+        hipLaunchKernelGGL(peac::peac_refine_wide, dim3(B), dim3(peac::NT_REFINE_WIDE), 0, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+                           p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
+    else
+        hipLaunchKernelGGL(peac::peac_refine, dim3(B), dim3(peac::NT_REFINE), 0, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+                           p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
     mark();
     p->order_B = B;
     PLANAR_HIP_CHECK(hipGetLastError());
