@@ -23,6 +23,7 @@
 //   K7 lbd_describe     one wavefront per kept line: 63 support rows on 63 lanes, band sums in reference order
 // HBM traffic is small (a 640x480 frame: 0.3 MB in, 3 KB out, ~5 MB of L2-resident intermediates); K4 is latency bound.
 #include "common.h"
+#include "wave_ops.h"
 
 namespace planar {
 namespace lsd {
@@ -827,12 +828,13 @@ __device__ inline void chains3(const Det& D, int n, double out[3], bool sub2, F 
         }
         lds_sync();
     }
-    out[0] = __shfl(acc, 0, 64); out[1] = __shfl(acc, 1, 64); out[2] = __shfl(acc, 2, 64);
+    out[0] = planar::wave_lane(acc, 0); out[1] = planar::wave_lane(acc, 1); out[2] = planar::wave_lane(acc, 2);
 }
 
-__device__ inline double wave_max_d(double v) { for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; }
-__device__ inline double wave_min_d(double v) { for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64)); return v; }
-__device__ inline int wave_sum_i(int v) { for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+// reductions on the DPP ladder (wave_ops.h): a __shfl_xor butterfly is six LDS-pipe permutes per 32-bit word
+__device__ inline double wave_max_d(double v) { return planar::wave_max_f64(v); }
+__device__ inline double wave_min_d(double v) { return planar::wave_min_f64(v); }
+__device__ inline int wave_sum_i(int v) { return planar::wave_sum_i32(v); }
 
 __device__ __forceinline__ double modgrad_of(const Det& D, uint32_t pxy) { return sqrt(D.g2[(pxy >> 16) * D.w + (pxy & 0xffff)] / 4.0); }
 
@@ -1073,7 +1075,7 @@ __device__ int rect_counts(const Det& D, const Rect& rec, const double* precs, i
     int total = 0, wmax = 0;
     for (int k = lane; k < nrows; k += 64) { int xa; const int c = row_span(k, xa); total += c; wmax = max(wmax, c); }
     total = wave_sum_i(total);
-    for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    wmax = (int)planar::wave_max_f64((double)wmax);            // (exact: an int32 is a double)
     int alg[NP];
     for (int q = 0; q < NP; q++) alg[q] = 0;
     auto test = [&](float deg) {

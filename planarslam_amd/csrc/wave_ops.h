@@ -42,5 +42,26 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// reductions over the 64 lanes with the result in every lane (wave-uniform): the DPP ladder leaves the total in lane 63.  A butterfly of __shfl_xor costs
+// six LDS-pipe permutes per 32-bit word (~120 cycles each for a lone wavefront); the ladder is six VALU steps.
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_add(v), 63); }
+#define PLANAR_DPP_F64(v, ctrl, rmask, idv)                                                                                   \
+    __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(idv), __double2hiint(v), ctrl, rmask, 0xf, false),            \
+                     __builtin_amdgcn_update_dpp(__double2loint(idv), __double2loint(v), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ double wave_max_f64(double v) {
+    const double id = -__builtin_inf();
+    v = fmax(v, PLANAR_DPP_F64(v, 0x111, 0xf, id)); v = fmax(v, PLANAR_DPP_F64(v, 0x112, 0xf, id));
+    v = fmax(v, PLANAR_DPP_F64(v, 0x114, 0xf, id)); v = fmax(v, PLANAR_DPP_F64(v, 0x118, 0xf, id));
+    v = fmax(v, PLANAR_DPP_F64(v, 0x142, 0xa, id)); v = fmax(v, PLANAR_DPP_F64(v, 0x143, 0xc, id));
+    return wave_lane(v, 63);
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+    const double id = __builtin_inf();
+    v = fmin(v, PLANAR_DPP_F64(v, 0x111, 0xf, id)); v = fmin(v, PLANAR_DPP_F64(v, 0x112, 0xf, id));
+    v = fmin(v, PLANAR_DPP_F64(v, 0x114, 0xf, id)); v = fmin(v, PLANAR_DPP_F64(v, 0x118, 0xf, id));
+    v = fmin(v, PLANAR_DPP_F64(v, 0x142, 0xa, id)); v = fmin(v, PLANAR_DPP_F64(v, 0x143, 0xc, id));
+    return wave_lane(v, 63);
+}
+
 }  // namespace planar
 #endif
