@@ -45,6 +45,17 @@ def orb_algorithmic_bytes(ex, avg_kp):
             "orb_fast_cells": sum(px), "orb_sort": 0, "orb_octree": 0, "orb_blur": 2 * sum(px), "orb_describe": avg_kp * (709 + 512 + 60)}
 
 
+def pick_device(args, torch):
+    """LOCAL_RANK's GPU.  RCCL needs one device per rank; with --backend gloo the ranks wrap around the visible devices."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if args.backend == "nccl":
+            raise SystemExit(f"rank {local_rank} has no GPU ({ndev} visible): RCCL needs one device per rank (use --backend gloo to share devices)")
+        local_rank %= ndev
+    return local_rank
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +70,10 @@ def main():
     ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 latency block (0 = skip)")
     ap.add_argument("--pcie-steps", type=int, default=4, help="steps of the PCIe-inclusive loop (0 = skip)")
     ap.add_argument("--canvases", type=int, default=NCANVAS, help="distinct synthetic canvases per GPU (the streams tile over them)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the barrier / max-over-ranks (nccl = RCCL, one rank per GPU).  gloo: ranks may share a GPU "
+                         "(rank r uses device r mod device_count; the BA workload then exchanges through the hosted transport) - how the N > 1 "
+                         "launch, rendezvous, shard and print paths are exercised on a 1-GPU box")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes that synthesise the canvases (0 = up to 32; 1 = in this process: rocprofv3 --pmc hangs in "
                                                              "forked children, profiles/README.md)")
     args = ap.parse_args()
@@ -93,12 +108,12 @@ def main():
     import torch
 
     from planarslam_amd.dist import Ranks, whole_job_fps
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    local_rank = pick_device(args, torch)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    ranks = Ranks(backend="nccl", device=dev)          # RCCL: barrier + max-over-ranks only (frames shard, no data collective)
+    ranks = Ranks(backend=args.backend, device=dev)    # RCCL (or gloo): barrier + max-over-ranks only (frames shard, no data collective)
     rank, world = ranks.rank, ranks.world
 
     from planarslam_amd import Context, ORBextractor, Optimizer, PlaneDetection
@@ -175,11 +190,22 @@ def main():
                                                                                           tp.ldesc[0].data_ptr(), tp.leq[0].data_ptr(), tp.nl[0].data_ptr())))):
                 torch.cuda.synchronize()
                 fn(); torch.cuda.synchronize()
+                check(L.planar_peac_set_profiling(pd0.h, 1)); check(L.planar_lsd_set_profiling(ls0.h, 1))
                 t1 = time.perf_counter(); fn(); torch.cuda.synchronize()
                 standalone[name] = round((time.perf_counter() - t1) * 1e3, 3)
+                import ctypes as C0
+                tot = np.zeros(4); nc = C0.c_int64()
+                if name.startswith("peac"):
+                    check(L.planar_peac_get_profile(pd0.h, tot.ctypes.data, C0.byref(nc)))
+                    standalone["peac_kernels_alone_ms"] = dict(zip(("peac_blocks", "peac_ahc", "peac_order", "peac_refine"), (round(float(x), 3) for x in tot)))
+                else:
+                    check(L.planar_lsd_get_profile(ls0.h, tot.ctypes.data, C0.byref(nc)))
+                    standalone["lsd_kernels_alone_ms"] = dict(zip(("preprocess", "lsd_sort", "lsd_detect", "improve+accept+keylines+lbd"), (round(float(x), 3) for x in tot)))
+                check(L.planar_peac_set_profiling(pd0.h, 0)); check(L.planar_lsd_set_profiling(ls0.h, 0))
         ex.set_profiling(True)
         if full:
             for q in tp.pds: check(L.planar_peac_set_profiling(q.h, 1))
+            for q in tp.lss: check(L.planar_lsd_set_profiling(q.h, 1))
         evsets = [{n: torch.cuda.Event(enable_timing=True) for n in EV} for _ in range(args.steps)]
         sides = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
         barrier()
@@ -199,6 +225,12 @@ def main():
                 check(L.planar_peac_get_profile(q.h, tot.ctypes.data, C.byref(nc)))
                 check(L.planar_peac_set_profiling(q.h, 0))
                 peac_ms += tot; peac_calls += nc.value
+            lsd_ms, lsd_calls = np.zeros(4), 0
+            for q in tp.lss:
+                tot = np.zeros(4); nc = C.c_int64()
+                check(L.planar_lsd_get_profile(q.h, tot.ctypes.data, C.byref(nc)))
+                check(L.planar_lsd_set_profiling(q.h, 0))
+                lsd_ms += tot; lsd_calls += nc.value
     if full:
         tp.check()
 
@@ -262,8 +294,8 @@ def main():
     # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this
     # command, KB per launch, summed over the stage's kernels); raw counter sums (narrow gathers: no wide-read correction applied)
     traffic = None
-    traffic_note = "null: profiles/r02_pmc_fetch_write_kb_per_launch.csv (tools/collect_profiles.sh) not found"
-    pmc_csv = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_kb_per_launch.csv")
+    pmc_csv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_fetch_write_kb_per_launch.csv") for r in (3, 2)) if os.path.exists(q)), "")
+    traffic_note = "null: no profiles/r0N_pmc_fetch_write_kb_per_launch.csv (tools/pmc_counters.py) found"
     pmc_keys = {"peac_blocks+peac_ahc+peac_refine": ("planar::peac::peac_blocks", "planar::peac::peac_ahc", "planar::peac::peac_refine"),
                 "lsd_detect(+7 small kernels)": ("planar::lsd::lsd_detect",)}.get(dom, ("planar::orb::" + dom,))
     if os.path.exists(pmc_csv):
@@ -274,11 +306,27 @@ def main():
                 f_tot += float(f_kb); w_tot += float(w_kb)
         if f_tot + w_tot > 0:
             traffic = int((f_tot + w_tot) * 1024 * B / 1024)
-            traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, B=1024): {f_tot / 1024:.0f} MB read + {w_tot / 1024:.0f} MB written per launch"
+            traffic_note = (f"NOT measured in this run: read from the committed {os.path.relpath(pmc_csv, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
+                            f"`bench.py --canvases 16 --gen-procs 1`, B=1024; counter collection hangs in forked children): {f_tot / 1024:.0f} MB read + {w_tot / 1024:.0f} MB written per launch")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
+                "traffic": traffic, "traffic_source": os.path.relpath(pmc_csv, ROOT) if traffic is not None else None, "traffic_note": traffic_note, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
                 "pipeline_algorithmic_GBps": round(per_frame * fps / 1e9, 2),
                 "note": "latency-bound sequential stage (one wavefront per frame); see DESIGN.md" if dom.startswith(("peac", "lsd")) else None, "kernels": kernels}
+    if full:
+        # the three kernels with the most device time, each against the roofline on its own: algorithmic bytes of its stage per launch
+        # divided by the kernel's average duration - alone on the device (calibration launch before the timed region) and inside the pipelined step
+        lav = lsd_ms / max(1, lsd_calls)
+        ka, la = standalone.get("peac_kernels_alone_ms", {}), standalone.get("lsd_kernels_alone_ms", {})
+        per = {}
+        for name, alone, corun, nbytes in (("peac_ahc", ka.get("peac_ahc"), float(pav[1]), 1843200 * B), ("peac_refine", ka.get("peac_refine"), float(pav[3]), 1843200 * B),
+                                           ("lsd_sort", la.get("lsd_sort"), float(lav[1]), 312160 * B), ("lsd_detect", la.get("lsd_detect"), float(lav[2]), 312160 * B)):
+            e = {"alg_bytes_per_launch": int(nbytes), "corun_avg_ms": round(corun, 3), "alone_ms": alone}
+            if corun > 0: e["frac_corun"] = round(nbytes / (corun * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+            if alone: e["frac_alone"] = round(nbytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+            per[name] = e
+        roofline["per_kernel"] = per
+        roofline["per_kernel_note"] = ("peac_ahc = peac_ahc3 (fast attempt) + peac_ahc2 (exact kernel for frames with bit-equal keys) bracketed together; durations from HIP events right "
+                                       "before / after each launch on the stream it runs on")
 
     # ---- PCIe-inclusive rate: the same step fed from pinned host memory and drained to it (H2D / D2H on copy streams, overlapped) ----
     pcie = None
@@ -337,6 +385,7 @@ def main():
     if args.cpu_seconds > 0 and world == 1:        # rank 0 at N = 1 only
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import cpu_baseline as cb
+        cb.use_fast_build()                          # -O3 -march=native, compiled on this box (the tests keep checking against the -O2 build)
         t_each = args.cpu_seconds / 3.0
         r1 = cb.run(t_each, seed=rank, full=full)
         r3 = cb.run(t_each, seed=rank, threads3=True, full=full) if full else None
@@ -347,7 +396,7 @@ def main():
                "one_thread": {"value": round(r1["frames"] / r1["seconds"], 2), "cores": 1, "frames": r1["frames"], "ms_per_frame": cb.summarize(r1)},
                "threads3": None if r3 is None else {"value": round(r3["frames"] / r3["seconds"], 2), "cores": 3, "frames": r3["frames"], "ms_per_frame": cb.summarize(r3),
                                                      "note": "extraction on 3 threads per frame as src/Frame.cc:90-95; matching + LM single-threaded"},
-               "host_cores": ncores}
+               "host_cores": ncores, "cpu_model": cb.cpu_model(), "build": cb.build_flags()}
 
     # ---- single-frame latency (B = 1, host-pointer entry points: H2D + kernels + D2H + sync; the reference is a live B = 1 tracker) ----
     latency = None
@@ -377,6 +426,17 @@ def main():
                                                                        np.ones((1, len(de1)), np.uint8), np.zeros((1, len(de1)), np.uint8))),
                    "reps": args.latency_reps, "note": "median wall ms per call, one frame, host buffers in and out"}
         latency["extract_3_stages_serial_sum"] = round(latency["orb_extract"] + latency["lsd_lbd_extract"] + latency["peac_segment"], 3)
+        # the reference's operating point: Frame::Frame runs the three extractors on three threads (src/Frame.cc:90-95).  Here: three host threads, each calling
+        # its extractor's host-pointer entry point on its own context / stream (ctypes releases the GIL), one frame.
+        import threading
+        c2, c3 = Context(local_rank), Context(local_rank)
+        ls3 = LS1(W, H, 1, c2); pd3 = PlaneDetection(W, H, max_batch=1, ctx=c3)
+
+        def three():
+            th = [threading.Thread(target=f) for f in (lambda: ex1(g1), lambda: ls3.ExtractLineSegment(g1), lambda: pd3.run(dp1[None]))]
+            for t in th: t.start()
+            for t in th: t.join()
+        latency["extract_3_threads_concurrent"] = med(three)
 
     workload = ("configs[2]+[3] as the reference's per-frame Track(): extract (ORB + LSD/LBD lines + isLineGood + PEAC planes + voxel clouds / RANSAC refit + surface normals on three streams, ComputeStereoFromRGBD) -> TrackManhattanFrame -> "
                 "SearchByProjection(Cur, Last) + LSD SearchByDescriptor + MatchORBPoints + PlaneMatcher -> TranslationOptimization 4x10 -> isInFrustum + SearchByProjection(map) + "
@@ -394,6 +454,7 @@ def main():
                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}, "not_yet_in_workload": nyi,
                    "parallelism": f"frame-sharded x{world}, no collective"},
         "roofline": roofline, "cpu_baseline": cpu, "latency_b1_ms": latency, "value_pcie_inclusive": pcie,
+        "scaling_curve": "this line is one point (n_gpus above); the 1/2/4/8 curve exists only where the driver's SCALE record is not 'skipped'",
     }
     if quality:
         out["config"].update(quality)
@@ -412,19 +473,22 @@ def main_ba(args):
     from planarslam_amd import Communicator, Context, local_bundle_adjustment, shard_problem
     from planarslam_amd.dist import Ranks
     from planarslam_amd.synth import TUM3, ba_problem
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    local_rank = pick_device(args, torch)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    ranks = Ranks(backend="nccl", device=dev)
+    ranks = Ranks(backend=args.backend, device=dev)
     rank, world = ranks.rank, ranks.world
     ctx = Context(local_rank)
     comm = None
-    if world > 1:
+    if world > 1 and args.backend == "nccl":
         box = [Communicator.unique_id() if rank == 0 else None]
         ranks.dist.broadcast_object_list(box, src=0, device=dev)
         comm = Communicator(ctx, box[0], world, rank)
+    elif world > 1:                                               # gloo: the exchange of ba.hip goes through the hosted transport (ranks may share a GPU)
+        from planarslam_amd import HostedCommunicator
+        comm = HostedCommunicator.torch(ctx)
     prob = ba_problem(seed=99)                                    # 2400 points + 500 line end points + 100 planes, 10 keyframes (2 fixed)
     mine = shard_problem(prob, rank, world) if world > 1 else prob
 
@@ -454,7 +518,7 @@ def main_ba(args):
             "config": {"workload": "BASELINE config[4]: local BA, 10 keyframes (2 fixed), 2400 map points + 250 lines + 100 planes, %d edges; landmarks partitioned over ranks" % E,
                        "keyframes": K, "landmark_vertices": L, "edges": E, "parallelism": "landmark-partition x%d" % world,
                        "exchange": {"per_trial": "A: %d doubles (Hpp|bp|chi2|S|b) + B: 3 doubles (chi2, scale, stop)" % exch_a, "bytes_A": exch_a * 8,
-                                    "transport": "RCCL all-reduce" if world > 1 else "none (single GPU)"}},
+                                    "transport": ("RCCL all-reduce" if args.backend == "nccl" else "hosted (gloo, host-staged)") if world > 1 else "none (single GPU)"}},
             "lm_iterations": int(res["lm_iters"]), "outlier_edges": int(res["e_outlier"].sum())}
     it_ms = elapsed / args.steps * 1e3 / max(1, int(res["lm_iters"]))
     line["roofline"] = {"bound": "hbm", "achieved": round(it_bytes / world / (it_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

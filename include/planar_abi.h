@@ -389,6 +389,10 @@ int planar_lsd_detect_dev(planar_lsd* lsd, int B, int max_lines, planar_keyline*
  * 2 visiting order int32 (returns n), 3 raw segments 40 B each {x1,y1,x2,y2 float; width,p,nfa double} (returns count),
  * 4 number of grown regions int32[1] */
 int planar_lsd_read_stage(planar_lsd* lsd, int frame, int stage, void* out, int64_t out_bytes);
+/* Per-launch timing with HIP events on the context stream (bench.py's roofline leg), as planar_peac_set_profiling: get_profile synchronises and returns the
+ * summed milliseconds of the recorded calls, total_ms[4] = preprocessing (blurs, gradient, Sobel), lsd_sort, lsd_detect, the rest, their number, and resets. */
+int planar_lsd_set_profiling(planar_lsd* lsd, int enable);
+int planar_lsd_get_profile(planar_lsd* lsd, double* total_ms, int64_t* calls);
 /* test hook: device emulation of libstdc++ std::sort with the sort_lines_by_response comparator (include/auxiliar.h:43-48) */
 int planar_debug_std_sort_desc(planar_ctx* ctx, float* keys, int32_t* perm, int n);
 

@@ -1628,6 +1628,13 @@ struct planar_lsd {
     int pre_B = 0;
     int tie_order = 0;   // 0: libstdc++ std::sort order inside a gradient bin (what the reference library produces), 1: raster order
     int sort_smem = 0;
+    // planar_lsd_set_profiling: HIP events around the launches of a recorded call; slots: preprocessing (two blurs, gradient, Sobel), lsd_sort, lsd_detect,
+    // the rest (improve, accept, KeyLines, LBD)
+    bool profiling = false;
+    std::vector<std::vector<hipEvent_t>> ev_sets;
+    size_t ev_used = 0;
+    std::vector<hipEvent_t>* ev_cur = nullptr;
+    ~planar_lsd() { for (auto& v : ev_sets) for (hipEvent_t e : v) (void)hipEventDestroy(e); }
 };
 
 // host mirrors of the oracle's coefficient tables (same expressions, same libm)
@@ -1756,12 +1763,24 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     uint8_t* ws = o->d_ws.as<uint8_t>();
     lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
     PLANAR_HIP_CHECK(hipMemsetAsync(dm, 0, sizeof(lsd::Misc) * (size_t)B, st));
+    o->ev_cur = nullptr;
+    if (o->profiling) {
+        if (o->ev_used == o->ev_sets.size()) {
+            std::vector<hipEvent_t> v(5);
+            for (hipEvent_t& e : v) PLANAR_HIP_CHECK(hipEventCreate(&e));
+            o->ev_sets.push_back(v);
+        }
+        o->ev_cur = &o->ev_sets[o->ev_used++];
+        (void)hipEventRecord((*o->ev_cur)[0], st);
+    }
     const dim3 gfull((P.W + 63) / 64, (P.H + 15) / 16, B);
     hipLaunchKernelGGL(lsd::lsd_gauss<7>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>(), ws, P.frame_bytes, P.off_blur7);
     hipLaunchKernelGGL(lsd::lsd_gauss<5>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>() + 8, ws, P.frame_bytes, P.off_blur5);
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
     hipLaunchKernelGGL(lsd::lbd_sobel, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, dP, ws);
+    if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[1], st);
     hipLaunchKernelGGL(lsd::lsd_sort, dim3(B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order);
+    if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[2], st);
     PLANAR_HIP_CHECK(hipGetLastError());
     o->pre_B = B;
     return PLANAR_OK;
@@ -1776,11 +1795,36 @@ int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d
     uint8_t* ws = o->d_ws.as<uint8_t>();
     lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
     hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, st, dP, ws, dm);
+    if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[3], st);
     hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm);
     hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm);
     hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines);
     hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
+    if (o->ev_cur) { (void)hipEventRecord((*o->ev_cur)[4], st); o->ev_cur = nullptr; }
     PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+// Per-launch HIP-event timing (bench.py's roofline leg), as planar_peac_set_profiling: slots preprocessing, lsd_sort, lsd_detect, the rest
+int planar_lsd_set_profiling(planar_lsd* o, int enable) {
+    PLANAR_REQUIRE(o != nullptr, PLANAR_EINVAL, "lsd is null");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
+    o->profiling = enable != 0;
+    o->ev_used = 0; o->ev_cur = nullptr;
+    return PLANAR_OK;
+}
+int planar_lsd_get_profile(planar_lsd* o, double* total_ms /* [4] */, int64_t* calls) {
+    PLANAR_REQUIRE(o && total_ms && calls, PLANAR_EINVAL, "null argument");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
+    for (int i = 0; i < 4; i++) total_ms[i] = 0;
+    for (size_t c = 0; c < o->ev_used; c++)
+        for (int i = 0; i < 4; i++) {
+            float ms = 0;
+            PLANAR_HIP_CHECK(hipEventElapsedTime(&ms, o->ev_sets[c][i], o->ev_sets[c][i + 1]));
+            total_ms[i] += ms;
+        }
+    *calls = (int64_t)o->ev_used;
+    o->ev_used = 0;
     return PLANAR_OK;
 }
 

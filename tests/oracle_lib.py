@@ -27,7 +27,9 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        # PLANAR_ORACLE_LIB: bench.py's cpu_baseline leg points this at oracle/liboracle_fast.so (-O3 -march=native, built on the box it is timed on);
+        # the tests always check against the -O2 build
+        path = os.environ.get("PLANAR_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

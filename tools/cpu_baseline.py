@@ -22,6 +22,36 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 W, H = 640, 480
 NPTS, NLINES, NPLANES = 1000, 75, 4
+FAST_LIB = os.path.join(ROOT, "oracle", "liboracle_fast.so")
+_BUILD = {"flags": "-O2 -ffp-contract=off (oracle/liboracle.so, the checker's build)", "lib": "oracle/liboracle.so"}
+
+
+def use_fast_build():
+    """Builds oracle/liboracle_fast.so with -O3 -march=native ON THIS MACHINE (SURVEY.md §8d's flags for the CPU leg) and makes oracle_lib load it in this
+    process and its workers.  Falls back to the checker's -O2 build (and says so in the line) when there is no compiler."""
+    import subprocess
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        os.environ["PLANAR_ORACLE_LIB"] = FAST_LIB
+        cxx = subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+        _BUILD.update(flags="-O3 -march=native -ffp-contract=off", lib="oracle/liboracle_fast.so (built on this box)", compiler=cxx)
+    except Exception as e:   # noqa: BLE001
+        _BUILD["note"] = f"liboracle_fast.so could not be built here ({type(e).__name__}): timed on the -O2 build"
+    return dict(_BUILD)
+
+
+def build_flags():
+    return dict(_BUILD)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def _inputs(seed, nsrc):
