@@ -52,7 +52,7 @@ struct Plan {
     double gaussCoefL[21], gaussCoefG[63];
 };
 
-struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; };
+struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int n_staged; int pad_; };
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2: 7th-order odd polynomial, degrees; plain mul/add (no FMA), see oracle/cvprim.cpp
@@ -438,7 +438,10 @@ __device__ __forceinline__ int wg_partition_rel(uint32_t* arr, uint16_t* Lb, uin
 }
 
 // ---- K3: the visiting order: descending 1024-bin order; ties per plan->tie_order ---------------------------------------------------
-__global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int tie_order) {
+// phase 0: the whole sort by one workgroup per frame (grid (1, B)).  phases 1 / 2 / 3 split it into three launches so that the LDS tier - the ranges of
+// <= SORT_STAGE elements are independent - runs on many workgroups per frame (grid (R, B): workgroup x takes ranges x, x + R, ...): a single frame (the
+// reference's one-camera operating point) then spends 0.3 instead of 4.9 ms there.  1: keys + global-memory tier, 2: LDS tier, 3: the two radix passes.
+__global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int tie_order, int phase) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     __shared__ int wsum[SORT_NW];
     __shared__ int s_ncur, s_nnext, s_nsmall, s_wl[SORT_NW], s_wr[SORT_NW], s_bc[4];
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ pla
     __shared__ short s_leaf[SORT_NW][SORT_SMALL / 16][3];
     int* cnt = (int*)sort_lds;                                  // [32 * SORT_NT] radix counters (passes A / B)
     const Plan& P = *plan;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
     const float* ang = (const float*)(F + P.off_ang);
     const uint32_t* g2a = (const uint32_t*)(F + P.off_g2);
@@ -459,18 +462,21 @@ __global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ pla
     const int w1 = P.w - 1, n = w1 * (P.h - 1);
     const double max_grad = misc->g2max ? sqrt(misc->g2max / 4.0) : -1.0;
     const double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
-    for (int i = tid; i < n; i += SORT_NT) {
-        const int y = i / w1, x = i - y * w1, pix = y * P.w + x;
-        arr[i] = ((uint32_t)int(sqrt(g2a[pix] / 4.0) * bin_coef) << 20) | (uint32_t)pix;
+    if (phase <= 1) {
+        for (int i = tid; i < n; i += SORT_NT) {
+            const int y = i / w1, x = i - y * w1, pix = y * P.w + x;
+            arr[i] = ((uint32_t)int(sqrt(g2a[pix] / 4.0) * bin_coef) << 20) | (uint32_t)pix;
+        }
+        __threadfence_block();
+        __syncthreads();
     }
-    __threadfence_block();
-    __syncthreads();
     long long ts0 = __builtin_readcyclecounter(), ts1 = ts0, ts2 = ts0;
-    if (tie_order == 0 && n > 16) {
-        const int cap = n / 17 + 16;
+    const int cap = n / 17 + 16;
+    SortRange* staged = (SortRange*)(F + P.off_reg) + 2 * cap;
+    if (phase <= 1 && tid == 0) { s_nsmall = 0; }
+    if (tie_order == 0 && n > 16 && phase <= 1) {
         SortRange* cur = (SortRange*)(F + P.off_reg);
         SortRange* next = cur + cap;
-        SortRange* staged = next + cap;
         if (tid == 0) { int lg = 0; for (int t = n; t > 1; t >>= 1) lg++; cur[0] = SortRange{0, n, 2 * lg}; s_ncur = 1; s_nnext = 0; s_nsmall = 0; }
         __syncthreads();
         // tier 1: ranges too large for LDS, partitioned in global memory by the whole workgroup, one recursion level per iteration
@@ -492,13 +498,21 @@ __global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ pla
             __syncthreads();
         }
         ts1 = __builtin_readcyclecounter();
+    }
+    if (phase == 1) {
+        __syncthreads();
+        if (tid == 0) { misc->n_staged = s_nsmall; misc->t[5] = ts1 - ts0; }
+        return;
+    }
+    if (tie_order == 0 && n > 16 && phase != 3) {
         // tier 2: a range of <= 16384 elements is staged in LDS once and its whole recursion finished there:
         //   > SORT_SMALL: workgroup partitions;  <= SORT_SMALL: one wavefront per sub-range (ballot partitions);  <= 64: one LANE per sub-range.
         uint32_t* sbuf = (uint32_t*)sort_lds;
         uint16_t* Ls = (uint16_t*)(sbuf + SORT_STAGE);
         uint16_t* Rs = Ls + SORT_STAGE;
-        const int nstaged = s_nsmall;
-        for (int sr = 0; sr < nstaged; sr++) {
+        __syncthreads();
+        const int nstaged = phase == 0 ? s_nsmall : misc->n_staged;
+        for (int sr = phase == 0 ? 0 : (int)blockIdx.x; sr < nstaged; sr += phase == 0 ? 1 : (int)gridDim.x) {
             const SortRange R = staged[sr];
             const int sz = R.l - R.f;
             for (int i = tid; i < sz; i += SORT_NT) sbuf[i] = arr[R.f + i];
@@ -590,6 +604,7 @@ __global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ pla
         __syncthreads();
     }
     ts2 = __builtin_readcyclecounter();
+    if (phase == 2) { if (tid == 0 && blockIdx.x == 0) misc->t[6] = ts2 - ts1; return; }
     // __final_insertion_sort == stable sort of the current arrangement by descending bin: two 5-bit LSD radix passes.  Every wavefront owns
     // a contiguous part of the array and walks it 64 elements at a time (coalesced); the rank of an element among the equal digits of its
     // chunk is a popcount over the match mask built from five ballots, the running (digit, wavefront) counters live in LDS.  Order inside
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ pla
         [&](uint32_t e) { return (int)((e >> 25) & 31); },
         [&](uint32_t) { return true; },
         [&](uint32_t e, int i, int pos) { ord[pos] = e & 0xfffffu; ordr[pos] = (uint32_t)i; });
-    if (tid == 0) { misc->n_ord = N; misc->t[5] = ts1 - ts0; misc->t[6] = ts2 - ts1; misc->t[7] = __builtin_readcyclecounter() - ts2; }
+    if (tid == 0) { misc->n_ord = N; if (phase == 0) { misc->t[5] = ts1 - ts0; misc->t[6] = ts2 - ts1; } misc->t[7] = __builtin_readcyclecounter() - ts2; }
 }
 
 // ---- K4: the sequential detector, one wavefront per frame -----------------------------------------------------------
@@ -1779,7 +1794,14 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
     hipLaunchKernelGGL(lsd::lbd_sobel, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, dP, ws);
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[1], st);
-    hipLaunchKernelGGL(lsd::lsd_sort, dim3(B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order);
+    if (o->tie_order != 0)
+        hipLaunchKernelGGL(lsd::lsd_sort, dim3(1, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 0);
+    else {   // three launches: the LDS tier of a frame spreads over R workgroups (ranges are independent)
+        const int R = B <= 16 ? 128 : (B <= 256 ? 16 : 4);
+        hipLaunchKernelGGL(lsd::lsd_sort, dim3(1, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 1);
+        hipLaunchKernelGGL(lsd::lsd_sort, dim3(R, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 2);
+        hipLaunchKernelGGL(lsd::lsd_sort, dim3(1, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 3);
+    }
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[2], st);
     PLANAR_HIP_CHECK(hipGetLastError());
     o->pre_B = B;
