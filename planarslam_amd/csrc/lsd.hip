@@ -1794,10 +1794,10 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
     hipLaunchKernelGGL(lsd::lbd_sobel, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, dP, ws);
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[1], st);
-    if (o->tie_order != 0)
+    if (o->tie_order != 0 || B > 256)   // a large batch fills the device with one workgroup per frame: one launch (the split measures 3 % slower at B = 1024)
         hipLaunchKernelGGL(lsd::lsd_sort, dim3(1, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 0);
     else {   // three launches: the LDS tier of a frame spreads over R workgroups (ranges are independent)
-        const int R = B <= 16 ? 128 : (B <= 256 ? 16 : 4);
+        const int R = B <= 16 ? 128 : 16;
         hipLaunchKernelGGL(lsd::lsd_sort, dim3(1, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 1);
         hipLaunchKernelGGL(lsd::lsd_sort, dim3(R, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 2);
         hipLaunchKernelGGL(lsd::lsd_sort, dim3(1, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 3);
