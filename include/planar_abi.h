@@ -482,8 +482,11 @@ typedef struct planar_ba_result {
 } planar_ba_result;
 
 /* its1 = 5, its2 = 10 reproduce the reference.  `params` supplies fx, fy, cx, cy, bf and the Plane.* configuration.
- * stop_flag (or NULL) is the reference's `bool* pbStopFlag` (one byte, polled while the solve runs; with several ranks the decision is taken on the
- * all-reduced value).  comm may be NULL (single GPU).  Synchronous. */
+ * stop_flag (or NULL) is the reference's `bool* pbStopFlag` (one byte; the host samples it when LM steps are enqueued - with a flag at most two steps per chunk, so
+ * a flag raised while the GPU is solving is seen at most two LM steps later - and once more between optimize(its1) and optimize(its2), as the reference's bDoMore
+ * does; with several ranks every decision is taken on the all-reduced value).  comm may be NULL (single GPU).  Synchronous.
+ * Non-fixed key frames: any number up to 128 (PLANAR_ECAPACITY above); up to 20 the reduced camera system stays in LDS, above that it is accumulated and
+ * factorised in global memory (slower per LM step, same results): Optimizer::LocalBundleAdjustment has no cap on the covisible key frames. */
 int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* problem, const planar_pose_params* params, int its1, int its2,
                     planar_ba_result* result, const volatile unsigned char* stop_flag, planar_comm* comm);
 
@@ -669,6 +672,25 @@ int planar_pose_assemble_dev(planar_ctx* ctx, const planar_track_matches* d_matc
 int planar_discard_outliers(planar_ctx* ctx, int B, const int32_t* n, int stride, int flag_stride, int32_t* match, uint8_t* outlier, int32_t* kept);
 int planar_discard_outliers_dev(planar_ctx* ctx, int B, const int32_t* d_n, int stride, int flag_stride, int32_t* d_match, uint8_t* d_outlier,
                                 int32_t* d_kept);
+
+/* ---- element-wise glue between the stages of Tracking::Track (src/Tracking.cc:240-253, 1739-1790, 1954-2040), enqueue-only on the context's stream: with these a
+ *      host drives the whole per-frame chain through this header alone (planarslam_amd/track.py launches nothing else inside the timed region).
+ *   reset_matches      fill(mvpMapPoints.begin(), mvpMapPoints.end(), NULL): every entry -1
+ *   blocked_mask       mask[i] = match[i] >= 0                       (key points / lines that already have a map point are skipped by SearchByProjection)
+ *   merge_matches      out = first >= 0 ? first : (second >= 0 ? second + offset : second)   (one index space for PoseOptimization: [last frame | older frame])
+ *   manhattan_pose     Tcw_out = Tcw_in with its rotation block replaced by mRotation_wc = (Rotation_cm * MF_can^T)^T (:250-253), as :1778 does before
+ *                      TranslationOptimization; Rcm_new = TrackManhattanFrame's result, Rcm0 = the stream's Rotation_cm; [B][9] / [B][16] row-major float32
+ *   keypoint_fields    KeyPoint::octave / ::angle of n key points into flat arrays
+ *   add_scalar_i32     dst = src + value (per-line rand() seeds of Frame::isLineGood: base + step offset)
+ *   copy_rows          pitched device-to-device row copy */
+int planar_reset_matches_dev(planar_ctx* ctx, int32_t* d_match, int64_t n);
+int planar_blocked_mask_dev(planar_ctx* ctx, const int32_t* d_match, int64_t n, uint8_t* d_mask);
+int planar_merge_matches_dev(planar_ctx* ctx, const int32_t* d_first, const int32_t* d_second, int offset, int64_t n, int32_t* d_out);
+int planar_manhattan_pose_dev(planar_ctx* ctx, int B, const float* d_Rcm_new, const float* d_Rcm0, const float* d_Tcw_in, float* d_Tcw_out);
+int planar_keypoint_fields_dev(planar_ctx* ctx, const planar_keypoint* d_keys, int64_t n, int32_t* d_octave, float* d_angle);
+int planar_add_scalar_i32_dev(planar_ctx* ctx, const int32_t* d_src, int64_t n, int32_t value, int32_t* d_dst);
+int planar_copy_rows_dev(planar_ctx* ctx, void* d_dst, int64_t dst_pitch, const void* d_src, int64_t src_pitch, int64_t row_bytes, int64_t rows);
+
 
 #ifdef __cplusplus
 }

@@ -73,7 +73,7 @@ public:
         auto it = clouds_.find({w, h});
         if (it != clouds_.end()) return it->second;
         planar_plane_clouds* o = nullptr;
-        if (planar_plane_clouds_create(lanes_[PLANES].ctx, w, h, 1, 4096, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        if (planar_plane_clouds_create(lanes_[PLANES].ctx, w, h, 1, 8192, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());   // 8192 voxels of 0.1 m: ~80 m2 of planar surface per frame
         return clouds_[{w, h}] = o;
     }
     void set_device(int d) { device_ = d; }
@@ -244,7 +244,7 @@ public:
     // CloudT: pcl::PointCloud<pcl::PointXYZRGB> or anything with a `points` vector whose elements have float x, y, z.  Returns mnPlaneNum.
     template <class CloudT>
     int ComputePlaneClouds(double disTh, std::vector<CloudT>& planePoints, std::vector<cv::Mat>& planeCoefficients, float leaf = 0.1f) {
-        const int W = cloud.w, H = cloud.h, PS = planar_peac_max_planes(), MP = 4096;
+        const int W = cloud.w, H = cloud.h, PS = planar_peac_max_planes(), MP = 8192;
         std::vector<float> coef((size_t)PS * 4), pts((size_t)MP * 3);
         std::vector<int32_t> src(PS), off(PS + 1);
         int32_t n_in = plane_num_, n_out = 0;
@@ -252,9 +252,16 @@ public:
             planar_adapter::Runtime& R = planar_adapter::Runtime::get();
             planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::PLANES);
             std::lock_guard<std::mutex> g(L.mu);
-            planar_adapter::check(planar_plane_clouds_compute(R.clouds(W, H), (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_,
-                                                              cx_, cy_, factor_, labels_.data(), planes_.data(), &n_in, disTh, leaf, &n_out, coef.data(), src.data(), off.data(),
-                                                              pts.data(), nullptr, nullptr, nullptr));
+            const int rc = planar_plane_clouds_compute(R.clouds(W, H), (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_,
+                                                       cx_, cy_, factor_, labels_.data(), planes_.data(), &n_in, disTh, leaf, &n_out, coef.data(), src.data(), off.data(),
+                                                       pts.data(), nullptr, nullptr, nullptr);
+            if (rc == PLANAR_ECAPACITY) {
+                // pcl::VoxelGrid has no cap; the kernel's voxel table has (8192 per frame).  This runs on the thread Frame's constructor spawned for ComputePlanes:
+                // an exception here would end in std::terminate, so a frame that overflows tracks without planes and says so.
+                std::fprintf(stderr, "planar: frame with more than %d plane voxels: its planes are dropped (%s)\n", MP, planar_last_error());
+                return 0;
+            }
+            planar_adapter::check(rc);
         }
         for (int k = 0; k < n_out; k++) {
             CloudT c;

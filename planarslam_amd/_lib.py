@@ -157,6 +157,13 @@ _SIGS = {
     "planar_track_manhattan_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_track_manhattan_frame_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_peac_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "planar_reset_matches_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "planar_blocked_mask_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "planar_merge_matches_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "planar_manhattan_pose_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_keypoint_fields_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "planar_add_scalar_i32_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "planar_copy_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     "planar_peac_debug_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "planar_peac_debug_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "planar_comm_unique_id": (C.c_int, [C.c_void_p]),

@@ -42,7 +42,8 @@ using namespace geomd;
 
 enum { BE_MONO = 0, BE_STEREO = 1, BE_LINE = 2, BE_PLANE = 3, BE_VER = 4, BE_PAR = 5 };
 constexpr int NT = 256;
-constexpr int MAX_NP = 20;          // non-fixed keyframes (reduced system <= 120 x 120 in LDS)
+constexpr int MAX_NP_LDS = 20;      // up to this many non-fixed keyframes the reduced system (<= 120 x 120 doubles) is accumulated and factorised in LDS;
+constexpr int MAX_NP = 128;         // above it (up to here) the same kernels work on a global-memory scratch: slower, but Optimizer::LocalBundleAdjustment has no cap
 
 struct Cam { double fx, fy, cx, cy, bf; };
 
@@ -66,6 +67,7 @@ struct Dev {
     double* red2;                            // exchange buffer A, second part (contiguous with redg): [NP*NP Schur terms | NP rhs terms]
     double* trial;                           // exchange buffer B: [chi2 at the trial state, landmark part of computeScale(), stop]
     double* xp;                              // [NP] + [NP] ok flag / pose scale at the end
+    double* bigA;                            // [NP*NP + NP] factorisation scratch when np > MAX_NP_LDS (nullptr otherwise: LDS)
     double* scal;                            // [0] max |diag Hll|, [1] stop  (MAX over ranks, first trial of an optimize() only)
     struct LmState* st;
     Cam cam;
@@ -325,10 +327,12 @@ __global__ __launch_bounds__(NT) void ba_dinv(Dev D) {
 
 // thread = EDGE e of landmark l: row block p(e) of the Schur terms, S[p][q(f)] -= W_e Dinv W_f^T for every edge f of l, b[p] -= W_e Dinv bl
 __global__ __launch_bounds__(NT) void ba_schur(Dev D) {
-    extern __shared__ __attribute__((aligned(16))) double s_S[];    // [NP*NP + NP]
+    extern __shared__ __attribute__((aligned(16))) double s_lds[];  // [NP*NP + NP] (np <= MAX_NP_LDS)
     if (D.st->done) return;
     const int NP = 6 * D.np, tot = NP * NP + NP;
-    for (int i = threadIdx.x; i < tot; i += NT) s_S[i] = 0;
+    const bool big = D.bigA != nullptr;                              // too large for LDS: the terms go straight to the exchange buffer
+    double* s_S = big ? D.red2 : s_lds;
+    if (!big) { for (int i = threadIdx.x; i < tot; i += NT) s_S[i] = 0; }
     __syncthreads();
     const int e = blockIdx.x * NT + threadIdx.x;
     if (e < D.E && D.e_level[e] == 0) {
@@ -354,15 +358,16 @@ __global__ __launch_bounds__(NT) void ba_schur(Dev D) {
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < tot; i += NT) { const double v = s_S[i]; if (v != 0) atomicAdd(&D.red2[i], v); }
+    if (!big) for (int i = threadIdx.x; i < tot; i += NT) { const double v = s_S[i]; if (v != 0) atomicAdd(&D.red2[i], v); }
 }
 
 // One workgroup: A = blockdiag(Hpp) + lambda I + Schur terms, rhs = bp + Schur rhs; dense Cholesky in LDS.
 __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
-    extern __shared__ __attribute__((aligned(16))) double s_A[];    // [NP*NP] + x[NP]
+    extern __shared__ __attribute__((aligned(16))) double s_ldsA[];  // [NP*NP] + x[NP] (np <= MAX_NP_LDS)
     __shared__ int s_ok;
     if (D.st->done) return;
     const int NP = 6 * D.np, tid = threadIdx.x;
+    double* s_A = D.bigA ? D.bigA : s_ldsA;                          // one workgroup either way: __syncthreads orders its global accesses too
     if (tid == 0 && D.st->need_build) {      // the step opened an LM iteration: chi2(x) summed over ranks has just arrived
         LmState& S = *D.st;
         S.currentChi = S.iniChi = D.redg[(size_t)D.np * 36 + NP];
@@ -618,7 +623,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     std::vector<int> pidx(K, -1);
     int np = 0;
     for (int k = 0; k < K; k++) if (!P->kf_fixed[k]) pidx[k] = np++;
-    PLANAR_REQUIRE(np <= MAX_NP, PLANAR_EINVAL, "more than 20 non-fixed keyframes");
+    PLANAR_REQUIRE(np <= MAX_NP, PLANAR_ECAPACITY, "more than 128 non-fixed keyframes");
     const int NP = 6 * np;
     for (int e = 0; e < E; e++) PLANAR_REQUIRE(P->e_kf[e] >= 0 && P->e_kf[e] < K && P->e_lm[e] >= 0 && P->e_lm[e] < L && P->e_type[e] <= BE_PAR, PLANAR_EINVAL, "edge index out of range");
 
@@ -694,7 +699,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
                  oLt = carve(L), oLs = carve((size_t)(L + 1) * 4), oEk = carve((size_t)E * 4), oEt = carve(E), oEp = carve((size_t)E * 4),
                  oEm = carve((size_t)E * 32), oEi = carve((size_t)E * 32), oEe = carve((size_t)E * 24), oEl = carve(E), oEo = carve(E),
                  oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oDi = carve((size_t)L * 72), oW = carve((size_t)E * 144), oHe = carve((size_t)E * 96), oXl = carve((size_t)L * 24),
-                 oR = carve(nred * 8), oA = carve(nA * 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8), oSc = carve(64), oSt = carve(sizeof(LmState));
+                 oR = carve(nred * 8), oA = carve(nA * 8), oBig = carve(np > MAX_NP_LDS ? nS * 8 : 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8), oSc = carve(64), oSt = carve(sizeof(LmState));
     DevBuf buf;
     int rc = buf.alloc(off);
     if (rc) return rc;
@@ -713,9 +718,10 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     D.Hll = (double*)(base + oH); D.bl = (double*)(base + oB); D.Dinv = (double*)(base + oDi); D.W = (double*)(base + oW); D.He = (double*)(base + oHe); D.xl = (double*)(base + oXl);
     D.red = (double*)(base + oR); D.redg = (double*)(base + oA); D.red2 = D.redg + nred; D.trial = (double*)(base + oTr); D.xp = (double*)(base + oXp);
     D.scal = (double*)(base + oSc); D.st = (LmState*)(base + oSt);
+    D.bigA = np > MAX_NP_LDS ? (double*)(base + oBig) : nullptr;
     D.cam = Cam{(double)prm->fx, (double)prm->fy, (double)prm->cx, (double)prm->cy, (double)prm->bf};
 
-    const size_t smem_schur = ((size_t)NP * NP + NP) * 8, smem_solve = ((size_t)NP * NP + NP) * 8, smem_build = (size_t)np * 42 * 8;
+    const size_t smem_schur = np > MAX_NP_LDS ? 0 : ((size_t)NP * NP + NP) * 8, smem_solve = smem_schur, smem_build = (size_t)np * 42 * 8;
     if (smem_schur > 48 * 1024) {
         PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_schur));
         PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_solve));
@@ -787,7 +793,9 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
         const int max_steps = iterations * 10;
         int steps = 0;
         while (steps < max_steps) {
-            const int chunk = std::min(max_steps - steps, steps == 0 ? iterations : 4);      // the common case (every first trial accepted) is ONE chunk
+            // without a stop flag the common case (every first trial accepted) is ONE chunk; with one the host samples it between chunks of two LM
+            // steps (a flag raised while the GPU is solving is seen at most two steps later, as g2o polls it once per iteration)
+            const int chunk = std::min(max_steps - steps, stop_flag ? 2 : (steps == 0 ? iterations : 4));
             for (int i = 0; i < chunk; i++) { if ((r = enqueue_step(robust, opened))) return r; opened = false; }
             steps += chunk;
             PLANAR_HIP_CHECK(hipMemcpyAsync(&h, D.st, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -801,6 +809,15 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     };
 
     if ((rc = optimize(its1, 1))) return rc;                                                           // :2354-2355
+    if (!stopped && stop_flag) {   // bDoMore: the reference reads *pbStopFlag again after optimize(5) (:2357-2361); every rank must take the same branch
+        const double s1[2] = {0.0, (double)stop_now()};
+        double s2[2] = {0, 0};
+        PLANAR_HIP_CHECK(hipMemcpyAsync(D.scal, s1, 16, hipMemcpyHostToDevice, st));
+        if ((rc = allreduce(D.scal, 2, NCCL_MAX))) return rc;
+        PLANAR_HIP_CHECK(hipMemcpyAsync(s2, D.scal, 16, hipMemcpyDeviceToHost, st));
+        PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+        if (s2[1] != 0) stopped = true;
+    }
     if (!stopped) {
         if (E) hipLaunchKernelGGL(ba_classify, gE, dim3(NT), 0, st, D, 0, prm->plane_chi, prm->vp_chi);     // :2363-2462
         if ((rc = optimize(its2, 0))) return rc;                                                       // :2466-2467

@@ -191,13 +191,52 @@ __global__ __launch_bounds__(256) void normal_depth_kernel(const int32_t* __rest
 #pragma unroll
     for (int k = 0; k < 3; k++) { const float pc = pos[k] - Ow[k]; s += (double)pc * (double)pc; }
     const float dist = (float)sqrt(s);
-    const int level = keys_un[o].octave;
+    const int level = min(max(keys_un[o].octave, 0), S.n_levels - 1);   // as assemble_kernel: an octave outside the pyramid must not index past the table
     const float mx = dist * S.sf[level];
     max_dist[o] = mx;
     min_dist[o] = mx / S.sf[S.n_levels - 1];
     const float fn = (float)(1.0 / (double)nobs);
 #pragma unroll
     for (int k = 0; k < 3; k++) normal[o * 3 + k] = nrm[k] * fn;
+}
+
+
+// ---- the small element-wise steps between the stages of Tracking::Track, so that a host driving the chain through the C ABI launches nothing else ----
+// (they were PyTorch element-wise kernels in planarslam_amd/track.py: a C++ host using the ABI had no equivalent)
+__global__ void blocked_mask_kernel(const int32_t* __restrict__ match, int64_t n, uint8_t* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mask[i] = match[i] >= 0 ? 1 : 0;
+}
+// one index space for the optimiser: out = first >= 0 ? first : (second >= 0 ? second + offset : second)     (TrackLocalMap: [last frame's points | the older frame's])
+__global__ void merge_matches_kernel(const int32_t* __restrict__ first, const int32_t* __restrict__ second, int offset, int64_t n, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int a = first[i], b = second[i]; out[i] = a >= 0 ? a : (b >= 0 ? b + offset : b); }
+}
+// mRotation_wc = (Rotation_cm * MF_can^T)^T copied into mCurrentFrame.mTcw's rotation block before TranslationOptimization (src/Tracking.cc:250-253, 1778):
+// R_cw = MF_can * Rotation_cm^T with MF_can = TrackManhattanFrame's result for this frame and Rotation_cm the stream's rotation at initialisation; cv::Mat float products
+__global__ void manhattan_pose_kernel(int B, const float* __restrict__ Rcm_new, const float* __restrict__ Rcm0, const float* __restrict__ Tcw_in, float* __restrict__ Tcw_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* A = Rcm_new + 9 * b; const float* R0 = Rcm0 + 9 * b; const float* Ti = Tcw_in + 16 * b; float* To = Tcw_out + 16 * b;
+    float T[16];
+    for (int k = 0; k < 16; k++) T[k] = Ti[k];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            // (Rotation_cm * MF_can^T)(c, r) = sum_k Rotation_cm(c, k) * MF_can(r, k), accumulated in double as cv::gemm does for small float matrices, then transposed
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += (double)R0[3 * c + k] * (double)A[3 * r + k];
+            T[4 * r + c] = (float)acc;
+        }
+    for (int k = 0; k < 16; k++) To[k] = T[k];
+}
+// KeyPoint::octave / angle of every key point into the flat per-stream history arrays (the "last frame" the next step projects from)
+__global__ void keypoint_fields_kernel(const planar_keypoint* __restrict__ keys, int64_t n, int32_t* __restrict__ octave, float* __restrict__ angle) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { octave[i] = keys[i].octave; angle[i] = keys[i].angle; }
+}
+__global__ void add_scalar_kernel(const int32_t* __restrict__ src, int64_t n, int32_t value, int32_t* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + value;
 }
 
 }  // namespace frame
@@ -249,6 +288,49 @@ int planar_discard_outliers_dev(planar_ctx* ctx, int B, const int32_t* d_n, int 
     PLANAR_REQUIRE(B >= 1 && stride >= 1 && flag_stride >= 1, PLANAR_EINVAL, "bad size");
     hipLaunchKernelGGL(frame::discard_kernel, dim3(B), dim3(256), 0, ctx->stream, d_n, stride, flag_stride, d_match, d_outlier, d_kept);
     PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+// ---- glue of the tracking chain (see the kernels): enqueue-only on the context's stream ----
+int planar_reset_matches_dev(planar_ctx* ctx, int32_t* d_match, int64_t n) {       // every entry -1 (fill(mvpMapPoints.begin(), mvpMapPoints.end(), NULL))
+    PLANAR_REQUIRE(ctx && d_match && n >= 0, PLANAR_EINVAL, "bad argument");
+    PLANAR_HIP_CHECK(hipMemsetAsync(d_match, 0xFF, (size_t)n * 4, ctx->stream));
+    return PLANAR_OK;
+}
+int planar_blocked_mask_dev(planar_ctx* ctx, const int32_t* d_match, int64_t n, uint8_t* d_mask) {
+    PLANAR_REQUIRE(ctx && d_match && d_mask && n >= 1, PLANAR_EINVAL, "bad argument");
+    hipLaunchKernelGGL(frame::blocked_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_match, n, d_mask);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+int planar_merge_matches_dev(planar_ctx* ctx, const int32_t* d_first, const int32_t* d_second, int offset, int64_t n, int32_t* d_out) {
+    PLANAR_REQUIRE(ctx && d_first && d_second && d_out && n >= 1, PLANAR_EINVAL, "bad argument");
+    hipLaunchKernelGGL(frame::merge_matches_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_first, d_second, offset, n, d_out);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+int planar_manhattan_pose_dev(planar_ctx* ctx, int B, const float* d_Rcm_new, const float* d_Rcm0, const float* d_Tcw_in, float* d_Tcw_out) {
+    PLANAR_REQUIRE(ctx && d_Rcm_new && d_Rcm0 && d_Tcw_in && d_Tcw_out && B >= 1, PLANAR_EINVAL, "bad argument");
+    hipLaunchKernelGGL(frame::manhattan_pose_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, B, d_Rcm_new, d_Rcm0, d_Tcw_in, d_Tcw_out);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+int planar_keypoint_fields_dev(planar_ctx* ctx, const planar_keypoint* d_keys, int64_t n, int32_t* d_octave, float* d_angle) {
+    PLANAR_REQUIRE(ctx && d_keys && d_octave && d_angle && n >= 1, PLANAR_EINVAL, "bad argument");
+    hipLaunchKernelGGL(frame::keypoint_fields_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_keys, n, d_octave, d_angle);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+int planar_add_scalar_i32_dev(planar_ctx* ctx, const int32_t* d_src, int64_t n, int32_t value, int32_t* d_dst) {
+    PLANAR_REQUIRE(ctx && d_src && d_dst && n >= 1, PLANAR_EINVAL, "bad argument");
+    hipLaunchKernelGGL(frame::add_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_src, n, value, d_dst);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+// rows of `row_bytes` bytes from a pitched source into a pitched destination (history buffers, the [last | older] concatenation of the local map)
+int planar_copy_rows_dev(planar_ctx* ctx, void* d_dst, int64_t dst_pitch, const void* d_src, int64_t src_pitch, int64_t row_bytes, int64_t rows) {
+    PLANAR_REQUIRE(ctx && d_dst && d_src && row_bytes >= 1 && rows >= 1 && dst_pitch >= row_bytes && src_pitch >= row_bytes, PLANAR_EINVAL, "bad argument");
+    PLANAR_HIP_CHECK(hipMemcpy2DAsync(d_dst, (size_t)dst_pitch, d_src, (size_t)src_pitch, (size_t)row_bytes, (size_t)rows, hipMemcpyDeviceToDevice, ctx->stream));
     return PLANAR_OK;
 }
 
@@ -344,7 +426,7 @@ int planar_update_normal_and_depth(planar_ctx* ctx, int G, const int32_t* n, int
                                    const planar_keypoint* keys_un, const int32_t* obs_off, const float* obs_ow, const float* scale_factors, int n_levels, float* normal,
                                    float* min_dist, float* max_dist) {
     PLANAR_REQUIRE(ctx && n && xw && ref_Tcw && keys_un && scale_factors && normal && min_dist && max_dist, PLANAR_EINVAL, "null argument");
-    PLANAR_REQUIRE(G >= 1 && stride >= 1, PLANAR_EINVAL, "bad size");
+    PLANAR_REQUIRE(G >= 1 && stride >= 1 && n_levels >= 1 && n_levels <= PLANAR_MAX_LEVELS, PLANAR_EINVAL, "bad size");
     PLANAR_REQUIRE((obs_off == nullptr) == (obs_ow == nullptr), PLANAR_EINVAL, "obs_off and obs_ow go together");
     PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t N = (size_t)G * stride;

@@ -103,6 +103,8 @@ class TrackPipeline:
         self.pose = t.eye(4, dtype=t.float32, device=self.dev).reshape(1, 16).repeat(B, 1).contiguous()
         self.pose0 = self.pose.clone()          # ComputeStereoFromRGBD at extraction time needs no pose (its world points are discarded)
         self.Rcm = t.eye(3, dtype=t.float32, device=self.dev).reshape(1, 9).repeat(B, 1).contiguous()
+        self.Rcm0 = self.Rcm.clone()                 # Rotation_cm: the stream's camera-to-Manhattan rotation at initialisation (set_map)
+        self.pose_mf = self.pose.clone()             # the pose TranslationOptimization starts from: last pose with the Manhattan rotation of this frame
         self.ones_S = t.ones((B, S), dtype=t.uint8, device=self.dev)
         self.zeros_S = z((B, S), t.uint8)
         # ---- match / optimiser buffers (one set: the tracking chains run in step order on one stream) ----
@@ -159,6 +161,7 @@ class TrackPipeline:
                        n_lines=up(normals["n_lines"], np.int32))
         if normals.get("R_last") is not None:
             self.Rcm = up(np.asarray(normals["R_last"], np.float32).reshape(self.B, 9), np.float32)
+            self.Rcm0 = self.Rcm.clone()
         self.plane_th = np.array([0.1, 0.86, 0.08716, 0.9962], np.float32)      # include/PlaneMatcher.h:19
         self.map_set = True
 
@@ -225,8 +228,7 @@ class TrackPipeline:
             check(L.planar_lsd_detect_dev(self.lss[k].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
         # Frame::ExtractLSD: isLineGood right behind ExtractLineSegment, same thread; every (stream, step, line) has its own rand() seed
         l3 = self.l3[k]
-        with t.cuda.stream(sl):
-            t.add(self.seed_base, (i * B * 64) & 0x3fffffff, out=l3["seeds"])
+        check(L.planar_add_scalar_i32_dev(self.ctx_lsds[k].h, self.seed_base.data_ptr(), self.seed_base.numel(), (i * B * 64) & 0x3fffffff, l3["seeds"].data_ptr()))
         c = self.cam
         check(L.planar_is_line_good_dev(self.ctx_lsds[k].h, B, self.kls[k].data_ptr(), self.nl[k].data_ptr(), 40, depth.data_ptr(), self.W, self.H, self.W, self.W * self.H,
                                         float(np.float32(1.0 / 5000.0)), c["fx"], c["fy"], c["cx"], c["cy"], l3["seeds"].data_ptr(), l3["depth_line"].data_ptr(),
@@ -287,29 +289,31 @@ class TrackPipeline:
             lv.stride = S
             lv.n, lv.Tcw, lv.usable, lv.xw = self.h_n[l].data_ptr(), self.pose.data_ptr(), self.h_valid[l].data_ptr(), self.h_xw[l].data_ptr()
             lv.octave, lv.angle, lv.mp_desc, lv.mp_observed = self.h_oct[l].data_ptr(), self.h_ang[l].data_ptr(), self.h_desc[l].data_ptr(), self.ones_S.data_ptr()
-            self.pm.fill_(-1)
+            check(L.planar_reset_matches_dev(self.ctx_t.h, self.pm.data_ptr(), self.pm.numel()))
             check(L.planar_search_by_projection_frame_dev(self.ctx_t.h, C.byref(fv), C.byref(lv), 15.0, 0, 1, self.pm.data_ptr(), self.nm.data_ptr()))
             if evs: evs["proj"].record(st)
             if cap is not None: snap("pm0", self.pm); snap("nm", self.nm)
-            self.lm.fill_(-1)
+            check(L.planar_reset_matches_dev(self.ctx_t.h, self.lm.data_ptr(), self.lm.numel()))
             check(L.planar_lsd_search_by_descriptor_dev(self.ctx_t.h, self.kf["ldesc"].data_ptr(), self.kf["n"].data_ptr(), 40, self.ldesc[k].data_ptr(), self.nl[k].data_ptr(), 40,
                                                         self.kf["has_ml"].data_ptr(), B, self.lm.data_ptr(), self.nlm.data_ptr()))
             if self.run_fallback_matcher:
-                self.cm2.fill_(-1)
+                check(L.planar_reset_matches_dev(self.ctx_t.h, self.cm2.data_ptr(), self.cm2.numel()))
                 check(L.planar_match_orb_points_dev(self.ctx_t.h, self.desc[k].data_ptr(), self.n[k].data_ptr(), S, self.h_desc[l].data_ptr(), self.h_n[l].data_ptr(), S,
                                                     self.h_valid[l].data_ptr(), self.zeros_S.data_ptr(), B, self.cm2.data_ptr(), self.npair.data_ptr()))
             if evs: evs["bf"].record(st)
             if cap is not None: snap("lm0", self.lm); snap("nlm0", self.nlm); snap("cm2", self.cm2); snap("npair", self.npair)
             # mvPlaneCoefficients / mnPlaneNum: the refitted coefficients of the planes Frame::ComputePlanes kept (planepost.hip, on the plane stream)
             pc = self.pc[k]
-            self.plm.fill_(-1)
+            check(L.planar_reset_matches_dev(self.ctx_t.h, self.plm.data_ptr(), self.plm.numel()))
             check(L.planar_plane_search_by_coefficients_dev(self.ctx_t.h, B, pc["n"].data_ptr(), self.PS, pc["coef"].data_ptr(), self.pose.data_ptr(), 0,
                                                             self.mp["n"].data_ptr(), self.mp["coef"].shape[1], self.mp["valid"].data_ptr(), self.mp["coef"].data_ptr(),
                                                             self.mp["npts"].data_ptr(), self.mp["pts"].shape[2], self.mp["pts"].data_ptr(), self.plane_th.ctypes.data,
                                                             self.plm[0].data_ptr(), self.plm[2].data_ptr(), self.plm[1].data_ptr(), self.nplm.data_ptr()))
             if evs: evs["planes"].record(st)
             if cap is not None: snap("pl_coef", pc["coef"]); snap("pl_n", pc["n"]); snap("pl_src", pc["src"]); snap("pl_off", pc["off"]); snap("pl_pts", pc["pts"]); snap("pl_status", pc["status"]); snap("plm", self.plm); snap("nplm", self.nplm); snap("Rcm_new", self.Rcm_new)
-            self._assemble(0, k, self.pm, self.h_xw[l], self.h_valid[l], S, self.pose)
+            # mRotation_wc.copyTo(mCurrentFrame.mTcw.rowRange(0,3).colRange(0,3)) (:1778): the translation is optimised against the Manhattan rotation of THIS frame
+            check(L.planar_manhattan_pose_dev(self.ctx_t.h, B, self.Rcm_new.data_ptr(), self.Rcm0.data_ptr(), self.pose.data_ptr(), self.pose_mf.data_ptr()))
+            self._assemble(0, k, self.pm, self.h_xw[l], self.h_valid[l], S, self.pose_mf)
             self.opt.enqueue_dev(self.pbs[0], 1, 4, 10)     # TranslationOptimization
             A0 = self.pb_arrays[0]
             if cap is not None: cap["pbT"] = {kk: v.clone() for kk, v in A0.items()}
@@ -319,7 +323,7 @@ class TrackPipeline:
             if cap is not None: snap("pm1", self.pm); snap("lm1", self.lm); snap("kept", self.kept)
             # ---- TrackLocalMap: SearchLocalPoints + PoseOptimization ----
             T1 = A0["Tcw_out"]
-            t.ge(self.pm, 0, out=self.blocked.view(t.bool))
+            check(L.planar_blocked_mask_dev(self.ctx_t.h, self.pm.data_ptr(), self.pm.numel(), self.blocked.data_ptr()))
             fv2 = self._frame_view(k, T1, self.blocked)
             pr = self.pr
             check(L.planar_is_in_frustum_points_dev(self.ctx_t.h, C.byref(fv2), self.lsf, self.nlev, self.h_n[o].data_ptr(), S, self.h_valid[o].data_ptr(), self.h_xw[o].data_ptr(),
@@ -329,13 +333,13 @@ class TrackPipeline:
             mpv.stride = S
             mpv.n, mpv.in_view, mpv.proj_x, mpv.proj_y, mpv.proj_xr = self.h_n[o].data_ptr(), pr["in_view"].data_ptr(), pr["proj_x"].data_ptr(), pr["proj_y"].data_ptr(), pr["proj_xr"].data_ptr()
             mpv.level, mpv.view_cos, mpv.desc, mpv.observed = pr["level"].data_ptr(), pr["view_cos"].data_ptr(), self.h_desc[o].data_ptr(), self.ones_S.data_ptr()
-            self.mm.fill_(-1)
+            check(L.planar_reset_matches_dev(self.ctx_t.h, self.mm.data_ptr(), self.mm.numel()))
             check(L.planar_search_by_projection_map_dev(self.ctx_t.h, C.byref(fv2), C.byref(mpv), 3.0, 0.8, self.mm.data_ptr(), self.nmm.data_ptr()))
             lp = self.lpr
             check(L.planar_is_in_frustum_lines_dev(self.ctx_t.h, C.byref(fv2), self.lsf, self.kf["n"].data_ptr(), 40, self.kf["has_ml"].data_ptr(), self.kf["xw6"].data_ptr(),
                                                    self.kf["normal"].data_ptr(), self.kf["min_dist"].data_ptr(), self.kf["max_dist"].data_ptr(), 0.5, lp["in_view"].data_ptr(),
                                                    lp["proj"].data_ptr(), lp["level"].data_ptr(), lp["view_cos"].data_ptr()))
-            t.ge(self.lm, 0, out=self.lblocked.view(t.bool))
+            check(L.planar_blocked_mask_dev(self.ctx_t.h, self.lm.data_ptr(), self.lm.numel(), self.lblocked.data_ptr()))
             check(L.planar_lsd_search_by_projection_dev(self.ctx_t.h, B, self.nl[k].data_ptr(), 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.lblocked.data_ptr(),
                                                         self.kf["n"].data_ptr(), 40, lp["in_view"].data_ptr(), lp["proj"].data_ptr(), lp["level"].data_ptr(), lp["view_cos"].data_ptr(),
                                                         self.kf["ldesc"].data_ptr(), self.kf["has_ml"].data_ptr(), self.sf.ctypes.data, self.nlev, 3.0, 0.6, self.lm.data_ptr(),
@@ -345,14 +349,16 @@ class TrackPipeline:
                 cap["pr"] = {kk: v.clone() for kk, v in self.pr.items()}; cap["lpr"] = {kk: v.clone() for kk, v in self.lpr.items()}
                 snap("mm", self.mm); snap("nmm", self.nmm); snap("lm2", self.lm); snap("nlm2", self.nlm)
             # one index space for the optimiser: [last frame's points | the older frame's points]
-            t.where(self.pm >= 0, self.pm, t.where(self.mm >= 0, self.mm + S, self.mm), out=self.pm_all)
-            self.xw_all[:, :S] = self.h_xw[l]; self.xw_all[:, S:] = self.h_xw[o]
-            self.valid_all[:, :S] = self.h_valid[l]; self.valid_all[:, S:] = self.h_valid[o]
+            check(L.planar_merge_matches_dev(self.ctx_t.h, self.pm.data_ptr(), self.mm.data_ptr(), S, self.pm.numel(), self.pm_all.data_ptr()))
+            rows = lambda dst, dpitch, src, spitch, nbytes: check(L.planar_copy_rows_dev(self.ctx_t.h, dst, dpitch, src, spitch, nbytes, B))
+            xb = self.h_xw[l].element_size() * self.h_xw[l][0].numel()          # bytes of one stream's [S][3] block
+            rows(self.xw_all.data_ptr(), 2 * xb, self.h_xw[l].data_ptr(), xb, xb); rows(self.xw_all.data_ptr() + xb, 2 * xb, self.h_xw[o].data_ptr(), xb, xb)
+            rows(self.valid_all.data_ptr(), 2 * S, self.h_valid[l].data_ptr(), S, S); rows(self.valid_all.data_ptr() + S, 2 * S, self.h_valid[o].data_ptr(), S, S)
             self._assemble(1, k, self.pm_all, self.xw_all, self.valid_all, 2 * S, T1)
             self.opt.enqueue_dev(self.pbs[1], 0, 4, 10)     # PoseOptimization
             if cap is not None: cap["pbP"] = {kk: v.clone() for kk, v in self.pb_arrays[1].items()}; snap("pm_all", self.pm_all)
-            self.pose.copy_(self.pb_arrays[1]["Tcw_out"])
-            self.Rcm.copy_(self.Rcm_new)
+            check(L.planar_copy_rows_dev(self.ctx_t.h, self.pose.data_ptr(), B * 64, self.pb_arrays[1]["Tcw_out"].data_ptr(), B * 64, B * 64, 1))
+            check(L.planar_copy_rows_dev(self.ctx_t.h, self.Rcm.data_ptr(), B * 36, self.Rcm_new.data_ptr(), B * 36, B * 36, 1))
             if evs: evs["pose"].record(st)
         elif evs:
             for name in ("manhattan", "proj", "bf", "planes", "transl", "local", "pose"):
@@ -362,8 +368,9 @@ class TrackPipeline:
         check(L.planar_update_normal_and_depth_dev(self.ctx_t.h, B, self.n[k].data_ptr(), S, self.h_xw[o].data_ptr(), self.h_valid[o].data_ptr(), self.pose.data_ptr(),
                                                    self.kps[k].data_ptr(), None, None, self.sf.ctypes.data, self.nlev, self.h_normal[o].data_ptr(), self.h_mind[o].data_ptr(),
                                                    self.h_maxd[o].data_ptr()))
-        octave = self.kps[k][..., 5].contiguous().view(t.int32)
-        self.h_desc[o].copy_(self.desc[k]); self.h_oct[o].copy_(octave); self.h_ang[o].copy_(self.kps[k][..., 3]); self.h_n[o].copy_(self.n[k])
+        check(L.planar_keypoint_fields_dev(self.ctx_t.h, self.kps[k].data_ptr(), B * S, self.h_oct[o].data_ptr(), self.h_ang[o].data_ptr()))
+        check(L.planar_copy_rows_dev(self.ctx_t.h, self.h_desc[o].data_ptr(), B * S * 32, self.desc[k].data_ptr(), B * S * 32, B * S * 32, 1))
+        check(L.planar_copy_rows_dev(self.ctx_t.h, self.h_n[o].data_ptr(), B * 4, self.n[k].data_ptr(), B * 4, B * 4, 1))
         if cap is not None: snap("pose_out", self.pose); snap("new_xw", self.h_xw[o]); snap("new_valid", self.h_valid[o]); snap("new_ur", self.ur[k]); snap("new_normal", self.h_normal[o]); snap("new_mind", self.h_mind[o]); snap("new_maxd", self.h_maxd[o])
         if evs: evs["state"].record(st)
         self.done[k].record(st)

@@ -10,13 +10,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _compare(prob, comm=None, ctx=None):
+    """Smoke comparison with the restated oracle on synthetic graphs.  The GATE of BA parity is test_ba_hip_equals_reference_fixture below
+    (the real Optimizer::LocalBundleAdjustment's outputs, exact erase lists); here a threshold knife edge may flip an edge in a thousand."""
     from planarslam_amd import local_bundle_adjustment
     got = local_bundle_adjustment(prob, TUM3, ctx=ctx, comm=comm)
     want = ol.local_ba(prob, TUM3)
     assert np.abs(got["kf_Tcw"] - want["kf_Tcw"]).max() <= 1e-5
     assert np.abs(got["lm"] - want["lm"]).max() <= 1e-5
     assert abs(got["lm_iters"] - want["lm_iters"]) <= 1
-    assert (got["e_outlier"] != want["e_outlier"]).mean() <= 1e-3          # threshold knife edges only
+    assert (got["e_outlier"] != want["e_outlier"]).mean() <= 1e-3
     return got, want
 
 
@@ -27,6 +29,13 @@ def test_ba_small():
 def test_ba_config5_shape():
     # BASELINE config 5: 10 keyframes x ~3000 features (2400 points + 500 lines + 100 planes)
     got, want = _compare(ba_problem(seed=99))
+    assert np.array_equal(got["e_outlier"], want["e_outlier"])
+
+
+def test_ba_more_than_twenty_free_keyframes():
+    """Optimizer::LocalBundleAdjustment has no cap on the covisible key frames (GetVectorCovisibleKeyFrames returns more than 20 on real sequences).
+    Above 20 free key frames the reduced camera system leaves LDS (global-memory Schur accumulation and Cholesky): same results."""
+    got, want = _compare(ba_problem(seed=21, n_kf=34, n_points=900, n_lines=120, n_planes=24))
     assert np.array_equal(got["e_outlier"], want["e_outlier"])
 
 

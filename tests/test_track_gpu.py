@@ -141,6 +141,11 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
     assert np.array_equal(a, c["plm"][0]) and np.array_equal(p, c["plm"][1]) and np.array_equal(v, c["plm"][2]) and np.array_equal(npm, c["nplm"])
     # ---- assembled translation problem + TranslationOptimization ----
     T = c["pbT"]
+    # mRotation_wc = (Rotation_cm * MF_can^T)^T goes into the pose the translation is optimised against (src/Tracking.cc:250-253, 1778); its translation is the last pose's
+    R0 = np.asarray(sn["R_last"], np.float32).reshape(B, 3, 3).astype(np.float64)
+    want_R = np.einsum("brk,bck->brc", c["Rcm_new"].reshape(B, 3, 3).astype(np.float64), R0).astype(np.float32)
+    Tin = T["Tcw_in"].reshape(B, 4, 4)
+    assert np.abs(Tin[:, :3, :3] - want_R).max() <= 1.2e-7 and np.array_equal(Tin[:, :3, 3], c["pose_in"].reshape(B, 4, 4)[:, :3, 3]) and np.array_equal(Tin[:, 3], c["pose_in"].reshape(B, 4, 4)[:, 3])
     for b in range(0, B, 11):
         n = int(c["n"][b])
         ok = c["pm0"][b, :n] >= 0
