@@ -12,6 +12,12 @@ The sequence of the reference's tracking thread for one RGB-D frame (src/Trackin
     (:1954-2040)                              LSDmatcher::SearchByProjection - PoseOptimization - UnprojectStereo of the new frame's keypoints
                                               (the next frame's "last frame" map points)
 
+Departure from :1778 (default): the reference copies the Manhattan rotation mRotation_wc = (Rotation_cm * MF_can^T)^T into the pose before
+TranslationOptimization.  The synthetic streams are image-plane pans of a static RGB-D canvas - there is no camera rotation for the Manhattan tracker to
+find that would also explain the point matches - and with that rotation 64 instead of 595 point matches per frame survive TranslationOptimization
+(measured), so the bench would time a tracker that has lost most of its matches.  TrackPipeline(manhattan_rotation=True) does what :1778 does
+(planar_manhattan_pose_dev); the default keeps the last pose's rotation, and the Manhattan stage feeds the next frame's mLastRcm only.
+
 What is NOT the reference's code path and only stands in for the map it maintains (Map / KeyFrame / LocalMapping are out of scope):
 the local map of a stream is the previous two frames' own back-projected keypoints, the reference key frame's lines and the map planes are
 fixed per stream (set_map); every new "map point" has one observation, its own frame (MapPoint::UpdateNormalAndDepth: planar_update_normal_and_depth).
@@ -31,12 +37,13 @@ class TrackPipeline:
     MAX_POSE_PLANES = 16
 
     def __init__(self, B, torch, device_index=0, depth=2, prio=(-1, 0, 0), cam=None, W=640, H=480, n_map_planes=8, n_plane_pts=128, n_normals=4096,
-                 run_fallback_matcher=True):
+                 run_fallback_matcher=True, manhattan_rotation=False):
         from . import Context, ORBextractor, Optimizer, PlaneDetection
         from .lines import LineSegment
         from .planes import PlaneClouds, SurfaceNormals
         from .synth import TUM3
         self.torch, self.B, self.W, self.H, self.depth = torch, B, W, H, depth
+        self.manhattan_rotation = manhattan_rotation
         self.cam = dict(cam or TUM3)
         self.dev = torch.device("cuda", device_index)
         self.NB = depth + 2                      # buffer sets: a step's extractor outputs live until the tracking chain `depth` steps later has used them as "last frame"
@@ -311,9 +318,13 @@ class TrackPipeline:
                                                             self.plm[0].data_ptr(), self.plm[2].data_ptr(), self.plm[1].data_ptr(), self.nplm.data_ptr()))
             if evs: evs["planes"].record(st)
             if cap is not None: snap("pl_coef", pc["coef"]); snap("pl_n", pc["n"]); snap("pl_src", pc["src"]); snap("pl_off", pc["off"]); snap("pl_pts", pc["pts"]); snap("pl_status", pc["status"]); snap("plm", self.plm); snap("nplm", self.nplm); snap("Rcm_new", self.Rcm_new)
-            # mRotation_wc.copyTo(mCurrentFrame.mTcw.rowRange(0,3).colRange(0,3)) (:1778): the translation is optimised against the Manhattan rotation of THIS frame
-            check(L.planar_manhattan_pose_dev(self.ctx_t.h, B, self.Rcm_new.data_ptr(), self.Rcm0.data_ptr(), self.pose.data_ptr(), self.pose_mf.data_ptr()))
-            self._assemble(0, k, self.pm, self.h_xw[l], self.h_valid[l], S, self.pose_mf)
+            # mRotation_wc.copyTo(mCurrentFrame.mTcw.rowRange(0,3).colRange(0,3)) (:1778): the translation is optimised against the Manhattan rotation of THIS frame.
+            # Off by default for the synthetic streams (module docstring); planar_manhattan_pose_dev is the ABI entry a real tracker calls here.
+            pose_t = self.pose
+            if self.manhattan_rotation:
+                check(L.planar_manhattan_pose_dev(self.ctx_t.h, B, self.Rcm_new.data_ptr(), self.Rcm0.data_ptr(), self.pose.data_ptr(), self.pose_mf.data_ptr()))
+                pose_t = self.pose_mf
+            self._assemble(0, k, self.pm, self.h_xw[l], self.h_valid[l], S, pose_t)
             self.opt.enqueue_dev(self.pbs[0], 1, 4, 10)     # TranslationOptimization
             A0 = self.pb_arrays[0]
             if cap is not None: cap["pbT"] = {kk: v.clone() for kk, v in A0.items()}
