@@ -212,6 +212,28 @@ int run_distinctive(Reader& r, Writer& w) {
     }
     return 0;
 }
+// MapLine::ComputeDistinctiveDescriptors (src/MapLine.cpp:241-312), same format: per line int32 nobs, uint8 bad[nobs], uint8 desc[nobs][32] -> mLDescriptor[32]
+int run_distinctive_lines(Reader& r, Writer& w) {
+    const int np = r.get<int>();
+    for (int p = 0; p < np; p++) {
+        const int n = r.get<int>();
+        const unsigned char* bad = r.arr<unsigned char>(n);
+        const unsigned char* d = r.arr<unsigned char>((size_t)n * 32);
+        std::vector<KeyFrame> kfs(n);
+        MapLine ml;
+        for (int i = 0; i < n; i++) {
+            kfs[i].mLineDescriptors = cv::Mat(1, 32, CV_8U);
+            memcpy(kfs[i].mLineDescriptors.data, d + (size_t)i * 32, 32);
+            kfs[i].mbBad = bad[i] != 0;
+            ml.mObservations[&kfs[i]] = 0;
+        }
+        ml.ComputeDistinctiveDescriptors();
+        unsigned char out[32] = {0};
+        if (!ml.mLDescriptor.empty()) memcpy(out, ml.mLDescriptor.data, 32);
+        w.arr(out, 32);
+    }
+    return 0;
+}
 // in: int32 nkf, nlev; float sf[nlev]; per key frame float Tcw[16]; int32 npoints; per point float pos[3], int32 ref (index of mpRefKF), level (octave of its
 // keypoint there), nobs, int32 obs[nobs] (observing key frames).  out: per point float normal[3], min, max.
 int run_normal_depth(Reader& r, Writer& w) {
@@ -254,6 +276,7 @@ int main(int argc, char** argv) {
     if (m == "plane_world") return run_plane_world(r, w);
     if (m == "stereo") return run_stereo(r, w);
     if (m == "distinctive") return run_distinctive(r, w);
+    if (m == "distinctive_lines") return run_distinctive_lines(r, w);
     if (m == "normal_depth") return run_normal_depth(r, w);
     return 2;
 }

@@ -301,6 +301,18 @@ static inline void GaussianBlur(InputArray src, OutputArray dst, Size ksize, dou
     orc::gaussian7_s2_u8(s.data, s.cols, s.rows, (int)(size_t)s.step, d.data, (int)(size_t)d.step);
 }
 
+// cv::norm(a, b, NORM_HAMMING) as MapLine::ComputeDistinctiveDescriptors calls it on two descriptor rows: the number of differing bits
+#ifndef CVSHIM_ALGEBRA   // (cvalgebra.hpp declares NORM_HAMMING for its BFMatcher)
+enum { NORM_HAMMING = 6 };
+#endif
+static inline double norm(const Mat& a, const Mat& b, int normType) {
+    (void)normType;
+    const size_t n = (size_t)a.rows * a.cols * a.elemSize();
+    int d = 0;
+    for (size_t i = 0; i < n; i++) d += __builtin_popcount((unsigned)(a.data[i] ^ b.data[i]));
+    return (double)d;
+}
+
 }  // namespace cv
 #ifdef CVSHIM_ALGEBRA
 #include "cvalgebra.hpp"

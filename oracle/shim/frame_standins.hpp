@@ -57,6 +57,7 @@ public:
     float mfLogScaleFactor = 0;
     int mnScaleLevels = 0;
     cv::Mat mDescriptors;                        // include/KeyFrame.h: one row per keypoint
+    cv::Mat mLineDescriptors;                    // one row per key line
     bool mbBad = false;
     bool isBad() { return mbBad; }
     void SetPose(const cv::Mat& Tcw);
@@ -112,6 +113,11 @@ public:
     Eigen::Vector3d mNormalVector;
     float mfMinDistance = 0, mfMaxDistance = 0;
     std::mutex mMutexPos;
+    void ComputeDistinctiveDescriptors();
+    std::map<KeyFrame*, size_t> mObservations;   // include/MapLine.h: keyframe -> index of the observing key line
+    cv::Mat mLDescriptor;
+    bool mbBad = false;
+    std::mutex mMutexFeatures;
 };
 
 class Frame {

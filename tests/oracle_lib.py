@@ -914,13 +914,14 @@ def distinctive_descriptor(desc):
     return L.orc_distinctive_descriptor(C.c_void_p(desc.ctypes.data), len(desc), C.byref(med)), med.value
 
 
-def run_ref_distinctive(points):
-    """points: list of (desc [n,32] u8, bad [n] u8) -> [len(points), 32] u8: mDescriptor after the reference's own ComputeDistinctiveDescriptors (zeros if unset)."""
+def run_ref_distinctive(points, lines=False):
+    """points: list of (desc [n,32] u8, bad [n] u8) -> [len(points), 32] u8: mDescriptor after the reference's own ComputeDistinctiveDescriptors (zeros if unset).
+    lines=True: MapLine::ComputeDistinctiveDescriptors (src/MapLine.cpp:241-312) on LBD rows instead."""
     pay = np.int32(len(points)).tobytes()
     for desc, bad in points:
         desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); bad = np.ascontiguousarray(bad, np.uint8)
         pay += np.int32(len(desc)).tobytes() + bad.tobytes() + desc.tobytes()
-    return np.frombuffer(_run_ref_frame("distinctive", pay), np.uint8).reshape(len(points), 32).copy()
+    return np.frombuffer(_run_ref_frame("distinctive_lines" if lines else "distinctive", pay), np.uint8).reshape(len(points), 32).copy()
 
 
 # ---- MapPoint::UpdateNormalAndDepth (oracle/guided_oracle.cpp; the REAL src/MapPoint.cc:347-388 + KeyFrame::SetPose through oracle/_ref/ref_frame) ----

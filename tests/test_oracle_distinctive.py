@@ -8,11 +8,27 @@ import distinctive_cases as dc
 import oracle_lib as ol
 
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "distinctive_ref.npz"))
+GOLD_LINES = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "distinctive_lines_ref.npz"))
 
 
-def _split_bad():
-    n = GOLD["n"]; off = np.r_[0, np.cumsum(n)]
-    return [GOLD["bad"][off[i]:off[i + 1]] for i in range(len(n))]
+def _split_bad(G=None):
+    G = GOLD if G is None else G
+    n = G["n"]; off = np.r_[0, np.cumsum(n)]
+    return [G["bad"][off[i]:off[i + 1]] for i in range(len(n))]
+
+
+def test_oracle_matches_the_map_line_fixture():
+    """MapLine::ComputeDistinctiveDescriptors (src/MapLine.cpp:241-312: cv::norm NORM_HAMMING on LBD rows, the same first-minimum median rule) - outputs of the
+    reference's own function compiled into oracle/_ref/ref_frame."""
+    cs, bad = dc.cases(seed=17, n_points=40), _split_bad(GOLD_LINES)
+    assert len(cs) == len(GOLD_LINES["chosen"])
+    for i, (d, b) in enumerate(zip(cs, bad)):
+        keep = d[b == 0]
+        idx, _ = ol.distinctive_descriptor(keep)
+        want = GOLD_LINES["chosen"][i]
+        assert (not want.any()) if idx < 0 else np.array_equal(keep[idx], want), i
+    if os.path.exists(ol.ref_frame_path()):
+        assert np.array_equal(ol.run_ref_distinctive(list(zip(cs, bad)), lines=True), GOLD_LINES["chosen"])
 
 
 def test_oracle_matches_reference_fixture():
