@@ -1,28 +1,37 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh rNN'): the bench line, the rocprofv3 kernel summary of the same command, the two PMC passes
-# (separate runs, --kernel-trace only, as gpurun requires), the BA bench, the GPU test suite and smoke().  Everything under timeout; outputs in gpurun_out/<tag>_*.
-tag=${1:-r03}
+# Runs ON THE GPU BOX in THREE short gpurun calls (a call that hangs must not eat the round's GPU budget: every command has its own timeout AND each call a
+# small gpurun --timeout):   gpurun --timeout 330 -- 'bash tools/collect_profiles.sh r03 bench'   |   ... r03 pmc   |   ... r03 suite
+# bench: the bench line, the BA bench, the rocprofv3 kernel summary of the same command.  pmc: HBM traffic and issue counters (separate passes, --kernel-trace only,
+# as gpurun requires).  suite: the GPU tests and smoke().  Outputs in gpurun_out/<tag>_*.
+tag=${1:-r03}; what=${2:-bench}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
-timeout 420 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
-timeout 200 python bench.py --workload ba --steps 20 --warmup 3 > $O/${tag}_bench_ba.json 2>> $O/${tag}_bench.err
-cd /tmp && export TMPDIR=/tmp
 FL="--steps 6 --warmup 3 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
-# counter passes: separate runs, --kernel-trace only.  The canvases are synthesised in-process (--gen-procs 1, 16 of them): rocprofv3 --pmc hangs when the
-# profiled process forks worker processes (what killed every counter pass earlier in round 2, profiles/README.md)
+# counter passes: the canvases are synthesised in-process (--gen-procs 1, 16 of them): rocprofv3 --pmc hangs when the profiled process forks workers (profiles/README.md)
 PF="--gen-procs 1 --canvases 16 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
-timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_fetch -- python $R/bench.py $PF > /dev/null 2>&1
-timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_write -- python $R/bench.py $PF > /dev/null 2>&1
-python $R/tools/pmc_summary.py $O/${tag}_pmc_fetch $O/${tag}_pmc_write > $O/${tag}_pmc_fetch_write_kb_per_launch.csv 2>> $O/${tag}_bench.err
-# issue counters: instructions per launch, share of a wavefront's resident time with an instruction in flight / waiting
-timeout 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/${tag}_pmc_sq1 -- python $R/bench.py $PF > /dev/null 2>&1
-timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/${tag}_pmc_sq2 -- python $R/bench.py $PF > /dev/null 2>&1
-python $R/tools/pmc_counters.py $O/${tag}_pmc_sq1 $O/${tag}_pmc_sq2 > $O/${tag}_pmc_sq_per_launch.csv 2>> $O/${tag}_bench.err
-cd $R
-f=$(ls $O/${tag}_trace/*/*kernel_stats.csv | head -1); cp $f $O/${tag}_kernel_stats.csv
-t=$(ls $O/${tag}_trace/*/*kernel_trace.csv | head -1); (head -1 $t; tail -80 $t) > $O/${tag}_kernel_trace_tail.csv
-rm -rf $O/${tag}_trace $O/${tag}_pmc_fetch $O/${tag}_pmc_write $O/${tag}_pmc_sq1 $O/${tag}_pmc_sq2
-timeout 900 python -m pytest tests -m gpu -q > $O/${tag}_gpu_tests.log 2>&1
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${tag}_smoke.log 2>&1
-grep -a "passed\|failed" $O/${tag}_gpu_tests.log; tail -1 $O/${tag}_smoke.log; cut -c1-250 $O/${tag}_bench.json
+if [ $what = bench ]; then
+    timeout 150 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+    timeout 60 python bench.py --workload ba --steps 20 --warmup 3 > $O/${tag}_bench_ba.json 2>> $O/${tag}_bench.err
+    cd /tmp && export TMPDIR=/tmp
+    timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
+    cd $R
+    f=$(ls $O/${tag}_trace/*/*kernel_stats.csv | head -1); cp $f $O/${tag}_kernel_stats.csv
+    t=$(ls $O/${tag}_trace/*/*kernel_trace.csv | head -1); (head -1 $t; tail -80 $t) > $O/${tag}_kernel_trace_tail.csv
+    rm -rf $O/${tag}_trace
+    cut -c1-200 $O/${tag}_bench.json; head -5 $O/${tag}_kernel_stats.csv | cut -c1-160
+elif [ $what = pmc ]; then
+    cd /tmp && export TMPDIR=/tmp
+    timeout 70 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_fetch -- python $R/bench.py $PF > /dev/null 2>&1
+    timeout 70 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_write -- python $R/bench.py $PF > /dev/null 2>&1
+    python $R/tools/pmc_summary.py $O/${tag}_pmc_fetch $O/${tag}_pmc_write > $O/${tag}_pmc_fetch_write_kb_per_launch.csv 2>> $O/${tag}_bench.err
+    # issue counters: instructions per launch, share of a wavefront's resident time with an instruction in flight / waiting
+    timeout 70 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/${tag}_pmc_sq1 -- python $R/bench.py $PF > /dev/null 2>&1
+    timeout 70 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/${tag}_pmc_sq2 -- python $R/bench.py $PF > /dev/null 2>&1
+    python $R/tools/pmc_counters.py $O/${tag}_pmc_sq1 $O/${tag}_pmc_sq2 > $O/${tag}_pmc_sq_per_launch.csv 2>> $O/${tag}_bench.err
+    rm -rf $O/${tag}_pmc_fetch $O/${tag}_pmc_write $O/${tag}_pmc_sq1 $O/${tag}_pmc_sq2
+    head -8 $O/${tag}_pmc_fetch_write_kb_per_launch.csv; head -8 $O/${tag}_pmc_sq_per_launch.csv
+else
+    timeout 200 python -m pytest tests -m gpu -q > $O/${tag}_gpu_tests.log 2>&1
+    timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${tag}_smoke.log 2>&1
+    grep -a "passed\|failed" $O/${tag}_gpu_tests.log; tail -1 $O/${tag}_smoke.log
+fi
