@@ -66,6 +66,14 @@ static inline int ahc2_smem_bytes(const Layout& L) {
 
 typedef unsigned long long u64;
 
+// host emulator only: after a pruned evaluation of a pooled bag (eval_big) also run the in-order evaluation of ALL its candidates and compare (err 9)
+#ifdef PLANAR_WAVE_EMUL
+static int g_peac_check_prune = 0;
+#define PEAC_CHECK_PRUNE (g_peac_check_prune != 0)
+#else
+#define PEAC_CHECK_PRUNE false
+#endif
+
 constexpr int ST_RETRY = 100;              // status of a frame the fast kernel gave up on (exact FP64 tie between live nodes): peac_ahc2 redoes it
 constexpr unsigned K_EMPTY = 0xffffff80u;  // tournament queue: no node (above every key)
 
@@ -366,7 +374,8 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
     };
     auto set_bit = [&](unsigned id) { atomicOr(&bmp[id >> 5], 1u << (id & 31)); };
 
-    int dbg_hits = 0, dbg_phases = 0, dbg_nodes = 0, dbg_big = 0;
+    int dbg_hits = 0, dbg_phases = 0, dbg_nodes = 0, dbg_big = 0, dbg_prune_skip = 0, dbg_bigsolves = 0;
+    (void)dbg_prune_skip;
 
     // One candidate merge per lane: node `nd` with its live neighbour `r` (or r == TOMB: none).
     // Returns ok (the neighbour passed the normal-similarity test) and the merged moments / plane / N.
@@ -522,19 +531,9 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
         dbg_phases++; dbg_nodes += __popcll(heads & lane_below(total));
     };
 
-    // ---- a popped node whose bag lives in the pool (more than 64 entries when it was created): resolve + deduplicate + sort the bag in place
-    //      through the bitmap, evaluate it 64 entries at a time in ascending id, write the result to its candidate record.
-    auto eval_big = [&](int p, int cp, unsigned off) -> int {
-        for (int k0 = 0; k0 < cp; k0 += 64) {
-            const unsigned e = k0 + lane < cp ? (unsigned)bpool[off + k0 + lane] : TOMB;
-            const unsigned r = chase(e);
-            if (r != TOMB) set_bit(r);
-        }
-        WFENCE();
-        const int n2 = bitmap_prefix();
-        bitmap_emit(bpool + off, false);
-        GFENCE();
-        PEAC_TICK(19);
+    // ---- a popped node whose bag lives in the pool (more than 64 entries when it was created).
+    // In-order evaluation of a resolved, deduplicated bag of n2 entries SORTED by id, 64 at a time: the reference's scan (:1043-1049), quirk included.
+    auto eval_big_inorder = [&](int p, int n2, unsigned off) {
         bool have = false; double best_mse = 0; int best_nb = 0, best_N = 0;
         double best_stats[9]; Geo best_geo;
 #pragma unroll
@@ -581,6 +580,135 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             rr[0] = (uint32_t)n2 | ((have ? 1u : 0u) | (mok ? 2u : 0u) | 4u) << 16;
             rr[1] = (uint32_t)(have ? best_nb : 0) | (rr[1] & 0xffff0000u);
             *(double*)(rr + 4) = have ? best_mse : 0.0;
+        }
+    };
+    // The bag is resolved, deduplicated (first occurrence through the bitmap) and packed in place, unsorted.  Such a node has 100-250 live neighbours
+    // - three or four eigen-solves of latency if all are evaluated - but only the SMALLEST merged mse matters.  So: the merged moments of every
+    // candidate are formed in registers (<= 4 per lane) together with a rigorous lower bound of the mse the solver would return
+    // (merged_mse_lower_bound, peac_eig.h); every lane solves its most promising candidate; candidates whose bound lies above the best solved mse
+    // cannot win or tie and are dropped; the few that remain go through another round.  Typically one solve per node.  Exact ties / NaNs (the
+    // reference's in-order rule matters) and bags above 256 entries sort the bag and take the in-order path.
+    auto eval_big = [&](int p, int cp, unsigned off) -> int {
+        int n2 = 0;
+        for (int k0 = 0; k0 < cp; k0 += 64) {
+            const unsigned e = k0 + lane < cp ? (unsigned)bpool[off + k0 + lane] : TOMB;
+            const unsigned r = chase(e);
+            bool keep = false;
+            if (r != TOMB) { const unsigned bit = 1u << (r & 31); keep = !(atomicOr(&bmp[r >> 5], bit) & bit); }
+            const u64 km = __ballot(keep);
+            if (keep) bpool[off + n2 + __popcll(km & lane_below(lane))] = (u16)r;    // at or below the entries read so far
+            n2 += __popcll(km);
+        }
+        for (int t = lane; t < W32; t += 64) bmp[t] = 0;
+        GFENCE();
+        PEAC_TICK(19);
+        const double INF = __builtin_inf(), BIG = 1.7976931348623157e308;
+        bool fallback = false;
+        {
+            const double* sp = g_stats + (size_t)p * 9;
+            const double* gp = geo_of(p) + 3;
+            double ps[9];
+#pragma unroll
+            for (int t = 0; t < 9; t++) ps[t] = sp[t];
+            const double pn0 = gp[0], pn1 = gp[1], pn2 = gp[2];
+            const int Na = g_N[p];
+            double b_ms[9], b_mse = INF; Geo b_g; unsigned b_r = TOMB; bool b_have = false, odd = false;
+#pragma unroll
+            for (int t = 0; t < 9; t++) b_ms[t] = 0;
+#pragma unroll
+            for (int t = 0; t < 3; t++) { b_g.center[t] = 0; b_g.normal[t] = 0; }
+            b_g.mse = 0;
+            // the best solved mse, wave-uniform.  "None yet" is DBL_MAX, not infinity: hipcc (ROCm 7.2) materialises a uniform +inf with
+            // s_mov_b64 and a 64-bit literal, which gfx950 does not have - the register ends up 0 (tests/test_build_sanity.py scans for it).
+            double bestm = BIG;
+            for (int g0 = 0; g0 < n2; g0 += 256) {             // 256 candidates at a time: four per lane in registers
+                double cms[4][9], clb[4]; int cN[4]; unsigned cr[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    cr[c] = TOMB; clb[c] = INF; cN[c] = 1;
+#pragma unroll
+                    for (int t = 0; t < 9; t++) cms[c][t] = 0;
+                    if (g0 + c * 64 < n2) {
+                        const unsigned r = g0 + c * 64 + lane < n2 ? (unsigned)bpool[off + g0 + c * 64 + lane] : TOMB;
+                        if (r != TOMB) {
+                            const double* gn = geo_of((int)r) + 3;
+                            const double* sb = g_stats + (size_t)r * 9;
+                            const double n0 = gn[0], n1 = gn[1], n2v = gn[2];
+                            double ms[9];
+#pragma unroll
+                            for (int t = 0; t < 9; t++) ms[t] = sb[t];
+                            const int Nb = g_N[r];
+                            if (!(fabs(pn0 * n0 + pn1 * n1 + pn2 * n2v) < C.cos_merge)) {   // AHCPlaneFitter.hpp:1035
+#pragma unroll
+                                for (int t = 0; t < 9; t++) cms[c][t] = ps[t] + ms[t];
+                                cN[c] = Na + Nb; cr[c] = r;
+                                clb[c] = merged_mse_lower_bound(cms[c], cN[c]);
+                            }
+                        }
+                    }
+                }
+                PEAC_TICK(20);
+                while (true) {
+                    int sel = 0; double lbs = clb[0];
+#pragma unroll
+                    for (int c = 1; c < 4; c++) if (clb[c] < lbs) { lbs = clb[c]; sel = c; }
+                    const bool go = lbs < INF && lbs <= bestm;
+                    if (!__ballot(go)) break;
+                    double s2[9]; int N2 = 1; unsigned r2 = TOMB;
+#pragma unroll
+                    for (int t = 0; t < 9; t++) s2[t] = t >= 3 && t < 6 ? 1.0 : 0.0;          // idle lanes solve a harmless diagonal matrix
+#pragma unroll
+                    for (int c = 0; c < 4; c++) if (go && sel == c) {
+#pragma unroll
+                        for (int t = 0; t < 9; t++) s2[t] = cms[c][t];
+                        N2 = cN[c]; r2 = cr[c]; clb[c] = INF;
+                    }
+                    Geo g2;
+                    stats_compute_u(s2, N2, g2);
+                    if (go) {
+                        if (!(g2.mse < BIG)) odd = true;                            // NaN / infinite: the in-order path decides
+                        else if (!b_have || g2.mse < b_mse) {
+                            b_have = true; b_mse = g2.mse; b_g = g2; b_r = r2;
+#pragma unroll
+                            for (int t = 0; t < 9; t++) b_ms[t] = s2[t];
+                        } else if (g2.mse == b_mse) odd = true;
+                    }
+                    bestm = wave_min_f64(b_have ? b_mse : BIG);
+                    dbg_bigsolves++;
+                    PEAC_TICK(15);
+                }
+            }
+            const u64 eqm = __ballot(b_have && b_mse == bestm);
+            if (__ballot(odd) || __popcll(eqm) > 1) { fallback = true; dbg_prune_skip = 1; }
+            else {
+                const bool have = eqm != 0;
+                const int wl = have ? __ffsll((long long)eqm) - 1 : 0;
+                if (have && lane == wl) write_merged(p, b_ms, b_g);
+                const double w_z = wave_lane(b_g.center[2], wl);
+                const unsigned w_nb = wave_lane(b_r, wl);
+                if (lane == 0) {
+                    uint32_t* rr = rec(p);
+                    const bool mok = have && bestm < T_mse_merge(w_z);
+                    rr[0] = (uint32_t)n2 | ((have ? 1u : 0u) | (mok ? 2u : 0u) | 4u) << 16;
+                    rr[1] = (uint32_t)(have ? w_nb : 0u) | (rr[1] & 0xffff0000u);
+                    *(double*)(rr + 4) = have ? bestm : 0.0;
+                }
+                if (PEAC_CHECK_PRUNE) fallback = true;
+            }
+        }
+        if (fallback) {
+            uint32_t chk0 = 0, chk1 = 0; double chkm = 0;
+            if (PEAC_CHECK_PRUNE) { GFENCE(); chk0 = rec(p)[0]; chk1 = rec(p)[1]; chkm = *(const double*)(rec(p) + 4); WFENCE(); }
+            for (int k0 = 0; k0 < n2; k0 += 64) if (k0 + lane < n2) set_bit((unsigned)bpool[off + k0 + lane]);
+            WFENCE();
+            bitmap_prefix();
+            bitmap_emit(bpool + off, false);
+            GFENCE();
+            eval_big_inorder(p, n2, off);
+            dbg_bigsolves += (n2 + 63) / 64;
+            GFENCE();
+            if (PEAC_CHECK_PRUNE && dbg_prune_skip == 0 && (rec(p)[0] != chk0 || ((rec(p)[0] >> 16) & 1u && (rec(p)[1] != chk1 || *(const double*)(rec(p) + 4) != chkm)))) err = 9;
+            dbg_prune_skip = 0;
         }
         dbg_big++;
         return n2;
@@ -828,6 +956,7 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                 timing[(size_t)frame * TSLOTS + 9] = n_nodes;
                 timing[(size_t)frame * TSLOTS + 7] = ((long long)dbg_phases << 40) | ((long long)dbg_nodes << 20) | dbg_hits;
                 timing[(size_t)frame * TSLOTS + 10] = dbg_big;
+                timing[(size_t)frame * TSLOTS + 11] = dbg_bigsolves;
                 for (int t = 0; t < 24; t++) timing[(size_t)frame * TSLOTS + 16 + t] = cyc[t];
             }
         }

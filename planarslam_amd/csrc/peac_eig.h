@@ -140,5 +140,52 @@ PLANAR_HD void eig33u(double a00, double a10, double a11, double a20, double a21
     v0[0] = q00; v0[1] = q10; v0[2] = q20;
 }
 
+
+// A lower bound of the mse PlaneSeg::Stats::compute returns for the moments s[9] of N points (mse = smallest eigenvalue of the scatter matrix K,
+// times 1 / N), without the eigen-solve.  K is formed with the very expressions of stats_compute_u, so it is the matrix the solver sees.  Its
+// characteristic polynomial p(x) = x^3 - tr x^2 + M2 x - det (M2 = sum of the principal 2x2 minors) has three positive roots l1 <= l2 <= l3, and on
+// [0, l1] p is negative, increasing and concave: a Newton step from x <= l1 lands at x' <= l1 again.  Three steps from 0 (the first is det / M2, tight
+// to a relative l1 / l2 only - candidate merges of a large region differ by far less) reach the rounding floor.  Every step is an UNDER-step:
+// -p(x) is reduced and p'(x) enlarged by running error bounds of their evaluation (16 eps * the sum of the absolute values of the terms, coefficient
+// errors included), so the iterate stays below l1 in floating point too.  The QR iteration is backward stable: its eigenvalues are those of K + E,
+// ||E|| <= 64 eps tr|K| with a wide margin.  If det cannot be certified positive the bound is -inf (the candidate is solved).  The clustering only
+// uses the bound to SKIP candidates that provably lose (peac_ahc2.h, eval_big); tests/test_peac_eig.py checks bound <= solver on synthetic moments,
+// tests/test_peac_emul.py checks every pruned decision of whole frames against evaluating all candidates.
+PLANAR_HD double merged_mse_lower_bound(const double s[9], int N) {
+    const double sc = 1.0 / N;
+    const double k00 = s[3] - s[0] * s[0] * sc, k01 = s[6] - s[0] * s[1] * sc, k02 = s[8] - s[0] * s[2] * sc;
+    const double k11 = s[4] - s[1] * s[1] * sc, k12 = s[7] - s[1] * s[2] * sc, k22 = s[5] - s[2] * s[2] * sc;
+    const double m0 = k11 * k22 - k12 * k12, m1 = k01 * k22 - k12 * k02, m2 = k01 * k12 - k11 * k02;
+    const double a0 = fabs(k11 * k22) + k12 * k12, a1 = fabs(k01 * k22) + fabs(k12 * k02), a2 = fabs(k01 * k12) + fabs(k11 * k02);
+    const double c0 = k00 * m0 - k01 * m1 + k02 * m2;                                   // det
+    const double c1 = (k00 * k11 - k01 * k01) + (k00 * k22 - k02 * k02) + m0;           // M2
+    const double c2 = k00 + k11 + k22;                                                  // trace
+    const double eps16 = 16.0 * 2.220446049250313e-16;
+    const double E0 = eps16 * (fabs(k00) * a0 + fabs(k01) * a1 + fabs(k02) * a2);
+    const double E1 = eps16 * (fabs(k00 * k11) + k01 * k01 + fabs(k00 * k22) + k02 * k02 + a0);
+    const double tr = fabs(k00) + fabs(k11) + fabs(k22);
+    const double E2 = eps16 * tr;
+    double x = 0;
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        const double x2 = x * x;
+        const double negp = ((c0 - c1 * x) + c2 * x2) - x2 * x;                         // -p(x) >= 0 left of l1
+        const double Ep = E0 + x * E1 + x2 * E2 + eps16 * (fabs(c0) + fabs(c1) * x + fabs(c2) * x2 + x2 * x);
+        const double dp = (c1 - 2.0 * c2 * x) + 3.0 * x2;                               // p'(x) > 0 left of l1
+        const double Ed = E1 + 2.0 * x * E2 + eps16 * (fabs(c1) + 2.0 * fabs(c2) * x + 3.0 * x2);
+        const double num = negp - Ep, den = dp + Ed;
+        double step = num / den;
+        step -= step * 1e-15;
+        if (!(step > 0)) step = 0;
+        x += step;
+        x -= x * 2.220446049250313e-16;
+    }
+    double lb = x - 4.0 * eps16 * tr;
+    lb = lb * sc;
+    lb -= fabs(lb) * 1e-15;
+    if (!(c0 - E0 > 0) || !(c1 - E1 > 0) || !(lb == lb)) lb = -__builtin_inf();
+    return lb;
+}
+
 }  // namespace peac
 }  // namespace planar

@@ -22,4 +22,22 @@ long peac_eig_compare(const double* mats, long n, long* first_bad) {
     }
     return bad;
 }
+
+// stats: [n][9] moments (sx sy sz sxx syy szz sxy syz sxz), N: [n].  lb[i] = merged_mse_lower_bound, mse[i] = what PlaneSeg::Stats::compute's
+// solver returns for the same moments (the expressions of stats_compute_u in peac_ahc2.h).  Returns the number of i with lb[i] > mse[i].
+long peac_lb_check(const double* stats, const int* N, long n, double* lb, double* mse) {
+    long bad = 0;
+    for (long i = 0; i < n; i++) {
+        const double* s = stats + i * 9;
+        const double sc = 1.0 / N[i];
+        const double k00 = s[3] - s[0] * s[0] * sc, k01 = s[6] - s[0] * s[1] * sc, k02 = s[8] - s[0] * s[2] * sc;
+        const double k11 = s[4] - s[1] * s[1] * sc, k12 = s[7] - s[1] * s[2] * sc, k22 = s[5] - s[2] * s[2] * sc;
+        double ev[3], v[3];
+        planar::peac::eig33u(k00, k01, k11, k02, k12, k22, ev, v);
+        mse[i] = ev[0] * sc;
+        lb[i] = planar::peac::merged_mse_lower_bound(s, N[i]);
+        if (lb[i] > mse[i]) bad++;
+    }
+    return bad;
+}
 }

@@ -22,11 +22,13 @@ extern "C" {
 // stats[9]; hand [4 + 128] = n_ext, err, n_nodes, -, extracted ids; dsp / dss [NB] as the kernel leaves them; nouse [(NB2 + 31) / 32].
 // Returns 0, or -1 with a message in err.
 int peac_emul_dims(int W, int H, int* NB, int* NB2) { const Layout L = make_layout(W, H); *NB = L.NB; *NB2 = L.NB2; return 0; }
+// mode bit 2 (| 4): every pruned evaluation of a pooled bag is checked against the in-order evaluation of all its candidates (kernel status 9).
 // mode 0: what the library does (the fast kernel, then the exact kernel if it left ST_RETRY); 1: exact kernel only; 2: fast kernel only.
-// stats_out: [0] status, [1] rendezvous count, [2] phases << 40 | nodes evaluated << 20 | valid-record pops, [3] pops of pool bags, [4] 1 if the fast kernel gave up
+// stats_out: [0] status, [1] rendezvous count, [2] phases << 40 | nodes evaluated << 20 | valid-record pops, [3] pops of pool bags, [4] 1 if the fast kernel gave up, [5] eigen-solves spent on pool bags
 int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, float cx, float cy, float factor, int mode, double* nodes, int32_t* hand,
                       uint16_t* dsp, uint16_t* dss, uint32_t* nouse, int64_t* stats_out, char* err, int errlen) {
     try {
+        planar::peac::g_peac_check_prune = (mode & 4) ? 1 : 0; mode &= 3;
         const Layout L = make_layout(W, H);
         const Consts C = make_consts();
         if (L.NB > 3072) throw std::runtime_error("image too large for the clustering kernel");
@@ -63,7 +65,7 @@ int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, f
         memcpy(hand, g_hand, (4 + MAX_PLANES) * 4);
         memcpy(dsp, F + L.off_h_dsp, (size_t)L.NB * 2); memcpy(dss, F + L.off_h_dss, (size_t)L.NB * 2);
         memcpy(nouse, F + L.off_h_nouse, (size_t)((L.NB2 + 31) / 32) * 4);
-        if (stats_out) { stats_out[0] = status; stats_out[1] = wave_emul::S().n_sync; stats_out[2] = timing[7]; stats_out[3] = timing[10]; stats_out[4] = retried; }
+        if (stats_out) { stats_out[0] = status; stats_out[1] = wave_emul::S().n_sync; stats_out[2] = timing[7]; stats_out[3] = timing[10]; stats_out[4] = retried; stats_out[5] = timing[11]; }
         return 0;
     } catch (const std::exception& e) {
         snprintf(err, errlen, "%s", e.what());

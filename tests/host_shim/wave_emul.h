@@ -189,6 +189,10 @@ inline unsigned wave_min_u32(unsigned v) {
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = ::wave_emul::shfl(900100 + o, v, (::wave_emul::S().cur & 63) ^ o); v = t < v ? t : v; }
     return v;
 }
+inline double wave_min_f64(double v) {
+    for (int o = 32; o > 0; o >>= 1) { const double t = ::wave_emul::shfl(900200 + o, v, (::wave_emul::S().cur & 63) ^ o); v = t < v ? t : v; }
+    return v;
+}
 }  // namespace planar
 
 // ---- the HIP device functions the kernels use ----

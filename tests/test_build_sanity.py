@@ -1,0 +1,25 @@
+"""Build sanity of the device code (no GPU needed: hipcc cross-compiles).
+
+hipcc of ROCm 7.2 can materialise a wave-uniform FP64 constant whose low half is zero (+inf, 2^k ...) as `s_mov_b64 sN, <64-bit literal>`.  gfx950 has
+no 64-bit literals on SALU moves: the object file carries the low 32 bits and the register ends up 0 - silently (found in round 3: a "best so far =
++inf" that started at 0 in the PEAC clustering kernel; the host emulator cannot see such a thing).  The kernels avoid such constants (DBL_MAX instead of
++inf for uniform values); this test scans the ISA of the kernels that use FP64 sentinels for the pattern."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+BAD = re.compile(r"s_mov_b64\s+s\[[0-9:]+\],\s*(0x[0-9a-fA-F]{9,}|-?[0-9]{11,})")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src", ["peac.hip", "lsd.hip"])
+def test_no_64bit_literal_scalar_moves(src, tmp_path):
+    out = tmp_path / (src + ".s")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-function", "-S", "--cuda-device-only",
+                           os.path.join(ROOT, "planarslam_amd", "csrc", src), "-o", str(out)], stderr=subprocess.DEVNULL)
+    bad = [ln.strip() for ln in open(out) if BAD.search(ln)]
+    assert not bad, f"{src}: scalar moves with a 64-bit literal (not encodable on gfx950, the register would hold the low half only): {bad[:4]}"

@@ -20,6 +20,8 @@ def lib():
     L = ctypes.CDLL(SO)
     L.peac_eig_compare.restype = ctypes.c_long
     L.peac_eig_compare.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+    L.peac_lb_check.restype = ctypes.c_long
+    L.peac_lb_check.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
     return L
 
 
@@ -55,3 +57,42 @@ def test_wavefront_solver_is_bit_identical_to_the_oracle(lib):
         first = ctypes.c_long(-1)
         bad = lib.peac_eig_compare(s.ctypes.data, len(s), ctypes.byref(first))
         assert bad == 0, f"{bad} of {len(s)} matrices differ; first: {s[first.value]}"
+
+
+def _moments(rng, n, unit):
+    """moments of noisy planar patches at camera distances (unit: 1.0 = metres, 1000.0 = millimetres, as PEAC sees them), float32 points like a depth
+    map's back-projection; some thin (line-like), some exactly planar, some tiny"""
+    st = np.empty((n, 9)); Ns = np.empty(n, np.int32)
+    for i in range(n):
+        N = int(rng.choice([4, 16, 100, 400, 3000, 30000]))
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        basis = np.linalg.svd(nrm[None])[2][1:]
+        ext = rng.uniform(0.01, 1.5, 2) * (rng.choice([1.0, 1e-2, 1e-4]), 1.0)
+        noise = rng.choice([0.0, 1e-5, 1e-3, 0.01, 0.2])
+        pts = (rng.normal(size=(N, 2)) * ext) @ basis + nrm * rng.normal(size=(N, 1)) * noise + np.array([rng.normal(), rng.normal(), rng.uniform(0.5, 6)])
+        pts = (pts * unit).astype(np.float32).astype(np.float64)
+        s = pts.sum(0); q = (pts * pts).sum(0)
+        st[i] = [s[0], s[1], s[2], q[0], q[1], q[2], (pts[:, 0] * pts[:, 1]).sum(), (pts[:, 1] * pts[:, 2]).sum(), (pts[:, 0] * pts[:, 2]).sum()]
+        Ns[i] = N
+    return st, Ns
+
+
+def test_mse_lower_bound_never_exceeds_the_solver(lib):
+    """merged_mse_lower_bound (peac_eig.h) is what lets the clustering skip eigen-solves: it must never lie above the mse the solver returns, and it
+    should be tight where it matters (plane-like regions)."""
+    rng = np.random.default_rng(11)
+    for unit in (1.0, 1000.0):
+        st, Ns = _moments(rng, 6000, unit)
+        lb = np.empty(len(st)); mse = np.empty(len(st))
+        bad = lib.peac_lb_check(st.ctypes.data, Ns.ctypes.data, len(st), lb.ctypes.data, mse.ctypes.data)
+        assert bad == 0, f"{bad} bounds above the solver's mse; e.g. {np.flatnonzero(lb > mse)[:5]}"
+        fin = np.isfinite(lb) & (mse > 0)
+        assert fin.mean() > 0.5
+        assert np.median(lb[fin] / mse[fin]) > 0.98
+    # sums of two patches (what a candidate merge is), degenerate inputs
+    st, Ns = _moments(rng, 4000, 1000.0)
+    st2 = st[:2000] + st[2000:]; N2 = (Ns[:2000] + Ns[2000:]).astype(np.int32)
+    z = np.zeros((3, 9)); zN = np.array([1, 4, 100], np.int32)
+    for a, b in ((st2, N2), (z, zN)):
+        a = np.ascontiguousarray(a); lb = np.empty(len(a)); mse = np.empty(len(a))
+        assert lib.peac_lb_check(a.ctypes.data, b.ctypes.data, len(a), lb.ctypes.data, mse.ctypes.data) == 0

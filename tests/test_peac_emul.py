@@ -62,7 +62,7 @@ def _run(libs, d, mode=0):
     assert np.array_equal(roots, oroot) and np.array_equal(dss[roots], osize), "DisjointSet partition differs"
     dead = np.array([(nouse[i >> 5] >> (i & 31)) & 1 for i in range(n)], bool)
     assert dead[live].all(), "a node of the graph is still marked alive after the clustering"
-    return dict(retried=bool(st[4]), phases=int(st[2] >> 40), evaluated=int((st[2] >> 20) & 0xFFFFF), hits=int(st[2] & 0xFFFFF), big=int(st[3]), nodes=int(n), planes=int(hand[0]))
+    return dict(retried=bool(st[4]), phases=int(st[2] >> 40), evaluated=int((st[2] >> 20) & 0xFFFFF), hits=int(st[2] & 0xFFFFF), big=int(st[3]), big_solves=int(st[5]), nodes=int(n), planes=int(hand[0]))
 
 
 @pytest.mark.parametrize("w,h,seed,noise,holes", [(160, 120, 5, True, True), (320, 240, 77, True, True), (320, 240, 78, False, True), (640, 480, 4321, True, True),
@@ -96,3 +96,14 @@ def test_big_bags_go_through_the_pool(libs):
     """a noise-free scene grows regions with more than 64 neighbours: the bags in the pool, their compaction and slot reuse are exercised"""
     info = _run(libs, depth_image(51, 640, 480, noise=False, holes=False))
     assert info["big"] > 0
+
+
+@pytest.mark.parametrize("seed,noise", [(51, False), (4336, True), (4346, True)])
+def test_pruned_evaluation_of_big_bags_agrees_with_evaluating_everything(libs, seed, noise):
+    """eval_big solves only the candidates whose lower bound does not rule them out; with mode | 4 the emulated kernel also evaluates ALL candidates
+    in order after every pruned evaluation and reports status 9 on any difference (best neighbour, mse, flags)"""
+    info = _run(libs, depth_image(seed, 640, 480, noise=noise, holes=noise), mode=4)
+    assert info["big"] > 0
+    if noise:                                                         # the point of pruning: about one solve per node instead of one per 64 neighbours
+        fast = _run(libs, depth_image(seed, 640, 480, noise=noise, holes=noise), mode=2)
+        assert fast["big_solves"] < 1.5 * fast["big"], fast
