@@ -590,18 +590,6 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
     // reference's in-order rule matters) and bags above 256 entries sort the bag and take the in-order path.
     auto eval_big = [&](int p, int cp, unsigned off) -> int {
         int n2 = 0;
-        for (int k0 = 0; k0 < cp; k0 += 64) {
-            const unsigned e = k0 + lane < cp ? (unsigned)bpool[off + k0 + lane] : TOMB;
-            const unsigned r = chase(e);
-            bool keep = false;
-            if (r != TOMB) { const unsigned bit = 1u << (r & 31); keep = !(atomicOr(&bmp[r >> 5], bit) & bit); }
-            const u64 km = __ballot(keep);
-            if (keep) bpool[off + n2 + __popcll(km & lane_below(lane))] = (u16)r;    // at or below the entries read so far
-            n2 += __popcll(km);
-        }
-        for (int t = lane; t < W32; t += 64) bmp[t] = 0;
-        GFENCE();
-        PEAC_TICK(19);
         const double INF = __builtin_inf(), BIG = 1.7976931348623157e308;
         bool fallback = false;
         {
@@ -621,31 +609,48 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             // the best solved mse, wave-uniform.  "None yet" is DBL_MAX, not infinity: hipcc (ROCm 7.2) materialises a uniform +inf with
             // s_mov_b64 and a 64-bit literal, which gfx950 does not have - the register ends up 0 (tests/test_build_sanity.py scans for it).
             double bestm = BIG;
-            for (int g0 = 0; g0 < n2; g0 += 256) {             // 256 candidates at a time: four per lane in registers
-                double cms[4][9], clb[4]; int cN[4]; unsigned cr[4];
+            // 256 bag entries at a time, four per lane.  In a batch the frame workspaces do not fit the caches: every dependent global access is an HBM
+            // round trip (2-4 k cycles), so each kind of load is issued for all four chunks before anything waits for it: entries, then the
+            // candidates' normals and N, then their moments.
+            for (int g0 = 0; g0 < cp; g0 += 256) {
+                unsigned cr[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) cr[c] = g0 + c * 64 + lane < cp ? (unsigned)bpool[off + g0 + c * 64 + lane] : TOMB;
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    cr[c] = TOMB; clb[c] = INF; cN[c] = 1;
+                    if (g0 + c * 64 >= cp) break;
+                    const unsigned r = chase(cr[c]);
+                    bool keep = false;
+                    if (r != TOMB) { const unsigned bit = 1u << (r & 31); keep = !(atomicOr(&bmp[r >> 5], bit) & bit); }
+                    const u64 km = __ballot(keep);
+                    if (keep) bpool[off + n2 + __popcll(km & lane_below(lane))] = (u16)r;    // the resolved bag, packed in place: at or below the entries read so far
+                    n2 += __popcll(km);
+                    cr[c] = keep ? r : TOMB;                                                  // this lane's candidate of chunk c
+                }
+                PEAC_TICK(19);
+                double cms[4][9], clb[4], cn[4][3]; int cN[4];
 #pragma unroll
-                    for (int t = 0; t < 9; t++) cms[c][t] = 0;
-                    if (g0 + c * 64 < n2) {
-                        const unsigned r = g0 + c * 64 + lane < n2 ? (unsigned)bpool[off + g0 + c * 64 + lane] : TOMB;
-                        if (r != TOMB) {
-                            const double* gn = geo_of((int)r) + 3;
-                            const double* sb = g_stats + (size_t)r * 9;
-                            const double n0 = gn[0], n1 = gn[1], n2v = gn[2];
-                            double ms[9];
+                for (int c = 0; c < 4; c++) {
+                    const int idx = cr[c] == TOMB ? p : (int)cr[c];
+                    const double* gn = geo_of(idx) + 3;
+                    cn[c][0] = gn[0]; cn[c][1] = gn[1]; cn[c][2] = gn[2];
+                    cN[c] = g_N[idx];
+                }
 #pragma unroll
-                            for (int t = 0; t < 9; t++) ms[t] = sb[t];
-                            const int Nb = g_N[r];
-                            if (!(fabs(pn0 * n0 + pn1 * n1 + pn2 * n2v) < C.cos_merge)) {   // AHCPlaneFitter.hpp:1035
+                for (int c = 0; c < 4; c++) {
+                    const double* sb = g_stats + (size_t)(cr[c] == TOMB ? p : (int)cr[c]) * 9;
 #pragma unroll
-                                for (int t = 0; t < 9; t++) cms[c][t] = ps[t] + ms[t];
-                                cN[c] = Na + Nb; cr[c] = r;
-                                clb[c] = merged_mse_lower_bound(cms[c], cN[c]);
-                            }
-                        }
-                    }
+                    for (int t = 0; t < 9; t++) cms[c][t] = sb[t];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const bool ok = cr[c] != TOMB && !(fabs(pn0 * cn[c][0] + pn1 * cn[c][1] + pn2 * cn[c][2]) < C.cos_merge);   // AHCPlaneFitter.hpp:1035
+#pragma unroll
+                    for (int t = 0; t < 9; t++) cms[c][t] = ps[t] + cms[c][t];
+                    cN[c] = Na + cN[c];
+                    if (!ok) cr[c] = TOMB;
+                    const double lb = merged_mse_lower_bound(cms[c], cN[c]);
+                    clb[c] = ok ? lb : INF;
                 }
                 PEAC_TICK(20);
                 while (true) {
@@ -678,6 +683,8 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                     PEAC_TICK(15);
                 }
             }
+            for (int t = lane; t < W32; t += 64) bmp[t] = 0;
+            GFENCE();
             const u64 eqm = __ballot(b_have && b_mse == bestm);
             if (__ballot(odd) || __popcll(eqm) > 1) { fallback = true; dbg_prune_skip = 1; }
             else {
@@ -844,38 +851,63 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
                 WFENCE();
                 PEAC_TICK(7);
             } else {
-                // a bag in the pool on either side: chunks of 64 entries set their bits, the lanes that own bitmap words emit the result
-                for (int k0 = 0; k0 < n; k0 += 64) {
-                    unsigned e = TOMB;
-                    if (k0 + lane < n) e = bigA ? (unsigned)bpool[offA + k0 + lane] : rootA;
-                    const unsigned r = chase(e);
-                    if (r != TOMB && r != (unsigned)p && r != (unsigned)nb) set_bit(r);
-                }
-                for (int k0 = 0; k0 < nbn; k0 += 64) {
-                    unsigned e = TOMB;
-                    if (k0 + lane < nbn) e = bigB ? (unsigned)bpool[offB + k0 + lane] : rootB;
-                    const unsigned r = chase(e);
-                    if (r != TOMB && r != (unsigned)p && r != (unsigned)nb) set_bit(r);
-                }
-                WFENCE();
-                nm = bitmap_prefix();
+                // a bag in the pool on either side.  The new bag is written while the old ones are read, 64 entries at a time: first occurrence through
+                // the bitmap (atomic OR), survivors packed by ballot / popcount.  Destination: the pool slot of a dying bag that can hold n + nbn
+                // entries - that bag is read first, the write position never passes the read position - else a new slot (a region that absorbs
+                // its neighbours one by one keeps its slot).  p's entries are live or TOMB (its record was evaluated in this iteration).
+                const int ub = n + nbn;
+                const unsigned saved_top = pool_top;
+                bool fresh = false, firstB = false;
                 u16* dst;
-                if (nm <= 64) dst = roots_of(m);
+                if (ub <= 64) dst = roots_of(m);
                 else {
-                    // reuse a dying bag's slot when the new bag fits (a region that absorbs its neighbours one by one keeps its slot)
                     const int capA = bigA ? (int)bpool[offA - 1] : 0, capB = bigB ? (int)bpool[offB - 1] : 0;
-                    if (capA >= nm && (capA <= capB || capB < nm)) offM = offA;
-                    else if (capB >= nm) offM = offB;
+                    if (capA >= ub && (capA <= capB || capB < ub)) offM = offA;
+                    else if (capB >= ub) { offM = offB; firstB = true; }
                     else {
-                        const int cap = nm + nm / 4 + 16;
+                        const int cap = ub + ub / 4 + 16;
                         if (pool_top + 1 + cap > (unsigned)L.bpool_cap) { err = 2; break; }
                         if (lane == 0) bpool[pool_top] = (u16)cap;
-                        offM = pool_top + 1; pool_top += 1 + cap;
+                        offM = pool_top + 1; pool_top += 1 + cap; fresh = true;
                     }
-                    bigM = true;
                     dst = bpool + offM;
                 }
-                bitmap_emit(dst, true);
+                nm = 0;
+                for (int side = 0; side < 2; side++) {
+                    const bool isA = (side == 0) != firstB;
+                    const int cnt = isA ? n : nbn;
+                    const bool bigS = isA ? bigA : bigB;
+                    const unsigned offS = isA ? offA : offB, rootS = isA ? rootA : rootB;
+                    for (int g0 = 0; g0 < cnt; g0 += 256) {           // four chunks are requested together: one memory latency per 256 entries
+                        unsigned e4[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            e4[c] = TOMB;
+                            if (g0 + c * 64 + lane < cnt) e4[c] = bigS ? (unsigned)bpool[offS + g0 + c * 64 + lane] : rootS;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            if (g0 + c * 64 >= cnt) break;
+                            unsigned r = e4[c];
+                            if (!isA) r = chase(r);
+                            bool keep = false;
+                            if (r != TOMB && r != (unsigned)p && r != (unsigned)nb) { const unsigned bit = 1u << (r & 31); keep = !(atomicOr(&bmp[r >> 5], bit) & bit); }
+                            const u64 km = __ballot(keep);
+                            if (keep) { dst[nm + __popcll(km & lane_below(lane))] = (u16)r; inval(r); }
+                            nm += __popcll(km);
+                        }
+                    }
+                }
+                for (int t = lane; t < W32; t += 64) bmp[t] = 0;
+                if (ub > 64) {
+                    if (nm <= 64) {                                   // the union fits the record again: the bag moves there, a new slot is given back
+                        GFENCE();
+                        if (lane < nm) roots_of(m)[lane] = dst[lane];
+                        if (fresh) pool_top = saved_top;
+                        offM = 0;
+                    } else bigM = true;
+                }
+                WFENCE();
                 PEAC_TICK(8);
             }
             // node m: its moments / plane are the best merge of p's record (AHCPlaneSeg.hpp:301-315)

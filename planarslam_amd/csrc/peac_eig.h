@@ -165,16 +165,20 @@ PLANAR_HD double merged_mse_lower_bound(const double s[9], int N) {
     const double E1 = eps16 * (fabs(k00 * k11) + k01 * k01 + fabs(k00 * k22) + k02 * k02 + a0);
     const double tr = fabs(k00) + fabs(k11) + fabs(k22);
     const double E2 = eps16 * tr;
-    double x = 0;
+    // first step from 0: det / M2.  Later steps: the error bounds are taken at xm = the smallest diagonal entry (>= l1 >= every iterate; the bounds
+    // grow with x), once for both steps.
+    double x = (c0 - (E0 + eps16 * fabs(c0))) / (c1 + (E1 + eps16 * fabs(c1)));
+    x -= x * 1e-15;
+    if (!(x > 0)) x = 0;
+    const double xm = fmin(k00, fmin(k11, k22)), xm2 = xm * xm;
+    const double Ep = E0 + xm * E1 + xm2 * E2 + eps16 * (fabs(c0) + fabs(c1) * xm + fabs(c2) * xm2 + xm2 * xm);
+    const double Ed = E1 + 2.0 * xm * E2 + eps16 * (fabs(c1) + 2.0 * fabs(c2) * xm + 3.0 * xm2);
 #pragma unroll
-    for (int it = 0; it < 3; it++) {
+    for (int it = 0; it < 2; it++) {
         const double x2 = x * x;
         const double negp = ((c0 - c1 * x) + c2 * x2) - x2 * x;                         // -p(x) >= 0 left of l1
-        const double Ep = E0 + x * E1 + x2 * E2 + eps16 * (fabs(c0) + fabs(c1) * x + fabs(c2) * x2 + x2 * x);
         const double dp = (c1 - 2.0 * c2 * x) + 3.0 * x2;                               // p'(x) > 0 left of l1
-        const double Ed = E1 + 2.0 * x * E2 + eps16 * (fabs(c1) + 2.0 * fabs(c2) * x + 3.0 * x2);
-        const double num = negp - Ep, den = dp + Ed;
-        double step = num / den;
+        double step = (negp - Ep) / (dp + Ed);
         step -= step * 1e-15;
         if (!(step > 0)) step = 0;
         x += step;
@@ -183,7 +187,7 @@ PLANAR_HD double merged_mse_lower_bound(const double s[9], int N) {
     double lb = x - 4.0 * eps16 * tr;
     lb = lb * sc;
     lb -= fabs(lb) * 1e-15;
-    if (!(c0 - E0 > 0) || !(c1 - E1 > 0) || !(lb == lb)) lb = -__builtin_inf();
+    if (!(c0 - E0 > 0) || !(c1 - E1 > 0) || !(xm > 0) || !(lb == lb)) lb = -__builtin_inf();
     return lb;
 }
 
