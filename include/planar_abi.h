@@ -313,6 +313,27 @@ int planar_is_in_frustum_lines_dev(planar_ctx* ctx, const planar_frame_view* d_f
                                    const float* d_max_dist, float viewing_cos_limit, uint8_t* d_in_view, float* d_proj, int32_t* d_level,
                                    float* d_view_cos);
 
+/* ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) (src/ORBmatcher.cc:829-979), the SEARCH half: for every map point the
+ * keypoint of the key frame it would be fused with (:847-951: projection, KeyFrame::IsInImage src/KeyFrame.cc:715-718, distance / viewing-angle
+ * gates, MapPoint::PredictScale, KeyFrame::GetFeaturesInArea src/KeyFrame.cc:639-678, level / chi-square gates, smallest Hamming distance, TH_LOW).
+ * The map edits that follow (:953-974: Replace / AddObservation / AddMapPoint) stay with the caller's map: a point's gates read only its own state
+ * on entry, so they do not feed back into the search.  Batched over B key frames (LocalMapping::SearchInNeighbors fuses the same list into every
+ * neighbour key frame: points_shared = 1).
+ *   kf: keys_un, u_right, desc, Tcw, bounds, grid, fx fy cx cy bf, scale_factors are read (blocked is ignored)
+ *   inv_level_sigma2[n_levels] = KeyFrame::mvInvLevelSigma2; log_scale_factor / n_levels = mfLogScaleFactor / mnScaleLevels
+ *   usable[j] = vpMapPoints[j] != NULL && !isBad() && !IsInKeyFrame(pKF); xw / normal / desc = GetWorldPos() / GetNormal() / GetDescriptor();
+ *   min_dist / max_dist = mfMinDistance / mfMaxDistance (the 0.8 / 1.2 factors of GetMin/MaxDistanceInvariance are applied here)
+ *   fuse_idx[b][j] = bestIdx where bestDist <= TH_LOW (the reference then counts the point in its return value), else -1;
+ *   fuse_dist[b][j] (may be NULL) = bestDist (256: no candidate); rows j >= n[b] read -1 / 256; n_fused[b] = the function's return value. */
+int planar_fuse_search(planar_ctx* ctx, const planar_frame_view* kf, const float* inv_level_sigma2, float log_scale_factor, int n_levels,
+                       const int32_t* n, int stride, int points_shared, const uint8_t* usable, const float* xw, const float* normal,
+                       const float* min_dist, const float* max_dist, const uint8_t* desc, float th, int32_t* fuse_idx, int32_t* fuse_dist,
+                       int32_t* n_fused);
+int planar_fuse_search_dev(planar_ctx* ctx, const planar_frame_view* d_kf, const float* inv_level_sigma2 /* host */, float log_scale_factor, int n_levels,
+                           const int32_t* d_n, int stride, int points_shared, const uint8_t* d_usable, const float* d_xw, const float* d_normal,
+                           const float* d_min_dist, const float* d_max_dist, const uint8_t* d_desc, float th, int32_t* d_fuse_idx,
+                           int32_t* d_fuse_dist, int32_t* d_n_fused);
+
 /* cv::line_descriptor::KeyLine (opencv_contrib line_descriptor/descriptor.hpp), same field order, 68 bytes. */
 typedef struct planar_keyline {
     float angle;
@@ -575,7 +596,7 @@ int planar_track_manhattan_frame_dev(planar_ctx* ctx, int B, const float* d_R_la
  *   state / nvox / info (optional, per DETECTOR plane, stride pl_stride / pl_stride / pl_stride * 12): 0 kept, 1 distance, 2 no inliers; voxels;
  *                                  {RANSAC iterations, best count, best sample[3], inliers, inliers after the refit, sampler draws, model[4] bits}  */
 typedef struct planar_plane_clouds planar_plane_clouds;
-int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* voxels per frame: a power of two <= 8192; the kernel holds 101 KB of LDS up to 4096, 146 KB at 8192 */, planar_plane_clouds** out);
+int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* voxels per frame: a power of two <= 8192; the kernel holds 36 KB of LDS up to 4096, 64 KB at 8192; the key table is in the workspace */, planar_plane_clouds** out);
 void planar_plane_clouds_destroy(planar_plane_clouds* pc);
 int planar_plane_clouds_stride(const planar_plane_clouds* pc, int* pl_stride, int* max_points);
 /* Profiling aid, as planar_peac_read_timing: per-frame phase timestamps of the last call, out[B][16] (100 MHz ticks: [0] entry, [1] table cleared, [2] voxel sums,

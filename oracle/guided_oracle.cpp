@@ -439,6 +439,65 @@ void is_in_frustum_lines(const planar_frame_view& F, int b, float log_scale_fact
     }
 }
 
+// ---- ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>&, th), the search half (src/ORBmatcher.cc:829-951); pinned through oracle/_ref/ref_match
+//      mode `fuse` (the real function with KeyFrame::GetFeaturesInArea / IsInImage src/KeyFrame.cc:639-678, 715-718 and MapPoint::PredictScale
+//      src/MapPoint.cc:402-417 compiled in).  fuse_idx[j] = bestIdx where bestDist <= TH_LOW, else -1; returns nFused.
+int fuse_search(const planar_frame_view& K, int b, const float* inv_sigma2, float log_scale_factor, int n_levels, int n, const uint8_t* usable, const float* xw,
+                const float* normal, const float* min_dist, const float* max_dist, const uint8_t* desc, float th, int32_t* fuse_idx, int32_t* fuse_dist) {
+    const planar_keypoint* keys = K.keys_un + (size_t)b * K.stride;
+    const float* uR = K.u_right + (size_t)b * K.stride;
+    const uint8_t* kdesc = K.desc + (size_t)b * K.stride * 32;
+    Grid g;
+    g.build(K, keys, K.n[b]);                                              // KeyFrame::mGrid = the frame's grid (src/KeyFrame.cc:56-63)
+    const FrustumPose P = frustum_pose(K.Tcw + (size_t)b * 16);           // GetRotation, GetTranslation, GetCameraCenter (Ow = -Rwc * tcw)
+    std::vector<int> ind;
+    int nFused = 0;
+    for (int j = 0; j < n; j++) {
+        fuse_idx[j] = -1;
+        if (fuse_dist) fuse_dist[j] = 256;
+        if (!usable[j]) continue;                                          // :849-853
+        const float* X = xw + 3 * j;
+        const float xc = gemm3_row(P.Rcw, X, P.tcw[0]), yc = gemm3_row(P.Rcw + 3, X, P.tcw[1]), zc = gemm3_row(P.Rcw + 6, X, P.tcw[2]);
+        if (zc < 0.0f) continue;
+        const float invz = 1 / zc;
+        const float x = xc * invz, y = yc * invz;
+        const float u = K.fx * x + K.cx, v = K.fy * y + K.cy;
+        if (!(u >= K.min_x && u < K.max_x && v >= K.min_y && v < K.max_y)) continue;   // KeyFrame::IsInImage
+        const float ur = u - K.bf * invz;
+        const float maxDistance = 1.2f * max_dist[j], minDistance = 0.8f * min_dist[j];
+        const float PO[3] = {X[0] - P.Ow[0], X[1] - P.Ow[1], X[2] - P.Ow[2]};
+        const float dist3D = norm3(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        if (dot3(PO, normal + 3 * j) < 0.5 * dist3D) continue;
+        const float ratio = max_dist[j] / dist3D;                          // MapPoint::PredictScale(dist, pKF)
+        int lvl = (int)std::ceil(logf_cr(ratio) / log_scale_factor);
+        if (lvl < 0) lvl = 0; else if (lvl >= n_levels) lvl = n_levels - 1;
+        const float radius = th * K.scale_factors[lvl];
+        features_in_area(K, g, keys, u, v, radius, -1, -1, ind);           // KeyFrame::GetFeaturesInArea: no level bounds
+        if (ind.empty()) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : ind) {
+            const planar_keypoint& kp = keys[idx];
+            const int kl = kp.octave;
+            if (kl < lvl - 1 || kl > lvl) continue;
+            const float ex = u - kp.x, ey = v - kp.y;
+            if (uR[idx] >= 0) {
+                const float er = ur - uR[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * inv_sigma2[kl] > 7.8) continue;
+            } else {
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_sigma2[kl] > 5.99) continue;
+            }
+            const int dist = descriptor_distance(desc + (size_t)j * 32, kdesc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (fuse_dist) fuse_dist[j] = bestDist;
+        if (bestDist <= TH_LOW) { fuse_idx[j] = bestIdx; nFused++; }
+    }
+    return nFused;
+}
+
 }  // namespace orc
 
 extern "C" {
@@ -459,6 +518,16 @@ int orc_is_in_frustum_lines(const planar_frame_view* F, float lsf, const int32_t
         const size_t o = (size_t)b * stride;
         orc::is_in_frustum_lines(*F, b, lsf, n[b], valid + o, xw6 + o * 6, normal + o * 3, min_dist + o, max_dist + o, limit, in_view + o, proj + o * 4,
                                  level + o, vc + o);
+    }
+    return 0;
+}
+int orc_fuse_search(const planar_frame_view* K, const float* inv_sigma2, float lsf, int n_levels, const int32_t* n, int stride, int points_shared,
+                    const uint8_t* usable, const float* xw, const float* normal, const float* min_dist, const float* max_dist, const uint8_t* desc, float th,
+                    int32_t* fuse_idx, int32_t* fuse_dist, int32_t* n_fused) {
+    for (int b = 0; b < K->B; b++) {
+        const size_t o = points_shared ? 0 : (size_t)b * stride, oo = (size_t)b * stride;
+        n_fused[b] = orc::fuse_search(*K, b, inv_sigma2, lsf, n_levels, n[points_shared ? 0 : b], usable + o, xw + o * 3, normal + o * 3, min_dist + o, max_dist + o,
+                                      desc + o * 32, th, fuse_idx + oo, fuse_dist ? fuse_dist + oo : nullptr);
     }
     return 0;
 }

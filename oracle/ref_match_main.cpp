@@ -1,7 +1,7 @@
 // oracle/ref_match_main.cpp — TEST INFRASTRUCTURE.  Driver for the REAL reference matchers, compiled from
 // /root/reference/src/ORBmatcher.cc, src/LSDmatcher.cpp and src/PlaneMatcher.cpp where they lie (never copied) against the stand-ins in
 // oracle/shim (cvshim.hpp + cvalgebra.hpp + match_standins.hpp) into oracle/_ref/ref_match.
-//   ref_match <mode> <in.bin> <out.bin>     mode = proj_frame | proj_map | bow | match_orb | plane | lsd_proj | lsd_desc
+//   ref_match <mode> <in.bin> <out.bin>     mode = proj_frame | proj_map | bow | match_orb | plane | lsd_proj | lsd_desc | fuse
 // in/out files are sequences of blocks {int64 nbytes; bytes}; tests/oracle_lib.py (run_ref_match) writes and reads them.
 #include <cstdio>
 #include <cstdlib>
@@ -248,6 +248,50 @@ int main(int argc, char** argv) {
         std::vector<int32_t> match(nc, -1);
         for (size_t i = 0; i < nc; i++) if (res[i]) match[i] = res[i]->index;
         out.put(match.data(), match.size()); out.put(&n, 1);
+    } else if (mode == "fuse") {
+        // ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:829-979).  prm = {th, log_scale_factor, n_levels}
+        Frame F;
+        std::vector<MapPoint> dummies;
+        fill_frame(F, in, dummies);
+        const float* inv_sigma2 = in.get<float>();
+        const float* Tcw = in.get<float>();
+        size_t np;
+        const uint8_t* usable = in.get<uint8_t>(&np);
+        const float *xw = in.get<float>(), *nrm = in.get<float>(), *mind = in.get<float>(), *maxd = in.get<float>();
+        const uint8_t* d = in.get<uint8_t>();
+        const uint8_t* kf_state = in.get<uint8_t>();     // per keypoint of the key frame: 0 no map point, 1 a map point, 2 a bad map point
+        const int32_t* kf_obs = in.get<int32_t>();       // its Observations()
+        const int32_t* mp_obs = in.get<int32_t>();
+        const int n_levels = (int)prm[2];
+        KeyFrame kf;
+        kf.N = F.N; kf.mvKeysUn = F.mvKeysUn; kf.mvKeys = F.mvKeys; kf.mvuRight = F.mvuRight; kf.mDescriptors = F.mDescriptors;
+        kf.fx = Frame::fx; kf.fy = Frame::fy; kf.cx = Frame::cx; kf.cy = Frame::cy; kf.mbf = F.mbf; kf.mb = F.mb;
+        kf.mnMinX = Frame::mnMinX; kf.mnMaxX = Frame::mnMaxX; kf.mnMinY = Frame::mnMinY; kf.mnMaxY = Frame::mnMaxY;
+        kf.mfGridElementWidthInv = Frame::mfGridElementWidthInv; kf.mfGridElementHeightInv = Frame::mfGridElementHeightInv;
+        kf.mvScaleFactors = F.mvScaleFactors; kf.mvInvLevelSigma2.assign(inv_sigma2, inv_sigma2 + n_levels);
+        kf.mfLogScaleFactor = prm[1]; kf.mnScaleLevels = n_levels;
+        kf.mGrid.resize(kf.mnGridCols);                  // as the KeyFrame constructor does (src/KeyFrame.cc:56-63)
+        for (int i = 0; i < kf.mnGridCols; i++) { kf.mGrid[i].resize(kf.mnGridRows); for (int j = 0; j < kf.mnGridRows; j++) kf.mGrid[i][j] = F.mGrid[i][j]; }
+        kf.SetPose(mat_f32(4, 4, Tcw));
+        std::vector<MapPoint> kfmps(F.N);
+        kf.mps.assign(F.N, nullptr);
+        for (int i = 0; i < F.N; i++) if (kf_state[i]) { kfmps[i].bad = kf_state[i] == 2; kfmps[i].nobs = kf_obs[i]; kfmps[i].index = -2 - i; kf.mps[i] = &kfmps[i]; }
+        std::vector<MapPoint> mps(np);
+        std::vector<MapPoint*> vp(np, nullptr);
+        for (size_t i = 0; i < np; i++) {
+            mps[i].pos = mat_f32(3, 1, xw + 3 * i); mps[i].normal = mat_f32(3, 1, nrm + 3 * i); mps[i].desc = desc_mat(1, d + 32 * i);
+            mps[i].mfMinDistance = mind[i]; mps[i].mfMaxDistance = maxd[i]; mps[i].nobs = mp_obs[i]; mps[i].index = (int)i;
+            // not usable: a NULL entry, a bad point or one the key frame already observes, in turn
+            if (usable[i]) vp[i] = &mps[i];
+            else if (i % 3 == 1) { mps[i].bad = true; vp[i] = &mps[i]; }
+            else if (i % 3 == 2) { mps[i].in_kf = true; vp[i] = &mps[i]; }
+        }
+        fuse_log().clear();
+        ORBmatcher matcher(0.6f, true);
+        const int nFused = matcher.Fuse(&kf, vp, prm[0]);
+        std::vector<int32_t> idx(np, -1);
+        for (auto& e : fuse_log()) idx[e.first] = e.second;
+        out.put(idx.data(), idx.size()); out.put(&nFused, 1);
     } else { std::fprintf(stderr, "unknown mode\n"); return 2; }
     std::fclose(out.f);
     return 0;

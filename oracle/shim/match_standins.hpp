@@ -6,8 +6,9 @@
 // Frame::AssignFeaturesToGrid / lineDescriptorMAD / GetFeaturesInArea / GetLinesInArea / PosInGrid / ComputePlaneWorldCoeff live in
 // src/Frame.cc, which cannot be built as a whole here (PCL, threads, the extractors).  With -DSTANDINS_REAL_FRAME_FUNCS (how
 // oracle/Makefile builds ref_match) they are only DECLARED here and their bodies are the reference's own: lines 155-168, 269-293,
-// 440-535, 815-820 of src/Frame.cc extracted at build time into oracle/_ref/gen/frame_extract_match.cpp.  Without the macro the
-// restated bodies below are used.  KeyFrame's copies (src/KeyFrame.cc, same text) stay restated.
+// 440-535, 815-820 of src/Frame.cc extracted at build time into oracle/_ref/gen/frame_extract_match.cpp, together with src/MapPoint.cc:390-434
+// (distance invariance, PredictScale) and src/KeyFrame.cc:79-93, 107-111, 120-130, 639-678, 715-718 (pose getters, GetFeaturesInArea, IsInImage) for
+// ORBmatcher::Fuse.  Without the macro the restated bodies / stubs below are used.  KeyFrame's line helpers (src/KeyFrame.cc, same text) stay restated.
 #pragma once
 #define MAPPOINT_H
 #define KEYFRAME_H
@@ -53,18 +54,40 @@ class Map;
 class MapPlane;
 class MapLine;
 
+// a std::mutex that does not stop the holder classes from living in std::vector (the extracted reference bodies lock mMutexPos / mMutexPose)
+struct CopyableMutex : std::mutex {
+    CopyableMutex() {}
+    CopyableMutex(const CopyableMutex&) {}
+    CopyableMutex& operator=(const CopyableMutex&) { return *this; }
+};
+// ORBmatcher::Fuse does not return what it matched: the harness reads it off the calls it makes (MapPoint::GetDescriptor of the point being searched,
+// then KeyFrame::GetMapPoint(bestIdx) exactly once per fused point)
+inline int& fuse_current() { static int v = -1; return v; }
+inline std::vector<std::pair<int, int>>& fuse_log() { static std::vector<std::pair<int, int>> v; return v; }
+
 class MapPoint {
 public:
     cv::Mat GetWorldPos() { return pos.clone(); }
     cv::Mat GetNormal() { return normal.clone(); }
-    cv::Mat GetDescriptor() { return desc.clone(); }
+    cv::Mat GetDescriptor() { fuse_current() = index; return desc.clone(); }
     bool isBad() { return bad; }
     int Observations() { return nobs; }
+#ifdef STANDINS_REAL_FRAME_FUNCS
+    // bodies: src/MapPoint.cc:390-434, extracted at build time
+    float GetMinDistanceInvariance();
+    float GetMaxDistanceInvariance();
+    int PredictScale(const float& currentDist, KeyFrame* pKF);
+    int PredictScale(const float& currentDist, Frame* pF);
+    float mfMinDistance = 0, mfMaxDistance = 0;
+    CopyableMutex mMutexPos;
+#else
     float GetMinDistanceInvariance() { return 0.f; }
     float GetMaxDistanceInvariance() { return 1e9f; }
     int PredictScale(const float&, KeyFrame*) { return 0; }
     int PredictScale(const float&, Frame*) { return 0; }
-    bool IsInKeyFrame(KeyFrame*) { return false; }
+#endif
+    bool IsInKeyFrame(KeyFrame*) { return in_kf; }
+    bool in_kf = false;
     int GetIndexInKeyFrame(KeyFrame*) { return -1; }
     void AddObservation(KeyFrame*, size_t) {}
     void Replace(MapPoint*) {}
@@ -174,6 +197,8 @@ public:
     static float mnMinX, mnMaxX, mnMinY, mnMaxY;
     static float mfGridElementWidthInv, mfGridElementHeightInv;
     std::vector<float> mvScaleFactors;
+    float mfLogScaleFactor = 0;
+    int mnScaleLevels = 0;
     DBoW2::FeatureVector mFeatVec;
     std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
     // lines
@@ -285,13 +310,31 @@ public:
 #endif
     std::vector<MapPoint*> GetMapPointMatches() { return mps; }
     std::set<MapPoint*> GetMapPoints() { return std::set<MapPoint*>(); }
-    MapPoint* GetMapPoint(const size_t& i) { return mps[i]; }
+    MapPoint* GetMapPoint(const size_t& i) { fuse_log().push_back(std::make_pair(fuse_current(), (int)i)); return mps[i]; }
     void AddMapPoint(MapPoint*, const size_t&) {}
+    int mnScaleLevels = 0;
+#ifdef STANDINS_REAL_FRAME_FUNCS
+    // bodies: src/KeyFrame.cc:79-93 (SetPose), 107-111 (GetCameraCenter), 120-130 (GetRotation, GetTranslation), 639-678 (GetFeaturesInArea), 715-718
+    // (IsInImage), extracted at build time; the members they touch (include/KeyFrame.h)
+    void SetPose(const cv::Mat& Tcw);
+    cv::Mat GetRotation();
+    cv::Mat GetTranslation();
+    cv::Mat GetCameraCenter();
+    bool IsInImage(const float& x, const float& y) const;
+    vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r) const;
+    cv::Mat Tcw, Twc, Ow, Cw;
+    float mHalfBaseline = 0;
+    CopyableMutex mMutexPose;
+    int mnGridCols = FRAME_GRID_COLS, mnGridRows = FRAME_GRID_ROWS;
+    float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    std::vector<std::vector<std::vector<size_t>>> mGrid;
+#else
     cv::Mat GetRotation() { return cv::Mat(); }
     cv::Mat GetTranslation() { return cv::Mat(); }
     cv::Mat GetCameraCenter() { return cv::Mat(); }
     bool IsInImage(const float&, const float&) const { return true; }
     vector<size_t> GetFeaturesInArea(const float&, const float&, const float&) const { return vector<size_t>(); }
+#endif
 };
 
 }  // namespace Planar_SLAM

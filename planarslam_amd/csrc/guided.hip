@@ -5,6 +5,7 @@
 //   planar_search_by_bow                ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...)                  src/ORBmatcher.cc:160-292
 //   planar_lsd_search_by_projection     LSDmatcher::SearchByProjection + Frame::GetLinesInArea           src/LSDmatcher.cpp:141-211, src/Frame.cc:491-524
 //   planar_plane_search_by_coefficients PlaneMatcher::SearchMapByCoefficients                           src/PlaneMatcher.cpp:10-79
+//   planar_fuse_search                  ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th), the search half   src/ORBmatcher.cc:829-951
 //
 // The reference resolves probes one after another and every assignment changes what later probes may take
 // ("mvpMapPoints[i2]->Observations() > 0"), so the result depends on probe order.  The kernels keep that order
@@ -81,7 +82,8 @@ __device__ inline void load_desc(uint32_t* a, const uint8_t* p) {
 }
 
 // Frame::AssignFeaturesToGrid (src/Frame.cc:155-166, PosInGrid :526-535) into cell_start / items.
-__device__ void build_grid(Lds& s, const planar_frame_view& f, const planar_keypoint* keys, int N) {
+template <typename L>
+__device__ void build_grid(L& s, const planar_frame_view& f, const planar_keypoint* keys, int N) {
     const int tid = threadIdx.x;
     uint32_t* cnt = s.cand;            // [NCELL] counters, then cursors
     for (int c = tid; c < NCELL; c += NT) cnt[c] = 0;
@@ -750,6 +752,116 @@ __global__ __launch_bounds__(256) void frustum_lines_kernel(planar_frame_view F,
     view_cos[o] = viewCos;
 }
 
+// ---- ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th), search half (src/ORBmatcher.cc:829-951): one workgroup per key frame, one thread per map point.
+// No probe order to keep: a point's gates read only its own state on entry (the map edits of :953-974 are the caller's).
+struct FuseLds {
+    uint32_t cand[NCELL];          // build_grid's counters / cursors
+    uint16_t cell_start[NCELL + 1];
+    uint16_t items[MAXN];
+    int wsum[NT / 64];
+    int n_fused;
+};
+struct FuseArgs {
+    planar_frame_view f;
+    float inv_sigma2[PLANAR_MAX_LEVELS];
+    float lsf, th;
+    int n_levels, stride, shared;
+    const int32_t* n;
+    const uint8_t *usable, *desc;
+    const float *xw, *normal, *min_dist, *max_dist;
+    int32_t *fuse_idx, *fuse_dist, *n_fused;
+};
+__device__ inline float fuse_norm3(const float* v) { return (float)sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); }   // cv::norm: double accumulation
+
+__global__ __launch_bounds__(NT) void fuse_kernel(FuseArgs a) {
+    __shared__ FuseLds s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const planar_frame_view& f = a.f;
+    const int N = f.n[b];
+    const planar_keypoint* keys = f.keys_un + (size_t)b * f.stride;
+    const float* uR = f.u_right + (size_t)b * f.stride;
+    const uint8_t* kdesc = f.desc + (size_t)b * f.stride * 32;
+    if (tid == 0) s.n_fused = 0;
+    build_grid(s, f, keys, N);                                   // KeyFrame::mGrid is the frame's (src/KeyFrame.cc:56-63)
+    // GetRotation / GetTranslation / GetCameraCenter (src/KeyFrame.cc:79-93, 107-130): Ow = -Rwc * tcw, general gemm path (double accumulation)
+    const float* T = f.Tcw + (size_t)b * 16;
+    float Rcw[9], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[3 * r + c] = T[4 * r + c]; tcw[r] = T[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) {
+        double sum = 0;
+        for (int k = 0; k < 3; k++) sum += (double)Rcw[3 * k + i] * (double)tcw[k];
+        Ow[i] = (float)(sum * -1.0);
+    }
+    const size_t po = a.shared ? 0 : (size_t)b * a.stride;
+    const size_t oo = (size_t)b * a.stride;
+    const int NP = a.n[a.shared ? 0 : b];
+    int fused = 0;
+    for (int j = tid; j < a.stride; j += NT) {
+        int bestDist = 256, bestIdx = -1;
+        if (j < NP && a.usable[po + j]) {                                              // rows beyond n[b] read -1 / 256
+            const float* X = a.xw + (po + j) * 3;
+            const float xc = gemm3_row(Rcw[0], Rcw[1], Rcw[2], X, tcw[0]), yc = gemm3_row(Rcw[3], Rcw[4], Rcw[5], X, tcw[1]);
+            const float zc = gemm3_row(Rcw[6], Rcw[7], Rcw[8], X, tcw[2]);
+            if (!(zc < 0.0f)) {                                                        // :858
+                const float invz = 1.0f / zc;
+                const float x = xc * invz, y = yc * invz;
+                const float u = f.fx * x + f.cx, v = f.fy * y + f.cy;
+                if (u >= f.min_x && u < f.max_x && v >= f.min_y && v < f.max_y) {       // KeyFrame::IsInImage
+                    const float ur = u - f.bf * invz;
+                    const float maxDistance = 1.2f * a.max_dist[po + j], minDistance = 0.8f * a.min_dist[po + j];
+                    const float PO[3] = {X[0] - Ow[0], X[1] - Ow[1], X[2] - Ow[2]};
+                    const float dist3D = fuse_norm3(PO);
+                    const float* Pn = a.normal + (po + j) * 3;
+                    const double dotp = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+                    if (!(dist3D < minDistance || dist3D > maxDistance) && !(dotp < 0.5 * (double)dist3D)) {     // :878, :884
+                        const float ratio = a.max_dist[po + j] / dist3D;                // MapPoint::PredictScale (src/MapPoint.cc:402-417)
+                        int lvl = (int)ceilf((float)log((double)ratio) / a.lsf);
+                        if (lvl < 0) lvl = 0; else if (lvl >= a.n_levels) lvl = a.n_levels - 1;
+                        const float radius = a.th * f.scale_factors[lvl];
+                        uint32_t d[8];
+                        load_desc(d, a.desc + (po + j) * 32);
+                        // KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:639-678): the frame's window walk without level bounds
+                        const int nMinCellX = max(0, (int)floorf((u - f.min_x - radius) * f.grid_w_inv));
+                        const int nMaxCellX = min(PLANAR_GRID_COLS - 1, (int)ceilf((u - f.min_x + radius) * f.grid_w_inv));
+                        const int nMinCellY = max(0, (int)floorf((v - f.min_y - radius) * f.grid_h_inv));
+                        const int nMaxCellY = min(PLANAR_GRID_ROWS - 1, (int)ceilf((v - f.min_y + radius) * f.grid_h_inv));
+                        if (nMinCellX < PLANAR_GRID_COLS && nMaxCellX >= 0 && nMinCellY < PLANAR_GRID_ROWS && nMaxCellY >= 0 && nMinCellY <= nMaxCellY)
+                            for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+                                const int c0 = s.cell_start[ix * PLANAR_GRID_ROWS + nMinCellY], c1 = s.cell_start[ix * PLANAR_GRID_ROWS + nMaxCellY + 1];
+                                for (int k = c0; k < c1; k++) {
+                                    const int idx = s.items[k];
+                                    const planar_keypoint kp = keys[idx];
+                                    if (!(fabsf(kp.x - u) < radius && fabsf(kp.y - v) < radius)) continue;
+                                    const int kl = kp.octave;
+                                    if (kl < lvl - 1 || kl > lvl) continue;                                     // :912
+                                    const float kr = uR[idx];
+                                    const float ex = u - kp.x, ey = v - kp.y;
+                                    if (kr >= 0) {
+                                        const float er = ur - kr;
+                                        const float e2 = ex * ex + ey * ey + er * er;
+                                        if ((double)(e2 * a.inv_sigma2[kl]) > 7.8) continue;                    // :927
+                                    } else {
+                                        const float e2 = ex * ex + ey * ey;
+                                        if ((double)(e2 * a.inv_sigma2[kl]) > 5.99) continue;                   // :938
+                                    }
+                                    const int dist = hamming256(d, kdesc + (size_t)idx * 32);
+                                    if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+                                }
+                            }
+                    }
+                }
+            }
+        }
+        const bool hit = bestDist <= TH_LOW;                                            // :953
+        a.fuse_idx[oo + j] = hit ? bestIdx : -1;
+        if (a.fuse_dist) a.fuse_dist[oo + j] = bestDist;
+        fused += hit ? 1 : 0;
+    }
+    if (fused) atomicAdd(&s.n_fused, fused);
+    __syncthreads();
+    if (tid == 0) a.n_fused[b] = s.n_fused;
+}
+
 static int check_view(const planar_frame_view* f) {
     PLANAR_REQUIRE(f->B >= 1 && f->stride >= 1 && f->stride <= MAXN, PLANAR_EINVAL, "frame view: B >= 1 and 1 <= stride <= PLANAR_MAX_FRAME_KEYS required");
     PLANAR_REQUIRE(f->n && f->keys_un && f->u_right && f->desc, PLANAR_EINVAL, "frame view: null array");
@@ -874,6 +986,54 @@ int planar_search_by_projection_map(planar_ctx* ctx, const planar_frame_view* fr
     dp.n = s.dev<int32_t>(p0); dp.in_view = s.dev<uint8_t>(p1); dp.proj_x = s.dev<float>(p2); dp.proj_y = s.dev<float>(p3); dp.proj_xr = s.dev<float>(p4);
     dp.level = s.dev<int32_t>(p5); dp.view_cos = s.dev<float>(p6); dp.desc = s.dev<uint8_t>(p7); dp.observed = s.dev<uint8_t>(p8);
     rc = planar_search_by_projection_map_dev(ctx, &df, &dp, th, nn_ratio, s.dev<int32_t>(om), s.dev<int32_t>(on));
+    if (rc) return rc;
+    return s.download(ctx->stream);
+}
+
+int planar_fuse_search_dev(planar_ctx* ctx, const planar_frame_view* kf, const float* inv_level_sigma2, float log_scale_factor, int n_levels, const int32_t* d_n,
+                           int stride, int points_shared, const uint8_t* d_usable, const float* d_xw, const float* d_normal, const float* d_min_dist,
+                           const float* d_max_dist, const uint8_t* d_desc, float th, int32_t* d_fuse_idx, int32_t* d_fuse_dist, int32_t* d_n_fused) {
+    PLANAR_REQUIRE(ctx && kf && inv_level_sigma2 && d_n && d_usable && d_xw && d_normal && d_min_dist && d_max_dist && d_desc && d_fuse_idx && d_n_fused,
+                   PLANAR_EINVAL, "null argument");
+    int rc = guided::check_view(kf);
+    if (rc) return rc;
+    PLANAR_REQUIRE(kf->Tcw != nullptr, PLANAR_EINVAL, "key-frame view: Tcw required");
+    PLANAR_REQUIRE(stride >= 1 && n_levels >= 1 && n_levels <= PLANAR_MAX_LEVELS, PLANAR_EINVAL, "stride >= 1 and 1 <= n_levels <= PLANAR_MAX_LEVELS required");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    guided::FuseArgs a{};
+    a.f = *kf;
+    for (int l = 0; l < n_levels; l++) a.inv_sigma2[l] = inv_level_sigma2[l];
+    a.lsf = log_scale_factor; a.th = th; a.n_levels = n_levels; a.stride = stride; a.shared = points_shared ? 1 : 0;
+    a.n = d_n; a.usable = d_usable; a.desc = d_desc; a.xw = d_xw; a.normal = d_normal; a.min_dist = d_min_dist; a.max_dist = d_max_dist;
+    a.fuse_idx = d_fuse_idx; a.fuse_dist = d_fuse_dist; a.n_fused = d_n_fused;
+    hipLaunchKernelGGL(guided::fuse_kernel, dim3(kf->B), dim3(guided::NT), 0, ctx->stream, a);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_fuse_search(planar_ctx* ctx, const planar_frame_view* kf, const float* inv_level_sigma2, float log_scale_factor, int n_levels, const int32_t* n,
+                       int stride, int points_shared, const uint8_t* usable, const float* xw, const float* normal, const float* min_dist,
+                       const float* max_dist, const uint8_t* desc, float th, int32_t* fuse_idx, int32_t* fuse_dist, int32_t* n_fused) {
+    PLANAR_REQUIRE(ctx && kf && inv_level_sigma2 && n && usable && xw && normal && min_dist && max_dist && desc && fuse_idx && n_fused, PLANAR_EINVAL, "null argument");
+    int rc = guided::check_view(kf);
+    if (rc) return rc;
+    PLANAR_REQUIRE(kf->Tcw != nullptr && stride >= 1, PLANAR_EINVAL, "key-frame view: Tcw required, stride >= 1");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    int ix[6];
+    stage_view(s, kf, true, ix);
+    const int B = kf->B;
+    const size_t np = (size_t)(points_shared ? 1 : B) * stride, no = (size_t)B * stride;
+    const int p0 = s.in(n, (size_t)(points_shared ? 1 : B) * 4), p1 = s.in(usable, np), p2 = s.in(xw, np * 12), p3 = s.in(normal, np * 12), p4 = s.in(min_dist, np * 4),
+              p5 = s.in(max_dist, np * 4), p6 = s.in(desc, np * 32);
+    const int o0 = s.out(fuse_idx, no * 4), o1 = fuse_dist ? s.out(fuse_dist, no * 4) : -1, o2 = s.out(n_fused, (size_t)B * 4);
+    rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    planar_frame_view d = *kf;
+    patch_view(s, &d, ix);
+    rc = planar_fuse_search_dev(ctx, &d, inv_level_sigma2, log_scale_factor, n_levels, s.dev<int32_t>(p0), stride, points_shared, s.dev<uint8_t>(p1), s.dev<float>(p2),
+                                s.dev<float>(p3), s.dev<float>(p4), s.dev<float>(p5), s.dev<uint8_t>(p6), th, s.dev<int32_t>(o0),
+                                o1 >= 0 ? s.dev<int32_t>(o1) : nullptr, s.dev<int32_t>(o2));
     if (rc) return rc;
     return s.download(ctx->stream);
 }

@@ -14,7 +14,7 @@
 //                 (2^-36 m): integer addition is associative, so the centroids do not depend on the order the hardware retires the atomics in.
 //                 PCL sums floats in std::sort's (unstable) order; a centroid here is the correctly rounded mean, within the float-summation
 //                 error of the reference's (a few 1e-6 m), and reproducible.  PCL's bounding-box pass (getMinMax3D) is not needed: see voxel_key.
-//   C  order      occupied slots -> LDS list of (plane, i2, i1, i0, slot) -> bitonic sort = PCL's output order (ascending voxel index).
+//   C  order      occupied slots -> LDS list of (plane, i2, i1, i0, slot), compacted -> bitonic sort = PCL's output order (ascending voxel index).
 //   D  centroids  -> workspace, per-plane [first, last).
 //   E  refit      one WAVEFRONT per plane: distance gate (ballot), RANSAC with PCL's deterministic sampler (mt19937 seeded 12345: the stream is the
 //                 same for every plane, so it is a table made at create time), counts by ballot + popcount, the covariance sums as nine float
@@ -36,10 +36,10 @@ constexpr int VOX_BIAS = 8192;            // voxel coordinates floor(x / leaf) a
 constexpr unsigned long long EMPTY = ~0ull;
 
 struct Geo {
-    int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (LDS); mini: entries of a wavefront's tile table
+    int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (frame workspace); mini: entries of a wavefront's tile table (LDS)
     float fx, fy, cx, cy, factor, leaf;
     double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
-    size_t ws_stride, off_cnt, off_sum, off_cent;
+    size_t ws_stride, off_cnt, off_sum, off_cent, off_key;
 };
 
 struct Pt { float x, y, z; };
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
                                                           const int* __restrict__ n_planes, const int* __restrict__ rng, unsigned char* ws_all, int* n_out,
                                                           float* coef_out, int* src_out, int* off_out, float* pts_out, int* status, int* state_out,
                                                           int* nvox_out, int* info_out, long long* timing) {
-    extern __shared__ unsigned long long s_list[];        // max_points keys; the refit's shuffle array (u16) reuses it
+    extern __shared__ unsigned long long s_list[];        // the wavefronts' tile tables (B); then the list of occupied slots (C, D: max_points keys); then the refit's shuffle array (E, u16)
     __shared__ int s_first[MAXP], s_last[MAXP], s_state[MAXP], s_k[MAXP], s_o[MAXP + 1];
     __shared__ float s_coef[MAXP][4];
     __shared__ int s_n, s_err, s_kept;
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
     unsigned* tcnt = (unsigned*)(ws + G.off_cnt);
     unsigned long long* tsum = (unsigned long long*)(ws + G.off_sum);
     float* cent = (float*)(ws + G.off_cent);
+    unsigned long long* gkey = (unsigned long long*)(ws + G.off_key);   // the frame's key table: global memory (L2), touched once per (tile, voxel)
     int npl = n_planes[b];
     if (npl > MAXP) npl = MAXP;
     if (npl > G.pl_stride) npl = G.pl_stride;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
     auto mark = [&](int q) { if (tmark && tid == 0) tmark[q] = wall_clock64(); };
     mark(0);
 
-    for (int i = tid; i < TC; i += NT) { s_list[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TC + i] = 0ull; tsum[2 * TC + i] = 0ull; }
+    for (int i = tid; i < TC; i += NT) { gkey[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TC + i] = 0ull; tsum[2 * TC + i] = 0ull; }
     for (int i = tid; i < MAXP; i += NT) { s_first[i] = 0; s_last[i] = 0; s_state[i] = 0; }
     if (tid == 0) { s_n = 0; s_err = 0; s_kept = 0; }
     __threadfence();
@@ -335,19 +336,19 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
     // ---- B: voxel sums.  A wavefront takes a tile of 64 columns x ROWS rows and every lane walks DOWN its column: the 64 labels / depths of a row are
     //      one coalesced read, and a lane sums its run of equal (plane, voxel) in registers.  A finished run goes to the wavefront's own 128-entry LDS
     //      table (CAS on the key, four LDS atomics); at the end of the tile the table's entries - one per voxel the tile touched - go to the frame's
-    //      tables: an LDS CAS on the key table for the slot, then four fire-and-forget global atomics on the slot's count and sums.  A run that finds the
+    //      tables: a CAS on the frame's key table (global memory, L2) for the slot, then four fire-and-forget global atomics on the slot's count and sums.  A run that finds the
     //      small table crowded goes to the frame's tables directly.  All sums are integers: the path taken does not change the result. ----
     {
         constexpr int ROWS = 60, UNR = 4;
-        const int MINI = G.mini;                                    // 128 entries per wavefront (64 when the key table takes 128 KB), behind the key table
-        unsigned long long* mk = s_list + TC + (size_t)wave * 4 * MINI;      // keys, then the three sums
+        const int MINI = G.mini;                                    // 128 entries per wavefront
+        unsigned long long* mk = s_list + (size_t)wave * 4 * MINI;           // keys, then the three sums
         unsigned long long* ms0 = mk + MINI; unsigned long long* ms1 = ms0 + MINI; unsigned long long* ms2 = ms1 + MINI;
-        unsigned* mc = (unsigned*)(s_list + TC + (size_t)(NT / 64) * 4 * MINI) + (size_t)wave * MINI;
+        unsigned* mc = (unsigned*)(s_list + (size_t)(NT / 64) * 4 * MINI) + (size_t)wave * MINI;
         auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
         auto to_frame = [&](unsigned long long key, unsigned cnt, unsigned long long sx, unsigned long long sy, unsigned long long sz) {
             unsigned h = hash64(key) & (unsigned)(TC - 1);
             for (int probe = 0; probe < TC; probe++) {
-                const unsigned long long k = atomicCAS(&s_list[h], EMPTY, key);
+                const unsigned long long k = atomicCAS(&gkey[h], EMPTY, key);
                 if (k == EMPTY) { if (atomicAdd(&s_n, 1) >= G.max_points) s_err = 3; }
                 if (k == EMPTY || k == key) {
                     atomicAdd(&tcnt[h], cnt);
@@ -450,9 +451,17 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
 
     // ---- C: the key table, tagged with its slot numbers, sorted in place = PCL's output order (empty slots sort to the end) ----
     if (!err) {
-        for (int i = tid; i < TC; i += NT) { const unsigned long long k = s_list[i]; if (k != EMPTY) s_list[i] = (k << 14) | (unsigned long long)i; }
+        int n2 = 64;
+        while (n2 < M) n2 <<= 1;                                     // M <= max_points: the list fits the LDS block
+        if (tid == 0) s_kept = 0;
+        for (int i = M + tid; i < n2; i += NT) s_list[i] = EMPTY;
         __syncthreads();
-        bitonic(s_list, TC);
+        for (int i = tid; i < TC; i += NT) {
+            const unsigned long long k = __hip_atomic_load(&gkey[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k != EMPTY) s_list[atomicAdd(&s_kept, 1)] = (k << 14) | (unsigned long long)i;
+        }
+        __syncthreads();
+        bitonic(s_list, n2);
         // ---- D: centroids, per-plane ranges ----
         for (int r = tid; r < M; r += NT) {
             const unsigned long long e = s_list[r];
@@ -668,7 +677,7 @@ struct planar_plane_clouds {
     planar_ctx* ctx = nullptr;
     int max_batch = 0;
     planar::planepost::Geo G{};
-    size_t smem = 0;
+    size_t smem = 0, smem_cloud = 0;
     planar::DevBuf ws, rng, dbg;
     bool timing = false;
 };
@@ -692,20 +701,25 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
     G.off_cnt = 0;
     G.off_sum = (size_t)G.tcap * 4;
     G.off_cent = G.off_sum + (size_t)G.tcap * 24;
-    G.ws_stride = align_up(G.off_cent + (size_t)max_points * 12, (size_t)256);
-    G.mini = max_points > 4096 ? 64 : 128;
-    // the key table (64 KB at the default 4096 voxels per frame) + eight tile tables of `mini` entries x 36 B: 101 KB; 146 KB at 8192 voxels
-    p->smem = (size_t)G.tcap * 8 + (size_t)(planepost::NT / 64) * G.mini * 36;
+    G.off_key = align_up(G.off_cent + (size_t)max_points * 12, (size_t)16);
+    G.ws_stride = align_up(G.off_key + (size_t)G.tcap * 8, (size_t)256);
+    G.mini = 128;
+    // LDS of plane_clouds_kernel: eight tile tables of 128 entries x 36 B while the pixels are summed, the list of occupied slots (max_points x 8 B)
+    // while they are sorted: 36 KB at the default 4096 voxels per frame (three workgroups per CU next to other kernels), 64 KB at 8192.  The frame's
+    // key table itself (2 * max_points slots) lives in the workspace.  voxel_cloud_kernel (one workgroup, the map side) keeps its key table in LDS.
+    p->smem = std::max((size_t)(planepost::NT / 64) * G.mini * 36, (size_t)max_points * 8);
+    p->smem_cloud = (size_t)G.tcap * 8;
     int rc = p->ws.alloc(G.ws_stride * (size_t)max_batch);
     if (!rc) rc = p->rng.alloc((size_t)planepost::NRNG * 4);
     if (rc) { delete p; return rc; }
     std::vector<int> tab;
     planepost::sampler_table(tab);
     if (hipMemcpy(p->rng.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("plane_clouds: sampler table upload failed"); delete p; return PLANAR_EDEVICE; }
-    if (p->smem > 40 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)planepost::plane_clouds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::voxel_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
-        if (e != hipSuccess) { (void)hipGetLastError(); set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", p->smem); delete p; return PLANAR_EINVAL; }
+    {
+        hipError_t e = hipSuccess;
+        if (p->smem > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::plane_clouds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
+        if (e == hipSuccess && p->smem_cloud > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::voxel_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_cloud);
+        if (e != hipSuccess) { (void)hipGetLastError(); set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", std::max(p->smem, p->smem_cloud)); delete p; return PLANAR_EINVAL; }
     }
     *out = p;
     return PLANAR_OK;
@@ -856,7 +870,7 @@ int planar_merge_plane_points(planar_plane_clouds* p, const double* Twc, const f
     planepost::Geo G = p->G;
     G.leaf = leaf;
     if (n) hipLaunchKernelGGL(planepost::merge_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.dev<double>(i_T), s.dev<float>(i_f), n_frame, s.dev<float>(i_m), n_map, s.dev<float>(t_all));
-    hipLaunchKernelGGL(planepost::voxel_cloud_kernel, dim3(1), dim3(planepost::NT), p->smem, st, G, s.dev<float>(t_all), n, p->ws.as<unsigned char>(), s.dev<float>(t_out),
+    hipLaunchKernelGGL(planepost::voxel_cloud_kernel, dim3(1), dim3(planepost::NT), p->smem_cloud, st, G, s.dev<float>(t_all), n, p->ws.as<unsigned char>(), s.dev<float>(t_out),
                        s.dev<int>(o_h), s.dev<int>(o_h) + 1);
     PLANAR_HIP_CHECK(hipGetLastError());
     if ((rc = s.download(st))) return rc;

@@ -3,6 +3,7 @@
     ORBmatcher.SearchByProjection(CurrentFrame, LastFrame, th, bMono)   reference src/ORBmatcher.cc:1396 (include/ORBmatcher.h:45)
     ORBmatcher.SearchByProjection(F, vpMapPoints, th)                   reference src/ORBmatcher.cc:46   (include/ORBmatcher.h:41)
     ORBmatcher.SearchByBoW(pKF, F, vpMapPointMatches)                   reference src/ORBmatcher.cc:160  (include/ORBmatcher.h:59)
+    ORBmatcher.Fuse(pKF, vpMapPoints, th), the search half              reference src/ORBmatcher.cc:829  (include/ORBmatcher.h:81)
     LSDmatcher.SearchByProjection(F, vpMapLines, th)                    reference src/LSDmatcher.cpp:141
     PlaneMatcher.SearchMapByCoefficients(pF, vpMapPlanes)               reference src/PlaneMatcher.cpp:10
 
@@ -108,6 +109,27 @@ class ORBmatcher:
                                          a["desc"].ctypes.data, b["n"].ctypes.data, fs, b["node"].ctypes.data, b["angle"].ctypes.data,
                                          b["desc"].ctypes.data, self.mfNNratio, int(self.mbCheckOrientation), m.ctypes.data, nm.ctypes.data))
         return m, nm
+
+
+    def Fuse(self, kf: dict, mp: dict, th: float = 3.0, inv_level_sigma2=None, log_scale_factor: float | None = None, n_levels: int | None = None, shared: bool = False):
+        """Fuse(pKF, vpMapPoints, th) for B key frames (`kf`: a frame dict with Tcw), the search half: which keypoint of the key frame each map point
+        would be fused with.  mp: n, usable (non-NULL, not bad, not yet in the key frame), xw, normal, min_dist, max_dist (mfMinDistance /
+        mfMaxDistance), desc; shared: one list [1,S] for every key frame (LocalMapping::SearchInNeighbors).
+        Returns (fuse_idx [B,S] keypoint index / -1, fuse_dist [B,S] best Hamming distance (256: no candidate), n_fused [B] = the return values)."""
+        fv, keep = frame_view(kf)
+        sf = np.asarray(kf["scale_factors"], np.float32)
+        nl = n_levels or len(sf)
+        lsf = float(np.float32(np.log(np.float32(sf[1])))) if log_scale_factor is None else log_scale_factor      # KeyFrame::mfLogScaleFactor
+        # mvInvLevelSigma2[i] = 1 / (mvScaleFactors[i] * mvScaleFactors[i]) (src/ORBextractor.cc:441-446)
+        inv = _c(1.0 / (sf[:nl] * sf[:nl]) if inv_level_sigma2 is None else inv_level_sigma2, np.float32)
+        a = dict(n=_c(mp["n"], np.int32), usable=_c(mp["usable"], np.uint8), xw=_c(mp["xw"], np.float32), normal=_c(mp["normal"], np.float32),
+                 min_dist=_c(mp["min_dist"], np.float32), max_dist=_c(mp["max_dist"], np.float32), desc=_c(mp["desc"], np.uint8))
+        S = a["usable"].shape[-1]
+        idx = np.full((fv.B, S), -1, np.int32); dist = np.full((fv.B, S), 256, np.int32); nf = np.zeros(fv.B, np.int32)
+        check(lib().planar_fuse_search(self.ctx.h, C.byref(fv), inv.ctypes.data, lsf, nl, a["n"].ctypes.data, S, int(shared), a["usable"].ctypes.data, a["xw"].ctypes.data,
+                                       a["normal"].ctypes.data, a["min_dist"].ctypes.data, a["max_dist"].ctypes.data, a["desc"].ctypes.data, th,
+                                       idx.ctypes.data, dist.ctypes.data, nf.ctypes.data))
+        return idx, dist, nf
 
 
 class LSDmatcher:

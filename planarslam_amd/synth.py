@@ -546,6 +546,38 @@ def guided_local_map(frame, seed=14, n_points=2500, n_lines=300):
     return frame, mp, ml
 
 
+def guided_fuse_points(frame, seed=15, n_points=2500, hit=0.6, bits=60, pix_noise=1.5, inv_level_sigma2=None):
+    """Map points to fuse into posed key frames (ORBmatcher::Fuse): `hit` of them are back-projections of the key frame's own keypoints
+    (descriptor = the keypoint's with up to `bits` flipped, pixel noise, a predicted level at or one above the keypoint's octave), the rest the
+    generic local map of guided_local_map (behind the camera, outside the image, out of range, oblique).  Returns (frame with Tcw, mp) with
+    mp: n, usable, xw, normal, min_dist, max_dist, desc [+ observations for the map edits]."""
+    rng = np.random.default_rng(seed)
+    frame, mp, _ = guided_local_map(frame, seed=seed + 1, n_points=n_points, n_lines=4)
+    B = frame["keys_un"].shape[0]
+    mp = {k: v.copy() for k, v in mp.items()}
+    mp["usable"] = mp.pop("valid")
+    for b in range(B):
+        T = frame["Tcw"][b].reshape(4, 4).astype(np.float64)
+        Twc = np.linalg.inv(T); Ow = Twc[:3, 3]
+        m, nk = int(mp["n"][b]), int(frame["n"][b])
+        sel = np.flatnonzero(rng.random(m) < hit)
+        kp = rng.integers(0, nk, len(sel))
+        keys = frame["keys_un"][b]
+        ur = frame["u_right"][b, kp]
+        z = np.where(ur >= 0, frame["bf"] / np.maximum(keys["x"][kp] - ur, 1e-3), rng.uniform(0.6, 6.0, len(sel)))
+        u = keys["x"][kp] + rng.normal(0, pix_noise, len(sel)); v = keys["y"][kp] + rng.normal(0, pix_noise, len(sel))
+        Xc = np.stack([(u - frame["cx"]) * z / frame["fx"], (v - frame["cy"]) * z / frame["fy"], z, np.ones(len(sel))], 1)
+        X = (Twc @ Xc.T).T[:, :3]
+        d = np.linalg.norm(X - Ow, axis=1)
+        nrm = (X - Ow) / d[:, None] + rng.normal(0, 0.25, X.shape); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        lvl = keys["octave"][kp] + rng.integers(0, 2, len(sel))                   # the key point's level must be lvl - 1 or lvl
+        mx = d * 1.2 ** (lvl - rng.uniform(0.05, 0.95, len(sel)))                  # PredictScale = ceil(log(max / d) / log 1.2) = lvl
+        mp["xw"][b, sel] = X; mp["normal"][b, sel] = nrm; mp["max_dist"][b, sel] = mx; mp["min_dist"][b, sel] = mx / 1.2 ** 7 * 0.5
+        mp["desc"][b, sel] = _flip_bits(rng, frame["desc"][b, kp], bits)
+    mp["observations"] = rng.integers(1, 9, mp["usable"].shape).astype(np.int32)
+    return frame, mp
+
+
 def manhattan_scene(B=4, n_normals=8500, n_lines=40, seed=21, tilt_deg=4.0, noise=0.04, clutter=0.25, drop_axis=None):
     """Surface normals and vanishing directions of a Manhattan world seen from B cameras (Tracking::TrackManhattanFrame input).
 

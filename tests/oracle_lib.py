@@ -493,6 +493,41 @@ def is_in_frustum_points(frame, mp, log_scale_factor, n_levels, limit=0.5):
     return out
 
 
+def _inv_sigma2(frame, n_levels):
+    sf = np.asarray(frame["scale_factors"], np.float32)[:n_levels]
+    return np.ascontiguousarray(np.float32(1.0) / (sf * sf), np.float32)
+
+
+def fuse_search(kf, mp, th, log_scale_factor, n_levels, shared=False, inv_level_sigma2=None):
+    """oracle/guided_oracle.cpp fuse_search = ORBmatcher::Fuse(pKF, vpMapPoints, th), search half.  Returns (fuse_idx, fuse_dist, n_fused)."""
+    G = _g(); L = lib()
+    fv, keep = G.frame_view(kf)
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    inv = _inv_sigma2(kf, n_levels) if inv_level_sigma2 is None else c(inv_level_sigma2, np.float32)
+    a = [c(mp["n"], np.int32), c(mp["usable"], np.uint8), c(mp["xw"], np.float32), c(mp["normal"], np.float32), c(mp["min_dist"], np.float32), c(mp["max_dist"], np.float32),
+         c(mp["desc"], np.uint8)]
+    S = a[1].shape[-1]
+    idx = np.full((fv.B, S), -1, np.int32); dist = np.full((fv.B, S), 256, np.int32); nf = np.zeros(fv.B, np.int32)
+    L.orc_fuse_search(C.byref(fv), p(inv), C.c_float(log_scale_factor), int(n_levels), p(a[0]), S, int(shared), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[6]),
+                      C.c_float(th), p(idx), p(dist), p(nf))
+    return idx, dist, nf
+
+
+def ref_fuse(kf, mp, b, th, log_scale_factor, n_levels, shared=False, kf_state=None, kf_obs=None):
+    """One key frame through the REAL ORBmatcher::Fuse (oracle/_ref/ref_match, mode fuse).  Returns (fuse_idx [n], nFused)."""
+    pb = 0 if shared else b
+    npb = int(mp["n"][pb]); nk = int(kf["n"][b])
+    state = np.zeros(nk, np.uint8) if kf_state is None else np.asarray(kf_state, np.uint8)[:nk]
+    kobs = np.zeros(nk, np.int32) if kf_obs is None else np.asarray(kf_obs, np.int32)[:nk]
+    blocks = [np.array([th, log_scale_factor, float(n_levels)], np.float32)] + _frame_blocks(kf, b) + [
+        _inv_sigma2(kf, n_levels), np.asarray(kf["Tcw"][b], np.float32), mp["usable"][pb, :npb].astype(np.uint8), mp["xw"][pb, :npb].astype(np.float32),
+        mp["normal"][pb, :npb].astype(np.float32), mp["min_dist"][pb, :npb].astype(np.float32), mp["max_dist"][pb, :npb].astype(np.float32), mp["desc"][pb, :npb],
+        state, kobs, np.asarray(mp.get("observations", np.ones_like(mp["usable"], dtype=np.int32))[pb, :npb], np.int32)]
+    idx, nf = _run_ref_match("fuse", blocks, 2)
+    return idx, int(nf[0])
+
+
 def is_in_frustum_lines(frame, ml, log_scale_factor, limit=0.5):
     G = _g(); L = lib()
     fv, keep = G.frame_view(frame)

@@ -70,6 +70,9 @@ def test_argument_errors_are_reported_without_touching_a_device():
         lambda: L.planar_is_line_good(None, 1, p, p, 40, p, 640, 480, 640, 640 * 480, 0.0002, 535.4, 539.2, 320.1, 247.6, p, p, p, p, p, p, p, p),
         lambda: L.planar_bow_transform(None, None, p, 1, 1, 4, p, p, p, p, p, p),
         lambda: L.planar_track_manhattan_frame(None, 1, p, p, p, 1, p, p, 1, p, None, None, None),
+        # round-3 entry points
+        lambda: L.planar_fuse_search(None, ctypes.byref(fv), p, 0.18, 8, p, 1, 0, p, p, p, p, p, p, 3.0, p, None, p),
+        lambda: L.planar_fuse_search_dev(None, ctypes.byref(fv), p, 0.18, 8, p, 1, 0, p, p, p, p, p, p, 3.0, p, None, p),
     ]
     for i, c in enumerate(calls):
         rc = c()
