@@ -363,6 +363,23 @@ int planar_lsd_search_by_projection_dev(planar_ctx* ctx, int B, const int32_t* d
                                         const float* scale_factors /* host */, int n_levels, float th, float nn_ratio, int32_t* d_match,
                                         int32_t* d_nmatches);
 
+/* LSDmatcher::Fuse(KeyFrame* pKF, const vector<MapLine*>& vpMapLines, th) (src/LSDmatcher.cpp:884-1015), the SEARCH half (:904-991): projection of both
+ * end points, image-bounds / distance / viewing-angle gates, MapLine::PredictScale (src/MapLine.cpp:381-390, not clamped), KeyFrame::GetLinesInArea
+ * (src/KeyFrame.cc:680-712), level gate, smallest Hamming distance, TH_LOW.  The map edits (:993-1010) stay with the caller, as for planar_fuse_search.
+ *   kf: only B, Tcw, fx fy cx cy, min/max bounds and scale_factors are read (the key-point arrays may be NULL)
+ *   keylines / ldesc = pKF->mvKeyLines / mLineDescriptors; usable[j] = vpMapLines[j] != NULL && !isBad(); xw6 / normal = GetWorldPos() / GetNormal()
+ *   (doubles); min_dist / max_dist = mfMinDistance / mfMaxDistance.  A predicted level outside [0, n_levels) indexes mvScaleFactors out of
+ *   bounds in the reference (undefined); such a line is skipped here.
+ *   fuse_idx[b][j] = bestIdx where bestDist <= TH_LOW else -1; fuse_dist (may be NULL) = bestDist (INT_MAX: no candidate); rows j >= n_ml[b] read -1 / INT_MAX. */
+int planar_lsd_fuse_search(planar_ctx* ctx, const planar_frame_view* kf, float log_scale_factor, int n_levels, const int32_t* n_lines, int line_stride,
+                           const planar_keyline* keylines, const uint8_t* ldesc, const int32_t* n_ml, int ml_stride, int lines_shared,
+                           const uint8_t* usable, const double* xw6, const double* normal, const float* min_dist, const float* max_dist,
+                           const uint8_t* ml_desc, float th, int32_t* fuse_idx, int32_t* fuse_dist, int32_t* n_fused);
+int planar_lsd_fuse_search_dev(planar_ctx* ctx, const planar_frame_view* d_kf, float log_scale_factor, int n_levels, const int32_t* d_n_lines, int line_stride,
+                               const planar_keyline* d_keylines, const uint8_t* d_ldesc, const int32_t* d_n_ml, int ml_stride, int lines_shared,
+                               const uint8_t* d_usable, const double* d_xw6, const double* d_normal, const float* d_min_dist, const float* d_max_dist,
+                               const uint8_t* d_ml_desc, float th, int32_t* d_fuse_idx, int32_t* d_fuse_dist, int32_t* d_n_fused);
+
 /* PlaneMatcher::SearchMapByCoefficients(Frame&, const vector<MapPlane*>&) (src/PlaneMatcher.cpp:10-66) with
  * Frame::ComputePlaneWorldCoeff (src/Frame.cc:815-820) and PointDistanceFromPlane (:67-79).
  *   pl_coef [B][pl_stride][4]  mvPlaneCoefficients[i] (camera frame)      Tcw [B][16]

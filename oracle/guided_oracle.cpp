@@ -16,6 +16,7 @@
 // float products summed left to right, then (float)(t*alpha + c*beta) in double) and its general path
 // (double accumulation, used when a transpose flag is set) are restated from the 3.4 sources by reading.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -498,6 +499,65 @@ int fuse_search(const planar_frame_view& K, int b, const float* inv_sigma2, floa
     return nFused;
 }
 
+// ---- LSDmatcher::Fuse(KeyFrame*, const vector<MapLine*>&, th), the search half (src/LSDmatcher.cpp:884-991); pinned through ref_match mode `lsd_fuse`
+//      (the real function with KeyFrame::GetLinesInArea src/KeyFrame.cc:680-712 and MapLine::PredictScale src/MapLine.cpp:381-390 compiled in).
+int lsd_fuse_search(const planar_frame_view& K, int b, float log_scale_factor, int n_levels, int n_lines, const planar_keyline* kl, const uint8_t* ldesc, int n,
+                    const uint8_t* usable, const double* xw6, const double* normal, const float* min_dist, const float* max_dist, const uint8_t* desc, float th,
+                    int32_t* fuse_idx, int32_t* fuse_dist) {
+    const FrustumPose P = frustum_pose(K.Tcw + (size_t)b * 16);
+    int nFused = 0;
+    std::vector<int> vIndices;
+    for (int j = 0; j < n; j++) {
+        fuse_idx[j] = -1;
+        if (fuse_dist) fuse_dist[j] = INT_MAX;
+        if (!usable[j]) continue;
+        float SP[3], EP[3];
+        for (int k = 0; k < 3; k++) { SP[k] = (float)xw6[6 * j + k]; EP[k] = (float)xw6[6 * j + 3 + k]; }
+        const float SPcX = gemm3_row(P.Rcw, SP, P.tcw[0]), SPcY = gemm3_row(P.Rcw + 3, SP, P.tcw[1]), SPcZ = gemm3_row(P.Rcw + 6, SP, P.tcw[2]);
+        const float EPcX = gemm3_row(P.Rcw, EP, P.tcw[0]), EPcY = gemm3_row(P.Rcw + 3, EP, P.tcw[1]), EPcZ = gemm3_row(P.Rcw + 6, EP, P.tcw[2]);
+        if (SPcZ < 0.0f || EPcZ < 0.0f) continue;
+        const float invz1 = 1.0f / SPcZ;
+        const float u1 = K.fx * SPcX * invz1 + K.cx, v1 = K.fy * SPcY * invz1 + K.cy;
+        if (u1 < K.min_x || u1 > K.max_x) continue;
+        if (v1 < K.min_y || v1 > K.max_y) continue;
+        const float invz2 = 1.0f / EPcZ;
+        const float u2 = K.fx * EPcX * invz2 + K.cx, v2 = K.fy * EPcY * invz2 + K.cy;
+        if (u2 < K.min_x || u2 > K.max_x) continue;
+        if (v2 < K.min_y || v2 > K.max_y) continue;
+        const float maxDistance = 1.2f * max_dist[j], minDistance = 0.8f * min_dist[j];
+        float OM[3];
+        for (int k = 0; k < 3; k++) OM[k] = (float)((double)(SP[k] + EP[k]) * 0.5) - P.Ow[k];
+        const float dist = norm3(OM);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float pn[3] = {(float)normal[3 * j], (float)normal[3 * j + 1], (float)normal[3 * j + 2]};
+        if (dot3(OM, pn) < 0.5 * dist) continue;
+        const float ratio = max_dist[j] / dist;
+        const int lvl = (int)std::ceil(logf_cr(ratio) / log_scale_factor);   // MapLine::PredictScale: no clamping
+        if (lvl < 0 || lvl >= n_levels) continue;                            // mvScaleFactors[lvl] out of bounds = UB in the reference; defined as "skip"
+        const float radius = th * K.scale_factors[lvl];
+        // KeyFrame::GetLinesInArea(u1, v1, u2, v2, radius) (src/KeyFrame.cc:680-712), minLevel = maxLevel = -1: no level bounds
+        vIndices.clear();
+        for (int i = 0; i < n_lines; i++) {
+            const float distance = (float)((0.5 * (u1 + u2) - kl[i].pt_x) * (0.5 * (u1 + u2) - kl[i].pt_x) + (0.5 * (v1 + v2) - kl[i].pt_y) * (0.5 * (v1 + v2) - kl[i].pt_y));
+            if (distance > radius * radius) continue;
+            const float slope = (v1 - v2) / (u1 - u2) - kl[i].angle;
+            if (slope > radius * 0.01) continue;
+            vIndices.push_back(i);
+        }
+        if (vIndices.empty()) continue;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int idx : vIndices) {
+            const int klLevel = kl[idx].octave;
+            if (klLevel < lvl - 1 || klLevel > lvl) continue;
+            const int d = descriptor_distance(desc + (size_t)j * 32, ldesc + (size_t)idx * 32);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (fuse_dist) fuse_dist[j] = bestDist;
+        if (bestDist <= TH_LOW) { fuse_idx[j] = bestIdx; nFused++; }
+    }
+    return nFused;
+}
+
 }  // namespace orc
 
 extern "C" {
@@ -528,6 +588,16 @@ int orc_fuse_search(const planar_frame_view* K, const float* inv_sigma2, float l
         const size_t o = points_shared ? 0 : (size_t)b * stride, oo = (size_t)b * stride;
         n_fused[b] = orc::fuse_search(*K, b, inv_sigma2, lsf, n_levels, n[points_shared ? 0 : b], usable + o, xw + o * 3, normal + o * 3, min_dist + o, max_dist + o,
                                       desc + o * 32, th, fuse_idx + oo, fuse_dist ? fuse_dist + oo : nullptr);
+    }
+    return 0;
+}
+int orc_lsd_fuse_search(const planar_frame_view* K, float lsf, int n_levels, const int32_t* n_lines, int line_stride, const planar_keyline* keylines,
+                        const uint8_t* ldesc, const int32_t* n_ml, int ml_stride, int lines_shared, const uint8_t* usable, const double* xw6, const double* normal,
+                        const float* min_dist, const float* max_dist, const uint8_t* ml_desc, float th, int32_t* fuse_idx, int32_t* fuse_dist, int32_t* n_fused) {
+    for (int b = 0; b < K->B; b++) {
+        const size_t lo = (size_t)b * line_stride, o = lines_shared ? 0 : (size_t)b * ml_stride, oo = (size_t)b * ml_stride;
+        n_fused[b] = orc::lsd_fuse_search(*K, b, lsf, n_levels, n_lines[b], keylines + lo, ldesc + lo * 32, n_ml[lines_shared ? 0 : b], usable + o, xw6 + o * 6,
+                                          normal + o * 3, min_dist + o, max_dist + o, ml_desc + o * 32, th, fuse_idx + oo, fuse_dist ? fuse_dist + oo : nullptr);
     }
     return 0;
 }

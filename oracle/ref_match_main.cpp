@@ -1,7 +1,7 @@
 // oracle/ref_match_main.cpp — TEST INFRASTRUCTURE.  Driver for the REAL reference matchers, compiled from
 // /root/reference/src/ORBmatcher.cc, src/LSDmatcher.cpp and src/PlaneMatcher.cpp where they lie (never copied) against the stand-ins in
 // oracle/shim (cvshim.hpp + cvalgebra.hpp + match_standins.hpp) into oracle/_ref/ref_match.
-//   ref_match <mode> <in.bin> <out.bin>     mode = proj_frame | proj_map | bow | match_orb | plane | lsd_proj | lsd_desc | fuse
+//   ref_match <mode> <in.bin> <out.bin>     mode = proj_frame | proj_map | bow | match_orb | plane | lsd_proj | lsd_desc | fuse | lsd_fuse
 // in/out files are sequences of blocks {int64 nbytes; bytes}; tests/oracle_lib.py (run_ref_match) writes and reads them.
 #include <cstdio>
 #include <cstdlib>
@@ -290,6 +290,43 @@ int main(int argc, char** argv) {
         ORBmatcher matcher(0.6f, true);
         const int nFused = matcher.Fuse(&kf, vp, prm[0]);
         std::vector<int32_t> idx(np, -1);
+        for (auto& e : fuse_log()) idx[e.first] = e.second;
+        out.put(idx.data(), idx.size()); out.put(&nFused, 1);
+    } else if (mode == "lsd_fuse") {
+        // LSDmatcher::Fuse(KeyFrame*, const vector<MapLine*>&, th) (src/LSDmatcher.cpp:884-1015).  prm = {th, log_scale_factor}
+        size_t nl, nm, nsf;
+        const cv::line_descriptor::KeyLine* kl = in.get<cv::line_descriptor::KeyLine>(&nl);
+        const uint8_t* ldesc = in.get<uint8_t>();
+        const float* intr = in.get<float>();             // min_x, max_x, min_y, max_y, fx, fy, cx, cy, bf
+        const float* sf = in.get<float>(&nsf);
+        const float* Tcw = in.get<float>();
+        const uint8_t* usable = in.get<uint8_t>(&nm);
+        const double *xw6 = in.get<double>(), *nrm = in.get<double>();
+        const float *mind = in.get<float>(), *maxd = in.get<float>();
+        const uint8_t* d = in.get<uint8_t>();
+        const uint8_t* kf_state = in.get<uint8_t>();
+        const int32_t* kf_obs = in.get<int32_t>();
+        const int32_t* ml_obs = in.get<int32_t>();
+        KeyFrame kf;
+        kf.mvKeyLines.assign(kl, kl + nl); kf.mLineDescriptors = desc_mat((int)nl, ldesc);
+        kf.mnMinX = intr[0]; kf.mnMaxX = intr[1]; kf.mnMinY = intr[2]; kf.mnMaxY = intr[3]; kf.fx = intr[4]; kf.fy = intr[5]; kf.cx = intr[6]; kf.cy = intr[7]; kf.mbf = intr[8];
+        kf.mvScaleFactors.assign(sf, sf + nsf); kf.mfLogScaleFactor = prm[1]; kf.mnScaleLevels = (int)nsf;
+        kf.SetPose(mat_f32(4, 4, Tcw));
+        std::vector<MapLine> kfmls(nl), mls(nm);
+        kf.mls.assign(nl, nullptr);
+        for (size_t i = 0; i < nl; i++) if (kf_state[i]) { kfmls[i].bad = kf_state[i] == 2; kfmls[i].nobs = kf_obs[i]; kfmls[i].index = -2 - (int)i; kf.mls[i] = &kfmls[i]; }
+        std::vector<MapLine*> vp(nm, nullptr);
+        for (size_t i = 0; i < nm; i++) {
+            for (int k = 0; k < 6; k++) mls[i].mWorldPos(k) = xw6[6 * i + k];
+            for (int k = 0; k < 3; k++) mls[i].normal(k) = nrm[3 * i + k];
+            mls[i].mLDescriptor = desc_mat(1, d + 32 * i); mls[i].mfMinDistance = mind[i]; mls[i].mfMaxDistance = maxd[i]; mls[i].nobs = ml_obs[i]; mls[i].index = (int)i;
+            if (usable[i]) vp[i] = &mls[i];
+            else if (i % 2 == 1) { mls[i].bad = true; vp[i] = &mls[i]; }      // not usable: a NULL entry or a bad line, in turn
+        }
+        fuse_log().clear();
+        LSDmatcher matcher;
+        const int nFused = matcher.Fuse(&kf, vp, prm[0]);
+        std::vector<int32_t> idx(nm, -1);
         for (auto& e : fuse_log()) idx[e.first] = e.second;
         out.put(idx.data(), idx.size()); out.put(&nFused, 1);
     } else { std::fprintf(stderr, "unknown mode\n"); return 2; }

@@ -7,8 +7,8 @@
 // src/Frame.cc, which cannot be built as a whole here (PCL, threads, the extractors).  With -DSTANDINS_REAL_FRAME_FUNCS (how
 // oracle/Makefile builds ref_match) they are only DECLARED here and their bodies are the reference's own: lines 155-168, 269-293,
 // 440-535, 815-820 of src/Frame.cc extracted at build time into oracle/_ref/gen/frame_extract_match.cpp, together with src/MapPoint.cc:390-434
-// (distance invariance, PredictScale) and src/KeyFrame.cc:79-93, 107-111, 120-130, 639-678, 715-718 (pose getters, GetFeaturesInArea, IsInImage) for
-// ORBmatcher::Fuse.  Without the macro the restated bodies / stubs below are used.  KeyFrame's line helpers (src/KeyFrame.cc, same text) stay restated.
+// (distance invariance, PredictScale), src/MapLine.cpp:369-390 (the same for lines) and src/KeyFrame.cc:79-93, 107-111, 120-130, 639-678, 680-713,
+// 715-718 (pose getters, GetFeaturesInArea, GetLinesInArea, IsInImage) for ORBmatcher::Fuse / LSDmatcher::Fuse.  Without the macro the restated bodies / stubs below are used.  KeyFrame's line helpers (src/KeyFrame.cc, same text) stay restated.
 #pragma once
 #define MAPPOINT_H
 #define KEYFRAME_H
@@ -107,12 +107,21 @@ class MapLine {
 public:
     Vector6d GetWorldPos() { return mWorldPos; }
     Eigen::Vector3d GetNormal() { return normal; }
-    cv::Mat GetDescriptor() { return mLDescriptor.clone(); }
+    cv::Mat GetDescriptor() { fuse_current() = index; return mLDescriptor.clone(); }
     bool isBad() { return bad; }
     int Observations() { return nobs; }
+#ifdef STANDINS_REAL_FRAME_FUNCS
+    // bodies: src/MapLine.cpp:369-390, extracted at build time
+    float GetMinDistanceInvariance();
+    float GetMaxDistanceInvariance();
+    int PredictScale(const float& currentDist, const float& logScaleFactor);
+    float mfMinDistance = 0, mfMaxDistance = 0;
+    CopyableMutex mMutexPos;
+#else
     float GetMinDistanceInvariance() { return 0.f; }
     float GetMaxDistanceInvariance() { return 1e9f; }
     int PredictScale(const float&, const float&) { return 0; }
+#endif
     int PredictScale(const float&, KeyFrame*) { return 0; }
     int PredictScale(const float&, Frame*) { return 0; }
     bool IsInKeyFrame(KeyFrame*) { return false; }
@@ -301,9 +310,14 @@ public:
     float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfLogScaleFactor = 0;
     std::vector<MapLine*> GetMapLineMatches() { return mls; }
     std::set<MapLine*> GetMapLines() { return std::set<MapLine*>(); }
-    MapLine* GetMapLine(const size_t& i) { return mls[i]; }
+    MapLine* GetMapLine(const size_t& i) { fuse_log().push_back(std::make_pair(fuse_current(), (int)i)); return mls[i]; }
     void AddMapLine(MapLine*, const size_t&) {}
-#ifndef STANDINS_NO_REFERENCE
+#ifdef STANDINS_REAL_FRAME_FUNCS
+    // body: src/KeyFrame.cc:680-713, extracted at build time
+    vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r, const int minLevel = -1,
+                                  const int maxLevel = -1) const;
+    void lineDescriptorMAD(vector<vector<cv::DMatch>> m, double& a, double& b) const { line_descriptor_mad(m, a, b); }
+#elif !defined(STANDINS_NO_REFERENCE)
     vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r, const int minLevel = -1,
                                   const int maxLevel = -1) const { return lines_in_area(mvKeyLines, x1, y1, x2, y2, r, minLevel, maxLevel); }
     void lineDescriptorMAD(vector<vector<cv::DMatch>> m, double& a, double& b) const { line_descriptor_mad(m, a, b); }

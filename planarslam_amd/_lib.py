@@ -121,6 +121,8 @@ _SIGS = {
     "planar_search_by_projection_map_dev": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.POINTER(MapProbes), C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "planar_fuse_search": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3),
     "planar_fuse_search_dev": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3),
+    "planar_lsd_fuse_search": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3),
+    "planar_lsd_fuse_search_dev": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3),
     "planar_is_in_frustum_points": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.c_float, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 6),
     "planar_is_in_frustum_points_dev": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.c_float, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 6),
     "planar_is_in_frustum_lines": (C.c_int, [C.c_void_p, C.POINTER(FrameView), C.c_float, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 4),

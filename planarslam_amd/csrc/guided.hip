@@ -6,6 +6,7 @@
 //   planar_lsd_search_by_projection     LSDmatcher::SearchByProjection + Frame::GetLinesInArea           src/LSDmatcher.cpp:141-211, src/Frame.cc:491-524
 //   planar_plane_search_by_coefficients PlaneMatcher::SearchMapByCoefficients                           src/PlaneMatcher.cpp:10-79
 //   planar_fuse_search                  ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th), the search half   src/ORBmatcher.cc:829-951
+//   planar_lsd_fuse_search              LSDmatcher::Fuse(KeyFrame*, vpMapLines, th), the search half    src/LSDmatcher.cpp:884-991
 //
 // The reference resolves probes one after another and every assignment changes what later probes may take
 // ("mvpMapPoints[i2]->Observations() > 0"), so the result depends on probe order.  The kernels keep that order
@@ -862,6 +863,92 @@ __global__ __launch_bounds__(NT) void fuse_kernel(FuseArgs a) {
     if (tid == 0) a.n_fused[b] = s.n_fused;
 }
 
+// ---- LSDmatcher::Fuse(KeyFrame*, vpMapLines, th), search half (src/LSDmatcher.cpp:884-991): one wavefront per key frame, one lane per map line; every
+//      lane scans the key frame's key lines in index order (KeyFrame::GetLinesInArea is a linear scan, src/KeyFrame.cc:680-712).
+struct LineFuseArgs {
+    planar_frame_view f;
+    float lsf, th;
+    int n_levels, line_stride, ml_stride, shared;
+    const int32_t *n_lines, *n_ml;
+    const planar_keyline* keylines;
+    const uint8_t *ldesc, *usable, *ml_desc;
+    const double *xw6, *normal;
+    const float *min_dist, *max_dist;
+    int32_t *fuse_idx, *fuse_dist, *n_fused;
+};
+
+__global__ __launch_bounds__(64) void lsd_fuse_kernel(LineFuseArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const planar_frame_view& f = a.f;
+    const int NLn = a.n_lines[b];
+    const size_t lo = (size_t)b * a.line_stride, mo = a.shared ? 0 : (size_t)b * a.ml_stride, oo = (size_t)b * a.ml_stride;
+    const int NM = a.n_ml[a.shared ? 0 : b];
+    const planar_keyline* kl = a.keylines + lo;
+    const uint8_t* ldesc = a.ldesc + lo * 32;
+    const float* T = f.Tcw + (size_t)b * 16;
+    float Rcw[9], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[3 * r + c] = T[4 * r + c]; tcw[r] = T[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) {
+        double sum = 0;
+        for (int k = 0; k < 3; k++) sum += (double)Rcw[3 * k + i] * (double)tcw[k];
+        Ow[i] = (float)(sum * -1.0);
+    }
+    int fused = 0;
+    for (int j = lane; j < a.ml_stride; j += 64) {
+        int bestDist = 0x7fffffff, bestIdx = -1;
+        bool go = j < NM && a.usable[mo + j] != 0;
+        float u1 = 0, v1 = 0, u2 = 0, v2 = 0, radius = 0;
+        int lvl = 0;
+        if (go) {
+            float SP[3], EP[3];
+            for (int k = 0; k < 3; k++) { SP[k] = (float)a.xw6[6 * (mo + j) + k]; EP[k] = (float)a.xw6[6 * (mo + j) + 3 + k]; }
+            const float SPcX = gemm3_row(Rcw[0], Rcw[1], Rcw[2], SP, tcw[0]), SPcY = gemm3_row(Rcw[3], Rcw[4], Rcw[5], SP, tcw[1]);
+            const float SPcZ = gemm3_row(Rcw[6], Rcw[7], Rcw[8], SP, tcw[2]);
+            const float EPcX = gemm3_row(Rcw[0], Rcw[1], Rcw[2], EP, tcw[0]), EPcY = gemm3_row(Rcw[3], Rcw[4], Rcw[5], EP, tcw[1]);
+            const float EPcZ = gemm3_row(Rcw[6], Rcw[7], Rcw[8], EP, tcw[2]);
+            go = !(SPcZ < 0.0f || EPcZ < 0.0f);
+            const float invz1 = 1.0f / SPcZ, invz2 = 1.0f / EPcZ;
+            u1 = f.fx * SPcX * invz1 + f.cx; v1 = f.fy * SPcY * invz1 + f.cy;
+            u2 = f.fx * EPcX * invz2 + f.cx; v2 = f.fy * EPcY * invz2 + f.cy;
+            if (u1 < f.min_x || u1 > f.max_x || v1 < f.min_y || v1 > f.max_y) go = false;
+            if (u2 < f.min_x || u2 > f.max_x || v2 < f.min_y || v2 > f.max_y) go = false;
+            const float maxDistance = 1.2f * a.max_dist[mo + j], minDistance = 0.8f * a.min_dist[mo + j];
+            float OM[3];
+            for (int k = 0; k < 3; k++) OM[k] = (float)((double)(SP[k] + EP[k]) * 0.5) - Ow[k];
+            const float dist = fuse_norm3(OM);
+            if (dist < minDistance || dist > maxDistance) go = false;
+            const float pn[3] = {(float)a.normal[3 * (mo + j)], (float)a.normal[3 * (mo + j) + 1], (float)a.normal[3 * (mo + j) + 2]};
+            const double dotp = (double)OM[0] * pn[0] + (double)OM[1] * pn[1] + (double)OM[2] * pn[2];
+            if (dotp < 0.5 * (double)dist) go = false;
+            const float ratio = a.max_dist[mo + j] / dist;                   // MapLine::PredictScale: not clamped
+            lvl = (int)ceilf((float)log((double)ratio) / a.lsf);
+            if (lvl < 0 || lvl >= a.n_levels) go = false;                    // mvScaleFactors[lvl] out of bounds in the reference (UB): skipped
+            if (go) radius = a.th * f.scale_factors[lvl];
+        }
+        if (go) {
+            uint32_t d[8];
+            load_desc(d, a.ml_desc + (mo + j) * 32);
+            for (int i = 0; i < NLn; i++) {
+                const planar_keyline k = kl[i];
+                const double mx = 0.5 * (double)(u1 + u2) - (double)k.pt_x, my = 0.5 * (double)(v1 + v2) - (double)k.pt_y;
+                const float distance = (float)(mx * mx + my * my);
+                if (distance > radius * radius) continue;
+                const float slope = (v1 - v2) / (u1 - u2) - k.angle;
+                if ((double)slope > (double)radius * 0.01) continue;
+                if (k.octave < lvl - 1 || k.octave > lvl) continue;          // :968
+                const int dist = hamming256(d, ldesc + (size_t)i * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdx = i; }
+            }
+        }
+        const bool hit = bestDist <= TH_LOW;
+        a.fuse_idx[oo + j] = hit ? bestIdx : -1;
+        if (a.fuse_dist) a.fuse_dist[oo + j] = bestDist;
+        fused += hit ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) fused += __shfl_xor(fused, o, 64);
+    if (lane == 0) a.n_fused[b] = fused;
+}
+
 static int check_view(const planar_frame_view* f) {
     PLANAR_REQUIRE(f->B >= 1 && f->stride >= 1 && f->stride <= MAXN, PLANAR_EINVAL, "frame view: B >= 1 and 1 <= stride <= PLANAR_MAX_FRAME_KEYS required");
     PLANAR_REQUIRE(f->n && f->keys_un && f->u_right && f->desc, PLANAR_EINVAL, "frame view: null array");
@@ -1034,6 +1121,50 @@ int planar_fuse_search(planar_ctx* ctx, const planar_frame_view* kf, const float
     rc = planar_fuse_search_dev(ctx, &d, inv_level_sigma2, log_scale_factor, n_levels, s.dev<int32_t>(p0), stride, points_shared, s.dev<uint8_t>(p1), s.dev<float>(p2),
                                 s.dev<float>(p3), s.dev<float>(p4), s.dev<float>(p5), s.dev<uint8_t>(p6), th, s.dev<int32_t>(o0),
                                 o1 >= 0 ? s.dev<int32_t>(o1) : nullptr, s.dev<int32_t>(o2));
+    if (rc) return rc;
+    return s.download(ctx->stream);
+}
+
+int planar_lsd_fuse_search_dev(planar_ctx* ctx, const planar_frame_view* kf, float log_scale_factor, int n_levels, const int32_t* d_n_lines, int line_stride,
+                               const planar_keyline* d_keylines, const uint8_t* d_ldesc, const int32_t* d_n_ml, int ml_stride, int lines_shared,
+                               const uint8_t* d_usable, const double* d_xw6, const double* d_normal, const float* d_min_dist, const float* d_max_dist,
+                               const uint8_t* d_ml_desc, float th, int32_t* d_fuse_idx, int32_t* d_fuse_dist, int32_t* d_n_fused) {
+    PLANAR_REQUIRE(ctx && kf && kf->Tcw && d_n_lines && d_keylines && d_ldesc && d_n_ml && d_usable && d_xw6 && d_normal && d_min_dist && d_max_dist && d_ml_desc &&
+                       d_fuse_idx && d_n_fused, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(kf->B >= 1 && line_stride >= 1 && ml_stride >= 1 && n_levels >= 1 && n_levels <= PLANAR_MAX_LEVELS, PLANAR_EINVAL,
+                   "B, strides >= 1 and 1 <= n_levels <= PLANAR_MAX_LEVELS required");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    guided::LineFuseArgs a{};
+    a.f = *kf; a.lsf = log_scale_factor; a.th = th; a.n_levels = n_levels; a.line_stride = line_stride; a.ml_stride = ml_stride; a.shared = lines_shared ? 1 : 0;
+    a.n_lines = d_n_lines; a.n_ml = d_n_ml; a.keylines = d_keylines; a.ldesc = d_ldesc; a.usable = d_usable; a.ml_desc = d_ml_desc; a.xw6 = d_xw6; a.normal = d_normal;
+    a.min_dist = d_min_dist; a.max_dist = d_max_dist; a.fuse_idx = d_fuse_idx; a.fuse_dist = d_fuse_dist; a.n_fused = d_n_fused;
+    hipLaunchKernelGGL(guided::lsd_fuse_kernel, dim3(kf->B), dim3(64), 0, ctx->stream, a);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+
+int planar_lsd_fuse_search(planar_ctx* ctx, const planar_frame_view* kf, float log_scale_factor, int n_levels, const int32_t* n_lines, int line_stride,
+                           const planar_keyline* keylines, const uint8_t* ldesc, const int32_t* n_ml, int ml_stride, int lines_shared, const uint8_t* usable,
+                           const double* xw6, const double* normal, const float* min_dist, const float* max_dist, const uint8_t* ml_desc, float th,
+                           int32_t* fuse_idx, int32_t* fuse_dist, int32_t* n_fused) {
+    PLANAR_REQUIRE(ctx && kf && kf->Tcw && n_lines && keylines && ldesc && n_ml && usable && xw6 && normal && min_dist && max_dist && ml_desc && fuse_idx && n_fused,
+                   PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(kf->B >= 1 && line_stride >= 1 && ml_stride >= 1, PLANAR_EINVAL, "B, strides >= 1 required");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    const int B = kf->B;
+    const size_t nl = (size_t)B * line_stride, nm = (size_t)(lines_shared ? 1 : B) * ml_stride, no = (size_t)B * ml_stride;
+    const int t = s.in(kf->Tcw, (size_t)B * 64), l0 = s.in(n_lines, (size_t)B * 4), l1 = s.in(keylines, nl * sizeof(planar_keyline)), l2 = s.in(ldesc, nl * 32);
+    const int m0 = s.in(n_ml, (size_t)(lines_shared ? 1 : B) * 4), m1 = s.in(usable, nm), m2 = s.in(xw6, nm * 48), m3 = s.in(normal, nm * 24), m4 = s.in(min_dist, nm * 4),
+              m5 = s.in(max_dist, nm * 4), m6 = s.in(ml_desc, nm * 32);
+    const int o0 = s.out(fuse_idx, no * 4), o1 = fuse_dist ? s.out(fuse_dist, no * 4) : -1, o2 = s.out(n_fused, (size_t)B * 4);
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    planar_frame_view d = *kf;
+    d.Tcw = s.dev<float>(t);
+    rc = planar_lsd_fuse_search_dev(ctx, &d, log_scale_factor, n_levels, s.dev<int32_t>(l0), line_stride, s.dev<planar_keyline>(l1), s.dev<uint8_t>(l2), s.dev<int32_t>(m0),
+                                    ml_stride, lines_shared, s.dev<uint8_t>(m1), s.dev<double>(m2), s.dev<double>(m3), s.dev<float>(m4), s.dev<float>(m5),
+                                    s.dev<uint8_t>(m6), th, s.dev<int32_t>(o0), o1 >= 0 ? s.dev<int32_t>(o1) : nullptr, s.dev<int32_t>(o2));
     if (rc) return rc;
     return s.download(ctx->stream);
 }

@@ -5,6 +5,7 @@
     ORBmatcher.SearchByBoW(pKF, F, vpMapPointMatches)                   reference src/ORBmatcher.cc:160  (include/ORBmatcher.h:59)
     ORBmatcher.Fuse(pKF, vpMapPoints, th), the search half              reference src/ORBmatcher.cc:829  (include/ORBmatcher.h:81)
     LSDmatcher.SearchByProjection(F, vpMapLines, th)                    reference src/LSDmatcher.cpp:141
+    LSDmatcher.Fuse(pKF, vpMapLines, th), the search half               reference src/LSDmatcher.cpp:884
     PlaneMatcher.SearchMapByCoefficients(pF, vpMapPlanes)               reference src/PlaneMatcher.cpp:10
 
 The reference's Frame / MapPoint objects become dicts of numpy arrays (the field names of include/planar_abi.h's
@@ -156,6 +157,40 @@ class LSDmatcher:
                                                     b["desc"].ctypes.data, b["observed"].ctypes.data, sf.ctypes.data, len(sf), th, self.mfNNratio,
                                                     m.ctypes.data, nm.ctypes.data))
         return m, nm
+
+
+def pose_view(kf: dict):
+    """planar_frame_view holding only what the line matchers read of a key frame: B, Tcw [B,16], intrinsics, image bounds, scale factors"""
+    keep = dict(Tcw=_c(kf["Tcw"], np.float32))
+    v = FrameView()
+    v.B, v.stride = keep["Tcw"].reshape(-1, 16).shape[0], 1
+    v.Tcw = keep["Tcw"].ctypes.data
+    for k in ("min_x", "max_x", "min_y", "max_y", "fx", "fy", "cx", "cy", "bf", "b"):
+        setattr(v, k, float(kf[k]))
+    for i, x in enumerate(_c(kf["scale_factors"], np.float32)):
+        v.scale_factors[i] = float(x)
+    return v, keep
+
+
+def lsd_fuse(kf: dict, lines: dict, ml: dict, th: float = 3.0, log_scale_factor: float | None = None, n_levels: int | None = None, shared: bool = False,
+             ctx: Context | None = None):
+    """LSDmatcher::Fuse(pKF, vpMapLines, th) for B key frames, the search half (reference src/LSDmatcher.cpp:884-991).  kf: Tcw + intrinsics + bounds +
+    scale_factors; lines: n, keylines [B,S] (KEYLINE_DTYPE), ldesc; ml: n, usable, xw6 (float64), normal (float64), min_dist, max_dist, desc.
+    Returns (fuse_idx [B,S] key-line index / -1, fuse_dist [B,S] (INT_MAX: no candidate), n_fused [B])."""
+    ctx = ctx or Context(0)
+    fv, keep = pose_view(kf)
+    sf = np.asarray(kf["scale_factors"], np.float32)
+    nl = n_levels or len(sf)
+    lsf = float(np.float32(np.log(np.float32(sf[1])))) if log_scale_factor is None else log_scale_factor
+    a = dict(nl=_c(lines["n"], np.int32), kl=_c(lines["keylines"], KEYLINE_DTYPE), ld=_c(lines["ldesc"], np.uint8), n=_c(ml["n"], np.int32), usable=_c(ml["usable"], np.uint8),
+             xw6=_c(ml["xw6"], np.float64), normal=_c(ml["normal"], np.float64), min_dist=_c(ml["min_dist"], np.float32), max_dist=_c(ml["max_dist"], np.float32),
+             desc=_c(ml["desc"], np.uint8))
+    S = a["usable"].shape[-1]
+    idx = np.full((fv.B, S), -1, np.int32); dist = np.full((fv.B, S), 2 ** 31 - 1, np.int32); nf = np.zeros(fv.B, np.int32)
+    check(lib().planar_lsd_fuse_search(ctx.h, C.byref(fv), lsf, nl, a["nl"].ctypes.data, a["kl"].shape[1], a["kl"].ctypes.data, a["ld"].ctypes.data, a["n"].ctypes.data, S,
+                                       int(shared), a["usable"].ctypes.data, a["xw6"].ctypes.data, a["normal"].ctypes.data, a["min_dist"].ctypes.data,
+                                       a["max_dist"].ctypes.data, a["desc"].ctypes.data, th, idx.ctypes.data, dist.ctypes.data, nf.ctypes.data))
+    return idx, dist, nf
 
 
 class PlaneMatcher:

@@ -578,6 +578,59 @@ def guided_fuse_points(frame, seed=15, n_points=2500, hit=0.6, bits=60, pix_nois
     return frame, mp
 
 
+def guided_fuse_lines(B=3, n_lines=60, n_ml=300, seed=17, hit=0.6, bits=60):
+    """Key frames with key lines + map lines to fuse into them (LSDmatcher::Fuse): `hit` of the map lines are back-projections of a key line's end
+    points (descriptor with up to `bits` flipped, predicted level at or one above the key line's octave), the rest random segments around the
+    camera (behind it, outside the image, out of range, oblique).  Returns (kf dict: Tcw + intrinsics + scale factors, lines dict, ml dict)."""
+    from ._lib import KEYLINE_DTYPE
+    rng = np.random.default_rng(seed)
+    K = TUM3
+    kf = dict(B=B, Tcw=np.zeros((B, 16), np.float32), min_x=0.0, max_x=640.0, min_y=0.0, max_y=480.0, fx=K["fx"], fy=K["fy"], cx=K["cx"], cy=K["cy"], bf=K["bf"],
+              b=K["bf"] / K["fx"], scale_factors=scale_factors())
+    kl = np.zeros((B, n_lines), KEYLINE_DTYPE)
+    lines = dict(n=np.zeros(B, np.int32), keylines=kl, ldesc=rng.integers(0, 256, (B, n_lines, 32), dtype=np.uint8))
+    ml = dict(n=np.zeros(B, np.int32), usable=np.zeros((B, n_ml), np.uint8), xw6=np.zeros((B, n_ml, 6)), normal=np.zeros((B, n_ml, 3)),
+              min_dist=np.zeros((B, n_ml), np.float32), max_dist=np.zeros((B, n_ml), np.float32), desc=rng.integers(0, 256, (B, n_ml, 32), dtype=np.uint8),
+              observations=rng.integers(1, 9, (B, n_ml)).astype(np.int32))
+    for b in range(B):
+        T = _se3(rng, 0.3, rng.normal(0, 0.5, 3))
+        kf["Tcw"][b] = T.astype(np.float32).ravel()
+        Twc = np.linalg.inv(T); Ow = Twc[:3, 3]
+        nl = n_lines if b == 0 else int(rng.integers(n_lines // 2, n_lines + 1))
+        lines["n"][b] = nl
+        cx_ = rng.uniform(60, 580, nl); cy_ = rng.uniform(60, 420, nl); ang = rng.uniform(-1.2, 1.2, nl); half = rng.uniform(15, 55, nl)
+        kl["start_x"][b, :nl] = cx_ - half * np.cos(ang); kl["start_y"][b, :nl] = cy_ - half * np.sin(ang)
+        kl["end_x"][b, :nl] = cx_ + half * np.cos(ang); kl["end_y"][b, :nl] = cy_ + half * np.sin(ang)
+        kl["pt_x"][b, :nl] = cx_; kl["pt_y"][b, :nl] = cy_
+        # GetLinesInArea compares the SLOPE of the projected segment with KeyLine::angle, one-sided (slope - angle <= r / 100)
+        kl["angle"][b, :nl] = np.tan(ang) + rng.uniform(-0.02, 0.6, nl)
+        kl["octave"][b, :nl] = rng.integers(0, 3, nl) * (b % 2)          # key frame 0: one octave, like the reference's LSD
+        kl["line_length"][b, :nl] = 2 * half
+
+        def back(u, v, z):
+            Xc = np.stack([(u - K["cx"]) * z / K["fx"], (v - K["cy"]) * z / K["fy"], z, np.ones(len(u))], 1)
+            return (Twc @ Xc.T).T[:, :3]
+        m = n_ml if b == 0 else int(rng.integers(n_ml // 2, n_ml + 1))
+        ml["n"][b] = m
+        ml["usable"][b, :m] = rng.random(m) < 0.93
+        # misses: random segments
+        u = rng.uniform(-120, 760, m); v = rng.uniform(-100, 580, m); z = rng.uniform(-1.0, 7.0, m); z[np.abs(z) < 0.2] = 0.5
+        S = back(u, v, z); E = S + rng.normal(0, 0.3, (m, 3))
+        src = rng.integers(0, nl, m)
+        isel = rng.random(m) < hit
+        zs = rng.uniform(0.8, 5.0, m); ze = zs + rng.normal(0, 0.15, m)
+        S[isel] = back(kl["start_x"][b, src] + rng.normal(0, 1.0, m), kl["start_y"][b, src] + rng.normal(0, 1.0, m), zs)[isel]
+        E[isel] = back(kl["end_x"][b, src] + rng.normal(0, 1.0, m), kl["end_y"][b, src] + rng.normal(0, 1.0, m), ze)[isel]
+        M = 0.5 * (S + E); dm = np.linalg.norm(M - Ow, axis=1)
+        nrm = (M - Ow) / dm[:, None] + rng.normal(0, 0.3, (m, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        lvl = kl["octave"][b, src] + rng.integers(0, 2, m)
+        mx = np.where(isel, dm * 1.2 ** (lvl - rng.uniform(0.05, 0.95, m)), dm * rng.uniform(0.4, 4.5, m))   # misses: some predicted levels out of the pyramid
+        ml["xw6"][b, :m] = np.concatenate([S, E], 1); ml["normal"][b, :m] = nrm
+        ml["max_dist"][b, :m] = mx; ml["min_dist"][b, :m] = mx / 1.2 ** 7 * np.where(isel, 0.5, rng.uniform(0.5, 1.6, m))
+        d = ml["desc"][b, :m]; d[isel] = _flip_bits(rng, lines["ldesc"][b, src[isel]], bits); ml["desc"][b, :m] = d
+    return kf, lines, ml
+
+
 def manhattan_scene(B=4, n_normals=8500, n_lines=40, seed=21, tilt_deg=4.0, noise=0.04, clutter=0.25, drop_axis=None):
     """Surface normals and vanishing directions of a Manhattan world seen from B cameras (Tracking::TrackManhattanFrame input).
 

@@ -19,3 +19,7 @@ def kf_map_points(kf, seed=7):
     rng = np.random.default_rng(seed)
     shape = kf["keys_un"].shape
     return rng.choice([0, 1, 2], shape, p=[0.5, 0.4, 0.1]).astype(np.uint8), rng.integers(1, 9, shape).astype(np.int32)
+
+
+def fuse_lines_case(seed=171, B=3, n_lines=60, n_ml=300):
+    return synth.guided_fuse_lines(B=B, n_lines=n_lines, n_ml=n_ml, seed=seed)

@@ -528,6 +528,37 @@ def ref_fuse(kf, mp, b, th, log_scale_factor, n_levels, shared=False, kf_state=N
     return idx, int(nf[0])
 
 
+def lsd_fuse_search(kf, lines, ml, th, log_scale_factor, n_levels, shared=False):
+    """oracle/guided_oracle.cpp lsd_fuse_search = LSDmatcher::Fuse(pKF, vpMapLines, th), search half.  Returns (fuse_idx, fuse_dist, n_fused)."""
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    G = _g(); L = lib()
+    fv, keep = G.pose_view(kf)
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    a = [c(lines["n"], np.int32), c(lines["keylines"], KEYLINE_DTYPE), c(lines["ldesc"], np.uint8), c(ml["n"], np.int32), c(ml["usable"], np.uint8), c(ml["xw6"], np.float64),
+         c(ml["normal"], np.float64), c(ml["min_dist"], np.float32), c(ml["max_dist"], np.float32), c(ml["desc"], np.uint8)]
+    S = a[4].shape[-1]
+    idx = np.full((fv.B, S), -1, np.int32); dist = np.full((fv.B, S), 2 ** 31 - 1, np.int32); nf = np.zeros(fv.B, np.int32)
+    L.orc_lsd_fuse_search(C.byref(fv), C.c_float(log_scale_factor), int(n_levels), p(a[0]), a[1].shape[1], p(a[1]), p(a[2]), p(a[3]), S, int(shared), p(a[4]), p(a[5]), p(a[6]),
+                          p(a[7]), p(a[8]), p(a[9]), C.c_float(th), p(idx), p(dist), p(nf))
+    return idx, dist, nf
+
+
+def ref_lsd_fuse(kf, lines, ml, b, th, log_scale_factor, n_levels, kf_state=None, kf_obs=None):
+    """One key frame through the REAL LSDmatcher::Fuse (oracle/_ref/ref_match, mode lsd_fuse).  Returns (fuse_idx [n], nFused)."""
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    nl, nm = int(lines["n"][b]), int(ml["n"][b])
+    state = np.zeros(nl, np.uint8) if kf_state is None else np.asarray(kf_state, np.uint8)[:nl]
+    kobs = np.zeros(nl, np.int32) if kf_obs is None else np.asarray(kf_obs, np.int32)[:nl]
+    intr = np.array([kf["min_x"], kf["max_x"], kf["min_y"], kf["max_y"], kf["fx"], kf["fy"], kf["cx"], kf["cy"], kf["bf"]], np.float32)
+    blocks = [np.array([th, log_scale_factor], np.float32), np.ascontiguousarray(lines["keylines"][b, :nl], KEYLINE_DTYPE), lines["ldesc"][b, :nl], intr,
+              np.asarray(kf["scale_factors"], np.float32)[:n_levels], np.asarray(kf["Tcw"][b], np.float32), ml["usable"][b, :nm].astype(np.uint8),
+              ml["xw6"][b, :nm].astype(np.float64), ml["normal"][b, :nm].astype(np.float64), ml["min_dist"][b, :nm].astype(np.float32),
+              ml["max_dist"][b, :nm].astype(np.float32), ml["desc"][b, :nm], state, kobs, np.asarray(ml["observations"][b, :nm], np.int32)]
+    idx, nf = _run_ref_match("lsd_fuse", blocks, 2)
+    return idx, int(nf[0])
+
+
 def is_in_frustum_lines(frame, ml, log_scale_factor, limit=0.5):
     G = _g(); L = lib()
     fv, keep = G.frame_view(frame)

@@ -73,6 +73,8 @@ def test_argument_errors_are_reported_without_touching_a_device():
         # round-3 entry points
         lambda: L.planar_fuse_search(None, ctypes.byref(fv), p, 0.18, 8, p, 1, 0, p, p, p, p, p, p, 3.0, p, None, p),
         lambda: L.planar_fuse_search_dev(None, ctypes.byref(fv), p, 0.18, 8, p, 1, 0, p, p, p, p, p, p, 3.0, p, None, p),
+        lambda: L.planar_lsd_fuse_search(None, ctypes.byref(fv), 0.18, 8, p, 1, p, p, p, 1, 0, p, p, p, p, p, p, 3.0, p, None, p),
+        lambda: L.planar_lsd_fuse_search_dev(None, ctypes.byref(fv), 0.18, 8, p, 1, p, p, p, 1, 0, p, p, p, p, p, p, 3.0, p, None, p),
     ]
     for i, c in enumerate(calls):
         rc = c()

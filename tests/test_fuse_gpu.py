@@ -60,3 +60,31 @@ def test_fuse_search_many_key_frames(ctx):
     idx, dist, nf = ORBmatcher(ctx=ctx).Fuse(kf, mp, 3.0)
     oidx, odist, onf = O.fuse_search(kf, mp, 3.0, lsf, nlev)
     np.testing.assert_array_equal(idx, oidx); np.testing.assert_array_equal(nf, onf)
+
+
+@pytest.mark.parametrize("th", [3.0, 6.0])
+def test_lsd_fuse_search_matches_oracle_and_reference_fixture(ctx, th):
+    """planar_lsd_fuse_search = LSDmatcher::Fuse(pKF, vpMapLines, th), the search half (reference src/LSDmatcher.cpp:884-991)"""
+    from planarslam_amd.guided import lsd_fuse
+    kf, lines, ml = cases.fuse_lines_case()
+    lsf, nlev = cases.scale()
+    idx, dist, nf = lsd_fuse(kf, lines, ml, th, ctx=ctx)
+    oidx, odist, onf = O.lsd_fuse_search(kf, lines, ml, th, lsf, nlev)
+    np.testing.assert_array_equal(idx, oidx); np.testing.assert_array_equal(dist, odist); np.testing.assert_array_equal(nf, onf)
+    g = np.load(GOLD)
+    np.testing.assert_array_equal(idx, g[f"lsd_fuse_idx_th{th}"]); np.testing.assert_array_equal(nf, g[f"lsd_n_fused_th{th}"])
+    assert nf.min() > 100
+
+
+def test_lsd_fuse_search_many_key_frames_and_empty(ctx):
+    from planarslam_amd.guided import lsd_fuse
+    kf, lines, ml = cases.fuse_lines_case(seed=181, B=300, n_lines=80, n_ml=200)
+    lines["n"][3] = 0; ml["n"][5] = 0; ml["usable"][7] = 0
+    lsf, nlev = cases.scale()
+    idx, dist, nf = lsd_fuse(kf, lines, ml, 3.0, ctx=ctx)
+    oidx, odist, onf = O.lsd_fuse_search(kf, lines, ml, 3.0, lsf, nlev)
+    for b in range(300):
+        n = int(ml["n"][b])
+        np.testing.assert_array_equal(idx[b, :n], oidx[b, :n]); np.testing.assert_array_equal(dist[b, :n], odist[b, :n])
+    np.testing.assert_array_equal(nf, onf)
+    assert nf[3] == nf[5] == nf[7] == 0 and nf.sum() > 10000

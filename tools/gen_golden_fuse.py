@@ -23,4 +23,22 @@ for th in (3.0, 1.5):
         idx[b, :len(r)] = r; nf[b] = n
     out[f"fuse_idx_th{th}"] = idx; out[f"n_fused_th{th}"] = nf
     print("th", th, "fused per key frame", nf, "of", mp["n"])
+# LSDmatcher::Fuse: the real function reads mvScaleFactors[level] with an unclamped level; lines whose level leaves the pyramid (skipped by the product and
+# the oracle) are kept out of its input, with a margin for float rounding
+kfl, lines, ml = cases.fuse_lines_case()
+rng = np.random.default_rng(5)
+lstate = rng.choice([0, 1, 2], lines["keylines"].shape, p=[0.5, 0.4, 0.1]).astype(np.uint8); lobs = rng.integers(1, 9, lstate.shape).astype(np.int32)
+Bl, Sl = ml["usable"].shape
+for th in (3.0, 6.0):
+    idx = np.full((Bl, Sl), -1, np.int32); nf = np.zeros(Bl, np.int32)
+    for b in range(Bl):
+        n = int(ml["n"][b])
+        T = kfl["Tcw"][b].reshape(4, 4).astype(np.float64)
+        Ow = -T[:3, :3].T @ T[:3, 3]
+        q = np.log(ml["max_dist"][b, :n] / np.linalg.norm(0.5 * (ml["xw6"][b, :n, :3] + ml["xw6"][b, :n, 3:]) - Ow, axis=1)) / lsf
+        safe = dict(ml); safe["usable"] = ml["usable"].copy(); safe["usable"][b, :n][(q <= -1 + 1e-3) | (q > nlev - 1 - 1e-3)] = 0
+        r, k = O.ref_lsd_fuse(kfl, lines, safe, b, th, lsf, nlev, kf_state=lstate[b], kf_obs=lobs[b])
+        idx[b, :len(r)] = r; nf[b] = k
+    out[f"lsd_fuse_idx_th{th}"] = idx; out[f"lsd_n_fused_th{th}"] = nf
+    print("lines th", th, "fused per key frame", nf, "of", ml["n"])
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "fuse_points_ref.npz"), **out)
