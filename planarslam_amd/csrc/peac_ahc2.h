@@ -87,7 +87,7 @@ constexpr unsigned K_EMPTY = 0xffffff80u;  // tournament queue: no node (above e
 //               it is recomputed, across columns at the top, at a push) the FP64 keys are compared, and bit-equal FP64 keys of two live nodes
 //               end the attempt with ST_RETRY: the launch of peac_ahc2 that follows redoes exactly those frames with the exact heap.
 template <bool FAST>
-__device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
+__device__ __forceinline__ int ahc_frame(const Layout& L, const Consts& C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
                                           long long* __restrict__ timing, const int frame) {
     PLANAR_DYN_SMEM(smem);
     __shared__ int s_ext[MAX_PLANES];
@@ -993,15 +993,23 @@ __device__ __forceinline__ void ahc_frame(const Layout& L, const Consts& C, uint
             }
         }
     }
+    return wave_uni(err);
 }
 
 // The fast attempt: every frame of the batch, taken from a start-order counter (longest first, see peac_order), not from the block index.
+// retry_inline: a frame the fast attempt gives up on (ST_RETRY) is redone with the exact heap by the same workgroup, which holds the LDS already - a separate
+// launch of the exact kernel over the batch would have to be granted 38 KB of LDS per workgroup just to find, almost always, nothing to do.
 __global__ __launch_bounds__(64) void peac_ahc3(Layout L, Consts C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
-                                                long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order) {
+                                                long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order, int retry_inline) {
     __shared__ int s_frame;
     if (threadIdx.x == 0) { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
     __syncthreads();
-    ahc_frame<true>(L, C, ws, status, timing, s_frame);
+    const int st = ahc_frame<true>(L, C, ws, status, timing, s_frame);
+    if (st == ST_RETRY && retry_inline) {
+        __syncthreads();
+        ahc_frame<false>(L, C, ws, status, timing, s_frame);
+        if (timing && threadIdx.x == 0) timing[(size_t)s_frame * TSLOTS + 12] = 1;      // the frame went through both kernels
+    }
 }
 // The exact kernel.  only_retry != 0: workgroup b redoes frame b if the fast attempt left ST_RETRY there and exits at once otherwise.
 __global__ __launch_bounds__(64) void peac_ahc2(Layout L, Consts C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,

@@ -12,9 +12,9 @@ using namespace planar::peac;
 namespace {
 struct BlocksArgs { Layout L; Intr K; const uint16_t* depth; int pitch; int64_t stride; uint8_t* ws; };
 void blocks_entry(void* a) { auto* A = (BlocksArgs*)a; peac_blocks(A->L, A->K, A->depth, A->pitch, A->stride, A->ws); }
-struct AhcArgs { Layout L; Consts C; uint8_t* ws; int32_t* status; long long* timing; int* next; };
+struct AhcArgs { Layout L; Consts C; uint8_t* ws; int32_t* status; long long* timing; int* next; int retry_inline; };
 void ahc_exact_entry(void* a) { auto* A = (AhcArgs*)a; peac_ahc2(A->L, A->C, A->ws, A->status, A->timing, A->next, nullptr, 0); }
-void ahc_fast_entry(void* a) { auto* A = (AhcArgs*)a; peac_ahc3(A->L, A->C, A->ws, A->status, A->timing, A->next, nullptr); }
+void ahc_fast_entry(void* a) { auto* A = (AhcArgs*)a; peac_ahc3(A->L, A->C, A->ws, A->status, A->timing, A->next, nullptr, A->retry_inline); }
 }  // namespace
 
 extern "C" {
@@ -42,14 +42,13 @@ int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, f
         }
         int32_t status = -1; int next = 0;
         long long timing[TSLOTS] = {0};
-        AhcArgs aa{L, C, ws.data(), &status, timing, &next};
+        AhcArgs aa{L, C, ws.data(), &status, timing, &next, mode == 0 ? 1 : 0};
         wave_emul::Dim3 bi, bd; bd.x = 64; bd.y = 1; bd.z = 1;
         bool retried = false;
-        if (mode != 1) {
+        if (mode != 1) {   // mode 0: the library's launch (a frame the fast attempt gives up on is redone by the same workgroup); mode 2: the fast attempt alone
             wave_emul::launch_block(ahc_fast_entry, &aa, 64, bi, bd, (size_t)ahc2_smem_bytes(L));
-            retried = status == ST_RETRY;
-        }
-        if (mode == 1 || (mode == 0 && retried)) { next = 0; wave_emul::launch_block(ahc_exact_entry, &aa, 64, bi, bd, (size_t)ahc2_smem_bytes(L)); }
+            retried = status == ST_RETRY || timing[12] != 0;
+        } else { next = 0; wave_emul::launch_block(ahc_exact_entry, &aa, 64, bi, bd, (size_t)ahc2_smem_bytes(L)); }
         const uint8_t* F = ws.data();
         const double* st = (const double*)(F + L.off_stats); const double* ge = (const double*)(F + L.off_geo);
         const int* N = (const int*)(F + L.off_N); const uint16_t* rid = (const uint16_t*)(F + L.off_h_rid);
