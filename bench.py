@@ -325,8 +325,9 @@ def main():
             if alone: e["frac_alone"] = round(nbytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
             per[name] = e
         roofline["per_kernel"] = per
-        roofline["per_kernel_note"] = ("peac_ahc = peac_ahc3 (fast attempt) + peac_ahc2 (exact kernel for frames with bit-equal keys) bracketed together; durations from HIP events right "
-                                       "before / after each launch on the stream it runs on")
+        roofline["per_kernel_note"] = ("peac_ahc = peac_ahc3 (the clustering launch: fast attempt, frames with bit-equal keys redone with the exact heap by the same workgroup); durations "
+                                       "from HIP events right before / after each launch on the stream it runs on.  co-run >> alone: the single-wavefront kernels of the two side chains "
+                                       "each fill a CU's LDS (4 x 38 KB) while resident, so the chains time-share the CUs (tools/corun_probe.py; DESIGN.md)")
 
     # ---- PCIe-inclusive rate: the same step fed from pinned host memory and drained to it (H2D / D2H on copy streams, overlapped) ----
     pcie = None

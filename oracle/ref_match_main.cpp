@@ -248,6 +248,7 @@ int main(int argc, char** argv) {
         std::vector<int32_t> match(nc, -1);
         for (size_t i = 0; i < nc; i++) if (res[i]) match[i] = res[i]->index;
         out.put(match.data(), match.size()); out.put(&n, 1);
+#ifdef STANDINS_REAL_FRAME_FUNCS   // the Fuse modes need the reference's own KeyFrame / MapPoint / MapLine bodies (not in the adapter harness on the GPU box)
     } else if (mode == "fuse") {
         // ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:829-979).  prm = {th, log_scale_factor, n_levels}
         Frame F;
@@ -329,6 +330,7 @@ int main(int argc, char** argv) {
         std::vector<int32_t> idx(nm, -1);
         for (auto& e : fuse_log()) idx[e.first] = e.second;
         out.put(idx.data(), idx.size()); out.put(&nFused, 1);
+#endif
     } else { std::fprintf(stderr, "unknown mode\n"); return 2; }
     std::fclose(out.f);
     return 0;
