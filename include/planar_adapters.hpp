@@ -5,6 +5,7 @@
 //   Planar_SLAM::ORBextractor   <- include/ORBextractor.h:45-112, src/ORBextractor.cc                 (always)
 //   PlaneDetection              <- include/PlaneExtractor.h:36-56, src/PlaneExtractor.cpp             (always)
 //   Planar_SLAM::LineSegment    <- include/LSDextractor.h:344-352, src/LSDextractor.cpp               (PLANAR_ADAPTERS_WITH_LINES)
+//   ORBmatcher::Fuse / LSDmatcher::Fuse (search on the device, map edits as in the reference)         (PLANAR_ADAPTERS_WITH_FUSE, needs one accessor, see there)
 //   ORBmatcher / LSDmatcher / PlaneMatcher / Optimizer member functions                                (PLANAR_ADAPTERS_WITH_TRACKING:
 //       include this header AFTER the reference's Frame.h, KeyFrame.h, MapPoint.h, MapLine.h, MapPlane.h, ORBmatcher.h, LSDmatcher.h,
 //       PlaneMatcher.h and Optimizer.h; it then DEFINES the member functions those headers declare - gather the Frame fields into flat
@@ -529,6 +530,129 @@ inline int LSDmatcher::SearchByProjection(Frame& F, const std::vector<MapLine*>&
     for (int i = 0; i < nl; i++) if (match[i] >= 0) F.mvpMapLines[i] = vpMapLines[match[i]];
     return nmatches;
 }
+
+// ---- Fuse (LocalMapping::SearchInNeighbors).  Enabled with PLANAR_ADAPTERS_WITH_FUSE: the search needs the UNSCALED invariance distances of a map point / line
+//      (MapPoint::PredictScale divides mfMaxDistance; GetMaxDistanceInvariance() returns 1.2f * it), which include/MapPoint.h / MapLine.h keep protected - add
+//          void GetDistanceRange(float& mn, float& mx) { unique_lock<mutex> lock(mMutexPos); mn = mfMinDistance; mx = mfMaxDistance; }
+//      to both classes.  The search half runs on the device; the map edits are the reference's own statements on its own objects.
+#ifdef PLANAR_ADAPTERS_WITH_FUSE
+// ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th)  (src/ORBmatcher.cc:829-979)
+inline int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th) {
+    const int M = (int)vpMapPoints.size(), N = pKF->N;
+    if (M == 0) return 0;
+    // the key frame's side (what FrameGather collects of a Frame; KeyFrame keeps the bounds / grid constants per object and the pose behind GetPose())
+    int32_t n = N;
+    std::vector<planar_keypoint> keys(N > 0 ? N : 1);
+    std::vector<float> ur(keys.size(), -1.f);
+    std::vector<uint8_t> kdesc(keys.size() * 32, 0);
+    for (int i = 0; i < N; i++) {
+        std::memcpy(&keys[i], &pKF->mvKeysUn[i], sizeof(planar_keypoint));
+        ur[i] = pKF->mvuRight.empty() ? -1.f : pKF->mvuRight[i];
+        std::memcpy(&kdesc[(size_t)i * 32], pKF->mDescriptors.ptr(i), 32);
+    }
+    float Tcw[16];
+    { cv::Mat T = pKF->GetPose(); for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw[4 * r + c] = T.at<float>(r, c); }
+    planar_frame_view v;
+    std::memset(&v, 0, sizeof(v));
+    v.B = 1; v.stride = (int32_t)keys.size(); v.n = &n; v.keys_un = keys.data(); v.u_right = ur.data(); v.desc = kdesc.data(); v.Tcw = Tcw;
+    v.min_x = pKF->mnMinX; v.max_x = pKF->mnMaxX; v.min_y = pKF->mnMinY; v.max_y = pKF->mnMaxY;
+    v.grid_w_inv = pKF->mfGridElementWidthInv; v.grid_h_inv = pKF->mfGridElementHeightInv;
+    v.fx = pKF->fx; v.fy = pKF->fy; v.cx = pKF->cx; v.cy = pKF->cy; v.bf = pKF->mbf; v.b = pKF->mb;
+    for (size_t l = 0; l < pKF->mvScaleFactors.size() && l < PLANAR_MAX_LEVELS; l++) v.scale_factors[l] = pKF->mvScaleFactors[l];
+    // the map points' side
+    std::vector<uint8_t> usable(M, 0), desc((size_t)M * 32, 0);
+    std::vector<float> xw((size_t)M * 3, 0.f), nrm((size_t)M * 3, 0.f), mn(M, 0.f), mx(M, 0.f);
+    for (int j = 0; j < M; j++) {
+        MapPoint* p = vpMapPoints[j];
+        if (!p || p->isBad() || p->IsInKeyFrame(pKF)) continue;                     // :849-853
+        usable[j] = 1;
+        cv::Mat X = p->GetWorldPos(), nv = p->GetNormal(), d = p->GetDescriptor();
+        for (int k = 0; k < 3; k++) { xw[3 * j + k] = X.at<float>(k); nrm[3 * j + k] = nv.at<float>(k); }
+        std::memcpy(&desc[(size_t)j * 32], d.ptr(0), 32);
+        p->GetDistanceRange(mn[j], mx[j]);
+    }
+    std::vector<int32_t> idx(M, -1);
+    int32_t m = M, nFused = 0;
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_fuse_search(L.ctx, &v, pKF->mvInvLevelSigma2.data(), pKF->mfLogScaleFactor, pKF->mnScaleLevels, &m, M, 0, usable.data(), xw.data(),
+                                                 nrm.data(), mn.data(), mx.data(), desc.data(), th, idx.data(), nullptr, &nFused));
+    }
+    for (int j = 0; j < M; j++) {                                                   // :953-974
+        if (idx[j] < 0) continue;
+        MapPoint* pMP = vpMapPoints[j];
+        MapPoint* pMPinKF = pKF->GetMapPoint(idx[j]);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) {
+                if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                else pMPinKF->Replace(pMP);
+            }
+        } else {
+            pMP->AddObservation(pKF, idx[j]);
+            pKF->AddMapPoint(pMP, idx[j]);
+        }
+    }
+    return nFused;
+}
+
+// LSDmatcher::Fuse(KeyFrame*, const vector<MapLine*>&, th)  (src/LSDmatcher.cpp:884-1015)
+inline int LSDmatcher::Fuse(KeyFrame* pKF, const std::vector<MapLine*>& vpMapLines, const float th) {
+    const int M = (int)vpMapLines.size();
+    int32_t nl = (int32_t)pKF->mvKeyLines.size();
+    if (M == 0 || nl == 0) return 0;
+    static_assert(sizeof(cv::line_descriptor::KeyLine) == sizeof(planar_keyline), "KeyLine layout");
+    std::vector<uint8_t> ldesc((size_t)nl * 32);
+    for (int i = 0; i < nl; i++) std::memcpy(&ldesc[(size_t)i * 32], pKF->mLineDescriptors.ptr(i), 32);
+    float Tcw[16];
+    { cv::Mat T = pKF->GetPose(); for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw[4 * r + c] = T.at<float>(r, c); }
+    planar_frame_view v;
+    std::memset(&v, 0, sizeof(v));
+    v.B = 1; v.stride = 1; v.Tcw = Tcw;
+    v.min_x = pKF->mnMinX; v.max_x = pKF->mnMaxX; v.min_y = pKF->mnMinY; v.max_y = pKF->mnMaxY;
+    v.fx = pKF->fx; v.fy = pKF->fy; v.cx = pKF->cx; v.cy = pKF->cy; v.bf = pKF->mbf; v.b = pKF->mb;
+    const int n_levels = (int)std::min<size_t>(pKF->mvScaleFactors.size(), PLANAR_MAX_LEVELS);
+    for (int l = 0; l < n_levels; l++) v.scale_factors[l] = pKF->mvScaleFactors[l];
+    std::vector<uint8_t> usable(M, 0), desc((size_t)M * 32, 0);
+    std::vector<double> xw6((size_t)M * 6, 0.0), nrm((size_t)M * 3, 0.0);
+    std::vector<float> mn(M, 0.f), mx(M, 0.f);
+    for (int j = 0; j < M; j++) {
+        MapLine* p = vpMapLines[j];
+        if (!p || p->isBad()) continue;                                             // :906-907
+        usable[j] = 1;
+        const Vector6d P = p->GetWorldPos();
+        const Eigen::Vector3d Pn = p->GetNormal();
+        for (int k = 0; k < 6; k++) xw6[6 * j + k] = P(k);
+        for (int k = 0; k < 3; k++) nrm[3 * j + k] = Pn(k);
+        cv::Mat d = p->GetDescriptor();
+        std::memcpy(&desc[(size_t)j * 32], d.ptr(0), 32);
+        p->GetDistanceRange(mn[j], mx[j]);
+    }
+    std::vector<int32_t> idx(M, -1);
+    int32_t m = M, nFused = 0;
+    {
+        planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
+        std::lock_guard<std::mutex> g(L.mu);
+        planar_adapter::check(planar_lsd_fuse_search(L.ctx, &v, pKF->mfLogScaleFactor, n_levels, &nl, nl, (const planar_keyline*)pKF->mvKeyLines.data(), ldesc.data(), &m, M, 0,
+                                                     usable.data(), xw6.data(), nrm.data(), mn.data(), mx.data(), desc.data(), th, idx.data(), nullptr, &nFused));
+    }
+    for (int j = 0; j < M; j++) {                                                   // :993-1010
+        if (idx[j] < 0) continue;
+        MapLine* pML = vpMapLines[j];
+        MapLine* pMLinKF = pKF->GetMapLine(idx[j]);
+        if (pMLinKF) {
+            if (!pMLinKF->isBad()) {
+                if (pMLinKF->Observations() > pML->Observations()) pML->Replace(pMLinKF);
+                else pMLinKF->Replace(pML);
+            }
+        } else {
+            pML->AddObservation(pKF, idx[j]);
+            pKF->AddMapLine(pML, idx[j]);
+        }
+    }
+    return nFused;
+}
+#endif   // PLANAR_ADAPTERS_WITH_FUSE
 
 // PlaneMatcher::SearchMapByCoefficients(Frame&, const vector<MapPlane*>&)  (src/PlaneMatcher.cpp:10-66)
 inline int PlaneMatcher::SearchMapByCoefficients(Frame& pF, const std::vector<MapPlane*>& vpMapPlanes) {

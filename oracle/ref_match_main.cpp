@@ -248,7 +248,6 @@ int main(int argc, char** argv) {
         std::vector<int32_t> match(nc, -1);
         for (size_t i = 0; i < nc; i++) if (res[i]) match[i] = res[i]->index;
         out.put(match.data(), match.size()); out.put(&n, 1);
-#ifdef STANDINS_REAL_FRAME_FUNCS   // the Fuse modes need the reference's own KeyFrame / MapPoint / MapLine bodies (not in the adapter harness on the GPU box)
     } else if (mode == "fuse") {
         // ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:829-979).  prm = {th, log_scale_factor, n_levels}
         Frame F;
@@ -271,12 +270,16 @@ int main(int argc, char** argv) {
         kf.mfGridElementWidthInv = Frame::mfGridElementWidthInv; kf.mfGridElementHeightInv = Frame::mfGridElementHeightInv;
         kf.mvScaleFactors = F.mvScaleFactors; kf.mvInvLevelSigma2.assign(inv_sigma2, inv_sigma2 + n_levels);
         kf.mfLogScaleFactor = prm[1]; kf.mnScaleLevels = n_levels;
+#ifdef STANDINS_REAL_FRAME_FUNCS
         kf.mGrid.resize(kf.mnGridCols);                  // as the KeyFrame constructor does (src/KeyFrame.cc:56-63)
         for (int i = 0; i < kf.mnGridCols; i++) { kf.mGrid[i].resize(kf.mnGridRows); for (int j = 0; j < kf.mnGridRows; j++) kf.mGrid[i][j] = F.mGrid[i][j]; }
         kf.SetPose(mat_f32(4, 4, Tcw));
+#else
+        kf.Tcw = mat_f32(4, 4, Tcw);                     // the adapter reads GetPose(); the grid is built on the device
+#endif
         std::vector<MapPoint> kfmps(F.N);
         kf.mps.assign(F.N, nullptr);
-        for (int i = 0; i < F.N; i++) if (kf_state[i]) { kfmps[i].bad = kf_state[i] == 2; kfmps[i].nobs = kf_obs[i]; kfmps[i].index = -2 - i; kf.mps[i] = &kfmps[i]; }
+        for (int i = 0; i < F.N; i++) if (kf_state[i]) { kfmps[i].bad = kf_state[i] == 2; kfmps[i].nobs = kf_obs[i]; kfmps[i].index = -2 - i; kfmps[i].kf_slot = i; kf.mps[i] = &kfmps[i]; }
         std::vector<MapPoint> mps(np);
         std::vector<MapPoint*> vp(np, nullptr);
         for (size_t i = 0; i < np; i++) {
@@ -290,8 +293,11 @@ int main(int argc, char** argv) {
         fuse_log().clear();
         ORBmatcher matcher(0.6f, true);
         const int nFused = matcher.Fuse(&kf, vp, prm[0]);
+        // which slot each point was paired with: from the edits (AddObservation / Replace); a pairing with a BAD map point of the key frame makes no edit and is
+        // read off the GetMapPoint call instead (the reference asks for the descriptor of the point being searched right before)
         std::vector<int32_t> idx(np, -1);
-        for (auto& e : fuse_log()) idx[e.first] = e.second;
+        for (size_t i = 0; i < np; i++) idx[i] = mps[i].fuse_idx;
+        for (auto& e : fuse_log()) if (e.first >= 0 && idx[e.first] < 0 && kf.mps[e.second] && kf.mps[e.second]->bad) idx[e.first] = e.second;
         out.put(idx.data(), idx.size()); out.put(&nFused, 1);
     } else if (mode == "lsd_fuse") {
         // LSDmatcher::Fuse(KeyFrame*, const vector<MapLine*>&, th) (src/LSDmatcher.cpp:884-1015).  prm = {th, log_scale_factor}
@@ -312,10 +318,14 @@ int main(int argc, char** argv) {
         kf.mvKeyLines.assign(kl, kl + nl); kf.mLineDescriptors = desc_mat((int)nl, ldesc);
         kf.mnMinX = intr[0]; kf.mnMaxX = intr[1]; kf.mnMinY = intr[2]; kf.mnMaxY = intr[3]; kf.fx = intr[4]; kf.fy = intr[5]; kf.cx = intr[6]; kf.cy = intr[7]; kf.mbf = intr[8];
         kf.mvScaleFactors.assign(sf, sf + nsf); kf.mfLogScaleFactor = prm[1]; kf.mnScaleLevels = (int)nsf;
+#ifdef STANDINS_REAL_FRAME_FUNCS
         kf.SetPose(mat_f32(4, 4, Tcw));
+#else
+        kf.Tcw = mat_f32(4, 4, Tcw);
+#endif
         std::vector<MapLine> kfmls(nl), mls(nm);
         kf.mls.assign(nl, nullptr);
-        for (size_t i = 0; i < nl; i++) if (kf_state[i]) { kfmls[i].bad = kf_state[i] == 2; kfmls[i].nobs = kf_obs[i]; kfmls[i].index = -2 - (int)i; kf.mls[i] = &kfmls[i]; }
+        for (size_t i = 0; i < nl; i++) if (kf_state[i]) { kfmls[i].bad = kf_state[i] == 2; kfmls[i].nobs = kf_obs[i]; kfmls[i].index = -2 - (int)i; kfmls[i].kf_slot = (int)i; kf.mls[i] = &kfmls[i]; }
         std::vector<MapLine*> vp(nm, nullptr);
         for (size_t i = 0; i < nm; i++) {
             for (int k = 0; k < 6; k++) mls[i].mWorldPos(k) = xw6[6 * i + k];
@@ -328,9 +338,9 @@ int main(int argc, char** argv) {
         LSDmatcher matcher;
         const int nFused = matcher.Fuse(&kf, vp, prm[0]);
         std::vector<int32_t> idx(nm, -1);
-        for (auto& e : fuse_log()) idx[e.first] = e.second;
+        for (size_t i = 0; i < nm; i++) idx[i] = mls[i].fuse_idx;
+        for (auto& e : fuse_log()) if (e.first >= 0 && idx[e.first] < 0 && kf.mls[e.second] && kf.mls[e.second]->bad) idx[e.first] = e.second;
         out.put(idx.data(), idx.size()); out.put(&nFused, 1);
-#endif
     } else { std::fprintf(stderr, "unknown mode\n"); return 2; }
     std::fclose(out.f);
     return 0;

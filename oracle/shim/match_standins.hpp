@@ -88,9 +88,15 @@ public:
 #endif
     bool IsInKeyFrame(KeyFrame*) { return in_kf; }
     bool in_kf = false;
+#ifndef STANDINS_REAL_FRAME_FUNCS
+    float mfMinDistance = 0, mfMaxDistance = 0;
+#endif
+    // the one accessor the Fuse adapter needs and include/MapPoint.h lacks: the UNSCALED invariance distances
+    void GetDistanceRange(float& mn, float& mx) { mn = mfMinDistance; mx = mfMaxDistance; }
+    int fuse_idx = -1, kf_slot = -1;      // harness: which key-frame slot Fuse paired this point with, read off the edits it makes
     int GetIndexInKeyFrame(KeyFrame*) { return -1; }
-    void AddObservation(KeyFrame*, size_t) {}
-    void Replace(MapPoint*) {}
+    void AddObservation(KeyFrame*, size_t i) { fuse_idx = (int)i; }
+    void Replace(MapPoint* o) { if (kf_slot >= 0) o->fuse_idx = kf_slot; else if (o->kf_slot >= 0) fuse_idx = o->kf_slot; }
     float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
     bool mbTrackInView = false;
     int mnTrackScaleLevel = 0;
@@ -121,13 +127,16 @@ public:
     float GetMinDistanceInvariance() { return 0.f; }
     float GetMaxDistanceInvariance() { return 1e9f; }
     int PredictScale(const float&, const float&) { return 0; }
+    float mfMinDistance = 0, mfMaxDistance = 0;
 #endif
+    void GetDistanceRange(float& mn, float& mx) { mn = mfMinDistance; mx = mfMaxDistance; }
+    int fuse_idx = -1, kf_slot = -1;
     int PredictScale(const float&, KeyFrame*) { return 0; }
     int PredictScale(const float&, Frame*) { return 0; }
     bool IsInKeyFrame(KeyFrame*) { return false; }
     int GetIndexInKeyFrame(KeyFrame*) { return -1; }
-    void AddObservation(KeyFrame*, size_t) {}
-    void Replace(MapLine*) {}
+    void AddObservation(KeyFrame*, size_t i) { fuse_idx = (int)i; }
+    void Replace(MapLine* o) { if (kf_slot >= 0) o->fuse_idx = kf_slot; else if (o->kf_slot >= 0) fuse_idx = o->kf_slot; }
     float mTrackProjX1 = 0, mTrackProjY1 = 0, mTrackProjX2 = 0, mTrackProjY2 = 0;
     bool mbTrackInView = false;
     int mnTrackScaleLevel = 0;
@@ -327,6 +336,9 @@ public:
     MapPoint* GetMapPoint(const size_t& i) { fuse_log().push_back(std::make_pair(fuse_current(), (int)i)); return mps[i]; }
     void AddMapPoint(MapPoint*, const size_t&) {}
     int mnScaleLevels = 0;
+    cv::Mat GetPose() { return Tcw.clone(); }     // src/KeyFrame.cc:95-99
+    cv::Mat Tcw;
+    float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
 #ifdef STANDINS_REAL_FRAME_FUNCS
     // bodies: src/KeyFrame.cc:79-93 (SetPose), 107-111 (GetCameraCenter), 120-130 (GetRotation, GetTranslation), 639-678 (GetFeaturesInArea), 715-718
     // (IsInImage), extracted at build time; the members they touch (include/KeyFrame.h)
@@ -336,11 +348,10 @@ public:
     cv::Mat GetCameraCenter();
     bool IsInImage(const float& x, const float& y) const;
     vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r) const;
-    cv::Mat Tcw, Twc, Ow, Cw;
+    cv::Mat Twc, Ow, Cw;
     float mHalfBaseline = 0;
     CopyableMutex mMutexPose;
     int mnGridCols = FRAME_GRID_COLS, mnGridRows = FRAME_GRID_ROWS;
-    float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
     std::vector<std::vector<std::vector<size_t>>> mGrid;
 #else
     cv::Mat GetRotation() { return cv::Mat(); }

@@ -18,6 +18,7 @@ public:
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
     int MatchORBPoints(Frame& CurrentFrame, const Frame& LastFrame);
     int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
 protected:
     float mfNNratio;
     bool mbCheckOrientation;
@@ -28,6 +29,7 @@ public:
     LSDmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
     int SearchByDescriptor(KeyFrame* pKF, Frame& currentF, std::vector<MapLine*>& vpMapLineMatches);
     int SearchByProjection(Frame& F, const std::vector<MapLine*>& vpMapLines, const float th = 3);
+    int Fuse(KeyFrame* pKF, const std::vector<MapLine*>& vpMapLines, const float th = 3.0);
 protected:
     float mfNNratio;
     bool mbCheckOrientation;
@@ -56,4 +58,5 @@ public:
 }  // namespace Planar_SLAM
 
 #define PLANAR_ADAPTERS_WITH_TRACKING
+#define PLANAR_ADAPTERS_WITH_FUSE      // the stand-in MapPoint / MapLine carry GetDistanceRange (oracle/shim/match_standins.hpp)
 #include "planar_adapters.hpp"

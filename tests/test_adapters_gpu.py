@@ -3,7 +3,7 @@ the same inputs the real reference processed.
 
   adapter_match   = oracle/ref_match_main.cpp (the harness that drives the REAL src/ORBmatcher.cc / LSDmatcher.cpp / PlaneMatcher.cpp in
                     oracle/_ref/ref_match) rebuilt with tests/adapter_shim/*.h in place of the reference headers, so ORBmatcher::SearchByProjection,
-                    SearchByBoW, MatchORBPoints, LSDmatcher::SearchByProjection / SearchByDescriptor and PlaneMatcher::SearchMapByCoefficients
+                    SearchByBoW, MatchORBPoints, Fuse, LSDmatcher::SearchByProjection / SearchByDescriptor / Fuse and PlaneMatcher::SearchMapByCoefficients
                     are the adapter definitions (gather Frame fields -> C ABI -> scatter MapPoint* back).  Expected: tests/golden/guided_ref.npz
                     (outputs of the real reference on the same seeds): every index identical.
   adapter_pose    = Optimizer::PoseOptimization / TranslationOptimization(Frame*) adapters on stand-in Frames; expected tests/golden/opt_ref.npz
@@ -87,6 +87,29 @@ def test_matcher_adapters_equal_real_reference_fixtures(as_reference, golden_dir
     for b in range(3):
         m, n = O.ref_lsd_search_by_projection(lines, ml, b, synth.scale_factors(), 3.0, 0.6)
         np.testing.assert_array_equal(m, g["lsd_proj_match"][b, :len(m)]); assert n == g["lsd_proj_n"][b]
+
+
+def test_fuse_adapters_equal_real_reference_fixtures(as_reference, golden_dir):
+    """ORBmatcher::Fuse / LSDmatcher::Fuse adapters (search on the device, the reference's map edits on the stand-in objects) against the pairings the REAL
+    functions made on the same inputs (tests/golden/fuse_points_ref.npz).  The harness reads a pairing off the edit the adapter makes (AddObservation / Replace),
+    so the key frame's occupied slots hold no bad map points here (those make no edit); the search result does not depend on the slots' state."""
+    import fuse_cases as fc
+    g = np.load(os.path.join(golden_dir, "fuse_points_ref.npz"))
+    kf, mp = fc.fuse_case(seed=131)
+    lsf, nlev = fc.scale()
+    state, kobs = fc.kf_map_points(kf)
+    state = np.minimum(state, 1)
+    for th in (3.0, 1.5):
+        for b in range(kf["keys_un"].shape[0]):
+            idx, nf = O.ref_fuse(kf, mp, b, th, lsf, nlev, kf_state=state[b], kf_obs=kobs[b])
+            np.testing.assert_array_equal(idx, g[f"fuse_idx_th{th}"][b, :len(idx)]); assert nf == g[f"n_fused_th{th}"][b]
+    kfl, lines, ml = fc.fuse_lines_case()
+    rng = np.random.default_rng(5)
+    lstate = np.minimum(rng.choice([0, 1, 2], lines["keylines"].shape, p=[0.5, 0.4, 0.1]), 1).astype(np.uint8); lobs = rng.integers(1, 9, lstate.shape).astype(np.int32)
+    for th in (3.0, 6.0):
+        for b in range(kfl["B"]):
+            idx, nf = O.ref_lsd_fuse(kfl, lines, ml, b, th, lsf, nlev, kf_state=lstate[b], kf_obs=lobs[b])
+            np.testing.assert_array_equal(idx, g[f"lsd_fuse_idx_th{th}"][b, :len(idx)]); assert nf == g[f"lsd_n_fused_th{th}"][b]
 
 
 def test_descriptor_matcher_adapters_equal_oracle(as_reference):
