@@ -997,41 +997,33 @@ __device__ double nfa(const Plan& P, int n, int k, double p, int pj, int lane) {
     const double tolerance = 0.1;
     // The tail is a sequential recurrence (term *= mult; bin_tail += term), but the stopping rule of iteration i only reads iteration i's
     // values.  Per block of 64 iterations: lane j computes the multiplier of "its" iteration (the division is the expensive part and is
-    // independent), the chain then runs over the 64 multipliers broadcast by readlane (two FP64 operations per step), every lane keeps the
-    // values of its own step and evaluates the expensive rule (pow, log10) for it - only in blocks that contain a step with bin_term < 1;
-    // the first lane whose rule fires is where the reference breaks.
+    // independent), the chain runs through the lanes (below), every lane ends up with the values of its own step and evaluates the expensive
+    // rule (pow, log10) for it - only in blocks that contain a step with bin_term < 1; the first lane whose rule fires is where the reference breaks.
     for (int i = k + 1; i <= n;) {
         const int cnt = min(64, n - i + 1);
         const double my_bin = lane < cnt ? double(n - (i + lane) + 1) / double(i + lane) : 2.0;
         const double my_mult = my_bin * p_term;
-        const int mlo = __double2loint(my_mult), mhi = __double2hiint(my_mult);
-        double t = term, bt = bin_tail, my_term = 0, my_tail = 0;
         const bool rule = lane < cnt && my_bin < 1;
-        const bool any_rule = __ballot(rule) != 0;
-        if (any_rule) {
-            for (int j = 0; j < cnt; j++) {
-                const double mult_term = __hiloint2double(__builtin_amdgcn_readlane(mhi, j), __builtin_amdgcn_readlane(mlo, j));
-                t *= mult_term;
-                bt += t;
-                if (j == lane) { my_term = t; my_tail = bt; }
-            }
-        } else {   // no step of this block can stop the loop: only the end of the chain is needed
-            for (int j = 0; j < cnt; j++) {
-                const double mult_term = __hiloint2double(__builtin_amdgcn_readlane(mhi, j), __builtin_amdgcn_readlane(mlo, j));
-                t *= mult_term;
-                bt += t;
-            }
+        // The chain travels through the lanes: every step, each lane takes the pair (term, tail) of the lane below it (DPP wave_shr:1; lane 0 takes the
+        // block's input), multiplies / adds ITS iteration's multiplier.  Lane 0 is right from step 0 on, lane s from step s on (its input no longer changes),
+        // so after cnt steps lane s < cnt holds exactly the reference's values after iteration i + s - the same operations in the same order, six VALU
+        // instructions per step and no cross-lane reads (a v_readlane pair per step cost 4x as much).
+        double t = term, bt = bin_tail;
+        for (int step = 0; step < cnt; step++) {                 // lane cnt - 1 is right after cnt steps
+            const double tin = PLANAR_DPP_F64(t, 0x138, 0xf, term), bin = PLANAR_DPP_F64(bt, 0x138, 0xf, bin_tail);
+            t = tin * my_mult;
+            bt = bin + t;
         }
-        if (any_rule) {
+        if (__ballot(rule) != 0) {
             bool brk = false;
             if (rule) {
-                const double err = my_term * ((1 - pow(my_mult, double(n - (i + lane) + 1))) / (1 - my_mult) - 1);
-                brk = err < tolerance * fabs(-log10(my_tail) - LOG_NT) * my_tail;
+                const double err = t * ((1 - pow(my_mult, double(n - (i + lane) + 1))) / (1 - my_mult) - 1);
+                brk = err < tolerance * fabs(-log10(bt) - LOG_NT) * bt;
             }
             const unsigned long long m = __ballot(brk);
-            if (m) { bin_tail = __shfl(my_tail, __ffsll((long long)m) - 1, 64); return -log10(bin_tail) - LOG_NT; }
+            if (m) { bin_tail = planar::wave_lane(bt, __ffsll((long long)m) - 1); return -log10(bin_tail) - LOG_NT; }
         }
-        term = t; bin_tail = bt; i += cnt;
+        term = planar::wave_lane(t, cnt - 1); bin_tail = planar::wave_lane(bt, cnt - 1); i += cnt;
     }
     return -log10(bin_tail) - LOG_NT;
 }
@@ -1818,7 +1810,7 @@ int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d
     lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
     hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, st, dP, ws, dm);
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[3], st);
-    hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm);
+    hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm);   // 512 / 2048 wavefronts per frame measure the same
     hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm);
     hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines);
     hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
