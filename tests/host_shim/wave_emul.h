@@ -174,6 +174,7 @@ inline void launch_block(void (*fn)(void*), void* arg, int nthreads, Dim3 bidx, 
 
 // ---- planarslam_amd/csrc/wave_ops.h for the emulator ----
 #define PLANAR_WAVE_EMUL 1
+#define PLANAR_DPP_F64(v, ctrl, rmask, idv) ::planar::dpp_f64(__LINE__, (v), (ctrl), (idv))
 namespace planar {
 inline int wave_uni(int v) { return ::wave_emul::shfl(900001, v, 0); }
 inline unsigned wave_uni(unsigned v) { return ::wave_emul::shfl(900002, v, 0); }
@@ -188,6 +189,13 @@ inline int wave_scan_add(int v) {
 inline unsigned wave_min_u32(unsigned v) {
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = ::wave_emul::shfl(900100 + o, v, (::wave_emul::S().cur & 63) ^ o); v = t < v ? t : v; }
     return v;
+}
+// DPP on an FP64 value (wave_ops.h PLANAR_DPP_F64): only wave_shr:1 (0x138) is emulated - lane l receives lane l - 1's value, lane 0 keeps `idv`
+inline double dpp_f64(int line, double v, int ctrl, double idv) {
+    if (ctrl != 0x138) ::wave_emul::fail("wave_emul: DPP control not emulated");
+    const int l = ::wave_emul::S().cur & 63;
+    const double got = ::wave_emul::shfl(line, v, l > 0 ? l - 1 : 0);
+    return l > 0 ? got : idv;
 }
 inline double wave_min_f64(double v) {
     for (int o = 32; o > 0; o >>= 1) { const double t = ::wave_emul::shfl(900200 + o, v, (::wave_emul::S().cur & 63) ^ o); v = t < v ? t : v; }
