@@ -3,9 +3,13 @@
 # small gpurun --timeout):   gpurun --timeout 330 -- 'bash tools/collect_profiles.sh r03 bench'   |   ... r03 pmc   |   ... r03 suite
 # bench: the bench line, the BA bench, the rocprofv3 kernel summary of the same command.  pmc: HBM traffic and issue counters (separate passes, --kernel-trace only,
 # as gpurun requires).  suite: the GPU tests and smoke().  Outputs in gpurun_out/<tag>_*.
+# On a box whose image is still paging in, the first `import torch` alone takes 1-2 minutes: every mode starts with an untimed-in-spirit warm-up import (own timeout), so
+# that the per-command timeouts below measure the commands and not the cold start (twice this round a call on a cold box ran into every timeout with no output).
+# Give the bench mode `gpurun --timeout 600`.
 tag=${1:-r03}; what=${2:-bench}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
+timeout 240 python -c "import torch, numpy; print('warm', torch.cuda.is_available())" > $O/${tag}_warmup.log 2>&1
 FL="--steps 6 --warmup 3 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
 # counter passes: the canvases are synthesised in-process (--gen-procs 1, 16 of them): rocprofv3 --pmc hangs when the profiled process forks workers (profiles/README.md)
 PF="--gen-procs 1 --canvases 16 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
