@@ -16,7 +16,7 @@ BAD = re.compile(r"s_mov_b64\s+s\[[0-9:]+\],\s*(0x[0-9a-fA-F]{9,}|-?[0-9]{11,})"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src", ["peac.hip", "lsd.hip"])
+@pytest.mark.parametrize("src", ["peac.hip", "lsd.hip", "pose.hip", "ba.hip", "planepost.hip", "line3d.hip", "manhattan.hip"])   # the FP64 kernels
 def test_no_64bit_literal_scalar_moves(src, tmp_path):
     out = tmp_path / (src + ".s")
     subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-function", "-S", "--cuda-device-only",
