@@ -1,0 +1,80 @@
+// tests/host_shim/isort_host.cpp — TEST INFRASTRUCTURE: the product's std::sort-arrangement engine (planarslam_amd/csrc/isort.h, the same source
+// hipcc compiles for gfx950) compiled for the host and run on the wave64 emulator of wave_emul.h, next to the REAL std::sort of this libstdc++ with a
+// comparator that looks at the key only (what pcl::VoxelGrid and OpenCV's LSD call).  tests/test_isort_emul.py compares the two word for word.
+#include "wave_emul.h"
+
+#include "../../planarslam_amd/csrc/isort.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+using namespace planar::isort;
+
+namespace {
+struct GArgs { uint32_t* arr; const Range* init; int n_init, n_stage, nr_cap; Range* ranges; Block* blocks; int max_blocks; int* counts; int rows_cap; int* status; int shift; };
+template <int SHIFT, int T>
+void g_entry(void* p) {
+    auto* A = (GArgs*)p;
+    PLANAR_DYN_SMEM(lds);
+    global_tier<SHIFT, T>(A->arr, A->init, A->n_init, A->n_stage, A->nr_cap, A->ranges, A->blocks, A->max_blocks, A->counts, lds, A->rows_cap, A->status);
+}
+struct LArgs { uint32_t* arr; const Range* ranges; int nr, f, l; int* status; };
+template <int SHIFT, int T, int E>
+void l_entry(void* p) {
+    auto* A = (LArgs*)p;
+    PLANAR_DYN_SMEM(lds);
+    lds_tier<SHIFT, T, E>(A->arr, A->ranges, A->nr, A->f, A->l, lds, A->status);
+}
+template <int SHIFT, int TG, int T, int E>
+int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status, long* stats) {
+    std::vector<Range> init(n_ranges);
+    int longest = 0;
+    for (int i = 0; i < n_ranges; i++) {
+        const int n = bounds[i + 1] - bounds[i];
+        int lg = 0; for (int t = n; t > 1; t >>= 1) lg++;
+        init[i] = Range{bounds[i], bounds[i + 1], 2 * lg};
+        longest = std::max(longest, n);
+    }
+    if (n_stage <= 0 || n_stage > T * E) n_stage = T * E;
+    const int rows_cap = GlobalLayout<TG>::rows_for(longest);
+    std::vector<Range> ranges(G_FMAX);
+    std::vector<Block> blocks(G_FMAX);
+    int counts[2] = {0, 0};
+    GArgs ga{arr, init.data(), n_ranges, n_stage, std::min(T, 64), ranges.data(), blocks.data(), G_FMAX, counts, rows_cap, status, SHIFT};
+    wave_emul::Dim3 bi, bd; bd.x = TG; bd.y = 1; bd.z = 1;
+    wave_emul::launch_block(g_entry<SHIFT, TG>, &ga, TG, bi, bd, (size_t)GlobalLayout<TG>::bytes(rows_cap), 256 * 1024);
+    if (stats) { stats[0] = counts[0]; stats[1] = counts[1]; stats[2] = wave_emul::S().n_sync; }
+    bd.x = T;
+    for (int b = 0; b < counts[1]; b++) {
+        LArgs la{arr, ranges.data() + blocks[b].r0, blocks[b].nr, blocks[b].f, blocks[b].l, status};
+        wave_emul::launch_block(l_entry<SHIFT, T, E>, &la, T, bi, bd, (size_t)LdsLayout<T, E>::bytes, 256 * 1024);
+    }
+    if (stats) stats[3] = wave_emul::S().n_sync;
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+// arr [total]: in/out.  bounds [n_ranges + 1]: every [bounds[i], bounds[i+1]) is sorted on its own, as std::sort(first, last, key <) would.
+// config 0: production shapes (global tier 1024 threads; LDS tier 1024 threads x 23 elements); 1: small shapes that force many levels and the
+// global tier on short arrays (256 threads; 256 x 5).  shift: 19 or 20.  n_stage: LDS-tier capacity override (0 = the configuration's).
+// Returns 0, or -1 with a message in err.  stats [4]: ranges, blocks, rendezvous count after the global tier, after everything.
+int isort_emul(uint32_t* arr, const int* bounds, int n_ranges, int shift, int config, int n_stage, int* status, long* stats, char* err, int errlen) {
+    try {
+        *status = 0;
+        if (shift == 19 && config == 0) return run<19, 1024, 1024, 23>(arr, bounds, n_ranges, n_stage, status, stats);
+        if (shift == 20 && config == 0) return run<20, 1024, 1024, 23>(arr, bounds, n_ranges, n_stage, status, stats);
+        if (shift == 19 && config == 1) return run<19, 256, 256, 5>(arr, bounds, n_ranges, n_stage, status, stats);
+        if (shift == 20 && config == 1) return run<20, 256, 256, 5>(arr, bounds, n_ranges, n_stage, status, stats);
+        if (shift == 19 && config == 2) return run<19, 256, 128, 32>(arr, bounds, n_ranges, n_stage, status, stats);
+        throw std::runtime_error("isort_emul: unknown configuration");
+    } catch (const std::exception& e) { snprintf(err, errlen, "%s", e.what()); return -1; }
+}
+
+// the real thing: std::sort with a comparator on the key only
+void isort_std_sort(uint32_t* arr, const int* bounds, int n_ranges, int shift) {
+    for (int i = 0; i < n_ranges; i++)
+        std::sort(arr + bounds[i], arr + bounds[i + 1], [shift](uint32_t a, uint32_t b) { return (a >> shift) < (b >> shift); });
+}
+}

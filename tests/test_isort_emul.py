@@ -1,0 +1,91 @@
+"""The product's std::sort-arrangement engine (planarslam_amd/csrc/isort.h: the very source hipcc compiles for gfx950) compiled with g++ and run on the
+host-side wave64 emulator (tests/host_shim/wave_emul.h) against the REAL std::sort of this libstdc++ with a key-only comparator - the call
+pcl::VoxelGrid::applyFilter (voxel index) and OpenCV's LSD (1024-bin gradient norm) make.  Word-for-word equality: where std::sort leaves elements of
+equal key is exactly what the product has to reproduce (the float summation order of a voxel's points; the order LSD visits its seeds in)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tests", "host_shim")
+SO = os.path.join(SHIM, "libisort_host.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    src = os.path.join(SHIM, "isort_host.cpp")
+    deps = [src, os.path.join(SHIM, "wave_emul.h"), os.path.join(ROOT, "planarslam_amd", "csrc", "isort.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-o", SO, src])
+    E = C.CDLL(SO)
+    vp = C.c_void_p
+    E.isort_emul.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_char_p, C.c_int]
+    E.isort_std_sort.argtypes = [vp, vp, C.c_int, C.c_int]
+    return E
+
+
+def _check(E, keys, bounds, shift, config, n_stage=0):
+    n = len(keys)
+    assert n < (1 << shift)
+    arr = ((keys.astype(np.uint32) << np.uint32(shift)) | np.arange(n, dtype=np.uint32)).astype(np.uint32)
+    want = arr.copy()
+    b = np.asarray(bounds, np.int32)
+    E.isort_std_sort(want.ctypes.data, b.ctypes.data, len(b) - 1, shift)
+    status = C.c_int(-1); stats = np.zeros(4, np.int64); err = C.create_string_buffer(512)
+    rc = E.isort_emul(arr.ctypes.data, b.ctypes.data, len(b) - 1, shift, config, n_stage, C.byref(status), stats.ctypes.data, err, 512)
+    assert rc == 0, err.value.decode()
+    assert status.value == 0, f"engine status {status.value}"
+    bad = np.nonzero(arr != want)[0]
+    assert bad.size == 0, f"{bad.size} words differ from std::sort, first at {bad[0]}: engine {arr[bad[0]]:#x} std::sort {want[bad[0]]:#x} (stats {stats})"
+    return stats
+
+
+def _voxel_like(rng, n, run, nkeys):
+    """keys as a plane's voxel indices look in raster order: runs of equal keys that drift"""
+    base = np.cumsum(rng.integers(-2, 3, size=n // run + 2))
+    k = np.repeat(base, run)[:n] + rng.integers(0, 2, size=n) * rng.integers(0, nkeys // 8 + 1)
+    return (k - k.min()) % nkeys
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_small_shapes_many_levels(lib, seed):
+    """256-thread workgroups, 5 elements per thread: the global tier runs on arrays of a few thousand elements, the LDS tier sees every piece layout"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3000, 9000))
+    for keys in (rng.integers(0, 1 << 10, n), rng.integers(0, 7, n), _voxel_like(rng, n, 26, 300), np.arange(n) % 1024, np.zeros(n, np.int64),
+                 np.sort(rng.integers(0, 500, n)), np.sort(rng.integers(0, 500, n))[::-1].copy()):
+        _check(lib, keys, [0, n], 20 if seed & 1 else 19, 1)
+
+
+def test_many_ranges_and_tiny_ranges(lib):
+    rng = np.random.default_rng(7)
+    sizes = [0, 1, 2, 3, 15, 16, 17, 18, 33, 100, 1279, 1280, 1281, 4000, 1, 16, 17, 2500, 0, 40]
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(bounds[-1])
+    _check(lib, rng.integers(0, 64, n), bounds, 19, 1)
+    _check(lib, _voxel_like(rng, n, 9, 200), bounds, 19, 1)
+    _check(lib, rng.integers(0, 1 << 12, n), bounds, 19, 2)       # 128 threads x 32 elements: full 32-bit chunk masks
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_production_shapes(lib, seed):
+    """1024 threads, 23 elements per thread; a wall-sized plane (global tier), mid-sized and small planes packed into blocks"""
+    rng = np.random.default_rng(seed)
+    sizes = [70000, 23552, 23553, 9000, 300, 12, 5000] if seed == 11 else [120000, 40, 700, 17]
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(bounds[-1])
+    keys = np.concatenate([_voxel_like(rng, s, 26, 2000) for s in sizes])
+    st = _check(lib, keys, bounds, 19, 0)
+    assert st[1] >= 3
+
+
+def test_lsd_like_keys(lib):
+    """the 1024-bin gradient norm of an image: most pixels in the lowest bins, a long tail; descending order = ascending 1023 - bin"""
+    rng = np.random.default_rng(5)
+    n = 511 * 383
+    g = np.abs(rng.normal(0, 1, n)) ** 3
+    bins = np.minimum((g / g.max() * 1023).astype(np.int64), 1023)
+    _check(lib, 1023 - bins, [0, n], 20, 0)
