@@ -19,14 +19,18 @@
 //   global_tier<SHIFT, T>   one workgroup per array set (frame): ranges longer than the LDS tier's capacity are partitioned in global memory.
 //                           Stops are BITMAPS in LDS (one ballot per 64 elements), ranks are popcount prefix sums, the k-th stop is a binary
 //                           search + an in-word select: the array itself is read once and only swapped elements are written.
-//   lds_tier<SHIFT, T, E>   one workgroup per block of <= T * E elements (any number of ranges): staged in LDS once, every level of the
-//                           recursion is six barriers (medians | flags + two segmented scans | ranks, cuts, left stops | swaps | new list),
-//                           whatever the number of segments; ranges of <= 16 elements are insertion-sorted (stable) on the spot, so the block
-//                           goes back to global memory SORTED, ties in std::sort's order.
-// A depth-limit overflow (heap-sort fallback) is not reproduced: status 2.  It needs ~2 lg n maximally unbalanced partitions in a row.
+//   lds_tier<SHIFT, T, E>   one workgroup per block of <= T * E elements (any number of ranges): staged in LDS once.  A level of the recursion is
+//                           medians | flags + two segmented scans | cuts | left stops | swaps | new list, whatever the number of segments: the
+//                           whole workgroup runs the levels above 2048 elements, single wavefronts everything below; the leaves of <= 16
+//                           elements are ranked (stable) in the write-back, so the block goes back SORTED, ties in std::sort's order.
+// A range whose depth budget runs out is heap-sorted as libstdc++ does it (heap_sort below, one thread: sequential by nature).  That is not a corner case
+// for voxel keys: the saw-tooth key sequence of a plane in raster order makes the median-of-three partitions degenerate for about one plane in a hundred.
 // tests/host_shim/isort_host.cpp compiles this file with g++ on the wave64 emulator and checks it against the real std::sort.
 #pragma once
 #include <stdint.h>
+#ifndef PLANAR_WAVE_EMUL
+#include "wave_ops.h"
+#endif
 
 namespace planar {
 namespace isort {
@@ -34,7 +38,10 @@ namespace isort {
 struct Range { int f, l, d; };          // [f, l) of the array, d = depth budget left (2 * lg n at the top)
 struct Block { int f, l, r0, nr; };     // LDS-tier job: the span [f, l) holds ranges r0 .. r0 + nr - 1 of the sorted range list
 
-constexpr int ST_DEPTH = 2, ST_CAPACITY = 3;
+constexpr int ST_CAPACITY = 3;
+#ifdef PLANAR_WAVE_EMUL
+static long g_levels = 0, g_segs = 0, g_heap = 0;      // emulator statistics: LDS-tier levels run, segments partitioned, elements heap-sorted
+#endif
 
 __device__ __forceinline__ int lg2i(int n) { return 31 - __clz(n); }          // std::__lg
 __device__ __forceinline__ int depth_limit(int n) { return n > 1 ? 2 * lg2i(n) : 0; }
@@ -94,14 +101,51 @@ __device__ __forceinline__ int median_pos(uint32_t xa, uint32_t xb, uint32_t xc,
     return Bm;
 }
 
-// stable insertion sort of a[f, l) by key: what __final_insertion_sort makes of a range the partitions are done with
+// std::__partial_sort(first, last, last) = __make_heap + __sort_heap, statement by statement (bits/stl_heap.h: __adjust_heap sifts the hole down to a leaf
+// along the larger children - the right one on ties - and __push_heap carries the value back up): what __introsort_loop does with a range of more than 16
+// elements when its depth budget is used up.  Sequential by nature (every pop depends on the heap the previous one left); one thread runs it.  On voxel
+// keys in raster order (saw-tooth runs) the median-of-three partitions DO degenerate now and then: about one plane in a hundred ends here.
 template <int SHIFT>
-__device__ __forceinline__ void insertion(uint32_t* a, int f, int l) {
-    for (int i = f + 1; i < l; i++) {
-        const uint32_t v = a[i], kv = v >> SHIFT;
-        int j = i;
-        while (j > f) { const uint32_t u = a[j - 1]; if (!((u >> SHIFT) > kv)) break; a[j] = u; j--; }
-        a[j] = v;
+__device__ __forceinline__ void adjust_heap(uint32_t* first, int hole, int len, uint32_t value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        const uint32_t r = first[child], l = first[child - 1];
+        if ((r >> SHIFT) < (l >> SHIFT)) { child--; first[hole] = l; } else first[hole] = r;
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    const uint32_t kv = value >> SHIFT;
+    while (hole > top) {
+        const int parent = (hole - 1) / 2;
+        const uint32_t u = first[parent];
+        if (!((u >> SHIFT) < kv)) break;
+        first[hole] = u;
+        hole = parent;
+    }
+    first[hole] = value;
+}
+template <int SHIFT>
+__device__ __forceinline__ void heap_sort(uint32_t* a, int f, int l) {
+    uint32_t* first = a + f;
+    const int len = l - f;
+#ifdef PLANAR_WAVE_EMUL
+    g_heap += len;
+#endif
+    if (len < 2) return;
+    for (int parent = (len - 2) / 2;; parent--) {
+        adjust_heap<SHIFT>(first, parent, len, first[parent]);
+        if (parent == 0) break;
+    }
+    for (int last = len - 1; last > 0; last--) {
+        const uint32_t value = first[last];
+        first[last] = first[0];
+        adjust_heap<SHIFT>(first, 0, last, value);
     }
 }
 
@@ -122,193 +166,409 @@ __device__ __forceinline__ int select64(unsigned long long w, int k) {
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // LDS tier
 // ---------------------------------------------------------------------------------------------------------------------------------------
-template <int T, int E>
-struct LdsLayout {
-    static constexpr int N = T * E, NW = T / 64, SMAX = N / 17 + 2;
-    static_assert(E >= 1 && E <= 32, "a thread's chunk is a 32-bit mask");
-    static_assert(SMAX <= 2 * T, "two segments per thread in the list steps");
-    static constexpr int off_a = 0;
-    static constexpr int off_posh = off_a + N * 4;                                  // u16 [N / 2 + 2]
-    static constexpr int off_sf = off_posh + ((N / 2 + 2) * 2 + 3) / 4 * 4;         // u16 [2][SMAX]
-    static constexpr int off_sl = off_sf + 2 * SMAX * 2;
-    static constexpr int off_scut = off_sl + 2 * SMAX * 2;                          // u16 [SMAX]
-    static constexpr int off_sd = off_scut + SMAX * 2;                              // u8 [2][SMAX]
-    static constexpr int off_buf = (off_sd + 2 * SMAX + 3) / 4 * 4;                 // int [4 * NW + 4]
-    static constexpr int bytes = off_buf + (4 * NW + 4) * 4;
+// The level loop below (sort_levels) is written once and run at two scopes: by the whole workgroup on the segments of more than W_CAP elements
+// (a level costs a handful of workgroup barriers whatever it holds, so only the few top levels of a block run there), and by single wavefronts on
+// segments of <= W_CAP = 1984 elements, which they take from a task list and finish on their own - no workgroup barrier, sixteen of them side by side.
+// Nothing is insertion-sorted on the way: every cut sets a bit, and the block's last pass ranks every element inside its <= 16-element leaf
+// (stable: what __final_insertion_sort would do) while it writes the block back.
+constexpr int W_E = 31, W_CAP = 64 * W_E, W_LIST = 128, G_LIST = 32, TASKS = 256;      // (an odd stride: lane l's chunk starts at bank 31 l mod 32)
+
+template <int T>
+struct WgScope {
+    static constexpr int NT = T;
+    int* s_buf;                                               // [4 * T / 64]
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ int exscan(int v, int* total) const { return block_exscan<T, int>(v, s_buf, total); }
+    __device__ __forceinline__ void seg_scan(int vL, int rL, int vR, int rR, int& cL, int& cR) const { seg_scan2<T>(vL, rL, vR, rR, s_buf, cL, cR); }
+};
+#ifndef PLANAR_WAVE_EMUL
+// inclusive segmented prefix sum over the 64 lanes on DPP row operations (the Kogge-Stone ladder of wave_scan_add with the pair operator
+// (v, g) <- (g ? v : v + v', g | g')): no LDS-pipe permute, no wait
+__device__ __forceinline__ void dpp_seg_scan(int& v, int& g) {
+#define ISORT_DPP_STEP(ctrl, rmask)                                                                                                    \
+    {                                                                                                                                  \
+        const int tv = __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false), tg = __builtin_amdgcn_update_dpp(0, g, ctrl, rmask, 0xf, false); \
+        v = g ? v : v + tv; g |= tg;                                                                                                   \
+    }
+    ISORT_DPP_STEP(0x111, 0xf) ISORT_DPP_STEP(0x112, 0xf) ISORT_DPP_STEP(0x114, 0xf) ISORT_DPP_STEP(0x118, 0xf) ISORT_DPP_STEP(0x142, 0xa) ISORT_DPP_STEP(0x143, 0xc)
+#undef ISORT_DPP_STEP
+}
+#endif
+struct WaveScope {                                            // one wavefront: its LDS accesses execute in order, a "barrier" only pins the compiler
+    static constexpr int NT = 64;
+    __device__ __forceinline__ int tid() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    __device__ __forceinline__ int exscan(int v, int* total) const {
+        const int inc = ::planar::wave_scan_add(v);
+        *total = ::planar::wave_lane(inc, 63);
+        return inc - v;
+    }
+    __device__ __forceinline__ void seg_scan(int vL, int rL, int vR, int rR, int& cL, int& cR) const {
+        const int lane = threadIdx.x & 63;
+#if defined(PLANAR_WAVE_EMUL) || defined(ISORT_NO_DPP)
+        int aL = vL, gL = rL, aR = vR, gR = rR;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int tv = __shfl_up(aL, o), tf = __shfl_up(gL, o), uv = __shfl_down(aR, o), uf = __shfl_down(gR, o);
+            if (lane >= o) { if (!gL) aL += tv; gL |= tf; }
+            if (lane + o < 64) { if (!gR) aR += uv; gR |= uf; }
+        }
+        const int eL = __shfl_up(aL, 1), eR = __shfl_down(aR, 1);
+        cL = lane == 0 ? 0 : eL;
+        cR = lane == 63 ? 0 : eR;
+#else
+        // forward on DPP; the backward scan is the forward one on the lane-reversed input (one permute each way)
+        int aL = vL, gL = rL;
+        dpp_seg_scan(aL, gL);
+        cL = __builtin_amdgcn_update_dpp(0, aL, 0x138, 0xf, 0xf, false);            // wave_shr:1: the lane before (lane 0: nothing)
+        const int packed = __shfl(vR | (rR << 16), 63 - lane);
+        int aR = packed & 0xffff, gR = packed >> 16;
+        dpp_seg_scan(aR, gR);
+        const int ex = __builtin_amdgcn_update_dpp(0, aR, 0x138, 0xf, 0xf, false);
+        cR = __shfl(ex, 63 - lane);
+#endif
+    }
 };
 
-// Sorts arr[span_f, span_l) (<= T * E elements), which consists of the nr ranges `ranges` (sorted by f, disjoint; gaps are left alone), as
-// std::sort would have finished each of them.  All T threads of the workgroup call it.
-template <int SHIFT, int T, int E>
-__device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ ranges, int nr, int span_f, int span_l, uint8_t* lds, int* status) {
-    using LL = LdsLayout<T, E>;
-    constexpr int SMAX = LL::SMAX;
-    uint32_t* a = (uint32_t*)(lds + LL::off_a);
-    uint16_t* posh = (uint16_t*)(lds + LL::off_posh);
-    uint16_t* sfb = (uint16_t*)(lds + LL::off_sf);
-    uint16_t* slb = (uint16_t*)(lds + LL::off_sl);
-    uint16_t* scut = (uint16_t*)(lds + LL::off_scut);
-    uint8_t* sdb = lds + LL::off_sd;
-    int* s_buf = (int*)(lds + LL::off_buf);
-    const int tid = threadIdx.x;
-    const int n = span_l - span_f;
-    for (int i = tid; i < n; i += T) a[i] = arr[span_f + i];
-    __syncthreads();
-    int nseg;
-    {   // the initial list: ranges of more than 16 elements; shorter ones are finished here
-        int keep = 0;
-        Range R{0, 0, 0};
-        if (tid < nr) {
-            R = ranges[tid];
-            R.f -= span_f; R.l -= span_f;
-            if (R.l - R.f > 16) keep = 1;
-            else if (R.l - R.f > 1) insertion<SHIFT>(a, R.f, R.l);
-        }
-        int tot;
-        const int off = block_exscan<T, int>(keep, s_buf, &tot);
-        if (keep) { sfb[off] = (uint16_t)R.f; slb[off] = (uint16_t)R.l; sdb[off] = (uint8_t)R.d; }
-        nseg = tot;
-        __syncthreads();
+struct Lists {                                                // a scope's segment lists (double-buffered) and per-segment results, all in LDS
+    uint16_t *f, *l, *cut, *mm;                               // f, l: [2][cap]; cut, mm: [cap]
+    uint8_t* d;                                               // [2][cap]
+    int cap;
+};
+struct Tasks { uint16_t *f, *l; uint8_t* d; int* n; };        // segments of 17 .. W_CAP elements waiting for a wavefront; n[0] count, n[1] next
+
+template <int T, int E>
+struct LdsLayout {
+    static constexpr int N = T * E, NW = T / 64;
+    static_assert(E >= 1 && E <= 32, "a thread's chunk is a 32-bit mask");
+    static constexpr int off_a = 0;
+    static constexpr int off_posh = off_a + N * 4;                                  // u16 [N / 2 + 2]
+    static constexpr int off_mb = off_posh + ((N / 2 + 2) * 2 + 3) / 4 * 4;         // u32 [N / 32 + 2]: a cut / range boundary at this position
+    static constexpr int off_kb = off_mb + (N / 32 + 2) * 4;                        // u32 [N / 32 + 2]: the leaf that starts here lies inside a range
+    static constexpr int off_wl = off_kb + (N / 32 + 2) * 4;                        // per wavefront: lists of W_LIST entries: f, l [2][W_LIST] u16; cut, mm u16; d [2][W_LIST] u8
+    static constexpr int wl_bytes = W_LIST * (4 + 4 + 2 + 2 + 2);
+    static constexpr int off_gl = off_wl + NW * wl_bytes;                           // the workgroup's lists, G_LIST entries, same layout
+    static constexpr int gl_bytes = G_LIST * (4 + 4 + 2 + 2 + 2);
+    static constexpr int off_tk = off_gl + gl_bytes;                                // tasks: f, l u16 [TASKS]; d u8 [TASKS]
+    static constexpr int off_buf = (off_tk + TASKS * 5 + 3) / 4 * 4;                // int [4 * NW + 4]
+    static constexpr int bytes = off_buf + (4 * NW + 4) * 4;
+    static_assert(bytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
+};
+__device__ __forceinline__ Lists carve_lists(uint8_t* p, int cap) {
+    Lists L;
+    L.f = (uint16_t*)p; L.l = L.f + 2 * cap; L.cut = L.l + 2 * cap; L.mm = L.cut + cap; L.d = (uint8_t*)(L.mm + cap); L.cap = cap;
+    return L;
+}
+
+#ifdef ISORT_TIMING
+#define ISORT_MARK(k) do { const long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) g_isort_t[k] += _t - _tm; _tm = _t; } while (0)
+__device__ long long g_isort_t[16];
+#else
+#define ISORT_MARK(k) do { } while (0)
+#endif
+
+// __move_median_to_first for the segment [f, l) in LDS
+template <int SHIFT>
+__device__ __forceinline__ void move_median(uint32_t* a, int f, int l) {
+    const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
+    const uint32_t xa = a[A], xb = a[Bm], xc = a[Cc], xf = a[f];
+    const int t = median_pos<SHIFT>(xa, xb, xc, A, Bm, Cc);
+    a[f] = t == A ? xa : (t == Bm ? xb : xc); a[t] = xf;
+}
+
+// All levels of the recursion below the nseg segments listed in L (buffer 0), by the threads of scope S; thread t owns the elements
+// [c_base + t * E, c_base + (t + 1) * E) below c_end.  Children of more than keep_above elements stay in the scope's list, smaller ones of more than
+// 16 go to the task list TK (none when keep_above == 16); a child whose depth budget is used up is heap-sorted on the spot.
+// A level is latency, not arithmetic (a wavefront's ~40 dependent LDS round trips, four wavefronts per SIMD to hide them behind), so the code keeps the
+// number of dependent LDS accesses down: the first segment of a thread's chunk is tracked from level to level instead of searched, the three segments
+// a chunk can touch are read together, swaps go four at a time, the pivots of the next level are placed by the thread that lists the segment.
+template <int SHIFT, int E, class S>
+__device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* posh, uint32_t* mb, uint32_t* kb, const Lists& L, int nseg, int c_base, int c_end,
+                                            int keep_above, const Tasks& TK, int* status) {
+#ifdef ISORT_TIMING
+    long long _tm = __builtin_readcyclecounter();
+#endif
+    constexpr int NT = S::NT;
+    const int tid = sc.tid();
+    const int c0 = min(c_base + tid * E, c_end), c1 = min(c0 + E, c_end), cap = L.cap;
+    int s0;                                                      // the first listed segment that ends behind c0
+    {
+        for (int s = tid; s < nseg; s += NT) move_median<SHIFT>(a, L.f[s], L.l[s]);
+        int lo_ = 0, hi_ = nseg;
+        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if ((int)L.l[mid] > c0) hi_ = mid; else lo_ = mid + 1; }
+        s0 = lo_;
+        sc.sync();
     }
-    const int c0 = tid * E, c1 = min(c0 + E, n);
     int cur = 0;
     while (nseg > 0) {
-        uint16_t* sf = sfb + cur * SMAX; uint16_t* sl = slb + cur * SMAX; uint8_t* sd = sdb + cur * SMAX;
-        // ---- A: pivots (median of three to the front) ----
-        for (int s = tid; s < nseg; s += T) {
-            const int f = sf[s], l = sl[s];
-            if (sd[s] == 0) *status = ST_DEPTH;
-            const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
-            const int t = median_pos<SHIFT>(a[A], a[Bm], a[Cc], A, Bm, Cc);
-            const uint32_t x = a[f]; a[f] = a[t]; a[t] = x;
-        }
-        __syncthreads();
-        // ---- B: this thread's E elements: which segments they belong to (at most three pieces), where the scans stop ----
+#ifdef PLANAR_WAVE_EMUL
+        if (tid == 0) { g_levels++; g_segs += nseg; }
+#endif
+        uint16_t* sf = L.f + cur * cap; uint16_t* sl = L.l + cur * cap; uint8_t* sd = L.d + cur * cap;
+        uint16_t* scut = L.cut; uint16_t* smm = L.mm;
+        ISORT_MARK(1);
+        // ---- B: this thread's E elements: the (at most three) segments they belong to, where the two scans stop ----
         uint32_t mL = 0, mR = 0;
         int npc = 0;
-        int ps[3] = {0, 0, 0}, plo[3] = {0, 0, 0}, phi[3] = {0, 0, 0};
-        if (c0 < n) {
-            uint32_t kk[E];
+        int pf[3], pl_[3], plo[3], phi[3];
+        uint32_t ppv[3];
+        {
+            uint32_t key[E];
 #pragma unroll
-            for (int j = 0; j < E; j++) kk[j] = a[min(c0 + j, n - 1)] >> SHIFT;
-            int lo_ = 0, hi_ = nseg;
-            while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if ((int)sl[mid] > c0) hi_ = mid; else lo_ = mid + 1; }
-            for (int s = lo_; s < nseg && npc < 3; s++) {
-                const int f = sf[s], l = sl[s];
-                if (f >= c1) break;
-                const int lo = max(f + 1, c0) - c0, hi = min(l, c1) - c0;
-                if (lo < hi) {
-                    const uint32_t pv = a[f] >> SHIFT;
-                    uint32_t ge = 0, le = 0;
+            for (int j = 0; j < E; j++) key[j] = a[min(c0 + j, max(c_end - 1, 0))];
 #pragma unroll
-                    for (int j = 0; j < E; j++) { ge |= (uint32_t)(kk[j] >= pv) << j; le |= (uint32_t)(kk[j] <= pv) << j; }
-                    const uint32_t rm = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-                    mL |= ge & rm; mR |= le & rm;
+            for (int q = 0; q < 3; q++) { const int s = min(s0 + q, nseg - 1); pf[q] = sf[s]; pl_[q] = sl[s]; }
 #pragma unroll
-                    for (int q = 0; q < 3; q++) if (npc == q) { ps[q] = s; plo[q] = lo; phi[q] = hi; }
-                    npc++;
-                }
-                if (l >= c1) break;
+            for (int q = 0; q < 3; q++) ppv[q] = a[pf[q]] >> SHIFT;
+            uint32_t rm_all = 0;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int lo = max(pf[q] + 1, c0) - c0, hi = min(pl_[q], c1) - c0;
+                const bool on = s0 + q < nseg && lo < hi;
+                plo[q] = on ? lo : 99; phi[q] = on ? hi : 99;
+                if (on) { npc = q + 1; rm_all |= (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u); }
             }
+            uint32_t ge = 0, le = 0;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const uint32_t pv = j >= plo[2] ? ppv[2] : (j >= plo[1] ? ppv[1] : ppv[0]), k = key[j] >> SHIFT;
+                ge |= (uint32_t)(k >= pv) << j; le |= (uint32_t)(k <= pv) << j;
+            }
+            mL = ge & rm_all; mR = le & rm_all;
         }
         auto rmask = [&](int q) { return (phi[q] >= 32 ? 0xffffffffu : ((1u << phi[q]) - 1u)) & ~((1u << plo[q]) - 1u); };
         // does the first piece's segment have elements before this chunk / the last piece's segment elements behind it
-        const bool contL = npc > 0 && (int)sf[ps[0]] + 1 < c0;
-        int lastq = 0;
+        const bool contL = npc > 0 && pf[0] + 1 < c0;
+        const int lastq = npc > 0 ? npc - 1 : 0;
+        int l_last = pl_[0];
 #pragma unroll
-        for (int q = 1; q < 3; q++) if (q < npc) lastq = q;
-        int last_s = ps[0];
-#pragma unroll
-        for (int q = 1; q < 3; q++) if (q < npc) last_s = ps[q];
-        const bool contR = npc > 0 && (int)sl[last_s] > c1;
+        for (int q = 1; q < 3; q++) if (q < npc) l_last = pl_[q];
+        const bool contR = npc > 0 && l_last > c1;
         uint32_t rm_last = 0;
 #pragma unroll
         for (int q = 0; q < 3; q++) if (q == lastq && npc > 0) rm_last = rmask(q);
         const uint32_t rm_first = npc > 0 ? rmask(0) : 0u;
         int carryL, carryR;
-        seg_scan2<T>(__popc(mL & rm_last), !(npc == 1 && contL), __popc(mR & rm_first), !(npc == 1 && contR), s_buf, carryL, carryR);
-        // ---- D: ranks; the left-scan stops that will be swapped publish their positions; the thread that sees x* writes the cut ----
+        ISORT_MARK(2);
+        sc.seg_scan(__popc(mL & rm_last), !(npc == 1 && contL), __popc(mR & rm_first), !(npc == 1 && contR), carryL, carryR);
+        ISORT_MARK(3);
+        // ---- D1: the piece with g false at its start and true behind its end holds x*: it writes the segment's cut and its number of swaps m ----
+        int pA0[3] = {0, 0, 0}, pBe[3] = {0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             if (q >= npc) continue;
-            const int s = ps[q], f = sf[s], l = sl[s];
-            const uint32_t rm = rmask(q);
-            int A = (q == 0 && contL) ? carryL : 0;
-            int Bf = ((q == lastq && contR) ? carryR : 0) + __popc(mR & rm);
-            const uint32_t pv = a[f] >> SHIFT;
-            const int base = (f + 1) >> 1;
-            bool gprev = false, eLp = false, eRp = false;        // g and the flags of the element before the piece
-            if (c0 + plo[q] > f + 1) {                           // (then plo == 0: the element is the previous thread's last one)
-                const uint32_t kp = a[c0 - 1] >> SHIFT;
-                eLp = kp >= pv; eRp = kp <= pv;
-                gprev = (A - (int)eLp) >= (Bf + (int)eRp);
-            }
-            for (int j = plo[q]; j <= phi[q]; j++) {
-                const bool end = j == phi[q];
-                if (end && c0 + j != l) break;                   // the virtual position l belongs to the thread that holds l - 1
-                const bool isL = !end && ((mL >> j) & 1u), isR = !end && ((mR >> j) & 1u);
-                const bool g = A >= Bf;
-                if (g && !gprev) {
-                    const int Ap = A - (int)eLp, Bp = Bf + (int)eRp;
-                    scut[s] = (uint16_t)(c0 + j - ((eLp && eRp && Ap == Bp - 1) ? 1 : 0));
+            const uint32_t rm = rmask(q), Lp = mL & rm, Rp = mR & rm;
+            const int A0 = (q == 0 && contL) ? carryL : 0, Be = (q == lastq && contR) ? carryR : 0;
+            pA0[q] = A0; pBe[q] = Be;
+            if (!(A0 >= Be + __popc(Rp)) && A0 + __popc(Lp) >= Be) {
+                int jl = plo[q], jh = phi[q];                    // g(jl) false, g(jh) true: x* in (jl, jh]
+                while (jh - jl > 1) {
+                    const int mid = (jl + jh) >> 1;
+                    if (A0 + __popc(Lp & ((1u << mid) - 1u)) >= Be + __popc(Rp >> mid)) jh = mid; else jl = mid;
                 }
-                if (isL && Bf - (int)isR >= A + 1) posh[base + A] = (uint16_t)(c0 + j);
-                gprev = g; eLp = isL; eRp = isR;
-                A += (int)isL; Bf -= (int)isR;
+                const int e = jh - 1;                            // the element before x*: in this piece
+                const bool eL = (Lp >> e) & 1u, eR = (Rp >> e) & 1u;
+                const int Ap = A0 + __popc(Lp & ((1u << e) - 1u)), Bp = Be + __popc(Rp >> e);
+                scut[s0 + q] = (uint16_t)(c0 + jh - ((eL && eR && Ap == Bp - 1) ? 1 : 0));
+                smm[s0 + q] = (uint16_t)max(Ap, Bp - (int)eR);
             }
         }
-        __syncthreads();
-        // ---- E: the right-scan stops that are swapped fetch their partners ----
+        sc.sync();
+        ISORT_MARK(4);
+        // ---- D2: the first m stops of the left scan publish their positions (rank order) ----
+        int pm[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) pm[q] = smm[min(s0 + q, nseg - 1)];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             if (q >= npc) continue;
-            const int s = ps[q], f = sf[s];
-            const uint32_t rm = rmask(q);
-            int A = (q == 0 && contL) ? carryL : 0;
-            int Bf = ((q == lastq && contR) ? carryR : 0) + __popc(mR & rm);
-            const int base = (f + 1) >> 1;
-            for (int j = plo[q]; j < phi[q]; j++) {
-                const bool isL = (mL >> j) & 1u, isR = (mR >> j) & 1u;
-                if (isR && A >= Bf) {
-                    const int pL = posh[base + Bf - 1], qq = c0 + j;
-                    const uint32_t x = a[pL], y = a[qq];
-                    a[pL] = y; a[qq] = x;
+            uint32_t bits = mL & rmask(q);
+            const int base = ((pf[q] + 1) >> 1) + pA0[q];
+            const int gl = min(max(pm[q] - pA0[q], 0), __popc(bits));
+            for (int k = 0; k < gl; k++) { const int j = __ffs((int)bits) - 1; bits &= bits - 1u; posh[base + k] = (uint16_t)(c0 + j); }
+        }
+        sc.sync();
+        ISORT_MARK(5);
+        // ---- E: the first m stops of the right scan (it walks downwards) fetch their partners and swap, four at a time ----
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if (q >= npc) continue;
+            uint32_t bits = mR & rmask(q);
+            const int base = ((pf[q] + 1) >> 1) + pBe[q];
+            const int gr = min(max(pm[q] - pBe[q], 0), __popc(bits));
+            constexpr int SU = 4;
+            for (int t0 = 0; t0 < gr; t0 += SU) {
+                int qq[SU], pL[SU];
+                uint32_t x[SU], y[SU];
+#pragma unroll
+                for (int u = 0; u < SU; u++) {
+                    const int j = bits ? 31 - __clz((int)bits) : 0;
+                    if (t0 + u < gr) bits &= ~(1u << j);
+                    qq[u] = c0 + j;
+                    pL[u] = posh[base + min(t0 + u, gr - 1)];
                 }
-                A += (int)isL; Bf -= (int)isR;
+#pragma unroll
+                for (int u = 0; u < SU; u++) { x[u] = a[pL[u]]; y[u] = a[qq[u]]; }
+#pragma unroll
+                for (int u = 0; u < SU; u++) if (t0 + u < gr) { a[pL[u]] = y[u]; a[qq[u]] = x[u]; }
             }
         }
-        __syncthreads();
-        // ---- F: the next level's list (children of more than 16 elements, in order); shorter children are finished now ----
+        sc.sync();
+        ISORT_MARK(6);
+        // ---- F: the cuts become leaf boundaries; children: stay listed (their pivot is placed now) / become a wavefront's task / are finished (leaf, or
+        //      heap sort at depth 0).  smm[s] <- the new index of s's first listed child, bit 15: the left child is listed ----
         {
-            uint16_t* nf = sfb + (cur ^ 1) * SMAX; uint16_t* nl = slb + (cur ^ 1) * SMAX; uint8_t* nd = sdb + (cur ^ 1) * SMAX;
-            int cf[4], cl[4], cd[4], nk = 0;
+            uint16_t* nf = L.f + (cur ^ 1) * cap; uint16_t* nl = L.l + (cur ^ 1) * cap; uint8_t* nd = L.d + (cur ^ 1) * cap;
+            int cf[4], cl[4], cd[4], nk = 0, nk0 = 0;
+            bool leftk[2] = {false, false};
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int s = 2 * tid + u;
+                if (u == 1) nk0 = nk;
                 if (s < nseg) {
-                    const int f = sf[s], l = sl[s], cut = scut[s], d = sd[s] > 0 ? sd[s] - 1 : 0;
+                    const int f = sf[s], l = sl[s], cut = scut[s], d = sd[s] - 1;      // (listed segments have a budget of at least one)
+                    atomicOr(&mb[cut >> 5], 1u << (cut & 31)); atomicOr(&kb[cut >> 5], 1u << (cut & 31));
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const int xf = h ? cut : f, xl = h ? l : cut;
-                        if (xl - xf > 16) {
+                        if (xl - xf > 16 && d == 0) heap_sort<SHIFT>(a, xf, xl);          // budget used up: the heap-sort fallback (a leaf of more than 16: left alone later)
+                        else if (xl - xf > keep_above) {
 #pragma unroll
                             for (int z = 0; z < 4; z++) if (nk == z) { cf[z] = xf; cl[z] = xl; cd[z] = d; }
                             nk++;
-                        } else if (xl - xf > 1) insertion<SHIFT>(a, xf, xl);
+                            if (h == 0) leftk[u] = true;
+                            move_median<SHIFT>(a, xf, xl);
+                        } else if (xl - xf > 16) {
+                            const int k = atomicAdd(&TK.n[0], 1);
+                            if (k < TASKS) { TK.f[k] = (uint16_t)xf; TK.l[k] = (uint16_t)xl; TK.d[k] = (uint8_t)d; } else *status = ST_CAPACITY;
+                        }
                     }
                 }
             }
             int tot;
-            const int off = block_exscan<T, int>(nk, s_buf, &tot);
+            const int off = sc.exscan(nk, &tot);
 #pragma unroll
-            for (int z = 0; z < 4; z++) if (z < nk) { nf[off + z] = (uint16_t)cf[z]; nl[off + z] = (uint16_t)cl[z]; nd[off + z] = (uint8_t)cd[z]; }
+            for (int z = 0; z < 4; z++) if (z < nk && off + z < cap) { nf[off + z] = (uint16_t)cf[z]; nl[off + z] = (uint16_t)cl[z]; nd[off + z] = (uint8_t)cd[z]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) if (2 * tid + u < nseg) smm[2 * tid + u] = (uint16_t)((off + (u ? nk0 : 0)) | (leftk[u] ? 0x8000 : 0));
+            if (tot > cap) { *status = ST_CAPACITY; tot = cap; }
+            sc.sync();
+            // this thread's first segment in the new list: the children of the old one (or what follows them)
+            if (s0 < nseg) { const int v = smm[s0], cutv = scut[s0]; s0 = (v & 0x7fff) + (((v & 0x8000) && cutv <= c0) ? 1 : 0); } else s0 = tot;
             nseg = tot;
             cur ^= 1;
-            __syncthreads();
+            sc.sync();
+        }
+        ISORT_MARK(7);
+    }
+}
+
+// Sorts arr[span_f, span_l) (<= T * E elements), which consists of the nr <= T ranges `ranges` (sorted by f, disjoint; anything between them is left
+// alone), as std::sort would have finished each of them.  All T threads of the workgroup call it.
+template <int SHIFT, int T, int E>
+__device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ ranges, int nr, int span_f, int span_l, uint8_t* lds, int* status) {
+    using LL = LdsLayout<T, E>;
+    uint32_t* a = (uint32_t*)(lds + LL::off_a);
+    uint16_t* posh = (uint16_t*)(lds + LL::off_posh);
+    uint32_t* mb = (uint32_t*)(lds + LL::off_mb);
+    uint32_t* kb = (uint32_t*)(lds + LL::off_kb);
+    int* s_buf = (int*)(lds + LL::off_buf);
+    int* s_tn = s_buf + 4 * LL::NW;                              // [0] tasks, [1] next task
+    Tasks TK;
+    TK.f = (uint16_t*)(lds + LL::off_tk); TK.l = TK.f + TASKS; TK.d = (uint8_t*)(TK.l + TASKS); TK.n = s_tn;
+    const Lists GL = carve_lists(lds + LL::off_gl, G_LIST);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = span_l - span_f;
+#ifdef ISORT_TIMING
+    long long _tm = __builtin_readcyclecounter();
+#endif
+    for (int i = tid; i < n; i += T) a[i] = arr[span_f + i];
+    for (int i = tid; i < LL::N / 32 + 2; i += T) { mb[i] = 0u; kb[i] = 0u; }
+    if (tid == 0) { s_tn[0] = 0; s_tn[1] = 0; }
+    __syncthreads();
+    const WgScope<T> wg{s_buf};
+    int nseg;
+    {   // the ranges: boundaries; more than W_CAP elements: the workgroup's list; more than 16: a task; depth 0 (cannot be, but harmless): heap sort
+        int keep = 0;
+        Range R{0, 0, 0};
+        if (tid < nr) {
+            R = ranges[tid];
+            R.f -= span_f; R.l -= span_f;
+            atomicOr(&mb[R.f >> 5], 1u << (R.f & 31)); atomicOr(&kb[R.f >> 5], 1u << (R.f & 31));
+            atomicOr(&mb[R.l >> 5], 1u << (R.l & 31));
+            if (R.l - R.f > 16 && R.d == 0) heap_sort<SHIFT>(a, R.f, R.l);
+            else if (R.l - R.f > W_CAP) keep = 1;
+            else if (R.l - R.f > 16) {
+                const int k = atomicAdd(&s_tn[0], 1);
+                if (k < TASKS) { TK.f[k] = (uint16_t)R.f; TK.l[k] = (uint16_t)R.l; TK.d[k] = (uint8_t)R.d; } else *status = ST_CAPACITY;
+            }
+        }
+        if (tid == 0) { atomicOr(&mb[0], 1u); atomicOr(&mb[n >> 5], 1u << (n & 31)); }
+        int tot;
+        const int off = wg.exscan(keep, &tot);
+        if (keep && off < G_LIST) { GL.f[off] = (uint16_t)R.f; GL.l[off] = (uint16_t)R.l; GL.d[off] = (uint8_t)R.d; }
+        if (tot > G_LIST) { *status = ST_CAPACITY; tot = G_LIST; }
+        nseg = tot;
+        __syncthreads();
+    }
+    ISORT_MARK(0);
+    sort_levels<SHIFT, E, WgScope<T>>(wg, a, posh, mb, kb, GL, nseg, 0, n, W_CAP, TK, status);
+    __syncthreads();
+#ifdef ISORT_TIMING
+    _tm = __builtin_readcyclecounter();
+#endif
+    {   // the tasks: one wavefront each, first come first served
+        const WaveScope wv;
+        const Lists WL = carve_lists(lds + LL::off_wl + wave * LL::wl_bytes, W_LIST);
+        const int ntasks = min(s_tn[0], TASKS);
+        const Tasks none{nullptr, nullptr, nullptr, s_tn};
+        while (true) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&s_tn[1], 1);
+            t = __shfl(t, 0);
+            if (t >= ntasks) break;
+            const int f = TK.f[t], l = TK.l[t];
+            if (lane == 0) { WL.f[0] = (uint16_t)f; WL.l[0] = (uint16_t)l; WL.d[0] = TK.d[t]; }
+            wv.sync();
+            sort_levels<SHIFT, W_E, WaveScope>(wv, a, posh, mb, kb, WL, 1, f, l, 16, none, status);
         }
     }
-    for (int i = tid; i < n; i += T) arr[span_f + i] = a[i];
     __syncthreads();
+    ISORT_MARK(8);
+    // the write-back; an element of a leaf of <= 16 elements inside a range goes to its stable rank in the leaf (__final_insertion_sort).  Four elements
+    // per thread at a time, the leaf walked as 16 predicated reads: nothing in here waits for the previous element
+    constexpr int WU = 4;
+    for (int i0 = tid; i0 < n; i0 += T * WU) {
+        uint32_t v[WU];
+        int s[WU], e[WU], dest[WU];
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            const int i = min(i0 + u * T, n - 1), w = i >> 5, bi = i & 31;
+            v[u] = a[i];
+            const uint32_t mw = mb[w], mp = mb[max(w - 1, 0)], mn = mb[w + 1];
+            const uint32_t below = mw & (0xffffffffu >> (31 - bi)), above = bi == 31 ? 0u : (mw & (0xffffffffu << (bi + 1)));
+            s[u] = below ? (w << 5) + 31 - __clz((int)below) : ((w > 0 && mp) ? ((w - 1) << 5) + 31 - __clz((int)mp) : -1);
+            e[u] = above ? (w << 5) + __ffs((int)above) - 1 : (mn ? ((w + 1) << 5) + __ffs((int)mn) - 1 : -1);
+        }
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            const int i = min(i0 + u * T, n - 1);
+            const bool leaf = s[u] >= 0 && e[u] >= 0 && e[u] - s[u] <= 16 && ((kb[max(s[u], 0) >> 5] >> (max(s[u], 0) & 31)) & 1u);
+            const uint32_t kv = v[u] >> SHIFT;
+            int rank = 0;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int jj = max(s[u], 0) + t;
+                const uint32_t kj = a[min(jj, n - 1)] >> SHIFT;
+                rank += (leaf && jj < e[u] && (kj < kv || (kj == kv && jj < i))) ? 1 : 0;
+            }
+            dest[u] = leaf ? s[u] + rank : i;
+        }
+#pragma unroll
+        for (int u = 0; u < WU; u++) if (i0 + u * T < n) arr[span_f + dest[u]] = v[u];
+    }
+    __syncthreads();
+    ISORT_MARK(9);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -443,7 +703,8 @@ __device__ void global_tier(uint32_t* __restrict__ arr, const Range* __restrict_
         int nq = 0, nf = 0;
         for (int i = 0; i < n_init; i++) {
             const Range R = init[i];
-            if (R.l - R.f > n_stage) { if (nq < G_QMAX) qb[nq++] = R; else *status = ST_CAPACITY; }
+            if (R.l - R.f > n_stage && R.d > 0) { if (nq < G_QMAX) qb[nq++] = R; else *status = ST_CAPACITY; }
+            else if (R.l - R.f > n_stage) heap_sort<SHIFT>(arr, R.f, R.l);
             else if (R.l - R.f > 1) { if (nf < G_FMAX) fin[nf++] = R; else *status = ST_CAPACITY; }
         }
         s_c[0] = nq; s_c[1] = 0; s_c[2] = nf;
@@ -455,14 +716,13 @@ __device__ void global_tier(uint32_t* __restrict__ arr, const Range* __restrict_
         if (ncur == 0) break;
         for (int r = 0; r < ncur; r++) {
             const Range R = qb[cur * G_QMAX + r];
-            if (R.d == 0) { if (tid == 0) *status = ST_DEPTH; }
             const int cut = wg_partition<SHIFT, T>(arr, R.f, R.l, lds, rows_cap, status);
             if (tid == 0) {
-                const int d = R.d > 0 ? R.d - 1 : 0;
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const Range C{h ? cut : R.f, h ? R.l : cut, d};
-                    if (C.l - C.f > n_stage) { if (s_c[1] < G_QMAX) qb[(cur ^ 1) * G_QMAX + s_c[1]++] = C; else *status = ST_CAPACITY; }
+                    const Range C{h ? cut : R.f, h ? R.l : cut, R.d - 1};       // (queued ranges have a budget of at least one)
+                    if (C.l - C.f > n_stage && C.d > 0) { if (s_c[1] < G_QMAX) qb[(cur ^ 1) * G_QMAX + s_c[1]++] = C; else *status = ST_CAPACITY; }
+                    else if (C.l - C.f > n_stage) heap_sort<SHIFT>(arr, C.f, C.l);  // budget used up on a range too long for LDS: the fallback in global memory (slow, rare)
                     else if (C.l - C.f > 1) { if (s_c[2] < G_FMAX) fin[s_c[2]++] = C; else *status = ST_CAPACITY; }
                 }
             }

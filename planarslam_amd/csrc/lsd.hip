@@ -9,9 +9,9 @@
 //   K1 lsd_gauss        8U fixed-point Gaussian (7x7 sigma 0.75 for LSD, 5x5 sigma 1 for LBD), LDS tile, pixel-parallel
 //   K2 lsd_grad         0.8x INTER_LINEAR_EXACT resample fused with the 2x2 gradient: level-line angle (float degrees,
 //                       exactly what fastAtan2 returned), squared gradient (u32), per-frame max, pixel-parallel
-//   K3 lsd_sort         per frame: the visiting order = std::sort by 1024-bin gradient norm.  The order libstdc++'s introsort leaves among equal
-//                       bins is reproduced with parallel Hoare partitions (global memory -> ranges staged in LDS -> one wavefront ->
-//                       one lane per small range), then two stable 5-bit radix passes drop undefined pixels and finish the sort
+//   K3 lsd_sort_*       per frame: the visiting order = std::sort by 1024-bin gradient norm.  The order libstdc++'s introsort leaves among equal
+//                       bins is reproduced by isort.h (level-synchronous parallel Hoare partitions: bitmaps of the scans' stops in the global
+//                       tier, whole recursion levels at once in LDS blocks), then the undefined pixels are dropped
 //   K4 lsd_detect       ONE WAVEFRONT PER FRAME, the sequential part: region growing in the reference's visiting order
 //                       (the level-line angle of a region is updated after every accepted pixel, so acceptance is a
 //                       chain), rectangle fit, density refinement, NFA validation.  The wave hides memory latency by
@@ -25,6 +25,7 @@
 #include "common.h"
 #include "wave_ops.h"
 #include "lsd_nfa.h"
+#include "isort.h"
 
 namespace planar {
 namespace lsd {
@@ -46,14 +47,14 @@ struct Plan {
     double rho, prec, p, log_nt, density_th, log_eps;
     int min_reg_size;
     // per-frame workspace offsets (bytes)
-    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_pix, off_seed, off_ord, off_ordr, off_gused, off_tmp, off_reg, off_segs, off_kl, off_rects, off_res, frame_bytes;
+    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_pix, off_seed, off_ord, off_ordr, off_gused, off_tmp, off_reg, off_valid, off_sortr, off_sortb, off_segs, off_kl, off_rects, off_res, frame_bytes;
     // host-evaluated tables (glibc, as the reference library would): log_gamma(x) for integer x, and per halving j of p
     const double* lgamma_tab;   // [w*h + 3]
     double p_log[12], p1_log[12], p_log10[12];
     double gaussCoefL[21], gaussCoefG[63];
 };
 
-struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int n_staged; int pad_; };
+struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int sort_counts[2]; };   // sort_counts: ranges, LDS-tier blocks
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2: 7th-order odd polynomial, degrees; plain mul/add (no FMA), see oracle/cvprim.cpp
@@ -157,13 +158,13 @@ __global__ __launch_bounds__(256) void lsd_grad(const Plan* __restrict__ plan, c
         ang[o] = deg;
         const double a = (double)deg * DEG_TO_RADS;
         const float af = (float)a;
-        pix4[o] = make_float4(deg, (float)cos((double)af), (float)sin((double)af), 0.f);   // .w: compact index, filled by lsd_sort
+        pix4[o] = make_float4(deg, (float)cos((double)af), (float)sin((double)af), 0.f);   // .w: compact index, filled by lsd_sort_compact
         seedcs[o] = make_float2((float)cos(a), (float)sin(a));
         atomicMax(&misc->g2max, (uint32_t)g2);
     }
 }
 
-// ---- K3: descending 1024-bin order, raster order inside a bin -------------------------------------------------------
+// ---- K3: the visiting order: descending 1024-bin norm, ties as std::sort leaves them ----------------------------------------------------
 template <int NW>   // exclusive scan over a workgroup of NW wavefronts
 __device__ inline int block_exscan(int v, int* wsum, int* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -180,436 +181,145 @@ __device__ inline int block_exscan(int v, int* wsum, int* total) {
 
 __device__ __forceinline__ void wave_sync();
 __device__ __forceinline__ void lds_sync();
-// libstdc++ std::sort(ordered_points, compare_norm) reproduced in parallel (tie_order 0).  lsd.cpp sorts all (w-1)(h-1) pixels by their
-// 1024-bin gradient norm with std::sort, so pixels of equal bin end up in the order libstdc++'s introsort leaves them.  That order is a
-// deterministic function of the bin sequence:
-//   * __introsort_loop: every Hoare partition (median of first+1 / mid / last-1 moved to the front, unguarded scans) swaps the k-th element
-//     that stops the left scan (bin <= pivot, ascending position) with the k-th that stops the right scan (bin >= pivot, descending position)
-//     for k < m = #{k : L_k < R_k}, and cuts at min(L_m, R_{m-1}).  Stops, m and the swaps are prefix-scan / ballot computations;
-//     the recursion tree is walked level by level (ranges are disjoint), ranges of <= 4096 elements are finished inside LDS by one wavefront
-//     (<= SORT_LEAF elements: one LANE per sub-range runs the sequential loop on its own elements);
-//   * __final_insertion_sort is a stable sort of the arrangement the partitions leave = the two radix passes below.
-// Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py).  A depth-limit overflow (heap-sort fallback of introsort)
-// cannot be reproduced this way and raises status 2; it needs ~34 unbalanced partitions in a row and does not occur on 10-bit keys.
-constexpr int SORT_NT = 256;        // threads of lsd_sort: 4 wavefronts keep 4 sub-ranges (or 4 shares of a big one) in flight; 38 KB LDS, so four frames share a CU
-constexpr int SORT_NW = SORT_NT / 64;
-constexpr int SORT_SMALL = 2048;    // finished by one wavefront
-constexpr int SORT_STAGE = 4096;    // staged in LDS by the workgroup (32 KB + 6 KB static); 2048 (22 KB, co-resident with four plane-clustering wavefronts) measured 15.1 instead of 10.7 ms alone and no faster step
-constexpr int SORT_LEAF = 64;       // finished by one lane
-struct SortRange { int f, l, d; };
+// lsd.cpp sorts all (w-1)(h-1) gradient pixels by their 1024-bin norm with std::sort(compare_norm: a.norm > b.norm), so pixels of equal bin are
+// visited in the order libstdc++'s introsort leaves them.  isort.h computes that arrangement in parallel (tie_order 0): words are
+// (1023 - bin) << 20 | pixel, ascending.  Three launches:
+//   lsd_sort_global   one workgroup per frame: the words, a bitmap of the pixels with a defined angle, and the partitions of the ranges longer than
+//                     an LDS block (bitmaps of the scans' stops in LDS: the array is read once per level, only swapped words are written);
+//   lsd_sort_lds      one workgroup per block of <= 23 552 words, up to SORT_R per frame: everything below, in LDS, written back sorted;
+//   lsd_sort_compact  one workgroup per frame: drops the undefined pixels (they took part in the partitions), numbers the rest.
+// Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py) and on the emulator (tests/test_isort_emul.py).
+constexpr int SORT_T = 1024, SORT_E = 23, SORT_SHIFT = 20, SORT_R = 16;
+using SortLds = isort::LdsLayout<SORT_T, SORT_E>;
+using SortGl = isort::GlobalLayout<SORT_T>;
 
-// one wavefront; arr[f, l) in LDS, l - f > 16; Lb / Rb are LDS scratch arrays indexed like arr.  Returns the cut.
-__device__ __forceinline__ int partition_step(uint32_t* arr, uint16_t* Lb, uint16_t* Rb, int f, int l, int lane) {
-    {   // __move_median_to_first(first, first + 1, mid, last - 1), comp(a, b) = a.norm > b.norm
-        const int A = f + 1, B = f + (l - f) / 2, C = l - 1;
-        const uint32_t a = arr[A] >> 20, bq = arr[B] >> 20, c = arr[C] >> 20;
-        int t;
-        if (a > bq) { if (bq > c) t = B; else if (a > c) t = C; else t = A; }
-        else if (a > c) t = A;
-        else if (bq > c) t = C;
-        else t = B;
-        if (lane == 0) { const uint32_t x = arr[f]; arr[f] = arr[t]; arr[t] = x; }
-        lds_sync();
-    }
-    const uint32_t pv = arr[f] >> 20;
-    constexpr int U = 4;                                      // chunks per iteration: the LDS reads are issued together
-    int cntL = 0, cntR = 0;
-    // one ascending pass finds the stops of both scans: left scan !(x > pivot), right scan !(pivot > x).  The right scan walks downwards,
-    // so its k-th stop is Rb[f + 1 + cntR - 1 - k].
-    for (int base = f + 1; base < l; base += 64 * U) {
-        uint32_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) v[u] = arr[min(base + 64 * u + lane, l - 1)];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = base + 64 * u + lane;
-            const uint32_t k = v[u] >> 20;
-            const bool isL = i < l && !(k > pv), isR = i < l && !(pv > k);
-            const unsigned long long mL = __ballot(isL), mR = __ballot(isR), below = (1ull << lane) - 1ull;
-            if (isL) Lb[f + 1 + cntL + __popcll(mL & below)] = (uint16_t)i;
-            if (isR) Rb[f + 1 + cntR + __popcll(mR & below)] = (uint16_t)i;
-            cntL += __popcll(mL); cntR += __popcll(mR);
-        }
-    }
-    lds_sync();
-    const int kmax = min(cntL, cntR), rtop = f + cntR;        // Rb[rtop - k] = k-th stop of the right scan
-    int m = 0;
-    for (int kb = 0; kb < kmax; kb += 64) {
-        const int k = kb + lane;
-        int Lk = 0, Rk = 0;
-        bool good = false;
-        if (k < kmax) { Lk = Lb[f + 1 + k]; Rk = Rb[rtop - k]; good = Lk < Rk; }
-        const int ng = __popcll(__ballot(good));              // L ascending, R descending: the good pairs are a prefix
-        if (good) { const uint32_t x = arr[Lk]; arr[Lk] = arr[Rk]; arr[Rk] = x; }
-        m += ng;
-        if (ng < min(64, kmax - kb)) break;
-    }
-    lds_sync();
-    int cut = 0x7fffffff;
-    if (m < cntL) cut = min(cut, (int)Lb[f + 1 + m]);
-    if (m > 0) cut = min(cut, (int)Rb[rtop - (m - 1)]);
-    return cut;
-}
-
-// One Hoare partition of arr[f, l) by the whole workgroup (SORT_NT threads); same arithmetic as partition_step.  Works on global memory
-// (IdxT = uint32_t) and on a range staged in LDS (IdxT = uint16_t); one instantiation per address space.  Returns the cut in every thread.
-// bc[0..3]: pivot, swapped position t, old arr[f], old arr[t] (threads patch their reads instead of waiting for the median swap to land).
-template <typename IdxT>
-__device__ __forceinline__ int wg_partition(uint32_t* arr, IdxT* Lb, IdxT* Rb, int f, int l, int tid, int* s_wl, int* s_wr, int* bc) {
-    const int lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {   // __move_median_to_first(first, first + 1, mid, last - 1)
-        const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
-        const uint32_t xa = arr[A], xb = arr[Bm], xc = arr[Cc], xf = arr[f];
-        const uint32_t a = xa >> 20, bq = xb >> 20, c = xc >> 20;
-        int t; uint32_t xt;
-        if (a > bq) { if (bq > c) { t = Bm; xt = xb; } else if (a > c) { t = Cc; xt = xc; } else { t = A; xt = xa; } }
-        else if (a > c) { t = A; xt = xa; }
-        else if (bq > c) { t = Cc; xt = xc; }
-        else { t = Bm; xt = xb; }
-        arr[f] = xt; arr[t] = xf;
-        bc[0] = (int)(xt >> 20); bc[1] = t; bc[2] = (int)xf;
-    }
-    __syncthreads();
-    const uint32_t pv = (uint32_t)bc[0];
-    const int tpos = bc[1];
-    const uint32_t tval = (uint32_t)bc[2] >> 20;                  // the element now at position t (the old front)
-    // each wavefront owns a contiguous share of [f+1, l) and walks it in coalesced chunks, U chunks of loads in flight
-    constexpr int U = 8;
-    const int len = l - (f + 1), qlen = (len + SORT_NW - 1) / SORT_NW;
-    const int q0 = f + 1 + min(len, wave * qlen), q1 = f + 1 + min(len, wave * qlen + qlen);
-    int cl = 0, cr = 0;
-    for (int base = q0; base < q1; base += 64 * U) {
-        uint32_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) v[u] = arr[min(base + 64 * u + lane, q1 - 1)];          // unconditional loads: all U in flight
-#pragma unroll
-        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : v[u] >> 20) : 0xffffffffu; }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const bool in = base + 64 * u + lane < q1;
-            cl += __popcll(__ballot(in && !(v[u] > pv)));
-            cr += __popcll(__ballot(in && !(pv > v[u])));
-        }
-    }
-    if (lane == 0) { s_wl[wave] = cl; s_wr[wave] = cr; }
-    __syncthreads();
-    int totL = 0, totR = 0, wl = f + 1, ra = 0;
-    for (int q = 0; q < SORT_NW; q++) { totL += s_wl[q]; totR += s_wr[q]; if (q < wave) { wl += s_wl[q]; ra += s_wr[q]; } }
-    for (int base = q0; base < q1; base += 64 * U) {             // one pass writes both stop lists; R is descending: slot = totR - 1 - ascending rank
-        uint32_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) v[u] = arr[min(base + 64 * u + lane, q1 - 1)];          // unconditional loads: all U in flight
-#pragma unroll
-        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : v[u] >> 20) : 0xffffffffu; }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = base + 64 * u + lane;
-            const bool isL = i < q1 && !(v[u] > pv), isR = i < q1 && !(pv > v[u]);
-            const unsigned long long mkL = __ballot(isL), mkR = __ballot(isR);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (isL) Lb[wl + __popcll(mkL & below)] = (IdxT)i;
-            if (isR) Rb[f + 1 + (totR - 1 - (ra + __popcll(mkR & below)))] = (IdxT)i;
-            wl += __popcll(mkL); ra += __popcll(mkR);
-        }
-    }
-    if (tid == 0) bc[3] = 0;
-    __syncthreads();
-    const int kmax = min(totL, totR);
-    int good = 0;
-    constexpr int PU = 4;                                         // pairs in flight per thread (two dependent round trips each)
-    for (int k0 = tid; k0 < kmax; k0 += SORT_NT * PU) {
-        int Lk[PU], Rk[PU];
-        uint32_t xl[PU], xr[PU];
-#pragma unroll
-        for (int u = 0; u < PU; u++) { const int k = min(k0 + SORT_NT * u, kmax - 1); Lk[u] = (int)Lb[f + 1 + k]; Rk[u] = (int)Rb[f + 1 + k]; }
-#pragma unroll
-        for (int u = 0; u < PU; u++) if (k0 + SORT_NT * u >= kmax) { Lk[u] = 1; Rk[u] = 0; }
-#pragma unroll
-        for (int u = 0; u < PU; u++) { xl[u] = arr[max(Lk[u], f)]; xr[u] = arr[max(Rk[u], f)]; }      // unconditional: all loads in flight
-#pragma unroll
-        for (int u = 0; u < PU; u++) if (Lk[u] < Rk[u]) { arr[Lk[u]] = xr[u]; arr[Rk[u]] = xl[u]; good++; }
-    }
-    for (int o = 32; o >= 1; o >>= 1) good += __shfl_xor(good, o, 64);
-    if (lane == 0 && good) atomicAdd(&bc[3], good);
-    __syncthreads();
-    const int m = bc[3];                                          // the swapped pairs are a prefix of the pair list
-    int cut = 0x7fffffff;
-    if (m < totL) cut = min(cut, (int)Lb[f + 1 + m]);
-    if (m > 0) cut = min(cut, (int)Rb[f + 1 + m - 1]);
-    __syncthreads();
-    return cut;
-}
-
-// The same partition for ranges in GLOBAL memory, with less traffic: wavefront w writes the stops of its own share [q0_w, q1_w) of the range into Lb / Rb
-// at the share's own positions, as 16-bit offsets from q0_w, in ONE pass over the keys.  There is no counting pass: the k-th stop of the left scan
-// (ascending) and of the right scan (descending) are found through the per-wavefront counts.  Needs shares of < 65536 elements.
-__device__ __forceinline__ int wg_partition_rel(uint32_t* arr, uint16_t* Lb, uint16_t* Rb, int f, int l, int tid, int* s_wl, int* s_wr, int* bc) {
-    const int lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {   // __move_median_to_first(first, first + 1, mid, last - 1)
-        const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
-        const uint32_t xa = arr[A], xb = arr[Bm], xc = arr[Cc], xf = arr[f];
-        const uint32_t a = xa >> 20, bq = xb >> 20, c = xc >> 20;
-        int t; uint32_t xt;
-        if (a > bq) { if (bq > c) { t = Bm; xt = xb; } else if (a > c) { t = Cc; xt = xc; } else { t = A; xt = xa; } }
-        else if (a > c) { t = A; xt = xa; }
-        else if (bq > c) { t = Cc; xt = xc; }
-        else { t = Bm; xt = xb; }
-        arr[f] = xt; arr[t] = xf;
-        bc[0] = (int)(xt >> 20); bc[1] = t; bc[2] = (int)xf;
-    }
-    __syncthreads();
-    const uint32_t pv = (uint32_t)bc[0];
-    const int tpos = bc[1];
-    const uint32_t tval = (uint32_t)bc[2] >> 20;                  // the element now at position t (the old front)
-    constexpr int U = 8;
-    const int len = l - (f + 1), qlen = (len + SORT_NW - 1) / SORT_NW;
-    const int q0 = f + 1 + min(len, wave * qlen), q1 = f + 1 + min(len, wave * qlen + qlen);
-    int cl = 0, cr = 0;
-    for (int base = q0; base < q1; base += 64 * U) {
-        uint32_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) v[u] = arr[min(base + 64 * u + lane, q1 - 1)];          // unconditional loads: all U in flight
-#pragma unroll
-        for (int u = 0; u < U; u++) { const int i = base + 64 * u + lane; v[u] = i < q1 ? (i == tpos ? tval : v[u] >> 20) : 0xffffffffu; }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = base + 64 * u + lane;
-            const bool isL = i < q1 && !(v[u] > pv), isR = i < q1 && !(pv > v[u]);
-            const unsigned long long mkL = __ballot(isL), mkR = __ballot(isR);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (isL) Lb[q0 + cl + __popcll(mkL & below)] = (uint16_t)(i - q0);
-            if (isR) Rb[q0 + cr + __popcll(mkR & below)] = (uint16_t)(i - q0);
-            cl += __popcll(mkL); cr += __popcll(mkR);
-        }
-    }
-    if (lane == 0) { s_wl[wave] = cl; s_wr[wave] = cr; }
-    if (tid == 0) bc[3] = 0;
-    __syncthreads();
-    int pl[SORT_NW + 1], sr[SORT_NW + 1], wq0[SORT_NW], wcr[SORT_NW];      // pl[w]: left stops before wavefront w; sr[w]: right stops behind it
-    pl[0] = 0;
-#pragma unroll
-    for (int q = 0; q < SORT_NW; q++) { pl[q + 1] = pl[q] + s_wl[q]; wcr[q] = s_wr[q]; wq0[q] = f + 1 + min(len, q * qlen); }
-    sr[SORT_NW - 1] = 0;
-#pragma unroll
-    for (int q = SORT_NW - 2; q >= 0; q--) sr[q] = sr[q + 1] + wcr[q + 1];
-    const int totL = pl[SORT_NW], totR = sr[0] + wcr[0];
-    auto Lat = [&](int k) {                                       // k-th stop of the left scan
-        int w = 0;
-#pragma unroll
-        for (int q = 1; q < SORT_NW; q++) w += k >= pl[q];
-        int b0 = wq0[0], p0 = pl[0];
-#pragma unroll
-        for (int q = 1; q < SORT_NW; q++) if (w == q) { b0 = wq0[q]; p0 = pl[q]; }
-        return b0 + (int)Lb[b0 + (k - p0)];
-    };
-    auto Rat = [&](int k) {                                       // k-th stop of the right scan (it walks downwards)
-        int c = 0;
-#pragma unroll
-        for (int q = 0; q < SORT_NW - 1; q++) c += k >= sr[q];
-        const int w = SORT_NW - 1 - c;
-        int b0 = wq0[0], s0 = sr[0], c0 = wcr[0];
-#pragma unroll
-        for (int q = 1; q < SORT_NW; q++) if (w == q) { b0 = wq0[q]; s0 = sr[q]; c0 = wcr[q]; }
-        return b0 + (int)Rb[b0 + (c0 - 1 - (k - s0))];
-    };
-    const int kmax = min(totL, totR);
-    int good = 0;
-    constexpr int PU = 4;                                         // pairs in flight per thread (two dependent round trips each)
-    for (int k0 = tid; k0 < kmax; k0 += SORT_NT * PU) {
-        int Lk[PU], Rk[PU];
-        uint32_t xl[PU], xr[PU];
-#pragma unroll
-        for (int u = 0; u < PU; u++) { const int k = min(k0 + SORT_NT * u, kmax - 1); Lk[u] = Lat(k); Rk[u] = Rat(k); }
-#pragma unroll
-        for (int u = 0; u < PU; u++) if (k0 + SORT_NT * u >= kmax) { Lk[u] = 1; Rk[u] = 0; }
-#pragma unroll
-        for (int u = 0; u < PU; u++) { xl[u] = arr[max(Lk[u], f)]; xr[u] = arr[max(Rk[u], f)]; }      // unconditional: all loads in flight
-#pragma unroll
-        for (int u = 0; u < PU; u++) if (Lk[u] < Rk[u]) { arr[Lk[u]] = xr[u]; arr[Rk[u]] = xl[u]; good++; }
-    }
-    for (int o = 32; o >= 1; o >>= 1) good += __shfl_xor(good, o, 64);
-    if (lane == 0 && good) atomicAdd(&bc[3], good);
-    __syncthreads();
-    const int m = bc[3];                                          // the swapped pairs are a prefix of the pair list
-    int cut = 0x7fffffff;
-    if (m < totL) cut = min(cut, Lat(m));
-    if (m > 0) cut = min(cut, Rat(m - 1));
-    __syncthreads();
-    return cut;
-}
-
-// ---- K3: the visiting order: descending 1024-bin order; ties per plan->tie_order ---------------------------------------------------
-// phase 0: the whole sort by one workgroup per frame (grid (1, B)).  phases 1 / 2 / 3 split it into three launches so that the LDS tier - the ranges of
-// <= SORT_STAGE elements are independent - runs on many workgroups per frame (grid (R, B): workgroup x takes ranges x, x + R, ...): a single frame (the
-// reference's one-camera operating point) then spends 0.3 instead of 4.9 ms there.  1: keys + global-memory tier, 2: LDS tier, 3: the two radix passes.
-__global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int tie_order, int phase) {
+__global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int rows_cap) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
-    __shared__ int wsum[SORT_NW];
-    __shared__ int s_ncur, s_nnext, s_nsmall, s_wl[SORT_NW], s_wr[SORT_NW], s_bc[4];
-    __shared__ int s_loc[2][2 * SORT_STAGE / SORT_SMALL + 8][3], s_nloc[2], s_wave[2 * SORT_STAGE / SORT_SMALL + 8][3], s_nwave;
-    __shared__ int s_stack[SORT_NW][48][3];
-    __shared__ short s_leaf[SORT_NW][SORT_SMALL / 16][3];
-    int* cnt = (int*)sort_lds;                                  // [32 * SORT_NT] radix counters (passes A / B)
+    __shared__ isort::Range s_init;
     const Plan& P = *plan;
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    const float* ang = (const float*)(F + P.off_ang);
+    const uint32_t* g2a = (const uint32_t*)(F + P.off_g2);
+    uint32_t* arr = (uint32_t*)(F + P.off_tmp);
+    unsigned long long* vb = (unsigned long long*)(F + P.off_valid);
+    Misc* misc = miscs + b;
+    const int w1 = P.w - 1, h1 = P.h - 1, n = w1 * h1, npix = P.w * P.h;
+    const double max_grad = misc->g2max ? sqrt(misc->g2max / 4.0) : -1.0;
+    const double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
+    const long long ts0 = __builtin_readcyclecounter();
+    for (int p0 = tid - lane; p0 < npix; p0 += SORT_T) {
+        const int pix = p0 + lane, y = pix / P.w, x = pix - y * P.w;
+        const bool in = pix < npix && x < w1 && y < h1;
+        bool valid = false;
+        if (in) {
+            const int bin = int(sqrt(g2a[pix] / 4.0) * bin_coef);
+            arr[pix - y] = ((uint32_t)(N_BINS - 1 - bin) << SORT_SHIFT) | (uint32_t)pix;
+            valid = ang[pix] != NOTDEF_F;
+        }
+        const unsigned long long m = __ballot(valid);
+        if (lane == 0) vb[p0 >> 6] = m;
+    }
+    if (tid == 0) s_init = isort::Range{0, n, isort::depth_limit(n)};
+    __threadfence_block();
+    __syncthreads();
+    isort::global_tier<SORT_SHIFT, SORT_T>(arr, &s_init, 1, SortLds::N, 64, (isort::Range*)(F + P.off_sortr), (isort::Block*)(F + P.off_sortb), isort::G_FMAX,
+                                           misc->sort_counts, sort_lds, rows_cap, &misc->status);
+    if (tid == 0) misc->t[5] = __builtin_readcyclecounter() - ts0;
+}
+
+__global__ __launch_bounds__(SORT_T) void lsd_sort_lds(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    extern __shared__ __align__(16) uint8_t sort_lds[];
+    const Plan& P = *plan;
+    const int b = blockIdx.x;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    Misc* misc = miscs + b;
+    const isort::Range* ranges = (const isort::Range*)(F + P.off_sortr);
+    const isort::Block* blocks = (const isort::Block*)(F + P.off_sortb);
+    const int nb = misc->sort_counts[1];
+    const long long ts0 = __builtin_readcyclecounter();
+    for (int k = blockIdx.y; k < nb; k += gridDim.y) {
+        const isort::Block K = blocks[k];
+        isort::lds_tier<SORT_SHIFT, SORT_T, SORT_E>((uint32_t*)(F + P.off_tmp), ranges + K.r0, K.nr, K.f, K.l, sort_lds, &misc->status);
+    }
+    if (threadIdx.x == 0 && blockIdx.y == 0) misc->t[6] = __builtin_readcyclecounter() - ts0;
+}
+
+__global__ __launch_bounds__(SORT_T) void lsd_sort_compact(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    __shared__ int s_cnt[SORT_T / 64];
+    const Plan& P = *plan;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    const uint32_t* arr = (const uint32_t*)(F + P.off_tmp);
+    const unsigned long long* vb = (const unsigned long long*)(F + P.off_valid);
+    uint32_t* ord = (uint32_t*)(F + P.off_ord);
+    uint32_t* ordr = (uint32_t*)(F + P.off_ordr);
+    float* pixw = (float*)(F + P.off_pix);
+    Misc* misc = miscs + b;
+    const int n = (P.w - 1) * (P.h - 1);
+    const long long ts0 = __builtin_readcyclecounter();
+    constexpr int NW = SORT_T / 64, U = 4;
+    const int seg = ((n + NW - 1) / NW + 63) & ~63, w0 = min(n, wave * seg), w1 = min(n, w0 + seg);
+    auto is_valid = [&](uint32_t e, bool in) { const uint32_t pix = e & 0xfffffu; return in && ((vb[pix >> 6] >> (pix & 63u)) & 1ull); };
+    int cnt = 0;
+    for (int i0 = w0; i0 < w1; i0 += 64 * U) {
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) e[u] = arr[min(i0 + 64 * u + lane, w1 - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) cnt += __popcll(__ballot(is_valid(e[u], i0 + 64 * u + lane < w1)));
+    }
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    int pos = 0, total = 0;
+    for (int q = 0; q < NW; q++) { if (q < wave) pos += s_cnt[q]; total += s_cnt[q]; }
+    for (int i0 = w0; i0 < w1; i0 += 64 * U) {
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) e[u] = arr[min(i0 + 64 * u + lane, w1 - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool v = is_valid(e[u], i0 + 64 * u + lane < w1);
+            const unsigned long long m = __ballot(v);
+            if (v) {
+                const uint32_t pix = e[u] & 0xfffffu, slot = (uint32_t)(pos + __popcll(m & ((1ull << lane) - 1ull)));
+                ord[slot] = pix; ordr[slot] = slot;
+                pixw[(size_t)pix * 4 + 3] = __uint_as_float(slot);     // the pixel's compact index: its `used` flag lives there
+            }
+            pos += __popcll(m);
+        }
+    }
+    if (tid == 0) { misc->n_ord = total; misc->t[7] = __builtin_readcyclecounter() - ts0; }
+}
+
+// tie_order 1 (raster order inside a bin; a selectable alternative to the library's order): a stable sort = two 5-bit LSD radix passes.  Every
+// wavefront owns a contiguous part of the array and walks it 64 elements at a time (coalesced); the rank of an element among the equal digits of its
+// chunk is a popcount over the match mask built from five ballots, the running (digit, wavefront) counters live in LDS.  Undefined pixels are dropped in
+// the first pass.
+constexpr int SORT_NT = 256, SORT_NW = SORT_NT / 64;
+__global__ __launch_bounds__(SORT_NT) void lsd_sort_raster(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    __shared__ int wsum[SORT_NW];
+    __shared__ int cnt[32 * SORT_NW];
+    const Plan& P = *plan;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
     const float* ang = (const float*)(F + P.off_ang);
     const uint32_t* g2a = (const uint32_t*)(F + P.off_g2);
     uint32_t* arr = (uint32_t*)(F + P.off_tmp);                 // bin << 20 | pixel, all (w-1)(h-1) gradient pixels
     uint32_t* ord = (uint32_t*)(F + P.off_ord);
     uint32_t* ordr = (uint32_t*)(F + P.off_ordr);
-    uint32_t* tmpA = (uint32_t*)(F + P.off_reg);                // pass A output (the range lists are dead by then)
+    uint32_t* tmpA = (uint32_t*)(F + P.off_reg);
     Misc* misc = miscs + b;
     const int w1 = P.w - 1, n = w1 * (P.h - 1);
     const double max_grad = misc->g2max ? sqrt(misc->g2max / 4.0) : -1.0;
     const double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
-    if (phase <= 1) {
-        for (int i = tid; i < n; i += SORT_NT) {
-            const int y = i / w1, x = i - y * w1, pix = y * P.w + x;
-            arr[i] = ((uint32_t)int(sqrt(g2a[pix] / 4.0) * bin_coef) << 20) | (uint32_t)pix;
-        }
-        __threadfence_block();
-        __syncthreads();
+    for (int i = tid; i < n; i += SORT_NT) {
+        const int y = i / w1, x = i - y * w1, pix = y * P.w + x;
+        arr[i] = ((uint32_t)int(sqrt(g2a[pix] / 4.0) * bin_coef) << 20) | (uint32_t)pix;
     }
-    long long ts0 = __builtin_readcyclecounter(), ts1 = ts0, ts2 = ts0;
-    const int cap = n / 17 + 16;
-    SortRange* staged = (SortRange*)(F + P.off_reg) + 2 * cap;
-    if (phase <= 1 && tid == 0) { s_nsmall = 0; }
-    if (tie_order == 0 && n > 16 && phase <= 1) {
-        SortRange* cur = (SortRange*)(F + P.off_reg);
-        SortRange* next = cur + cap;
-        if (tid == 0) { int lg = 0; for (int t = n; t > 1; t >>= 1) lg++; cur[0] = SortRange{0, n, 2 * lg}; s_ncur = 1; s_nnext = 0; s_nsmall = 0; }
-        __syncthreads();
-        // tier 1: ranges too large for LDS, partitioned in global memory by the whole workgroup, one recursion level per iteration
-        while (true) {
-            const int ncur = s_ncur;
-            if (ncur == 0) break;
-            for (int r = 0; r < ncur; r++) {
-                const SortRange R = cur[r];
-                if (R.l - R.f <= 16) continue;
-                if (R.l - R.f <= SORT_STAGE) { if (tid == 0) staged[atomicAdd(&s_nsmall, 1)] = R; continue; }
-                if (R.d == 0) { if (tid == 0) misc->status = 2; continue; }
-                const int cut = (R.l - R.f - 1 + SORT_NW - 1) / SORT_NW < 65536 ? wg_partition_rel(arr, (uint16_t*)ord, (uint16_t*)ordr, R.f, R.l, tid, s_wl, s_wr, s_bc)
-                                                                              : wg_partition<uint32_t>(arr, ord, ordr, R.f, R.l, tid, s_wl, s_wr, s_bc);
-                if (tid == 0) { const int k = atomicAdd(&s_nnext, 2); next[k] = SortRange{cut, R.l, R.d - 1}; next[k + 1] = SortRange{R.f, cut, R.d - 1}; }
-            }
-            __syncthreads();
-            if (tid == 0) { s_ncur = s_nnext; s_nnext = 0; }
-            SortRange* t = cur; cur = next; next = t;
-            __syncthreads();
-        }
-        ts1 = __builtin_readcyclecounter();
-    }
-    if (phase == 1) {
-        __syncthreads();
-        if (tid == 0) { misc->n_staged = s_nsmall; misc->t[5] = ts1 - ts0; }
-        return;
-    }
-    if (tie_order == 0 && n > 16 && phase != 3) {
-        // tier 2: a range of <= 16384 elements is staged in LDS once and its whole recursion finished there:
-        //   > SORT_SMALL: workgroup partitions;  <= SORT_SMALL: one wavefront per sub-range (ballot partitions);  <= 64: one LANE per sub-range.
-        uint32_t* sbuf = (uint32_t*)sort_lds;
-        uint16_t* Ls = (uint16_t*)(sbuf + SORT_STAGE);
-        uint16_t* Rs = Ls + SORT_STAGE;
-        __syncthreads();
-        const int nstaged = phase == 0 ? s_nsmall : misc->n_staged;
-        for (int sr = phase == 0 ? 0 : (int)blockIdx.x; sr < nstaged; sr += phase == 0 ? 1 : (int)gridDim.x) {
-            const SortRange R = staged[sr];
-            const int sz = R.l - R.f;
-            for (int i = tid; i < sz; i += SORT_NT) sbuf[i] = arr[R.f + i];
-            if (tid == 0) { s_loc[0][0][0] = 0; s_loc[0][0][1] = sz; s_loc[0][0][2] = R.d; s_nloc[0] = 1; s_nloc[1] = 0; s_nwave = 0; }
-            __syncthreads();
-            for (int lev = 0;; lev ^= 1) {
-                const int nc = s_nloc[lev];
-                if (nc == 0) break;
-                for (int r = 0; r < nc; r++) {
-                    const int f = s_loc[lev][r][0], l = s_loc[lev][r][1], d = s_loc[lev][r][2];
-                    if (l - f <= 16) continue;
-                    if (l - f <= SORT_SMALL) { if (tid == 0) { const int k = s_nwave++; s_wave[k][0] = f; s_wave[k][1] = l; s_wave[k][2] = d; } continue; }
-                    if (d == 0) { if (tid == 0) misc->status = 2; continue; }
-                    const int cut = wg_partition<uint16_t>(sbuf, Ls, Rs, f, l, tid, s_wl, s_wr, s_bc);
-                    if (tid == 0) {
-                        const int k = s_nloc[lev ^ 1]; s_nloc[lev ^ 1] = k + 2;
-                        s_loc[lev ^ 1][k][0] = cut; s_loc[lev ^ 1][k][1] = l; s_loc[lev ^ 1][k][2] = d - 1;
-                        s_loc[lev ^ 1][k + 1][0] = f; s_loc[lev ^ 1][k + 1][1] = cut; s_loc[lev ^ 1][k + 1][2] = d - 1;
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) s_nloc[lev] = 0;
-                __syncthreads();
-            }
-            const int nwave = s_nwave;
-            for (int r = wave; r < nwave; r += SORT_NW) {
-                int sp = 0;
-                if (lane == 0) { s_stack[wave][0][0] = s_wave[r][0]; s_stack[wave][0][1] = s_wave[r][1]; s_stack[wave][0][2] = s_wave[r][2]; }
-                sp = 1;
-                int nleaf = 0;                                    // sub-ranges of <= SORT_LEAF elements, finished below one per LANE
-                lds_sync();
-                while (sp > 0) {
-                    sp--;
-                    int f = s_stack[wave][sp][0], l = s_stack[wave][sp][1], d = s_stack[wave][sp][2];   // (plain LDS reads: a volatile cast turns them into FLAT loads, which also wait for every outstanding global access)
-                    while (l - f > 16) {
-                        if (l - f <= SORT_LEAF) { if (lane == 0) { s_leaf[wave][nleaf][0] = (short)f; s_leaf[wave][nleaf][1] = (short)l; s_leaf[wave][nleaf][2] = (short)d; } nleaf++; break; }
-                        if (d == 0) { if (lane == 0) misc->status = 2; break; }
-                        --d;
-                        const int cut = partition_step(sbuf, Ls, Rs, f, l, lane);
-                        if (sp < 47) { if (lane == 0) { s_stack[wave][sp][0] = cut; s_stack[wave][sp][1] = l; s_stack[wave][sp][2] = d; } sp++; }
-                        else if (lane == 0) misc->status = 2;
-                        lds_sync();
-                        l = cut;
-                    }
-                }
-                lds_sync();
-                // leaves: 64 at a time, every lane runs libstdc++'s sequential __introsort_loop on its own <= 64 elements (in LDS)
-                for (int l0 = 0; l0 < nleaf; l0 += 64) {
-                    if (l0 + lane < nleaf) {
-                        int stf[6], stl[6], std_[6], q = 0;
-                        stf[0] = s_leaf[wave][l0 + lane][0]; stl[0] = s_leaf[wave][l0 + lane][1]; std_[0] = s_leaf[wave][l0 + lane][2]; q = 1;
-                        while (q > 0) {
-                            q--;
-                            int f = stf[q], l = stl[q], d = std_[q];
-                            while (l - f > 16) {
-                                if (d == 0) { misc->status = 2; break; }
-                                --d;
-                                const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
-                                const uint32_t a = sbuf[A] >> 20, bq = sbuf[Bm] >> 20, c = sbuf[Cc] >> 20;
-                                int t;
-                                if (a > bq) { if (bq > c) t = Bm; else if (a > c) t = Cc; else t = A; }
-                                else if (a > c) t = A;
-                                else if (bq > c) t = Cc;
-                                else t = Bm;
-                                { const uint32_t x = sbuf[f]; sbuf[f] = sbuf[t]; sbuf[t] = x; }
-                                const uint32_t pv = sbuf[f] >> 20;
-                                int lo = f + 1, hi = l;
-                                while (true) {                    // __unguarded_partition
-                                    while ((sbuf[lo] >> 20) > pv) ++lo;
-                                    --hi;
-                                    while (pv > (sbuf[hi] >> 20)) --hi;
-                                    if (!(lo < hi)) break;
-                                    const uint32_t x = sbuf[lo]; sbuf[lo] = sbuf[hi]; sbuf[hi] = x;
-                                    ++lo;
-                                }
-                                if (q < 6) { stf[q] = lo; stl[q] = l; std_[q] = d; q++; } else misc->status = 2;
-                                l = lo;
-                            }
-                        }
-                    }
-                }
-                lds_sync();
-            }
-            __syncthreads();
-            for (int i = tid; i < sz; i += SORT_NT) arr[R.f + i] = sbuf[i];
-            __syncthreads();
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    ts2 = __builtin_readcyclecounter();
-    if (phase == 2) { if (tid == 0 && blockIdx.x == 0) misc->t[6] = ts2 - ts1; return; }
-    // __final_insertion_sort == stable sort of the current arrangement by descending bin: two 5-bit LSD radix passes.  Every wavefront owns
-    // a contiguous part of the array and walks it 64 elements at a time (coalesced); the rank of an element among the equal digits of its
-    // chunk is a popcount over the match mask built from five ballots, the running (digit, wavefront) counters live in LDS.  Order inside
-    // a bin = array order.  Undefined pixels took part in the partitions above; they are dropped in the first pass.
+    __threadfence_block();
+    __syncthreads();
+    const long long ts2 = __builtin_readcyclecounter();
     int* wcnt = cnt;                                          // [32][SORT_NW] counters, digit-major = output order
     auto radix_pass = [&](const uint32_t* in, int M, auto digit_of, auto keep, auto emit) -> int {
         const int seg = ((M + SORT_NW - 1) / SORT_NW + 63) & ~63, w0 = min(M, wave * seg), w1 = min(M, w0 + seg);
@@ -673,7 +383,7 @@ __global__ __launch_bounds__(SORT_NT) void lsd_sort(const Plan* __restrict__ pla
         [&](uint32_t e) { return (int)((e >> 25) & 31); },
         [&](uint32_t) { return true; },
         [&](uint32_t e, int i, int pos) { ord[pos] = e & 0xfffffu; ordr[pos] = (uint32_t)i; });
-    if (tid == 0) { misc->n_ord = N; if (phase == 0) { misc->t[5] = ts1 - ts0; misc->t[6] = ts2 - ts1; } misc->t[7] = __builtin_readcyclecounter() - ts2; }
+    if (tid == 0) { misc->n_ord = N; misc->t[7] = __builtin_readcyclecounter() - ts2; }
 }
 
 // ---- K4: the sequential detector, one wavefront per frame -----------------------------------------------------------
@@ -1474,7 +1184,7 @@ __global__ __launch_bounds__(64) void lsd_keylines(const Plan* __restrict__ plan
     };
     if (n <= LDS_SORT) body(key_l, idx_l);
     else body((float*)(F + P.off_tmp), (int*)(F + P.off_tmp) + MAX_SEGS);
-    if (lane == 0) { n_out[b] = nk; misc->n_kl = nk; }
+    if (lane == 0) { n_out[b] = misc->status ? -misc->status : nk; misc->n_kl = nk; }   // a frame whose workspace overflowed (1) or whose sort is not reproducible (2, 3) reports -status
 }
 
 // ---- K7: LBD (BinaryDescriptor::computeLBD + binaryConversion), one wavefront per kept line ----------------------------
@@ -1603,7 +1313,7 @@ struct planar_lsd {
     int stage_lines = 0;
     int pre_B = 0;
     int tie_order = 0;   // 0: libstdc++ std::sort order inside a gradient bin (what the reference library produces), 1: raster order
-    int sort_smem = 0;
+    int sort_smem_g = 0, sort_smem_l = 0, sort_rows = 0;
     // planar_lsd_set_profiling: HIP events around the launches of a recorded call; slots: preprocessing (two blurs, gradient, Sobel), lsd_sort, lsd_detect,
     // the rest (improve, accept, KeyLines, LBD)
     bool profiling = false;
@@ -1682,6 +1392,7 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     const size_t NPf = (size_t)width * height, NPs = (size_t)P.w * P.h;
     P.off_blur7 = carve(NPf); P.off_blur5 = carve(NPf); P.off_dx = carve(NPf * 2); P.off_dy = carve(NPf * 2);
     P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_pix = carve(NPs * 16); P.off_seed = carve(NPs * 8); P.off_ordr = carve(NPs * 4); P.off_gused = carve((NPs + 31) / 32 * 4 + 256); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
+    P.off_valid = carve((NPs + 63) / 64 * 8 + 8); P.off_sortr = carve((size_t)isort::G_FMAX * sizeof(isort::Range)); P.off_sortb = carve((size_t)isort::G_FMAX * sizeof(isort::Block));
     P.off_segs = carve((size_t)lsd::MAX_SEGS * sizeof(lsd::Seg)); P.off_kl = carve((size_t)lsd::MAX_SEGS * sizeof(planar_keyline));
     P.off_rects = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Rect)); P.off_res = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Seg));
     P.frame_bytes = off;
@@ -1719,9 +1430,14 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     if (e == hipSuccess) e = hipMemcpy(o->d_cx.p, cx.data(), cx.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_cy.p, cy.data(), cy.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_taps.p, taps, sizeof(taps), hipMemcpyHostToDevice);
-    o->sort_smem = std::max(32 * lsd::SORT_NW * 4, lsd::SORT_STAGE * 8);   // radix counters [32][SORT_NW] | staged range + the two stop lists
+    // LDS of the sort kernels: the global tier keeps two stop bitmaps + two rank arrays over the longest range (all (w-1)(h-1) pixels), the LDS tier a block
+    o->sort_rows = lsd::SortGl::rows_for((P.w - 1) * (P.h - 1));
+    o->sort_smem_g = lsd::SortGl::bytes(o->sort_rows);
+    o->sort_smem_l = lsd::SortLds::bytes;
+    if (o->sort_smem_g > 160 * 1024) { delete o; set_error("planar_lsd_create: image too large for the LDS-resident stop bitmaps of the sort"); return PLANAR_EINVAL; }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_detect, hipFuncAttributeMaxDynamicSharedMemorySize, o->detect_smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_sort, hipFuncAttributeMaxDynamicSharedMemorySize, o->sort_smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_sort_global, hipFuncAttributeMaxDynamicSharedMemorySize, o->sort_smem_g);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, o->sort_smem_l);
     if (e != hipSuccess) { delete o; set_error("planar_lsd_create: %s", hipGetErrorString(e)); return PLANAR_EDEVICE; }
     *out = o;
     return PLANAR_OK;
@@ -1755,13 +1471,11 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
     hipLaunchKernelGGL(lsd::lbd_sobel, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, dP, ws);
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[1], st);
-    if (o->tie_order != 0 || B > 256)   // a large batch fills the device with one workgroup per frame: one launch (the split measures 3 % slower at B = 1024)
-        hipLaunchKernelGGL(lsd::lsd_sort, dim3(1, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 0);
-    else {   // three launches: the LDS tier of a frame spreads over R workgroups (ranges are independent)
-        const int R = B <= 16 ? 128 : 16;
-        hipLaunchKernelGGL(lsd::lsd_sort, dim3(1, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 1);
-        hipLaunchKernelGGL(lsd::lsd_sort, dim3(R, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 2);
-        hipLaunchKernelGGL(lsd::lsd_sort, dim3(1, B), dim3(lsd::SORT_NT), o->sort_smem, st, dP, ws, dm, o->tie_order, 3);
+    if (o->tie_order != 0) hipLaunchKernelGGL(lsd::lsd_sort_raster, dim3(B), dim3(lsd::SORT_NT), 0, st, dP, ws, dm);
+    else {
+        hipLaunchKernelGGL(lsd::lsd_sort_global, dim3(B), dim3(lsd::SORT_T), o->sort_smem_g, st, dP, ws, dm, o->sort_rows);
+        hipLaunchKernelGGL(lsd::lsd_sort_lds, dim3(B, lsd::SORT_R), dim3(lsd::SORT_T), o->sort_smem_l, st, dP, ws, dm);
+        hipLaunchKernelGGL(lsd::lsd_sort_compact, dim3(B), dim3(lsd::SORT_T), 0, st, dP, ws, dm);
     }
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[2], st);
     PLANAR_HIP_CHECK(hipGetLastError());
@@ -1847,6 +1561,8 @@ int planar_lsd_extract(planar_lsd* o, const uint8_t* gray, int B, int pitch, int
     PLANAR_HIP_CHECK(hipMemcpyAsync(line_eq, o->d_eq.p, n * 24, hipMemcpyDeviceToHost, st));
     PLANAR_HIP_CHECK(hipMemcpyAsync(n_lines, o->d_n.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+    for (int b = 0; b < B; b++)
+        if (n_lines[b] < 0) { set_error("planar_lsd_extract: frame %d: %s", b, n_lines[b] == -1 ? "more regions / segments than the workspace holds" : "the std::sort order of the gradient pixels is not reproducible (introsort depth limit / sort workspace)"); return PLANAR_ECAPACITY; }
     return PLANAR_OK;
 }
 
@@ -1876,7 +1592,7 @@ int planar_lsd_read_stage(planar_lsd* o, int frame, int stage, void* out, int64_
             long long* o64 = (long long*)out;
             for (int i = 0; i < 5; i++) o64[i] = m.t[i];
             o64[5] = m.n_ord; o64[6] = m.n_grown_px;
-            if (out_bytes >= 80) { o64[7] = m.t[5]; o64[8] = m.t[6]; o64[9] = m.t[7]; }   // lsd_sort: workgroup tier, LDS tier, radix passes
+            if (out_bytes >= 80) { o64[7] = m.t[5]; o64[8] = m.t[6]; o64[9] = m.t[7]; }   // sort: keys + global tier, LDS tier (workgroup y = 0), compaction
             return PLANAR_OK;
         }
         default: set_error("planar_lsd_read_stage: unknown stage"); return PLANAR_EINVAL;

@@ -21,6 +21,7 @@
 //                 chains (lane t owns accumulator t, all lanes walk the points together), eigen33 in float.
 //   F  compaction of the kept planes into the output arrays.
 #include "common.h"
+#include "isort.h"
 
 #include <algorithm>
 #include <cmath>
@@ -31,7 +32,6 @@ namespace planepost {
 constexpr int NT = 512;
 constexpr int MAXP = 128;                 // planar_peac_max_planes()
 constexpr int NRNG = 32768;               // sampler values kept (a refit that needs more reports PLANAR_ECAPACITY)
-constexpr double FIX_SCALE = 68719476736.0;   // 2^36: the voxel sums are fixed point, exact for every float of magnitude 2^-13 .. 2^7 m
 constexpr int VOX_BIAS = 8192;            // voxel coordinates floor(x / leaf) are kept in 14 bits each
 constexpr unsigned long long EMPTY = ~0ull;
 
@@ -39,7 +39,7 @@ struct Geo {
     int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (frame workspace); mini: entries of a wavefront's tile table (LDS)
     float fx, fy, cx, cy, factor, leaf;
     double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
-    size_t ws_stride, off_cnt, off_sum, off_cent, off_key;
+    size_t ws_stride, off_cnt, off_cent, off_key, off_rank, off_vstart, off_pl, off_init, off_meta, off_ranges, off_blocks, off_items;
 };
 
 struct Pt { float x, y, z; };
@@ -298,25 +298,41 @@ __device__ __forceinline__ void bitonic(unsigned long long* a, int n2) {
         }
 }
 
-__global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
-                                                          const int* __restrict__ labels_all, const double* __restrict__ planes_all, int planes_stride,
-                                                          const int* __restrict__ n_planes, const int* __restrict__ rng, unsigned char* ws_all, int* n_out,
-                                                          float* coef_out, int* src_out, int* off_out, float* pts_out, int* status, int* state_out,
-                                                          int* nvox_out, int* info_out, long long* timing) {
-    extern __shared__ unsigned long long s_list[];        // the wavefronts' tile tables (B); then the list of occupied slots (C, D: max_points keys); then the refit's shuffle array (E, u16)
-    __shared__ int s_first[MAXP], s_last[MAXP], s_state[MAXP], s_k[MAXP], s_o[MAXP + 1];
-    __shared__ float s_coef[MAXP][4];
-    __shared__ int s_n, s_err, s_kept;
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+// Frame::ComputePlanes head, five launches per batch (one workgroup per frame unless noted):
+//   plane_voxels_kernel   the occupied voxels of every plane (key table + per-voxel point counts), sorted = PCL's output order; the start of every voxel in the
+//                         frame's item array; one sort range per plane
+//   plane_items_kernel    the item array: for every plane its member pixels in RASTER order (the order Frame.cc:655-668 pushes them into the cloud), each as
+//                         (voxel << 19 | pixel): a stable partition of the label image by plane (ballot ranks per 64-pixel row, per-wavefront counters)
+//   plane_sort_global / plane_sort_lds   (isort.h) every plane's items arranged as std::sort(index_vector) of VoxelGrid::applyFilter leaves them: sorted by
+//                         voxel, points of one voxel in libstdc++'s introsort order - the order PCL adds them up in
+//   plane_tail_kernel     thread per voxel: the FLOAT sums in that order, centroid = sum / (float)count; then the distance gate and the RANSAC refit (one
+//                         wavefront per plane) and the compaction of the kept planes
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+constexpr int PS_T = 1024, PS_E = 23, PS_SHIFT = 19, PS_R = 24;
+using PsLds = isort::LdsLayout<PS_T, PS_E>;
+using PsGl = isort::GlobalLayout<PS_T>;
+constexpr int ERR_SORT = 5;
+
+struct Meta { int n_init, counts[2], err, M, npl, sort_status, pad; };
+
+__global__ __launch_bounds__(NT) void plane_voxels_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
+                                                          const int* __restrict__ labels_all, const int* __restrict__ n_planes, unsigned char* ws_all, long long* timing) {
+    extern __shared__ unsigned long long s_list[];        // the wavefronts' tile tables (B); then the list of occupied slots (C, D: max_points keys)
+    __shared__ int s_first[MAXP], s_last[MAXP];
+    __shared__ int s_n, s_err, s_kept, s_scan[NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int HW = G.W * G.H;
     const unsigned short* D = depth_all + (size_t)b * frame_stride_px;
     const int* lab = labels_all + (size_t)b * HW;
-    const double* planes = planes_all + (size_t)b * planes_stride * 8;
     unsigned char* ws = ws_all + (size_t)b * G.ws_stride;
     unsigned* tcnt = (unsigned*)(ws + G.off_cnt);
-    unsigned long long* tsum = (unsigned long long*)(ws + G.off_sum);
-    float* cent = (float*)(ws + G.off_cent);
     unsigned long long* gkey = (unsigned long long*)(ws + G.off_key);   // the frame's key table: global memory (L2), touched once per (tile, voxel)
+    unsigned short* srank = (unsigned short*)(ws + G.off_rank);
+    int* vstart = (int*)(ws + G.off_vstart);
+    int* pfl = (int*)(ws + G.off_pl);
+    isort::Range* init = (isort::Range*)(ws + G.off_init);
+    Meta* meta = (Meta*)(ws + G.off_meta);
     int npl = n_planes[b];
     if (npl > MAXP) npl = MAXP;
     if (npl > G.pl_stride) npl = G.pl_stride;
@@ -326,66 +342,54 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
     auto mark = [&](int q) { if (tmark && tid == 0) tmark[q] = wall_clock64(); };
     mark(0);
 
-    for (int i = tid; i < TC; i += NT) { gkey[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TC + i] = 0ull; tsum[2 * TC + i] = 0ull; }
-    for (int i = tid; i < MAXP; i += NT) { s_first[i] = 0; s_last[i] = 0; s_state[i] = 0; }
+    for (int i = tid; i < TC; i += NT) { gkey[i] = EMPTY; tcnt[i] = 0u; }
+    for (int i = tid; i < MAXP; i += NT) { s_first[i] = 0; s_last[i] = 0; }
     if (tid == 0) { s_n = 0; s_err = 0; s_kept = 0; }
     __threadfence();
     __syncthreads();
 
     mark(1);
-    // ---- B: voxel sums.  A wavefront takes a tile of 64 columns x ROWS rows and every lane walks DOWN its column: the 64 labels / depths of a row are
-    //      one coalesced read, and a lane sums its run of equal (plane, voxel) in registers.  A finished run goes to the wavefront's own 128-entry LDS
-    //      table (CAS on the key, four LDS atomics); at the end of the tile the table's entries - one per voxel the tile touched - go to the frame's
-    //      tables: a CAS on the frame's key table (global memory, L2) for the slot, then four fire-and-forget global atomics on the slot's count and sums.  A run that finds the
-    //      small table crowded goes to the frame's tables directly.  All sums are integers: the path taken does not change the result. ----
+    // ---- B: the voxels and their point counts.  A wavefront takes a tile of 64 columns x ROWS rows and every lane walks DOWN its column: the 64 labels / depths
+    //      of a row are one coalesced read, and a lane counts its run of equal (plane, voxel) in a register.  A finished run goes to the wavefront's own 128-entry
+    //      LDS table (CAS on the key, one LDS atomic); at the end of the tile the table's entries - one per voxel the tile touched - go to the frame's table: a CAS
+    //      on the frame's key table (global memory, L2) for the slot, then one fire-and-forget global atomic on the slot's count.  A run that finds the small table
+    //      crowded goes to the frame's table directly. ----
     {
         constexpr int ROWS = 60, UNR = 4;
         const int MINI = G.mini;                                    // 128 entries per wavefront
-        unsigned long long* mk = s_list + (size_t)wave * 4 * MINI;           // keys, then the three sums
-        unsigned long long* ms0 = mk + MINI; unsigned long long* ms1 = ms0 + MINI; unsigned long long* ms2 = ms1 + MINI;
-        unsigned* mc = (unsigned*)(s_list + (size_t)(NT / 64) * 4 * MINI) + (size_t)wave * MINI;
+        unsigned long long* mk = s_list + (size_t)wave * MINI;
+        unsigned* mc = (unsigned*)(s_list + (size_t)(NT / 64) * MINI) + (size_t)wave * MINI;
         auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-        auto to_frame = [&](unsigned long long key, unsigned cnt, unsigned long long sx, unsigned long long sy, unsigned long long sz) {
+        auto to_frame = [&](unsigned long long key, unsigned cnt) {
             unsigned h = hash64(key) & (unsigned)(TC - 1);
             for (int probe = 0; probe < TC; probe++) {
                 const unsigned long long k = atomicCAS(&gkey[h], EMPTY, key);
                 if (k == EMPTY) { if (atomicAdd(&s_n, 1) >= G.max_points) s_err = 3; }
-                if (k == EMPTY || k == key) {
-                    atomicAdd(&tcnt[h], cnt);
-                    atomicAdd(&tsum[h], sx); atomicAdd(&tsum[TC + h], sy); atomicAdd(&tsum[2 * TC + h], sz);
-                    return;
-                }
+                if (k == EMPTY || k == key) { atomicAdd(&tcnt[h], cnt); return; }
                 h = (h + 1) & (unsigned)(TC - 1);
             }
             s_err = 3;
         };
-        long long c_rows = 0, c_end = 0, c_park = 0, n_park = 0;
         const int strips = (G.W + 63) / 64, tiles = strips * ((G.H + ROWS - 1) / ROWS);
         for (int tile = wave; tile < tiles; tile += NT / 64) {
             const int px = (tile % strips) * 64 + lane, y0 = (tile / strips) * ROWS, y1 = min(y0 + ROWS, G.H);
             const bool col = px < G.W;
-            for (int e = lane; e < MINI; e += 64) { mk[e] = EMPTY; mc[e] = 0u; ms0[e] = 0ull; ms1[e] = 0ull; ms2[e] = 0ull; }
+            for (int e = lane; e < MINI; e += 64) { mk[e] = EMPTY; mc[e] = 0u; }
             wfence();
-            // the run being summed (cur) and the last finished one (pend).  Finished runs are parked: the insertion code below runs - for every lane
+            // the run being counted (cur) and the last finished one (pend).  Finished runs are parked: the insertion code below runs - for every lane
             // that has something parked, together - only when some lane finishes a second run, i.e. every ten rows or so instead of at every row
             unsigned long long cur = EMPTY, pend = EMPTY;
             unsigned cnt = 0, pcnt = 0;
-            double sx = 0, sy = 0, sz = 0;               // a run's sums: doubles (a run is at most ROWS floats of one voxel), fixed point from there on
-            long long psx = 0, psy = 0, psz = 0;
             auto flush_parked = [&]() {
                 if (pend != EMPTY) {
                     unsigned h = (hash64(pend) >> 7) & (unsigned)(MINI - 1);
                     bool done = false;
                     for (int probe = 0; probe < 8 && !done; probe++) {
                         const unsigned long long k = atomicCAS(&mk[h], EMPTY, pend);
-                        if (k == EMPTY || k == pend) {
-                            atomicAdd(&mc[h], pcnt);
-                            atomicAdd(&ms0[h], (unsigned long long)psx); atomicAdd(&ms1[h], (unsigned long long)psy); atomicAdd(&ms2[h], (unsigned long long)psz);
-                            done = true;
-                        }
+                        if (k == EMPTY || k == pend) { atomicAdd(&mc[h], pcnt); done = true; }
                         h = (h + 1) & (unsigned)(MINI - 1);
                     }
-                    if (!done) to_frame(pend, pcnt, (unsigned long long)psx, (unsigned long long)psy, (unsigned long long)psz);
+                    if (!done) to_frame(pend, pcnt);
                     pend = EMPTY;
                 }
             };
@@ -401,51 +405,42 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
                     l[q] = (col && yb + q < y1) ? lv : -1;
                 }
             };
-            const long long t_r0 = clock64();
             load(y0, l4, d4);
             for (int yb = y0; yb < y1; yb += UNR) {
-                load(yb + UNR, ln, dn);                       // the next rows are in flight while these are summed
+                load(yb + UNR, ln, dn);                       // the next rows are in flight while these are counted
 #pragma unroll
                 for (int q = 0; q < UNR; q++) {
                     const int l = l4[q];
                     const bool on = l >= 0 && l < npl;
-                    Pt p = {0.f, 0.f, 0.f};
                     unsigned long long key = cur;
                     bool fin = false;
+                    const Pt p = cam_point(G, d4[q], px, yb + q);
                     if (on) {
-                        p = cam_point(G, d4[q], px, yb + q);
                         if (!voxel_key(p.x, p.y, p.z, inv, (unsigned)l, key)) { s_err = 3; key = cur; }
                         fin = key != cur;
                     }
-                    if (__ballot(fin && cur != EMPTY && pend != EMPTY) != 0ull) { const long long t_p = clock64(); flush_parked(); c_park += clock64() - t_p; n_park++; }
+                    if (__ballot(fin && cur != EMPTY && pend != EMPTY) != 0ull) flush_parked();
                     if (fin) {
-                        if (cur != EMPTY) { pend = cur; pcnt = cnt; psx = __double2ll_rn(sx * FIX_SCALE); psy = __double2ll_rn(sy * FIX_SCALE); psz = __double2ll_rn(sz * FIX_SCALE); }
-                        cur = key; cnt = 0; sx = sy = sz = 0;
+                        if (cur != EMPTY) { pend = cur; pcnt = cnt; }
+                        cur = key; cnt = 0;
                     }
-                    if (on && key == cur && cur != EMPTY) {
-                        cnt++;
-                        sx += (double)p.x; sy += (double)p.y; sz += (double)p.z;
-                    }
+                    if (on && key == cur && cur != EMPTY) cnt++;
                 }
 #pragma unroll
                 for (int q = 0; q < UNR; q++) { l4[q] = ln[q]; d4[q] = dn[q]; }
             }
-            const long long t_r1 = clock64();
-            c_rows += t_r1 - t_r0;
             flush_parked();
-            pend = cur; pcnt = cnt; psx = __double2ll_rn(sx * FIX_SCALE); psy = __double2ll_rn(sy * FIX_SCALE); psz = __double2ll_rn(sz * FIX_SCALE);
+            pend = cur; pcnt = cnt;
             flush_parked();
             wfence();
             for (int e = lane; e < MINI; e += 64)
-                if (mk[e] != EMPTY) to_frame(mk[e], mc[e], ms0[e], ms1[e], ms2[e]);
+                if (mk[e] != EMPTY) to_frame(mk[e], mc[e]);
             wfence();
-            c_end += clock64() - t_r1;
         }
-        if (tmark && tid == 0) { tmark[8] = c_rows; tmark[9] = c_end; tmark[10] = n_park; tmark[11] = c_park; }
     }
     __threadfence();
     __syncthreads();
-    int err = s_err;
+    const int err = s_err;
     const int M = err ? 0 : s_n;
     mark(2);
 
@@ -462,19 +457,202 @@ __global__ __launch_bounds__(NT) void plane_clouds_kernel(Geo G, const unsigned 
         }
         __syncthreads();
         bitonic(s_list, n2);
-        // ---- D: centroids, per-plane ranges ----
-        for (int r = tid; r < M; r += NT) {
+        // ---- D: every voxel's place in the sorted order (its sort key), per-plane voxel ranges, the start of every voxel in the frame's item array ----
+        const int per = (M + NT - 1) / NT, r0 = min(M, tid * per), r1 = min(M, r0 + per);
+        int mine = 0;
+        for (int r = r0; r < r1; r++) {
             const unsigned long long e = s_list[r];
             const int s = (int)(e & 0x3fffull), p = (int)(e >> 56);
-            const double cnt = (double)__hip_atomic_load(&tcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const long long S = (long long)__hip_atomic_load(&tsum[c * TC + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cent[(size_t)r * 3 + c] = (float)(((double)S * (1.0 / FIX_SCALE)) / cnt);
-            }
+            srank[s] = (unsigned short)r;
+            mine += (int)__hip_atomic_load(&tcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (r == 0 || (int)(s_list[r - 1] >> 56) != p) s_first[p] = r;
             if (r == M - 1 || (int)(s_list[r + 1] >> 56) != p) s_last[p] = r + 1;
         }
+        int total;
+        int run = isort::block_exscan<NT, int>(mine, s_scan, &total);
+        for (int r = r0; r < r1; r++) {
+            vstart[r] = run;
+            run += (int)__hip_atomic_load(&tcnt[(int)(s_list[r] & 0x3fffull)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) vstart[M] = total;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int p = tid; p < MAXP; p += NT) { pfl[p] = s_first[p]; pfl[MAXP + p] = s_last[p]; }
+    if (tid == 0) {
+        int k = 0;
+        for (int p = 0; p < npl && !err; p++) {
+            if (s_last[p] <= s_first[p]) continue;
+            const int f = vstart[s_first[p]], l = vstart[s_last[p]];
+            init[k++] = isort::Range{f, l, isort::depth_limit(l - f)};
+        }
+        meta->n_init = k; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = npl; meta->sort_status = 0;
+    }
+    mark(3);
+}
+
+// The item array.  Workgroup of PS_T threads per frame; wavefront w owns the pixels [w * S, (w + 1) * S) in raster order.
+__global__ __launch_bounds__(PS_T) void plane_items_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
+                                                           const int* __restrict__ labels_all, unsigned char* ws_all) {
+    constexpr int NW = PS_T / 64;
+    __shared__ unsigned s_cnt[NW][MAXP];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = G.W * G.H;
+    unsigned char* ws = ws_all + (size_t)b * G.ws_stride;
+    const Meta* meta = (const Meta*)(ws + G.off_meta);
+    if (meta->err || meta->n_init == 0) return;
+    const unsigned short* D = depth_all + (size_t)b * frame_stride_px;
+    const int* lab = labels_all + (size_t)b * HW;
+    const unsigned long long* gkey = (const unsigned long long*)(ws + G.off_key);
+    const unsigned short* srank = (const unsigned short*)(ws + G.off_rank);
+    const int* vstart = (const int*)(ws + G.off_vstart);
+    const int* pfl = (const int*)(ws + G.off_pl);
+    uint32_t* items = (uint32_t*)(ws + G.off_items);
+    const int npl = meta->npl, TC = G.tcap;
+    const float inv = 1.0f / G.leaf;
+    for (int i = tid; i < NW * MAXP; i += PS_T) (&s_cnt[0][0])[i] = 0u;
+    __syncthreads();
+    const int S = ((HW + NW - 1) / NW + 63) & ~63, w0 = min(HW, wave * S), w1 = min(HW, w0 + S);
+    auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    constexpr int U = 4;
+    for (int i0 = w0; i0 < w1; i0 += 64 * U) {            // pass 1: members per (wavefront, plane)
+        int l[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) l[u] = lab[min(i0 + 64 * u + lane, w1 - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool on = i0 + 64 * u + lane < w1 && l[u] >= 0 && l[u] < npl;
+            unsigned long long rem = __ballot(on);
+            while (rem) {
+                const int L = __builtin_amdgcn_readlane(l[u], __builtin_ctzll(rem));
+                const unsigned long long m = __ballot(on && l[u] == L);
+                if (lane == 0) s_cnt[wave][L] += (unsigned)__popcll(m);
+                rem &= ~m;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < npl) {                                       // exclusive scan over the wavefronts, from the plane's start in the item array
+        const int first = pfl[tid], last = pfl[MAXP + tid];
+        unsigned run = last > first ? (unsigned)vstart[first] : 0u;
+        for (int w = 0; w < NW; w++) { const unsigned t = s_cnt[w][tid]; s_cnt[w][tid] = run; run += t; }
+    }
+    __syncthreads();
+    for (int i0 = w0; i0 < w1; i0 += 64 * U) {            // pass 2: every member pixel's item at its rank among the plane's pixels
+        int l[U];
+        unsigned short d[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int pix = min(i0 + 64 * u + lane, w1 - 1), py = pix / G.W, px = pix - py * G.W;
+            l[u] = lab[pix];
+            d[u] = D[(size_t)py * pitch_px + px];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int pix = i0 + 64 * u + lane, pc = min(pix, w1 - 1), py = pc / G.W, px = pc - py * G.W;
+            const bool on = pix < w1 && l[u] >= 0 && l[u] < npl;
+            const Pt p = cam_point(G, d[u], px, py);
+            uint32_t item = 0;
+            if (on) {
+                unsigned long long key;
+                voxel_key(p.x, p.y, p.z, inv, (unsigned)l[u], key);
+                unsigned h = hash64(key) & (unsigned)(TC - 1);
+                for (int probe = 0; probe < TC && gkey[h] != key; probe++) h = (h + 1) & (unsigned)(TC - 1);
+                item = ((uint32_t)srank[h] << PS_SHIFT) | (uint32_t)pix;
+            }
+            unsigned long long rem = __ballot(on);
+            while (rem) {
+                const int L = __builtin_amdgcn_readlane(l[u], __builtin_ctzll(rem));
+                const bool mine = on && l[u] == L;
+                const unsigned long long m = __ballot(mine);
+                const unsigned base = s_cnt[wave][L];
+                wfence();
+                if (mine) items[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = item;
+                if (lane == 0) s_cnt[wave][L] = base + (unsigned)__popcll(m);
+                wfence();
+                rem &= ~m;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(PS_T) void plane_sort_global(Geo G, unsigned char* ws_all, int rows_cap) {
+    extern __shared__ __align__(16) uint8_t sort_lds[];
+    unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
+    Meta* meta = (Meta*)(ws + G.off_meta);
+    if (meta->err || meta->n_init == 0) return;
+    isort::global_tier<PS_SHIFT, PS_T>((uint32_t*)(ws + G.off_items), (const isort::Range*)(ws + G.off_init), meta->n_init, PsLds::N, 64, (isort::Range*)(ws + G.off_ranges),
+                                       (isort::Block*)(ws + G.off_blocks), isort::G_FMAX, meta->counts, sort_lds, rows_cap, &meta->sort_status);
+}
+
+__global__ __launch_bounds__(PS_T) void plane_sort_lds(Geo G, unsigned char* ws_all) {
+    extern __shared__ __align__(16) uint8_t sort_lds[];
+    unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
+    Meta* meta = (Meta*)(ws + G.off_meta);
+    if (meta->err) return;
+    const isort::Range* ranges = (const isort::Range*)(ws + G.off_ranges);
+    const isort::Block* blocks = (const isort::Block*)(ws + G.off_blocks);
+    const int nb = meta->counts[1];
+    for (int k = blockIdx.y; k < nb; k += gridDim.y) {
+        const isort::Block K = blocks[k];
+        isort::lds_tier<PS_SHIFT, PS_T, PS_E>((uint32_t*)(ws + G.off_items), ranges + K.r0, K.nr, K.f, K.l, sort_lds, &meta->sort_status);
+    }
+}
+
+// PlaneDetection::readDepthImage for one thread (no wave-level branch: callers are in divergent loops)
+__device__ __forceinline__ Pt cam_point_thread(const Geo& G, unsigned short d, int px, int py) {
+    const double z = (double)d * (double)G.factor;
+    const double nx = ((double)px - (double)G.cx) * z, ny = ((double)py - (double)G.cy) * z;
+    bool near_x, near_y;
+    double tx = mul_rcp(nx, G.rfx, near_x), ty = mul_rcp(ny, G.rfy, near_y);
+    if (near_x) tx = nx / (double)G.fx;
+    if (near_y) ty = ny / (double)G.fy;
+    return {(float)tx, (float)ty, (float)z};
+}
+
+__global__ __launch_bounds__(NT) void plane_tail_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
+                                                        const double* __restrict__ planes_all, int planes_stride, const int* __restrict__ rng, unsigned char* ws_all,
+                                                        int* n_out, float* coef_out, int* src_out, int* off_out, float* pts_out, int* status, int* state_out,
+                                                        int* nvox_out, int* info_out, long long* timing) {
+    extern __shared__ unsigned long long s_list[];        // the refit's shuffle array (u16 per voxel)
+    __shared__ int s_first[MAXP], s_last[MAXP], s_state[MAXP], s_k[MAXP], s_o[MAXP + 1];
+    __shared__ float s_coef[MAXP][4];
+    __shared__ int s_err, s_kept;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned short* D = depth_all + (size_t)b * frame_stride_px;
+    const double* planes = planes_all + (size_t)b * planes_stride * 8;
+    unsigned char* ws = ws_all + (size_t)b * G.ws_stride;
+    float* cent = (float*)(ws + G.off_cent);
+    const int* vstart = (const int*)(ws + G.off_vstart);
+    const int* pfl = (const int*)(ws + G.off_pl);
+    const uint32_t* items = (const uint32_t*)(ws + G.off_items);
+    const Meta* meta = (const Meta*)(ws + G.off_meta);
+    const int npl = meta->npl;
+    int err = meta->err ? meta->err : (meta->sort_status ? ERR_SORT : 0);
+    const int M = err ? 0 : meta->M;
+    long long* tmark = timing ? timing + (size_t)b * 16 : nullptr;
+    auto mark = [&](int q) { if (tmark && tid == 0) tmark[q] = wall_clock64(); };
+    for (int i = tid; i < MAXP; i += NT) { s_first[i] = pfl[i]; s_last[i] = pfl[MAXP + i]; s_state[i] = 0; }
+    if (tid == 0) { s_err = 0; s_kept = 0; }
+    // ---- the voxel centroids: a voxel's points added up as floats in the sorted order, then divided by the count (VoxelGrid::applyFilter) ----
+    for (int r = tid; r < M; r += NT) {
+        const int i0 = vstart[r], i1 = vstart[r + 1];
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        constexpr int U = 4;
+        for (int i = i0; i < i1; i += U) {
+            uint32_t it[U];
+            unsigned short d[U];
+            int px[U], py[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) it[u] = items[min(i + u, i1 - 1)];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int pix = (int)(it[u] & ((1u << PS_SHIFT) - 1u)); py[u] = pix / G.W; px[u] = pix - py[u] * G.W; d[u] = D[(size_t)py[u] * pitch_px + px[u]]; }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (i + u < i1) { const Pt p = cam_point_thread(G, d[u], px[u], py[u]); cx += p.x; cy += p.y; cz += p.z; }
+        }
+        const float cnt = (float)(i1 - i0);
+        cent[(size_t)r * 3] = cx / cnt; cent[(size_t)r * 3 + 1] = cy / cnt; cent[(size_t)r * 3 + 2] = cz / cnt;
     }
     __threadfence();
     __syncthreads();
@@ -597,15 +775,20 @@ __global__ void merge_gather_kernel(const double* __restrict__ T, const float* _
     }
 }
 
-// pcl::VoxelGrid of one free-standing cloud (the map-side merge): the same table / sort / centroid steps as plane_clouds_kernel, one workgroup
-__global__ __launch_bounds__(NT) void voxel_cloud_kernel(Geo G, const float* __restrict__ pts, int n, unsigned char* ws, float* out, int* n_out, int* status) {
+// pcl::VoxelGrid of one free-standing cloud (the map-side merge), workspace of frame 0: cloud_voxels_kernel (key table in LDS, voxel order, every point's item
+// voxel << 19 | index, in index order) -> plane_sort_global / plane_sort_lds (one range: the whole cloud) -> cloud_sums_kernel (the float sums in std::sort's order)
+__global__ __launch_bounds__(NT) void cloud_voxels_kernel(Geo G, const float* __restrict__ pts, int n, unsigned char* ws) {
     extern __shared__ unsigned long long s_list[];
-    __shared__ int s_n, s_err;
+    __shared__ int s_n, s_err, s_scan[NT / 64];
     const int tid = threadIdx.x, TC = G.tcap;
     unsigned* tcnt = (unsigned*)(ws + G.off_cnt);
-    unsigned long long* tsum = (unsigned long long*)(ws + G.off_sum);
+    unsigned short* srank = (unsigned short*)(ws + G.off_rank);
+    int* vstart = (int*)(ws + G.off_vstart);
+    uint32_t* items = (uint32_t*)(ws + G.off_items);
+    isort::Range* init = (isort::Range*)(ws + G.off_init);
+    Meta* meta = (Meta*)(ws + G.off_meta);
     const float inv = 1.0f / G.leaf;
-    for (int i = tid; i < TC; i += NT) { s_list[i] = EMPTY; tcnt[i] = 0u; tsum[i] = 0ull; tsum[TC + i] = 0ull; tsum[2 * TC + i] = 0ull; }
+    for (int i = tid; i < TC; i += NT) { s_list[i] = EMPTY; tcnt[i] = 0u; }
     if (tid == 0) { s_n = 0; s_err = 0; }
     __threadfence();
     __syncthreads();
@@ -618,14 +801,8 @@ __global__ __launch_bounds__(NT) void voxel_cloud_kernel(Geo G, const float* __r
         for (int probe = 0; probe < TC && !done; probe++) {
             const unsigned long long k = atomicCAS(&s_list[h], EMPTY, key);
             if (k == EMPTY) { if (atomicAdd(&s_n, 1) >= G.max_points) s_err = 3; }
-            if (k == EMPTY || k == key) {
-                atomicAdd(&tcnt[h], 1u);
-                atomicAdd(&tsum[h], (unsigned long long)__double2ll_rn((double)x * FIX_SCALE));
-                atomicAdd(&tsum[TC + h], (unsigned long long)__double2ll_rn((double)y * FIX_SCALE));
-                atomicAdd(&tsum[2 * TC + h], (unsigned long long)__double2ll_rn((double)z * FIX_SCALE));
-                done = true;
-            }
-            h = (h + 1) & (unsigned)(TC - 1);
+            if (k == EMPTY || k == key) { atomicAdd(&tcnt[h], 1u); items[i] = h; done = true; }
+            else h = (h + 1) & (unsigned)(TC - 1);
         }
         if (!done) s_err = 3;
     }
@@ -636,15 +813,39 @@ __global__ __launch_bounds__(NT) void voxel_cloud_kernel(Geo G, const float* __r
         for (int i = tid; i < TC; i += NT) { const unsigned long long k = s_list[i]; if (k != EMPTY) s_list[i] = (k << 14) | (unsigned long long)i; }
         __syncthreads();
         bitonic(s_list, TC);
-        for (int r = tid; r < M; r += NT) {
+        const int per = (M + NT - 1) / NT, r0 = min(M, tid * per), r1 = min(M, r0 + per);
+        int mine = 0;
+        for (int r = r0; r < r1; r++) {
             const int s = (int)(s_list[r] & 0x3fffull);
-            const double cnt = (double)__hip_atomic_load(&tcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const long long S = (long long)__hip_atomic_load(&tsum[c * TC + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                out[(size_t)r * 3 + c] = (float)(((double)S * (1.0 / FIX_SCALE)) / cnt);
-            }
+            srank[s] = (unsigned short)r;
+            mine += (int)__hip_atomic_load(&tcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        int total;
+        int run = isort::block_exscan<NT, int>(mine, s_scan, &total);
+        for (int r = r0; r < r1; r++) { vstart[r] = run; run += (int)__hip_atomic_load(&tcnt[(int)(s_list[r] & 0x3fffull)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (tid == 0) vstart[M] = total;
+        __threadfence();
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) items[i] = ((uint32_t)srank[items[i]] << PS_SHIFT) | (uint32_t)i;
+    }
+    if (tid == 0) {
+        init[0] = isort::Range{0, n, isort::depth_limit(n)};
+        meta->n_init = (!err && n > 0) ? 1 : 0; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = 1; meta->sort_status = 0;
+    }
+}
+
+__global__ __launch_bounds__(NT) void cloud_sums_kernel(Geo G, const float* __restrict__ pts, unsigned char* ws, float* out, int* n_out, int* status) {
+    const int tid = threadIdx.x;
+    const int* vstart = (const int*)(ws + G.off_vstart);
+    const uint32_t* items = (const uint32_t*)(ws + G.off_items);
+    const Meta* meta = (const Meta*)(ws + G.off_meta);
+    const int err = meta->err ? meta->err : (meta->sort_status ? ERR_SORT : 0), M = err ? 0 : meta->M;
+    for (int r = tid; r < M; r += NT) {
+        const int i0 = vstart[r], i1 = vstart[r + 1];
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        for (int i = i0; i < i1; i++) { const int j = (int)(items[i] & ((1u << PS_SHIFT) - 1u)); cx += pts[j * 3]; cy += pts[j * 3 + 1]; cz += pts[j * 3 + 2]; }
+        const float cnt = (float)(i1 - i0);
+        out[(size_t)r * 3] = cx / cnt; out[(size_t)r * 3 + 1] = cy / cnt; out[(size_t)r * 3 + 2] = cz / cnt;
     }
     if (tid == 0) { *n_out = M; *status = err; }
 }
@@ -677,7 +878,8 @@ struct planar_plane_clouds {
     planar_ctx* ctx = nullptr;
     int max_batch = 0;
     planar::planepost::Geo G{};
-    size_t smem = 0, smem_cloud = 0;
+    size_t smem = 0, smem_tail = 0, smem_cloud = 0, smem_sort_g = 0, smem_sort_l = 0;
+    int sort_rows = 0;
     planar::DevBuf ws, rng, dbg;
     bool timing = false;
 };
@@ -690,6 +892,7 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
     PLANAR_REQUIRE(ctx && out, PLANAR_EINVAL, "null argument");
     PLANAR_REQUIRE(width >= 16 && height >= 16 && width <= 4096 && height <= 4096 && max_batch >= 1, PLANAR_EINVAL, "bad size");
     PLANAR_REQUIRE(max_points >= 64 && max_points <= 8192 && (max_points & (max_points - 1)) == 0, PLANAR_EINVAL, "max_points must be a power of two in [64, 8192]");
+    PLANAR_REQUIRE((long long)width * height <= (1ll << planepost::PS_SHIFT), PLANAR_EINVAL, "at most 2^19 pixels per frame (a sort word is voxel << 19 | pixel)");
     PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
     planar_plane_clouds* p = new planar_plane_clouds;
     p->ctx = ctx; p->max_batch = max_batch;
@@ -698,17 +901,32 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
     G.leaf = 0.1f; G.dist_th = 0.05;
     G.log_probability = std::log(1.0 - 0.99);
     G.tcap = 2 * max_points;
-    G.off_cnt = 0;
-    G.off_sum = (size_t)G.tcap * 4;
-    G.off_cent = G.off_sum + (size_t)G.tcap * 24;
-    G.off_key = align_up(G.off_cent + (size_t)max_points * 12, (size_t)16);
-    G.ws_stride = align_up(G.off_key + (size_t)G.tcap * 8, (size_t)256);
+    {   // per-frame workspace
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, (size_t)256); return o; };
+        G.off_cnt = carve((size_t)G.tcap * 4);                      // points per voxel slot
+        G.off_key = carve((size_t)G.tcap * 8);                      // the frame's voxel key table
+        G.off_rank = carve((size_t)G.tcap * 2);                     // slot -> place in PCL's output order
+        G.off_cent = carve((size_t)max_points * 12);                // centroids in that order
+        G.off_vstart = carve((size_t)(max_points + 1) * 4);         // first item of every voxel
+        G.off_pl = carve((size_t)2 * planepost::MAXP * 4);          // per plane: first / last voxel
+        G.off_init = carve((size_t)planepost::MAXP * sizeof(isort::Range));
+        G.off_meta = carve(sizeof(planepost::Meta));
+        G.off_ranges = carve((size_t)isort::G_FMAX * sizeof(isort::Range));
+        G.off_blocks = carve((size_t)isort::G_FMAX * sizeof(isort::Block));
+        G.off_items = carve(std::max((size_t)width * height, (size_t)65536) * 4);   // (voxel << 19 | pixel) per member pixel; the map-side merge sorts up to 65536 points here
+        G.ws_stride = off;
+    }
     G.mini = 128;
-    // LDS of plane_clouds_kernel: eight tile tables of 128 entries x 36 B while the pixels are summed, the list of occupied slots (max_points x 8 B)
-    // while they are sorted: 36 KB at the default 4096 voxels per frame (three workgroups per CU next to other kernels), 64 KB at 8192.  The frame's
-    // key table itself (2 * max_points slots) lives in the workspace.  voxel_cloud_kernel (one workgroup, the map side) keeps its key table in LDS.
-    p->smem = std::max((size_t)(planepost::NT / 64) * G.mini * 36, (size_t)max_points * 8);
+    // LDS of plane_voxels_kernel: eight tile tables of 128 entries x 12 B while the pixels are counted, the list of occupied slots (max_points x 8 B)
+    // while they are sorted: 32 KB at the default 4096 voxels per frame, 64 KB at 8192.  The frame's key table itself (2 * max_points slots) lives in
+    // the workspace.  plane_tail_kernel: the refit's shuffle array (2 B per voxel).  cloud_voxels_kernel (one workgroup, the map side) keeps its key table in LDS.
+    p->smem = std::max((size_t)(planepost::NT / 64) * G.mini * 12, (size_t)max_points * 8);
+    p->smem_tail = (size_t)max_points * 2;
     p->smem_cloud = (size_t)G.tcap * 8;
+    p->sort_rows = planepost::PsGl::rows_for(std::max(width * height, 65536));
+    p->smem_sort_g = (size_t)planepost::PsGl::bytes(p->sort_rows);
+    p->smem_sort_l = (size_t)planepost::PsLds::bytes;
     int rc = p->ws.alloc(G.ws_stride * (size_t)max_batch);
     if (!rc) rc = p->rng.alloc((size_t)planepost::NRNG * 4);
     if (rc) { delete p; return rc; }
@@ -717,9 +935,11 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
     if (hipMemcpy(p->rng.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("plane_clouds: sampler table upload failed"); delete p; return PLANAR_EDEVICE; }
     {
         hipError_t e = hipSuccess;
-        if (p->smem > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::plane_clouds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
-        if (e == hipSuccess && p->smem_cloud > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::voxel_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_cloud);
-        if (e != hipSuccess) { (void)hipGetLastError(); set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", std::max(p->smem, p->smem_cloud)); delete p; return PLANAR_EINVAL; }
+        if (p->smem > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::plane_voxels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
+        if (e == hipSuccess && p->smem_cloud > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::cloud_voxels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_cloud);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_g);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_l);
+        if (e != hipSuccess) { (void)hipGetLastError(); set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", std::max(std::max(p->smem, p->smem_cloud), p->smem_sort_g)); delete p; return PLANAR_EINVAL; }
     }
     *out = p;
     return PLANAR_OK;
@@ -757,14 +977,18 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     PLANAR_REQUIRE(B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "B must be in [1, max_batch]");
     PLANAR_REQUIRE(pitch_px >= p->G.W && frame_stride_px >= (int64_t)pitch_px * p->G.H, PLANAR_EINVAL, "pitch/frame_stride too small");
     PLANAR_REQUIRE(leaf > 0.f && dist_th >= 0.0, PLANAR_EINVAL, "leaf / dist_th");
-    // the fixed-point voxel sums hold 2^19 points of magnitude < 2^7 m
-    PLANAR_REQUIRE(65535.0 * (double)depth_factor * std::max(1.0, std::max(p->G.W / (double)fx, p->G.H / (double)fy)) < 128.0, PLANAR_EINVAL, "depth range too large");
     planepost::Geo G = p->G;
     G.fx = fx; G.fy = fy; G.cx = cx; G.cy = cy; G.factor = depth_factor; G.leaf = leaf; G.dist_th = dist_th;
     G.rfx = 1.0 / (double)fx; G.rfy = 1.0 / (double)fy;
-    hipLaunchKernelGGL(planepost::plane_clouds_kernel, dim3(B), dim3(planepost::NT), p->smem, p->ctx->stream, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, d_planes,
-                       planar_peac_max_planes(), d_n_planes, p->rng.as<int>(), p->ws.as<unsigned char>(), d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox,
-                       d_info, p->timing ? p->dbg.as<long long>() : nullptr);
+    hipStream_t st = p->ctx->stream;
+    unsigned char* ws = p->ws.as<unsigned char>();
+    long long* tm = p->timing ? p->dbg.as<long long>() : nullptr;
+    hipLaunchKernelGGL(planepost::plane_voxels_kernel, dim3(B), dim3(planepost::NT), p->smem, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, d_n_planes, ws, tm);
+    hipLaunchKernelGGL(planepost::plane_items_kernel, dim3(B), dim3(planepost::PS_T), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
+    hipLaunchKernelGGL(planepost::plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
+    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_R), dim3(planepost::PS_T), p->smem_sort_l, st, G, ws);
+    hipLaunchKernelGGL(planepost::plane_tail_kernel, dim3(B), dim3(planepost::NT), p->smem_tail, st, G, d_depth, pitch_px, (long)frame_stride_px, d_planes,
+                       planar_peac_max_planes(), p->rng.as<int>(), ws, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox, d_info, tm);
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
 }
@@ -798,7 +1022,7 @@ int planar_plane_clouds_compute(planar_plane_clouds* p, const uint16_t* depth, i
         return rc;
     if ((rc = s.download(st))) return rc;
     for (int b = 0; b < B; b++)
-        if (h_status[b]) { set_error("plane_clouds: frame %d exceeded a capacity (code %d: 3 = voxels / index range, 4 = sampler table)", b, h_status[b]); return PLANAR_ECAPACITY; }
+        if (h_status[b]) { set_error("plane_clouds: frame %d exceeded a capacity (code %d: 3 = voxels / index range, 4 = sampler table, 5 = the std::sort order of a plane's points is not reproducible: introsort depth limit / sort workspace)", b, h_status[b]); return PLANAR_ECAPACITY; }
     return PLANAR_OK;
 }
 
@@ -870,11 +1094,14 @@ int planar_merge_plane_points(planar_plane_clouds* p, const double* Twc, const f
     planepost::Geo G = p->G;
     G.leaf = leaf;
     if (n) hipLaunchKernelGGL(planepost::merge_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.dev<double>(i_T), s.dev<float>(i_f), n_frame, s.dev<float>(i_m), n_map, s.dev<float>(t_all));
-    hipLaunchKernelGGL(planepost::voxel_cloud_kernel, dim3(1), dim3(planepost::NT), p->smem_cloud, st, G, s.dev<float>(t_all), n, p->ws.as<unsigned char>(), s.dev<float>(t_out),
-                       s.dev<int>(o_h), s.dev<int>(o_h) + 1);
+    unsigned char* ws = p->ws.as<unsigned char>();
+    hipLaunchKernelGGL(planepost::cloud_voxels_kernel, dim3(1), dim3(planepost::NT), p->smem_cloud, st, G, s.dev<float>(t_all), n, ws);
+    hipLaunchKernelGGL(planepost::plane_sort_global, dim3(1), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
+    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(1, planepost::PS_R), dim3(planepost::PS_T), p->smem_sort_l, st, G, ws);
+    hipLaunchKernelGGL(planepost::cloud_sums_kernel, dim3(1), dim3(planepost::NT), 0, st, G, s.dev<float>(t_all), ws, s.dev<float>(t_out), s.dev<int>(o_h), s.dev<int>(o_h) + 1);
     PLANAR_HIP_CHECK(hipGetLastError());
     if ((rc = s.download(st))) return rc;
-    if (h[1]) { set_error("merge_plane_points: more than %d voxels (or voxel index overflow)", p->G.max_points); return PLANAR_ECAPACITY; }
+    if (h[1]) { set_error("merge_plane_points: more than %d voxels, voxel index overflow, or a std::sort order that is not reproducible (code %d)", p->G.max_points, h[1]); return PLANAR_ECAPACITY; }
     PLANAR_REQUIRE(h[0] <= out_cap, PLANAR_ECAPACITY, "out_cap too small");
     *n_out = h[0];
     if (h[0]) PLANAR_HIP_CHECK(hipMemcpy(out_points, s.dev<float>(t_out), (size_t)h[0] * 12, hipMemcpyDeviceToHost));

@@ -50,7 +50,7 @@ int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status
         LArgs la{arr, ranges.data() + blocks[b].r0, blocks[b].nr, blocks[b].f, blocks[b].l, status};
         wave_emul::launch_block(l_entry<SHIFT, T, E>, &la, T, bi, bd, (size_t)LdsLayout<T, E>::bytes, 256 * 1024);
     }
-    if (stats) stats[3] = wave_emul::S().n_sync;
+    if (stats) { stats[3] = wave_emul::S().n_sync; stats[4] = g_levels; stats[5] = g_segs; stats[6] = g_heap; g_levels = 0; g_segs = 0; g_heap = 0; }
     return 0;
 }
 }  // namespace
@@ -59,7 +59,7 @@ extern "C" {
 // arr [total]: in/out.  bounds [n_ranges + 1]: every [bounds[i], bounds[i+1]) is sorted on its own, as std::sort(first, last, key <) would.
 // config 0: production shapes (global tier 1024 threads; LDS tier 1024 threads x 23 elements); 1: small shapes that force many levels and the
 // global tier on short arrays (256 threads; 256 x 5).  shift: 19 or 20.  n_stage: LDS-tier capacity override (0 = the configuration's).
-// Returns 0, or -1 with a message in err.  stats [4]: ranges, blocks, rendezvous count after the global tier, after everything.
+// Returns 0, or -1 with a message in err.  stats [7] (last: elements that went through the heap-sort fallback): ranges, blocks, rendezvous count after the global tier, after everything, LDS-tier levels, segments partitioned there.
 int isort_emul(uint32_t* arr, const int* bounds, int n_ranges, int shift, int config, int n_stage, int* status, long* stats, char* err, int errlen) {
     try {
         *status = 0;

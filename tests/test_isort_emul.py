@@ -34,7 +34,7 @@ def _check(E, keys, bounds, shift, config, n_stage=0):
     want = arr.copy()
     b = np.asarray(bounds, np.int32)
     E.isort_std_sort(want.ctypes.data, b.ctypes.data, len(b) - 1, shift)
-    status = C.c_int(-1); stats = np.zeros(4, np.int64); err = C.create_string_buffer(512)
+    status = C.c_int(-1); stats = np.zeros(7, np.int64); err = C.create_string_buffer(512)
     rc = E.isort_emul(arr.ctypes.data, b.ctypes.data, len(b) - 1, shift, config, n_stage, C.byref(status), stats.ctypes.data, err, 512)
     assert rc == 0, err.value.decode()
     assert status.value == 0, f"engine status {status.value}"
@@ -89,3 +89,38 @@ def test_lsd_like_keys(lib):
     g = np.abs(rng.normal(0, 1, n)) ** 3
     bins = np.minimum((g / g.max() * 1023).astype(np.int64), 1023)
     _check(lib, 1023 - bins, [0, n], 20, 0)
+
+
+def _plane_voxel_keys(seed, noise):
+    """voxel ranks (PCL's ascending voxel index = lexicographic (z, y, x) voxel coordinates) of every detected plane's pixels in raster order"""
+    import oracle_lib as ol
+    from planarslam_amd.synth import depth_image
+    d = depth_image(seed, noise=noise)
+    planes, labels = ol.peac_run(d)
+    fx, fy, cx, cy = [np.float64(np.float32(v)) for v in (535.4, 539.2, 320.1, 247.6)]
+    fac = np.float64(np.float32(1 / 5000.0))
+    out = []
+    for p in range(len(planes)):
+        ys, xs = np.nonzero(labels == p)
+        z = d[ys, xs].astype(np.float64) * fac
+        pts = np.stack([(xs - cx) * z / fx, (ys - cy) * z / fy, z], 1).astype(np.float32)
+        ijk = np.floor(pts * (np.float32(1.0) / np.float32(0.1))).astype(np.int64)
+        _, r = np.unique((ijk[:, 2] * 100000 + ijk[:, 1]) * 100000 + ijk[:, 0], return_inverse=True)
+        out.append(r)
+    return out
+
+
+def test_heap_sort_fallback_on_real_plane_keys(lib):
+    """The 220 417-pixel plane of synthetic frame 60: its saw-tooth voxel keys make 34 median-of-three partitions in a row peel off a few percent each, and
+    libstdc++ heap-sorts what is left (424 ranges, the longest 45 161 elements: tools/ trace in DESIGN.md).  The engine must end in the same place."""
+    ks = _plane_voxel_keys(60, True)
+    sizes = [len(k) for k in ks]
+    assert max(sizes) > 200000
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    off = np.concatenate([[0], np.cumsum([k.max() + 1 for k in ks])])[:-1]
+    _check(lib, np.concatenate([k + o for k, o in zip(ks, off)]), bounds, 19, 0)
+    # and with the fallback inside LDS blocks (small capacity -> short ranges reach depth 0 there)
+    ks = _plane_voxel_keys(705, True)
+    bounds = np.concatenate([[0], np.cumsum([len(k) for k in ks])])
+    off = np.concatenate([[0], np.cumsum([k.max() + 1 for k in ks])])[:-1]
+    _check(lib, np.concatenate([k + o for k, o in zip(ks, off)]), bounds, 19, 0)
