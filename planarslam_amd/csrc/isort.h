@@ -61,34 +61,74 @@ __device__ __forceinline__ V block_exscan(V v, V* s_w, V* total) {
     return base + inc - v;
 }
 
-// Two segmented scans over the workgroup's threads at once.  Forward: (vL, resetL) -> what the threads before this one accumulated since the
-// last reset (exclusive).  Backward: the same from the other end.  s_buf: [4 * T / 64] ints; two barriers.
-template <int T>
-__device__ __forceinline__ void seg_scan2(int vL, int resetL, int vR, int resetR, int* s_buf, int& carryL, int& carryR) {
-    constexpr int NW = T / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int aL = vL, gL = resetL, aR = vR, gR = resetR;
+#ifndef PLANAR_WAVE_EMUL
+// inclusive segmented prefix sum over the 64 lanes on DPP row operations (the Kogge-Stone ladder of wave_scan_add with the pair operator
+// (v, g) <- (g ? v : v + v', g | g')): no LDS-pipe permute, no wait
+__device__ __forceinline__ void dpp_seg_scan(int& v, int& g) {
+#define ISORT_DPP_STEP(ctrl, rmask)                                                                                                    \
+    {                                                                                                                                  \
+        const int tv = __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false), tg = __builtin_amdgcn_update_dpp(0, g, ctrl, rmask, 0xf, false); \
+        v = g ? v : v + tv; g |= tg;                                                                                                   \
+    }
+    ISORT_DPP_STEP(0x111, 0xf) ISORT_DPP_STEP(0x112, 0xf) ISORT_DPP_STEP(0x114, 0xf) ISORT_DPP_STEP(0x118, 0xf) ISORT_DPP_STEP(0x142, 0xa) ISORT_DPP_STEP(0x143, 0xc)
+#undef ISORT_DPP_STEP
+}
+#endif
+// Two segmented scans over one wavefront at once.  Forward: (vL, resetL) -> what the lanes before this one accumulated since the last reset
+// (exclusive; eL / egL: value and whether a reset lies in between).  Backward: the same from the other end.  incL / incR: the inclusive values.
+__device__ __forceinline__ void wave_seg_scan2(int vL, int rL, int vR, int rR, int& eL, int& egL, int& eR, int& egR, int& incL, int& incgL, int& incR, int& incgR) {
+    const int lane = threadIdx.x & 63;
+#if defined(PLANAR_WAVE_EMUL) || defined(ISORT_NO_DPP)
+    int aL = vL, gL = rL, aR = vR, gR = rR;
     for (int o = 1; o < 64; o <<= 1) {
         const int tv = __shfl_up(aL, o), tf = __shfl_up(gL, o), uv = __shfl_down(aR, o), uf = __shfl_down(gR, o);
         if (lane >= o) { if (!gL) aL += tv; gL |= tf; }
         if (lane + o < 64) { if (!gR) aR += uv; gR |= uf; }
     }
-    const int eL = __shfl_up(aL, 1), egL = __shfl_up(gL, 1), eR = __shfl_down(aR, 1), egR = __shfl_down(gR, 1);
-    if (lane == 63) { s_buf[w] = aL; s_buf[NW + w] = gL; }
-    if (lane == 0) { s_buf[2 * NW + w] = aR; s_buf[3 * NW + w] = gR; }
+    eL = __shfl_up(aL, 1); egL = __shfl_up(gL, 1); eR = __shfl_down(aR, 1); egR = __shfl_down(gR, 1);
+    if (lane == 0) { eL = 0; egL = 0; }
+    if (lane == 63) { eR = 0; egR = 0; }
+    incL = aL; incgL = gL; incR = aR; incgR = gR;
+#else
+    // forward on DPP; the backward scan is the forward one on the lane-reversed input (one permute each way)
+    int aL = vL, gL = rL;
+    dpp_seg_scan(aL, gL);
+    eL = __builtin_amdgcn_update_dpp(0, aL, 0x138, 0xf, 0xf, false);                // wave_shr:1: the lane before (lane 0: nothing)
+    egL = __builtin_amdgcn_update_dpp(0, gL, 0x138, 0xf, 0xf, false);
+    const int packed = __shfl(vR | (rR << 24), 63 - lane);
+    int aR = packed & 0xffffff, gR = packed >> 24;
+    dpp_seg_scan(aR, gR);
+    const int ex = __builtin_amdgcn_update_dpp(0, aR | (gR << 24), 0x138, 0xf, 0xf, false);
+    const int back = __shfl(ex, 63 - lane), binc = __shfl(aR | (gR << 24), 63 - lane);
+    eR = back & 0xffffff; egR = back >> 24;
+    incR = binc & 0xffffff; incgR = binc >> 24;
+    incL = aL; incgL = gL;
+#endif
+}
+
+// Two segmented scans over the workgroup's threads at once (see wave_seg_scan2).  s_buf: [2][4 * T / 64] ints, the half alternates with `parity` so that
+// one barrier is enough.
+template <int T>
+__device__ __forceinline__ void seg_scan2(int vL, int resetL, int vR, int resetR, int* s_buf, int parity, int& carryL, int& carryR) {
+    constexpr int NW = T / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int eL, egL, eR, egR, aL, gL, aR, gR;
+    wave_seg_scan2(vL, resetL, vR, resetR, eL, egL, eR, egR, aL, gL, aR, gR);
+    int* sb = s_buf + (parity & 1) * 4 * NW;
+    if (lane == 63) { sb[w] = aL; sb[NW + w] = gL; }
+    if (lane == 0) { sb[2 * NW + w] = aR; sb[3 * NW + w] = gR; }
     __syncthreads();
     int wl = 0, wr = 0;
     for (int q = 0; q < NW; q++) {
-        const int v = s_buf[q], g = s_buf[NW + q];
+        const int v = sb[q], g = sb[NW + q];
         if (q < w) wl = g ? v : wl + v;
     }
     for (int q = NW - 1; q >= 0; q--) {
-        const int v = s_buf[2 * NW + q], g = s_buf[3 * NW + q];
+        const int v = sb[2 * NW + q], g = sb[3 * NW + q];
         if (q > w) wr = g ? v : wr + v;
     }
     carryL = lane == 0 ? wl : (egL ? eL : eL + wl);
     carryR = lane == 63 ? wr : (egR ? eR : eR + wr);
-    __syncthreads();
 }
 
 // __move_median_to_first(f, f + 1, mid, l - 1) with comp = key <; returns the position whose element goes to the front
@@ -176,25 +216,12 @@ constexpr int W_E = 31, W_CAP = 64 * W_E, W_LIST = 128, G_LIST = 32, TASKS = 256
 template <int T>
 struct WgScope {
     static constexpr int NT = T;
-    int* s_buf;                                               // [4 * T / 64]
+    int* s_buf;                                               // [2 * T / 64] (exscan, as 64-bit slots elsewhere) + [2][4 * T / 64] (seg_scan)
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int exscan(int v, int* total) const { return block_exscan<T, int>(v, s_buf, total); }
-    __device__ __forceinline__ void seg_scan(int vL, int rL, int vR, int rR, int& cL, int& cR) const { seg_scan2<T>(vL, rL, vR, rR, s_buf, cL, cR); }
+    __device__ __forceinline__ void seg_scan(int vL, int rL, int vR, int rR, int parity, int& cL, int& cR) const { seg_scan2<T>(vL, rL, vR, rR, s_buf + 2 * T / 64, parity, cL, cR); }
 };
-#ifndef PLANAR_WAVE_EMUL
-// inclusive segmented prefix sum over the 64 lanes on DPP row operations (the Kogge-Stone ladder of wave_scan_add with the pair operator
-// (v, g) <- (g ? v : v + v', g | g')): no LDS-pipe permute, no wait
-__device__ __forceinline__ void dpp_seg_scan(int& v, int& g) {
-#define ISORT_DPP_STEP(ctrl, rmask)                                                                                                    \
-    {                                                                                                                                  \
-        const int tv = __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false), tg = __builtin_amdgcn_update_dpp(0, g, ctrl, rmask, 0xf, false); \
-        v = g ? v : v + tv; g |= tg;                                                                                                   \
-    }
-    ISORT_DPP_STEP(0x111, 0xf) ISORT_DPP_STEP(0x112, 0xf) ISORT_DPP_STEP(0x114, 0xf) ISORT_DPP_STEP(0x118, 0xf) ISORT_DPP_STEP(0x142, 0xa) ISORT_DPP_STEP(0x143, 0xc)
-#undef ISORT_DPP_STEP
-}
-#endif
 struct WaveScope {                                            // one wavefront: its LDS accesses execute in order, a "barrier" only pins the compiler
     static constexpr int NT = 64;
     __device__ __forceinline__ int tid() const { return threadIdx.x & 63; }
@@ -204,30 +231,11 @@ struct WaveScope {                                            // one wavefront: 
         *total = ::planar::wave_lane(inc, 63);
         return inc - v;
     }
-    __device__ __forceinline__ void seg_scan(int vL, int rL, int vR, int rR, int& cL, int& cR) const {
-        const int lane = threadIdx.x & 63;
-#if defined(PLANAR_WAVE_EMUL) || defined(ISORT_NO_DPP)
-        int aL = vL, gL = rL, aR = vR, gR = rR;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int tv = __shfl_up(aL, o), tf = __shfl_up(gL, o), uv = __shfl_down(aR, o), uf = __shfl_down(gR, o);
-            if (lane >= o) { if (!gL) aL += tv; gL |= tf; }
-            if (lane + o < 64) { if (!gR) aR += uv; gR |= uf; }
-        }
-        const int eL = __shfl_up(aL, 1), eR = __shfl_down(aR, 1);
-        cL = lane == 0 ? 0 : eL;
-        cR = lane == 63 ? 0 : eR;
-#else
-        // forward on DPP; the backward scan is the forward one on the lane-reversed input (one permute each way)
-        int aL = vL, gL = rL;
-        dpp_seg_scan(aL, gL);
-        cL = __builtin_amdgcn_update_dpp(0, aL, 0x138, 0xf, 0xf, false);            // wave_shr:1: the lane before (lane 0: nothing)
-        const int packed = __shfl(vR | (rR << 16), 63 - lane);
-        int aR = packed & 0xffff, gR = packed >> 16;
-        dpp_seg_scan(aR, gR);
-        const int ex = __builtin_amdgcn_update_dpp(0, aR, 0x138, 0xf, 0xf, false);
-        cR = __shfl(ex, 63 - lane);
-#endif
+    __device__ __forceinline__ void seg_scan(int vL, int rL, int vR, int rR, int, int& cL, int& cR) const {
+        int egL, egR, a0, a1, a2, a3;
+        wave_seg_scan2(vL, rL, vR, rR, cL, egL, cR, egR, a0, a1, a2, a3);
     }
+    __device__ __forceinline__ void sync_lists() const { sync(); }
 };
 
 struct Lists {                                                // a scope's segment lists (double-buffered) and per-segment results, all in LDS
@@ -250,8 +258,8 @@ struct LdsLayout {
     static constexpr int off_gl = off_wl + NW * wl_bytes;                           // the workgroup's lists, G_LIST entries, same layout
     static constexpr int gl_bytes = G_LIST * (4 + 4 + 2 + 2 + 2);
     static constexpr int off_tk = off_gl + gl_bytes;                                // tasks: f, l u16 [TASKS]; d u8 [TASKS]
-    static constexpr int off_buf = (off_tk + TASKS * 5 + 3) / 4 * 4;                // int [4 * NW + 4]
-    static constexpr int bytes = off_buf + (4 * NW + 4) * 4;
+    static constexpr int off_buf = (off_tk + TASKS * 5 + 3) / 4 * 4;                // int [10 * NW + 4]
+    static constexpr int bytes = off_buf + (10 * NW + 4) * 4;
     static_assert(bytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 };
 __device__ __forceinline__ Lists carve_lists(uint8_t* p, int cap) {
@@ -350,7 +358,7 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
         const uint32_t rm_first = npc > 0 ? rmask(0) : 0u;
         int carryL, carryR;
         ISORT_MARK(2);
-        sc.seg_scan(__popc(mL & rm_last), !(npc == 1 && contL), __popc(mR & rm_first), !(npc == 1 && contR), carryL, carryR);
+        sc.seg_scan(__popc(mL & rm_last), !(npc == 1 && contL), __popc(mR & rm_first), !(npc == 1 && contR), cur, carryL, carryR);
         ISORT_MARK(3);
         // ---- D1: the piece with g false at its start and true behind its end holds x*: it writes the segment's cut and its number of swaps m ----
         int pA0[3] = {0, 0, 0}, pBe[3] = {0, 0, 0};
@@ -456,8 +464,7 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
             // this thread's first segment in the new list: the children of the old one (or what follows them)
             if (s0 < nseg) { const int v = smm[s0], cutv = scut[s0]; s0 = (v & 0x7fff) + (((v & 0x8000) && cutv <= c0) ? 1 : 0); } else s0 = tot;
             nseg = tot;
-            cur ^= 1;
-            sc.sync();
+            cur ^= 1;                                            // (no barrier here: the next writes to scut / smm are behind the scan's)
         }
         ISORT_MARK(7);
     }
@@ -473,7 +480,7 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
     uint32_t* mb = (uint32_t*)(lds + LL::off_mb);
     uint32_t* kb = (uint32_t*)(lds + LL::off_kb);
     int* s_buf = (int*)(lds + LL::off_buf);
-    int* s_tn = s_buf + 4 * LL::NW;                              // [0] tasks, [1] next task
+    int* s_tn = s_buf + 10 * LL::NW;                             // [0] tasks, [1] next task
     Tasks TK;
     TK.f = (uint16_t*)(lds + LL::off_tk); TK.l = TK.f + TASKS; TK.d = (uint8_t*)(TK.l + TASKS); TK.n = s_tn;
     const Lists GL = carve_lists(lds + LL::off_gl, G_LIST);
