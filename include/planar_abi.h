@@ -616,6 +616,9 @@ typedef struct planar_plane_clouds planar_plane_clouds;
 int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* voxels per frame: a power of two <= 8192; the kernel holds 36 KB of LDS up to 4096, 64 KB at 8192; the key table is in the workspace */, planar_plane_clouds** out);
 void planar_plane_clouds_destroy(planar_plane_clouds* pc);
 int planar_plane_clouds_stride(const planar_plane_clouds* pc, int* pl_stride, int* max_points);
+/* diagnostics (synchronises): per frame of the last call, out [B][4] = {ranges that went through libstdc++'s heap-sort fallback (std::sort of
+ * pcl::VoxelGrid::applyFilter on a plane whose introsort depth budget ran out), their elements, the longest, LDS-tier sort blocks} */
+int planar_plane_clouds_sort_stats(planar_plane_clouds* pc, int B, int64_t* out);
 /* Profiling aid, as planar_peac_read_timing: per-frame phase timestamps of the last call, out[B][16] (100 MHz ticks: [0] entry, [1] table cleared, [2] voxel sums,
  * [3] sorted + centroids, [4] refit, [5] end; [6] voxels, [7] planes; [8..11] shader-clock cycles of wavefront 0 in the voxel-sum phase: row loops, tile ends,
  * executions of the parked-run insertion and the cycles in it). */

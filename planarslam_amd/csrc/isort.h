@@ -23,8 +23,9 @@
 //                           medians | flags + two segmented scans | cuts | left stops | swaps | new list, whatever the number of segments: the
 //                           whole workgroup runs the levels above 2048 elements, single wavefronts everything below; the leaves of <= 16
 //                           elements are ranked (stable) in the write-back, so the block goes back SORTED, ties in std::sort's order.
-// A range whose depth budget runs out is heap-sorted as libstdc++ does it (heap_sort below, one thread: sequential by nature).  That is not a corner case
-// for voxel keys: the saw-tooth key sequence of a plane in raster order makes the median-of-three partitions degenerate for about one plane in a hundred.
+// A range whose depth budget runs out is heap-sorted as libstdc++ does it: the tiers record it, heap_jobs runs it afterwards (level-parallel __make_heap,
+// software-pipelined __sort_heap; see "The heap-sort fallback" below).  That is not a corner case for voxel keys: the saw-tooth key sequence of a plane
+// in raster order makes the median-of-three partitions degenerate for about one plane in fifty.
 // tests/host_shim/isort_host.cpp compiles this file with g++ on the wave64 emulator and checks it against the real std::sort.
 #pragma once
 #include <stdint.h>
@@ -40,7 +41,7 @@ struct Block { int f, l, r0, nr; };     // LDS-tier job: the span [f, l) holds r
 
 constexpr int ST_CAPACITY = 3;
 #ifdef PLANAR_WAVE_EMUL
-static long g_levels = 0, g_segs = 0, g_heap = 0;      // emulator statistics: LDS-tier levels run, segments partitioned, elements heap-sorted
+static long g_levels = 0, g_segs = 0;      // emulator statistics: LDS-tier levels run, segments partitioned
 #endif
 
 __device__ __forceinline__ int lg2i(int n) { return 31 - __clz(n); }          // std::__lg
@@ -141,51 +142,108 @@ __device__ __forceinline__ int median_pos(uint32_t xa, uint32_t xb, uint32_t xc,
     return Bm;
 }
 
-// std::__partial_sort(first, last, last) = __make_heap + __sort_heap, statement by statement (bits/stl_heap.h: __adjust_heap sifts the hole down to a leaf
-// along the larger children - the right one on ties - and __push_heap carries the value back up): what __introsort_loop does with a range of more than 16
-// elements when its depth budget is used up.  Sequential by nature (every pop depends on the heap the previous one left); one thread runs it.  On voxel
-// keys in raster order (saw-tooth runs) the median-of-three partitions DO degenerate now and then: about one plane in a hundred ends here.
-template <int SHIFT>
-__device__ __forceinline__ void adjust_heap(uint32_t* first, int hole, int len, uint32_t value) {
-    const int top = hole;
-    int child = hole;
-    while (child < (len - 1) / 2) {
-        child = 2 * (child + 1);
-        const uint32_t r = first[child], l = first[child - 1];
-        if ((r >> SHIFT) < (l >> SHIFT)) { child--; first[hole] = l; } else first[hole] = r;
-        hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-        child = 2 * (child + 1);
-        first[hole] = first[child - 1];
-        hole = child - 1;
-    }
-    const uint32_t kv = value >> SHIFT;
-    while (hole > top) {
-        const int parent = (hole - 1) / 2;
-        const uint32_t u = first[parent];
-        if (!((u >> SHIFT) < kv)) break;
-        first[hole] = u;
-        hole = parent;
-    }
-    first[hole] = value;
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The heap-sort fallback
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// std::__partial_sort(first, last, last) = __make_heap + __sort_heap (bits/stl_heap.h) is what __introsort_loop does with a range of more than 16
+// elements whose depth budget is used up.  That is not a corner case here: the saw-tooth voxel keys of a plane in raster order make the
+// median-of-three partitions peel off a few percent per level, and about one plane in fifty ends with ranges of up to tens of thousands of elements
+// in this branch.  Every pop depends on the heap the previous one left, but not on all of it:
+//   * __adjust_heap(hole, value) sifts the hole down to a leaf along the larger children (the right one on ties) and __push_heap carries the value back
+//     up while the parent is smaller.  Keys along that path do not increase downwards, so the value ends below the last path element that is >= it:
+//     the same final state as walking DOWN and stopping at the first chosen child that is smaller than the value (nothing below is touched);
+//   * __make_heap's sift-downs of the nodes of one depth touch disjoint subtrees: a whole depth at a time, one lane per node;
+//   * in __sort_heap pop t + 1 reads at heap level j what pop t wrote at level j + 1: pops run two levels apart, HP of them in flight on HP lanes of
+//     one wavefront.  A pop starts (it takes the last heap element as its value and puts the root there) only when no earlier pop in flight can
+//     still reach that element, i.e. none of their holes is one of its ancestors.
+// Jobs (ranges) are recorded by the two tiers and run by heap_jobs afterwards; a range's first H_LDS elements (the top of the heap) live in LDS.
+struct HeapJob { int f, l; };
+struct HeapSink { HeapJob* jobs; int* n; int cap; };      // where the tiers record the ranges that need the fallback (global memory; n: atomic counter)
+__device__ __forceinline__ void push_heap_job(const HeapSink& H, int f, int l, int* status) {
+    const int k = atomicAdd(H.n, 1);
+    if (k < H.cap) H.jobs[k] = HeapJob{f, l}; else *status = ST_CAPACITY;
 }
+constexpr int HP = 8;                  // pops in flight (heap depth <= 16 levels, two levels apart)
+
+struct HeapMem {                       // element i of the range: LDS below cap, the array itself (global memory) above
+    uint32_t* lds; uint32_t* glb; int cap;
+    __device__ __forceinline__ uint32_t ld(int i) const { return i < cap ? lds[i] : glb[i]; }
+    __device__ __forceinline__ void st(int i, uint32_t x) const { if (i < cap) lds[i] = x; else glb[i] = x; }
+};
+__device__ __forceinline__ int heap_level(int i) { return 31 - __clz(i + 1); }
+
+// one step of a top-down sift in a heap of `len` elements: the hole h takes its larger child if that child is not smaller than the value (-> true, h moves
+// down), else the value (-> false: finished)
 template <int SHIFT>
-__device__ __forceinline__ void heap_sort(uint32_t* a, int f, int l) {
-    uint32_t* first = a + f;
-    const int len = l - f;
-#ifdef PLANAR_WAVE_EMUL
-    g_heap += len;
-#endif
-    if (len < 2) return;
-    for (int parent = (len - 2) / 2;; parent--) {
-        adjust_heap<SHIFT>(first, parent, len, first[parent]);
-        if (parent == 0) break;
+__device__ __forceinline__ bool sift_step(const HeapMem& M, int& h, int len, uint32_t v) {
+    const int c = 2 * h + 2;
+    uint32_t pick = 0;
+    int pi = -1;
+    if (c < len) { const uint32_t r = M.ld(c), l = M.ld(c - 1); if ((r >> SHIFT) < (l >> SHIFT)) { pick = l; pi = c - 1; } else { pick = r; pi = c; } }
+    else if (c == len) { pick = M.ld(c - 1); pi = c - 1; }
+    if (pi >= 0 && !((pick >> SHIFT) < (v >> SHIFT))) { M.st(h, pick); h = pi; return true; }
+    M.st(h, v);
+    return false;
+}
+
+// heap-sorts the k elements behind M (one wavefront calls it; `sync` orders its LDS / global accesses)
+template <int SHIFT>
+__device__ __forceinline__ void heap_sort_wave(const HeapMem& M, int k) {
+    const int lane = threadIdx.x & 63;
+    auto wsync = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); };   // (one wavefront: orders its own LDS / global accesses)
+    if (k < 2) return;
+    // __make_heap: depth by depth from the last parent's, one lane per node
+    for (int dd = heap_level((k - 2) / 2); dd >= 0; dd--) {
+        const int first = (1 << dd) - 1, last = min((1 << (dd + 1)) - 2, (k - 2) / 2);
+        for (int i0 = first; i0 <= last; i0 += 64) {
+            int h = i0 + lane;
+            const bool on = h <= last;
+            const uint32_t v = on ? M.ld(h) : 0u;
+            bool go = on;
+            while (__ballot(go) != 0ull) { if (go) go = sift_step<SHIFT>(M, h, k, v); }
+        }
+        wsync();
     }
-    for (int last = len - 1; last > 0; last--) {
-        const uint32_t value = first[last];
-        first[last] = first[0];
-        adjust_heap<SHIFT>(first, 0, last, value);
+    // __sort_heap: pop t (t = 0 .. k - 2) takes the last element z = k - 1 - t of the heap as its value, puts the root there and sifts in the heap of z
+    // elements; lane t % HP runs it, one level per step, started at least two steps after pop t - 1: by construction it reads at level j + 1 what its
+    // predecessor wrote two or more steps ago, and nothing else has to be checked from step to step.
+    bool on = false;                       // this lane has a pop in flight
+    int h = 0, len = 0;                    // its hole, its heap size
+    uint32_t v = 0;
+    int next = 0, gap = 2;                 // the next pop to start, steps since the last start (uniform)
+    while (true) {
+        if (next <= k - 2 && gap >= 2) {
+            // ... unless a pop in flight can still reach z (its hole is z or one of z's ancestors: it may yet write there), or the lane is still busy
+            const int z = k - 1 - next, zl = heap_level(z), owner = next % HP;
+            bool blocks = false;
+            if (on) { const int hl = heap_level(h); blocks = lane == owner || (hl <= zl && ((z + 1) >> (zl - hl)) == h + 1); }
+            if (__ballot(blocks) == 0ull) {
+                const uint32_t vz = M.ld(z), root = M.ld(0);
+                if (lane == owner) { on = true; h = 0; len = z; v = vz; M.st(z, root); }
+                wsync();
+                next++; gap = 0;
+            }
+        }
+        if (on) on = sift_step<SHIFT>(M, h, len, v);
+        wsync();
+        gap++;
+        if (next > k - 2 && __ballot(on) == 0ull) break;
+    }
+}
+
+// The jobs first, first + stride, ... of an array, by one wavefront (a workgroup of 64 threads); lds: cap 32-bit words
+template <int SHIFT>
+__device__ void heap_jobs(uint32_t* __restrict__ arr, const HeapJob* __restrict__ jobs, int njobs, int first, int stride, uint32_t* lds, int cap) {
+    const int lane = threadIdx.x & 63;
+    for (int j = first; j < njobs; j += stride) {
+        const HeapJob J = jobs[j];
+        const int k = J.l - J.f, in_lds = min(k, cap);
+        for (int i = lane; i < in_lds; i += 64) lds[i] = arr[J.f + i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        const HeapMem M{lds, arr + J.f, cap};
+        heap_sort_wave<SHIFT>(M, k);
+        for (int i = lane; i < in_lds; i += 64) arr[J.f + i] = lds[i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -292,7 +350,7 @@ __device__ __forceinline__ void move_median(uint32_t* a, int f, int l) {
 // a chunk can touch are read together, swaps go four at a time, the pivots of the next level are placed by the thread that lists the segment.
 template <int SHIFT, int E, class S>
 __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* posh, uint32_t* mb, uint32_t* kb, const Lists& L, int nseg, int c_base, int c_end,
-                                            int keep_above, const Tasks& TK, int* status) {
+                                            int keep_above, const Tasks& TK, const HeapSink& HS, int span_f, int* status) {
 #ifdef ISORT_TIMING
     long long _tm = __builtin_readcyclecounter();
 #endif
@@ -439,7 +497,7 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const int xf = h ? cut : f, xl = h ? l : cut;
-                        if (xl - xf > 16 && d == 0) heap_sort<SHIFT>(a, xf, xl);          // budget used up: the heap-sort fallback (a leaf of more than 16: left alone later)
+                        if (xl - xf > 16 && d == 0) push_heap_job(HS, span_f + xf, span_f + xl, status);   // budget used up: the heap-sort fallback, later (a leaf of more than 16: the write-back leaves it alone)
                         else if (xl - xf > keep_above) {
 #pragma unroll
                             for (int z = 0; z < 4; z++) if (nk == z) { cf[z] = xf; cl[z] = xl; cd[z] = d; }
@@ -473,7 +531,7 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
 // Sorts arr[span_f, span_l) (<= T * E elements), which consists of the nr <= T ranges `ranges` (sorted by f, disjoint; anything between them is left
 // alone), as std::sort would have finished each of them.  All T threads of the workgroup call it.
 template <int SHIFT, int T, int E>
-__device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ ranges, int nr, int span_f, int span_l, uint8_t* lds, int* status) {
+__device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ ranges, int nr, int span_f, int span_l, uint8_t* lds, const HeapSink& HS, int* status) {
     using LL = LdsLayout<T, E>;
     uint32_t* a = (uint32_t*)(lds + LL::off_a);
     uint16_t* posh = (uint16_t*)(lds + LL::off_posh);
@@ -503,7 +561,7 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
             R.f -= span_f; R.l -= span_f;
             atomicOr(&mb[R.f >> 5], 1u << (R.f & 31)); atomicOr(&kb[R.f >> 5], 1u << (R.f & 31));
             atomicOr(&mb[R.l >> 5], 1u << (R.l & 31));
-            if (R.l - R.f > 16 && R.d == 0) heap_sort<SHIFT>(a, R.f, R.l);
+            if (R.l - R.f > 16 && R.d == 0) push_heap_job(HS, span_f + R.f, span_f + R.l, status);
             else if (R.l - R.f > W_CAP) keep = 1;
             else if (R.l - R.f > 16) {
                 const int k = atomicAdd(&s_tn[0], 1);
@@ -519,7 +577,7 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
         __syncthreads();
     }
     ISORT_MARK(0);
-    sort_levels<SHIFT, E, WgScope<T>>(wg, a, posh, mb, kb, GL, nseg, 0, n, W_CAP, TK, status);
+    sort_levels<SHIFT, E, WgScope<T>>(wg, a, posh, mb, kb, GL, nseg, 0, n, W_CAP, TK, HS, span_f, status);
     __syncthreads();
 #ifdef ISORT_TIMING
     _tm = __builtin_readcyclecounter();
@@ -537,7 +595,7 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
             const int f = TK.f[t], l = TK.l[t];
             if (lane == 0) { WL.f[0] = (uint16_t)f; WL.l[0] = (uint16_t)l; WL.d[0] = TK.d[t]; }
             wv.sync();
-            sort_levels<SHIFT, W_E, WaveScope>(wv, a, posh, mb, kb, WL, 1, f, l, 16, none, status);
+            sort_levels<SHIFT, W_E, WaveScope>(wv, a, posh, mb, kb, WL, 1, f, l, 16, none, HS, span_f, status);
         }
     }
     __syncthreads();
@@ -699,7 +757,7 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
 // out_counts: [0] ranges, [1] blocks.
 template <int SHIFT, int T>
 __device__ void global_tier(uint32_t* __restrict__ arr, const Range* __restrict__ init, int n_init, int n_stage, int nr_cap, Range* __restrict__ out_ranges,
-                            Block* __restrict__ out_blocks, int max_blocks, int* __restrict__ out_counts, uint8_t* lds, int rows_cap, int* status) {
+                            Block* __restrict__ out_blocks, int max_blocks, int* __restrict__ out_counts, uint8_t* lds, int rows_cap, const HeapSink& HS, int* status) {
     using GL = GlobalLayout<T>;
     Range* qb = (Range*)(lds + GL::off_q(rows_cap));
     Range* fin = (Range*)(lds + GL::off_fin(rows_cap));
@@ -711,7 +769,7 @@ __device__ void global_tier(uint32_t* __restrict__ arr, const Range* __restrict_
         for (int i = 0; i < n_init; i++) {
             const Range R = init[i];
             if (R.l - R.f > n_stage && R.d > 0) { if (nq < G_QMAX) qb[nq++] = R; else *status = ST_CAPACITY; }
-            else if (R.l - R.f > n_stage) heap_sort<SHIFT>(arr, R.f, R.l);
+            else if (R.l - R.f > n_stage) push_heap_job(HS, R.f, R.l, status);
             else if (R.l - R.f > 1) { if (nf < G_FMAX) fin[nf++] = R; else *status = ST_CAPACITY; }
         }
         s_c[0] = nq; s_c[1] = 0; s_c[2] = nf;
@@ -729,7 +787,7 @@ __device__ void global_tier(uint32_t* __restrict__ arr, const Range* __restrict_
                 for (int h = 0; h < 2; h++) {
                     const Range C{h ? cut : R.f, h ? R.l : cut, R.d - 1};       // (queued ranges have a budget of at least one)
                     if (C.l - C.f > n_stage && C.d > 0) { if (s_c[1] < G_QMAX) qb[(cur ^ 1) * G_QMAX + s_c[1]++] = C; else *status = ST_CAPACITY; }
-                    else if (C.l - C.f > n_stage) heap_sort<SHIFT>(arr, C.f, C.l);  // budget used up on a range too long for LDS: the fallback in global memory (slow, rare)
+                    else if (C.l - C.f > n_stage) push_heap_job(HS, C.f, C.l, status);   // budget used up on a range too long for an LDS block: the fallback, later
                     else if (C.l - C.f > 1) { if (s_c[2] < G_FMAX) fin[s_c[2]++] = C; else *status = ST_CAPACITY; }
                 }
             }

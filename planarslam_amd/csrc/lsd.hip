@@ -47,14 +47,14 @@ struct Plan {
     double rho, prec, p, log_nt, density_th, log_eps;
     int min_reg_size;
     // per-frame workspace offsets (bytes)
-    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_pix, off_seed, off_ord, off_ordr, off_gused, off_tmp, off_reg, off_valid, off_sortr, off_sortb, off_segs, off_kl, off_rects, off_res, frame_bytes;
+    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_pix, off_seed, off_ord, off_ordr, off_gused, off_tmp, off_reg, off_valid, off_sortr, off_sortb, off_heapj, off_segs, off_kl, off_rects, off_res, frame_bytes;
     // host-evaluated tables (glibc, as the reference library would): log_gamma(x) for integer x, and per halving j of p
     const double* lgamma_tab;   // [w*h + 3]
     double p_log[12], p1_log[12], p_log10[12];
     double gaussCoefL[21], gaussCoefG[63];
 };
 
-struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int sort_counts[2]; };   // sort_counts: ranges, LDS-tier blocks
+struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int sort_counts[2]; int heap_n; int pad_; };   // sort_counts: ranges, LDS-tier blocks; heap_n: ranges left to the heap-sort fallback
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2: 7th-order odd polynomial, degrees; plain mul/add (no FMA), see oracle/cvprim.cpp
@@ -190,6 +190,7 @@ __device__ __forceinline__ void lds_sync();
 //   lsd_sort_compact  one workgroup per frame: drops the undefined pixels (they took part in the partitions), numbers the rest.
 // Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py) and on the emulator (tests/test_isort_emul.py).
 constexpr int SORT_T = 1024, SORT_E = 23, SORT_SHIFT = 20, SORT_R = 16;
+constexpr int SORT_HJOBS = 1024, SORT_HCAP = 8192, SORT_HY = 2;       // heap-sort fallback: jobs per frame, words of a job kept in LDS, workgroups per frame
 using SortLds = isort::LdsLayout<SORT_T, SORT_E>;
 using SortGl = isort::GlobalLayout<SORT_T>;
 
@@ -223,8 +224,9 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict
     if (tid == 0) s_init = isort::Range{0, n, isort::depth_limit(n)};
     __threadfence_block();
     __syncthreads();
+    const isort::HeapSink HS{(isort::HeapJob*)(F + P.off_heapj), &misc->heap_n, SORT_HJOBS};
     isort::global_tier<SORT_SHIFT, SORT_T>(arr, &s_init, 1, SortLds::N, 64, (isort::Range*)(F + P.off_sortr), (isort::Block*)(F + P.off_sortb), isort::G_FMAX,
-                                           misc->sort_counts, sort_lds, rows_cap, &misc->status);
+                                           misc->sort_counts, sort_lds, rows_cap, HS, &misc->status);
     if (tid == 0) misc->t[5] = __builtin_readcyclecounter() - ts0;
 }
 
@@ -237,12 +239,22 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_lds(const Plan* __restrict__ 
     const isort::Range* ranges = (const isort::Range*)(F + P.off_sortr);
     const isort::Block* blocks = (const isort::Block*)(F + P.off_sortb);
     const int nb = misc->sort_counts[1];
+    const isort::HeapSink HS{(isort::HeapJob*)(F + P.off_heapj), &misc->heap_n, SORT_HJOBS};
     const long long ts0 = __builtin_readcyclecounter();
     for (int k = blockIdx.y; k < nb; k += gridDim.y) {
         const isort::Block K = blocks[k];
-        isort::lds_tier<SORT_SHIFT, SORT_T, SORT_E>((uint32_t*)(F + P.off_tmp), ranges + K.r0, K.nr, K.f, K.l, sort_lds, &misc->status);
+        isort::lds_tier<SORT_SHIFT, SORT_T, SORT_E>((uint32_t*)(F + P.off_tmp), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &misc->status);
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) misc->t[6] = __builtin_readcyclecounter() - ts0;
+}
+
+// the ranges whose introsort depth budget ran out (none on gradient images so far; the engine is the voxel grid's, planepost.hip): one wavefront per job
+__global__ __launch_bounds__(64) void lsd_sort_heap(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    extern __shared__ __align__(16) uint8_t sort_lds[];
+    const Plan& P = *plan;
+    uint8_t* F = ws + (size_t)blockIdx.x * P.frame_bytes;
+    const int nj = min(miscs[blockIdx.x].heap_n, SORT_HJOBS);
+    if (nj) isort::heap_jobs<SORT_SHIFT>((uint32_t*)(F + P.off_tmp), (const isort::HeapJob*)(F + P.off_heapj), nj, blockIdx.y, gridDim.y, (uint32_t*)sort_lds, SORT_HCAP);
 }
 
 __global__ __launch_bounds__(SORT_T) void lsd_sort_compact(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
@@ -1392,7 +1404,7 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     const size_t NPf = (size_t)width * height, NPs = (size_t)P.w * P.h;
     P.off_blur7 = carve(NPf); P.off_blur5 = carve(NPf); P.off_dx = carve(NPf * 2); P.off_dy = carve(NPf * 2);
     P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_pix = carve(NPs * 16); P.off_seed = carve(NPs * 8); P.off_ordr = carve(NPs * 4); P.off_gused = carve((NPs + 31) / 32 * 4 + 256); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
-    P.off_valid = carve((NPs + 63) / 64 * 8 + 8); P.off_sortr = carve((size_t)isort::G_FMAX * sizeof(isort::Range)); P.off_sortb = carve((size_t)isort::G_FMAX * sizeof(isort::Block));
+    P.off_valid = carve((NPs + 63) / 64 * 8 + 8); P.off_sortr = carve((size_t)isort::G_FMAX * sizeof(isort::Range)); P.off_sortb = carve((size_t)isort::G_FMAX * sizeof(isort::Block)); P.off_heapj = carve((size_t)lsd::SORT_HJOBS * sizeof(isort::HeapJob));
     P.off_segs = carve((size_t)lsd::MAX_SEGS * sizeof(lsd::Seg)); P.off_kl = carve((size_t)lsd::MAX_SEGS * sizeof(planar_keyline));
     P.off_rects = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Rect)); P.off_res = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Seg));
     P.frame_bytes = off;
@@ -1475,6 +1487,7 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     else {
         hipLaunchKernelGGL(lsd::lsd_sort_global, dim3(B), dim3(lsd::SORT_T), o->sort_smem_g, st, dP, ws, dm, o->sort_rows);
         hipLaunchKernelGGL(lsd::lsd_sort_lds, dim3(B, lsd::SORT_R), dim3(lsd::SORT_T), o->sort_smem_l, st, dP, ws, dm);
+        hipLaunchKernelGGL(lsd::lsd_sort_heap, dim3(B, lsd::SORT_HY), dim3(64), lsd::SORT_HCAP * 4, st, dP, ws, dm);
         hipLaunchKernelGGL(lsd::lsd_sort_compact, dim3(B), dim3(lsd::SORT_T), 0, st, dP, ws, dm);
     }
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[2], st);

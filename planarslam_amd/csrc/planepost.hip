@@ -39,7 +39,7 @@ struct Geo {
     int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (frame workspace); mini: entries of a wavefront's tile table (LDS)
     float fx, fy, cx, cy, factor, leaf;
     double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
-    size_t ws_stride, off_cnt, off_cent, off_key, off_rank, off_vstart, off_pl, off_init, off_meta, off_ranges, off_blocks, off_items;
+    size_t ws_stride, off_cnt, off_cent, off_key, off_rank, off_vstart, off_pl, off_init, off_meta, off_ranges, off_blocks, off_heapj, off_items;
 };
 
 struct Pt { float x, y, z; };
@@ -310,11 +310,12 @@ __device__ __forceinline__ void bitonic(unsigned long long* a, int n2) {
 //                         wavefront per plane) and the compaction of the kept planes
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
 constexpr int PS_T = 1024, PS_E = 23, PS_SHIFT = 19, PS_R = 24;
+constexpr int PS_HJOBS = 1024, PS_HCAP = 36864, PS_HY = 4;        // heap-sort fallback: jobs per frame, words of a job kept in LDS (144 KB: the top 15 levels of any heap), workgroups per frame
 using PsLds = isort::LdsLayout<PS_T, PS_E>;
 using PsGl = isort::GlobalLayout<PS_T>;
 constexpr int ERR_SORT = 5;
 
-struct Meta { int n_init, counts[2], err, M, npl, sort_status, pad; };
+struct Meta { int n_init, counts[2], err, M, npl, sort_status, heap_n; };
 
 __global__ __launch_bounds__(NT) void plane_voxels_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
                                                           const int* __restrict__ labels_all, const int* __restrict__ n_planes, unsigned char* ws_all, long long* timing) {
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(NT) void plane_voxels_kernel(Geo G, const unsigned 
             const int f = vstart[s_first[p]], l = vstart[s_last[p]];
             init[k++] = isort::Range{f, l, isort::depth_limit(l - f)};
         }
-        meta->n_init = k; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = npl; meta->sort_status = 0;
+        meta->n_init = k; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = npl; meta->sort_status = 0; meta->heap_n = 0;
     }
     mark(3);
 }
@@ -581,8 +582,9 @@ __global__ __launch_bounds__(PS_T) void plane_sort_global(Geo G, unsigned char* 
     unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
     Meta* meta = (Meta*)(ws + G.off_meta);
     if (meta->err || meta->n_init == 0) return;
+    const isort::HeapSink HS{(isort::HeapJob*)(ws + G.off_heapj), &meta->heap_n, PS_HJOBS};
     isort::global_tier<PS_SHIFT, PS_T>((uint32_t*)(ws + G.off_items), (const isort::Range*)(ws + G.off_init), meta->n_init, PsLds::N, 64, (isort::Range*)(ws + G.off_ranges),
-                                       (isort::Block*)(ws + G.off_blocks), isort::G_FMAX, meta->counts, sort_lds, rows_cap, &meta->sort_status);
+                                       (isort::Block*)(ws + G.off_blocks), isort::G_FMAX, meta->counts, sort_lds, rows_cap, HS, &meta->sort_status);
 }
 
 __global__ __launch_bounds__(PS_T) void plane_sort_lds(Geo G, unsigned char* ws_all) {
@@ -593,10 +595,20 @@ __global__ __launch_bounds__(PS_T) void plane_sort_lds(Geo G, unsigned char* ws_
     const isort::Range* ranges = (const isort::Range*)(ws + G.off_ranges);
     const isort::Block* blocks = (const isort::Block*)(ws + G.off_blocks);
     const int nb = meta->counts[1];
+    const isort::HeapSink HS{(isort::HeapJob*)(ws + G.off_heapj), &meta->heap_n, PS_HJOBS};
     for (int k = blockIdx.y; k < nb; k += gridDim.y) {
         const isort::Block K = blocks[k];
-        isort::lds_tier<PS_SHIFT, PS_T, PS_E>((uint32_t*)(ws + G.off_items), ranges + K.r0, K.nr, K.f, K.l, sort_lds, &meta->sort_status);
+        isort::lds_tier<PS_SHIFT, PS_T, PS_E>((uint32_t*)(ws + G.off_items), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &meta->sort_status);
     }
+}
+
+// the ranges whose introsort depth budget ran out: libstdc++'s heap sort, one wavefront per job (isort.h: level-parallel make_heap, pipelined sort_heap)
+__global__ __launch_bounds__(64) void plane_sort_heap(Geo G, unsigned char* ws_all) {
+    extern __shared__ __align__(16) uint8_t sort_lds[];
+    unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
+    const Meta* meta = (const Meta*)(ws + G.off_meta);
+    const int nj = meta->err ? 0 : min(meta->heap_n, PS_HJOBS);
+    if (nj) isort::heap_jobs<PS_SHIFT>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj), nj, blockIdx.y, gridDim.y, (uint32_t*)sort_lds, PS_HCAP);
 }
 
 // PlaneDetection::readDepthImage for one thread (no wave-level branch: callers are in divergent loops)
@@ -830,7 +842,7 @@ __global__ __launch_bounds__(NT) void cloud_voxels_kernel(Geo G, const float* __
     }
     if (tid == 0) {
         init[0] = isort::Range{0, n, isort::depth_limit(n)};
-        meta->n_init = (!err && n > 0) ? 1 : 0; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = 1; meta->sort_status = 0;
+        meta->n_init = (!err && n > 0) ? 1 : 0; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = 1; meta->sort_status = 0; meta->heap_n = 0;
     }
 }
 
@@ -914,6 +926,7 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
         G.off_meta = carve(sizeof(planepost::Meta));
         G.off_ranges = carve((size_t)isort::G_FMAX * sizeof(isort::Range));
         G.off_blocks = carve((size_t)isort::G_FMAX * sizeof(isort::Block));
+        G.off_heapj = carve((size_t)planepost::PS_HJOBS * sizeof(isort::HeapJob));
         G.off_items = carve(std::max((size_t)width * height, (size_t)65536) * 4);   // (voxel << 19 | pixel) per member pixel; the map-side merge sorts up to 65536 points here
         G.ws_stride = off;
     }
@@ -939,6 +952,7 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
         if (e == hipSuccess && p->smem_cloud > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::cloud_voxels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_cloud);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_g);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_l);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_heap, hipFuncAttributeMaxDynamicSharedMemorySize, planepost::PS_HCAP * 4);
         if (e != hipSuccess) { (void)hipGetLastError(); set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", std::max(std::max(p->smem, p->smem_cloud), p->smem_sort_g)); delete p; return PLANAR_EINVAL; }
     }
     *out = p;
@@ -959,6 +973,25 @@ int planar_plane_clouds_read_timing(planar_plane_clouds* p, int B, int64_t* out)
     PLANAR_REQUIRE(p && out && p->dbg.p && B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "timing not enabled / bad B");
     PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
     PLANAR_HIP_CHECK(hipMemcpy(out, p->dbg.p, (size_t)B * 128, hipMemcpyDeviceToHost));
+    return PLANAR_OK;
+}
+
+// diagnostics: per frame of the last call {ranges left to libstdc++'s heap-sort fallback, their elements, the longest, LDS-tier blocks}
+int planar_plane_clouds_sort_stats(planar_plane_clouds* p, int B, int64_t* out /* [B][4] */) {
+    PLANAR_REQUIRE(p && out && B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "bad argument");
+    PLANAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    std::vector<isort::HeapJob> jobs(planepost::PS_HJOBS);
+    for (int b = 0; b < B; b++) {
+        const unsigned char* ws = p->ws.as<unsigned char>() + (size_t)b * p->G.ws_stride;
+        planepost::Meta m;
+        PLANAR_HIP_CHECK(hipMemcpy(&m, ws + p->G.off_meta, sizeof(m), hipMemcpyDeviceToHost));
+        const int nj = std::min(m.heap_n, planepost::PS_HJOBS);
+        if (nj) PLANAR_HIP_CHECK(hipMemcpy(jobs.data(), ws + p->G.off_heapj, (size_t)nj * sizeof(isort::HeapJob), hipMemcpyDeviceToHost));
+        int64_t el = 0, mx = 0;
+        for (int j = 0; j < nj; j++) { el += jobs[j].l - jobs[j].f; mx = std::max<int64_t>(mx, jobs[j].l - jobs[j].f); }
+        out[b * 4] = m.heap_n; out[b * 4 + 1] = el; out[b * 4 + 2] = mx; out[b * 4 + 3] = m.counts[1];
+    }
     return PLANAR_OK;
 }
 
@@ -987,6 +1020,7 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     hipLaunchKernelGGL(planepost::plane_items_kernel, dim3(B), dim3(planepost::PS_T), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
     hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_R), dim3(planepost::PS_T), p->smem_sort_l, st, G, ws);
+    hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(B, planepost::PS_HY), dim3(64), planepost::PS_HCAP * 4, st, G, ws);
     hipLaunchKernelGGL(planepost::plane_tail_kernel, dim3(B), dim3(planepost::NT), p->smem_tail, st, G, d_depth, pitch_px, (long)frame_stride_px, d_planes,
                        planar_peac_max_planes(), p->rng.as<int>(), ws, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox, d_info, tm);
     PLANAR_HIP_CHECK(hipGetLastError());
@@ -1098,6 +1132,7 @@ int planar_merge_plane_points(planar_plane_clouds* p, const double* Twc, const f
     hipLaunchKernelGGL(planepost::cloud_voxels_kernel, dim3(1), dim3(planepost::NT), p->smem_cloud, st, G, s.dev<float>(t_all), n, ws);
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(1), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
     hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(1, planepost::PS_R), dim3(planepost::PS_T), p->smem_sort_l, st, G, ws);
+    hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(1, planepost::PS_HY), dim3(64), planepost::PS_HCAP * 4, st, G, ws);
     hipLaunchKernelGGL(planepost::cloud_sums_kernel, dim3(1), dim3(planepost::NT), 0, st, G, s.dev<float>(t_all), ws, s.dev<float>(t_out), s.dev<int>(o_h), s.dev<int>(o_h) + 1);
     PLANAR_HIP_CHECK(hipGetLastError());
     if ((rc = s.download(st))) return rc;

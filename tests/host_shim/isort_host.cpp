@@ -12,22 +12,29 @@
 using namespace planar::isort;
 
 namespace {
-struct GArgs { uint32_t* arr; const Range* init; int n_init, n_stage, nr_cap; Range* ranges; Block* blocks; int max_blocks; int* counts; int rows_cap; int* status; int shift; };
+struct GArgs { uint32_t* arr; const Range* init; int n_init, n_stage, nr_cap; Range* ranges; Block* blocks; int max_blocks; int* counts; int rows_cap; int* status; int shift; HeapSink HS; };
 template <int SHIFT, int T>
 void g_entry(void* p) {
     auto* A = (GArgs*)p;
     PLANAR_DYN_SMEM(lds);
-    global_tier<SHIFT, T>(A->arr, A->init, A->n_init, A->n_stage, A->nr_cap, A->ranges, A->blocks, A->max_blocks, A->counts, lds, A->rows_cap, A->status);
+    global_tier<SHIFT, T>(A->arr, A->init, A->n_init, A->n_stage, A->nr_cap, A->ranges, A->blocks, A->max_blocks, A->counts, lds, A->rows_cap, A->HS, A->status);
 }
-struct LArgs { uint32_t* arr; const Range* ranges; int nr, f, l; int* status; };
+struct LArgs { uint32_t* arr; const Range* ranges; int nr, f, l; int* status; HeapSink HS; };
+struct HArgs { uint32_t* arr; const HeapJob* jobs; int njobs, cap; };
+template <int SHIFT>
+void h_entry(void* p) {
+    auto* A = (HArgs*)p;
+    PLANAR_DYN_SMEM(lds);
+    heap_jobs<SHIFT>(A->arr, A->jobs, A->njobs, 0, 1, (uint32_t*)lds, A->cap);
+}
 template <int SHIFT, int T, int E>
 void l_entry(void* p) {
     auto* A = (LArgs*)p;
     PLANAR_DYN_SMEM(lds);
-    lds_tier<SHIFT, T, E>(A->arr, A->ranges, A->nr, A->f, A->l, lds, A->status);
+    lds_tier<SHIFT, T, E>(A->arr, A->ranges, A->nr, A->f, A->l, lds, A->HS, A->status);
 }
 template <int SHIFT, int TG, int T, int E>
-int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status, long* stats) {
+int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status, long* stats, int heap_cap = 36864) {
     std::vector<Range> init(n_ranges);
     int longest = 0;
     for (int i = 0; i < n_ranges; i++) {
@@ -41,16 +48,26 @@ int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status
     std::vector<Range> ranges(G_FMAX);
     std::vector<Block> blocks(G_FMAX);
     int counts[2] = {0, 0};
-    GArgs ga{arr, init.data(), n_ranges, n_stage, std::min(T, 64), ranges.data(), blocks.data(), G_FMAX, counts, rows_cap, status, SHIFT};
+    std::vector<HeapJob> jobs(4096);
+    int njobs = 0;
+    const HeapSink HS{jobs.data(), &njobs, (int)jobs.size()};
+    GArgs ga{arr, init.data(), n_ranges, n_stage, std::min(T, 64), ranges.data(), blocks.data(), G_FMAX, counts, rows_cap, status, SHIFT, HS};
     wave_emul::Dim3 bi, bd; bd.x = TG; bd.y = 1; bd.z = 1;
     wave_emul::launch_block(g_entry<SHIFT, TG>, &ga, TG, bi, bd, (size_t)GlobalLayout<TG>::bytes(rows_cap), 256 * 1024);
     if (stats) { stats[0] = counts[0]; stats[1] = counts[1]; stats[2] = wave_emul::S().n_sync; }
     bd.x = T;
     for (int b = 0; b < counts[1]; b++) {
-        LArgs la{arr, ranges.data() + blocks[b].r0, blocks[b].nr, blocks[b].f, blocks[b].l, status};
+        LArgs la{arr, ranges.data() + blocks[b].r0, blocks[b].nr, blocks[b].f, blocks[b].l, status, HS};
         wave_emul::launch_block(l_entry<SHIFT, T, E>, &la, T, bi, bd, (size_t)LdsLayout<T, E>::bytes, 256 * 1024);
     }
-    if (stats) { stats[3] = wave_emul::S().n_sync; stats[4] = g_levels; stats[5] = g_segs; stats[6] = g_heap; g_levels = 0; g_segs = 0; g_heap = 0; }
+    long heap_elems = 0;
+    for (int j = 0; j < std::min(njobs, (int)jobs.size()); j++) heap_elems += jobs[j].l - jobs[j].f;
+    if (njobs) {   // the fallback jobs: one wavefront; heap_cap words of the range in "LDS", the rest addressed in the array
+        HArgs ha{arr, jobs.data(), std::min(njobs, (int)jobs.size()), heap_cap};
+        bd.x = 64;
+        wave_emul::launch_block(h_entry<SHIFT>, &ha, 64, bi, bd, (size_t)heap_cap * 4, 256 * 1024);
+    }
+    if (stats) { stats[3] = wave_emul::S().n_sync; stats[4] = g_levels; stats[5] = g_segs; stats[6] = heap_elems; stats[7] = njobs; g_levels = 0; g_segs = 0; }
     return 0;
 }
 }  // namespace
@@ -59,7 +76,7 @@ extern "C" {
 // arr [total]: in/out.  bounds [n_ranges + 1]: every [bounds[i], bounds[i+1]) is sorted on its own, as std::sort(first, last, key <) would.
 // config 0: production shapes (global tier 1024 threads; LDS tier 1024 threads x 23 elements); 1: small shapes that force many levels and the
 // global tier on short arrays (256 threads; 256 x 5).  shift: 19 or 20.  n_stage: LDS-tier capacity override (0 = the configuration's).
-// Returns 0, or -1 with a message in err.  stats [7] (last: elements that went through the heap-sort fallback): ranges, blocks, rendezvous count after the global tier, after everything, LDS-tier levels, segments partitioned there.
+// Returns 0, or -1 with a message in err.  stats [8] (last two: elements that went through the heap-sort fallback, its jobs): ranges, blocks, rendezvous count after the global tier, after everything, LDS-tier levels, segments partitioned there.
 int isort_emul(uint32_t* arr, const int* bounds, int n_ranges, int shift, int config, int n_stage, int* status, long* stats, char* err, int errlen) {
     try {
         *status = 0;
@@ -68,6 +85,7 @@ int isort_emul(uint32_t* arr, const int* bounds, int n_ranges, int shift, int co
         if (shift == 19 && config == 1) return run<19, 256, 256, 5>(arr, bounds, n_ranges, n_stage, status, stats);
         if (shift == 20 && config == 1) return run<20, 256, 256, 5>(arr, bounds, n_ranges, n_stage, status, stats);
         if (shift == 19 && config == 2) return run<19, 256, 128, 32>(arr, bounds, n_ranges, n_stage, status, stats);
+        if (shift == 19 && config == 3) return run<19, 1024, 1024, 23>(arr, bounds, n_ranges, n_stage, status, stats, 1000);   // fallback jobs with only 1000 words in LDS
         throw std::runtime_error("isort_emul: unknown configuration");
     } catch (const std::exception& e) { snprintf(err, errlen, "%s", e.what()); return -1; }
 }

@@ -34,7 +34,7 @@ def _check(E, keys, bounds, shift, config, n_stage=0):
     want = arr.copy()
     b = np.asarray(bounds, np.int32)
     E.isort_std_sort(want.ctypes.data, b.ctypes.data, len(b) - 1, shift)
-    status = C.c_int(-1); stats = np.zeros(7, np.int64); err = C.create_string_buffer(512)
+    status = C.c_int(-1); stats = np.zeros(8, np.int64); err = C.create_string_buffer(512)
     rc = E.isort_emul(arr.ctypes.data, b.ctypes.data, len(b) - 1, shift, config, n_stage, C.byref(status), stats.ctypes.data, err, 512)
     assert rc == 0, err.value.decode()
     assert status.value == 0, f"engine status {status.value}"
@@ -118,7 +118,10 @@ def test_heap_sort_fallback_on_real_plane_keys(lib):
     assert max(sizes) > 200000
     bounds = np.concatenate([[0], np.cumsum(sizes)])
     off = np.concatenate([[0], np.cumsum([k.max() + 1 for k in ks])])[:-1]
-    _check(lib, np.concatenate([k + o for k, o in zip(ks, off)]), bounds, 19, 0)
+    keys = np.concatenate([k + o for k, o in zip(ks, off)])
+    st = _check(lib, keys, bounds, 19, 0)
+    assert st[7] > 100 and st[6] > 50000, st                      # hundreds of fallback ranges, the longest tens of thousands of elements
+    _check(lib, keys, bounds, 19, 3)                             # the same with only 1000 words of every fallback range in LDS (the rest in the array)
     # and with the fallback inside LDS blocks (small capacity -> short ranges reach depth 0 there)
     ks = _plane_voxel_keys(705, True)
     bounds = np.concatenate([[0], np.cumsum([len(k) for k in ks])])

@@ -10,7 +10,7 @@ using namespace planar::isort;
 constexpr int T = 1024, E = 23, SHIFT = 19;
 __global__ __launch_bounds__(T) void k(uint32_t* arr, const Range* r, int nr, int n, int* status) {
     extern __shared__ __align__(16) uint8_t lds[];
-    lds_tier<SHIFT, T, E>(arr + (size_t)blockIdx.x * n, r, nr, 0, n, lds, status);
+    static __device__ HeapJob hj[64]; static __device__ int hn; const HeapSink HS{hj, &hn, 64}; lds_tier<SHIFT, T, E>(arr + (size_t)blockIdx.x * n, r, nr, 0, n, lds, HS, status);
 }
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : T * E, nkeys = argc > 2 ? atoi(argv[2]) : 1024, NB = argc > 3 ? atoi(argv[3]) : 1;
