@@ -165,83 +165,87 @@ __device__ __forceinline__ void push_heap_job(const HeapSink& H, int f, int l, i
 }
 constexpr int HP = 8;                  // pops in flight (heap depth <= 16 levels, two levels apart)
 
-struct HeapMem {                       // element i of the range: LDS below cap, the array itself (global memory) above
+template <bool HYBRID>
+struct HeapMem {                       // element i of the range: LDS below cap, the array itself (global memory) above (HYBRID), or all of it in LDS
     uint32_t* lds; uint32_t* glb; int cap;
-    __device__ __forceinline__ uint32_t ld(int i) const { return i < cap ? lds[i] : glb[i]; }
-    __device__ __forceinline__ void st(int i, uint32_t x) const { if (i < cap) lds[i] = x; else glb[i] = x; }
+    __device__ __forceinline__ uint32_t ld(int i) const { if (HYBRID) return i < cap ? lds[i] : glb[i]; return lds[i]; }
+    __device__ __forceinline__ void st(int i, uint32_t x) const { if (HYBRID) { if (i < cap) lds[i] = x; else glb[i] = x; } else lds[i] = x; }
+    __device__ __forceinline__ void sync() const {   // one wavefront: LDS accesses execute in order; its global stores have to land before another lane's load
+        if (HYBRID) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 };
 __device__ __forceinline__ int heap_level(int i) { return 31 - __clz(i + 1); }
 
-// one step of a top-down sift in a heap of `len` elements: the hole h takes its larger child if that child is not smaller than the value (-> true, h moves
-// down), else the value (-> false: finished)
-template <int SHIFT>
-__device__ __forceinline__ bool sift_step(const HeapMem& M, int& h, int len, uint32_t v) {
-    const int c = 2 * h + 2;
-    uint32_t pick = 0;
-    int pi = -1;
-    if (c < len) { const uint32_t r = M.ld(c), l = M.ld(c - 1); if ((r >> SHIFT) < (l >> SHIFT)) { pick = l; pi = c - 1; } else { pick = r; pi = c; } }
-    else if (c == len) { pick = M.ld(c - 1); pi = c - 1; }
-    if (pi >= 0 && !((pick >> SHIFT) < (v >> SHIFT))) { M.st(h, pick); h = pi; return true; }
-    M.st(h, v);
-    return false;
+// one step of a top-down sift in a heap of `len` elements: the hole h takes its larger child (the right one on ties) if that child is not smaller than the
+// value (-> true, h moves down), else the value (-> false: finished).  Branch-free: a lone wavefront pays ~8 cycles per instruction, whatever it is.
+template <int SHIFT, bool HYBRID>
+__device__ __forceinline__ bool sift_step(const HeapMem<HYBRID>& M, int& h, int len, uint32_t v) {
+    const int c = 2 * h + 2, last = len - 1;
+    const uint32_t r = M.ld(min(c, max(last, 0))), l = M.ld(min(c - 1, max(last, 0)));
+    const bool has_l = c - 1 < len, take_r = c < len && !((r >> SHIFT) < (l >> SHIFT));
+    const uint32_t pick = take_r ? r : l;
+    const bool cont = has_l && !((pick >> SHIFT) < (v >> SHIFT));
+    M.st(h, cont ? pick : v);
+    h = cont ? (take_r ? c : c - 1) : h;
+    return cont;
 }
 
-// heap-sorts the k elements behind M (one wavefront calls it; `sync` orders its LDS / global accesses)
-template <int SHIFT>
-__device__ __forceinline__ void heap_sort_wave(const HeapMem& M, int k) {
+// heap-sorts the k elements behind M (one wavefront calls it)
+template <int SHIFT, bool HYBRID>
+__device__ __forceinline__ void heap_sort_wave(const HeapMem<HYBRID>& M, int k) {
     const int lane = threadIdx.x & 63;
-    auto wsync = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); };   // (one wavefront: orders its own LDS / global accesses)
     if (k < 2) return;
     // __make_heap: depth by depth from the last parent's, one lane per node
     for (int dd = heap_level((k - 2) / 2); dd >= 0; dd--) {
         const int first = (1 << dd) - 1, last = min((1 << (dd + 1)) - 2, (k - 2) / 2);
         for (int i0 = first; i0 <= last; i0 += 64) {
-            int h = i0 + lane;
-            const bool on = h <= last;
-            const uint32_t v = on ? M.ld(h) : 0u;
-            bool go = on;
-            while (__ballot(go) != 0ull) { if (go) go = sift_step<SHIFT>(M, h, k, v); }
+            int h = min(i0 + lane, last);
+            const uint32_t v = M.ld(h);
+            bool go = i0 + lane <= last;
+            while (__ballot(go) != 0ull) { if (go) go = sift_step<SHIFT, HYBRID>(M, h, k, v); }
         }
-        wsync();
+        M.sync();
     }
     // __sort_heap: pop t (t = 0 .. k - 2) takes the last element z = k - 1 - t of the heap as its value, puts the root there and sifts in the heap of z
     // elements; lane t % HP runs it, one level per step, started at least two steps after pop t - 1: by construction it reads at level j + 1 what its
     // predecessor wrote two or more steps ago, and nothing else has to be checked from step to step.
     bool on = false;                       // this lane has a pop in flight
-    int h = 0, len = 0;                    // its hole, its heap size
+    int h = 0, lv = 0, len = 0;            // its hole, the hole's level, its heap size
     uint32_t v = 0;
     int next = 0, gap = 2;                 // the next pop to start, steps since the last start (uniform)
     while (true) {
         if (next <= k - 2 && gap >= 2) {
             // ... unless a pop in flight can still reach z (its hole is z or one of z's ancestors: it may yet write there), or the lane is still busy
             const int z = k - 1 - next, zl = heap_level(z), owner = next % HP;
-            bool blocks = false;
-            if (on) { const int hl = heap_level(h); blocks = lane == owner || (hl <= zl && ((z + 1) >> (zl - hl)) == h + 1); }
+            const bool blocks = on && (lane == owner || (lv <= zl && ((z + 1) >> (zl - min(lv, zl))) == h + 1));
             if (__ballot(blocks) == 0ull) {
                 const uint32_t vz = M.ld(z), root = M.ld(0);
-                if (lane == owner) { on = true; h = 0; len = z; v = vz; M.st(z, root); }
-                wsync();
+                if (lane == owner) { on = true; h = 0; lv = 0; len = z; v = vz; M.st(z, root); }
+                M.sync();
                 next++; gap = 0;
             }
         }
-        if (on) on = sift_step<SHIFT>(M, h, len, v);
-        wsync();
+        if (on) { on = sift_step<SHIFT, HYBRID>(M, h, len, v); lv++; }
+        M.sync();
         gap++;
         if (next > k - 2 && __ballot(on) == 0ull) break;
     }
 }
 
-// The jobs first, first + stride, ... of an array, by one wavefront (a workgroup of 64 threads); lds: cap 32-bit words
+// The jobs first, first + stride, ... of a job list whose ranges hold min_len .. max_len elements, by one wavefront; lds: cap 32-bit words of this
+// wavefront.  A range longer than cap keeps its first cap elements (the top of the heap) in LDS and the rest in place.
 template <int SHIFT>
-__device__ void heap_jobs(uint32_t* __restrict__ arr, const HeapJob* __restrict__ jobs, int njobs, int first, int stride, uint32_t* lds, int cap) {
+__device__ void heap_jobs(uint32_t* __restrict__ arr, const HeapJob* __restrict__ jobs, int njobs, int first, int stride, uint32_t* lds, int cap, int min_len, int max_len) {
     const int lane = threadIdx.x & 63;
     for (int j = first; j < njobs; j += stride) {
         const HeapJob J = jobs[j];
         const int k = J.l - J.f, in_lds = min(k, cap);
+        if (k < min_len || k > max_len) continue;
         for (int i = lane; i < in_lds; i += 64) lds[i] = arr[J.f + i];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
-        const HeapMem M{lds, arr + J.f, cap};
-        heap_sort_wave<SHIFT>(M, k);
+        if (k <= cap) { const HeapMem<false> M{lds, arr + J.f, cap}; heap_sort_wave<SHIFT, false>(M, k); }
+        else { const HeapMem<true> M{lds, arr + J.f, cap}; heap_sort_wave<SHIFT, true>(M, k); }
         for (int i = lane; i < in_lds; i += 64) arr[J.f + i] = lds[i];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
     }

@@ -189,9 +189,9 @@ __device__ __forceinline__ void lds_sync();
 //   lsd_sort_lds      one workgroup per block of <= 23 552 words, up to SORT_R per frame: everything below, in LDS, written back sorted;
 //   lsd_sort_compact  one workgroup per frame: drops the undefined pixels (they took part in the partitions), numbers the rest.
 // Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py) and on the emulator (tests/test_isort_emul.py).
-constexpr int SORT_T = 1024, SORT_E = 23, SORT_SHIFT = 20, SORT_R = 16;
+constexpr int SORT_T = 1024, SORT_LT = 256, SORT_E = 23, SORT_SHIFT = 20, SORT_R = 64;      // SORT_T: threads of the global tier and the compaction; SORT_LT x SORT_E: an LDS block
 constexpr int SORT_HJOBS = 1024, SORT_HCAP = 8192, SORT_HY = 2;       // heap-sort fallback: jobs per frame, words of a job kept in LDS, workgroups per frame
-using SortLds = isort::LdsLayout<SORT_T, SORT_E>;
+using SortLds = isort::LdsLayout<SORT_LT, SORT_E>;
 using SortGl = isort::GlobalLayout<SORT_T>;
 
 __global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int rows_cap) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict
     if (tid == 0) misc->t[5] = __builtin_readcyclecounter() - ts0;
 }
 
-__global__ __launch_bounds__(SORT_T) void lsd_sort_lds(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+__global__ __launch_bounds__(SORT_LT) void lsd_sort_lds(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     const Plan& P = *plan;
     const int b = blockIdx.x;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_lds(const Plan* __restrict__ 
     const long long ts0 = __builtin_readcyclecounter();
     for (int k = blockIdx.y; k < nb; k += gridDim.y) {
         const isort::Block K = blocks[k];
-        isort::lds_tier<SORT_SHIFT, SORT_T, SORT_E>((uint32_t*)(F + P.off_tmp), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &misc->status);
+        isort::lds_tier<SORT_SHIFT, SORT_LT, SORT_E>((uint32_t*)(F + P.off_tmp), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &misc->status);
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) misc->t[6] = __builtin_readcyclecounter() - ts0;
 }
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) void lsd_sort_heap(const Plan* __restrict__ pla
     const Plan& P = *plan;
     uint8_t* F = ws + (size_t)blockIdx.x * P.frame_bytes;
     const int nj = min(miscs[blockIdx.x].heap_n, SORT_HJOBS);
-    if (nj) isort::heap_jobs<SORT_SHIFT>((uint32_t*)(F + P.off_tmp), (const isort::HeapJob*)(F + P.off_heapj), nj, blockIdx.y, gridDim.y, (uint32_t*)sort_lds, SORT_HCAP);
+    if (nj) isort::heap_jobs<SORT_SHIFT>((uint32_t*)(F + P.off_tmp), (const isort::HeapJob*)(F + P.off_heapj), nj, blockIdx.y, gridDim.y, (uint32_t*)sort_lds, SORT_HCAP, 0, 1 << 30);
 }
 
 __global__ __launch_bounds__(SORT_T) void lsd_sort_compact(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
@@ -1486,7 +1486,7 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     if (o->tie_order != 0) hipLaunchKernelGGL(lsd::lsd_sort_raster, dim3(B), dim3(lsd::SORT_NT), 0, st, dP, ws, dm);
     else {
         hipLaunchKernelGGL(lsd::lsd_sort_global, dim3(B), dim3(lsd::SORT_T), o->sort_smem_g, st, dP, ws, dm, o->sort_rows);
-        hipLaunchKernelGGL(lsd::lsd_sort_lds, dim3(B, lsd::SORT_R), dim3(lsd::SORT_T), o->sort_smem_l, st, dP, ws, dm);
+        hipLaunchKernelGGL(lsd::lsd_sort_lds, dim3(B, lsd::SORT_R), dim3(lsd::SORT_LT), o->sort_smem_l, st, dP, ws, dm);
         hipLaunchKernelGGL(lsd::lsd_sort_heap, dim3(B, lsd::SORT_HY), dim3(64), lsd::SORT_HCAP * 4, st, dP, ws, dm);
         hipLaunchKernelGGL(lsd::lsd_sort_compact, dim3(B), dim3(lsd::SORT_T), 0, st, dP, ws, dm);
     }

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace planar {
 namespace planepost {
@@ -310,7 +311,11 @@ __device__ __forceinline__ void bitonic(unsigned long long* a, int n2) {
 //                         wavefront per plane) and the compaction of the kept planes
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
 constexpr int PS_T = 1024, PS_E = 23, PS_SHIFT = 19, PS_R = 24;
-constexpr int PS_HJOBS = 1024, PS_HCAP = 36864, PS_HY = 4;        // heap-sort fallback: jobs per frame, words of a job kept in LDS (144 KB: the top 15 levels of any heap), workgroups per frame
+constexpr int PS_HJOBS = 1024;                                     // heap-sort fallback: jobs per frame
+// ... run in three launches by size, so that the many short ranges do not each hold a CU's LDS: (longest range, words of LDS per wavefront, wavefronts
+// per workgroup, workgroups per frame); a range longer than the last class's LDS keeps the top of its heap there and the rest in place
+struct HeapClass { int max_len, cap, waves, wgs; };
+constexpr HeapClass PS_HC[3] = {{2048, 2048, 4, 1}, {16384, 16384, 1, 2}, {1 << 30, 36864, 1, 2}};
 using PsLds = isort::LdsLayout<PS_T, PS_E>;
 using PsGl = isort::GlobalLayout<PS_T>;
 constexpr int ERR_SORT = 5;
@@ -603,12 +608,13 @@ __global__ __launch_bounds__(PS_T) void plane_sort_lds(Geo G, unsigned char* ws_
 }
 
 // the ranges whose introsort depth budget ran out: libstdc++'s heap sort, one wavefront per job (isort.h: level-parallel make_heap, pipelined sort_heap)
-__global__ __launch_bounds__(64) void plane_sort_heap(Geo G, unsigned char* ws_all) {
+__global__ __launch_bounds__(256) void plane_sort_heap(Geo G, unsigned char* ws_all, int min_len, int max_len, int cap) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
     const Meta* meta = (const Meta*)(ws + G.off_meta);
-    const int nj = meta->err ? 0 : min(meta->heap_n, PS_HJOBS);
-    if (nj) isort::heap_jobs<PS_SHIFT>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj), nj, blockIdx.y, gridDim.y, (uint32_t*)sort_lds, PS_HCAP);
+    const int nj = meta->err ? 0 : min(meta->heap_n, PS_HJOBS), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (nj) isort::heap_jobs<PS_SHIFT>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj), nj, blockIdx.y * nw + wave, gridDim.y * nw,
+                                       (uint32_t*)sort_lds + (size_t)wave * cap, cap, min_len, max_len);
 }
 
 // PlaneDetection::readDepthImage for one thread (no wave-level branch: callers are in divergent loops)
@@ -952,7 +958,7 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
         if (e == hipSuccess && p->smem_cloud > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::cloud_voxels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_cloud);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_g);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_l);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_heap, hipFuncAttributeMaxDynamicSharedMemorySize, planepost::PS_HCAP * 4);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_heap, hipFuncAttributeMaxDynamicSharedMemorySize, planepost::PS_HC[2].cap * 4);
         if (e != hipSuccess) { (void)hipGetLastError(); set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", std::max(std::max(p->smem, p->smem_cloud), p->smem_sort_g)); delete p; return PLANAR_EINVAL; }
     }
     *out = p;
@@ -1020,7 +1026,10 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     hipLaunchKernelGGL(planepost::plane_items_kernel, dim3(B), dim3(planepost::PS_T), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
     hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_R), dim3(planepost::PS_T), p->smem_sort_l, st, G, ws);
-    hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(B, planepost::PS_HY), dim3(64), planepost::PS_HCAP * 4, st, G, ws);
+    for (int c = 0; c < 3 && !getenv("PLANAR_DEV_SKIP_HEAP"); c++) {   // (the environment variable: a developer's timing experiment, results are then wrong)
+        const planepost::HeapClass& H = planepost::PS_HC[c];
+        hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(B, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
+    }
     hipLaunchKernelGGL(planepost::plane_tail_kernel, dim3(B), dim3(planepost::NT), p->smem_tail, st, G, d_depth, pitch_px, (long)frame_stride_px, d_planes,
                        planar_peac_max_planes(), p->rng.as<int>(), ws, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox, d_info, tm);
     PLANAR_HIP_CHECK(hipGetLastError());
@@ -1132,7 +1141,10 @@ int planar_merge_plane_points(planar_plane_clouds* p, const double* Twc, const f
     hipLaunchKernelGGL(planepost::cloud_voxels_kernel, dim3(1), dim3(planepost::NT), p->smem_cloud, st, G, s.dev<float>(t_all), n, ws);
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(1), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
     hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(1, planepost::PS_R), dim3(planepost::PS_T), p->smem_sort_l, st, G, ws);
-    hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(1, planepost::PS_HY), dim3(64), planepost::PS_HCAP * 4, st, G, ws);
+    for (int c = 0; c < 3 && !getenv("PLANAR_DEV_SKIP_HEAP"); c++) {   // (the environment variable: a developer's timing experiment, results are then wrong)
+        const planepost::HeapClass& H = planepost::PS_HC[c];
+        hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(1, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
+    }
     hipLaunchKernelGGL(planepost::cloud_sums_kernel, dim3(1), dim3(planepost::NT), 0, st, G, s.dev<float>(t_all), ws, s.dev<float>(t_out), s.dev<int>(o_h), s.dev<int>(o_h) + 1);
     PLANAR_HIP_CHECK(hipGetLastError());
     if ((rc = s.download(st))) return rc;

@@ -25,7 +25,7 @@ template <int SHIFT>
 void h_entry(void* p) {
     auto* A = (HArgs*)p;
     PLANAR_DYN_SMEM(lds);
-    heap_jobs<SHIFT>(A->arr, A->jobs, A->njobs, 0, 1, (uint32_t*)lds, A->cap);
+    heap_jobs<SHIFT>(A->arr, A->jobs, A->njobs, 0, 1, (uint32_t*)lds, A->cap, 0, 1 << 30);
 }
 template <int SHIFT, int T, int E>
 void l_entry(void* p) {
