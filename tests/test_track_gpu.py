@@ -17,8 +17,7 @@ pytestmark = pytest.mark.gpu
 B, W, H, MARGIN, STEPS, DEPTH = 64, 640, 480, 48, 5, 2
 
 
-@pytest.fixture(scope="module")
-def run():
+def run_pipeline():
     import torch
     from planarslam_amd.synth import stream_canvases
     from planarslam_amd.track import TrackPipeline, build_map
@@ -57,6 +56,44 @@ def run():
     tp.check()
     cap = {j: {k: ({kk: vv.cpu().numpy() for kk, vv in v.items()} if isinstance(v, dict) else v.cpu().numpy()) for k, v in c.items()} for j, c in tp.captured.items()}
     return dict(tp=tp, cap=cap, inputs=inputs, maps=maps, S=tp.S, PS=tp.PS, sf=np.asarray(tp.sf, np.float32), lsf=tp.lsf)
+
+
+@pytest.fixture(scope="module")
+def run():
+    return run_pipeline()
+
+
+def oracle_chain_coefficients(c, d):
+    """Frame::mvPlaneCoefficients of the oracle's own plane chain for every frame of a captured step"""
+    coef_o = np.zeros_like(c["pl_coef"])
+    for b in range(B):
+        npl = int(c["npl"][b])
+        want = ol.plane_clouds(d[b], c["lab"][b].reshape(H, W), c["pls"][b, :npl])
+        coef_o[b, :want["n"]] = want["coef"]
+    return coef_o
+
+
+KEYS_P = ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid", "ln_obs", "ln_xw", "pl_meas", "pl_valid", "pl_world")
+GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "track_pose_ref.npz")
+
+
+def _real_optimiser(pb, mode, tag):
+    """The captured problems through the REAL Optimizer::PoseOptimization / TranslationOptimization (oracle/_ref/ref_opt: src/Optimizer.cc:550-1275,
+    2995-3738 + the vendored g2o, compiled where they lie).  Where the binary did not travel, the committed fixture of its outputs on these very problems
+    (tools/gen_golden_track_pose.py; the pipeline is deterministic, the problems are checked by a digest)."""
+    import hashlib
+    import os
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(pb[k]).tobytes() for k in KEYS_P + ("Tcw",))).hexdigest()
+    if os.path.exists(ol.ref_opt_path()):
+        r = ol.run_ref_pose(pb, TUM3, mode)
+        return dict(r, digest=digest, source="ref_opt")
+    z = np.load(GOLDEN)
+    assert str(z[tag + "/digest"]) == digest, "the captured problem is not the one the fixture was made from"
+    MP, ML, MM = pb["pt_valid"].shape[1], pb["ln_valid"].shape[1], pb["pl_valid"].shape[1]
+    nb = len(pb["n_points"])
+    return dict(Tcw=z[tag + "/Tcw"], n_inliers=z[tag + "/n_inliers"], pt_outlier=np.unpackbits(z[tag + "/pt_outlier"])[:nb * MP].reshape(nb, MP),
+                ln_outlier=np.unpackbits(z[tag + "/ln_outlier"])[:nb * ML].reshape(nb, ML), pl_outlier=np.unpackbits(z[tag + "/pl_outlier"])[:nb * MM * 3].reshape(nb, MM, 3),
+                digest=digest, source="fixture")
 
 
 def _frame_dict(c, Tcw, blocked=None):
@@ -129,13 +166,13 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
         want = ol.plane_clouds(d[b], c["lab"][b].reshape(H, W), c["pls"][b, :npl])
         k = want["n"]
         assert int(c["pl_n"][b]) == k and np.array_equal(c["pl_src"][b, :k], want["src"]) and np.array_equal(c["pl_off"][b, :k + 1], want["pt_off"])
-        assert np.abs(c["pl_pts"][b, :want["pt_off"][k]] - want["points"]).max(initial=0) < 2e-5
-        for q in range(k):                      # the refit equals the oracle's on the kernel's own cloud (tests/test_planepost_gpu.py explains the two tolerances)
+        assert np.array_equal(c["pl_pts"][b, :want["pt_off"][k]], want["points"])      # PCL's float sums in std::sort's order: every bit
+        for q in range(k):                      # the refit equals the oracle's on the (identical) cloud
             P = c["pls"][b, want["src"][q]]
             c0 = np.array([P[1], P[2], P[3], -(P[1] * P[4] + P[2] * P[5] + P[3] * P[6])]).astype(np.float32)
             st, pl, _ = ol.plane_refit(c0, c["pl_pts"][b, want["pt_off"][q]:want["pt_off"][q + 1]], 0.05)
             assert st == 0 and np.abs(pl - c["pl_coef"][b, q]).max() < 1e-6
-        assert np.abs(c["pl_coef"][b, :k] - want["coef"]).max(initial=0) < 2e-3
+        assert np.abs(c["pl_coef"][b, :k] - want["coef"]).max(initial=0) <= 1e-6
     coef = c["pl_coef"]
     a, v, p, npm = ol.plane_search_by_coefficients(dict(n=c["pl_n"], coef=coef, Tcw=c["pose_in"]), dict(n=mp["n"], valid=mp["valid"], coef=mp["coef"], npts=mp["npts"], pts=mp["pts"]))
     assert np.array_equal(a, c["plm"][0]) and np.array_equal(p, c["plm"][1]) and np.array_equal(v, c["plm"][2]) and np.array_equal(npm, c["nplm"])
@@ -149,12 +186,19 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
         assert np.array_equal(T["pt_valid"][b, :n] > 0, ok)
         assert np.array_equal(T["pt_xw"][b, :n][ok], c["last_xw"][b][c["pm0"][b, :n][ok]])
         assert np.array_equal(T["pt_obs"][b, :n, 0], keys["x"][b, :n]) and np.array_equal(T["pt_obs"][b, :n, 2], c["ur"][b, :n])
-    pbT = {k: T[k] for k in ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid", "ln_obs", "ln_xw", "pl_meas", "pl_valid", "pl_world")}
+    pbT = {k: T[k] for k in KEYS_P}
     pbT["Tcw"] = T["Tcw_in"]
+    # the REAL TranslationOptimization on the captured problems: 1e-5 on EVERY frame, identical inlier counts and outlier flags
+    r = _real_optimiser(pbT, 1, f"step{which}/T")
+    dT = np.abs(r["Tcw"] - T["Tcw_out"]).max(1)
+    assert dT.max() <= 1e-5, (r["source"], float(dT.max()), np.nonzero(dT > 1e-5)[0].tolist())
+    assert np.array_equal(r["n_inliers"], T["n_inliers"])
+    # ... and the restating oracle (whose LM trial sequence may differ from g2o's on flat minima: a weaker witness, kept for the CPU-only picture)
     w = ol.pose_optimize(pbT, TUM3, 1, 4, 10)
-    dT = np.abs(w["Tcw"] - T["Tcw_out"]).max(1)
-    same_its = w["lm_iters"] == T["lm_iters"]
-    assert (dT <= 1e-5).mean() >= 0.95 and dT.max() <= 1e-4 and np.array_equal(w["n_inliers"], T["n_inliers"])   # (iteration counts differ in ~10 % of the frames: knife-edge stop tests)
+    dTo = np.abs(w["Tcw"] - T["Tcw_out"]).max(1)
+    assert (dTo <= 1e-5).mean() >= 0.95 and dTo.max() <= 1e-4 and np.array_equal(w["n_inliers"], T["n_inliers"])
+    vT = T["pt_valid"] > 0
+    assert np.array_equal(r["pt_outlier"][vT] > 0, w["pt_outlier"][vT] > 0)
     # (the device cleared the flags of the matches it then dropped; compare what the optimiser wrote through the matches that survived)
     dropped = (c["pm0"] >= 0) & (c["pm1"] < 0)
     assert np.array_equal(dropped, (w["pt_outlier"] > 0) & (c["pm0"] >= 0))
@@ -185,19 +229,23 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
     want_all = np.where(c["pm1"] >= 0, c["pm1"], np.where(c["mm"] >= 0, c["mm"] + S, -1))
     assert np.array_equal(want_all, c["pm_all"])
     Pp = c["pbP"]
-    pbP = {k: Pp[k] for k in ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid", "ln_obs", "ln_xw", "pl_meas", "pl_valid", "pl_world")}
+    pbP = {k: Pp[k] for k in KEYS_P}
     pbP["Tcw"] = Pp["Tcw_in"]
     assert np.array_equal(Pp["Tcw_in"], T1)
-    w = ol.pose_optimize(pbP, TUM3, 0, 4, 10)
-    dT = np.abs(w["Tcw"] - Pp["Tcw_out"]).max(1)
-    same_its = w["lm_iters"] == Pp["lm_iters"]
-    # At a flat minimum the accept / reject decisions of the LM trials (rho > 0 on chi2 differences in the 9th digit) are knife edges: the device, the
-    # oracle and the reference's own g2o (checked on such a frame: device - reference 5e-10, oracle - reference 1.4e-5) can take different
-    # trial sequences to equivalent poses ~1e-5 apart.  1e-5 for at least 95 % of the frames, 1e-4 for every frame, identical inlier counts.
-    assert (dT <= 1e-5).mean() >= 0.95 and dT.max() <= 1e-4
-    assert np.array_equal(w["n_inliers"], Pp["n_inliers"])
+    # the REAL PoseOptimization on the captured problems: 1e-5 on EVERY frame, identical inlier counts and outlier flags (src/Optimizer.cc:550-1275)
+    r = _real_optimiser(pbP, 0, f"step{which}/P")
+    dT = np.abs(r["Tcw"] - Pp["Tcw_out"]).max(1)
+    assert dT.max() <= 1e-5, (r["source"], float(dT.max()), np.nonzero(dT > 1e-5)[0].tolist())
+    assert np.array_equal(r["n_inliers"], Pp["n_inliers"])
     v = Pp["pt_valid"] > 0
-    assert np.array_equal(w["pt_outlier"][v], Pp["pt_outlier"][v])          # rows without a map point are never written
+    assert np.array_equal(r["pt_outlier"][v] > 0, Pp["pt_outlier"][v] > 0)          # rows without a map point are never written
+    # the restating oracle: at a flat minimum the accept / reject decisions of the LM trials (rho > 0 on chi2 differences in the 9th digit) are knife edges
+    # and its trial sequence can differ from g2o's (poses ~1e-5 apart): a weaker witness than the real optimiser above
+    w = ol.pose_optimize(pbP, TUM3, 0, 4, 10)
+    dTo = np.abs(w["Tcw"] - Pp["Tcw_out"]).max(1)
+    assert (dTo <= 1e-5).mean() >= 0.95 and dTo.max() <= 1e-4
+    assert np.array_equal(w["n_inliers"], Pp["n_inliers"])
+    assert np.array_equal(w["pt_outlier"][v], Pp["pt_outlier"][v])
     assert np.array_equal(c["pose_out"], Pp["Tcw_out"]) and Pp["n_inliers"].mean() > 300
     for b in range(0, B, 13):
         n = int(c["n"][b])
@@ -213,14 +261,11 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
 
 @pytest.mark.parametrize("which", [0, 1])
 def test_pose_with_the_oracles_own_plane_chain(run, which):
-    """SURVEY §8 f4, end to end.  The device's voxel centroids are the correctly rounded exact means; PCL (and the oracle) sum floats in std::sort order, so
-    the centroids differ in the last bit and - the reference's single-pass float covariance being ulp-sensitive - the refitted mvPlaneCoefficients by up
-    to ~1e-3 on some planes (tests/test_planepost_gpu.py).  What the tracker consumes must not notice: with the ORACLE's own plane chain (its clouds, its
-    refit) in place of the device's, PlaneMatcher makes the same associations on every frame, both optimisers keep identical inlier / outlier sets, and
-    TranslationOptimization returns the device's pose within 1e-5 on every frame (largest gap 5e-7).  PoseOptimization: within 1e-5 on >= 90 % of the
-    frames and within 5e-5 on all of them - MEASURED: 2-4 of 64 frames land 1.1e-5 .. 2.2e-5 apart, and the same optimiser fed the two chains shows the
-    same gap, i.e. on those frames the plane chain (not an LM knife edge) moves the pose past north_star's 1e-5.  Closing that needs PCL's within-voxel
-    summation order (libstdc++'s introsort order of every plane's index vector) on the device: DESIGN.md §7."""
+    """SURVEY §8 f4, end to end.  PCL (and the oracle) add a voxel's points up as floats in the order std::sort leaves them; since round 4 the device
+    reproduces that order (isort.h, libstdc++'s heap-sort fallback included), so its centroids are the oracle's bit for bit and its refitted
+    mvPlaneCoefficients the oracle's to 1e-6.  With the ORACLE's own plane chain in place of the device's, PlaneMatcher makes the same associations on every
+    frame and the REAL optimisers (oracle/_ref/ref_opt) return the device's pose within 1e-5 on EVERY frame, for both TranslationOptimization and
+    PoseOptimization, with identical inlier counts and outlier flags."""
     j = STEPS - 2 + which
     c, (g, d) = run["cap"][j], run["inputs"][j]
     kf, mp, sn = run["maps"]
@@ -231,36 +276,26 @@ def test_pose_with_the_oracles_own_plane_chain(run, which):
         want = ol.plane_clouds(d[b], c["lab"][b].reshape(H, W), c["pls"][b, :npl])
         k = want["n"]
         assert int(c["pl_n"][b]) == k and np.array_equal(c["pl_src"][b, :k], want["src"])
+        assert np.array_equal(c["pl_pts"][b, :want["pt_off"][k]], want["points"]), b
         coef_o[b, :k] = want["coef"]
         worst = max(worst, float(np.abs(c["pl_coef"][b, :k] - want["coef"]).max(initial=0)))
-    assert worst < 5e-3                                     # (how far apart the two chains' coefficients are on these frames: reported by -v on failure)
+    assert worst <= 1e-6, worst
     # PlaneMatcher::SearchMapByCoefficients on the oracle's coefficients: the device's associations (plane, parallel, vertical), frame by frame
     a, v, p, npm = ol.plane_search_by_coefficients(dict(n=c["pl_n"], coef=coef_o, Tcw=c["pose_in"]), dict(n=mp["n"], valid=mp["valid"], coef=mp["coef"], npts=mp["npts"], pts=mp["pts"]))
     assert np.array_equal(a, c["plm"][0]) and np.array_equal(p, c["plm"][1]) and np.array_equal(v, c["plm"][2]) and np.array_equal(npm, c["nplm"])
-    keysP = ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid", "ln_obs", "ln_xw", "pl_meas", "pl_valid", "pl_world")
     MM = c["pbT"]["pl_meas"].shape[1]
     for name, mode in (("pbT", 1), ("pbP", 0)):
         Q = c[name]
-        pb = {k: Q[k] for k in keysP}
+        pb = {k: Q[k] for k in KEYS_P}
         pb["pl_meas"] = np.ascontiguousarray(coef_o[:, :MM]).astype(np.float32)      # Frame::mvPlaneCoefficients of the oracle's chain; associations unchanged (checked above)
-        assert np.array_equal(pb["pl_meas"] != 0, Q["pl_meas"] != 0) or np.array_equal((pb["pl_meas"] != 0).any(2), (Q["pl_meas"] != 0).any(2))
+        assert np.array_equal((pb["pl_meas"] != 0).any(2), (Q["pl_meas"] != 0).any(2))
         pb["Tcw"] = Q["Tcw_in"]
-        w = ol.pose_optimize(pb, TUM3, mode, 4, 10)
-        dT = np.abs(w["Tcw"] - Q["Tcw_out"]).max(1)
-        pb0 = dict(pb, pl_meas=Q["pl_meas"])
-        w0 = ol.pose_optimize(pb0, TUM3, mode, 4, 10)          # the oracle optimiser on the DEVICE's coefficients: the baseline of the comparison above
-        dT0 = np.abs(w0["Tcw"] - Q["Tcw_out"]).max(1)
-        dC = np.abs(w["Tcw"] - w0["Tcw"]).max(1)                # oracle chain vs device chain through the SAME optimiser
-        print(name, "frames > 1e-5: chain", np.nonzero(dT > 1e-5)[0].tolist(), "baseline", np.nonzero(dT0 > 1e-5)[0].tolist(), "same-optimiser gap max %.2e, > 1e-5 at" % dC.max(), np.nonzero(dC > 1e-5)[0].tolist(),
-              "lm iters equal:", float((w["lm_iters"] == w0["lm_iters"]).mean()))
-        if name == "pbT":
-            assert dT.max() <= 1e-5 and dC.max() <= 1e-5, (name, float(dT.max()), float(dC.max()))
-        else:
-            assert (dT <= 1e-5).mean() >= 0.90 and dT.max() <= 5e-5 and dC.max() <= 5e-5, (name, float(dT.max()), float((dT <= 1e-5).mean()), float(dC.max()))
-        assert np.array_equal(w["n_inliers"], Q["n_inliers"]) and np.array_equal(w["n_inliers"], w0["n_inliers"]), name
+        r = _real_optimiser(pb, mode, f"step{which}/{name}_oracle_chain")
+        dT = np.abs(r["Tcw"] - Q["Tcw_out"]).max(1)
+        assert dT.max() <= 1e-5, (name, r["source"], float(dT.max()), np.nonzero(dT > 1e-5)[0].tolist())
+        assert np.array_equal(r["n_inliers"], Q["n_inliers"]), name
         vmask = Q["pt_valid"] > 0
-        if name == "pbP":
-            assert np.array_equal(w["pt_outlier"][vmask], Q["pt_outlier"][vmask])
+        assert np.array_equal(r["pt_outlier"][vmask] > 0, Q["pt_outlier"][vmask] > 0), name
 
 
 def test_manhattan_rotation_into_the_translation_pose():
