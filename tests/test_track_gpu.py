@@ -193,10 +193,10 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
     dT = np.abs(r["Tcw"] - T["Tcw_out"]).max(1)
     assert dT.max() <= 1e-5, (r["source"], float(dT.max()), np.nonzero(dT > 1e-5)[0].tolist())
     assert np.array_equal(r["n_inliers"], T["n_inliers"])
-    # ... and the restating oracle (whose LM trial sequence may differ from g2o's on flat minima: a weaker witness, kept for the CPU-only picture)
+    # ... and the restating oracle: on these problems it is within 2e-6 of the real optimiser on every frame too (tools/gen_golden_track_pose.py prints it)
     w = ol.pose_optimize(pbT, TUM3, 1, 4, 10)
     dTo = np.abs(w["Tcw"] - T["Tcw_out"]).max(1)
-    assert (dTo <= 1e-5).mean() >= 0.95 and dTo.max() <= 1e-4 and np.array_equal(w["n_inliers"], T["n_inliers"])
+    assert dTo.max() <= 1e-5 and np.array_equal(w["n_inliers"], T["n_inliers"])
     vT = T["pt_valid"] > 0
     assert np.array_equal(r["pt_outlier"][vT] > 0, w["pt_outlier"][vT] > 0)
     # (the device cleared the flags of the matches it then dropped; compare what the optimiser wrote through the matches that survived)
@@ -239,11 +239,11 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
     assert np.array_equal(r["n_inliers"], Pp["n_inliers"])
     v = Pp["pt_valid"] > 0
     assert np.array_equal(r["pt_outlier"][v] > 0, Pp["pt_outlier"][v] > 0)          # rows without a map point are never written
-    # the restating oracle: at a flat minimum the accept / reject decisions of the LM trials (rho > 0 on chi2 differences in the 9th digit) are knife edges
-    # and its trial sequence can differ from g2o's (poses ~1e-5 apart): a weaker witness than the real optimiser above
+    # the restating oracle: within 2e-6 of the real optimiser on every frame of these steps (at a flat minimum the accept / reject decisions of the LM trials are
+    # knife edges - rho > 0 on chi2 differences in the 9th digit - and a restatement could part ways with g2o there; it does not on these 128 problems)
     w = ol.pose_optimize(pbP, TUM3, 0, 4, 10)
     dTo = np.abs(w["Tcw"] - Pp["Tcw_out"]).max(1)
-    assert (dTo <= 1e-5).mean() >= 0.95 and dTo.max() <= 1e-4
+    assert dTo.max() <= 1e-5
     assert np.array_equal(w["n_inliers"], Pp["n_inliers"])
     assert np.array_equal(w["pt_outlier"][v], Pp["pt_outlier"][v])
     assert np.array_equal(c["pose_out"], Pp["Tcw_out"]) and Pp["n_inliers"].mean() > 300

@@ -39,5 +39,21 @@ for which in (0, 1):
                 out[key + "/" + k] = np.packbits(r[k] > 0)
             dT = np.abs(r["Tcw"] - Q["Tcw_out"]).max(1)
             print(f"{key}: device vs the real optimiser: max {dT.max():.2e}, frames > 1e-5: {(dT > 1e-5).sum()} of {len(dT)}; inlier counts equal: {np.array_equal(r['n_inliers'], Q['n_inliers'])}")
+# (diagnostics: frames on which the restating oracle and the real optimiser part ways, with their problems: PLANAR_DUMP_KNIFE=path)
+if os.environ.get("PLANAR_DUMP_KNIFE"):
+    knife = {}
+    for which in (0, 1):
+        c = run["cap"][tt.STEPS - 2 + which]
+        for name, mode in (("pbT", 1), ("pbP", 0)):
+            Q = c[name]
+            pb = {k: Q[k] for k in tt.KEYS_P}; pb["Tcw"] = Q["Tcw_in"]
+            r = ol.run_ref_pose(pb, TUM3, mode); w = ol.pose_optimize(pb, TUM3, mode, 4, 10)
+            bad = np.nonzero(np.abs(r["Tcw"] - w["Tcw"]).max(1) > 2e-6)[0]
+            print(name, which, "oracle vs real optimiser > 2e-6 on frames", bad.tolist())
+            for b in bad[:3]:
+                for k in tt.KEYS_P + ("Tcw",):
+                    knife[f"{which}/{name}/{b}/{k}"] = pb[k][b:b + 1]
+                knife[f"{which}/{name}/{b}/ref"] = r["Tcw"][b]; knife[f"{which}/{name}/{b}/dev"] = Q["Tcw_out"][b]
+    np.savez_compressed(os.environ["PLANAR_DUMP_KNIFE"], **knife)
 np.savez_compressed(out_path, **out)
 print("wrote", out_path, os.path.getsize(out_path), "bytes")
