@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="camera streams per GPU = frames per GPU per step")
-    ap.add_argument("--workload", choices=["full", "orb", "ba"], default="full",
+    ap.add_argument("--workload", choices=["full", "orb", "ba", "pose"], default="full",
                     help="full: the per-frame path (BASELINE metric); orb: config[1] only; ba: config[4], ONE local bundle adjustment partitioned over the ranks")
     ap.add_argument("--depth", type=int, default=2, help="software-pipeline depth: the tracking chain of step i runs during step i + depth")
     ap.add_argument("--prio", default="-1,0,0", help="stream priorities: point stream, LSD streams, PEAC streams[, tracking stream] (lower = higher priority)")
@@ -94,6 +94,8 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
+    if args.workload == "pose":
+        return main_pose(args)
     if args.workload == "ba":
         return main_ba(args)
     B = args.batch
@@ -159,6 +161,7 @@ def main():
         o_kps = torch.zeros((B, ex.kp_cap, 7), dtype=torch.float32, device=dev); o_desc = torch.zeros((B, ex.kp_cap, 32), dtype=torch.uint8, device=dev)
         o_n = torch.zeros(B, dtype=torch.int32, device=dev)
 
+    PC_SLOTS = ("plane_voxels", "plane_items", "plane_sort_global", "plane_sort_lds", "plane_sort_heap", "plane_tail")
     EV = ("start", "orb", "stereo", "wait0", "wait1", "manhattan", "proj", "bf", "planes", "transl", "local", "pose", "state")
 
     def step(i, evs=None, side=None):
@@ -202,10 +205,28 @@ def main():
                     check(L.planar_lsd_get_profile(ls0.h, tot.ctypes.data, C0.byref(nc)))
                     standalone["lsd_kernels_alone_ms"] = dict(zip(("preprocess", "lsd_sort", "lsd_detect", "improve+accept+keylines+lbd"), (round(float(x), 3) for x in tot)))
                 check(L.planar_peac_set_profiling(pd0.h, 0)); check(L.planar_lsd_set_profiling(ls0.h, 0))
+            # the plane clouds (Frame::ComputePlanes head: voxel grid in PCL's std::sort order + refit) alone, on the labels the calibration launch above left
+            pc0 = tp.pcs[0]
+            run_pc = lambda: pc0.compute_dev(depths[0].data_ptr(), tp.lab[0].data_ptr(), tp.pls[0].data_ptr(), tp.npl[0].data_ptr(), B, tp.pc[0]["n"].data_ptr(), tp.pc[0]["coef"].data_ptr(),
+                                             tp.pc[0]["src"].data_ptr(), tp.pc[0]["off"].data_ptr(), tp.pc[0]["pts"].data_ptr(), tp.pc[0]["status"].data_ptr())
+            run_pc(); torch.cuda.synchronize()
+            check(L.planar_plane_clouds_set_profiling(pc0.h, 1))
+            t1 = time.perf_counter(); run_pc(); torch.cuda.synchronize()
+            standalone["plane_clouds_alone_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+            tot6 = np.zeros(6); nc = C0.c_int64()
+            check(L.planar_plane_clouds_get_profile(pc0.h, tot6.ctypes.data, C0.byref(nc)))
+            check(L.planar_plane_clouds_set_profiling(pc0.h, 0))
+            standalone["plane_clouds_kernels_alone_ms"] = dict(zip(PC_SLOTS, (round(float(x), 3) for x in tot6)))
+            st4 = np.zeros((B, 4), np.int64)
+            check(L.planar_plane_clouds_sort_stats(pc0.h, B, st4.ctypes.data))
+            standalone["plane_sort_stats"] = {"frames_with_heap_sort_fallback": int((st4[:, 0] > 0).sum()), "fallback_ranges": int(st4[:, 0].sum()), "fallback_elements": int(st4[:, 1].sum()),
+                                              "longest_fallback_range": int(st4[:, 2].max()), "lds_blocks_per_frame": round(float(st4[:, 3].mean()), 1),
+                                              "note": "std::sort of pcl::VoxelGrid::applyFilter per plane: ranges whose introsort depth budget ran out go through libstdc++'s heap sort (isort.h)"}
         ex.set_profiling(True)
         if full:
             for q in tp.pds: check(L.planar_peac_set_profiling(q.h, 1))
             for q in tp.lss: check(L.planar_lsd_set_profiling(q.h, 1))
+            for q in tp.pcs: check(L.planar_plane_clouds_set_profiling(q.h, 1))
         evsets = [{n: torch.cuda.Event(enable_timing=True) for n in EV} for _ in range(args.steps)]
         sides = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
         barrier()
@@ -231,6 +252,12 @@ def main():
                 check(L.planar_lsd_get_profile(q.h, tot.ctypes.data, C.byref(nc)))
                 check(L.planar_lsd_set_profiling(q.h, 0))
                 lsd_ms += tot; lsd_calls += nc.value
+            pc_ms, pc_calls = np.zeros(6), 0
+            for q in tp.pcs:
+                tot = np.zeros(6); nc = C.c_int64()
+                check(L.planar_plane_clouds_get_profile(q.h, tot.ctypes.data, C.byref(nc)))
+                check(L.planar_plane_clouds_set_profiling(q.h, 0))
+                pc_ms += tot; pc_calls += nc.value
     if full:
         tp.check()
 
@@ -269,6 +296,13 @@ def main():
                        "stream_bracket_ms": round(stage_ms["peac(stream 2)"], 3),
                        "note": "avg_launch_ms: HIP events right before / after each launch on the PEAC stream, inside the timed region (what rocprofv3's AverageNs measures); "
                                "stream_bracket_ms also holds the surface-normal kernel and the queueing between launches with up to depth+2 launch sets in flight"}
+        # plane clouds (Frame::ComputePlanes head): read labels + depth (1 843 200 B / frame), write <= 4096 centroids; its launches bracketed one by one
+        ck = "plane_clouds(voxels+items+sort+tail)"
+        cav = pc_ms / max(1, pc_calls)
+        cand[ck] = (float(cav.sum()), 1843200 * B)
+        kernels[ck] = {"ms_per_step": round(float(cav.sum()), 4), "launches_per_step": 8, "alone_ms": standalone["plane_clouds_alone_ms"],
+                       "avg_launch_ms": dict(zip(PC_SLOTS, (round(float(x), 3) for x in cav))), "alone_launch_ms": standalone["plane_clouds_kernels_alone_ms"],
+                       "sort_stats_of_the_calibration_batch": standalone["plane_sort_stats"]}
         lk = "lsd_detect(+7 small kernels)"
         cand[lk] = (standalone["lsd_lbd_alone_ms"], (307200 + 40 * 124) * B)
         kernels[lk] = {"ms_per_step": round(stage_ms["lsd_lbd(stream 3)"], 4), "launches_per_step": 8, "alone_ms": standalone["lsd_lbd_alone_ms"]}
@@ -294,24 +328,35 @@ def main():
     # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this
     # command, KB per launch, summed over the stage's kernels); raw counter sums (narrow gathers: no wide-read correction applied)
     traffic = None
-    pmc_csv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_fetch_write_kb_per_launch.csv") for r in (3, 2)) if os.path.exists(q)), "")
+    pmc_csv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_fetch_write_kb_per_launch.csv") for r in (4, 3, 2)) if os.path.exists(q)), "")
     traffic_note = "null: no profiles/r0N_pmc_fetch_write_kb_per_launch.csv (tools/pmc_counters.py) found"
+    # the kernels of the dominant stage as rocprofv3 names them (prefix match: template / overload suffixes vary); a key without a row is an ERROR, not a zero
     pmc_keys = {"peac_blocks+peac_ahc+peac_refine": ("planar::peac::peac_blocks", "planar::peac::peac_ahc", "planar::peac::peac_refine"),
+                "plane_clouds(voxels+items+sort+tail)": ("planar::planepost::plane_voxels_kernel", "planar::planepost::plane_items_kernel", "planar::planepost::plane_sort_global",
+                                                         "planar::planepost::plane_sort_lds", "planar::planepost::plane_sort_heap", "planar::planepost::plane_tail_kernel"),
                 "lsd_detect(+7 small kernels)": ("planar::lsd::lsd_detect",)}.get(dom, ("planar::orb::" + dom,))
     if os.path.exists(pmc_csv):
         f_tot = w_tot = 0.0
+        seen = set()
         for line in open(pmc_csv).read().splitlines()[1:]:
             k, _, f_kb, w_kb = line.rsplit(",", 3)
-            if k in pmc_keys:
-                f_tot += float(f_kb); w_tot += float(w_kb)
-        if f_tot + w_tot > 0:
+            hit = next((q for q in pmc_keys if k.strip('"').startswith(q)), None)
+            if hit:
+                f_tot += float(f_kb); w_tot += float(w_kb); seen.add(hit)
+        missing = [q for q in pmc_keys if q not in seen]
+        if missing:
+            traffic_note = f"null: {os.path.relpath(pmc_csv, ROOT)} has no row for {missing} (the counter file predates these kernels: re-collect with tools/collect_profiles.sh)"
+            print(f"bench.py: WARNING: roofline.traffic not reported: {traffic_note}", file=sys.stderr)
+        elif f_tot + w_tot > 0:
             traffic = int((f_tot + w_tot) * 1024 * B / 1024)
             traffic_note = (f"NOT measured in this run: read from the committed {os.path.relpath(pmc_csv, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
                             f"`bench.py --canvases 16 --gen-procs 1`, B=1024; counter collection hangs in forked children): {f_tot / 1024:.0f} MB read + {w_tot / 1024:.0f} MB written per launch")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "traffic_source": os.path.relpath(pmc_csv, ROOT) if traffic is not None else None, "traffic_note": traffic_note, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
                 "pipeline_algorithmic_GBps": round(per_frame * fps / 1e9, 2),
-                "note": "latency-bound sequential stage (one wavefront per frame); see DESIGN.md" if dom.startswith(("peac", "lsd")) else None, "kernels": kernels}
+                "note": "latency-bound sequential stage (one wavefront per frame); see DESIGN.md" if dom.startswith(("peac", "lsd")) else
+                        ("the voxel grid of Frame::ComputePlanes in PCL's summation order: every plane's points arranged as libstdc++'s std::sort leaves them (isort.h); see DESIGN.md" if dom.startswith("plane_clouds") else None),
+                "kernels": kernels}
     if full:
         # the three kernels with the most device time, each against the roofline on its own: algorithmic bytes of its stage per launch
         # divided by the kernel's average duration - alone on the device (calibration launch before the timed region) and inside the pipelined step
@@ -319,7 +364,9 @@ def main():
         ka, la = standalone.get("peac_kernels_alone_ms", {}), standalone.get("lsd_kernels_alone_ms", {})
         per = {}
         for name, alone, corun, nbytes in (("peac_ahc", ka.get("peac_ahc"), float(pav[1]), 1843200 * B), ("peac_refine", ka.get("peac_refine"), float(pav[3]), 1843200 * B),
-                                           ("lsd_sort", la.get("lsd_sort"), float(lav[1]), 312160 * B), ("lsd_detect", la.get("lsd_detect"), float(lav[2]), 312160 * B)):
+                                           ("lsd_sort", la.get("lsd_sort"), float(lav[1]), 312160 * B), ("lsd_detect", la.get("lsd_detect"), float(lav[2]), 312160 * B),
+                                           ("plane_sort_lds", standalone["plane_clouds_kernels_alone_ms"].get("plane_sort_lds"), float(cav[3]), 1843200 * B),
+                                           ("plane_sort_heap", standalone["plane_clouds_kernels_alone_ms"].get("plane_sort_heap"), float(cav[4]), 1843200 * B)):
             e = {"alg_bytes_per_launch": int(nbytes), "corun_avg_ms": round(corun, 3), "alone_ms": alone}
             if corun > 0: e["frac_corun"] = round(nbytes / (corun * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
             if alone: e["frac_alone"] = round(nbytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
@@ -464,7 +511,8 @@ def main():
 
 
 def main_ba(args):
-    """BASELINE config[4]: local bundle adjustment of 10 keyframes x 3000 point / line / plane features.  ONE problem; its landmarks (with all
+    """BASELINE configs[4] (0-based: the fifth entry, "Local BA"; DESIGN.md and earlier rounds also called it "config 5" counting from one): local bundle adjustment
+    of 10 free key frames (+ 2 fixed ones that only observe) x 3000 point / line / plane features.  ONE problem; its landmarks (with all
     their edges) are partitioned over the ranks, every rank linearises its part, and the reduced camera system is all-reduced over RCCL twice
     per LM trial (planarslam_amd/csrc/ba.hip).  A step = one complete solve (optimize(5), outlier levels, optimize(10), erase flags) through the
     host-pointer entry point, so the upload of the graph is inside the timed region.  Total work is fixed: "scaling": "strong"."""
@@ -507,6 +555,7 @@ def main_ba(args):
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
     K, L, E = len(prob["kf_fixed"]), len(prob["lm_type"]), len(prob["e_kf"])
     np_free = int((np.asarray(prob["kf_fixed"]) == 0).sum())
+    K_pre, L_pre, E_pre, np_free_pre = K, L, E, np_free
     NP = 6 * np_free
     exch_a = np_free * 36 + NP + 2 + NP * NP + NP
     # algorithmic HBM bytes of one LM iteration with one trial: errors (pose 64 + landmark 32 + meas 32 + info 32 in, err 24 out) twice,
@@ -516,7 +565,8 @@ def main_ba(args):
     line = {"metric": "local bundle adjustments/sec (10 keyframes x 3000 point/line/plane features, g2oAddition edges)", "value": round(args.steps / elapsed, 3),
             "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config[4]: local BA, 10 keyframes (2 fixed), 2400 map points + 250 lines + 100 planes, %d edges; landmarks partitioned over ranks" % E,
+            "config": {"workload": "BASELINE configs[4] (0-based; 'Local BA'): %d free + %d fixed key-frame vertices, 2400 map points + 250 lines (500 end-point vertices) + 100 planes "
+                                   "= %d landmark vertices, %d edges; landmarks partitioned over ranks" % (np_free_pre, K_pre - np_free_pre, L_pre, E_pre),
                        "keyframes": K, "landmark_vertices": L, "edges": E, "parallelism": "landmark-partition x%d" % world,
                        "exchange": {"per_trial": "A: %d doubles (Hpp|bp|chi2|S|b) + B: 3 doubles (chi2, scale, stop)" % exch_a, "bytes_A": exch_a * 8,
                                     "transport": ("RCCL all-reduce" if args.backend == "nccl" else "hosted (gloo, host-staged)") if world > 1 else "none (single GPU)"}},
@@ -539,6 +589,122 @@ def main_ba(args):
         comm.close()
     if rank == 0:
         print(json.dumps(line))
+    ranks.close()
+
+
+def _pose_cpu_chunk(a):
+    """worker of main_pose's all-cores CPU leg (oracle/pose_oracle.cpp on a slice of the batch); top level so that it pickles"""
+    batch, lo, hi, reps = a
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from planarslam_amd.synth import TUM3
+    sl = {k: v[lo:hi] for k, v in batch.items()}
+    t = time.perf_counter()
+    for _ in range(reps):
+        ol.pose_optimize(sl, TUM3, 0, 4, 10)
+    return time.perf_counter() - t
+
+
+def main_pose(args):
+    """BASELINE configs[3]: pose-only Levenberg-Marquardt, 1000 point + 150 line (75 lines x 2 end points) + 12 plane (4 planes x plane / parallel / vertical)
+    edges per frame, batch = 256 frames per GPU (synth.pose_batch(B = 256, seed = 7 + 1000 * rank)), resident in HBM.  A step = Optimizer::PoseOptimization
+    (src/Optimizer.cc:550-1275: four rounds of optimize(10) with outlier reclassification) for every frame of the batch: one launch of pose_opt_kernel.  Frames are
+    independent: every rank has its own batch, no collective ("weak")."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from planarslam_amd import Context
+    from planarslam_amd._lib import PoseBatch, check, lib
+    from planarslam_amd.dist import Ranks
+    from planarslam_amd.optimizer import make_params
+    from planarslam_amd.synth import TUM3, pose_batch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    local_rank = pick_device(args, torch)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ranks = Ranks(backend=args.backend, device=dev)
+    rank, world = ranks.rank, ranks.world
+    B = 256 if args.batch == 1024 else args.batch                 # (--batch keeps its default for the full workload; this one is quoted on 256)
+    host = pose_batch(B=B, n_points=1000, n_lines=75, n_planes=4, seed=7 + 1000 * rank)
+    L = lib()
+    stream = torch.cuda.Stream(device=dev)
+    ctx = Context(local_rank, stream=stream.cuda_stream)
+    params = make_params(TUM3)
+    MP, ML, MM = host["pt_valid"].shape[1], host["ln_valid"].shape[1], host["pl_valid"].shape[1]
+    keys_in = ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid", "ln_obs", "ln_xw", "pl_meas", "pl_valid", "pl_world")
+    d = {k: torch.from_numpy(np.ascontiguousarray(host[k])).to(dev) for k in keys_in}
+    d["Tcw_in"] = torch.from_numpy(np.ascontiguousarray(host["Tcw"], np.float32)).to(dev)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    d.update(Tcw_out=z((B, 16), torch.float32), pt_outlier=z((B, MP), torch.uint8), ln_outlier=z((B, ML), torch.uint8), pl_outlier=z((B, MM, 3), torch.uint8),
+             n_inliers=z((B,), torch.int32), lm_iters=z((B,), torch.int32))
+    pb = PoseBatch()
+    pb.B, pb.max_points, pb.max_lines, pb.max_planes = B, MP, ML, MM
+    for k in keys_in + ("Tcw_in", "Tcw_out", "pt_outlier", "ln_outlier", "pl_outlier", "n_inliers", "lm_iters"):
+        setattr(pb, k, d[k].data_ptr())
+
+    def barrier():
+        torch.cuda.synchronize(); ranks.barrier(); torch.cuda.synchronize()
+
+    def run(rounds, its, steps, warmup):
+        with torch.cuda.stream(stream):
+            for _ in range(warmup):
+                check(L.planar_pose_opt_dev(ctx.h, C.byref(pb), C.byref(params), 0, rounds, its))
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            for _ in range(steps):
+                check(L.planar_pose_opt_dev(ctx.h, C.byref(pb), C.byref(params), 0, rounds, its))
+            e1.record(stream)
+            barrier()
+            return ranks.max_over_ranks(time.perf_counter() - t0), e0.elapsed_time(e1) / steps, float(d["lm_iters"].float().mean().item())
+
+    el_1, k_1, it_1 = run(1, 10, args.steps, args.warmup)        # one optimize(10): the "10 iters" protocol of BASELINE.md
+    el, k_ms, lm_it = run(4, 10, args.steps, args.warmup)         # the reference's PoseOptimization: 4 x optimize(10)
+    if rank != 0:
+        ranks.close()
+        return
+    # parity of this very batch with the real optimiser is tests/test_pose_gpu.py::test_pose_hip_equals_reference_fixture (c4_b256)
+    alg = 65130 * B * lm_it                                       # SURVEY §8d: bytes of one LM evaluation of one frame x measured LM iterations per frame
+    line = {"metric": "pose-only LM problems/sec (1000 point + 150 line + 12 plane edges, 4 x 10 iterations, batch 256 per GPU)", "value": round(B * world * args.steps / el, 1),
+            "unit": "problems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3] (0-based): pose-only LM, synth.pose_batch(B=%d, n_points=1000, n_lines=75 (150 end-point edges), n_planes=4 (12 plane / parallel / "
+                                   "vertical edges), seed=7), Optimizer::PoseOptimization = 4 rounds of optimize(10) with outlier reclassification; inputs resident in HBM" % B,
+                       "frames_per_gpu_per_step": B, "avg_lm_iterations_per_frame": round(lm_it, 2),
+                       "protocol_1x10": {"problems_per_s": round(B * world * args.steps / el_1, 1), "ms_per_step": round(el_1 / args.steps * 1e3, 4), "avg_lm_iterations_per_frame": round(it_1, 2)}},
+            "roofline": {"bound": "hbm", "kernel": "pose_opt_kernel<2>", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg),
+                         "note": "65 130 B per frame per LM evaluation (SURVEY §8d) x the measured LM iterations; HIP events on the kernel's stream around the timed launches.  One workgroup per "
+                                 "frame runs the whole protocol on chip in FP64: 256 frames = 256 workgroups = one per CU, latency-bound (DESIGN.md §4)"}}
+    if args.cpu_seconds > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol                                  # test infrastructure, used here only as the timed CPU baseline
+        nb = min(B, 32)
+        sl = {k: np.ascontiguousarray(v[:nb]) for k, v in host.items() if k != "T_gt"}
+        n, t1 = 0, time.perf_counter()
+        while n < 1 or time.perf_counter() - t1 < min(args.cpu_seconds, 18.0) / 3:
+            ol.pose_optimize(sl, TUM3, 0, 4, 10); n += 1
+        one = nb * n / (time.perf_counter() - t1)
+        line["cpu_baseline"] = {"value": round(one, 2), "unit": "problems/s", "cores": 1, "kind": "port",
+                                "sample": "%d x the first %d problems of the batch through oracle/pose_oracle.cpp (g2o's LM restated, pinned to the real Optimizer.cc: tests/test_oracle_opt_ref.py), one thread" % (n, nb)}
+        try:
+            import multiprocessing as mp
+            ncores = os.cpu_count() or 1
+            full = {k: np.ascontiguousarray(v) for k, v in host.items() if k != "T_gt"}
+            per = max(1, B // ncores)
+            jobs = [(full, lo, min(B, lo + per), 2) for lo in range(0, B, per)]
+            t1 = time.perf_counter()
+            with mp.get_context("fork").Pool(min(ncores, len(jobs))) as pool:
+                pool.map(_pose_cpu_chunk, jobs)
+            line["cpu_baseline"]["all_cores"] = {"value": round(2 * B / (time.perf_counter() - t1), 1), "unit": "problems/s", "cores": min(ncores, len(jobs)),
+                                                 "sample": "the whole batch twice, one worker process per %d problems" % per}
+        except Exception as e:                                    # (a box without fork / enough memory: the one-thread figure stands)
+            line["cpu_baseline"]["all_cores"] = {"error": type(e).__name__}
+    print(json.dumps(line))
     ranks.close()
 
 

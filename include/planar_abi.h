@@ -616,6 +616,10 @@ typedef struct planar_plane_clouds planar_plane_clouds;
 int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* voxels per frame: a power of two <= 8192; the kernel holds 36 KB of LDS up to 4096, 64 KB at 8192; the key table is in the workspace */, planar_plane_clouds** out);
 void planar_plane_clouds_destroy(planar_plane_clouds* pc);
 int planar_plane_clouds_stride(const planar_plane_clouds* pc, int* pl_stride, int* max_points);
+/* HIP-event timing of the launches of planar_plane_clouds_compute_dev (bench.py's roofline leg), as planar_peac_set_profiling: total_ms [6] = plane_voxels,
+ * plane_items, plane_sort_global, plane_sort_lds, plane_sort_heap, plane_tail over `calls` recorded calls */
+int planar_plane_clouds_set_profiling(planar_plane_clouds* pc, int enable);
+int planar_plane_clouds_get_profile(planar_plane_clouds* pc, double* total_ms, int64_t* calls);
 /* diagnostics (synchronises): per frame of the last call, out [B][4] = {ranges that went through libstdc++'s heap-sort fallback (std::sort of
  * pcl::VoxelGrid::applyFilter on a plane whose introsort depth budget ran out), their elements, the longest, LDS-tier sort blocks} */
 int planar_plane_clouds_sort_stats(planar_plane_clouds* pc, int B, int64_t* out);

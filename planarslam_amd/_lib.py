@@ -144,6 +144,8 @@ _SIGS = {
     "planar_lsd_max_segments": (C.c_int, []),
     "planar_lsd_set_tie_order": (C.c_int, [C.c_void_p, C.c_int]),
     "planar_plane_clouds_sort_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "planar_plane_clouds_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "planar_plane_clouds_get_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_lsd_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "planar_lsd_get_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_lsd_scaled_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -900,6 +900,12 @@ struct planar_plane_clouds {
     int sort_rows = 0;
     planar::DevBuf ws, rng, dbg;
     bool timing = false;
+    // planar_plane_clouds_set_profiling: HIP events around the launches of a recorded call; slots: plane_voxels, plane_items, plane_sort_global, plane_sort_lds,
+    // plane_sort_heap (three launches), plane_tail
+    bool profiling = false;
+    std::vector<std::vector<hipEvent_t>> ev_sets;
+    size_t ev_used = 0;
+    ~planar_plane_clouds() { for (auto& v : ev_sets) for (hipEvent_t e : v) (void)hipEventDestroy(e); }
 };
 
 using namespace planar;
@@ -982,6 +988,30 @@ int planar_plane_clouds_read_timing(planar_plane_clouds* p, int B, int64_t* out)
     return PLANAR_OK;
 }
 
+// Per-launch HIP-event timing (bench.py's roofline leg), as planar_peac_set_profiling: slots plane_voxels, plane_items, plane_sort_global, plane_sort_lds,
+// plane_sort_heap (its three launches together), plane_tail
+int planar_plane_clouds_set_profiling(planar_plane_clouds* p, int enable) {
+    PLANAR_REQUIRE(p != nullptr, PLANAR_EINVAL, "null argument");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    p->profiling = enable != 0;
+    p->ev_used = 0;
+    return PLANAR_OK;
+}
+int planar_plane_clouds_get_profile(planar_plane_clouds* p, double* total_ms /* [6] */, int64_t* calls) {
+    PLANAR_REQUIRE(p && total_ms && calls, PLANAR_EINVAL, "null argument");
+    PLANAR_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    for (int i = 0; i < 6; i++) total_ms[i] = 0;
+    for (size_t c = 0; c < p->ev_used; c++)
+        for (int i = 0; i < 6; i++) {
+            float ms = 0;
+            PLANAR_HIP_CHECK(hipEventElapsedTime(&ms, p->ev_sets[c][i], p->ev_sets[c][i + 1]));
+            total_ms[i] += ms;
+        }
+    *calls = (int64_t)p->ev_used;
+    p->ev_used = 0;
+    return PLANAR_OK;
+}
+
 // diagnostics: per frame of the last call {ranges left to libstdc++'s heap-sort fallback, their elements, the longest, LDS-tier blocks}
 int planar_plane_clouds_sort_stats(planar_plane_clouds* p, int B, int64_t* out /* [B][4] */) {
     PLANAR_REQUIRE(p && out && B >= 1 && B <= p->max_batch, PLANAR_EINVAL, "bad argument");
@@ -1022,16 +1052,34 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     hipStream_t st = p->ctx->stream;
     unsigned char* ws = p->ws.as<unsigned char>();
     long long* tm = p->timing ? p->dbg.as<long long>() : nullptr;
+    std::vector<hipEvent_t>* evs = nullptr;
+    if (p->profiling) {
+        if (p->ev_used == p->ev_sets.size()) {
+            std::vector<hipEvent_t> v(7);
+            for (hipEvent_t& e : v) PLANAR_HIP_CHECK(hipEventCreate(&e));
+            p->ev_sets.push_back(v);
+        }
+        evs = &p->ev_sets[p->ev_used++];
+    }
+    int li = 0;
+    auto mark = [&]() { if (evs) (void)hipEventRecord((*evs)[li], st); li++; };
+    mark();
     hipLaunchKernelGGL(planepost::plane_voxels_kernel, dim3(B), dim3(planepost::NT), p->smem, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, d_n_planes, ws, tm);
+    mark();
     hipLaunchKernelGGL(planepost::plane_items_kernel, dim3(B), dim3(planepost::PS_T), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
+    mark();
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
+    mark();
     hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_R), dim3(planepost::PS_T), p->smem_sort_l, st, G, ws);
+    mark();
     for (int c = 0; c < 3 && !getenv("PLANAR_DEV_SKIP_HEAP"); c++) {   // (the environment variable: a developer's timing experiment, results are then wrong)
         const planepost::HeapClass& H = planepost::PS_HC[c];
         hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(B, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
     }
+    mark();
     hipLaunchKernelGGL(planepost::plane_tail_kernel, dim3(B), dim3(planepost::NT), p->smem_tail, st, G, d_depth, pitch_px, (long)frame_stride_px, d_planes,
                        planar_peac_max_planes(), p->rng.as<int>(), ws, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox, d_info, tm);
+    mark();
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
 }
