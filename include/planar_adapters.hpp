@@ -39,12 +39,13 @@ enum Role { POINTS = 0, LINES = 1, PLANES = 2, TRACKING = 3, NROLES = 4 };
 class Runtime {
 public:
     static Runtime& get() { static Runtime r; return r; }           // destroyed at process exit: plans first, then contexts
+    static void complain(const char* what) { std::fprintf(stderr, "planar (%s): %s\n", what, planar_last_error()); }
     struct Lane { std::mutex mu; planar_ctx* ctx = nullptr; };
     // the role's context (created on first use) - hold lane(role).mu while a call on it is in flight
     Lane& lane(Role r) {
         Lane& l = lanes_[r];
         std::lock_guard<std::mutex> g(create_mu_);
-        if (!l.ctx && planar_ctx_create(&l.ctx, device_) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        if (!l.ctx && planar_ctx_create(&l.ctx, device_) != PLANAR_OK) { l.ctx = nullptr; complain("planar_ctx_create"); }   // (no exceptions: this runs on the threads Frame's constructor spawns; the calls on a null context fail and degrade)
         return l;
     }
     typedef std::tuple<int, int, int, int, int, int, int> OrbKey;   // w, h, nfeatures, scale * 1e6, nlevels, ini, min
@@ -53,28 +54,28 @@ public:
         auto it = orbs_.find(k);
         if (it != orbs_.end()) return it->second;
         planar_orb* o = nullptr;
-        if (planar_orb_create(lanes_[POINTS].ctx, &p, w, h, 1, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        if (planar_orb_create(lanes_[POINTS].ctx, &p, w, h, 1, &o) != PLANAR_OK) { complain("planar_orb_create"); return nullptr; }
         return orbs_[k] = o;
     }
     planar_lsd* lsd(int w, int h) {                                 // call with lane(LINES).mu held
         auto it = lsds_.find({w, h});
         if (it != lsds_.end()) return it->second;
         planar_lsd* o = nullptr;
-        if (planar_lsd_create(lanes_[LINES].ctx, w, h, 1, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        if (planar_lsd_create(lanes_[LINES].ctx, w, h, 1, &o) != PLANAR_OK) { complain("planar_lsd_create"); return nullptr; }
         return lsds_[{w, h}] = o;
     }
     planar_peac* peac(int w, int h) {                               // call with lane(PLANES).mu held
         auto it = peacs_.find({w, h});
         if (it != peacs_.end()) return it->second;
         planar_peac* o = nullptr;
-        if (planar_peac_create(lanes_[PLANES].ctx, w, h, 1, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());
+        if (planar_peac_create(lanes_[PLANES].ctx, w, h, 1, &o) != PLANAR_OK) { complain("planar_peac_create"); return nullptr; }
         return peacs_[{w, h}] = o;
     }
     planar_plane_clouds* clouds(int w, int h) {                     // call with lane(PLANES).mu held
         auto it = clouds_.find({w, h});
         if (it != clouds_.end()) return it->second;
         planar_plane_clouds* o = nullptr;
-        if (planar_plane_clouds_create(lanes_[PLANES].ctx, w, h, 1, 8192, &o) != PLANAR_OK) throw std::runtime_error(planar_last_error());   // 8192 voxels of 0.1 m: ~80 m2 of planar surface per frame
+        if (planar_plane_clouds_create(lanes_[PLANES].ctx, w, h, 1, 8192, &o) != PLANAR_OK) { complain("planar_plane_clouds_create"); return nullptr; }   // 8192 voxels of 0.1 m: ~80 m2 of planar surface per frame
         return clouds_[{w, h}] = o;
     }
     void set_device(int d) { device_ = d; }
@@ -98,7 +99,14 @@ private:
     std::map<std::pair<int, int>, planar_plane_clouds*> clouds_;
 };
 
-inline void check(int rc) { if (rc != PLANAR_OK) throw std::runtime_error(planar_last_error()); }
+// The reference's convention is no exceptions: its extractors run on threads Frame's constructor spawns, its matchers / optimisers on the tracking and
+// local-mapping threads, none with a handler - a throw would end in std::terminate.  A failing call says so on stderr and the adapter degrades to "nothing
+// found" (no key points / lines / planes / matches, the pose left alone), which the reference's own state machine handles (tracking lost -> relocalisation).
+inline bool ok(int rc, const char* where) {
+    if (rc == PLANAR_OK) return true;
+    std::fprintf(stderr, "planar (%s): %s - degraded to \"nothing found\"\n", where, planar_last_error());
+    return false;
+}
 
 }  // namespace planar_adapter
 
@@ -122,11 +130,12 @@ public:
         planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::POINTS);
         std::lock_guard<std::mutex> g(L.mu);
         planar_orb* orb = R.orb(params(), image.cols, image.rows);
+        if (!orb) { _keypoints.clear(); _descriptors.release(); return; }
         const int cap = planar_orb_max_keypoints(orb);
         std::vector<planar_keypoint> kps(cap);
         std::vector<uint8_t> desc((size_t)cap * 32);
         int32_t n = 0;
-        planar_adapter::check(planar_orb_extract(orb, image.data, 1, (int)image.step, (int64_t)image.step * image.rows, kps.data(), desc.data(), &n));
+        if (!planar_adapter::ok(planar_orb_extract(orb, image.data, 1, (int)image.step, (int64_t)image.step * image.rows, kps.data(), desc.data(), &n), "ORBextractor")) n = 0;
         static_assert(sizeof(cv::KeyPoint) == sizeof(planar_keypoint), "cv::KeyPoint layout");
         _keypoints.resize(n);
         if (n) std::memcpy((void*)_keypoints.data(), kps.data(), (size_t)n * sizeof(planar_keypoint));
@@ -223,8 +232,8 @@ public:
             planar_adapter::Runtime& R = planar_adapter::Runtime::get();
             planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::PLANES);
             std::lock_guard<std::mutex> g(L.mu);
-            planar_adapter::check(planar_peac_segment(R.peac(W, H), (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_, cx_, cy_,
-                                                      factor_, labels.data(), planes.data(), &n));
+            if (!planar_adapter::ok(planar_peac_segment(R.peac(W, H), (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_, cx_, cy_,
+                                                        factor_, labels.data(), planes.data(), &n), "PlaneDetection")) { n = 0; labels.assign((size_t)W * H, -1); }
         }
         plane_num_ = n;
         plane_vertices_.assign(n, std::vector<int>());
@@ -262,7 +271,7 @@ public:
                 std::fprintf(stderr, "planar: frame with more than %d plane voxels: its planes are dropped (%s)\n", MP, planar_last_error());
                 return 0;
             }
-            planar_adapter::check(rc);
+            if (!planar_adapter::ok(rc, "ComputePlaneClouds")) return 0;
         }
         for (int k = 0; k < n_out; k++) {
             CloudT c;
@@ -309,8 +318,8 @@ public:
             planar_adapter::Runtime& R = planar_adapter::Runtime::get();
             planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::LINES);
             std::lock_guard<std::mutex> g(L.mu);
-            planar_adapter::check(planar_lsd_extract(R.lsd(W, H), img.data, 1, (int)img.step, (int64_t)img.step * H, lsdNFeatures, (planar_keyline*)keylines.data(), desc.data(),
-                                                     (double*)(keylineFunctions.data() + first), &n));
+            if (!planar_adapter::ok(planar_lsd_extract(R.lsd(W, H), img.data, 1, (int)img.step, (int64_t)img.step * H, lsdNFeatures, (planar_keyline*)keylines.data(), desc.data(),
+                                                       (double*)(keylineFunctions.data() + first), &n), "LineSegment")) n = 0;
         }
         keylines.resize(n);
         keylineFunctions.resize(first + n);
@@ -387,7 +396,7 @@ inline int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& Last
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_search_by_projection_frame(L.ctx, &cur.view, &last, th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, match.data(), &nmatches));
+        if (!planar_adapter::ok(planar_search_by_projection_frame(L.ctx, &cur.view, &last, th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, match.data(), &nmatches), "planar_search_by_projection_frame")) return 0;
     }
     for (int i = 0; i < CurrentFrame.N; i++) {
         if (match[i] == UNTOUCHED) continue;
@@ -421,7 +430,7 @@ inline int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_search_by_projection_map(L.ctx, &fr.view, &pr, th, mfNNratio, match.data(), &nmatches));
+        if (!planar_adapter::ok(planar_search_by_projection_map(L.ctx, &fr.view, &pr, th, mfNNratio, match.data(), &nmatches), "planar_search_by_projection_map")) return 0;
     }
     for (int i = 0; i < F.N; i++) if (match[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[match[i]];
     return nmatches;
@@ -443,7 +452,7 @@ inline int ORBmatcher::MatchORBPoints(Frame& CurrentFrame, const Frame& LastFram
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_match_orb_points(L.ctx, cd.data(), &nc, nc > 0 ? nc : 1, ld.data(), &nl, nl > 0 ? nl : 1, has.data(), outl.data(), 1, match.data(), &npair));
+        if (!planar_adapter::ok(planar_match_orb_points(L.ctx, cd.data(), &nc, nc > 0 ? nc : 1, ld.data(), &nl, nl > 0 ? nl : 1, has.data(), outl.data(), 1, match.data(), &npair), "planar_match_orb_points")) return 0;
     }
     for (int i = 0; i < nc; i++) if (match[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[match[i]];
     return npair;
@@ -472,8 +481,8 @@ inline int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_search_by_bow(L.ctx, 1, &nk, nk, knode.data(), kus.data(), kang.data(), kd.data(), &nf, nf, fnode.data(), fang.data(), fd.data(), mfNNratio,
-                                                   mbCheckOrientation ? 1 : 0, match.data(), &nmatches));
+        if (!planar_adapter::ok(planar_search_by_bow(L.ctx, 1, &nk, nk, knode.data(), kus.data(), kang.data(), kd.data(), &nf, nf, fnode.data(), fang.data(), fd.data(), mfNNratio,
+                                                   mbCheckOrientation ? 1 : 0, match.data(), &nmatches), "planar_search_by_bow")) return 0;
     }
     for (int i = 0; i < nf; i++) if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
     return nmatches;
@@ -493,7 +502,7 @@ inline int LSDmatcher::SearchByDescriptor(KeyFrame* pKF, Frame& currentF, std::v
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_lsd_search_by_descriptor(L.ctx, kd.data(), &nk, nk, cd.data(), &nc, nc, has.data(), 1, match.data(), &nmatches));
+        if (!planar_adapter::ok(planar_lsd_search_by_descriptor(L.ctx, kd.data(), &nk, nk, cd.data(), &nc, nc, has.data(), 1, match.data(), &nmatches), "planar_lsd_search_by_descriptor")) return 0;
     }
     for (int i = 0; i < nc && i < currentF.NL; i++) if (match[i] >= 0) vpMapLineMatches[i] = vpMapLinesKF[match[i]];
     return nmatches;
@@ -523,9 +532,9 @@ inline int LSDmatcher::SearchByProjection(Frame& F, const std::vector<MapLine*>&
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_lsd_search_by_projection(L.ctx, 1, &nl, nl, (const planar_keyline*)F.mvKeylinesUn.data(), ldesc.data(), blocked.data(), &nm, nm, inview.data(),
+        if (!planar_adapter::ok(planar_lsd_search_by_projection(L.ctx, 1, &nl, nl, (const planar_keyline*)F.mvKeylinesUn.data(), ldesc.data(), blocked.data(), &nm, nm, inview.data(),
                                                               proj.data(), lvl.data(), vc.data(), mdesc.data(), obs.data(), F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), th,
-                                                              mfNNratio, match.data(), &nmatches));
+                                                              mfNNratio, match.data(), &nmatches), "planar_lsd_search_by_projection")) return 0;
     }
     for (int i = 0; i < nl; i++) if (match[i] >= 0) F.mvpMapLines[i] = vpMapLines[match[i]];
     return nmatches;
@@ -576,8 +585,8 @@ inline int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPo
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_fuse_search(L.ctx, &v, pKF->mvInvLevelSigma2.data(), pKF->mfLogScaleFactor, pKF->mnScaleLevels, &m, M, 0, usable.data(), xw.data(),
-                                                 nrm.data(), mn.data(), mx.data(), desc.data(), th, idx.data(), nullptr, &nFused));
+        if (!planar_adapter::ok(planar_fuse_search(L.ctx, &v, pKF->mvInvLevelSigma2.data(), pKF->mfLogScaleFactor, pKF->mnScaleLevels, &m, M, 0, usable.data(), xw.data(),
+                                                 nrm.data(), mn.data(), mx.data(), desc.data(), th, idx.data(), nullptr, &nFused), "planar_fuse_search")) return 0;
     }
     for (int j = 0; j < M; j++) {                                                   // :953-974
         if (idx[j] < 0) continue;
@@ -633,8 +642,8 @@ inline int LSDmatcher::Fuse(KeyFrame* pKF, const std::vector<MapLine*>& vpMapLin
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_lsd_fuse_search(L.ctx, &v, pKF->mfLogScaleFactor, n_levels, &nl, nl, (const planar_keyline*)pKF->mvKeyLines.data(), ldesc.data(), &m, M, 0,
-                                                     usable.data(), xw6.data(), nrm.data(), mn.data(), mx.data(), desc.data(), th, idx.data(), nullptr, &nFused));
+        if (!planar_adapter::ok(planar_lsd_fuse_search(L.ctx, &v, pKF->mfLogScaleFactor, n_levels, &nl, nl, (const planar_keyline*)pKF->mvKeyLines.data(), ldesc.data(), &m, M, 0,
+                                                     usable.data(), xw6.data(), nrm.data(), mn.data(), mx.data(), desc.data(), th, idx.data(), nullptr, &nFused), "planar_lsd_fuse_search")) return 0;
     }
     for (int j = 0; j < M; j++) {                                                   // :993-1010
         if (idx[j] < 0) continue;
@@ -684,8 +693,8 @@ inline int PlaneMatcher::SearchMapByCoefficients(Frame& pF, const std::vector<Ma
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_plane_search_by_coefficients(L.ctx, 1, &np, np, coef.data(), T.data(), 0, &nm, nm ? nm : 1, valid.data(), mcoef.data(), npts.data(), maxp, pts.data(),
-                                                                  th, a.data(), v.data(), par.data(), &nmatches));
+        if (!planar_adapter::ok(planar_plane_search_by_coefficients(L.ctx, 1, &np, np, coef.data(), T.data(), 0, &nm, nm ? nm : 1, valid.data(), mcoef.data(), npts.data(), maxp, pts.data(),
+                                                                  th, a.data(), v.data(), par.data(), &nmatches), "planar_plane_search_by_coefficients")) return 0;
     }
     for (int i = 0; i < np; i++) {
         if (a[i] >= 0) pF.mvpMapPlanes[i] = vpMapPlanes[a[i]];
@@ -736,7 +745,7 @@ template <class FrameT> inline int pose_opt(FrameT* pFrame, int mode) {
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::tracking_lane();
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_pose_opt(L.ctx, &pb, &prm, mode, 4, 10));
+        if (!planar_adapter::ok(planar_pose_opt(L.ctx, &pb, &prm, mode, 4, 10), "planar_pose_opt")) return 0;
     }
     // the reference writes the flags of the correspondences it used and the pose through Frame::SetPose
     for (int i = 0; i < N; i++) if (pt_valid[i]) pFrame->mvbOutlier[i] = pt_out[i] != 0;
@@ -875,7 +884,7 @@ inline void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Ma
     {
         planar_adapter::Runtime::Lane& L = planar_adapter::Runtime::get().lane(planar_adapter::TRACKING);
         std::lock_guard<std::mutex> g(L.mu);
-        planar_adapter::check(planar_local_ba(L.ctx, &P, &prm, 5, 10, &R, reinterpret_cast<const volatile unsigned char*>(pbStopFlag), nullptr));
+        if (!planar_adapter::ok(planar_local_ba(L.ctx, &P, &prm, 5, 10, &R, reinterpret_cast<const volatile unsigned char*>(pbStopFlag), nullptr), "planar_local_ba")) return;
     }
     // erase lists (:2471-2620) and write-back (:2622-2680) under the map mutex
     std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);

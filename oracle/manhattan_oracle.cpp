@@ -156,4 +156,22 @@ int orc_track_manhattan(const float* R_last, const float* normals, int n, const 
     return nfound;
 }
 
+
+// mRotation_wc = (Rotation_cm * MF_can^T)^T copied into mTcw's rotation block before TranslationOptimization (src/Tracking.cc:251-253, 1778).  MF_can_T is a
+// materialised cv::Mat, so the product carries no transpose flag and takes cv::gemm's small-matrix path (3x3 CV_32F): products and sums in float, then
+// (float)(t * alpha) with alpha = 1.0 a double.  Pinned to the real statements: oracle/_ref/ref_frame manhattan_pose (tests/test_oracle_frame_ref.py).
+void orc_manhattan_pose(const float* Rcm0, const float* MF_can, const float* Tcw_in, float* Tcw_out, int n) {
+    for (int b = 0; b < n; b++) {
+        const float* R0 = Rcm0 + 9 * b; const float* A = MF_can + 9 * b;
+        float T[16];
+        std::memcpy(T, Tcw_in + 16 * b, 64);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                const float t = R0[3 * i] * A[3 * j] + R0[3 * i + 1] * A[3 * j + 1] + R0[3 * i + 2] * A[3 * j + 2];   // (Rotation_cm * MF_can_T)(i, j)
+                T[4 * j + i] = (float)((double)t * 1.0);                                                            // transposed into mTcw(j, i)
+            }
+        std::memcpy(Tcw_out + 16 * b, T, 64);
+    }
+}
+
 }  // extern "C"

@@ -84,6 +84,19 @@ int run_manhattan(Reader& r, Writer& w) {
     return 0;
 }
 
+// src/Tracking.cc:251-253 + :1778: mRotation_wc = (Rotation_cm * MF_can^T)^T copied into mTcw's rotation block
+int run_manhattan_pose(Reader& r, Writer& w) {
+    const int B = r.get<int>();
+    for (int b = 0; b < B; b++) {
+        const float* R0 = r.arr<float>(9); const float* Rn = r.arr<float>(9); const float* T = r.arr<float>(16);
+        Tracking K;
+        K.Rotation_cm = mat_f32(3, 3, R0); K.MF_can = mat_f32(3, 3, Rn); K.mCurrentFrame.mTcw = mat_f32(4, 4, T);
+        K.ManhattanPoseStatements();
+        w.arr((const float*)K.mCurrentFrame.mTcw.data, 16);
+    }
+    return 0;
+}
+
 int run_frustum_points(Reader& r, Writer& w) {
     Frame F;
     set_camera(F, r);
@@ -270,6 +283,7 @@ int main(int argc, char** argv) {
     Reader r(argv[2]);
     Writer w(argv[3]);
     if (m == "manhattan") return run_manhattan(r, w);
+    if (m == "manhattan_pose") return run_manhattan_pose(r, w);
     if (m == "frustum_points") return run_frustum_points(r, w);
     if (m == "frustum_lines") return run_frustum_lines(r, w);
     if (m == "area") return run_area(r, w);

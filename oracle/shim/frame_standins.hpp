@@ -161,6 +161,8 @@ public:
     ResultOfMS ProjectSN2MF(int a, const cv::Mat& R_cm, const vector<SurfaceNormal>& vTempSurfaceNormal, vector<FrameLine>& vVanishingDirection, const int numOfSN);
     axiSNV ProjectSN2Conic(int a, const cv::Mat& R_cm, const vector<SurfaceNormal>& vTempSurfaceNormal, vector<FrameLine>& vVanishingDirection);
     cv::Mat TrackManhattanFrame(cv::Mat& mLastRcm, vector<SurfaceNormal>& vSurfaceNormal, vector<FrameLine>& vVanishingDirection);
+    void ManhattanPoseStatements();   // src/Tracking.cc:251-253 (MF_can_T, mRotation_wc) and :1778 (copied into mCurrentFrame.mTcw), wrapped by oracle/Makefile
+    cv::Mat MF_can, MF_can_T, mRotation_wc, Rotation_cm;   // include/Tracking.h
     Frame mCurrentFrame;
 };
 

@@ -11,7 +11,14 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PLANAR_HIP_LIB: a developer override (e.g. the -DPLANAR_PEAC_TIMING build made by `make -C planarslam_amd/csrc timing`); never a fallback
-LIB_PATH = os.environ.get("PLANAR_HIP_LIB") or os.path.join(_HERE, "libplanar_hip.so")
+LIB_PATH = os.path.join(_HERE, "libplanar_hip.so")
+if os.environ.get("PLANAR_HIP_LIB"):
+    _ov = os.path.abspath(os.environ["PLANAR_HIP_LIB"])
+    if os.path.dirname(_ov) != _HERE:      # only builds that sit next to the product library (in-tree: what the driver records as loaded native code)
+        raise ImportError(f"PLANAR_HIP_LIB={_ov}: a developer override must be a library inside {_HERE}")
+    import warnings
+    warnings.warn(f"planarslam_amd: loading the developer build {_ov} instead of libplanar_hip.so (PLANAR_HIP_LIB)")
+    LIB_PATH = _ov
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])

@@ -222,10 +222,10 @@ __global__ void manhattan_pose_kernel(int B, const float* __restrict__ Rcm_new, 
     for (int k = 0; k < 16; k++) T[k] = Ti[k];
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) {
-            // (Rotation_cm * MF_can^T)(c, r) = sum_k Rotation_cm(c, k) * MF_can(r, k), accumulated in double as cv::gemm does for small float matrices, then transposed
-            double acc = 0;
-            for (int k = 0; k < 3; k++) acc += (double)R0[3 * c + k] * (double)A[3 * r + k];
-            T[4 * r + c] = (float)acc;
+            // (Rotation_cm * MF_can_T)(c, r) = sum_k Rotation_cm(c, k) * MF_can(r, k): MF_can_T is a materialised cv::Mat, the product has no transpose flag and
+            // takes cv::gemm's small-matrix path for 3x3 CV_32F - products and sums in float, then (float)(t * alpha) with alpha = 1.0 a double; then transposed
+            const float t = R0[3 * c] * A[3 * r] + R0[3 * c + 1] * A[3 * r + 1] + R0[3 * c + 2] * A[3 * r + 2];
+            T[4 * r + c] = (float)((double)t * 1.0);
         }
     for (int k = 0; k < 16; k++) To[k] = T[k];
 }

@@ -1330,6 +1330,7 @@ struct planar_lsd {
     // the rest (improve, accept, KeyLines, LBD)
     bool profiling = false;
     std::vector<std::vector<hipEvent_t>> ev_sets;
+    std::vector<char> ev_complete;       // the detect half of the set was recorded too (planar_lsd_detect_dev followed planar_lsd_preprocess_dev)
     size_t ev_used = 0;
     std::vector<hipEvent_t>* ev_cur = nullptr;
     ~planar_lsd() { for (auto& v : ev_sets) for (hipEvent_t e : v) (void)hipEventDestroy(e); }
@@ -1460,6 +1461,7 @@ void planar_lsd_destroy(planar_lsd* o) { delete o; }
 int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride) {
     PLANAR_REQUIRE(o && d_gray, PLANAR_EINVAL, "null argument");
     PLANAR_REQUIRE(B >= 1 && B <= o->max_batch, PLANAR_EINVAL, "B out of range");
+    PLANAR_REQUIRE(B <= 65535, PLANAR_EINVAL, "at most 65535 frames per call (the frame index is a grid's y / z coordinate in several launches)");
     PLANAR_REQUIRE(pitch >= o->W, PLANAR_EINVAL, "bad pitch");
     hipStream_t st = o->ctx->stream;
     const lsd::Plan& P = o->plan;
@@ -1473,7 +1475,9 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
             std::vector<hipEvent_t> v(5);
             for (hipEvent_t& e : v) PLANAR_HIP_CHECK(hipEventCreate(&e));
             o->ev_sets.push_back(v);
+            o->ev_complete.push_back(0);
         }
+        o->ev_complete[o->ev_used] = 0;
         o->ev_cur = &o->ev_sets[o->ev_used++];
         (void)hipEventRecord((*o->ev_cur)[0], st);
     }
@@ -1510,7 +1514,7 @@ int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d
     hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm);
     hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines);
     hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
-    if (o->ev_cur) { (void)hipEventRecord((*o->ev_cur)[4], st); o->ev_cur = nullptr; }
+    if (o->ev_cur) { (void)hipEventRecord((*o->ev_cur)[4], st); o->ev_complete[o->ev_used - 1] = 1; o->ev_cur = nullptr; }
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
 }
@@ -1527,13 +1531,17 @@ int planar_lsd_get_profile(planar_lsd* o, double* total_ms /* [4] */, int64_t* c
     PLANAR_REQUIRE(o && total_ms && calls, PLANAR_EINVAL, "null argument");
     PLANAR_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
     for (int i = 0; i < 4; i++) total_ms[i] = 0;
-    for (size_t c = 0; c < o->ev_used; c++)
+    int64_t counted = 0;
+    for (size_t c = 0; c < o->ev_used; c++) {
+        if (!o->ev_complete[c]) continue;            // a preprocess-only call: events [3], [4] were never recorded
         for (int i = 0; i < 4; i++) {
             float ms = 0;
             PLANAR_HIP_CHECK(hipEventElapsedTime(&ms, o->ev_sets[c][i], o->ev_sets[c][i + 1]));
             total_ms[i] += ms;
         }
-    *calls = (int64_t)o->ev_used;
+        counted++;
+    }
+    *calls = counted;
     o->ev_used = 0;
     return PLANAR_OK;
 }

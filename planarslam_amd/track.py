@@ -12,11 +12,9 @@ The sequence of the reference's tracking thread for one RGB-D frame (src/Trackin
     (:1954-2040)                              LSDmatcher::SearchByProjection - PoseOptimization - UnprojectStereo of the new frame's keypoints
                                               (the next frame's "last frame" map points)
 
-Departure from :1778 (default): the reference copies the Manhattan rotation mRotation_wc = (Rotation_cm * MF_can^T)^T into the pose before
-TranslationOptimization.  The synthetic streams are image-plane pans of a static RGB-D canvas - there is no camera rotation for the Manhattan tracker to
-find that would also explain the point matches - and with that rotation 64 instead of 595 point matches per frame survive TranslationOptimization
-(measured), so the bench would time a tracker that has lost most of its matches.  TrackPipeline(manhattan_rotation=True) does what :1778 does
-(planar_manhattan_pose_dev); the default keeps the last pose's rotation, and the Manhattan stage feeds the next frame's mLastRcm only.
+Manhattan rotation (:250-253, :1778): mRotation_wc = (Rotation_cm * MF_can^T)^T is copied into the pose before TranslationOptimization, as the reference does
+(planar_manhattan_pose_dev; manhattan_rotation=False keeps the last pose's rotation instead).  Rotation_cm is initialised as in :224-230: FindManhattan on the
+stream's first frame (a host-side stand-in of Map::FindManhattan in build_map: Map is out of scope), refined by TrackManhattanFrame on the first tracked frame.
 
 What is NOT the reference's code path and only stands in for the map it maintains (Map / KeyFrame / LocalMapping are out of scope):
 the local map of a stream is the previous two frames' own back-projected keypoints, the reference key frame's lines and the map planes are
@@ -37,7 +35,7 @@ class TrackPipeline:
     MAX_POSE_PLANES = 16
 
     def __init__(self, B, torch, device_index=0, depth=2, prio=(-1, 0, 0), cam=None, W=640, H=480, n_map_planes=8, n_plane_pts=128, n_normals=4096,
-                 run_fallback_matcher=True, manhattan_rotation=False):
+                 run_fallback_matcher=True, manhattan_rotation=True):
         from . import Context, ORBextractor, Optimizer, PlaneDetection
         from .lines import LineSegment
         from .planes import PlaneClouds, SurfaceNormals
@@ -147,6 +145,7 @@ class TrackPipeline:
         self.skip = set(os.environ.get("PLANAR_TRACK_SKIP", "").split(","))     # timing diagnosis only (tools): leave a stage's launches out, results are then meaningless
         self.pending = []
         self.map_set = False
+        self.rcm0_set = False           # Rotation_cm is fixed by the first tracked frame
         self.step_count = 0
         self.capture_steps = set()      # tests: steps whose stage inputs / outputs are cloned (on the stream) into self.captured[j]
         self.captured = {}
@@ -289,6 +288,9 @@ class TrackPipeline:
             check(L.planar_track_manhattan_frame_dev(self.ctx_t.h, B, self.Rcm.data_ptr(), self.snrm[k].data_ptr(), self.n_snrm.data_ptr(), self.SN,
                                                      self.l3[k]["packed"].data_ptr(), self.l3[k]["n_good"].data_ptr(), 40,
                                                      self.Rcm_new.data_ptr(), None, None, None))
+            if not self.rcm0_set:                           # Rotation_cm = TrackManhattanFrame(FindManhattan(first frame), ...) (src/Tracking.cc:227-230): the first tracked frame
+                check(L.planar_copy_rows_dev(self.ctx_t.h, self.Rcm0.data_ptr(), B * 36, self.Rcm_new.data_ptr(), B * 36, B * 36, 1))
+                self.rcm0_set = True
             if evs: evs["manhattan"].record(st)
             # ---- TranslationWithMotionModel ----
             fv = self._frame_view(k, self.pose)             # zero-velocity motion model: predicted pose = last pose
@@ -317,9 +319,8 @@ class TrackPipeline:
                                                             self.mp["npts"].data_ptr(), self.mp["pts"].shape[2], self.mp["pts"].data_ptr(), self.plane_th.ctypes.data,
                                                             self.plm[0].data_ptr(), self.plm[2].data_ptr(), self.plm[1].data_ptr(), self.nplm.data_ptr()))
             if evs: evs["planes"].record(st)
-            if cap is not None: snap("pl_coef", pc["coef"]); snap("pl_n", pc["n"]); snap("pl_src", pc["src"]); snap("pl_off", pc["off"]); snap("pl_pts", pc["pts"]); snap("pl_status", pc["status"]); snap("plm", self.plm); snap("nplm", self.nplm); snap("Rcm_new", self.Rcm_new)
+            if cap is not None: snap("pl_coef", pc["coef"]); snap("pl_n", pc["n"]); snap("pl_src", pc["src"]); snap("pl_off", pc["off"]); snap("pl_pts", pc["pts"]); snap("pl_status", pc["status"]); snap("plm", self.plm); snap("nplm", self.nplm); snap("Rcm_new", self.Rcm_new); snap("Rcm0", self.Rcm0)
             # mRotation_wc.copyTo(mCurrentFrame.mTcw.rowRange(0,3).colRange(0,3)) (:1778): the translation is optimised against the Manhattan rotation of THIS frame.
-            # Off by default for the synthetic streams (module docstring); planar_manhattan_pose_dev is the ABI entry a real tracker calls here.
             pose_t = self.pose
             if self.manhattan_rotation:
                 check(L.planar_manhattan_pose_dev(self.ctx_t.h, B, self.Rcm_new.data_ptr(), self.Rcm0.data_ptr(), self.pose.data_ptr(), self.pose_mf.data_ptr()))
@@ -400,6 +401,36 @@ class TrackPipeline:
                                    "(3 = more voxels than max_points / coordinate range, 4 = sampler table exhausted)")
 
 
+def find_manhattan(normals, sizes, ver_th=0.08716):
+    """Host-side stand-in of Map::FindManhattan (reference src/Map.cc:160-363; Map is out of scope, SURVEY §2), plane branch: the pair of frame planes whose
+    normals are perpendicular within ver_th with the most points; their normals (signs: largest component positive) and the cross product, sorted by the axis
+    each is closest to, orthonormalised by U * V^T of the SVD.  normals [n,3], sizes [n] -> Rotation_cm [3,3] f32 (identity without such a pair)."""
+    best, max_size = None, 0
+    n = len(normals)
+    for i in range(n):
+        for j in range(i + 1, n):
+            angle = float(np.float32(normals[i][0]) * np.float32(normals[j][0]) + np.float32(normals[i][1]) * np.float32(normals[j][1]) + np.float32(normals[i][2]) * np.float32(normals[j][2]))
+            if -ver_th < angle < ver_th and sizes[i] + sizes[j] > max_size:
+                max_size = sizes[i] + sizes[j]
+                best = (np.asarray(normals[i], np.float32).copy(), np.asarray(normals[j], np.float32).copy())
+    R = np.eye(3, dtype=np.float32)
+    if best is None:
+        return R
+    p1, p2 = best
+    loc1 = int(np.argmax(np.abs(p1))); p1 = -p1 if p1[loc1] < 0 else p1
+    loc2 = int(np.argmax(np.abs(p2))); p2 = -p2 if p2[loc2] < 0 else p2
+    p3 = np.cross(p1, p2).astype(np.float32)
+    loc3 = int(np.argmax(np.abs(p3))); p3 = -p3 if p3[loc3] < 0 else p3
+    by_axis = {loc1: p1}
+    by_axis[loc2] = p2
+    by_axis[loc3] = p3
+    if len(by_axis) < 3:
+        return R
+    M = np.stack([by_axis[0], by_axis[1], by_axis[2]], 1).astype(np.float32)       # columns: the x-, y-, z-like directions
+    U, _, Vt = np.linalg.svd(M.astype(np.float64))
+    return (U @ Vt).astype(np.float32)
+
+
 def build_map(gray0, depth0, cam, torch_dev=None, seed=0, n_map_planes=8, n_plane_pts=128, n_normals=4096):
     """Host-side stand-in for the map of each stream, built from its first frame with the product extractors (numpy in, numpy out):
     the reference key frame's lines (end points back-projected with the depth at the end points, as Frame::isLineGood does when the depth is
@@ -442,4 +473,6 @@ def build_map(gray0, depth0, cam, torch_dev=None, seed=0, n_map_planes=8, n_plan
             pp = np.stack([(xx - cx) * zz / fx, (yy - cy) * zz / fy, zz], -1)
             mp["npts"][b, q] = len(pp); mp["pts"][b, q, :len(pp)] = pp; mp["valid"][b, q] = 1
     sc = manhattan_scene(B=B, n_normals=n_normals, n_lines=40, seed=21 + seed)
-    return kf_lines, mp, dict(normals=sc["normals"], n_normals=sc["n_normals"], lines=sc["lines"], n_lines=sc["n_lines"], R_last=sc["R_last"])
+    # Rotation_cm's seed: FindManhattan on the first frame's planes (refined by TrackManhattanFrame on the first tracked frame, TrackPipeline._track_on_stream)
+    R_last = np.stack([find_manhattan([np.asarray(pl[1:4]) for pl in res[b][0]], [int((res[b][1] == q).sum()) for q in range(len(res[b][0]))]) for b in range(B)])
+    return kf_lines, mp, dict(normals=sc["normals"], n_normals=sc["n_normals"], lines=sc["lines"], n_lines=sc["n_lines"], R_last=R_last)

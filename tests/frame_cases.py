@@ -38,3 +38,20 @@ def stereo_case():
     n = np.array([S, 1000, 37], np.int32)
     Tcw = np.stack([synth._se3(rng, 0.3, rng.normal(0, 0.5, 3)).astype(np.float32).ravel() for _ in range(B)])
     return keys, n, depth, Tcw
+
+
+def manhattan_pose_case(n=64, seed=31):
+    """Rotation_cm [n,9], MF_can [n,9] (unit-quaternion rotations, a few of them only slightly apart as on consecutive frames) and mTcw [n,16]"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+
+    def rot(q):
+        q = q / np.linalg.norm(q, axis=1, keepdims=True)
+        w, x, y, z = q.T
+        return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).astype(np.float32)
+    q0 = rng.normal(size=(n, 4))
+    q1 = np.where((np.arange(n) % 2 == 0)[:, None], q0 + rng.normal(scale=0.01, size=(n, 4)), rng.normal(size=(n, 4)))
+    T = np.tile(np.eye(4, dtype=np.float32).reshape(1, 16), (n, 1)); T[:, [3, 7, 11]] = rng.normal(size=(n, 3)).astype(np.float32)
+    T[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]] = rot(rng.normal(size=(n, 4)))
+    return rot(q0), rot(q1), T

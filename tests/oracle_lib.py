@@ -729,6 +729,23 @@ def run_ref_manhattan(R_last, normals, lines):
     return dict(R=np.frombuffer(buf, "<f4", 9, 0).reshape(3, 3).copy(), member=np.frombuffer(buf, np.uint8, n + nl, 36).copy())
 
 
+def run_ref_manhattan_pose(Rcm0, MF_can, Tcw):
+    """The reference's own statements src/Tracking.cc:251-253 + :1778 (oracle/_ref/ref_frame manhattan_pose): mRotation_wc = (Rotation_cm * MF_can^T)^T copied into mTcw."""
+    Rcm0 = np.ascontiguousarray(Rcm0, np.float32).reshape(-1, 9); MF = np.ascontiguousarray(MF_can, np.float32).reshape(-1, 9); T = np.ascontiguousarray(Tcw, np.float32).reshape(-1, 16)
+    n = len(T)
+    pay = np.int32(n).tobytes() + b"".join(Rcm0[b].tobytes() + MF[b].tobytes() + T[b].tobytes() for b in range(n))
+    return np.frombuffer(_run_ref_frame("manhattan_pose", pay), "<f4").reshape(n, 16).copy()
+
+
+def manhattan_pose(Rcm0, MF_can, Tcw):
+    """oracle/manhattan_oracle.cpp orc_manhattan_pose: [n,9], [n,9], [n,16] f32 -> [n,16] f32"""
+    L = lib()
+    Rcm0 = np.ascontiguousarray(Rcm0, np.float32).reshape(-1, 9); MF = np.ascontiguousarray(MF_can, np.float32).reshape(-1, 9); T = np.ascontiguousarray(Tcw, np.float32).reshape(-1, 16)
+    out = np.zeros_like(T)
+    L.orc_manhattan_pose(C.c_void_p(Rcm0.ctypes.data), C.c_void_p(MF.ctypes.data), C.c_void_p(T.ctypes.data), C.c_void_p(out.ctypes.data), len(T))
+    return out
+
+
 def _camera_block(frame, log_scale_factor, n_levels):
     cam = np.array([frame["fx"], frame["fy"], frame["cx"], frame["cy"], frame["bf"], frame["min_x"], frame["max_x"], frame["min_y"], frame["max_y"],
                     log_scale_factor], np.float32)

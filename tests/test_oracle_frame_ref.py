@@ -23,6 +23,18 @@ def golden(golden_dir):
     return np.load(os.path.join(golden_dir, "frame_ref.npz"))
 
 
+def test_manhattan_pose_oracle_equals_reference_fixture(golden):
+    """mRotation_wc = (Rotation_cm * MF_can^T)^T into mTcw (src/Tracking.cc:251-253, 1778): the oracle against the real statements (cv::gemm's float small-matrix path)"""
+    R0, MF, T = cases.manhattan_pose_case()
+    want = golden["manhattan_pose/Tcw"]
+    got = ol.manhattan_pose(R0, MF, T)
+    assert np.array_equal(got, want)
+    dbl = np.einsum("nik,njk->nij", R0.reshape(-1, 3, 3).astype(np.float64), MF.reshape(-1, 3, 3).astype(np.float64)).astype(np.float32)   # what a double accumulation would give
+    assert (dbl.transpose(0, 2, 1) != want.reshape(-1, 4, 4)[:, :3, :3]).any(), "the case does not tell float from double accumulation"
+    if HAVE_REF:
+        assert np.array_equal(ol.run_ref_manhattan_pose(R0, MF, T), want)
+
+
 @pytest.mark.parametrize("name", list(cases.MANHATTAN_CASES))
 def test_manhattan_oracle_equals_reference_fixture(golden, name):
     sc = synth.manhattan_scene(**cases.MANHATTAN_CASES[name])

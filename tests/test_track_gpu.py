@@ -178,7 +178,10 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
     assert np.array_equal(a, c["plm"][0]) and np.array_equal(p, c["plm"][1]) and np.array_equal(v, c["plm"][2]) and np.array_equal(npm, c["nplm"])
     # ---- assembled translation problem + TranslationOptimization ----
     T = c["pbT"]
-    assert np.array_equal(T["Tcw_in"], c["pose_in"])          # (default: the last pose; TrackPipeline(manhattan_rotation=True) is what src/Tracking.cc:1778 does, see below)
+    # src/Tracking.cc:1778: the last pose with the Manhattan rotation (Rotation_cm * MF_can^T)^T of THIS frame in its rotation block (oracle pinned to the real statements)
+    assert np.array_equal(T["Tcw_in"], ol.manhattan_pose(c["Rcm0"], c["Rcm_new"], c["pose_in"]))
+    rot_gap = np.abs(T["Tcw_in"].reshape(B, 4, 4)[:, :3, :3] - c["pose_in"].reshape(B, 4, 4)[:, :3, :3]).max()
+    assert rot_gap < 0.02, rot_gap                              # the streams pan without rotating: the Manhattan rotation stays next to the tracked one
     for b in range(0, B, 11):
         n = int(c["n"][b])
         ok = c["pm0"][b, :n] >= 0
@@ -299,35 +302,17 @@ def test_pose_with_the_oracles_own_plane_chain(run, which):
 
 
 def test_manhattan_rotation_into_the_translation_pose():
-    """planar_manhattan_pose_dev = mRotation_wc = (Rotation_cm * MF_can^T)^T copied into mTcw's rotation block (src/Tracking.cc:250-253, 1778)."""
+    """planar_manhattan_pose_dev = mRotation_wc = (Rotation_cm * MF_can^T)^T copied into mTcw's rotation block (src/Tracking.cc:251-253, 1778), against the oracle
+    that tests/test_oracle_frame_ref.py pins to the real statements (cv::gemm's small-matrix path: float products, float sums)."""
     import torch
+    import frame_cases
     from planarslam_amd import Context
     from planarslam_amd._lib import check, lib
-    rng = np.random.default_rng(3)
-    n = 37
-
-    def rot(k):
-        q = rng.normal(size=(k, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
-        w, x, y, z = q.T
-        return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).astype(np.float32)
-    Rn, R0 = rot(n), rot(n)
-    T = np.tile(np.eye(4, dtype=np.float32).reshape(1, 16), (n, 1)); T[:, [3, 7, 11]] = rng.normal(size=(n, 3)).astype(np.float32)
+    R0, Rn, T = frame_cases.manhattan_pose_case()
+    n = len(T)
     dev = torch.device("cuda", 0)
     dRn, dR0, dT = (torch.from_numpy(a).to(dev) for a in (Rn, R0, T))
     out = torch.zeros_like(dT)
     ctx = Context(0, stream=torch.cuda.current_stream().cuda_stream)
     check(lib().planar_manhattan_pose_dev(ctx.h, n, dRn.data_ptr(), dR0.data_ptr(), dT.data_ptr(), out.data_ptr()))
-    got = out.cpu().numpy().reshape(n, 4, 4)
-    want = np.zeros((n, 3, 3), np.float32)
-    for b in range(n):
-        M = np.zeros((3, 3), np.float32)                                            # Rotation_cm * MF_can^T, accumulated in double (cv::gemm), float result
-        for r in range(3):
-            for c2 in range(3):
-                acc = 0.0
-                for k in range(3):
-                    acc += float(R0[b, 3 * r + k]) * float(Rn[b, 3 * c2 + k])
-                M[r, c2] = np.float32(acc)
-        want[b] = M.T
-    assert np.array_equal(got[:, :3, :3], want)
-    assert np.array_equal(got[:, :3, 3], T.reshape(n, 4, 4)[:, :3, 3]) and np.array_equal(got[:, 3], T.reshape(n, 4, 4)[:, 3])
+    assert np.array_equal(out.cpu().numpy(), ol.manhattan_pose(R0, Rn, T))

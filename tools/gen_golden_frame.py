@@ -23,6 +23,8 @@ for name, kw in cases.MANHATTAN_CASES.items():
         r = O.run_ref_manhattan(sc["R_last"][b], sc["normals"][b, :n], sc["lines"][b, :m])
         R[b] = r["R"]; member[b, :n] = r["member"][:n]; member[b, sc["normals"].shape[1]:sc["normals"].shape[1] + m] = r["member"][n:]
     out[f"manhattan/{name}/R"] = R; out[f"manhattan/{name}/member"] = member
+R0, MF, T = cases.manhattan_pose_case()
+out["manhattan_pose/Tcw"] = O.run_ref_manhattan_pose(R0, MF, T)      # src/Tracking.cc:251-253 + :1778
 frame, mp, ml = cases.frustum_case()
 lsf, nlev = cases.frustum_scale()
 B, S = mp["valid"].shape

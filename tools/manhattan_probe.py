@@ -1,0 +1,19 @@
+"""How far the Manhattan rotation (src/Tracking.cc:250-253) is from the tracked rotation on the synthetic streams, and what TranslationOptimization keeps (developer probe)."""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import test_track_gpu as tt  # noqa: E402
+
+run = tt.run_pipeline()
+for which in (0, 1):
+    c = run["cap"][tt.STEPS - 2 + which]
+    T = c["pbT"]
+    gap = np.abs(T["Tcw_in"].reshape(-1, 4, 4)[:, :3, :3] - c["pose_in"].reshape(-1, 4, 4)[:, :3, :3]).max((1, 2))
+    ang = np.degrees(np.arccos(np.clip((np.einsum("nij,nij->n", T["Tcw_in"].reshape(-1, 4, 4)[:, :3, :3], c["pose_in"].reshape(-1, 4, 4)[:, :3, :3]) - 1) / 2, -1, 1)))
+    d0 = np.abs(c["Rcm_new"] - c["Rcm0"]).max(1)
+    print(f"step {which}: rotation gap max {gap.max():.4f} median {np.median(gap):.4f}; angle deg max {ang.max():.2f} median {np.median(ang):.3f}; |Rcm_new - Rcm0| max {d0.max():.4f} median {np.median(d0):.5f}")
+    print("   translation-opt inliers: mean %.1f min %d; pose-opt inliers mean %.1f min %d; projection matches mean %.1f" % (T["n_inliers"].mean(), T["n_inliers"].min(), c["pbP"]["n_inliers"].mean(), c["pbP"]["n_inliers"].min(), c["nm"].mean()))
+    worst = np.argsort(-ang)[:5]
+    print("   worst frames", worst.tolist(), "angles", np.round(ang[worst], 2).tolist(), "inliers", T["n_inliers"][worst].tolist())
