@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="camera streams per GPU = frames per GPU per step")
     ap.add_argument("--workload", choices=["full", "orb", "ba", "pose"], default="full",
                     help="full: the per-frame path (BASELINE metric); orb: config[1] only; ba: config[4], ONE local bundle adjustment partitioned over the ranks")
-    ap.add_argument("--depth", type=int, default=2, help="software-pipeline depth: the tracking chain of step i runs during step i + depth")
+    ap.add_argument("--depth", type=int, default=3, help="software-pipeline depth: the tracking chain of step i runs during step i + depth")
     ap.add_argument("--prio", default="-1,0,0", help="stream priorities: point stream, LSD streams, PEAC streams[, tracking stream] (lower = higher priority)")
     ap.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the cpu_baseline leg, split over its three variants (0 = skip)")
     ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 latency block (0 = skip)")

@@ -310,13 +310,14 @@ __device__ __forceinline__ void bitonic(unsigned long long* a, int n2) {
 //   plane_tail_kernel     thread per voxel: the FLOAT sums in that order, centroid = sum / (float)count; then the distance gate and the RANSAC refit (one
 //                         wavefront per plane) and the compaction of the kept planes
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
-constexpr int PS_T = 1024, PS_E = 23, PS_SHIFT = 19, PS_R = 24;
+constexpr int PS_T = 1024, PS_LT = 256, PS_E = 23, PS_SHIFT = 19, PS_R = 96;      // PS_T: threads of the item / global-tier kernels; PS_LT x PS_E: an LDS block (40 KB: four per CU, and room for the other streams' workgroups)
 constexpr int PS_HJOBS = 1024;                                     // heap-sort fallback: jobs per frame
 // ... run in three launches by size, so that the many short ranges do not each hold a CU's LDS: (longest range, words of LDS per wavefront, wavefronts
 // per workgroup, workgroups per frame); a range longer than the last class's LDS keeps the top of its heap there and the rest in place
 struct HeapClass { int max_len, cap, waves, wgs; };
-constexpr HeapClass PS_HC[3] = {{2048, 2048, 4, 1}, {16384, 16384, 1, 2}, {1 << 30, 36864, 1, 2}};
-using PsLds = isort::LdsLayout<PS_T, PS_E>;
+constexpr HeapClass PS_HC[3] = {{2048, 2048, 4, 1}, {8192, 8192, 1, 2}, {1 << 30, 8192, 1, 4}};   // (a pop costs ~0.6 us with the heap in LDS and ~1 us with only its top there: instruction latency
+// of a lone wavefront either way - but a workgroup that wants a whole CU's LDS waits for a CU to drain while the other streams keep them busy, so the long ranges keep 32 KB)
+using PsLds = isort::LdsLayout<PS_LT, PS_E>;
 using PsGl = isort::GlobalLayout<PS_T>;
 constexpr int ERR_SORT = 5;
 
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(PS_T) void plane_sort_global(Geo G, unsigned char* 
                                        (isort::Block*)(ws + G.off_blocks), isort::G_FMAX, meta->counts, sort_lds, rows_cap, HS, &meta->sort_status);
 }
 
-__global__ __launch_bounds__(PS_T) void plane_sort_lds(Geo G, unsigned char* ws_all) {
+__global__ __launch_bounds__(PS_LT) void plane_sort_lds(Geo G, unsigned char* ws_all) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
     Meta* meta = (Meta*)(ws + G.off_meta);
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(PS_T) void plane_sort_lds(Geo G, unsigned char* ws_
     const isort::HeapSink HS{(isort::HeapJob*)(ws + G.off_heapj), &meta->heap_n, PS_HJOBS};
     for (int k = blockIdx.y; k < nb; k += gridDim.y) {
         const isort::Block K = blocks[k];
-        isort::lds_tier<PS_SHIFT, PS_T, PS_E>((uint32_t*)(ws + G.off_items), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &meta->sort_status);
+        isort::lds_tier<PS_SHIFT, PS_LT, PS_E>((uint32_t*)(ws + G.off_items), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &meta->sort_status);
     }
 }
 
@@ -1070,10 +1071,11 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     mark();
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
     mark();
-    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_R), dim3(planepost::PS_T), p->smem_sort_l, st, G, ws);
+    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);
     mark();
-    for (int c = 0; c < 3 && !getenv("PLANAR_DEV_SKIP_HEAP"); c++) {   // (the environment variable: a developer's timing experiment, results are then wrong)
+    for (int c = 0; c < 3 && !getenv("PLANAR_DEV_SKIP_HEAP"); c++) {   // (the environment variables: a developer's timing experiments, results are then wrong)
         const planepost::HeapClass& H = planepost::PS_HC[c];
+        if (getenv("PLANAR_DEV_SKIP_HEAP_CLASS") && atoi(getenv("PLANAR_DEV_SKIP_HEAP_CLASS")) == c) continue;
         hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(B, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
     }
     mark();
@@ -1188,7 +1190,7 @@ int planar_merge_plane_points(planar_plane_clouds* p, const double* Twc, const f
     unsigned char* ws = p->ws.as<unsigned char>();
     hipLaunchKernelGGL(planepost::cloud_voxels_kernel, dim3(1), dim3(planepost::NT), p->smem_cloud, st, G, s.dev<float>(t_all), n, ws);
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(1), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
-    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(1, planepost::PS_R), dim3(planepost::PS_T), p->smem_sort_l, st, G, ws);
+    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(1, planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);
     for (int c = 0; c < 3 && !getenv("PLANAR_DEV_SKIP_HEAP"); c++) {   // (the environment variable: a developer's timing experiment, results are then wrong)
         const planepost::HeapClass& H = planepost::PS_HC[c];
         hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(1, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT
 timeout 240 python -c "import torch; print('warm', torch.cuda.is_available())"
-timeout 900 python -m pytest tests/test_track_gpu.py -q -x 2>&1 | tail -12
-timeout 600 python tools/gen_golden_track_pose.py gpurun_out/track_pose_ref.npz 2>&1 | tail -9
+P='import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], j["ms_per_step"], j["config"]["stage_ms_per_step"]["wait_lines_planes"], j["roofline"]["kernels"]["plane_clouds(voxels+items+sort+tail)"]["avg_launch_ms"])'
+F="--steps 16 --warmup 6 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
+for d in 3 4 6; do echo depth $d; timeout 300 python bench.py --depth $d $F 2>/dev/null | python -c "$P"; done

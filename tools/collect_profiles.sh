@@ -1,12 +1,12 @@
 #!/bin/bash
 # Runs ON THE GPU BOX in THREE short gpurun calls (a call that hangs must not eat the round's GPU budget: every command has its own timeout AND each call a
-# small gpurun --timeout):   gpurun --timeout 330 -- 'bash tools/collect_profiles.sh r03 bench'   |   ... r03 pmc   |   ... r03 suite
+# small gpurun --timeout):   gpurun --timeout 600 -- 'bash tools/collect_profiles.sh r04 bench'   |   ... r04 pmc   |   ... r04 suite
 # bench: the bench line, the BA bench, the rocprofv3 kernel summary of the same command.  pmc: HBM traffic and issue counters (separate passes, --kernel-trace only,
 # as gpurun requires).  suite: the GPU tests and smoke().  Outputs in gpurun_out/<tag>_*.
 # On a box whose image is still paging in, the first `import torch` alone takes 1-2 minutes: every mode starts with an untimed-in-spirit warm-up import (own timeout), so
 # that the per-command timeouts below measure the commands and not the cold start (twice this round a call on a cold box ran into every timeout with no output).
 # Give the bench mode `gpurun --timeout 600`.
-tag=${1:-r03}; what=${2:-bench}
+tag=${1:-r04}; what=${2:-bench}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 240 python -c "import torch, numpy; print('warm', torch.cuda.is_available())" > $O/${tag}_warmup.log 2>&1
@@ -14,10 +14,11 @@ FL="--steps 6 --warmup 3 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
 # counter passes: the canvases are synthesised in-process (--gen-procs 1, 16 of them): rocprofv3 --pmc hangs when the profiled process forks workers (profiles/README.md)
 PF="--gen-procs 1 --canvases 16 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
 if [ $what = bench ]; then
-    timeout 150 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+    timeout 240 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
     timeout 60 python bench.py --workload ba --steps 20 --warmup 3 > $O/${tag}_bench_ba.json 2>> $O/${tag}_bench.err
+    timeout 90 python bench.py --workload pose --steps 50 --warmup 5 > $O/${tag}_bench_pose.json 2>> $O/${tag}_bench.err
     cd /tmp && export TMPDIR=/tmp
-    timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
+    timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
     cd $R
     f=$(ls $O/${tag}_trace/*/*kernel_stats.csv | head -1); cp $f $O/${tag}_kernel_stats.csv
     t=$(ls $O/${tag}_trace/*/*kernel_trace.csv | head -1); (head -1 $t; tail -80 $t) > $O/${tag}_kernel_trace_tail.csv
@@ -35,7 +36,7 @@ elif [ $what = pmc ]; then
     rm -rf $O/${tag}_pmc_fetch $O/${tag}_pmc_write $O/${tag}_pmc_sq1 $O/${tag}_pmc_sq2
     head -8 $O/${tag}_pmc_fetch_write_kb_per_launch.csv; head -8 $O/${tag}_pmc_sq_per_launch.csv
 else
-    timeout 200 python -m pytest tests -m gpu -q > $O/${tag}_gpu_tests.log 2>&1
+    timeout 300 python -m pytest tests -m gpu -q > $O/${tag}_gpu_tests.log 2>&1
     timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${tag}_smoke.log 2>&1
     grep -a "passed\|failed" $O/${tag}_gpu_tests.log; tail -1 $O/${tag}_smoke.log
 fi
