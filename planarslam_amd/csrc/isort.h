@@ -155,7 +155,7 @@ __device__ __forceinline__ int median_pos(uint32_t xa, uint32_t xb, uint32_t xc,
 //   * __make_heap's sift-downs of the nodes of one depth touch disjoint subtrees: a whole depth at a time, one lane per node;
 //   * in __sort_heap pop t + 1 reads at heap level j what pop t wrote at level j + 1: pops run two levels apart, HP of them in flight on HP lanes of
 //     one wavefront.  A pop starts (it takes the last heap element as its value and puts the root there) only when no earlier pop in flight can
-//     still reach that element, i.e. none of their holes is one of its ancestors.
+//     still reach that element, i.e. none of their holes is one of its ancestors.  (HP >= half the heap's depth: 8 lanes for 16 levels.)
 // Jobs (ranges) are recorded by the two tiers and run by heap_jobs afterwards; a range's first H_LDS elements (the top of the heap) live in LDS.
 struct HeapJob { int f, l; };
 struct HeapSink { HeapJob* jobs; int* n; int cap; };      // where the tiers record the ranges that need the fallback (global memory; n: atomic counter)
@@ -208,14 +208,14 @@ __device__ __forceinline__ void heap_sort_wave(const HeapMem<HYBRID>& M, int k) 
         M.sync();
     }
     // __sort_heap: pop t (t = 0 .. k - 2) takes the last element z = k - 1 - t of the heap as its value, puts the root there and sifts in the heap of z
-    // elements; lane t % HP runs it, one level per step, started at least two steps after pop t - 1: by construction it reads at level j + 1 what its
-    // predecessor wrote two or more steps ago, and nothing else has to be checked from step to step.
+    // elements; lane t % HP runs it, TWO levels per step (two half-steps with a fence between them), and a new pop starts every step: pop t + 1 reads level
+    // j + 1 in the half-step after pop t wrote it, so by construction nothing else has to be checked from step to step.
     bool on = false;                       // this lane has a pop in flight
     int h = 0, lv = 0, len = 0;            // its hole, the hole's level, its heap size
     uint32_t v = 0;
-    int next = 0, gap = 2;                 // the next pop to start, steps since the last start (uniform)
+    int next = 0;                          // the next pop to start (uniform)
     while (true) {
-        if (next <= k - 2 && gap >= 2) {
+        if (next <= k - 2) {
             // ... unless a pop in flight can still reach z (its hole is z or one of z's ancestors: it may yet write there), or the lane is still busy
             const int z = k - 1 - next, zl = heap_level(z), owner = next % HP;
             const bool blocks = on && (lane == owner || (lv <= zl && ((z + 1) >> (zl - min(lv, zl))) == h + 1));
@@ -223,12 +223,13 @@ __device__ __forceinline__ void heap_sort_wave(const HeapMem<HYBRID>& M, int k) 
                 const uint32_t vz = M.ld(z), root = M.ld(0);
                 if (lane == owner) { on = true; h = 0; lv = 0; len = z; v = vz; M.st(z, root); }
                 M.sync();
-                next++; gap = 0;
+                next++;
             }
         }
         if (on) { on = sift_step<SHIFT, HYBRID>(M, h, len, v); lv++; }
         M.sync();
-        gap++;
+        if (on) { on = sift_step<SHIFT, HYBRID>(M, h, len, v); lv++; }
+        M.sync();
         if (next > k - 2 && __ballot(on) == 0ull) break;
     }
 }
