@@ -728,6 +728,13 @@ int planar_discard_outliers_dev(planar_ctx* ctx, int B, const int32_t* d_n, int 
  *   keypoint_fields    KeyPoint::octave / ::angle of n key points into flat arrays
  *   add_scalar_i32     dst = src + value (per-line rand() seeds of Frame::isLineGood: base + step offset)
  *   copy_rows          pitched device-to-device row copy */
+/* Frame::UndistortKeyPoints (reference src/Frame.cc:545-573: cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK), five iterations in double): keys [B][stride]
+ * -> keys_un [B][stride] (every field copied, pt undistorted); dist_coef: host array k1, k2, p1, p2, k3 (Camera.k1 .. Camera.k3 of the reference's yaml files);
+ * k1 == 0 copies, as :546-549.  Frame::ComputeImageBounds (:575-598) is the same call on the four image corners. */
+int planar_undistort_keypoints(planar_ctx* ctx, int B, const planar_keypoint* keys, const int32_t* n, int stride, float fx, float fy, float cx, float cy, const float* dist_coef,
+                               planar_keypoint* keys_un);
+int planar_undistort_keypoints_dev(planar_ctx* ctx, int B, const planar_keypoint* d_keys, const int32_t* d_n, int stride, float fx, float fy, float cx, float cy,
+                                   const float* dist_coef, planar_keypoint* d_keys_un);
 int planar_reset_matches_dev(planar_ctx* ctx, int32_t* d_match, int64_t n);
 int planar_blocked_mask_dev(planar_ctx* ctx, const int32_t* d_match, int64_t n, uint8_t* d_mask);
 int planar_merge_matches_dev(planar_ctx* ctx, const int32_t* d_first, const int32_t* d_second, int offset, int64_t n, int32_t* d_out);

@@ -679,6 +679,36 @@ void stereo_from_rgbd(const planar_keypoint* keys, const planar_keypoint* keys_u
     }
 }
 }  // namespace orc
+// Frame::UndistortKeyPoints (src/Frame.cc:545-573) = cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK).  PARITY UNPINNED: OpenCV is not in this image and
+// the reference holds no test vector for it; this is the published loop of imgproc/src/undistort.cpp (3.4.x cvUndistortPointsInternal, default criteria = 5 iterations,
+// no tilt: invMatTilt = I), kept in the library's literal form (k[14] with zeros past the five given, RR = P * I through a 3x3 double product) so that the device's
+// simplified form is checked against every term the library evaluates.
+extern "C" int orc_undistort_keypoints(const planar_keypoint* keys, int n, float fx_, float fy_, float cx_, float cy_, const float* dist5, planar_keypoint* keys_un) {
+    for (int i = 0; i < n; i++) keys_un[i] = keys[i];
+    if (dist5[0] == 0.0f) return 0;                                             // :546-549
+    double A[3][3] = {{(double)fx_, 0, (double)cx_}, {0, (double)fy_, (double)cy_}, {0, 0, 1}}, RR[3][3], PP[3][3], k[14] = {0};
+    for (int j = 0; j < 5; j++) k[j] = (double)dist5[j];
+    double I3[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) PP[r][c] = A[r][c];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double s = 0; for (int q = 0; q < 3; q++) s += PP[r][q] * I3[q][c]; RR[r][c] = s; }
+    const double fx = A[0][0], fy = A[1][1], ifx = 1. / fx, ify = 1. / fy, cx = A[0][2], cy = A[1][2];
+    for (int i = 0; i < n; i++) {
+        double x = keys[i].x, y = keys[i].y, x0, y0;
+        x = (x - cx) * ifx; y = (y - cy) * ify;
+        const double vz = 0 * x + 0 * y + 1, invProj = vz ? 1. / vz : 1;          // invMatTilt * (x, y, 1)
+        x0 = x = invProj * (1 * x + 0 * y + 0); y0 = y = invProj * (0 * x0 + 1 * y + 0);
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist; y = (y0 - deltaY) * icdist;
+        }
+        const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2], yy = RR[1][0] * x + RR[1][1] * y + RR[1][2], ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        keys_un[i].x = (float)(xx * ww); keys_un[i].y = (float)(yy * ww);
+    }
+    return 0;
+}
 extern "C" int orc_stereo_from_rgbd(const planar_keypoint* keys, const planar_keypoint* keys_un, int n, const uint16_t* depth, int pitch_px, float factor,
                                     float fx, float fy, float cx, float cy, float bf, const float* Tcw, float* u_right, float* z_out, float* xw, uint8_t* valid) {
     orc::stereo_from_rgbd(keys, keys_un, n, depth, pitch_px, factor, fx, fy, cx, cy, bf, Tcw, u_right, z_out, xw, valid);

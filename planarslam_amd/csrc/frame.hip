@@ -229,6 +229,37 @@ __global__ void manhattan_pose_kernel(int B, const float* __restrict__ Rcm_new, 
         }
     for (int k = 0; k < 16; k++) To[k] = T[k];
 }
+// Frame::UndistortKeyPoints (src/Frame.cc:545-573): cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) on the key points' pixel positions; every other
+// cv::KeyPoint field is copied.  The library's loop (imgproc/src/undistort.cpp, cvUndistortPointsInternal with the default criteria = five iterations), in double:
+//   x = (u - cx) / fx ... as (u - cx) * (1 / fx); five times: r2 = x x + y y; icdist = (1 + ((k7 r2 + k6) r2 + k5) r2) / (1 + ((k4 r2 + k1) r2 + k0) r2);
+//   dx = 2 k2 x y + k3 (r2 + 2 x x); dy = k2 (r2 + 2 y y) + 2 k3 x y; x = (x0 - dx) icdist; y = (y0 - dy) icdist;   then P = K: u' = fx x + cx (through the 3x3 product).
+// k = (k1, k2, p1, p2, k3) as the reference's yaml files give them (Camera.k1 ... Camera.k3); k[0] == 0: mvKeysUn = mvKeys (Frame.cc:546-549).
+struct UndistortParams { double fx, fy, cx, cy, k[5]; };
+__device__ __forceinline__ void undistort_point(const UndistortParams& U, float u, float v, float& ou, float& ov) {
+    const double ifx = 1.0 / U.fx, ify = 1.0 / U.fy;
+    double x = (double)u, y = (double)v;
+    x = (x - U.cx) * ifx; y = (y - U.cy) * ify;
+    const double x0 = x, y0 = y;
+#pragma unroll 1
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        // the library's k[5..11] (rational, thin-prism terms) are zero for a five-coefficient mDistCoef: their products add +0 and the numerator is exactly 1
+        const double icdist = 1.0 / (1.0 + ((U.k[4] * r2 + U.k[1]) * r2 + U.k[0]) * r2);
+        const double deltaX = 2.0 * U.k[2] * x * y + U.k[3] * (r2 + 2.0 * x * x);
+        const double deltaY = U.k[2] * (r2 + 2.0 * y * y) + 2.0 * U.k[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    // RR = P * R with R = I and P = K (exact products): xx = fx x + 0 y + cx, ww = 1 / (0 x + 0 y + 1) = 1
+    ou = (float)(U.fx * x + U.cx); ov = (float)(U.fy * y + U.cy);
+}
+__global__ void undistort_kernel(UndistortParams U, int B, const planar_keypoint* __restrict__ keys, const int32_t* __restrict__ n, int stride, planar_keypoint* __restrict__ keys_un) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n[b] || i >= stride) return;
+    planar_keypoint kp = keys[(size_t)b * stride + i];
+    if (U.k[0] != 0.0) undistort_point(U, kp.x, kp.y, kp.x, kp.y);
+    keys_un[(size_t)b * stride + i] = kp;
+}
 // KeyPoint::octave / angle of every key point into the flat per-stream history arrays (the "last frame" the next step projects from)
 __global__ void keypoint_fields_kernel(const planar_keypoint* __restrict__ keys, int64_t n, int32_t* __restrict__ octave, float* __restrict__ angle) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -314,6 +345,28 @@ int planar_manhattan_pose_dev(planar_ctx* ctx, int B, const float* d_Rcm_new, co
     hipLaunchKernelGGL(frame::manhattan_pose_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, B, d_Rcm_new, d_Rcm0, d_Tcw_in, d_Tcw_out);
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
+}
+int planar_undistort_keypoints_dev(planar_ctx* ctx, int B, const planar_keypoint* d_keys, const int32_t* d_n, int stride, float fx, float fy, float cx, float cy,
+                                   const float* dist_coef /* host: k1, k2, p1, p2, k3 */, planar_keypoint* d_keys_un) {
+    PLANAR_REQUIRE(ctx && d_keys && d_n && dist_coef && d_keys_un, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && B <= 65535 && stride >= 1, PLANAR_EINVAL, "bad size");
+    frame::UndistortParams U{(double)fx, (double)fy, (double)cx, (double)cy, {(double)dist_coef[0], (double)dist_coef[1], (double)dist_coef[2], (double)dist_coef[3], (double)dist_coef[4]}};
+    hipLaunchKernelGGL(frame::undistort_kernel, dim3((stride + 255) / 256, B), dim3(256), 0, ctx->stream, U, B, d_keys, d_n, stride, d_keys_un);
+    PLANAR_HIP_CHECK(hipGetLastError());
+    return PLANAR_OK;
+}
+int planar_undistort_keypoints(planar_ctx* ctx, int B, const planar_keypoint* keys, const int32_t* n, int stride, float fx, float fy, float cx, float cy, const float* dist_coef,
+                               planar_keypoint* keys_un) {
+    PLANAR_REQUIRE(ctx && keys && n && dist_coef && keys_un, PLANAR_EINVAL, "null argument");
+    PLANAR_REQUIRE(B >= 1 && stride >= 1, PLANAR_EINVAL, "bad size");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    Stager s;
+    const int i_k = s.in(keys, (size_t)B * stride * sizeof(planar_keypoint)), i_n = s.in(n, (size_t)B * 4), o_k = s.out(keys_un, (size_t)B * stride * sizeof(planar_keypoint));
+    int rc = s.upload(ctx->stream);
+    if (rc) return rc;
+    PLANAR_HIP_CHECK(hipMemsetAsync(s.dev<uint8_t>(o_k), 0, (size_t)B * stride * sizeof(planar_keypoint), ctx->stream));
+    if ((rc = planar_undistort_keypoints_dev(ctx, B, s.dev<planar_keypoint>(i_k), s.dev<int32_t>(i_n), stride, fx, fy, cx, cy, dist_coef, s.dev<planar_keypoint>(o_k)))) return rc;
+    return s.download(ctx->stream);
 }
 int planar_keypoint_fields_dev(planar_ctx* ctx, const planar_keypoint* d_keys, int64_t n, int32_t* d_octave, float* d_angle) {
     PLANAR_REQUIRE(ctx && d_keys && d_octave && d_angle && n >= 1, PLANAR_EINVAL, "bad argument");

@@ -18,6 +18,18 @@ def _c(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 
 
+def undistort_keypoints(keys, n, cam, dist_coef, ctx: Context | None = None):
+    """Frame::UndistortKeyPoints (reference src/Frame.cc:545-573): keys [B, stride] KP_DTYPE (mvKeys), dist_coef (k1, k2, p1, p2, k3) -> mvKeysUn [B, stride]."""
+    ctx = ctx or Context(0)
+    keys = _c(keys, KP_DTYPE); n = _c(n, np.int32); d = _c(dist_coef, np.float32)
+    if d.shape != (5,):
+        raise ValueError("dist_coef is (k1, k2, p1, p2, k3)")
+    B, S = keys.shape
+    out = np.zeros_like(keys)
+    check(lib().planar_undistort_keypoints(ctx.h, B, keys.ctypes.data, n.ctypes.data, S, cam["fx"], cam["fy"], cam["cx"], cam["cy"], d.ctypes.data, out.ctypes.data))
+    return out
+
+
 def stereo_from_rgbd(keys, n, depth, Tcw, cam, depth_factor=1.0 / 5000.0, keys_un=None, ctx: Context | None = None):
     """keys [B, stride] KP_DTYPE (mvKeys; keys_un = mvKeysUn, default the same), depth [B, H, W] uint16, Tcw [B, 16].
     Returns dict(u_right, depth [B, stride] float32, xw [B, stride, 3] float32, valid [B, stride] uint8)."""

@@ -35,7 +35,7 @@ class TrackPipeline:
     MAX_POSE_PLANES = 16
 
     def __init__(self, B, torch, device_index=0, depth=2, prio=(-1, 0, 0), cam=None, W=640, H=480, n_map_planes=8, n_plane_pts=128, n_normals=4096,
-                 run_fallback_matcher=True, manhattan_rotation=True):
+                 run_fallback_matcher=True, manhattan_rotation=True, dist_coef=None):
         from . import Context, ORBextractor, Optimizer, PlaneDetection
         from .lines import LineSegment
         from .planes import PlaneClouds, SurfaceNormals
@@ -43,6 +43,8 @@ class TrackPipeline:
         self.torch, self.B, self.W, self.H, self.depth = torch, B, W, H, depth
         self.manhattan_rotation = manhattan_rotation
         self.cam = dict(cam or TUM3)
+        # Camera.k1, k2, p1, p2, k3 (mDistCoef): Frame::UndistortKeyPoints runs after the extractor when k1 != 0 (Frame.cc:545-573); TUM3's are zero -> mvKeysUn = mvKeys
+        self.dist_coef = None if dist_coef is None or float(dist_coef[0]) == 0.0 else np.ascontiguousarray(dist_coef, np.float32).reshape(5)
         self.dev = torch.device("cuda", device_index)
         self.NB = depth + 2                      # buffer sets: a step's extractor outputs live until the tracking chain `depth` steps later has used them as "last frame"
         self.L = lib()
@@ -76,6 +78,7 @@ class TrackPipeline:
         NB = self.NB
         # ---- per-step buffers ----
         self.kps = [z((B, S, 7), t.float32) for _ in range(NB)]
+        self.kpu = self.kps if self.dist_coef is None else [z((B, S, 7), t.float32) for _ in range(NB)]     # mvKeysUn
         self.desc = [z((B, S, 32), t.uint8) for _ in range(NB)]
         self.n = [z((B,), t.int32) for _ in range(NB)]
         self.ur = [z((B, S), t.float32) for _ in range(NB)]
@@ -175,7 +178,7 @@ class TrackPipeline:
     def _frame_view(self, k, Tcw, blocked=None):
         fv = FrameView()
         fv.B, fv.stride = self.B, self.S
-        fv.n, fv.keys_un, fv.u_right, fv.desc = self.n[k].data_ptr(), self.kps[k].data_ptr(), self.ur[k].data_ptr(), self.desc[k].data_ptr()
+        fv.n, fv.keys_un, fv.u_right, fv.desc = self.n[k].data_ptr(), self.kpu[k].data_ptr(), self.ur[k].data_ptr(), self.desc[k].data_ptr()
         fv.blocked = blocked.data_ptr() if blocked is not None else None
         fv.Tcw = Tcw.data_ptr()
         fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(self.W), 0.0, float(self.H)
@@ -188,14 +191,14 @@ class TrackPipeline:
 
     def _stereo(self, ctx, k, Tcw, depth, ur, zd, xw, valid):
         c = self.cam
-        check(self.L.planar_stereo_from_rgbd_dev(ctx.h, self.B, self.kps[k].data_ptr(), self.kps[k].data_ptr(), self.n[k].data_ptr(), self.S, depth.data_ptr(),
+        check(self.L.planar_stereo_from_rgbd_dev(ctx.h, self.B, self.kps[k].data_ptr(), self.kpu[k].data_ptr(), self.n[k].data_ptr(), self.S, depth.data_ptr(),
                                                  self.W, self.W * self.H, float(np.float32(1.0 / 5000.0)), c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], Tcw.data_ptr(),
                                                  ur.data_ptr(), zd.data_ptr(), xw.data_ptr(), valid.data_ptr()))
 
     def _assemble(self, which, k, pt_match, mp_xw, mp_valid, mp_stride, Tcw):
         m = TrackMatches()
         m.B, m.stride, m.mp_stride, m.n_levels = self.B, self.S, mp_stride, self.nlev
-        m.n, m.keys_un, m.u_right = self.n[k].data_ptr(), self.kps[k].data_ptr(), self.ur[k].data_ptr()
+        m.n, m.keys_un, m.u_right = self.n[k].data_ptr(), self.kpu[k].data_ptr(), self.ur[k].data_ptr()
         m.pt_match, m.mp_xw, m.mp_valid = pt_match.data_ptr(), mp_xw.data_ptr(), mp_valid.data_ptr()
         for i, v in enumerate(self.inv_sigma2):
             m.inv_level_sigma2[i] = float(v)
@@ -244,6 +247,10 @@ class TrackPipeline:
         self.join_p[k].record(sp); self.join_l[k].record(sl)
         if "orb" not in self.skip:
             self.ex.extract_dev(gray.data_ptr(), self.kps[k].data_ptr(), self.desc[k].data_ptr(), self.n[k].data_ptr(), B)
+            if self.dist_coef is not None:
+                c = self.cam
+                check(self.L.planar_undistort_keypoints_dev(self.ctx.h, B, self.kps[k].data_ptr(), self.n[k].data_ptr(), self.S, c["fx"], c["fy"], c["cx"], c["cy"],
+                                                            self.dist_coef.ctypes.data, self.kpu[k].data_ptr()))
         if evs: evs["orb"].record(st)
         # Frame::ComputeStereoFromRGBD: mvuRight / mvDepth of the new keypoints (the world points come after the pose is known)
         self._stereo(self.ctx, k, self.pose0, depth, self.ur[k], self.zd[k], self.xw_tmp, self.valid_tmp)
@@ -275,7 +282,7 @@ class TrackPipeline:
         if j in self.capture_steps:
             cap = self.captured[j] = {}
             snap = lambda name, x: cap.__setitem__(name, x.clone())
-            for name, x in (("kps", self.kps[k]), ("desc", self.desc[k]), ("n", self.n[k]), ("ur", self.ur[k]), ("zd", self.zd[k]), ("kls", self.kls[k]), ("ldesc", self.ldesc[k]),
+            for name, x in (("kps", self.kps[k]), ("kpu", self.kpu[k]), ("desc", self.desc[k]), ("n", self.n[k]), ("ur", self.ur[k]), ("zd", self.zd[k]), ("kls", self.kls[k]), ("ldesc", self.ldesc[k]),
                             ("leq", self.leq[k]), ("nl", self.nl[k]), ("lab", self.lab[k]), ("pls", self.pls[k]), ("npl", self.npl[k]), ("snrm", self.snrm[k]), ("l3_packed", self.l3[k]["packed"]), ("l3_n_good", self.l3[k]["n_good"]), ("l3_seeds", self.l3[k]["seeds"]),
                             ("l3_lines3d", self.l3[k]["lines3d"]), ("l3_depth_line", self.l3[k]["depth_line"]), ("pose_in", self.pose), ("Rcm_in", self.Rcm),
                             ("last_xw", self.h_xw[l]), ("last_valid", self.h_valid[l]), ("last_desc", self.h_desc[l]), ("last_oct", self.h_oct[l]), ("last_ang", self.h_ang[l]),
@@ -378,7 +385,7 @@ class TrackPipeline:
         # ---- the new frame becomes a "last frame": back-projected keypoints (UnprojectStereo) and what MapPoint::UpdateNormalAndDepth keeps ----
         self._stereo(self.ctx_t, k, self.pose, depth, self.ur[k], self.zd[k], self.h_xw[o], self.h_valid[o])
         check(L.planar_update_normal_and_depth_dev(self.ctx_t.h, B, self.n[k].data_ptr(), S, self.h_xw[o].data_ptr(), self.h_valid[o].data_ptr(), self.pose.data_ptr(),
-                                                   self.kps[k].data_ptr(), None, None, self.sf.ctypes.data, self.nlev, self.h_normal[o].data_ptr(), self.h_mind[o].data_ptr(),
+                                                   self.kpu[k].data_ptr(), None, None, self.sf.ctypes.data, self.nlev, self.h_normal[o].data_ptr(), self.h_mind[o].data_ptr(),
                                                    self.h_maxd[o].data_ptr()))
         check(L.planar_keypoint_fields_dev(self.ctx_t.h, self.kps[k].data_ptr(), B * S, self.h_oct[o].data_ptr(), self.h_ang[o].data_ptr()))
         check(L.planar_copy_rows_dev(self.ctx_t.h, self.h_desc[o].data_ptr(), B * S * 32, self.desc[k].data_ptr(), B * S * 32, B * S * 32, 1))

@@ -40,6 +40,27 @@ def stereo_case():
     return keys, n, depth, Tcw
 
 
+# Camera.k1 .. Camera.k3 of the reference's Examples/RGB-D yaml files: TUM1, TUM2, and TUM3 (all zero -> mvKeysUn = mvKeys)
+DIST = {"TUM1": ((517.306408, 516.469215, 318.643040, 255.313989), (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)),
+        "TUM2": ((520.908620, 521.007327, 325.141442, 249.701764), (0.231222, -0.784899, -0.003257, -0.000105, 0.917205)),
+        "TUM3": ((535.4, 539.2, 320.1, 247.6), (0.0, 0.0, 0.0, 0.0, 0.0))}
+
+
+def undistort_case(seed=35):
+    """Keypoints over the whole image incl. its four corners (Frame::ComputeImageBounds runs the same call on them) for Frame::UndistortKeyPoints"""
+    import numpy as np
+    from planarslam_amd._lib import KP_DTYPE
+    rng = np.random.default_rng(seed)
+    B, S = 3, 1300
+    keys = np.zeros((B, S), KP_DTYPE)
+    keys["x"] = rng.uniform(0, 639.99, (B, S)).astype(np.float32); keys["y"] = rng.uniform(0, 479.99, (B, S)).astype(np.float32)
+    keys["x"][:, :4] = [0.0, 640.0, 0.0, 640.0]; keys["y"][:, :4] = [0.0, 0.0, 480.0, 480.0]
+    for f in ("size", "angle", "response"):
+        keys[f] = rng.uniform(0, 300, (B, S)).astype(np.float32)
+    keys["octave"] = rng.integers(0, 8, (B, S)); keys["class_id"] = -1
+    return keys, np.array([S, 1024, 5], np.int32)
+
+
 def manhattan_pose_case(n=64, seed=31):
     """Rotation_cm [n,9], MF_can [n,9] (unit-quaternion rotations, a few of them only slightly apart as on consecutive frames) and mTcw [n,16]"""
     import numpy as np

@@ -775,15 +775,24 @@ def run_ref_frustum_lines(frame, ml, b, log_scale_factor, limit=0.5):
     return idx, rec
 
 
-def stereo_from_rgbd(keys, depth, Tcw, cam, depth_factor=1.0 / 5000.0):
-    """CPU oracle of Frame::ComputeStereoFromRGBD + UnprojectStereo for ONE frame: keys [n] KP_DTYPE, depth [H, W] uint16."""
+def stereo_from_rgbd(keys, depth, Tcw, cam, depth_factor=1.0 / 5000.0, keys_un=None):
+    """CPU oracle of Frame::ComputeStereoFromRGBD + UnprojectStereo for ONE frame: keys [n] KP_DTYPE (mvKeys; keys_un = mvKeysUn, default the same), depth [H, W] uint16."""
     L = lib()
-    keys = np.ascontiguousarray(keys, KP_DTYPE); depth = np.ascontiguousarray(depth, np.uint16); Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    keys = np.ascontiguousarray(keys, KP_DTYPE); keys_un = keys if keys_un is None else np.ascontiguousarray(keys_un, KP_DTYPE); depth = np.ascontiguousarray(depth, np.uint16); Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16)
     n = len(keys)
     out = dict(u_right=np.zeros(n, np.float32), depth=np.zeros(n, np.float32), xw=np.zeros((n, 3), np.float32), valid=np.zeros(n, np.uint8))
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    L.orc_stereo_from_rgbd(p(keys), p(keys), C.c_int(n), p(depth), C.c_int(depth.shape[1]), C.c_float(np.float32(depth_factor)), C.c_float(cam["fx"]), C.c_float(cam["fy"]),
+    L.orc_stereo_from_rgbd(p(keys), p(keys_un), C.c_int(n), p(depth), C.c_int(depth.shape[1]), C.c_float(np.float32(depth_factor)), C.c_float(cam["fx"]), C.c_float(cam["fy"]),
                            C.c_float(cam["cx"]), C.c_float(cam["cy"]), C.c_float(cam["bf"]), p(Tcw), p(out["u_right"]), p(out["depth"]), p(out["xw"]), p(out["valid"]))
+    return out
+
+
+def undistort_keypoints(keys, cam, dist_coef):
+    """CPU oracle of Frame::UndistortKeyPoints for ONE frame (cv::undistortPoints' published loop; unpinned): keys [n] KP_DTYPE, dist_coef (k1, k2, p1, p2, k3)."""
+    keys = np.ascontiguousarray(keys, KP_DTYPE); out = np.zeros_like(keys); d = np.ascontiguousarray(dist_coef, np.float32)
+    assert d.shape == (5,)
+    lib().orc_undistort_keypoints(keys.ctypes.data_as(C.c_void_p), C.c_int(len(keys)), C.c_float(cam["fx"]), C.c_float(cam["fy"]), C.c_float(cam["cx"]), C.c_float(cam["cy"]),
+                                  d.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     return out
 
 

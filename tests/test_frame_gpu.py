@@ -132,3 +132,19 @@ def test_discard_outliers():
                     k += 1
         np.testing.assert_array_equal(m[b], wm); np.testing.assert_array_equal(o[b], wo)
         assert kept[b] == k
+
+
+def test_undistort_keypoints_equals_the_oracle():
+    """Frame::UndistortKeyPoints on the device == the oracle's literal restatement of cv::undistortPoints, bit for bit, for the TUM1/TUM2 coefficients of the
+    reference's yaml files; TUM3 (k1 = 0) copies; rows past n[b] stay zero."""
+    from planarslam_amd import frame as F
+    keys, n = cases.undistort_case()
+    for name, (K, D) in cases.DIST.items():
+        cam = dict(fx=K[0], fy=K[1], cx=K[2], cy=K[3])
+        got = F.undistort_keypoints(keys, n, cam, D)
+        for b in range(len(n)):
+            want = ol.undistort_keypoints(keys[b, :n[b]], cam, D)
+            assert got[b, :n[b]].tobytes() == want.tobytes(), (name, b)
+            assert not got[b, n[b]:].tobytes().strip(b"\0")
+        if D[0] == 0:
+            assert got[0].tobytes() == keys[0].tobytes()

@@ -160,3 +160,30 @@ def test_is_in_frustum_points_and_lines_properties():
     il = ol["in_view"] > 0
     assert 0.05 < il[ml["valid"] > 0].mean() < 0.9
     assert (ol["proj"][il] >= 0).all() and (ol["proj"][il][:, [0, 2]] <= 640).all()
+
+
+def test_undistort_keypoints_inverts_the_distortion_model():
+    """The oracle of Frame::UndistortKeyPoints (cv::undistortPoints' five fixed-point iterations; unpinned - OpenCV is not in this image): pushing its
+    output through the forward Brown-Conrady model comes back to the key point - to the few hundredths of a pixel five iterations reach inside the image, and
+    coarser in the far corners where the iteration has not converged (what the reference then uses as mnMinX .. mnMaxY)."""
+    import frame_cases as fc
+    keys, n = fc.undistort_case()
+    for name, (K, D) in fc.DIST.items():
+        cam = dict(fx=K[0], fy=K[1], cx=K[2], cy=K[3])
+        un = O.undistort_keypoints(keys[0], cam, D)
+        for f in ("size", "angle", "response", "octave", "class_id"):
+            assert np.array_equal(un[f], keys[0][f])
+        if D[0] == 0:
+            assert np.array_equal(un, keys[0])
+            continue
+        fx, fy, cx, cy = [np.float64(np.float32(v)) for v in K]
+        k1, k2, p1, p2, k3 = [np.float64(np.float32(v)) for v in D]
+        x = (un["x"].astype(np.float64) - cx) / fx; y = (un["y"].astype(np.float64) - cy) / fy
+        r2 = x * x + y * y
+        rad = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+        xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x); yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        err = np.hypot(xd * fx + cx - keys[0]["x"], yd * fy + cy - keys[0]["y"])
+        r_px = np.hypot(keys[0]["x"] - cx, keys[0]["y"] - cy)
+        assert err[r_px < 250].max() < 0.05, (name, err[r_px < 250].max())
+        assert err.max() < 6.0, (name, err.max())
+        assert np.abs(un["x"] - keys[0]["x"]).max() > 5                      # and it does move the corners by many pixels

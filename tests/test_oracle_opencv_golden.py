@@ -52,3 +52,15 @@ def test_lsd_and_lbd(gold):
             want = gold[f"lbd/{s}/keylines"]
             np.testing.assert_array_equal(kl["pt_x"], want[:, 3].astype(np.float32))
             np.testing.assert_array_equal(kl["response"], want[:, 5].astype(np.float32))
+
+
+def test_undistort_points(gold):
+    import frame_cases as fc
+    if "undistort/TUM1" not in gold.files:
+        pytest.skip("opencv_golden.npz predates the undistortPoints vectors: re-run tools/dump_opencv_golden.py")
+    keys, _ = fc.undistort_case()
+    for name, (K, D) in fc.DIST.items():
+        un = O.undistort_keypoints(keys[0], dict(fx=K[0], fy=K[1], cx=K[2], cy=K[3]), D)
+        if D[0] == 0:
+            continue                      # the reference does not call the library then (Frame.cc:546-549)
+        assert np.array_equal(np.stack([un["x"], un["y"]], 1), gold[f"undistort/{name}"]), name

@@ -320,3 +320,50 @@ def test_manhattan_rotation_into_the_translation_pose():
     ctx = Context(0, stream=torch.cuda.current_stream().cuda_stream)
     check(lib().planar_manhattan_pose_dev(ctx.h, n, dRn.data_ptr(), dR0.data_ptr(), dT.data_ptr(), out.data_ptr()))
     assert np.array_equal(out.cpu().numpy(), ol.manhattan_pose(R0, Rn, T))
+
+
+def test_pipeline_with_a_distorting_camera():
+    """Camera.k1 != 0 (TUM1's yaml): the pipeline's mvKeysUn = Frame::UndistortKeyPoints(mvKeys), mvuRight / mvDepth read the depth at mvKeys and project from
+    mvKeysUn (Frame.cc:600-623), and the chain behind them (matchers, pose) runs on the undistorted keys - poses stay finite and tracked."""
+    import torch
+    import frame_cases
+    from planarslam_amd._lib import KP_DTYPE
+    from planarslam_amd.synth import stream_canvases
+    from planarslam_amd.track import TrackPipeline, build_map
+    K, D = frame_cases.DIST["TUM1"]
+    cam = dict(TUM3, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
+    cam["bf"] = 40.0
+    Bs = 16
+    cg, cd = stream_canvases(Bs, 3, W + 2 * MARGIN, H + 2 * MARGIN, procs=8)
+    dev = torch.device("cuda", 0)
+    tp = TrackPipeline(Bs, torch, 0, depth=1, cam=cam, dist_coef=D)
+    win = lambda i: tuple(a[:, pan_offset(i, MARGIN)[1]:pan_offset(i, MARGIN)[1] + H, pan_offset(i, MARGIN)[0]:pan_offset(i, MARGIN)[0] + W].copy() for a in (cg, cd))
+    g0, d0 = win(0)
+    tp.set_map(*build_map(g0, d0, cam, seed=1))
+    n_steps = 5
+    tp.capture_steps = {n_steps - 1}
+    frames = [torch.zeros((Bs, H, W), dtype=torch.uint8, device=dev) for _ in range(tp.NB)]
+    depths = [torch.zeros((Bs, H, W), dtype=torch.int16, device=dev) for _ in range(tp.NB)]
+    with torch.cuda.stream(tp.stream):
+        for i in range(n_steps):
+            k = i % tp.NB
+            tp.stream.wait_event(tp.done[k])
+            g, d = win(i)
+            frames[k].copy_(torch.from_numpy(g)); depths[k].copy_(torch.from_numpy(d.view(np.int16)))
+            tp.step(i, frames[k], depths[k])
+        tp.drain()
+    torch.cuda.synchronize()
+    tp.check()
+    c = tp.captured[n_steps - 1]
+    kps, kpu, n, ur, zd = (c[x].cpu().numpy() for x in ("kps", "kpu", "n", "ur", "zd"))
+    moved = 0.0
+    for b in range(0, Bs, 3):
+        nb = int(n[b])
+        k = kps[b, :nb].copy().view(KP_DTYPE).reshape(nb)
+        want = ol.undistort_keypoints(k, cam, D)
+        assert kpu[b, :nb].tobytes() == want.tobytes()
+        st = ol.stereo_from_rgbd(k, d[b], np.eye(4, dtype=np.float32), cam, keys_un=want)
+        assert np.array_equal(ur[b, :nb], st["u_right"]) and np.array_equal(zd[b, :nb], st["depth"])
+        moved = max(moved, float(np.abs(want["x"] - k["x"]).max()))
+    assert moved > 1.0                                                          # the lens model does move key points by pixels
+    assert np.isfinite(c["pose_out"].cpu().numpy()).all()

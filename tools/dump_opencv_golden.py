@@ -67,6 +67,14 @@ def main():
             out[f"lbd/{s}/desc"] = np.asarray(desc, np.uint8)
         except Exception as e:
             print("line_descriptor python bindings unavailable:", e)
+    # Frame::UndistortKeyPoints: cv::undistortPoints(mat, mat, K, D, R = empty, P = K) on tests/frame_cases.undistort_case()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import frame_cases as fc
+    keys, _ = fc.undistort_case()
+    pts = np.stack([keys[0]["x"], keys[0]["y"]], 1).reshape(-1, 1, 2).astype(np.float32)
+    for name, (K, D) in fc.DIST.items():
+        Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32); Dm = np.array(D, np.float32).reshape(5, 1)
+        out[f"undistort/{name}"] = cv2.undistortPoints(pts, Km, Dm, None, None, Km).reshape(-1, 2).astype(np.float32)
     path = os.path.join(ROOT, "tests", "golden", "opencv_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "with", len(out), "arrays from OpenCV", cv2.__version__)
