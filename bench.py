@@ -676,7 +676,7 @@ def main_pose(args):
                                    "vertical edges), seed=7), Optimizer::PoseOptimization = 4 rounds of optimize(10) with outlier reclassification; inputs resident in HBM" % B,
                        "frames_per_gpu_per_step": B, "avg_lm_iterations_per_frame": round(lm_it, 2),
                        "protocol_1x10": {"problems_per_s": round(B * world * args.steps / el_1, 1), "ms_per_step": round(el_1 / args.steps * 1e3, 4), "avg_lm_iterations_per_frame": round(it_1, 2)}},
-            "roofline": {"bound": "hbm", "kernel": "pose_opt_kernel<2>", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "pose_opt_kernel", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg),
                          "note": "65 130 B per frame per LM evaluation (SURVEY §8d) x the measured LM iterations; HIP events on the kernel's stream around the timed launches.  One workgroup per "
                                  "frame runs the whole protocol on chip in FP64: 256 frames = 256 workgroups = one per CU, latency-bound (DESIGN.md §4)"}}

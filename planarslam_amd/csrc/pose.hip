@@ -91,9 +91,9 @@ __device__ __forceinline__ bool ldlt_step(double (&A)[6][6], int (&tr)[6], int& 
 template <int K>
 __device__ __forceinline__ void perm_swap(double (&y)[6], int t) {   // y[K] <-> y[t], t >= K
 #pragma unroll
-    for (int j = K + 1; j < 6; j++) if (t == j) dswap(y[K], y[j]);
+    for (int j = K + 1; j < 6; j++) { const bool sw = t == j; const double a = y[K], c = y[j]; y[K] = sw ? c : a; y[j] = sw ? a : c; }   // (selects: an if-chain of swaps gets turned into a dynamically indexed array in scratch)
 }
-__device__ bool ldlt_solve6(const double* Hu /*21 upper, row-major*/, double lambda, const double b[6], double x[6]) {
+__device__ __forceinline__ bool ldlt_solve6(const double* Hu /*21 upper, row-major*/, double lambda, const double b[6], double x[6]) {
     double A[6][6];
     {
         int k = 0;
@@ -298,10 +298,31 @@ __device__ void block_reduce(double* v, double* lds /* [4][N] */) {
     for (int k = 0; k < N; k++) v[k] = (lds[k] + lds[N + k]) + (lds[2 * N + k] + lds[3 * N + k]);
 }
 
-// WAVES = minimum waves per SIMD the register allocator must leave room for: 2 -> 256 VGPRs, two frames per CU, 92 VGPRs spilled to scratch;
-// 1 -> 256 VGPRs + AGPRs as spill space (no scratch traffic), one frame per CU.  planar_pose_opt_dev picks (see there).
-template <int WAVES>
-__global__ __launch_bounds__(NT, WAVES) void pose_opt_kernel(BatchDev Bt, ParamsDev P) {
+// the same sums (same association), left in LDS at dst[0 .. N) instead of in every thread's registers: what follows an evaluation is wavefront-uniform work (the 6x6
+// solve, the gain ratio), and 28 doubles x 256 threads of registers held across it are what used to spill
+template <int N>
+__device__ __forceinline__ void block_reduce_to(const double* v, double* lds /* [4][N] */, double* dst /* [N], LDS */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double x = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if (lane == 0) lds[wave * N + k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) { const int k = threadIdx.x; dst[k] = (lds[k] + lds[N + k]) + (lds[2 * N + k] + lds[3 * N + k]); }
+    __syncthreads();
+}
+__device__ __forceinline__ void se3_store(double* p, const SE3& T) { p[0] = T.r.x; p[1] = T.r.y; p[2] = T.r.z; p[3] = T.r.w; p[4] = T.t.x; p[5] = T.t.y; p[6] = T.t.z; }
+__device__ __forceinline__ SE3 se3_load(const double* p) { SE3 T; T.r.x = p[0]; T.r.y = p[1]; T.r.z = p[2]; T.r.w = p[3]; T.t.x = p[4]; T.t.y = p[5]; T.t.z = p[6]; return T; }
+constexpr int UNI_DOUBLES = 28 + 3 * 8;   // wavefront-uniform state kept in LDS: H | b | chi of the last evaluation, T0, T_eval, the LM step's backup pose
+
+// Two workgroups (frames) per CU: 256 VGPRs per thread.  No scratch: what is wavefront-uniform between evaluations lives in LDS (above), the plane edges' numeric
+// Jacobians are complete before the accumulators exist, and nothing that depends on the thread index alone is carried through the whole kernel
+// (tests/test_build_sanity.py checks the ISA: 0 spilled VGPRs, 0 bytes of private segment).
+__global__ __launch_bounds__(NT, 2) void pose_opt_kernel(BatchDev Bt, ParamsDev P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     Frame F;
@@ -320,8 +341,10 @@ __global__ __launch_bounds__(NT, WAVES) void pose_opt_kernel(BatchDev Bt, Params
 
     // LDS carve: reduction scratch, numeric-Jacobian scratch, levels
     double* red = (double*)smem;                              // [4][28]
-    double* pj = red + 4 * 28;                                // [3 * max_planes][12][3] perturbed errors
-    uint8_t* lvl_pt = (uint8_t*)(pj + (size_t)Bt.max_planes * 3 * 36);   // [max_points] 0 active, 1 outlier, 2 absent (pj is sized by the batch's plane capacity)
+    double* uH = red + 4 * 28;                                // [21] H, [6] b, [1] chi of the last full evaluation (uniform)
+    double* uT0 = uH + 28; double* uTe = uT0 + 8; double* uBk = uTe + 8;   // T0, T_eval, the LM step's backup
+    double* pj = uH + UNI_DOUBLES;                            // [3 * max_planes][13][3] perturbed errors (12) + the error itself
+    uint8_t* lvl_pt = (uint8_t*)(pj + (size_t)Bt.max_planes * 3 * 39);   // [max_points] 0 active, 1 outlier, 2 absent (pj is sized by the batch's plane capacity)
     uint8_t* lvl_ln = lvl_pt + Bt.max_points;                 // [max_lines]
     uint8_t* lvl_pl = lvl_ln + Bt.max_lines;                  // [max_planes*3]
     const int kinds = P.mode == 0 ? 3 : 1;
@@ -369,12 +392,35 @@ __global__ __launch_bounds__(NT, WAVES) void pose_opt_kernel(BatchDev Bt, Params
         T0.r = qnormalize(qfrom(R));
         T0.t = {(double)Tin[3], (double)Tin[7], (double)Tin[11]};
     }
-    SE3 T = T0, T_eval = T0;
+    SE3 T = T0;
+    if (tid == 0) { se3_store(uT0, T0); se3_store(uTe, T0); }
+    __syncthreads();
     bool robust = true;
     int nBad = 0, lm_total = 0;
 
     // one pass over the active edges at pose Tc.  full: also J, H, b.
     auto evaluate = [&](const SE3& Tc, bool full, Acc& acc) {
+        if (full) {
+            // numeric Jacobians first (task (pe, r): r < 12 the error at the pose perturbed by +-1e-9 along d = r / 2, r = 12 the error at Tc itself; into LDS): the heaviest
+            // expression trees of the kernel run before the 28 accumulators are live, and the accumulation below only reads
+            for (int task = tid; task < npe * 13; task += NT) {
+                const int pe = task / 13, r = task - pe * 13;
+                if (lvl_pl[pe] != 0) continue;
+                const int kind = pe / F.nm, i = pe - kind * F.nm;
+                SE3 Tp = Tc;
+                if (r < 12) {
+                    double add[6];
+#pragma unroll
+                    for (int dd = 0; dd < 6; dd++) add[dd] = (dd == (r >> 1)) ? ((r & 1) ? -1e-9 : 1e-9) : 0.0;
+                    Tp = se3_mul(se3_exp(add), Tc);
+                }
+                const Plane local = plane_local(Tp, load_map_plane(F, P, i, kind), P.mode == 1);
+                double err[3];
+                plane_error(kind, local, plane_from_float(F.pl_meas + 4 * i), err);
+                pj[task * 3] = err[0]; pj[task * 3 + 1] = err[1]; pj[task * 3 + 2] = err[2];
+            }
+            __syncthreads();
+        }
         for (int k = 0; k < 21; k++) acc.h[k] = 0;
         for (int k = 0; k < 6; k++) acc.b[k] = 0;
         acc.chi = 0;
@@ -403,46 +449,35 @@ __global__ __launch_bounds__(NT, WAVES) void pose_opt_kernel(BatchDev Bt, Params
             if (full) { double J[3][6]; line_jac(P, p, l, J); accumulate(acc, 3, err, J, info, robust, P.dStereo); }
             else acc.chi += edge_chi(3, err, info, robust, P.dStereo);
         }
-        if (full) {
-            // numeric Jacobians: task (pe, d, sign) -> perturbed error
-            for (int task = tid; task < npe * 12; task += NT) {
-                const int pe = task / 12, r = task - pe * 12;
-                if (lvl_pl[pe] != 0) continue;
-                const int kind = pe / F.nm, i = pe - kind * F.nm;
-                double add[6];
-#pragma unroll
-                for (int dd = 0; dd < 6; dd++) add[dd] = (dd == (r >> 1)) ? ((r & 1) ? -1e-9 : 1e-9) : 0.0;
-                const SE3 Tp = se3_mul(se3_exp(add), Tc);
-                const Plane local = plane_local(Tp, load_map_plane(F, P, i, kind), P.mode == 1);
-                double err[3];
-                plane_error(kind, local, plane_from_float(F.pl_meas + 4 * i), err);
-                pj[task * 3] = err[0]; pj[task * 3 + 1] = err[1]; pj[task * 3 + 2] = err[2];
-            }
-            __syncthreads();
-        }
-        for (int pe = tid; pe < npe; pe += NT) {
+        for (int pe_ = tid; pe_ < npe; pe_ += NT) {
+            int pe = pe_;
+            asm volatile("" : "+v"(pe));      // (npe <= 96 < NT: without this everything below that depends on tid only is hoisted to the kernel's start and held in registers throughout)
             if (lvl_pl[pe] != 0) continue;
             const int kind = pe / F.nm, i = pe - kind * F.nm;
             int dim; double info[3], delta;
             plane_info(P, kind, dim, info, delta);
-            const Plane local = plane_local(Tc, load_map_plane(F, P, i, kind), P.mode == 1);
-            double err[3];
-            plane_error(kind, local, plane_from_float(F.pl_meas + 4 * i), err);
             if (full) {
+                const double err[3] = {pj[(pe * 13 + 12) * 3], pj[(pe * 13 + 12) * 3 + 1], pj[(pe * 13 + 12) * 3 + 2]};
                 double J[3][6];
                 const double scalar = 1.0 / (2 * 1e-9);
                 for (int d = 0; d < 6; d++)
                     for (int r = 0; r < 3; r++)
-                        J[r][d] = (r < dim) ? scalar * (pj[(pe * 12 + 2 * d) * 3 + r] - pj[(pe * 12 + 2 * d + 1) * 3 + r]) : 0.0;
+                        J[r][d] = (r < dim) ? scalar * (pj[(pe * 13 + 2 * d) * 3 + r] - pj[(pe * 13 + 2 * d + 1) * 3 + r]) : 0.0;
                 if (P.mode == 1) for (int r = 0; r < 3; r++) J[r][0] = J[r][1] = J[r][2] = 0;
                 accumulate(acc, dim, err, J, info, robust, delta);
-            } else acc.chi += edge_chi(dim, err, info, robust, delta);
+            } else {
+                const Plane local = plane_local(Tc, load_map_plane(F, P, i, kind), P.mode == 1);
+                double err[3];
+                plane_error(kind, local, plane_from_float(F.pl_meas + 4 * i), err);
+                acc.chi += edge_chi(dim, err, info, robust, delta);
+            }
         }
     };
 
     for (int round = 0; round < P.rounds; round++) {
-        T = T0;                                           // restart from the initial pose (:998)
-        T_eval = T0;
+        T = se3_load(uT0);                                // restart from the initial pose (:998)
+        __syncthreads();
+        if (tid == 0) se3_store(uTe, T);                  // T_eval
         // any active edge?  (initializeOptimization(0) with no level-0 edge leaves the vertex inactive)
         double act[1] = {0};
         for (int i = tid; i < F.np; i += NT) act[0] += lvl_pt[i] == 0;
@@ -454,34 +489,35 @@ __global__ __launch_bounds__(NT, WAVES) void pose_opt_kernel(BatchDev Bt, Params
             int nBadIt = 0;
             for (int it = 0; it < P.its; it++) {
                 lm_total++;
-                Acc acc;
-                evaluate(T, true, acc);
-                block_reduce<28>((double*)&acc, red);
-                T_eval = T;
-                double currentChi = acc.chi, tempChi = currentChi;
+                {
+                    Acc acc;
+                    evaluate(T, true, acc);
+                    if (tid == 0) se3_store(uTe, T);              // T_eval (read after the barriers of the reduction)
+                    block_reduce_to<28>((const double*)&acc, red, uH);
+                }
+                double currentChi = uH[27], tempChi = currentChi;
                 const double iniChi = currentChi;
                 if (it == 0) {
                     double maxDiag = 0;
                     int k = 0;
-                    for (int r = 0; r < 6; r++) { maxDiag = fmax(fabs(acc.h[k]), maxDiag); k += 6 - r; }
+                    for (int r = 0; r < 6; r++) { maxDiag = fmax(fabs(uH[k]), maxDiag); k += 6 - r; }
                     lambda = 1e-5 * maxDiag; ni = 2; nBadIt = 0;
                 }
                 double rho = 0;
                 int qmax = 0;
                 double x[6] = {0, 0, 0, 0, 0, 0};
                 do {
-                    const SE3 backup = T;
-                    const bool ok2 = ldlt_solve6(acc.h, lambda, acc.b, x);
+                    if (tid == 0) se3_store(uBk, T);              // the step's backup pose
+                    const bool ok2 = ldlt_solve6(uH, lambda, uH + 21, x);
                     T = se3_mul(se3_exp(x), T);
-                    Acc trial;
-                    evaluate(T, false, trial);
-                    double c1[1] = {trial.chi};
+                    double c1[1];
+                    { Acc trial; evaluate(T, false, trial); c1[0] = trial.chi; }
+                    if (tid == 0) se3_store(uTe, T);              // T_eval
                     block_reduce<1>(c1, red);
-                    T_eval = T;
                     tempChi = ok2 ? c1[0] : 1.7976931348623157e308;
                     rho = currentChi - tempChi;
                     double scale = 0;
-                    for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + acc.b[j]);
+                    for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + uH[21 + j]);
                     scale += 1e-3;
                     rho /= scale;
                     if (rho > 0 && isfinite(tempChi)) {
@@ -490,7 +526,7 @@ __global__ __launch_bounds__(NT, WAVES) void pose_opt_kernel(BatchDev Bt, Params
                         alpha = fmin(alpha, 2. / 3.);
                         lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
                     } else {
-                        lambda *= ni; ni *= 2; T = backup;
+                        lambda *= ni; ni *= 2; T = se3_load(uBk);
                     }
                     qmax++;
                 } while (rho < 0 && qmax < 10);
@@ -502,6 +538,8 @@ __global__ __launch_bounds__(NT, WAVES) void pose_opt_kernel(BatchDev Bt, Params
         // ---- classification (:1002-1262 / :3465-3560) ----
         double bad[1] = {0};
         const bool strip = round == 2;
+        __syncthreads();
+        const SE3 T_eval = se3_load(uTe);
         for (int i = tid; i < F.np; i += NT) {
             if (lvl_pt[i] == 2) continue;
             const float* obs = F.pt_obs + 3 * i;
@@ -529,7 +567,9 @@ __global__ __launch_bounds__(NT, WAVES) void pose_opt_kernel(BatchDev Bt, Params
             lvl_ln[i] = out ? 1 : 0; o_ln[i] = out ? 1 : 0;
             if (P.mode == 0) bad[0] += out;                  // the translation variant counts nLineBad separately
         }
-        for (int pe = tid; pe < npe; pe += NT) {
+        for (int pe_ = tid; pe_ < npe; pe_ += NT) {
+            int pe = pe_;
+            asm volatile("" : "+v"(pe));
             if (lvl_pl[pe] == 2) continue;
             const int kind = pe / F.nm, i = pe - kind * F.nm;
             const SE3& Tc = lvl_pl[pe] == 1 ? T : T_eval;
@@ -596,19 +636,10 @@ static int pose_launch(planar_ctx* ctx, const planar_pose_batch* bt, const plana
     P.dMono = (double)(float)sqrt(5.991); P.dStereo = (double)(float)sqrt(7.815);            // const float delta* (:583-584)
     P.dPlane = (double)(float)sqrt(prm->plane_chi); P.dVP = (double)(float)sqrt(prm->vp_chi);   // (:780,:783)
     P.mode = mode; P.rounds = rounds; P.its = its;
-    const size_t smem = (4 * 28 + (size_t)bt->max_planes * 3 * 36) * sizeof(double) + (size_t)bt->max_points + bt->max_lines + 3 * (size_t)bt->max_planes + 16;
+    const size_t smem = (4 * 28 + pose::UNI_DOUBLES + (size_t)bt->max_planes * 3 * 39) * sizeof(double) + (size_t)bt->max_points + bt->max_lines + 3 * (size_t)bt->max_planes + 16;
     PLANAR_REQUIRE(smem <= 160 * 1024, PLANAR_EINVAL, "problem too large for LDS");
-    if (smem > 64 * 1024)
-        PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    static const int waves = [] { const char* e = getenv("PLANAR_POSE_WAVES"); return e ? atoi(e) : 2; }();   // measurement switch (tools/pose_waves.py); default = the faster one
-    if (waves == 4) {
-        if (smem > 64 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(pose::pose_opt_kernel<4>, dim3(bt->B), dim3(pose::NT), smem, ctx->stream, B, P);
-    } else if (waves == 1) {
-        if (smem > 64 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(pose::pose_opt_kernel<1>, dim3(bt->B), dim3(pose::NT), smem, ctx->stream, B, P);
-    } else
-        hipLaunchKernelGGL(pose::pose_opt_kernel<2>, dim3(bt->B), dim3(pose::NT), smem, ctx->stream, B, P);
+    if (smem > 64 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)pose::pose_opt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(pose::pose_opt_kernel, dim3(bt->B), dim3(pose::NT), smem, ctx->stream, B, P);
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
 }

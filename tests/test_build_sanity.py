@@ -23,3 +23,19 @@ def test_no_64bit_literal_scalar_moves(src, tmp_path):
                            os.path.join(ROOT, "planarslam_amd", "csrc", src), "-o", str(out)], stderr=subprocess.DEVNULL)
     bad = [ln.strip() for ln in open(out) if BAD.search(ln)]
     assert not bad, f"{src}: scalar moves with a 64-bit literal (not encodable on gfx950, the register would hold the low half only): {bad[:4]}"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_pose_opt_kernel_has_no_scratch(tmp_path):
+    """pose_opt_kernel at two workgroups per CU (256 VGPRs): the register allocator spills nothing and no array lives in private memory (round 3: 92 VGPRs)."""
+    out = tmp_path / "pose.s"
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-function", "-S", "--cuda-device-only",
+                           os.path.join(ROOT, "planarslam_amd", "csrc", "pose.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    meta = text[text.index("amdhsa.kernels:"):]
+    blocks = [b for b in meta.split("  - .agpr_count:") if "pose_opt_kernel" in b]
+    assert len(blocks) == 1
+    get = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", blocks[0]).group(1))
+    assert get("vgpr_spill_count") == 0 and get("private_segment_fixed_size") == 0, blocks[0]
+    assert get("vgpr_count") <= 256
+    assert "scratch_" not in text[:text.index("amdhsa.kernels:")]

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for m in 0 1; do ./tools/micro/isort_time256 5888 300 1024 $m 1 | tail -2 | cut -c1-400; done
-./tools/micro/isort_time256 5888 300 4096 1 1 | tail -2 | cut -c1-400
+timeout 900 python -m pytest tests -m gpu -x -q -k "pose or opt or track or adapters" 2>&1 | tail -5
+timeout 300 python bench.py --workload pose 2>/dev/null | tail -1 | cut -c1-900
