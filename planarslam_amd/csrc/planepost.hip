@@ -37,6 +37,7 @@ constexpr int VOX_BIAS = 8192;            // voxel coordinates floor(x / leaf) a
 constexpr unsigned long long EMPTY = ~0ull;
 
 struct Geo {
+    int dev_skip_heap = 0;                          // (developer's timing switch: PLANAR_DEV_SKIP_HEAP*)
     int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (frame workspace); mini: entries of a wavefront's tile table (LDS)
     float fx, fy, cx, cy, factor, leaf;
     double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
@@ -321,7 +322,7 @@ using PsLds = isort::LdsLayout<PS_LT, PS_E>;
 using PsGl = isort::GlobalLayout<PS_T>;
 constexpr int ERR_SORT = 5;
 
-struct Meta { int n_init, counts[2], err, M, npl, sort_status, heap_n; };
+struct Meta { int n_init, counts[2], err, M, npl, sort_status, heap_n, heap_n_global; };   // heap_n_global: the fallback jobs the global tier left (the long ones), known before the LDS tier runs
 
 __global__ __launch_bounds__(NT) void plane_voxels_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
                                                           const int* __restrict__ labels_all, const int* __restrict__ n_planes, unsigned char* ws_all, long long* timing) {
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(NT) void plane_voxels_kernel(Geo G, const unsigned 
             const int f = vstart[s_first[p]], l = vstart[s_last[p]];
             init[k++] = isort::Range{f, l, isort::depth_limit(l - f)};
         }
-        meta->n_init = k; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = npl; meta->sort_status = 0; meta->heap_n = 0;
+        meta->n_init = k; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = npl; meta->sort_status = 0; meta->heap_n = 0; meta->heap_n_global = 0;
     }
     mark(3);
 }
@@ -591,31 +592,44 @@ __global__ __launch_bounds__(PS_T) void plane_sort_global(Geo G, unsigned char* 
     const isort::HeapSink HS{(isort::HeapJob*)(ws + G.off_heapj), &meta->heap_n, PS_HJOBS};
     isort::global_tier<PS_SHIFT, PS_T>((uint32_t*)(ws + G.off_items), (const isort::Range*)(ws + G.off_init), meta->n_init, PsLds::N, 64, (isort::Range*)(ws + G.off_ranges),
                                        (isort::Block*)(ws + G.off_blocks), isort::G_FMAX, meta->counts, sort_lds, rows_cap, HS, &meta->sort_status);
+    __syncthreads();
+    if (threadIdx.x == 0) meta->heap_n_global = min(meta->heap_n, PS_HJOBS);
 }
 
+// Workgroups blockIdx.y < PS_EARLY do not take LDS-tier blocks: their first wavefront heap-sorts the fallback jobs the GLOBAL tier left (ranges longer than an
+// LDS block - the 100 000-element ones are here; disjoint from everything the LDS tier touches), so the longest sequential job of the chain starts with the
+// LDS tier instead of after it, on the same stream (a side stream per handle cost more than it hid: the pipeline's streams already outnumber the hardware queues).
+constexpr int PS_EARLY = 4;
 __global__ __launch_bounds__(PS_LT) void plane_sort_lds(Geo G, unsigned char* ws_all) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
     Meta* meta = (Meta*)(ws + G.off_meta);
     if (meta->err) return;
+    if (blockIdx.y < PS_EARLY) {
+        static_assert(PsLds::bytes >= PS_HC[2].cap * 4, "the early heap jobs keep the top PS_HC[2].cap words of a range in this workgroup's LDS");
+        const int ng = meta->heap_n_global;
+        if (threadIdx.x < 64 && ng > 0 && !G.dev_skip_heap)
+            isort::heap_jobs<PS_SHIFT>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj), ng, blockIdx.y, PS_EARLY, (uint32_t*)sort_lds, PS_HC[2].cap, 0, 1 << 30);
+        return;
+    }
     const isort::Range* ranges = (const isort::Range*)(ws + G.off_ranges);
     const isort::Block* blocks = (const isort::Block*)(ws + G.off_blocks);
     const int nb = meta->counts[1];
     const isort::HeapSink HS{(isort::HeapJob*)(ws + G.off_heapj), &meta->heap_n, PS_HJOBS};
-    for (int k = blockIdx.y; k < nb; k += gridDim.y) {
+    for (int k = blockIdx.y - PS_EARLY; k < nb; k += gridDim.y - PS_EARLY) {
         const isort::Block K = blocks[k];
         isort::lds_tier<PS_SHIFT, PS_LT, PS_E>((uint32_t*)(ws + G.off_items), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &meta->sort_status);
     }
 }
 
-// the ranges whose introsort depth budget ran out: libstdc++'s heap sort, one wavefront per job (isort.h: level-parallel make_heap, pipelined sort_heap)
-__global__ __launch_bounds__(256) void plane_sort_heap(Geo G, unsigned char* ws_all, int min_len, int max_len, int cap) {
+// part 1: the jobs of the LDS tier (part 0, the global tier's, ran inside plane_sort_lds)
+__global__ __launch_bounds__(256) void plane_sort_heap(Geo G, unsigned char* ws_all, int part, int min_len, int max_len, int cap) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
     const Meta* meta = (const Meta*)(ws + G.off_meta);
-    const int nj = meta->err ? 0 : min(meta->heap_n, PS_HJOBS), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (nj) isort::heap_jobs<PS_SHIFT>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj), nj, blockIdx.y * nw + wave, gridDim.y * nw,
-                                       (uint32_t*)sort_lds + (size_t)wave * cap, cap, min_len, max_len);
+    const int ng = meta->heap_n_global, lo = part ? ng : 0, hi = meta->err ? 0 : (part ? min(meta->heap_n, PS_HJOBS) : ng), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (hi > lo) isort::heap_jobs<PS_SHIFT>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj) + lo, hi - lo, blockIdx.y * nw + wave, gridDim.y * nw,
+                                           (uint32_t*)sort_lds + (size_t)wave * cap, cap, min_len, max_len);
 }
 
 // PlaneDetection::readDepthImage for one thread (no wave-level branch: callers are in divergent loops)
@@ -849,7 +863,7 @@ __global__ __launch_bounds__(NT) void cloud_voxels_kernel(Geo G, const float* __
     }
     if (tid == 0) {
         init[0] = isort::Range{0, n, isort::depth_limit(n)};
-        meta->n_init = (!err && n > 0) ? 1 : 0; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = 1; meta->sort_status = 0; meta->heap_n = 0;
+        meta->n_init = (!err && n > 0) ? 1 : 0; meta->counts[0] = 0; meta->counts[1] = 0; meta->err = err; meta->M = M; meta->npl = 1; meta->sort_status = 0; meta->heap_n = 0; meta->heap_n_global = 0;
     }
 }
 
@@ -1071,13 +1085,18 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     mark();
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
     mark();
-    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);
-    mark();
-    for (int c = 0; c < 3 && !getenv("PLANAR_DEV_SKIP_HEAP"); c++) {   // (the environment variables: a developer's timing experiments, results are then wrong)
+    // (the environment variables: a developer's timing experiments, results are then wrong)
+    const bool skip_heap = getenv("PLANAR_DEV_SKIP_HEAP") != nullptr;
+    const int skip_class = getenv("PLANAR_DEV_SKIP_HEAP_CLASS") ? atoi(getenv("PLANAR_DEV_SKIP_HEAP_CLASS")) : -1;
+    G.dev_skip_heap = skip_heap || skip_class == 2;
+    auto heap_launch = [&](hipStream_t q, int part, int c) {
         const planepost::HeapClass& H = planepost::PS_HC[c];
-        if (getenv("PLANAR_DEV_SKIP_HEAP_CLASS") && atoi(getenv("PLANAR_DEV_SKIP_HEAP_CLASS")) == c) continue;
-        hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(B, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
-    }
+        if (skip_heap || skip_class == c) return;
+        hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(B, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, q, G, ws, part, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
+    };
+    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_EARLY + planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);   // + the global tier's fallback jobs
+    mark();
+    heap_launch(st, 1, 0); heap_launch(st, 1, 1);            // the LDS tier's jobs (at most a block long)
     mark();
     hipLaunchKernelGGL(planepost::plane_tail_kernel, dim3(B), dim3(planepost::NT), p->smem_tail, st, G, d_depth, pitch_px, (long)frame_stride_px, d_planes,
                        planar_peac_max_planes(), p->rng.as<int>(), ws, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox, d_info, tm);
@@ -1190,10 +1209,10 @@ int planar_merge_plane_points(planar_plane_clouds* p, const double* Twc, const f
     unsigned char* ws = p->ws.as<unsigned char>();
     hipLaunchKernelGGL(planepost::cloud_voxels_kernel, dim3(1), dim3(planepost::NT), p->smem_cloud, st, G, s.dev<float>(t_all), n, ws);
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(1), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
-    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(1, planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);
-    for (int c = 0; c < 3 && !getenv("PLANAR_DEV_SKIP_HEAP"); c++) {   // (the environment variable: a developer's timing experiment, results are then wrong)
+    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(1, planepost::PS_EARLY + planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);
+    for (int c = 0; c < 2; c++) {                            // the LDS tier's fallback jobs (the global tier's ran inside plane_sort_lds)
         const planepost::HeapClass& H = planepost::PS_HC[c];
-        hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(1, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
+        hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(1, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, 1, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
     }
     hipLaunchKernelGGL(planepost::cloud_sums_kernel, dim3(1), dim3(planepost::NT), 0, st, G, s.dev<float>(t_all), ws, s.dev<float>(t_out), s.dev<int>(o_h), s.dev<int>(o_h) + 1);
     PLANAR_HIP_CHECK(hipGetLastError());

@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q -k "pose or opt or track or adapters" 2>&1 | tail -5
-timeout 300 python bench.py --workload pose 2>/dev/null | tail -1 | cut -c1-900
+for d in 4 6; do timeout 600 python bench.py --depth $d 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('depth', $d, d['value'], d['ms_per_step'])
+"; done
