@@ -54,7 +54,7 @@ struct Plan {
     double gaussCoefL[21], gaussCoefG[63];
 };
 
-struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int sort_counts[2]; int heap_n; int n_hard; };   // sort_counts: ranges, LDS-tier blocks; heap_n: ranges left to the heap-sort fallback
+struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int sort_counts[2]; int heap_n; int pad_; };   // sort_counts: ranges, LDS-tier blocks; heap_n: ranges left to the heap-sort fallback
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2: 7th-order odd polynomial, degrees; plain mul/add (no FMA), see oracle/cvprim.cpp
@@ -707,10 +707,7 @@ __device__ inline bool double_equal(double a, double b) {
 // at most -log10(first term) - LOG_NT = -log1term / ln 10 - LOG_NT; when that bound is below `beat` (by a margin a million times the rounding of the two
 // expressions) the answer is "no" whatever the tail is, and the bound is returned instead of the value: no exp, no 64-step chain, no pow / log10.  A trial that
 // could win is evaluated in full, so every value that is kept or compared closely is the reference's.
-// LANE: every lane evaluates its OWN (n, k, p) - the reference's loop as it stands, one iteration after the other; otherwise the 64 lanes share one evaluation
-// (nfa_tail: the recurrence travels through the lanes).
-template <bool LANE>
-__device__ __attribute__((noinline)) double nfa(const Plan& P, int n, int k, double p, int pj, int lane, double beat = -1.7976931348623157e308) {   // (one copy per kernel: exp / pow / log10 inlined at every call site made the NFA kernels larger than the instruction cache)
+__device__ double nfa(const Plan& P, int n, int k, double p, int pj, int lane, double beat = -1.7976931348623157e308) {
     const double LOG_NT = P.log_nt;
     if (n == 0 || k == 0) return -LOG_NT;
     if (n == k) return -LOG_NT - double(n) * P.p_log10[pj];
@@ -727,35 +724,11 @@ __device__ __attribute__((noinline)) double nfa(const Plan& P, int n, int k, dou
         if (k > n * p) return -log1term / 2.30258509299404568402 - LOG_NT;
         else return -LOG_NT;
     }
-    if (!LANE) return nfa_tail(term, n, k, p_term, LOG_NT, lane);
-    // the reference's loop, iteration by iteration; written as "run the cheap iterations up to the next one that has to evaluate the stopping rule, then evaluate
-    // it" so that the lanes of a wavefront (each with its own n, k) meet at the expensive part (pow, log10) instead of dragging each other through it in
-    // every iteration: the rule usually fires the first time it is looked at
-    double bin_tail = term;
-    const double tolerance = 0.1;
-    int i = k + 1;
-    while (i <= n) {
-        double mult_term = 0;
-        bool rule = false;
-        while (i <= n) {
-            const double bin_term = double(n - i + 1) / double(i);
-            mult_term = bin_term * p_term;
-            term = term * mult_term;
-            bin_tail = bin_tail + term;
-            if (bin_term < 1) { rule = true; break; }
-            ++i;
-        }
-        if (!rule) break;
-        const double err = term * ((1 - pow(mult_term, double(n - i + 1))) / (1 - mult_term) - 1);
-        if (err < tolerance * fabs(-log10(bin_tail) - LOG_NT) * bin_tail) break;
-        ++i;
-    }
-    return -log10(bin_tail) - LOG_NT;
+    return nfa_tail(term, n, k, p_term, LOG_NT, lane);
 }
 
 // Counts the pixels of the rectangle (total) and, for each of the np tolerances precs[], those aligned with rec.theta.
-// LANE: the calling lane walks its own rectangle pixel by pixel (small rectangles: 64 of them per wavefront at once); otherwise the wavefront shares one.
-template <int NP, bool LANE>
+template <int NP>
 __device__ int rect_counts(const Det& D, const Rect& rec, const double* precs, int* alg_out) {
     const int lane = D.lane;
     const double half_width = rec.width / 2.0;
@@ -765,41 +738,39 @@ __device__ int rect_counts(const Det& D, const Rect& rec, const double* precs, i
     ox[1] = int(rec.x2 - dyhw); oy[1] = int(rec.y2 + dxhw);
     ox[2] = int(rec.x2 + dyhw); oy[2] = int(rec.y2 - dxhw);
     ox[3] = int(rec.x1 + dyhw); oy[3] = int(rec.y1 - dxhw);
-    // std::sort of the 4 corners by (x, then y): a total order (equal pairs are the same pair), so a five-comparator network leaves what the library's sort leaves;
-    // and everything below picks corners by selects, not by indexing - per lane (LANE) an indexed int[4] would live in scratch memory
-    auto cswap = [&](int a_, int b_) {
-        const bool sw = ox[b_] == ox[a_] ? oy[b_] < oy[a_] : ox[b_] < ox[a_];
-        const int tx = ox[a_], ty = oy[a_];
-        ox[a_] = sw ? ox[b_] : tx; oy[a_] = sw ? oy[b_] : ty; ox[b_] = sw ? tx : ox[b_]; oy[b_] = sw ? ty : oy[b_];
-    };
-    cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
-    auto pick = [&](const int (&v)[4], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); };
-    int min_y = 0, vmin = oy[0], vmax = oy[0];
-#pragma unroll
-    for (int i = 1; i < 4; ++i) {
-        if (vmin > oy[i]) { min_y = i; vmin = oy[i]; }
-        if (vmax < oy[i]) vmax = oy[i];
+    // std::sort of 4 elements == insertion sort by (x, then y)
+    for (int i = 1; i < 4; i++) {
+        const int vx = ox[i], vy = oy[i];
+        int j = i - 1;
+        while (j >= 0 && (vx == ox[j] ? vy < oy[j] : vx < ox[j])) { ox[j + 1] = ox[j]; oy[j + 1] = oy[j]; j--; }
+        ox[j + 1] = vx; oy[j + 1] = vy;
     }
-    // leftmost: the first corner (ascending x) that is not min_y; rightmost: of the two left after that, the later one if its x is larger, else the earlier;
-    // tailp: the last one (the library's strict comparisons keep the first of equals)
-    const int leftmost = min_y == 0 ? 1 : 0;
-    int ra = -1, rb = -1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) if (i != min_y && i != leftmost) { if (ra < 0) ra = i; else rb = i; }
-    const int rightmost = pick(ox, rb) > pick(ox, ra) ? rb : ra;
-    const int tailp = rightmost == ra ? rb : ra;
-    const int oxm = pick(ox, min_y), oym = vmin, oxl = pick(ox, leftmost), oyl = pick(oy, leftmost), oxr = pick(ox, rightmost), oyr = pick(oy, rightmost), oxt = pick(ox, tailp);
+    int min_y = 0, max_y = 0;
+    for (int i = 1; i < 4; ++i) {
+        if (oy[min_y] > oy[i]) min_y = i;
+        if (oy[max_y] < oy[i]) max_y = i;
+    }
+    bool taken[4] = {false, false, false, false};
+    taken[min_y] = true;
+    int leftmost = -1;
+    for (int i = 0; i < 4; ++i) if (!taken[i]) { if (leftmost < 0) leftmost = i; else if (ox[leftmost] > ox[i]) leftmost = i; }
+    taken[leftmost] = true;
+    int rightmost = -1;
+    for (int i = 0; i < 4; ++i) if (!taken[i]) { if (rightmost < 0) rightmost = i; else if (ox[rightmost] < ox[i]) rightmost = i; }
+    taken[rightmost] = true;
+    int tailp = -1;
+    for (int i = 0; i < 4; ++i) if (!taken[i]) { if (tailp < 0) tailp = i; else if (ox[tailp] > ox[i]) tailp = i; }
     // integer divisions and the ox[tailp] (not oy) operands are the library's own
-    const long long flstep = (oym != oyl) ? (oxm - oxl) / (oym - oyl) : 0;
-    const long long slstep = (oyl != oxt) ? (oxl - oxt) / (oyl - oxt) : 0;
-    const long long frstep = (oym != oyr) ? (oxm - oxr) / (oym - oyr) : 0;
-    const long long srstep = (oyr != oxt) ? (oxr - oxt) / (oyr - oxt) : 0;
+    const long long flstep = (oy[min_y] != oy[leftmost]) ? (ox[min_y] - ox[leftmost]) / (oy[min_y] - oy[leftmost]) : 0;
+    const long long slstep = (oy[leftmost] != ox[tailp]) ? (ox[leftmost] - ox[tailp]) / (oy[leftmost] - ox[tailp]) : 0;
+    const long long frstep = (oy[min_y] != oy[rightmost]) ? (ox[min_y] - ox[rightmost]) / (oy[min_y] - oy[rightmost]) : 0;
+    const long long srstep = (oy[rightmost] != ox[tailp]) ? (ox[rightmost] - ox[tailp]) / (oy[rightmost] - ox[tailp]) : 0;
     // The reference walks the rows with left_x += lstep / right_x += rstep (doubles).  All operands are integers, so the sums are
     // exact and row k of the in-image rows has the closed form below (rows outside the image skip the update in the library).
-    const long long x0 = oxm;
-    const int ylo = max(oym, 0), yhi = min(vmax, D.h - 1);
+    const long long x0 = ox[min_y];
+    const int ylo = max(oy[min_y], 0), yhi = min(oy[max_y], D.h - 1);
     const int nrows = yhi >= ylo ? yhi - ylo + 1 : 0;
-    const int ly = oyl, ry = oyr;
+    const int ly = oy[leftmost], ry = oy[rightmost];
     auto row_span = [&](int k, int& xa) -> int {      // clipped [xa, xa + c) of in-image row k; returns c
         const long long nl = min(max((long long)ly - ylo, 0ll), (long long)k), nr = min(max((long long)ry - ylo, 0ll), (long long)k);
         const long long left = x0 + nl * flstep + (k - nl) * slstep, right = x0 + nr * frstep + (k - nr) * srstep;
@@ -807,6 +778,10 @@ __device__ int rect_counts(const Det& D, const Rect& rec, const double* precs, i
         xa = (int)a;
         return b >= a ? (int)(b - a + 1) : 0;
     };
+    int total = 0, wmax = 0;
+    for (int k = lane; k < nrows; k += 64) { int xa; const int c = row_span(k, xa); total += c; wmax = max(wmax, c); }
+    total = wave_sum_i(total);
+    wmax = (int)planar::wave_max_f64((double)wmax);            // (exact: an int32 is a double)
     int alg[NP];
     for (int q = 0; q < NP; q++) alg[q] = 0;
     auto test = [&](float deg) {
@@ -819,28 +794,6 @@ __device__ int rect_counts(const Det& D, const Rect& rec, const double* precs, i
         }
         for (int q = 0; q < NP; q++) if (n_theta <= precs[q]) alg[q]++;
     };
-    if (LANE) {
-        int total = 0;
-        constexpr int LU = 8;                                // gathers in flight (a lane's loop would otherwise wait out one L2 round trip per pixel)
-        for (int k = 0; k < nrows; k++) {
-            int xa; const int c = row_span(k, xa);
-            const int base = (ylo + k) * D.w + xa;
-            total += c;
-            for (int x = 0; x < c; x += LU) {
-                float deg[LU];
-#pragma unroll
-                for (int u = 0; u < LU; u++) deg[u] = D.ang[base + min(x + u, c - 1)];
-#pragma unroll
-                for (int u = 0; u < LU; u++) if (x + u < c) test(deg[u]);
-            }
-        }
-        for (int q = 0; q < NP; q++) alg_out[q] = alg[q];
-        return total;
-    }
-    int total = 0, wmax = 0;
-    for (int k = lane; k < nrows; k += 64) { int xa; const int c = row_span(k, xa); total += c; wmax = max(wmax, c); }
-    total = wave_sum_i(total);
-    wmax = (int)planar::wave_max_f64((double)wmax);            // (exact: an int32 is a double)
     constexpr int RU = 4;                                    // gathers in flight per lane (unconditional loads of a clamped index)
     if (wmax > 0 && wmax <= 64) {
         int wp = 1; while (wp < wmax) wp <<= 1;
@@ -875,19 +828,14 @@ __device__ int rect_counts(const Det& D, const Rect& rec, const double* precs, i
     return total;
 }
 
-template <bool LANE>
 __device__ double rect_nfa(const Det& D, const Rect& rec, double beat) {
     int alg;
-    const int total = rect_counts<1, LANE>(D, rec, &rec.prec, &alg);
-    return nfa<LANE>(*D.plan, total, alg, rec.p, rec.pj, D.lane, beat);
+    const int total = rect_counts<1>(D, rec, &rec.prec, &alg);
+    return nfa(*D.plan, total, alg, rec.p, rec.pj, D.lane, beat);
 }
 
-// rect_improve in two parts.  Head: the first evaluation and the five finer-precision trials (one pass over the rectangle's pixels counts all six tolerances).
-// -> true: finished - the region is meaningful, or no further trial can run (every later trial needs width - 0.5 >= 0.5, and the width only shrinks).
-// Tail: the three groups of five width trials and the last five precision trials, from the head's (rec, log_nfa).
-template <bool LANE>
-__device__ bool rect_improve_head(const Det& D, Rect& rec, double LOG_EPS, double& log_nfa_out) {
-    const double delta = 0.5;
+__device__ double rect_improve(const Det& D, Rect& rec, double LOG_EPS) {
+    const double delta = 0.5, delta_2 = delta / 2.0;
     const Plan& P = *D.plan;
     // first evaluation + the five "finer precision" trials share the geometry: one pass over the pixels counts all six tolerances
     Rect r = rec;
@@ -895,59 +843,57 @@ __device__ bool rect_improve_head(const Det& D, Rect& rec, double LOG_EPS, doubl
     precs[0] = rec.prec; ps[0] = rec.p;
     for (int n = 1; n < 6; ++n) { ps[n] = ps[n - 1] / 2; precs[n] = ps[n] * LSD_PI; }
     int algs[6];
-    const int total0 = rect_counts<6, LANE>(D, rec, precs, algs);
-    double log_nfa = nfa<LANE>(P, total0, algs[0], ps[0], rec.pj, D.lane);
-    log_nfa_out = log_nfa;
-    if (log_nfa > LOG_EPS) return true;
-#pragma nounroll
+    const int total0 = rect_counts<6>(D, rec, precs, algs);
+    double log_nfa = nfa(P, total0, algs[0], ps[0], rec.pj, D.lane);
+    if (log_nfa > LOG_EPS) return log_nfa;
     for (int n = 0; n < 5; ++n) {
         r.p /= 2;
         r.prec = r.p * LSD_PI;
         r.pj++;
-        const double v = nfa<LANE>(P, total0, algs[n + 1], r.p, r.pj, D.lane, log_nfa);
+        const double v = nfa(P, total0, algs[n + 1], r.p, r.pj, D.lane, log_nfa);
         if (v > log_nfa) { log_nfa = v; rec = r; }
     }
-    log_nfa_out = log_nfa;
-    return log_nfa > LOG_EPS || !((rec.width - delta) >= 0.5);
-}
-
-template <bool LANE>
-__device__ double rect_improve_tail(const Det& D, Rect& rec, double LOG_EPS, double log_nfa) {
-    const double delta = 0.5, delta_2 = delta / 2.0;
-    const Plan& P = *D.plan;
-    Rect r;
-    double precs[6], ps[6];
-    int algs[6];
-    // the three groups of five width trials - narrower / narrower from one side / from the other - as ONE loop around one call site (the library writes the
-    // groups out; x += -dy d and x -= -dy d are x + s (-dy d) with s = +-1, exactly): the code of a trial exists once, the kernel fits the instruction cache
-#pragma nounroll
-    for (int stage = 0; stage < 3; ++stage) {
-        r = rec;
-        const double sg = stage == 1 ? 1.0 : -1.0;
-#pragma nounroll
-        for (int n = 0; n < 5; ++n) {
-            if ((r.width - delta) >= 0.5) {
-                if (stage) {
-                    r.x1 += sg * (-r.dy * delta_2); r.y1 += sg * (r.dx * delta_2);
-                    r.x2 += sg * (-r.dy * delta_2); r.y2 += sg * (r.dx * delta_2);
-                }
-                r.width -= delta;
-                const double v = rect_nfa<LANE>(D, r, log_nfa);
-                if (v > log_nfa) { rec = r; log_nfa = v; }
-            }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.width -= delta;
+            const double v = rect_nfa(D, r, log_nfa);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
         }
-        if (log_nfa > LOG_EPS) return log_nfa;
     }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
+            r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+            r.width -= delta;
+            const double v = rect_nfa(D, r, log_nfa);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
+            r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+            r.width -= delta;
+            const double v = rect_nfa(D, r, log_nfa);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
     r = rec;
     if ((r.width - delta) >= 0.5) {      // the width test is the same for all five trials (the width does not change here)
         for (int n = 0; n < 5; ++n) { ps[n] = (n ? ps[n - 1] : r.p) / 2; precs[n] = ps[n] * LSD_PI; }
-        const int total = rect_counts<5, LANE>(D, r, precs, algs);
-#pragma nounroll
+        const int total = rect_counts<5>(D, r, precs, algs);
         for (int n = 0; n < 5; ++n) {
             r.p /= 2;
             r.prec = r.p * LSD_PI;
             r.pj++;
-            const double v = nfa<LANE>(P, total, algs[n], r.p, r.pj, D.lane, log_nfa);
+            const double v = nfa(P, total, algs[n], r.p, r.pj, D.lane, log_nfa);
             if (v > log_nfa) { rec = r; log_nfa = v; }
         }
     }
@@ -1020,49 +966,15 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
         }
     }
     if (lane == 0) {
-        misc->n_rect = min(n_rect, MAX_RECTS); misc->n_regions = n_regions; misc->n_grown_px = n_px; misc->n_hard = 0;
+        misc->n_rect = min(n_rect, MAX_RECTS); misc->n_regions = n_regions; misc->n_grown_px = n_px;
         if (n_rect > MAX_RECTS) misc->status = 1;
         misc->t[0] = __builtin_readcyclecounter() - t_begin; misc->t[1] = t_grow; misc->t[2] = t_rect; misc->t[3] = t_refine; misc->t[4] = t_nfa;
     }
 }
 
-// ---- K4b: NFA stage of every region that survived refine(), all regions of all frames in parallel.  Almost everything in it is scalar work per region (the
-// rectangle's corner geometry with its integer divisions, exp / pow / log10 of the binomial tail) on a few dozen pixels, and 98 % of the regions are decided by
-// rect_improve's head.  lsd_improve: a wavefront takes 64 regions and every lane does the head of ITS region as the reference's scalar code does (LANE = true).
-// What is left - rectangles of more than IMPROVE_LANE_PX pixels (long lines), regions that go on to the width trials - is listed and finished by
-// lsd_improve_hard, one wavefront per region with the pixels and the tail's recurrence spread over the lanes.  (Round 3: one wavefront per region for
-// everything = 63 lanes repeating lane 0's scalar work.)
-constexpr int IMPROVE_LANE_PX = 192;
-constexpr uint32_t IMPROVE_FRESH = 0x80000000u;               // hard-list entry whose head has not run
-__device__ __forceinline__ Seg improve_result(Rect rec, double log_nfa) {
-    rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
-    rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8; rec.width /= 0.8;
-    return Seg{float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2), rec.width, rec.p, log_nfa};
-}
-__global__ __launch_bounds__(64) void lsd_improve(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
-    const Plan& P = *plan;
-    const int b = blockIdx.y, lane = threadIdx.x;
-    uint8_t* F = ws + (size_t)b * P.frame_bytes;
-    Det D{};
-    D.ang = (const float*)(F + P.off_ang); D.plan = plan; D.w = P.w; D.h = P.h; D.log_nt = P.log_nt; D.lane = lane;
-    Rect* rects = (Rect*)(F + P.off_rects);
-    Seg* res = (Seg*)(F + P.off_res);
-    uint32_t* hard = (uint32_t*)(F + P.off_tmp);              // (lsd_detect's scratch: free by now)
-    const int n = miscs[b].n_rect;
-    for (int c0 = blockIdx.x * 64; c0 < n; c0 += gridDim.x * 64) {
-        const int i = c0 + lane;
-        if (i >= n) continue;
-        Rect rec = rects[i];
-        // pixels of the rectangle, generously: (length + 2) x (width + 2)
-        const double len = sqrt(dist2(rec.x1, rec.y1, rec.x2, rec.y2));
-        if ((len + 2.0) * (rec.width + 2.0) <= (double)IMPROVE_LANE_PX) {
-            double log_nfa;
-            if (rect_improve_head<true>(D, rec, P.log_eps, log_nfa)) res[i] = improve_result(rec, log_nfa);
-            else { rects[i] = rec; res[i].nfa = log_nfa; hard[atomicAdd(&miscs[b].n_hard, 1)] = (uint32_t)i; }
-        } else hard[atomicAdd(&miscs[b].n_hard, 1)] = (uint32_t)i | IMPROVE_FRESH;
-    }
-}
-__global__ __launch_bounds__(64) void lsd_improve_hard(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, const Misc* __restrict__ miscs) {
+// ---- K4b: NFA stage of every region that survived refine(): one wavefront (= one workgroup) per region, all regions of all frames in
+// parallel; 128 wavefronts per frame share the frame's regions round-robin
+__global__ __launch_bounds__(64) void lsd_improve(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, const Misc* __restrict__ miscs) {
     const Plan& P = *plan;
     const int b = blockIdx.y, lane = threadIdx.x;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
@@ -1070,17 +982,13 @@ __global__ __launch_bounds__(64) void lsd_improve_hard(const Plan* __restrict__ 
     D.ang = (const float*)(F + P.off_ang); D.plan = plan; D.w = P.w; D.h = P.h; D.log_nt = P.log_nt; D.lane = lane;
     const Rect* rects = (const Rect*)(F + P.off_rects);
     Seg* res = (Seg*)(F + P.off_res);
-    const uint32_t* hard = (const uint32_t*)(F + P.off_tmp);
-    const int n = miscs[b].n_hard;
-    for (int q = blockIdx.x; q < n; q += gridDim.x) {
-        const uint32_t e = hard[q];
-        const int i = (int)(e & ~IMPROVE_FRESH);
+    const int n = miscs[b].n_rect;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
         Rect rec = rects[i];
-        double log_nfa = res[i].nfa;
-        bool done = false;
-        if (e & IMPROVE_FRESH) done = rect_improve_head<false>(D, rec, P.log_eps, log_nfa);
-        if (!done) log_nfa = rect_improve_tail<false>(D, rec, P.log_eps, log_nfa);
-        if (lane == 0) res[i] = improve_result(rec, log_nfa);
+        const double log_nfa = rect_improve(D, rec, P.log_eps);
+        rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+        rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8; rec.width /= 0.8;
+        if (lane == 0) res[i] = Seg{float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2), rec.width, rec.p, log_nfa};
     }
 }
 
@@ -1610,8 +1518,7 @@ int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d
     lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
     hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, st, dP, ws, dm);
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[3], st);
-    hipLaunchKernelGGL(lsd::lsd_improve, dim3(lsd::MAX_RECTS / 64 / 2, B), dim3(64), 0, st, dP, ws, dm);   // 64 regions per wavefront and turn
-    hipLaunchKernelGGL(lsd::lsd_improve_hard, dim3(64, B), dim3(64), 0, st, dP, ws, dm);
+    hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm);   // 512 / 2048 wavefronts per frame measure the same
     hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm);
     hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines);
     hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
