@@ -69,7 +69,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the cpu_baseline leg, split over its three variants (0 = skip)")
     ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 latency block (0 = skip)")
     ap.add_argument("--pcie-steps", type=int, default=4, help="steps of the PCIe-inclusive loop (0 = skip)")
-    ap.add_argument("--canvases", type=int, default=NCANVAS, help="distinct synthetic canvases per GPU (the streams tile over them)")
+    ap.add_argument("--canvases", type=int, default=NCANVAS, help="distinct synthetic canvases (pan) / room scenes with their textures (se3) per GPU (the streams tile over them)")
+    ap.add_argument("--streams", choices=["se3", "pan"], default="se3",
+                    help="se3: every stream is a camera moving through a textured box room - gray and depth of every frame ray-cast from the same SE3 pose "
+                         "(planarslam_amd/synth_se3.py; rendered on the GPU before the timed region, --loop frames per stream resident in HBM, played forwards and "
+                         "backwards); pan: rounds 1-3's streams - a 640x480 window panning over unrelated gray / depth canvases")
+    ap.add_argument("--loop", type=int, default=12, help="frames per stream of the se3 loop (resident: B x loop x 0.92 MB)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the barrier / max-over-ranks (nccl = RCCL, one rank per GPU).  gloo: ranks may share a GPU "
                          "(rank r uses device r mod device_count; the BA workload then exchanges through the hosted transport) - how the N > 1 "
@@ -124,19 +129,37 @@ def main():
 
     prio = [int(x) for x in args.prio.split(',')]
     d_canv_g = torch.from_numpy(canv_g).to(dev)
-    d_canv_d = torch.from_numpy(canv_d.view(np.int16)).to(dev)
-    ngroups = (B + ncanv - 1) // ncanv
-    goff = [(24 * (g & 1), 24 * ((g >> 1) & 1)) for g in range(ngroups)]   # streams that share a canvas look through windows 24 px apart
+    se3 = args.streams == "se3"
+    if se3:
+        # B camera streams in ncanv textured rooms (stream s: room s mod ncanv, its own SE3 path), args.loop frames each, rendered here and resident in HBM
+        from planarslam_amd import synth_se3
+        t_r = time.perf_counter()
+        loop_g, loop_d, Twc_true = synth_se3.render_streams(torch, d_canv_g, B, args.loop, TUM3, seed=rank_env, W=W, H=H)
+        torch.cuda.synchronize()
+        t_gen += time.perf_counter() - t_r
+        canv_g = loop_g[:1, 0].cpu().numpy(); canv_d = loop_d[:1, 0].cpu().numpy().view(np.uint16)     # (the B = 1 latency block and the CPU leg take stream 0's first frame)
+        canv_g = np.pad(canv_g, ((0, 0), (MARGIN, MARGIN), (MARGIN, MARGIN))); canv_d = np.pad(canv_d, ((0, 0), (MARGIN, MARGIN), (MARGIN, MARGIN)))
 
-    def window(i, out_g, out_d):
-        """The frames of step i: a strided device copy out of the resident canvases (part of the step)."""
-        ox, oy = pan_offset(i, MARGIN)
-        for g in range(ngroups):
-            a, b = g * ncanv, min(B, (g + 1) * ncanv)
-            x0, y0 = ox + goff[g][0], oy + goff[g][1]
-            out_g[a:b].copy_(d_canv_g[:b - a, y0:y0 + H, x0:x0 + W])
+        def window(i, out_g, out_d):
+            """The frames of step i: a strided device copy out of the resident loops (part of the step)."""
+            fi = synth_se3.frame_index(i, args.loop)
+            out_g.copy_(loop_g[:, fi])
             if out_d is not None:
-                out_d[a:b].copy_(d_canv_d[:b - a, y0:y0 + H, x0:x0 + W])
+                out_d.copy_(loop_d[:, fi])
+    else:
+        d_canv_d = torch.from_numpy(canv_d.view(np.int16)).to(dev)
+        ngroups = (B + ncanv - 1) // ncanv
+        goff = [(24 * (g & 1), 24 * ((g >> 1) & 1)) for g in range(ngroups)]   # streams that share a canvas look through windows 24 px apart
+
+        def window(i, out_g, out_d):
+            """The frames of step i: a strided device copy out of the resident canvases (part of the step)."""
+            ox, oy = pan_offset(i, MARGIN)
+            for g in range(ngroups):
+                a, b = g * ncanv, min(B, (g + 1) * ncanv)
+                x0, y0 = ox + goff[g][0], oy + goff[g][1]
+                out_g[a:b].copy_(d_canv_g[:b - a, y0:y0 + H, x0:x0 + W])
+                if out_d is not None:
+                    out_d[a:b].copy_(d_canv_d[:b - a, y0:y0 + H, x0:x0 + W])
 
     L = lib()
     if full:
@@ -148,7 +171,7 @@ def main():
         # the per-stream map stand-ins (reference key frame's lines, map planes) from the streams' first frames, through the product extractors
         window(0, frames[0], depths[0])
         torch.cuda.synchronize()
-        nmap = min(B, ncanv)
+        nmap = B if se3 else min(B, ncanv)      # (se3: every stream has its own first frame, hence its own map)
         kf_lines, map_planes, normals = build_map(frames[0][:nmap].cpu().numpy(), depths[0][:nmap].cpu().numpy().view(np.uint16), TUM3, seed=rank)
         rep = lambda a: np.concatenate([a] * ((B + len(a) - 1) // len(a)))[:B]
         tp.set_map({k: rep(v) for k, v in kf_lines.items()}, {k: rep(v) for k, v in map_planes.items()}, {k: rep(v) for k, v in normals.items()})
@@ -497,7 +520,10 @@ def main():
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8/f64" if full else "u8", "data": "synthetic",
-        "config": {"workload": workload, "frames_per_gpu_per_step": B, "distinct_canvases_per_gpu": ncanv, "window": "pans <= 8 px per step; every step is a new frame for every stream",
+        "config": {"workload": workload, "frames_per_gpu_per_step": B, "distinct_canvases_per_gpu": ncanv,
+                   "streams": (f"se3: {B} cameras in {ncanv} textured box rooms, gray + depth ray-cast from the same pose, {args.loop}-frame constant-velocity sweeps (1.2 cm, 0.25 deg per frame) "
+                               f"played forwards and backwards; resident in HBM, a strided device copy per step" if se3 else "pan: a 640x480 window moving <= 8 px per step over unrelated gray / depth canvases"),
+                   "window": "every step is a new frame for every stream",
                    "pipeline_depth": args.depth, "avg_keypoints_per_frame": round(avg_kp, 1), "input_generation_s": round(t_gen, 1),
                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}, "not_yet_in_workload": nyi,
                    "parallelism": f"frame-sharded x{world}, no collective"},

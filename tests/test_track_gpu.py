@@ -367,3 +367,48 @@ def test_pipeline_with_a_distorting_camera():
         moved = max(moved, float(np.abs(want["x"] - k["x"]).max()))
     assert moved > 1.0                                                          # the lens model does move key points by pixels
     assert np.isfinite(c["pose_out"].cpu().numpy()).all()
+
+
+def test_pipeline_tracks_se3_rendered_streams():
+    """Streams rendered from SE3 camera motion in a textured box room (planarslam_amd/synth_se3.py: gray and depth of a frame come from the same pose): the
+    pipeline's pose of every stream follows the TRUE camera motion - the map is the stream's first frame at the identity pose, so the estimate is compared with
+    inv(Twc[j]) Twc[0].  This is the property the panned canvases of the other tests cannot have (their gray and depth do not belong to one camera)."""
+    import torch
+    from planarslam_amd import synth_se3
+    from planarslam_amd.synth import gray_image
+    from planarslam_amd.track import TrackPipeline, build_map
+    Bs, K, n_steps = 16, 8, 12
+    dev = torch.device("cuda", 0)
+    tex = torch.from_numpy(np.stack([gray_image(1234 + i, W + 2 * MARGIN, H + 2 * MARGIN) for i in range(Bs)])).to(dev)
+    loop_g, loop_d, Twc = synth_se3.render_streams(torch, tex, Bs, K, TUM3, seed=3)
+    tp = TrackPipeline(Bs, torch, 0, depth=1)
+    tp.set_map(*build_map(loop_g[:, 0].cpu().numpy(), loop_d[:, 0].cpu().numpy().view(np.uint16), TUM3, seed=1))
+    tp.capture_steps = {n_steps - 1}
+    frames = [torch.zeros((Bs, H, W), dtype=torch.uint8, device=dev) for _ in range(tp.NB)]
+    depths = [torch.zeros((Bs, H, W), dtype=torch.int16, device=dev) for _ in range(tp.NB)]
+    with torch.cuda.stream(tp.stream):
+        for i in range(n_steps):
+            k = i % tp.NB
+            tp.stream.wait_event(tp.done[k])
+            fi = synth_se3.frame_index(i, K)
+            frames[k].copy_(loop_g[:, fi]); depths[k].copy_(loop_d[:, fi])
+            tp.step(i, frames[k], depths[k])
+        tp.drain()
+    torch.cuda.synchronize()
+    tp.check()
+    c = tp.captured[n_steps - 1]
+    T = c["pose_out"].cpu().numpy().reshape(Bs, 4, 4).astype(np.float64)
+    fi = synth_se3.frame_index(n_steps - 1, K)
+    assert fi != 0
+    dt, dr, moved = [], [], []
+    for b in range(Bs):
+        want = synth_se3.relative_pose(Twc[b], fi, 0)
+        dR = T[b, :3, :3] @ want[:3, :3].T
+        dr.append(np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))))
+        dt.append(np.linalg.norm(T[b, :3, 3] - want[:3, 3]))
+        moved.append(np.linalg.norm(want[:3, 3]))
+    dt, dr = np.array(dt), np.array(dr)
+    print("se3 streams: translation error (m)", np.round(dt, 4), "rotation error (deg)", np.round(dr, 3), "true motion (m)", np.round(moved, 3))
+    assert np.median(moved) > 0.02                                          # the cameras did move
+    assert np.median(dt) < 0.01 and np.median(dr) < 0.2, (dt, dr)          # and the tracker knows where to (1 cm, 0.2 deg; depth noise is 0.0012 z^2)
+    assert (dt < 0.05).mean() >= 0.9 and (dr < 1.0).mean() >= 0.9, (dt, dr)
