@@ -11,14 +11,14 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 240 python -c "import torch, numpy; print('warm', torch.cuda.is_available())" > $O/${tag}_warmup.log 2>&1
 FL="--steps 6 --warmup 3 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
-# counter passes: the canvases are synthesised in-process (--gen-procs 1, 16 of them): rocprofv3 --pmc hangs when the profiled process forks workers (profiles/README.md)
-PF="--gen-procs 1 --canvases 16 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
+# counter passes: the textures are synthesised in-process (--gen-procs 1, 16 rooms, 4-frame loops): rocprofv3 --pmc hangs when the profiled process forks workers (profiles/README.md)
+PF="--gen-procs 1 --canvases 16 --loop 4 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
 if [ $what = bench ]; then
     timeout 240 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
     timeout 60 python bench.py --workload ba --steps 20 --warmup 3 > $O/${tag}_bench_ba.json 2>> $O/${tag}_bench.err
     timeout 90 python bench.py --workload pose --steps 50 --warmup 5 > $O/${tag}_bench_pose.json 2>> $O/${tag}_bench.err
     cd /tmp && export TMPDIR=/tmp
-    timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
     cd $R
     f=$(ls $O/${tag}_trace/*/*kernel_stats.csv | head -1); cp $f $O/${tag}_kernel_stats.csv
     t=$(ls $O/${tag}_trace/*/*kernel_trace.csv | head -1); (head -1 $t; tail -80 $t) > $O/${tag}_kernel_trace_tail.csv
@@ -26,12 +26,12 @@ if [ $what = bench ]; then
     cut -c1-200 $O/${tag}_bench.json; head -5 $O/${tag}_kernel_stats.csv | cut -c1-160
 elif [ $what = pmc ]; then
     cd /tmp && export TMPDIR=/tmp
-    timeout 70 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_fetch -- python $R/bench.py $PF > /dev/null 2>&1
-    timeout 70 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_write -- python $R/bench.py $PF > /dev/null 2>&1
+    timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_fetch -- python $R/bench.py $PF > /dev/null 2>&1
+    timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_pmc_write -- python $R/bench.py $PF > /dev/null 2>&1
     python $R/tools/pmc_summary.py $O/${tag}_pmc_fetch $O/${tag}_pmc_write > $O/${tag}_pmc_fetch_write_kb_per_launch.csv 2>> $O/${tag}_bench.err
     # issue counters: instructions per launch, share of a wavefront's resident time with an instruction in flight / waiting
-    timeout 70 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/${tag}_pmc_sq1 -- python $R/bench.py $PF > /dev/null 2>&1
-    timeout 70 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/${tag}_pmc_sq2 -- python $R/bench.py $PF > /dev/null 2>&1
+    timeout 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/${tag}_pmc_sq1 -- python $R/bench.py $PF > /dev/null 2>&1
+    timeout 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/${tag}_pmc_sq2 -- python $R/bench.py $PF > /dev/null 2>&1
     python $R/tools/pmc_counters.py $O/${tag}_pmc_sq1 $O/${tag}_pmc_sq2 > $O/${tag}_pmc_sq_per_launch.csv 2>> $O/${tag}_bench.err
     rm -rf $O/${tag}_pmc_fetch $O/${tag}_pmc_write $O/${tag}_pmc_sq1 $O/${tag}_pmc_sq2
     head -8 $O/${tag}_pmc_fetch_write_kb_per_launch.csv; head -8 $O/${tag}_pmc_sq_per_launch.csv
