@@ -114,16 +114,17 @@ def render(torch, scenes, tex, Twc, cam, W=640, H=480, noise_seed=0, factor=5000
     R = t(Twc[:, :3, :3]); o = t(Twc[:, :3, 3])
     ys, xs = torch.meshgrid(torch.arange(H, device=dev, dtype=f32), torch.arange(W, device=dev, dtype=f32), indexing="ij")
     rc = torch.stack([(xs - cam["cx"]) / cam["fx"], (ys - cam["cy"]) / cam["fy"], torch.ones_like(xs)], 0)      # [3, H, W], z = 1: t is the depth
-    rw = torch.einsum("sij,jhw->sihw", R, rc)                                                                     # [S, 3, H, W]
+    dot3 = lambda v, F: v[:, 0, None, None] * F[:, 0] + v[:, 1, None, None] * F[:, 1] + v[:, 2, None, None] * F[:, 2]       # [S, 3] . [S, 3, H, W] (no BLAS call: the
+    rw = torch.stack([R[:, i, 0, None, None] * rc[0] + R[:, i, 1, None, None] * rc[1] + R[:, i, 2, None, None] * rc[2] for i in range(3)], 1)   # profiles stay ours)
     best_t = torch.full((S, H, W), float("inf"), device=dev, dtype=f32)
     best_u = torch.zeros((S, H, W), device=dev, dtype=f32); best_v = torch.zeros_like(best_u); best_g = torch.zeros_like(best_u)
     for f in range(nF):
         nf = n[:, f]                                                                                               # [S, 3]
-        den = torch.einsum("si,sihw->shw", nf, rw)
-        num = -(torch.einsum("si,si->s", nf, o) + d[:, f])[:, None, None]
+        den = dot3(nf, rw)
+        num = -((nf * o).sum(1) + d[:, f])[:, None, None]
         tt = torch.where(den.abs() > 1e-9, num / den, torch.full_like(den, float("inf")))
         Xh = o[:, :, None, None] + tt[:, None] * rw                                                                # hit points [S, 3, H, W]
-        u = torch.einsum("si,sihw->shw", a[:, f], Xh); v = torch.einsum("si,sihw->shw", b[:, f], Xh)
+        u = dot3(a[:, f], Xh); v = dot3(b[:, f], Xh)
         ok = (tt > 0.05) & (tt < best_t) & (u >= lo[:, f, 0, None, None]) & (u <= hi[:, f, 0, None, None]) & (v >= lo[:, f, 1, None, None]) & (v <= hi[:, f, 1, None, None])
         best_t = torch.where(ok, tt, best_t)
         best_u = torch.where(ok, u * TEX_PX_PER_M + toff[:, f, 0, None, None], best_u)

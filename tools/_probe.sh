@@ -1,13 +1,7 @@
 cd $GRAFT_REPO_ROOT
-( time timeout 900 python bench.py > /tmp/b.json 2>/tmp/b.err ) 2>&1 | tail -3
-tail -3 /tmp/b.err | cut -c1-300
-python -c "
-import json
-d=json.loads(open('/tmp/b.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['config']['input_generation_s'], d['config'].get('avg_keypoints_per_frame'))
-print({k:v for k,v in d['config'].items() if k not in ('workload','stage_ms_per_step','not_yet_in_workload')})
-print(d['config']['stage_ms_per_step'])
-pk=d['roofline'].get('per_kernel',{})
-for k,v in pk.items(): print(k, v)
-print(d['roofline'].get('plane_sort_stats'))
-"
+for m in none lsd peac planepost orb normals; do PLANAR_TRACK_SKIP=$m timeout 600 python bench.py --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+s=d['config']['stage_ms_per_step']
+print('skip $m', d['value'], d['ms_per_step'], 'peac', s.get('peac(stream 2)'), 'lsd', s.get('lsd_lbd(stream 3)'), 'orb', s.get('orb_extract'))
+"; done
