@@ -676,6 +676,9 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrow = (l - f - 1 + 63) / 64;
     if (nrow > rows_cap) { if (tid == 0) *status = ST_CAPACITY; return f + (l - f) / 2; }
+#ifdef ISORT_TIMING
+    long long _tm = __builtin_readcyclecounter();
+#endif
     if (tid == 0) {
         const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
         const uint32_t xa = arr[A], xb = arr[Bm], xc = arr[Cc], xf = arr[f];
@@ -688,6 +691,7 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
     const uint32_t pv = (uint32_t)s_i[0];
     const int tpos = s_i[1];
     const uint32_t xfront = (uint32_t)s_i[2];
+    ISORT_MARK(10);
     // ---- pass 1: one read of the range; a row of 64 elements = one ballot per scan ----
     constexpr int U = 4;
     for (int rb = wave; rb < nrow; rb += NW * U) {
@@ -705,6 +709,7 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
         }
     }
     __syncthreads();
+    ISORT_MARK(11);
     // ---- ranks: exclusive popcount prefix per row ----
     const int RP = (nrow + T - 1) / T, r_begin = min(nrow, tid * RP), r_end = min(nrow, r_begin + RP);
     unsigned long long mine = 0;
@@ -718,6 +723,7 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
     const int totL = (int)(tot >> 32), totR = (int)(uint32_t)tot;
     if (tid == 0) { pL[nrow] = (uint32_t)totL; pR[nrow] = (uint32_t)totR; }
     __syncthreads();
+    ISORT_MARK(12);
     // ---- x*: the row where A >= B turns true, then the bit inside it ----
     for (int r = r_begin; r < r_end; r++) {
         const int A0 = (int)pL[r], B0 = totR - (int)pR[r], A1 = (int)pL[r + 1], B1 = totR - (int)pR[r + 1];
@@ -737,6 +743,7 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
     }
     __syncthreads();
     const int cut = s_i[3], m = s_i[4];
+    ISORT_MARK(13);
     // ---- swaps: the k-th stop of the left scan (k < m) with the k-th of the right scan, lane = element of a row ----
     for (int r = wave; r < nrow; r += NW) {
         const int pl = (int)pL[r];
@@ -754,6 +761,7 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
     }
     __threadfence_block();
     __syncthreads();
+    ISORT_MARK(14);
     return cut;
 }
 
