@@ -728,14 +728,17 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
     for (int r = r_begin; r < r_end; r++) {
         const int A0 = (int)pL[r], B0 = totR - (int)pR[r], A1 = (int)pL[r + 1], B1 = totR - (int)pR[r + 1];
         if (!(A0 >= B0) && A1 >= B1) {
+            // the first j in 1 .. 64 with A0 + #L among the row's first j elements >= B0 - #R among them (the difference only grows with j: six halvings
+            // instead of a walk of up to 64 steps by one thread while the other 1023 wait at the barrier)
             const unsigned long long Lb = Lw[r], Rb = Rw[r];
-            int j = 1, A = A0, Bf = B0;
-            bool eL = false, eR = false;
-            for (; j <= 64; j++) {
-                eL = (Lb >> (j - 1)) & 1ull; eR = (Rb >> (j - 1)) & 1ull;
-                A += (int)eL; Bf -= (int)eR;
-                if (A >= Bf) break;
+            auto low = [](int j_) { return j_ >= 64 ? ~0ull : ((1ull << j_) - 1ull); };
+            int jl = 0, j = 64;
+            while (j - jl > 1) {
+                const int mid = (jl + j) >> 1;
+                if (A0 + __popcll(Lb & low(mid)) >= B0 - __popcll(Rb & low(mid))) j = mid; else jl = mid;
             }
+            const bool eL = (Lb >> (j - 1)) & 1ull, eR = (Rb >> (j - 1)) & 1ull;
+            const int A = A0 + __popcll(Lb & low(j)), Bf = B0 - __popcll(Rb & low(j));
             const int xs = f + 1 + 64 * r + j, Ap = A - (int)eL, Bp = Bf + (int)eR;
             s_i[3] = xs - ((eL && eR && Ap == Bp - 1) ? 1 : 0);
             s_i[4] = max(Ap, Bf);
