@@ -644,7 +644,7 @@ __device__ __forceinline__ Pt cam_point_thread(const Geo& G, unsigned short d, i
     return {(float)tx, (float)ty, (float)z};
 }
 
-__global__ __launch_bounds__(NT) void plane_tail_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
+__global__ __launch_bounds__(NT, 4) void plane_tail_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
                                                         const double* __restrict__ planes_all, int planes_stride, const int* __restrict__ rng, unsigned char* ws_all,
                                                         int* n_out, float* coef_out, int* src_out, int* off_out, float* pts_out, int* status, int* state_out,
                                                         int* nvox_out, int* info_out, long long* timing) {
