@@ -20,7 +20,19 @@ if [ $what = bench ]; then
     cd /tmp && export TMPDIR=/tmp
     timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
     cd $R
-    f=$(ls $O/${tag}_trace/*/*kernel_stats.csv | head -1); cp $f $O/${tag}_kernel_stats.csv
+    f=$(ls $O/${tag}_trace/*/*kernel_stats.csv | head -1); cp $f $O/${tag}_kernel_stats_all.csv
+    # the product's kernels only (the at::native rows of the full file are the input renderer, planarslam_amd/synth_se3.py, before the timed region), percentages of their sum
+    python - "$O/${tag}_kernel_stats_all.csv" "$O/${tag}_kernel_stats.csv" << 'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "planar::" in r["Name"]]
+tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+with open(sys.argv[2], "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_ALL)
+    w.writeheader()
+    for r in rows:
+        r["Percentage"] = f"{100.0 * float(r['TotalDurationNs']) / tot:.2f}"
+        w.writerow(r)
+PY
     t=$(ls $O/${tag}_trace/*/*kernel_trace.csv | head -1); (head -1 $t; tail -80 $t) > $O/${tag}_kernel_trace_tail.csv
     rm -rf $O/${tag}_trace
     cut -c1-200 $O/${tag}_bench.json; head -5 $O/${tag}_kernel_stats.csv | cut -c1-160
