@@ -646,6 +646,7 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
 // ---------------------------------------------------------------------------------------------------------------------------------------
 constexpr int G_QMAX = 64;       // ranges longer than the LDS tier's capacity alive at one level
 constexpr int G_FMAX = 512;      // ranges handed to the LDS tier, per array set
+constexpr int G_POSH = 6144;     // swaps of a partition go through a table of this many positions at a time (24 KB: beside the bitmaps of a 640 x 480 range in 160 KB)
 
 template <int T>
 struct GlobalLayout {            // LDS of global_tier for arrays whose longest range has `rows` 64-element rows
@@ -658,7 +659,8 @@ struct GlobalLayout {            // LDS of global_tier for arrays whose longest 
     __host__ __device__ static constexpr int off_fin(int rows) { return off_q(rows) + 2 * G_QMAX * 12; }              // Range [G_FMAX]
     __host__ __device__ static constexpr int off_rank(int rows) { return off_fin(rows) + G_FMAX * 12; }               // Range [G_FMAX] (sorted copy)
     __host__ __device__ static constexpr int off_buf(int rows) { return off_rank(rows) + G_FMAX * 12; }               // u64 [NW] + ints
-    __host__ __device__ static constexpr int bytes(int rows) { return off_buf(rows) + NW * 8 + 64; }
+    __host__ __device__ static constexpr int off_posh(int rows) { return off_buf(rows) + NW * 8 + 64; }               // u32 [G_POSH]: the swaps' rendezvous table
+    __host__ __device__ static constexpr int bytes(int rows) { return off_posh(rows) + G_POSH * 4; }
     __host__ __device__ static constexpr int rows_for(int n) { return (n + 63) / 64 + 1; }
 };
 
@@ -747,19 +749,38 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
     __syncthreads();
     const int cut = s_i[3], m = s_i[4];
     ISORT_MARK(13);
-    // ---- swaps: the k-th stop of the left scan (k < m) with the k-th of the right scan, lane = element of a row ----
-    for (int r = wave; r < nrow; r += NW) {
-        const int pl = (int)pL[r];
-        if (pl >= m) break;
-        const unsigned long long Lb = Lw[r];
-        const int k = pl + __popcll(Lb & ((1ull << lane) - 1ull));
-        if (((Lb >> lane) & 1ull) && k < m) {
-            const int rk = totR - 1 - k;
+    // ---- swaps: the k-th stop of the left scan (k < m) with the k-th of the right scan (counted from the right), G_POSH ranks at a time: the right stops write
+    //      their positions into a table indexed by rank, the left stops read their partner there (a binary search over the row prefixes + an in-word select per
+    //      element before: two thirds of the tier's time).  lane = element of a row; a chunk's rows are found once per wavefront ----
+    {
+        uint32_t* posh = (uint32_t*)(lds + GL::off_posh(rows_cap));
+        auto row_of = [&](const uint32_t* pref, int rank) {       // the last row whose prefix is <= rank (pref[0] = 0 <= rank)
             int lo = 0, hi = nrow;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)pR[mid] <= rk) lo = mid; else hi = mid; }
-            const int q = f + 1 + 64 * lo + select64(Rw[lo], rk - (int)pR[lo]), p = f + 1 + 64 * r + lane;
-            const uint32_t x = arr[p], y = arr[q];
-            arr[p] = y; arr[q] = x;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)pref[mid] <= rank) lo = mid; else hi = mid; }
+            return lo;
+        };
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (int base = 0; base < m; base += G_POSH) {
+            const int kend = min(m, base + G_POSH);
+            const int rr_lo = totR - kend, rr_hi = totR - 1 - base;          // the right stops of these ranks, counted from the left
+            const int ra = row_of(pR, rr_lo), rb = row_of(pR, rr_hi);
+            for (int r = ra + wave; r <= rb; r += NW) {
+                const unsigned long long Rb = Rw[r];
+                const int rr = (int)pR[r] + __popcll(Rb & below);
+                if (((Rb >> lane) & 1ull) && rr >= rr_lo && rr <= rr_hi) posh[(totR - 1 - rr) - base] = (uint32_t)(f + 1 + 64 * r + lane);
+            }
+            __syncthreads();
+            const int la = row_of(pL, base), lb = row_of(pL, kend - 1);
+            for (int r = la + wave; r <= lb; r += NW) {
+                const unsigned long long Lb = Lw[r];
+                const int k = (int)pL[r] + __popcll(Lb & below);
+                if (((Lb >> lane) & 1ull) && k >= base && k < kend) {
+                    const int q = (int)posh[k - base], p = f + 1 + 64 * r + lane;
+                    const uint32_t x = arr[p], y = arr[q];
+                    arr[p] = y; arr[q] = x;
+                }
+            }
+            __syncthreads();
         }
     }
     __threadfence_block();
