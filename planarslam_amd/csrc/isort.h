@@ -695,7 +695,7 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
     const uint32_t xfront = (uint32_t)s_i[2];
     ISORT_MARK(10);
     // ---- pass 1: one read of the range; a row of 64 elements = one ballot per scan ----
-    constexpr int U = 4;
+    constexpr int U = 8;
     for (int rb = wave; rb < nrow; rb += NW * U) {
         uint32_t x[U];
 #pragma unroll
