@@ -320,8 +320,8 @@ struct LdsLayout {
     static constexpr int wl_bytes = W_LIST * (4 + 4 + 2 + 2 + 2);
     static constexpr int off_gl = off_wl + NW * wl_bytes;                           // the workgroup's lists, G_LIST entries, same layout
     static constexpr int gl_bytes = G_LIST * (4 + 4 + 2 + 2 + 2);
-    static constexpr int off_tk = off_gl + gl_bytes;                                // tasks: f, l u16 [TASKS]; d u8 [TASKS]
-    static constexpr int off_buf = (off_tk + TASKS * 5 + 3) / 4 * 4;                // int [10 * NW + 4]
+    static constexpr int off_tk = off_gl + gl_bytes;                                // tasks: f, l u16 [TASKS]; d u8 [TASKS]; order u8 [TASKS]
+    static constexpr int off_buf = (off_tk + TASKS * 6 + 3) / 4 * 4;                // int [10 * NW + 4]
     static constexpr int bytes = off_buf + (10 * NW + 4) * 4;
     static_assert(bytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 };
@@ -592,11 +592,21 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
         const Lists WL = carve_lists(lds + LL::off_wl + wave * LL::wl_bytes, W_LIST);
         const int ntasks = min(s_tn[0], TASKS);
         const Tasks none{nullptr, nullptr, nullptr, s_tn};
+        // longest task first: a block has a handful of tasks of very different lengths for its four wavefronts, and the block ends with the last of them
+        uint8_t* order = TK.d + TASKS;                           // (TASKS <= 256)
+        if (tid < ntasks) {
+            const int mine = TK.l[tid] - TK.f[tid];
+            int rank = 0;
+            for (int j = 0; j < ntasks; j++) { const int o = TK.l[j] - TK.f[j]; rank += (o > mine || (o == mine && j < tid)) ? 1 : 0; }
+            order[rank] = (uint8_t)tid;
+        }
+        __syncthreads();
         while (true) {
             int t = 0;
             if (lane == 0) t = atomicAdd(&s_tn[1], 1);
             t = __shfl(t, 0);
             if (t >= ntasks) break;
+            t = order[t];
             const int f = TK.f[t], l = TK.l[t];
             if (lane == 0) { WL.f[0] = (uint16_t)f; WL.l[0] = (uint16_t)l; WL.d[0] = TK.d[t]; }
             wv.sync();

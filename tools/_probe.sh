@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-./tools/micro/isort_gtime 195000 1024 0 | tail -1 | cut -c1-330
-./tools/micro/isort_gtime 120000 1024 1 | tail -1 | cut -c1-330
+for m in 0 1; do ./tools/micro/isort_time256 5888 300 8192 $m 1 | tail -2 | cut -c1-400; done
