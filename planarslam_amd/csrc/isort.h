@@ -324,6 +324,7 @@ struct LdsLayout {
     static constexpr int off_buf = (off_tk + TASKS * 6 + 3) / 4 * 4;                // int [10 * NW + 4]
     static constexpr int bytes = off_buf + (10 * NW + 4) * 4;
     static_assert(bytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
+    static_assert(bytes >= (N + W_CAP + 32) * 4, "a chunk's key loads may run W_CAP words past the block (sort_levels, B)");
 };
 __device__ __forceinline__ Lists carve_lists(uint8_t* p, int cap) {
     Lists L;
@@ -386,7 +387,7 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
         {
             uint32_t key[E];
 #pragma unroll
-            for (int j = 0; j < E; j++) key[j] = a[min(c0 + j, max(c_end - 1, 0))];
+            for (int j = 0; j < E; j++) key[j] = a[c0 + j];          // (past c_end: words of the block's LDS that no piece covers - LdsLayout keeps W_CAP words behind `a` readable)
 #pragma unroll
             for (int q = 0; q < 3; q++) { const int s = min(s0 + q, nseg - 1); pf[q] = sf[s]; pl_[q] = sl[s]; }
 #pragma unroll
