@@ -640,7 +640,7 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 const int jj = max(s[u], 0) + t;
-                const uint32_t kj = a[min(jj, n - 1)] >> SHIFT;
+                const uint32_t kj = a[jj] >> SHIFT;                  // (jj < e[u] <= n where it counts; behind the block: readable, see LdsLayout)
                 rank += (leaf && jj < e[u] && (kj < kv || (kj == kv && jj < i))) ? 1 : 0;
             }
             dest[u] = leaf ? s[u] + rank : i;
