@@ -199,30 +199,36 @@ __global__ __launch_bounds__(256) void orb_fast_cells(const PlanDev* __restrict_
     int* out_count = cell_count + (int64_t)frame * plan->ncells_total + blockIdx.x;
     if (ww <= 0 || wh <= 0) { if (tid == 0) *out_count = 0; return; }
     const int tw = ww + 6, th = wh + 6;            // pixel tile with 3-px halo
-    const int tstride = (tw + 3) & ~3;
+    // the tile is fetched as aligned 32-bit words (rows of the pyramid start on 16-byte boundaries): it begins `mis` bytes left of the window's halo
+    const int gx0 = C.x0 - 3, mis = gx0 & 3, nd = (mis + tw + 3) >> 2;
+    const int tstride = nd * 4;
     const int sw = ww + 2, sh = wh + 2;            // score tile with 1-px zero border
     uint8_t* tile = smem;
     uint8_t* score = smem + ((tstride * th + 15) & ~15);
     const uint8_t* img = pyr + (int64_t)frame * plan->pyr_stride + L.off;
-    for (int i = tid; i < tw * th; i += 256) {
-        const int y = i / tw, x = i - y * tw;
-        tile[y * tstride + x] = img[(int64_t)(C.y0 - 3 + y) * L.pitch + (C.x0 - 3 + x)];
+    {
+        const int q = tid & 15;                    // (nd <= 16: cells are at most 54 pixels wide, checked at plan creation)
+        if (q < nd)
+            for (int y = tid >> 4; y < th; y += 16)
+                *(uint32_t*)(tile + y * tstride + 4 * q) = *(const uint32_t*)(img + (int64_t)(C.y0 - 3 + y) * L.pitch + (gx0 - mis) + 4 * q);
     }
     for (int i = tid; i < sw * sh; i += 256) score[i] = 0;
     if (tid == 0) s_any_ini = 0;
     __syncthreads();
     const int min_th = plan->min_th, ini_th = plan->ini_th;
     const int npx = ww * wh;
+    const float inv_ww = 1.0f / (float)ww;
+    auto row_of = [&](int p_) { return (int)(((float)p_ + 0.5f) * inv_ww); };      // p / ww for p < 2^12, ww <= 64: the product is off by < 2^-11, the nearest integers are 0.5 / ww away
     for (int p = tid; p < npx; p += 256) {
-        const int y = p / ww, x = p - y * ww;
-        const int s = fast_score_lds(tile + (y + 3) * tstride + (x + 3), tstride, min_th);
+        const int y = row_of(p), x = p - y * ww;
+        const int s = fast_score_lds(tile + (y + 3) * tstride + (x + 3 + mis), tstride, min_th);
         score[(y + 1) * sw + (x + 1)] = (uint8_t)s;   // 0 or [min_th, 254]
     }
     __syncthreads();
     // pass A: does any NMS survivor reach iniTh?
     int any = 0;
     for (int p = tid; p < npx; p += 256) {
-        const int y = p / ww, x = p - y * ww;
+        const int y = row_of(p), x = p - y * ww;
         const uint8_t* sc = score + (y + 1) * sw + (x + 1);
         const int s = sc[0];
         if (s >= ini_th && s > sc[-1] && s > sc[1] && s > sc[-sw - 1] && s > sc[-sw] && s > sc[-sw + 1] &&
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void orb_fast_cells(const PlanDev* __restrict_
         bool keep = false;
         int x = 0, y = 0, s = 0;
         if (p < npx) {
-            y = p / ww; x = p - y * ww;
+            y = row_of(p); x = p - y * ww;
             const uint8_t* sc = score + (y + 1) * sw + (x + 1);
             s = sc[0];
             keep = s >= th_cell && s > sc[-1] && s > sc[1] && s > sc[-sw - 1] && s > sc[-sw] && s > sc[-sw + 1] &&
@@ -909,7 +915,8 @@ int planar_orb_create(planar_ctx* ctx, const planar_orb_params* p, int W, int H,
                 C.slot_cap = ((C.ww + 1) / 2) * ((C.wh + 1) / 2);   // strict 8-neighbour maxima bound
                 cand_off += C.slot_cap;
                 o->cells.push_back(C);
-                const int tstride = (C.ww + 6 + 3) & ~3;
+                const int tstride = ((((int)C.x0 - 3) & 3) + C.ww + 6 + 3) & ~3;            // orb_fast_cells' tile: aligned 32-bit words per row, <= 16 of them
+                if (tstride > 64 || C.ww * C.wh >= 4096) { delete o; set_error("planar_orb_create: FAST cell of %d x %d pixels at level %d is larger than the kernel's tile", (int)C.ww, (int)C.wh, l); return PLANAR_EINVAL; }
                 const int bytes = ((tstride * (C.wh + 6) + 15) & ~15) + (C.ww + 2) * (C.wh + 2);
                 max_tile_bytes = std::max(max_tile_bytes, bytes);
             }
