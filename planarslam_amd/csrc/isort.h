@@ -356,7 +356,7 @@ __device__ __forceinline__ void move_median(uint32_t* a, int f, int l) {
 // a chunk can touch are read together, swaps go four at a time, the pivots of the next level are placed by the thread that lists the segment.
 template <int SHIFT, int E, class S>
 __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* posh, uint32_t* mb, uint32_t* kb, const Lists& L, int nseg, int c_base, int c_end,
-                                            int keep_above, const Tasks& TK, const HeapSink& HS, int span_f, int* status) {
+                                            int keep_above, const Tasks& TK, const HeapSink& HS, int span_f, int* status, uint32_t skip_key) {
 #ifdef ISORT_TIMING
     long long _tm = __builtin_readcyclecounter();
 #endif
@@ -500,9 +500,11 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
                 if (s < nseg) {
                     const int f = sf[s], l = sl[s], cut = scut[s], d = sd[s] - 1;      // (listed segments have a budget of at least one)
                     atomicOr(&mb[cut >> 5], 1u << (cut & 31)); atomicOr(&kb[cut >> 5], 1u << (cut & 31));
+                    const bool drop_right = (a[f] >> SHIFT) > skip_key;            // everything from the cut on is >= the pivot (it sits at f): nothing the caller wants is in there
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const int xf = h ? cut : f, xl = h ? l : cut;
+                        if (h == 1 && drop_right) continue;
                         if (xl - xf > 16 && d == 0) push_heap_job(HS, span_f + xf, span_f + xl, status);   // budget used up: the heap-sort fallback, later (a leaf of more than 16: the write-back leaves it alone)
                         else if (xl - xf > keep_above) {
 #pragma unroll
@@ -537,7 +539,8 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
 // Sorts arr[span_f, span_l) (<= T * E elements), which consists of the nr <= T ranges `ranges` (sorted by f, disjoint; anything between them is left
 // alone), as std::sort would have finished each of them.  All T threads of the workgroup call it.
 template <int SHIFT, int T, int E>
-__device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ ranges, int nr, int span_f, int span_l, uint8_t* lds, const HeapSink& HS, int* status) {
+__device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ ranges, int nr, int span_f, int span_l, uint8_t* lds, const HeapSink& HS, int* status,
+                         uint32_t skip_key = 0xffffffffu) {
     using LL = LdsLayout<T, E>;
     uint32_t* a = (uint32_t*)(lds + LL::off_a);
     uint16_t* posh = (uint16_t*)(lds + LL::off_posh);
@@ -583,7 +586,7 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
         __syncthreads();
     }
     ISORT_MARK(0);
-    sort_levels<SHIFT, E, WgScope<T>>(wg, a, posh, mb, kb, GL, nseg, 0, n, W_CAP, TK, HS, span_f, status);
+    sort_levels<SHIFT, E, WgScope<T>>(wg, a, posh, mb, kb, GL, nseg, 0, n, W_CAP, TK, HS, span_f, status, skip_key);
     __syncthreads();
 #ifdef ISORT_TIMING
     _tm = __builtin_readcyclecounter();
@@ -611,7 +614,7 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
             const int f = TK.f[t], l = TK.l[t];
             if (lane == 0) { WL.f[0] = (uint16_t)f; WL.l[0] = (uint16_t)l; WL.d[0] = TK.d[t]; }
             wv.sync();
-            sort_levels<SHIFT, W_E, WaveScope>(wv, a, posh, mb, kb, WL, 1, f, l, 16, none, HS, span_f, status);
+            sort_levels<SHIFT, W_E, WaveScope>(wv, a, posh, mb, kb, WL, 1, f, l, 16, none, HS, span_f, status, skip_key);
         }
     }
     __syncthreads();
@@ -803,9 +806,13 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
 // The workgroup partitions every range of `init` (n_init <= G_FMAX, disjoint) that is longer than n_stage until none is left, then writes the
 // resulting ranges sorted by position to out_ranges and packs consecutive ones into LDS-tier blocks (span <= n_stage, <= nr_cap ranges).
 // out_counts: [0] ranges, [1] blocks.
+// skip_key: the caller only needs the elements whose key is <= skip_key where std::sort would put them (LSD: the pixels with a defined angle).  A partition's right part
+// holds nothing below its pivot, so when the pivot's key is above skip_key that part is left as it is - never queued, never handed to the LDS tier, no fallback job.
+// What is left unsorted are whole index ranges of unwanted elements: every wanted element still ends exactly where std::sort puts it.
 template <int SHIFT, int T>
 __device__ void global_tier(uint32_t* __restrict__ arr, const Range* __restrict__ init, int n_init, int n_stage, int nr_cap, Range* __restrict__ out_ranges,
-                            Block* __restrict__ out_blocks, int max_blocks, int* __restrict__ out_counts, uint8_t* lds, int rows_cap, const HeapSink& HS, int* status) {
+                            Block* __restrict__ out_blocks, int max_blocks, int* __restrict__ out_counts, uint8_t* lds, int rows_cap, const HeapSink& HS, int* status,
+                            uint32_t skip_key = 0xffffffffu) {
     using GL = GlobalLayout<T>;
     Range* qb = (Range*)(lds + GL::off_q(rows_cap));
     Range* fin = (Range*)(lds + GL::off_fin(rows_cap));
@@ -831,8 +838,10 @@ __device__ void global_tier(uint32_t* __restrict__ arr, const Range* __restrict_
             const Range R = qb[cur * G_QMAX + r];
             const int cut = wg_partition<SHIFT, T>(arr, R.f, R.l, lds, rows_cap, status);
             if (tid == 0) {
+                const bool drop_right = (uint32_t)((const int*)(lds + GL::off_buf(rows_cap)))[2 * GL::NW] > skip_key;   // the pivot's key (wg_partition's s_i[0])
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
+                    if (h == 1 && drop_right) continue;
                     const Range C{h ? cut : R.f, h ? R.l : cut, R.d - 1};       // (queued ranges have a budget of at least one)
                     if (C.l - C.f > n_stage && C.d > 0) { if (s_c[1] < G_QMAX) qb[(cur ^ 1) * G_QMAX + s_c[1]++] = C; else *status = ST_CAPACITY; }
                     else if (C.l - C.f > n_stage) push_heap_job(HS, C.f, C.l, status);   // budget used up on a range too long for an LDS block: the fallback, later

@@ -54,7 +54,7 @@ struct Plan {
     double gaussCoefL[21], gaussCoefG[63];
 };
 
-struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int sort_counts[2]; int heap_n; int pad_; };   // sort_counts: ranges, LDS-tier blocks; heap_n: ranges left to the heap-sort fallback
+struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int sort_counts[2]; int heap_n; int sort_kv; int sort_prefix; int pad_; };   // sort_counts: ranges, LDS-tier blocks; heap_n: ranges left to the heap-sort fallback; sort_kv: the largest sort key of a pixel with a defined angle, sort_prefix: words with a key <= that
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2: 7th-order odd polynomial, degrees; plain mul/add (no FMA), see oracle/cvprim.cpp
@@ -209,6 +209,10 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict
     const double max_grad = misc->g2max ? sqrt(misc->g2max / 4.0) : -1.0;
     const double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
     const long long ts0 = __builtin_readcyclecounter();
+    __shared__ unsigned int s_kv, s_prefix;
+    if (tid == 0) { s_kv = 0u; s_prefix = 0u; }
+    __syncthreads();
+    uint32_t kv = 0;                                        // the largest key of a pixel with a defined angle (they are the only ones lsd_sort_compact keeps)
     for (int p0 = tid - lane; p0 < npix; p0 += SORT_T) {
         const int pix = p0 + lane, y = pix / P.w, x = pix - y * P.w;
         const bool in = pix < npix && x < w1 && y < h1;
@@ -217,16 +221,31 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict
             const int bin = int(sqrt(g2a[pix] / 4.0) * bin_coef);
             arr[pix - y] = ((uint32_t)(N_BINS - 1 - bin) << SORT_SHIFT) | (uint32_t)pix;
             valid = ang[pix] != NOTDEF_F;
+            if (valid) kv = max(kv, (uint32_t)(N_BINS - 1 - bin));
         }
         const unsigned long long m = __ballot(valid);
         if (lane == 0) vb[p0 >> 6] = m;
     }
+    kv = (uint32_t)planar::wave_max_f64((double)kv);        // (exact: a 10-bit integer)
+    if (lane == 0) atomicMax(&s_kv, kv);
+    __syncthreads();
+    kv = s_kv;
+    // The pixels without an angle took part in OpenCV's std::sort, but nothing reads where they end up; they are 85-90 % of the words and have the largest keys.  Ranges
+    // that provably hold only keys above kv are left unsorted (isort.h: skip_key) - the wanted words still land exactly where std::sort puts them: the first `prefix` places.
+    int cnt = 0;
+    for (int p0 = tid - lane; p0 < npix; p0 += SORT_T) {
+        const int pix = p0 + lane, y = pix / P.w, x = pix - y * P.w;
+        if (pix < npix && x < w1 && y < h1) cnt += ((arr[pix - y] >> SORT_SHIFT) <= kv) ? 1 : 0;
+    }
+    cnt = planar::wave_sum_i32(cnt);
+    if (lane == 0) atomicAdd(&s_prefix, (unsigned int)cnt);
     if (tid == 0) s_init = isort::Range{0, n, isort::depth_limit(n)};
     __threadfence_block();
     __syncthreads();
+    if (tid == 0) { misc->sort_kv = (int)kv; misc->sort_prefix = (int)s_prefix; }
     const isort::HeapSink HS{(isort::HeapJob*)(F + P.off_heapj), &misc->heap_n, SORT_HJOBS};
     isort::global_tier<SORT_SHIFT, SORT_T>(arr, &s_init, 1, SortLds::N, 64, (isort::Range*)(F + P.off_sortr), (isort::Block*)(F + P.off_sortb), isort::G_FMAX,
-                                           misc->sort_counts, sort_lds, rows_cap, HS, &misc->status);
+                                           misc->sort_counts, sort_lds, rows_cap, HS, &misc->status, kv);
     if (tid == 0) misc->t[5] = __builtin_readcyclecounter() - ts0;
 }
 
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(SORT_LT, 4) void lsd_sort_lds(const Plan* __restric
     const long long ts0 = __builtin_readcyclecounter();
     for (int k = blockIdx.y; k < nb; k += gridDim.y) {
         const isort::Block K = blocks[k];
-        isort::lds_tier<SORT_SHIFT, SORT_LT, SORT_E>((uint32_t*)(F + P.off_tmp), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &misc->status);
+        isort::lds_tier<SORT_SHIFT, SORT_LT, SORT_E>((uint32_t*)(F + P.off_tmp), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &misc->status, (uint32_t)misc->sort_kv);
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) misc->t[6] = __builtin_readcyclecounter() - ts0;
 }
@@ -269,7 +288,7 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_compact(const Plan* __restric
     uint32_t* ordr = (uint32_t*)(F + P.off_ordr);
     float* pixw = (float*)(F + P.off_pix);
     Misc* misc = miscs + b;
-    const int n = (P.w - 1) * (P.h - 1);
+    const int n = min((P.w - 1) * (P.h - 1), misc->sort_prefix);      // the words with a key <= the largest defined pixel's: the sorted front of the array (lsd_sort_global)
     const long long ts0 = __builtin_readcyclecounter();
     constexpr int NW = SORT_T / 64, U = 4;
     const int seg = ((n + NW - 1) / NW + 63) & ~63, w0 = min(n, wave * seg), w1 = min(n, w0 + seg);

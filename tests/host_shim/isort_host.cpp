@@ -12,14 +12,14 @@
 using namespace planar::isort;
 
 namespace {
-struct GArgs { uint32_t* arr; const Range* init; int n_init, n_stage, nr_cap; Range* ranges; Block* blocks; int max_blocks; int* counts; int rows_cap; int* status; int shift; HeapSink HS; };
+struct GArgs { uint32_t* arr; const Range* init; int n_init, n_stage, nr_cap; Range* ranges; Block* blocks; int max_blocks; int* counts; int rows_cap; int* status; int shift; HeapSink HS; uint32_t skip_key; };
 template <int SHIFT, int T>
 void g_entry(void* p) {
     auto* A = (GArgs*)p;
     PLANAR_DYN_SMEM(lds);
-    global_tier<SHIFT, T>(A->arr, A->init, A->n_init, A->n_stage, A->nr_cap, A->ranges, A->blocks, A->max_blocks, A->counts, lds, A->rows_cap, A->HS, A->status);
+    global_tier<SHIFT, T>(A->arr, A->init, A->n_init, A->n_stage, A->nr_cap, A->ranges, A->blocks, A->max_blocks, A->counts, lds, A->rows_cap, A->HS, A->status, A->skip_key);
 }
-struct LArgs { uint32_t* arr; const Range* ranges; int nr, f, l; int* status; HeapSink HS; };
+struct LArgs { uint32_t* arr; const Range* ranges; int nr, f, l; int* status; HeapSink HS; uint32_t skip_key; };
 struct HArgs { uint32_t* arr; const HeapJob* jobs; int njobs, cap; };
 template <int SHIFT>
 void h_entry(void* p) {
@@ -31,10 +31,10 @@ template <int SHIFT, int T, int E>
 void l_entry(void* p) {
     auto* A = (LArgs*)p;
     PLANAR_DYN_SMEM(lds);
-    lds_tier<SHIFT, T, E>(A->arr, A->ranges, A->nr, A->f, A->l, lds, A->HS, A->status);
+    lds_tier<SHIFT, T, E>(A->arr, A->ranges, A->nr, A->f, A->l, lds, A->HS, A->status, A->skip_key);
 }
 template <int SHIFT, int TG, int T, int E>
-int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status, long* stats, int heap_cap = 36864) {
+int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status, long* stats, int heap_cap = 36864, uint32_t skip_key = 0xffffffffu) {
     std::vector<Range> init(n_ranges);
     int longest = 0;
     for (int i = 0; i < n_ranges; i++) {
@@ -51,13 +51,13 @@ int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status
     std::vector<HeapJob> jobs(4096);
     int njobs = 0;
     const HeapSink HS{jobs.data(), &njobs, (int)jobs.size()};
-    GArgs ga{arr, init.data(), n_ranges, n_stage, std::min(T, 64), ranges.data(), blocks.data(), G_FMAX, counts, rows_cap, status, SHIFT, HS};
+    GArgs ga{arr, init.data(), n_ranges, n_stage, std::min(T, 64), ranges.data(), blocks.data(), G_FMAX, counts, rows_cap, status, SHIFT, HS, skip_key};
     wave_emul::Dim3 bi, bd; bd.x = TG; bd.y = 1; bd.z = 1;
     wave_emul::launch_block(g_entry<SHIFT, TG>, &ga, TG, bi, bd, (size_t)GlobalLayout<TG>::bytes(rows_cap), 256 * 1024);
     if (stats) { stats[0] = counts[0]; stats[1] = counts[1]; stats[2] = wave_emul::S().n_sync; }
     bd.x = T;
     for (int b = 0; b < counts[1]; b++) {
-        LArgs la{arr, ranges.data() + blocks[b].r0, blocks[b].nr, blocks[b].f, blocks[b].l, status, HS};
+        LArgs la{arr, ranges.data() + blocks[b].r0, blocks[b].nr, blocks[b].f, blocks[b].l, status, HS, skip_key};
         wave_emul::launch_block(l_entry<SHIFT, T, E>, &la, T, bi, bd, (size_t)LdsLayout<T, E>::bytes, 256 * 1024);
     }
     long heap_elems = 0;
@@ -87,6 +87,16 @@ int isort_emul(uint32_t* arr, const int* bounds, int n_ranges, int shift, int co
         if (shift == 19 && config == 2) return run<19, 256, 128, 32>(arr, bounds, n_ranges, n_stage, status, stats);
         if (shift == 19 && config == 3) return run<19, 1024, 1024, 23>(arr, bounds, n_ranges, n_stage, status, stats, 1000);   // fallback jobs with only 1000 words in LDS
         throw std::runtime_error("isort_emul: unknown configuration");
+    } catch (const std::exception& e) { snprintf(err, errlen, "%s", e.what()); return -1; }
+}
+
+// the same with a skip key (isort.h, global_tier): only the elements whose key is <= skip_key have to end where std::sort puts them.  config 0 or 1 as above.
+int isort_emul_skip(uint32_t* arr, const int* bounds, int n_ranges, int shift, int config, unsigned skip_key, int* status, long* stats, char* err, int errlen) {
+    try {
+        *status = 0;
+        if (shift == 20 && config == 0) return run<20, 1024, 256, 23>(arr, bounds, n_ranges, 0, status, stats, 36864, skip_key);
+        if (shift == 20 && config == 1) return run<20, 256, 256, 5>(arr, bounds, n_ranges, 0, status, stats, 36864, skip_key);
+        throw std::runtime_error("isort_emul_skip: unknown configuration");
     } catch (const std::exception& e) { snprintf(err, errlen, "%s", e.what()); return -1; }
 }
 

@@ -24,6 +24,7 @@ def lib():
     vp = C.c_void_p
     E.isort_emul.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_char_p, C.c_int]
     E.isort_std_sort.argtypes = [vp, vp, C.c_int, C.c_int]
+    E.isort_emul_skip.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_uint, vp, vp, C.c_char_p, C.c_int]
     return E
 
 
@@ -127,3 +128,33 @@ def test_heap_sort_fallback_on_real_plane_keys(lib):
     bounds = np.concatenate([[0], np.cumsum([len(k) for k in ks])])
     off = np.concatenate([[0], np.cumsum([k.max() + 1 for k in ks])])[:-1]
     _check(lib, np.concatenate([k + o for k, o in zip(ks, off)]), bounds, 19, 0)
+
+
+@pytest.mark.parametrize("config", [0, 1])
+def test_skip_key_leaves_every_wanted_element_where_std_sort_puts_it(lib, config):
+    """LSD's use of the engine: 88 % of a frame's gradient pixels have no defined angle (the lowest bins = the highest keys) and are dropped after the sort.  With a skip key
+    the right part of a partition whose pivot is above it is never sorted; every element at or below the key still has to be exactly where std::sort leaves it, the
+    rest only has to be the same multiset in the same index ranges."""
+    rng = np.random.default_rng(21 + config)
+    n = 511 * 383 if config == 0 else 9000
+    bins = np.where(rng.random(n) < 0.88, rng.integers(0, 6, n), np.minimum(1023, (-60.0 * np.log(rng.random(n))).astype(np.int64) + 6))
+    keys = (1023 - bins).astype(np.uint32)
+    skip = int(1023 - 6)                                                  # wanted: bins >= 6
+    shift = 20
+    arr = ((keys << np.uint32(shift)) | np.arange(n, dtype=np.uint32)).astype(np.uint32)
+    want = arr.copy()
+    b = np.asarray([0, n], np.int32)
+    lib.isort_std_sort(want.ctypes.data, b.ctypes.data, 1, shift)
+    status = C.c_int(-1); stats = np.zeros(8, np.int64); err = C.create_string_buffer(512)
+    rc = lib.isort_emul_skip(arr.ctypes.data, b.ctypes.data, 1, shift, config, skip, C.byref(status), stats.ctypes.data, err, 512)
+    assert rc == 0 and status.value == 0, (err.value.decode(), status.value)
+    wanted = (want >> np.uint32(shift)) <= skip
+    n_w = int(wanted.sum())
+    assert 0.08 * n < n_w < 0.2 * n and wanted[:n_w].all()               # they are the front of the sorted array
+    assert np.array_equal(arr[:n_w], want[:n_w])
+    assert np.array_equal(np.sort(arr[n_w:]), np.sort(want[n_w:]))       # the rest: the same elements, in some order
+    full = np.zeros(8, np.int64)
+    arr2 = ((keys << np.uint32(shift)) | np.arange(n, dtype=np.uint32)).astype(np.uint32)
+    lib.isort_emul_skip(arr2.ctypes.data, b.ctypes.data, 1, shift, config, 0xFFFFFFFF, C.byref(status), full.ctypes.data, err, 512)
+    assert np.array_equal(arr2, want)
+    assert stats[1] < 0.5 * full[1]                                        # and most LDS-tier blocks never exist
