@@ -200,7 +200,6 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict
     const Plan& P = *plan;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
-    const float* ang = (const float*)(F + P.off_ang);
     const uint32_t* g2a = (const uint32_t*)(F + P.off_g2);
     uint32_t* arr = (uint32_t*)(F + P.off_tmp);
     unsigned long long* vb = (unsigned long long*)(F + P.off_valid);
@@ -218,9 +217,10 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict
         const bool in = pix < npix && x < w1 && y < h1;
         bool valid = false;
         if (in) {
-            const int bin = int(sqrt(g2a[pix] / 4.0) * bin_coef);
+            const double norm = sqrt(g2a[pix] / 4.0);
+            const int bin = int(norm * bin_coef);
             arr[pix - y] = ((uint32_t)(N_BINS - 1 - bin) << SORT_SHIFT) | (uint32_t)pix;
-            valid = ang[pix] != NOTDEF_F;
+            valid = !(norm <= P.rho);                        // = (ang[pix] != NOTDEF): lsd_grad's own test on the same integer, without reading the angle image
             if (valid) kv = max(kv, (uint32_t)(N_BINS - 1 - bin));
         }
         const unsigned long long m = __ballot(valid);
