@@ -407,6 +407,11 @@ void planar_lsd_destroy(planar_lsd* lsd);
 int planar_lsd_max_segments(void);   /* raw LSD segments kept per frame before the top-`max_lines` cut (2048) */
 int planar_lsd_scaled_size(planar_lsd* lsd, int* w, int* h);   /* the 0.8x working resolution */
 int planar_lsd_set_tie_order(planar_lsd* lsd, int tie_order);   /* 0 (default): libstdc++ std::sort order, 1: raster order */
+/* 1: the NFA stage (rect_improve) only for the regions that can end among the max_lines key lines LineSegment::ExtractLineSegment keeps (reference src/LSDextractor.cpp:17-27:
+ * sort by response, resize to 40): the longest regions first, the rest only where that cannot settle the frame (fewer than max_lines + 1 accepted, a shorter region could still
+ * reach the kept ones, or equal responses among them).  Key lines, descriptors and equations are those of the default mode, bit for bit; what planar_lsd_read_stage(.., 3, ..) returns
+ * (the raw segments) is then only the part that was evaluated.  0 (default): every region. */
+int planar_lsd_set_top_only(planar_lsd* lsd, int enable);
 /* gray     : B frames of 8-bit gray (the `img` argument), pitch / frame_stride in bytes
  * max_lines: lsdNFeatures (40 in the reference); per-frame stride of the outputs
  * keylines : [B][max_lines] cv::line_descriptor::KeyLine records   ldesc: [B][max_lines][32] LBD bytes

@@ -150,6 +150,7 @@ _SIGS = {
     "planar_lsd_destroy": (None, [C.c_void_p]),
     "planar_lsd_max_segments": (C.c_int, []),
     "planar_lsd_set_tie_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "planar_lsd_set_top_only": (C.c_int, [C.c_void_p, C.c_int]),
     "planar_undistort_keypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p]),
     "planar_undistort_keypoints_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p]),
     "planar_plane_clouds_sort_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

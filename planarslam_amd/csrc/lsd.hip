@@ -47,14 +47,14 @@ struct Plan {
     double rho, prec, p, log_nt, density_th, log_eps;
     int min_reg_size;
     // per-frame workspace offsets (bytes)
-    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_pix, off_seed, off_ord, off_ordr, off_gused, off_tmp, off_reg, off_valid, off_sortr, off_sortb, off_heapj, off_segs, off_kl, off_rects, off_res, frame_bytes;
+    size_t off_blur7, off_blur5, off_dx, off_dy, off_ang, off_g2, off_pix, off_seed, off_ord, off_ordr, off_gused, off_tmp, off_reg, off_valid, off_sortr, off_sortb, off_heapj, off_segs, off_kl, off_rects, off_res, off_est, frame_bytes;
     // host-evaluated tables (glibc, as the reference library would): log_gamma(x) for integer x, and per halving j of p
     const double* lgamma_tab;   // [w*h + 3]
     double p_log[12], p1_log[12], p_log10[12];
     double gaussCoefL[21], gaussCoefG[63];
 };
 
-struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int sort_counts[2]; int heap_n; int sort_kv; int sort_prefix; int pad_; };   // sort_counts: ranges, LDS-tier blocks; heap_n: ranges left to the heap-sort fallback; sort_kv: the largest sort key of a pixel with a defined angle, sort_prefix: words with a key <= that
+struct Misc { uint32_t g2max; int n_ord; int n_seg; int n_kl; int status; int n_regions; int n_grown_px; int n_rect; long long t[8]; int sort_counts[2]; int heap_n; int sort_kv; int sort_prefix; int pad_; float imp_T; int imp_done; int imp_redo; int imp_full; };   // sort_counts: ranges, LDS-tier blocks; heap_n: ranges left to the heap-sort fallback; sort_kv: the largest sort key of a pixel with a defined angle, sort_prefix: words with a key <= that
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2: 7th-order odd polynomial, degrees; plain mul/add (no FMA), see oracle/cvprim.cpp
@@ -994,7 +994,9 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
 
 // ---- K4b: NFA stage of every region that survived refine(): one wavefront (= one workgroup) per region, all regions of all frames in
 // parallel; 128 wavefronts per frame share the frame's regions round-robin
-__global__ __launch_bounds__(64) void lsd_improve(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, const Misc* __restrict__ miscs) {
+// phase < 0: every region.  The top-lines mode (planar_lsd_set_top_only; lsd_improve_plan below): phase 0 = the regions at least imp_T long, 1 = the others if the
+// check after phase 0 could not settle the frame, 2 = the others if the settled frame's kept lines turned out to hold equal responses.
+__global__ __launch_bounds__(64) void lsd_improve(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, const Misc* __restrict__ miscs, int phase) {
     const Plan& P = *plan;
     const int b = blockIdx.y, lane = threadIdx.x;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
@@ -1002,8 +1004,15 @@ __global__ __launch_bounds__(64) void lsd_improve(const Plan* __restrict__ plan,
     D.ang = (const float*)(F + P.off_ang); D.plan = plan; D.w = P.w; D.h = P.h; D.log_nt = P.log_nt; D.lane = lane;
     const Rect* rects = (const Rect*)(F + P.off_rects);
     Seg* res = (Seg*)(F + P.off_res);
-    const int n = miscs[b].n_rect;
+    const float* est = (const float*)(F + P.off_est);
+    const Misc& M = miscs[b];
+    const int n = M.n_rect;
+    if (phase == 1 && (M.imp_done || M.imp_full)) return;
+    if (phase == 2 && !(M.imp_done && M.imp_redo && !M.imp_full)) return;
+    const float T = phase >= 0 ? M.imp_T : 0.f;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        if (phase == 0 && !(est[i] >= T)) continue;
+        if (phase > 0 && est[i] >= T) continue;
         Rect rec = rects[i];
         const double log_nfa = rect_improve(D, rec, P.log_eps);
         rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
@@ -1012,10 +1021,96 @@ __global__ __launch_bounds__(64) void lsd_improve(const Plan* __restrict__ plan,
     }
 }
 
-// ---- K4c: the accepted segments (NFA above the threshold), in region order -----------------------------------------------------------
-__global__ __launch_bounds__(64) void lsd_accept(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+// ---- top-lines mode.  LineSegment::ExtractLineSegment keeps the max_lines (40) key lines of largest response (src/LSDextractor.cpp:17-27), and a region's length is fixed before
+// rect_improve (its trials move both end points by the same vector).  So: the NFA stage for the IMP_K longest regions first; if more than max_lines of them are accepted and the
+// max_lines-th largest response is above anything a shorter region could reach, the kept lines and their order are the full run's - std::sort leaves distinct responses in one
+// order whatever else is in the array.  Equal floats among the first max_lines + 1 responses make that order depend on the whole array: then (and when too few are accepted) every
+// region goes through the NFA stage after all.  lsd_improve_plan: lengths, the IMP_K-th largest as imp_T, every result preset to "rejected".
+constexpr int IMP_K = 96;
+__device__ inline planar_keyline make_keyline(const Seg& sg, int cols, int rows, int class_id);
+__global__ __launch_bounds__(256) void lsd_improve_plan(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    __shared__ int s_cnt[4];
+    const Plan& P = *plan;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    const Rect* rects = (const Rect*)(F + P.off_rects);
+    Seg* res = (Seg*)(F + P.off_res);
+    float* est = (float*)(F + P.off_est);
+    Misc* misc = miscs + b;
+    const int n = misc->n_rect;
+    for (int i = tid; i < n; i += 256) {
+        const Rect r = rects[i];
+        est[i] = (float)sqrt(dist2(r.x1, r.y1, r.x2, r.y2));
+        res[i] = Seg{0.f, 0.f, 0.f, 0.f, 0.0, 0.0, -1.7976931348623157e308};
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t tbits = 0;                                     // imp_T = 0: all regions
+    if (n > IMP_K && n <= MAX_SEGS) {                       // (more regions than segment slots: all of them, so that an overflow is seen as in the default mode)  the largest t with at least IMP_K lengths >= t (positive floats order as their bit patterns)
+        uint32_t lo = 0u, hi = 0x7f800000u;                 // count(lo) >= K, count(hi) < K
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            int c = 0;
+            for (int i = tid; i < n; i += 256) c += (__float_as_uint(est[i]) >= mid) ? 1 : 0;
+            c = planar::wave_sum_i32(c);
+            __syncthreads();
+            if (lane == 0) s_cnt[wave] = c;
+            __syncthreads();
+            const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            if (tot >= IMP_K) lo = mid; else hi = mid;
+        }
+        tbits = lo;
+    }
+    if (tid == 0) { misc->imp_T = __uint_as_float(tbits); misc->imp_done = 0; misc->imp_redo = 0; misc->imp_full = tbits == 0u ? 1 : 0; }
+}
+// after phase 0: is the frame settled?  One wavefront per frame.
+__global__ __launch_bounds__(64) void lsd_improve_check(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int max_lines) {
+    constexpr int CAP = 1024;
+    __shared__ float s_resp[CAP];
     const Plan& P = *plan;
     const int b = blockIdx.x, lane = threadIdx.x;
+    uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    const Seg* res = (const Seg*)(F + P.off_res);
+    const float* est = (const float*)(F + P.off_est);
+    Misc* misc = miscs + b;
+    if (misc->imp_full) return;
+    const int n = misc->n_rect;
+    const float T = misc->imp_T;
+    int na = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        bool ok = false;
+        float r = 0.f;
+        if (i < n && est[i] >= T) { const Seg sg = res[i]; ok = sg.nfa > P.log_eps; if (ok) r = make_keyline(sg, P.W, P.H, 0).response; }
+        const unsigned long long m = __ballot(ok);
+        const int pos = na + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && pos < CAP) s_resp[pos] = r;
+        na += __popcll(m);
+    }
+    __syncthreads();
+    int done = 0;
+    if (na > max_lines && na <= CAP) {
+        uint32_t lo = 0u, hi = 0x7f800000u;                 // the max_lines-th largest response: the largest t with at least max_lines responses >= t
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            int c = 0;
+            for (int i = lane; i < na; i += 64) c += (__float_as_uint(s_resp[i]) >= mid) ? 1 : 0;
+            c = planar::wave_sum_i32(c);
+            if (c >= max_lines) lo = mid; else hi = mid;
+        }
+        // what a region shorter than imp_T could reach: its end points move by the same vector in rect_improve, are divided by 0.8, rounded to floats (1e-4 px) and clipped
+        // to the image (which only shortens): (T / 0.8 + 1e-3) / max(W, H) bounds its response from above
+        const double bound = ((double)T / 0.8 + 1e-3) / (double)max(P.W, P.H);
+        done = (double)__uint_as_float(lo) > bound ? 1 : 0;
+    }
+    if (lane == 0) misc->imp_done = done;
+}
+
+// ---- K4c: the accepted segments (NFA above the threshold), in region order -----------------------------------------------------------
+__global__ __launch_bounds__(64) void lsd_accept(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int phase) {
+    const Plan& P = *plan;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (phase == 1 && !(miscs[b].imp_done && miscs[b].imp_redo && !miscs[b].imp_full)) return;     // (top-lines mode: only the frames that are being redone)
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
     const Seg* res = (const Seg*)(F + P.off_res);
     Seg* segs = (Seg*)(F + P.off_segs);
@@ -1188,7 +1283,7 @@ __device__ inline planar_keyline make_keyline(const Seg& sg, int cols, int rows,
 }
 
 __global__ __launch_bounds__(64) void lsd_keylines(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int max_lines,
-                                                   planar_keyline* __restrict__ out_kl, double* __restrict__ out_eq, int32_t* __restrict__ n_out) {
+                                                   planar_keyline* __restrict__ out_kl, double* __restrict__ out_eq, int32_t* __restrict__ n_out, int phase) {
     // 8 KB of LDS so that this kernel can start while peac_segment still holds most of every CU's LDS; frames with more raw
     // segments than that sort in global scratch
     constexpr int LDS_SORT = 1024;
@@ -1198,6 +1293,8 @@ __global__ __launch_bounds__(64) void lsd_keylines(const Plan* __restrict__ plan
     const int b = blockIdx.x, lane = threadIdx.x;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
     Misc* misc = miscs + b;
+    if (phase == 1 && !(misc->imp_done && misc->imp_redo && !misc->imp_full)) return;             // (top-lines mode: only the frames that are being redone)
+    const bool partial = (phase == 0 || phase == 3) && misc->imp_done && !misc->imp_full;          // only the longest regions went through the NFA stage (3: the test mode that redoes every such frame)
     const Seg* segs = (const Seg*)(F + P.off_segs);
     const int n = min(misc->n_seg, MAX_SEGS);
     const int nk = min(n, max_lines);
@@ -1211,6 +1308,11 @@ __global__ __launch_bounds__(64) void lsd_keylines(const Plan* __restrict__ plan
             if (lane == 0) { SortBuf s{key, idx}; std_sort_desc(s, n); }
             __threadfence_block();
             __syncthreads();
+            if (partial) {                       // equal responses among the kept lines (or at their border): std::sort's arrangement of them depends on the segments that were left out
+                bool tie = false;
+                for (int i = lane; i < min(n - 1, max_lines); i += 64) tie = tie || key[i] == key[i + 1];
+                if ((__ballot(tie) != 0ull || phase == 3) && lane == 0) misc->imp_redo = 1;
+            }
         }
         for (int i = lane; i < nk; i += 64) {
             const planar_keyline kl = make_keyline(segs[idx[i]], P.W, P.H, n > max_lines ? i : idx[i]);
@@ -1353,6 +1455,7 @@ struct planar_lsd {
     int stage_lines = 0;
     int pre_B = 0;
     int tie_order = 0;   // 0: libstdc++ std::sort order inside a gradient bin (what the reference library produces), 1: raster order
+    int top_only = 0;    // planar_lsd_set_top_only: the NFA stage only for the regions that can end among the max_lines kept key lines
     int sort_smem_g = 0, sort_smem_l = 0, sort_rows = 0;
     // planar_lsd_set_profiling: HIP events around the launches of a recorded call; slots: preprocessing (two blurs, gradient, Sobel), lsd_sort, lsd_detect,
     // the rest (improve, accept, KeyLines, LBD)
@@ -1435,7 +1538,7 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_pix = carve(NPs * 16); P.off_seed = carve(NPs * 8); P.off_ordr = carve(NPs * 4); P.off_gused = carve((NPs + 31) / 32 * 4 + 256); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
     P.off_valid = carve((NPs + 63) / 64 * 8 + 8); P.off_sortr = carve((size_t)isort::G_FMAX * sizeof(isort::Range)); P.off_sortb = carve((size_t)isort::G_FMAX * sizeof(isort::Block)); P.off_heapj = carve((size_t)lsd::SORT_HJOBS * sizeof(isort::HeapJob));
     P.off_segs = carve((size_t)lsd::MAX_SEGS * sizeof(lsd::Seg)); P.off_kl = carve((size_t)lsd::MAX_SEGS * sizeof(planar_keyline));
-    P.off_rects = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Rect)); P.off_res = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Seg));
+    P.off_rects = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Rect)); P.off_res = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Seg)); P.off_est = carve((size_t)lsd::MAX_RECTS * 4);
     P.frame_bytes = off;
     o->detect_smem = 64 * 3 * 8 + lsd::USED_LDS_BITS / 8 + lsd::RING * 4 + 16;
     if (o->detect_smem > 150 * 1024 || NPs > (1u << 20)) { delete o; set_error("planar_lsd_create: image too large for the LDS-resident used map"); return PLANAR_EINVAL; }
@@ -1538,9 +1641,22 @@ int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d
     lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
     hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, st, dP, ws, dm);
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[3], st);
-    hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm);   // 512 / 2048 wavefronts per frame measure the same
-    hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm);
-    hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines);
+    if (!o->top_only) {
+        hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm, -1);   // 512 / 2048 wavefronts per frame measure the same
+        hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm, 0);
+        hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines, -1);
+    } else {
+        // the longest regions first; the others only for the frames the first pass cannot settle (the later launches return at once for the settled frames)
+        hipLaunchKernelGGL(lsd::lsd_improve_plan, dim3(B), dim3(256), 0, st, dP, ws, dm);
+        hipLaunchKernelGGL(lsd::lsd_improve, dim3(32, B), dim3(64), 0, st, dP, ws, dm, 0);
+        hipLaunchKernelGGL(lsd::lsd_improve_check, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines);
+        hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm, 1);
+        hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm, 0);
+        hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines, o->top_only == 2 ? 3 : 0);
+        hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm, 2);
+        hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm, 1);
+        hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines, 1);
+    }
     hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
     if (o->ev_cur) { (void)hipEventRecord((*o->ev_cur)[4], st); o->ev_complete[o->ev_used - 1] = 1; o->ev_cur = nullptr; }
     PLANAR_HIP_CHECK(hipGetLastError());
@@ -1644,6 +1760,12 @@ int planar_lsd_read_stage(planar_lsd* o, int frame, int stage, void* out, int64_
             if (out_bytes >= 80) { o64[7] = m.t[5]; o64[8] = m.t[6]; o64[9] = m.t[7]; }   // sort: keys + global tier, LDS tier (workgroup y = 0), compaction
             return PLANAR_OK;
         }
+        case 6: {   // top-lines mode (planar_lsd_set_top_only) of the last call: settled by the longest regions alone, redone for equal responses, all regions from the start, regions
+            PLANAR_REQUIRE(out_bytes >= 32, PLANAR_EINVAL, "buffer too small");
+            long long* o64 = (long long*)out;
+            o64[0] = m.imp_done; o64[1] = m.imp_redo; o64[2] = m.imp_full; o64[3] = m.n_rect;
+            return PLANAR_OK;
+        }
         default: set_error("planar_lsd_read_stage: unknown stage"); return PLANAR_EINVAL;
     }
     PLANAR_REQUIRE((int64_t)bytes <= out_bytes, PLANAR_EINVAL, "buffer too small");
@@ -1651,6 +1773,11 @@ int planar_lsd_read_stage(planar_lsd* o, int frame, int stage, void* out, int64_
     return ret;
 }
 
+int planar_lsd_set_top_only(planar_lsd* o, int enable) {
+    PLANAR_REQUIRE(o != nullptr, PLANAR_EINVAL, "null argument");
+    o->top_only = enable == 2 ? 2 : (enable != 0);          // (2: as 1, and every frame the longest regions settled is redone with all regions - exercises that path in the tests)
+    return PLANAR_OK;
+}
 int planar_lsd_set_tie_order(planar_lsd* o, int tie_order) {
     PLANAR_REQUIRE(o && (tie_order == 0 || tie_order == 1), PLANAR_EINVAL, "tie_order must be 0 (libstdc++ std::sort order) or 1 (raster order)");
     o->tie_order = tie_order;

@@ -14,7 +14,7 @@ SEG_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4")
 
 
 class LineSegment:
-    def __init__(self, width: int = 640, height: int = 480, max_batch: int = 1, ctx: Context | None = None, tie_order: int = 0):
+    def __init__(self, width: int = 640, height: int = 480, max_batch: int = 1, ctx: Context | None = None, tie_order: int = 0, top_only: bool = False):
         self.ctx = ctx or Context(0)
         self.W, self.H, self.max_batch = width, height, max_batch
         h = C.c_void_p()
@@ -26,6 +26,9 @@ class LineSegment:
         # 0: pixels of one gradient bin in libstdc++ std::sort order (the reference library), 1: raster order
         check(lib().planar_lsd_set_tie_order(self.h, tie_order))
         self.tie_order = tie_order
+        # the NFA stage only for the regions that can end among the kept key lines (same key lines; planar_lsd_set_top_only)
+        check(lib().planar_lsd_set_top_only(self.h, int(top_only)))          # (2: test mode, every settled frame is redone)
+        self.top_only = top_only
 
     def ExtractLineSegment(self, img, lsdNFeatures: int = 40):
         """img [B,H,W] or [H,W] uint8.  Returns (keylines [B,40] KEYLINE_DTYPE, ldesc [B,40,32] uint8,
@@ -54,6 +57,8 @@ class LineSegment:
             out = np.zeros(lib().planar_lsd_max_segments(), SEG_DTYPE)
         elif stage == 5:
             out = np.zeros(10, np.int64)
+        elif stage == 6:
+            out = np.zeros(4, np.int64)
         else:
             out = np.zeros(1, np.int32)
         r = check(lib().planar_lsd_read_stage(self.h, frame, stage, out.ctypes.data, out.nbytes))

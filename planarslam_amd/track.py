@@ -60,7 +60,7 @@ class TrackPipeline:
         self.ex = ORBextractor(1000, 1.2, 8, 20, 7, width=W, height=H, max_batch=B, ctx=self.ctx)
         self.S = S = self.ex.kp_cap
         self.pds = [PlaneDetection(W, H, max_batch=B, ctx=c) for c in self.ctx_peacs]
-        self.lss = [LineSegment(W, H, B, c) for c in self.ctx_lsds]
+        self.lss = [LineSegment(W, H, B, c, top_only=True) for c in self.ctx_lsds]      # (the 40 key lines are all the step reads)
         self.sns = [SurfaceNormals(W, H, B, c) for c in self.ctx_peacs]     # Frame::ComputePlanes: PEAC, then the surface normals, on the plane thread
         self.SN = self.sns[0].count
         self.pcs = [PlaneClouds(W, H, B, ctx=c) for c in self.ctx_peacs]       # ... and before them the voxel clouds + RANSAC refit of every plane (Frame.cc:655-692)

@@ -140,3 +140,49 @@ def test_other_image_sizes(ctx, size):
         assert kl[b, :n[b]].tobytes() == rk.tobytes()
         np.testing.assert_array_equal(desc[b, :n[b]], rd)
         np.testing.assert_array_equal(eq[b, :n[b]], re)
+
+
+def test_top_only_mode_gives_the_same_key_lines(ctx):
+    """planar_lsd_set_top_only: the NFA stage for the longest regions first, the rest only where that cannot settle the frame.  Key lines, descriptors and equations are the default
+    mode's bit for bit - on ordinary images (settled by the longest regions), on an image with fewer than 41 segments (all regions from the start or after the check), on a grid of
+    equal-length edges (equal responses among the kept lines: redone with all regions) and on an empty image."""
+    from planarslam_amd.lines import LineSegment
+    rng = np.random.default_rng(23)
+    grid = np.full((480, 640), 60, np.uint8)
+    for gy in range(0, 480, 24):
+        for gx in range(0, 640, 24):
+            if rng.random() < 0.9:
+                w, h = rng.integers(12, 20, 2)
+                grid[gy + 2:gy + 2 + h, gx + 2:gx + 2 + w] = rng.integers(120, 255)
+    few = np.full((480, 640), 40, np.uint8); few[100:300, 150:450] = 200
+    noisy = np.clip(synth.gray_image(3).astype(np.int32) + rng.integers(-40, 41, (480, 640)), 0, 255).astype(np.uint8)
+    bars = np.full((480, 640), 50, np.uint8)                          # noise-free bars: the two long edges of a bar are mirror images - equal responses among the kept lines
+    for i in range(26):
+        y0, x0 = 8 + 18 * i, 20 + 3 * (i % 5)
+        bars[y0:y0 + 9, x0:x0 + 120 + 17 * i] = 210
+    imgs = np.stack([synth.gray_image(1234), synth.gray_image(5), grid, few, np.full((480, 640), 90, np.uint8), noisy, synth.gray_image(77), synth.gray_image(9), bars])
+    B = len(imgs)
+    full = LineSegment(640, 480, B, ctx)
+    top = LineSegment(640, 480, B, ctx, top_only=True)
+    kf, df, ef, nf = full.ExtractLineSegment(imgs)
+    kt, dt, et, nt = top.ExtractLineSegment(imgs)
+    np.testing.assert_array_equal(nt, nf)
+    stats = np.stack([top.read_stage(b, 6) for b in range(B)])
+    for b in range(B):
+        n = int(nf[b])
+        assert kt[b, :n].tobytes() == kf[b, :n].tobytes(), (b, stats[b])
+        np.testing.assert_array_equal(dt[b, :n], df[b, :n]); np.testing.assert_array_equal(et[b, :n], ef[b, :n])
+    print("top-only [settled, redone, all regions, regions]:", stats.tolist())
+    redo = LineSegment(640, 480, B, ctx, top_only=2)                           # the path taken when kept lines have equal responses, forced for every settled frame
+    kr, dr, er, nr = redo.ExtractLineSegment(imgs)
+    np.testing.assert_array_equal(nr, nf)
+    stats_r = np.stack([redo.read_stage(b, 6) for b in range(B)])
+    assert (stats_r[:, 1] == stats_r[:, 0]).all() and stats_r[:, 1].sum() >= 5
+    for b in range(B):
+        n = int(nf[b])
+        assert kr[b, :n].tobytes() == kf[b, :n].tobytes() and np.array_equal(dr[b, :n], df[b, :n]) and np.array_equal(er[b, :n], ef[b, :n]), b
+    assert len(redo.read_stage(0, 3)) == len(full.read_stage(0, 3))            # after the redo every region has been through the NFA stage
+    assert stats[0, 0] == 1 and stats[1, 0] == 1 and stats[6, 0] == 1            # ordinary images: the longest regions settle the frame ...
+    assert (stats[[0, 1, 6], 1] == 0).all()                                    # ... without equal responses among the kept lines
+    assert stats[3, 0] == 0 and nf[3] <= 40 and nf[4] == 0                      # too few segments: every region
+    assert len(top.read_stage(0, 3)) < len(full.read_stage(0, 3))               # and fewer regions went through the NFA stage
