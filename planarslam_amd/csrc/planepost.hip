@@ -37,7 +37,7 @@ constexpr int VOX_BIAS = 8192;            // voxel coordinates floor(x / leaf) a
 constexpr unsigned long long EMPTY = ~0ull;
 
 struct Geo {
-    int dev_skip_heap = 0;                          // (developer's timing switch: PLANAR_DEV_SKIP_HEAP*)
+    int dev_skip_heap = 0;                          // (always 0; was a timing switch of the round-4 experiments: leaving the fallback jobs out)
     int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (frame workspace); mini: entries of a wavefront's tile table (LDS)
     float fx, fy, cx, cy, factor, leaf;
     double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
@@ -1086,13 +1086,8 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     mark();
     hipLaunchKernelGGL(planepost::plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
     mark();
-    // (the environment variables: a developer's timing experiments, results are then wrong)
-    const bool skip_heap = getenv("PLANAR_DEV_SKIP_HEAP") != nullptr;
-    const int skip_class = getenv("PLANAR_DEV_SKIP_HEAP_CLASS") ? atoi(getenv("PLANAR_DEV_SKIP_HEAP_CLASS")) : -1;
-    G.dev_skip_heap = skip_heap || skip_class == 2;
     auto heap_launch = [&](hipStream_t q, int part, int c) {
         const planepost::HeapClass& H = planepost::PS_HC[c];
-        if (skip_heap || skip_class == c) return;
         hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(B, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, q, G, ws, part, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
     };
     hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_EARLY + planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);   // + the global tier's fallback jobs
