@@ -33,6 +33,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ENV_OVERRIDES = []
+PARITY_SAMPLE = True    # after the timed region: a few frames of the last step against the oracle (tools/stage_skip.py turns it off: nothing to compare there)
 W, H = 640, 480
 MARGIN = 48
 NCANVAS = 256
@@ -56,6 +58,60 @@ def pick_device(args, torch):
     return local_rank
 
 
+def parity_sample(tp, frames, depths, k, B, cam, streams=None):
+    """AFTER the timed region: a few frames of the LAST timed step against the CPU oracle (the checker; never the thing measured) - the buffers of set k still hold that
+    step's inputs and every stage's outputs: ORB key points / descriptors, key lines / LBD / line equations (the LSD's top-lines mode), PEAC labels and planes, the
+    planes' voxel clouds (PCL's float sums in std::sort's order) bit for bit; the refitted coefficients to 1e-6; TranslationOptimization and PoseOptimization of the
+    last tracking chain within 1e-5 of the oracle's LM on the problems the device assembled, inlier counts equal.  -> {"frames": n, "ok": bool, ...}"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol                                      # test infrastructure: used here only as the checker, outside the timed region
+    from planarslam_amd._lib import KEYLINE_DTYPE
+    streams = streams or sorted({0, B // 3, (2 * B) // 3, B - 1})
+    H_, W_ = frames[k].shape[1:]
+    o = ol.OrbOracle()
+    fails, worst_pose, worst_coef = [], 0.0, 0.0
+    KEYS = ("n_points", "n_lines", "n_planes", "pt_valid", "pt_xw", "pt_obs", "pt_inv_sigma2", "ln_valid", "ln_obs", "ln_xw", "pl_meas", "pl_valid", "pl_world")
+    for b in streams:
+        g = frames[k][b].cpu().numpy(); d = depths[k][b].cpu().numpy().view(np.uint16)
+        n = int(tp.n[k][b]); kp, de = o.extract(g)
+        if not (n == len(kp) and tp.kps[k][b, :n].cpu().numpy().tobytes() == kp.tobytes() and np.array_equal(tp.desc[k][b, :n].cpu().numpy(), de)):
+            fails.append(f"stream {b}: ORB")
+        rk, rd, re, _, _ = ol.extract_line_segment(g, tie_order=0)
+        nl = int(tp.nl[k][b]); kl = tp.kls[k].cpu().numpy().view(KEYLINE_DTYPE).reshape(B, 40)
+        if not (nl == len(rk) and kl[b, :nl].tobytes() == rk.tobytes() and np.array_equal(tp.ldesc[k][b, :nl].cpu().numpy(), rd) and np.array_equal(tp.leq[k][b, :nl].cpu().numpy(), re)):
+            fails.append(f"stream {b}: LSD/LBD")
+        planes, labels = ol.peac_run(d)
+        npl = int(tp.npl[k][b]); lab = tp.lab[k][b].cpu().numpy().reshape(H_, W_)
+        if not (npl == len(planes) and np.array_equal(lab, labels) and np.array_equal(tp.pls[k][b, :npl].cpu().numpy(), planes)):
+            fails.append(f"stream {b}: PEAC")
+        else:
+            want = ol.plane_clouds(d, labels, planes)
+            pc = tp.pc[k]; q = want["n"]
+            off = pc["off"][b].cpu().numpy()
+            if not (int(pc["n"][b]) == q and np.array_equal(pc["src"][b, :q].cpu().numpy(), want["src"]) and np.array_equal(off[:q + 1], want["pt_off"])
+                    and np.array_equal(pc["pts"][b, :off[q]].cpu().numpy(), want["points"])):
+                fails.append(f"stream {b}: plane clouds")
+            else:
+                worst_coef = max(worst_coef, float(np.abs(pc["coef"][b, :q].cpu().numpy() - want["coef"]).max(initial=0)))
+        for which, mode in ((0, 1), (1, 0)):                     # the last chain's TranslationOptimization / PoseOptimization problems, as the device assembled them
+            A = tp.pb_arrays[which]
+            pb = {kk: A[kk][b:b + 1].cpu().numpy() for kk in KEYS}
+            pb["Tcw"] = A["Tcw_in"][b:b + 1].cpu().numpy()
+            w = ol.pose_optimize(pb, cam, mode, 4, 10)
+            dT = float(np.abs(w["Tcw"] - A["Tcw_out"][b:b + 1].cpu().numpy()).max())
+            worst_pose = max(worst_pose, dT)
+            if not (dT <= 1e-5 and int(w["n_inliers"][0]) == int(A["n_inliers"][b])):
+                fails.append(f"stream {b}: {'TranslationOptimization' if mode else 'PoseOptimization'} ({dT:.2e})")
+    if worst_coef > 1e-6:
+        fails.append(f"plane refit {worst_coef:.2e}")
+    for f in fails:
+        print(f"bench.py: PARITY SAMPLE MISMATCH: {f}", file=sys.stderr)
+    return {"frames": len(streams), "streams": streams, "ok": not fails, "mismatches": fails, "max_pose_diff_vs_oracle": worst_pose, "max_refit_coef_diff": worst_coef,
+            "checked": "last timed step: ORB keypoints+descriptors, key lines+LBD+equations, PEAC labels+planes, voxel centroids bit-exact; refit <= 1e-6; both optimisers <= 1e-5 "
+                       "and inlier counts (oracle = checker, run after the timed region; the full comparison is tests/test_track_gpu.py on these se3 streams)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,7 +123,9 @@ def main():
     ap.add_argument("--depth", type=int, default=3, help="software-pipeline depth: the tracking chain of step i runs during step i + depth")
     ap.add_argument("--prio", default="-1,0,0", help="stream priorities: point stream, LSD streams, PEAC streams[, tracking stream] (lower = higher priority)")
     ap.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the cpu_baseline leg, split over its three variants (0 = skip)")
-    ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 latency block (0 = skip)")
+    ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 pose-optimisation call (0 = skip the whole latency block)")
+    ap.add_argument("--latency-frames", type=int, default=200, help="distinct frames of the B = 1 latency block (4/5 se3 frames, 1/5 panned canvas windows)")
+    ap.add_argument("--sub-steps", type=int, default=20, help="steps of the BASELINE configs[1] / [3] / [4] sub-runs folded into the default line as sub_benchmarks (0 = skip)")
     ap.add_argument("--pcie-steps", type=int, default=4, help="steps of the PCIe-inclusive loop (0 = skip)")
     ap.add_argument("--canvases", type=int, default=NCANVAS, help="distinct synthetic canvases (pan) / room scenes with their textures (se3) per GPU (the streams tile over them)")
     ap.add_argument("--streams", choices=["se3", "pan"], default="se3",
@@ -82,6 +140,13 @@ def main():
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes that synthesise the canvases (0 = up to 32; 1 = in this process: rocprofv3 --pmc hangs in "
                                                              "forked children, profiles/README.md)")
     args = ap.parse_args()
+    # no timing / variant switch reaches the timed region through the environment: the product reads none (PLANAR_HIP_LIB, a developer build of the same library, is
+    # reported in the line; stage skipping lives in tools/stage_skip.py, which relabels its output)
+    bad = sorted(k for k in os.environ if k.startswith("PLANAR_") and k not in ("PLANAR_HIP_LIB", "PLANAR_ORACLE_LIB"))
+    if bad:
+        raise SystemExit(f"bench.py: refusing to run with {bad} set: the bench line is the product's default path only")
+    global ENV_OVERRIDES
+    ENV_OVERRIDES = [f"{k}={os.environ[k]}" for k in ("PLANAR_HIP_LIB",) if os.environ.get(k)]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU, RCCL rendezvous on 127.0.0.1) and pass the line through
@@ -111,6 +176,7 @@ def main():
     t_gen = time.perf_counter()
     canv_g, canv_d = stream_canvases(ncanv, rank_env, W + 2 * MARGIN, H + 2 * MARGIN, procs=args.gen_procs or max(1, min(32, (os.cpu_count() or 1) // max(1, world_env))))
     t_gen = time.perf_counter() - t_gen
+    canv_g0, canv_d0 = canv_g, canv_d            # (the panned windows of the B = 1 latency block)
 
     import torch
 
@@ -281,8 +347,11 @@ def main():
                 check(L.planar_plane_clouds_get_profile(q.h, tot.ctypes.data, C.byref(nc)))
                 check(L.planar_plane_clouds_set_profiling(q.h, 0))
                 pc_ms += tot; pc_calls += nc.value
+    parity = None
     if full:
         tp.check()
+        if PARITY_SAMPLE and rank_env == 0:
+            parity = parity_sample(tp, frames, depths, (args.warmup + args.steps - 1) % NB, B, TUM3)
 
     seg = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in evsets) / args.steps
     stage_ms = {"orb_extract": seg("start", "orb")}
@@ -305,14 +374,12 @@ def main():
     avg_kp = n_kp / B
     kernels = {k: {"ms_per_step": round(v[0] / max(1, calls), 4), "launches_per_step": v[1] // max(1, calls)} for k, v in prof.items()}
     alg = orb_algorithmic_bytes(ex, avg_kp)
-    cand = {k: (v[0] / max(1, v[1]), alg.get(k, 0) * B) for k, v in prof.items()}          # (avg launch ms, algorithmic bytes per launch)
     quality = None
     t_pc_pts = lambda q: torch.gather(q.pc[0]["off"], 1, q.pc[0]["n"].long().unsqueeze(1)).float().mean().item()     # pt_off[b][n[b]] = voxel centroids kept
     if full:
         # PEAC: read u16 depth + write int32 labels (1 843 200 B/frame); peac_blocks + peac_ahc + peac_order + peac_refine bracketed together
         pk = "peac_blocks+peac_ahc+peac_refine"
         pav = peac_ms / max(1, peac_calls)          # average duration of each launch, HIP events tight around it (co-run: other streams share the CUs)
-        cand[pk] = (float(pav.sum()), 1843200 * B)
         kernels[pk] = {"ms_per_step": round(float(pav.sum()), 4), "launches_per_step": 4, "alone_ms": standalone["peac_alone_ms"],
                        "avg_launch_ms": {"peac_blocks": round(float(pav[0]), 3), "peac_ahc": round(float(pav[1]), 3), "peac_order": round(float(pav[2]), 3),
                                          "peac_refine": round(float(pav[3]), 3)},
@@ -322,18 +389,14 @@ def main():
         # plane clouds (Frame::ComputePlanes head): read labels + depth (1 843 200 B / frame), write <= 4096 centroids; its launches bracketed one by one
         ck = "plane_clouds(voxels+items+sort+tail)"
         cav = pc_ms / max(1, pc_calls)
-        cand[ck] = (float(cav.sum()), 1843200 * B)
         kernels[ck] = {"ms_per_step": round(float(cav.sum()), 4), "launches_per_step": 8, "alone_ms": standalone["plane_clouds_alone_ms"],
                        "avg_launch_ms": dict(zip(PC_SLOTS, (round(float(x), 3) for x in cav))), "alone_launch_ms": standalone["plane_clouds_kernels_alone_ms"],
                        "sort_stats_of_the_calibration_batch": standalone["plane_sort_stats"]}
         lk = "lsd_detect(+7 small kernels)"
-        cand[lk] = (standalone["lsd_lbd_alone_ms"], (307200 + 40 * 124) * B)
         kernels[lk] = {"ms_per_step": round(stage_ms["lsd_lbd(stream 3)"], 4), "launches_per_step": 8, "alone_ms": standalone["lsd_lbd_alone_ms"]}
-        cand["projection_kernel"] = (stage_ms["search_by_projection_last"], (1000 * (28 + 4 + 32) + 1000 * (12 + 4 + 4 + 32 + 2)) * B)
         kernels["projection_kernel"] = {"ms_per_step": round(stage_ms["search_by_projection_last"], 4), "launches_per_step": 1}
         A1 = tp.pb_arrays[1]
         lm_it = float(A1["lm_iters"].float().mean().item())
-        cand["pose_opt_kernel"] = (stage_ms["assemble+pose_opt_4x10"], 65130 * B * 2 * max(lm_it, 1.0))
         kernels["pose_opt_kernel"] = {"ms_per_step": round(stage_ms["assemble+pose_opt_4x10"], 4), "launches_per_step": 2, "avg_lm_iterations": round(lm_it, 2)}
         quality = {"avg_planes_per_frame": round(float(tp.npl[0].float().mean().item()), 2), "avg_planes_kept_per_frame": round(float(tp.pc[0]["n"].float().mean().item()), 2),
                    "avg_plane_cloud_points_per_frame": round(float(t_pc_pts(tp)), 1), "avg_lines_per_frame": round(float(tp.nl[0].float().mean().item()), 2),
@@ -343,61 +406,68 @@ def main():
                    "avg_plane_matches_per_frame": round(float(tp.nplm.float().mean().item()), 2),
                    "avg_translation_opt_inliers": round(float(tp.pb_arrays[0]["n_inliers"].float().mean().item()), 1),
                    "avg_pose_opt_inliers": round(float(A1["n_inliers"].float().mean().item()), 1)}
-    dom = max(cand, key=lambda k: cand[k][0] * (kernels[k]["launches_per_step"] if k in prof else 1))
-    dom_ms, dom_bytes = cand[dom]
+    ms_per_step = elapsed / args.steps * 1e3
+    # ---- roofline: ONE KERNEL, the one with the most device time per step.  Durations: HIP events right before / after each launch on the stream the kernel runs on,
+    #      inside the timed region (co-run with the other streams: what rocprofv3's AverageNs of the same command measures), and the same launch alone on the device
+    #      (calibration launch before the timed region: rocprofv3's Min).  Bytes: SURVEY §8d's algorithmic figure of the kernel's stage x frames per launch. ----
+    per = {}
+
+    def add_kernel(name, rocprof, corun, alone, nbytes, launches=1):
+        e = {"rocprof_name": rocprof, "alg_bytes_per_launch": int(nbytes), "corun_avg_ms": round(float(corun), 3), "alone_ms": None if alone is None else round(float(alone), 3),
+             "launches_per_step": launches}
+        if corun > 0: e["frac_corun"] = round(nbytes / (corun * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+        if alone: e["frac_alone"] = round(nbytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+        per[name] = e
+    for k, v in prof.items():                                  # the ORB kernels (per-launch events of the extractor): average over their launches
+        add_kernel(k, "planar::orb::" + k, v[0] / max(1, v[1]), None, alg.get(k, 0) * B, v[1] // max(1, calls))
+    if full:
+        lav = lsd_ms / max(1, lsd_calls)
+        ka, la, ca = standalone.get("peac_kernels_alone_ms", {}), standalone.get("lsd_kernels_alone_ms", {}), standalone["plane_clouds_kernels_alone_ms"]
+        add_kernel("peac_blocks", "planar::peac::peac_blocks", pav[0], ka.get("peac_blocks"), 614400 * B)
+        add_kernel("peac_ahc3", "planar::peac::peac_ahc3", pav[1], ka.get("peac_ahc"), 1843200 * B)
+        add_kernel("peac_refine", "planar::peac::peac_refine", pav[3], ka.get("peac_refine"), 1843200 * B)
+        add_kernel("lsd_sort(4 launches)", "planar::lsd::lsd_sort", lav[1], la.get("lsd_sort"), 312160 * B, 4)
+        add_kernel("lsd_detect", "planar::lsd::lsd_detect", lav[2], la.get("lsd_detect"), 312160 * B)
+        for i, nm in enumerate(PC_SLOTS):
+            add_kernel(nm, "planar::planepost::" + nm + ("" if nm.startswith("plane_sort") else "_kernel"), cav[i], ca.get(nm), 1843200 * B, 2 if nm == "plane_sort_heap" else 1)
+    dom = max(per, key=lambda k: per[k]["corun_avg_ms"] * (per[k]["launches_per_step"] if k in prof else 1))
+    dom_ms, dom_bytes = per[dom]["corun_avg_ms"], per[dom]["alg_bytes_per_launch"]
+    if dom_ms > ms_per_step:
+        print(f"bench.py: WARNING: the HIP-event bracket of {dom} ({dom_ms:.1f} ms) exceeds the step ({ms_per_step:.1f} ms): launches of several steps overlap on its stream", file=sys.stderr)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # ORB; + PEAC (depth in, labels out) + normals; + plane clouds (labels + depth in); + matchers + two pose problems
-    per_frame = 1961064 + (1843200 + 312160 if full else 0) + (1843200 if full else 0) + (72000 + 118000 + 65130 * 2 * 40 if full else 0)
-    # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this
-    # command, KB per launch, summed over the stage's kernels); raw counter sums (narrow gathers: no wide-read correction applied)
+    # algorithmic bytes of the whole step per frame: ORB; + PEAC (depth in, labels out) + normals; + plane clouds (labels + depth in); + matchers + the two pose problems
+    # (65 130 B per LM evaluation x the MEASURED evaluations of both optimisers)
+    lm_both = (float(tp.pb_arrays[0]["lm_iters"].float().mean().item()) + float(tp.pb_arrays[1]["lm_iters"].float().mean().item())) if full else 0.0
+    per_frame = 1961064 + ((1843200 + 312160) + 1843200 + 72000 + 118000 + 65130 * lm_both if full else 0)
+    # HBM-side traffic of that kernel from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this command, KB per launch;
+    # raw counter sums); a kernel without a row is reported as null with the reason, never as zero
     traffic = None
-    pmc_csv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_fetch_write_kb_per_launch.csv") for r in (4, 3, 2)) if os.path.exists(q)), "")
+    pmc_csv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_fetch_write_kb_per_launch.csv") for r in (5, 4, 3, 2)) if os.path.exists(q)), "")
     traffic_note = "null: no profiles/r0N_pmc_fetch_write_kb_per_launch.csv (tools/pmc_counters.py) found"
-    # the kernels of the dominant stage as rocprofv3 names them (prefix match: template / overload suffixes vary); a key without a row is an ERROR, not a zero
-    pmc_keys = {"peac_blocks+peac_ahc+peac_refine": ("planar::peac::peac_blocks", "planar::peac::peac_ahc", "planar::peac::peac_refine"),
-                "plane_clouds(voxels+items+sort+tail)": ("planar::planepost::plane_voxels_kernel", "planar::planepost::plane_items_kernel", "planar::planepost::plane_sort_global",
-                                                         "planar::planepost::plane_sort_lds", "planar::planepost::plane_sort_heap", "planar::planepost::plane_tail_kernel"),
-                "lsd_detect(+7 small kernels)": ("planar::lsd::lsd_detect",)}.get(dom, ("planar::orb::" + dom,))
     if os.path.exists(pmc_csv):
         f_tot = w_tot = 0.0
-        seen = set()
-        for line in open(pmc_csv).read().splitlines()[1:]:
-            k, _, f_kb, w_kb = line.rsplit(",", 3)
-            hit = next((q for q in pmc_keys if k.strip('"').startswith(q)), None)
-            if hit:
-                f_tot += float(f_kb); w_tot += float(w_kb); seen.add(hit)
-        missing = [q for q in pmc_keys if q not in seen]
-        if missing:
-            traffic_note = f"null: {os.path.relpath(pmc_csv, ROOT)} has no row for {missing} (the counter file predates these kernels: re-collect with tools/collect_profiles.sh)"
-            print(f"bench.py: WARNING: roofline.traffic not reported: {traffic_note}", file=sys.stderr)
-        elif f_tot + w_tot > 0:
+        for ln in open(pmc_csv).read().splitlines()[1:]:
+            k, _, f_kb, w_kb = ln.rsplit(",", 3)
+            if k.strip('"').replace("void ", "").startswith(per[dom]["rocprof_name"]):
+                f_tot += float(f_kb); w_tot += float(w_kb)
+        if f_tot + w_tot > 0:
             traffic = int((f_tot + w_tot) * 1024 * B / 1024)
             traffic_note = (f"NOT measured in this run: read from the committed {os.path.relpath(pmc_csv, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
                             f"`bench.py --canvases 16 --gen-procs 1`, B=1024; counter collection hangs in forked children): {f_tot / 1024:.0f} MB read + {w_tot / 1024:.0f} MB written per launch")
+        else:
+            traffic_note = f"null: {os.path.relpath(pmc_csv, ROOT)} has no row for {per[dom]['rocprof_name']} (re-collect with tools/collect_profiles.sh)"
+            print(f"bench.py: WARNING: roofline.traffic not reported: {traffic_note}", file=sys.stderr)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": traffic, "traffic_source": os.path.relpath(pmc_csv, ROOT) if traffic is not None else None, "traffic_note": traffic_note, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
-                "pipeline_algorithmic_GBps": round(per_frame * fps / 1e9, 2),
-                "note": "latency-bound sequential stage (one wavefront per frame); see DESIGN.md" if dom.startswith(("peac", "lsd")) else
-                        ("the voxel grid of Frame::ComputePlanes in PCL's summation order: every plane's points arranged as libstdc++'s std::sort leaves them (isort.h); see DESIGN.md" if dom.startswith("plane_clouds") else None),
-                "kernels": kernels}
+                "traffic": traffic, "traffic_source": os.path.relpath(pmc_csv, ROOT) if traffic is not None else None, "traffic_note": traffic_note,
+                "avg_launch_ms": round(dom_ms, 4), "alone_ms": per[dom]["alone_ms"], "frac_alone": per[dom].get("frac_alone"), "algorithmic_bytes_per_launch": int(dom_bytes),
+                "pipeline_algorithmic_GBps": round(per_frame * fps / 1e9, 2), "algorithmic_bytes_per_frame_of_the_step": int(per_frame),
+                "note": ("one kernel (the one with the most device time per step), not a stage: avg_launch_ms = HIP events right before / after each of its launches on its own stream "
+                         "inside the timed region (co-run with the other streams; rocprofv3's AverageNs of the same command), alone_ms = the same launch alone on the device "
+                         "(rocprofv3's Min).  peac_ahc3 / lsd_detect: one sequential wavefront per frame, latency-bound (DESIGN.md §4)"),
+                "per_kernel": per, "stages": kernels}
     if full:
-        # the three kernels with the most device time, each against the roofline on its own: algorithmic bytes of its stage per launch
-        # divided by the kernel's average duration - alone on the device (calibration launch before the timed region) and inside the pipelined step
-        lav = lsd_ms / max(1, lsd_calls)
-        ka, la = standalone.get("peac_kernels_alone_ms", {}), standalone.get("lsd_kernels_alone_ms", {})
-        per = {}
-        for name, alone, corun, nbytes in (("peac_ahc", ka.get("peac_ahc"), float(pav[1]), 1843200 * B), ("peac_refine", ka.get("peac_refine"), float(pav[3]), 1843200 * B),
-                                           ("lsd_sort", la.get("lsd_sort"), float(lav[1]), 312160 * B), ("lsd_detect", la.get("lsd_detect"), float(lav[2]), 312160 * B),
-                                           ("plane_sort_lds", standalone["plane_clouds_kernels_alone_ms"].get("plane_sort_lds"), float(cav[3]), 1843200 * B),
-                                           ("plane_sort_heap", standalone["plane_clouds_kernels_alone_ms"].get("plane_sort_heap"), float(cav[4]), 1843200 * B)):
-            e = {"alg_bytes_per_launch": int(nbytes), "corun_avg_ms": round(corun, 3), "alone_ms": alone}
-            if corun > 0: e["frac_corun"] = round(nbytes / (corun * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
-            if alone: e["frac_alone"] = round(nbytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
-            per[name] = e
-        roofline["per_kernel"] = per
-        roofline["per_kernel_note"] = ("peac_ahc = peac_ahc3 (the clustering launch: fast attempt, frames with bit-equal keys redone with the exact heap by the same workgroup); durations "
-                                       "from HIP events right before / after each launch on the stream it runs on.  co-run >> alone: the single-wavefront kernels of the two side chains "
-                                       "each fill a CU's LDS (4 x 38 KB) while resident, so the chains time-share the CUs (tools/corun_probe.py; DESIGN.md)")
+        roofline["per_kernel_note"] = ("co-run >> alone for the wide kernels: up to depth + 2 steps are in flight and every kernel waits for CUs behind the other streams' launches; "
+                                       "the single-wavefront kernels of the two side chains stretch when other wavefronts share their SIMDs (tools/corun_probe.py; DESIGN.md)")
 
     # ---- PCIe-inclusive rate: the same step fed from pinned host memory and drained to it (H2D / D2H on copy streams, overlapped) ----
     pcie = None
@@ -457,6 +527,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import cpu_baseline as cb
         cb.use_fast_build()                          # -O3 -march=native, compiled on this box (the tests keep checking against the -O2 build)
+        import oracle_lib as _ol
+        _ol._LIB = None                              # (the parity sample above loaded the checker's -O2 build: the timed legs below load the fast one)
         t_each = args.cpu_seconds / 3.0
         r1 = cb.run(t_each, seed=rank, full=full)
         r3 = cb.run(t_each, seed=rank, threads3=True, full=full) if full else None
@@ -469,45 +541,125 @@ def main():
                                                      "note": "extraction on 3 threads per frame as src/Frame.cc:90-95; matching + LM single-threaded"},
                "host_cores": ncores, "cpu_model": cb.cpu_model(), "build": cb.build_flags()}
 
-    # ---- single-frame latency (B = 1, host-pointer entry points: H2D + kernels + D2H + sync; the reference is a live B = 1 tracker) ----
+    # ---- single-frame latency (B = 1, host-pointer entry points: H2D + kernels + D2H + sync; the reference is a live B = 1 tracker).  Every stage the adapters call per
+    #      frame (include/planar_adapters.hpp): ORBextractor, ExtractLineSegment + isLineGood, PlaneDetection + ComputePlanes' voxel clouds / refit + surface normals,
+    #      PoseOptimization; over `--latency-frames` DISTINCT frames (se3 frames of different streams, then panned canvas windows: the regime with heap-sort fallbacks),
+    #      each frame timed once after an untimed pass of the first frames: p50 / p99 / max ----
     latency = None
     if world == 1 and full and args.latency_reps > 0:
         from planarslam_amd.lines import LineSegment as LS1
+        from planarslam_amd.lines import is_line_good as ilg1
         from planarslam_amd.matcher import ORBmatcher as OM1
+        from planarslam_amd.planes import PlaneClouds as PC1
+        from planarslam_amd.planes import SurfaceNormals as SN1
         from planarslam_amd.synth import pose_batch
-        c1 = Context(local_rank)
-        ex1 = ORBextractor(1000, 1.2, 8, 20, 7, width=W, height=H, max_batch=1, ctx=c1)
-        ls1 = LS1(W, H, 1, c1)
-        pd1 = PlaneDetection(W, H, max_batch=1, ctx=c1)
-        opt1 = Optimizer(TUM3, ctx=c1)
-        om1 = OM1(ctx=c1)
-        g1 = np.ascontiguousarray(canv_g[0, MARGIN:MARGIN + H, MARGIN:MARGIN + W]); dp1 = np.ascontiguousarray(canv_d[0, MARGIN:MARGIN + H, MARGIN:MARGIN + W])
-        pb1 = pose_batch(B=1, n_points=1000, n_lines=75, n_planes=4, seed=7)
-        kp1, de1 = ex1(g1)
-
-        def med(fn):
-            fn(); fn()
-            ts = []
-            for _ in range(args.latency_reps):
-                t1 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t1) * 1e3)
-            return round(float(np.median(ts)), 3)
-        latency = {"orb_extract": med(lambda: ex1(g1)), "lsd_lbd_extract": med(lambda: ls1.ExtractLineSegment(g1)),
-                   "peac_segment": med(lambda: pd1.run(dp1[None])), "pose_opt_4x10": med(lambda: opt1.PoseOptimization(pb1, 4, 10)),
-                   "match_orb_points": med(lambda: om1.MatchORBPoints(de1[None], np.array([len(de1)], np.int32), de1[None], np.array([len(de1)], np.int32),
-                                                                       np.ones((1, len(de1)), np.uint8), np.zeros((1, len(de1)), np.uint8))),
-                   "reps": args.latency_reps, "note": "median wall ms per call, one frame, host buffers in and out"}
-        latency["extract_3_stages_serial_sum"] = round(latency["orb_extract"] + latency["lsd_lbd_extract"] + latency["peac_segment"], 3)
-        # the reference's operating point: Frame::Frame runs the three extractors on three threads (src/Frame.cc:90-95).  Here: three host threads, each calling
-        # its extractor's host-pointer entry point on its own context / stream (ctypes releases the GIL), one frame.
         import threading
-        c2, c3 = Context(local_rank), Context(local_rank)
-        ls3 = LS1(W, H, 1, c2); pd3 = PlaneDetection(W, H, max_batch=1, ctx=c3)
+        nlat = max(8, args.latency_frames)
+        lat_g, lat_d, kinds = [], [], []
+        if se3:
+            ns = min(B, (nlat * 4) // 5)
+            for q in range(ns):
+                fi = (q * 5) % args.loop
+                lat_g.append(loop_g[q, fi].cpu().numpy()); lat_d.append(loop_d[q, fi].cpu().numpy().view(np.uint16)); kinds.append("se3")
+        npan = nlat - len(lat_g)
+        for q in range(npan):                                     # panned windows over the unrelated gray / depth canvases of rounds 1-3
+            c_, ox = q % len(canv_g0), 8 * ((q // len(canv_g0)) % 12)
+            lat_g.append(np.ascontiguousarray(canv_g0[c_, MARGIN:MARGIN + H, ox:ox + W])); lat_d.append(np.ascontiguousarray(canv_d0[c_, MARGIN:MARGIN + H, ox:ox + W])); kinds.append("pan")
+        cs = [Context(local_rank) for _ in range(3)]
+        ex1 = ORBextractor(1000, 1.2, 8, 20, 7, width=W, height=H, max_batch=1, ctx=cs[0])
+        ls1 = LS1(W, H, 1, cs[1])
+        pd1 = PlaneDetection(W, H, max_batch=1, ctx=cs[2]); pc1 = PC1(W, H, 1, ctx=cs[2]); sn1 = SN1(W, H, 1, cs[2])
+        opt1 = Optimizer(TUM3, ctx=cs[0]); om1 = OM1(ctx=cs[0])
+        pb1 = pose_batch(B=1, n_points=1000, n_lines=75, n_planes=4, seed=7)
+        PSn = pd1.max_planes
+        Kc = (TUM3["fx"], TUM3["fy"], TUM3["cx"], TUM3["cy"])
+        tms = {k: [] for k in ("orb_extract", "lsd_lbd_extract", "is_line_good", "peac_segment", "plane_clouds_refit", "surface_normals", "pose_opt_4x10", "frame_3_threads")}
 
-        def three():
-            th = [threading.Thread(target=f) for f in (lambda: ex1(g1), lambda: ls3.ExtractLineSegment(g1), lambda: pd3.run(dp1[None]))]
-            for t in th: t.start()
-            for t in th: t.join()
-        latency["extract_3_threads_concurrent"] = med(three)
+        def timed(key, fn, rec):
+            t1 = time.perf_counter(); r = fn(); dt = (time.perf_counter() - t1) * 1e3
+            if rec: tms[key].append(dt)
+            return r
+
+        def points(g, rec):
+            timed("orb_extract", lambda: ex1(g), rec)
+
+        def lines(g, d, rec, i):
+            kl, _, _, nl_ = timed("lsd_lbd_extract", lambda: ls1.ExtractLineSegment(g), rec)
+            timed("is_line_good", lambda: ilg1(kl, nl_, d[None], np.array([64 * i], np.int32), cam=Kc, ctx=cs[1]), rec)
+
+        def planes(d, rec):
+            pls_, lab_ = timed("peac_segment", lambda: pd1.run(d[None])[0], rec)
+            pl = np.zeros((1, PSn, 8)); pl[0, :len(pls_)] = pls_
+            timed("plane_clouds_refit", lambda: pc1.compute(d[None], lab_[None], pl, np.array([len(pls_)], np.int32), K=Kc), rec)
+            timed("surface_normals", lambda: sn1.compute(d, K=Kc), rec)
+
+        def frame_threads(g, d, i):
+            th = [threading.Thread(target=f) for f in (lambda: points(g, False), lambda: lines(g, d, False, i), lambda: planes(d, False))]
+            t1 = time.perf_counter()
+            for t_ in th: t_.start()
+            for t_ in th: t_.join()
+            return (time.perf_counter() - t1) * 1e3
+        for i in range(3):                                        # untimed: first-call allocations, code page-in
+            points(lat_g[i], False); lines(lat_g[i], lat_d[i], False, i); planes(lat_d[i], False); frame_threads(lat_g[i], lat_d[i], i)
+            opt1.PoseOptimization(pb1, 4, 10)
+        for i in range(len(lat_g)):
+            points(lat_g[i], True); lines(lat_g[i], lat_d[i], True, i); planes(lat_d[i], True)
+            tms["frame_3_threads"].append(frame_threads(lat_g[i], lat_d[i], i))
+            if i < args.latency_reps:
+                timed("pose_opt_4x10", lambda: opt1.PoseOptimization(pb1, 4, 10), True)
+        pct = lambda v: {"p50": round(float(np.percentile(v, 50)), 3), "p99": round(float(np.percentile(v, 99)), 3), "max": round(float(np.max(v)), 3)}
+        latency = {k: pct(v) for k, v in tms.items() if v}
+        kk = np.array(kinds)
+        for nm in ("peac_segment", "plane_clouds_refit", "lsd_lbd_extract", "frame_3_threads"):
+            for kind in ("se3", "pan"):
+                sel = np.array(tms[nm])[kk == kind]
+                if len(sel): latency[nm][kind + "_p50"] = round(float(np.percentile(sel, 50)), 3); latency[nm][kind + "_max"] = round(float(sel.max()), 3)
+        cp = np.array(tms["peac_segment"]) + np.array(tms["plane_clouds_refit"]) + np.array(tms["surface_normals"])
+        latency["compute_planes(peac+clouds+normals)"] = pct(cp)
+        latency["extract_lines(lsd+lbd+is_line_good)"] = pct(np.array(tms["lsd_lbd_extract"]) + np.array(tms["is_line_good"]))
+        # back-compatible scalars (medians): what earlier rounds' lines carried
+        for nm in ("orb_extract", "lsd_lbd_extract", "peac_segment", "pose_opt_4x10"):
+            latency[nm + "_p50"] = latency[nm]["p50"]
+        latency.update({"frames": len(lat_g), "frames_se3": int((kk == "se3").sum()), "frames_pan": int((kk == "pan").sum()),
+                        "note": "wall ms per call, ONE frame, host buffers in and out, every frame distinct and timed once; frame_3_threads = Frame::Frame's three extractor threads "
+                                "(src/Frame.cc:90-95): points | lines + isLineGood | PEAC + voxel clouds / refit + normals, each on its own host thread, context and stream"})
+
+    # ---- sub_benchmarks: BASELINE configs[1] (ORB only), configs[3] (pose-only LM, B = 256) and configs[4] (local BA) as short sub-runs of THIS command, each with its
+    #      own roofline and cpu_baseline, so that the driver's default invocation carries a number for every BASELINE config that fits one GPU ----
+    sub = None
+    if full and world == 1 and args.sub_steps > 0:
+        sub = {}
+        cpu_s = min(args.cpu_seconds, 6.0)
+        # configs[1]: the pipeline's own extractor on the resident streams, window copy included (== `--workload orb`)
+        with torch.cuda.stream(stream):
+            ex.set_profiling(True)
+            for i in range(3):
+                window(i, frames[i % NB], None); ex.extract_dev(frames[i % NB].data_ptr(), tp.kps[i % NB].data_ptr(), tp.desc[i % NB].data_ptr(), tp.n[i % NB].data_ptr(), B)
+            torch.cuda.synchronize()
+            ex.get_profile()
+            t1 = time.perf_counter()
+            for i in range(args.sub_steps):
+                window(3 + i, frames[i % NB], None); ex.extract_dev(frames[i % NB].data_ptr(), tp.kps[i % NB].data_ptr(), tp.desc[i % NB].data_ptr(), tp.n[i % NB].data_ptr(), B)
+            torch.cuda.synchronize()
+            dt_orb = time.perf_counter() - t1
+            oprof, ocalls = ex.get_profile()
+            ex.set_profiling(False)
+        okp = float(tp.n[(args.sub_steps - 1) % NB].float().mean().item())
+        oalg = orb_algorithmic_bytes(ex, okp)
+        odom = max(oprof, key=lambda k: oprof[k][0])
+        o_ms = oprof[odom][0] / max(1, oprof[odom][1])
+        sub["orb"] = {"metric": "ORB frames/sec (640x480 gray, 8-level pyramid, 1000 keypoints + 256-bit rBRIEF)", "value": round(B * args.sub_steps / dt_orb, 1), "unit": "frames/s",
+                      "steps": args.sub_steps, "ms_per_step": round(dt_orb / args.sub_steps * 1e3, 3), "dtype": "u8",
+                      "config": {"workload": "BASELINE configs[1]: ORB only, the se3 streams' frames, window copy inside the timed loop", "frames_per_step": B, "avg_keypoints_per_frame": round(okp, 1)},
+                      "roofline": {"bound": "hbm", "kernel": odom, "achieved": round(oalg.get(odom, 0) * B / (o_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(oalg.get(odom, 0) * B / (o_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(o_ms, 4),
+                                   "kernels_ms_per_step": {k: round(v[0] / max(1, ocalls), 3) for k, v in oprof.items()}}}
+        if cpu_s > 0:
+            r_o = cb.run(cpu_s / 2, seed=rank, full=False)
+            sub["orb"]["cpu_baseline"] = {"value": round(r_o["frames"] / r_o["seconds"], 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                                          "sample": "%d frames through oracle/orb_oracle.cpp (pinned to the real ORBextractor.cc), one thread" % r_o["frames"]}
+        sub["pose"] = pose_line(args.sub_steps, 3, cpu_s, 1024, ranks, local_rank, dev)
+        sub["ba"] = ba_line(max(3, args.sub_steps // 4), 2, cpu_s / 2, args.backend, ranks, local_rank, dev)
 
     workload = ("configs[2]+[3] as the reference's per-frame Track(): extract (ORB + LSD/LBD lines + isLineGood + PEAC planes + voxel clouds / RANSAC refit + surface normals on three streams, ComputeStereoFromRGBD) -> TrackManhattanFrame -> "
                 "SearchByProjection(Cur, Last) + LSD SearchByDescriptor + MatchORBPoints + PlaneMatcher -> TranslationOptimization 4x10 -> isInFrustum + SearchByProjection(map) + "
@@ -523,11 +675,13 @@ def main():
         "config": {"workload": workload, "frames_per_gpu_per_step": B, "distinct_canvases_per_gpu": ncanv,
                    "streams": (f"se3: {B} cameras in {ncanv} textured box rooms, gray + depth ray-cast from the same pose, {args.loop}-frame constant-velocity sweeps (1.2 cm, 0.25 deg per frame) "
                                f"played forwards and backwards; resident in HBM, a strided device copy per step" if se3 else "pan: a 640x480 window moving <= 8 px per step over unrelated gray / depth canvases"),
-                   "window": "every step is a new frame for every stream",
+                   "window": (f"every step shows every stream the next frame of its {args.loop}-frame loop (forwards, then backwards: {2 * args.loop - 2} steps per cycle)" if se3
+                              else "every step is a new window position for every stream"),
                    "pipeline_depth": args.depth, "avg_keypoints_per_frame": round(avg_kp, 1), "input_generation_s": round(t_gen, 1),
                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}, "not_yet_in_workload": nyi,
                    "parallelism": f"frame-sharded x{world}, no collective"},
-        "roofline": roofline, "cpu_baseline": cpu, "latency_b1_ms": latency, "value_pcie_inclusive": pcie,
+        "roofline": roofline, "cpu_baseline": cpu, "parity_sample": parity, "sub_benchmarks": sub, "latency_b1_ms": latency, "value_pcie_inclusive": pcie,
+        "env_overrides": ENV_OVERRIDES,
         "scaling_curve": "this line is one point (n_gpus above); the 1/2/4/8 curve exists only where the driver's SCALE record is not 'skipped'",
     }
     if quality:
@@ -537,23 +691,36 @@ def main():
 
 
 def main_ba(args):
-    """BASELINE configs[4] (0-based: the fifth entry, "Local BA"; DESIGN.md and earlier rounds also called it "config 5" counting from one): local bundle adjustment
-    of 10 free key frames (+ 2 fixed ones that only observe) x 3000 point / line / plane features.  ONE problem; its landmarks (with all
-    their edges) are partitioned over the ranks, every rank linearises its part, and the reduced camera system is all-reduced over RCCL twice
-    per LM trial (planarslam_amd/csrc/ba.hip).  A step = one complete solve (optimize(5), outlier levels, optimize(10), erase flags) through the
-    host-pointer entry point, so the upload of the graph is inside the timed region.  Total work is fixed: "scaling": "strong"."""
-    import numpy as np
+    """`--workload ba`: BASELINE configs[4] as its own command (see ba_line)."""
     import torch
 
-    from planarslam_amd import Communicator, Context, local_bundle_adjustment, shard_problem
     from planarslam_amd.dist import Ranks
-    from planarslam_amd.synth import TUM3, ba_problem
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     local_rank = pick_device(args, torch)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ranks = Ranks(backend=args.backend, device=dev)
+    line = ba_line(args.steps, args.warmup, args.cpu_seconds, args.backend, ranks, local_rank, dev)
+    if line is not None:
+        print(json.dumps(line))
+    ranks.close()
+
+
+def ba_line(steps, warmup, cpu_seconds, backend, ranks, local_rank, dev):
+    """BASELINE configs[4] (0-based: the fifth entry, "Local BA"; DESIGN.md and earlier rounds also called it "config 5" counting from one): local bundle adjustment
+    of 10 free key frames (+ 2 fixed ones that only observe) x 3000 point / line / plane features.  ONE problem; its landmarks (with all
+    their edges) are partitioned over the ranks, every rank linearises its part, and the reduced camera system is all-reduced over RCCL twice
+    per LM trial (planarslam_amd/csrc/ba.hip).  A step = one complete solve (optimize(5), outlier levels, optimize(10), erase flags) through the
+    host-pointer entry point, so the upload of the graph is inside the timed region.  Total work is fixed: "scaling": "strong".  Returns the line on rank 0."""
+    import types
+
+    import numpy as np
+    import torch
+
+    from planarslam_amd import Communicator, Context, local_bundle_adjustment, shard_problem
+    from planarslam_amd.synth import TUM3, ba_problem
+    args = types.SimpleNamespace(steps=steps, warmup=warmup, cpu_seconds=cpu_seconds, backend=backend)
     rank, world = ranks.rank, ranks.world
     ctx = Context(local_rank)
     comm = None
@@ -613,45 +780,59 @@ def main_ba(args):
                                 "sample": "%d solves of the same problem by oracle/ba_oracle.cpp (dense Schur + Cholesky restatement of g2o's LM), one thread" % n}
     if comm is not None:
         comm.close()
-    if rank == 0:
-        print(json.dumps(line))
-    ranks.close()
+    return line if rank == 0 else None
+
+
+_POSE_CPU_BATCH = None
 
 
 def _pose_cpu_chunk(a):
-    """worker of main_pose's all-cores CPU leg (oracle/pose_oracle.cpp on a slice of the batch); top level so that it pickles"""
-    batch, lo, hi, reps = a
+    """worker of pose_line's all-cores CPU leg: `count` problems of the inherited batch from `lo` on (wrapping) through oracle/pose_oracle.cpp"""
+    lo, count = a
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import oracle_lib as ol
     from planarslam_amd.synth import TUM3
-    sl = {k: v[lo:hi] for k, v in batch.items()}
-    t = time.perf_counter()
-    for _ in range(reps):
-        ol.pose_optimize(sl, TUM3, 0, 4, 10)
-    return time.perf_counter() - t
+    nb = len(_POSE_CPU_BATCH["n_points"])
+    idx = (lo + np.arange(count)) % nb
+    sl = {k: np.ascontiguousarray(v[idx]) for k, v in _POSE_CPU_BATCH.items()}
+    ol.pose_optimize(sl, TUM3, 0, 4, 10)
+    return count
 
 
 def main_pose(args):
-    """BASELINE configs[3]: pose-only Levenberg-Marquardt, 1000 point + 150 line (75 lines x 2 end points) + 12 plane (4 planes x plane / parallel / vertical)
-    edges per frame, batch = 256 frames per GPU (synth.pose_batch(B = 256, seed = 7 + 1000 * rank)), resident in HBM.  A step = Optimizer::PoseOptimization
-    (src/Optimizer.cc:550-1275: four rounds of optimize(10) with outlier reclassification) for every frame of the batch: one launch of pose_opt_kernel.  Frames are
-    independent: every rank has its own batch, no collective ("weak")."""
-    import ctypes as C
-
-    import numpy as np
+    """`--workload pose`: BASELINE configs[3] as its own command (see pose_line)."""
     import torch
 
-    from planarslam_amd import Context
-    from planarslam_amd._lib import PoseBatch, check, lib
     from planarslam_amd.dist import Ranks
-    from planarslam_amd.optimizer import make_params
-    from planarslam_amd.synth import TUM3, pose_batch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     local_rank = pick_device(args, torch)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ranks = Ranks(backend=args.backend, device=dev)
+    line = pose_line(args.steps, args.warmup, args.cpu_seconds, args.batch, ranks, local_rank, dev)
+    if line is not None:
+        print(json.dumps(line))
+    ranks.close()
+
+
+def pose_line(steps, warmup, cpu_seconds, batch, ranks, local_rank, dev):
+    """BASELINE configs[3]: pose-only Levenberg-Marquardt, 1000 point + 150 line (75 lines x 2 end points) + 12 plane (4 planes x plane / parallel / vertical)
+    edges per frame, batch = 256 frames per GPU (synth.pose_batch(B = 256, seed = 7 + 1000 * rank)), resident in HBM.  A step = Optimizer::PoseOptimization
+    (src/Optimizer.cc:550-1275: four rounds of optimize(10) with outlier reclassification) for every frame of the batch: one launch of pose_opt_kernel.  Frames are
+    independent: every rank has its own batch, no collective ("weak").  Returns the line on rank 0."""
+    import ctypes as C
+    import types
+
+    import numpy as np
+    import torch
+
+    from planarslam_amd import Context
+    from planarslam_amd._lib import PoseBatch, check, lib
+    from planarslam_amd.optimizer import make_params
+    from planarslam_amd.synth import TUM3, pose_batch
+    args = types.SimpleNamespace(steps=steps, warmup=warmup, cpu_seconds=cpu_seconds, batch=batch)
     rank, world = ranks.rank, ranks.world
     B = 256 if args.batch == 1024 else args.batch                 # (--batch keeps its default for the full workload; this one is quoted on 256)
     host = pose_batch(B=B, n_points=1000, n_lines=75, n_planes=4, seed=7 + 1000 * rank)
@@ -691,8 +872,7 @@ def main_pose(args):
     el_1, k_1, it_1 = run(1, 10, args.steps, args.warmup)        # one optimize(10): the "10 iters" protocol of BASELINE.md
     el, k_ms, lm_it = run(4, 10, args.steps, args.warmup)         # the reference's PoseOptimization: 4 x optimize(10)
     if rank != 0:
-        ranks.close()
-        return
+        return None
     # parity of this very batch with the real optimiser is tests/test_pose_gpu.py::test_pose_hip_equals_reference_fixture (c4_b256)
     alg = 65130 * B * lm_it                                       # bytes of one LM evaluation of one frame x measured LM iterations per frame
     line = {"metric": "pose-only LM problems/sec (1000 point + 150 line + 12 plane edges, 4 x 10 iterations, batch 256 per GPU)", "value": round(B * world * args.steps / el, 1),
@@ -718,20 +898,25 @@ def main_pose(args):
         line["cpu_baseline"] = {"value": round(one, 2), "unit": "problems/s", "cores": 1, "kind": "port",
                                 "sample": "%d x the first %d problems of the batch through oracle/pose_oracle.cpp (g2o's LM restated, pinned to the real Optimizer.cc: tests/test_oracle_opt_ref.py), one thread" % (n, nb)}
         try:
+            # all host cores: a persistent pool of forked workers (the batch and the warm oracle import are inherited, nothing is pickled but two integers), every
+            # worker solves 32 problems of the batch per task; one untimed task per worker first (page-in, first call), then the timed map
             import multiprocessing as mp
             ncores = os.cpu_count() or 1
-            full = {k: np.ascontiguousarray(v) for k, v in host.items() if k != "T_gt"}
-            per = max(1, B // ncores)
-            jobs = [(full, lo, min(B, lo + per), 2) for lo in range(0, B, per)]
-            t1 = time.perf_counter()
-            with mp.get_context("fork").Pool(min(ncores, len(jobs))) as pool:
-                pool.map(_pose_cpu_chunk, jobs)
-            line["cpu_baseline"]["all_cores"] = {"value": round(2 * B / (time.perf_counter() - t1), 1), "unit": "problems/s", "cores": min(ncores, len(jobs)),
-                                                 "sample": "the whole batch twice, one worker process per %d problems" % per}
+            global _POSE_CPU_BATCH
+            _POSE_CPU_BATCH = {k: np.ascontiguousarray(v) for k, v in host.items() if k != "T_gt"}
+            per = 32
+            jobs = [((w * per) % B, per) for w in range(ncores)]
+            with mp.get_context("fork").Pool(ncores) as pool:
+                pool.map(_pose_cpu_chunk, [(j[0], 2) for j in jobs], chunksize=1)
+                t1 = time.perf_counter()
+                pool.map(_pose_cpu_chunk, jobs, chunksize=1)
+                dt_all = time.perf_counter() - t1
+            line["cpu_baseline"]["all_cores"] = {"value": round(per * ncores / dt_all, 1), "unit": "problems/s", "cores": ncores,
+                                                 "sample": "%d forked workers (persistent pool, oracle imported and batch inherited before the fork, one untimed warm-up task each), "
+                                                           "each solving %d problems of the batch" % (ncores, per)}
         except Exception as e:                                    # (a box without fork / enough memory: the one-thread figure stands)
             line["cpu_baseline"]["all_cores"] = {"error": type(e).__name__}
-    print(json.dumps(line))
-    ranks.close()
+    return line
 
 
 if __name__ == "__main__":

@@ -428,6 +428,10 @@ int planar_lsd_extract_dev(planar_lsd* lsd, const uint8_t* d_gray, int B, int pi
  * detect = region growing / NFA, KeyLines, LBD.  planar_lsd_detect_dev returns PLANAR_ESTATE without a matching preprocess. */
 int planar_lsd_preprocess_dev(planar_lsd* lsd, const uint8_t* d_gray, int B, int pitch, int64_t frame_stride);
 int planar_lsd_detect_dev(planar_lsd* lsd, int B, int max_lines, planar_keyline* d_keylines, uint8_t* d_ldesc, double* d_line_eq, int32_t* d_n_lines);
+/* Per-frame status of the last detect / extract call (synchronises the context's stream).  n_lines is never negative: a frame whose workspace overflowed (more
+ * regions / segments than it holds) or whose std::sort order could not be reproduced delivers ZERO lines, and this call (which planar_lsd_extract makes itself)
+ * returns PLANAR_ECAPACITY naming the frame; planar_last_error() has the reason.  The device entry points never synchronise: their callers check when they read back. */
+int planar_lsd_check(planar_lsd* lsd, int B);
 /* diagnostics (tests / profiling; stage 5 = cycle counters, see lsd.hip): stage 0 level-line angle float deg [w*h] (-1024 undefined), 1 squared gradient u32 [w*h],
  * 2 visiting order int32 (returns n), 3 raw segments 40 B each {x1,y1,x2,y2 float; width,p,nfa double} (returns count),
  * 4 number of grown regions int32[1] */
@@ -463,6 +467,10 @@ int planar_peac_segment_dev(planar_peac* peac, const uint16_t* d_depth, int B, i
 int planar_peac_debug_layout(planar_peac* peac, int64_t* out /* [12] */);
 int planar_peac_debug_read(planar_peac* peac, int frame, int64_t offset, int64_t bytes, void* out);
 int planar_peac_check(planar_peac* peac, int B);
+/* A/B aid (tools/peac_ab.py and the tests; nothing in the product calls it, and no environment variable selects a kernel): clustering 0 = product (fast attempt +
+ * exact redo), 1 = exact heap only, 2 = the round-2 clustering kernel; wide_below = batch size up to which the refinement runs 1024 threads per frame (< 0: keep).
+ * Every variant returns the same labels and planes. */
+int planar_peac_set_variant(planar_peac* peac, int clustering, int wide_below);
 /* Per-launch timing with HIP events on the context stream (bench.py's roofline leg), as planar_orb_set_profiling: get_profile synchronises and returns the
  * summed milliseconds of the four launches of the recorded calls (total_ms[4] = peac_blocks, peac_ahc, peac_order, peac_refine), their number, and resets. */
 int planar_peac_set_profiling(planar_peac* peac, int enable);

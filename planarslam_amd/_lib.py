@@ -163,6 +163,7 @@ _SIGS = {
     "planar_lsd_extract_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_lsd_preprocess_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64]),
     "planar_lsd_detect_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "planar_lsd_check": (C.c_int, [C.c_void_p, C.c_int]),
     "planar_lsd_read_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "planar_debug_std_sort_desc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "planar_peac_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -171,6 +172,7 @@ _SIGS = {
     "planar_peac_segment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_peac_segment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_peac_check": (C.c_int, [C.c_void_p, C.c_int]),
+    "planar_peac_set_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "planar_track_manhattan_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_track_manhattan_frame_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_peac_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

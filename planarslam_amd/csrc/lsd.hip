@@ -1326,7 +1326,9 @@ __global__ __launch_bounds__(64) void lsd_keylines(const Plan* __restrict__ plan
     };
     if (n <= LDS_SORT) body(key_l, idx_l);
     else body((float*)(F + P.off_tmp), (int*)(F + P.off_tmp) + MAX_SEGS);
-    if (lane == 0) { n_out[b] = misc->status ? -misc->status : nk; misc->n_kl = nk; }   // a frame whose workspace overflowed (1) or whose sort is not reproducible (2, 3) reports -status
+    // a frame whose workspace overflowed (status 1) or whose sort is not reproducible (2, 3) delivers ZERO lines - the count the device consumers read stays >= 0 - and
+    // reports its status through planar_lsd_check
+    if (lane == 0) { n_out[b] = misc->status ? 0 : nk; misc->n_kl = nk; }
 }
 
 // ---- K7: LBD (BinaryDescriptor::computeLBD + binaryConversion), one wavefront per kept line ----------------------------
@@ -1726,8 +1728,23 @@ int planar_lsd_extract(planar_lsd* o, const uint8_t* gray, int B, int pitch, int
     PLANAR_HIP_CHECK(hipMemcpyAsync(line_eq, o->d_eq.p, n * 24, hipMemcpyDeviceToHost, st));
     PLANAR_HIP_CHECK(hipMemcpyAsync(n_lines, o->d_n.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+    return planar_lsd_check(o, B);
+}
+
+// Per-frame status of the last detect call (synchronises): PLANAR_ECAPACITY if a frame's workspace overflowed (more regions / rectangles / segments than it holds: code 1)
+// or its std::sort order could not be reproduced (2, 3).  Such a frame delivered zero lines.
+int planar_lsd_check(planar_lsd* o, int B) {
+    PLANAR_REQUIRE(o && B >= 1 && B <= o->max_batch, PLANAR_EINVAL, "bad argument");
+    PLANAR_HIP_CHECK(hipSetDevice(o->ctx->device));
+    PLANAR_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
+    std::vector<lsd::Misc> m(B);
+    PLANAR_HIP_CHECK(hipMemcpy(m.data(), o->d_misc.p, (size_t)B * sizeof(lsd::Misc), hipMemcpyDeviceToHost));
     for (int b = 0; b < B; b++)
-        if (n_lines[b] < 0) { set_error("planar_lsd_extract: frame %d: %s", b, n_lines[b] == -1 ? "more regions / segments than the workspace holds" : "the std::sort order of the gradient pixels is not reproducible (introsort depth limit / sort workspace)"); return PLANAR_ECAPACITY; }
+        if (m[b].status != 0) {
+            set_error("planar_lsd: frame %d (zero lines delivered): %s (code %d)", b, m[b].status == 1 ? "more regions / segments than the workspace holds"
+                      : "the std::sort order of the gradient pixels is not reproducible (introsort depth limit / sort workspace)", m[b].status);
+            return PLANAR_ECAPACITY;
+        }
     return PLANAR_OK;
 }
 

@@ -1023,9 +1023,10 @@ struct planar_peac {
     peac::Layout L{};
     peac::Consts C{};
     int smem = 0, smem2 = 0;
-    int wide_below = 64;                                      // batches up to this size refine with 1024 threads per frame (PLANAR_PEAC_WIDE overrides; 0 = never)
-    bool exact_only = false;                                  // PLANAR_PEAC_AHC=exact: skip the fast attempt (tests / A-B runs)
-    bool legacy_ahc = false;                                  // PLANAR_PEAC_AHC=legacy: the round-2 clustering kernel (eager neighbour lists), for A/B runs
+    // kernel variants, set only through planar_peac_set_variant (tools' A/B runs and tests; no environment switch reaches the product path)
+    int wide_below = 64;                                      // batches up to this size refine with 1024 threads per frame (0 = never)
+    bool exact_only = false;                                  // skip the fast clustering attempt: every frame through the exact heap
+    bool legacy_ahc = false;                                  // the round-2 clustering kernel (eager neighbour lists)
     DevBuf d_ws, d_status, d_timing, d_next, d_order;
     int order_B = 0;                                          // batch size d_order was computed for (0: none yet)
     DevBuf d_depth, d_labels, d_planes, d_nplanes;   // staging for the host-pointer entry point
@@ -1050,8 +1051,6 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     o->C = peac::make_consts();
     const peac::Layout& L = o->L;
     o->smem2 = peac::ahc2_smem_bytes(L);
-    { const char* e = getenv("PLANAR_PEAC_AHC"); o->legacy_ahc = e && !strcmp(e, "legacy"); o->exact_only = e && !strcmp(e, "exact"); }
-    { const char* e = getenv("PLANAR_PEAC_WIDE"); if (e) o->wide_below = atoi(e); }
     // peac_ahc (legacy): heap keys + ids, neighbour-list pool, list offsets / counts, set sizes, root ids, dead / cache-valid bits
     o->smem = L.NB * 4 + L.NB * 2 + 2 * ((L.NB2 + 31) / 32) * 4 + L.NB + 16;
     if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem > 150 * 1024 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d needs %d B of LDS for the merge heap", width, height, o->smem); return PLANAR_EINVAL; }
@@ -1067,6 +1066,14 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
 }
 
 void planar_peac_destroy(planar_peac* p) { delete p; }
+// A/B aid (tools/peac_ab.py, tests): clustering variant 0 = product (fast attempt + exact redo), 1 = exact only, 2 = the round-2 kernel; wide_below < 0 keeps the default.
+// All variants produce the same labels and planes; nothing in the product calls this.
+int planar_peac_set_variant(planar_peac* p, int clustering, int wide_below) {
+    PLANAR_REQUIRE(p && clustering >= 0 && clustering <= 2, PLANAR_EINVAL, "bad argument");
+    p->exact_only = clustering == 1; p->legacy_ahc = clustering == 2;
+    if (wide_below >= 0) p->wide_below = wide_below;
+    return PLANAR_OK;
+}
 int planar_peac_max_planes(void) { return peac::MAX_PLANES; }
 
 int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int pitch_px, int64_t frame_stride_px, float fx, float fy,

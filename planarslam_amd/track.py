@@ -144,8 +144,17 @@ class TrackPipeline:
             for k, v in a.items():
                 setattr(pb, k, v.data_ptr())
             self.pb_arrays.append(a); self.pbs.append(pb)
-        import os
-        self.skip = set(os.environ.get("PLANAR_TRACK_SKIP", "").split(","))     # timing diagnosis only (tools): leave a stage's launches out, results are then meaningless
+        # Frame::ComputeImageBounds (Frame.cc:573-598): the four image corners through cv::undistortPoints when k1 != 0; mfGridElement*Inv from them (:122-123)
+        self.bounds = (0.0, float(W), 0.0, float(H))
+        if self.dist_coef is not None:
+            cr = t.zeros((1, 4, 7), dtype=t.float32, device=self.dev)
+            cr[0, :, 0] = t.tensor([0.0, W, 0.0, W], device=self.dev); cr[0, :, 1] = t.tensor([0.0, 0.0, H, H], device=self.dev)
+            cu = t.zeros_like(cr); n4 = t.full((1,), 4, dtype=t.int32, device=self.dev)
+            c = self.cam
+            check(self.L.planar_undistort_keypoints_dev(self.ctx.h, 1, cr.data_ptr(), n4.data_ptr(), 4, c["fx"], c["fy"], c["cx"], c["cy"], self.dist_coef.ctypes.data, cu.data_ptr()))
+            self.stream.synchronize()
+            m = cu[0, :, :2].cpu().numpy()
+            self.bounds = (float(min(m[0, 0], m[2, 0])), float(max(m[1, 0], m[3, 0])), float(min(m[0, 1], m[1, 1])), float(max(m[2, 1], m[3, 1])))
         self.pending = []
         self.map_set = False
         self.rcm0_set = False           # Rotation_cm is fixed by the first tracked frame
@@ -173,6 +182,7 @@ class TrackPipeline:
             self.Rcm0 = self.Rcm.clone()
         self.plane_th = np.array([0.1, 0.86, 0.08716, 0.9962], np.float32)      # include/PlaneMatcher.h:19
         self.map_set = True
+        self.rcm0_set = False           # a new map: Rotation_cm is refined again by the first tracked frame (src/Tracking.cc:227-230)
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def _frame_view(self, k, Tcw, blocked=None):
@@ -181,8 +191,9 @@ class TrackPipeline:
         fv.n, fv.keys_un, fv.u_right, fv.desc = self.n[k].data_ptr(), self.kpu[k].data_ptr(), self.ur[k].data_ptr(), self.desc[k].data_ptr()
         fv.blocked = blocked.data_ptr() if blocked is not None else None
         fv.Tcw = Tcw.data_ptr()
-        fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(self.W), 0.0, float(self.H)
-        fv.grid_w_inv, fv.grid_h_inv = 64.0 / self.W, 48.0 / self.H
+        fv.min_x, fv.max_x, fv.min_y, fv.max_y = self.bounds
+        fv.grid_w_inv = float(np.float32(64.0) / np.float32(np.float32(fv.max_x) - np.float32(fv.min_x)))
+        fv.grid_h_inv = float(np.float32(48.0) / np.float32(np.float32(fv.max_y) - np.float32(fv.min_y)))
         c = self.cam
         fv.fx, fv.fy, fv.cx, fv.cy, fv.bf, fv.b = c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], c["bf"] / c["fx"]
         for i, v in enumerate(self.sf):
@@ -209,6 +220,46 @@ class TrackPipeline:
         m.Tcw = Tcw.data_ptr()
         check(self.L.planar_pose_assemble_dev(self.ctx_t.h, C.byref(m), C.byref(self.pbs[which])))
 
+    # ---- the extraction stages of one step, each on the stream the reference's thread of that name stands for (src/Frame.cc:90-95) ----
+    def _lines_head(self, k, gray):
+        """LineSegment::ExtractLineSegment, first half (smoothing, gradients, the pixel order) - line stream"""
+        check(self.L.planar_lsd_preprocess_dev(self.lss[k].h, gray.data_ptr(), self.B, self.W, self.W * self.H))
+
+    def _planes(self, k, depth):
+        """PlaneDetection (PEAC) - plane stream"""
+        self.pds[k].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), self.B)
+
+    def _plane_clouds(self, k, depth):
+        """Frame::ComputePlanes' voxel clouds + RANSAC refit (Frame.cc:655-692) - plane stream"""
+        pc = self.pc[k]
+        self.pcs[k].compute_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), self.B, pc["n"].data_ptr(), pc["coef"].data_ptr(),
+                                pc["src"].data_ptr(), pc["off"].data_ptr(), pc["pts"].data_ptr(), pc["status"].data_ptr(), dist_th=self.plane_dist_th,
+                                K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
+
+    def _normals(self, k, depth):
+        """Frame::ComputePlanes' surface normals - plane stream"""
+        self.sns[k].compute_dev(depth.data_ptr(), self.snrm[k].data_ptr(), self.B, K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
+
+    def _lines_tail(self, i, k, depth):
+        """ExtractLineSegment, second half (region growing, NFA, key lines, LBD), then Frame::isLineGood right behind it on the same thread - line stream"""
+        L, B = self.L, self.B
+        check(L.planar_lsd_detect_dev(self.lss[k].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
+        l3 = self.l3[k]                                     # every (stream, step, line) has its own rand() seed
+        check(L.planar_add_scalar_i32_dev(self.ctx_lsds[k].h, self.seed_base.data_ptr(), self.seed_base.numel(), (i * B * 64) & 0x3fffffff, l3["seeds"].data_ptr()))
+        c = self.cam
+        check(L.planar_is_line_good_dev(self.ctx_lsds[k].h, B, self.kls[k].data_ptr(), self.nl[k].data_ptr(), 40, depth.data_ptr(), self.W, self.H, self.W, self.W * self.H,
+                                        float(np.float32(1.0 / 5000.0)), c["fx"], c["fy"], c["cx"], c["cy"], l3["seeds"].data_ptr(), l3["depth_line"].data_ptr(),
+                                        l3["lines3d"].data_ptr(), l3["good"].data_ptr(), l3["direction"].data_ptr(), l3["n_inliers"].data_ptr(), l3["packed"].data_ptr(),
+                                        l3["n_good"].data_ptr()))
+
+    def _points(self, k, gray):
+        """ORBextractor::operator() (+ Frame::UndistortKeyPoints for a distorting camera) - main stream"""
+        self.ex.extract_dev(gray.data_ptr(), self.kps[k].data_ptr(), self.desc[k].data_ptr(), self.n[k].data_ptr(), self.B)
+        if self.dist_coef is not None:
+            c = self.cam
+            check(self.L.planar_undistort_keypoints_dev(self.ctx.h, self.B, self.kps[k].data_ptr(), self.n[k].data_ptr(), self.S, c["fx"], c["fy"], c["cx"], c["cy"],
+                                                        self.dist_coef.ctypes.data, self.kpu[k].data_ptr()))
+
     # ------------------------------------------------------------------------------------------------------------------------------
     def step(self, i, gray, depth, evs=None, side=None):
         """Enqueue step i: extraction of `gray` [B,H,W] u8 / `depth` [B,H,W] i16-as-u16 (device tensors that stay valid until the step's
@@ -221,36 +272,15 @@ class TrackPipeline:
         if evs: evs["start"].record(st)
         sl.wait_event(self.ev_in[k]); sp.wait_event(self.ev_in[k])
         if side: side[2].record(sl)
-        if "lsd" not in self.skip:
-            check(L.planar_lsd_preprocess_dev(self.lss[k].h, gray.data_ptr(), B, self.W, self.W * self.H))
+        self._lines_head(k, gray)
         if side: side[0].record(sp)
-        if "peac" not in self.skip:
-            self.pds[k].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), B)
-        if "planepost" not in self.skip:
-            pc = self.pc[k]
-            self.pcs[k].compute_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), B, pc["n"].data_ptr(), pc["coef"].data_ptr(),
-                                    pc["src"].data_ptr(), pc["off"].data_ptr(), pc["pts"].data_ptr(), pc["status"].data_ptr(), dist_th=self.plane_dist_th,
-                                    K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
-        if "normals" not in self.skip:
-            self.sns[k].compute_dev(depth.data_ptr(), self.snrm[k].data_ptr(), B, K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
-        if "lsd" not in self.skip:
-            check(L.planar_lsd_detect_dev(self.lss[k].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
-        # Frame::ExtractLSD: isLineGood right behind ExtractLineSegment, same thread; every (stream, step, line) has its own rand() seed
-        l3 = self.l3[k]
-        check(L.planar_add_scalar_i32_dev(self.ctx_lsds[k].h, self.seed_base.data_ptr(), self.seed_base.numel(), (i * B * 64) & 0x3fffffff, l3["seeds"].data_ptr()))
-        c = self.cam
-        check(L.planar_is_line_good_dev(self.ctx_lsds[k].h, B, self.kls[k].data_ptr(), self.nl[k].data_ptr(), 40, depth.data_ptr(), self.W, self.H, self.W, self.W * self.H,
-                                        float(np.float32(1.0 / 5000.0)), c["fx"], c["fy"], c["cx"], c["cy"], l3["seeds"].data_ptr(), l3["depth_line"].data_ptr(),
-                                        l3["lines3d"].data_ptr(), l3["good"].data_ptr(), l3["direction"].data_ptr(), l3["n_inliers"].data_ptr(), l3["packed"].data_ptr(),
-                                        l3["n_good"].data_ptr()))
+        self._planes(k, depth)
+        self._plane_clouds(k, depth)
+        self._normals(k, depth)
+        self._lines_tail(i, k, depth)
         if side: side[1].record(sp); side[3].record(sl)
         self.join_p[k].record(sp); self.join_l[k].record(sl)
-        if "orb" not in self.skip:
-            self.ex.extract_dev(gray.data_ptr(), self.kps[k].data_ptr(), self.desc[k].data_ptr(), self.n[k].data_ptr(), B)
-            if self.dist_coef is not None:
-                c = self.cam
-                check(self.L.planar_undistort_keypoints_dev(self.ctx.h, B, self.kps[k].data_ptr(), self.n[k].data_ptr(), self.S, c["fx"], c["fy"], c["cx"], c["cy"],
-                                                            self.dist_coef.ctypes.data, self.kpu[k].data_ptr()))
+        self._points(k, gray)
         if evs: evs["orb"].record(st)
         # Frame::ComputeStereoFromRGBD: mvuRight / mvDepth of the new keypoints (the world points come after the pose is known)
         self._stereo(self.ctx, k, self.pose0, depth, self.ur[k], self.zd[k], self.xw_tmp, self.valid_tmp)
@@ -401,6 +431,8 @@ class TrackPipeline:
         check(self.ex.L.planar_orb_check(self.ex.h))
         for q in self.pds:
             check(q.L.planar_peac_check(q.h, self.B))
+        for q in self.lss:
+            check(self.L.planar_lsd_check(q.h, self.B))
         for k, pc in enumerate(self.pc):
             bad = pc["status"].nonzero()
             if len(bad):

@@ -1,7 +1,8 @@
 """The bench's pipelined schedule (planarslam_amd/track.py: five streams, buffer sets reused across steps, the tracking chain of step i - depth
 enqueued behind the extraction of step i) checked against the CPU oracle, stage by stage and frame by frame.
 
-B = 64 camera streams, five steps; the last two steps (both with a full tracking chain, overlapping the extraction launches of later steps) have
+Run twice: on the panned canvases of rounds 1-3 and on the SE3-rendered streams bench.py times by default (same renderer, same pipeline depth, the LSD in its top-lines
+mode: what the driver's bench line is made of is what is compared here).  B = 64 camera streams, five (pan) / seven (se3) steps; the last two steps (both with a full tracking chain, overlapping the extraction launches of later steps) have
 every stage's inputs and outputs cloned on the stream (TrackPipeline.capture_steps).  Each oracle stage is fed the DEVICE's inputs of that stage
 (so a 1e-5 difference of an optimiser cannot snowball into different matches downstream) and must reproduce the device's outputs: bit-exact for
 extraction, stereo, all matchers, frustum, assembly; 1e-5 on poses / rotation with identical outlier flags for the optimisers and the Manhattan tracker.
@@ -14,29 +15,44 @@ from planarslam_amd._lib import KEYLINE_DTYPE
 from planarslam_amd.synth import TUM3, pan_offset, scale_factors
 
 pytestmark = pytest.mark.gpu
-B, W, H, MARGIN, STEPS, DEPTH = 64, 640, 480, 48, 5, 2
+B, W, H, MARGIN = 64, 640, 480, 48
+# "pan": rounds 1-3's input (a window panning over unrelated gray / depth canvases).  "se3": THE INPUT bench.py TIMES BY DEFAULT (--streams se3): cameras moving through
+# textured box rooms, gray and depth of a frame ray-cast from one pose (planarslam_amd/synth_se3.py), with bench.py's pipeline depth and its 12-frame loop.
+KINDS = {"pan": dict(depth=2, steps=5, tag=""), "se3": dict(depth=3, steps=7, tag="se3/", loop=12)}
 
 
-def run_pipeline():
+def run_pipeline(kind="pan"):
     import torch
     from planarslam_amd.synth import stream_canvases
     from planarslam_amd.track import TrackPipeline, build_map
+    cfg = KINDS[kind]
+    STEPS, DEPTH = cfg["steps"], cfg["depth"]
     cg, cd = stream_canvases(16, 3, W + 2 * MARGIN, H + 2 * MARGIN, procs=8)
     dev = torch.device("cuda", 0)
-    dg, dd = torch.from_numpy(cg).to(dev), torch.from_numpy(cd.view(np.int16)).to(dev)
-    goff = [(24 * (g & 1), 24 * ((g >> 1) & 1)) for g in range(4)]
+    if kind == "se3":
+        # as bench.py: the canvases are the rooms' textures, stream s lives in room s mod 16 on its own SE3 path; every stream has its own first frame, hence its own map
+        from planarslam_amd import synth_se3
+        loop_g, loop_d, _ = synth_se3.render_streams(torch, torch.from_numpy(cg).to(dev), B, cfg["loop"], TUM3, seed=3, W=W, H=H)
+        loop_g, loop_d = loop_g.cpu().numpy(), loop_d.cpu().numpy().view(np.uint16)
 
-    def window_np(i):
-        ox, oy = pan_offset(i, MARGIN)
-        g = np.zeros((B, H, W), np.uint8); d = np.zeros((B, H, W), np.uint16)
-        for q in range(4):
-            x0, y0 = ox + goff[q][0], oy + goff[q][1]
-            g[q * 16:(q + 1) * 16] = cg[:, y0:y0 + H, x0:x0 + W]; d[q * 16:(q + 1) * 16] = cd[:, y0:y0 + H, x0:x0 + W]
-        return g, d
+        def window_np(i):
+            fi = synth_se3.frame_index(i, cfg["loop"])
+            return np.ascontiguousarray(loop_g[:, fi]), np.ascontiguousarray(loop_d[:, fi])
+    else:
+        goff = [(24 * (g & 1), 24 * ((g >> 1) & 1)) for g in range(4)]
+
+        def window_np(i):
+            ox, oy = pan_offset(i, MARGIN)
+            g = np.zeros((B, H, W), np.uint8); d = np.zeros((B, H, W), np.uint16)
+            for q in range(4):
+                x0, y0 = ox + goff[q][0], oy + goff[q][1]
+                g[q * 16:(q + 1) * 16] = cg[:, y0:y0 + H, x0:x0 + W]; d[q * 16:(q + 1) * 16] = cd[:, y0:y0 + H, x0:x0 + W]
+            return g, d
     tp = TrackPipeline(B, torch, 0, depth=DEPTH)
     g0, d0 = window_np(0)
-    kf, mp, sn = build_map(g0[:16], d0[:16], TUM3, seed=1)
-    rep = lambda a: np.concatenate([a] * 4)[:B]
+    nmap = B if kind == "se3" else 16
+    kf, mp, sn = build_map(g0[:nmap], d0[:nmap], TUM3, seed=1)
+    rep = lambda a: np.concatenate([a] * (B // nmap))[:B]
     maps = ({k: rep(v) for k, v in kf.items()}, {k: rep(v) for k, v in mp.items()}, {k: rep(v) for k, v in sn.items()})
     tp.set_map(*maps)
     tp.capture_steps = {STEPS - 2, STEPS - 1}
@@ -55,12 +71,12 @@ def run_pipeline():
     torch.cuda.synchronize()
     tp.check()
     cap = {j: {k: ({kk: vv.cpu().numpy() for kk, vv in v.items()} if isinstance(v, dict) else v.cpu().numpy()) for k, v in c.items()} for j, c in tp.captured.items()}
-    return dict(tp=tp, cap=cap, inputs=inputs, maps=maps, S=tp.S, PS=tp.PS, sf=np.asarray(tp.sf, np.float32), lsf=tp.lsf)
+    return dict(tp=tp, cap=cap, inputs=inputs, maps=maps, S=tp.S, PS=tp.PS, sf=np.asarray(tp.sf, np.float32), lsf=tp.lsf, kind=kind, steps=STEPS, tag=cfg["tag"])
 
 
-@pytest.fixture(scope="module")
-def run():
-    return run_pipeline()
+@pytest.fixture(scope="module", params=["pan", "se3"])
+def run(request):
+    return run_pipeline(request.param)
 
 
 def oracle_chain_coefficients(c, d):
@@ -106,7 +122,7 @@ def _frame_dict(c, Tcw, blocked=None):
 
 @pytest.mark.parametrize("which", [0, 1])
 def test_extraction_of_a_pipelined_step(run, which):
-    j = STEPS - 2 + which
+    j = run["steps"] - 2 + which
     c, (g, d) = run["cap"][j], run["inputs"][j]
     o = ol.OrbOracle()
     kl = c["kls"].view(KEYLINE_DTYPE).reshape(B, 40)
@@ -124,7 +140,7 @@ def test_extraction_of_a_pipelined_step(run, which):
 
 @pytest.mark.parametrize("which", [0, 1])
 def test_tracking_chain_of_a_pipelined_step(run, which):
-    j = STEPS - 2 + which
+    j = run["steps"] - 2 + which
     c, (g, d) = run["cap"][j], run["inputs"][j]
     S, PS, sf, lsf = run["S"], run["PS"], run["sf"], run["lsf"]
     kf, mp, sn = run["maps"]
@@ -184,7 +200,9 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
     # the tracked one - within TrackManhattanFrame's own frame-to-frame scatter on these scenes (median ~0.6 deg, a few streams several degrees: measured by
     # tools/manhattan_probe.py), which costs TranslationOptimization inliers on those streams exactly as it would cost the reference
     rot_gap = np.abs(T["Tcw_in"].reshape(B, 4, 4)[:, :3, :3] - c["pose_in"].reshape(B, 4, 4)[:, :3, :3]).max((1, 2))
-    assert np.median(rot_gap) < 0.03 and rot_gap.max() < 0.25, (float(np.median(rot_gap)), float(rot_gap.max()))
+    # (se3 rooms: the walls ARE a Manhattan frame that turns against the camera, 0.25 deg per frame; the bound is a sanity check of the scene, not a parity statement)
+    print(f"[{run['kind']}] Manhattan rotation vs tracked rotation: median {np.median(rot_gap):.4f}, max {rot_gap.max():.4f}; TranslationOptimization inliers {T['n_inliers'].mean():.0f}")
+    assert np.median(rot_gap) < 0.03 and rot_gap.max() < (0.25 if run["kind"] == "pan" else 0.5), (float(np.median(rot_gap)), float(rot_gap.max()))
     assert T["n_inliers"].mean() > 300, float(T["n_inliers"].mean())
     for b in range(0, B, 11):
         n = int(c["n"][b])
@@ -196,7 +214,7 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
     pbT = {k: T[k] for k in KEYS_P}
     pbT["Tcw"] = T["Tcw_in"]
     # the REAL TranslationOptimization on the captured problems: 1e-5 on EVERY frame, identical inlier counts and outlier flags
-    r = _real_optimiser(pbT, 1, f"step{which}/T")
+    r = _real_optimiser(pbT, 1, f"{run['tag']}step{which}/T")
     dT = np.abs(r["Tcw"] - T["Tcw_out"]).max(1)
     assert dT.max() <= 1e-5, (r["source"], float(dT.max()), np.nonzero(dT > 1e-5)[0].tolist())
     assert np.array_equal(r["n_inliers"], T["n_inliers"])
@@ -240,7 +258,7 @@ def test_tracking_chain_of_a_pipelined_step(run, which):
     pbP["Tcw"] = Pp["Tcw_in"]
     assert np.array_equal(Pp["Tcw_in"], T1)
     # the REAL PoseOptimization on the captured problems: 1e-5 on EVERY frame, identical inlier counts and outlier flags (src/Optimizer.cc:550-1275)
-    r = _real_optimiser(pbP, 0, f"step{which}/P")
+    r = _real_optimiser(pbP, 0, f"{run['tag']}step{which}/P")
     dT = np.abs(r["Tcw"] - Pp["Tcw_out"]).max(1)
     assert dT.max() <= 1e-5, (r["source"], float(dT.max()), np.nonzero(dT > 1e-5)[0].tolist())
     assert np.array_equal(r["n_inliers"], Pp["n_inliers"])
@@ -273,7 +291,7 @@ def test_pose_with_the_oracles_own_plane_chain(run, which):
     mvPlaneCoefficients the oracle's to 1e-6.  With the ORACLE's own plane chain in place of the device's, PlaneMatcher makes the same associations on every
     frame and the REAL optimisers (oracle/_ref/ref_opt) return the device's pose within 1e-5 on EVERY frame, for both TranslationOptimization and
     PoseOptimization, with identical inlier counts and outlier flags."""
-    j = STEPS - 2 + which
+    j = run["steps"] - 2 + which
     c, (g, d) = run["cap"][j], run["inputs"][j]
     kf, mp, sn = run["maps"]
     coef_o = np.zeros_like(c["pl_coef"])
@@ -297,7 +315,7 @@ def test_pose_with_the_oracles_own_plane_chain(run, which):
         pb["pl_meas"] = np.ascontiguousarray(coef_o[:, :MM]).astype(np.float32)      # Frame::mvPlaneCoefficients of the oracle's chain; associations unchanged (checked above)
         assert np.array_equal((pb["pl_meas"] != 0).any(2), (Q["pl_meas"] != 0).any(2))
         pb["Tcw"] = Q["Tcw_in"]
-        r = _real_optimiser(pb, mode, f"step{which}/{name}_oracle_chain")
+        r = _real_optimiser(pb, mode, f"{run['tag']}step{which}/{name}_oracle_chain")
         dT = np.abs(r["Tcw"] - Q["Tcw_out"]).max(1)
         assert dT.max() <= 1e-5, (name, r["source"], float(dT.max()), np.nonzero(dT > 1e-5)[0].tolist())
         assert np.array_equal(r["n_inliers"], Q["n_inliers"]), name

@@ -1,5 +1,5 @@
 """Generate tests/golden/track_pose_ref.npz ON THE GPU BOX: the pose problems the pipelined Track() step assembles on the device (tests/test_track_gpu.py: 64 streams,
-the last two of five steps) through the REAL reference optimiser, oracle/_ref/ref_opt = src/Optimizer.cc:550-1275 (PoseOptimization) and :2995-3738
+the last two steps of the panned and of the SE3-rendered run) through the REAL reference optimiser, oracle/_ref/ref_opt = src/Optimizer.cc:550-1275 (PoseOptimization) and :2995-3738
 (TranslationOptimization) + the vendored g2o, compiled where they lie.  Stored: the reference's poses, inlier counts and outlier flags, and a digest of every
 problem (the pipeline is deterministic: tests/test_track_gpu.py recomputes the digest before it trusts the fixture).
     gpurun -- 'python tools/gen_golden_track_pose.py gpurun_out/track_pose_ref.npz'   then copy the file to tests/golden/."""
@@ -16,44 +16,33 @@ import test_track_gpu as tt  # noqa: E402
 from planarslam_amd.synth import TUM3  # noqa: E402
 
 out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "track_pose_ref.npz")
-run = tt.run_pipeline()
 out = {}
-for which in (0, 1):
-    j = tt.STEPS - 2 + which
-    c, (g, d) = run["cap"][j], run["inputs"][j]
-    coef_o = tt.oracle_chain_coefficients(c, d)
-    for name, mode, tag in (("pbT", 1, "T"), ("pbP", 0, "P")):
-        Q = c[name]
-        MM = Q["pl_meas"].shape[1]
-        for variant in ("", "_oracle_chain"):
-            pb = {k: Q[k] for k in tt.KEYS_P}
-            pb["Tcw"] = Q["Tcw_in"]
-            key = f"step{which}/{tag}"
-            if variant:
-                pb["pl_meas"] = np.ascontiguousarray(coef_o[:, :MM]).astype(np.float32)
-                key = f"step{which}/{name}_oracle_chain"
-            r = ol.run_ref_pose(pb, TUM3, mode)
-            out[key + "/digest"] = hashlib.sha256(b"".join(np.ascontiguousarray(pb[k]).tobytes() for k in tt.KEYS_P + ("Tcw",))).hexdigest()
-            out[key + "/Tcw"] = r["Tcw"]; out[key + "/n_inliers"] = r["n_inliers"]
-            for k in ("pt_outlier", "ln_outlier", "pl_outlier"):
-                out[key + "/" + k] = np.packbits(r[k] > 0)
-            dT = np.abs(r["Tcw"] - Q["Tcw_out"]).max(1)
-            print(f"{key}: device vs the real optimiser: max {dT.max():.2e}, frames > 1e-5: {(dT > 1e-5).sum()} of {len(dT)}; inlier counts equal: {np.array_equal(r['n_inliers'], Q['n_inliers'])}")
-# (diagnostics: frames on which the restating oracle and the real optimiser part ways, with their problems: PLANAR_DUMP_KNIFE=path)
-if os.environ.get("PLANAR_DUMP_KNIFE"):
-    knife = {}
+for kind in ("pan", "se3"):
+    run = tt.run_pipeline(kind)
+    pre = tt.KINDS[kind]["tag"]
     for which in (0, 1):
-        c = run["cap"][tt.STEPS - 2 + which]
-        for name, mode in (("pbT", 1), ("pbP", 0)):
+        j = run["steps"] - 2 + which
+        c, (g, d) = run["cap"][j], run["inputs"][j]
+        coef_o = tt.oracle_chain_coefficients(c, d)
+        for name, mode, tag in (("pbT", 1, "T"), ("pbP", 0, "P")):
             Q = c[name]
-            pb = {k: Q[k] for k in tt.KEYS_P}; pb["Tcw"] = Q["Tcw_in"]
-            r = ol.run_ref_pose(pb, TUM3, mode); w = ol.pose_optimize(pb, TUM3, mode, 4, 10)
-            bad = np.nonzero(np.abs(r["Tcw"] - w["Tcw"]).max(1) > 2e-6)[0]
-            print(name, which, "oracle vs real optimiser > 2e-6 on frames", bad.tolist())
-            for b in bad[:3]:
-                for k in tt.KEYS_P + ("Tcw",):
-                    knife[f"{which}/{name}/{b}/{k}"] = pb[k][b:b + 1]
-                knife[f"{which}/{name}/{b}/ref"] = r["Tcw"][b]; knife[f"{which}/{name}/{b}/dev"] = Q["Tcw_out"][b]
-    np.savez_compressed(os.environ["PLANAR_DUMP_KNIFE"], **knife)
+            MM = Q["pl_meas"].shape[1]
+            for variant in ("", "_oracle_chain"):
+                pb = {k: Q[k] for k in tt.KEYS_P}
+                pb["Tcw"] = Q["Tcw_in"]
+                key = f"{pre}step{which}/{tag}"
+                if variant:
+                    pb["pl_meas"] = np.ascontiguousarray(coef_o[:, :MM]).astype(np.float32)
+                    key = f"{pre}step{which}/{name}_oracle_chain"
+                r = ol.run_ref_pose(pb, TUM3, mode)
+                out[key + "/digest"] = hashlib.sha256(b"".join(np.ascontiguousarray(pb[k]).tobytes() for k in tt.KEYS_P + ("Tcw",))).hexdigest()
+                out[key + "/Tcw"] = r["Tcw"]; out[key + "/n_inliers"] = r["n_inliers"]
+                for k in ("pt_outlier", "ln_outlier", "pl_outlier"):
+                    out[key + "/" + k] = np.packbits(r[k] > 0)
+                dT = np.abs(r["Tcw"] - Q["Tcw_out"]).max(1)
+                w = ol.pose_optimize(pb, TUM3, mode, 4, 10)
+                dO = np.abs(r["Tcw"] - w["Tcw"]).max(1)
+                print(f"{key}: device vs the real optimiser: max {dT.max():.2e}, frames > 1e-5: {(dT > 1e-5).sum()} of {len(dT)}; inlier counts equal: "
+                      f"{np.array_equal(r['n_inliers'], Q['n_inliers'])}; restating oracle vs the real optimiser: max {dO.max():.2e}")
 np.savez_compressed(out_path, **out)
 print("wrote", out_path, os.path.getsize(out_path), "bytes")
