@@ -430,7 +430,10 @@ def main():
         add_kernel("lsd_detect", "planar::lsd::lsd_detect", lav[2], la.get("lsd_detect"), 312160 * B)
         for i, nm in enumerate(PC_SLOTS):
             add_kernel(nm, "planar::planepost::" + nm + ("" if nm.startswith("plane_sort") else "_kernel"), cav[i], ca.get(nm), 1843200 * B, 2 if nm == "plane_sort_heap" else 1)
-    dom = max(per, key=lambda k: per[k]["corun_avg_ms"] * (per[k]["launches_per_step"] if k in prof else 1))
+    # "most device time": the launch's duration ALONE on the device where the calibration measured it (the co-run brackets of the wide kernels mostly measure how long a
+    # launch queued for CUs behind the other streams - lsd_sort's four launches: 4.7 ms alone, 100 ms of brackets); the ORB-only workload has only the live averages
+    dev_time = lambda k: (per[k]["alone_ms"] if per[k]["alone_ms"] else 0.0) if full else per[k]["corun_avg_ms"] * per[k]["launches_per_step"]
+    dom = max(per, key=dev_time)
     dom_ms, dom_bytes = per[dom]["corun_avg_ms"], per[dom]["alg_bytes_per_launch"]
     if dom_ms > ms_per_step:
         print(f"bench.py: WARNING: the HIP-event bracket of {dom} ({dom_ms:.1f} ms) exceeds the step ({ms_per_step:.1f} ms): launches of several steps overlap on its stream", file=sys.stderr)
@@ -904,7 +907,7 @@ def pose_line(steps, warmup, cpu_seconds, batch, ranks, local_rank, dev):
             ncores = os.cpu_count() or 1
             global _POSE_CPU_BATCH
             _POSE_CPU_BATCH = {k: np.ascontiguousarray(v) for k, v in host.items() if k != "T_gt"}
-            per = 32
+            per = 128
             jobs = [((w * per) % B, per) for w in range(ncores)]
             with mp.get_context("fork").Pool(ncores) as pool:
                 pool.map(_pose_cpu_chunk, [(j[0], 2) for j in jobs], chunksize=1)
