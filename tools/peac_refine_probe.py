@@ -45,4 +45,6 @@ print("per frame (ms)      mean    p50    max")
 for nm, v in (("seeds+erosion", seeds), ("flood fill", flood), ("cluster+relabel", tail), ("refine total", seeds + flood + tail), ("ahc (clustering kernel)", ms(t[:, 3]))):
     print(f"{nm:24s} {v.mean():6.2f} {np.median(v):6.2f} {v.max():6.2f}")
 print(f"queue entries: mean {q.mean():.0f} p50 {np.median(q):.0f} max {q.max()}  -> flood-fill steps of 512 entries: mean {np.ceil(q / 512).mean():.0f}; us per step: {(flood * 1e3 / np.maximum(1, np.ceil(q / 512))).mean():.1f}")
+st = t[:, 7]
+print(f"flood-fill steps actually taken: mean {st.mean():.0f} p50 {np.median(st):.0f} max {st.max()}; entries per step {(q / np.maximum(st, 1)).mean():.0f}; us per step {(flood * 1e3 / np.maximum(st, 1)).mean():.2f}")
 print(f"planes per frame {npl.float().mean().item():.2f}; unlabelled pixels {black.mean() * 100:.1f} %")
