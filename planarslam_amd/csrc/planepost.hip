@@ -41,7 +41,7 @@ struct Geo {
     int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (frame workspace); mini: entries of a wavefront's tile table (LDS)
     float fx, fy, cx, cy, factor, leaf;
     double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
-    size_t ws_stride, off_cnt, off_cent, off_key, off_rank, off_vstart, off_pl, off_init, off_meta, off_ranges, off_blocks, off_heapj, off_items;
+    size_t ws_stride, off_cnt, off_cent, off_key, off_rank, off_vstart, off_pl, off_init, off_meta, off_ranges, off_blocks, off_heapj, off_items, off_dsort;
 };
 
 struct Pt { float x, y, z; };
@@ -308,7 +308,7 @@ __device__ __forceinline__ void bitonic(unsigned long long* a, int n2) {
 //                         (voxel << 19 | pixel): a stable partition of the label image by plane (ballot ranks per 64-pixel row, per-wavefront counters)
 //   plane_sort_global / plane_sort_lds   (isort.h) every plane's items arranged as std::sort(index_vector) of VoxelGrid::applyFilter leaves them: sorted by
 //                         voxel, points of one voxel in libstdc++'s introsort order - the order PCL adds them up in
-//   plane_tail_kernel     thread per voxel: the FLOAT sums in that order, centroid = sum / (float)count; then the distance gate and the RANSAC refit (one
+//   plane_tail_kernel     the items' depths gathered in sorted order (streaming), then thread per voxel: the FLOAT sums in that order, centroid = sum / (float)count; then the distance gate and the RANSAC refit (one
 //                         wavefront per plane) and the compaction of the kept planes
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
 constexpr int PS_T = 1024, PS_LT = 256, PS_E = 23, PS_SHIFT = 19, PS_R = 96;      // PS_T: threads of the item / global-tier kernels; PS_LT x PS_E: an LDS block (40 KB: four per CU, and room for the other streams' workgroups)
@@ -668,25 +668,40 @@ __global__ __launch_bounds__(NT, 4) void plane_tail_kernel(Geo G, const unsigned
     auto mark = [&](int q) { if (tmark && tid == 0) tmark[q] = wall_clock64(); };
     for (int i = tid; i < MAXP; i += NT) { s_first[i] = pfl[i]; s_last[i] = pfl[MAXP + i]; s_state[i] = 0; }
     if (tid == 0) { s_err = 0; s_kept = 0; }
-    // ---- the voxel centroids: a voxel's points added up as floats in the sorted order, then divided by the count (VoxelGrid::applyFilter) ----
-    for (int r = tid; r < M; r += NT) {
-        const int i0 = vstart[r], i1 = vstart[r + 1];
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-        constexpr int U = 4;
-        for (int i = i0; i < i1; i += U) {
-            uint32_t it[U];
-            unsigned short d[U];
-            int px[U], py[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) it[u] = items[min(i + u, i1 - 1)];
-#pragma unroll
-            for (int u = 0; u < U; u++) { const int pix = (int)(it[u] & ((1u << PS_SHIFT) - 1u)); py[u] = pix / G.W; px[u] = pix - py[u] * G.W; d[u] = D[(size_t)py[u] * pitch_px + px[u]]; }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (i + u < i1) { const Pt p = cam_point_thread(G, d[u], px[u], py[u]); cx += p.x; cy += p.y; cz += p.z; }
+    // ---- the voxel centroids: a voxel's points added up as floats in the sorted order, then divided by the count (VoxelGrid::applyFilter).
+    //      Pass 1, all lanes streaming over the sorted items: item -> its pixel's depth, written next to the item (dsort[i]): consecutive items belong to one voxel,
+    //      i.e. to one image patch, so the 2-byte reads of an instruction share a few cache lines.  Pass 2, a lane per voxel: the float chains, every lane walking
+    //      its own CONTIGUOUS run of (item, depth) - round 4 fetched the depth from the image inside this loop, a line per lane and step from 64 patches at once:
+    //      10 GB of fetches per 1024 frames for a 0.6 MB image ----
+    {
+        unsigned short* dsort = (unsigned short*)(ws + G.off_dsort);
+        const int total = M > 0 ? vstart[M] : 0;
+        for (int i = tid; i < total; i += NT) {
+            const int pix = (int)(items[i] & ((1u << PS_SHIFT) - 1u)), yy = pix / G.W;
+            dsort[i] = D[(size_t)yy * pitch_px + (pix - yy * G.W)];
         }
-        const float cnt = (float)(i1 - i0);
-        cent[(size_t)r * 3] = cx / cnt; cent[(size_t)r * 3 + 1] = cy / cnt; cent[(size_t)r * 3 + 2] = cz / cnt;
+        __threadfence_block();
+        __syncthreads();
+        for (int r = tid; r < M; r += NT) {
+            const int i0 = vstart[r], i1 = vstart[r + 1];
+            float cx = 0.f, cy = 0.f, cz = 0.f;
+            constexpr int U = 4;
+            for (int i = i0; i < i1; i += U) {
+                uint32_t it[U];
+                unsigned short d[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) { it[u] = items[min(i + u, i1 - 1)]; d[u] = dsort[min(i + u, i1 - 1)]; }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (i + u < i1) {
+                        const int pix = (int)(it[u] & ((1u << PS_SHIFT) - 1u)), yy = pix / G.W;
+                        const Pt p = cam_point_thread(G, d[u], pix - yy * G.W, yy);
+                        cx += p.x; cy += p.y; cz += p.z;
+                    }
+            }
+            const float cnt = (float)(i1 - i0);
+            cent[(size_t)r * 3] = cx / cnt; cent[(size_t)r * 3 + 1] = cy / cnt; cent[(size_t)r * 3 + 2] = cz / cnt;
+        }
     }
     __threadfence();
     __syncthreads();
@@ -956,6 +971,7 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
         G.off_blocks = carve((size_t)isort::G_FMAX * sizeof(isort::Block));
         G.off_heapj = carve((size_t)planepost::PS_HJOBS * sizeof(isort::HeapJob));
         G.off_items = carve(std::max((size_t)width * height, (size_t)65536) * 4);   // (voxel << 19 | pixel) per member pixel; the map-side merge sorts up to 65536 points here
+        G.off_dsort = carve((size_t)width * height * 2);            // the items' depth values, in sorted order (plane_tail_kernel)
         G.ws_stride = off;
     }
     G.mini = 128;
