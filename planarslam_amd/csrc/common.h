@@ -90,6 +90,19 @@ struct Stager {
     }
 };
 
+// XCD-aware (frame, block) from a ONE-dimensional grid of per_frame * B workgroups.  MI355X has 8 XCDs, each with its own 4 MB L2, and the dispatcher deals consecutive
+// workgroup ids round-robin to them (block b -> XCD b % 8: observed, MI355X_MICROARCH.md; speed only, nothing depends on it for correctness).  A kernel whose
+// workgroups of one frame re-read the same bytes (overlapping patches / support regions of one image) wants a frame's workgroups on ONE XCD, so that the frame's
+// image is fetched into one L2 once instead of into all eight: ids cycle through groups of 8 frames (id % 8 picks the frame of the group = the XCD), a frame's
+// workgroups follow each other on their XCD.  The last B % 8 frames keep the plain order.  Bijective over [0, per_frame * B).
+#ifdef __HIPCC__
+__device__ __forceinline__ void xcd_frame_block(int per_frame, int B, int& frame, int& blk) {
+    const int n = (int)blockIdx.x, group = 8 * per_frame, full = (B >> 3) * group;
+    if (n < full) { const int g = n / group, r = n - g * group; frame = g * 8 + (r & 7); blk = r >> 3; }
+    else { const int r = n - full; frame = (B & ~7) + r / per_frame; blk = r - (r / per_frame) * per_frame; }
+}
+#endif
+
 }  // namespace planar
 
 struct planar_ctx {

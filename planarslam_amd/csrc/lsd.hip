@@ -18,7 +18,7 @@
 //                       expanding 7 queued pixels x 9 neighbours per round trip and resolving acceptances in lane
 //                       order; FP64 moment sums run as three independent chains on three lanes (same order as the
 //                       reference => bit-identical), min/max and NFA pixel counts are order-free wave reductions.
-//   K5 lbd_sobel        Sobel dx, dy (16S) of the 5x5-blurred image
+//   (K5, the Sobel images of the 5x5-blurred image, is fused into K7 since round 5)
 //   K6 lsd_keylines     per frame: KeyLine fields, libstdc++ std::sort emulation on `response`, keep max_lines, equations
 //   K7 lbd_describe     one wavefront per kept line: 63 support rows on 63 lanes, band sums in reference order
 // HBM traffic is small (a 640x480 frame: 0.3 MB in, 3 KB out, ~5 MB of L2-resident intermediates); K4 is latency bound.
@@ -1130,22 +1130,6 @@ __global__ __launch_bounds__(64) void lsd_accept(const Plan* __restrict__ plan, 
 }
 
 // ---- K5: Sobel 3x3 (cv::Sobel CV_16S, BORDER_REFLECT_101) of the 5x5-blurred image ------------------------------------
-__global__ __launch_bounds__(256) void lbd_sobel(const Plan* __restrict__ plan, uint8_t* __restrict__ ws) {
-    const Plan& P = *plan;
-    const int b = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.W || y >= P.H) return;
-    uint8_t* F = ws + (size_t)b * P.frame_bytes;
-    const uint8_t* S = F + P.off_blur5;
-    const int W = P.W, H = P.H;
-    const uint8_t* r0 = S + (size_t)reflect101(y - 1, H) * W;
-    const uint8_t* r1 = S + (size_t)y * W;
-    const uint8_t* r2 = S + (size_t)reflect101(y + 1, H) * W;
-    const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
-    ((int16_t*)(F + P.off_dx))[(size_t)y * W + x] = (int16_t)((r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]));
-    ((int16_t*)(F + P.off_dy))[(size_t)y * W + x] = (int16_t)((r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]));
-}
-
 // ---- K6: KeyLines + std::sort by response + keep max_lines + line equations --------------------------------------------
 // libstdc++ std::sort (bits/stl_algo.h: __introsort_loop, __unguarded_partition_pivot, __final_insertion_sort,
 // heap fallback) on keys[] (descending `response`), carrying idx[]; executed by one lane, data in LDS.
@@ -1337,17 +1321,20 @@ __constant__ int LBD_COMB[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 
                                     {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8}, {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
 
 __global__ __launch_bounds__(64) void lbd_describe(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, const Misc* __restrict__ miscs, int max_lines,
-                                                   uint8_t* __restrict__ out_desc) {
+                                                   uint8_t* __restrict__ out_desc, int B) {
     __shared__ float row[LSP_H][8];    // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 row sums (after the global weight)
     __shared__ float des[NUM_OF_BANDS * 8];
     const Plan& P = *plan;
-    const int b = blockIdx.y, li = blockIdx.x, lane = threadIdx.x;
+    int b, li;
+    xcd_frame_block(max_lines, B, b, li);           // a frame's support regions overlap: its lines on one XCD (common.h)
+    const int lane = threadIdx.x;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
     const Misc* misc = miscs + b;
     if (li >= misc->n_kl) return;
     const planar_keyline L = ((const planar_keyline*)(F + P.off_kl))[li];
-    const int16_t* dxImg = (const int16_t*)(F + P.off_dx);
-    const int16_t* dyImg = (const int16_t*)(F + P.off_dy);
+    // the Sobel derivatives (16S, 3x3, BORDER_REFLECT_101) of the 5x5-blurred image are taken where they are read: eight byte reads of a 0.3 MB image per sample
+    // instead of two 2-byte reads of two 0.6 MB images that a separate kernel had to write first (rounds 1-4: lbd_sobel, 1.9 GB + lbd_describe 6.1 GB per 1024 frames)
+    const uint8_t* S5 = F + P.off_blur5;
     const short realWidth = (short)P.W, imageWidth = (short)(P.W - 1), imageHeight = (short)(P.H - 1);
     const short lengthOfLSP = (short)L.num_pixels;
     const short halfWidth = (lengthOfLSP - 1) / 2, halfHeight = (LSP_H - 1) / 2;
@@ -1367,7 +1354,12 @@ __global__ __launch_bounds__(64) void lbd_describe(const Plan* __restrict__ plan
             const short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
             tempCor = (short)roundf(sCorY);
             const short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
-            const short dx = dxImg[(size_t)yCor * realWidth + xCor], dy = dyImg[(size_t)yCor * realWidth + xCor];
+            const uint8_t* r0 = S5 + (size_t)reflect101(yCor - 1, P.H) * realWidth;
+            const uint8_t* r1 = S5 + (size_t)yCor * realWidth;
+            const uint8_t* r2 = S5 + (size_t)reflect101(yCor + 1, P.H) * realWidth;
+            const int xm = reflect101(xCor - 1, P.W), xp = reflect101(xCor + 1, P.W);
+            const int a0 = r0[xm], a1 = r0[xCor], a2 = r0[xp], b0 = r1[xm], b2 = r1[xp], c0 = r2[xm], c1 = r2[xCor], c2 = r2[xp];
+            const short dx = (short)((a2 - a0) + 2 * (b2 - b0) + (c2 - c0)), dy = (short)((c0 - a0) + 2 * (c1 - a1) + (c2 - a2));
             const float gDL = dx * dL[0] + dy * dL[1];
             const float gDO = dx * dO[0] + dy * dO[1];
             if (gDL > 0) pgdLRowSum += gDL; else ngdLRowSum -= gDL;
@@ -1536,7 +1528,8 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o2 = off; off = align_up(off + bytes, (size_t)256); return o2; };
     const size_t NPf = (size_t)width * height, NPs = (size_t)P.w * P.h;
-    P.off_blur7 = carve(NPf); P.off_blur5 = carve(NPf); P.off_dx = carve(NPf * 2); P.off_dy = carve(NPf * 2);
+    P.off_blur7 = carve(NPf); P.off_blur5 = carve(NPf); P.off_dx = 0; P.off_dy = 0;   // (no Sobel images since round 5)
+    
     P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_pix = carve(NPs * 16); P.off_seed = carve(NPs * 8); P.off_ordr = carve(NPs * 4); P.off_gused = carve((NPs + 31) / 32 * 4 + 256); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
     P.off_valid = carve((NPs + 63) / 64 * 8 + 8); P.off_sortr = carve((size_t)isort::G_FMAX * sizeof(isort::Range)); P.off_sortb = carve((size_t)isort::G_FMAX * sizeof(isort::Block)); P.off_heapj = carve((size_t)lsd::SORT_HJOBS * sizeof(isort::HeapJob));
     P.off_segs = carve((size_t)lsd::MAX_SEGS * sizeof(lsd::Seg)); P.off_kl = carve((size_t)lsd::MAX_SEGS * sizeof(planar_keyline));
@@ -1618,7 +1611,6 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     hipLaunchKernelGGL(lsd::lsd_gauss<7>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>(), ws, P.frame_bytes, P.off_blur7);
     hipLaunchKernelGGL(lsd::lsd_gauss<5>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>() + 8, ws, P.frame_bytes, P.off_blur5);
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
-    hipLaunchKernelGGL(lsd::lbd_sobel, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, dP, ws);
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[1], st);
     if (o->tie_order != 0) hipLaunchKernelGGL(lsd::lsd_sort_raster, dim3(B), dim3(lsd::SORT_NT), 0, st, dP, ws, dm);
     else {
@@ -1659,7 +1651,7 @@ int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d
         hipLaunchKernelGGL(lsd::lsd_accept, dim3(B), dim3(64), 0, st, dP, ws, dm, 1);
         hipLaunchKernelGGL(lsd::lsd_keylines, dim3(B), dim3(64), 0, st, dP, ws, dm, max_lines, d_keylines, d_line_eq, d_n_lines, 1);
     }
-    hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines, B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc);
+    hipLaunchKernelGGL(lsd::lbd_describe, dim3(max_lines * B), dim3(64), 0, st, dP, ws, dm, max_lines, d_ldesc, B);
     if (o->ev_cur) { (void)hipEventRecord((*o->ev_cur)[4], st); o->ev_complete[o->ev_used - 1] = 1; o->ev_cur = nullptr; }
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;

@@ -700,10 +700,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 __global__ __launch_bounds__(256) void orb_describe(const PlanDev* __restrict__ plan, const uint8_t* __restrict__ pyr,
                                                     const uint8_t* __restrict__ blur, const uint32_t* __restrict__ kept,
                                                     const int* __restrict__ kept_count, planar_keypoint* __restrict__ kps,
-                                                    uint8_t* __restrict__ desc, int32_t* __restrict__ n_out) {
-    const int frame = blockIdx.y;
+                                                    uint8_t* __restrict__ desc, int32_t* __restrict__ n_out, int per_frame, int B) {
+    // a frame's 1000 patches (38 rows of the level image and of its blurred clone each) overlap 4-5 times over: its workgroups run on one XCD (common.h), so that
+    // the frame's two pyramids go through ONE L2 once (rounds 1-4: spread over all eight, 5.0 GB of fetches per 1024 frames for 1.6 GB of pyramids)
+    int frame, bx;
+    xcd_frame_block(per_frame, B, frame, bx);
     const int sub = threadIdx.x & 15;
-    const int kpi = blockIdx.x * 16 + (threadIdx.x >> 4);       // keypoint index in the frame's output
+    const int kpi = bx * 16 + (threadIdx.x >> 4);               // keypoint index in the frame's output
     // locate level: prefix over per-level kept counts
     int level = -1, first = 0, total = 0;
     for (int l = 0; l < plan->nlevels; l++) {
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(256) void orb_describe(const PlanDev* __restrict__ 
         if (level < 0 && kpi < total + c) { level = l; first = total; }
         total += c;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) n_out[frame] = total;
+    if (bx == 0 && threadIdx.x == 0) n_out[frame] = total;
     if (level < 0) return;                                      // uniform per 16-lane group
     const LevelDev& L = plan->lv[level];
     const uint32_t key = kept[(int64_t)frame * plan->kept_stride + L.kept_off + (kpi - first)];
@@ -1096,8 +1099,8 @@ int planar_orb_extract_dev(planar_orb* o, const uint8_t* d_gray, int B, int pitc
     mark();
     hipLaunchKernelGGL(orb_blur, dim3((unsigned)o->tiles.size(), B), dim3(256), 0, st, dp, o->d_tiles.as<TileDev>(), pyr, o->d_blur.as<uint8_t>());
     mark();
-    hipLaunchKernelGGL(orb_describe, dim3((P.kp_cap + 15) / 16, B), dim3(256), 0, st, dp, pyr, o->d_blur.as<uint8_t>(), o->d_kept.as<uint32_t>(),
-                       o->d_kept_count.as<int>(), d_kps, d_desc, d_n_out);
+    hipLaunchKernelGGL(orb_describe, dim3((P.kp_cap + 15) / 16 * B), dim3(256), 0, st, dp, pyr, o->d_blur.as<uint8_t>(), o->d_kept.as<uint32_t>(),
+                       o->d_kept_count.as<int>(), d_kps, d_desc, d_n_out, (P.kp_cap + 15) / 16, B);
     mark();
     PLANAR_HIP_CHECK(hipGetLastError());
     o->last_B = B;
