@@ -629,6 +629,12 @@ typedef struct planar_plane_clouds planar_plane_clouds;
 int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_batch, int max_points /* voxels per frame: a power of two <= 8192; the kernel holds 36 KB of LDS up to 4096, 64 KB at 8192; the key table is in the workspace */, planar_plane_clouds** out);
 void planar_plane_clouds_destroy(planar_plane_clouds* pc);
 int planar_plane_clouds_stride(const planar_plane_clouds* pc, int* pl_stride, int* max_points);
+/* Plane window: the compute calls that follow only process the detector planes [first, first + count) of every frame (count < 0: all planes again).  pcl::VoxelGrid
+ * has no voxel cap (reference src/Frame.cc:674-679); a frame's voxel table here holds max_points (<= 8192) voxels for all its planes together, and a compute call
+ * reports PLANAR_ECAPACITY (frame status 3) beyond that.  Such a frame goes through once more plane by plane (window (i, 1) for every plane i, results appended in
+ * plane order: exactly the sequence of Frame::ComputePlanes' loop) - include/planar_adapters.hpp and planarslam_amd.planes.PlaneClouds.compute do so; only a SINGLE
+ * plane of more than max_points voxels (> 80 m^2 of surface at the 0.1 m leaf) is beyond the structure and is dropped with a message. */
+int planar_plane_clouds_set_plane_window(planar_plane_clouds* pc, int first, int count);
 /* HIP-event timing of the launches of planar_plane_clouds_compute_dev (bench.py's roofline leg), as planar_peac_set_profiling: total_ms [6] = plane_voxels,
  * plane_items, plane_sort_global, plane_sort_lds, plane_sort_heap, plane_tail over `calls` recorded calls */
 int planar_plane_clouds_set_profiling(planar_plane_clouds* pc, int enable);

@@ -68,14 +68,16 @@ public:
         auto it = peacs_.find({w, h});
         if (it != peacs_.end()) return it->second;
         planar_peac* o = nullptr;
-        if (planar_peac_create(lanes_[PLANES].ctx, w, h, 1, &o) != PLANAR_OK) { complain("planar_peac_create"); return nullptr; }
+        // (a size the plane path does not support - more than 3072 blocks of 10x10, i.e. more pixels than 640x480 - is reported ONCE: the failed size is remembered
+        //  as a null handle, later frames of that size track without planes without repeating the message; INTEGRATION.md "Frame sizes")
+        if (planar_peac_create(lanes_[PLANES].ctx, w, h, 1, &o) != PLANAR_OK) { complain("planar_peac_create"); o = nullptr; }
         return peacs_[{w, h}] = o;
     }
     planar_plane_clouds* clouds(int w, int h) {                     // call with lane(PLANES).mu held
         auto it = clouds_.find({w, h});
         if (it != clouds_.end()) return it->second;
         planar_plane_clouds* o = nullptr;
-        if (planar_plane_clouds_create(lanes_[PLANES].ctx, w, h, 1, 8192, &o) != PLANAR_OK) { complain("planar_plane_clouds_create"); return nullptr; }   // 8192 voxels of 0.1 m: ~80 m2 of planar surface per frame
+        if (planar_plane_clouds_create(lanes_[PLANES].ctx, w, h, 1, 8192, &o) != PLANAR_OK) { complain("planar_plane_clouds_create"); o = nullptr; }   // 8192 voxels of 0.1 m per pass (a frame with more goes plane by plane); sizes beyond 2^19 pixels: reported once
         return clouds_[{w, h}] = o;
     }
     void set_device(int d) { device_ = d; }
@@ -232,7 +234,9 @@ public:
             planar_adapter::Runtime& R = planar_adapter::Runtime::get();
             planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::PLANES);
             std::lock_guard<std::mutex> g(L.mu);
-            if (!planar_adapter::ok(planar_peac_segment(R.peac(W, H), (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_, cx_, cy_,
+            planar_peac* pp = R.peac(W, H);
+            if (!pp) { n = 0; labels.assign((size_t)W * H, -1); }          // (unsupported frame size: said once, at create)
+            else if (!planar_adapter::ok(planar_peac_segment(pp, (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_, cx_, cy_,
                                                         factor_, labels.data(), planes.data(), &n), "PlaneDetection")) { n = 0; labels.assign((size_t)W * H, -1); }
         }
         plane_num_ = n;
@@ -258,30 +262,49 @@ public:
         std::vector<float> coef((size_t)PS * 4), pts((size_t)MP * 3);
         std::vector<int32_t> src(PS), off(PS + 1);
         int32_t n_in = plane_num_, n_out = 0;
+        auto append = [&](int k, const float* cf, const int32_t* of, const float* pt) {     // kept plane k of a call's outputs -> mvPlanePoints / mvPlaneCoefficients
+            CloudT c;
+            c.points.resize(of[k + 1] - of[k]);
+            for (int i = of[k]; i < of[k + 1]; i++) { auto& p = c.points[i - of[k]]; p.x = pt[(size_t)i * 3]; p.y = pt[(size_t)i * 3 + 1]; p.z = pt[(size_t)i * 3 + 2]; }
+            planePoints.push_back(c);
+            cv::Mat m(4, 1, CV_32F);
+            for (int t = 0; t < 4; t++) m.at<float>(t, 0) = cf[(size_t)k * 4 + t];
+            planeCoefficients.push_back(m);
+        };
         {
             planar_adapter::Runtime& R = planar_adapter::Runtime::get();
             planar_adapter::Runtime::Lane& L = R.lane(planar_adapter::PLANES);
             std::lock_guard<std::mutex> g(L.mu);
+            if (!R.clouds(W, H)) return 0;                                   // (unsupported frame size: said once, at create)
             const int rc = planar_plane_clouds_compute(R.clouds(W, H), (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_,
                                                        cx_, cy_, factor_, labels_.data(), planes_.data(), &n_in, disTh, leaf, &n_out, coef.data(), src.data(), off.data(),
                                                        pts.data(), nullptr, nullptr, nullptr);
-            if (rc == PLANAR_ECAPACITY) {
-                // pcl::VoxelGrid has no cap; the kernel's voxel table has (8192 per frame).  This runs on the thread Frame's constructor spawned for ComputePlanes:
-                // an exception here would end in std::terminate, so a frame that overflows tracks without planes and says so.
-                std::fprintf(stderr, "planar: frame with more than %d plane voxels: its planes are dropped (%s)\n", MP, planar_last_error());
-                return 0;
+            if (rc == PLANAR_ECAPACITY && std::strstr(planar_last_error(), "(code 3") != nullptr) {
+                // pcl::VoxelGrid has no voxel cap (src/Frame.cc:674-679); the frame's voxel table here has (8192 for all planes together).  The frame goes through once
+                // more PLANE BY PLANE (planar_plane_clouds_set_plane_window), results appended in plane order - the very sequence of Frame::ComputePlanes' loop, every
+                // plane's cloud and refit what the one-pass call would have produced.  Only a single plane of more than 8192 voxels (> 80 m^2 at the 0.1 m leaf) is
+                // beyond the structure: it alone is dropped, with a message (this runs on the thread Frame's constructor spawned: no exception may leave it).
+                planar_plane_clouds* pc = R.clouds(W, H);
+                int total = 0;
+                for (int i = 0; i < n_in; i++) {
+                    int32_t n1 = 0;
+                    planar_plane_clouds_set_plane_window(pc, i, 1);
+                    const int rc1 = planar_plane_clouds_compute(pc, (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_, cx_, cy_, factor_,
+                                                                labels_.data(), planes_.data(), &n_in, disTh, leaf, &n1, coef.data(), src.data(), off.data(), pts.data(), nullptr,
+                                                                nullptr, nullptr);
+                    if (rc1 == PLANAR_ECAPACITY && std::strstr(planar_last_error(), "(code 3") != nullptr) {
+                        std::fprintf(stderr, "planar: plane %d of this frame alone has more than %d voxels: dropped (%s)\n", i, MP, planar_last_error());
+                        continue;
+                    }
+                    if (!planar_adapter::ok(rc1, "ComputePlaneClouds (plane by plane)")) { total = 0; planePoints.clear(); planeCoefficients.clear(); break; }
+                    if (n1 == 1) { append(0, coef.data(), off.data(), pts.data()); total++; }
+                }
+                planar_plane_clouds_set_plane_window(pc, 0, -1);
+                return total;
             }
             if (!planar_adapter::ok(rc, "ComputePlaneClouds")) return 0;
         }
-        for (int k = 0; k < n_out; k++) {
-            CloudT c;
-            c.points.resize(off[k + 1] - off[k]);
-            for (int i = off[k]; i < off[k + 1]; i++) { auto& p = c.points[i - off[k]]; p.x = pts[(size_t)i * 3]; p.y = pts[(size_t)i * 3 + 1]; p.z = pts[(size_t)i * 3 + 2]; }
-            planePoints.push_back(c);
-            cv::Mat m(4, 1, CV_32F);
-            for (int t = 0; t < 4; t++) m.at<float>(t, 0) = coef[(size_t)k * 4 + t];
-            planeCoefficients.push_back(m);
-        }
+        for (int k = 0; k < n_out; k++) append(k, coef.data(), off.data(), pts.data());
         return n_out;
     }
 

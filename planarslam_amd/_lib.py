@@ -206,6 +206,7 @@ _SIGS = {
     "planar_plane_clouds_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "planar_plane_clouds_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "planar_plane_clouds_stride": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "planar_plane_clouds_set_plane_window": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "planar_plane_clouds_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_double, C.c_float] + [C.c_void_p] * 8),
     "planar_plane_clouds_compute_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,

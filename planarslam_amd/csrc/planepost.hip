@@ -38,6 +38,7 @@ constexpr unsigned long long EMPTY = ~0ull;
 
 struct Geo {
     int dev_skip_heap = 0;                          // (always 0; was a timing switch of the round-4 experiments: leaving the fallback jobs out)
+    int pl_first = 0, pl_count = 1 << 20;         // plane window (planar_plane_clouds_set_plane_window): only the detector planes [pl_first, pl_first + pl_count) are processed
     int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (frame workspace); mini: entries of a wavefront's tile table (LDS)
     float fx, fy, cx, cy, factor, leaf;
     double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(NT) void plane_voxels_kernel(Geo G, const unsigned 
 #pragma unroll
                 for (int q = 0; q < UNR; q++) {
                     const int l = l4[q];
-                    const bool on = l >= 0 && l < npl;
+                    const bool on = l >= G.pl_first && l < npl && l - G.pl_first < G.pl_count;
                     unsigned long long key = cur;
                     bool fin = false;
                     const Pt p = cam_point(G, d4[q], px, yb + q);
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(PS_T) void plane_items_kernel(Geo G, const unsigned
         for (int u = 0; u < U; u++) l[u] = lab[min(i0 + 64 * u + lane, w1 - 1)];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const bool on = i0 + 64 * u + lane < w1 && l[u] >= 0 && l[u] < npl;
+            const bool on = i0 + 64 * u + lane < w1 && l[u] >= G.pl_first && l[u] < npl && l[u] - G.pl_first < G.pl_count;
             unsigned long long rem = __ballot(on);
             while (rem) {
                 const int L = __builtin_amdgcn_readlane(l[u], __builtin_ctzll(rem));
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(PS_T) void plane_items_kernel(Geo G, const unsigned
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int pix = i0 + 64 * u + lane, pc = min(pix, w1 - 1), py = pc / G.W, px = pc - py * G.W;
-            const bool on = pix < w1 && l[u] >= 0 && l[u] < npl;
+            const bool on = pix < w1 && l[u] >= G.pl_first && l[u] < npl && l[u] - G.pl_first < G.pl_count;
             const Pt p = cam_point(G, d[u], px, py);
             uint32_t item = 0;
             if (on) {
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(NT, 4) void plane_tail_kernel(Geo G, const unsigned
     const int M = err ? 0 : meta->M;
     long long* tmark = timing ? timing + (size_t)b * 16 : nullptr;
     auto mark = [&](int q) { if (tmark && tid == 0) tmark[q] = wall_clock64(); };
-    for (int i = tid; i < MAXP; i += NT) { s_first[i] = pfl[i]; s_last[i] = pfl[MAXP + i]; s_state[i] = 0; }
+    for (int i = tid; i < MAXP; i += NT) { s_first[i] = pfl[i]; s_last[i] = pfl[MAXP + i]; s_state[i] = (i >= G.pl_first && i - G.pl_first < G.pl_count) ? 0 : 3; }   // 3: outside the plane window
     if (tid == 0) { s_err = 0; s_kept = 0; }
     // ---- the voxel centroids: a voxel's points added up as floats in the sorted order, then divided by the count (VoxelGrid::applyFilter).
     //      Pass 1, all lanes streaming over the sorted items: item -> its pixel's depth, written next to the item (dsort[i]): consecutive items belong to one voxel,
@@ -711,6 +712,7 @@ __global__ __launch_bounds__(NT, 4) void plane_tail_kernel(Geo G, const unsigned
     unsigned short* shuf = (unsigned short*)s_list;
     if (!err)
     for (int p = wave; p < npl; p += NT / 64) {
+        if (s_state[p] != 0) continue;                  // outside the plane window
         const double* P = planes + (size_t)p * 8;
         const double nx = P[1], ny = P[2], nz = P[3];
         float c[4] = {(float)nx, (float)ny, (float)nz, (float)-(nx * P[4] + ny * P[5] + nz * P[6])};
@@ -1004,6 +1006,16 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
 }
 
 void planar_plane_clouds_destroy(planar_plane_clouds* p) { delete p; }
+
+// The following compute calls only process the detector planes [first, first + count) of every frame (count < 0: all planes again).  For callers whose frames can
+// hold more voxels than max_points: pcl::VoxelGrid has no cap (src/Frame.cc:674-679), the frame's voxel table here has, and PLANAR_ECAPACITY (code 3) from a compute
+// call means "this frame's planes together have more than max_points voxels" - the same frame goes through plane by plane (include/planar_adapters.hpp does that).
+int planar_plane_clouds_set_plane_window(planar_plane_clouds* p, int first, int count) {
+    PLANAR_REQUIRE(p && first >= 0, PLANAR_EINVAL, "bad argument");
+    p->G.pl_first = count < 0 ? 0 : first;
+    p->G.pl_count = count < 0 ? (1 << 20) : count;
+    return PLANAR_OK;
+}
 
 // Profiling aid: per-frame phase timestamps of the last call, out[B][8] (100 MHz ticks: [0] entry, [1] table cleared, [2] voxel sums, [3] sorted + centroids,
 // [4] refit, [5] end; [6] voxels, [7] planes).  Enabling allocates the buffer.

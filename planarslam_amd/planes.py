@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import Context, check, lib
+from ._lib import Context, PlanarError, check, lib
 
 
 class PlaneDetection:
@@ -130,7 +130,7 @@ class PlaneClouds:
         except Exception:
             pass
 
-    def compute(self, depth, labels, planes, n_planes, dist_th=0.05, leaf=0.1, K=(535.4, 539.2, 320.1, 247.6), depth_factor=1.0 / 5000.0, debug=False):
+    def compute(self, depth, labels, planes, n_planes, dist_th=0.05, leaf=0.1, K=(535.4, 539.2, 320.1, 247.6), depth_factor=1.0 / 5000.0, debug=False, retry_per_plane=True):
         """depth [B,H,W] u16, labels [B,H,W] i32, planes [B,max_planes,8] f64, n_planes [B] (PlaneDetection's outputs) -> per frame
         dict(n, coef [n,4], src [n], pt_off [n+1], points [m,3]) (+ state / nvox / info per detector plane with debug=True)."""
         d = np.ascontiguousarray(depth, np.uint16); lab = np.ascontiguousarray(labels, np.int32); pl = np.ascontiguousarray(planes, np.float64)
@@ -141,12 +141,22 @@ class PlaneClouds:
         n = np.zeros(B, np.int32); coef = np.zeros((B, PS, 4), np.float32); src = np.zeros((B, PS), np.int32); off = np.zeros((B, PS + 1), np.int32)
         pts = np.zeros((B, MP, 3), np.float32)
         state = np.zeros((B, PS), np.int32); nvox = np.zeros((B, PS), np.int32); info = np.zeros((B, PS, 12), np.int32)
-        check(self.L.planar_plane_clouds_compute(self.h, d.ctypes.data, B, W, W * H, K[0], K[1], K[2], K[3], np.float32(depth_factor), lab.ctypes.data, pl.ctypes.data,
-                                                 npl.ctypes.data, float(dist_th), np.float32(leaf), n.ctypes.data, coef.ctypes.data, src.ctypes.data, off.ctypes.data,
-                                                 pts.ctypes.data, state.ctypes.data if debug else None, nvox.ctypes.data if debug else None,
-                                                 info.ctypes.data if debug else None))
+        rc = self.L.planar_plane_clouds_compute(self.h, d.ctypes.data, B, W, W * H, K[0], K[1], K[2], K[3], np.float32(depth_factor), lab.ctypes.data, pl.ctypes.data,
+                                                npl.ctypes.data, float(dist_th), np.float32(leaf), n.ctypes.data, coef.ctypes.data, src.ctypes.data, off.ctypes.data,
+                                                pts.ctypes.data, state.ctypes.data if debug else None, nvox.ctypes.data if debug else None,
+                                                info.ctypes.data if debug else None)
+        overflow = False
+        try:
+            check(rc)
+        except PlanarError as e:                      # PLANAR_ECAPACITY, code 3: some frame's planes together hold more than max_points voxels (pcl::VoxelGrid has no cap)
+            if not (retry_per_plane and e.code == -4 and "(code 3" in str(e)):
+                raise
+            overflow = True
         out = []
         for b in range(B):
+            if overflow:
+                out.append(self._per_plane(d[b:b + 1], lab[b:b + 1], pl[b:b + 1], npl[b:b + 1], dist_th, leaf, K, depth_factor))
+                continue
             k = int(n[b])
             r = dict(n=k, coef=coef[b, :k].copy(), src=src[b, :k].copy(), pt_off=off[b, :k + 1].copy(), points=pts[b, :off[b, k]].copy())
             if debug:
@@ -154,6 +164,35 @@ class PlaneClouds:
                 r.update(state=state[b, :P].copy(), nvox=nvox[b, :P].copy(), info=[_refit_info(info[b, i]) for i in range(P)])
             out.append(r)
         return out
+
+    def _per_plane(self, d, lab, pl, npl, dist_th, leaf, K, depth_factor):
+        """One frame whose planes together overflow the voxel table: plane by plane through the plane window, results appended in plane order (the sequence of the
+        loop of Frame::ComputePlanes, src/Frame.cc:655-692).  A single plane of more than max_points voxels is dropped (listed in the result's `dropped`)."""
+        H, W = d.shape[1:]
+        PS, MP = self.pl_stride, self.max_points
+        n = np.zeros(1, np.int32); coef = np.zeros((1, PS, 4), np.float32); src = np.zeros((1, PS), np.int32); off = np.zeros((1, PS + 1), np.int32)
+        pts = np.zeros((1, MP, 3), np.float32)
+        res = dict(n=0, coef=[], src=[], pt_off=[0], points=[], dropped=[])
+        try:
+            for i in range(int(npl[0])):
+                check(self.L.planar_plane_clouds_set_plane_window(self.h, i, 1))
+                rc = self.L.planar_plane_clouds_compute(self.h, d.ctypes.data, 1, W, W * H, K[0], K[1], K[2], K[3], np.float32(depth_factor), lab.ctypes.data, pl.ctypes.data,
+                                                        npl.ctypes.data, float(dist_th), np.float32(leaf), n.ctypes.data, coef.ctypes.data, src.ctypes.data, off.ctypes.data,
+                                                        pts.ctypes.data, None, None, None)
+                try:
+                    check(rc)
+                except PlanarError as e:
+                    if not (e.code == -4 and "(code 3" in str(e)):
+                        raise
+                    res["dropped"].append(i); continue
+                if int(n[0]) == 1:
+                    res["n"] += 1; res["coef"].append(coef[0, 0].copy()); res["src"].append(i); res["points"].append(pts[0, :off[0, 1]].copy())
+                    res["pt_off"].append(res["pt_off"][-1] + int(off[0, 1]))
+        finally:
+            check(self.L.planar_plane_clouds_set_plane_window(self.h, 0, -1))
+        k = res["n"]
+        return dict(n=k, coef=np.array(res["coef"], np.float32).reshape(k, 4), src=np.array(res["src"], np.int32), pt_off=np.array(res["pt_off"], np.int32),
+                    points=np.concatenate(res["points"] + [np.zeros((0, 3), np.float32)]), dropped=res["dropped"])
 
     def compute_dev(self, d_depth, d_labels, d_planes, d_n_planes, B, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, dist_th=0.05, leaf=0.1,
                     K=(535.4, 539.2, 320.1, 247.6), depth_factor=1.0 / 5000.0):

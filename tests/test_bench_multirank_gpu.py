@@ -38,3 +38,22 @@ def test_two_ranks_shard_frames_and_print_one_line():
 def test_two_ranks_partition_the_bundle_adjustment():
     d = _bench("--workload", "ba", "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "solves/s" and d["value"] > 0
+
+
+def test_two_ranks_each_solve_their_own_pose_batch():
+    """BASELINE configs[3] at N = 2: every rank has its own batch of 256 pose problems (seed 7 + 1000 * rank), no collective on the data path; rank 0 prints the
+    whole-job rate = both ranks' problems over the slowest rank's time."""
+    K = 3
+    d = _bench("--workload", "pose", "--gpus", "2", "--backend", "gloo", "--steps", str(K), "--warmup", "1", "--cpu-seconds", "0")
+    assert d["n_gpus"] == 2 and d["steps"] == K and d["scaling"] == "weak" and d["unit"] == "problems/s"
+    assert d["config"]["frames_per_gpu_per_step"] == 256
+    assert abs(d["value"] - 2 * 256 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    assert d["roofline"]["kernel"] == "pose_opt_kernel" and d["roofline"]["frac"] > 0
+
+
+def test_the_bench_refuses_environment_switches():
+    """No timing / variant switch reaches the timed region through the environment: bench.py exits non-zero when a PLANAR_* variable other than the developer-library
+    override is set (round 4's PLANAR_TRACK_SKIP / PLANAR_PEAC_AHC no longer exist in the product either)."""
+    env = dict(os.environ, PLANAR_TRACK_SKIP="lsd")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "refusing to run" in (p.stderr + p.stdout)

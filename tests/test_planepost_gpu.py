@@ -207,3 +207,52 @@ def test_plane_clouds_other_size_and_row_pitch():
                                             npl.ctypes.data, 0.05, np.float32(0.1), n.ctypes.data, coef.ctypes.data, src.ctypes.data, off.ctypes.data, pts.ctypes.data, None, None, None))
     k = got["n"]
     assert n[0] == k and np.array_equal(off[0, :k + 1], got["pt_off"]) and np.array_equal(coef[0, :k], got["coef"]) and np.array_equal(pts[0, :off[0, k]], got["points"])
+
+
+def far_room_depth():
+    """A room seen from far: floor, ceiling, back wall and two side walls at 5-10 m, noise-free.  Its planes together hold about 16 000 voxels of 0.1 m - twice what
+    the frame's voxel table holds (max_points <= 8192) - but none of them more than the table.  pcl::VoxelGrid has no cap (reference src/Frame.cc:674-679)."""
+    import torch
+    from planarslam_amd import synth_se3
+    from planarslam_amd.synth import TUM3, gray_image
+    X, Y, Z = np.eye(3)
+    inf = np.inf
+    F = [(-Y, 1.45, X, Z), (Y, 2.25, X, Z), (-Z, 9.95, X, Y), (Z, 1.0, X, Y), (X, 3.95, Z, Y), (-X, 3.95, Z, Y)]
+    scene = dict(n=np.array([f[0] for f in F], np.float64), d=np.array([f[1] for f in F], np.float64), a=np.array([f[2] for f in F], np.float64),
+                 b=np.array([f[3] for f in F], np.float64), lo=np.full((6, 2), -inf), hi=np.full((6, 2), inf), toff=np.zeros((6, 2)), gain=np.ones(6))
+    tex = torch.from_numpy(gray_image(77, 736, 576)[None])
+    T = np.eye(4)[None]
+    _, d = synth_se3.render(torch, [scene], tex, T, TUM3, depth_noise=False, holes=False, pixel_noise=0)
+    return d[0].numpy().view(np.uint16)
+
+
+def test_frame_with_more_voxels_than_the_table_goes_plane_by_plane():
+    """a frame whose planes together exceed the voxel table used to lose ALL its planes in the adapter.  Now the one-pass call reports the
+    overflow (status 3) and the frame goes through once more plane by plane (planar_plane_clouds_set_plane_window; include/planar_adapters.hpp and
+    PlaneClouds.compute do this): every plane's cloud and refit are the oracle's, in plane order - bit-exact centroids, coefficients to 1e-6."""
+    from planarslam_amd import PlaneClouds, PlaneDetection
+    from planarslam_amd._lib import PlanarError
+    d = far_room_depth()
+    planes, labels = PlaneDetection(640, 480, max_batch=1).run(d)
+    oplanes, olabels = ol.peac_run(d)
+    assert np.array_equal(labels, olabels) and np.array_equal(planes, oplanes) and len(planes) >= 4
+    want = ol.plane_clouds(d, olabels, oplanes)
+    per_plane = np.diff(want["pt_off"])
+    assert want["pt_off"][-1] > 8192 and per_plane.max() <= 8192, (int(want["pt_off"][-1]), per_plane.tolist())      # the premise: too many together, none alone
+    pcz = PlaneClouds(640, 480, max_points=8192)
+    pl = np.zeros((1, pcz.pl_stride, 8)); pl[0, :len(planes)] = planes
+    npl = np.array([len(planes)], np.int32)
+    with pytest.raises(PlanarError) as e:                                      # the one-pass call says so ...
+        pcz.compute(d[None], labels[None], pl, npl, retry_per_plane=False)
+    assert e.value.code == -4 and "(code 3" in str(e.value)
+    got = pcz.compute(d[None], labels[None], pl, npl)[0]                       # ... and the plane-by-plane pass delivers what pcl::VoxelGrid delivers
+    assert got["dropped"] == [] and got["n"] == want["n"] and np.array_equal(got["src"], want["src"]) and np.array_equal(got["pt_off"], want["pt_off"])
+    assert np.array_equal(got["points"], want["points"])
+    assert np.abs(got["coef"] - want["coef"]).max() <= 1e-6
+    # the window is reset: an ordinary frame afterwards goes through in one pass
+    d2 = depth_image(4321)
+    p2, l2 = PlaneDetection(640, 480, max_batch=1).run(d2)
+    pl2 = np.zeros((1, pcz.pl_stride, 8)); pl2[0, :len(p2)] = p2
+    g2 = pcz.compute(d2[None], l2[None], pl2, np.array([len(p2)], np.int32))[0]
+    w2 = ol.plane_clouds(d2, l2, p2)
+    assert "dropped" not in g2 and g2["n"] == w2["n"] and np.array_equal(g2["points"], w2["points"])
