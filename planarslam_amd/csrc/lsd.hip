@@ -86,13 +86,16 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // ---- K1: 8U fixed-point Gaussian, ksize 5 or 7 (cv::GaussianBlur, BORDER_REFLECT_101) ---------------------------
 template <int KS>
 __global__ __launch_bounds__(256) void lsd_gauss(const uint8_t* __restrict__ src, int pitch, int64_t src_stride, int W, int H,
-                                                 const int* __restrict__ taps_g, uint8_t* __restrict__ ws, size_t frame_bytes, size_t off_dst) {
+                                                 const int* __restrict__ taps_g, uint8_t* __restrict__ ws, size_t frame_bytes, size_t off_dst, int B) {
     constexpr int R = KS / 2, TW = 64, TH = 16;
     __shared__ uint8_t s_in[TH + 2 * R][TW + 2 * R];
     __shared__ uint16_t s_h[TH + 2 * R][TW];
     int taps[KS];
     for (int i = 0; i < KS; i++) taps[i] = taps_g[i];
-    const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tid = threadIdx.x;
+    int b, tile;
+    xcd_frame_block(tiles_x * tiles_y, B, b, tile);          // neighbouring tiles share their halos: a frame's tiles on one XCD (common.h)
+    const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
     const uint8_t* S = src + (int64_t)b * src_stride;
     for (int i = tid; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
         const int r = i / (TW + 2 * R), c = i % (TW + 2 * R);
@@ -1607,9 +1610,9 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
         o->ev_cur = &o->ev_sets[o->ev_used++];
         (void)hipEventRecord((*o->ev_cur)[0], st);
     }
-    const dim3 gfull((P.W + 63) / 64, (P.H + 15) / 16, B);
-    hipLaunchKernelGGL(lsd::lsd_gauss<7>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>(), ws, P.frame_bytes, P.off_blur7);
-    hipLaunchKernelGGL(lsd::lsd_gauss<5>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>() + 8, ws, P.frame_bytes, P.off_blur5);
+    const dim3 gfull((unsigned)(((P.W + 63) / 64) * ((P.H + 15) / 16) * B));
+    hipLaunchKernelGGL(lsd::lsd_gauss<7>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>(), ws, P.frame_bytes, P.off_blur7, B);
+    hipLaunchKernelGGL(lsd::lsd_gauss<5>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>() + 8, ws, P.frame_bytes, P.off_blur5, B);
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[1], st);
     if (o->tie_order != 0) hipLaunchKernelGGL(lsd::lsd_sort_raster, dim3(B), dim3(lsd::SORT_NT), 0, st, dP, ws, dm);

@@ -187,16 +187,17 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int stride, int 
 
 __global__ __launch_bounds__(256) void orb_fast_cells(const PlanDev* __restrict__ plan, const CellDev* __restrict__ cells,
                                                       const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
-                                                      int* __restrict__ cell_count, int* __restrict__ dropped) {
+                                                      int* __restrict__ cell_count, int* __restrict__ dropped, int B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_wave_cnt[4];
     __shared__ int s_any_ini;
-    const CellDev C = cells[blockIdx.x];
+    int frame, cell;
+    xcd_frame_block(plan->ncells_total, B, frame, cell);      // neighbouring cells share their 3-pixel halos: a frame's cells on one XCD (common.h)
+    const CellDev C = cells[cell];
     const LevelDev& L = plan->lv[C.level];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ww = C.ww, wh = C.wh;
-    const int frame = blockIdx.y;
-    int* out_count = cell_count + (int64_t)frame * plan->ncells_total + blockIdx.x;
+    int* out_count = cell_count + (int64_t)frame * plan->ncells_total + cell;
     if (ww <= 0 || wh <= 0) { if (tid == 0) *out_count = 0; return; }
     const int tw = ww + 6, th = wh + 6;            // pixel tile with 3-px halo
     // the tile is fetched as aligned 32-bit words (rows of the pyramid start on 16-byte boundaries): it begins `mis` bytes left of the window's halo
@@ -607,15 +608,17 @@ __global__ __launch_bounds__(64) void orb_octree(const PlanDev* __restrict__ pla
 struct TileDev { short level, tx, ty, pad; };
 
 __global__ __launch_bounds__(256) void orb_blur(const PlanDev* __restrict__ plan, const TileDev* __restrict__ tiles,
-                                                const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+                                                const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int n_tiles, int B) {
     // 22 input rows x 18 words (columns x0 - 4 .. x0 + 67) as 32-bit words; horizontal sums as u16 with a row stride of 68 (8-byte aligned, banks spread)
     __shared__ uint32_t s_pw[22][19];
     __shared__ __attribute__((aligned(8))) uint16_t s_h[22][68];
-    const TileDev T = tiles[blockIdx.x];
+    int frame, tile;
+    xcd_frame_block(n_tiles, B, frame, tile);                 // neighbouring tiles share 3 rows / 4 columns of halo: a frame's tiles on one XCD (common.h)
+    const TileDev T = tiles[tile];
     const LevelDev& L = plan->lv[T.level];
     const int tid = threadIdx.x;
     const int x0 = T.tx * 64, y0 = T.ty * 16;
-    const uint8_t* img = pyr + (int64_t)blockIdx.y * plan->pyr_stride + L.off;
+    const uint8_t* img = pyr + (int64_t)frame * plan->pyr_stride + L.off;
     for (int i = tid; i < 22 * 18; i += 256) {
         const int r = i / 18, wq = i - r * 18;
         int y = y0 + r - 3;
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(256) void orb_blur(const PlanDev* __restrict__ plan
         for (int i = 0; i < 4; i++) packed |= min((acc[i] + 32768u) >> 16, 255u) << (8 * i);
         const int y = y0 + r, x = x0 + c4;
         if (y < L.h && x < L.pitch)
-            *(uint32_t*)(blur + (int64_t)blockIdx.y * plan->pyr_stride + L.off + (int64_t)y * L.pitch + x) = packed;
+            *(uint32_t*)(blur + (int64_t)frame * plan->pyr_stride + L.off + (int64_t)y * L.pitch + x) = packed;
     }
 }
 
@@ -1088,8 +1091,8 @@ int planar_orb_extract_dev(planar_orb* o, const uint8_t* d_gray, int B, int pitc
         hipLaunchKernelGGL(orb_resize, dim3((n + 255) / 256, B), dim3(256), 0, st, dp, o->d_tabs.as<short4>(), pyr, l);
         mark();
     }
-    hipLaunchKernelGGL(orb_fast_cells, dim3(P.ncells_total, B), dim3(256), o->fast_smem, st, dp, o->d_cells.as<CellDev>(), pyr,
-                       o->d_cand.as<uint32_t>(), o->d_cell_count.as<int>(), o->d_dropped.as<int>());
+    hipLaunchKernelGGL(orb_fast_cells, dim3(P.ncells_total * B), dim3(256), o->fast_smem, st, dp, o->d_cells.as<CellDev>(), pyr,
+                       o->d_cand.as<uint32_t>(), o->d_cell_count.as<int>(), o->d_dropped.as<int>(), B);
     mark();
     hipLaunchKernelGGL(orb_sort, dim3(P.nlevels, B), dim3(256), 0, st, dp, o->d_cells.as<CellDev>(), o->d_cand.as<uint32_t>(),
                        o->d_cell_count.as<int>(), o->d_sortA.as<uint64_t>(), o->d_sortB.as<uint64_t>(), o->d_level_count.as<int>());
@@ -1097,7 +1100,7 @@ int planar_orb_extract_dev(planar_orb* o, const uint8_t* d_gray, int B, int pitc
     hipLaunchKernelGGL(orb_octree, dim3(P.nlevels, B), dim3(64), o->oct_smem, st, dp, o->d_sortA.as<uint64_t>(), o->d_sortB.as<uint64_t>(),
                        o->d_level_count.as<int>(), o->d_kept.as<uint32_t>(), o->d_kept_count.as<int>(), o->node_cap);
     mark();
-    hipLaunchKernelGGL(orb_blur, dim3((unsigned)o->tiles.size(), B), dim3(256), 0, st, dp, o->d_tiles.as<TileDev>(), pyr, o->d_blur.as<uint8_t>());
+    hipLaunchKernelGGL(orb_blur, dim3((unsigned)o->tiles.size() * B), dim3(256), 0, st, dp, o->d_tiles.as<TileDev>(), pyr, o->d_blur.as<uint8_t>(), (int)o->tiles.size(), B);
     mark();
     hipLaunchKernelGGL(orb_describe, dim3((P.kp_cap + 15) / 16 * B), dim3(256), 0, st, dp, pyr, o->d_blur.as<uint8_t>(), o->d_kept.as<uint32_t>(),
                        o->d_kept_count.as<int>(), d_kps, d_desc, d_n_out, (P.kp_cap + 15) / 16, B);

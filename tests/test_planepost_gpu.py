@@ -53,7 +53,7 @@ def test_refit_many_iterations_exact():
     assert max(its) >= 8 and sum(its) >= 50, its
 
 
-def _gpu_frames(depths, dist_th=0.05, max_points=4096, debug=True):
+def _gpu_frames(depths, dist_th=0.05, max_points=4096, debug=True, retry_per_plane=True):
     from planarslam_amd import PlaneClouds, PlaneDetection
     B = len(depths)
     det = PlaneDetection(640, 480, max_batch=B)
@@ -61,7 +61,7 @@ def _gpu_frames(depths, dist_th=0.05, max_points=4096, debug=True):
     planes = np.zeros((B, det.max_planes, 8)); labels = np.zeros((B, 480, 640), np.int32); n = np.zeros(B, np.int32)
     for b, (p, l) in enumerate(res):
         planes[b, :len(p)] = p; labels[b] = l; n[b] = len(p)
-    return res, PlaneClouds(640, 480, max_batch=B, max_points=max_points).compute(depths, labels, planes, n, dist_th=dist_th, debug=debug)
+    return res, PlaneClouds(640, 480, max_batch=B, max_points=max_points).compute(depths, labels, planes, n, dist_th=dist_th, debug=debug, retry_per_plane=retry_per_plane)
 
 
 @pytest.mark.parametrize("dist_th", [0.05, 0.03])
@@ -128,7 +128,10 @@ def test_plane_clouds_capacity_is_reported():
     from planarslam_amd import PlanarError
     depths = depth_image(50)[None]
     with pytest.raises(PlanarError):
-        _gpu_frames(depths, max_points=64, debug=False)
+        _gpu_frames(depths, max_points=64, debug=False, retry_per_plane=False)
+    # with the plane-by-plane pass a plane that alone overflows the table is dropped and listed (here every plane: 64 voxels hold 0.6 m^2)
+    res, got = _gpu_frames(depths, max_points=64, debug=False)
+    assert got[0]["n"] == 0 and got[0]["dropped"] == list(range(len(res[0][0])))
 
 
 def test_flag_matched_plane_points_matches_oracle():
