@@ -120,6 +120,77 @@ __global__ __launch_bounds__(256) void lsd_gauss(const uint8_t* __restrict__ src
     }
 }
 
+// Both Gaussians (7x7 for the detector, 5x5 for the descriptor) of one 64x16 tile from ONE read of the tile, four pixels per thread: the image as aligned 32-bit
+// words, horizontal sums as packed u16 in LDS, four outputs per thread and store.  Same fixed-point arithmetic as lsd_gauss (u16-saturated row sums, (s + 2^15) >> 16).
+// Requires W % 4 == 0, pitch % 4 == 0 and 4-byte aligned frames (the host falls back to lsd_gauss otherwise).
+__global__ __launch_bounds__(256) void lsd_gauss75(const uint8_t* __restrict__ src, int pitch, int64_t src_stride, int W, int H, const int* __restrict__ taps_g,
+                                                   uint8_t* __restrict__ ws, size_t frame_bytes, size_t off7, size_t off5, int B) {
+    constexpr int TW = 64, TH = 16, R = 3, NR = TH + 2 * R, NWD = TW / 4 + 2;      // 22 input rows x 18 words (columns x0 - 4 .. x0 + 67)
+    __shared__ uint32_t s_in[NR][NWD + 1];
+    __shared__ __attribute__((aligned(8))) uint16_t s_h7[NR][TW + 4], s_h5[NR][TW + 4];
+    int t7[7], t5[5];
+    for (int i = 0; i < 7; i++) t7[i] = taps_g[i];
+    for (int i = 0; i < 5; i++) t5[i] = taps_g[8 + i];
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tid = threadIdx.x;
+    int b, tile;
+    xcd_frame_block(tiles_x * tiles_y, B, b, tile);          // neighbouring tiles share their halos: a frame's tiles on one XCD (common.h)
+    const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+    const uint8_t* S = src + (int64_t)b * src_stride;
+    for (int i = tid; i < NR * NWD; i += 256) {
+        const int r = i / NWD, wq = i - r * NWD;
+        const uint8_t* row = S + (int64_t)reflect101(y0 + r - R, H) * pitch;
+        const int xb = x0 - 4 + 4 * wq;
+        uint32_t v;
+        if (xb >= 0 && xb + 3 < W) v = *(const uint32_t*)(row + xb);
+        else v = (uint32_t)row[reflect101(xb, W)] | ((uint32_t)row[reflect101(xb + 1, W)] << 8) | ((uint32_t)row[reflect101(xb + 2, W)] << 16) | ((uint32_t)row[reflect101(xb + 3, W)] << 24);
+        s_in[r][wq] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < NR * (TW / 4); i += 256) {           // horizontal sums of outputs 4 * q .. 4 * q + 3 of row r: bytes 4 * q + 1 .. 4 * q + 10 of the word row
+        const int r = i / (TW / 4), q = i - r * (TW / 4);
+        const uint32_t w0 = s_in[r][q], w1 = s_in[r][q + 1], w2 = s_in[r][q + 2];
+        uint32_t px[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { px[k] = (w0 >> (8 * k)) & 0xffu; px[4 + k] = (w1 >> (8 * k)) & 0xffu; px[8 + k] = (w2 >> (8 * k)) & 0xffu; }
+        uint32_t h7[4], h5[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {                          // output column 4 * q + o = word-row byte 4 + 4 * q + o; taps reach bytes o + 1 .. o + 7 of px
+            uint32_t a = 0, c = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) a += (uint32_t)t7[k] * px[o + 1 + k];
+#pragma unroll
+            for (int k = 0; k < 5; k++) c += (uint32_t)t5[k] * px[o + 2 + k];
+            h7[o] = min(a, 65535u); h5[o] = min(c, 65535u);
+        }
+        *(uint2*)&s_h7[r][4 * q] = make_uint2(h7[0] | (h7[1] << 16), h7[2] | (h7[3] << 16));
+        *(uint2*)&s_h5[r][4 * q] = make_uint2(h5[0] | (h5[1] << 16), h5[2] | (h5[3] << 16));
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, q = tid & 15;                  // 16 rows x 16 groups of four columns
+        const int x = x0 + 4 * q, y = y0 + r;
+        if (x < W && y < H) {
+            uint32_t a[4] = {0, 0, 0, 0}, c[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const uint2 v = *(const uint2*)&s_h7[r + k][4 * q];
+                a[0] += (uint32_t)t7[k] * (v.x & 0xffffu); a[1] += (uint32_t)t7[k] * (v.x >> 16); a[2] += (uint32_t)t7[k] * (v.y & 0xffffu); a[3] += (uint32_t)t7[k] * (v.y >> 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint2 v = *(const uint2*)&s_h5[r + 1 + k][4 * q];
+                c[0] += (uint32_t)t5[k] * (v.x & 0xffffu); c[1] += (uint32_t)t5[k] * (v.x >> 16); c[2] += (uint32_t)t5[k] * (v.y & 0xffffu); c[3] += (uint32_t)t5[k] * (v.y >> 16);
+            }
+            uint32_t o7 = 0, o5 = 0;
+#pragma unroll
+            for (int o = 0; o < 4; o++) { o7 |= min((a[o] + 32768u) >> 16, 255u) << (8 * o); o5 |= min((c[o] + 32768u) >> 16, 255u) << (8 * o); }
+            uint8_t* F = ws + (size_t)b * frame_bytes;
+            *(uint32_t*)(F + off7 + (size_t)y * W + x) = o7;
+            *(uint32_t*)(F + off5 + (size_t)y * W + x) = o5;
+        }
+    }
+}
+
 // ---- K2: INTER_LINEAR_EXACT 0.8x resample + ll_angle gradient ------------------------------------------------------
 struct Coef { int ofs, c0, c1; };
 
@@ -1611,8 +1682,12 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
         (void)hipEventRecord((*o->ev_cur)[0], st);
     }
     const dim3 gfull((unsigned)(((P.W + 63) / 64) * ((P.H + 15) / 16) * B));
-    hipLaunchKernelGGL(lsd::lsd_gauss<7>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>(), ws, P.frame_bytes, P.off_blur7, B);
-    hipLaunchKernelGGL(lsd::lsd_gauss<5>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>() + 8, ws, P.frame_bytes, P.off_blur5, B);
+    if ((P.W & 3) == 0 && (pitch & 3) == 0 && (frame_stride & 3) == 0 && ((uintptr_t)d_gray & 3) == 0 && (P.off_blur7 & 3) == 0 && (P.off_blur5 & 3) == 0 && (P.frame_bytes & 3) == 0)
+        hipLaunchKernelGGL(lsd::lsd_gauss75, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>(), ws, P.frame_bytes, P.off_blur7, P.off_blur5, B);
+    else {
+        hipLaunchKernelGGL(lsd::lsd_gauss<7>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>(), ws, P.frame_bytes, P.off_blur7, B);
+        hipLaunchKernelGGL(lsd::lsd_gauss<5>, gfull, dim3(256), 0, st, d_gray, pitch, frame_stride, P.W, P.H, o->d_taps.as<int>() + 8, ws, P.frame_bytes, P.off_blur5, B);
+    }
     hipLaunchKernelGGL(lsd::lsd_grad, dim3((P.w + 63) / 64, (P.h + 3) / 4, B), dim3(256), 0, st, dP, o->d_cx.as<lsd::Coef>(), o->d_cy.as<lsd::Coef>(), ws, dm);
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[1], st);
     if (o->tie_order != 0) hipLaunchKernelGGL(lsd::lsd_sort_raster, dim3(B), dim3(lsd::SORT_NT), 0, st, dP, ws, dm);
