@@ -117,7 +117,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="camera streams per GPU = frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="camera streams per GPU = frames per GPU per step (0: 1536 for the full workload - six frames per CU; the "
+                                                         "one-workgroup-per-frame kernels end with their slowest frames and a longer launch hides more of that tail: 10.3 k frames/s "
+                                                         "at 1024, 10.7-10.9 k at 1536, measured in round 5; 2048 does not fit the five buffer sets' workspaces in 288 GB -, "
+                                                         "1024 for --workload orb, 256 for --workload pose)")
     ap.add_argument("--workload", choices=["full", "orb", "ba", "pose"], default="full",
                     help="full: the per-frame path (BASELINE metric); orb: config[1] only; ba: config[4], ONE local bundle adjustment partitioned over the ranks")
     ap.add_argument("--depth", type=int, default=3, help="software-pipeline depth: the tracking chain of step i runs during step i + depth")
@@ -168,8 +171,8 @@ def main():
         return main_pose(args)
     if args.workload == "ba":
         return main_ba(args)
-    B = args.batch
     full = args.workload == "full"
+    B = args.batch or (1536 if full else 1024)
     # ---- inputs: generated on worker processes BEFORE the GPU runtime is initialised (fork) ----
     from planarslam_amd.synth import TUM3, pan_offset, stream_canvases
     ncanv = min(args.canvases, B)
@@ -454,7 +457,7 @@ def main():
             if k.strip('"').replace("void ", "").startswith(per[dom]["rocprof_name"]):
                 f_tot += float(f_kb); w_tot += float(w_kb)
         if f_tot + w_tot > 0:
-            traffic = int((f_tot + w_tot) * 1024 * B / 1024)
+            traffic = int((f_tot + w_tot) * 1024 * B / 1024)                      # (the counter passes run B = 1024: scaled to this run's frames per launch)
             traffic_note = (f"NOT measured in this run: read from the committed {os.path.relpath(pmc_csv, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
                             f"`bench.py --canvases 16 --gen-procs 1`, B=1024; counter collection hangs in forked children): {f_tot / 1024:.0f} MB read + {w_tot / 1024:.0f} MB written per launch")
         else:
@@ -661,7 +664,7 @@ def main():
             r_o = cb.run(cpu_s / 2, seed=rank, full=False)
             sub["orb"]["cpu_baseline"] = {"value": round(r_o["frames"] / r_o["seconds"], 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                           "sample": "%d frames through oracle/orb_oracle.cpp (pinned to the real ORBextractor.cc), one thread" % r_o["frames"]}
-        sub["pose"] = pose_line(args.sub_steps, 3, cpu_s, 1024, ranks, local_rank, dev)
+        sub["pose"] = pose_line(args.sub_steps, 3, cpu_s, 0, ranks, local_rank, dev)
         sub["ba"] = ba_line(max(3, args.sub_steps // 4), 2, cpu_s / 2, args.backend, ranks, local_rank, dev)
 
     workload = ("configs[2]+[3] as the reference's per-frame Track(): extract (ORB + LSD/LBD lines + isLineGood + PEAC planes + voxel clouds / RANSAC refit + surface normals on three streams, ComputeStereoFromRGBD) -> TrackManhattanFrame -> "
@@ -837,7 +840,7 @@ def pose_line(steps, warmup, cpu_seconds, batch, ranks, local_rank, dev):
     from planarslam_amd.synth import TUM3, pose_batch
     args = types.SimpleNamespace(steps=steps, warmup=warmup, cpu_seconds=cpu_seconds, batch=batch)
     rank, world = ranks.rank, ranks.world
-    B = 256 if args.batch == 1024 else args.batch                 # (--batch keeps its default for the full workload; this one is quoted on 256)
+    B = args.batch or 256                                         # BASELINE configs[3] is quoted on 256
     host = pose_batch(B=B, n_points=1000, n_lines=75, n_planes=4, seed=7 + 1000 * rank)
     L = lib()
     stream = torch.cuda.Stream(device=dev)

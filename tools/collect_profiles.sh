@@ -6,17 +6,15 @@
 # On a box whose image is still paging in, the first `import torch` alone takes 1-2 minutes: every mode starts with an untimed-in-spirit warm-up import (own timeout), so
 # that the per-command timeouts below measure the commands and not the cold start (twice this round a call on a cold box ran into every timeout with no output).
 # Give the bench mode `gpurun --timeout 600`.
-tag=${1:-r04}; what=${2:-bench}
+tag=${1:-r05}; what=${2:-bench}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 240 python -c "import torch, numpy; print('warm', torch.cuda.is_available())" > $O/${tag}_warmup.log 2>&1
-FL="--steps 6 --warmup 3 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
+FL="--steps 6 --warmup 3 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 --sub-steps 0"
 # counter passes: the textures are synthesised in-process (--gen-procs 1, 16 rooms, 4-frame loops): rocprofv3 --pmc hangs when the profiled process forks workers (profiles/README.md)
-PF="--gen-procs 1 --canvases 16 --loop 4 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0"
+PF="--gen-procs 1 --canvases 16 --loop 4 --batch 1024 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 --sub-steps 0"   # B = 1024 as in every earlier round's counter files (bench.py scales traffic to its own batch)
 if [ $what = bench ]; then
-    timeout 240 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
-    timeout 60 python bench.py --workload ba --steps 20 --warmup 3 > $O/${tag}_bench_ba.json 2>> $O/${tag}_bench.err
-    timeout 90 python bench.py --workload pose --steps 50 --warmup 5 > $O/${tag}_bench_pose.json 2>> $O/${tag}_bench.err
+    timeout 400 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err          # (configs[1] / [3] / [4] ride in its sub_benchmarks since round 5)
     cd /tmp && export TMPDIR=/tmp
     timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python $R/bench.py $FL > $O/${tag}_bench_under_rocprof.json 2>/dev/null
     cd $R
@@ -35,6 +33,22 @@ with open(sys.argv[2], "w", newline="") as f:
 PY
     t=$(ls $O/${tag}_trace/*/*kernel_trace.csv | head -1); (head -1 $t; tail -80 $t) > $O/${tag}_kernel_trace_tail.csv
     rm -rf $O/${tag}_trace
+    # the same summary at B = 1024 frames per launch: the batch every earlier round's tables are quoted on
+    cd /tmp
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace1k -- python $R/bench.py $FL --batch 1024 > $O/${tag}_bench_b1024_under_rocprof.json 2>/dev/null
+    cd $R
+    f=$(ls $O/${tag}_trace1k/*/*kernel_stats.csv | head -1); python - "$f" "$O/${tag}_kernel_stats_b1024.csv" << 'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "planar::" in r["Name"]]
+tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+with open(sys.argv[2], "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_ALL)
+    w.writeheader()
+    for r in rows:
+        r["Percentage"] = f"{100.0 * float(r['TotalDurationNs']) / tot:.2f}"
+        w.writerow(r)
+PY
+    rm -rf $O/${tag}_trace1k
     cut -c1-200 $O/${tag}_bench.json; head -5 $O/${tag}_kernel_stats.csv | cut -c1-160
 elif [ $what = pmc ]; then
     cd /tmp && export TMPDIR=/tmp
@@ -48,7 +62,7 @@ elif [ $what = pmc ]; then
     rm -rf $O/${tag}_pmc_fetch $O/${tag}_pmc_write $O/${tag}_pmc_sq1 $O/${tag}_pmc_sq2
     head -8 $O/${tag}_pmc_fetch_write_kb_per_launch.csv; head -8 $O/${tag}_pmc_sq_per_launch.csv
 else
-    timeout 300 python -m pytest tests -m gpu -q > $O/${tag}_gpu_tests.log 2>&1
+    timeout 600 python -m pytest tests -m gpu -q > $O/${tag}_gpu_tests.log 2>&1
     timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${tag}_smoke.log 2>&1
     grep -a "passed\|failed" $O/${tag}_gpu_tests.log; tail -1 $O/${tag}_smoke.log
 fi
