@@ -524,13 +524,27 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
             }
             return cdist;
         };
+        // |n_a . n_b| of two extracted planes (PlaneSeg::normalSimilarity), normals from LDS for the first NGEO planes
+        auto nsim_planes = [&](int a, int b2) {
+            if (a < NGEO && b2 < NGEO) return fabs(s_geo[a][3] * s_geo[b2][3] + s_geo[a][4] * s_geo[b2][4] + s_geo[a][5] * s_geo[b2][5]);
+            return nsim(s_ext[a], s_ext[b2]);
+        };
         // queue[a], through the LDS ring where it holds it: entries [q_head, cached_hi) of the queue live in s_ring[a % NENT] and nowhere else
         int cached_hi = 0;
         auto entry_at = [&](int a) -> unsigned { return a < cached_hi ? s_ring[a & (NENT - 1)] : queue[a]; };
         int q_head = 0, q_tail = s_scalar[2], n_steps = 0;
+#ifdef PLANAR_REFINE_PHASES
+        long long ph[6] = {0, 0, 0, 0, 0, 0}, pt0 = 0;
+#define PH_T0() pt0 = (long long)wall_clock64()
+#define PH(i) do { const long long t_ = (long long)wall_clock64(); ph[i] += t_ - pt0; pt0 = t_; } while (0)
+#else
+#define PH_T0() do { } while (0)
+#define PH(i) do { } while (0)
+#endif
         while (q_head < q_tail && !err) {
             const int nent = min(NENT, q_tail - q_head);
             n_steps++;
+            PH_T0();
             // ---- A1 ----
             if (tid == 0) s_scalar[3] = 0;
             if (tid < PBW) s_pushbits[tid] = 0u;
@@ -581,6 +595,7 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
                 }
             }
             __syncthreads();
+            PH(0);
             // ---- A2 ----
             const int nwork = s_scalar[3];
             for (int t = tid; t < nwork; t += NT) {
@@ -592,49 +607,72 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
                 s_next[t] = (unsigned short)atomicExch(&s_head[slot_of(cx, cy)], (unsigned)t);
             }
             __syncthreads();
+            PH(1);
             // ---- B ----
             for (int t = tid; t < nwork; t += NT) {
                 const unsigned wt = s_word[t];
                 const unsigned pixw = wt & 0xffffffu;
                 const int px = (int)(wt & 0xfffu), py = (int)((wt >> 12) & 0xfffu);
                 const int myp = (int)s_pair[t];
-                const unsigned h0 = s_head[slot_of(px, py)];
-                bool leader = true;
-                for (unsigned q = h0; q != END; q = s_next[q])
-                    if ((s_word[q] & 0xffffffu) == pixw && (int)s_pair[q] < myp) { leader = false; break; }
-                if (!leader) continue;
                 const size_t pix = (size_t)py * W + px;
                 const int trail0 = (int)s_m0[t];
+                float dcur = 3.4028234663852886e38f;
+                if (trail0 >= 0) dcur = distMap[pix];                      // (asked for before the chain is walked: the round trip overlaps the walk)
+                const unsigned h0 = s_head[slot_of(px, py)];
+                // ONE walk of the slot's chain: am I the pixel's first pair, and which are its items - up to four are kept in registers, sorted by pair index
+                unsigned qi[4] = {END, END, END, END};
+                int qp[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+                int m = 0;
+                bool leader = true;
+                for (unsigned q = h0; q != END; q = s_next[q]) {
+                    if ((s_word[q] & 0xffffffu) != pixw) continue;
+                    int p_ = (int)s_pair[q];
+                    unsigned i_ = q;
+                    if (p_ < myp) { leader = false; break; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (p_ < qp[k]) { const int tp = qp[k]; const unsigned ti = qi[k]; qp[k] = p_; qi[k] = i_; p_ = tp; i_ = ti; }
+                    m++;
+                }
+                if (!leader) continue;
+                // one pair of this pixel, in the reference's order: `trail` is the membership byte as it stands, dcur the distance that goes with a membership >= 0
+                auto step_item = [&](unsigned it, int itp, bool commit, int& trail, float& dc, int& nclaims) {
+                    const unsigned w = s_word[it];
+                    const int plid = (int)((w >> 24) & 0x7fu);
+                    if (!(trail <= -6) && !(trail >= 0 && trail == plid)) {
+                        if (w >> 31) {
+                            if (commit && trail >= 0 && nsim_planes(plid, trail) >= C.cos_refine) {   // n_pl.connect(pl)
+                                atomicOr(&s_adj[trail][plid >> 5], 1u << (plid & 31));
+                                atomicOr(&s_adj[plid][trail >> 5], 1u << (trail & 31));
+                            }
+                            const float cd = s_cd[it];
+                            if (cd < (trail >= 0 ? dc : 3.4028234663852886e38f)) {
+                                trail = plid; dc = cd; nclaims++;
+                                if (commit) atomicOr(&s_pushbits[itp >> 5], 1u << (itp & 31));
+                            } else if (trail < 0) trail -= 1;
+                        } else if (trail < 0) trail -= 1;
+                    }
+                };
                 // the fold over this pixel's items with pair index < limit, in ascending pair index; commit: with its side effects (connects, push bits)
-                auto fold = [&](int limit, bool commit, int& trail, float& dcur, int& nclaims) {
-                    int lastp = -1;
+                auto fold = [&](int limit, bool commit, int& trail, float& dc, int& nclaims) {
+                    if (m <= 4) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (k < m && qp[k] < limit) step_item(qi[k], qp[k], commit, trail, dc, nclaims);
+                        return;
+                    }
+                    int lastp = -1;                                        // more than four pairs at one pixel in one step: pick them off the chain one by one
                     while (true) {
                         unsigned best = END; int bestp = 0x7fffffff;
                         for (unsigned q = h0; q != END; q = s_next[q]) {
-                            const int qp = (int)s_pair[q];
-                            if ((s_word[q] & 0xffffffu) == pixw && qp > lastp && qp < bestp) { best = q; bestp = qp; }
+                            const int qp_ = (int)s_pair[q];
+                            if ((s_word[q] & 0xffffffu) == pixw && qp_ > lastp && qp_ < bestp) { best = q; bestp = qp_; }
                         }
                         if (best == END || bestp >= limit) break;
                         lastp = bestp;
-                        const unsigned w = s_word[best];
-                        const int plid = (int)((w >> 24) & 0x7fu);
-                        if (!(trail <= -6) && !(trail >= 0 && trail == plid)) {
-                            if (w >> 31) {
-                                if (commit && trail >= 0 && nsim(s_ext[plid], s_ext[trail]) >= C.cos_refine) {   // n_pl.connect(pl)
-                                    atomicOr(&s_adj[trail][plid >> 5], 1u << (plid & 31));
-                                    atomicOr(&s_adj[plid][trail >> 5], 1u << (trail & 31));
-                                }
-                                const float cd = s_cd[best];
-                                if (cd < (trail >= 0 ? dcur : 3.4028234663852886e38f)) {
-                                    trail = plid; dcur = cd; nclaims++;
-                                    if (commit) atomicOr(&s_pushbits[bestp >> 5], 1u << (bestp & 31));
-                                } else if (trail < 0) trail -= 1;
-                            } else if (trail < 0) trail -= 1;
-                        }
+                        step_item(best, bestp, commit, trail, dc, nclaims);
                     }
                 };
                 int trail = trail0, nclaims = 0;
-                float dcur = trail0 >= 0 ? distMap[pix] : 3.4028234663852886e38f;
                 const float dcur0 = dcur;
                 fold(0x7fffffff, true, trail, dcur, nclaims);
                 if (trail != trail0) member[pix] = (signed char)trail;
@@ -652,15 +690,17 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
                         if (dir < 0) continue;
                         int tr = trail0, nc = 0; float dc = dcur0;
                         fold(4 * e + dir, false, tr, dc, nc);
-                        if (tr >= 0 && tr != trail0 && nsim(s_ext[trail0], s_ext[tr]) >= C.cos_refine) {
+                        if (tr >= 0 && tr != trail0 && nsim_planes(trail0, tr) >= C.cos_refine) {
                             atomicOr(&s_adj[tr][trail0 >> 5], 1u << (trail0 & 31));
                             atomicOr(&s_adj[trail0][tr >> 5], 1u << (tr & 31));
                         }
                     }
                 }
             }
+            PH(2);
             __threadfence_block();
             __syncthreads();
+            PH(3);
             // ---- C: pushes in pair order ----
             if (wave == 0) {                                           // exclusive prefix popcounts of the push bitmap's words (lane l: words l * PBW / 64 ..)
                 constexpr int WPL = (PBW + 63) / 64;
@@ -696,7 +736,11 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
             q_tail += npush;
             q_head = q_next;
             __syncthreads();                                             // (global pushes are read at the earliest one step later: B's fence of that step is behind them)
+            PH(4);
         }
+#ifdef PLANAR_REFINE_PHASES
+        if (tid == 0 && timing) for (int i = 0; i < 5; i++) timing[(size_t)frame * TSLOTS + 20 + i] = ph[i];
+#endif
         if (tid == 0) { s_scalar[2] = q_tail; s_scalar[3] = n_steps; if (err) s_scalar[1] = err; }
     }
     __syncthreads();

@@ -47,4 +47,8 @@ for nm, v in (("seeds+erosion", seeds), ("flood fill", flood), ("cluster+relabel
 print(f"queue entries: mean {q.mean():.0f} p50 {np.median(q):.0f} max {q.max()}  -> flood-fill steps of 512 entries: mean {np.ceil(q / 512).mean():.0f}; us per step: {(flood * 1e3 / np.maximum(1, np.ceil(q / 512))).mean():.1f}")
 st = t[:, 7]
 print(f"flood-fill steps actually taken: mean {st.mean():.0f} p50 {np.median(st):.0f} max {st.max()}; entries per step {(q / np.maximum(st, 1)).mean():.0f}; us per step {(flood * 1e3 / np.maximum(st, 1)).mean():.2f}")
+if t[:, 20:25].any():
+    names = ("A1 entries+membership", "A2 geometry+chains", "B folds", "B fence+barrier", "C pushes")
+    tot = t[:, 20:25].sum(1).astype(float)
+    print("flood-fill phases (share of the loop, mean over frames; us per step): " + "  ".join(f"{n} {100 * (t[:, 20 + i] / np.maximum(tot, 1)).mean():.0f}% {(t[:, 20 + i] / 100.0 / np.maximum(st, 1)).mean():.1f}" for i, n in enumerate(names)))
 print(f"planes per frame {npl.float().mean().item():.2f}; unlabelled pixels {black.mean() * 100:.1f} %")
