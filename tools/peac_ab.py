@@ -1,4 +1,5 @@
-"""A/B of the clustering kernels (debug aid): runs PlaneDetection with the round-2 kernel (planar_peac_set_variant(.., 2, ..)) and with peac_ahc2 on the same depth
+"""A/B of the clustering kernels (debug aid): runs PlaneDetection with the exact-heap kernel only (planar_peac_set_variant(.., 1, ..); named "legacy" below for the
+round-2 kernel this tool was written against, which no longer exists) and with the product's fast attempt + exact redo on the same depth
 images, compares labels / planes with the oracle and - on a mismatch - the node records the two kernels left in the frame workspace (first node whose
 moments / plane / N / rid differ = the first merge that went differently), plus per-frame timing of both."""
 import os, sys
@@ -16,7 +17,7 @@ depths = np.stack([depth_image(SEED0 + i, noise=(i % 2 == 0) or SEED0 != 50, hol
 
 def run(kind):
     pd = PlaneDetection(640, 480, max_batch=B)
-    check(pd.L.planar_peac_set_variant(pd.h, 2 if kind == "legacy" else 0, -1))
+    check(pd.L.planar_peac_set_variant(pd.h, 1 if kind == "legacy" else 0, -1))
     try:
         res = pd.run(depths); err = None
     except Exception as e:   # capacity errors etc.
