@@ -655,7 +655,11 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
                 };
                 // the fold over this pixel's items with pair index < limit, in ascending pair index; commit: with its side effects (connects, push bits)
                 auto fold = [&](int limit, bool commit, int& trail, float& dc, int& nclaims) {
+#ifdef PLANAR_REFINE_PARANOID               // test build (tests/test_peac_gpu.py::test_rare_paths...): the generic path for every pixel
+                    if (false) {
+#else
                     if (m <= 4) {
+#endif
 #pragma unroll
                         for (int k = 0; k < 4; k++) if (k < m && qp[k] < limit) step_item(qi[k], qp[k], commit, trail, dc, nclaims);
                         return;
@@ -677,7 +681,11 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
                 fold(0x7fffffff, true, trail, dcur, nclaims);
                 if (trail != trail0) member[pix] = (signed char)trail;
                 if (nclaims) distMap[pix] = dcur;
+#ifdef PLANAR_REFINE_PARANOID               // ... and the replay whenever the pixel changed hands at all (then it only repeats connects the claims made themselves)
+                if (trail0 >= 0 && nclaims >= 1) {
+#else
                 if (trail0 >= 0 && nclaims >= 2) {
+#endif
                     // extra_connects: the pixel was plane A's at the start of the step and changed hands at least twice within it.  A pair (A -> this pixel) that
                     // the reference processes after the second change connects A with the owner of that moment; such pairs were left out in A1: find them among
                     // the step's entries (an entry of plane A on a 4-neighbour of the pixel), replay the fold up to each (no side effects) and connect

@@ -66,3 +66,41 @@ def test_hip_more_frames_than_cus_and_repeated_calls():
             wp, wl = want[b % 3]
             assert np.array_equal(res[b][1], wl), f"labels frame {b}"
             assert res[b][0].shape == wp.shape and np.array_equal(res[b][0], wp), f"planes frame {b}"
+
+
+def test_refinement_rare_paths_give_the_same_labels():
+    """peac_refine folds a pixel's pairs through a fast path (up to four pairs of one pixel in one flood-fill step, sorted in registers) and keeps two rare ones: the generic
+    fold (more than four pairs) and the `extra_connects` replay (the pixel changed hands twice within a step).  The test build `-DPLANAR_REFINE_PARANOID`
+    (make -C planarslam_amd/csrc paranoid) sends EVERY pixel through the generic fold and replays every pixel that changed hands at all - both must be no-ops on the
+    result: labels and planes of that build equal the product's (which equal the oracle's) on golden, synthetic and SE3-rendered frames."""
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "planarslam_amd", "libplanar_hip_paranoid.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "planarslam_amd", "csrc"), "paranoid"])
+    import torch
+    from planarslam_amd import PlaneDetection, synth_se3
+    from planarslam_amd.synth import TUM3, gray_image
+    tex = torch.from_numpy(np.stack([gray_image(1234 + i, 736, 576) for i in range(4)])).cuda()
+    _, loop_d, _ = synth_se3.render_streams(torch, tex, 8, 2, TUM3, seed=5)
+    depths = [np.load(p)["depth"] for p in GOLD] + [depth_image(50 + i, noise=(i % 2 == 0), holes=(i % 3 != 0)) for i in range(4)]
+    depths += [loop_d[b, 1].cpu().numpy().view(np.uint16) for b in range(8)]
+    depths = np.stack(depths)
+    res = PlaneDetection(640, 480, max_batch=len(depths)).run(depths)
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "d.npy"), depths)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+                "from planarslam_amd import PlaneDetection\n"
+                "d = np.load(%r)\n"
+                "r = PlaneDetection(640, 480, max_batch=len(d)).run(d)\n"
+                "np.savez(%r, labels=np.stack([x[1] for x in r]), n=np.array([len(x[0]) for x in r]), planes=np.concatenate([x[0] for x in r]))\n") % (root, os.path.join(td, "d.npy"), os.path.join(td, "o.npz"))
+        subprocess.check_call([sys.executable, "-W", "ignore", "-c", code], env=dict(os.environ, PLANAR_HIP_LIB=lib))
+        z = np.load(os.path.join(td, "o.npz"))
+    assert np.array_equal(z["n"], [len(x[0]) for x in res])
+    assert np.array_equal(z["labels"], np.stack([x[1] for x in res]))
+    assert np.array_equal(z["planes"], np.concatenate([x[0] for x in res]))
+    for b in (len(GOLD) + 4, len(depths) - 1):                       # (and the product's are the oracle's on the SE3 frames too)
+        op, olab = ol.peac_run(depths[b])
+        assert np.array_equal(res[b][1], olab) and np.array_equal(res[b][0], op)
