@@ -203,24 +203,38 @@ __device__ __forceinline__ int scaled_px(const uint8_t* __restrict__ B7, int W, 
     return (int)min((v + 32768u) >> 16, 255u);
 }
 
+// (float)cos / sin of the FP64 angle of a level-line angle in degrees: what a pixel contributes when it SEEDS a region (lsd.cpp region_grow: sumdx = cos(reg_angle), ...).
+// Rounds 1-4 stored the pair for every pixel (8 B per pixel written by lsd_grad, two FP64 trigonometric calls each); only a few thousand pixels per frame ever seed.
+__device__ __forceinline__ float2 seed_cos_sin(float deg) {
+    const double a = (double)deg * DEG_TO_RADS;
+    return make_float2((float)cos(a), (float)sin(a));
+}
+
 __global__ __launch_bounds__(256) void lsd_grad(const Plan* __restrict__ plan, const Coef* __restrict__ cxs, const Coef* __restrict__ cys,
                                                 uint8_t* __restrict__ ws, Misc* __restrict__ miscs) {
+    // the 65 x 5 pixels of the 0.8x image this workgroup's 64 x 4 gradients need, each resampled ONCE (rounds 1-4: four times, by the four gradients that share it)
+    __shared__ uint8_t s_px[5][68];
     const Plan& P = *plan;
     const int b = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.w || y >= P.h) return;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
     uint8_t* F = ws + (size_t)b * P.frame_bytes;
+    const uint8_t* B7 = F + P.off_blur7;
+    for (int i = threadIdx.x; i < 5 * 65; i += 256) {
+        const int r = i / 65, c = i - r * 65;
+        const int xs = min(x0 + c, P.w - 1), ys = min(y0 + r, P.h - 1);
+        s_px[r][c] = (uint8_t)scaled_px(B7, P.W, cxs[xs], cys[ys]);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= P.w || y >= P.h) return;
     float* ang = (float*)(F + P.off_ang);
     uint32_t* g2a = (uint32_t*)(F + P.off_g2);
     float4* pix4 = (float4*)(F + P.off_pix);      // {angle deg, cosf(angle), sinf(angle), compact index}: one 16-byte gather per neighbour
-    float2* seedcs = (float2*)(F + P.off_seed);   // (float)cos / sin of the FP64 angle, used when the pixel seeds a region
     Misc* misc = miscs + b;
     const size_t o = (size_t)y * P.w + x;
     if (x >= P.w - 1 || y >= P.h - 1) { ang[o] = NOTDEF_F; g2a[o] = 0; pix4[o] = make_float4(NOTDEF_F, 0.f, 0.f, 0.f); return; }
-    const uint8_t* B7 = F + P.off_blur7;
-    const Coef cx0 = cxs[x], cx1 = cxs[x + 1], cy0 = cys[y], cy1 = cys[y + 1];
-    const int s00 = scaled_px(B7, P.W, cx0, cy0), s10 = scaled_px(B7, P.W, cx1, cy0);
-    const int s01 = scaled_px(B7, P.W, cx0, cy1), s11 = scaled_px(B7, P.W, cx1, cy1);
+    const int s00 = s_px[ly][lx], s10 = s_px[ly][lx + 1], s01 = s_px[ly + 1][lx], s11 = s_px[ly + 1][lx + 1];
     const int DA = s11 - s00, BC = s10 - s01;
     const int gx = DA + BC, gy = DA - BC;
     const int g2 = gx * gx + gy * gy;
@@ -233,7 +247,6 @@ __global__ __launch_bounds__(256) void lsd_grad(const Plan* __restrict__ plan, c
         const double a = (double)deg * DEG_TO_RADS;
         const float af = (float)a;
         pix4[o] = make_float4(deg, (float)cos((double)af), (float)sin((double)af), 0.f);   // .w: compact index, filled by lsd_sort_compact
-        seedcs[o] = make_float2((float)cos(a), (float)sin(a));
         atomicMax(&misc->g2max, (uint32_t)g2);
     }
 }
@@ -499,7 +512,6 @@ struct Det {
     const float* ang;
     const uint32_t* g2;
     const float4* pix4;
-    const float2* seedcs;
     const Plan* plan;
     uint32_t* reg;      // region points, x | y << 16, in growth order
     uint32_t* tmp;      // scratch (reduce_region_radius)
@@ -781,7 +793,7 @@ __device__ bool refine(const Det& D, int& n, double& reg_angle, double prec, dou
     const double mean_angle = sum / double(cnt);
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / double(cnt) + mean_angle * mean_angle);
     wave_sync();
-    n = region_grow(D, seed_pix, rank_of(D, seed_pix), D.ang[seed_pix], D.seedcs[seed_pix], tau, reg_angle);
+    n = region_grow(D, seed_pix, rank_of(D, seed_pix), D.ang[seed_pix], seed_cos_sin(D.ang[seed_pix]), tau, reg_angle);
     wave_sync();
     if (n < 2) return false;
     region2rect(D, n, reg_angle, prec, p, rec);
@@ -1004,7 +1016,7 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
     Misc* misc = miscs + b;
     Det D;
     D.ang = (const float*)(F + P.off_ang); D.g2 = (const uint32_t*)(F + P.off_g2);
-    D.pix4 = (const float4*)(F + P.off_pix); D.seedcs = (const float2*)(F + P.off_seed); D.plan = plan;
+    D.pix4 = (const float4*)(F + P.off_pix); D.plan = plan;
     D.reg = (uint32_t*)(F + P.off_reg); D.tmp = (uint32_t*)(F + P.off_tmp);
     D.w = P.w; D.h = P.h; D.log_nt = P.log_nt; D.lane = lane;
     const int used_words = USED_LDS_BITS / 32, gused_words = (P.w * P.h + 31) / 32;
@@ -1027,7 +1039,8 @@ __global__ __launch_bounds__(64) void lsd_detect(const Plan* __restrict__ plan, 
         const int pix = base + lane < n_ord ? (int)ord[base + lane] : -1;
         const uint32_t prk = base + lane < n_ord ? ordr[base + lane] : 0u;
         const float sdeg = pix >= 0 ? D.ang[pix] : 0.f;             // seed angle / (cos, sin) of the 64 candidates of this block
-        const float2 scs = pix >= 0 ? D.seedcs[pix] : make_float2(0.f, 0.f);
+        float2 scs = make_float2(0.f, 0.f);                           // (on the fly, 64 candidates at a time, and only for blocks that still hold an unused pixel: see seed_cos_sin)
+        if (__ballot(pix >= 0 && !used_get(D, prk)) != 0ull) scs = pix >= 0 && sdeg != NOTDEF_F ? seed_cos_sin(sdeg) : make_float2(0.f, 0.f);
         int cursor = 0;
         while (true) {
             const bool cand = pix >= 0 && lane >= cursor && !used_get(D, prk);
@@ -1604,7 +1617,8 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     const size_t NPf = (size_t)width * height, NPs = (size_t)P.w * P.h;
     P.off_blur7 = carve(NPf); P.off_blur5 = carve(NPf); P.off_dx = 0; P.off_dy = 0;   // (no Sobel images since round 5)
     
-    P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_pix = carve(NPs * 16); P.off_seed = carve(NPs * 8); P.off_ordr = carve(NPs * 4); P.off_gused = carve((NPs + 31) / 32 * 4 + 256); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
+    P.off_ang = carve(NPs * 4); P.off_g2 = carve(NPs * 4); P.off_pix = carve(NPs * 16); P.off_seed = 0;   // (no per-pixel seed table since round 5)
+     P.off_ordr = carve(NPs * 4); P.off_gused = carve((NPs + 31) / 32 * 4 + 256); P.off_ord = carve(NPs * 4); P.off_tmp = carve(NPs * 4); P.off_reg = carve(NPs * 4 + 64);
     P.off_valid = carve((NPs + 63) / 64 * 8 + 8); P.off_sortr = carve((size_t)isort::G_FMAX * sizeof(isort::Range)); P.off_sortb = carve((size_t)isort::G_FMAX * sizeof(isort::Block)); P.off_heapj = carve((size_t)lsd::SORT_HJOBS * sizeof(isort::HeapJob));
     P.off_segs = carve((size_t)lsd::MAX_SEGS * sizeof(lsd::Seg)); P.off_kl = carve((size_t)lsd::MAX_SEGS * sizeof(planar_keyline));
     P.off_rects = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Rect)); P.off_res = carve((size_t)lsd::MAX_RECTS * sizeof(lsd::Seg)); P.off_est = carve((size_t)lsd::MAX_RECTS * 4);
