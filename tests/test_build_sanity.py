@@ -39,3 +39,18 @@ def test_pose_opt_kernel_has_no_scratch(tmp_path):
     assert get("vgpr_spill_count") == 0 and get("private_segment_fixed_size") == 0, blocks[0]
     assert get("vgpr_count") <= 256
     assert "scratch_" not in text[:text.index("amdhsa.kernels:")]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_peac_refine_fits_four_frames_per_cu(tmp_path):
+    """peac_refine runs one workgroup per frame and a batch of 1024 frames puts four on every CU: its LDS must stay within a quarter of a CU's 160 KB (round 5:
+    39.8 KB with the work-item arrays of the flood fill), and the flood-fill loop itself must not touch scratch (the spills of the final clustering are outside it)."""
+    out = tmp_path / "peac.s"
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-function", "-S", "--cuda-device-only",
+                           os.path.join(ROOT, "planarslam_amd", "csrc", "peac.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    meta = text[text.index("amdhsa.kernels:"):]
+    blocks = [b for b in meta.split("  - .agpr_count:") if "peac_refineE" in b]
+    assert len(blocks) == 1
+    lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blocks[0]).group(1))
+    assert lds <= 160 * 1024 // 4, lds
