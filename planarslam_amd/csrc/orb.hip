@@ -148,27 +148,39 @@ __device__ __forceinline__ bool has9(uint32_t m16) {
     return (a & 0xffffu) != 0;
 }
 
-__device__ __forceinline__ int fast_score_lds(const uint8_t* c, int stride, int min_th) {
+// Three stages of cv::FAST's test for one pixel, each a separate DENSE pass over the survivors of the one before (orb_fast_cells): with all three in one function a
+// wavefront executes the long stages whenever ONE of its 64 pixels needs them - on textured images that is always (rounds 1-4: 229 lane-instructions per pixel).
+// fast_quick: a run of 9 of the 16 circle pixels contains one pixel of every opposite pair, so two pairs decide most non-corners with four reads (cv::FAST does the same)
+__device__ __forceinline__ bool fast_quick(const uint8_t* c, int stride, int min_th) {
     const int v = c[0];
-    {   // a run of 9 of the 16 circle pixels contains one pixel of every opposite pair: two pairs decide most non-corners with four reads (cv::FAST does the same)
-        const int a0 = v - c[3 * stride], a8 = v - c[-3 * stride], a4 = v - c[3], a12 = v - c[-3];
-        const bool dark = (a0 > min_th || a8 > min_th) && (a4 > min_th || a12 > min_th);
-        const bool bright = (a0 < -min_th || a8 < -min_th) && (a4 < -min_th || a12 < -min_th);
-        if (!dark && !bright) return 0;
-    }
-    int d[16];
+    const int a0 = v - c[3 * stride], a8 = v - c[-3 * stride], a4 = v - c[3], a12 = v - c[-3];
+    const bool dark = (a0 > min_th || a8 > min_th) && (a4 > min_th || a12 > min_th);
+    const bool bright = (a0 < -min_th || a8 < -min_th) && (a4 < -min_th || a12 < -min_th);
+    return dark || bright;
+}
+__device__ __forceinline__ void fast_ring(const uint8_t* c, int stride, int d[16]) {
+    const int v = c[0];
     d[0] = v - c[3 * stride];       d[1] = v - c[3 * stride + 1];   d[2] = v - c[2 * stride + 2];   d[3] = v - c[stride + 3];
     d[4] = v - c[3];                d[5] = v - c[-stride + 3];      d[6] = v - c[-2 * stride + 2];  d[7] = v - c[-3 * stride + 1];
     d[8] = v - c[-3 * stride];      d[9] = v - c[-3 * stride - 1];  d[10] = v - c[-2 * stride - 2]; d[11] = v - c[-stride - 3];
     d[12] = v - c[-3];              d[13] = v - c[stride - 3];      d[14] = v - c[2 * stride - 2];  d[15] = v - c[3 * stride - 1];
+}
+// fast_is_corner: nine contiguous circle pixels darker / brighter than the centre by more than min_th
+__device__ __forceinline__ bool fast_is_corner(const uint8_t* c, int stride, int min_th) {
+    int d[16];
+    fast_ring(c, stride, d);
     uint32_t dark = 0, bright = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         dark |= (uint32_t)(d[k] > min_th) << k;
         bright |= (uint32_t)(d[k] < -min_th) << k;
     }
-    if (!(has9(dark) || has9(bright))) return 0;
-    // exact score: max over the 16 nine-pixel arcs of min(d) (dark) / min(-d) (bright), minus 1
+    return has9(dark) || has9(bright);
+}
+// fast_corner_score: cornerScore<16> of a pixel that IS a corner: max over the 16 nine-pixel arcs of min(d) (dark) / min(-d) (bright), minus 1
+__device__ __forceinline__ int fast_corner_score(const uint8_t* c, int stride) {
+    int d[16];
+    fast_ring(c, stride, d);
     int lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
@@ -190,7 +202,7 @@ __global__ __launch_bounds__(256) void orb_fast_cells(const PlanDev* __restrict_
                                                       int* __restrict__ cell_count, int* __restrict__ dropped, int B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_wave_cnt[4];
-    __shared__ int s_any_ini;
+    __shared__ int s_any_ini, s_cnt;
     int frame, cell;
     xcd_frame_block(plan->ncells_total, B, frame, cell);      // neighbouring cells share their 3-pixel halos: a frame's cells on one XCD (common.h)
     const CellDev C = cells[cell];
@@ -214,16 +226,49 @@ __global__ __launch_bounds__(256) void orb_fast_cells(const PlanDev* __restrict_
                 *(uint32_t*)(tile + y * tstride + 4 * q) = *(const uint32_t*)(img + (int64_t)(C.y0 - 3 + y) * L.pitch + (gx0 - mis) + 4 * q);
     }
     for (int i = tid; i < sw * sh; i += 256) score[i] = 0;
-    if (tid == 0) s_any_ini = 0;
+    if (tid == 0) { s_any_ini = 0; s_cnt = 0; }
     __syncthreads();
     const int min_th = plan->min_th, ini_th = plan->ini_th;
     const int npx = ww * wh;
     const float inv_ww = 1.0f / (float)ww;
     auto row_of = [&](int p_) { return (int)(((float)p_ + 0.5f) * inv_ww); };      // p / ww for p < 2^12, ww <= 64: the product is off by < 2^-11, the nearest integers are 0.5 / ww away
-    for (int p = tid; p < npx; p += 256) {
+    // the score map in three dense passes: quick test of every pixel -> list; the nine-contiguous test of the list -> list; the exact score of those
+    unsigned short* list = (unsigned short*)(score + ((sw * sh + 15) & ~15));      // [npx]
+    auto compact = [&](bool keep, int value, int& count) {                          // appends `value` of the lanes with `keep` (order irrelevant: scores go to their pixel's place)
+        const unsigned long long m = __ballot(keep);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_cnt, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)value;
+        (void)count;
+    };
+    int dummy = 0;
+    for (int p0 = 0; p0 < npx; p0 += 256) {
+        const int p = p0 + tid;
+        bool k1 = false;
+        if (p < npx) { const int y = row_of(p), x = p - y * ww; k1 = fast_quick(tile + (y + 3) * tstride + (x + 3 + mis), tstride, min_th); }
+        compact(k1, p, dummy);
+    }
+    __syncthreads();
+    const int n1 = s_cnt;
+    __syncthreads();
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    // (the second list is built in place: entry i is read by the thread that may overwrite a slot j <= i only after every thread of this pass has read its own)
+    for (int i0 = 0; i0 < n1; i0 += 256) {
+        const int i = i0 + tid;
+        int p = 0;
+        bool k2 = false;
+        if (i < n1) { p = list[i]; const int y = row_of(p), x = p - y * ww; k2 = fast_is_corner(tile + (y + 3) * tstride + (x + 3 + mis), tstride, min_th); }
+        __syncthreads();
+        compact(k2, p, dummy);
+        __syncthreads();
+    }
+    const int n2 = s_cnt;
+    for (int i = tid; i < n2; i += 256) {
+        const int p = list[i];
         const int y = row_of(p), x = p - y * ww;
-        const int s = fast_score_lds(tile + (y + 3) * tstride + (x + 3 + mis), tstride, min_th);
-        score[(y + 1) * sw + (x + 1)] = (uint8_t)s;   // 0 or [min_th, 254]
+        score[(y + 1) * sw + (x + 1)] = (uint8_t)fast_corner_score(tile + (y + 3) * tstride + (x + 3 + mis), tstride);   // [min_th, 254]
     }
     __syncthreads();
     // pass A: does any NMS survivor reach iniTh?
@@ -923,7 +968,7 @@ int planar_orb_create(planar_ctx* ctx, const planar_orb_params* p, int W, int H,
                 o->cells.push_back(C);
                 const int tstride = ((((int)C.x0 - 3) & 3) + C.ww + 6 + 3) & ~3;            // orb_fast_cells' tile: aligned 32-bit words per row, <= 16 of them
                 if (tstride > 64 || C.ww * C.wh >= 4096) { delete o; set_error("planar_orb_create: FAST cell of %d x %d pixels at level %d is larger than the kernel's tile", (int)C.ww, (int)C.wh, l); return PLANAR_EINVAL; }
-                const int bytes = ((tstride * (C.wh + 6) + 15) & ~15) + (C.ww + 2) * (C.wh + 2);
+                const int bytes = ((tstride * (C.wh + 6) + 15) & ~15) + (((C.ww + 2) * (C.wh + 2) + 15) & ~15) + 2 * C.ww * C.wh;   // pixel tile, score tile, the candidate list
                 max_tile_bytes = std::max(max_tile_bytes, bytes);
             }
         }
