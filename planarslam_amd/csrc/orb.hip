@@ -799,8 +799,8 @@ __global__ __launch_bounds__(256) void orb_describe(const PlanDev* __restrict__ 
     const int step = L.pitch;
     uint32_t bits = 0;
     const signed char* pat = c_pattern + sub * 64;
-#pragma unroll 4
-    for (int i = 0; i < 16; i++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {                      // (fully unrolled: the 32 taps of a lane are independent byte loads, all of them in flight)
         const float x0 = (float)pat[4 * i], y0 = (float)pat[4 * i + 1], x1 = (float)pat[4 * i + 2], y1 = (float)pat[4 * i + 3];
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
