@@ -552,18 +552,21 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
 #pragma unroll
             for (int jj = 0; jj < FE; jj++) {
                 if (NT * jj >= nent) break;                            // (uniform: a short step costs what it holds)
+                if (NT * jj + (tid & ~63) >= nent) continue;           // (this wavefront's 64 entries lie beyond the step's: no ballot below is shared across wavefronts)
                 const int e = tid + NT * jj;
                 const unsigned ent = e < nent ? entry_at(q_head + e) : NONE;
                 const bool have = ent != NONE;
                 const int sx = (int)(ent & 0xfffu), sy = (int)((ent >> 12) & 0xfffu), plid = (int)((ent >> 24) & 0x7fu);
                 bool act[4];
                 int m0[4];
+                const int ebx = sx / WIN, eby = sy / WIN, erx = sx - ebx * WIN, ery = sy - eby * WIN;   // the entry's block: a neighbour is in it or in the next one over
 #pragma unroll
                 for (int dir = 0; dir < 4; dir++) {                    // getValid4Neighbor order (:398-410): left, right, up, down, invalid ones skipped
                     const int cx = sx + (dir == 0 ? -1 : (dir == 1 ? 1 : 0)), cy = sy + (dir == 2 ? -1 : (dir == 3 ? 1 : 0));
                     act[dir] = have && cx >= 0 && cx < W && cy >= 0 && cy < H;
                     if (act[dir]) {
-                        const int by = cy / WIN, bx = cx / WIN;
+                        const int bx = ebx + (dir == 0 ? -(int)(erx == 0) : (dir == 1 ? (int)(erx == WIN - 1) : 0));
+                        const int by = eby + (dir == 2 ? -(int)(ery == 0) : (dir == 3 ? (int)(ery == WIN - 1) : 0));
                         if (by < Nh && bx < Nw && S.blk[by * Nw + bx] >= 0) act[dir] = false;      // only "black" blocks are refined
                     }
                     m0[dir] = act[dir] ? (int)member[(size_t)cy * W + cx] : -128;
