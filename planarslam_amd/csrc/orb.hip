@@ -201,7 +201,6 @@ __global__ __launch_bounds__(256) void orb_fast_cells(const PlanDev* __restrict_
                                                       const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                                       int* __restrict__ cell_count, int* __restrict__ dropped, int B) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ int s_wave_cnt[4];
     __shared__ int s_any_ini, s_cnt;
     int frame, cell;
     xcd_frame_block(plan->ncells_total, B, frame, cell);      // neighbouring cells share their 3-pixel halos: a frame's cells on one XCD (common.h)
@@ -271,47 +270,56 @@ __global__ __launch_bounds__(256) void orb_fast_cells(const PlanDev* __restrict_
         score[(y + 1) * sw + (x + 1)] = (uint8_t)fast_corner_score(tile + (y + 3) * tstride + (x + 3 + mis), tstride);   // [min_th, 254]
     }
     __syncthreads();
-    // pass A: does any NMS survivor reach iniTh?
+    // Non-maximum suppression and emission over the CORNERS only (the list of the third pass; every other pixel scores 0 and can neither survive nor win):
+    // pass A: the corners that are strict 8-neighbour maxima, and whether one of them reaches iniTh
+    __shared__ unsigned s_keep[128];                     // a bit per window pixel (npx < 4096)
+    __shared__ unsigned short s_kpre[128];
+    for (int i = tid; i < 128; i += 256) s_keep[i] = 0u;
+    __syncthreads();
     int any = 0;
-    for (int p = tid; p < npx; p += 256) {
+    bool ismax[4] = {false, false, false, false};      // (n2 <= slot_cap would need <= 4 rounds of 256 only for cells of > 2048 pixels; larger lists loop again below)
+    for (int i = tid, k = 0; i < n2; i += 256, k++) {
+        const int p = list[i];
         const int y = row_of(p), x = p - y * ww;
         const uint8_t* sc = score + (y + 1) * sw + (x + 1);
         const int s = sc[0];
-        if (s >= ini_th && s > sc[-1] && s > sc[1] && s > sc[-sw - 1] && s > sc[-sw] && s > sc[-sw + 1] &&
-            s > sc[sw - 1] && s > sc[sw] && s > sc[sw + 1])
-            any = 1;
+        const bool mx = s > sc[-1] && s > sc[1] && s > sc[-sw - 1] && s > sc[-sw] && s > sc[-sw + 1] && s > sc[sw - 1] && s > sc[sw] && s > sc[sw + 1];
+        if (k < 4) ismax[k] = mx;
+        if (mx && s >= ini_th) any = 1;
     }
     if (__any(any) && lane == 0) s_any_ini = 1;
     __syncthreads();
     const int th_cell = s_any_ini ? ini_th : min_th;
-    // pass B: ordered compaction (row-major over the window == cv::FAST emission order)
+    // pass B: the survivors' bits, prefix counts of the bitmap's words, and every survivor to its rank: row-major over the window == cv::FAST's emission order
+    for (int i = tid, k = 0; i < n2; i += 256, k++) {
+        const int p = list[i];
+        const int y = row_of(p), x = p - y * ww;
+        const uint8_t* sc = score + (y + 1) * sw + (x + 1);
+        const int s = sc[0];
+        const bool mx = k < 4 ? ismax[k] : (s > sc[-1] && s > sc[1] && s > sc[-sw - 1] && s > sc[-sw] && s > sc[-sw + 1] && s > sc[sw - 1] && s > sc[sw] && s > sc[sw + 1]);
+        if (mx && s >= th_cell) atomicOr(&s_keep[p >> 5], 1u << (p & 31));
+    }
+    __syncthreads();
+    if (wave == 0) {                                    // 128 words: two per lane
+        const int c0 = __popc(s_keep[2 * lane]), c1 = __popc(s_keep[2 * lane + 1]);
+        int incl = c0 + c1;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        s_kpre[2 * lane] = (unsigned short)(incl - c0 - c1); s_kpre[2 * lane + 1] = (unsigned short)(incl - c1);
+        if (lane == 63) s_cnt = incl;
+    }
+    __syncthreads();
     uint32_t* slots = cand + (int64_t)frame * plan->cand_stride + C.slot_off;
     const int relx = C.x0 - L.minBX, rely = C.y0 - L.minBY;
-    int base = 0;
-    for (int p0 = 0; p0 < npx; p0 += 256) {
-        const int p = p0 + tid;
-        bool keep = false;
-        int x = 0, y = 0, s = 0;
-        if (p < npx) {
-            y = row_of(p); x = p - y * ww;
-            const uint8_t* sc = score + (y + 1) * sw + (x + 1);
-            s = sc[0];
-            keep = s >= th_cell && s > sc[-1] && s > sc[1] && s > sc[-sw - 1] && s > sc[-sw] && s > sc[-sw + 1] &&
-                   s > sc[sw - 1] && s > sc[sw] && s > sc[sw + 1];
+    for (int i = tid; i < n2; i += 256) {
+        const int p = list[i];
+        const unsigned bits = s_keep[p >> 5];
+        if ((bits >> (p & 31)) & 1u) {
+            const int pos = (int)s_kpre[p >> 5] + __popc(bits & ((1u << (p & 31)) - 1u));
+            const int y = row_of(p), x = p - y * ww;
+            if (pos < C.slot_cap) slots[pos] = (uint32_t)(x + relx) | ((uint32_t)(y + rely) << 12) | ((uint32_t)score[(y + 1) * sw + (x + 1)] << 24);
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) { const int c = s_wave_cnt[w]; if (w < wave) before += c; total += c; }
-        if (keep) {
-            const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < C.slot_cap) slots[pos] = (uint32_t)(x + relx) | ((uint32_t)(y + rely) << 12) | ((uint32_t)s << 24);
-        }
-        base += total;
-        __syncthreads();
     }
+    const int base = s_cnt;
     if (tid == 0) {
         *out_count = min(base, C.slot_cap);
         // slot_cap = ceil(w/2) * ceil(h/2) bounds the strict 8-neighbour maxima of a cell, so this never fires; counted (planar_orb_check), not assumed
