@@ -478,8 +478,11 @@ def build_map(gray0, depth0, cam, torch_dev=None, seed=0, n_map_planes=8, n_plan
     from .lines import LineSegment
     from .synth import manhattan_scene
     B, H, W = gray0.shape
-    ls = LineSegment(W, H, B)
-    kl, ldesc, eq, nl = ls.ExtractLineSegment(gray0)
+    CH = 256        # the extractors' workspaces here are scratch beside the pipeline's own (17 MB per frame of max_batch): a chunk of the streams at a time
+    ls = LineSegment(W, H, min(B, CH))
+    parts = [ls.ExtractLineSegment(gray0[a:a + CH]) for a in range(0, B, CH)]
+    kl, ldesc, eq, nl = (np.concatenate([p[i] for p in parts]) for i in range(4))
+    del ls, parts
     fx, fy, cx, cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
     xw6 = np.zeros((B, 40, 6)); normal = np.zeros((B, 40, 3)); mind = np.zeros((B, 40), np.float32); maxd = np.zeros((B, 40), np.float32)
     dm = depth0.astype(np.float64) / 5000.0
@@ -494,8 +497,9 @@ def build_map(gray0, depth0, cam, torch_dev=None, seed=0, n_map_planes=8, n_plan
             mid = 0.5 * (np.array(pts[0]) + np.array(pts[1])); d = np.linalg.norm(mid)
             normal[b, i] = mid / max(d, 1e-9); maxd[b, i] = d * 1.2 ** 3; mind[b, i] = maxd[b, i] / 1.2 ** 7
     kf_lines = dict(n=nl.astype(np.int32), ldesc=ldesc, xw6=xw6, normal=normal, min_dist=mind, max_dist=maxd)
-    pd = PlaneDetection(W, H, max_batch=B)
-    res = pd.run(depth0.astype(np.uint16))
+    pd = PlaneDetection(W, H, max_batch=min(B, CH))
+    res = [r for a in range(0, B, CH) for r in pd.run(depth0[a:a + CH].astype(np.uint16))]
+    del pd
     M, P = n_map_planes, n_plane_pts
     mp = dict(n=np.zeros(B, np.int32), valid=np.zeros((B, M), np.uint8), coef=np.zeros((B, M, 4), np.float32), npts=np.zeros((B, M), np.int32), pts=np.zeros((B, M, P, 3), np.float32))
     ys, xs = np.mgrid[4:H:16, 4:W:16]
