@@ -38,6 +38,8 @@ PARITY_SAMPLE = True    # after the timed region: a few frames of the last step 
 W, H = 640, 480
 MARGIN = 48
 NCANVAS = 256
+SEQ_CUS = 0             # default CU partition of the sequential kernels (--seq-cus): set from the round-6 measurements, DESIGN.md
+SEQ_WHICH = 3
 
 
 def orb_algorithmic_bytes(ex, avg_kp):
@@ -125,6 +127,11 @@ def main():
                     help="full: the per-frame path (BASELINE metric); orb: config[1] only; ba: config[4], ONE local bundle adjustment partitioned over the ranks")
     ap.add_argument("--depth", type=int, default=3, help="software-pipeline depth: the tracking chain of step i runs during step i + depth")
     ap.add_argument("--prio", default="-1,0,0", help="stream priorities: point stream, LSD streams, PEAC streams[, tracking stream] (lower = higher priority)")
+    ap.add_argument("--work-sets", type=int, default=0, help="extractor sets (line / plane stream + the extractors' workspaces): 0 = one per extraction in flight (= --depth)")
+    ap.add_argument("--seq-cus", type=int, default=SEQ_CUS, help="compute units the one-wavefront-per-frame kernels (PEAC clustering, LSD region growing) are confined to by a "
+                                                                "CU-masked side stream (planar_ctx_set_seq_stream); 0 = no partition")
+    ap.add_argument("--seq-which", type=int, default=SEQ_WHICH, help="which of them: 1 PEAC clustering, 2 LSD region growing, 3 both")
+    ap.add_argument("--seq-per-ctx", action="store_true", help="one masked stream per context instead of one shared by all sets")
     ap.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the cpu_baseline leg, split over its three variants (0 = skip)")
     ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 pose-optimisation call (0 = skip the whole latency block)")
     ap.add_argument("--latency-frames", type=int, default=200, help="distinct frames of the B = 1 latency block (4/5 se3 frames, 1/5 panned canvas windows)")
@@ -232,7 +239,8 @@ def main():
 
     L = lib()
     if full:
-        tp = TrackPipeline(B, torch, local_rank, depth=args.depth, prio=prio, cam=TUM3, W=W, H=H)
+        tp = TrackPipeline(B, torch, local_rank, depth=args.depth, prio=prio, cam=TUM3, W=W, H=H, work_sets=args.work_sets or None, seq_cus=args.seq_cus,
+                           seq_which=args.seq_which, seq_shared=not args.seq_per_ctx)
         NB = tp.NB
         stream, ex = tp.stream, tp.ex
         frames = [torch.zeros((B, H, W), dtype=torch.uint8, device=dev) for _ in range(NB)]
@@ -683,7 +691,10 @@ def main():
                                f"played forwards and backwards; resident in HBM, a strided device copy per step" if se3 else "pan: a 640x480 window moving <= 8 px per step over unrelated gray / depth canvases"),
                    "window": (f"every step shows every stream the next frame of its {args.loop}-frame loop (forwards, then backwards: {2 * args.loop - 2} steps per cycle)" if se3
                               else "every step is a new window position for every stream"),
-                   "pipeline_depth": args.depth, "avg_keypoints_per_frame": round(avg_kp, 1), "input_generation_s": round(t_gen, 1),
+                   "pipeline_depth": args.depth,
+                   "extractor_sets": tp.NW if full else None,
+                   "cu_partition": ({"sequential_kernels_on_cus": args.seq_cus, "which": args.seq_which, "stream": "per context" if args.seq_per_ctx else "shared"} if full and args.seq_cus else None),
+                   "avg_keypoints_per_frame": round(avg_kp, 1), "input_generation_s": round(t_gen, 1),
                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}, "not_yet_in_workload": nyi,
                    "parallelism": f"frame-sharded x{world}, no collective"},
         "roofline": roofline, "cpu_baseline": cpu, "parity_sample": parity, "sub_benchmarks": sub, "latency_b1_ms": latency, "value_pcie_inclusive": pcie,

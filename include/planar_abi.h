@@ -53,6 +53,15 @@ void planar_ctx_destroy(planar_ctx* ctx);
 /* Use an external hipStream_t (e.g. torch's current stream) for all subsequent work; NULL
  * restores the context's own stream. */
 int planar_ctx_set_stream(planar_ctx* ctx, void* hip_stream);
+/* CU partition for the extractors' one-wavefront-per-frame kernels (no reference counterpart: the reference runs its three extractors on three CPU threads,
+ * src/Frame.cc:90-95; this is the device-side analogue of pinning the sequential ones to some cores).  planar_cu_stream_create makes a HIP stream whose kernels
+ * run only on the compute units whose bit is set in cu_mask (n_words x 32 bits, bit i = CU i in the driver's round-robin-over-XCDs numbering:
+ * hipExtStreamCreateWithCUMask); planar_ctx_set_seq_stream(ctx, s) makes the context launch the PEAC clustering kernel and LSD's region-growing kernel on s
+ * (forked from / joined into the context's stream by events, so results and ordering are unchanged); s = NULL restores the single-stream behaviour (default).
+ * One such stream may be shared by several contexts.  The caller destroys it after the contexts. */
+int planar_cu_stream_create(int device, const uint32_t* cu_mask, int n_words, void** out_stream);
+void planar_cu_stream_destroy(void* stream);
+int planar_ctx_set_seq_stream(planar_ctx* ctx, void* stream);
 void* planar_ctx_get_stream(planar_ctx* ctx);
 int planar_ctx_sync(planar_ctx* ctx);
 const char* planar_last_error(void);
@@ -468,7 +477,7 @@ int planar_peac_debug_layout(planar_peac* peac, int64_t* out /* [12] */);
 int planar_peac_debug_read(planar_peac* peac, int frame, int64_t offset, int64_t bytes, void* out);
 int planar_peac_check(planar_peac* peac, int B);
 /* A/B aid (tools/peac_ab.py and the tests; nothing in the product calls it, and no environment variable selects a kernel): clustering 0 = product (fast attempt +
- * exact redo), 1 = exact heap only, 2 = the round-2 clustering kernel; wide_below = batch size up to which the refinement runs 1024 threads per frame (< 0: keep).
+ * exact redo), 1 = exact heap only (anything else: PLANAR_EINVAL); wide_below = batch size up to which the refinement runs 1024 threads per frame (< 0: keep).
  * Every variant returns the same labels and planes. */
 int planar_peac_set_variant(planar_peac* peac, int clustering, int wide_below);
 /* Per-launch timing with HIP events on the context stream (bench.py's roofline leg), as planar_orb_set_profiling: get_profile synchronises and returns the

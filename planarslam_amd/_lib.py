@@ -97,6 +97,9 @@ _SIGS = {
     "planar_ctx_destroy": (None, [C.c_void_p]),
     "planar_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "planar_ctx_get_stream": (C.c_void_p, [C.c_void_p]),
+    "planar_cu_stream_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "planar_cu_stream_destroy": (None, [C.c_void_p]),
+    "planar_ctx_set_seq_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "planar_ctx_sync": (C.c_int, [C.c_void_p]),
     "planar_orb_create": (C.c_int, [C.c_void_p, C.POINTER(OrbParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "planar_orb_destroy": (None, [C.c_void_p]),
@@ -262,6 +265,18 @@ def check(rc: int):
     return rc
 
 
+def cu_stream_create(device: int, n_cus: int, first: int = 0, total: int = 256) -> int:
+    """A HIP stream restricted to n_cus compute units, bits first .. first + n_cus - 1 of the driver's CU numbering (which deals consecutive bits round-robin to the
+    XCDs, so any contiguous run is spread evenly over them) -> the hipStream_t as an int (planar_cu_stream_destroy frees it)."""
+    import numpy as np
+    words = np.zeros((total + 31) // 32, np.uint32)
+    for i in range(first, min(first + n_cus, total)):
+        words[i >> 5] |= np.uint32(1 << (i & 31))
+    out = C.c_void_p()
+    check(lib().planar_cu_stream_create(device, words.ctypes.data, len(words), C.byref(out)))
+    return out.value
+
+
 class Context:
     """planar_ctx: one HIP device + stream.  Not re-entrant (one per host thread)."""
 
@@ -276,6 +291,10 @@ class Context:
 
     def set_stream(self, hip_stream: int | None):
         check(self.L.planar_ctx_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_seq_stream(self, hip_stream: int | None):
+        """the side stream (e.g. a CU-masked one, cu_stream_create) the context launches its one-wavefront-per-frame kernels on; None: its own stream"""
+        check(self.L.planar_ctx_set_seq_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
 
     def sync(self):
         check(self.L.planar_ctx_sync(self.h))

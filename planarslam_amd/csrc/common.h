@@ -110,6 +110,22 @@ struct planar_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;   // the stream work is enqueued on (own_stream unless overridden)
     planar::DevBuf scratch;         // grow-only device scratch for entry points that need temporaries
+    // Optional side stream for the one-wavefront-per-frame kernels of the extractors (PEAC clustering, LSD region growing): planar_ctx_set_seq_stream.  Such a kernel
+    // is latency-bound and occupies a CU for tens of milliseconds with four wavefronts; on a CU-masked stream (planar_cu_stream_create) it stays on a subset of the
+    // CUs while the wide kernels of `stream` keep the rest.  seq_begin() / seq_end() bracket the launch: fork by event from `stream`, join back into it.
+    hipStream_t seq_stream = nullptr;
+    hipEvent_t seq_fork = nullptr, seq_join = nullptr;
+    hipStream_t seq_begin() {
+        if (!seq_stream) return stream;
+        (void)hipEventRecord(seq_fork, stream);
+        (void)hipStreamWaitEvent(seq_stream, seq_fork, 0);
+        return seq_stream;
+    }
+    void seq_end() {
+        if (!seq_stream) return;
+        (void)hipEventRecord(seq_join, seq_stream);
+        (void)hipStreamWaitEvent(stream, seq_join, 0);
+    }
     int ensure_scratch(size_t bytes) {
         if (scratch.bytes >= bytes) return PLANAR_OK;
         // a previous kernel may still be reading the old block

@@ -35,6 +35,8 @@ int planar_ctx_create(planar_ctx** out, int device) {
 
 void planar_ctx_destroy(planar_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->seq_fork) (void)hipEventDestroy(ctx->seq_fork);
+    if (ctx->seq_join) (void)hipEventDestroy(ctx->seq_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -42,6 +44,32 @@ void planar_ctx_destroy(planar_ctx* ctx) {
 int planar_ctx_set_stream(planar_ctx* ctx, void* s) {
     PLANAR_REQUIRE(ctx != nullptr, PLANAR_EINVAL, "ctx is null");
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return PLANAR_OK;
+}
+
+int planar_cu_stream_create(int device, const uint32_t* cu_mask, int n_words, void** out_stream) {
+    PLANAR_REQUIRE(out_stream && cu_mask && n_words >= 1 && n_words <= 32, PLANAR_EINVAL, "bad argument");
+    *out_stream = nullptr;
+    bool any = false;
+    for (int i = 0; i < n_words; i++) any = any || cu_mask[i] != 0u;
+    PLANAR_REQUIRE(any, PLANAR_EINVAL, "empty CU mask");
+    PLANAR_HIP_CHECK(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    PLANAR_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
+    *out_stream = (void*)s;
+    return PLANAR_OK;
+}
+
+void planar_cu_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
+
+int planar_ctx_set_seq_stream(planar_ctx* ctx, void* s) {
+    PLANAR_REQUIRE(ctx != nullptr, PLANAR_EINVAL, "ctx is null");
+    PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
+    if (s && !ctx->seq_fork) {
+        PLANAR_HIP_CHECK(hipEventCreateWithFlags(&ctx->seq_fork, hipEventDisableTiming));
+        PLANAR_HIP_CHECK(hipEventCreateWithFlags(&ctx->seq_join, hipEventDisableTiming));
+    }
+    ctx->seq_stream = (hipStream_t)s;
     return PLANAR_OK;
 }
 

@@ -1725,7 +1725,8 @@ int planar_lsd_detect_dev(planar_lsd* o, int B, int max_lines, planar_keyline* d
     const lsd::Plan* dP = o->d_plan.as<lsd::Plan>();
     uint8_t* ws = o->d_ws.as<uint8_t>();
     lsd::Misc* dm = o->d_misc.as<lsd::Misc>();
-    hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, st, dP, ws, dm);
+    hipLaunchKernelGGL(lsd::lsd_detect, dim3(B), dim3(64), o->detect_smem, o->ctx->seq_begin(), dP, ws, dm);      // (the context's side stream when it has one)
+    o->ctx->seq_end();
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[3], st);
     if (!o->top_only) {
         hipLaunchKernelGGL(lsd::lsd_improve, dim3(128, B), dim3(64), 0, st, dP, ws, dm, -1);   // 512 / 2048 wavefronts per frame measure the same

@@ -955,12 +955,15 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     {
         // the fast attempt (tournament queue), then the exact kernel for the frames it gave up on (bit-equal keys of two live nodes: degenerate input)
         // (the workgroup that gave up redoes its frame itself: no second launch)
+        // (on the context's side stream when it has one: planar_ctx_set_seq_stream)
+        hipStream_t sq = p->ctx->seq_begin();
         if (!p->exact_only)
-            hipLaunchKernelGGL(peac::peac_ahc3, dim3(B), dim3(64), p->smem2, st, p->L, p->C, p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(),
+            hipLaunchKernelGGL(peac::peac_ahc3, dim3(B), dim3(64), p->smem2, sq, p->L, p->C, p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(),
                                p->d_timing.as<long long>(), p->d_next.as<int>(), p->order_B == B ? p->d_order.as<int>() : nullptr, 1);
         else
-            hipLaunchKernelGGL(peac::peac_ahc2, dim3(B), dim3(64), p->smem2, st, p->L, p->C, p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(),
+            hipLaunchKernelGGL(peac::peac_ahc2, dim3(B), dim3(64), p->smem2, sq, p->L, p->C, p->d_ws.as<uint8_t>(), p->d_status.as<int32_t>(),
                                p->d_timing.as<long long>(), p->d_next.as<int>(), p->order_B == B ? p->d_order.as<int>() : nullptr, 0);
+        p->ctx->seq_end();
     }
     mark();
     hipLaunchKernelGGL(peac::peac_order, dim3((B + 255) / 256), dim3(256), 0, st, p->d_timing.as<long long>(), B, p->d_order.as<int>());

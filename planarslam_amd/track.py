@@ -35,7 +35,7 @@ class TrackPipeline:
     MAX_POSE_PLANES = 16
 
     def __init__(self, B, torch, device_index=0, depth=2, prio=(-1, 0, 0), cam=None, W=640, H=480, n_map_planes=8, n_plane_pts=128, n_normals=4096,
-                 run_fallback_matcher=True, manhattan_rotation=True, dist_coef=None):
+                 run_fallback_matcher=True, manhattan_rotation=True, dist_coef=None, work_sets=None, seq_cus=0, seq_which=3, seq_shared=True):
         from . import Context, ORBextractor, Optimizer, PlaneDetection
         from .lines import LineSegment
         from .planes import PlaneClouds, SurfaceNormals
@@ -47,16 +47,29 @@ class TrackPipeline:
         self.dist_coef = None if dist_coef is None or float(dist_coef[0]) == 0.0 else np.ascontiguousarray(dist_coef, np.float32).reshape(5)
         self.dev = torch.device("cuda", device_index)
         self.NB = depth + 2                      # buffer sets: a step's extractor outputs live until the tracking chain `depth` steps later has used them as "last frame"
+        # extractor sets (line / plane stream + the extractors' WORKSPACES, 18 MB per frame): only the outputs have to outlive the extraction, so there are as many as
+        # extractions in flight (step i uses set i mod NW; the stream's own order guards the workspace), not one per buffer set
+        self.NW = NW = min(self.NB, max(1, depth if work_sets is None else int(work_sets)))
         self.L = lib()
         self.stream = torch.cuda.Stream(device=device_index, priority=prio[0])
         self.ctx = Context(device_index, stream=self.stream.cuda_stream)
         # the tracking chain of step i - depth runs on its own stream, beside the point extraction of step i (they share nothing but buffers guarded by events)
         self.s_track = torch.cuda.Stream(device=device_index, priority=prio[3] if len(prio) > 3 else prio[0])
         self.ctx_t = Context(device_index, stream=self.s_track.cuda_stream)
-        self.s_peacs = [torch.cuda.Stream(device=device_index, priority=prio[2]) for _ in range(self.NB)]
-        self.s_lsds = [torch.cuda.Stream(device=device_index, priority=prio[1]) for _ in range(self.NB)]
+        self.s_peacs = [torch.cuda.Stream(device=device_index, priority=prio[2]) for _ in range(NW)]
+        self.s_lsds = [torch.cuda.Stream(device=device_index, priority=prio[1]) for _ in range(NW)]
         self.ctx_peacs = [Context(device_index, stream=q.cuda_stream) for q in self.s_peacs]
         self.ctx_lsds = [Context(device_index, stream=q.cuda_stream) for q in self.s_lsds]
+        # CU partition (planar_ctx_set_seq_stream): the one-wavefront-per-frame kernels (PEAC clustering: seq_which & 1, LSD region growing: & 2) on streams masked to
+        # seq_cus compute units - one shared by all sets (their launches then run in step order) or one per context
+        self.seq_streams = []
+        if seq_cus:
+            from ._lib import cu_stream_create
+            targets = (self.ctx_peacs if seq_which & 1 else []) + (self.ctx_lsds if seq_which & 2 else [])
+            for c in targets:
+                if not seq_shared or not self.seq_streams:
+                    self.seq_streams.append(cu_stream_create(device_index, int(seq_cus)))
+                c.set_seq_stream(self.seq_streams[-1])
         self.ex = ORBextractor(1000, 1.2, 8, 20, 7, width=W, height=H, max_batch=B, ctx=self.ctx)
         self.S = S = self.ex.kp_cap
         self.pds = [PlaneDetection(W, H, max_batch=B, ctx=c) for c in self.ctx_peacs]
@@ -147,13 +160,13 @@ class TrackPipeline:
         # Frame::ComputeImageBounds (Frame.cc:573-598): the four image corners through cv::undistortPoints when k1 != 0; mfGridElement*Inv from them (:122-123)
         self.bounds = (0.0, float(W), 0.0, float(H))
         if self.dist_coef is not None:
-            cr = t.zeros((1, 4, 7), dtype=t.float32, device=self.dev)
-            cr[0, :, 0] = t.tensor([0.0, W, 0.0, W], device=self.dev); cr[0, :, 1] = t.tensor([0.0, 0.0, H, H], device=self.dev)
-            cu = t.zeros_like(cr); n4 = t.full((1,), 4, dtype=t.int32, device=self.dev)
+            # a one-off of four points: the synchronous host-pointer entry point (numpy in / out), so nothing here depends on which torch stream is current
+            cr = np.zeros((1, 4, 7), np.float32)
+            cr[0, :, 0] = [0.0, W, 0.0, W]; cr[0, :, 1] = [0.0, 0.0, H, H]
+            cu = np.zeros_like(cr); n4 = np.full((1,), 4, np.int32)
             c = self.cam
-            check(self.L.planar_undistort_keypoints_dev(self.ctx.h, 1, cr.data_ptr(), n4.data_ptr(), 4, c["fx"], c["fy"], c["cx"], c["cy"], self.dist_coef.ctypes.data, cu.data_ptr()))
-            self.stream.synchronize()
-            m = cu[0, :, :2].cpu().numpy()
+            check(self.L.planar_undistort_keypoints(self.ctx.h, 1, cr.ctypes.data, n4.ctypes.data, 4, c["fx"], c["fy"], c["cx"], c["cy"], self.dist_coef.ctypes.data, cu.ctypes.data))
+            m = cu[0, :, :2]
             self.bounds = (float(min(m[0, 0], m[2, 0])), float(max(m[1, 0], m[3, 0])), float(min(m[0, 1], m[1, 1])), float(max(m[2, 1], m[3, 1])))
         self.pending = []
         self.map_set = False
@@ -221,33 +234,33 @@ class TrackPipeline:
         check(self.L.planar_pose_assemble_dev(self.ctx_t.h, C.byref(m), C.byref(self.pbs[which])))
 
     # ---- the extraction stages of one step, each on the stream the reference's thread of that name stands for (src/Frame.cc:90-95) ----
-    def _lines_head(self, k, gray):
+    def _lines_head(self, w, gray):
         """LineSegment::ExtractLineSegment, first half (smoothing, gradients, the pixel order) - line stream"""
-        check(self.L.planar_lsd_preprocess_dev(self.lss[k].h, gray.data_ptr(), self.B, self.W, self.W * self.H))
+        check(self.L.planar_lsd_preprocess_dev(self.lss[w].h, gray.data_ptr(), self.B, self.W, self.W * self.H))
 
-    def _planes(self, k, depth):
+    def _planes(self, w, k, depth):
         """PlaneDetection (PEAC) - plane stream"""
-        self.pds[k].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), self.B)
+        self.pds[w].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), self.B)
 
-    def _plane_clouds(self, k, depth):
+    def _plane_clouds(self, w, k, depth):
         """Frame::ComputePlanes' voxel clouds + RANSAC refit (Frame.cc:655-692) - plane stream"""
         pc = self.pc[k]
-        self.pcs[k].compute_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), self.B, pc["n"].data_ptr(), pc["coef"].data_ptr(),
+        self.pcs[w].compute_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), self.B, pc["n"].data_ptr(), pc["coef"].data_ptr(),
                                 pc["src"].data_ptr(), pc["off"].data_ptr(), pc["pts"].data_ptr(), pc["status"].data_ptr(), dist_th=self.plane_dist_th,
                                 K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
 
-    def _normals(self, k, depth):
+    def _normals(self, w, k, depth):
         """Frame::ComputePlanes' surface normals - plane stream"""
-        self.sns[k].compute_dev(depth.data_ptr(), self.snrm[k].data_ptr(), self.B, K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
+        self.sns[w].compute_dev(depth.data_ptr(), self.snrm[k].data_ptr(), self.B, K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))
 
-    def _lines_tail(self, i, k, depth):
+    def _lines_tail(self, i, w, k, depth):
         """ExtractLineSegment, second half (region growing, NFA, key lines, LBD), then Frame::isLineGood right behind it on the same thread - line stream"""
         L, B = self.L, self.B
-        check(L.planar_lsd_detect_dev(self.lss[k].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
+        check(L.planar_lsd_detect_dev(self.lss[w].h, B, 40, self.kls[k].data_ptr(), self.ldesc[k].data_ptr(), self.leq[k].data_ptr(), self.nl[k].data_ptr()))
         l3 = self.l3[k]                                     # every (stream, step, line) has its own rand() seed
-        check(L.planar_add_scalar_i32_dev(self.ctx_lsds[k].h, self.seed_base.data_ptr(), self.seed_base.numel(), (i * B * 64) & 0x3fffffff, l3["seeds"].data_ptr()))
+        check(L.planar_add_scalar_i32_dev(self.ctx_lsds[w].h, self.seed_base.data_ptr(), self.seed_base.numel(), (i * B * 64) & 0x3fffffff, l3["seeds"].data_ptr()))
         c = self.cam
-        check(L.planar_is_line_good_dev(self.ctx_lsds[k].h, B, self.kls[k].data_ptr(), self.nl[k].data_ptr(), 40, depth.data_ptr(), self.W, self.H, self.W, self.W * self.H,
+        check(L.planar_is_line_good_dev(self.ctx_lsds[w].h, B, self.kls[k].data_ptr(), self.nl[k].data_ptr(), 40, depth.data_ptr(), self.W, self.H, self.W, self.W * self.H,
                                         float(np.float32(1.0 / 5000.0)), c["fx"], c["fy"], c["cx"], c["cy"], l3["seeds"].data_ptr(), l3["depth_line"].data_ptr(),
                                         l3["lines3d"].data_ptr(), l3["good"].data_ptr(), l3["direction"].data_ptr(), l3["n_inliers"].data_ptr(), l3["packed"].data_ptr(),
                                         l3["n_good"].data_ptr()))
@@ -264,20 +277,20 @@ class TrackPipeline:
     def step(self, i, gray, depth, evs=None, side=None):
         """Enqueue step i: extraction of `gray` [B,H,W] u8 / `depth` [B,H,W] i16-as-u16 (device tensors that stay valid until the step's
         tracking chain has run) on the three streams, then the tracking chain of step i - depth.  evs / side: optional timing events."""
-        t, L, B, k = self.torch, self.L, self.B, i % self.NB
-        sp, sl = self.s_peacs[k], self.s_lsds[k]
+        t, L, B, k, w = self.torch, self.L, self.B, i % self.NB, i % self.NW
+        sp, sl = self.s_peacs[w], self.s_lsds[w]
         st = self.stream
         st.wait_event(self.done[k])                         # the buffers of step i - NB have been consumed
         self.ev_in[k].record(st)                            # the caller gathered this step's frames on the main stream
         if evs: evs["start"].record(st)
         sl.wait_event(self.ev_in[k]); sp.wait_event(self.ev_in[k])
         if side: side[2].record(sl)
-        self._lines_head(k, gray)
+        self._lines_head(w, gray)
         if side: side[0].record(sp)
-        self._planes(k, depth)
-        self._plane_clouds(k, depth)
-        self._normals(k, depth)
-        self._lines_tail(i, k, depth)
+        self._planes(w, k, depth)
+        self._plane_clouds(w, k, depth)
+        self._normals(w, k, depth)
+        self._lines_tail(i, w, k, depth)
         if side: side[1].record(sp); side[3].record(sl)
         self.join_p[k].record(sp); self.join_l[k].record(sl)
         self._points(k, gray)

@@ -384,6 +384,11 @@ def test_pipeline_with_a_distorting_camera():
         assert np.array_equal(ur[b, :nb], st["u_right"]) and np.array_equal(zd[b, :nb], st["depth"])
         moved = max(moved, float(np.abs(want["x"] - k["x"]).max()))
     assert moved > 1.0                                                          # the lens model does move key points by pixels
+    # Frame::ComputeImageBounds (Frame.cc:575-598): the four undistorted image corners, as the oracle undistorts them
+    corners = np.zeros(4, KP_DTYPE); corners["x"] = [0.0, W, 0.0, W]; corners["y"] = [0.0, 0.0, H, H]
+    cu = ol.undistort_keypoints(corners, cam, D)
+    want_bounds = (float(min(cu["x"][0], cu["x"][2])), float(max(cu["x"][1], cu["x"][3])), float(min(cu["y"][0], cu["y"][1])), float(max(cu["y"][2], cu["y"][3])))
+    assert tp.bounds == want_bounds and want_bounds != (0.0, float(W), 0.0, float(H)) and np.isfinite(want_bounds).all()
     assert np.isfinite(c["pose_out"].cpu().numpy()).all()
 
 
