@@ -42,6 +42,7 @@ struct Block { int f, l, r0, nr; };     // LDS-tier job: the span [f, l) holds r
 constexpr int ST_CAPACITY = 3;
 #ifdef PLANAR_WAVE_EMUL
 static long g_levels = 0, g_segs = 0;      // emulator statistics: LDS-tier levels run, segments partitioned
+static long g_wlev = 0, g_wlanes = 0, g_glev = 0, g_glanes = 0, g_eqseg = 0, g_eqelem = 0;      // wavefront-scope passes and the lanes that had elements in them, workgroup-scope passes; all-equal segments finished in closed form
 #endif
 
 __device__ __forceinline__ int lg2i(int n) { return 31 - __clz(n); }          // std::__lg
@@ -274,6 +275,29 @@ __device__ __forceinline__ int select64(unsigned long long w, int k) {
 // segments of <= W_CAP = 1984 elements, which they take from a task list and finish on their own - no workgroup barrier, sixteen of them side by side.
 // Nothing is insertion-sorted on the way: every cut sets a bit, and the block's last pass ranks every element inside its <= 16-element leaf
 // (stable: what __final_insertion_sort would do) while it writes the block back.
+//
+// Segments whose keys are ALL EQUAL (a voxel's points once the partitions have isolated it: where every chain of the recursion ends) are not partitioned at all.
+// With equal keys every comparison of __move_median_to_first is false (it swaps first with mid), both scans of __unguarded_partition stop at once (it swaps k with
+// n - k for k = 1 .. while k < n - k and returns ceil(n / 2)), and both children are all-equal again: where an element ends is a function of its position and n
+// alone (equal_dest below, <= 11 steps of integer arithmetic).  A wavefront-scope pass recognises such a segment (every element stops both scans: the two segmented
+// scans carry both stop counts), puts its pivot back, flags its start (eb) and drops it from the list; the write-back sends its elements straight to their places.
+// On a plane's voxel keys that takes the last three to six levels off every chain.
+// levels of __introsort_loop an all-equal range of n elements goes through (each costs one unit of the depth budget; it halves)
+__device__ __forceinline__ int equal_levels(int n) { int k = 0; while (n > 16) { n = (n + 1) >> 1; k++; } return k; }
+// where the element at position p of an all-equal range of n elements is when std::sort returns (the depth budget must cover equal_levels(n): no heap sort on the way;
+// __final_insertion_sort moves nothing: it is stable).  One level: swap(0, n / 2); positions 1 .. n - 1 reversed (k <-> n - k); cut at ceil(n / 2).
+__device__ __forceinline__ int equal_dest(int p, int n) {
+    int base = 0;
+    while (n > 16) {
+        const int mid = n >> 1, c = (n + 1) >> 1;
+        p = p == mid ? 0 : (p == 0 ? n - mid : n - p);
+        const bool right = p >= c;
+        base += right ? c : 0; p -= right ? c : 0; n = right ? n - c : c;
+    }
+    return base + p;
+}
+constexpr int EQ_CUT = 0xffff;            // scut[] value of a segment recognised as all-equal (a real cut is < 2^16 - 1: blocks hold fewer elements)
+
 constexpr int W_E = 31, W_CAP = 64 * W_E, W_LIST = 128, G_LIST = 32, TASKS = 256;      // (an odd stride: lane l's chunk starts at bank 31 l mod 32)
 
 template <int T>
@@ -301,11 +325,12 @@ struct WaveScope {                                            // one wavefront: 
     __device__ __forceinline__ void sync_lists() const { sync(); }
 };
 
-struct Lists {                                                // a scope's segment lists (double-buffered) and per-segment results, all in LDS
-    uint16_t *f, *l, *cut, *mm;                               // f, l: [2][cap]; cut, mm: [cap]
-    uint8_t* d;                                               // [2][cap]
+struct Lists {                                                // a scope's segment list and per-segment results, all in LDS ([cap] each).  One buffer: a pass reads its
+    uint16_t *f, *l, *pre, *cut, *mm;                         // segments into registers before the scan of phase F and writes the children behind it.
+    uint8_t* d;                                               // pre[s]: the elements behind their pivots of the segments listed before s
     int cap;
 };
+constexpr int LIST_BYTES = 2 + 2 + 2 + 2 + 2 + 1;             // per list entry
 struct Tasks { uint16_t *f, *l; uint8_t* d; int* n; };        // segments of 17 .. W_CAP elements waiting for a wavefront; n[0] count, n[1] next
 
 template <int T, int E>
@@ -316,19 +341,21 @@ struct LdsLayout {
     static constexpr int off_posh = off_a + N * 4;                                  // u16 [N / 2 + 2]
     static constexpr int off_mb = off_posh + ((N / 2 + 2) * 2 + 3) / 4 * 4;         // u32 [N / 32 + 2]: a cut / range boundary at this position
     static constexpr int off_kb = off_mb + (N / 32 + 2) * 4;                        // u32 [N / 32 + 2]: the leaf that starts here lies inside a range
-    static constexpr int off_wl = off_kb + (N / 32 + 2) * 4;                        // per wavefront: lists of W_LIST entries: f, l [2][W_LIST] u16; cut, mm u16; d [2][W_LIST] u8
-    static constexpr int wl_bytes = W_LIST * (4 + 4 + 2 + 2 + 2);
+    static constexpr int off_eb = off_kb + (N / 32 + 2) * 4;                        // u32 [N / 32 + 2]: an all-equal segment finished in closed form starts here (no cut inside it)
+    static constexpr int off_fwd = off_eb + (N / 32 + 2) * 4;                       // u16 [N / 32 + 2]: the closed-form segment that covers the first element of this 32-element word starts at .. (0xffff: none)
+    static constexpr int off_wl = off_fwd + ((N / 32 + 2) * 2 + 3) / 4 * 4;         // per wavefront: lists of W_LIST entries: f, l [2][W_LIST] u16; cut, mm u16; d [2][W_LIST] u8
+    static constexpr int wl_bytes = (W_LIST * LIST_BYTES + 3) / 4 * 4;
     static constexpr int off_gl = off_wl + NW * wl_bytes;                           // the workgroup's lists, G_LIST entries, same layout
-    static constexpr int gl_bytes = G_LIST * (4 + 4 + 2 + 2 + 2);
-    static constexpr int off_tk = off_gl + gl_bytes;                                // tasks: f, l u16 [TASKS]; d u8 [TASKS]; order u8 [TASKS]
-    static constexpr int off_buf = (off_tk + TASKS * 6 + 3) / 4 * 4;                // int [10 * NW + 4]
+    static constexpr int gl_bytes = (G_LIST * LIST_BYTES + 3) / 4 * 4;
+    static constexpr int off_tk = off_gl + gl_bytes;                                // tasks: f, l u16 [TASKS]; d u8 [TASKS]; group starts u16 [TASKS + 2]
+    static constexpr int off_buf = (off_tk + TASKS * 8 + 3) / 4 * 4;                // int [10 * NW + 4]
     static constexpr int bytes = off_buf + (10 * NW + 4) * 4;
     static_assert(bytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
     static_assert(bytes >= (N + W_CAP + 32) * 4, "a chunk's key loads may run W_CAP words past the block (sort_levels, B)");
 };
 __device__ __forceinline__ Lists carve_lists(uint8_t* p, int cap) {
     Lists L;
-    L.f = (uint16_t*)p; L.l = L.f + 2 * cap; L.cut = L.l + 2 * cap; L.mm = L.cut + cap; L.d = (uint8_t*)(L.mm + cap); L.cap = cap;
+    L.f = (uint16_t*)p; L.l = L.f + cap; L.pre = L.l + cap; L.cut = L.pre + cap; L.mm = L.cut + cap; L.d = (uint8_t*)(L.mm + cap); L.cap = cap;
     return L;
 }
 
@@ -348,81 +375,100 @@ __device__ __forceinline__ void move_median(uint32_t* a, int f, int l) {
     a[f] = t == A ? xa : (t == Bm ? xb : xc); a[t] = xf;
 }
 
-// All levels of the recursion below the nseg segments listed in L (buffer 0), by the threads of scope S; thread t owns the elements
-// [c_base + t * E, c_base + (t + 1) * E) below c_end.  Children of more than keep_above elements stay in the scope's list, smaller ones of more than
-// 16 go to the task list TK (none when keep_above == 16); a child whose depth budget is used up is heap-sorted on the spot.
+// All levels of the recursion below the nseg segments listed in L (buffer 0; any order, disjoint, each of more than 16 elements, together at most NT * E elements),
+// by the threads of scope S.  Children of more than keep_above elements stay in the scope's list, smaller ones of more than 16 go to the task list TK (none when
+// keep_above == 16); a child whose depth budget is used up is recorded for the heap-sort fallback.
+//
+// The threads share the ACTIVE elements - the elements behind the pivots of the segments still listed, concatenated in list order - evenly: with A of them a thread owns
+// Q = ceil(A / NT) consecutive ones (bit j of its masks = its j-th), which lie in at most three segments (a segment has more than 16, Q <= E <= 32) as contiguous pieces;
+// pre[] (the running count of active elements per listed segment) maps a thread's range to its pieces.  A pass therefore costs what is still being partitioned, not the
+// span the job started with: the passes at the end of a chain, when most segments are leaves or closed-form segments, touch a few elements per lane.
 // A level is latency, not arithmetic (a wavefront's ~40 dependent LDS round trips, four wavefronts per SIMD to hide them behind), so the code keeps the
-// number of dependent LDS accesses down: the first segment of a thread's chunk is tracked from level to level instead of searched, the three segments
-// a chunk can touch are read together, swaps go four at a time, the pivots of the next level are placed by the thread that lists the segment.
+// number of dependent LDS accesses down: the three segments a thread can touch are read together, swaps go four at a time, the pivots of the next level are placed
+// by the thread that lists the segment.
 template <int SHIFT, int E, class S>
-__device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* posh, uint32_t* mb, uint32_t* kb, const Lists& L, int nseg, int c_base, int c_end,
+__device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* posh, uint32_t* mb, uint32_t* kb, uint32_t* eb, uint16_t* fwd, const Lists& L, int nseg,
                                             int keep_above, const Tasks& TK, const HeapSink& HS, int span_f, int* status, uint32_t skip_key) {
 #ifdef ISORT_TIMING
     long long _tm = __builtin_readcyclecounter();
 #endif
     constexpr int NT = S::NT;
-    const int tid = sc.tid();
-    const int c0 = min(c_base + tid * E, c_end), c1 = min(c0 + E, c_end), cap = L.cap;
-    int s0;                                                      // the first listed segment that ends behind c0
-    {
-        for (int s = tid; s < nseg; s += NT) move_median<SHIFT>(a, L.f[s], L.l[s]);
-        int lo_ = 0, hi_ = nseg;
-        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if ((int)L.l[mid] > c0) hi_ = mid; else lo_ = mid + 1; }
-        s0 = lo_;
+    constexpr bool PACK = NT == 64;      // (wavefront scope: the scans carry both stop counts, see B)
+    const int tid = sc.tid(), cap = L.cap;
+    int A;                                                       // active elements of the current list
+    {   // the initial list: pivots to the front, pre[]
+        int m[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int s_ = 2 * tid + u;
+            if (s_ < nseg) { const int f = L.f[s_], l = L.l[s_]; move_median<SHIFT>(a, f, l); m[u] = l - f - 1; }
+        }
+        const int off = sc.exscan(m[0] + m[1], &A);
+        if (2 * tid < nseg) L.pre[2 * tid] = (uint16_t)off;
+        if (2 * tid + 1 < nseg) L.pre[2 * tid + 1] = (uint16_t)(off + m[0]);
+        if (A > NT * E) { *status = ST_CAPACITY; nseg = 0; }
         sc.sync();
     }
     int cur = 0;
     while (nseg > 0) {
+        const int Q = (A + NT - 1) / NT;                         // (uniform; <= E)
 #ifdef PLANAR_WAVE_EMUL
-        if (tid == 0) { g_levels++; g_segs += nseg; }
+        if (tid == 0) { g_levels++; g_segs += nseg; if (NT == 64) { g_wlev++; g_wlanes += Q; } else { g_glev++; g_glanes += Q; } }
 #endif
-        uint16_t* sf = L.f + cur * cap; uint16_t* sl = L.l + cur * cap; uint8_t* sd = L.d + cur * cap;
+        uint16_t* sf = L.f; uint16_t* sl = L.l; uint16_t* sp = L.pre; uint8_t* sd = L.d;
         uint16_t* scut = L.cut; uint16_t* smm = L.mm;
         ISORT_MARK(1);
-        // ---- B: this thread's E elements: the (at most three) segments they belong to, where the two scans stop ----
+        // ---- B: this thread's active elements [a0, a1): the (at most three) segments they belong to, where the two scans stop ----
+        const int a0 = min(tid * Q, A), a1 = min(a0 + Q, A);
+        int s0 = 0;                                              // the listed segment that holds active element a0: the last one with pre <= a0
+        { int hi_ = nseg; while (hi_ - s0 > 1) { const int mid = (s0 + hi_) >> 1; if ((int)sp[mid] <= a0) s0 = mid; else hi_ = mid; } }
         uint32_t mL = 0, mR = 0;
         int npc = 0;
-        int pf[3], pl_[3], plo[3], phi[3];
+        int pf[3], pl_[3], plo[3], phi[3], pb[3];                // piece q: bits [plo, phi) of the masks; bit j is the element at position pb[q] + j
         uint32_t ppv[3];
+        bool contL = false, contR = false;
         {
-            uint32_t key[E];
 #pragma unroll
-            for (int j = 0; j < E; j++) key[j] = a[c0 + j];          // (past c_end: words of the block's LDS that no piece covers - LdsLayout keeps W_CAP words behind `a` readable)
-#pragma unroll
-            for (int q = 0; q < 3; q++) { const int s = min(s0 + q, nseg - 1); pf[q] = sf[s]; pl_[q] = sl[s]; }
+            for (int q = 0; q < 3; q++) { const int s_ = min(s0 + q, nseg - 1); pf[q] = sf[s_]; pl_[q] = sl[s_]; pb[q] = sp[s_]; }
 #pragma unroll
             for (int q = 0; q < 3; q++) ppv[q] = a[pf[q]] >> SHIFT;
-            uint32_t rm_all = 0;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
-                const int lo = max(pf[q] + 1, c0) - c0, hi = min(pl_[q], c1) - c0;
+                const int g0 = pb[q], g1 = g0 + (pl_[q] - pf[q] - 1);              // the segment's active range
+                const int lo = max(g0, a0) - a0, hi = min(g1, a1) - a0;
                 const bool on = s0 + q < nseg && lo < hi;
                 plo[q] = on ? lo : 99; phi[q] = on ? hi : 99;
-                if (on) { npc = q + 1; rm_all |= (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u); }
+                pb[q] = on ? pf[q] + 1 + a0 - g0 : 0;
+                if (on) { npc = q + 1; contR = g1 > a1; if (q == 0) contL = g0 < a0; }
             }
+            const uint32_t rm_all = a1 - a0 >= 32 ? 0xffffffffu : ((1u << (a1 - a0)) - 1u);
             uint32_t ge = 0, le = 0;
+            for (int j0 = 0; j0 < Q; j0 += 4) {                  // (elements behind the thread's last one: masked; their reads stay inside the block's LDS, see LdsLayout)
 #pragma unroll
-            for (int j = 0; j < E; j++) {
-                const uint32_t pv = j >= plo[2] ? ppv[2] : (j >= plo[1] ? ppv[1] : ppv[0]), k = key[j] >> SHIFT;
-                ge |= (uint32_t)(k >= pv) << j; le |= (uint32_t)(k <= pv) << j;
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + u;
+                    const bool q2 = j >= plo[2], q1 = j >= plo[1];
+                    const uint32_t pv = q2 ? ppv[2] : (q1 ? ppv[1] : ppv[0]);
+                    const uint32_t k = a[(q2 ? pb[2] : (q1 ? pb[1] : pb[0])) + j] >> SHIFT;
+                    ge |= (uint32_t)(k >= pv) << (j & 31); le |= (uint32_t)(k <= pv) << (j & 31);
+                }
             }
             mL = ge & rm_all; mR = le & rm_all;
         }
         auto rmask = [&](int q) { return (phi[q] >= 32 ? 0xffffffffu : ((1u << phi[q]) - 1u)) & ~((1u << plo[q]) - 1u); };
-        // does the first piece's segment have elements before this chunk / the last piece's segment elements behind it
-        const bool contL = npc > 0 && pf[0] + 1 < c0;
+        // contL / contR: the first piece's segment has active elements before this thread's / the last piece's segment behind them
         const int lastq = npc > 0 ? npc - 1 : 0;
-        int l_last = pl_[0];
-#pragma unroll
-        for (int q = 1; q < 3; q++) if (q < npc) l_last = pl_[q];
-        const bool contR = npc > 0 && l_last > c1;
         uint32_t rm_last = 0;
 #pragma unroll
         for (int q = 0; q < 3; q++) if (q == lastq && npc > 0) rm_last = rmask(q);
         const uint32_t rm_first = npc > 0 ? rmask(0) : 0u;
-        int carryL, carryR;
+        int carryL, carryR, carryL2 = 0, carryR2 = 0;
         ISORT_MARK(2);
-        sc.seg_scan(__popc(mL & rm_last), !(npc == 1 && contL), __popc(mR & rm_first), !(npc == 1 && contR), cur, carryL, carryR);
+        // (wavefront scope: both scans carry BOTH stop counts, 12 bits each - a wavefront's job has at most W_CAP < 4096 elements -, so that the piece that holds x* knows
+        // the segment's totals: every element stops both scans = all keys equal the pivot's)
+        sc.seg_scan(__popc(mL & rm_last) | (PACK ? __popc(mR & rm_last) << 12 : 0), !(npc == 1 && contL),
+                    __popc(mR & rm_first) | (PACK ? __popc(mL & rm_first) << 12 : 0), !(npc == 1 && contR), cur, carryL, carryR);
+        if (PACK) { carryL2 = carryL >> 12; carryL &= 0xfff; carryR2 = carryR >> 12; carryR &= 0xfff; }
         ISORT_MARK(3);
         // ---- D1: the piece with g false at its start and true behind its end holds x*: it writes the segment's cut and its number of swaps m ----
         int pA0[3] = {0, 0, 0}, pBe[3] = {0, 0, 0};
@@ -441,8 +487,12 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
                 const int e = jh - 1;                            // the element before x*: in this piece
                 const bool eL = (Lp >> e) & 1u, eR = (Rp >> e) & 1u;
                 const int Ap = A0 + __popc(Lp & ((1u << e) - 1u)), Bp = Be + __popc(Rp >> e);
-                scut[s0 + q] = (uint16_t)(c0 + jh - ((eL && eR && Ap == Bp - 1) ? 1 : 0));
+                scut[s0 + q] = (uint16_t)(pb[q] + jh - ((eL && eR && Ap == Bp - 1) ? 1 : 0));
                 smm[s0 + q] = (uint16_t)max(Ap, Bp - (int)eR);
+                if (PACK) {                                      // all n - 1 elements behind the pivot stop both scans, and the budget covers the halvings: closed form (equal_dest)
+                    const int n1 = pl_[q] - pf[q] - 1, totL = A0 + __popc(Lp) + ((q == lastq && contR) ? carryR2 : 0), totR = Be + __popc(Rp) + ((q == 0 && contL) ? carryL2 : 0);
+                    if (totL == n1 && totR == n1 && (int)sd[s0 + q] >= equal_levels(n1 + 1)) { scut[s0 + q] = (uint16_t)EQ_CUT; smm[s0 + q] = 0; }
+                }
             }
         }
         sc.sync();
@@ -457,7 +507,7 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
             uint32_t bits = mL & rmask(q);
             const int base = ((pf[q] + 1) >> 1) + pA0[q];
             const int gl = min(max(pm[q] - pA0[q], 0), __popc(bits));
-            for (int k = 0; k < gl; k++) { const int j = __ffs((int)bits) - 1; bits &= bits - 1u; posh[base + k] = (uint16_t)(c0 + j); }
+            for (int k = 0; k < gl; k++) { const int j = __ffs((int)bits) - 1; bits &= bits - 1u; posh[base + k] = (uint16_t)(pb[q] + j); }
         }
         sc.sync();
         ISORT_MARK(5);
@@ -474,9 +524,9 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
                 uint32_t x[SU], y[SU];
 #pragma unroll
                 for (int u = 0; u < SU; u++) {
-                    const int j = bits ? 31 - __clz((int)bits) : 0;
+                    const int j = bits ? 31 - __clz((int)bits) : plo[q];
                     if (t0 + u < gr) bits &= ~(1u << j);
-                    qq[u] = c0 + j;
+                    qq[u] = pb[q] + j;
                     pL[u] = posh[base + min(t0 + u, gr - 1)];
                 }
 #pragma unroll
@@ -487,30 +537,37 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
         }
         sc.sync();
         ISORT_MARK(6);
-        // ---- F: the cuts become leaf boundaries; children: stay listed (their pivot is placed now) / become a wavefront's task / are finished (leaf, or
-        //      heap sort at depth 0).  smm[s] <- the new index of s's first listed child, bit 15: the left child is listed ----
+        // ---- F: the cuts become leaf boundaries; children: stay listed (their pivot is placed now) / become a wavefront's task / are finished (leaf, closed-form
+        //      segment, or heap sort at depth 0) ----
         {
-            uint16_t* nf = L.f + (cur ^ 1) * cap; uint16_t* nl = L.l + (cur ^ 1) * cap; uint8_t* nd = L.d + (cur ^ 1) * cap;
-            int cf[4], cl[4], cd[4], nk = 0, nk0 = 0;
-            bool leftk[2] = {false, false};
+            uint16_t* nf = sf; uint16_t* nl = sl; uint16_t* np = sp; uint8_t* nd = sd;      // (in place: every thread has read its segments before the scan below lets any write)
+            int cf[4], cl[4], cd[4], nk = 0, nact = 0;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int s = 2 * tid + u;
-                if (u == 1) nk0 = nk;
                 if (s < nseg) {
                     const int f = sf[s], l = sl[s], cut = scut[s], d = sd[s] - 1;      // (listed segments have a budget of at least one)
-                    atomicOr(&mb[cut >> 5], 1u << (cut & 31)); atomicOr(&kb[cut >> 5], 1u << (cut & 31));
+                    const bool equal = PACK && cut == EQ_CUT;
+                    if (equal) {                                                   // all keys equal: the pivot goes back where __move_median_to_first took it from (mid), the
+                        const int mid = f + (l - f) / 2;                           // segment is flagged and leaves the list; the write-back places its elements (equal_dest)
+                        const uint32_t x = a[f]; a[f] = a[mid]; a[mid] = x;
+                        atomicOr(&eb[f >> 5], 1u << (f & 31));
+                        posh[(f + 1) >> 1] = (uint16_t)l;                          // (its own, now idle, part of the rendezvous table) the write-back finds the segment's end here,
+                        for (int w = (f >> 5) + 1; w <= ((l - 1) >> 5); w++) fwd[w] = (uint16_t)f;   // and its start from any word whose first element it covers
+#ifdef PLANAR_WAVE_EMUL
+                        g_eqseg++; g_eqelem += l - f;
+#endif
+                    } else { atomicOr(&mb[cut >> 5], 1u << (cut & 31)); atomicOr(&kb[cut >> 5], 1u << (cut & 31)); }
                     const bool drop_right = (a[f] >> SHIFT) > skip_key;            // everything from the cut on is >= the pivot (it sits at f): nothing the caller wants is in there
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const int xf = h ? cut : f, xl = h ? l : cut;
-                        if (h == 1 && drop_right) continue;
+                        if (equal || (h == 1 && drop_right)) continue;
                         if (xl - xf > 16 && d == 0) push_heap_job(HS, span_f + xf, span_f + xl, status);   // budget used up: the heap-sort fallback, later (a leaf of more than 16: the write-back leaves it alone)
                         else if (xl - xf > keep_above) {
 #pragma unroll
                             for (int z = 0; z < 4; z++) if (nk == z) { cf[z] = xf; cl[z] = xl; cd[z] = d; }
-                            nk++;
-                            if (h == 0) leftk[u] = true;
+                            nk++; nact += xl - xf - 1;
                             move_median<SHIFT>(a, xf, xl);
                         } else if (xl - xf > 16) {
                             const int k = atomicAdd(&TK.n[0], 1);
@@ -519,18 +576,17 @@ __device__ __forceinline__ void sort_levels(const S& sc, uint32_t* a, uint16_t* 
                     }
                 }
             }
-            int tot;
-            const int off = sc.exscan(nk, &tot);
+            int tot;                                             // one scan for both: listed children (low 9 bits: at most 4 per thread, `cap` in all) and their active elements
+            const int offp = sc.exscan(nk | (nact << 9), &tot);
+            int off = offp & 0x1ff, run = offp >> 9;
 #pragma unroll
-            for (int z = 0; z < 4; z++) if (z < nk && off + z < cap) { nf[off + z] = (uint16_t)cf[z]; nl[off + z] = (uint16_t)cl[z]; nd[off + z] = (uint8_t)cd[z]; }
-#pragma unroll
-            for (int u = 0; u < 2; u++) if (2 * tid + u < nseg) smm[2 * tid + u] = (uint16_t)((off + (u ? nk0 : 0)) | (leftk[u] ? 0x8000 : 0));
-            if (tot > cap) { *status = ST_CAPACITY; tot = cap; }
+            for (int z = 0; z < 4; z++)
+                if (z < nk && off + z < cap) { nf[off + z] = (uint16_t)cf[z]; nl[off + z] = (uint16_t)cl[z]; nd[off + z] = (uint8_t)cd[z]; np[off + z] = (uint16_t)run; run += cl[z] - cf[z] - 1; }
+            A = tot >> 9; tot &= 0x1ff;
+            if (tot > cap) { *status = ST_CAPACITY; tot = 0; }
             sc.sync();
-            // this thread's first segment in the new list: the children of the old one (or what follows them)
-            if (s0 < nseg) { const int v = smm[s0], cutv = scut[s0]; s0 = (v & 0x7fff) + (((v & 0x8000) && cutv <= c0) ? 1 : 0); } else s0 = tot;
             nseg = tot;
-            cur ^= 1;                                            // (no barrier here: the next writes to scut / smm are behind the scan's)
+            cur ^= 1;                                            // (the segmented scan's buffer parity; no barrier here: the next writes to scut / smm are behind the scan's)
         }
         ISORT_MARK(7);
     }
@@ -546,8 +602,10 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
     uint16_t* posh = (uint16_t*)(lds + LL::off_posh);
     uint32_t* mb = (uint32_t*)(lds + LL::off_mb);
     uint32_t* kb = (uint32_t*)(lds + LL::off_kb);
+    uint32_t* eb = (uint32_t*)(lds + LL::off_eb);
+    uint16_t* fwd = (uint16_t*)(lds + LL::off_fwd);
     int* s_buf = (int*)(lds + LL::off_buf);
-    int* s_tn = s_buf + 10 * LL::NW;                             // [0] tasks, [1] next task
+    int* s_tn = s_buf + 10 * LL::NW;                             // [0] tasks, [1] next group, [2] groups
     Tasks TK;
     TK.f = (uint16_t*)(lds + LL::off_tk); TK.l = TK.f + TASKS; TK.d = (uint8_t*)(TK.l + TASKS); TK.n = s_tn;
     const Lists GL = carve_lists(lds + LL::off_gl, G_LIST);
@@ -557,8 +615,8 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
     long long _tm = __builtin_readcyclecounter();
 #endif
     for (int i = tid; i < n; i += T) a[i] = arr[span_f + i];
-    for (int i = tid; i < LL::N / 32 + 2; i += T) { mb[i] = 0u; kb[i] = 0u; }
-    if (tid == 0) { s_tn[0] = 0; s_tn[1] = 0; }
+    for (int i = tid; i < LL::N / 32 + 2; i += T) { mb[i] = 0u; kb[i] = 0u; eb[i] = 0u; fwd[i] = (uint16_t)0xffff; }
+    if (tid == 0) { s_tn[0] = 0; s_tn[1] = 0; s_tn[2] = 0; }
     __syncthreads();
     const WgScope<T> wg{s_buf};
     int nseg;
@@ -586,67 +644,89 @@ __device__ void lds_tier(uint32_t* __restrict__ arr, const Range* __restrict__ r
         __syncthreads();
     }
     ISORT_MARK(0);
-    sort_levels<SHIFT, E, WgScope<T>>(wg, a, posh, mb, kb, GL, nseg, 0, n, W_CAP, TK, HS, span_f, status, skip_key);
+    sort_levels<SHIFT, E, WgScope<T>>(wg, a, posh, mb, kb, eb, fwd, GL, nseg, W_CAP, TK, HS, span_f, status, skip_key);
     __syncthreads();
 #ifdef ISORT_TIMING
     _tm = __builtin_readcyclecounter();
 #endif
-    {   // the tasks: one wavefront each, first come first served
+    {   // the tasks, in groups of at most W_CAP elements (consecutive entries of the task list: sort_levels takes segments in any order); a wavefront per group, first
+        // come first served.  A block's tasks add up to at most its span, so there are about as many groups as wavefronts and every lane of them has elements
         const WaveScope wv;
         const Lists WL = carve_lists(lds + LL::off_wl + wave * LL::wl_bytes, W_LIST);
         const int ntasks = min(s_tn[0], TASKS);
         const Tasks none{nullptr, nullptr, nullptr, s_tn};
-        // longest task first: a block has a handful of tasks of very different lengths for its four wavefronts, and the block ends with the last of them
-        uint8_t* order = TK.d + TASKS;                           // (TASKS <= 256)
-        if (tid < ntasks) {
-            const int mine = TK.l[tid] - TK.f[tid];
-            int rank = 0;
-            for (int j = 0; j < ntasks; j++) { const int o = TK.l[j] - TK.f[j]; rank += (o > mine || (o == mine && j < tid)) ? 1 : 0; }
-            order[rank] = (uint8_t)tid;
+        uint16_t* gstart = (uint16_t*)(lds + LL::off_tk + 5 * TASKS);       // [groups + 1]
+        if (tid == 0) {
+            int total = 0;
+            for (int t = 0; t < ntasks; t++) total += TK.l[t] - TK.f[t];
+            // as many groups as wavefronts where that fits, of about equal size: the block ends with its longest group, and a pass costs what the group holds
+            const int target = min(W_CAP, max((total + LL::NW - 1) / LL::NW, 64));
+            int g = 0, sum = 0;
+            gstart[0] = 0;
+            for (int t = 0; t < ntasks; t++) {
+                const int len = TK.l[t] - TK.f[t];
+                if (sum > 0 && (sum + len > W_CAP || sum + len / 2 > target)) { gstart[++g] = (uint16_t)t; sum = 0; }
+                sum += len;
+            }
+            if (ntasks > 0) gstart[++g] = (uint16_t)ntasks;
+            s_tn[2] = g;
         }
         __syncthreads();
+        const int ngroups = s_tn[2];
         while (true) {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(&s_tn[1], 1);
-            t = __shfl(t, 0);
-            if (t >= ntasks) break;
-            t = order[t];
-            const int f = TK.f[t], l = TK.l[t];
-            if (lane == 0) { WL.f[0] = (uint16_t)f; WL.l[0] = (uint16_t)l; WL.d[0] = TK.d[t]; }
+            int g = 0;
+            if (lane == 0) g = atomicAdd(&s_tn[1], 1);
+            g = __shfl(g, 0);
+            if (g >= ngroups) break;
+            const int t0 = gstart[g], cnt = gstart[g + 1] - t0;              // (<= W_CAP / 17 < W_LIST tasks)
+            for (int i = lane; i < cnt; i += 64) { WL.f[i] = TK.f[t0 + i]; WL.l[i] = TK.l[t0 + i]; WL.d[i] = TK.d[t0 + i]; }
             wv.sync();
-            sort_levels<SHIFT, W_E, WaveScope>(wv, a, posh, mb, kb, WL, 1, f, l, 16, none, HS, span_f, status, skip_key);
+            sort_levels<SHIFT, W_E, WaveScope>(wv, a, posh, mb, kb, eb, fwd, WL, cnt, 16, none, HS, span_f, status, skip_key);
         }
     }
     __syncthreads();
     ISORT_MARK(8);
-    // the write-back; an element of a leaf of <= 16 elements inside a range goes to its stable rank in the leaf (__final_insertion_sort).  Four elements
-    // per thread at a time, the leaf walked as 16 predicated reads: nothing in here waits for the previous element
+    // the write-back; an element of a leaf of <= 16 elements inside a range goes to its stable rank in the leaf (__final_insertion_sort), an element of a closed-form
+    // segment to equal_dest of its position, anything else stays.  A leaf's boundaries are within a word of the element; a closed-form segment's start is the nearest
+    // boundary below where that is within a word, else fwd[] of the element's word, and its end is in the segment's slot of the rendezvous table: no searches.
+    // Four elements per thread at a time (each a row of 64 consecutive elements per wavefront); the leaf walk (16 predicated reads) is skipped by rows without a leaf
     constexpr int WU = 4;
-    for (int i0 = tid; i0 < n; i0 += T * WU) {
+    for (int ib = 0; ib < n; ib += T * WU) {                 // (the same trip count for every lane: the ballots below)
+        const int i0 = ib + tid;
         uint32_t v[WU];
         int s[WU], e[WU], dest[WU];
+        bool leaf[WU];
 #pragma unroll
         for (int u = 0; u < WU; u++) {
             const int i = min(i0 + u * T, n - 1), w = i >> 5, bi = i & 31;
             v[u] = a[i];
             const uint32_t mw = mb[w], mp = mb[max(w - 1, 0)], mn = mb[w + 1];
+            const int fw = fwd[w];
             const uint32_t below = mw & (0xffffffffu >> (31 - bi)), above = bi == 31 ? 0u : (mw & (0xffffffffu << (bi + 1)));
-            s[u] = below ? (w << 5) + 31 - __clz((int)below) : ((w > 0 && mp) ? ((w - 1) << 5) + 31 - __clz((int)mp) : -1);
+            s[u] = below ? (w << 5) + 31 - __clz((int)below) : ((w > 0 && mp) ? ((w - 1) << 5) + 31 - __clz((int)mp) : (fw != 0xffff ? fw : -1));
             e[u] = above ? (w << 5) + __ffs((int)above) - 1 : (mn ? ((w + 1) << 5) + __ffs((int)mn) - 1 : -1);
         }
 #pragma unroll
         for (int u = 0; u < WU; u++) {
+            const int i = min(i0 + u * T, n - 1), sb = max(s[u], 0);
+            const bool flagged = s[u] >= 0 && ((eb[sb >> 5] >> (sb & 31)) & 1u);
+            leaf[u] = s[u] >= 0 && e[u] >= 0 && e[u] - s[u] <= 16 && ((kb[sb >> 5] >> (sb & 31)) & 1u);
+            dest[u] = i;
+            if (flagged) dest[u] = sb + equal_dest(i - sb, (int)posh[(sb + 1) >> 1] - sb);
+        }
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            if (__ballot(leaf[u]) == 0ull) continue;
             const int i = min(i0 + u * T, n - 1);
-            const bool leaf = s[u] >= 0 && e[u] >= 0 && e[u] - s[u] <= 16 && ((kb[max(s[u], 0) >> 5] >> (max(s[u], 0) & 31)) & 1u);
             const uint32_t kv = v[u] >> SHIFT;
             int rank = 0;
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 const int jj = max(s[u], 0) + t;
                 const uint32_t kj = a[jj] >> SHIFT;                  // (jj < e[u] <= n where it counts; behind the block: readable, see LdsLayout)
-                rank += (leaf && jj < e[u] && (kj < kv || (kj == kv && jj < i))) ? 1 : 0;
+                rank += (leaf[u] && jj < e[u] && (kj < kv || (kj == kv && jj < i))) ? 1 : 0;
             }
-            dest[u] = leaf ? s[u] + rank : i;
+            if (leaf[u]) dest[u] = s[u] + rank;
         }
 #pragma unroll
         for (int u = 0; u < WU; u++) if (i0 + u * T < n) arr[span_f + dest[u]] = v[u];

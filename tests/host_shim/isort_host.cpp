@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 using namespace planar::isort;
@@ -68,24 +69,27 @@ int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status
         wave_emul::launch_block(h_entry<SHIFT>, &ha, 64, bi, bd, (size_t)heap_cap * 4, 256 * 1024);
     }
     if (stats) { stats[3] = wave_emul::S().n_sync; stats[4] = g_levels; stats[5] = g_segs; stats[6] = heap_elems; stats[7] = njobs; g_levels = 0; g_segs = 0; }
+    if (getenv("ISORT_STATS")) fprintf(stderr, "isort: wavefront-scope passes %ld, elements per lane and pass %.2f; workgroup-scope passes %ld, elements per lane and pass %.2f; all-equal segments in closed form %ld (%ld elements)\n", g_wlev, g_wlev ? (double)g_wlanes / g_wlev : 0.0, g_glev, g_glev ? (double)g_glanes / g_glev : 0.0, g_eqseg, g_eqelem);
+    g_wlev = g_wlanes = g_glev = g_glanes = g_eqseg = g_eqelem = 0;
     return 0;
 }
 }  // namespace
 
 extern "C" {
 // arr [total]: in/out.  bounds [n_ranges + 1]: every [bounds[i], bounds[i+1]) is sorted on its own, as std::sort(first, last, key <) would.
-// config 0: production shapes (global tier 1024 threads; LDS tier 1024 threads x 23 elements); 1: small shapes that force many levels and the
+// config 0: the product's shapes (global tier 1024 threads; LDS tier 256 threads x 23 elements: planepost.hip PS_T / PS_LT / PS_E, lsd.hip SORT_*); 4: 512 x 23; 1: small shapes that force many levels and the
 // global tier on short arrays (256 threads; 256 x 5).  shift: 19 or 20.  n_stage: LDS-tier capacity override (0 = the configuration's).
 // Returns 0, or -1 with a message in err.  stats [8] (last two: elements that went through the heap-sort fallback, its jobs): ranges, blocks, rendezvous count after the global tier, after everything, LDS-tier levels, segments partitioned there.
 int isort_emul(uint32_t* arr, const int* bounds, int n_ranges, int shift, int config, int n_stage, int* status, long* stats, char* err, int errlen) {
     try {
         *status = 0;
-        if (shift == 19 && config == 0) return run<19, 1024, 1024, 23>(arr, bounds, n_ranges, n_stage, status, stats);
-        if (shift == 20 && config == 0) return run<20, 1024, 1024, 23>(arr, bounds, n_ranges, n_stage, status, stats);
+        if (shift == 19 && config == 0) return run<19, 1024, 256, 23>(arr, bounds, n_ranges, n_stage, status, stats);
+        if (shift == 20 && config == 0) return run<20, 1024, 256, 23>(arr, bounds, n_ranges, n_stage, status, stats);
         if (shift == 19 && config == 1) return run<19, 256, 256, 5>(arr, bounds, n_ranges, n_stage, status, stats);
         if (shift == 20 && config == 1) return run<20, 256, 256, 5>(arr, bounds, n_ranges, n_stage, status, stats);
         if (shift == 19 && config == 2) return run<19, 256, 128, 32>(arr, bounds, n_ranges, n_stage, status, stats);
-        if (shift == 19 && config == 3) return run<19, 1024, 1024, 23>(arr, bounds, n_ranges, n_stage, status, stats, 1000);   // fallback jobs with only 1000 words in LDS
+        if (shift == 19 && config == 4) return run<19, 1024, 512, 23>(arr, bounds, n_ranges, n_stage, status, stats);                  // eight wavefronts per LDS block
+        if (shift == 19 && config == 3) return run<19, 1024, 256, 23>(arr, bounds, n_ranges, n_stage, status, stats, 1000);   // fallback jobs with only 1000 words in LDS
         throw std::runtime_error("isort_emul: unknown configuration");
     } catch (const std::exception& e) { snprintf(err, errlen, "%s", e.what()); return -1; }
 }
