@@ -38,8 +38,8 @@ PARITY_SAMPLE = True    # after the timed region: a few frames of the last step 
 W, H = 640, 480
 MARGIN = 48
 NCANVAS = 256
-SEQ_CUS = 0             # default CU partition of the sequential kernels (--seq-cus): set from the round-6 measurements, DESIGN.md
-SEQ_WHICH = 3
+SEQ_CUS = 128           # default CU partition: PEAC's clustering kernel (one wavefront per frame, 352 registers, 38 KB of LDS) confined to half of the CUs by a CU-masked
+SEQ_WHICH = 1           # side stream, so that the other half always has room for the wide kernels' workgroups (round-6 sweep, DESIGN.md §6: +2-4 % at 2048 frames per step)
 
 
 def orb_algorithmic_bytes(ex, avg_kp):
@@ -119,9 +119,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="camera streams per GPU = frames per GPU per step (0: 1536 for the full workload - six frames per CU; the "
-                                                         "one-workgroup-per-frame kernels end with their slowest frames and a longer launch hides more of that tail: 10.3 k frames/s "
-                                                         "at 1024, 10.7-10.9 k at 1536, measured in round 5; 2048 does not fit the five buffer sets' workspaces in 288 GB -, "
+    ap.add_argument("--batch", type=int, default=0, help="camera streams per GPU = frames per GPU per step (0: 2048 for the full workload - two full rounds of the clustering "
+                                                         "kernel's 1024 frames; it fits since the extractors' workspaces exist per extraction in flight, not per buffer set -, "
                                                          "1024 for --workload orb, 256 for --workload pose)")
     ap.add_argument("--workload", choices=["full", "orb", "ba", "pose"], default="full",
                     help="full: the per-frame path (BASELINE metric); orb: config[1] only; ba: config[4], ONE local bundle adjustment partitioned over the ranks")
@@ -179,7 +178,7 @@ def main():
     if args.workload == "ba":
         return main_ba(args)
     full = args.workload == "full"
-    B = args.batch or (1536 if full else 1024)
+    B = args.batch or (2048 if full else 1024)
     # ---- inputs: generated on worker processes BEFORE the GPU runtime is initialised (fork) ----
     from planarslam_amd.synth import TUM3, pan_offset, stream_canvases
     ncanv = min(args.canvases, B)
@@ -239,8 +238,18 @@ def main():
 
     L = lib()
     if full:
+        torch.cuda.synchronize()
+        free0, talloc0 = torch.cuda.mem_get_info(dev)[0], torch.cuda.memory_allocated(dev)
         tp = TrackPipeline(B, torch, local_rank, depth=args.depth, prio=prio, cam=TUM3, W=W, H=H, work_sets=args.work_sets or None, seq_cus=args.seq_cus,
                            seq_which=args.seq_which, seq_shared=not args.seq_per_ctx)
+        torch.cuda.synchronize()
+        # device memory the pipeline holds per frame of the batch: the extractors' workspaces (hipMalloc inside the library: ORB's one set + NW sets of LSD / PEAC / plane
+        # clouds / normals) = what left the device's free pool minus what torch's allocator took for the NB sets of outputs, the per-stream state and the optimiser buffers
+        mem_total = free0 - torch.cuda.mem_get_info(dev)[0]
+        mem_torch = torch.cuda.memory_allocated(dev) - talloc0
+        MEM = {"workspace_bytes_per_frame": int(max(0, mem_total - mem_torch) // B), "output_and_state_bytes_per_frame": int(mem_torch // B),
+               "pipeline_bytes_total": int(mem_total), "extractor_sets": tp.NW, "buffer_sets": tp.NB,
+               "note": "workspace = hipMalloc'ed inside libplanar_hip.so (free-memory delta minus torch's allocations; torch's caching allocator may round the latter up)"}
         NB = tp.NB
         stream, ex = tp.stream, tp.ex
         frames = [torch.zeros((B, H, W), dtype=torch.uint8, device=dev) for _ in range(NB)]
@@ -692,7 +701,7 @@ def main():
                    "window": (f"every step shows every stream the next frame of its {args.loop}-frame loop (forwards, then backwards: {2 * args.loop - 2} steps per cycle)" if se3
                               else "every step is a new window position for every stream"),
                    "pipeline_depth": args.depth,
-                   "extractor_sets": tp.NW if full else None,
+                   "extractor_sets": tp.NW if full else None, "device_memory": MEM if full else None,
                    "cu_partition": ({"sequential_kernels_on_cus": args.seq_cus, "which": args.seq_which, "stream": "per context" if args.seq_per_ctx else "shared"} if full and args.seq_cus else None),
                    "avg_keypoints_per_frame": round(avg_kp, 1), "input_generation_s": round(t_gen, 1),
                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}, "not_yet_in_workload": nyi,

@@ -276,7 +276,10 @@ __device__ __forceinline__ void lds_sync();
 //   lsd_sort_lds      one workgroup per block of <= 23 552 words, up to SORT_R per frame: everything below, in LDS, written back sorted;
 //   lsd_sort_compact  one workgroup per frame: drops the undefined pixels (they took part in the partitions), numbers the rest.
 // Checked against the real std::sort through the oracle (tests/test_lsd_gpu.py) and on the emulator (tests/test_isort_emul.py).
-constexpr int SORT_T = 1024, SORT_LT = 256, SORT_E = 23, SORT_SHIFT = 20, SORT_R = 64;      // SORT_T: threads of the global tier and the compaction; SORT_LT x SORT_E: an LDS block
+#ifndef PLANAR_WIDE_T
+#define PLANAR_WIDE_T 1024      // (developer build `make narrow`: 256 - the round-6 co-residency experiment)
+#endif
+constexpr int SORT_T = PLANAR_WIDE_T, SORT_LT = 256, SORT_E = 23, SORT_SHIFT = 20, SORT_R = 64;      // SORT_T: threads of the global tier and the compaction; SORT_LT x SORT_E: an LDS block
 constexpr int SORT_HJOBS = 1024, SORT_HCAP = 8192, SORT_HY = 2;       // heap-sort fallback: jobs per frame, words of a job kept in LDS, workgroups per frame
 using SortLds = isort::LdsLayout<SORT_LT, SORT_E>;
 using SortGl = isort::GlobalLayout<SORT_T>;

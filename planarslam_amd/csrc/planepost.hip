@@ -312,7 +312,10 @@ __device__ __forceinline__ void bitonic(unsigned long long* a, int n2) {
 //   plane_tail_kernel     the items' depths gathered in sorted order (streaming), then thread per voxel: the FLOAT sums in that order, centroid = sum / (float)count; then the distance gate and the RANSAC refit (one
 //                         wavefront per plane) and the compaction of the kept planes
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
-constexpr int PS_T = 1024, PS_LT = 256, PS_E = 23, PS_SHIFT = 19, PS_R = 96;      // PS_T: threads of the item / global-tier kernels; PS_LT x PS_E: an LDS block (40 KB: four per CU, and room for the other streams' workgroups)
+#ifndef PLANAR_WIDE_T
+#define PLANAR_WIDE_T 1024      // (developer build `make narrow`: 256 - the round-6 co-residency experiment)
+#endif
+constexpr int PS_T = PLANAR_WIDE_T, PS_LT = 256, PS_E = 23, PS_SHIFT = 19, PS_R = 96;      // PS_T: threads of the item / global-tier kernels; PS_LT x PS_E: an LDS block (40 KB: four per CU, and room for the other streams' workgroups)
 constexpr int PS_HJOBS = 1024;                                     // heap-sort fallback: jobs per frame
 // ... run in three launches by size, so that the many short ranges do not each hold a CU's LDS: (longest range, words of LDS per wavefront, wavefronts
 // per workgroup, workgroups per frame); a range longer than the last class's LDS keeps the top of its heap there and the rest in place

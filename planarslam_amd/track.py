@@ -66,10 +66,17 @@ class TrackPipeline:
         if seq_cus:
             from ._lib import cu_stream_create
             targets = (self.ctx_peacs if seq_which & 1 else []) + (self.ctx_lsds if seq_which & 2 else [])
-            for c in targets:
-                if not seq_shared or not self.seq_streams:
-                    self.seq_streams.append(cu_stream_create(device_index, int(seq_cus)))
-                c.set_seq_stream(self.seq_streams[-1])
+            try:
+                for c in targets:
+                    if not seq_shared or not self.seq_streams:
+                        self.seq_streams.append(cu_stream_create(device_index, int(seq_cus)))
+                    c.set_seq_stream(self.seq_streams[-1])
+            except Exception as e:      # a runtime that refuses CU masks: same results on the contexts' own streams (speed only)
+                import sys
+                print(f"TrackPipeline: no CU partition ({e}); the sequential kernels stay on their extractors' streams", file=sys.stderr)
+                for c in targets:
+                    c.set_seq_stream(None)
+                self.seq_streams = []
         self.ex = ORBextractor(1000, 1.2, 8, 20, 7, width=W, height=H, max_batch=B, ctx=self.ctx)
         self.S = S = self.ex.kp_cap
         self.pds = [PlaneDetection(W, H, max_batch=B, ctx=c) for c in self.ctx_peacs]
