@@ -68,8 +68,8 @@ public:
         auto it = peacs_.find({w, h});
         if (it != peacs_.end()) return it->second;
         planar_peac* o = nullptr;
-        // (a size the plane path does not support - more than 3072 blocks of 10x10, i.e. more pixels than 640x480 - is reported ONCE: the failed size is remembered
-        //  as a null handle, later frames of that size track without planes without repeating the message; INTEGRATION.md "Frame sizes")
+        // (a size the plane path does not support - more than ~10 900 blocks of 10x10: 1280x720 fits since round 6, 1920x1080 does not - is reported ONCE: the failed size is
+        //  remembered as a null handle, later frames of that size track without planes without repeating the message; INTEGRATION.md "Frame sizes")
         if (planar_peac_create(lanes_[PLANES].ctx, w, h, 1, &o) != PLANAR_OK) { complain("planar_peac_create"); o = nullptr; }
         return peacs_[{w, h}] = o;
     }

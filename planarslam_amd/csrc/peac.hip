@@ -65,7 +65,8 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
 
     __shared__ float s_hm[MAX_PLANES];      // the heap of the final clustering holds <= MAX_PLANES nodes
     __shared__ u16 s_hi[MAX_PLANES];
-    __shared__ signed char s_blk[3072];      // block -> plane id (NB <= 3072 is checked at create time)
+    PLANAR_DYN_SMEM(s_dyn);
+    signed char* s_blk = (signed char*)s_dyn;      // [NB] block -> plane id (dynamic LDS: the launch passes refine_smem_bytes(L))
     Lds S;
     S.h_key = s_hm; S.h_id = s_hi;
     S.pool = (u16*)(F + L.off_h_pool); S.nb_off = (u16*)(F + L.off_h_nboff); S.nb_cnt = (u16*)(F + L.off_h_nbcnt);
@@ -882,7 +883,7 @@ struct planar_peac {
     int W = 0, H = 0, max_batch = 0;
     peac::Layout L{};
     peac::Consts C{};
-    int smem2 = 0;
+    int smem2 = 0, smem_refine = 0;
     // kernel variants, set only through planar_peac_set_variant (tools' A/B runs and tests; no environment switch reaches the product path)
     int wide_below = 64;                                      // batches up to this size refine with 1024 threads per frame (0 = never)
     bool exact_only = false;                                  // skip the fast clustering attempt: every frame through the exact heap
@@ -910,7 +911,19 @@ int planar_peac_create(planar_ctx* ctx, int width, int height, int max_batch, pl
     o->C = peac::make_consts();
     const peac::Layout& L = o->L;
     o->smem2 = peac::ahc2_smem_bytes(L);
-    if (L.pool_cap > 65535 || L.NB2 > 65535 || L.NB > 3072) { delete o; set_error("planar_peac_create: %dx%d has more blocks than the kernels' 16-bit node ids / 3072-entry block map hold", width, height); return PLANAR_EINVAL; }
+    // Frame sizes: node ids are 16 bits, and the clustering wavefront keeps the queue keys (8 B per block), the merge-parent table (4 B per block) and three bitmaps in LDS:
+    // up to ~10 900 blocks = 160 KB (1280x720 = 9 216 blocks: 114 KB, one frame per CU at a time; 640x480 = 3 072: 38 KB, four per CU)
+    o->smem_refine = (int)((L.NB + 15) / 16 * 16);
+    if (L.pool_cap > 65535 || L.NB2 > 65535 || o->smem2 > 160 * 1024 - 2048) {
+        delete o;
+        set_error("planar_peac_create: %dx%d = %d blocks of 10x10 pixels: the clustering kernel's LDS-resident queue holds about 10 900 (1280x720 fits, 1920x1080 does not)", width, height, L.NB);
+        return PLANAR_EINVAL;
+    }
+    if (o->smem2 > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)peac::peac_ahc3, hipFuncAttributeMaxDynamicSharedMemorySize, o->smem2);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)peac::peac_ahc2, hipFuncAttributeMaxDynamicSharedMemorySize, o->smem2);
+        if (e != hipSuccess) { (void)hipGetLastError(); delete o; set_error("planar_peac_create: %d bytes of LDS per workgroup are not available: %s", o->smem2, hipGetErrorString(e)); return PLANAR_EINVAL; }
+    }
     int rc;
     if ((rc = o->d_ws.alloc((size_t)max_batch * L.frame_bytes)) || (rc = o->d_status.alloc((size_t)max_batch * 4)) ||
         (rc = o->d_timing.alloc((size_t)max_batch * peac::TSLOTS * 8)) || (rc = o->d_next.alloc(256)) || (rc = o->d_order.alloc((size_t)max_batch * 4))) { delete o; return rc; }
@@ -969,10 +982,10 @@ int planar_peac_segment_dev(planar_peac* p, const uint16_t* d_depth, int B, int 
     hipLaunchKernelGGL(peac::peac_order, dim3((B + 255) / 256), dim3(256), 0, st, p->d_timing.as<long long>(), B, p->d_order.as<int>());
     mark();
     if (B <= p->wide_below)
-        hipLaunchKernelGGL(peac::peac_refine_wide, dim3(B), dim3(peac::NT_REFINE_WIDE), 0, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+        hipLaunchKernelGGL(peac::peac_refine_wide, dim3(B), dim3(peac::NT_REFINE_WIDE), p->smem_refine, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
                            p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
     else
-        hipLaunchKernelGGL(peac::peac_refine, dim3(B), dim3(peac::NT_REFINE), 0, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
+        hipLaunchKernelGGL(peac::peac_refine, dim3(B), dim3(peac::NT_REFINE), p->smem_refine, st, p->L, K, p->C, d_depth, pitch_px, frame_stride_px,
                            p->d_ws.as<uint8_t>(), d_labels, (int64_t)p->W * p->H, d_planes, d_n_planes, p->d_status.as<int32_t>(), p->d_timing.as<long long>());
     mark();
     p->order_B = B;

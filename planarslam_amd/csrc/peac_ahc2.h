@@ -271,7 +271,36 @@ __device__ __forceinline__ int ahc_frame(const Layout& L, const Consts& C, uint8
         if (!P.any || d < P.d) { P.d = d; P.id = id; P.any = true; P.tie = false; }
         else if (d == P.d) P.tie = true;
     };
+    // (frames of more than 4096 blocks - 8192 node ids, two per lane and column - take the general form: any number of ids per lane)
+    auto col_recompute_large = [&](int Lc) {
+        unsigned mn = K_EMPTY;
+        for (int i = Lc + 64 * lane; i < NB2; i += 4096) mn = min(mn, kproxy(K[i]));
+        mn = wave_min_u32(mn);
+        int id = -1; unsigned v = K_EMPTY;
+        if (mn != K_EMPTY) {
+            int nmatch = 0, first = -1;
+            for (int base = 0; base < NB2; base += 4096) {
+                const int i = base + Lc + 64 * lane;
+                const u64 m = __ballot(i < NB2 && kproxy(K[min(i, NB2 - 1)]) == mn);
+                if (m) { if (first < 0) first = base + Lc + 64 * (__ffsll((long long)m) - 1); nmatch += __popcll(m); }
+            }
+            if (nmatch == 1) id = first;
+            else {
+                GFENCE();
+                Pick P{-1, 0.0, false, false};
+                for (int base = 0; base < NB2; base += 4096) {
+                    const int i = base + Lc + 64 * lane;
+                    for (u64 m = __ballot(i < NB2 && kproxy(K[min(i, NB2 - 1)]) == mn); m; m &= m - 1) pick_add(P, base + Lc + 64 * (__ffsll((long long)m) - 1));
+                }
+                if (P.tie) err = ST_RETRY;
+                id = P.id;
+            }
+            v = K[id];
+        }
+        if (lane == Lc) { cm_v = v; cm_id = id; }
+    };
     auto col_recompute = [&](int Lc) {                        // Lc wave-uniform
+        if (NB2 > 8192) { col_recompute_large(Lc); return; }
         const int i1 = Lc + 64 * lane, i2 = i1 + 4096;
         const unsigned v1 = i1 < NB2 ? K[i1] : K_EMPTY, v2 = i2 < NB2 ? K[i2] : K_EMPTY;
         const unsigned p1 = kproxy(v1), p2 = kproxy(v2);
@@ -342,7 +371,47 @@ __device__ __forceinline__ int ahc_frame(const Layout& L, const Consts& C, uint8
     };
     // exclusive prefix of the bitmap words' popcounts -> pre[]; returns the number of set bits.  Lane j owns words 3j .. 3j+2.
     unsigned bw[3];
+    // (frames of more than 3072 blocks: more than 192 bitmap words = three per lane; the general forms walk the bitmap 192 words at a time and re-read the words)
+    auto bitmap_prefix_large = [&]() -> int {
+        int carry = 0;
+        for (int w0 = 0; w0 < W32; w0 += 192) {
+            int c[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const int w = w0 + 3 * lane + k; c[k] = w < W32 ? __popc(bmp[w]) : 0; }
+            const int tot = c[0] + c[1] + c[2];
+            const int incl = wave_scan_add(tot);
+            const int ex = carry + incl - tot;
+            if (w0 + 3 * lane < W32) pre[w0 + 3 * lane] = (u16)ex;
+            if (w0 + 3 * lane + 1 < W32) pre[w0 + 3 * lane + 1] = (u16)(ex + c[0]);
+            if (w0 + 3 * lane + 2 < W32) pre[w0 + 3 * lane + 2] = (u16)(ex + c[0] + c[1]);
+            carry += wave_lane(incl, 63);
+        }
+        WFENCE();
+        return carry;
+    };
+    auto bitmap_emit_large = [&](u16* dst, bool with_inval) {
+        for (int w0 = 0; w0 < W32; w0 += 192) {
+            if (w0 + 3 * lane >= W32) continue;
+            int o = (int)pre[w0 + 3 * lane];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int wi = w0 + 3 * lane + k;
+                if (wi >= W32) break;
+                unsigned w = bmp[wi];
+                const int base = wi * 32;
+                if (w) bmp[wi] = 0;
+                while (w) {
+                    const int b = __ffs((int)w) - 1;
+                    w &= w - 1;
+                    dst[o++] = (u16)(base + b);
+                    if (with_inval) inval((unsigned)(base + b));
+                }
+            }
+        }
+        WFENCE();
+    };
     auto bitmap_prefix = [&]() -> int {
+        if (W32 > 192) return bitmap_prefix_large();
         int c[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) { const int w = 3 * lane + k; bw[k] = w < W32 ? bmp[w] : 0u; c[k] = __popc(bw[k]); }
@@ -357,6 +426,7 @@ __device__ __forceinline__ int ahc_frame(const Layout& L, const Consts& C, uint8
     };
     // the lanes that own bitmap words write their set bits, ascending, to dst[ex ...] and clear the words; with_inval: the ids' valid bits are cleared
     auto bitmap_emit = [&](u16* dst, bool with_inval) {
+        if (W32 > 192) { bitmap_emit_large(dst, with_inval); return; }
         int o = (int)pre[min(3 * lane, W32 - 1)];
 #pragma unroll
         for (int k = 0; k < 3; k++) {

@@ -153,8 +153,7 @@ __device__ void stats_compute(const double s[9], int N, Geo& g) {
 struct Layout {   // per-frame workspace (element offsets), identical for every frame
     int W, H, Nw, Nh, NB, NB2;   // NB2 = 2*NB: initial blocks + merged nodes
     int pool_cap, q_cap;
-    size_t off_stats, off_geo, off_N, off_rid, off_flags, off_nb_off, off_nb_cnt, off_pool, off_parent, off_size,
-        off_member, off_dist, off_blkmap, off_queue, off_seedcnt, off_cint, off_cdbl, frame_bytes;
+    size_t off_stats, off_geo, off_N, off_flags, off_member, off_dist, off_queue, off_seedcnt, frame_bytes;
     // state the clustering kernel (peac_ahc) leaves for the refinement kernel (peac_refine): disjoint set, root ids, dead bits, extracted planes
     size_t off_h_dsp, off_h_dss, off_h_rid, off_h_nouse, off_h_cval, off_h_hand, off_h_nboff, off_h_nbcnt, off_h_pool;
     // peac_ahc2 (lazy adjacency): candidate records (68 dwords per node, the bag of <= 64 neighbours inside) and the pool of the larger bags
@@ -174,7 +173,6 @@ __global__ __launch_bounds__(64) void peac_blocks(Layout L, Intr K, const uint16
     double* stats = (double*)(F + L.off_stats) + (size_t)blk * 9;
     double* geo = (double*)(F + L.off_geo) + (size_t)blk * 7;
     int* Narr = (int*)(F + L.off_N);
-    int* rid = (int*)(F + L.off_rid);
     uint8_t* flags = F + L.off_flags;   // bit0: in graph (pushed to minQ), bit1: nouse
     const uint16_t* D = depth + (size_t)frame * frame_stride_px;
     const int bi = blk / L.Nw, bj = blk - bi * L.Nw;
@@ -207,7 +205,6 @@ __global__ __launch_bounds__(64) void peac_blocks(Layout L, Intr K, const uint16
     for (int k = 0; k < 3; k++) { geo[k] = g.center[k]; geo[3 + k] = g.normal[k]; }
     geo[6] = g.mse;
     Narr[blk] = valid ? WIN * WIN : 0;
-    rid[blk] = blk;
     flags[blk] = (in_graph ? 1 : 0) | (valid ? 0 : 2);
 }
 
@@ -230,20 +227,18 @@ constexpr int CREC_DW = 68;   // dwords of a node's candidate record (peac_ahc2.
 static inline Layout make_layout(int width, int height) {
     Layout L{};
     L.W = width; L.H = height; L.Nw = width / WIN; L.Nh = height / WIN; L.NB = L.Nw * L.Nh; L.NB2 = 2 * L.NB;
-    // (legacy kernel / refinement) neighbour-list pool, u16 entries with u16 offsets: the blocks' 4-entry lists, then the merged nodes' lists
+    // (refinement's final clustering) neighbour-list pool, u16 entries with u16 offsets: the blocks' 4-entry lists, then the merged nodes' lists
     const int pool_want = 4 * L.NB + (16 * L.NB > MAX_PLANES * MAX_PLANES ? 16 * L.NB : MAX_PLANES * MAX_PLANES);
     L.pool_cap = pool_want < 65535 - 64 ? pool_want : 65535 - 64;
     L.q_cap = 2 * width * height;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o2 = off; off = (off + bytes + 255) / 256 * 256; return o2; };
+    // (round 6: the regions only the round-2 clustering kernel used - its 32-bit lists and pool, its candidate cache, the 32-bit disjoint set: 1.26 MB per frame - are gone)
     L.off_stats = carve((size_t)L.NB2 * 9 * 8); L.off_geo = carve((size_t)L.NB2 * 7 * 8); L.off_N = carve((size_t)L.NB2 * 4);
-    L.off_rid = carve((size_t)L.NB2 * 4); L.off_flags = carve((size_t)L.NB2); L.off_nb_off = carve((size_t)L.NB2 * 4);
-    L.off_nb_cnt = carve((size_t)L.NB2 * 4); L.off_pool = carve((size_t)L.pool_cap * 4);
-    L.off_parent = carve((size_t)L.NB * 4); L.off_size = carve((size_t)L.NB * 4); L.off_member = carve((size_t)width * height + 4);
-    L.off_dist = carve((size_t)width * height * 4); L.off_blkmap = carve((size_t)L.NB * 4); L.off_queue = carve((size_t)L.q_cap * 4);
+    L.off_flags = carve((size_t)L.NB2);
+    L.off_member = carve((size_t)width * height + 4);
+    L.off_dist = carve((size_t)width * height * 4); L.off_queue = carve((size_t)L.q_cap * 4);
     L.off_seedcnt = carve((size_t)L.NB * 4);
-    // (legacy kernel) candidate cache: per node 4 ints {have, best_nb, best_N, -} and 16 doubles {mse, stats[9], center[3], normal[3]}
-    L.off_cint = carve((size_t)L.NB2 * 16); L.off_cdbl = carve((size_t)L.NB2 * 16 * 8);
     L.off_h_dsp = carve((size_t)L.NB * 2); L.off_h_dss = carve((size_t)L.NB * 2); L.off_h_rid = carve((size_t)L.NB2 * 2);
     L.off_h_nouse = carve((size_t)((L.NB2 + 31) / 32) * 4); L.off_h_cval = carve((size_t)((L.NB2 + 31) / 32) * 4);
     L.off_h_hand = carve((size_t)(4 + MAX_PLANES) * 4);

@@ -31,7 +31,7 @@ int peac_emul_cluster(const uint16_t* depth, int W, int H, float fx, float fy, f
         planar::peac::g_peac_check_prune = (mode & 4) ? 1 : 0; mode &= 3;
         const Layout L = make_layout(W, H);
         const Consts C = make_consts();
-        if (L.NB > 3072) throw std::runtime_error("image too large for the clustering kernel");
+        if (L.NB2 > 65535 || ahc2_smem_bytes(L) > 160 * 1024 - 2048) throw std::runtime_error("image too large for the clustering kernel");
         std::vector<uint8_t> ws(L.frame_bytes, 0xEE);   // poisoned: the kernels must initialise what they read
         const Intr K{fx, fy, cx, cy, factor};
         BlocksArgs ba{L, K, depth, W, (int64_t)W * H, ws.data()};

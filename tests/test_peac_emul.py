@@ -75,6 +75,19 @@ def test_emulated_kernel_matches_oracle(libs, w, h, seed, noise, holes):
         _run(libs, d, mode=1)                             # the exact-heap kernel alone
 
 
+def test_frame_with_more_than_4096_blocks(libs):
+    """960x540 = 5 184 blocks: more than 8 192 node ids, so the tournament queue's columns hold more than two ids per lane (col_recompute_large) and the clustering
+    kernel's LDS grows with the block count (reference: any size, src/PlaneExtractor.cpp:59, include/peac/AHCPlaneFitter.hpp:225); the cameras' intrinsics scale with it"""
+    d = depth_image(4321, 960, 540, noise=True, holes=True)
+    info = _run(libs, d, mode=2)                          # the fast kernel on its own
+    assert info["nodes"] > 5184 and not info["retried"]
+    # noise-free: exact ties (the exact heap redoes the frame) and unions over more than 6 144 node ids (the union bitmap is walked 192 words at a time); every pruned
+    # evaluation of a pooled bag checked against evaluating all its candidates
+    d = depth_image(4321, 960, 540, noise=False, holes=True)
+    info = _run(libs, d, mode=4)
+    assert info["retried"] and info["big"] > 50
+
+
 def test_fast_kernel_alone_handles_generic_frames(libs):
     """noisy depth has no bit-equal mse values: the fast kernel must finish on its own (mode 2 does not fall back)"""
     for seed in (5, 6, 7):

@@ -50,6 +50,20 @@ def test_hip_other_size():
     assert np.array_equal(labels, olab) and np.array_equal(planes, op)
 
 
+@pytest.mark.parametrize("w,h,B", [(848, 480, 3), (1280, 720, 2), (325, 247, 2)])
+def test_hip_frames_beyond_640x480(w, h, B):
+    """PlaneDetection takes any frame size (reference: src/PlaneExtractor.cpp:59, include/peac/AHCPlaneFitter.hpp:225 - blocks of 10x10; the pixels outside the block grid are only reached by the flood fill).  848x480 = 4 032 blocks (RealSense); 1280x720 = 9 216 blocks: the clustering wavefront's queue and merge-parent table take 114 KB of LDS,
+    the tournament's columns hold five ids per lane; 325x247: neither side a multiple of the block size.  Labels and plane doubles bit-exact against the oracle."""
+    from planarslam_amd import PlaneDetection
+    depths = np.stack([depth_image(300 + 7 * i + w, w, h, noise=(i % 2 == 0), holes=True) for i in range(B)])
+    res = PlaneDetection(w, h, max_batch=B).run(depths)
+    for b in range(B):
+        op, olab = ol.peac_run(depths[b])
+        assert len(op) >= 1
+        assert np.array_equal(res[b][1], olab), f"labels frame {b}"
+        assert res[b][0].shape == op.shape and np.array_equal(res[b][0], op), f"planes frame {b}"
+
+
 def test_hip_more_frames_than_cus_and_repeated_calls():
     """Workgroups take their frame from a start-order counter: more frames than CUs (several dispatch rounds) and a second call on the
     same handle (counter reset) must give, frame by frame, what a single-frame call gives."""
