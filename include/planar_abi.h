@@ -449,8 +449,11 @@ int planar_lsd_read_stage(planar_lsd* lsd, int frame, int stage, void* out, int6
  * summed milliseconds of the recorded calls, total_ms[4] = preprocessing (blurs, gradient, Sobel), lsd_sort, lsd_detect, the rest, their number, and resets. */
 int planar_lsd_set_profiling(planar_lsd* lsd, int enable);
 int planar_lsd_get_profile(planar_lsd* lsd, double* total_ms, int64_t* calls);
-/* test hook: device emulation of libstdc++ std::sort with the sort_lines_by_response comparator (include/auxiliar.h:43-48) */
+#ifdef PLANAR_TEST_HOOKS
+/* test hook, exported by the TEST build only (libplanar_hip_paranoid.so, `make paranoid`): device emulation of libstdc++ std::sort with the sort_lines_by_response
+ * comparator (include/auxiliar.h:43-48) on raw keys */
 int planar_debug_std_sort_desc(planar_ctx* ctx, float* keys, int32_t* perm, int n);
+#endif
 
 /* ---- plane extractor (replaces PlaneDetection::readDepthImage + runPlaneDetection,
  *      src/PlaneExtractor.cpp:26-65 / include/PlaneExtractor.h:36-56, i.e. ahc::PlaneFitter::run with
@@ -663,6 +666,10 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* pc, const uint16_t* d_d
                                     float cx, float cy, float depth_factor, const int32_t* d_labels, const double* d_planes, const int32_t* d_n_planes,
                                     double dist_th, float leaf, int32_t* d_n_out, float* d_coef, int32_t* d_src, int32_t* d_pt_off, float* d_points,
                                     int32_t* d_status, int32_t* d_state, int32_t* d_nvox, int32_t* d_info);
+/* Per-frame result codes of the last planar_plane_clouds_compute call on this handle (host-pointer entry point; the _dev entry point delivers them in d_status): 0 ok,
+ * 3 = the frame's planes together hold more voxels than max_points (or a voxel index out of range) - pcl::VoxelGrid has no cap (src/Frame.cc:674-679), so callers redo
+ * exactly those frames plane by plane (planar_plane_clouds_set_plane_window) -, 4 = sampler table exhausted, 5 = std::sort order not reproducible.  out [B]. */
+int planar_plane_clouds_last_status(planar_plane_clouds* pc, int B, int32_t* out);
 /* Frame::MaxPointDistanceFromPlane on given clouds (host pointers): planes [n_clouds][4] in/out (written when state == 0), cloud q = points[pt_off[q] ..
  * pt_off[q + 1]); state / info as above. */
 int planar_plane_refit(planar_plane_clouds* pc, int n_clouds, const float* points, const int32_t* pt_off, double dist_th, float* planes, int32_t* state,

@@ -279,7 +279,9 @@ public:
             const int rc = planar_plane_clouds_compute(R.clouds(W, H), (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_,
                                                        cx_, cy_, factor_, labels_.data(), planes_.data(), &n_in, disTh, leaf, &n_out, coef.data(), src.data(), off.data(),
                                                        pts.data(), nullptr, nullptr, nullptr);
-            if (rc == PLANAR_ECAPACITY && std::strstr(planar_last_error(), "(code 3") != nullptr) {
+            int32_t fst = 0;                                                  // the frame's result code (3 = more voxels than the table holds), not the message's text
+            if (rc == PLANAR_ECAPACITY) planar_plane_clouds_last_status(R.clouds(W, H), 1, &fst);
+            if (rc == PLANAR_ECAPACITY && fst == 3) {
                 // pcl::VoxelGrid has no voxel cap (src/Frame.cc:674-679); the frame's voxel table here has (8192 for all planes together).  The frame goes through once
                 // more PLANE BY PLANE (planar_plane_clouds_set_plane_window), results appended in plane order - the very sequence of Frame::ComputePlanes' loop, every
                 // plane's cloud and refit what the one-pass call would have produced.  Only a single plane of more than 8192 voxels (> 80 m^2 at the 0.1 m leaf) is
@@ -292,7 +294,9 @@ public:
                     const int rc1 = planar_plane_clouds_compute(pc, (const uint16_t*)depth_.data, 1, (int)(depth_.step / 2), (int64_t)(depth_.step / 2) * H, fx_, fy_, cx_, cy_, factor_,
                                                                 labels_.data(), planes_.data(), &n_in, disTh, leaf, &n1, coef.data(), src.data(), off.data(), pts.data(), nullptr,
                                                                 nullptr, nullptr);
-                    if (rc1 == PLANAR_ECAPACITY && std::strstr(planar_last_error(), "(code 3") != nullptr) {
+                    int32_t pst = 0;
+                    if (rc1 == PLANAR_ECAPACITY) planar_plane_clouds_last_status(pc, 1, &pst);
+                    if (rc1 == PLANAR_ECAPACITY && pst == 3) {
                         std::fprintf(stderr, "planar: plane %d of this frame alone has more than %d voxels: dropped (%s)\n", i, MP, planar_last_error());
                         continue;
                     }

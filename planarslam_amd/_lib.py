@@ -214,6 +214,7 @@ _SIGS = {
                                              C.c_void_p, C.c_double, C.c_float] + [C.c_void_p] * 8),
     "planar_plane_clouds_compute_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_double, C.c_float] + [C.c_void_p] * 9),
+    "planar_plane_clouds_last_status": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "planar_plane_refit": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "planar_flag_matched_plane_points": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "planar_flag_matched_plane_points_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
@@ -236,12 +237,13 @@ _SIGS = {
     "planar_pose_opt_dev": (C.c_int, [C.c_void_p, C.POINTER(PoseBatch), C.POINTER(PoseParams), C.c_int, C.c_int, C.c_int]),
 }
 
+TEST_HOOKS = ("planar_debug_std_sort_desc",)     # declared under PLANAR_TEST_HOOKS in include/planar_abi.h
 _LIB = None
 
 
 def exported_symbols():
     """Every symbol include/planar_abi.h declares (kept in sync by tests/test_abi.py)."""
-    return sorted(_SIGS)
+    return sorted(n for n in _SIGS if n not in TEST_HOOKS)
 
 
 def lib():
@@ -252,6 +254,8 @@ def lib():
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
+            if name in TEST_HOOKS and not hasattr(L, name):
+                continue                       # only the test build (libplanar_hip_paranoid.so) exports these
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args

@@ -1519,10 +1519,12 @@ __global__ __launch_bounds__(64) void lbd_describe(const Plan* __restrict__ plan
     }
 }
 
-// debug: device std::sort emulation on raw keys (tests/test_lsd_gpu.py checks it against libstdc++)
+#ifdef PLANAR_TEST_HOOKS
+// TEST BUILD ONLY (make paranoid -> libplanar_hip_paranoid.so): the device std::sort emulation of lsd_keylines on raw keys (tests/test_lsd_gpu.py checks it against libstdc++)
 __global__ __launch_bounds__(64) void debug_sort_kernel(float* key, int* idx, int n) {
     if (threadIdx.x == 0) { SortBuf s{key, idx}; std_sort_desc(s, n); }
 }
+#endif
 
 }  // namespace lsd
 }  // namespace planar
@@ -1895,7 +1897,8 @@ int planar_lsd_scaled_size(planar_lsd* o, int* w, int* h) {
     return PLANAR_OK;
 }
 
-/* test hook: the device emulation of libstdc++ std::sort(first, last, greater-by-key) used for sort_lines_by_response;
+#ifdef PLANAR_TEST_HOOKS
+/* test hook (test build only): the device emulation of libstdc++ std::sort(first, last, greater-by-key) used for sort_lines_by_response;
  * keys [n] float (in/out), perm [n] int32 (out: original index of each sorted element) */
 int planar_debug_std_sort_desc(planar_ctx* ctx, float* keys, int32_t* perm, int n) {
     PLANAR_REQUIRE(ctx && keys && perm && n >= 0 && n <= (1 << 20), PLANAR_EINVAL, "bad argument");
@@ -1915,5 +1918,6 @@ int planar_debug_std_sort_desc(planar_ctx* ctx, float* keys, int32_t* perm, int 
     PLANAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return PLANAR_OK;
 }
+#endif
 
 }  // extern "C"

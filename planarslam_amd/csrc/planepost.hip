@@ -936,6 +936,7 @@ struct planar_plane_clouds {
     int sort_rows = 0;
     planar::DevBuf ws, rng, dbg;
     bool timing = false;
+    std::vector<int32_t> last_status;           // per-frame codes of the last host-pointer compute call
     // planar_plane_clouds_set_profiling: HIP events around the launches of a recorded call; slots: plane_voxels, plane_items, plane_sort_global, plane_sort_lds,
     // plane_sort_heap (three launches), plane_tail
     bool profiling = false;
@@ -1160,8 +1161,16 @@ int planar_plane_clouds_compute(planar_plane_clouds* p, const uint16_t* depth, i
                                               info ? s.dev<int32_t>(o_info) : nullptr)))
         return rc;
     if ((rc = s.download(st))) return rc;
+    p->last_status = h_status;                  // planar_plane_clouds_last_status: the per-frame codes of this call, for callers that branch on them
     for (int b = 0; b < B; b++)
         if (h_status[b]) { set_error("plane_clouds: frame %d exceeded a capacity (code %d: 3 = voxels / index range, 4 = sampler table, 5 = the std::sort order of a plane's points is not reproducible: introsort depth limit / sort workspace)", b, h_status[b]); return PLANAR_ECAPACITY; }
+    return PLANAR_OK;
+}
+
+int planar_plane_clouds_last_status(planar_plane_clouds* p, int B, int32_t* out) {
+    PLANAR_REQUIRE(p && out && B >= 1, PLANAR_EINVAL, "bad argument");
+    PLANAR_REQUIRE((size_t)B <= p->last_status.size(), PLANAR_EINVAL, "the last planar_plane_clouds_compute call had fewer frames");
+    for (int b = 0; b < B; b++) out[b] = p->last_status[b];
     return PLANAR_OK;
 }
 

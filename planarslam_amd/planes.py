@@ -145,54 +145,69 @@ class PlaneClouds:
                                                 npl.ctypes.data, float(dist_th), np.float32(leaf), n.ctypes.data, coef.ctypes.data, src.ctypes.data, off.ctypes.data,
                                                 pts.ctypes.data, state.ctypes.data if debug else None, nvox.ctypes.data if debug else None,
                                                 info.ctypes.data if debug else None)
-        overflow = False
+        status = np.zeros(B, np.int32)
         try:
             check(rc)
-        except PlanarError as e:                      # PLANAR_ECAPACITY, code 3: some frame's planes together hold more than max_points voxels (pcl::VoxelGrid has no cap)
-            if not (retry_per_plane and e.code == -4 and "(code 3" in str(e)):
+        except PlanarError as e:                      # PLANAR_ECAPACITY: the per-frame codes say which frames, and why (planar_plane_clouds_last_status)
+            if e.code != -4:
                 raise
-            overflow = True
+            check(self.L.planar_plane_clouds_last_status(self.h, B, status.ctypes.data))
+            # code 3: the frame's planes together hold more than max_points voxels (pcl::VoxelGrid has no cap): only THOSE frames go plane by plane; anything else is an error
+            if not retry_per_plane or ((status != 0) & (status != 3)).any():
+                raise
         out = []
         for b in range(B):
-            if overflow:
-                out.append(self._per_plane(d[b:b + 1], lab[b:b + 1], pl[b:b + 1], npl[b:b + 1], dist_th, leaf, K, depth_factor))
+            if status[b] == 3:
+                out.append(self._per_plane(d[b:b + 1], lab[b:b + 1], pl[b:b + 1], npl[b:b + 1], dist_th, leaf, K, depth_factor, debug))
                 continue
             k = int(n[b])
-            r = dict(n=k, coef=coef[b, :k].copy(), src=src[b, :k].copy(), pt_off=off[b, :k + 1].copy(), points=pts[b, :off[b, k]].copy())
+            r = dict(n=k, coef=coef[b, :k].copy(), src=src[b, :k].copy(), pt_off=off[b, :k + 1].copy(), points=pts[b, :off[b, k]].copy(), dropped=[])
             if debug:
                 P = int(npl[b])
                 r.update(state=state[b, :P].copy(), nvox=nvox[b, :P].copy(), info=[_refit_info(info[b, i]) for i in range(P)])
             out.append(r)
         return out
 
-    def _per_plane(self, d, lab, pl, npl, dist_th, leaf, K, depth_factor):
+    def _per_plane(self, d, lab, pl, npl, dist_th, leaf, K, depth_factor, debug=False):
         """One frame whose planes together overflow the voxel table: plane by plane through the plane window, results appended in plane order (the sequence of the
-        loop of Frame::ComputePlanes, src/Frame.cc:655-692).  A single plane of more than max_points voxels is dropped (listed in the result's `dropped`)."""
+        loop of Frame::ComputePlanes, src/Frame.cc:655-692).  A single plane of more than max_points voxels is dropped (listed in the result's `dropped`).  Same keys as
+        the one-pass result (with debug: state / nvox / info per detector plane; a dropped plane has state -2)."""
         H, W = d.shape[1:]
         PS, MP = self.pl_stride, self.max_points
+        P = int(npl[0])
         n = np.zeros(1, np.int32); coef = np.zeros((1, PS, 4), np.float32); src = np.zeros((1, PS), np.int32); off = np.zeros((1, PS + 1), np.int32)
         pts = np.zeros((1, MP, 3), np.float32)
-        res = dict(n=0, coef=[], src=[], pt_off=[0], points=[], dropped=[])
+        state = np.zeros((1, PS), np.int32); nvox = np.zeros((1, PS), np.int32); info = np.zeros((1, PS, 12), np.int32); st1 = np.zeros(1, np.int32)
+        res = dict(n=0, coef=[], src=[], pt_off=[0], points=[], dropped=[], state=np.full(P, -2, np.int32), nvox=np.zeros(P, np.int32), info=[None] * P)
         try:
-            for i in range(int(npl[0])):
+            for i in range(P):
                 check(self.L.planar_plane_clouds_set_plane_window(self.h, i, 1))
                 rc = self.L.planar_plane_clouds_compute(self.h, d.ctypes.data, 1, W, W * H, K[0], K[1], K[2], K[3], np.float32(depth_factor), lab.ctypes.data, pl.ctypes.data,
                                                         npl.ctypes.data, float(dist_th), np.float32(leaf), n.ctypes.data, coef.ctypes.data, src.ctypes.data, off.ctypes.data,
-                                                        pts.ctypes.data, None, None, None)
+                                                        pts.ctypes.data, state.ctypes.data if debug else None, nvox.ctypes.data if debug else None,
+                                                        info.ctypes.data if debug else None)
                 try:
                     check(rc)
                 except PlanarError as e:
-                    if not (e.code == -4 and "(code 3" in str(e)):
+                    if e.code != -4:
+                        raise
+                    check(self.L.planar_plane_clouds_last_status(self.h, 1, st1.ctypes.data))
+                    if st1[0] != 3:
                         raise
                     res["dropped"].append(i); continue
+                if debug:
+                    res["state"][i] = state[0, i]; res["nvox"][i] = nvox[0, i]; res["info"][i] = _refit_info(info[0, i])
                 if int(n[0]) == 1:
                     res["n"] += 1; res["coef"].append(coef[0, 0].copy()); res["src"].append(i); res["points"].append(pts[0, :off[0, 1]].copy())
                     res["pt_off"].append(res["pt_off"][-1] + int(off[0, 1]))
         finally:
             check(self.L.planar_plane_clouds_set_plane_window(self.h, 0, -1))
         k = res["n"]
-        return dict(n=k, coef=np.array(res["coef"], np.float32).reshape(k, 4), src=np.array(res["src"], np.int32), pt_off=np.array(res["pt_off"], np.int32),
-                    points=np.concatenate(res["points"] + [np.zeros((0, 3), np.float32)]), dropped=res["dropped"])
+        r = dict(n=k, coef=np.array(res["coef"], np.float32).reshape(k, 4), src=np.array(res["src"], np.int32), pt_off=np.array(res["pt_off"], np.int32),
+                 points=np.concatenate(res["points"] + [np.zeros((0, 3), np.float32)]), dropped=res["dropped"])
+        if debug:
+            r.update(state=res["state"], nvox=res["nvox"], info=res["info"])
+        return r
 
     def compute_dev(self, d_depth, d_labels, d_planes, d_n_planes, B, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, dist_th=0.05, leaf=0.1,
                     K=(535.4, 539.2, 320.1, 247.6), depth_factor=1.0 / 5000.0):

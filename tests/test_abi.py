@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "planar_abi.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef PLANAR_TEST_HOOKS.*?#endif", "", src, flags=re.S)      # hooks only the test build (libplanar_hip_paranoid.so) exports
     return sorted(set(re.findall(r"\b(planar_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -80,3 +81,10 @@ def test_argument_errors_are_reported_without_touching_a_device():
         rc = c()
         assert rc == EINVAL, (i, rc)
         assert len(L.planar_last_error()) > 0
+
+
+def test_product_library_carries_no_test_hooks():
+    """planar_debug_* entry points live in the test build only (make paranoid, -DPLANAR_TEST_HOOKS)"""
+    from planarslam_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    assert not any(hasattr(L, s) for s in _lib.TEST_HOOKS)

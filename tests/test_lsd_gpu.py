@@ -18,20 +18,38 @@ def ctx():
     return Context(0)
 
 
-def test_device_std_sort_matches_libstdcxx(ctx):
-    import ctypes as C
-    from planarslam_amd._lib import check, lib
+def test_device_std_sort_matches_libstdcxx():
+    """lsd_keylines' device emulation of libstdc++ std::sort(greater-by-response) on raw keys, through the hook only the TEST build of the library exports
+    (libplanar_hip_paranoid.so, `make paranoid`: -DPLANAR_TEST_HOOKS); run in a child process so that this process keeps the product library."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_path = os.path.join(root, "planarslam_amd", "libplanar_hip_paranoid.so")
+    if not os.path.exists(lib_path):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "planarslam_amd", "csrc"), "paranoid"])
     rng = np.random.default_rng(5)
     cases = [rng.random(n).astype(np.float32) for n in (0, 1, 2, 16, 17, 41, 172, 600, 2048)]
     cases += [rng.integers(0, 4, 500).astype(np.float32), rng.integers(0, 30, 2048).astype(np.float32), np.zeros(300, np.float32),
               np.arange(700, dtype=np.float32), np.arange(700, dtype=np.float32)[::-1].copy(),
               np.concatenate([np.arange(350), np.arange(350)[::-1]]).astype(np.float32)]
-    for keys in cases:
-        rk, rp = O.std_sort_desc(keys)
-        k = keys.copy(); perm = np.zeros(len(k), np.int32)
-        check(lib().planar_debug_std_sort_desc(ctx.h, k.ctypes.data, perm.ctypes.data, len(k)))
-        np.testing.assert_array_equal(k, rk)
-        np.testing.assert_array_equal(perm, rp)
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), *cases)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+                "from planarslam_amd._lib import Context, check, lib\n"
+                "ctx = Context(0); z = np.load(%r); out = {}\n"
+                "for name in z.files:\n"
+                "    k = z[name].copy(); perm = np.zeros(len(k), np.int32)\n"
+                "    check(lib().planar_debug_std_sort_desc(ctx.h, k.ctypes.data, perm.ctypes.data, len(k)))\n"
+                "    out['k_' + name] = k; out['p_' + name] = perm\n"
+                "np.savez(%r, **out)\n") % (root, os.path.join(td, "in.npz"), os.path.join(td, "out.npz"))
+        subprocess.check_call([sys.executable, "-W", "ignore", "-c", code], env=dict(os.environ, PLANAR_HIP_LIB=lib_path))
+        z = np.load(os.path.join(td, "out.npz"))
+        for i, keys in enumerate(cases):
+            rk, rp = O.std_sort_desc(keys)
+            np.testing.assert_array_equal(z[f"k_arr_{i}"], rk)
+            np.testing.assert_array_equal(z[f"p_arr_{i}"], rp)
 
 
 @pytest.mark.parametrize("tie", [0, 1])

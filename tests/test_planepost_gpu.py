@@ -266,4 +266,10 @@ def test_frame_with_more_voxels_than_the_table_goes_plane_by_plane():
     pl2 = np.zeros((1, pcz.pl_stride, 8)); pl2[0, :len(p2)] = p2
     g2 = pcz.compute(d2[None], l2[None], pl2, np.array([len(p2)], np.int32))[0]
     w2 = ol.plane_clouds(d2, l2, p2)
-    assert "dropped" not in g2 and g2["n"] == w2["n"] and np.array_equal(g2["points"], w2["points"])
+    assert g2["dropped"] == [] and g2["n"] == w2["n"] and np.array_equal(g2["points"], w2["points"])
+    # a batch with ONE overflowing frame: only that frame is redone plane by plane (per-frame codes: planar_plane_clouds_last_status), both results carry the same keys
+    pcz2 = PlaneClouds(640, 480, max_batch=2, max_points=pcz.max_points)
+    plb = np.zeros((2, pcz2.pl_stride, 8)); plb[0] = pl[0]; plb[1] = pl2[0]
+    both = pcz2.compute(np.stack([d, d2]), np.stack([labels, l2]), plb, np.array([len(planes), len(p2)], np.int32), debug=True)
+    assert set(both[0]) == set(both[1]) and both[0]["n"] == want["n"] and np.array_equal(both[0]["points"], want["points"])
+    assert both[1]["n"] == w2["n"] and np.array_equal(both[1]["points"], w2["points"]) and both[1]["dropped"] == []

@@ -6,13 +6,13 @@
 # On a box whose image is still paging in, the first `import torch` alone takes 1-2 minutes: every mode starts with an untimed-in-spirit warm-up import (own timeout), so
 # that the per-command timeouts below measure the commands and not the cold start (twice this round a call on a cold box ran into every timeout with no output).
 # Give the bench mode `gpurun --timeout 600`.
-tag=${1:-r05}; what=${2:-bench}
+tag=${1:-r06}; what=${2:-bench}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 240 python -c "import torch, numpy; print('warm', torch.cuda.is_available())" > $O/${tag}_warmup.log 2>&1
 FL="--steps 6 --warmup 3 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 --sub-steps 0"
 # counter passes: the textures are synthesised in-process (--gen-procs 1, 16 rooms, 4-frame loops): rocprofv3 --pmc hangs when the profiled process forks workers (profiles/README.md)
-PF="--gen-procs 1 --canvases 16 --loop 4 --batch 1024 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 --sub-steps 0"   # B = 1024 as in every earlier round's counter files (bench.py scales traffic to its own batch)
+PF="--gen-procs 1 --canvases 16 --loop 4 --batch 1024 --seq-cus 0 --steps 3 --warmup 1 --cpu-seconds 0 --latency-reps 0 --pcie-steps 0 --sub-steps 0"   # B = 1024 as in every earlier round's counter files (bench.py scales traffic to its own batch)
 if [ $what = bench ]; then
     timeout 400 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err          # (configs[1] / [3] / [4] ride in its sub_benchmarks since round 5)
     cd /tmp && export TMPDIR=/tmp

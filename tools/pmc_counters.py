@@ -5,7 +5,12 @@
 
 Sums a counter over the rows of one dispatch (rocprofv3 writes one row per counter instance / dimension), averages over the dispatches of a kernel without
 its first one, and adds two ratios when their inputs are present: wait = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (share of its resident time a wavefront waits for
-an instruction to complete) and active = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES."""
+an instruction to complete) and active = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES.
+
+Round 6: the passes' kernel traces (rocprofv3 writes *kernel_trace.csv next to the counters; under --pmc every dispatch runs alone) give each kernel's average duration,
+and with it issue_frac = (4 * SQ_INSTS_VALU + SQ_INSTS_SALU) / (duration * 1024 SIMDs * 2.4 GHz): the share of the device's instruction-issue cycles the launch used
+(a wave64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles, a scalar one for 1) - the lens that fits a path without a dense contraction and with
+L2-resident working sets, where the HBM fraction says little."""
 import csv
 import glob
 import os
@@ -22,12 +27,20 @@ def main():
                 key = (f, int(row["Dispatch_Id"]))
                 vals[key][row["Counter_Name"]] += float(row["Counter_Value"])
                 name[key] = row["Kernel_Name"].split("(")[0]
+    dur = defaultdict(list)                              # kernel -> durations (ns) of its dispatches in the passes' kernel traces
+    for d in sys.argv[1:]:
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                try:
+                    dur[row["Kernel_Name"].split("(")[0]].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+                except (KeyError, ValueError):
+                    pass
     per = defaultdict(lambda: defaultdict(list))
     for key in sorted(vals):
         for c, v in vals[key].items():
             per[name[key]][c].append(v)
     counters = sorted({c for k in per for c in per[k]})
-    print(",".join(["kernel", "launches_seen"] + counters + ["wait", "active"]))
+    print(",".join(["kernel", "launches_seen"] + counters + ["wait", "active", "avg_duration_us", "issue_frac"]))
     rows = []
     for k, cs in per.items():
         if not k.startswith(("planar::", "void planar::")):
@@ -37,7 +50,11 @@ def main():
         wc = avg.get("SQ_WAVE_CYCLES", 0.0)
         wait = avg["SQ_WAIT_INST_ANY"] / wc if wc and "SQ_WAIT_INST_ANY" in avg else float("nan")
         act = avg["SQ_ACTIVE_INST_ANY"] / wc if wc and "SQ_ACTIVE_INST_ANY" in avg else float("nan")
-        rows.append((avg.get("SQ_WAVE_CYCLES", 0.0), ",".join([k, str(n)] + [f"{avg.get(c, float('nan')):.0f}" for c in counters] + [f"{wait:.3f}", f"{act:.3f}"])))
+        dd = dur.get(k, [])
+        dd = dd[len(dd) // 8:] if len(dd) > 8 else dd     # (the first dispatches of a run include cold caches)
+        d_ns = sum(dd) / len(dd) if dd else float("nan")
+        issue = (4.0 * avg.get("SQ_INSTS_VALU", float("nan")) + avg.get("SQ_INSTS_SALU", float("nan"))) / (d_ns * 1e-9 * 1024 * 2.4e9) if dd else float("nan")
+        rows.append((avg.get("SQ_WAVE_CYCLES", 0.0), ",".join([k, str(n)] + [f"{avg.get(c, float('nan')):.0f}" for c in counters] + [f"{wait:.3f}", f"{act:.3f}", f"{d_ns / 1e3:.1f}", f"{issue:.4f}"])))
     for _, r in sorted(rows, reverse=True):
         print(r)
 
