@@ -465,7 +465,7 @@ def main():
     # HBM-side traffic of that kernel from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this command, KB per launch;
     # raw counter sums); a kernel without a row is reported as null with the reason, never as zero
     traffic = None
-    pmc_csv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_fetch_write_kb_per_launch.csv") for r in (5, 4, 3, 2)) if os.path.exists(q)), "")
+    pmc_csv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_fetch_write_kb_per_launch.csv") for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), "")
     traffic_note = "null: no profiles/r0N_pmc_fetch_write_kb_per_launch.csv (tools/pmc_counters.py) found"
     if os.path.exists(pmc_csv):
         f_tot = w_tot = 0.0
@@ -480,14 +480,43 @@ def main():
         else:
             traffic_note = f"null: {os.path.relpath(pmc_csv, ROOT)} has no row for {per[dom]['rocprof_name']} (re-collect with tools/collect_profiles.sh)"
             print(f"bench.py: WARNING: roofline.traffic not reported: {traffic_note}", file=sys.stderr)
+    # the lens that fits this path (no dense contraction, L2-resident working sets): instruction issue.  issue_frac = (4 x VALU + SALU wavefront-instructions) / (launch
+    # duration x 1024 SIMDs x 2.4 GHz), active / wait = share of the wavefronts' resident time with an instruction in flight / waiting for one; from the committed SQ
+    # counter passes (tools/pmc_counters.py: B = 1024, every launch alone on the device, no CU partition), like `traffic`
+    issue = None
+    sq_csv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_sq_per_launch.csv") for r in (6, 5)) if os.path.exists(q)), "")
+    if os.path.exists(sq_csv):
+        import csv as _csv
+        rows = list(_csv.DictReader(open(sq_csv)))
+        def _issue(rn):
+            for r_ in rows:
+                if r_["kernel"].replace("void ", "").startswith(rn) and r_.get("issue_frac") not in (None, "", "nan"):
+                    return {"issue_frac": float(r_["issue_frac"]), "active": float(r_["active"]), "wait": float(r_["wait"]), "valu_winst_per_launch": int(float(r_["SQ_INSTS_VALU"])),
+                            "salu_winst_per_launch": int(float(r_["SQ_INSTS_SALU"])), "alone_us_per_launch_b1024": float(r_["avg_duration_us"])}
+            return None
+        issue = _issue(per[dom]["rocprof_name"])
+        if issue:
+            issue["source"] = os.path.relpath(sq_csv, ROOT)
+            issue["note"] = ("NOT measured in this run: committed rocprofv3 --pmc passes (SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAVE_CYCLES / SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY, "
+                             "launches of 1024 frames alone on the device); issue_frac = (4 VALU + SALU) / (duration x 1024 SIMDs x 2.4 GHz)")
+        for k_, v_ in per.items():
+            q_ = _issue(v_["rocprof_name"])
+            if q_: v_["issue_frac"] = q_["issue_frac"]; v_["active"] = q_["active"]
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "traffic_source": os.path.relpath(pmc_csv, ROOT) if traffic is not None else None, "traffic_note": traffic_note,
+                "issue": issue,
                 "avg_launch_ms": round(dom_ms, 4), "alone_ms": per[dom]["alone_ms"], "frac_alone": per[dom].get("frac_alone"), "algorithmic_bytes_per_launch": int(dom_bytes),
                 "pipeline_algorithmic_GBps": round(per_frame * fps / 1e9, 2), "algorithmic_bytes_per_frame_of_the_step": int(per_frame),
                 "note": ("one kernel (the one with the most device time per step), not a stage: avg_launch_ms = HIP events right before / after each of its launches on its own stream "
                          "inside the timed region (co-run with the other streams; rocprofv3's AverageNs of the same command), alone_ms = the same launch alone on the device "
                          "(rocprofv3's Min).  peac_ahc3 / lsd_detect: one sequential wavefront per frame, latency-bound (DESIGN.md §4)"),
                 "per_kernel": per, "stages": kernels}
+    if full and args.seq_cus and (args.seq_which & 1) and dom == "peac_ahc3":
+        roofline["cu_partition"] = {"kernel_confined_to_cus": args.seq_cus, "of": 256,
+                                    "note": ("this kernel runs on a CU-masked side stream (planar_ctx_set_seq_stream): its launches take 256 / %d times longer than on the whole device - by "
+                                             "design, the other CUs run the wide kernels meanwhile - so `frac` (bytes / duration / 8 TB/s of the WHOLE device) is that much lower than "
+                                             "with --seq-cus 0; alone_ms is measured on the same mask") % args.seq_cus,
+                                    "frac_relative_to_its_share_of_hbm": round(achieved / HBM_PEAK_GBS * 256.0 / args.seq_cus, 6)}
     if full:
         roofline["per_kernel_note"] = ("co-run >> alone for the wide kernels: up to depth + 2 steps are in flight and every kernel waits for CUs behind the other streams' launches; "
                                        "the single-wavefront kernels of the two side chains stretch when other wavefronts share their SIMDs (tools/corun_probe.py; DESIGN.md)")

@@ -360,8 +360,9 @@ __device__ __forceinline__ Lists carve_lists(uint8_t* p, int cap) {
 }
 
 #ifdef ISORT_TIMING
-#define ISORT_MARK(k) do { const long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) g_isort_t[k] += _t - _tm; _tm = _t; } while (0)
-__device__ long long g_isort_t[16];
+#define ISORT_MARK(k) do { const long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) g_isort_t[(blockIdx.x % ISORT_TBLK) * 16 + (k)] += _t - _tm; _tm = _t; } while (0)
+constexpr int ISORT_TBLK = 8192;                    // a row of 16 buckets per block (thread 0 adds, nobody else touches the row): the host sums the rows
+__device__ long long g_isort_t[ISORT_TBLK * 16];
 #else
 #define ISORT_MARK(k) do { } while (0)
 #endif

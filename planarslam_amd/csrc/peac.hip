@@ -576,6 +576,12 @@ __device__ __forceinline__ void refine_frame(const Layout& L, const Intr& K, con
                 int total = 0;
 #pragma unroll
                 for (int dir = 0; dir < 4; dir++) {
+                    // INVARIANT behind `m0 != plid` (the reference's `continue` before any geometry, AHCPlaneFitter.hpp:441-447): inside a black block (or outside the block
+                    // grid) a membership >= 0 is only ever written by a fold of this flood fill, i.e. the pixel passed plane m0's geometric test when it became a member,
+                    // and it was pushed then.  A later pair of the SAME plane can neither change the byte nor the distance (same plane, same point: same distance) nor push
+                    // again; what it can still do is connect() its plane with a new owner when the pixel changes hands within the step - the case phase B replays
+                    // (extra_connects, when a pixel takes two claims in one step).  The -DPLANAR_REFINE_PARANOID build (tests/test_peac_gpu.py) drops this filter's
+                    // consequences: every pixel through the generic fold, every changed pixel replayed; its labels must equal the product's.
                     act[dir] = act[dir] && m0[dir] > -6 && m0[dir] != plid;       // a dead trail stays dead; the pair's own plane: nothing to do (see B)
                     nm[dir] = __ballot(act[dir]);
                     total += __popcll(nm[dir]);

@@ -115,6 +115,18 @@ def test_refinement_rare_paths_give_the_same_labels():
     assert np.array_equal(z["n"], [len(x[0]) for x in res])
     assert np.array_equal(z["labels"], np.stack([x[1] for x in res]))
     assert np.array_equal(z["planes"], np.concatenate([x[0] for x in res]))
+    # frames whose sides are not multiples of the 10-pixel block (pixels outside the block grid take part in the fill): the two builds agree there too
+    odd = np.stack([depth_image(900 + i, 325, 247, noise=(i % 2 == 0), holes=True) for i in range(3)])
+    res_odd = PlaneDetection(325, 247, max_batch=3).run(odd)
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "d.npy"), odd)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+                "from planarslam_amd import PlaneDetection\n"
+                "d = np.load(%r)\n"
+                "r = PlaneDetection(325, 247, max_batch=len(d)).run(d)\n"
+                "np.savez(%r, labels=np.stack([x[1] for x in r]))\n") % (root, os.path.join(td, "d.npy"), os.path.join(td, "o.npz"))
+        subprocess.check_call([sys.executable, "-W", "ignore", "-c", code], env=dict(os.environ, PLANAR_HIP_LIB=lib))
+        assert np.array_equal(np.load(os.path.join(td, "o.npz"))["labels"], np.stack([x[1] for x in res_odd]))
     for b in (len(GOLD) + 4, len(depths) - 1):                       # (and the product's are the oracle's on the SE3 frames too)
         op, olab = ol.peac_run(depths[b])
         assert np.array_equal(res[b][1], olab) and np.array_equal(res[b][0], op)

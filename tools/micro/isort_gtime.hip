@@ -19,7 +19,7 @@ __global__ __launch_bounds__(T) void k(uint32_t* arr, int n, int rows_cap, Range
     __syncthreads();
     const long long t0 = __builtin_readcyclecounter();
     global_tier<SHIFT, T>(arr + (size_t)blockIdx.x * n, &s_init, 1, NSTAGE, 64, ranges + (size_t)blockIdx.x * G_FMAX, blocks + (size_t)blockIdx.x * G_FMAX, G_FMAX, counts + 2 * blockIdx.x, lds, rows_cap, HS, status);
-    if (threadIdx.x == 0) atomicAdd((unsigned long long*)&g_isort_t[15], (unsigned long long)(__builtin_readcyclecounter() - t0));
+    if (threadIdx.x == 0) g_isort_t[(blockIdx.x % ISORT_TBLK) * 16 + 15] += __builtin_readcyclecounter() - t0;
 }
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 195000, NB = argc > 2 ? atoi(argv[2]) : 256, mode = argc > 3 ? atoi(argv[3]) : 0;
@@ -38,14 +38,16 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     for (int rep = 0; rep < 2; rep++) {
         hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-        long long z[16] = {0};
-        hipMemcpyToSymbol(HIP_SYMBOL(g_isort_t), z, sizeof(z));
+        static long long zz[ISORT_TBLK * 16]; long long z[16] = {0};
+        for (auto& q : zz) q = 0;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_isort_t), zz, sizeof(zz));
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
         hipLaunchKernelGGL(k, dim3(NB), dim3(T), smem, 0, d, n, rows_cap, dr, db, dc, ds);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        hipMemcpyFromSymbol(z, HIP_SYMBOL(g_isort_t), sizeof(z));
+        hipMemcpyFromSymbol(zz, HIP_SYMBOL(g_isort_t), sizeof(zz));
+        for (int b = 0; b < ISORT_TBLK; b++) for (int k = 0; k < 16; k++) z[k] += zz[b * 16 + k];
         std::vector<int> c(2 * NB); hipMemcpy(c.data(), dc, 8 * NB, hipMemcpyDeviceToHost);
         int st; hipMemcpy(&st, ds, 4, hipMemcpyDeviceToHost);
         printf("n %d blocks %d mode %d lds %d B: %.3f ms | thread-0 cycles summed over blocks: pivot %lld | pass1 ballots %lld | rank prefix %lld | x* %lld | swaps %lld | whole tier %lld | ranges %d blocks %d status %d\n",

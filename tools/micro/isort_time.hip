@@ -35,14 +35,16 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LdsLayout<T, E>::bytes);
     for (int rep = 0; rep < 3; rep++) {
         hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-        long long z[16] = {0};
-        hipMemcpyToSymbol(HIP_SYMBOL(g_isort_t), z, sizeof(z));
+        static long long zz[ISORT_TBLK * 16]; long long z[16] = {0};
+        for (auto& q : zz) q = 0;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_isort_t), zz, sizeof(zz));
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
         const int smem = LdsLayout<T, E>::bytes; hipLaunchKernelGGL(k, dim3(NB), dim3(T), smem, 0, d, dr, (int)hr.size(), n, ds);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        hipMemcpyFromSymbol(z, HIP_SYMBOL(g_isort_t), sizeof(z));
+        hipMemcpyFromSymbol(zz, HIP_SYMBOL(g_isort_t), sizeof(zz));
+        for (int b = 0; b < ISORT_TBLK; b++) for (int k = 0; k < 16; k++) z[k] += zz[b * 16 + k];
         printf("n %d keys %d blocks %d: %.3f ms | cycles (all blocks, thread 0): stage-in+init %lld | A medians %lld | B flags %lld | scans %lld | D1 %lld | D2 %lld | E swaps %lld | F list %lld | tasks %lld | write-back %lld\n", n, nkeys, NB, ms,
                z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7], z[8], z[9]);
     }
