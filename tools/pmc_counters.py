@@ -20,19 +20,36 @@ from collections import defaultdict
 
 def main():
     vals = defaultdict(lambda: defaultdict(float))      # (file, dispatch) -> counter -> sum
-    name = {}
+    name, grid = {}, {}
     for d in sys.argv[1:]:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 key = (f, int(row["Dispatch_Id"]))
                 vals[key][row["Counter_Name"]] += float(row["Counter_Value"])
                 name[key] = row["Kernel_Name"].split("(")[0]
+                try:
+                    grid[key] = int(float(row.get("Grid_Size", 0) or 0))
+                except ValueError:
+                    grid[key] = 0
+    # only the launches of the bench's own batch: the run also launches the extractors on 256-frame chunks (the map stand-ins, track.build_map) - smaller grids
+    gmax = defaultdict(int)
+    for key, g in grid.items():
+        gmax[name[key]] = max(gmax[name[key]], g)
+    for key in [k for k in vals if grid.get(k, 0) < gmax[name[k]]]:
+        del vals[key]
     dur = defaultdict(list)                              # kernel -> durations (ns) of its dispatches in the passes' kernel traces
     for d in sys.argv[1:]:
         for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-            for row in csv.DictReader(open(f)):
+            rows_t = list(csv.DictReader(open(f)))
+            gsz = lambda r: int(float(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)) * max(1, int(float(r.get("Grid_Size_Y", 1) or 1))) * max(1, int(float(r.get("Grid_Size_Z", 1) or 1)))
+            gm = defaultdict(int)
+            for row in rows_t:
+                gm[row["Kernel_Name"].split("(")[0]] = max(gm[row["Kernel_Name"].split("(")[0]], gsz(row))
+            for row in rows_t:
                 try:
-                    dur[row["Kernel_Name"].split("(")[0]].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+                    k_ = row["Kernel_Name"].split("(")[0]
+                    if gsz(row) == gm[k_]:
+                        dur[k_].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
                 except (KeyError, ValueError):
                     pass
     per = defaultdict(lambda: defaultdict(list))
@@ -51,7 +68,7 @@ def main():
         wait = avg["SQ_WAIT_INST_ANY"] / wc if wc and "SQ_WAIT_INST_ANY" in avg else float("nan")
         act = avg["SQ_ACTIVE_INST_ANY"] / wc if wc and "SQ_ACTIVE_INST_ANY" in avg else float("nan")
         dd = dur.get(k, [])
-        dd = dd[len(dd) // 8:] if len(dd) > 8 else dd     # (the first dispatches of a run include cold caches)
+        dd = dd[1:] if len(dd) > 2 else dd                 # (the first full-batch dispatch of a run includes cold caches)
         d_ns = sum(dd) / len(dd) if dd else float("nan")
         issue = (4.0 * avg.get("SQ_INSTS_VALU", float("nan")) + avg.get("SQ_INSTS_SALU", float("nan"))) / (d_ns * 1e-9 * 1024 * 2.4e9) if dd else float("nan")
         rows.append((avg.get("SQ_WAVE_CYCLES", 0.0), ",".join([k, str(n)] + [f"{avg.get(c, float('nan')):.0f}" for c in counters] + [f"{wait:.3f}", f"{act:.3f}", f"{d_ns / 1e3:.1f}", f"{issue:.4f}"])))

@@ -17,7 +17,7 @@ def per_kernel(d, counter):
     if not files:
         raise SystemExit(f"no counter_collection.csv under {d}")
     disp = defaultdict(float)
-    name = {}
+    name, grid = {}, {}
     for f in files:
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
@@ -25,6 +25,16 @@ def per_kernel(d, counter):
             key = (f, row["Dispatch_Id"])
             disp[key] += float(row["Counter_Value"])
             name[key] = row["Kernel_Name"].split("(")[0]
+            try:
+                grid[key] = int(float(row.get("Grid_Size", 0) or 0))
+            except ValueError:
+                grid[key] = 0
+    # (round 6) only the launches of the bench's own batch: the run also launches the extractors on 256-frame chunks (track.build_map) - smaller grids
+    gmax = defaultdict(int)
+    for key, g in grid.items():
+        gmax[name[key]] = max(gmax[name[key]], g)
+    for key in [k for k in disp if grid.get(k, 0) < gmax[name[k]]]:
+        del disp[key]
     by = defaultdict(list)
     for key in sorted(disp, key=lambda k: (k[0], int(k[1]))):
         by[name[key]].append(disp[key])
