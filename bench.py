@@ -741,6 +741,8 @@ def main():
     }
     if quality:
         out["config"].update(quality)
+    if full:
+        tp.close()
     print(json.dumps(out))
     ranks.close()
 

@@ -5,13 +5,17 @@
 // KeyFrame / MapPoint / MapLine / MapPlane objects arrives as plain arrays (planar_ba_problem).
 //
 //   ba_errors    thread = edge        FP64 residuals of the active edges (stored, like g2o's _error) + robust chi2
-//   ba_linearize thread = edge        Jacobians (analytic point/line, numeric plane), the edge's coupling block W = B^T (w Omega) A (6x3) and
-//                                     its landmark-block contribution; pose blocks Hpp / bp are summed in LDS per workgroup, then flushed
+//   ba_numjac    thread = (numeric edge, column)   g2o's central differences for the plane / parallel / vertical edges, one column (two error evaluations) per thread
+//   ba_linearize thread = edge        Jacobians (analytic point/line; the numeric ones from ba_numjac), the edge's coupling block W = B^T (w Omega) A (6x3) and
+//                                     its landmark-block contribution; pose blocks Hpp / bp (lower triangle) are summed in LDS per workgroup, then flushed
 //                                     with FP64 atomics
 //   ba_gather    thread = landmark    Hll (3x3), bl = sum of its edges' contributions in edge order
-//   ba_dinv      thread = landmark    Dinv = (Hll + lambda I)^-1, Dinv bl
-//   ba_schur     thread = edge        S[p(e)][q(f)] -= W_e Dinv W_f^T over the edges f of e's landmark, b -= W_e Dinv bl, accumulated in an
-//                                     LDS copy of the reduced system (<= 120 x 120 doubles) per workgroup, then flushed
+//   ba_dinv      thread = landmark    Dinv = (Hll + lambda I)^-1, Dinv bl; also prepares the trial's exchange buffers (redg <- red, red2 <- 0, trial <- 0)
+//   ba_schur     thread = (edge, 1/4 of its partner edges)   S[p(e)][q(f)] -= W_e Dinv W_f^T over the edges f of e's landmark, b -= W_e Dinv bl, accumulated in an
+//                                     LDS copy of the reduced system (<= 120 x 120 doubles) per workgroup, then flushed (lower triangle)
+// Round 6 (a solve of BASELINE configs[4]: 5.5 -> 3.7 ms): every launch of this chain ends with its slowest THREAD - the ~400 numeric-Jacobian edges (18 error evaluations
+// in one thread: ba_linearize 68 -> 15 + 22 us) and the edges of plane vertices (~30 partner edges against a point's ~5: ba_schur 62 -> 37 us) -, ba_solve was 378 workgroup
+// barriers (blocked by key frame: 90 -> 60 us), and three copies / memsets and ba_begin were launches of their own.
 //   [exchange]   RCCL all-reduce (sum) of the reduced camera system: landmarks (and all their edges) are partitioned
 //                across GPUs, every GPU then solves the same 6K x 6K system redundantly (29 KB payload)
 //   ba_solve     one workgroup        dense Cholesky of the reduced system in LDS, pose increments
@@ -62,6 +66,10 @@ struct Dev {
     uint8_t* e_out;                          // final "to erase" flag
     double* Hll; double* bl; double* Dinv; double* W; double* xl;   // [L][9] [L][3] [L][9] [E][18] [L][3] (xl: Dinv * bl)
     double* He;                              // [E][12]: the edge's A^T w Omega A (9) and -A^T w Omega e (3)
+    const int* e_numslot;                    // [E] slot of a numeric-Jacobian edge (plane / parallel / vertical) in J, -1 for the analytic ones
+    const int* num_idx;                      // [n_num] their edge indices
+    double* J;                               // [n_num][9][3]: columns 0..2 = d error / d landmark, 3..8 = d error / d pose (ba_numjac)
+    int n_num;
     double* red;                             // this rank's [np*36 Hpp | 6np bp | chi | pad], rebuilt at the start of an LM iteration
     double* redg;                            // exchange buffer A, first part: the same layout, summed over ranks
     double* red2;                            // exchange buffer A, second part (contiguous with redg): [NP*NP Schur terms | NP rhs terms]
@@ -167,11 +175,33 @@ __global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_o
     if (threadIdx.x == 0 && tot != 0) atomicAdd(chi_out, tot);
 }
 
-// opens an LM iteration: clears this rank's partial sums
-__global__ __launch_bounds__(NT) void ba_begin(Dev D, int nred) {
+// thread = (numeric-Jacobian edge, column): one column of g2o's central differences (base_binary_edge.hpp:131-198), two error evaluations.  Round 6: ba_linearize did all
+// 18 evaluations of such an edge in ONE thread, and the launch ended with those threads (68 us for 19 573 edges of which ~400 are numeric); same arithmetic per column.
+__global__ __launch_bounds__(NT) void ba_numjac(Dev D) {
     if (D.st->done || !D.st->need_build) return;
-    for (int i = blockIdx.x * NT + threadIdx.x; i < nred; i += gridDim.x * NT) D.red[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) D.scal[0] = 0;
+    const int gid = blockIdx.x * NT + threadIdx.x, slot = gid / 9, d = gid - slot * 9;
+    if (slot >= D.n_num) return;
+    const int e = D.num_idx[slot];
+    if (D.e_level[e] != 0) return;
+    const int l = edge_landmark(D, e);
+    const LmV Lm = load_lm(D, D.lm, l);
+    const int type = D.e_type[e], dim = edge_dim(type), kf = D.e_kf[e], p = D.pidx[kf];
+    const SE3 T = load_T(D.T, kf);
+    const double* meas = D.e_meas + (size_t)e * 4;
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    double e1[3] = {0, 0, 0}, e2[3] = {0, 0, 0};
+    if (d < 3) {
+        double add[3] = {0, 0, 0};
+        add[d] = delta; LmV Lp = Lm; lm_oplus(Lp, add); edge_error(D, type, T, Lp, meas, e1);
+        add[d] = -delta; LmV Lq = Lm; lm_oplus(Lq, add); edge_error(D, type, T, Lq, meas, e2);
+    } else if (p >= 0) {
+        double add[6] = {0, 0, 0, 0, 0, 0};
+        add[d - 3] = delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e1);
+        add[d - 3] = -delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e2);
+    }
+    double* o = D.J + ((size_t)slot * 9 + d) * 3;
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = i < dim ? scalar * (e1[i] - e2[i]) : 0.0;
 }
 
 // thread = EDGE: Jacobians, the edge's coupling block W = B^T (w Omega) A, its contribution to the landmark block (A^T w Omega A, -A^T w Omega e) and,
@@ -227,23 +257,15 @@ __global__ __launch_bounds__(NT) void ba_linearize(Dev D, int robust) {
                         B[2][0] = B[0][0] - c.bf * y / z_2; B[2][1] = B[0][1] + c.bf * x / z_2; B[2][2] = B[0][2]; B[2][3] = B[0][3]; B[2][5] = B[0][5] - c.bf / z_2;
                     }
                 }
-            } else {                             // numeric, both vertices (base_binary_edge.hpp:131-198)
-                const double delta = 1e-9, scalar = 1.0 / (2 * delta);
-                for (int d = 0; d < 3; d++) {
-                    double add[3] = {0, 0, 0}, e1[3], e2[3];
-                    add[d] = delta; LmV Lp = Lm; lm_oplus(Lp, add); edge_error(D, type, T, Lp, meas, e1);
-                    add[d] = -delta; LmV Lq = Lm; lm_oplus(Lq, add); edge_error(D, type, T, Lq, meas, e2);
+            } else {                             // numeric, both vertices (base_binary_edge.hpp:131-198): the columns ba_numjac left
+                const double* Jc = D.J + (size_t)D.e_numslot[e] * 27;
+                for (int d = 0; d < 3; d++)
 #pragma unroll
-                    for (int i = 0; i < 3; i++) if (i < dim) A[i][d] = scalar * (e1[i] - e2[i]);
-                }
+                    for (int i = 0; i < 3; i++) if (i < dim) A[i][d] = Jc[d * 3 + i];
                 if (p >= 0) {
-                    for (int d = 0; d < 6; d++) {
-                        double add[6] = {0, 0, 0, 0, 0, 0}, e1[3], e2[3];
-                        add[d] = delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e1);
-                        add[d] = -delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e2);
+                    for (int d = 0; d < 6; d++)
 #pragma unroll
-                        for (int i = 0; i < 3; i++) if (i < dim) B[i][d] = scalar * (e1[i] - e2[i]);
-                    }
+                        for (int i = 0; i < 3; i++) if (i < dim) B[i][d] = Jc[(3 + d) * 3 + i];
                 }
             }
             double w = 1;
@@ -259,7 +281,7 @@ __global__ __launch_bounds__(NT) void ba_linearize(Dev D, int robust) {
                 if (p >= 0) {
                     for (int a = 0; a < 6; a++) {
                         atomicAdd(&s_pp[p * 42 + 36 + a], B[i][a] * r);
-                        for (int cc = 0; cc < 6; cc++) atomicAdd(&s_pp[p * 42 + a * 6 + cc], B[i][a] * wo * B[i][cc]);
+                        for (int cc = 0; cc <= a; cc++) atomicAdd(&s_pp[p * 42 + a * 6 + cc], B[i][a] * wo * B[i][cc]);      // the lower triangle: all the solver reads (21 LDS atomics per row of the error instead of 36)
                         for (int cc = 0; cc < 3; cc++) Wb[a * 3 + cc] += B[i][a] * wo * A[i][cc];
                     }
                 }
@@ -310,10 +332,14 @@ __device__ __forceinline__ void inv3(const double* H, double lambda, double Di[9
 }
 
 // thread = landmark: Dinv = (Hll + lambda I)^-1 and Dinv * bl
-__global__ __launch_bounds__(NT) void ba_dinv(Dev D) {
+// ... and the trial's exchange buffers (round 6: a device-to-device copy and two memsets per trial were three more launches of ~5 us each): redg <- red, red2 <- 0, trial <- 0
+__global__ __launch_bounds__(NT) void ba_dinv(Dev D, int nred, int nS) {
     if (D.st->done) return;
     const double lambda = D.st->lambda;
     const int l = blockIdx.x * NT + threadIdx.x;
+    for (int i = l; i < nred; i += gridDim.x * NT) D.redg[i] = D.red[i];
+    for (int i = l; i < nS; i += gridDim.x * NT) D.red2[i] = 0;
+    if (l < 4) D.trial[l] = 0;
     if (l >= D.L) return;
     bool any = false;
     for (int e = D.lm_start[l]; e < D.lm_start[l + 1]; e++) any |= D.e_level[e] == 0;
@@ -326,18 +352,22 @@ __global__ __launch_bounds__(NT) void ba_dinv(Dev D) {
 }
 
 // thread = EDGE e of landmark l: row block p(e) of the Schur terms, S[p][q(f)] -= W_e Dinv W_f^T for every edge f of l, b[p] -= W_e Dinv bl
-__global__ __launch_bounds__(NT) void ba_schur(Dev D) {
+constexpr int SCHUR_SPLIT = 4;
+constexpr int NT_SCHUR = 256;       // (the LDS FP64 atomics of a workgroup serialise on its CU and every workgroup flushes 1 500 global atomics: 1024 threads 146 us, 64 threads 81 us, 256: 62 us)
+__global__ __launch_bounds__(NT_SCHUR) void ba_schur(Dev D) {
     extern __shared__ __attribute__((aligned(16))) double s_lds[];  // [NP*NP + NP] (np <= MAX_NP_LDS)
     if (D.st->done) return;
     const int NP = 6 * D.np, tot = NP * NP + NP;
     const bool big = D.bigA != nullptr;                              // too large for LDS: the terms go straight to the exchange buffer
     double* s_S = big ? D.red2 : s_lds;
-    if (!big) { for (int i = threadIdx.x; i < tot; i += NT) s_S[i] = 0; }
+    if (!big) { for (int i = threadIdx.x; i < tot; i += NT_SCHUR) s_S[i] = 0; }
     __syncthreads();
-    const int e = blockIdx.x * NT + threadIdx.x;
+    // thread = (edge e, slice sl of the partner edges): the launch ends with its slowest thread, and an edge of a plane vertex has ~30 partners where a point's has ~5 -
+    // SCHUR_SPLIT threads share an edge's partner loop (partner f goes to slice (f - e0) mod SCHUR_SPLIT), slice 0 adds the right-hand side
+    const int gid = blockIdx.x * NT_SCHUR + threadIdx.x, e = gid / SCHUR_SPLIT, sl = gid - e * SCHUR_SPLIT;
     if (e < D.E && D.e_level[e] == 0) {
         const int p = D.pidx[D.e_kf[e]];
-        if (p >= 0) {
+        if (p >= 0 && sl < D.lm_start[edge_landmark(D, e) + 1] - D.lm_start[edge_landmark(D, e)]) {
             const int l = edge_landmark(D, e);
             const int e0 = D.lm_start[l], e1 = D.lm_start[l + 1];
             const double* Di = D.Dinv + (size_t)l * 9;
@@ -346,8 +376,10 @@ __global__ __launch_bounds__(NT) void ba_schur(Dev D) {
             double BD[18];
             for (int a = 0; a < 6; a++)
                 for (int c = 0; c < 3; c++) BD[a * 3 + c] = We[a * 3] * Di[c] + We[a * 3 + 1] * Di[3 + c] + We[a * 3 + 2] * Di[6 + c];
-            for (int a = 0; a < 6; a++) atomicAdd(&s_S[NP * NP + p * 6 + a], -(We[a * 3] * db[0] + We[a * 3 + 1] * db[1] + We[a * 3 + 2] * db[2]));
-            for (int f = e0; f < e1; f++) {
+            if (sl == 0) for (int a = 0; a < 6; a++) atomicAdd(&s_S[NP * NP + p * 6 + a], -(We[a * 3] * db[0] + We[a * 3 + 1] * db[1] + We[a * 3 + 2] * db[2]));
+            // (Measured in round 6 and dropped: skipping the blocks above the diagonal, 62 -> 59 us; the ~30 edges of a plane vertex grouped by key frame - 81 block products
+            //  instead of ~900 - 62 -> 106 us: the launch ends with its slowest THREAD, and a group leader's scans and sums are a longer dependent chain than 30 block products)
+            for (int f = e0 + sl; f < e1; f += SCHUR_SPLIT) {
                 const int q = D.pidx[D.e_kf[f]];
                 if (q < 0 || D.e_level[f] != 0) continue;
                 const double* Wf = D.W + (size_t)f * 18;
@@ -358,7 +390,10 @@ __global__ __launch_bounds__(NT) void ba_schur(Dev D) {
         }
     }
     __syncthreads();
-    if (!big) for (int i = threadIdx.x; i < tot; i += NT) { const double v = s_S[i]; if (v != 0) atomicAdd(&D.red2[i], v); }
+    if (!big) for (int i = threadIdx.x; i < tot; i += NT_SCHUR) {   // (the solver reads the lower triangle only: the upper one is not flushed)
+        if (i < NP * NP && i % NP > i / NP) continue;
+        const double v = s_S[i]; if (v != 0) atomicAdd(&D.red2[i], v);
+    }
 }
 
 // One workgroup: A = blockdiag(Hpp) + lambda I + Schur terms, rhs = bp + Schur rhs; dense Cholesky in LDS.
@@ -386,33 +421,104 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
     for (int i = tid; i < NP; i += NT) x[i] = D.redg[(size_t)D.np * 36 + i] + D.red2[NP * NP + i];
     if (tid == 0) s_ok = 1;
     __syncthreads();
-    for (int j = 0; j < NP; j++) {              // right-looking Cholesky, lower triangle
-        if (tid == 0) { const double d = s_A[j * NP + j]; if (!(d > 0)) s_ok = 0; else s_A[j * NP + j] = sqrt(d); }
+    // Right-looking Cholesky of the lower triangle, SIX columns (one key frame's block) per round: the unblocked loop took three workgroup barriers per column (162 for
+    // 9 key frames, + 216 in the substitutions: the kernel's 90 us were barriers).  Per matrix element the operations and their order are the unblocked loop's - the
+    // products with earlier columns are subtracted one by one in ascending column order, mul then sub -, so the factor is the same doubles.  (Measured first and dropped:
+    // one wavefront with the rows in registers and the column loops unrolled - 17 000 instructions executed once per launch, 240 us: instruction fetch.)
+    const int nb = NP / 6;
+    for (int jb = 0; jb < nb; jb++) {
+        const int J0 = 6 * jb;
+        if (tid == 0) {                          // the diagonal block in one thread's registers (6 sqrt, 15 divisions; the loops are unrolled: constant indices)
+            double m[6][6];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) m[r][k] = k <= r ? s_A[(J0 + r) * NP + J0 + k] : 0.0;
+            bool good = true;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double d = m[c][c];
+                if (!(d > 0)) good = false;
+                const double djj = sqrt(d);
+                m[c][c] = djj;
+#pragma unroll
+                for (int r = c + 1; r < 6; r++) m[r][c] /= djj;
+#pragma unroll
+                for (int r = c + 1; r < 6; r++)
+#pragma unroll
+                    for (int k = c + 1; k <= r; k++) m[r][k] -= m[r][c] * m[k][c];
+            }
+            if (good) {
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int k = 0; k <= r; k++) s_A[(J0 + r) * NP + J0 + k] = m[r][k];
+            } else s_ok = 0;
+        }
         __syncthreads();
         if (!s_ok) break;
-        const double djj = s_A[j * NP + j];
-        for (int i = j + 1 + tid; i < NP; i += NT) s_A[i * NP + j] /= djj;
+        const int R0 = J0 + 6, nr = NP - R0;     // the rows below the block
+        if (tid < nr) {                          // panel: row i's six entries, column by column
+            const int i = R0 + tid;
+            double l[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double v = s_A[i * NP + J0 + c];
+#pragma unroll
+                for (int cp = 0; cp < 6; cp++) if (cp < c) v -= l[cp] * s_A[(J0 + c) * NP + J0 + cp];
+                l[c] = v / s_A[(J0 + c) * NP + J0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) s_A[i * NP + J0 + c] = l[c];
+        }
         __syncthreads();
-        for (int t = tid; t < (NP - j - 1) * (NP - j - 1); t += NT) {
-            const int i = j + 1 + t / (NP - j - 1), k = j + 1 + t % (NP - j - 1);
-            if (k <= i) s_A[i * NP + k] -= s_A[i * NP + j] * s_A[k * NP + j];
+        for (int t = tid; t < nr * nr; t += NT) {            // trailing update: six products per element, ascending column order
+            const int i = R0 + t / nr, k = R0 + t % nr;
+            if (k <= i) {
+                double v = s_A[i * NP + k];
+#pragma unroll
+                for (int c = 0; c < 6; c++) v -= s_A[i * NP + J0 + c] * s_A[k * NP + J0 + c];
+                s_A[i * NP + k] = v;
+            }
         }
         __syncthreads();
     }
     __syncthreads();
-    if (s_ok) {                                 // column-oriented substitutions: L y = rhs, then L^T x = y
-        for (int i = 0; i < NP; i++) {
-            if (tid == 0) x[i] /= s_A[i * NP + i];
+    if (s_ok) {                                 // substitutions, six unknowns per round: L y = rhs, then L^T x = y (same order of the subtractions as column by column)
+        for (int jb = 0; jb < nb; jb++) {
+            const int J0 = 6 * jb;
+            if (tid == 0) {
+                for (int c = 0; c < 6; c++) {
+                    const double xi = x[J0 + c] / s_A[(J0 + c) * NP + J0 + c];
+                    x[J0 + c] = xi;
+                    for (int r = c + 1; r < 6; r++) x[J0 + r] -= s_A[(J0 + r) * NP + J0 + c] * xi;
+                }
+            }
             __syncthreads();
-            const double xi = x[i];
-            for (int k = i + 1 + tid; k < NP; k += NT) x[k] -= s_A[k * NP + i] * xi;
+            for (int k = J0 + 6 + tid; k < NP; k += NT) {
+                double v = x[k];
+#pragma unroll
+                for (int c = 0; c < 6; c++) v -= s_A[k * NP + J0 + c] * x[J0 + c];
+                x[k] = v;
+            }
             __syncthreads();
         }
-        for (int i = NP - 1; i >= 0; i--) {
-            if (tid == 0) x[i] /= s_A[i * NP + i];
+        for (int jb = nb - 1; jb >= 0; jb--) {
+            const int J0 = 6 * jb;
+            if (tid == 0) {
+                for (int c = 5; c >= 0; c--) {
+                    const double xi = x[J0 + c] / s_A[(J0 + c) * NP + J0 + c];
+                    x[J0 + c] = xi;
+                    for (int r = c - 1; r >= 0; r--) x[J0 + r] -= s_A[(J0 + c) * NP + J0 + r] * xi;
+                }
+            }
             __syncthreads();
-            const double xi = x[i];
-            for (int k = tid; k < i; k += NT) x[k] -= s_A[i * NP + k] * xi;
+            for (int k = tid; k < J0; k += NT) {
+                double v = x[k];
+#pragma unroll
+                for (int c = 5; c >= 0; c--) v -= s_A[(J0 + c) * NP + k] * x[J0 + c];
+                x[k] = v;
+            }
             __syncthreads();
         }
     }
@@ -513,9 +619,14 @@ __global__ void ba_decide(Dev D) {
     if (finished) S.done = 1;
 }
 
-__global__ __launch_bounds__(NT) void ba_restore(Dev D) {
-    if (!D.st->restore) return;
+// ... and, when the next step opens an LM iteration, clears this rank's partial sums for it (round 6: was a launch of its own, ba_begin; the block is zero when a solve starts)
+__global__ __launch_bounds__(NT) void ba_restore(Dev D, int nred) {
     const int i = blockIdx.x * NT + threadIdx.x;
+    if (D.st->need_build) {
+        for (int q = i; q < nred; q += gridDim.x * NT) D.red[q] = 0;
+        if (i == 0) D.scal[0] = 0;
+    }
+    if (!D.st->restore) return;
     if (i < D.K) for (int a = 0; a < 8; a++) D.T[(size_t)i * 8 + a] = D.Tbak[(size_t)i * 8 + a];
     if (i < D.L) for (int a = 0; a < 4; a++) D.lm[(size_t)i * 4 + a] = D.lmbak[(size_t)i * 4 + a];
 }
@@ -660,6 +771,9 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
             e_partner[inv[o]] = inv[o + 1]; e_partner[inv[o + 1]] = inv[o];
             o++;
         }
+    std::vector<int> e_numslot(E, -1), num_idx;
+    for (int i = 0; i < E; i++) if (e_type[i] >= BE_PLANE) { e_numslot[i] = (int)num_idx.size(); num_idx.push_back(i); }
+    const int n_num = (int)num_idx.size();
     std::vector<double> T0((size_t)K * 8, 0.0), lm0((size_t)L * 4);
     for (int k = 0; k < K; k++) {     // Converter::toSE3Quat (host: same restated kernels as the device, in plain C++)
         const float* Tm = P->kf_Tcw + 16 * k;
@@ -699,17 +813,19 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
                  oLt = carve(L), oLs = carve((size_t)(L + 1) * 4), oEk = carve((size_t)E * 4), oEt = carve(E), oEp = carve((size_t)E * 4),
                  oEm = carve((size_t)E * 32), oEi = carve((size_t)E * 32), oEe = carve((size_t)E * 24), oEl = carve(E), oEo = carve(E),
                  oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oDi = carve((size_t)L * 72), oW = carve((size_t)E * 144), oHe = carve((size_t)E * 96), oXl = carve((size_t)L * 24),
-                 oR = carve(nred * 8), oA = carve(nA * 8), oBig = carve(np > MAX_NP_LDS ? nS * 8 : 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8), oSc = carve(64), oSt = carve(sizeof(LmState));
-    DevBuf buf;
-    int rc = buf.alloc(off);
+                 oR = carve(nred * 8), oA = carve(nA * 8), oBig = carve(np > MAX_NP_LDS ? nS * 8 : 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8), oSc = carve(64), oSt = carve(sizeof(LmState)),
+                 oNs = carve((size_t)E * 4), oNi = carve((size_t)n_num * 4), oJ = carve((size_t)n_num * 27 * 8);
+    // (the context's grow-only scratch block: a hipMalloc + hipFree per solve cost more than two LM trials, and hipFree synchronises the device)
+    int rc = ctx->ensure_scratch(off);
     if (rc) return rc;
-    uint8_t* base = buf.as<uint8_t>();
+    uint8_t* base = ctx->scratch.as<uint8_t>();
     PLANAR_HIP_CHECK(hipMemsetAsync(base, 0, off, st));
     auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
     PLANAR_HIP_CHECK(up(oT, T0.data(), T0.size() * 8)); PLANAR_HIP_CHECK(up(oP, pidx.data(), (size_t)K * 4));
     PLANAR_HIP_CHECK(up(oLm, lm0.data(), lm0.size() * 8)); PLANAR_HIP_CHECK(up(oLt, P->lm_type, L)); PLANAR_HIP_CHECK(up(oLs, lm_start.data(), (size_t)(L + 1) * 4));
     PLANAR_HIP_CHECK(up(oEk, e_kf.data(), (size_t)E * 4)); PLANAR_HIP_CHECK(up(oEt, e_type.data(), E)); PLANAR_HIP_CHECK(up(oEp, e_partner.data(), (size_t)E * 4));
     PLANAR_HIP_CHECK(up(oEm, e_meas.data(), e_meas.size() * 8)); PLANAR_HIP_CHECK(up(oEi, e_info.data(), e_info.size() * 8));
+    PLANAR_HIP_CHECK(up(oNs, e_numslot.data(), (size_t)E * 4)); PLANAR_HIP_CHECK(up(oNi, num_idx.data(), (size_t)n_num * 4));
     Dev D;
     D.K = K; D.np = np; D.L = L; D.E = E;
     D.T = (double*)(base + oT); D.Tbak = (double*)(base + oTb); D.pidx = (const int*)(base + oP); D.lm = (double*)(base + oLm); D.lmbak = (double*)(base + oLb);
@@ -719,6 +835,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     D.red = (double*)(base + oR); D.redg = (double*)(base + oA); D.red2 = D.redg + nred; D.trial = (double*)(base + oTr); D.xp = (double*)(base + oXp);
     D.scal = (double*)(base + oSc); D.st = (LmState*)(base + oSt);
     D.bigA = np > MAX_NP_LDS ? (double*)(base + oBig) : nullptr;
+    D.e_numslot = (const int*)(base + oNs); D.num_idx = (const int*)(base + oNi); D.J = (double*)(base + oJ); D.n_num = n_num;
     D.cam = Cam{(double)prm->fx, (double)prm->fy, (double)prm->cx, (double)prm->cy, (double)prm->bf};
 
     const size_t smem_schur = np > MAX_NP_LDS ? 0 : ((size_t)NP * NP + NP) * 8, smem_solve = smem_schur, smem_build = (size_t)np * 42 * 8;
@@ -750,8 +867,8 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
 
     // the launches that open an LM iteration; every kernel is predicated on the device state (need_build && !done)
     auto enqueue_open = [&](int robust) {
-        hipLaunchKernelGGL(ba_begin, dim3(4), dim3(NT), 0, st, D, (int)nred);
         if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.red + (size_t)np * 36 + NP, 1);
+        if (n_num) hipLaunchKernelGGL(ba_numjac, dim3((n_num * 9 + NT - 1) / NT), dim3(NT), 0, st, D);
         if (E) hipLaunchKernelGGL(ba_linearize, gE, dim3(NT), smem_build, st, D, robust);
         if (L) hipLaunchKernelGGL(ba_gather, gL, dim3(NT), 0, st, D);
     };
@@ -759,18 +876,15 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     auto enqueue_step = [&](int robust, bool opened) -> int {
         int r;
         if (!opened) enqueue_open(robust);
-        PLANAR_HIP_CHECK(hipMemcpyAsync(D.redg, D.red, nred * 8, hipMemcpyDeviceToDevice, st));
-        PLANAR_HIP_CHECK(hipMemsetAsync(D.red2, 0, nS * 8, st));
-        PLANAR_HIP_CHECK(hipMemsetAsync(D.trial, 0, 32, st));
-        if (L) hipLaunchKernelGGL(ba_dinv, gL, dim3(NT), 0, st, D);
-        if (E && NP) hipLaunchKernelGGL(ba_schur, gE, dim3(NT), smem_schur, st, D);
+        hipLaunchKernelGGL(ba_dinv, gL, dim3(NT), 0, st, D, (int)nred, (int)nS);      // (+ redg <- red, red2 <- 0, trial <- 0)
+        if (E && NP) hipLaunchKernelGGL(ba_schur, dim3(((size_t)E * SCHUR_SPLIT + NT_SCHUR - 1) / NT_SCHUR), dim3(NT_SCHUR), smem_schur, st, D);
         if ((r = allreduce(D.redg, nA, NCCL_SUM))) return r;                                            // exchange A
         hipLaunchKernelGGL(ba_solve, dim3(1), dim3(NT), smem_solve, st, D);
         hipLaunchKernelGGL(ba_update, gU, dim3(NT), 0, st, D, stop_now());
         if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.trial, 0);
         if ((r = allreduce(D.trial, 3, NCCL_SUM))) return r;                                            // exchange B
         hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, st, D);
-        hipLaunchKernelGGL(ba_restore, gU, dim3(NT), 0, st, D);
+        hipLaunchKernelGGL(ba_restore, gU, dim3(NT), 0, st, D, (int)nred);
         return PLANAR_OK;
     };
     // SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg

@@ -182,6 +182,22 @@ class TrackPipeline:
         self.capture_steps = set()      # tests: steps whose stage inputs / outputs are cloned (on the stream) into self.captured[j]
         self.captured = {}
 
+    def close(self):
+        """Releases the CU-masked side streams (after synchronising): the contexts fall back to their own streams."""
+        if getattr(self, "seq_streams", None):
+            self.torch.cuda.synchronize()
+            for c in self.ctx_peacs + self.ctx_lsds:
+                c.set_seq_stream(None)
+            for q in self.seq_streams:
+                self.L.planar_cu_stream_destroy(C.c_void_p(q))
+            self.seq_streams = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # ------------------------------------------------------------------------------------------------------------------------------
     def set_map(self, kf_lines: dict, map_planes: dict, normals: dict):
         """Per-stream stand-ins for the map (host numpy, uploaded once):
