@@ -175,33 +175,42 @@ __global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_o
     if (threadIdx.x == 0 && tot != 0) atomicAdd(chi_out, tot);
 }
 
-// thread = (numeric-Jacobian edge, column): one column of g2o's central differences (base_binary_edge.hpp:131-198), two error evaluations.  Round 6: ba_linearize did all
+// thread = (numeric-Jacobian edge, column, sign): one evaluation of g2o's central differences (base_binary_edge.hpp:131-198).  Round 6: ba_linearize did all
 // 18 evaluations of such an edge in ONE thread, and the launch ended with those threads (68 us for 19 573 edges of which ~400 are numeric); same arithmetic per column.
 __global__ __launch_bounds__(NT) void ba_numjac(Dev D) {
     if (D.st->done || !D.st->need_build) return;
-    const int gid = blockIdx.x * NT + threadIdx.x, slot = gid / 9, d = gid - slot * 9;
-    if (slot >= D.n_num) return;
-    const int e = D.num_idx[slot];
-    if (D.e_level[e] != 0) return;
-    const int l = edge_landmark(D, e);
-    const LmV Lm = load_lm(D, D.lm, l);
-    const int type = D.e_type[e], dim = edge_dim(type), kf = D.e_kf[e], p = D.pidx[kf];
-    const SE3 T = load_T(D.T, kf);
-    const double* meas = D.e_meas + (size_t)e * 4;
-    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
-    double e1[3] = {0, 0, 0}, e2[3] = {0, 0, 0};
-    if (d < 3) {
-        double add[3] = {0, 0, 0};
-        add[d] = delta; LmV Lp = Lm; lm_oplus(Lp, add); edge_error(D, type, T, Lp, meas, e1);
-        add[d] = -delta; LmV Lq = Lm; lm_oplus(Lq, add); edge_error(D, type, T, Lq, meas, e2);
-    } else if (p >= 0) {
-        double add[6] = {0, 0, 0, 0, 0, 0};
-        add[d - 3] = delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e1);
-        add[d - 3] = -delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, e2);
+    // thread = (edge slot, column d, sign): the two evaluations of a column on neighbouring lanes (lane ^ 1), combined by one shuffle
+    const int gid = blockIdx.x * NT + threadIdx.x, pair = gid >> 1, sgn = gid & 1, slot = pair / 9, d = pair - slot * 9;
+    const bool on = slot < D.n_num;
+    const int e = on ? D.num_idx[slot] : 0;
+    const bool act = on && D.e_level[e] == 0;
+    double ev[3] = {0, 0, 0};
+    int dim = 0;
+    if (act) {
+        const int l = edge_landmark(D, e);
+        const LmV Lm = load_lm(D, D.lm, l);
+        const int type = D.e_type[e], kf = D.e_kf[e], p = D.pidx[kf];
+        dim = edge_dim(type);
+        const SE3 T = load_T(D.T, kf);
+        const double* meas = D.e_meas + (size_t)e * 4;
+        const double delta = sgn ? -1e-9 : 1e-9;
+        if (d < 3) {
+            double add[3] = {0, 0, 0};
+            add[d] = delta; LmV Lp = Lm; lm_oplus(Lp, add); edge_error(D, type, T, Lp, meas, ev);
+        } else if (p >= 0) {
+            double add[6] = {0, 0, 0, 0, 0, 0};
+            add[d - 3] = delta; edge_error(D, type, se3_mul(se3_exp(add), T), Lm, meas, ev);
+        }
     }
-    double* o = D.J + ((size_t)slot * 9 + d) * 3;
+    const double scalar = 1.0 / (2 * 1e-9);
+    double o3[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) o[i] = i < dim ? scalar * (e1[i] - e2[i]) : 0.0;
+    for (int i = 0; i < 3; i++) { const double other = __shfl_xor(ev[i], 1); o3[i] = scalar * (ev[i] - other); }      // (sign 0 holds e(+delta), its neighbour e(-delta))
+    if (act && sgn == 0) {
+        double* o = D.J + ((size_t)slot * 9 + d) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; i++) o[i] = i < dim ? o3[i] : 0.0;
+    }
 }
 
 // thread = EDGE: Jacobians, the edge's coupling block W = B^T (w Omega) A, its contribution to the landmark block (A^T w Omega A, -A^T w Omega e) and,
@@ -423,50 +432,51 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
     __syncthreads();
     // Right-looking Cholesky of the lower triangle, SIX columns (one key frame's block) per round: the unblocked loop took three workgroup barriers per column (162 for
     // 9 key frames, + 216 in the substitutions: the kernel's 90 us were barriers).  Per matrix element the operations and their order are the unblocked loop's - the
-    // products with earlier columns are subtracted one by one in ascending column order, mul then sub -, so the factor is the same doubles.  (Measured first and dropped:
-    // one wavefront with the rows in registers and the column loops unrolled - 17 000 instructions executed once per launch, 240 us: instruction fetch.)
+    // products with earlier columns are subtracted one by one in ascending column order, mul then sub -, so the factor is the same doubles.  EVERY thread factors the 6x6
+    // diagonal block itself, in registers (6 sqrt, 15 divisions: cheaper than a barrier and a wait for one thread); thread 0 keeps the factor in s_D for the
+    // substitutions.  Two barriers per key frame here, one per key frame and direction below: 36 for 9 key frames.  (Measured first and dropped: one wavefront with the rows
+    // in registers and the column loops unrolled - 17 000 instructions executed once per launch, 240 us: instruction fetch.)
+    __shared__ double s_D[MAX_NP][21];          // factored diagonal blocks, row-major lower triangles
+    __shared__ double s_y[6 * MAX_NP];          // the solution of L y = rhs, then of L^T x = y
     const int nb = NP / 6;
-    for (int jb = 0; jb < nb; jb++) {
+    auto tri = [](int r, int k) { return r * (r + 1) / 2 + k; };
+    bool good = true;
+    for (int jb = 0; jb < nb && good; jb++) {
         const int J0 = 6 * jb;
-        if (tid == 0) {                          // the diagonal block in one thread's registers (6 sqrt, 15 divisions; the loops are unrolled: constant indices)
-            double m[6][6];
+        double m[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) m[r][k] = k <= r ? s_A[(J0 + r) * NP + J0 + k] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const double d = m[c][c];
+            if (!(d > 0)) good = false;
+            const double djj = sqrt(d);
+            m[c][c] = djj;
+#pragma unroll
+            for (int r = c + 1; r < 6; r++) m[r][c] /= djj;
+#pragma unroll
+            for (int r = c + 1; r < 6; r++)
+#pragma unroll
+                for (int k = c + 1; k <= r; k++) m[r][k] -= m[r][c] * m[k][c];
+        }
+        if (!good) break;                        // (every thread computed the same block: they all leave together)
+        if (tid == 0) {
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int k = 0; k < 6; k++) m[r][k] = k <= r ? s_A[(J0 + r) * NP + J0 + k] : 0.0;
-            bool good = true;
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                const double d = m[c][c];
-                if (!(d > 0)) good = false;
-                const double djj = sqrt(d);
-                m[c][c] = djj;
-#pragma unroll
-                for (int r = c + 1; r < 6; r++) m[r][c] /= djj;
-#pragma unroll
-                for (int r = c + 1; r < 6; r++)
-#pragma unroll
-                    for (int k = c + 1; k <= r; k++) m[r][k] -= m[r][c] * m[k][c];
-            }
-            if (good) {
-#pragma unroll
-                for (int r = 0; r < 6; r++)
-#pragma unroll
-                    for (int k = 0; k <= r; k++) s_A[(J0 + r) * NP + J0 + k] = m[r][k];
-            } else s_ok = 0;
+                for (int k = 0; k <= r; k++) s_D[jb][tri(r, k)] = m[r][k];
         }
-        __syncthreads();
-        if (!s_ok) break;
         const int R0 = J0 + 6, nr = NP - R0;     // the rows below the block
-        if (tid < nr) {                          // panel: row i's six entries, column by column
-            const int i = R0 + tid;
+        for (int i = R0 + tid; i < NP; i += NT) {                // panel: row i's six entries, column by column
             double l[6];
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 double v = s_A[i * NP + J0 + c];
 #pragma unroll
-                for (int cp = 0; cp < 6; cp++) if (cp < c) v -= l[cp] * s_A[(J0 + c) * NP + J0 + cp];
-                l[c] = v / s_A[(J0 + c) * NP + J0 + c];
+                for (int cp = 0; cp < 6; cp++) if (cp < c) v -= l[cp] * m[c][cp];
+                l[c] = v / m[c][c];
             }
 #pragma unroll
             for (int c = 0; c < 6; c++) s_A[i * NP + J0 + c] = l[c];
@@ -483,44 +493,59 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
         }
         __syncthreads();
     }
+    if (tid == 0) s_ok = good ? 1 : 0;
     __syncthreads();
-    if (s_ok) {                                 // substitutions, six unknowns per round: L y = rhs, then L^T x = y (same order of the subtractions as column by column)
-        for (int jb = 0; jb < nb; jb++) {
+    if (good) {                                 // substitutions, six unknowns per round: L y = rhs, then L^T x = y (same order of the subtractions as column by column)
+        for (int jb = 0; jb < nb; jb++) {        // every thread solves the block's six unknowns itself, then updates its rows below
             const int J0 = 6 * jb;
-            if (tid == 0) {
-                for (int c = 0; c < 6; c++) {
-                    const double xi = x[J0 + c] / s_A[(J0 + c) * NP + J0 + c];
-                    x[J0 + c] = xi;
-                    for (int r = c + 1; r < 6; r++) x[J0 + r] -= s_A[(J0 + r) * NP + J0 + c] * xi;
-                }
+            double yb[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) yb[c] = x[J0 + c];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                yb[c] = yb[c] / s_D[jb][tri(c, c)];
+#pragma unroll
+                for (int r = c + 1; r < 6; r++) yb[r] -= s_D[jb][tri(r, c)] * yb[c];
             }
-            __syncthreads();
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s_y[J0 + c] = yb[c];
+            }
             for (int k = J0 + 6 + tid; k < NP; k += NT) {
                 double v = x[k];
 #pragma unroll
-                for (int c = 0; c < 6; c++) v -= s_A[k * NP + J0 + c] * x[J0 + c];
+                for (int c = 0; c < 6; c++) v -= s_A[k * NP + J0 + c] * yb[c];
                 x[k] = v;
             }
             __syncthreads();
         }
+        for (int i = tid; i < NP; i += NT) x[i] = s_y[i];
+        __syncthreads();
         for (int jb = nb - 1; jb >= 0; jb--) {
             const int J0 = 6 * jb;
-            if (tid == 0) {
-                for (int c = 5; c >= 0; c--) {
-                    const double xi = x[J0 + c] / s_A[(J0 + c) * NP + J0 + c];
-                    x[J0 + c] = xi;
-                    for (int r = c - 1; r >= 0; r--) x[J0 + r] -= s_A[(J0 + c) * NP + J0 + r] * xi;
-                }
+            double xb[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) xb[c] = x[J0 + c];
+#pragma unroll
+            for (int c = 5; c >= 0; c--) {
+                xb[c] = xb[c] / s_D[jb][tri(c, c)];
+#pragma unroll
+                for (int r = c - 1; r >= 0; r--) xb[r] -= s_D[jb][tri(c, r)] * xb[c];
             }
-            __syncthreads();
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s_y[J0 + c] = xb[c];
+            }
             for (int k = tid; k < J0; k += NT) {
                 double v = x[k];
 #pragma unroll
-                for (int c = 5; c >= 0; c--) v -= s_A[(J0 + c) * NP + k] * x[J0 + c];
+                for (int c = 5; c >= 0; c--) v -= s_A[(J0 + c) * NP + k] * xb[c];
                 x[k] = v;
             }
             __syncthreads();
         }
+        for (int i = tid; i < NP; i += NT) x[i] = s_y[i];
+        __syncthreads();
     }
     if (tid == 0) {
         double scale = 0;
@@ -868,7 +893,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     // the launches that open an LM iteration; every kernel is predicated on the device state (need_build && !done)
     auto enqueue_open = [&](int robust) {
         if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.red + (size_t)np * 36 + NP, 1);
-        if (n_num) hipLaunchKernelGGL(ba_numjac, dim3((n_num * 9 + NT - 1) / NT), dim3(NT), 0, st, D);
+        if (n_num) hipLaunchKernelGGL(ba_numjac, dim3((n_num * 18 + NT - 1) / NT), dim3(NT), 0, st, D);
         if (E) hipLaunchKernelGGL(ba_linearize, gE, dim3(NT), smem_build, st, D, robust);
         if (L) hipLaunchKernelGGL(ba_gather, gL, dim3(NT), 0, st, D);
     };
