@@ -435,3 +435,47 @@ def test_pipeline_tracks_se3_rendered_streams():
     assert np.median(moved) > 0.02                                          # the cameras did move
     assert np.median(dt) < 0.01 and np.median(dr) < 0.2, (dt, dr)          # and the tracker knows where to (1 cm, 0.2 deg; depth noise is 0.0012 z^2)
     assert (dt < 0.05).mean() >= 0.9 and (dr < 1.0).mean() >= 0.9, (dt, dr)
+
+
+def test_cu_partition_and_extractor_sets_do_not_change_results():
+    """Round 6: the clustering kernel (and, with seq_which = 3, LSD's region growing) on a CU-masked side stream (planar_cu_stream_create / planar_ctx_set_seq_stream: fork
+    and join by events) and the extractors' workspaces per extraction in flight instead of per buffer set are scheduling only: every output of a pipelined run - the
+    extractors' and the tracker's - is bit-identical to the unpartitioned run's with one extractor set per buffer set (the stochastic part, the 3-D line RANSAC, is
+    seeded per stream and step).  The masked run must also have actually created its side stream."""
+    import torch
+    from planarslam_amd import synth_se3
+    from planarslam_amd.synth import gray_image
+    from planarslam_amd.track import TrackPipeline, build_map
+    Bs, K, n_steps = 24, 6, 9
+    dev = torch.device("cuda", 0)
+    tex = torch.from_numpy(np.stack([gray_image(4321 + i, W + 2 * MARGIN, H + 2 * MARGIN) for i in range(4)])).to(dev)
+    loop_g, loop_d, _ = synth_se3.render_streams(torch, tex, Bs, K, TUM3, seed=11)
+    maps = build_map(loop_g[:, 0].cpu().numpy(), loop_d[:, 0].cpu().numpy().view(np.uint16), TUM3, seed=1)
+    keys = ("kps", "desc", "n", "kls", "ldesc", "nl", "lab", "pls", "npl", "pl_coef", "pl_pts", "pl_n", "snrm", "l3_lines3d", "pm0", "lm2", "mm", "pose_out", "Rcm_new")
+
+    def run(**kw):
+        tp = TrackPipeline(Bs, torch, 0, depth=2, **kw)
+        tp.set_map(*maps)
+        tp.capture_steps = {n_steps - 1, n_steps - 2}
+        frames = [torch.zeros((Bs, H, W), dtype=torch.uint8, device=dev) for _ in range(tp.NB)]
+        depths = [torch.zeros((Bs, H, W), dtype=torch.int16, device=dev) for _ in range(tp.NB)]
+        with torch.cuda.stream(tp.stream):
+            for i in range(n_steps):
+                k = i % tp.NB
+                tp.stream.wait_event(tp.done[k])
+                fi = synth_se3.frame_index(i, K)
+                frames[k].copy_(loop_g[:, fi]); depths[k].copy_(loop_d[:, fi])
+                tp.step(i, frames[k], depths[k])
+            tp.drain()
+        torch.cuda.synchronize()
+        tp.check()
+        out = {(j, name): tp.captured[j][name].cpu().numpy() for j in tp.capture_steps for name in keys}
+        info = (tp.NW, len(tp.seq_streams))
+        tp.close()
+        return out, info
+
+    base, (nw0, ns0) = run(work_sets=4, seq_cus=0)
+    part, (nw1, ns1) = run(work_sets=2, seq_cus=64, seq_which=3)
+    assert (nw0, ns0) == (4, 0) and (nw1, ns1) == (2, 1)
+    for key in base:
+        assert np.array_equal(base[key], part[key], equal_nan=True), key
