@@ -77,7 +77,9 @@ public:
         auto it = clouds_.find({w, h});
         if (it != clouds_.end()) return it->second;
         planar_plane_clouds* o = nullptr;
-        if (planar_plane_clouds_create(lanes_[PLANES].ctx, w, h, 1, 8192, &o) != PLANAR_OK) { complain("planar_plane_clouds_create"); o = nullptr; }   // 8192 voxels of 0.1 m per pass (a frame with more goes plane by plane); sizes beyond 2^19 pixels: reported once
+        // 8192 voxels of 0.1 m per pass (a frame with more goes plane by plane); frames of more than 2^19 pixels (1280x720) carry 20 bits of pixel in a sort word: 4096 voxels per pass
+        const int max_voxels = (long long)w * h > (1ll << 19) ? 4096 : 8192;
+        if (planar_plane_clouds_create(lanes_[PLANES].ctx, w, h, 1, max_voxels, &o) != PLANAR_OK) { complain("planar_plane_clouds_create"); o = nullptr; }   // (sizes beyond 2^20 pixels: reported once)
         return clouds_[{w, h}] = o;
     }
     void set_device(int d) { device_ = d; }

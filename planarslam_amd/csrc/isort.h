@@ -744,24 +744,162 @@ constexpr int G_FMAX = 512;      // ranges handed to the LDS tier, per array set
 constexpr int G_POSH = 6144;     // swaps of a partition go through a table of this many positions at a time (24 KB: beside the bitmaps of a 640 x 480 range in 160 KB)
 
 template <int T>
-struct GlobalLayout {            // LDS of global_tier for arrays whose longest range has `rows` 64-element rows
+struct GlobalLayout {            // LDS of global_tier: stop bitmaps + rank prefixes of a range of up to `rows` 64-element rows, the rendezvous table, then the tier's lists
     static constexpr int NW = T / 64;
+    static constexpr int LDS_LIMIT = 160 * 1024 - 2560;                                                                // (a kernel's few static LDS words beside the block)
     __host__ __device__ static constexpr int off_Lw(int) { return 0; }
     __host__ __device__ static constexpr int off_Rw(int rows) { return rows * 8; }
     __host__ __device__ static constexpr int off_pL(int rows) { return rows * 16; }
     __host__ __device__ static constexpr int off_pR(int rows) { return rows * 16 + (rows + 1) * 4; }
-    __host__ __device__ static constexpr int off_q(int rows) { return (rows * 16 + (rows + 1) * 8 + 7) / 8 * 8; }     // Range [2][G_QMAX]
+    __host__ __device__ static constexpr int off_posh(int rows) { return (rows * 16 + (rows + 1) * 8 + 7) / 8 * 8; }  // u32 [G_POSH]: the swaps' rendezvous table
+    __host__ __device__ static constexpr int off_q(int rows) { return off_posh(rows) + G_POSH * 4; }                  // Range [2][G_QMAX]
     __host__ __device__ static constexpr int off_fin(int rows) { return off_q(rows) + 2 * G_QMAX * 12; }              // Range [G_FMAX]
     __host__ __device__ static constexpr int off_rank(int rows) { return off_fin(rows) + G_FMAX * 12; }               // Range [G_FMAX] (sorted copy)
     __host__ __device__ static constexpr int off_buf(int rows) { return off_rank(rows) + G_FMAX * 12; }               // u64 [NW] + ints
-    __host__ __device__ static constexpr int off_posh(int rows) { return off_buf(rows) + NW * 8 + 64; }               // u32 [G_POSH]: the swaps' rendezvous table
-    __host__ __device__ static constexpr int bytes(int rows) { return off_posh(rows) + G_POSH * 4; }
+    __host__ __device__ static constexpr int bytes(int rows) { return off_buf(rows) + NW * 8 + 64; }
     __host__ __device__ static constexpr int rows_for(int n) { return (n + 63) / 64 + 1; }
+    // A range LONGER than the bitmaps hold (round 6: frames beyond ~390 000 sort words - 1280x720) is partitioned by wg_partition_long, which keeps only the rank prefixes
+    // of its rows in LDS - two u32 per row, OVER the bitmaps, prefixes and rendezvous table of the ordinary path, none of which is live then - and recomputes a row's
+    // stops where it needs them.  plan(n): rows_cap for the ordinary path and rows_long (0: not needed) for an array of n words; false: n does not fit at all.
+    __host__ __device__ static constexpr int long_bytes(int rows_long) { return (rows_long + 2) * 8; }
+    static bool plan(int n, int& rows_cap, int& rows_long) {
+        rows_cap = rows_for(n); rows_long = 0;
+        if (bytes(rows_cap) <= LDS_LIMIT) return true;
+        rows_long = rows_for(n);
+        rows_cap = 1024;
+        while (off_q(rows_cap) < long_bytes(rows_long)) rows_cap += 64;
+        return bytes(rows_cap) <= LDS_LIMIT;
+    }
 };
 
 // One Hoare partition of arr[f, l) (l - f > 16) by the whole workgroup; returns the cut in every thread.
+// The same partition for a range whose rows do not fit the bitmaps (nrow <= rows_long).  LDS: pL / pR [nrow + 1] only.  Pass 1 counts the stops of every row; the row that
+// holds x* and the rows whose stops take part in the swaps have their ballots recomputed from the array (every row is read at most three times instead of once); the positions
+// of the m left and m right stops go to a scratch array in global memory (gpos [2][n / 2 + 1]) BEFORE any swap, so every ballot sees the unpartitioned range; then thread k
+// swaps pair k.  Same cut, same swaps as wg_partition.
 template <int SHIFT, int T>
-__device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* lds, int rows_cap, int* status) {
+__device__ int wg_partition_long(uint32_t* __restrict__ arr, int f, int l, uint8_t* lds, int rows_cap, uint32_t* __restrict__ gpos, int gpos_half) {
+    using GL = GlobalLayout<T>;
+    constexpr int NW = T / 64;
+    uint32_t* pL = (uint32_t*)lds;
+    const int nrow = (l - f - 1 + 63) / 64;
+    uint32_t* pR = pL + nrow + 1;
+    unsigned long long* s_w = (unsigned long long*)(lds + GL::off_buf(rows_cap));
+    int* s_i = (int*)(s_w + NW);          // [0] pivot key, [1] tpos, [2] old front, [3] cut, [4] m, [5] the row that holds x*
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        const int A = f + 1, Bm = f + (l - f) / 2, Cc = l - 1;
+        const uint32_t xa = arr[A], xb = arr[Bm], xc = arr[Cc], xf = arr[f];
+        const int t = median_pos<SHIFT>(xa, xb, xc, A, Bm, Cc);
+        const uint32_t xt = t == A ? xa : (t == Bm ? xb : xc);
+        arr[f] = xt; arr[t] = xf;
+        s_i[0] = (int)(xt >> SHIFT); s_i[1] = t; s_i[2] = (int)xf;
+    }
+    __syncthreads();
+    const uint32_t pv = (uint32_t)s_i[0];
+    const int tpos = s_i[1];
+    const uint32_t xfront = (uint32_t)s_i[2];
+    auto row_ballots = [&](int r, unsigned long long& bl, unsigned long long& br) {          // the whole wavefront calls it
+        const int i = f + 1 + 64 * r + lane;
+        const uint32_t x = arr[min(i, l - 1)];
+        const uint32_t k = (i == tpos ? xfront : x) >> SHIFT;
+        bl = __ballot(i < l && k >= pv); br = __ballot(i < l && k <= pv);
+    };
+    // ---- pass 1: the rows' stop counts ----
+    constexpr int U = 8;
+    for (int rb = wave; rb < nrow; rb += NW * U) {
+        uint32_t x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = arr[min(f + 1 + 64 * (rb + u * NW) + lane, l - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = rb + u * NW, i = f + 1 + 64 * r + lane;
+            if (r < nrow) {
+                const uint32_t k = (i == tpos ? xfront : x[u]) >> SHIFT;
+                const unsigned long long bl = __ballot(i < l && k >= pv), br = __ballot(i < l && k <= pv);
+                if (lane == 0) { pL[r] = (uint32_t)__popcll(bl); pR[r] = (uint32_t)__popcll(br); }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- ranks: exclusive prefixes in place ----
+    const int RP = (nrow + T - 1) / T, r_begin = min(nrow, tid * RP), r_end = min(nrow, r_begin + RP);
+    unsigned long long mine = 0;
+    for (int r = r_begin; r < r_end; r++) mine += ((unsigned long long)pL[r] << 32) | (unsigned long long)pR[r];
+    unsigned long long tot;
+    unsigned long long run = block_exscan<T, unsigned long long>(mine, s_w, &tot);
+    for (int r = r_begin; r < r_end; r++) {
+        const unsigned long long c = ((unsigned long long)pL[r] << 32) | (unsigned long long)pR[r];
+        pL[r] = (uint32_t)(run >> 32); pR[r] = (uint32_t)run;
+        run += c;
+    }
+    const int totL = (int)(tot >> 32), totR = (int)(uint32_t)tot;
+    if (tid == 0) { pL[nrow] = (uint32_t)totL; pR[nrow] = (uint32_t)totR; }
+    __syncthreads();
+    // ---- x*: the row where A >= B turns true; its ballots again, then the bit inside it (first wavefront) ----
+    for (int r = r_begin; r < r_end; r++) {
+        const int A0 = (int)pL[r], B0 = totR - (int)pR[r], A1 = (int)pL[r + 1], B1 = totR - (int)pR[r + 1];
+        if (!(A0 >= B0) && A1 >= B1) s_i[5] = r;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int r = s_i[5];
+        unsigned long long Lb, Rb;
+        row_ballots(r, Lb, Rb);
+        if (lane == 0) {
+            const int A0 = (int)pL[r], B0 = totR - (int)pR[r];
+            auto low = [](int j_) { return j_ >= 64 ? ~0ull : ((1ull << j_) - 1ull); };
+            int jl = 0, j = 64;
+            while (j - jl > 1) {
+                const int mid = (jl + j) >> 1;
+                if (A0 + __popcll(Lb & low(mid)) >= B0 - __popcll(Rb & low(mid))) j = mid; else jl = mid;
+            }
+            const bool eL = (Lb >> (j - 1)) & 1ull, eR = (Rb >> (j - 1)) & 1ull;
+            const int A = A0 + __popcll(Lb & low(j)), Bf = B0 - __popcll(Rb & low(j));
+            const int xs = f + 1 + 64 * r + j, Ap = A - (int)eL, Bp = Bf + (int)eR;
+            s_i[3] = xs - ((eL && eR && Ap == Bp - 1) ? 1 : 0);
+            s_i[4] = max(Ap, Bf);
+        }
+    }
+    __syncthreads();
+    const int cut = s_i[3], m = s_i[4];
+    // ---- the positions of the first m stops of the left scan and of the last m of the right scan, by rank ----
+    if (m > 0) {
+        auto row_of = [&](const uint32_t* pref, int rank) {       // the last row whose prefix is <= rank
+            int lo = 0, hi = nrow;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)pref[mid] <= rank) lo = mid; else hi = mid; }
+            return lo;
+        };
+        const unsigned long long below = (1ull << lane) - 1ull;
+        uint32_t* gL = gpos; uint32_t* gR = gpos + gpos_half;
+        const int lb = row_of(pL, m - 1), ra = row_of(pR, totR - m);
+        for (int r = wave; r <= lb; r += NW) {
+            unsigned long long Lb, Rb;
+            row_ballots(r, Lb, Rb);
+            const int k = (int)pL[r] + __popcll(Lb & below);
+            if (((Lb >> lane) & 1ull) && k < m) gL[k] = (uint32_t)(f + 1 + 64 * r + lane);
+        }
+        for (int r = ra + wave; r < nrow; r += NW) {
+            unsigned long long Lb, Rb;
+            row_ballots(r, Lb, Rb);
+            const int k = totR - 1 - ((int)pR[r] + __popcll(Rb & below));
+            if (((Rb >> lane) & 1ull) && k >= 0 && k < m) gR[k] = (uint32_t)(f + 1 + 64 * r + lane);
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int k = tid; k < m; k += T) {
+            const int pp = (int)gL[k], qq = (int)gR[k];
+            const uint32_t x = arr[pp], y = arr[qq];
+            arr[pp] = y; arr[qq] = x;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    return cut;
+}
+
+template <int SHIFT, int T>
+__device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* lds, int rows_cap, int* status, int rows_long = 0, uint32_t* gpos = nullptr, int gpos_half = 0) {
     using GL = GlobalLayout<T>;
     constexpr int NW = T / 64;
     unsigned long long* Lw = (unsigned long long*)(lds + GL::off_Lw(rows_cap));
@@ -772,7 +910,11 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
     int* s_i = (int*)(s_w + NW);          // [0] pivot key, [1] tpos, [2] old front, [3] cut, [4] m
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrow = (l - f - 1 + 63) / 64;
-    if (nrow > rows_cap) { if (tid == 0) *status = ST_CAPACITY; return f + (l - f) / 2; }
+    if (nrow > rows_cap) {
+        if (nrow <= rows_long && gpos && (l - f) / 2 + 1 <= gpos_half) return wg_partition_long<SHIFT, T>(arr, f, l, lds, rows_cap, gpos, gpos_half);
+        if (tid == 0) *status = ST_CAPACITY;
+        return f + (l - f) / 2;
+    }
 #ifdef ISORT_TIMING
     long long _tm = __builtin_readcyclecounter();
 #endif
@@ -893,7 +1035,7 @@ __device__ int wg_partition(uint32_t* __restrict__ arr, int f, int l, uint8_t* l
 template <int SHIFT, int T>
 __device__ void global_tier(uint32_t* __restrict__ arr, const Range* __restrict__ init, int n_init, int n_stage, int nr_cap, Range* __restrict__ out_ranges,
                             Block* __restrict__ out_blocks, int max_blocks, int* __restrict__ out_counts, uint8_t* lds, int rows_cap, const HeapSink& HS, int* status,
-                            uint32_t skip_key = 0xffffffffu) {
+                            uint32_t skip_key = 0xffffffffu, int rows_long = 0, uint32_t* gpos = nullptr, int gpos_half = 0) {
     using GL = GlobalLayout<T>;
     Range* qb = (Range*)(lds + GL::off_q(rows_cap));
     Range* fin = (Range*)(lds + GL::off_fin(rows_cap));
@@ -917,7 +1059,7 @@ __device__ void global_tier(uint32_t* __restrict__ arr, const Range* __restrict_
         if (ncur == 0) break;
         for (int r = 0; r < ncur; r++) {
             const Range R = qb[cur * G_QMAX + r];
-            const int cut = wg_partition<SHIFT, T>(arr, R.f, R.l, lds, rows_cap, status);
+            const int cut = wg_partition<SHIFT, T>(arr, R.f, R.l, lds, rows_cap, status, rows_long, gpos, gpos_half);
             if (tid == 0) {
                 const bool drop_right = (uint32_t)((const int*)(lds + GL::off_buf(rows_cap)))[2 * GL::NW] > skip_key;   // the pivot's key (wg_partition's s_i[0])
 #pragma unroll

@@ -284,7 +284,7 @@ constexpr int SORT_HJOBS = 1024, SORT_HCAP = 8192, SORT_HY = 2;       // heap-so
 using SortLds = isort::LdsLayout<SORT_LT, SORT_E>;
 using SortGl = isort::GlobalLayout<SORT_T>;
 
-__global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int rows_cap) {
+__global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict__ plan, uint8_t* __restrict__ ws, Misc* __restrict__ miscs, int rows_cap, int rows_long) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     __shared__ isort::Range s_init;
     const Plan& P = *plan;
@@ -335,7 +335,8 @@ __global__ __launch_bounds__(SORT_T) void lsd_sort_global(const Plan* __restrict
     if (tid == 0) { misc->sort_kv = (int)kv; misc->sort_prefix = (int)s_prefix; }
     const isort::HeapSink HS{(isort::HeapJob*)(F + P.off_heapj), &misc->heap_n, SORT_HJOBS};
     isort::global_tier<SORT_SHIFT, SORT_T>(arr, &s_init, 1, SortLds::N, 64, (isort::Range*)(F + P.off_sortr), (isort::Block*)(F + P.off_sortb), isort::G_FMAX,
-                                           misc->sort_counts, sort_lds, rows_cap, HS, &misc->status, kv);
+                                           misc->sort_counts, sort_lds, rows_cap, HS, &misc->status, kv,
+                                           rows_long, (uint32_t*)(F + P.off_ord), n / 2 + 1);      // (frames beyond ~390 000 words: the long partition's scratch is the visiting-order array, not yet written)
     if (tid == 0) misc->t[5] = __builtin_readcyclecounter() - ts0;
 }
 
@@ -1542,7 +1543,7 @@ struct planar_lsd {
     int pre_B = 0;
     int tie_order = 0;   // 0: libstdc++ std::sort order inside a gradient bin (what the reference library produces), 1: raster order
     int top_only = 0;    // planar_lsd_set_top_only: the NFA stage only for the regions that can end among the max_lines kept key lines
-    int sort_smem_g = 0, sort_smem_l = 0, sort_rows = 0;
+    int sort_smem_g = 0, sort_smem_l = 0, sort_rows = 0, sort_rows_long = 0;
     // planar_lsd_set_profiling: HIP events around the launches of a recorded call; slots: preprocessing (two blurs, gradient, Sobel), lsd_sort, lsd_detect,
     // the rest (improve, accept, KeyLines, LBD)
     bool profiling = false;
@@ -1663,10 +1664,10 @@ int planar_lsd_create(planar_ctx* ctx, int width, int height, int max_batch, pla
     if (e == hipSuccess) e = hipMemcpy(o->d_cy.p, cy.data(), cy.size() * sizeof(lsd::Coef), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(o->d_taps.p, taps, sizeof(taps), hipMemcpyHostToDevice);
     // LDS of the sort kernels: the global tier keeps two stop bitmaps + two rank arrays over the longest range (all (w-1)(h-1) pixels), the LDS tier a block
-    o->sort_rows = lsd::SortGl::rows_for((P.w - 1) * (P.h - 1));
+    // (a working image of more than ~390 000 pixels - 1280x720 - does not fit the bitmaps: its long ranges go through isort::wg_partition_long, round 6)
+    if (!lsd::SortGl::plan((P.w - 1) * (P.h - 1), o->sort_rows, o->sort_rows_long)) { delete o; set_error("planar_lsd_create: image too large for the sort's LDS-resident rank prefixes (about 1.1 M working pixels)"); return PLANAR_EINVAL; }
     o->sort_smem_g = lsd::SortGl::bytes(o->sort_rows);
     o->sort_smem_l = lsd::SortLds::bytes;
-    if (o->sort_smem_g > 160 * 1024) { delete o; set_error("planar_lsd_create: image too large for the LDS-resident stop bitmaps of the sort"); return PLANAR_EINVAL; }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_detect, hipFuncAttributeMaxDynamicSharedMemorySize, o->detect_smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_sort_global, hipFuncAttributeMaxDynamicSharedMemorySize, o->sort_smem_g);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lsd::lsd_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, o->sort_smem_l);
@@ -1711,7 +1712,7 @@ int planar_lsd_preprocess_dev(planar_lsd* o, const uint8_t* d_gray, int B, int p
     if (o->ev_cur) (void)hipEventRecord((*o->ev_cur)[1], st);
     if (o->tie_order != 0) hipLaunchKernelGGL(lsd::lsd_sort_raster, dim3(B), dim3(lsd::SORT_NT), 0, st, dP, ws, dm);
     else {
-        hipLaunchKernelGGL(lsd::lsd_sort_global, dim3(B), dim3(lsd::SORT_T), o->sort_smem_g, st, dP, ws, dm, o->sort_rows);
+        hipLaunchKernelGGL(lsd::lsd_sort_global, dim3(B), dim3(lsd::SORT_T), o->sort_smem_g, st, dP, ws, dm, o->sort_rows, o->sort_rows_long);
         hipLaunchKernelGGL(lsd::lsd_sort_lds, dim3(B, lsd::SORT_R), dim3(lsd::SORT_LT), o->sort_smem_l, st, dP, ws, dm);
         hipLaunchKernelGGL(lsd::lsd_sort_heap, dim3(B, lsd::SORT_HY), dim3(64), lsd::SORT_HCAP * 4, st, dP, ws, dm);
         hipLaunchKernelGGL(lsd::lsd_sort_compact, dim3(B), dim3(lsd::SORT_T), 0, st, dP, ws, dm);

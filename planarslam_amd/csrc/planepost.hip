@@ -42,7 +42,8 @@ struct Geo {
     int W, H, max_points, pl_stride, tcap, mini;   // tcap = 2 * max_points key slots (frame workspace); mini: entries of a wavefront's tile table (LDS)
     float fx, fy, cx, cy, factor, leaf;
     double dist_th, log_probability, rfx, rfy;        // rfx, rfy = 1 / fx, 1 / fy (doubles)
-    size_t ws_stride, off_cnt, off_cent, off_key, off_rank, off_vstart, off_pl, off_init, off_meta, off_ranges, off_blocks, off_heapj, off_items, off_dsort;
+    size_t ws_stride, off_cnt, off_cent, off_key, off_rank, off_vstart, off_pl, off_init, off_meta, off_ranges, off_blocks, off_heapj, off_items, off_dsort, off_gpos;
+    int rows_long = 0, gpos_half = 0;               // frames whose largest possible plane does not fit the global tier's stop bitmaps (isort::wg_partition_long): prefix rows, scratch half
 };
 
 struct Pt { float x, y, z; };
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(NT) void plane_voxels_kernel(Geo G, const unsigned 
 }
 
 // The item array.  Workgroup of PS_T threads per frame; wavefront w owns the pixels [w * S, (w + 1) * S) in raster order.
+template <int SH>     // SH: bits of the pixel index in an item (19: frames of up to 2^19 pixels, 8192 voxels; 20: up to 2^20 pixels, 4096 voxels)
 __global__ __launch_bounds__(PS_T) void plane_items_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
                                                            const int* __restrict__ labels_all, unsigned char* ws_all) {
     constexpr int NW = PS_T / 64;
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(PS_T) void plane_items_kernel(Geo G, const unsigned
                 voxel_key(p.x, p.y, p.z, inv, (unsigned)l[u], key);
                 unsigned h = hash64(key) & (unsigned)(TC - 1);
                 for (int probe = 0; probe < TC && gkey[h] != key; probe++) h = (h + 1) & (unsigned)(TC - 1);
-                item = ((uint32_t)srank[h] << PS_SHIFT) | (uint32_t)pix;
+                item = ((uint32_t)srank[h] << SH) | (uint32_t)pix;
             }
             unsigned long long rem = __ballot(on);
             while (rem) {
@@ -588,14 +590,16 @@ __global__ __launch_bounds__(PS_T) void plane_items_kernel(Geo G, const unsigned
     }
 }
 
+template <int SH>
 __global__ __launch_bounds__(PS_T) void plane_sort_global(Geo G, unsigned char* ws_all, int rows_cap) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
     Meta* meta = (Meta*)(ws + G.off_meta);
     if (meta->err || meta->n_init == 0) return;
     const isort::HeapSink HS{(isort::HeapJob*)(ws + G.off_heapj), &meta->heap_n, PS_HJOBS};
-    isort::global_tier<PS_SHIFT, PS_T>((uint32_t*)(ws + G.off_items), (const isort::Range*)(ws + G.off_init), meta->n_init, PsLds::N, 64, (isort::Range*)(ws + G.off_ranges),
-                                       (isort::Block*)(ws + G.off_blocks), isort::G_FMAX, meta->counts, sort_lds, rows_cap, HS, &meta->sort_status);
+    isort::global_tier<SH, PS_T>((uint32_t*)(ws + G.off_items), (const isort::Range*)(ws + G.off_init), meta->n_init, PsLds::N, 64, (isort::Range*)(ws + G.off_ranges),
+                                 (isort::Block*)(ws + G.off_blocks), isort::G_FMAX, meta->counts, sort_lds, rows_cap, HS, &meta->sort_status, 0xffffffffu,
+                                 G.rows_long, G.rows_long ? (uint32_t*)(ws + G.off_gpos) : nullptr, G.gpos_half);
     __syncthreads();
     if (threadIdx.x == 0) meta->heap_n_global = min(meta->heap_n, PS_HJOBS);
 }
@@ -605,6 +609,7 @@ __global__ __launch_bounds__(PS_T) void plane_sort_global(Geo G, unsigned char* 
 // LDS tier instead of after it, on the same stream (a side stream per handle cost more than it hid: the pipeline's streams already outnumber the hardware queues).
 constexpr int PS_EARLY = 4;
 // (four wavefronts per SIMD = four workgroups per CU, what their 40 KB of LDS allow: 128 VGPRs with 23 spilled measure 13 % faster than 163 unspilled at three)
+template <int SH>
 __global__ __launch_bounds__(PS_LT, 4) void plane_sort_lds(Geo G, unsigned char* ws_all) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(PS_LT, 4) void plane_sort_lds(Geo G, unsigned char*
         static_assert(PsLds::bytes >= PS_HC[2].cap * 4, "the early heap jobs keep the top PS_HC[2].cap words of a range in this workgroup's LDS");
         const int ng = meta->heap_n_global;
         if (threadIdx.x < 64 && ng > 0 && !G.dev_skip_heap)
-            isort::heap_jobs<PS_SHIFT>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj), ng, blockIdx.y, PS_EARLY, (uint32_t*)sort_lds, PS_HC[2].cap, 0, 1 << 30);
+            isort::heap_jobs<SH>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj), ng, blockIdx.y, PS_EARLY, (uint32_t*)sort_lds, PS_HC[2].cap, 0, 1 << 30);
         return;
     }
     const isort::Range* ranges = (const isort::Range*)(ws + G.off_ranges);
@@ -623,17 +628,18 @@ __global__ __launch_bounds__(PS_LT, 4) void plane_sort_lds(Geo G, unsigned char*
     const isort::HeapSink HS{(isort::HeapJob*)(ws + G.off_heapj), &meta->heap_n, PS_HJOBS};
     for (int k = blockIdx.y - PS_EARLY; k < nb; k += gridDim.y - PS_EARLY) {
         const isort::Block K = blocks[k];
-        isort::lds_tier<PS_SHIFT, PS_LT, PS_E>((uint32_t*)(ws + G.off_items), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &meta->sort_status);
+        isort::lds_tier<SH, PS_LT, PS_E>((uint32_t*)(ws + G.off_items), ranges + K.r0, K.nr, K.f, K.l, sort_lds, HS, &meta->sort_status);
     }
 }
 
 // part 1: the jobs of the LDS tier (part 0, the global tier's, ran inside plane_sort_lds)
+template <int SH>
 __global__ __launch_bounds__(256) void plane_sort_heap(Geo G, unsigned char* ws_all, int part, int min_len, int max_len, int cap) {
     extern __shared__ __align__(16) uint8_t sort_lds[];
     unsigned char* ws = ws_all + (size_t)blockIdx.x * G.ws_stride;
     const Meta* meta = (const Meta*)(ws + G.off_meta);
     const int ng = meta->heap_n_global, lo = part ? ng : 0, hi = meta->err ? 0 : (part ? min(meta->heap_n, PS_HJOBS) : ng), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (hi > lo) isort::heap_jobs<PS_SHIFT>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj) + lo, hi - lo, blockIdx.y * nw + wave, gridDim.y * nw,
+    if (hi > lo) isort::heap_jobs<SH>((uint32_t*)(ws + G.off_items), (const isort::HeapJob*)(ws + G.off_heapj) + lo, hi - lo, blockIdx.y * nw + wave, gridDim.y * nw,
                                            (uint32_t*)sort_lds + (size_t)wave * cap, cap, min_len, max_len);
 }
 
@@ -648,6 +654,7 @@ __device__ __forceinline__ Pt cam_point_thread(const Geo& G, unsigned short d, i
     return {(float)tx, (float)ty, (float)z};
 }
 
+template <int SH>
 __global__ __launch_bounds__(NT, 4) void plane_tail_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
                                                         const double* __restrict__ planes_all, int planes_stride, const int* __restrict__ rng, unsigned char* ws_all,
                                                         int* n_out, float* coef_out, int* src_out, int* off_out, float* pts_out, int* status, int* state_out,
@@ -681,7 +688,7 @@ __global__ __launch_bounds__(NT, 4) void plane_tail_kernel(Geo G, const unsigned
         unsigned short* dsort = (unsigned short*)(ws + G.off_dsort);
         const int total = M > 0 ? vstart[M] : 0;
         for (int i = tid; i < total; i += NT) {
-            const int pix = (int)(items[i] & ((1u << PS_SHIFT) - 1u)), yy = pix / G.W;
+            const int pix = (int)(items[i] & ((1u << SH) - 1u)), yy = pix / G.W;
             dsort[i] = D[(size_t)yy * pitch_px + (pix - yy * G.W)];
         }
         __threadfence_block();
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(NT, 4) void plane_tail_kernel(Geo G, const unsigned
 #pragma unroll
                 for (int u = 0; u < U; u++)
                     if (i + u < i1) {
-                        const int pix = (int)(it[u] & ((1u << PS_SHIFT) - 1u)), yy = pix / G.W;
+                        const int pix = (int)(it[u] & ((1u << SH) - 1u)), yy = pix / G.W;
                         const Pt p = cam_point_thread(G, d[u], pix - yy * G.W, yy);
                         cx += p.x; cy += p.y; cz += p.z;
                     }
@@ -933,7 +940,7 @@ struct planar_plane_clouds {
     int max_batch = 0;
     planar::planepost::Geo G{};
     size_t smem = 0, smem_tail = 0, smem_cloud = 0, smem_sort_g = 0, smem_sort_l = 0;
-    int sort_rows = 0;
+    int sort_rows = 0, shift = 19;
     planar::DevBuf ws, rng, dbg;
     bool timing = false;
     std::vector<int32_t> last_status;           // per-frame codes of the last host-pointer compute call
@@ -953,7 +960,9 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
     PLANAR_REQUIRE(ctx && out, PLANAR_EINVAL, "null argument");
     PLANAR_REQUIRE(width >= 16 && height >= 16 && width <= 4096 && height <= 4096 && max_batch >= 1, PLANAR_EINVAL, "bad size");
     PLANAR_REQUIRE(max_points >= 64 && max_points <= 8192 && (max_points & (max_points - 1)) == 0, PLANAR_EINVAL, "max_points must be a power of two in [64, 8192]");
-    PLANAR_REQUIRE((long long)width * height <= (1ll << planepost::PS_SHIFT), PLANAR_EINVAL, "at most 2^19 pixels per frame (a sort word is voxel << 19 | pixel)");
+    // a sort word is voxel << shift | pixel: 19 bits of pixel (8192 voxels) up to 2^19 pixels, 20 bits (4096 voxels) up to 2^20 - 1280x720 (round 6)
+    PLANAR_REQUIRE((long long)width * height <= (1ll << 20), PLANAR_EINVAL, "at most 2^20 pixels per frame (a sort word is voxel << 20 | pixel)");
+    PLANAR_REQUIRE((long long)width * height <= (1ll << planepost::PS_SHIFT) || max_points <= 4096, PLANAR_EINVAL, "frames of more than 2^19 pixels take max_points <= 4096 (12 bits of voxel beside 20 bits of pixel)");
     PLANAR_HIP_CHECK(hipSetDevice(ctx->device));
     planar_plane_clouds* p = new planar_plane_clouds;
     p->ctx = ctx; p->max_batch = max_batch;
@@ -978,8 +987,13 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
         G.off_heapj = carve((size_t)planepost::PS_HJOBS * sizeof(isort::HeapJob));
         G.off_items = carve(std::max((size_t)width * height, (size_t)65536) * 4);   // (voxel << 19 | pixel) per member pixel; the map-side merge sorts up to 65536 points here
         G.off_dsort = carve((size_t)width * height * 2);            // the items' depth values, in sorted order (plane_tail_kernel)
+        // the global tier of the sort: stop bitmaps for a range as long as the frame where that fits the LDS, else rank prefixes only + a scratch array for the swap partners
+        if (!planepost::PsGl::plan(std::max(width * height, 65536), p->sort_rows, G.rows_long)) { delete p; set_error("plane_clouds: frame too large for the sort's LDS-resident rank prefixes"); return PLANAR_EINVAL; }
+        G.gpos_half = G.rows_long ? width * height / 2 + 2 : 0;
+        G.off_gpos = carve(G.rows_long ? (size_t)G.gpos_half * 2 * 4 : 0);
         G.ws_stride = off;
     }
+    p->shift = (long long)width * height <= (1ll << planepost::PS_SHIFT) ? planepost::PS_SHIFT : 20;
     G.mini = 128;
     // LDS of plane_voxels_kernel: eight tile tables of 128 entries x 12 B while the pixels are counted, the list of occupied slots (max_points x 8 B)
     // while they are sorted: 32 KB at the default 4096 voxels per frame, 64 KB at 8192.  The frame's key table itself (2 * max_points slots) lives in
@@ -987,7 +1001,6 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
     p->smem = std::max((size_t)(planepost::NT / 64) * G.mini * 12, (size_t)max_points * 8);
     p->smem_tail = (size_t)max_points * 2;
     p->smem_cloud = (size_t)G.tcap * 8;
-    p->sort_rows = planepost::PsGl::rows_for(std::max(width * height, 65536));
     p->smem_sort_g = (size_t)planepost::PsGl::bytes(p->sort_rows);
     p->smem_sort_l = (size_t)planepost::PsLds::bytes;
     int rc = p->ws.alloc(G.ws_stride * (size_t)max_batch);
@@ -1000,9 +1013,12 @@ int planar_plane_clouds_create(planar_ctx* ctx, int width, int height, int max_b
         hipError_t e = hipSuccess;
         if (p->smem > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::plane_voxels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem);
         if (e == hipSuccess && p->smem_cloud > 40 * 1024) e = hipFuncSetAttribute((const void*)planepost::cloud_voxels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_cloud);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_g);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_l);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_heap, hipFuncAttributeMaxDynamicSharedMemorySize, planepost::PS_HC[2].cap * 4);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_global<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_g);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_lds<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_l);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_heap<19>, hipFuncAttributeMaxDynamicSharedMemorySize, planepost::PS_HC[2].cap * 4);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_global<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_g);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_lds<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->smem_sort_l);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planepost::plane_sort_heap<20>, hipFuncAttributeMaxDynamicSharedMemorySize, planepost::PS_HC[2].cap * 4);
         if (e != hipSuccess) { (void)hipGetLastError(); set_error("plane_clouds: %zu bytes of LDS per workgroup are not available", std::max(std::max(p->smem, p->smem_cloud), p->smem_sort_g)); delete p; return PLANAR_EINVAL; }
     }
     *out = p;
@@ -1114,20 +1130,23 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     mark();
     hipLaunchKernelGGL(planepost::plane_voxels_kernel, dim3(B), dim3(planepost::NT), p->smem, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, d_n_planes, ws, tm);
     mark();
-    hipLaunchKernelGGL(planepost::plane_items_kernel, dim3(B), dim3(planepost::PS_T), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
+    // (the item word's pixel field: 19 bits, or 20 for frames of more than 2^19 pixels - two instantiations of the five kernels that read it)
+#define PLANAR_BY_SHIFT(K, ...) do { if (p->shift == 20) hipLaunchKernelGGL(planepost::K<20>, __VA_ARGS__); else hipLaunchKernelGGL(planepost::K<19>, __VA_ARGS__); } while (0)
+    PLANAR_BY_SHIFT(plane_items_kernel, dim3(B), dim3(planepost::PS_T), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
     mark();
-    hipLaunchKernelGGL(planepost::plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
+    PLANAR_BY_SHIFT(plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
     mark();
     auto heap_launch = [&](hipStream_t q, int part, int c) {
         const planepost::HeapClass& H = planepost::PS_HC[c];
-        hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(B, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, q, G, ws, part, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
+        PLANAR_BY_SHIFT(plane_sort_heap, dim3(B, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, q, G, ws, part, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
     };
-    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(B, planepost::PS_EARLY + planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);   // + the global tier's fallback jobs
+    PLANAR_BY_SHIFT(plane_sort_lds, dim3(B, planepost::PS_EARLY + planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);   // + the global tier's fallback jobs
     mark();
     heap_launch(st, 1, 0); heap_launch(st, 1, 1);            // the LDS tier's jobs (at most a block long)
     mark();
-    hipLaunchKernelGGL(planepost::plane_tail_kernel, dim3(B), dim3(planepost::NT), p->smem_tail, st, G, d_depth, pitch_px, (long)frame_stride_px, d_planes,
-                       planar_peac_max_planes(), p->rng.as<int>(), ws, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox, d_info, tm);
+    PLANAR_BY_SHIFT(plane_tail_kernel, dim3(B), dim3(planepost::NT), p->smem_tail, st, G, d_depth, pitch_px, (long)frame_stride_px, d_planes,
+                    planar_peac_max_planes(), p->rng.as<int>(), ws, d_n_out, d_coef, d_src, d_pt_off, d_points, d_status, d_state, d_nvox, d_info, tm);
+#undef PLANAR_BY_SHIFT
     mark();
     PLANAR_HIP_CHECK(hipGetLastError());
     return PLANAR_OK;
@@ -1244,11 +1263,11 @@ int planar_merge_plane_points(planar_plane_clouds* p, const double* Twc, const f
     if (n) hipLaunchKernelGGL(planepost::merge_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.dev<double>(i_T), s.dev<float>(i_f), n_frame, s.dev<float>(i_m), n_map, s.dev<float>(t_all));
     unsigned char* ws = p->ws.as<unsigned char>();
     hipLaunchKernelGGL(planepost::cloud_voxels_kernel, dim3(1), dim3(planepost::NT), p->smem_cloud, st, G, s.dev<float>(t_all), n, ws);
-    hipLaunchKernelGGL(planepost::plane_sort_global, dim3(1), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
-    hipLaunchKernelGGL(planepost::plane_sort_lds, dim3(1, planepost::PS_EARLY + planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);
+    hipLaunchKernelGGL(planepost::plane_sort_global<planepost::PS_SHIFT>, dim3(1), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
+    hipLaunchKernelGGL(planepost::plane_sort_lds<planepost::PS_SHIFT>, dim3(1, planepost::PS_EARLY + planepost::PS_R), dim3(planepost::PS_LT), p->smem_sort_l, st, G, ws);
     for (int c = 0; c < 2; c++) {                            // the LDS tier's fallback jobs (the global tier's ran inside plane_sort_lds)
         const planepost::HeapClass& H = planepost::PS_HC[c];
-        hipLaunchKernelGGL(planepost::plane_sort_heap, dim3(1, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, 1, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
+        hipLaunchKernelGGL(planepost::plane_sort_heap<planepost::PS_SHIFT>, dim3(1, H.wgs), dim3(64 * H.waves), (size_t)H.cap * 4 * H.waves, st, G, ws, 1, c ? planepost::PS_HC[c - 1].max_len + 1 : 0, H.max_len, H.cap);
     }
     hipLaunchKernelGGL(planepost::cloud_sums_kernel, dim3(1), dim3(planepost::NT), 0, st, G, s.dev<float>(t_all), ws, s.dev<float>(t_out), s.dev<int>(o_h), s.dev<int>(o_h) + 1);
     PLANAR_HIP_CHECK(hipGetLastError());

@@ -13,12 +13,14 @@
 using namespace planar::isort;
 
 namespace {
-struct GArgs { uint32_t* arr; const Range* init; int n_init, n_stage, nr_cap; Range* ranges; Block* blocks; int max_blocks; int* counts; int rows_cap; int* status; int shift; HeapSink HS; uint32_t skip_key; };
+struct GArgs { uint32_t* arr; const Range* init; int n_init, n_stage, nr_cap; Range* ranges; Block* blocks; int max_blocks; int* counts; int rows_cap; int* status; int shift; HeapSink HS; uint32_t skip_key;
+               int rows_long; uint32_t* gpos; int gpos_half; };
 template <int SHIFT, int T>
 void g_entry(void* p) {
     auto* A = (GArgs*)p;
     PLANAR_DYN_SMEM(lds);
-    global_tier<SHIFT, T>(A->arr, A->init, A->n_init, A->n_stage, A->nr_cap, A->ranges, A->blocks, A->max_blocks, A->counts, lds, A->rows_cap, A->HS, A->status, A->skip_key);
+    global_tier<SHIFT, T>(A->arr, A->init, A->n_init, A->n_stage, A->nr_cap, A->ranges, A->blocks, A->max_blocks, A->counts, lds, A->rows_cap, A->HS, A->status, A->skip_key,
+                          A->rows_long, A->gpos, A->gpos_half);
 }
 struct LArgs { uint32_t* arr; const Range* ranges; int nr, f, l; int* status; HeapSink HS; uint32_t skip_key; };
 struct HArgs { uint32_t* arr; const HeapJob* jobs; int njobs, cap; };
@@ -35,7 +37,7 @@ void l_entry(void* p) {
     lds_tier<SHIFT, T, E>(A->arr, A->ranges, A->nr, A->f, A->l, lds, A->HS, A->status, A->skip_key);
 }
 template <int SHIFT, int TG, int T, int E>
-int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status, long* stats, int heap_cap = 36864, uint32_t skip_key = 0xffffffffu) {
+int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status, long* stats, int heap_cap = 36864, uint32_t skip_key = 0xffffffffu, int force_rows_cap = 0) {
     std::vector<Range> init(n_ranges);
     int longest = 0;
     for (int i = 0; i < n_ranges; i++) {
@@ -45,14 +47,21 @@ int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status
         longest = std::max(longest, n);
     }
     if (n_stage <= 0 || n_stage > T * E) n_stage = T * E;
-    const int rows_cap = GlobalLayout<TG>::rows_for(longest);
+    // the product's sizing (GlobalLayout::plan over the whole array), or - force_rows_cap - bitmaps for short ranges only, so that every longer range takes wg_partition_long
+    const int total = bounds[n_ranges] - bounds[0];
+    int rows_cap = 0, rows_long = 0;
+    if (force_rows_cap > 0) {
+        rows_cap = force_rows_cap; rows_long = GlobalLayout<TG>::rows_for(total);
+        if (GlobalLayout<TG>::off_q(rows_cap) < GlobalLayout<TG>::long_bytes(rows_long)) throw std::runtime_error("forced rows_cap too small for the long path's prefixes");
+    } else if (!GlobalLayout<TG>::plan(longest, rows_cap, rows_long)) throw std::runtime_error("array too large for the global tier");
+    std::vector<uint32_t> gpos((size_t)2 * (total / 2 + 1) + 2);
     std::vector<Range> ranges(G_FMAX);
     std::vector<Block> blocks(G_FMAX);
     int counts[2] = {0, 0};
     std::vector<HeapJob> jobs(4096);
     int njobs = 0;
     const HeapSink HS{jobs.data(), &njobs, (int)jobs.size()};
-    GArgs ga{arr, init.data(), n_ranges, n_stage, std::min(T, 64), ranges.data(), blocks.data(), G_FMAX, counts, rows_cap, status, SHIFT, HS, skip_key};
+    GArgs ga{arr, init.data(), n_ranges, n_stage, std::min(T, 64), ranges.data(), blocks.data(), G_FMAX, counts, rows_cap, status, SHIFT, HS, skip_key, rows_long, gpos.data(), total / 2 + 1};
     wave_emul::Dim3 bi, bd; bd.x = TG; bd.y = 1; bd.z = 1;
     wave_emul::launch_block(g_entry<SHIFT, TG>, &ga, TG, bi, bd, (size_t)GlobalLayout<TG>::bytes(rows_cap), 256 * 1024);
     if (stats) { stats[0] = counts[0]; stats[1] = counts[1]; stats[2] = wave_emul::S().n_sync; }
@@ -77,7 +86,7 @@ int run(uint32_t* arr, const int* bounds, int n_ranges, int n_stage, int* status
 
 extern "C" {
 // arr [total]: in/out.  bounds [n_ranges + 1]: every [bounds[i], bounds[i+1]) is sorted on its own, as std::sort(first, last, key <) would.
-// config 0: the product's shapes (global tier 1024 threads; LDS tier 256 threads x 23 elements: planepost.hip PS_T / PS_LT / PS_E, lsd.hip SORT_*); 4: 512 x 23; 1: small shapes that force many levels and the
+// config 0: the product's shapes (global tier 1024 threads; LDS tier 256 threads x 23 elements: planepost.hip PS_T / PS_LT / PS_E, lsd.hip SORT_*); 4: 512 x 23; 5: the product's shapes with stop bitmaps for ranges of <= 16 384 words only (every longer range goes through wg_partition_long, the path of frames beyond ~390 000 words); 1: small shapes that force many levels and the
 // global tier on short arrays (256 threads; 256 x 5).  shift: 19 or 20.  n_stage: LDS-tier capacity override (0 = the configuration's).
 // Returns 0, or -1 with a message in err.  stats [8] (last two: elements that went through the heap-sort fallback, its jobs): ranges, blocks, rendezvous count after the global tier, after everything, LDS-tier levels, segments partitioned there.
 int isort_emul(uint32_t* arr, const int* bounds, int n_ranges, int shift, int config, int n_stage, int* status, long* stats, char* err, int errlen) {
@@ -89,6 +98,8 @@ int isort_emul(uint32_t* arr, const int* bounds, int n_ranges, int shift, int co
         if (shift == 20 && config == 1) return run<20, 256, 256, 5>(arr, bounds, n_ranges, n_stage, status, stats);
         if (shift == 19 && config == 2) return run<19, 256, 128, 32>(arr, bounds, n_ranges, n_stage, status, stats);
         if (shift == 19 && config == 4) return run<19, 1024, 512, 23>(arr, bounds, n_ranges, n_stage, status, stats);                  // eight wavefronts per LDS block
+        if (shift == 19 && config == 5) return run<19, 1024, 256, 23>(arr, bounds, n_ranges, n_stage, status, stats, 36864, 0xffffffffu, 256);  // bitmaps for <= 16 384 words only: longer ranges through wg_partition_long
+        if (shift == 20 && config == 5) return run<20, 1024, 256, 23>(arr, bounds, n_ranges, n_stage, status, stats, 36864, 0xffffffffu, 256);
         if (shift == 19 && config == 3) return run<19, 1024, 256, 23>(arr, bounds, n_ranges, n_stage, status, stats, 1000);   // fallback jobs with only 1000 words in LDS
         throw std::runtime_error("isort_emul: unknown configuration");
     } catch (const std::exception& e) { snprintf(err, errlen, "%s", e.what()); return -1; }

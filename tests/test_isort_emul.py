@@ -83,6 +83,21 @@ def test_production_shapes(lib, seed):
     assert st[1] >= 3
 
 
+def test_ranges_longer_than_the_stop_bitmaps(lib):
+    """Frames beyond ~390 000 sort words (1280x720: LSD's 589 000 gradient pixels, a wall of 900 000 plane points) do not fit the global tier's LDS bitmaps: such a range is
+    partitioned by wg_partition_long (rank prefixes only in LDS, ballots recomputed, swap partners through a scratch array).  Configuration 5 gives the bitmaps 16 384 words, so
+    the top levels of these arrays take that path and the rest the ordinary one: word for word std::sort's arrangement."""
+    rng = np.random.default_rng(31)
+    sizes = [150000, 9000, 40000, 16385, 16384, 700]
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(bounds[-1])
+    keys = np.concatenate([_voxel_like(rng, s, 26, 1500) for s in sizes])
+    _check(lib, keys, bounds, 19, 5)
+    _check(lib, rng.integers(0, 1 << 10, n), [0, n], 20, 5)
+    g = np.abs(rng.normal(0, 1, n)) ** 3
+    _check(lib, 1023 - np.minimum((g / g.max() * 1023).astype(np.int64), 1023), [0, n], 20, 5)
+
+
 def test_lsd_like_keys(lib):
     """the 1024-bin gradient norm of an image: most pixels in the lowest bins, a long tail; descending order = ascending 1023 - bin"""
     rng = np.random.default_rng(5)

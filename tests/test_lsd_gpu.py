@@ -145,8 +145,10 @@ def test_many_segments_sort_in_global_scratch(ctx):
     np.testing.assert_array_equal(desc[0], rd)
 
 
-@pytest.mark.parametrize("size", [(752, 480), (320, 240), (500, 375)])
+@pytest.mark.parametrize("size", [(752, 480), (320, 240), (500, 375), (1280, 720)])
 def test_other_image_sizes(ctx, size):
+    """(1280 x 720, round 6: 589 000 gradient pixels at the 0.8x working scale do not fit the sort's LDS stop bitmaps: the top levels of the std::sort arrangement go through
+    isort::wg_partition_long - rank prefixes in LDS, ballots recomputed, swap partners through a scratch array)"""
     from planarslam_amd.lines import LineSegment
     W, H = size
     img = synth.gray_image(31, w=W, h=H)

@@ -220,6 +220,34 @@ def test_plane_clouds_other_size_and_row_pitch():
     assert n[0] == k and np.array_equal(off[0, :k + 1], got["pt_off"]) and np.array_equal(coef[0, :k], got["coef"]) and np.array_equal(pts[0, :off[0, k]], got["points"])
 
 
+def test_plane_clouds_of_a_1280x720_frame():
+    """Round 6: frames of more than 2^19 pixels.  A sort word carries 20 bits of pixel and 12 of voxel there (max_points <= 4096), and a plane of more than ~243 000 pixels
+    does not fit the sort's LDS stop bitmaps (isort::wg_partition_long).  PlaneDetection's labels and planes, the voxel centroids (bit-exact: PCL's float sums in std::sort's
+    order) and the refit against the oracle; 8192 voxels are refused for such a frame."""
+    from planarslam_amd import PlaneClouds, PlaneDetection
+    from planarslam_amd._lib import PlanarError
+    W, H = 1280, 720
+    cam = (1070.8, 1078.4, 640.2, 495.2)
+    with pytest.raises(PlanarError):
+        PlaneClouds(W, H, max_points=8192)
+    pcz = PlaneClouds(W, H, max_batch=2, max_points=4096)
+    ds = np.stack([depth_image(1587 + 11 * i, W, H, noise=(i == 0), holes=True) for i in range(2)])
+    res = PlaneDetection(W, H, max_batch=2).run(ds, K=cam)
+    pl = np.zeros((2, pcz.pl_stride, 8)); npl = np.zeros(2, np.int32)
+    for b in range(2):
+        op, olab = ol.peac_run(ds[b], *cam)
+        assert np.array_equal(res[b][1], olab) and np.array_equal(res[b][0], op)
+        pl[b, :len(op)] = op; npl[b] = len(op)
+    assert max(int((res[0][1] == q).sum()) for q in range(npl[0])) > 300000          # a plane longer than the stop bitmaps hold
+    got = pcz.compute(ds, np.stack([r[1] for r in res]), pl, npl, K=cam, debug=True)
+    for b in range(2):
+        want = ol.plane_clouds(ds[b], res[b][1], res[b][0], cam=cam)
+        g = got[b]
+        assert g["n"] == want["n"] and np.array_equal(g["state"], want["state"]) and np.array_equal(g["pt_off"], want["pt_off"]) and np.array_equal(g["nvox"], want["nvox"])
+        assert np.array_equal(g["points"], want["points"]), "voxel centroids differ from the oracle (PCL's summation order)"
+        assert np.abs(g["coef"] - want["coef"]).max(initial=0) <= 1e-6
+
+
 def far_room_depth():
     """A room seen from far: floor, ceiling, back wall and two side walls at 5-10 m, noise-free.  Its planes together hold about 16 000 voxels of 0.1 m - twice what
     the frame's voxel table holds (max_points <= 8192) - but none of them more than the table.  pcl::VoxelGrid has no cap (reference src/Frame.cc:674-679)."""
