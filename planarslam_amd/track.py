@@ -263,7 +263,8 @@ class TrackPipeline:
 
     def _planes(self, w, k, depth):
         """PlaneDetection (PEAC) - plane stream"""
-        self.pds[w].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), self.B)
+        self.pds[w].segment_dev(depth.data_ptr(), self.lab[k].data_ptr(), self.pls[k].data_ptr(), self.npl[k].data_ptr(), self.B,
+                                K=(self.cam["fx"], self.cam["fy"], self.cam["cx"], self.cam["cy"]))      # PlaneDetection::readDepthImage(Depth, K, ...): the frame's intrinsics
 
     def _plane_clouds(self, w, k, depth):
         """Frame::ComputePlanes' voxel clouds + RANSAC refit (Frame.cc:655-692) - plane stream"""
@@ -534,7 +535,7 @@ def build_map(gray0, depth0, cam, torch_dev=None, seed=0, n_map_planes=8, n_plan
             normal[b, i] = mid / max(d, 1e-9); maxd[b, i] = d * 1.2 ** 3; mind[b, i] = maxd[b, i] / 1.2 ** 7
     kf_lines = dict(n=nl.astype(np.int32), ldesc=ldesc, xw6=xw6, normal=normal, min_dist=mind, max_dist=maxd)
     pd = PlaneDetection(W, H, max_batch=min(B, CH))
-    res = [r for a in range(0, B, CH) for r in pd.run(depth0[a:a + CH].astype(np.uint16))]
+    res = [r for a in range(0, B, CH) for r in pd.run(depth0[a:a + CH].astype(np.uint16), K=(fx, fy, cx, cy))]
     del pd
     M, P = n_map_planes, n_plane_pts
     mp = dict(n=np.zeros(B, np.int32), valid=np.zeros((B, M), np.uint8), coef=np.zeros((B, M, 4), np.float32), npts=np.zeros((B, M), np.int32), pts=np.zeros((B, M, P, 3), np.float32))

@@ -479,3 +479,52 @@ def test_cu_partition_and_extractor_sets_do_not_change_results():
     assert (nw0, ns0) == (4, 0) and (nw1, ns1) == (2, 1)
     for key in base:
         assert np.array_equal(base[key], part[key], equal_nan=True), key
+
+
+def test_pipeline_tracks_a_1280x720_stream():
+    """Round 6: the whole per-frame path at 1280 x 720 (the sizes the plane and line extractors refused before): SE3-rendered HD streams, the tracker's pose against the
+    true camera motion, and the extractors' outputs of the last step against the oracle for one stream."""
+    import torch
+    from planarslam_amd import synth_se3
+    from planarslam_amd._lib import KP_DTYPE
+    from planarslam_amd.synth import gray_image
+    from planarslam_amd.track import TrackPipeline, build_map
+    Wh, Hh = 1280, 720
+    cam = dict(TUM3, fx=2 * TUM3["fx"], fy=2 * TUM3["fy"], cx=2 * TUM3["cx"], cy=2 * TUM3["cy"], bf=2 * TUM3["bf"])
+    Bs, K, n_steps = 4, 6, 8
+    dev = torch.device("cuda", 0)
+    tex = torch.from_numpy(np.stack([gray_image(77 + i, 736, 576) for i in range(2)])).to(dev)
+    loop_g, loop_d, Twc = synth_se3.render_streams(torch, tex, Bs, K, cam, seed=5, W=Wh, H=Hh)
+    tp = TrackPipeline(Bs, torch, 0, depth=1, cam=cam, W=Wh, H=Hh)
+    tp.set_map(*build_map(loop_g[:, 0].cpu().numpy(), loop_d[:, 0].cpu().numpy().view(np.uint16), cam, seed=1))
+    tp.capture_steps = {n_steps - 1}
+    frames = [torch.zeros((Bs, Hh, Wh), dtype=torch.uint8, device=dev) for _ in range(tp.NB)]
+    depths = [torch.zeros((Bs, Hh, Wh), dtype=torch.int16, device=dev) for _ in range(tp.NB)]
+    with torch.cuda.stream(tp.stream):
+        for i in range(n_steps):
+            k = i % tp.NB
+            tp.stream.wait_event(tp.done[k])
+            fi = synth_se3.frame_index(i, K)
+            frames[k].copy_(loop_g[:, fi]); depths[k].copy_(loop_d[:, fi])
+            tp.step(i, frames[k], depths[k])
+        tp.drain()
+    torch.cuda.synchronize()
+    tp.check()
+    c = tp.captured[n_steps - 1]
+    fi = synth_se3.frame_index(n_steps - 1, K)
+    T = c["pose_out"].cpu().numpy().reshape(Bs, 4, 4).astype(np.float64)
+    dt = [np.linalg.norm(T[b, :3, 3] - synth_se3.relative_pose(Twc[b], fi, 0)[:3, 3]) for b in range(Bs)]
+    # (the reference's search radii are in pixels and the streams move twice as many pixels per frame as at 640x480: some streams lose track with the zero-velocity
+    #  motion model - a property of the tracker's parameters, the same in the oracle -, so the pose check asks for the streams that hold on, the stage checks below for parity)
+    assert np.isfinite(T).all() and sorted(dt)[len(dt) // 2 - 1] < 0.02, dt
+    # stream 0 of the last step against the oracle: key points, key lines, plane labels
+    b = 0
+    g = loop_g[b, fi].cpu().numpy(); d = loop_d[b, fi].cpu().numpy().view(np.uint16)
+    n = int(c["n"][b]); kps = c["kps"][b, :n].cpu().numpy().copy().view(KP_DTYPE).reshape(n)
+    okps, odesc = ol.OrbOracle().extract(g)
+    assert kps.tobytes() == okps.tobytes() and np.array_equal(c["desc"][b, :n].cpu().numpy(), odesc)
+    rk, rd, re, _, nd = ol.extract_line_segment(g, tie_order=0)
+    nl = int(c["nl"][b])
+    assert nl == len(rk) and np.array_equal(c["ldesc"][b, :nl].cpu().numpy(), rd)
+    op, olab = ol.peac_run(d, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    assert np.array_equal(c["lab"][b].cpu().numpy().reshape(Hh, Wh), olab) and int(c["npl"][b]) == len(op) >= 2
