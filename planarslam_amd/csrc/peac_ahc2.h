@@ -1072,6 +1072,9 @@ __device__ __forceinline__ int ahc_frame(const Layout& L, const Consts& C, uint8
 __global__ __launch_bounds__(64) void peac_ahc3(Layout L, Consts C, uint8_t* __restrict__ ws, int32_t* __restrict__ status,
                                                 long long* __restrict__ timing, int* __restrict__ next_frame, const int* __restrict__ order, int retry_inline) {
     __shared__ int s_frame;
+#if defined(PLANAR_AHC_PRIO) && !defined(PLANAR_WAVE_EMUL)
+    __builtin_amdgcn_s_setprio(PLANAR_AHC_PRIO);             // (experiment: issue priority of the clustering wavefront over the wide kernels' wavefronts on its SIMD)
+#endif
     if (threadIdx.x == 0) { const int k = atomicAdd(next_frame, 1); s_frame = order ? order[k] : k; }
     __syncthreads();
     const int st = ahc_frame<true>(L, C, ws, status, timing, s_frame);
