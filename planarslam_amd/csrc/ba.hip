@@ -9,17 +9,18 @@
 //   ba_linearize thread = edge        Jacobians (analytic point/line; the numeric ones from ba_numjac), the edge's coupling block W = B^T (w Omega) A (6x3) and
 //                                     its landmark-block contribution; pose blocks Hpp / bp (lower triangle) are summed in LDS per workgroup, then flushed
 //                                     with FP64 atomics
-//   ba_gather    thread = landmark    Hll (3x3), bl = sum of its edges' contributions in edge order
+//   ba_gather    4 lanes = landmark   Hll (3x3), bl = sum of its edges' contributions; thread = (landmark, key frame) pair: the sum of its edges' coupling blocks
 //   ba_dinv      thread = landmark    Dinv = (Hll + lambda I)^-1, Dinv bl; also prepares the trial's exchange buffers (redg <- red, red2 <- 0, trial <- 0)
-//   ba_schur     thread = (edge, 1/4 of its partner edges)   S[p(e)][q(f)] -= W_e Dinv W_f^T over the edges f of e's landmark, b -= W_e Dinv bl, accumulated in an
-//                                     LDS copy of the reduced system (<= 120 x 120 doubles) per workgroup, then flushed (lower triangle)
-// Round 6 (a solve of BASELINE configs[4]: 5.5 -> 3.7 ms): every launch of this chain ends with its slowest THREAD - the ~400 numeric-Jacobian edges (18 error evaluations
-// in one thread: ba_linearize 68 -> 15 + 22 us) and the edges of plane vertices (~30 partner edges against a point's ~5: ba_schur 62 -> 37 us) -, ba_solve was 378 workgroup
-// barriers (blocked by key frame: 90 -> 60 us), and three copies / memsets and ba_begin were launches of their own.
+//   ba_schur     workgroup = (block (p, q) of the reduced system, slice of the landmarks)   S[p][q] -= sum_l Wp(l,p) Dinv_l Wp(l,q)^T, b[p] -= sum_l Wp(l,p) Dinv_l bl_l:
+//                                     register accumulation over the landmarks, one reduction per workgroup (lower triangle of blocks)
+// Round 6 (a solve of BASELINE configs[4]: 5.5 -> 3.4 ms -> see DESIGN.md 4.6): every launch of this chain ends with its slowest THREAD - the ~400 numeric-Jacobian
+// edges (18 error evaluations in one thread: ba_linearize 68 -> 15 + 13 us), the ~30 edges of a plane vertex wherever a thread walked a landmark's edges (ba_schur
+// 62 -> 37 us edge-parallel, then per key-frame pair; ba_update; ba_gather), one thread's walk over the unknowns at the end of ba_solve -, ba_solve was 378 workgroup
+// barriers (blocked by key frame), the landmark of an edge was a binary search, and three copies / memsets and ba_begin were launches of their own.
 //   [exchange]   RCCL all-reduce (sum) of the reduced camera system: landmarks (and all their edges) are partitioned
 //                across GPUs, every GPU then solves the same 6K x 6K system redundantly (29 KB payload)
 //   ba_solve     one workgroup        dense Cholesky of the reduced system in LDS, pose increments
-//   ba_update    thread = landmark    back-substitution x_l = Dinv (bl - W^T x_p), oplus on poses / points / planes
+//   ba_update    8 lanes = landmark   back-substitution x_l = Dinv (bl - sum over its pairs Wp^T x_p), oplus on poses / points / planes
 //   ba_decide    one thread           the Levenberg-Marquardt bookkeeping of optimization_algorithm_levenberg.cpp:61-164 (rho test, lambda
 //                                     schedule, <= 10 retries, stop rules) ON THE DEVICE, from the all-reduced [chi2, scale, stop] triple
 // One LM trial = one fixed launch sequence ("step") whose kernels read the LM state (lambda, need_build, done ...) from device memory, so
@@ -58,6 +59,17 @@ struct Dev {
     double* lm; double* lmbak;               // [L][4]: xyz0 | plane coefficients
     const uint8_t* lm_type;                  // 0 point, 1 plane
     const int* lm_start;                     // [L+1] CSR into the (landmark-sorted) edges
+    const int* e_lm;                         // [E] landmark of an edge
+    // (landmark, non-fixed key frame) PAIRS: the edges of a landmark at one key frame enter the Schur complement and the back-substitution only through the SUM of
+    // their coupling blocks (W_e Dinv W_f^T is bilinear), so both run over pairs - a point has one edge per pair, a plane vertex ~3 (plane / parallel / vertical)
+    int n_pairs;
+    const int* pair_start;                   // [n_pairs+1] CSR into pair_edges
+    const int* pair_edges;                   // edge indices, grouped by pair
+    const int* pair_p;                       // [n_pairs] hessian block of the pair's key frame
+    const int* lm_pair_start;                // [L+1] the pairs of a landmark are consecutive, ascending p
+    const int* pair_of;                      // [L][np] pair of (landmark, block), -1 if none
+    double* Wp;                              // [n_pairs][18] summed coupling blocks of the active edges (ba_gather)
+    uint8_t* lm_any;                         // [L] the landmark has an active edge (ba_gather)
     const int* e_kf; const uint8_t* e_type; const int* e_partner;
     const double* e_meas;                    // [E][4]
     const double* e_info;                    // [E][4]: info diag (3) + Huber delta
@@ -149,12 +161,8 @@ __device__ __forceinline__ double block_sum(double v, double* lds4) {
     return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
-// landmark of edge e: binary search in the CSR
-__device__ __forceinline__ int edge_landmark(const Dev& D, int e) {
-    int lo = 0, hi = D.L;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (D.lm_start[mid] <= e) lo = mid; else hi = mid; }
-    return lo;
-}
+// landmark of edge e (round 6: was a binary search in the CSR - eleven dependent loads at the head of every edge thread)
+__device__ __forceinline__ int edge_landmark(const Dev& D, int e) { return D.e_lm[e]; }
 
 // at_iteration_start = 1: only when the step opens an LM iteration (chi2(x) into red); 0: every live trial (chi2(x + dx) into trial[0])
 __global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_out, int at_iteration_start) {
@@ -308,27 +316,54 @@ __global__ __launch_bounds__(NT) void ba_linearize(Dev D, int robust) {
     }
 }
 
-// thread = landmark: its block Hll / bl = the sum of its edges' contributions IN EDGE ORDER (deterministic), max |diag| for computeLambdaInit
+// FOUR lanes = landmark: its block Hll / bl = the sum of its edges' contributions (lane s takes edges e0 + s, e0 + s + 4, ...; the four partial sums are combined
+// by two shuffles: a fixed order, so the result is deterministic), max |diag| for computeLambdaInit.  (One thread per landmark walked the ~30 edges of a plane vertex
+// one memory latency at a time: the launch's 12 us.)  Then thread = pair: the summed coupling block of its active edges (ba_linearize writes zeros for the others).
+constexpr int GATHER_SPLIT = 4;
 __global__ __launch_bounds__(NT) void ba_gather(Dev D) {
     if (D.st->done || !D.st->need_build) return;
-    const int l = blockIdx.x * NT + threadIdx.x;
+    const int gid = blockIdx.x * NT + threadIdx.x, l = gid / GATHER_SPLIT, sl = gid - l * GATHER_SPLIT;
     double maxd = 0;
+    double Hll[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+    int any = 0;
     if (l < D.L) {
-        double Hll[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-        bool any = false;
-        for (int e = D.lm_start[l]; e < D.lm_start[l + 1]; e++) {
+        const int e1 = D.lm_start[l + 1];
+        for (int e = D.lm_start[l] + sl; e < e1; e += GATHER_SPLIT) {
             if (D.e_level[e] != 0) continue;
-            any = true;
+            any = 1;
             const double* h = D.He + (size_t)e * 12;
             for (int i = 0; i < 9; i++) Hll[i] += h[i];
             for (int i = 0; i < 3; i++) bl[i] += h[9 + i];
         }
+    }
+#pragma unroll
+    for (int o = 1; o < GATHER_SPLIT; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) Hll[i] += __shfl_xor(Hll[i], o);
+#pragma unroll
+        for (int i = 0; i < 3; i++) bl[i] += __shfl_xor(bl[i], o);
+        any |= __shfl_xor(any, o);
+    }
+    if (l < D.L && sl == 0) {
         for (int i = 0; i < 9; i++) D.Hll[(size_t)l * 9 + i] = Hll[i];
         for (int i = 0; i < 3; i++) D.bl[(size_t)l * 3 + i] = bl[i];
+        D.lm_any[l] = (uint8_t)any;
         if (any) maxd = fmax(fabs(Hll[0]), fmax(fabs(Hll[4]), fabs(Hll[8])));
     }
     for (int o = 32; o > 0; o >>= 1) maxd = fmax(maxd, __shfl_xor(maxd, o));
     if ((threadIdx.x & 63) == 0 && maxd > 0) atomicMax((unsigned long long*)&D.scal[0], (unsigned long long)__double_as_longlong(maxd));
+    for (int j = gid; j < D.n_pairs; j += gridDim.x * NT) {
+        double w[18];
+#pragma unroll
+        for (int i = 0; i < 18; i++) w[i] = 0;
+        for (int k = D.pair_start[j]; k < D.pair_start[j + 1]; k++) {
+            const double* We = D.W + (size_t)D.pair_edges[k] * 18;
+#pragma unroll
+            for (int i = 0; i < 18; i++) w[i] += We[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 18; i++) D.Wp[(size_t)j * 18 + i] = w[i];
+    }
 }
 
 __device__ __forceinline__ void inv3(const double* H, double lambda, double Di[9]) {   // Matrix3d::inverse (cofactors)
@@ -350,9 +385,11 @@ __global__ __launch_bounds__(NT) void ba_dinv(Dev D, int nred, int nS) {
     for (int i = l; i < nS; i += gridDim.x * NT) D.red2[i] = 0;
     if (l < 4) D.trial[l] = 0;
     if (l >= D.L) return;
-    bool any = false;
-    for (int e = D.lm_start[l]; e < D.lm_start[l + 1]; e++) any |= D.e_level[e] == 0;
-    if (!any) return;
+    if (!D.lm_any[l]) {                       // (zeros, not stale values: ba_schur multiplies every landmark's Dinv with its - then zero - pair sums)
+        for (int i = 0; i < 9; i++) D.Dinv[(size_t)l * 9 + i] = 0;
+        for (int a = 0; a < 3; a++) D.xl[(size_t)l * 3 + a] = 0;
+        return;
+    }
     double Di[9];
     inv3(D.Hll + (size_t)l * 9, lambda, Di);
     for (int i = 0; i < 9; i++) D.Dinv[(size_t)l * 9 + i] = Di[i];
@@ -360,48 +397,73 @@ __global__ __launch_bounds__(NT) void ba_dinv(Dev D, int nred, int nS) {
     for (int a = 0; a < 3; a++) D.xl[(size_t)l * 3 + a] = Di[a * 3] * bl[0] + Di[a * 3 + 1] * bl[1] + Di[a * 3 + 2] * bl[2];
 }
 
-// thread = EDGE e of landmark l: row block p(e) of the Schur terms, S[p][q(f)] -= W_e Dinv W_f^T for every edge f of l, b[p] -= W_e Dinv bl
-constexpr int SCHUR_SPLIT = 4;
-constexpr int NT_SCHUR = 256;       // (the LDS FP64 atomics of a workgroup serialise on its CU and every workgroup flushes 1 500 global atomics: 1024 threads 146 us, 64 threads 81 us, 256: 62 us)
-__global__ __launch_bounds__(NT_SCHUR) void ba_schur(Dev D) {
-    extern __shared__ __attribute__((aligned(16))) double s_lds[];  // [NP*NP + NP] (np <= MAX_NP_LDS)
+// workgroup = (block (p, q) of the reduced system, p >= q; a slice of the landmarks): S[p][q] -= sum_l Wp(l,p) Dinv_l Wp(l,q)^T and, on the diagonal blocks,
+// b[p] -= sum_l Wp(l,p) Dinv_l bl_l, accumulated in REGISTERS (a thread takes landmarks tid, tid + 256 * slices, ...), reduced by three shuffles + one pass through LDS,
+// one FP64 atomic per element and workgroup.  Round 6, second form: the edge-parallel form (thread = edge x its partner edges, 36 LDS atomics per partner on addresses
+// that every edge of the same key-frame pair shares) took 37 us of a 183 us trial; per PAIR of key frames the products are a flat sum over landmarks.
+__global__ __launch_bounds__(NT) void ba_schur(Dev D, int slices) {
+    __shared__ double s_part[32][43];
     if (D.st->done) return;
-    const int NP = 6 * D.np, tot = NP * NP + NP;
-    const bool big = D.bigA != nullptr;                              // too large for LDS: the terms go straight to the exchange buffer
-    double* s_S = big ? D.red2 : s_lds;
-    if (!big) { for (int i = threadIdx.x; i < tot; i += NT_SCHUR) s_S[i] = 0; }
-    __syncthreads();
-    // thread = (edge e, slice sl of the partner edges): the launch ends with its slowest thread, and an edge of a plane vertex has ~30 partners where a point's has ~5 -
-    // SCHUR_SPLIT threads share an edge's partner loop (partner f goes to slice (f - e0) mod SCHUR_SPLIT), slice 0 adds the right-hand side
-    const int gid = blockIdx.x * NT_SCHUR + threadIdx.x, e = gid / SCHUR_SPLIT, sl = gid - e * SCHUR_SPLIT;
-    if (e < D.E && D.e_level[e] == 0) {
-        const int p = D.pidx[D.e_kf[e]];
-        if (p >= 0 && sl < D.lm_start[edge_landmark(D, e) + 1] - D.lm_start[edge_landmark(D, e)]) {
-            const int l = edge_landmark(D, e);
-            const int e0 = D.lm_start[l], e1 = D.lm_start[l + 1];
-            const double* Di = D.Dinv + (size_t)l * 9;
+    const int NP = 6 * D.np, combo = blockIdx.x / slices, sl = blockIdx.x - combo * slices;
+    int p = (int)((sqrt(8.0 * combo + 1.0) - 1.0) * 0.5);
+    while ((p + 1) * (p + 2) / 2 <= combo) p++;
+    while (p * (p + 1) / 2 > combo) p--;
+    const int q = combo - p * (p + 1) / 2;
+    double acc[36], rb[6];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) rb[i] = 0;
+    for (int l = sl * NT + threadIdx.x; l < D.L; l += slices * NT) {
+        const int i = D.pair_of[(size_t)l * D.np + p];
+        if (i < 0) continue;
+        const int j = p == q ? i : D.pair_of[(size_t)l * D.np + q];
+        if (j < 0) continue;
+        const double* Wi = D.Wp + (size_t)i * 18;
+        const double* Wj = D.Wp + (size_t)j * 18;
+        const double* Di = D.Dinv + (size_t)l * 9;
+        double wi[18], wj[18], di[9], BD[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) { wi[k] = Wi[k]; wj[k] = Wj[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) di[k] = Di[k];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) BD[a * 3 + c] = wi[a * 3] * di[c] + wi[a * 3 + 1] * di[3 + c] + wi[a * 3 + 2] * di[6 + c];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[a * 6 + c] -= BD[a * 3] * wj[c * 3] + BD[a * 3 + 1] * wj[c * 3 + 1] + BD[a * 3 + 2] * wj[c * 3 + 2];
+        if (p == q) {
             const double* db = D.xl + (size_t)l * 3;
-            const double* We = D.W + (size_t)e * 18;
-            double BD[18];
-            for (int a = 0; a < 6; a++)
-                for (int c = 0; c < 3; c++) BD[a * 3 + c] = We[a * 3] * Di[c] + We[a * 3 + 1] * Di[3 + c] + We[a * 3 + 2] * Di[6 + c];
-            if (sl == 0) for (int a = 0; a < 6; a++) atomicAdd(&s_S[NP * NP + p * 6 + a], -(We[a * 3] * db[0] + We[a * 3 + 1] * db[1] + We[a * 3 + 2] * db[2]));
-            // (Measured in round 6 and dropped: skipping the blocks above the diagonal, 62 -> 59 us; the ~30 edges of a plane vertex grouped by key frame - 81 block products
-            //  instead of ~900 - 62 -> 106 us: the launch ends with its slowest THREAD, and a group leader's scans and sums are a longer dependent chain than 30 block products)
-            for (int f = e0 + sl; f < e1; f += SCHUR_SPLIT) {
-                const int q = D.pidx[D.e_kf[f]];
-                if (q < 0 || D.e_level[f] != 0) continue;
-                const double* Wf = D.W + (size_t)f * 18;
-                for (int a = 0; a < 6; a++)
-                    for (int c = 0; c < 6; c++)
-                        atomicAdd(&s_S[(p * 6 + a) * NP + q * 6 + c], -(BD[a * 3] * Wf[c * 3] + BD[a * 3 + 1] * Wf[c * 3 + 1] + BD[a * 3 + 2] * Wf[c * 3 + 2]));
-            }
+            const double d0 = db[0], d1 = db[1], d2 = db[2];
+#pragma unroll
+            for (int a = 0; a < 6; a++) rb[a] -= wi[a * 3] * d0 + wi[a * 3 + 1] * d1 + wi[a * 3 + 2] * d2;
         }
     }
+#pragma unroll
+    for (int o = 32; o >= 8; o >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 36; i++) acc[i] += __shfl_xor(acc[i], o);
+#pragma unroll
+        for (int i = 0; i < 6; i++) rb[i] += __shfl_xor(rb[i], o);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < 8) {
+#pragma unroll
+        for (int i = 0; i < 36; i++) s_part[wv * 8 + lane][i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) s_part[wv * 8 + lane][36 + i] = rb[i];
+    }
     __syncthreads();
-    if (!big) for (int i = threadIdx.x; i < tot; i += NT_SCHUR) {   // (the solver reads the lower triangle only: the upper one is not flushed)
-        if (i < NP * NP && i % NP > i / NP) continue;
-        const double v = s_S[i]; if (v != 0) atomicAdd(&D.red2[i], v);
+    if (threadIdx.x < 42 && (threadIdx.x < 36 || p == q)) {
+        double v = 0;
+        for (int r = 0; r < 32; r++) v += s_part[r][threadIdx.x];
+        if (v != 0) {
+            if (threadIdx.x < 36) { const int a = threadIdx.x / 6, c = threadIdx.x - a * 6; atomicAdd(&D.red2[(size_t)(p * 6 + a) * NP + q * 6 + c], v); }
+            else atomicAdd(&D.red2[(size_t)NP * NP + p * 6 + (threadIdx.x - 36)], v);
+        }
     }
 }
 
@@ -409,6 +471,7 @@ __global__ __launch_bounds__(NT_SCHUR) void ba_schur(Dev D) {
 __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
     extern __shared__ __attribute__((aligned(16))) double s_ldsA[];  // [NP*NP] + x[NP] (np <= MAX_NP_LDS)
     __shared__ int s_ok;
+    __shared__ double s_b[6 * MAX_NP];          // the summed bp (for computeScale at the end)
     if (D.st->done) return;
     const int NP = 6 * D.np, tid = threadIdx.x;
     double* s_A = D.bigA ? D.bigA : s_ldsA;                          // one workgroup either way: __syncthreads orders its global accesses too
@@ -427,7 +490,7 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
         if (r == c) v += lambda;
         s_A[i] = v;
     }
-    for (int i = tid; i < NP; i += NT) x[i] = D.redg[(size_t)D.np * 36 + i] + D.red2[NP * NP + i];
+    for (int i = tid; i < NP; i += NT) { const double b = D.redg[(size_t)D.np * 36 + i]; s_b[i] = b; x[i] = b + D.red2[NP * NP + i]; }
     if (tid == 0) s_ok = 1;
     __syncthreads();
     // Right-looking Cholesky of the lower triangle, SIX columns (one key frame's block) per round: the unblocked loop took three workgroup barriers per column (162 for
@@ -547,16 +610,21 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
         for (int i = tid; i < NP; i += NT) x[i] = s_y[i];
         __syncthreads();
     }
+    // pose increments out + the pose part of computeScale(): the terms in parallel, their sum in index order by one thread FROM LDS (round 6: thread 0 walked the 6 np
+    // unknowns with a global load and a global store each - loads it may not hoist over stores that could alias - one memory latency per unknown: 30 of the kernel's 49 us)
+    if (s_ok) for (int i = tid; i < NP; i += NT) { const double xi = x[i]; D.xp[i] = xi; s_y[i] = xi * (lambda * xi + s_b[i]); }
+    __syncthreads();
     if (tid == 0) {
         double scale = 0;
-        if (s_ok) {
-            for (int i = 0; i < NP; i++) { D.xp[i] = x[i]; scale += x[i] * (lambda * x[i] + D.redg[(size_t)D.np * 36 + i]); }
-        }
+        if (s_ok) for (int i = 0; i < NP; i++) scale += s_y[i];
         D.xp[NP] = s_ok ? 1.0 : 0.0;
-        D.xp[NP + 1] = scale;        // pose part of computeScale()
+        D.xp[NP + 1] = scale;
     }
 }
 
+// EIGHT lanes = landmark (lane s takes the landmark's pairs s, s + 8, ...: W^T x_p summed per pair, combined by three shuffles), lane 0 finishes; thread = key frame
+// for the poses.  (One thread per landmark walked its edges - key frame index, block index, W, x_p: three dependent loads per edge, ~30 edges for a plane vertex: 22 us.)
+constexpr int UPDATE_SPLIT = 8;
 __global__ __launch_bounds__(NT) void ba_update(Dev D, int stop) {
     __shared__ double s4[4];
     if (D.st->done) return;
@@ -571,27 +639,38 @@ __global__ __launch_bounds__(NT) void ba_update(Dev D, int stop) {
         store_T(D.Tbak, i, T);
         if (ok && D.pidx[i] >= 0) { double u[6]; for (int a = 0; a < 6; a++) u[a] = D.xp[D.pidx[i] * 6 + a]; store_T(D.T, i, se3_mul(se3_exp(u), T)); }
     }
-    double sc = 0;
-    if (i < D.L) {
-        for (int a = 0; a < 4; a++) D.lmbak[(size_t)i * 4 + a] = D.lm[(size_t)i * 4 + a];
-        const int e0 = D.lm_start[i], e1 = D.lm_start[i + 1];
-        bool any = false;
-        for (int e = e0; e < e1; e++) any |= D.e_level[e] == 0;
-        if (any && ok) {
-            const double* bl = D.bl + (size_t)i * 3;
-            double cl[3] = {bl[0], bl[1], bl[2]};
-            for (int e = e0; e < e1; e++) {
-                const int p = D.pidx[D.e_kf[e]];
-                if (p < 0 || D.e_level[e] != 0) continue;
-                const double* We = D.W + (size_t)e * 18;
-                for (int c = 0; c < 3; c++) for (int a = 0; a < 6; a++) cl[c] -= We[a * 3 + c] * D.xp[p * 6 + a];
+    const int l = i / UPDATE_SPLIT, sl = i - l * UPDATE_SPLIT;
+    const bool act = l < D.L && ok && D.lm_any[l];
+    double part[3] = {0, 0, 0};
+    if (act) {
+        const int j1 = D.lm_pair_start[l + 1];
+        for (int j = D.lm_pair_start[l] + sl; j < j1; j += UPDATE_SPLIT) {
+            const double* Wj = D.Wp + (size_t)j * 18;
+            const double* xq = D.xp + D.pair_p[j] * 6;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const double xa = xq[a];
+#pragma unroll
+                for (int c = 0; c < 3; c++) part[c] += Wj[a * 3 + c] * xa;
             }
-            const double* Di = D.Dinv + (size_t)i * 9;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < UPDATE_SPLIT; o <<= 1)
+#pragma unroll
+        for (int c = 0; c < 3; c++) part[c] += __shfl_xor(part[c], o);
+    double sc = 0;
+    if (l < D.L && sl == 0) {
+        for (int a = 0; a < 4; a++) D.lmbak[(size_t)l * 4 + a] = D.lm[(size_t)l * 4 + a];
+        if (act) {
+            const double* bl = D.bl + (size_t)l * 3;
+            const double cl[3] = {bl[0] - part[0], bl[1] - part[1], bl[2] - part[2]};
+            const double* Di = D.Dinv + (size_t)l * 9;
             double xl[3];
             for (int a = 0; a < 3; a++) { xl[a] = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2]; sc += xl[a] * (lambda * xl[a] + bl[a]); }
-            LmV v = load_lm(D, D.lm, i);
+            LmV v = load_lm(D, D.lm, l);
             lm_oplus(v, xl);
-            double* o = D.lm + (size_t)i * 4;
+            double* o = D.lm + (size_t)l * 4;
             if (v.type == 0) { o[0] = v.X.x; o[1] = v.X.y; o[2] = v.X.z; } else for (int a = 0; a < 4; a++) o[a] = v.P.c[a];
         }
     }
@@ -763,21 +842,80 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     const int NP = 6 * np;
     for (int e = 0; e < E; e++) PLANAR_REQUIRE(P->e_kf[e] >= 0 && P->e_kf[e] < K && P->e_lm[e] >= 0 && P->e_lm[e] < L && P->e_type[e] <= BE_PAR, PLANAR_EINVAL, "edge index out of range");
 
-    // ---- host prep: sort edges by landmark (stable), CSR, line partners, information / Huber deltas ----
+    // ---- host prep: edges grouped by landmark (stable counting sort), CSR, line partners, information / Huber deltas.  Everything the device reads is written straight
+    //      into ONE pinned block that mirrors the head of the device block: one copy up, one copy down (round 6: ~25 copies from pageable vectors and a comparison sort
+    //      of the edges were a third of a solve's wall time) ----
     std::vector<int> perm(E), inv(E), lm_start(L + 1, 0);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return P->e_lm[a] < P->e_lm[b]; });
-    for (int i = 0; i < E; i++) { inv[perm[i]] = i; lm_start[P->e_lm[perm[i]] + 1]++; }
+    for (int o = 0; o < E; o++) lm_start[P->e_lm[o] + 1]++;
     for (int l = 0; l < L; l++) lm_start[l + 1] += lm_start[l];
+    {
+        std::vector<int> fill(lm_start.begin(), lm_start.end() - 1);
+        for (int o = 0; o < E; o++) { const int i = fill[P->e_lm[o]]++; perm[i] = o; inv[o] = i; }
+    }
+    // (landmark, non-fixed key frame) pairs, per landmark in ascending block order; the edges of a pair keep their order
+    std::vector<int> pair_start, pair_edges, pair_p, lm_pair_start(L + 1, 0), pair_of((size_t)L * std::max(np, 1), -1);
+    {
+        std::vector<int> cnt(std::max(np, 1), 0), pos(std::max(np, 1), 0), plist;
+        pair_edges.reserve(E); pair_p.reserve(E); pair_start.reserve(E + 1);
+        for (int l = 0; l < L; l++) {
+            plist.clear();
+            for (int e = lm_start[l]; e < lm_start[l + 1]; e++) { const int p = pidx[P->e_kf[perm[e]]]; if (p >= 0 && cnt[p]++ == 0) plist.push_back(p); }
+            std::sort(plist.begin(), plist.end());
+            int at = (int)pair_edges.size();
+            for (int p : plist) {
+                pair_of[(size_t)l * np + p] = (int)pair_p.size();
+                pair_p.push_back(p); pair_start.push_back(at);
+                pos[p] = at; at += cnt[p]; cnt[p] = 0;
+            }
+            pair_edges.resize(at);
+            for (int e = lm_start[l]; e < lm_start[l + 1]; e++) { const int p = pidx[P->e_kf[perm[e]]]; if (p >= 0) pair_edges[pos[p]++] = e; }
+            lm_pair_start[l + 1] = (int)pair_p.size();
+        }
+        pair_start.push_back((int)pair_edges.size());
+    }
+    const int n_pairs = (int)pair_p.size();
+    int n_num = 0;
+    for (int o = 0; o < E; o++) n_num += P->e_type[o] >= BE_PLANE;
+
+    // ---- device block: [uploaded arrays | key-frame poses, landmarks (up and down) | "to erase" flags (down) | zero-initialised work arrays] ----
+    const size_t nred = (size_t)np * 36 + NP + 2, nS = (size_t)NP * NP + NP, nA = nred + nS;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 8), (size_t)256); return o; };
+    const size_t oP = carve((size_t)K * 4), oLt = carve(L), oLs = carve((size_t)(L + 1) * 4), oEk = carve((size_t)E * 4), oEt = carve(E), oEp = carve((size_t)E * 4),
+                 oEm = carve((size_t)E * 32), oEi = carve((size_t)E * 32), oNs = carve((size_t)E * 4), oNi = carve((size_t)n_num * 4),
+                 oElm = carve((size_t)E * 4), oPs = carve((size_t)(n_pairs + 1) * 4), oPe = carve(pair_edges.size() * 4), oPp = carve((size_t)n_pairs * 4),
+                 oLps = carve((size_t)(L + 1) * 4), oPof = carve(pair_of.size() * 4), oSt = carve(sizeof(LmState)), oSc = carve(64),
+                 oT = carve((size_t)K * 64), oLm = carve((size_t)L * 32);
+    const size_t up_end = off;
+    const size_t oEo = carve(E);
+    const size_t down_end = off;
+    const size_t oTb = carve((size_t)K * 64), oLb = carve((size_t)L * 32), oEe = carve((size_t)E * 24), oEl = carve(E),
+                 oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oDi = carve((size_t)L * 72), oW = carve((size_t)E * 144), oHe = carve((size_t)E * 96), oXl = carve((size_t)L * 24),
+                 oR = carve(nred * 8), oA = carve(nA * 8), oBig = carve(np > MAX_NP_LDS ? nS * 8 : 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8),
+                 oJ = carve((size_t)n_num * 27 * 8), oWp = carve((size_t)n_pairs * 144), oAny = carve(L);
+    // (the context's grow-only blocks: a hipMalloc + hipFree per solve cost more than two LM trials, and hipFree synchronises the device)
+    int rc = ctx->ensure_scratch(off);
+    if (rc) return rc;
+    const size_t oHostState = down_end, oHostStop = down_end + 256;       // host-only slots behind the mirrored part: LM state read-back, stop words
+    if ((rc = ctx->ensure_host_scratch(down_end + 512))) return rc;
+    uint8_t* base = ctx->scratch.as<uint8_t>();
+    uint8_t* hb = (uint8_t*)ctx->host_scratch;
+    std::memset(hb + oSt, 0, oT - oSt);                                    // (LmState and scal start as zeros)
+
     const double angleInfo = 3282.8 / (prm->angle_info * prm->angle_info), disInfo = prm->distance_info * prm->distance_info;
     const double dMono = (double)(float)std::sqrt(5.991), dStereo = (double)(float)std::sqrt(7.815);
     const double dPlane = (double)(float)std::sqrt(prm->plane_chi), dVP = (double)(float)std::sqrt(prm->vp_chi);
-    std::vector<int> e_kf(E), e_partner(E, -1);
-    std::vector<uint8_t> e_type(E);
-    std::vector<double> e_meas((size_t)E * 4), e_info((size_t)E * 4);
+    int* e_kf = (int*)(hb + oEk); int* e_partner = (int*)(hb + oEp); int* e_numslot = (int*)(hb + oNs); int* num_idx = (int*)(hb + oNi); int* e_lm = (int*)(hb + oElm);
+    uint8_t* e_type = hb + oEt;
+    double* e_meas = (double*)(hb + oEm); double* e_info = (double*)(hb + oEi);
+    std::memcpy(hb + oP, pidx.data(), (size_t)K * 4); std::memcpy(hb + oLt, P->lm_type, L); std::memcpy(hb + oLs, lm_start.data(), (size_t)(L + 1) * 4);
+    std::memcpy(hb + oPs, pair_start.data(), pair_start.size() * 4); std::memcpy(hb + oPe, pair_edges.data(), pair_edges.size() * 4); std::memcpy(hb + oPp, pair_p.data(), (size_t)n_pairs * 4);
+    std::memcpy(hb + oLps, lm_pair_start.data(), (size_t)(L + 1) * 4); std::memcpy(hb + oPof, pair_of.data(), pair_of.size() * 4);
+    for (int l = 0; l < L; l++) for (int e = lm_start[l]; e < lm_start[l + 1]; e++) e_lm[e] = l;
+    int num_at = 0;
     for (int i = 0; i < E; i++) {
         const int o = perm[i];
-        e_kf[i] = P->e_kf[o]; e_type[i] = P->e_type[o];
+        e_kf[i] = P->e_kf[o]; e_type[i] = P->e_type[o]; e_partner[i] = -1;
         for (int a = 0; a < 4; a++) e_meas[(size_t)i * 4 + a] = P->e_meas[(size_t)o * 4 + a];
         const double is2 = (double)P->e_inv_sigma2[o];
         double* f = &e_info[(size_t)i * 4];
@@ -788,6 +926,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
             case BE_PLANE: f[0] = f[1] = angleInfo; f[2] = disInfo; f[3] = dPlane; break;
             default: f[0] = f[1] = angleInfo; f[2] = 0; f[3] = dVP; break;      // both VP edges use angleInfo (src/Optimizer.cc:2274-2276)
         }
+        if (e_type[i] >= BE_PLANE) { e_numslot[i] = num_at; num_idx[num_at++] = i; } else e_numslot[i] = -1;
     }
     // line edges come in consecutive (start, end) pairs in the caller's order (src/Optimizer.cc:2171-2201)
     for (int o = 0; o < E; o++)
@@ -796,10 +935,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
             e_partner[inv[o]] = inv[o + 1]; e_partner[inv[o + 1]] = inv[o];
             o++;
         }
-    std::vector<int> e_numslot(E, -1), num_idx;
-    for (int i = 0; i < E; i++) if (e_type[i] >= BE_PLANE) { e_numslot[i] = (int)num_idx.size(); num_idx.push_back(i); }
-    const int n_num = (int)num_idx.size();
-    std::vector<double> T0((size_t)K * 8, 0.0), lm0((size_t)L * 4);
+    double* T0 = (double*)(hb + oT); double* lm0 = (double*)(hb + oLm);
     for (int k = 0; k < K; k++) {     // Converter::toSE3Quat (host: same restated kernels as the device, in plain C++)
         const float* Tm = P->kf_Tcw + 16 * k;
         double m[3][3];
@@ -817,7 +953,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
         const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
         double* o = &T0[(size_t)k * 8];
         for (int a = 0; a < 4; a++) o[a] = q[a] / n;
-        o[4] = Tm[3]; o[5] = Tm[7]; o[6] = Tm[11];
+        o[4] = Tm[3]; o[5] = Tm[7]; o[6] = Tm[11]; o[7] = 0;
     }
     for (int l = 0; l < L; l++) {
         double* o = &lm0[(size_t)l * 4];
@@ -829,28 +965,8 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
             if (o[3] < 0.0) for (int a = 0; a < 4; a++) o[a] = -o[a];
         } else o[3] = 0;
     }
-
-    // ---- device block ----
-    const size_t nred = (size_t)np * 36 + NP + 2, nS = (size_t)NP * NP + NP, nA = nred + nS;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 8), (size_t)256); return o; };
-    const size_t oT = carve((size_t)K * 64), oTb = carve((size_t)K * 64), oP = carve((size_t)K * 4), oLm = carve((size_t)L * 32), oLb = carve((size_t)L * 32),
-                 oLt = carve(L), oLs = carve((size_t)(L + 1) * 4), oEk = carve((size_t)E * 4), oEt = carve(E), oEp = carve((size_t)E * 4),
-                 oEm = carve((size_t)E * 32), oEi = carve((size_t)E * 32), oEe = carve((size_t)E * 24), oEl = carve(E), oEo = carve(E),
-                 oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oDi = carve((size_t)L * 72), oW = carve((size_t)E * 144), oHe = carve((size_t)E * 96), oXl = carve((size_t)L * 24),
-                 oR = carve(nred * 8), oA = carve(nA * 8), oBig = carve(np > MAX_NP_LDS ? nS * 8 : 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8), oSc = carve(64), oSt = carve(sizeof(LmState)),
-                 oNs = carve((size_t)E * 4), oNi = carve((size_t)n_num * 4), oJ = carve((size_t)n_num * 27 * 8);
-    // (the context's grow-only scratch block: a hipMalloc + hipFree per solve cost more than two LM trials, and hipFree synchronises the device)
-    int rc = ctx->ensure_scratch(off);
-    if (rc) return rc;
-    uint8_t* base = ctx->scratch.as<uint8_t>();
-    PLANAR_HIP_CHECK(hipMemsetAsync(base, 0, off, st));
-    auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
-    PLANAR_HIP_CHECK(up(oT, T0.data(), T0.size() * 8)); PLANAR_HIP_CHECK(up(oP, pidx.data(), (size_t)K * 4));
-    PLANAR_HIP_CHECK(up(oLm, lm0.data(), lm0.size() * 8)); PLANAR_HIP_CHECK(up(oLt, P->lm_type, L)); PLANAR_HIP_CHECK(up(oLs, lm_start.data(), (size_t)(L + 1) * 4));
-    PLANAR_HIP_CHECK(up(oEk, e_kf.data(), (size_t)E * 4)); PLANAR_HIP_CHECK(up(oEt, e_type.data(), E)); PLANAR_HIP_CHECK(up(oEp, e_partner.data(), (size_t)E * 4));
-    PLANAR_HIP_CHECK(up(oEm, e_meas.data(), e_meas.size() * 8)); PLANAR_HIP_CHECK(up(oEi, e_info.data(), e_info.size() * 8));
-    PLANAR_HIP_CHECK(up(oNs, e_numslot.data(), (size_t)E * 4)); PLANAR_HIP_CHECK(up(oNi, num_idx.data(), (size_t)n_num * 4));
+    PLANAR_HIP_CHECK(hipMemcpyAsync(base, hb, up_end, hipMemcpyHostToDevice, st));
+    PLANAR_HIP_CHECK(hipMemsetAsync(base + up_end, 0, off - up_end, st));
     Dev D;
     D.K = K; D.np = np; D.L = L; D.E = E;
     D.T = (double*)(base + oT); D.Tbak = (double*)(base + oTb); D.pidx = (const int*)(base + oP); D.lm = (double*)(base + oLm); D.lmbak = (double*)(base + oLb);
@@ -861,14 +977,17 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     D.scal = (double*)(base + oSc); D.st = (LmState*)(base + oSt);
     D.bigA = np > MAX_NP_LDS ? (double*)(base + oBig) : nullptr;
     D.e_numslot = (const int*)(base + oNs); D.num_idx = (const int*)(base + oNi); D.J = (double*)(base + oJ); D.n_num = n_num;
+    D.e_lm = (const int*)(base + oElm); D.n_pairs = n_pairs; D.pair_start = (const int*)(base + oPs); D.pair_edges = (const int*)(base + oPe); D.pair_p = (const int*)(base + oPp);
+    D.lm_pair_start = (const int*)(base + oLps); D.pair_of = (const int*)(base + oPof); D.Wp = (double*)(base + oWp); D.lm_any = base + oAny;
     D.cam = Cam{(double)prm->fx, (double)prm->fy, (double)prm->cx, (double)prm->cy, (double)prm->bf};
 
-    const size_t smem_schur = np > MAX_NP_LDS ? 0 : ((size_t)NP * NP + NP) * 8, smem_solve = smem_schur, smem_build = (size_t)np * 42 * 8;
-    if (smem_schur > 48 * 1024) {
-        PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_schur));
-        PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_solve));
-    }
-    const dim3 gE((E + NT - 1) / NT ? (E + NT - 1) / NT : 1), gL((L + NT - 1) / NT ? (L + NT - 1) / NT : 1), gU((std::max(L, K) + NT - 1) / NT);
+    const size_t smem_solve = np > MAX_NP_LDS ? 0 : ((size_t)NP * NP + NP) * 8, smem_build = (size_t)np * 42 * 8;
+    if (smem_solve > 48 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_solve));
+    auto blocks = [](size_t n) { return dim3((unsigned)std::max<size_t>((n + NT - 1) / NT, 1)); };
+    const dim3 gE = blocks(E), gL = blocks(L), gU = blocks(std::max(L, K)), gG = blocks(std::max((size_t)L * GATHER_SPLIT, (size_t)n_pairs)),
+               gUp = blocks(std::max((size_t)L * UPDATE_SPLIT, (size_t)K));
+    // ba_schur: one workgroup per (block pair, slice of the landmarks); enough slices to give every CU a workgroup when the key frames are few
+    const int n_combo = np * (np + 1) / 2, schur_slices = std::max(1, std::min((L + NT - 1) / NT, 512 / std::max(n_combo, 1)));
     // a communicator of ONE rank still goes through ncclAllReduce (the same code path as N ranks); no communicator = single GPU, no exchange
     std::vector<double> staged;
     auto allreduce = [&](double* p, size_t n, int op) -> int {
@@ -895,17 +1014,17 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
         if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.red + (size_t)np * 36 + NP, 1);
         if (n_num) hipLaunchKernelGGL(ba_numjac, dim3((n_num * 18 + NT - 1) / NT), dim3(NT), 0, st, D);
         if (E) hipLaunchKernelGGL(ba_linearize, gE, dim3(NT), smem_build, st, D, robust);
-        if (L) hipLaunchKernelGGL(ba_gather, gL, dim3(NT), 0, st, D);
+        if (L) hipLaunchKernelGGL(ba_gather, gG, dim3(NT), 0, st, D);
     };
     // one LM trial.  No host decision inside: open (if the state says so), Schur, exchange A, solve, update, errors, exchange B, decide, restore.
     auto enqueue_step = [&](int robust, bool opened) -> int {
         int r;
         if (!opened) enqueue_open(robust);
         hipLaunchKernelGGL(ba_dinv, gL, dim3(NT), 0, st, D, (int)nred, (int)nS);      // (+ redg <- red, red2 <- 0, trial <- 0)
-        if (E && NP) hipLaunchKernelGGL(ba_schur, dim3(((size_t)E * SCHUR_SPLIT + NT_SCHUR - 1) / NT_SCHUR), dim3(NT_SCHUR), smem_schur, st, D);
+        if (n_pairs) hipLaunchKernelGGL(ba_schur, dim3((unsigned)(n_combo * schur_slices)), dim3(NT), 0, st, D, schur_slices);
         if ((r = allreduce(D.redg, nA, NCCL_SUM))) return r;                                            // exchange A
         hipLaunchKernelGGL(ba_solve, dim3(1), dim3(NT), smem_solve, st, D);
-        hipLaunchKernelGGL(ba_update, gU, dim3(NT), 0, st, D, stop_now());
+        hipLaunchKernelGGL(ba_update, gUp, dim3(NT), 0, st, D, stop_now());
         if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.trial, 0);
         if ((r = allreduce(D.trial, 3, NCCL_SUM))) return r;                                            // exchange B
         hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, st, D);
@@ -915,14 +1034,15 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     // SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg
     auto optimize = [&](int iterations, int robust) -> int {
         if (iterations <= 0) return PLANAR_OK;
-        LmState h;
+        LmState& h = *(LmState*)(hb + oHostState);       // (pinned: the copies below are asynchronous; the stream is idle whenever the host writes here)
         std::memset(&h, 0, sizeof(h));
         h.lambda = -1; h.ni = 2; h.iterations = iterations; h.need_build = 1;
         PLANAR_HIP_CHECK(hipMemcpyAsync(D.st, &h, sizeof(h), hipMemcpyHostToDevice, st));
         int r;
         // first trial: computeLambdaInit needs max |diag| over BOTH block families of the summed Hessian before the first Schur complement
         enqueue_open(robust);
-        const double stop0[1] = {(double)stop_now()};
+        double* stop0 = (double*)(hb + oHostStop);
+        stop0[0] = (double)stop_now();
         PLANAR_HIP_CHECK(hipMemcpyAsync(D.scal + 1, stop0, 8, hipMemcpyHostToDevice, st));
         PLANAR_HIP_CHECK(hipMemcpyAsync(D.redg, D.red, nred * 8, hipMemcpyDeviceToDevice, st));
         if ((r = allreduce(D.redg, nred, NCCL_SUM))) return r;
@@ -965,12 +1085,9 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     PLANAR_HIP_CHECK(hipGetLastError());
 
     // ---- results ----
-    std::vector<double> Tf((size_t)K * 8), lmf((size_t)L * 4);
-    std::vector<uint8_t> eo(E);
-    PLANAR_HIP_CHECK(hipMemcpyAsync(Tf.data(), D.T, Tf.size() * 8, hipMemcpyDeviceToHost, st));
-    if (L) PLANAR_HIP_CHECK(hipMemcpyAsync(lmf.data(), D.lm, lmf.size() * 8, hipMemcpyDeviceToHost, st));
-    if (E) PLANAR_HIP_CHECK(hipMemcpyAsync(eo.data(), D.e_out, E, hipMemcpyDeviceToHost, st));
+    PLANAR_HIP_CHECK(hipMemcpyAsync(hb + oT, base + oT, down_end - oT, hipMemcpyDeviceToHost, st));        // poses, landmarks, flags: adjacent by construction
     PLANAR_HIP_CHECK(hipStreamSynchronize(st));
+    const double* Tf = (const double*)(hb + oT); const double* lmf = (const double*)(hb + oLm); const uint8_t* eo = hb + oEo;
     for (int k = 0; k < K; k++) {      // SE3Quat -> 4x4 -> float32 (Converter::toCvMat)
         const double* q = &Tf[(size_t)k * 8];
         const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2], twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];

@@ -132,4 +132,16 @@ struct planar_ctx {
         if (scratch.p) (void)hipStreamSynchronize(stream);
         return scratch.alloc(bytes);
     }
+    // grow-only PINNED host block (planar_local_ba stages its whole problem through it: one copy each way instead of ~25 from pageable arrays)
+    void* host_scratch = nullptr;
+    size_t host_scratch_bytes = 0;
+    int ensure_host_scratch(size_t bytes) {
+        if (host_scratch_bytes >= bytes) return PLANAR_OK;
+        if (host_scratch) { (void)hipStreamSynchronize(stream); (void)hipHostFree(host_scratch); host_scratch = nullptr; host_scratch_bytes = 0; }
+        const size_t want = planar::align_up(bytes + bytes / 4, (size_t)4096);
+        hipError_t e = hipHostMalloc(&host_scratch, want, hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); host_scratch = nullptr; planar::set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return PLANAR_EDEVICE; }
+        host_scratch_bytes = want;
+        return PLANAR_OK;
+    }
 };

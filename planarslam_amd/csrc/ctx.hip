@@ -37,6 +37,7 @@ void planar_ctx_destroy(planar_ctx* ctx) {
     if (!ctx) return;
     if (ctx->seq_fork) (void)hipEventDestroy(ctx->seq_fork);
     if (ctx->seq_join) (void)hipEventDestroy(ctx->seq_join);
+    if (ctx->host_scratch) (void)hipHostFree(ctx->host_scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
