@@ -493,20 +493,21 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
     for (int i = tid; i < NP; i += NT) { const double b = D.redg[(size_t)D.np * 36 + i]; s_b[i] = b; x[i] = b + D.red2[NP * NP + i]; }
     if (tid == 0) s_ok = 1;
     __syncthreads();
-    // Right-looking Cholesky of the lower triangle, SIX columns (one key frame's block) per round: the unblocked loop took three workgroup barriers per column (162 for
-    // 9 key frames, + 216 in the substitutions: the kernel's 90 us were barriers).  Per matrix element the operations and their order are the unblocked loop's - the
-    // products with earlier columns are subtracted one by one in ascending column order, mul then sub -, so the factor is the same doubles.  EVERY thread factors the 6x6
-    // diagonal block itself, in registers (6 sqrt, 15 divisions: cheaper than a barrier and a wait for one thread); thread 0 keeps the factor in s_D for the
-    // substitutions.  Two barriers per key frame here, one per key frame and direction below: 36 for 9 key frames.  (Measured first and dropped: one wavefront with the rows
-    // in registers and the column loops unrolled - 17 000 instructions executed once per launch, 240 us: instruction fetch.)
-    __shared__ double s_D[MAX_NP][21];          // factored diagonal blocks, row-major lower triangles
-    __shared__ double s_y[6 * MAX_NP];          // the solution of L y = rhs, then of L^T x = y
-    const int nb = NP / 6;
+    // Right-looking Cholesky of the lower triangle, SIX columns (one key frame's block) per round (the unblocked loop took three workgroup barriers per column: 162 for
+    // 9 key frames, + 216 in the substitutions: the kernel's 90 us were barriers).  EVERY thread factors the 6x6 diagonal block itself, in registers (6 sqrt, 6
+    // reciprocals: cheaper than a barrier and a wait for one thread); thread 0 keeps the factor in s_D for the back substitution.  The right-hand side rides along as ROW NP
+    // of the matrix (x sits behind A in memory): its panel entries are L y = rhs solved block by block, so there is no forward substitution; rows are scaled by the
+    // reciprocal of the diagonal (one division per column instead of one per element and column).  Two barriers per key frame here, one below: 30 for 10 key frames.
+    // (Measured first and dropped: one wavefront with the rows in registers and the column loops unrolled - 17 000 instructions executed once per launch, 240 us: instruction
+    // fetch.)
+    __shared__ double s_D[MAX_NP][21];          // factored diagonal blocks, row-major lower triangles, the diagonal slots hold 1 / L_cc
+    __shared__ double s_y[6 * MAX_NP];          // the solution of L^T x = y while it is built
+    const int nb = NP / 6, tx = tid & 15, ty = tid >> 4;
     auto tri = [](int r, int k) { return r * (r + 1) / 2 + k; };
     bool good = true;
     for (int jb = 0; jb < nb && good; jb++) {
         const int J0 = 6 * jb;
-        double m[6][6];
+        double m[6][6], inv[6];
 #pragma unroll
         for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -516,9 +517,10 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
             const double d = m[c][c];
             if (!(d > 0)) good = false;
             const double djj = sqrt(d);
+            inv[c] = 1.0 / djj;
             m[c][c] = djj;
 #pragma unroll
-            for (int r = c + 1; r < 6; r++) m[r][c] /= djj;
+            for (int r = c + 1; r < 6; r++) m[r][c] *= inv[c];
 #pragma unroll
             for (int r = c + 1; r < 6; r++)
 #pragma unroll
@@ -529,28 +531,31 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int k = 0; k <= r; k++) s_D[jb][tri(r, k)] = m[r][k];
+                for (int k = 0; k <= r; k++) s_D[jb][tri(r, k)] = k == r ? inv[r] : m[r][k];
         }
-        const int R0 = J0 + 6, nr = NP - R0;     // the rows below the block
-        for (int i = R0 + tid; i < NP; i += NT) {                // panel: row i's six entries, column by column
+        const int R0 = J0 + 6;                   // the rows below the block; row NP = the right-hand side
+        for (int i = R0 + tid; i <= NP; i += NT) {               // panel: row i's six entries, column by column
             double l[6];
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 double v = s_A[i * NP + J0 + c];
 #pragma unroll
                 for (int cp = 0; cp < 6; cp++) if (cp < c) v -= l[cp] * m[c][cp];
-                l[c] = v / m[c][c];
+                l[c] = v * inv[c];
             }
 #pragma unroll
             for (int c = 0; c < 6; c++) s_A[i * NP + J0 + c] = l[c];
         }
         __syncthreads();
-        for (int t = tid; t < nr * nr; t += NT) {            // trailing update: six products per element, ascending column order
-            const int i = R0 + t / nr, k = R0 + t % nr;
-            if (k <= i) {
+        for (int i = R0 + ty; i <= NP; i += 16) {                // trailing update in 16 x 16 tiles of (row, column): six products per element, ascending column order
+            double li[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) li[c] = s_A[i * NP + J0 + c];
+            const int kmax = i < NP ? i : NP - 1;
+            for (int k = R0 + tx; k <= kmax; k += 16) {
                 double v = s_A[i * NP + k];
 #pragma unroll
-                for (int c = 0; c < 6; c++) v -= s_A[i * NP + J0 + c] * s_A[k * NP + J0 + c];
+                for (int c = 0; c < 6; c++) v -= li[c] * s_A[k * NP + J0 + c];
                 s_A[i * NP + k] = v;
             }
         }
@@ -558,32 +563,7 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
     }
     if (tid == 0) s_ok = good ? 1 : 0;
     __syncthreads();
-    if (good) {                                 // substitutions, six unknowns per round: L y = rhs, then L^T x = y (same order of the subtractions as column by column)
-        for (int jb = 0; jb < nb; jb++) {        // every thread solves the block's six unknowns itself, then updates its rows below
-            const int J0 = 6 * jb;
-            double yb[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) yb[c] = x[J0 + c];
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                yb[c] = yb[c] / s_D[jb][tri(c, c)];
-#pragma unroll
-                for (int r = c + 1; r < 6; r++) yb[r] -= s_D[jb][tri(r, c)] * yb[c];
-            }
-            if (tid == 0) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) s_y[J0 + c] = yb[c];
-            }
-            for (int k = J0 + 6 + tid; k < NP; k += NT) {
-                double v = x[k];
-#pragma unroll
-                for (int c = 0; c < 6; c++) v -= s_A[k * NP + J0 + c] * yb[c];
-                x[k] = v;
-            }
-            __syncthreads();
-        }
-        for (int i = tid; i < NP; i += NT) x[i] = s_y[i];
-        __syncthreads();
+    if (good) {                                 // x (row NP) now holds y; back substitution L^T x = y, six unknowns per round: every thread solves the block itself, then updates the rows above
         for (int jb = nb - 1; jb >= 0; jb--) {
             const int J0 = 6 * jb;
             double xb[6];
@@ -591,7 +571,7 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
             for (int c = 0; c < 6; c++) xb[c] = x[J0 + c];
 #pragma unroll
             for (int c = 5; c >= 0; c--) {
-                xb[c] = xb[c] / s_D[jb][tri(c, c)];
+                xb[c] = xb[c] * s_D[jb][tri(c, c)];
 #pragma unroll
                 for (int r = c - 1; r >= 0; r--) xb[r] -= s_D[jb][tri(c, r)] * xb[c];
             }
