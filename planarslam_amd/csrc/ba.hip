@@ -5,12 +5,11 @@
 // KeyFrame / MapPoint / MapLine / MapPlane objects arrives as plain arrays (planar_ba_problem).
 //
 //   ba_errors    thread = edge        FP64 residuals of the active edges (stored, like g2o's _error) + robust chi2
-//   ba_numjac    thread = (numeric edge, column)   g2o's central differences for the plane / parallel / vertical edges, one column (two error evaluations) per thread
-//   ba_linearize thread = edge        Jacobians (analytic point/line; the numeric ones from ba_numjac), the edge's coupling block W = B^T (w Omega) A (6x3) and
+//   (numjac)     thread = (numeric edge, column, sign)   the tail of ba_errors' grid when an LM iteration opens: g2o's central differences for the plane / parallel / vertical edges, one column (two error evaluations) per thread
+//   ba_linearize thread = edge        Jacobians (analytic point/line; the numeric ones from the numjac workgroups), the edge's coupling block W = B^T (w Omega) A (6x3) and
 //                                     its landmark-block contribution; pose blocks Hpp / bp (lower triangle) are summed in LDS per workgroup, then flushed
 //                                     with FP64 atomics
 //   ba_gather    4 lanes = landmark   Hll (3x3), bl = sum of its edges' contributions; thread = (landmark, key frame) pair: the sum of its edges' coupling blocks
-//   ba_dinv      thread = landmark    Dinv = (Hll + lambda I)^-1, Dinv bl; also prepares the trial's exchange buffers (redg <- red, red2 <- 0, trial <- 0)
 //   ba_schur     workgroup = (block (p, q) of the reduced system, slice of the landmarks)   S[p][q] -= sum_l Wp(l,p) Dinv_l Wp(l,q)^T, b[p] -= sum_l Wp(l,p) Dinv_l bl_l:
 //                                     register accumulation over the landmarks, one reduction per workgroup (lower triangle of blocks)
 // Round 6 (a solve of BASELINE configs[4]: 5.5 -> 3.4 ms -> see DESIGN.md 4.6): every launch of this chain ends with its slowest THREAD - the ~400 numeric-Jacobian
@@ -76,11 +75,11 @@ struct Dev {
     double* e_err;                           // [E][3]
     uint8_t* e_level;                        // 0 active, 1 outlier
     uint8_t* e_out;                          // final "to erase" flag
-    double* Hll; double* bl; double* Dinv; double* W; double* xl;   // [L][9] [L][3] [L][9] [E][18] [L][3] (xl: Dinv * bl)
+    double* Hll; double* bl; double* W;      // [L][9] [L][3] [E][18]
     double* He;                              // [E][12]: the edge's A^T w Omega A (9) and -A^T w Omega e (3)
     const int* e_numslot;                    // [E] slot of a numeric-Jacobian edge (plane / parallel / vertical) in J, -1 for the analytic ones
     const int* num_idx;                      // [n_num] their edge indices
-    double* J;                               // [n_num][9][3]: columns 0..2 = d error / d landmark, 3..8 = d error / d pose (ba_numjac)
+    double* J;                               // [n_num][9][3]: columns 0..2 = d error / d landmark, 3..8 = d error / d pose (numjac_block)
     int n_num;
     double* red;                             // this rank's [np*36 Hpp | 6np bp | chi | pad], rebuilt at the start of an LM iteration
     double* redg;                            // exchange buffer A, first part: the same layout, summed over ranks
@@ -165,9 +164,11 @@ __device__ __forceinline__ double block_sum(double v, double* lds4) {
 __device__ __forceinline__ int edge_landmark(const Dev& D, int e) { return D.e_lm[e]; }
 
 // at_iteration_start = 1: only when the step opens an LM iteration (chi2(x) into red); 0: every live trial (chi2(x + dx) into trial[0])
-__global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_out, int at_iteration_start) {
+__device__ __forceinline__ void numjac_block(const Dev& D, int block);
+__global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_out, int at_iteration_start, int n_err_blocks) {
     __shared__ double s4[4];
     if (D.st->done || (at_iteration_start && !D.st->need_build)) return;
+    if ((int)blockIdx.x >= n_err_blocks) { numjac_block(D, (int)blockIdx.x - n_err_blocks); return; }
     const int e = blockIdx.x * NT + threadIdx.x;
     double chi = 0;
     if (e < D.E && D.e_level[e] == 0) {
@@ -185,10 +186,10 @@ __global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_o
 
 // thread = (numeric-Jacobian edge, column, sign): one evaluation of g2o's central differences (base_binary_edge.hpp:131-198).  Round 6: ba_linearize did all
 // 18 evaluations of such an edge in ONE thread, and the launch ended with those threads (68 us for 19 573 edges of which ~400 are numeric); same arithmetic per column.
-__global__ __launch_bounds__(NT) void ba_numjac(Dev D) {
-    if (D.st->done || !D.st->need_build) return;
+// (its workgroups are the tail of the grid of the ba_errors launch that opens an LM iteration: neither reads what the other writes, and a launch of its own cost 5 us)
+__device__ __forceinline__ void numjac_block(const Dev& D, int block) {
     // thread = (edge slot, column d, sign): the two evaluations of a column on neighbouring lanes (lane ^ 1), combined by one shuffle
-    const int gid = blockIdx.x * NT + threadIdx.x, pair = gid >> 1, sgn = gid & 1, slot = pair / 9, d = pair - slot * 9;
+    const int gid = block * NT + threadIdx.x, pair = gid >> 1, sgn = gid & 1, slot = pair / 9, d = pair - slot * 9;
     const bool on = slot < D.n_num;
     const int e = on ? D.num_idx[slot] : 0;
     const bool act = on && D.e_level[e] == 0;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(NT) void ba_linearize(Dev D, int robust) {
                         B[2][0] = B[0][0] - c.bf * y / z_2; B[2][1] = B[0][1] + c.bf * x / z_2; B[2][2] = B[0][2]; B[2][3] = B[0][3]; B[2][5] = B[0][5] - c.bf / z_2;
                     }
                 }
-            } else {                             // numeric, both vertices (base_binary_edge.hpp:131-198): the columns ba_numjac left
+            } else {                             // numeric, both vertices (base_binary_edge.hpp:131-198): the columns numjac_block left
                 const double* Jc = D.J + (size_t)D.e_numslot[e] * 27;
                 for (int d = 0; d < 3; d++)
 #pragma unroll
@@ -375,35 +376,18 @@ __device__ __forceinline__ void inv3(const double* H, double lambda, double Di[9
     Di[6] = (d * h - e * g) * id; Di[7] = (b * g - a * h) * id; Di[8] = (a * e - b * d) * id;
 }
 
-// thread = landmark: Dinv = (Hll + lambda I)^-1 and Dinv * bl
-// ... and the trial's exchange buffers (round 6: a device-to-device copy and two memsets per trial were three more launches of ~5 us each): redg <- red, red2 <- 0, trial <- 0
-__global__ __launch_bounds__(NT) void ba_dinv(Dev D, int nred, int nS) {
-    if (D.st->done) return;
-    const double lambda = D.st->lambda;
-    const int l = blockIdx.x * NT + threadIdx.x;
-    for (int i = l; i < nred; i += gridDim.x * NT) D.redg[i] = D.red[i];
-    for (int i = l; i < nS; i += gridDim.x * NT) D.red2[i] = 0;
-    if (l < 4) D.trial[l] = 0;
-    if (l >= D.L) return;
-    if (!D.lm_any[l]) {                       // (zeros, not stale values: ba_schur multiplies every landmark's Dinv with its - then zero - pair sums)
-        for (int i = 0; i < 9; i++) D.Dinv[(size_t)l * 9 + i] = 0;
-        for (int a = 0; a < 3; a++) D.xl[(size_t)l * 3 + a] = 0;
-        return;
-    }
-    double Di[9];
-    inv3(D.Hll + (size_t)l * 9, lambda, Di);
-    for (int i = 0; i < 9; i++) D.Dinv[(size_t)l * 9 + i] = Di[i];
-    const double* bl = D.bl + (size_t)l * 3;
-    for (int a = 0; a < 3; a++) D.xl[(size_t)l * 3 + a] = Di[a * 3] * bl[0] + Di[a * 3 + 1] * bl[1] + Di[a * 3 + 2] * bl[2];
-}
-
 // workgroup = (block (p, q) of the reduced system, p >= q; a slice of the landmarks): S[p][q] -= sum_l Wp(l,p) Dinv_l Wp(l,q)^T and, on the diagonal blocks,
 // b[p] -= sum_l Wp(l,p) Dinv_l bl_l, accumulated in REGISTERS (a thread takes landmarks tid, tid + 256 * slices, ...), reduced by three shuffles + one pass through LDS,
 // one FP64 atomic per element and workgroup.  Round 6, second form: the edge-parallel form (thread = edge x its partner edges, 36 LDS atomics per partner on addresses
 // that every edge of the same key-frame pair shares) took 37 us of a 183 us trial; per PAIR of key frames the products are a flat sum over landmarks.
-__global__ __launch_bounds__(NT) void ba_schur(Dev D, int slices) {
+// (Hll + lambda I)^-1 is computed where it is used (here and in ba_update: 40 flops and a division against nine loads, and one launch less per trial: ba_dinv), and the
+// launch also refreshes this rank's half of exchange buffer A, redg <- red (the all-reduce sums redg in place, so it is re-copied on every trial).
+__global__ __launch_bounds__(NT) void ba_schur(Dev D, int slices, int nred, int n_combo) {
     __shared__ double s_part[32][43];
     if (D.st->done) return;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < nred; i += gridDim.x * NT) D.redg[i] = D.red[i];
+    if ((int)blockIdx.x >= n_combo * slices) return;
+    const double lambda = D.st->lambda;
     const int NP = 6 * D.np, combo = blockIdx.x / slices, sl = blockIdx.x - combo * slices;
     int p = (int)((sqrt(8.0 * combo + 1.0) - 1.0) * 0.5);
     while ((p + 1) * (p + 2) / 2 <= combo) p++;
@@ -416,17 +400,15 @@ __global__ __launch_bounds__(NT) void ba_schur(Dev D, int slices) {
     for (int i = 0; i < 6; i++) rb[i] = 0;
     for (int l = sl * NT + threadIdx.x; l < D.L; l += slices * NT) {
         const int i = D.pair_of[(size_t)l * D.np + p];
-        if (i < 0) continue;
+        if (i < 0 || !D.lm_any[l]) continue;
         const int j = p == q ? i : D.pair_of[(size_t)l * D.np + q];
         if (j < 0) continue;
         const double* Wi = D.Wp + (size_t)i * 18;
         const double* Wj = D.Wp + (size_t)j * 18;
-        const double* Di = D.Dinv + (size_t)l * 9;
         double wi[18], wj[18], di[9], BD[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) { wi[k] = Wi[k]; wj[k] = Wj[k]; }
-#pragma unroll
-        for (int k = 0; k < 9; k++) di[k] = Di[k];
+        inv3(D.Hll + (size_t)l * 9, lambda, di);
 #pragma unroll
         for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -436,8 +418,8 @@ __global__ __launch_bounds__(NT) void ba_schur(Dev D, int slices) {
 #pragma unroll
             for (int c = 0; c < 6; c++) acc[a * 6 + c] -= BD[a * 3] * wj[c * 3] + BD[a * 3 + 1] * wj[c * 3 + 1] + BD[a * 3 + 2] * wj[c * 3 + 2];
         if (p == q) {
-            const double* db = D.xl + (size_t)l * 3;
-            const double d0 = db[0], d1 = db[1], d2 = db[2];
+            const double* bl = D.bl + (size_t)l * 3;
+            const double d0 = di[0] * bl[0] + di[1] * bl[1] + di[2] * bl[2], d1 = di[3] * bl[0] + di[4] * bl[1] + di[5] * bl[2], d2 = di[6] * bl[0] + di[7] * bl[1] + di[8] * bl[2];
 #pragma unroll
             for (int a = 0; a < 6; a++) rb[a] -= wi[a * 3] * d0 + wi[a * 3 + 1] * d1 + wi[a * 3 + 2] * d2;
         }
@@ -475,22 +457,27 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
     if (D.st->done) return;
     const int NP = 6 * D.np, tid = threadIdx.x;
     double* s_A = D.bigA ? D.bigA : s_ldsA;                          // one workgroup either way: __syncthreads orders its global accesses too
-    if (tid == 0 && D.st->need_build) {      // the step opened an LM iteration: chi2(x) summed over ranks has just arrived
-        LmState& S = *D.st;
-        S.currentChi = S.iniChi = D.redg[(size_t)D.np * 36 + NP];
-        S.need_build = 0; S.qmax = 0; S.lm_iters++;
-    }
-    __syncthreads();
     const double lambda = D.st->lambda;
     double* x = s_A + NP * NP;
-    for (int i = tid; i < NP * NP; i += NT) {
-        const int r = i / NP, c = i - r * NP;
-        double v = D.red2[i];
-        if (r / 6 == c / 6) v += D.redg[(size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
-        if (r == c) v += lambda;
-        s_A[i] = v;
+    // A <- Schur terms, eight loads in flight per thread (one load, one conditional load and one LDS store per element left every element a memory latency of its own),
+    // then the diagonal blocks Hpp + lambda I on top
+    const int NN = NP * NP;
+    for (int b0 = 0; b0 < NN; b0 += NT * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int idx = b0 + u * NT + tid; v[u] = idx < NN ? D.red2[idx] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int idx = b0 + u * NT + tid; if (idx < NN) s_A[idx] = v[u]; }
     }
-    for (int i = tid; i < NP; i += NT) { const double b = D.redg[(size_t)D.np * 36 + i]; s_b[i] = b; x[i] = b + D.red2[NP * NP + i]; }
+    for (int i = tid; i < NP; i += NT) { const double b = D.redg[(size_t)D.np * 36 + i]; s_b[i] = b; x[i] = b + D.red2[NN + i]; }
+    __syncthreads();
+    for (int i = tid; i < D.np * 36; i += NT) {
+        const int p = i / 36, k = i - p * 36, r = k / 6, c = k - r * 6;
+        double* a = &s_A[(p * 6 + r) * NP + p * 6 + c];
+        double v = *a + D.redg[i];
+        if (r == c) v += lambda;
+        *a = v;
+    }
     if (tid == 0) s_ok = 1;
     __syncthreads();
     // Right-looking Cholesky of the lower triangle, SIX columns (one key frame's block) per round (the unblocked loop took three workgroup barriers per column: 162 for
@@ -599,6 +586,11 @@ __global__ __launch_bounds__(NT) void ba_solve(Dev D) {
         if (s_ok) for (int i = 0; i < NP; i++) scale += s_y[i];
         D.xp[NP] = s_ok ? 1.0 : 0.0;
         D.xp[NP + 1] = scale;
+        if (D.st->need_build) {              // the step opened an LM iteration: chi2(x) summed over ranks arrived with the exchange before this kernel
+            LmState& S = *D.st;
+            S.currentChi = S.iniChi = D.redg[(size_t)D.np * 36 + NP];
+            S.need_build = 0; S.qmax = 0; S.lm_iters++;
+        }
     }
 }
 
@@ -645,8 +637,8 @@ __global__ __launch_bounds__(NT) void ba_update(Dev D, int stop) {
         if (act) {
             const double* bl = D.bl + (size_t)l * 3;
             const double cl[3] = {bl[0] - part[0], bl[1] - part[1], bl[2] - part[2]};
-            const double* Di = D.Dinv + (size_t)l * 9;
-            double xl[3];
+            double Di[9], xl[3];
+            inv3(D.Hll + (size_t)l * 9, lambda, Di);
             for (int a = 0; a < 3; a++) { xl[a] = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2]; sc += xl[a] * (lambda * xl[a] + bl[a]); }
             LmV v = load_lm(D, D.lm, l);
             lm_oplus(v, xl);
@@ -704,8 +696,11 @@ __global__ void ba_decide(Dev D) {
 }
 
 // ... and, when the next step opens an LM iteration, clears this rank's partial sums for it (round 6: was a launch of its own, ba_begin; the block is zero when a solve starts)
-__global__ __launch_bounds__(NT) void ba_restore(Dev D, int nred) {
+// ... and the next trial's accumulators: red2 <- 0 (Schur terms), trial <- 0 (they are zero when a solve starts)
+__global__ __launch_bounds__(NT) void ba_restore(Dev D, int nred, int nS) {
     const int i = blockIdx.x * NT + threadIdx.x;
+    for (int q = i; q < nS; q += gridDim.x * NT) D.red2[q] = 0;
+    if (i < 4) D.trial[i] = 0;
     if (D.st->need_build) {
         for (int q = i; q < nred; q += gridDim.x * NT) D.red[q] = 0;
         if (i == 0) D.scal[0] = 0;
@@ -870,7 +865,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     const size_t oEo = carve(E);
     const size_t down_end = off;
     const size_t oTb = carve((size_t)K * 64), oLb = carve((size_t)L * 32), oEe = carve((size_t)E * 24), oEl = carve(E),
-                 oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oDi = carve((size_t)L * 72), oW = carve((size_t)E * 144), oHe = carve((size_t)E * 96), oXl = carve((size_t)L * 24),
+                 oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oW = carve((size_t)E * 144), oHe = carve((size_t)E * 96),
                  oR = carve(nred * 8), oA = carve(nA * 8), oBig = carve(np > MAX_NP_LDS ? nS * 8 : 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8),
                  oJ = carve((size_t)n_num * 27 * 8), oWp = carve((size_t)n_pairs * 144), oAny = carve(L);
     // (the context's grow-only blocks: a hipMalloc + hipFree per solve cost more than two LM trials, and hipFree synchronises the device)
@@ -952,7 +947,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     D.T = (double*)(base + oT); D.Tbak = (double*)(base + oTb); D.pidx = (const int*)(base + oP); D.lm = (double*)(base + oLm); D.lmbak = (double*)(base + oLb);
     D.lm_type = base + oLt; D.lm_start = (const int*)(base + oLs); D.e_kf = (const int*)(base + oEk); D.e_type = base + oEt; D.e_partner = (const int*)(base + oEp);
     D.e_meas = (const double*)(base + oEm); D.e_info = (const double*)(base + oEi); D.e_err = (double*)(base + oEe); D.e_level = base + oEl; D.e_out = base + oEo;
-    D.Hll = (double*)(base + oH); D.bl = (double*)(base + oB); D.Dinv = (double*)(base + oDi); D.W = (double*)(base + oW); D.He = (double*)(base + oHe); D.xl = (double*)(base + oXl);
+    D.Hll = (double*)(base + oH); D.bl = (double*)(base + oB); D.W = (double*)(base + oW); D.He = (double*)(base + oHe);
     D.red = (double*)(base + oR); D.redg = (double*)(base + oA); D.red2 = D.redg + nred; D.trial = (double*)(base + oTr); D.xp = (double*)(base + oXp);
     D.scal = (double*)(base + oSc); D.st = (LmState*)(base + oSt);
     D.bigA = np > MAX_NP_LDS ? (double*)(base + oBig) : nullptr;
@@ -964,7 +959,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     const size_t smem_solve = np > MAX_NP_LDS ? 0 : ((size_t)NP * NP + NP) * 8, smem_build = (size_t)np * 42 * 8;
     if (smem_solve > 48 * 1024) PLANAR_HIP_CHECK(hipFuncSetAttribute((const void*)ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_solve));
     auto blocks = [](size_t n) { return dim3((unsigned)std::max<size_t>((n + NT - 1) / NT, 1)); };
-    const dim3 gE = blocks(E), gL = blocks(L), gU = blocks(std::max(L, K)), gG = blocks(std::max((size_t)L * GATHER_SPLIT, (size_t)n_pairs)),
+    const dim3 gE = blocks(E), gU = blocks(std::max(L, K)), gG = blocks(std::max((size_t)L * GATHER_SPLIT, (size_t)n_pairs)),
                gUp = blocks(std::max((size_t)L * UPDATE_SPLIT, (size_t)K));
     // ba_schur: one workgroup per (block pair, slice of the landmarks); enough slices to give every CU a workgroup when the key frames are few
     const int n_combo = np * (np + 1) / 2, schur_slices = std::max(1, std::min((L + NT - 1) / NT, 512 / std::max(n_combo, 1)));
@@ -991,8 +986,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
 
     // the launches that open an LM iteration; every kernel is predicated on the device state (need_build && !done)
     auto enqueue_open = [&](int robust) {
-        if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.red + (size_t)np * 36 + NP, 1);
-        if (n_num) hipLaunchKernelGGL(ba_numjac, dim3((n_num * 18 + NT - 1) / NT), dim3(NT), 0, st, D);
+        if (E) hipLaunchKernelGGL(ba_errors, dim3(gE.x + (n_num * 18 + NT - 1) / NT), dim3(NT), 0, st, D, robust, D.red + (size_t)np * 36 + NP, 1, (int)gE.x);     // (+ the numeric Jacobians' columns)
         if (E) hipLaunchKernelGGL(ba_linearize, gE, dim3(NT), smem_build, st, D, robust);
         if (L) hipLaunchKernelGGL(ba_gather, gG, dim3(NT), 0, st, D);
     };
@@ -1000,15 +994,14 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     auto enqueue_step = [&](int robust, bool opened) -> int {
         int r;
         if (!opened) enqueue_open(robust);
-        hipLaunchKernelGGL(ba_dinv, gL, dim3(NT), 0, st, D, (int)nred, (int)nS);      // (+ redg <- red, red2 <- 0, trial <- 0)
-        if (n_pairs) hipLaunchKernelGGL(ba_schur, dim3((unsigned)(n_combo * schur_slices)), dim3(NT), 0, st, D, schur_slices);
+        hipLaunchKernelGGL(ba_schur, dim3((unsigned)std::max(n_pairs ? n_combo * schur_slices : 0, 2)), dim3(NT), 0, st, D, schur_slices, (int)nred, n_pairs ? n_combo : 0);     // (+ redg <- red)
         if ((r = allreduce(D.redg, nA, NCCL_SUM))) return r;                                            // exchange A
         hipLaunchKernelGGL(ba_solve, dim3(1), dim3(NT), smem_solve, st, D);
         hipLaunchKernelGGL(ba_update, gUp, dim3(NT), 0, st, D, stop_now());
-        if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.trial, 0);
+        if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.trial, 0, (int)gE.x);
         if ((r = allreduce(D.trial, 3, NCCL_SUM))) return r;                                            // exchange B
         hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, st, D);
-        hipLaunchKernelGGL(ba_restore, gU, dim3(NT), 0, st, D, (int)nred);
+        hipLaunchKernelGGL(ba_restore, gU, dim3(NT), 0, st, D, (int)nred, (int)nS);
         return PLANAR_OK;
     };
     // SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg
