@@ -165,7 +165,9 @@ __device__ __forceinline__ int edge_landmark(const Dev& D, int e) { return D.e_l
 
 // at_iteration_start = 1: only when the step opens an LM iteration (chi2(x) into red); 0: every live trial (chi2(x + dx) into trial[0])
 __device__ __forceinline__ void numjac_block(const Dev& D, int block);
-__global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_out, int at_iteration_start, int n_err_blocks) {
+__device__ void decide_body(const Dev& D, double trial_chi);
+// decide_cnt != nullptr (single GPU, the trial launch): the LAST workgroup to add its chi2 also takes the LM decision (ba_decide's body) - there is no exchange B to wait for
+__global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_out, int at_iteration_start, int n_err_blocks, unsigned* decide_cnt) {
     __shared__ double s4[4];
     if (D.st->done || (at_iteration_start && !D.st->need_build)) return;
     if ((int)blockIdx.x >= n_err_blocks) { numjac_block(D, (int)blockIdx.x - n_err_blocks); return; }
@@ -181,7 +183,17 @@ __global__ __launch_bounds__(NT) void ba_errors(Dev D, int robust, double* chi_o
         if (robust) { double r0, r1; huber(c2, D.e_info[(size_t)e * 4 + 3], r0, r1); chi = r0; } else chi = c2;
     }
     const double tot = block_sum(chi, s4);
-    if (threadIdx.x == 0 && tot != 0) atomicAdd(chi_out, tot);
+    if (threadIdx.x == 0) {
+        if (tot != 0) atomicAdd(chi_out, tot);
+        if (decide_cnt) {
+            __threadfence();
+            if (atomicAdd(decide_cnt, 1u) == gridDim.x - 1) {
+                *decide_cnt = 0;
+                __threadfence();
+                decide_body(D, __hip_atomic_load(chi_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+        }
+    }
 }
 
 // thread = (numeric-Jacobian edge, column, sign): one evaluation of g2o's central differences (base_binary_edge.hpp:131-198).  Round 6: ba_linearize did all
@@ -614,6 +626,19 @@ __global__ __launch_bounds__(NT) void ba_update(Dev D, int stop) {
     const int l = i / UPDATE_SPLIT, sl = i - l * UPDATE_SPLIT;
     const bool act = l < D.L && ok && D.lm_any[l];
     double part[3] = {0, 0, 0};
+    double H9[9], bl[3] = {0, 0, 0}, lm4[4] = {0, 0, 0, 0};         // (lane 0's loads, issued before the pair loop's dependent ones)
+#pragma unroll
+    for (int a = 0; a < 9; a++) H9[a] = 0;
+    if (l < D.L && sl == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) lm4[a] = D.lm[(size_t)l * 4 + a];
+        if (act) {
+#pragma unroll
+            for (int a = 0; a < 9; a++) H9[a] = D.Hll[(size_t)l * 9 + a];
+#pragma unroll
+            for (int a = 0; a < 3; a++) bl[a] = D.bl[(size_t)l * 3 + a];
+        }
+    }
     if (act) {
         const int j1 = D.lm_pair_start[l + 1];
         for (int j = D.lm_pair_start[l] + sl; j < j1; j += UPDATE_SPLIT) {
@@ -633,14 +658,13 @@ __global__ __launch_bounds__(NT) void ba_update(Dev D, int stop) {
         for (int c = 0; c < 3; c++) part[c] += __shfl_xor(part[c], o);
     double sc = 0;
     if (l < D.L && sl == 0) {
-        for (int a = 0; a < 4; a++) D.lmbak[(size_t)l * 4 + a] = D.lm[(size_t)l * 4 + a];
+        for (int a = 0; a < 4; a++) D.lmbak[(size_t)l * 4 + a] = lm4[a];
         if (act) {
-            const double* bl = D.bl + (size_t)l * 3;
             const double cl[3] = {bl[0] - part[0], bl[1] - part[1], bl[2] - part[2]};
             double Di[9], xl[3];
-            inv3(D.Hll + (size_t)l * 9, lambda, Di);
+            inv3(H9, lambda, Di);
             for (int a = 0; a < 3; a++) { xl[a] = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2]; sc += xl[a] * (lambda * xl[a] + bl[a]); }
-            LmV v = load_lm(D, D.lm, l);
+            LmV v; v.type = D.lm_type[l]; v.X = {lm4[0], lm4[1], lm4[2]}; v.P = Plane{{lm4[0], lm4[1], lm4[2], lm4[3]}};
             lm_oplus(v, xl);
             double* o = D.lm + (size_t)l * 4;
             if (v.type == 0) { o[0] = v.X.x; o[1] = v.X.y; o[2] = v.X.z; } else for (int a = 0; a < 4; a++) o[a] = v.P.c[a];
@@ -662,14 +686,13 @@ __global__ void ba_lambda_init(Dev D) {
 }
 
 // after the trial's exchange B: OptimizationAlgorithmLevenberg::solve :84-128 and the stop rules of SparseOptimizer::optimize
-__global__ void ba_decide(Dev D) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void decide_body(const Dev& D, double trial_chi) {
     LmState& S = *D.st;
     S.restore = 0;
     if (S.done) return;
     const int NP = 6 * D.np;
     const bool ok2 = D.xp[NP] != 0.0;
-    const double tempChi = ok2 ? D.trial[0] : 1.7976931348623157e308;
+    const double tempChi = ok2 ? trial_chi : 1.7976931348623157e308;
     const bool stop = D.trial[2] > 0;
     double rho = S.currentChi - tempChi;
     rho /= D.xp[NP + 1] + D.trial[1] + 1e-3;
@@ -693,6 +716,9 @@ __global__ void ba_decide(Dev D) {
     if (S.it >= S.iterations) finished = true;
     S.need_build = 1;
     if (finished) S.done = 1;
+}
+__global__ void ba_decide(Dev D) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) decide_body(D, D.trial[0]);
 }
 
 // ... and, when the next step opens an LM iteration, clears this rank's partial sums for it (round 6: was a launch of its own, ba_begin; the block is zero when a solve starts)
@@ -866,7 +892,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
     const size_t down_end = off;
     const size_t oTb = carve((size_t)K * 64), oLb = carve((size_t)L * 32), oEe = carve((size_t)E * 24), oEl = carve(E),
                  oH = carve((size_t)L * 72), oB = carve((size_t)L * 24), oW = carve((size_t)E * 144), oHe = carve((size_t)E * 96),
-                 oR = carve(nred * 8), oA = carve(nA * 8), oBig = carve(np > MAX_NP_LDS ? nS * 8 : 8), oTr = carve(32), oXp = carve((size_t)(NP + 2) * 8),
+                 oR = carve(nred * 8), oA = carve(nA * 8), oBig = carve(np > MAX_NP_LDS ? nS * 8 : 8), oTr = carve(64), oXp = carve((size_t)(NP + 2) * 8),
                  oJ = carve((size_t)n_num * 27 * 8), oWp = carve((size_t)n_pairs * 144), oAny = carve(L);
     // (the context's grow-only blocks: a hipMalloc + hipFree per solve cost more than two LM trials, and hipFree synchronises the device)
     int rc = ctx->ensure_scratch(off);
@@ -986,7 +1012,7 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
 
     // the launches that open an LM iteration; every kernel is predicated on the device state (need_build && !done)
     auto enqueue_open = [&](int robust) {
-        if (E) hipLaunchKernelGGL(ba_errors, dim3(gE.x + (n_num * 18 + NT - 1) / NT), dim3(NT), 0, st, D, robust, D.red + (size_t)np * 36 + NP, 1, (int)gE.x);     // (+ the numeric Jacobians' columns)
+        if (E) hipLaunchKernelGGL(ba_errors, dim3(gE.x + (n_num * 18 + NT - 1) / NT), dim3(NT), 0, st, D, robust, D.red + (size_t)np * 36 + NP, 1, (int)gE.x, (unsigned*)nullptr);     // (+ the numeric Jacobians' columns)
         if (E) hipLaunchKernelGGL(ba_linearize, gE, dim3(NT), smem_build, st, D, robust);
         if (L) hipLaunchKernelGGL(ba_gather, gG, dim3(NT), 0, st, D);
     };
@@ -998,9 +1024,10 @@ int planar_local_ba(planar_ctx* ctx, const planar_ba_problem* P, const planar_po
         if ((r = allreduce(D.redg, nA, NCCL_SUM))) return r;                                            // exchange A
         hipLaunchKernelGGL(ba_solve, dim3(1), dim3(NT), smem_solve, st, D);
         hipLaunchKernelGGL(ba_update, gUp, dim3(NT), 0, st, D, stop_now());
-        if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.trial, 0, (int)gE.x);
+        const bool inline_decide = E && !comm;       // single GPU: the last workgroup of the errors launch takes the LM decision (word 4 of `trial` counts the workgroups)
+        if (E) hipLaunchKernelGGL(ba_errors, gE, dim3(NT), 0, st, D, robust, D.trial, 0, (int)gE.x, inline_decide ? (unsigned*)(D.trial + 4) : (unsigned*)nullptr);
         if ((r = allreduce(D.trial, 3, NCCL_SUM))) return r;                                            // exchange B
-        hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, st, D);
+        if (!inline_decide) hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, st, D);
         hipLaunchKernelGGL(ba_restore, gU, dim3(NT), 0, st, D, (int)nred, (int)nS);
         return PLANAR_OK;
     };
