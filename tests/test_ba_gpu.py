@@ -44,6 +44,24 @@ def test_ba_points_only_and_all_fixed_but_one():
     _compare(pr)
 
 
+def test_ba_landmarks_without_edges_and_an_empty_graph():
+    """Graph shapes the (landmark, key frame) pair tables must survive: landmarks nobody observes (no pair, never updated), landmarks seen from fixed key frames
+    only (edges but no pair), and no edges at all (the poses come back as they went in)."""
+    from planarslam_amd import local_bundle_adjustment
+    pr = ba_problem(seed=7, n_kf=4, n_points=240, n_lines=0, n_planes=6, n_fixed_extra=2)
+    keep = (pr["e_lm"] % 5 != 0) | (pr["e_type"] >= 3)              # every fifth point loses all its observations
+    q = {k: (v[keep] if k.startswith("e_") else v) for k, v in pr.items()}
+    got = local_bundle_adjustment(q, TUM3)
+    want = ol.local_ba(q, TUM3)
+    assert np.abs(got["kf_Tcw"] - want["kf_Tcw"]).max() <= 1e-5
+    seen = np.zeros(len(q["lm_type"]), bool); seen[q["e_lm"]] = True
+    assert (~seen).sum() > 20 and np.abs(got["lm"][seen] - want["lm"][seen]).max() <= 1e-5
+    assert np.array_equal(got["lm"][~seen][:, :3], np.asarray(q["lm_init"], np.float64)[~seen][:, :3])
+    empty = {k: (v[:0] if k.startswith("e_") else v) for k, v in pr.items()}
+    got = local_bundle_adjustment(empty, TUM3)
+    assert np.abs(got["kf_Tcw"] - np.asarray(pr["kf_Tcw"], np.float32).reshape(-1, 16)).max() <= 1e-6 and len(got["e_outlier"]) == 0
+
+
 def test_ba_through_a_one_rank_rccl_communicator():
     from planarslam_amd import Communicator, Context
     ctx = Context(0)
