@@ -30,7 +30,10 @@
 namespace planar {
 namespace planepost {
 
-constexpr int NT = 512;
+#ifndef PLANAR_PP_NT
+#define PLANAR_PP_NT 512
+#endif
+constexpr int NT = PLANAR_PP_NT;     // threads of the voxel / tail kernels (a developer build may narrow them: make items256)
 constexpr int MAXP = 128;                 // planar_peac_max_planes()
 constexpr int NRNG = 32768;               // sampler values kept (a refit that needs more reports PLANAR_ECAPACITY)
 constexpr int VOX_BIAS = 8192;            // voxel coordinates floor(x / leaf) are kept in 14 bits each
@@ -325,6 +328,9 @@ constexpr HeapClass PS_HC[3] = {{2048, 2048, 4, 1}, {8192, 8192, 1, 2}, {1 << 30
 // of a lone wavefront either way - but a workgroup that wants a whole CU's LDS waits for a CU to drain while the other streams keep them busy, so the long ranges keep 32 KB)
 using PsLds = isort::LdsLayout<PS_LT, PS_E>;
 using PsGl = isort::GlobalLayout<PS_T>;
+// plane_items_kernel comes in two shapes: PS_T threads per frame (small batches: a frame wants all the wavefronts it can get) and 256 (throughput: 56 registers, one
+// wavefront per SIMD and 2 KB of LDS fit beside the four clustering wavefronts of a CU - 11 818 -> 11 917 frames/s, round 6)
+constexpr int PS_IT_SMALL = 256, PS_IT_BATCH = 256;     // batches of at least PS_IT_BATCH frames take the 256-thread shape
 constexpr int ERR_SORT = 5;
 
 struct Meta { int n_init, counts[2], err, M, npl, sort_status, heap_n, heap_n_global; };   // heap_n_global: the fallback jobs the global tier left (the long ones), known before the LDS tier runs
@@ -504,11 +510,11 @@ __global__ __launch_bounds__(NT) void plane_voxels_kernel(Geo G, const unsigned 
     mark(3);
 }
 
-// The item array.  Workgroup of PS_T threads per frame; wavefront w owns the pixels [w * S, (w + 1) * S) in raster order.
-template <int SH>     // SH: bits of the pixel index in an item (19: frames of up to 2^19 pixels, 8192 voxels; 20: up to 2^20 pixels, 4096 voxels)
-__global__ __launch_bounds__(PS_T) void plane_items_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
+// The item array.  Workgroup of IT threads per frame; wavefront w owns the pixels [w * S, (w + 1) * S) in raster order.
+template <int SH, int IT>     // SH: bits of the pixel index in an item (19: frames of up to 2^19 pixels, 8192 voxels; 20: up to 2^20 pixels, 4096 voxels)
+__global__ __launch_bounds__(IT) void plane_items_kernel(Geo G, const unsigned short* __restrict__ depth_all, int pitch_px, long frame_stride_px,
                                                            const int* __restrict__ labels_all, unsigned char* ws_all) {
-    constexpr int NW = PS_T / 64;
+    constexpr int NW = IT / 64;
     __shared__ unsigned s_cnt[NW][MAXP];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int HW = G.W * G.H;
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(PS_T) void plane_items_kernel(Geo G, const unsigned
     uint32_t* items = (uint32_t*)(ws + G.off_items);
     const int npl = meta->npl, TC = G.tcap;
     const float inv = 1.0f / G.leaf;
-    for (int i = tid; i < NW * MAXP; i += PS_T) (&s_cnt[0][0])[i] = 0u;
+    for (int i = tid; i < NW * MAXP; i += IT) (&s_cnt[0][0])[i] = 0u;
     __syncthreads();
     const int S = ((HW + NW - 1) / NW + 63) & ~63, w0 = min(HW, wave * S), w1 = min(HW, w0 + S);
     auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
@@ -1132,7 +1138,13 @@ int planar_plane_clouds_compute_dev(planar_plane_clouds* p, const uint16_t* d_de
     mark();
     // (the item word's pixel field: 19 bits, or 20 for frames of more than 2^19 pixels - two instantiations of the five kernels that read it)
 #define PLANAR_BY_SHIFT(K, ...) do { if (p->shift == 20) hipLaunchKernelGGL(planepost::K<20>, __VA_ARGS__); else hipLaunchKernelGGL(planepost::K<19>, __VA_ARGS__); } while (0)
-    PLANAR_BY_SHIFT(plane_items_kernel, dim3(B), dim3(planepost::PS_T), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
+    if (B >= planepost::PS_IT_BATCH) {
+        if (p->shift == 20) hipLaunchKernelGGL((planepost::plane_items_kernel<20, planepost::PS_IT_SMALL>), dim3(B), dim3(planepost::PS_IT_SMALL), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
+        else hipLaunchKernelGGL((planepost::plane_items_kernel<19, planepost::PS_IT_SMALL>), dim3(B), dim3(planepost::PS_IT_SMALL), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
+    } else {
+        if (p->shift == 20) hipLaunchKernelGGL((planepost::plane_items_kernel<20, planepost::PS_T>), dim3(B), dim3(planepost::PS_T), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
+        else hipLaunchKernelGGL((planepost::plane_items_kernel<19, planepost::PS_T>), dim3(B), dim3(planepost::PS_T), 0, st, G, d_depth, pitch_px, (long)frame_stride_px, d_labels, ws);
+    }
     mark();
     PLANAR_BY_SHIFT(plane_sort_global, dim3(B), dim3(planepost::PS_T), p->smem_sort_g, st, G, ws, p->sort_rows);
     mark();
