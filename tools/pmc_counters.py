@@ -71,7 +71,7 @@ def main():
         dd = dd[1:] if len(dd) > 2 else dd                 # (the first full-batch dispatch of a run includes cold caches)
         d_ns = sum(dd) / len(dd) if dd else float("nan")
         issue = (4.0 * avg.get("SQ_INSTS_VALU", float("nan")) + avg.get("SQ_INSTS_SALU", float("nan"))) / (d_ns * 1e-9 * 1024 * 2.4e9) if dd else float("nan")
-        rows.append((avg.get("SQ_WAVE_CYCLES", 0.0), ",".join([k, str(n)] + [f"{avg.get(c, float('nan')):.0f}" for c in counters] + [f"{wait:.3f}", f"{act:.3f}", f"{d_ns / 1e3:.1f}", f"{issue:.4f}"])))
+        rows.append((avg.get("SQ_WAVE_CYCLES", 0.0), ",".join([('"' + k + '"' if "," in k else k), str(n)] + [f"{avg.get(c, float('nan')):.0f}" for c in counters] + [f"{wait:.3f}", f"{act:.3f}", f"{d_ns / 1e3:.1f}", f"{issue:.4f}"])))
     for _, r in sorted(rows, reverse=True):
         print(r)
 

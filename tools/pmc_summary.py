@@ -48,7 +48,8 @@ def main():
     for k in sorted(fetch, key=lambda k: -fetch[k][0]):
         if not k.startswith(("planar::", "void planar::")):
             continue
-        print(f"{k},{fetch[k][1]},{fetch[k][0]:.2f},{write.get(k, (0.0, 0))[0]:.2f}")
+        kq = '"' + k + '"' if "," in k else k          # (a template kernel's name may hold a comma: plane_items_kernel<19, 256>)
+        print(f"{kq},{fetch[k][1]},{fetch[k][0]:.2f},{write.get(k, (0.0, 0))[0]:.2f}")
 
 
 if __name__ == "__main__":
