@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--work-sets", type=int, default=0, help="extractor sets (line / plane stream + the extractors' workspaces): 0 = one per extraction in flight (= --depth)")
     ap.add_argument("--seq-cus", type=int, default=SEQ_CUS, help="compute units the one-wavefront-per-frame kernels (PEAC clustering, LSD region growing) are confined to by a "
                                                                 "CU-masked side stream (planar_ctx_set_seq_stream); 0 = no partition")
-    ap.add_argument("--seq-which", type=int, default=SEQ_WHICH, help="which of them: 1 PEAC clustering, 2 LSD region growing, 3 both")
+    ap.add_argument("--seq-which", type=int, default=SEQ_WHICH, help="which of them: 1 PEAC clustering, 2 LSD region growing (on the same stream when shared), 3 both, 4 LSD region growing on a masked stream per line context, 5 = 1 + 4")
     ap.add_argument("--seq-per-ctx", action="store_true", help="one masked stream per context instead of one shared by all sets")
     ap.add_argument("--cpu-seconds", type=float, default=18.0, help="budget of the cpu_baseline leg, split over its three variants (0 = skip)")
     ap.add_argument("--latency-reps", type=int, default=15, help="repetitions of the B = 1 pose-optimisation call (0 = skip the whole latency block)")

@@ -65,12 +65,15 @@ class TrackPipeline:
         self.seq_streams = []
         if seq_cus:
             from ._lib import cu_stream_create
-            targets = (self.ctx_peacs if seq_which & 1 else []) + (self.ctx_lsds if seq_which & 2 else [])
+            targets = (self.ctx_peacs if seq_which & 1 else []) + (self.ctx_lsds if seq_which & 6 else [])
             try:
                 for c in targets:
-                    if not seq_shared or not self.seq_streams:
+                    own = (seq_which & 4) and c in self.ctx_lsds          # (& 4: region growing on the partition too, but on a masked stream per line context - not behind the clustering launches)
+                    if own or not seq_shared or not self.seq_streams:
                         self.seq_streams.append(cu_stream_create(device_index, int(seq_cus)))
-                    c.set_seq_stream(self.seq_streams[-1])
+                        if not own and seq_shared:
+                            shared = self.seq_streams[-1]
+                    c.set_seq_stream(self.seq_streams[-1] if own or not seq_shared else shared)
             except Exception as e:      # a runtime that refuses CU masks: same results on the contexts' own streams (speed only)
                 import sys
                 print(f"TrackPipeline: no CU partition ({e}); the sequential kernels stay on their extractors' streams", file=sys.stderr)
