@@ -10,7 +10,10 @@ using namespace planar::isort;
 #ifndef T_
 #define T_ 1024
 #endif
-constexpr int T = T_, E = 23, SHIFT = 19;
+#ifndef E_
+#define E_ 23
+#endif
+constexpr int T = T_, E = E_, SHIFT = 19;
 __global__ __launch_bounds__(T) void k(uint32_t* arr, const Range* r, int nr, int n, int* status) {
     extern __shared__ __align__(16) uint8_t lds[];
     static __device__ HeapJob hj[64]; static __device__ int hn; const HeapSink HS{hj, &hn, 64}; lds_tier<SHIFT, T, E>(arr + (size_t)blockIdx.x * n, r, nr, 0, n, lds, HS, status);
